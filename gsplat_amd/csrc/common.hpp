@@ -1,0 +1,168 @@
+// gsplat_amd — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+//
+// Everything here is written for wave64 / CDNA4 only. There is no CUDA path,
+// no hipify output and no multi-backend dispatch.
+//
+// Constants restate the reference's contract (values only):
+//   gsplat/cuda/include/Common.h:97-114, gsplat/cuda/_constants.py:16-27
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gsplat_amd.h"
+
+namespace gsx {
+
+// ---- constants of the rasterization contract --------------------------------
+constexpr float kAlphaThreshold      = 1.0f / 255.0f; // skip if alpha < this
+constexpr float kGaussianExtend      = 3.33f;         // truncation in std-devs
+constexpr float kMaxAlpha            = 0.99f;         // alpha clamp
+constexpr float kTransmittanceThresh = 1e-4f;         // pixel stops (exclusive) when T' <= this
+constexpr float kMinCompensation     = 0.005f;        // floor of sqrt(det/det_blur)
+constexpr float kMinOneMinusAlpha    = 1e-6f;         // floor of (1-alpha) in backward
+constexpr float kFilterInvSquare2DGS = 2.0f;          // 2DGS low-pass: min(3D kernel, 2*|d|^2)
+
+constexpr int kWave = 64;
+
+// ---- error plumbing for the C-ABI --------------------------------------------
+// Every gsx_* entry point returns 0 on success or a negative code; the message is
+// retrievable with gsx_last_error() (thread local).
+// (codes GSX_OK / GSX_ERR_* come from include/gsplat_amd.h)
+
+void set_last_error(const char *fmt, ...);
+int check_launch(const char *what);
+
+#define GSX_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::gsx::set_last_error(__VA_ARGS__); \
+            return GSX_ERR_ARG;         \
+        }                                      \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- wave64 cross-lane primitives (DPP; no LDS traffic) -----------------------
+// DPP control words (GCN3/CDNA ISA): quad_perm = 0x00..0xFF, row_shr:n = 0x110+n,
+// row_mirror = 0x140, row_half_mirror = 0x141, row_bcast15 = 0x142, row_bcast31 = 0x143.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float x)
+{
+    // old = 0 so lanes that are masked off / read out of bounds contribute 0.
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, BANK_MASK, false));
+}
+
+// Sum over each row of 16 lanes; every lane of the row ends up with the row sum.
+__device__ __forceinline__ float row16_sum(float x)
+{
+#if defined(GSX_SAFE_REDUCE) && GSX_SAFE_REDUCE
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+#endif
+    x += dpp_f32<0xB1>(x);  // quad_perm [1,0,3,2]
+    x += dpp_f32<0x4E>(x);  // quad_perm [2,3,0,1]
+    x += dpp_f32<0x141>(x); // row_half_mirror
+    x += dpp_f32<0x140>(x); // row_mirror
+    return x;
+}
+
+// Sum over the 64 lanes of the wave. The total is returned in every lane (via
+// v_readlane of the four row sums, which also makes the value wave-uniform).
+__device__ __forceinline__ float wave_sum(float x)
+{
+    x = row16_sum(x);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// Reduce FOUR per-lane values over the wave in one go ("reduce-scatter"): on return every lane of
+// 16-lane row r (= lane >> 4) holds the wave-wide sum of value r of (a, b, c, d).
+// gfx950 v_permlane16_swap / v_permlane32_swap fold two registers into one per step, so four
+// 64-lane reductions cost 3 swaps + 3 adds + 4 DPP adds instead of 4 x 6 DPP adds.
+//   permlane16_swap(x, y): odd rows of x <-> even rows of y      (ISA V_PERMLANE16_SWAP_B32)
+//   permlane32_swap(x, y): lanes 32-63 of x <-> lanes 0-31 of y  (ISA V_PERMLANE32_SWAP_B32)
+// Build with -DGSX_SAFE_REDUCE=1 to get a plain __shfl_xor version (debug / A-B reference).
+__device__ __forceinline__ float wave_sum4_scatter(float a, float b, float c, float d)
+{
+#if defined(GSX_SAFE_REDUCE) && GSX_SAFE_REDUCE
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+        c += __shfl_xor(c, o);
+        d += __shfl_xor(d, o);
+    }
+    const int row = (int)(threadIdx.x & 63u) >> 4;
+    return row == 0 ? a : (row == 1 ? b : (row == 2 ? c : d));
+#else
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    const float P = __uint_as_float(p[0]) + __uint_as_float(p[1]); // rows: a01, b01, a23, b23
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(d), false, false);
+    const float Q = __uint_as_float(q[0]) + __uint_as_float(q[1]); // rows: c01, d01, c23, d23
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(P), __float_as_uint(Q), false, false);
+    const float R = __uint_as_float(r[0]) + __uint_as_float(r[1]); // rows: a, b, c, d (per column)
+    return row16_sum(R);
+#endif
+}
+
+__device__ __forceinline__ int wave_max_i32(int x)
+{
+    // butterfly with DPP inside rows, then readlane across rows
+    auto step = [](int v, int o) { return v > o ? v : o; };
+#if defined(GSX_SAFE_REDUCE) && GSX_SAFE_REDUCE
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x = step(x, __shfl_xor(x, o));
+    return x;
+#endif
+    x = step(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
+    x = step(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
+    x = step(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));
+    x = step(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));
+    const int r0 = __builtin_amdgcn_readlane(x, 0);
+    const int r1 = __builtin_amdgcn_readlane(x, 16);
+    const int r2 = __builtin_amdgcn_readlane(x, 32);
+    const int r3 = __builtin_amdgcn_readlane(x, 48);
+    return step(step(r0, r1), step(r2, r3));
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// Hardware fp32 atomic add (global_atomic_add_f32, no CAS loop, no return).
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
+
+// ---- deterministic natural log -------------------------------------------------
+// Used where a float decision feeds INTEGER outputs (tile counts / radii): the
+// CPU oracle restates the same sequence of IEEE operations (explicit fmaf, no
+// contraction), so the integer results are bit-identical between the two.
+// Accuracy ~2 ulp on normal positive inputs, which is at least as tight as the
+// fast-math __logf the reference uses at the same places
+// (gsplat/cuda/csrc/ProjectionEWA3DGSFused.cu:180, IntersectTile.cu:303).
+__host__ __device__ __forceinline__ float det_logf(float x)
+{
+    // x = m * 2^e, m in [sqrt(1/2), sqrt(2))
+    union { float f; uint32_t u; } v;
+    v.f        = x;
+    int e      = (int)((v.u >> 23) & 0xFF) - 127;
+    v.u        = (v.u & 0x007FFFFFu) | 0x3F800000u; // m in [1,2)
+    float m    = v.f;
+    if (m > 1.41421356f) {
+        m *= 0.5f;
+        e += 1;
+    }
+    // log(m) = 2*atanh(s), s = (m-1)/(m+1); |s| <= 0.1716
+    const float s  = (m - 1.0f) / (m + 1.0f);
+    const float s2 = s * s;
+    float p        = 0.2222222222f;              // 2/9
+    p              = fmaf(p, s2, 0.2857142857f); // 2/7
+    p              = fmaf(p, s2, 0.4f);          // 2/5
+    p              = fmaf(p, s2, 0.6666666667f); // 2/3
+    p              = fmaf(p, s2, 2.0f);
+    const float lm = p * s;
+    return fmaf((float)e, 0.69314718056f, lm);
+}
+
+} // namespace gsx

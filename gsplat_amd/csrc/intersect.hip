@@ -1,0 +1,262 @@
+// Gaussian -> tile intersection: count / emit / offsets (gfx950).
+//
+// Restates the behaviour of gsplat::intersect_tile + gsplat::intersect_offset
+// (reference gsplat/cuda/csrc/IntersectTile.cu:83-207 ellipse helpers, :214-464 count+emit kernel,
+// :925-988 offsets kernel; host gsplat/cuda/csrc/Intersect.cpp:170-329, :547).
+//
+// This file is compiled with -ffp-contract=off: every float operation below is a single IEEE
+// operation (HIP's / and sqrtf are correctly rounded, det_logf uses explicit fmaf), and the CPU
+// oracle (oracle/gsplat_oracle.c) performs the same operations in the same order, so the INTEGER
+// outputs (tiles_per_gauss, isect_ids, flatten_ids, offsets) are bit-identical between the two.
+#include "common.hpp"
+
+namespace gsx {
+
+struct IsectArgs {
+    const float *means2d;      // [R,2]
+    const int32_t *radii;      // [R,2]
+    const float *depths;       // [R] (emit only)
+    const float *conics;       // [R,3] or null
+    const float *opacities;    // [R] or null
+    const int64_t *image_ids;  // [R] or null (packed)
+    const int64_t *cum;        // [R] inclusive cumsum (emit only)
+    int64_t rows;
+    uint32_t n_per_image;      // N (dense)
+    uint32_t tile_size, tile_w, tile_h;
+    uint32_t tile_n_bits;
+    int32_t *tiles_per_gauss;  // count only
+    int64_t *isect_ids;        // emit only
+    int32_t *flatten_ids;      // emit only
+};
+
+__host__ __device__ __forceinline__ int f2i_trunc_sat(float x)
+{
+    // float -> int truncation, saturating (NaN -> 0), identical on host and device
+    if (!(x == x)) return 0;
+    if (x >= 2.0e9f) return 2000000000;
+    if (x <= -2.0e9f) return -2000000000;
+    return (int)x;
+}
+__host__ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Where does the line u = coord cut the level-t ellipse of conic (A,B,C) centred at p?
+// Returns the two roots in v. (quadratic: coeff*(v-pv)^2 + 2*B*h*(v-pv) + other*h^2 - t = 0)
+__host__ __device__ __forceinline__ void ellipse_cut(float B, float coeff, float disc, float t, float pu, float pv,
+                                                     float coord, float &lo, float &hi)
+{
+    const float h    = coord - pu;
+    const float arg  = disc * h * h + t * coeff;
+    const float root = sqrtf(arg > 0.0f ? arg : 0.0f);
+    const float mbh  = -B * h;
+    lo               = (mbh - root) / coeff + pv;
+    hi               = (mbh + root) / coeff + pv;
+}
+
+// Visits every tile touched by the Gaussian; calls emit(tile_id). Returns the tile count.
+template <typename Emit>
+__host__ __device__ __forceinline__ int32_t walk_tiles(
+    float mx, float my, float rx, float ry, bool has_conic, float A, float B, float C, float opacity,
+    uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, Emit &&emit)
+{
+    const float ts = (float)tile_size;
+    int32_t count  = 0;
+    if (has_conic) {
+        // exact ellipse-vs-tile walk (SNUGBOX bbox + per-slab extents), opacity-aware level set
+        const float disc = B * B - A * C;
+        float t          = 2.0f * det_logf(opacity * 255.0f);
+        const float tmax = kGaussianExtend * kGaussianExtend;
+        if (t > tmax) t = tmax;
+        if (!(t > 0.0f) || !(disc < 0.0f)) return 0;
+        const float s  = -t / disc;
+        const float ex = sqrtf(s * C), ey = sqrtf(s * A);
+        const float bminx = mx - ex, bmaxx = mx + ex, bminy = my - ey, bmaxy = my + ey;
+        const float bx_c = B * ex / C, by_a = B * ey / A;
+        // coordinate (on the other axis) at which each bbox side touches the ellipse
+        const float y_at_xmin = my + bx_c, y_at_xmax = my - bx_c;
+        const float x_at_ymin = mx + by_a, x_at_ymax = mx - by_a;
+
+        const int rminx = clampi(f2i_trunc_sat(bminx / ts), 0, (int)tile_w);
+        const int rminy = clampi(f2i_trunc_sat(bminy / ts), 0, (int)tile_h);
+        const int rmaxx = clampi(f2i_trunc_sat(bmaxx / ts + 1.0f), 0, (int)tile_w);
+        const int rmaxy = clampi(f2i_trunc_sat(bmaxy / ts + 1.0f), 0, (int)tile_h);
+        const int yspan = rmaxy - rminy, xspan = rmaxx - rminx;
+        if (yspan <= 0 || xspan <= 0) return 0;
+
+        // iterate slabs along the SHORTER span (u), solve the covered range on the other axis (v)
+        const bool alongY = yspan < xspan;
+        const int u0 = alongY ? rminy : rminx, u1 = alongY ? rmaxy : rmaxx;
+        const int v0 = alongY ? rminx : rminy, v1 = alongY ? rmaxx : rmaxy;
+        const float pu = alongY ? my : mx, pv = alongY ? mx : my;
+        const float bmin_u = alongY ? bminy : bminx, bmax_u = alongY ? bmaxy : bmaxx;
+        const float bmin_v = alongY ? bminx : bminy, bmax_v = alongY ? bmaxx : bmaxy;
+        const float u_at_vmin = alongY ? y_at_xmin : x_at_ymin; // u where v is minimal
+        const float u_at_vmax = alongY ? y_at_xmax : x_at_ymax;
+        const float coeff     = alongY ? A : C;
+
+        float hi_lo = bmax_v, hi_hi = bmin_v; // "empty" interval: neutral under min/max below
+        float lo_lo, lo_hi;
+        float line_lo = (float)u0 * ts;
+        if (bmin_u <= line_lo) ellipse_cut(B, coeff, disc, t, pu, pv, line_lo, lo_lo, lo_hi);
+        else { lo_lo = hi_lo; lo_hi = hi_hi; }
+
+        for (int u = u0; u < u1; ++u) {
+            const float line_hi = line_lo + ts;
+            if (line_hi <= bmax_u) ellipse_cut(B, coeff, disc, t, pu, pv, line_hi, hi_lo, hi_hi);
+            const float vmin = (line_lo <= u_at_vmin && u_at_vmin < line_hi) ? bmin_v : fminf(lo_lo, hi_lo);
+            const float vmax = (line_lo <= u_at_vmax && u_at_vmax < line_hi) ? bmax_v : fmaxf(lo_hi, hi_hi);
+            const int tv0    = clampi(f2i_trunc_sat(vmin / ts), v0, v1);
+            const int tv1    = clampi(f2i_trunc_sat(vmax / ts + 1.0f), v0, v1);
+            for (int v = tv0; v < tv1; ++v) {
+                emit(alongY ? (int64_t)u * tile_w + v : (int64_t)v * tile_w + u);
+                ++count;
+            }
+            lo_lo   = hi_lo;
+            lo_hi   = hi_hi;
+            line_lo = line_hi;
+        }
+        return count;
+    }
+    // axis-aligned bounding box of (mean +- radius): min inclusive (floor), max exclusive (ceil)
+    const float tx = mx / ts, ty = my / ts, trx = rx / ts, try_ = ry / ts;
+    const int x0 = clampi(f2i_trunc_sat(floorf(tx - trx)), 0, (int)tile_w);
+    const int y0 = clampi(f2i_trunc_sat(floorf(ty - try_)), 0, (int)tile_h);
+    const int x1 = clampi(f2i_trunc_sat(ceilf(tx + trx)), 0, (int)tile_w);
+    const int y1 = clampi(f2i_trunc_sat(ceilf(ty + try_)), 0, (int)tile_h);
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            emit((int64_t)y * tile_w + x);
+            ++count;
+        }
+    return count;
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(256) isect_kernel(const IsectArgs a)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.rows) return;
+    const float rx = (float)a.radii[2 * idx], ry = (float)a.radii[2 * idx + 1];
+    if (rx <= 0.0f || ry <= 0.0f) {
+        if (!EMIT) a.tiles_per_gauss[idx] = 0;
+        return;
+    }
+    const float mx = a.means2d[2 * idx], my = a.means2d[2 * idx + 1];
+    const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
+    float A = 0.f, B = 0.f, C = 0.f, op = 0.f;
+    if (has_conic) {
+        A  = a.conics[3 * idx];
+        B  = a.conics[3 * idx + 1];
+        C  = a.conics[3 * idx + 2];
+        op = a.opacities[idx];
+    }
+    if (!EMIT) {
+        a.tiles_per_gauss[idx] =
+            walk_tiles(mx, my, rx, ry, has_conic, A, B, C, op, a.tile_size, a.tile_w, a.tile_h, [](int64_t) {});
+    } else {
+        const int64_t iid   = a.image_ids ? a.image_ids[idx] : idx / a.n_per_image;
+        const uint64_t hi   = (uint64_t)iid << (32 + a.tile_n_bits);
+        const uint64_t dkey = (uint64_t)__float_as_uint(a.depths[idx]);
+        int64_t cur         = idx == 0 ? 0 : a.cum[idx - 1];
+        walk_tiles(mx, my, rx, ry, has_conic, A, B, C, op, a.tile_size, a.tile_w, a.tile_h, [&](int64_t tile) {
+            a.isect_ids[cur]   = (int64_t)(hi | ((uint64_t)tile << 32) | dkey);
+            a.flatten_ids[cur] = (int32_t)idx;
+            ++cur;
+        });
+    }
+}
+
+// offsets[k] = first index of the sorted list whose (image, tile) >= k.
+__global__ void __launch_bounds__(256) isect_offsets_kernel(
+    const int64_t *sorted_ids, int64_t n_isects, uint32_t n_tiles, uint32_t tile_n_bits, int64_t total_tiles,
+    int32_t *offsets)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_isects) return;
+    const uint64_t tmask = (tile_n_bits >= 32) ? 0xFFFFFFFFull : ((1ull << tile_n_bits) - 1ull);
+    auto linear = [&](int64_t key) -> int64_t {
+        const uint64_t k = (uint64_t)key >> 32;
+        return (int64_t)(k >> tile_n_bits) * n_tiles + (int64_t)(k & tmask);
+    };
+    const int64_t cur  = linear(sorted_ids[i]);
+    const int64_t prev = i == 0 ? -1 : linear(sorted_ids[i - 1]);
+    for (int64_t k = prev + 1; k <= cur; ++k) offsets[k] = (int32_t)i;
+    if (i == n_isects - 1)
+        for (int64_t k = cur + 1; k < total_tiles; ++k) offsets[k] = (int32_t)n_isects;
+}
+
+static uint32_t bits_for_count(uint64_t count)
+{ // bits to index 0..count-1 (0 when count <= 1)  — reference MathUtils.h:25-35
+    uint32_t b = 0;
+    if (count <= 1) return 0;
+    uint64_t v = count - 1;
+    while (v) { ++b; v >>= 1; }
+    return b;
+}
+
+} // namespace gsx
+
+extern "C" int gsx_isect_count(const float *means2d, const int32_t *radii, const float *conics, const float *opacities,
+                               const int64_t *image_ids, int64_t rows, uint32_t n_per_image, uint32_t n_images,
+                               uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int32_t *tiles_per_gauss,
+                               void *stream)
+{
+    using namespace gsx;
+    (void)n_images;
+    GSX_REQUIRE(rows >= 0, "gsx_isect_count: negative rows");
+    GSX_REQUIRE(tile_size > 0, "gsx_isect_count: tile_size must be positive");
+    if (rows == 0) return GSX_OK;
+    GSX_REQUIRE(means2d && radii && tiles_per_gauss, "gsx_isect_count: null pointer");
+    IsectArgs a{};
+    a.means2d = means2d; a.radii = radii; a.conics = conics; a.opacities = opacities; a.image_ids = image_ids;
+    a.rows = rows; a.n_per_image = n_per_image ? n_per_image : 1; a.tile_size = tile_size; a.tile_w = tile_w;
+    a.tile_h = tile_h; a.tiles_per_gauss = tiles_per_gauss;
+    isect_kernel<false><<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    return check_launch("isect_count");
+}
+
+extern "C" int gsx_isect_emit(const float *means2d, const int32_t *radii, const float *depths, const float *conics,
+                              const float *opacities, const int64_t *image_ids, const int64_t *cum_tiles_per_gauss,
+                              int64_t rows, uint32_t n_per_image, uint32_t n_images, uint32_t tile_size,
+                              uint32_t tile_w, uint32_t tile_h, int64_t *isect_ids, int32_t *flatten_ids, void *stream)
+{
+    using namespace gsx;
+    GSX_REQUIRE(rows >= 0, "gsx_isect_emit: negative rows");
+    GSX_REQUIRE(tile_size > 0, "gsx_isect_emit: tile_size must be positive");
+    const uint32_t tile_bits = bits_for_count((uint64_t)tile_w * tile_h), image_bits = bits_for_count(n_images);
+    if (tile_bits + image_bits > 32) {
+        set_last_error("gsx_isect_emit: tile bits (%u) + image bits (%u) exceed the 32 key bits above the depth",
+                       tile_bits, image_bits);
+        return GSX_ERR_OVERFLOW;
+    }
+    if (rows == 0) return GSX_OK;
+    GSX_REQUIRE(means2d && radii && depths && cum_tiles_per_gauss, "gsx_isect_emit: null pointer");
+    IsectArgs a{};
+    a.means2d = means2d; a.radii = radii; a.depths = depths; a.conics = conics; a.opacities = opacities;
+    a.image_ids = image_ids; a.cum = cum_tiles_per_gauss; a.rows = rows; a.n_per_image = n_per_image ? n_per_image : 1;
+    a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h; a.tile_n_bits = tile_bits;
+    a.isect_ids = isect_ids; a.flatten_ids = flatten_ids;
+    isect_kernel<true><<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    return check_launch("isect_emit");
+}
+
+extern "C" int gsx_isect_offsets(const int64_t *isect_ids_sorted, int64_t n_isects, uint32_t n_images, uint32_t tile_w,
+                                 uint32_t tile_h, int32_t *offsets, void *stream)
+{
+    using namespace gsx;
+    const int64_t n_tiles = (int64_t)tile_w * tile_h, total = n_tiles * n_images;
+    if (total == 0) return GSX_OK;
+    GSX_REQUIRE(offsets != nullptr, "gsx_isect_offsets: null offsets");
+    GSX_REQUIRE(n_isects >= 0 && n_isects < (1ll << 31), "gsx_isect_offsets: n_isects out of range");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_isects == 0) {
+        if (hipMemsetAsync(offsets, 0, total * sizeof(int32_t), s) != hipSuccess) {
+            set_last_error("gsx_isect_offsets: memset failed");
+            return GSX_ERR_LAUNCH;
+        }
+        return GSX_OK;
+    }
+    GSX_REQUIRE(isect_ids_sorted != nullptr, "gsx_isect_offsets: null ids");
+    isect_offsets_kernel<<<dim3((uint32_t)ceil_div(n_isects, 256)), dim3(256), 0, s>>>(
+        isect_ids_sorted, n_isects, (uint32_t)n_tiles, bits_for_count((uint64_t)n_tiles), total, offsets);
+    return check_launch("isect_offsets");
+}

@@ -1,0 +1,82 @@
+// Shared pieces of the 3DGS alpha-compositing kernels (forward + backward).
+//
+// Work decomposition (MI355X-first, not the reference's 32-lane warp layout):
+//   * one 256-thread workgroup per 16x16 tile = 4 wave64s;
+//   * wave w owns the 8x8 pixel QUADRANT (w&1, w>>1) of the tile, lane l the pixel
+//     (l&7, l>>3) inside it. An 8x8 footprint per wave makes wave-level culling and
+//     wave-level early termination far more effective than 16x4 strips;
+//   * the tile's depth-sorted Gaussian list is walked in batches of 256 staged in LDS
+//     (coalesced gather through flatten_ids, then conflict-free broadcast reads).
+//
+// Semantics restated from the reference (behaviour, not code):
+//   gsplat/cuda/csrc/RasterizeToPixels3DGSDevice.cuh:44-173 (per-sample math)
+//   gsplat/cuda/csrc/RasterizeToPixels3DGSSerialBatchFwd.cu:41-297
+//   gsplat/cuda/csrc/RasterizeToPixels3DGSSerialBatchBwd.cu:41-320
+#pragma once
+#include "common.hpp"
+
+namespace gsx {
+
+struct Raster3DArgs {
+    // geometry of the launch
+    uint32_t n_images;    // I
+    uint32_t n_isects;    // M
+    uint32_t width;
+    uint32_t height;
+    uint32_t tile_size;   // <= 16
+    uint32_t tile_w;
+    uint32_t tile_h;
+    // channel chunking: this launch handles channels [ch_off, ch_off + nch) of cdim
+    uint32_t cdim;
+    uint32_t ch_off;
+    uint32_t nch;
+    uint32_t first_chunk; // 1 => this launch also owns alpha / last_ids / geometry-from-alpha terms
+    // forward inputs (rows indexed by flatten_ids: [I*N] dense or [nnz] packed)
+    const float *means2d;     // [R, 2]
+    const float *conics;      // [R, 3]
+    const float *colors;      // [R, cdim]
+    const float *opacities;   // [R]
+    const float *backgrounds; // [I, cdim] or null
+    const uint8_t *masks;     // [I, tile_h, tile_w] or null (torch bool)
+    const int32_t *isect_offsets; // [I, tile_h, tile_w]
+    const int32_t *flatten_ids;   // [M]
+    // forward outputs
+    float *render_colors; // [I, H, W, cdim]
+    float *render_alphas; // [I, H, W, 1]
+    int32_t *last_ids;    // [I, H, W]
+    // backward inputs
+    const float *v_render_colors; // [I, H, W, cdim]
+    const float *v_render_alphas; // [I, H, W, 1]
+    // backward outputs (zero-initialised by the caller; accumulated with atomics)
+    float *v_means2d_abs; // [R, 2] or null
+    float *v_means2d;     // [R, 2]
+    float *v_conics;      // [R, 3]
+    float *v_colors;      // [R, cdim]
+    float *v_opacities;   // [R]
+};
+
+// Block index -> (image, tile) with an XCD-aware remap: hardware places workgroup b on
+// XCD b % 8 (MI355X_MICROARCH.md "Workgroup dispatch"); neighbouring tiles share Gaussians,
+// so give each XCD a contiguous run of tiles to keep those rows in ITS private L2.
+// Pure performance remap: any placement is correct.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n_blocks)
+{
+    constexpr uint32_t kXcds = 8;
+    const uint32_t per_xcd   = (n_blocks + kXcds - 1) / kXcds;
+    return (b % kXcds) * per_xcd + (b / kXcds);
+}
+
+// thread -> pixel inside the tile.
+__device__ __forceinline__ void tile_pixel(uint32_t tid, uint32_t tile_size, uint32_t &lx, uint32_t &ly)
+{
+    if (tile_size == 16) {
+        const uint32_t w = tid >> 6, l = tid & 63u;
+        lx = ((w & 1u) << 3) | (l & 7u);
+        ly = ((w >> 1) << 3) | (l >> 3);
+    } else {
+        lx = tid % tile_size;
+        ly = tid / tile_size; // >= tile_size for surplus threads -> treated as outside
+    }
+}
+
+} // namespace gsx

@@ -1,0 +1,283 @@
+// 3DGS alpha compositing, backward (gfx950).
+// C-ABI entry: gsx_raster3d_bwd  (replaces torch op gsplat::rasterize_to_pixels_3dgs_bwd,
+// reference host fn gsplat/cuda/csrc/Rasterization.cpp:484-587, kernel
+// RasterizeToPixels3DGSSerialBatchBwd.cu:41-320, math RasterizeToPixels3DGSDevice.cuh:105-173).
+//
+// Gradient accumulation is re-designed for wave64 + 160 KiB LDS instead of the reference's
+// "32-lane reduce, then 9+D global atomics per warp per Gaussian":
+//   1. each lane computes its pixel's contribution to one Gaussian (K = D+6 [+2 absgrad] values);
+//   2. the wave reduces FOUR values at a time with permlane16/32 swaps + DPP (common.hpp);
+//   3. the K totals land in K different lanes, and ONE ds_add_f32 adds them into a per-tile LDS
+//      accumulator row for that Gaussian (4 waves -> 4-way LDS contention at most);
+//   4. after the batch, thread i flushes Gaussian i's row with global_atomic_add_f32 — one global
+//      atomic per (tile, Gaussian, component) instead of one per (warp, Gaussian, component),
+//      issued by full waves on 64 different rows.
+#include "raster3d.hpp"
+#include "../../include/gsplat_amd.h"
+
+namespace gsx {
+
+template <int CH, bool ABS>
+struct BwdCfg {
+    static constexpr int K     = CH + 6 + (ABS ? 2 : 0);     // values reduced per Gaussian
+    static constexpr int KQ    = (K + 3) / 4;                // groups of four
+    static constexpr int KP    = (K | 1);                    // odd row stride -> conflict-free flush
+    static constexpr int BATCH = (CH >= 16) ? 128 : 256;     // LDS budget for wide channel chunks
+    static constexpr size_t smem =
+        (size_t)BATCH * (sizeof(float4) + sizeof(float2) + sizeof(int32_t) * 2 + sizeof(float) * (CH + KP));
+};
+
+template <int CH, bool ABS>
+__global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
+{
+    using Cfg           = BwdCfg<CH, ABS>;
+    constexpr int K     = Cfg::K;
+    constexpr int KQ    = Cfg::KQ;
+    constexpr int KP    = Cfg::KP;
+    constexpr int BATCH = Cfg::BATCH;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4 *s_ga     = reinterpret_cast<float4 *>(smem_raw);       // x, y, opac, conic.a
+    float2 *s_gb     = reinterpret_cast<float2 *>(s_ga + BATCH);   // conic.b, conic.c
+    int32_t *s_id    = reinterpret_cast<int32_t *>(s_gb + BATCH);  // flatten id of the row
+    int32_t *s_touch = s_id + BATCH;                               // any lane contributed?
+    float *s_col     = reinterpret_cast<float *>(s_touch + BATCH); // [BATCH][CH]
+    float *s_acc     = s_col + BATCH * CH;                         // [BATCH][KP]
+
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
+    const uint32_t n_blocks        = tiles_per_image * a.n_images;
+    const uint32_t blk             = xcd_remap(blockIdx.x, n_blocks);
+    if (blk >= n_blocks) return;
+
+    const uint32_t image_id = blk / tiles_per_image;
+    const uint32_t tile_id  = blk % tiles_per_image;
+    if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) return;
+
+    const uint32_t tile_x = tile_id % a.tile_w;
+    const uint32_t tile_y = tile_id / a.tile_w;
+    const uint32_t tid    = threadIdx.x;
+    const uint32_t lane   = tid & 63u;
+
+    uint32_t lx, ly;
+    tile_pixel(tid, a.tile_size, lx, ly);
+    const uint32_t ox = tile_x * a.tile_size + lx;
+    const uint32_t oy = tile_y * a.tile_size + ly;
+    const bool inside = (lx < a.tile_size) && (ly < a.tile_size) && (ox < a.width) && (oy < a.height);
+    const float px    = (float)ox + 0.5f;
+    const float py    = (float)oy + 0.5f;
+    const size_t pix  = inside ? ((size_t)image_id * a.height + oy) * a.width + ox : 0;
+
+    const int32_t range_start = a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id];
+    const int32_t range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects
+                                                      : a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id + 1];
+    const int32_t n_batches   = (range_end - range_start + BATCH - 1) / BATCH;
+    if (n_batches <= 0) return;
+
+    // per-pixel state
+    const float T_final     = inside ? 1.0f - a.render_alphas[pix] : 1.0f;
+    float T                 = T_final;
+    const int32_t bin_final = inside ? a.last_ids[pix] : -1;
+    float v_c[CH], buffer[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        v_c[k]    = (inside && k < (int)a.nch) ? a.v_render_colors[pix * a.cdim + a.ch_off + k] : 0.0f;
+        buffer[k] = 0.0f;
+    }
+    // alpha-gradient term and background term belong to exactly one channel chunk / all chunks resp.
+    const float v_a = (inside && a.first_chunk) ? a.v_render_alphas[pix] : 0.0f;
+    float bg_dot    = 0.0f; // sum_k bg_k * v_c_k (this chunk)
+    if (a.backgrounds) {
+        const float *bg = a.backgrounds + (size_t)image_id * a.cdim + a.ch_off;
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (k < (int)a.nch) bg_dot += bg[k] * v_c[k];
+    }
+    const int32_t wave_bin_final = wave_max_i32(bin_final);
+
+    // zero the accumulator rows this thread owns
+    for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) s_acc[s * KP + k] = 0.0f;
+        s_touch[s] = 0;
+    }
+
+    for (int32_t b = 0; b < n_batches; ++b) {
+        // back-to-front: slot 0 is the farthest-back Gaussian of this batch
+        const int32_t batch_end  = range_end - 1 - BATCH * b;
+        const int32_t batch_size = min(BATCH, batch_end + 1 - range_start);
+
+        for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
+            const int32_t idx = batch_end - s;
+            if (idx >= range_start) {
+                const int32_t g  = a.flatten_ids[idx];
+                const float2 xy  = reinterpret_cast<const float2 *>(a.means2d)[g];
+                const float opac = a.opacities[g];
+                const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
+                s_id[s]        = g;
+                s_ga[s]        = make_float4(xy.x, xy.y, opac, ca);
+                s_gb[s]        = make_float2(cb, cc);
+                const float *c = a.colors + (size_t)g * a.cdim + a.ch_off;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) s_col[s * CH + k] = (k < (int)a.nch) ? c[k] : 0.0f;
+            }
+        }
+        __syncthreads();
+
+        // Gaussians behind every pixel's last contributor in this wave are skipped wholesale.
+        for (int32_t t = max(0, batch_end - wave_bin_final); t < batch_size; ++t) {
+            bool valid = inside && (batch_end - t <= bin_final);
+            float alpha = 0.f, opac = 0.f, vis = 0.f, dx = 0.f, dy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+            if (valid) {
+                const float4 ga = s_ga[t];
+                const float2 gb = s_gb[t];
+                opac = ga.z; ca = ga.w; cb = gb.x; cc = gb.y;
+                dx = ga.x - px;
+                dy = ga.y - py;
+                const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                vis   = __expf(-sigma);
+                alpha = fminf(kMaxAlpha, opac * vis);
+                valid = !(sigma < 0.0f || alpha < kAlphaThreshold);
+            }
+            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform
+
+            float loc[KQ * 4];
+#pragma unroll
+            for (int k = 0; k < KQ * 4; ++k) loc[k] = 0.0f;
+            if (valid) {
+                const float ra  = 1.0f / fmaxf(kMinOneMinusAlpha, 1.0f - alpha);
+                T              *= ra;
+                const float fac = alpha * T;
+                float v_alpha   = 0.0f;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const float c = s_col[t * CH + k];
+                    loc[k]        = fac * v_c[k];
+                    v_alpha      += (c * T - buffer[k] * ra) * v_c[k];
+                    buffer[k]    += c * fac;
+                }
+                v_alpha += T_final * ra * v_a;
+                v_alpha -= T_final * ra * bg_dot;
+                if (opac * vis <= kMaxAlpha) {
+                    const float v_sigma = -opac * vis * v_alpha;
+                    loc[CH + 0]         = 0.5f * v_sigma * dx * dx;
+                    loc[CH + 1]         = v_sigma * dx * dy;
+                    loc[CH + 2]         = 0.5f * v_sigma * dy * dy;
+                    const float vx      = v_sigma * (ca * dx + cb * dy);
+                    const float vy      = v_sigma * (cb * dx + cc * dy);
+                    loc[CH + 3]         = vx;
+                    loc[CH + 4]         = vy;
+                    loc[CH + 5]         = vis * v_alpha;
+                    if constexpr (ABS) {
+                        loc[CH + 6] = fabsf(vx);
+                        loc[CH + 7] = fabsf(vy);
+                    }
+                }
+            }
+            // reduce four values per step; row r of group j ends up with total of value 4j + r
+            float mine = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                const float r = wave_sum4_scatter(loc[4 * j], loc[4 * j + 1], loc[4 * j + 2], loc[4 * j + 3]);
+                if ((int)(lane & 15u) == j) mine = r;
+            }
+            const int vidx = 4 * (int)(lane & 15u) + (int)(lane >> 4);
+            if ((int)(lane & 15u) < KQ && vidx < K) atomicAdd(&s_acc[t * KP + vidx], mine); // ds_add_f32
+            if (lane == 0) s_touch[t] = 1;
+        }
+        __syncthreads();
+
+        // flush: thread s owns Gaussian s of the batch
+        for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
+            if (s < batch_size && s_touch[s]) {
+                const size_t g = (size_t)s_id[s];
+                float *row     = s_acc + s * KP;
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+                    if (k < (int)a.nch) atomic_add_f32(a.v_colors + g * a.cdim + a.ch_off + k, row[k]);
+                atomic_add_f32(a.v_conics + 3 * g + 0, row[CH + 0]);
+                atomic_add_f32(a.v_conics + 3 * g + 1, row[CH + 1]);
+                atomic_add_f32(a.v_conics + 3 * g + 2, row[CH + 2]);
+                atomic_add_f32(a.v_means2d + 2 * g + 0, row[CH + 3]);
+                atomic_add_f32(a.v_means2d + 2 * g + 1, row[CH + 4]);
+                atomic_add_f32(a.v_opacities + g, row[CH + 5]);
+                if constexpr (ABS) {
+                    atomic_add_f32(a.v_means2d_abs + 2 * g + 0, row[CH + 6]);
+                    atomic_add_f32(a.v_means2d_abs + 2 * g + 1, row[CH + 7]);
+                }
+#pragma unroll
+                for (int k = 0; k < KP; ++k) row[k] = 0.0f;
+                s_touch[s] = 0;
+            }
+        }
+        // The next iteration's staging writes s_ga/s_gb/s_col/s_id (read above only by the owner
+        // thread or before the barrier); its barrier orders the zeroed rows before new ds_adds.
+    }
+}
+
+template <int CH, bool ABS>
+static int launch_bwd(const Raster3DArgs &a, hipStream_t stream)
+{
+    const uint32_t n_blocks = a.tile_w * a.tile_h * a.n_images;
+    if (n_blocks == 0 || a.n_isects == 0) return GSX_OK;
+    const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
+    const uint32_t block = a.tile_size <= 8 ? 64u : 256u;
+    using Cfg = BwdCfg<CH, ABS>;
+    const size_t smem = Cfg::smem;
+    raster3d_bwd_kernel<CH, ABS><<<dim3(grid), dim3(block), smem, stream>>>(a);
+    return check_launch("raster3d_bwd");
+}
+
+template <bool ABS>
+static int bwd_dispatch(Raster3DArgs a, hipStream_t stream)
+{
+    uint32_t off = 0;
+    bool first   = true;
+    do {
+        const uint32_t rem = a.cdim - off;
+        const uint32_t n   = rem > 32 ? 32 : rem;
+        a.ch_off           = off;
+        a.nch              = n;
+        a.first_chunk      = first ? 1u : 0u;
+        int rc;
+        if (n <= 1) rc = launch_bwd<1, ABS>(a, stream);
+        else if (n <= 2) rc = launch_bwd<2, ABS>(a, stream);
+        else if (n <= 3) rc = launch_bwd<3, ABS>(a, stream);
+        else if (n <= 4) rc = launch_bwd<4, ABS>(a, stream);
+        else if (n <= 8) rc = launch_bwd<8, ABS>(a, stream);
+        else if (n <= 16) rc = launch_bwd<16, ABS>(a, stream);
+        else rc = launch_bwd<32, ABS>(a, stream);
+        if (rc != GSX_OK) return rc;
+        off += n;
+        first = false;
+    } while (off < a.cdim);
+    return GSX_OK;
+}
+
+} // namespace gsx
+
+extern "C" int gsx_raster3d_bwd(
+    const float *means2d, const float *conics, const float *colors, const float *opacities,
+    const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+    const float *render_alphas, const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+    uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+    uint32_t tile_w, uint32_t tile_h, float *v_means2d_abs, float *v_means2d, float *v_conics, float *v_colors,
+    float *v_opacities, void *stream)
+{
+    using namespace gsx;
+    GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster3d_bwd: tile_size must be in [1,16], got %u", tile_size);
+    GSX_REQUIRE(cdim >= 1, "gsx_raster3d_bwd: channels must be >= 1");
+    GSX_REQUIRE(v_means2d && v_conics && v_colors && v_opacities, "gsx_raster3d_bwd: null gradient output");
+    GSX_REQUIRE(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids && render_alphas && last_ids
+                                  && v_render_colors && v_render_alphas && isect_offsets),
+                "gsx_raster3d_bwd: null input");
+    Raster3DArgs a{};
+    a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height;
+    a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h; a.cdim = cdim;
+    a.means2d = means2d; a.conics = conics; a.colors = colors; a.opacities = opacities;
+    a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = isect_offsets; a.flatten_ids = flatten_ids;
+    a.render_alphas = const_cast<float *>(render_alphas); a.last_ids = const_cast<int32_t *>(last_ids);
+    a.v_render_colors = v_render_colors; a.v_render_alphas = v_render_alphas;
+    a.v_means2d_abs = v_means2d_abs; a.v_means2d = v_means2d; a.v_conics = v_conics; a.v_colors = v_colors;
+    a.v_opacities = v_opacities;
+    return v_means2d_abs ? bwd_dispatch<true>(a, (hipStream_t)stream) : bwd_dispatch<false>(a, (hipStream_t)stream);
+}

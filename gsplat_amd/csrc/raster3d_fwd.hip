@@ -1,0 +1,188 @@
+// 3DGS front-to-back alpha compositing, forward (gfx950).
+// C-ABI entry: gsx_raster3d_fwd  (replaces torch op gsplat::rasterize_to_pixels_3dgs,
+// reference host fn gsplat/cuda/csrc/Rasterization.cpp:275-365, kernel
+// RasterizeToPixels3DGSSerialBatchFwd.cu:41-297).
+#include "raster3d.hpp"
+#include "../../include/gsplat_amd.h"
+
+namespace gsx {
+
+constexpr int kBatch = 256;
+
+template <int CH>
+__global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4 *s_ga = reinterpret_cast<float4 *>(smem_raw);                 // x, y, opac, conic.a
+    float2 *s_gb = reinterpret_cast<float2 *>(s_ga + kBatch);            // conic.b, conic.c
+    float *s_col = reinterpret_cast<float *>(s_gb + kBatch);             // [kBatch][CH]
+
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
+    const uint32_t n_blocks        = tiles_per_image * a.n_images;
+    const uint32_t blk             = xcd_remap(blockIdx.x, n_blocks);
+    if (blk >= n_blocks) return; // uniform for the whole workgroup
+
+    const uint32_t image_id = blk / tiles_per_image;
+    const uint32_t tile_id  = blk % tiles_per_image;
+    const uint32_t tile_x   = tile_id % a.tile_w;
+    const uint32_t tile_y   = tile_id / a.tile_w;
+    const uint32_t tid      = threadIdx.x;
+
+    uint32_t lx, ly;
+    tile_pixel(tid, a.tile_size, lx, ly);
+    const uint32_t ox = tile_x * a.tile_size + lx;
+    const uint32_t oy = tile_y * a.tile_size + ly;
+    const bool inside = (lx < a.tile_size) && (ly < a.tile_size) && (ox < a.width) && (oy < a.height);
+    const float px    = (float)ox + 0.5f;
+    const float py    = (float)oy + 0.5f;
+    const size_t pix  = ((size_t)image_id * a.height + oy) * a.width + ox;
+
+    const float *bg = a.backgrounds ? a.backgrounds + (size_t)image_id * a.cdim + a.ch_off : nullptr;
+
+    // masked-off tile: background colour, zero alpha, last_id 0 (reference Fwd.cu:141-159)
+    if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) {
+        if (inside) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (k < (int)a.nch) a.render_colors[pix * a.cdim + a.ch_off + k] = bg ? bg[k] : 0.0f;
+            if (a.first_chunk) {
+                a.render_alphas[pix] = 0.0f;
+                a.last_ids[pix]      = 0;
+            }
+        }
+        return;
+    }
+
+    const int32_t range_start = a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id];
+    const int32_t range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects
+                                                      : a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id + 1];
+    const int32_t n_batches   = (range_end - range_start + kBatch - 1) / kBatch;
+
+    float T          = 1.0f;
+    uint32_t cur_idx = 0;
+    float acc[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) acc[k] = 0.0f;
+    bool done = !inside;
+
+    for (int32_t b = 0; b < n_batches; ++b) {
+        // block-wide early out: every pixel of the tile finished. Also fences LDS reuse.
+        if (__syncthreads_count(done) == (int)blockDim.x) break;
+
+        const int32_t batch_start = range_start + kBatch * b;
+        for (int s = (int)tid; s < kBatch; s += (int)blockDim.x) {
+            const int32_t idx = batch_start + s;
+            if (idx < range_end) {
+                const int32_t g  = a.flatten_ids[idx];
+                const float2 xy  = reinterpret_cast<const float2 *>(a.means2d)[g];
+                const float opac = a.opacities[g];
+                const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
+                s_ga[s]        = make_float4(xy.x, xy.y, opac, ca);
+                s_gb[s]        = make_float2(cb, cc);
+                const float *c = a.colors + (size_t)g * a.cdim + a.ch_off;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) s_col[s * CH + k] = (k < (int)a.nch) ? c[k] : 0.0f;
+            }
+        }
+        __syncthreads();
+
+        const int32_t batch_size = min(kBatch, range_end - batch_start);
+        // wave-level early termination: a finished 8x8 quadrant stops evaluating
+        // (it still takes part in staging and in the barriers above).
+        for (int32_t t = 0; t < batch_size; ++t) {
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+            const float4 ga = s_ga[t];
+            const float2 gb = s_gb[t];
+            const float dx  = ga.x - px;
+            const float dy  = ga.y - py;
+            const float sigma = 0.5f * (ga.w * dx * dx + gb.y * dy * dy) + gb.x * dx * dy;
+            const float vis   = __expf(-sigma);
+            const float alpha = fminf(kMaxAlpha, ga.z * vis);
+            if (done || sigma < 0.0f || alpha < kAlphaThreshold) continue;
+            const float next_T = T * (1.0f - alpha);
+            if (next_T <= kTransmittanceThresh) { // saturated: this Gaussian is excluded
+                done = true;
+                continue;
+            }
+            const float w = alpha * T;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) acc[k] += s_col[t * CH + k] * w;
+            cur_idx = (uint32_t)(batch_start + t);
+            T       = next_T;
+        }
+    }
+
+    if (inside) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (k < (int)a.nch)
+                a.render_colors[pix * a.cdim + a.ch_off + k] = bg ? (acc[k] + T * bg[k]) : acc[k];
+        if (a.first_chunk) {
+            a.render_alphas[pix] = 1.0f - T;
+            a.last_ids[pix]      = (int32_t)cur_idx;
+        }
+    }
+}
+
+template <int CH>
+static int launch_fwd(const Raster3DArgs &a, hipStream_t stream)
+{
+    const uint32_t n_blocks = a.tile_w * a.tile_h * a.n_images;
+    if (n_blocks == 0) return GSX_OK;
+    const uint32_t grid   = ((n_blocks + 7u) / 8u) * 8u; // xcd_remap needs a multiple of 8
+    const uint32_t block  = a.tile_size <= 8 ? 64u : 256u;
+    const size_t smem     = kBatch * (sizeof(float4) + sizeof(float2) + sizeof(float) * CH);
+    hipLaunchKernelGGL(raster3d_fwd_kernel<CH>, dim3(grid), dim3(block), smem, stream, a);
+    return check_launch("raster3d_fwd");
+}
+
+int raster3d_fwd_dispatch(Raster3DArgs a, hipStream_t stream)
+{
+    // walk the channel dimension in chunks of <= 32 (register budget); alphas, last_ids come
+    // from the first chunk (same rule as the reference orchestrator, Rendering.cpp:1353-1435).
+    uint32_t off = 0;
+    bool first   = true;
+    do {
+        const uint32_t rem = a.cdim - off;
+        const uint32_t n   = rem > 32 ? 32 : rem;
+        a.ch_off           = off;
+        a.nch              = n;
+        a.first_chunk      = first ? 1u : 0u;
+        int rc;
+        if (n <= 1) rc = launch_fwd<1>(a, stream);
+        else if (n <= 2) rc = launch_fwd<2>(a, stream);
+        else if (n <= 3) rc = launch_fwd<3>(a, stream);
+        else if (n <= 4) rc = launch_fwd<4>(a, stream);
+        else if (n <= 8) rc = launch_fwd<8>(a, stream);
+        else if (n <= 16) rc = launch_fwd<16>(a, stream);
+        else rc = launch_fwd<32>(a, stream);
+        if (rc != GSX_OK) return rc;
+        off += n;
+        first = false;
+    } while (off < a.cdim);
+    return GSX_OK;
+}
+
+} // namespace gsx
+
+extern "C" int gsx_raster3d_fwd(
+    const float *means2d, const float *conics, const float *colors, const float *opacities,
+    const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+    uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+    uint32_t tile_w, uint32_t tile_h, float *render_colors, float *render_alphas, int32_t *last_ids, void *stream)
+{
+    using namespace gsx;
+    GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster3d_fwd: tile_size must be in [1,16], got %u", tile_size);
+    GSX_REQUIRE(cdim >= 1, "gsx_raster3d_fwd: channels must be >= 1");
+    GSX_REQUIRE(render_colors && render_alphas && last_ids, "gsx_raster3d_fwd: null output");
+    GSX_REQUIRE(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids),
+                "gsx_raster3d_fwd: null input");
+    GSX_REQUIRE(isect_offsets != nullptr || n_images * tile_w * tile_h == 0, "gsx_raster3d_fwd: null isect_offsets");
+    Raster3DArgs a{};
+    a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height;
+    a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h; a.cdim = cdim;
+    a.means2d = means2d; a.conics = conics; a.colors = colors; a.opacities = opacities;
+    a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = isect_offsets; a.flatten_ids = flatten_ids;
+    a.render_colors = render_colors; a.render_alphas = render_alphas; a.last_ids = last_ids;
+    return raster3d_fwd_dispatch(a, (hipStream_t)stream);
+}

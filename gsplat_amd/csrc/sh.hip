@@ -1,0 +1,321 @@
+// Spherical-harmonics colour evaluation (degree <= 4) forward / backward, gfx950.
+// C-ABI entries: gsx_sh_fwd, gsx_sh_bwd. Replaces gsplat::spherical_harmonics{,_bwd}
+// (reference gsplat/cuda/csrc/SphericalHarmonicsCUDA.cu:48-146 basis, :444-569 fwd, :786-890 bwd;
+//  torch restatement gsplat/cuda/_torch_impl.py:968-1067).
+//
+// Basis: Sloan, "Efficient Spherical Harmonic Evaluation" (JCGT 2013) polynomial forms; the
+// constants are the published ones. Direction = mean - camera centre, centre = -R^T t.
+#include "common.hpp"
+
+namespace gsx {
+
+constexpr int kMaxBases = 25;
+
+// Y[0..nb) for unit direction (x,y,z); if GRAD also dY/dx, dY/dy, dY/dz (x,y,z treated as free).
+template <bool GRAD>
+__device__ __forceinline__ void sh_bases(int degree, float x, float y, float z, float *Y, float *Yx, float *Yy, float *Yz)
+{
+    Y[0] = 0.2820947917738781f;
+    if (GRAD) { Yx[0] = Yy[0] = Yz[0] = 0.0f; }
+    if (degree < 1) return;
+    const float c1 = 0.48860251190292f;
+    Y[1] = -c1 * y; Y[2] = c1 * z; Y[3] = -c1 * x;
+    if (GRAD) {
+        Yx[1] = 0.f; Yy[1] = -c1; Yz[1] = 0.f;
+        Yx[2] = 0.f; Yy[2] = 0.f; Yz[2] = c1;
+        Yx[3] = -c1; Yy[3] = 0.f; Yz[3] = 0.f;
+    }
+    if (degree < 2) return;
+    const float z2 = z * z;
+    const float C1 = x * x - y * y, S1 = 2.0f * x * y; // cos/sin(1*phi) * r^1... (Sloan's fC1,fS1)
+    const float C1x = 2.0f * x, C1y = -2.0f * y, S1x = 2.0f * y, S1y = 2.0f * x;
+    {
+        const float b = -1.092548430592079f * z, bz = -1.092548430592079f;
+        const float a = 0.5462742152960395f;
+        Y[4] = a * S1; Y[5] = b * y; Y[6] = 0.9461746957575601f * z2 - 0.3153915652525201f; Y[7] = b * x; Y[8] = a * C1;
+        if (GRAD) {
+            Yx[4] = a * S1x; Yy[4] = a * S1y; Yz[4] = 0.f;
+            Yx[5] = 0.f; Yy[5] = b; Yz[5] = bz * y;
+            Yx[6] = 0.f; Yy[6] = 0.f; Yz[6] = 2.0f * 0.9461746957575601f * z;
+            Yx[7] = b; Yy[7] = 0.f; Yz[7] = bz * x;
+            Yx[8] = a * C1x; Yy[8] = a * C1y; Yz[8] = 0.f;
+        }
+    }
+    if (degree < 3) return;
+    const float C2 = x * C1 - y * S1, S2 = x * S1 + y * C1;
+    const float C2x = 3.0f * C1, C2y = -3.0f * S1, S2x = 3.0f * S1, S2y = 3.0f * C1;
+    {
+        const float c = -2.285228997322329f * z2 + 0.4570457994644658f, cz = -2.0f * 2.285228997322329f * z;
+        const float b = 1.445305721320277f * z, bz = 1.445305721320277f;
+        const float a = -0.5900435899266435f;
+        Y[9] = a * S2; Y[10] = b * S1; Y[11] = c * y;
+        Y[12] = z * (1.865881662950577f * z2 - 1.119528997770346f);
+        Y[13] = c * x; Y[14] = b * C1; Y[15] = a * C2;
+        if (GRAD) {
+            Yx[9] = a * S2x; Yy[9] = a * S2y; Yz[9] = 0.f;
+            Yx[10] = b * S1x; Yy[10] = b * S1y; Yz[10] = bz * S1;
+            Yx[11] = 0.f; Yy[11] = c; Yz[11] = cz * y;
+            Yx[12] = 0.f; Yy[12] = 0.f; Yz[12] = 3.0f * 1.865881662950577f * z2 - 1.119528997770346f;
+            Yx[13] = c; Yy[13] = 0.f; Yz[13] = cz * x;
+            Yx[14] = b * C1x; Yy[14] = b * C1y; Yz[14] = bz * C1;
+            Yx[15] = a * C2x; Yy[15] = a * C2y; Yz[15] = 0.f;
+        }
+    }
+    if (degree < 4) return;
+    const float C3 = x * C2 - y * S2, S3 = x * S2 + y * C2;
+    const float C3x = 4.0f * C2, C3y = -4.0f * S2, S3x = 4.0f * S2, S3y = 4.0f * C2;
+    {
+        const float d = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+        const float dz = -3.0f * 4.683325804901025f * z2 + 2.007139630671868f;
+        const float c = 3.31161143515146f * z2 - 0.47308734787878f, cz = 2.0f * 3.31161143515146f * z;
+        const float b = -1.770130769779931f * z, bz = -1.770130769779931f;
+        const float a = 0.6258357354491763f;
+        const float p12 = 1.865881662950577f * z2 - 1.119528997770346f;     // Y12 / z
+        const float p6  = 0.9461746957575601f * z2 - 0.3153915652525201f;   // Y6
+        Y[16] = a * S3; Y[17] = b * S2; Y[18] = c * S1; Y[19] = d * y;
+        Y[20] = 1.984313483298443f * z2 * p12 - 1.006230589874905f * p6;
+        Y[21] = d * x; Y[22] = c * C1; Y[23] = b * C2; Y[24] = a * C3;
+        if (GRAD) {
+            Yx[16] = a * S3x; Yy[16] = a * S3y; Yz[16] = 0.f;
+            Yx[17] = b * S2x; Yy[17] = b * S2y; Yz[17] = bz * S2;
+            Yx[18] = c * S1x; Yy[18] = c * S1y; Yz[18] = cz * S1;
+            Yx[19] = 0.f; Yy[19] = d; Yz[19] = dz * y;
+            Yx[20] = 0.f; Yy[20] = 0.f;
+            Yz[20] = 1.984313483298443f * (2.0f * z * p12 + z2 * 2.0f * 1.865881662950577f * z)
+                   - 1.006230589874905f * 2.0f * 0.9461746957575601f * z;
+            Yx[21] = d; Yy[21] = 0.f; Yz[21] = dz * x;
+            Yx[22] = c * C1x; Yy[22] = c * C1y; Yz[22] = cz * C1;
+            Yx[23] = b * C2x; Yy[23] = b * C2y; Yz[23] = bz * C2;
+            Yx[24] = a * C3x; Yy[24] = a * C3y; Yz[24] = 0.f;
+        }
+    }
+}
+
+struct ShArgs {
+    int degree;
+    const float *means, *viewmats, *coeffs;
+    const uint8_t *masks;
+    const int64_t *batch_ids, *camera_ids, *gaussian_ids;
+    uint32_t B, C, N, K, D;
+    int64_t nnz; // < 0: dense
+    int coeffs_gathered; // packed: 1 = coeffs is [nnz,K,D]; 0 = coeffs is [N,K,D] indexed by gaussian_ids
+    float *colors;
+    const float *v_colors;
+    float *v_coeffs, *v_means;
+    int atomic_coeffs; // packed + !gathered + more than one image: rows of one Gaussian collide
+};
+
+// unnormalised view direction of gaussian (b,g) seen from camera (b,c): mean + R^T t
+__device__ __forceinline__ void view_dir(const ShArgs &a, uint32_t b, uint32_t c, uint32_t g, float *d)
+{
+    const float *m = a.means + ((size_t)b * a.N + g) * 3;
+    const float *V = a.viewmats + ((size_t)b * a.C + c) * 16;
+    const float tx = V[3], ty = V[7], tz = V[11];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) d[j] = m[j] + V[j] * tx + V[4 + j] * ty + V[8 + j] * tz;
+}
+
+__device__ __forceinline__ float safe_inv_norm(const float *d)
+{
+    const float n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    return n2 > 0.0f ? rsqrtf(n2) : 0.0f;
+}
+
+// one thread per (row, channel)
+__global__ void __launch_bounds__(256) sh_fwd_kernel(const ShArgs a)
+{
+    const int64_t rows = a.nnz >= 0 ? a.nnz : (int64_t)a.B * a.C * a.N;
+    const int64_t idx  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * a.D) return;
+    const int64_t row = idx / a.D;
+    const uint32_t ch = (uint32_t)(idx % a.D);
+    if (a.masks && !a.masks[row]) {
+        a.colors[idx] = 0.0f;
+        return;
+    }
+    uint32_t b, c, g;
+    int64_t crow;
+    if (a.nnz >= 0) {
+        b = (uint32_t)a.batch_ids[row]; c = (uint32_t)a.camera_ids[row]; g = (uint32_t)a.gaussian_ids[row];
+        crow = a.coeffs_gathered ? row : (int64_t)g;
+    } else {
+        g = (uint32_t)(row % a.N); c = (uint32_t)((row / a.N) % a.C); b = (uint32_t)(row / ((int64_t)a.N * a.C));
+        crow = g;
+    }
+    float d[3];
+    view_dir(a, b, c, g, d);
+    const float inv = safe_inv_norm(d);
+    float Y[kMaxBases];
+    sh_bases<false>(a.degree, d[0] * inv, d[1] * inv, d[2] * inv, Y, nullptr, nullptr, nullptr);
+    const int nb    = (a.degree + 1) * (a.degree + 1);
+    const float *co = a.coeffs + ((size_t)crow * a.K) * a.D + ch;
+    float acc       = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxBases; ++k)
+        if (k < nb) acc += Y[k] * co[(size_t)k * a.D];
+    a.colors[idx] = acc;
+}
+
+// dense backward: one thread per (gaussian, channel); loops over all B*C images in registers,
+// writes v_coeffs once (no atomics). v_means (optional, zero-initialised) via atomics.
+__global__ void __launch_bounds__(256) sh_bwd_dense_kernel(const ShArgs a)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)a.N * a.D) return;
+    const uint32_t g = (uint32_t)(idx / a.D), ch = (uint32_t)(idx % a.D);
+    const int nb     = (a.degree + 1) * (a.degree + 1);
+    float vco[kMaxBases];
+#pragma unroll
+    for (int k = 0; k < kMaxBases; ++k) vco[k] = 0.0f;
+    const float *co = a.coeffs + ((size_t)g * a.K) * a.D + ch;
+
+    for (uint32_t b = 0; b < a.B; ++b)
+        for (uint32_t c = 0; c < a.C; ++c) {
+            const int64_t row = ((int64_t)b * a.C + c) * a.N + g;
+            if (a.masks && !a.masks[row]) continue;
+            const float vc = a.v_colors[row * a.D + ch];
+            float d[3];
+            view_dir(a, b, c, g, d);
+            const float inv = safe_inv_norm(d);
+            const float x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
+            if (a.v_means) {
+                float Y[kMaxBases], Yx[kMaxBases], Yy[kMaxBases], Yz[kMaxBases];
+                sh_bases<true>(a.degree, x, y, z, Y, Yx, Yy, Yz);
+                float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+                for (int k = 0; k < kMaxBases; ++k)
+                    if (k < nb) {
+                        vco[k] += Y[k] * vc;
+                        const float w = co[(size_t)k * a.D] * vc;
+                        gx += Yx[k] * w; gy += Yy[k] * w; gz += Yz[k] * w;
+                    }
+                // through the normalisation: v_d = (g - (g.n) n) / |d|
+                const float dot = gx * x + gy * y + gz * z;
+                float *vm       = a.v_means + ((size_t)b * a.N + g) * 3;
+                atomic_add_f32(vm + 0, (gx - dot * x) * inv);
+                atomic_add_f32(vm + 1, (gy - dot * y) * inv);
+                atomic_add_f32(vm + 2, (gz - dot * z) * inv);
+            } else {
+                float Y[kMaxBases];
+                sh_bases<false>(a.degree, x, y, z, Y, nullptr, nullptr, nullptr);
+#pragma unroll
+                for (int k = 0; k < kMaxBases; ++k)
+                    if (k < nb) vco[k] += Y[k] * vc;
+            }
+        }
+    float *out = a.v_coeffs + ((size_t)g * a.K) * a.D + ch;
+    for (uint32_t k = 0; k < a.K; ++k) out[(size_t)k * a.D] = ((int)k < nb) ? vco[k < kMaxBases ? k : 0] : 0.0f;
+}
+
+// packed backward: one thread per (row, channel).
+__global__ void __launch_bounds__(256) sh_bwd_packed_kernel(const ShArgs a)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.nnz * a.D) return;
+    const int64_t row = idx / a.D;
+    const uint32_t ch = (uint32_t)(idx % a.D);
+    const int nb      = (a.degree + 1) * (a.degree + 1);
+    const uint32_t b = (uint32_t)a.batch_ids[row], c = (uint32_t)a.camera_ids[row], g = (uint32_t)a.gaussian_ids[row];
+    const int64_t crow = a.coeffs_gathered ? row : (int64_t)g;
+    float *out         = a.v_coeffs + ((size_t)crow * a.K) * a.D + ch;
+    const bool masked  = a.masks && !a.masks[row];
+    if (masked) {
+        if (a.coeffs_gathered)
+            for (uint32_t k = 0; k < a.K; ++k) out[(size_t)k * a.D] = 0.0f;
+        return;
+    }
+    const float vc = a.v_colors[idx];
+    float d[3];
+    view_dir(a, b, c, g, d);
+    const float inv = safe_inv_norm(d);
+    const float x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
+    float Y[kMaxBases], Yx[kMaxBases], Yy[kMaxBases], Yz[kMaxBases];
+    if (a.v_means) sh_bases<true>(a.degree, x, y, z, Y, Yx, Yy, Yz);
+    else sh_bases<false>(a.degree, x, y, z, Y, nullptr, nullptr, nullptr);
+    if (a.coeffs_gathered) {
+        for (uint32_t k = 0; k < a.K; ++k) out[(size_t)k * a.D] = ((int)k < nb) ? Y[k < kMaxBases ? k : 0] * vc : 0.0f;
+    } else {
+        // v_coeffs [N,K,D] zero-initialised by the caller
+#pragma unroll
+        for (int k = 0; k < kMaxBases; ++k)
+            if (k < nb) {
+                if (a.atomic_coeffs) atomic_add_f32(out + (size_t)k * a.D, Y[k] * vc);
+                else out[(size_t)k * a.D] = Y[k] * vc;
+            }
+    }
+    if (a.v_means) {
+        const float *co = a.coeffs + ((size_t)crow * a.K) * a.D + ch;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int k = 0; k < kMaxBases; ++k)
+            if (k < nb) {
+                const float w = co[(size_t)k * a.D] * vc;
+                gx += Yx[k] * w; gy += Yy[k] * w; gz += Yz[k] * w;
+            }
+        const float dot = gx * x + gy * y + gz * z;
+        float *vm       = a.v_means + ((size_t)b * a.N + g) * 3;
+        atomic_add_f32(vm + 0, (gx - dot * x) * inv);
+        atomic_add_f32(vm + 1, (gy - dot * y) * inv);
+        atomic_add_f32(vm + 2, (gz - dot * z) * inv);
+    }
+}
+
+static int check_sh(const char *fn, int degree, uint32_t K, uint32_t D, const float *means, const float *viewmats,
+                    const float *coeffs, int64_t nnz, const int64_t *bi, const int64_t *ci, const int64_t *gi)
+{
+    GSX_REQUIRE(degree >= 0 && degree <= 4, "%s: degrees_to_use must be in [0,4], got %d", fn, degree);
+    GSX_REQUIRE((uint32_t)((degree + 1) * (degree + 1)) <= K, "%s: coeffs K=%u too small for degree %d", fn, K, degree);
+    GSX_REQUIRE(D >= 1, "%s: D must be >= 1", fn);
+    GSX_REQUIRE(means && viewmats && coeffs, "%s: null input", fn);
+    GSX_REQUIRE(nnz < 0 || nnz == 0 || (bi && ci && gi), "%s: packed mode needs batch/camera/gaussian ids", fn);
+    return GSX_OK;
+}
+
+} // namespace gsx
+
+using namespace gsx;
+
+extern "C" int gsx_sh_fwd(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
+                          const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
+                          const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
+                          int coeffs_gathered, uint32_t K, uint32_t D, float *colors, void *stream)
+{
+    const int64_t rows = nnz >= 0 ? nnz : (int64_t)B * C * N;
+    if (rows == 0) return GSX_OK;
+    int rc = check_sh("gsx_sh_fwd", degrees_to_use, K, D, means, viewmats, coeffs, nnz, batch_ids, camera_ids, gaussian_ids);
+    if (rc != GSX_OK) return rc;
+    GSX_REQUIRE(colors, "gsx_sh_fwd: null output");
+    ShArgs a{};
+    a.degree = degrees_to_use; a.means = means; a.viewmats = viewmats; a.coeffs = coeffs; a.masks = masks;
+    a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
+    a.B = B; a.C = C; a.N = N; a.K = K; a.D = D; a.nnz = nnz; a.coeffs_gathered = coeffs_gathered; a.colors = colors;
+    sh_fwd_kernel<<<dim3((uint32_t)ceil_div(rows * D, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    return check_launch("sh_fwd");
+}
+
+extern "C" int gsx_sh_bwd(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
+                          const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
+                          const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
+                          int coeffs_gathered, uint32_t K, uint32_t D, const float *v_colors, float *v_coeffs,
+                          float *v_means, void *stream)
+{
+    int rc = check_sh("gsx_sh_bwd", degrees_to_use, K, D, means, viewmats, coeffs, nnz, batch_ids, camera_ids, gaussian_ids);
+    if (rc != GSX_OK) return rc;
+    GSX_REQUIRE(v_coeffs, "gsx_sh_bwd: null v_coeffs");
+    ShArgs a{};
+    a.degree = degrees_to_use; a.means = means; a.viewmats = viewmats; a.coeffs = coeffs; a.masks = masks;
+    a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
+    a.B = B; a.C = C; a.N = N; a.K = K; a.D = D; a.nnz = nnz; a.coeffs_gathered = coeffs_gathered;
+    a.v_colors = v_colors; a.v_coeffs = v_coeffs; a.v_means = v_means;
+    a.atomic_coeffs = (B * C) > 1;
+    if (nnz < 0) {
+        if ((int64_t)N * D == 0) return GSX_OK;
+        GSX_REQUIRE(v_colors || (int64_t)B * C == 0, "gsx_sh_bwd: null v_colors");
+        sh_bwd_dense_kernel<<<dim3((uint32_t)ceil_div((int64_t)N * D, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    } else {
+        if (nnz == 0) return GSX_OK;
+        GSX_REQUIRE(v_colors, "gsx_sh_bwd: null v_colors");
+        sh_bwd_packed_kernel<<<dim3((uint32_t)ceil_div(nnz * D, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    }
+    return check_launch("sh_bwd");
+}

@@ -1,0 +1,207 @@
+/* gsplat_amd — C ABI of the MI355X (gfx950) Gaussian-rasterization hot path.
+ *
+ * This is the drop-in boundary: one entry point per kernel-level stage of
+ * gsplat.rasterization() / rasterization_2dgs(). Every function
+ *   - takes raw DEVICE pointers, extents and a hipStream_t (as void*) — no torch types;
+ *   - never allocates, frees or synchronises: outputs and workspaces are caller-owned
+ *     (query sizes with the *_workspace_bytes functions);
+ *   - is re-entrant (no global mutable state; safe from autograd worker threads);
+ *   - returns 0 on success, a negative GSX_ERR_* code otherwise; gsx_last_error() gives the
+ *     message (thread local). The torch shim (gsplat_amd/_ops.py) turns codes into
+ *     RuntimeError / ValueError exactly where the reference raises them.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the
+ * reference checkout, nerfstudio-project/gsplat 1.6.0). The torch-side binding a gsplat
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Layout conventions (identical to the reference ops): all float tensors fp32, contiguous,
+ * row-major; "rows" R means [I*N] (dense, I = B*C images) or [nnz] (packed); bool tensors are
+ * 1 byte per element (torch.bool).
+ */
+#ifndef GSPLAT_AMD_H_
+#define GSPLAT_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSX_ABI_VERSION 1
+
+#define GSX_OK 0
+#define GSX_ERR_ARG (-1)       /* bad argument: maps to ValueError/RuntimeError in the shim */
+#define GSX_ERR_LAUNCH (-2)    /* HIP launch/runtime failure */
+#define GSX_ERR_WORKSPACE (-3) /* workspace too small */
+#define GSX_ERR_OVERFLOW (-4)  /* key width / index overflow (Intersect.cpp:219-228) */
+
+/* camera models — values of _C.CameraModelType (gsplat/cuda/include/Common.h:75-82) */
+#define GSX_CAMERA_PINHOLE 0
+#define GSX_CAMERA_ORTHO 1
+#define GSX_CAMERA_FISHEYE 2
+
+const char *gsx_last_error(void);
+int gsx_version(void);
+const char *gsx_arch(void); /* "gfx950" */
+
+/* ---------------------------------------------------------------------------------------------
+ * quat_scale_to_covar_preci{,_bwd}
+ * replaces torch ops gsplat::quat_scale_to_covar_preci{,_bwd} (gsplat/cuda/ext.cpp:984-991;
+ * host gsplat/cuda/csrc/QuatScaleToCovar.cpp; device math include/Utils.cuh:228-347).
+ * quats [n,4] (wxyz, normalised inside), scales [n,3]. Outputs [n,3,3] or, if triu, [n,6] in
+ * order (00,01,02,11,12,22). Any of covars/precis may be NULL.
+ * bwd: v_covars / v_precis same layout as the forward output (either may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+int gsx_quat_scale_to_covar_fwd(const float *quats, const float *scales, int64_t n, int triu,
+                                float *covars, float *precis, void *stream);
+int gsx_quat_scale_to_covar_bwd(const float *quats, const float *scales, int64_t n, int triu,
+                                const float *v_covars, const float *v_precis,
+                                float *v_quats, float *v_scales, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fully_fused_projection (dense): gsplat::projection_ewa_3dgs_fused{,_bwd}
+ * (ext.cpp:1052-1063; host Projection.cpp:366-440, 579-694; kernels
+ * ProjectionEWA3DGSFused.cu:38-219, 378-638).
+ * means [B,N,3]; covars [B,N,6] XOR (quats [B,N,4] + scales [B,N,3]); opacities [B,N] or NULL;
+ * viewmats [B,C,4,4]; Ks [B,C,3,3]. Outputs: radii int32 [B,C,N,2]; means2d [B,C,N,2];
+ * depths [B,C,N]; conics [B,C,N,3]; compensations [B,C,N] or NULL. Culled rows get radii=(0,0)
+ * and ZEROS in the other outputs (the reference leaves them uninitialised).
+ * bwd outputs are fully written (no pre-zeroing needed) except v_viewmats which must be
+ * zero-initialised when non-NULL: v_means [B,N,3], v_covars [B,N,6] | (v_quats [B,N,4],
+ * v_scales [B,N,3]), v_viewmats [B,C,4,4] or NULL.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_project_ewa_fwd(const float *means, const float *covars, const float *quats, const float *scales,
+                        const float *opacities, const float *viewmats, const float *Ks,
+                        uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                        float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
+                        int32_t *radii, float *means2d, float *depths, float *conics, float *compensations,
+                        void *stream);
+int gsx_project_ewa_bwd(const float *means, const float *covars, const float *quats, const float *scales,
+                        const float *viewmats, const float *Ks,
+                        uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                        float eps2d, int camera_model,
+                        const int32_t *radii, const float *conics, const float *compensations,
+                        const float *v_means2d, const float *v_depths, const float *v_conics,
+                        const float *v_compensations,
+                        float *v_means, float *v_covars, float *v_quats, float *v_scales, float *v_viewmats,
+                        void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fully_fused_projection (packed): gsplat::projection_ewa_3dgs_packed{,_bwd}
+ * (ext.cpp:1065-1077; host Projection.cpp:858-1215; kernels ProjectionEWA3DGSPacked.cu).
+ * Two-step protocol, allocation stays with the caller:
+ *   1. gsx_project_ewa_packed_count: visible[B*C*N] int32 (1/0) for every (image, gaussian);
+ *      caller runs gsx_scan_i32 over it (inclusive cumsum) and reads the total nnz = cum[last];
+ *   2. gsx_project_ewa_packed_write: compacts rows in (batch, camera, gaussian) order into
+ *      batch_ids/camera_ids/gaussian_ids int64 [nnz], indptr int32 [B*C+1], radii int32 [nnz,2],
+ *      means2d [nnz,2], depths [nnz], conics [nnz,3], compensations [nnz] or NULL.
+ * bwd accumulates with atomics: v_means/v_covars/v_quats/v_scales/v_viewmats must be zeroed.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_project_ewa_packed_count(const float *means, const float *covars, const float *quats, const float *scales,
+                                 const float *opacities, const float *viewmats, const float *Ks,
+                                 uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                                 float eps2d, float near_plane, float far_plane, float radius_clip,
+                                 int camera_model, int calc_compensations, int32_t *visible, void *stream);
+int gsx_project_ewa_packed_write(const float *means, const float *covars, const float *quats, const float *scales,
+                                 const float *opacities, const float *viewmats, const float *Ks,
+                                 uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                                 float eps2d, float near_plane, float far_plane, float radius_clip,
+                                 int camera_model, const int64_t *row_offsets /* INCLUSIVE cumsum of visible (gsx_scan_i32) */,
+                                 int64_t nnz,
+                                 int64_t *batch_ids, int64_t *camera_ids, int64_t *gaussian_ids, int32_t *indptr,
+                                 int32_t *radii, float *means2d, float *depths, float *conics,
+                                 float *compensations, void *stream);
+int gsx_project_ewa_packed_bwd(const float *means, const float *covars, const float *quats, const float *scales,
+                               const float *viewmats, const float *Ks,
+                               uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                               float eps2d, int camera_model, int64_t nnz,
+                               const int64_t *batch_ids, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                               const float *conics, const float *compensations,
+                               const float *v_means2d, const float *v_depths, const float *v_conics,
+                               const float *v_compensations,
+                               float *v_means, float *v_covars, float *v_quats, float *v_scales,
+                               float *v_viewmats, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * spherical_harmonics{,_bwd}: gsplat::spherical_harmonics{,_bwd} (ext.cpp:994-1002; host
+ * SphericalHarmonics.cpp; kernels SphericalHarmonicsCUDA.cu:444-569, 786-890).
+ * dir = mean - camera centre (centre = -R^T t from viewmats), normalised; Sloan basis, deg <= 4.
+ * Dense (nnz < 0): means [B,N,3], viewmats [B,C,4,4], coeffs [N,K,D] shared by all images,
+ *        masks bool [B,C,N] or NULL, colors [B,C,N,D].
+ * Packed (nnz >= 0): batch/camera/gaussian ids int64 [nnz], masks bool [nnz] or NULL,
+ *        colors [nnz,D]; coeffs_gathered=1: coeffs is [nnz,K,D] (pre-gathered by the caller, the
+ *        reference contract); coeffs_gathered=0: coeffs is [N,K,D] and is indexed through
+ *        gaussian_ids inside the kernel (saves the 4*K*D B/row gather copy; used by our
+ *        rasterization() orchestrator).
+ * Masked rows are written as zeros. bwd: v_coeffs has the shape of coeffs; it is fully written
+ * except in packed+ungathered mode, where it must be ZEROED by the caller. v_means [B,N,3] or
+ * NULL, must be ZEROED by the caller (accumulated with atomics).
+ * ------------------------------------------------------------------------------------------- */
+int gsx_sh_fwd(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
+               const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
+               const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz /* <0: dense */,
+               int coeffs_gathered, uint32_t K, uint32_t D, float *colors, void *stream);
+int gsx_sh_bwd(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
+               const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
+               const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
+               int coeffs_gathered, uint32_t K, uint32_t D, const float *v_colors, float *v_coeffs,
+               float *v_means, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * isect_tiles: gsplat::intersect_tile (ext.cpp:1022-1026; host Intersect.cpp:170-329; kernel
+ * IntersectTile.cu:214-464) split into its stages so that allocation stays with the caller:
+ *   gsx_isect_count  -> tiles_per_gauss int32 [R]
+ *   gsx_scan_i32     -> cum int64 [R] (INCLUSIVE prefix sum, like the reference's cumsum);
+ *                       total = cum[R-1]
+ *   gsx_isect_emit   -> isect_ids int64 [M], flatten_ids int32 [M] (unsorted)
+ *   gsx_sort_pairs   -> stable LSD radix sort on key bits [0, end_bit)
+ *   gsx_isect_offsets-> gsplat::intersect_offset (ext.cpp:1027; IntersectTile.cu:925-988)
+ * conics+opacities non-NULL selects the exact ellipse/tile test (AccuTile/SNUGBOX), else AABB.
+ * image_ids (int64 [R]) non-NULL = packed rows. Keys: image << (32+tile_bits) | tile << 32 |
+ * bits(float depth).
+ * ------------------------------------------------------------------------------------------- */
+int gsx_isect_count(const float *means2d, const int32_t *radii, const float *conics, const float *opacities,
+                    const int64_t *image_ids, int64_t rows, uint32_t n_per_image, uint32_t n_images,
+                    uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int32_t *tiles_per_gauss, void *stream);
+int gsx_isect_emit(const float *means2d, const int32_t *radii, const float *depths, const float *conics,
+                   const float *opacities, const int64_t *image_ids, const int64_t *cum_tiles_per_gauss,
+                   int64_t rows, uint32_t n_per_image, uint32_t n_images,
+                   uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                   int64_t *isect_ids, int32_t *flatten_ids, void *stream);
+int64_t gsx_scan_workspace_bytes(int64_t n);
+int gsx_scan_i32(const int32_t *in, int64_t n, int64_t *out_inclusive, void *workspace, int64_t workspace_bytes,
+                 void *stream);
+int64_t gsx_sort_pairs_workspace_bytes(int64_t n);
+/* Sorts (keys, vals) by key bits [0,end_bit). keys_alt/vals_alt are ping-pong buffers of the same size.
+ * On return *result_in_alt tells whether the sorted data is in the alt buffers (1) or the primary (0). */
+int gsx_sort_pairs(int64_t *keys, int32_t *vals, int64_t *keys_alt, int32_t *vals_alt, int64_t n, int end_bit,
+                   void *workspace, int64_t workspace_bytes, int *result_in_alt, void *stream);
+int gsx_isect_offsets(const int64_t *isect_ids_sorted, int64_t n_isects, uint32_t n_images, uint32_t tile_w,
+                      uint32_t tile_h, int32_t *offsets /* [I,tile_h,tile_w] */, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * rasterize_to_pixels (3DGS): gsplat::rasterize_to_pixels_3dgs{,_bwd} (ext.cpp:1079-1089; host
+ * Rasterization.cpp:275-365, 484-587; kernels RasterizeToPixels3DGSSerialBatch{Fwd,Bwd}.cu).
+ * Any channel count >= 1 (chunked by 32 internally); tile_size in [1,16].
+ * fwd outputs: render_colors [I,H,W,cdim], render_alphas [I,H,W,1], last_ids int32 [I,H,W].
+ * bwd: gradient outputs must be ZERO-initialised; v_means2d_abs may be NULL (absgrad off).
+ * v_backgrounds is a torch-side reduction in the reference (Rasterization.cpp:567-577) and in the shim.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_raster3d_fwd(const float *means2d, const float *conics, const float *colors, const float *opacities,
+                     const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                     const int32_t *flatten_ids, uint32_t n_images, uint32_t n_isects, uint32_t cdim,
+                     uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                     float *render_colors, float *render_alphas, int32_t *last_ids, void *stream);
+int gsx_raster3d_bwd(const float *means2d, const float *conics, const float *colors, const float *opacities,
+                     const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                     const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,
+                     const float *v_render_colors, const float *v_render_alphas,
+                     uint32_t n_images, uint32_t n_isects, uint32_t cdim,
+                     uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                     float *v_means2d_abs, float *v_means2d, float *v_conics, float *v_colors, float *v_opacities,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_AMD_H_ */
