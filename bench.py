@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the hot path: gsplat_amd.rasterization() forward + backward.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run,
+one rank per GPU over RCCL. A step = one fwd+bwd pass of rasterization() over one batch of synthetic input
+already resident in HBM. Rank 0 prints ONE JSON line.
+
+Workload at N=1 = BASELINE.json configs[2] ("c3"): 1 M synthetic Gaussians, one 1920x1080 pinhole camera,
+SH degree 3, 16x16 tiles, fwd+bwd, loss = render_colors.sum() (reference harness profiling/main.py:132-149).
+Workload at N>1 = configs[3] ("c4") shape: Gaussian-sharded distributed rasterization, 500 k Gaussians and
+4 cameras PER RANK (weak scaling: per-GPU projection work fixed; every rank composites its own 4 cameras over
+all N*500k Gaussians), all-gather cameras + all-to-all projected Gaussians (gsplat_amd/distributed.py).
+
+metric = Mpixels/s fwd+bwd = (images * H * W * steps) / wall time, whole job.
+roofline  = dominant kernel (the compositing backward) priced against HBM: algorithmic bytes per launch
+             / its mean launch duration measured live with HIP events on the launch stream.
+cpu_baseline = the CPU oracle pipeline (oracle/pipeline.py, OpenMP C + torch-CPU) on the same workload, rank 0, N=1.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, TILE = 1920, 1080, 16
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+FP32_PEAK_TFLOPS = 157.3
+
+
+def make_workload(n_gaussians: int, device, n_cameras: int = 1, seed: int = 0, rank: int = 0, world: int = 1):
+    """means uniform in a frustum-filling box z in [1, 20]; log-scales ~ N(log 0.01, 0.5)
+    (clipped); opacities U(0.05, 0.95); SH degree-3 coefficients N(0, 0.3) (+0.5 DC); cameras 1920x1080, f=1200.
+    With world > 1 every rank draws its own shard (seed + rank) of the same distribution."""
+    g = torch.Generator().manual_seed(seed + 7919 * rank)
+    fx = 1200.0
+    z = torch.rand(n_gaussians, generator=g) * 19.0 + 1.0
+    x = (torch.rand(n_gaussians, generator=g) - 0.5) * (WIDTH / fx) * z * 1.05
+    y = (torch.rand(n_gaussians, generator=g) - 0.5) * (HEIGHT / fx) * z * 1.05
+    means = torch.stack([x, y, z], -1)
+    quats = torch.nn.functional.normalize(torch.randn(n_gaussians, 4, generator=g), dim=-1)
+    log_s = math.log(0.01) + 0.5 * torch.randn(n_gaussians, 3, generator=g)
+    scales = torch.exp(log_s.clamp(math.log(0.002), math.log(0.05)))
+    opacities = torch.rand(n_gaussians, generator=g) * 0.9 + 0.05
+    colors = torch.randn(n_gaussians, 16, 3, generator=g) * 0.3
+    colors[:, 0, :] += 0.5
+    viewmats = torch.eye(4).repeat(n_cameras, 1, 1)
+    cam_g = torch.Generator().manual_seed(seed + 13 * rank)
+    for c in range(n_cameras):  # small yaw / shift per camera so views differ
+        ang = 0.02 * (c + n_cameras * rank)
+        viewmats[c, 0, 0] = math.cos(ang); viewmats[c, 0, 2] = math.sin(ang)
+        viewmats[c, 2, 0] = -math.sin(ang); viewmats[c, 2, 2] = math.cos(ang)
+        viewmats[c, 0, 3] = 0.05 * (c + n_cameras * rank)
+    Ks = torch.tensor([[fx, 0, WIDTH / 2], [0, fx, HEIGHT / 2], [0, 0, 1.0]]).repeat(n_cameras, 1, 1)
+    sc = dict(means=means, quats=quats, scales=scales, opacities=opacities, colors=colors, viewmats=viewmats, Ks=Ks)
+    return {k: v.to(device).contiguous() for k, v in sc.items()}, WIDTH, HEIGHT
+
+
+def algorithmic_bytes(M, V, P, T, D):
+    """SURVEY.md §8(d), fp32, compulsory traffic only."""
+    fwd = (28 + 4 * D) * M + 4 * T + (4 * D + 8) * P
+    bwd = (28 + 4 * D) * M + (4 * D + 12) * P + 2 * (4 * D + 24) * V
+    return fwd, bwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=None, help="Gaussians per rank (default 1M at N=1, 500k at N>1)")
+    ap.add_argument("--cameras", type=int, default=None, help="cameras per rank (default 1 at N=1, 4 at N>1)")
+    ap.add_argument("--dense", action="store_true", help="packed=False (default packed=True like the reference)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+    n_gpus = world if distributed else 1
+    assert args.gpus == n_gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import gsplat_amd
+    from gsplat_amd import _cabi
+
+    n_local = args.gaussians or (500_000 if distributed else 1_000_000)
+    n_cams = args.cameras or (4 if distributed else 1)
+    sc, W, H = make_workload(n_local, device, n_cameras=n_cams, rank=rank, world=world)
+    names = ("means", "quats", "scales", "opacities", "colors")
+    leaves = {k: sc[k].clone().requires_grad_(True) for k in names}
+    packed = not args.dense
+
+    def step():
+        for t in leaves.values():
+            t.grad = None
+        rc, ra, meta = gsplat_amd.rasterization(
+            leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"], sc["viewmats"],
+            sc["Ks"], W, H, sh_degree=3, packed=packed, tile_size=TILE, distributed=distributed)
+        rc.sum().backward()
+        return meta
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        meta = step()
+    barrier()
+    _cabi.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        meta = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _cabi.profile_end()
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    images = n_cams * n_gpus
+    pixels = images * W * H
+    mpix_s = pixels * args.steps / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel (rank 0's launches) -------------------------------------
+    M = int(meta["isect_ids"].numel())
+    V = int((meta["radii"] > 0).all(-1).sum().item()) if not distributed else M  # rows entering compositing
+    P_local = n_cams * W * H
+    T_local = n_cams * math.ceil(W / TILE) * math.ceil(H / TILE)
+    D = 3
+    b_fwd, b_bwd = algorithmic_bytes(M, V, P_local, T_local, D)
+    mean_ms = {k: sum(v) / len(v) for k, v in prof.items()}
+    per_step_ms = {k: sum(v) / args.steps for k, v in prof.items()}
+    t_fwd = mean_ms.get("gsx_raster3d_fwd", float("nan"))
+    t_bwd = mean_ms.get("gsx_raster3d_bwd", float("nan"))
+    dom, dom_bytes, dom_ms = ("raster3d_bwd", b_bwd, t_bwd) if not (t_fwd > t_bwd) else ("raster3d_fwd", b_fwd, t_fwd)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "algorithmic_bytes_per_launch": int(dom_bytes), "launch_ms": round(dom_ms, 4),
+        "n_isects": M, "rows": V, "pixels_per_launch": P_local,
+        "note": "compositing is VALU/exp/atomic-bound, not HBM-bound (SURVEY.md 8(d)); see DESIGN.md",
+    }
+
+    result = {
+        "metric": "Mpixels/s fwd+bwd @1M Gaussians/1080p" if not distributed else
+                  "Mpixels/s fwd+bwd, Gaussian-sharded 500k Gaussians + 4x1080p cameras per GPU",
+        "value": round(mpix_s, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("c3: 1M synthetic Gaussians, 1x1920x1080, SH deg 3, 16x16 tiles, fwd+bwd"
+                                if not distributed else
+                                f"c4-shape: {n_local} Gaussians + {n_cams}x1920x1080 cameras per rank, SH deg 3, "
+                                "distributed=True (all-gather cameras + all-to-all projected Gaussians)"),
+                   "gaussians_per_gpu": n_local, "cameras_per_gpu": n_cams, "packed": packed,
+                   "parallelism": f"gaussian-sharded x{n_gpus}" if distributed else "single"},
+        "roofline": roofline,
+        "stage_ms_per_step": {k.replace("gsx_", ""): round(v, 4) for k, v in sorted(per_step_ms.items())},
+    }
+
+    # ---- CPU baseline (rank 0, N=1): the oracle pipeline on the same workload ---------------------
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        from oracle.pipeline import rasterization_cpu
+
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        cs = {k: v.detach().cpu() for k, v in sc.items()}
+        ref = rasterization_cpu(cs["means"], cs["quats"], cs["scales"], cs["opacities"], cs["colors"], cs["viewmats"],
+                                cs["Ks"], W, H, sh_degree=3, render_mode="RGB")
+        t_cpu = ref["t_fwd"] + ref["t_bwd"]
+        result["cpu_baseline"] = {
+            "value": round(n_cams * W * H / t_cpu / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "1 full fwd+bwd step of the same 1M-Gaussian/1080p workload (oracle/pipeline.py: OpenMP C "
+                      "compositing + torch-CPU projection/SH)",
+            "t_fwd_s": round(ref["t_fwd"], 3), "t_bwd_s": round(ref["t_bwd"], 3), "n_isects": ref["n_isects"],
+        }
+    if rank == 0:
+        print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

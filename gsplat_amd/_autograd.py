@@ -1,0 +1,175 @@
+"""Autograd for the torch.ops.gsplat.* stage ops.
+
+The reference attaches autograd to its C++ ops from Python with
+``torch.library.register_autograd`` (``gsplat/cuda/_wrapper.py:74-111``, one ``Register*`` class
+per op). This module does the same for the ops defined in ``_ops.py``, with the same saved-tensor
+and ``needs_input_grad`` contract, so that the ``*_bwd`` ops see the argument order fixed by the
+reference (e.g. raster ``_wrapper.py:2078-2098``, projection ``:1022-1045``).
+
+When this package is used as a drop-in ``gsplat.csrc`` under the reference's own Python
+(INTEGRATION.md), the reference's ``_wrapper.py`` performs the registration instead and this
+module is not imported.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _ops  # noqa: F401  (defines the ops)
+
+NS = _ops.NS
+_registered = False
+
+
+def _bwd(name):
+    return getattr(torch.ops.gsplat, name + "_bwd")
+
+
+# ---- quat_scale_to_covar_preci (reference _wrapper.py:719-760) ----------------------------------
+def _qs_setup(ctx, inputs, output):
+    quats, scales, compute_covar, compute_preci, triu = inputs
+    ctx.triu = triu
+    ctx.save_for_backward(quats, scales)
+
+
+def _qs_backward(ctx, v_covars, v_precis):
+    quats, scales = ctx.saved_tensors
+    if v_covars is not None and v_covars.is_sparse:
+        v_covars = v_covars.to_dense()
+    if v_precis is not None and v_precis.is_sparse:
+        v_precis = v_precis.to_dense()
+    v_quats, v_scales = _bwd("quat_scale_to_covar_preci")(
+        quats, scales, ctx.triu,
+        None if v_covars is None else v_covars.contiguous(),
+        None if v_precis is None else v_precis.contiguous(),
+    )
+    return v_quats, v_scales, None, None, None
+
+
+# ---- spherical_harmonics (reference _wrapper.py:553-632) ----------------------------------------
+def _sh_setup(ctx, inputs, output):
+    (degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, viewmats_rs) = inputs
+    ctx.degrees_to_use = degrees_to_use
+    ctx.save_for_backward(means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, viewmats_rs)
+
+
+def _sh_backward(ctx, v_colors):
+    means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, viewmats_rs = ctx.saved_tensors
+    v_coeffs, v_means, v_viewmats, v_viewmats_rs = _bwd("spherical_harmonics")(
+        ctx.degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, viewmats_rs,
+        v_colors.contiguous(), ctx.needs_input_grad[1], ctx.needs_input_grad[2],
+        len(ctx.needs_input_grad) > 8 and ctx.needs_input_grad[8],
+    )
+    return (None, v_means, v_viewmats, v_coeffs, None, None, None, None, v_viewmats_rs)
+
+
+# ---- projection, dense (reference _wrapper.py:966-1062) -----------------------------------------
+def _proj_setup(ctx, inputs, output):
+    (means, covars, quats, scales, _opacities, viewmats, Ks, width, height, eps2d, _near, _far, _clip, _calc,
+     camera_model) = inputs
+    radii, _means2d, _depths, conics, compensations = output
+    ctx.width, ctx.height, ctx.eps2d, ctx.camera_model = width, height, eps2d, camera_model
+    ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, radii, conics, compensations)
+
+
+def _proj_backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_compensations):
+    means, covars, quats, scales, viewmats, Ks, radii, conics, compensations = ctx.saved_tensors
+    if v_compensations is not None:
+        v_compensations = v_compensations.contiguous()
+    v_means, v_covars, v_quats, v_scales, v_viewmats = _bwd("projection_ewa_3dgs_fused")(
+        means, covars, quats, scales, viewmats, Ks, ctx.width, ctx.height, ctx.eps2d, ctx.camera_model, radii, conics,
+        compensations, v_means2d.contiguous(), v_depths.contiguous(), v_conics.contiguous(), v_compensations,
+        ctx.needs_input_grad[5],
+    )
+    if not ctx.needs_input_grad[0]:
+        v_means = None
+    if not ctx.needs_input_grad[1]:
+        v_covars = None
+    if not ctx.needs_input_grad[2]:
+        v_quats = None
+    if not ctx.needs_input_grad[3]:
+        v_scales = None
+    return (v_means, v_covars, v_quats, v_scales, None, v_viewmats) + (None,) * 9
+
+
+# ---- projection, packed (reference _wrapper.py:1065-1191) ---------------------------------------
+def _projp_setup(ctx, inputs, output):
+    (means, covars, quats, scales, _opacities, viewmats, Ks, width, height, eps2d, _near, _far, _clip, sparse_grad,
+     _calc, camera_model) = inputs
+    (batch_ids, camera_ids, gaussian_ids, _indptr, _radii, _means2d, _depths, conics, compensations) = output
+    ctx.width, ctx.height, ctx.eps2d, ctx.camera_model, ctx.sparse_grad = width, height, eps2d, camera_model, sparse_grad
+    ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, batch_ids, camera_ids, gaussian_ids, conics,
+                          compensations)
+
+
+def _projp_backward(ctx, v_batch_ids, v_camera_ids, v_gaussian_ids, v_indptr, v_radii, v_means2d, v_depths, v_conics,
+                    v_compensations):
+    (means, covars, quats, scales, viewmats, Ks, batch_ids, camera_ids, gaussian_ids, conics,
+     compensations) = ctx.saved_tensors
+    if v_compensations is not None:
+        v_compensations = v_compensations.contiguous()
+    v_means, v_covars, v_quats, v_scales, v_viewmats = _bwd("projection_ewa_3dgs_packed")(
+        means, covars, quats, scales, viewmats, Ks, ctx.width, ctx.height, ctx.eps2d, ctx.camera_model,
+        ctx.sparse_grad, batch_ids, camera_ids, gaussian_ids, conics, compensations, v_means2d.contiguous(),
+        v_depths.contiguous(), v_conics.contiguous(), v_compensations, ctx.needs_input_grad[5],
+    )
+    if not ctx.needs_input_grad[0]:
+        v_means = None
+    if not ctx.needs_input_grad[1]:
+        v_covars = None
+    if not ctx.needs_input_grad[2]:
+        v_quats = None
+    if not ctx.needs_input_grad[3]:
+        v_scales = None
+    return (v_means, v_covars, v_quats, v_scales, None, v_viewmats) + (None,) * 10
+
+
+# ---- rasterize_to_pixels (reference _wrapper.py:2010-2117) --------------------------------------
+def _rast_setup(ctx, inputs, output):
+    (means2d, conics, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, isect_offsets,
+     flatten_ids, _packed, absgrad) = inputs
+    _render_colors, render_alphas, means2d_absgrad, last_ids = output
+    ctx.mark_non_differentiable(last_ids, means2d_absgrad)
+    ctx.width, ctx.height, ctx.tile_size, ctx.absgrad = image_width, image_height, tile_size, absgrad
+    ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids,
+                          render_alphas, last_ids, means2d_absgrad)
+
+
+def _rast_backward(ctx, v_render_colors, v_render_alphas, v_means2d_absgrad, v_last_ids):
+    (means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas, last_ids,
+     means2d_absgrad) = ctx.saved_tensors
+    v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities, v_backgrounds = _bwd("rasterize_to_pixels_3dgs")(
+        means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas, last_ids,
+        ctx.width, ctx.height, ctx.tile_size, ctx.absgrad, v_render_colors.contiguous(), v_render_alphas.contiguous(),
+        ctx.needs_input_grad[4],
+    )
+    if ctx.absgrad and v_means2d_abs is not None:
+        means2d_absgrad.copy_(v_means2d_abs)
+    return (v_means2d, v_conics, v_colors, v_opacities, v_backgrounds) + (None,) * 8
+
+
+_TABLE = {
+    "quat_scale_to_covar_preci": (_qs_backward, _qs_setup),
+    "spherical_harmonics": (_sh_backward, _sh_setup),
+    "projection_ewa_3dgs_fused": (_proj_backward, _proj_setup),
+    "projection_ewa_3dgs_packed": (_projp_backward, _projp_setup),
+    "rasterize_to_pixels_3dgs": (_rast_backward, _rast_setup),
+}
+
+
+def register(extra=None) -> None:
+    global _registered
+    if _registered:
+        return
+    table = dict(_TABLE)
+    if extra:
+        table.update(extra)
+    for name, (bwd, setup) in table.items():
+        try:
+            torch.library.register_autograd(f"{NS}::{name}", bwd, setup_context=setup)
+        except RuntimeError as e:  # already registered by the reference's _wrapper.py in this process
+            if "already" not in str(e).lower():
+                raise
+    _registered = True
+
+
+register()

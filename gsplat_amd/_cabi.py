@@ -1,0 +1,168 @@
+"""ctypes binding of the C-ABI in include/gsplat_amd.h (libgsplat_amd.so).
+
+This is the only place that crosses from Python into native code. There is NO CPU fallback:
+if the shared library is missing the import fails loudly, and every call targets HIP kernels
+on the current device/stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_ENV = "GSPLAT_AMD_LIB"  # optional override of the library path (e.g. a debug build)
+
+
+class GsplatAmdError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.environ.get(_LIB_ENV) or os.path.join(_HERE, "csrc", "libgsplat_amd.so")
+
+
+def _load() -> ctypes.CDLL:
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"gsplat_amd: native library not found at {path}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C gsplat_amd/csrc` "
+            "(hipcc, --offload-arch=gfx950). There is no CPU fallback."
+        )
+    return ctypes.CDLL(path)
+
+
+_lib = _load()
+
+# signature table: p = pointer (device pointer or NULL), u = uint32, i = int, l = int64, f = float
+_P, _U, _I, _L, _F = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_CODES = {"p": _P, "u": _U, "i": _I, "l": _L, "f": _F}
+
+_HEADER = os.path.join(os.path.dirname(_HERE), "include", "gsplat_amd.h")
+
+
+def _parse_header(path: str):
+    """Derive the ctypes signatures from include/gsplat_amd.h so that the header stays the single
+    source of truth. Returns {name: (restype_code, [arg codes])} for every `gsx_*` prototype."""
+    import re
+
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"\b(int64_t|int|const char \*)\s*(gsx_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        codes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    codes.append("p")
+                elif a.startswith("uint32_t"):
+                    codes.append("u")
+                elif a.startswith("int64_t"):
+                    codes.append("l")
+                elif a.startswith("float"):
+                    codes.append("f")
+                elif a.startswith("int "):
+                    codes.append("i")
+                else:
+                    raise ImportError(f"gsplat_amd: cannot parse argument '{a}' of {name} in {path}")
+        sigs[name] = ({"int": "i", "int64_t": "l"}.get(ret, "s"), codes)
+    return sigs
+
+
+SIGNATURES = _parse_header(_HEADER)
+
+
+def _bind():
+    for name, (ret, codes) in SIGNATURES.items():
+        fn = getattr(_lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = {"i": ctypes.c_int, "l": _L, "s": ctypes.c_char_p}[ret]
+        fn.argtypes = [_CODES[c] for c in codes]
+
+
+_bind()
+
+ABI_VERSION = _lib.gsx_version()
+ARCH = _lib.gsx_arch().decode()
+
+
+def exported_symbols():
+    return list(SIGNATURES)
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a tensor (None -> NULL). The tensor must be contiguous and on the GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise GsplatAmdError(
+            "gsplat_amd kernels only run on a ROCm device (got a CPU tensor); there is no CPU fallback"
+        )
+    if not t.is_contiguous():
+        raise GsplatAmdError("gsplat_amd: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+_profile = None  # list of (entry point, start event, end event) while profiling is on
+
+
+def profile_begin() -> None:
+    """Start recording a HIP-event pair around every gsx_* call (events go on the stream the kernels are
+    launched on: torch's current stream). Used by bench.py for per-kernel durations."""
+    global _profile
+    _profile = []
+
+
+def profile_end() -> dict:
+    """Stop recording; returns {entry point: [ms per call, ...]} (synchronises the device)."""
+    global _profile
+    rec, _profile = _profile or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for name, a, b in rec:
+        out.setdefault(name, []).append(a.elapsed_time(b))
+    return out
+
+
+def call(name: str, *args) -> None:
+    """Invoke a gsx_* entry point on the current stream; raise on a non-zero return code."""
+    fn = getattr(_lib, name)
+    if _profile is not None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args, current_stream())
+        b.record()
+        _profile.append((name, a, b))
+    else:
+        rc = fn(*args, current_stream())
+    if rc != 0:
+        msg = _lib.gsx_last_error().decode(errors="replace")
+        if rc == -1:
+            raise ValueError(f"{name}: {msg}")
+        raise GsplatAmdError(f"{name} failed (code {rc}): {msg}")
+
+
+def scan_workspace_bytes(n: int) -> int:
+    return int(_lib.gsx_scan_workspace_bytes(n))
+
+
+def sort_workspace_bytes(n: int) -> int:
+    return int(_lib.gsx_sort_pairs_workspace_bytes(n))
+
+
+def sort_pairs(keys, vals, keys_alt, vals_alt, n: int, end_bit: int, workspace) -> bool:
+    """Returns True when the sorted data ended up in the alt buffers."""
+    flag = ctypes.c_int(0)
+    rc = _lib.gsx_sort_pairs(ptr(keys), ptr(vals), ptr(keys_alt), ptr(vals_alt), n, end_bit, ptr(workspace),
+                             workspace.numel() * workspace.element_size(), ctypes.addressof(flag), current_stream())
+    if rc != 0:
+        raise GsplatAmdError(f"gsx_sort_pairs failed (code {rc}): {_lib.gsx_last_error().decode(errors='replace')}")
+    return bool(flag.value)

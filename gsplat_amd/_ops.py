@@ -1,0 +1,459 @@
+"""torch.ops.gsplat.* — the reference's dispatcher boundary, implemented on the MI355X C-ABI.
+
+Importing this module defines the reference's operator schemas (verbatim from
+``gsplat/cuda/ext.cpp:983-1213`` for the ops on the hot path) in the ``gsplat`` namespace and
+registers implementations for the ``CUDA`` dispatch key (HIP tensors carry that key on ROCm).
+Each implementation owns what the reference's C++ host op owns — shape checks, output
+allocation from the caching allocator, stream lookup, error translation — and hands raw device
+pointers to ``libgsplat_amd.so`` (``include/gsplat_amd.h``). Autograd is attached separately
+(``_autograd.py``), mirroring the reference's split between ``ext.cpp`` and ``_wrapper.py``.
+
+There is no CPU implementation: calling these ops with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _cabi
+from ._cabi import call, ptr
+
+NS = "gsplat"
+
+# If the reference's own extension is already loaded in this process, its TORCH_LIBRARY owns the
+# namespace; we then FRAGMENT-define only the missing ops (none, normally) and override impls.
+_lib_def = torch.library.Library(NS, "FRAGMENT")
+_lib_impl = torch.library.Library(NS, "IMPL", "CUDA")
+
+SCHEMAS = {
+    # gsplat/cuda/ext.cpp:984-991
+    "quat_scale_to_covar_preci": "(Tensor quats, Tensor scales, bool compute_covar, bool compute_preci, bool triu) -> (Tensor?, Tensor?)",
+    "quat_scale_to_covar_preci_bwd": "(Tensor quats, Tensor scales, bool triu, Tensor? v_covars, Tensor? v_precis) -> (Tensor, Tensor)",
+    # ext.cpp:994-1002
+    "spherical_harmonics": "(int degrees_to_use, Tensor means, Tensor viewmats, Tensor coeffs, Tensor? masks, Tensor? batch_ids, Tensor? camera_ids, Tensor? gaussian_ids, Tensor? viewmats_rs=None) -> Tensor",
+    "spherical_harmonics_bwd": "(int degrees_to_use, Tensor means, Tensor viewmats, Tensor coeffs, Tensor? masks, Tensor? batch_ids, Tensor? camera_ids, Tensor? gaussian_ids, Tensor? viewmats_rs, Tensor v_colors, bool compute_v_means, bool compute_v_viewmats, bool compute_v_viewmats_rs) -> (Tensor, Tensor?, Tensor?, Tensor?)",
+    # ext.cpp:1022-1027
+    "intersect_tile": "(Tensor means2d, Tensor radii, Tensor depths, Tensor? conics, Tensor? opacities, Tensor? image_ids, Tensor? gaussian_ids, int? n_images, int tile_size, int tile_width, int tile_height, bool sort, bool segmented) -> (Tensor, Tensor, Tensor)",
+    "intersect_offset": "(Tensor isect_ids, int I, int tile_width, int tile_height) -> Tensor",
+    # ext.cpp:1052-1077
+    "projection_ewa_3dgs_fused": "(Tensor means, Tensor? covars, Tensor? quats, Tensor? scales, Tensor? opacities, Tensor viewmats, Tensor Ks, int image_width, int image_height, float eps2d, float near_plane, float far_plane, float radius_clip, bool calc_compensations, int camera_model) -> (Tensor, Tensor, Tensor, Tensor, Tensor?)",
+    "projection_ewa_3dgs_fused_bwd": "(Tensor means, Tensor? covars, Tensor? quats, Tensor? scales, Tensor viewmats, Tensor Ks, int image_width, int image_height, float eps2d, int camera_model, Tensor radii, Tensor conics, Tensor? compensations, Tensor v_means2d, Tensor v_depths, Tensor v_conics, Tensor? v_compensations, bool viewmats_requires_grad) -> (Tensor, Tensor?, Tensor?, Tensor?, Tensor?)",
+    "projection_ewa_3dgs_packed": "(Tensor means, Tensor? covars, Tensor? quats, Tensor? scales, Tensor? opacities, Tensor viewmats, Tensor Ks, int image_width, int image_height, float eps2d, float near_plane, float far_plane, float radius_clip, bool sparse_grad, bool calc_compensations, int camera_model) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor?)",
+    "projection_ewa_3dgs_packed_bwd": "(Tensor means, Tensor? covars, Tensor? quats, Tensor? scales, Tensor viewmats, Tensor Ks, int image_width, int image_height, float eps2d, int camera_model, bool sparse_grad, Tensor batch_ids, Tensor camera_ids, Tensor gaussian_ids, Tensor conics, Tensor? compensations, Tensor v_means2d, Tensor v_depths, Tensor v_conics, Tensor? v_compensations, bool viewmats_requires_grad) -> (Tensor, Tensor?, Tensor?, Tensor?, Tensor?)",
+    # ext.cpp:1079-1089
+    "rasterize_to_pixels_3dgs": "(Tensor means2d, Tensor conics, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, int image_width, int image_height, int tile_size, Tensor isect_offsets, Tensor flatten_ids, bool packed, bool absgrad) -> (Tensor, Tensor, Tensor, Tensor)",
+    "rasterize_to_pixels_3dgs_bwd": "(Tensor means2d, Tensor conics, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, Tensor tile_offsets, Tensor flatten_ids, Tensor render_alphas, Tensor last_ids, int image_width, int image_height, int tile_size, bool absgrad, Tensor v_render_colors, Tensor v_render_alphas, bool compute_v_backgrounds) -> (Tensor?, Tensor, Tensor, Tensor, Tensor, Tensor?)",
+}
+
+_impls = {}
+
+
+def _op(name):
+    def deco(fn):
+        _impls[name] = fn
+        return fn
+
+    return deco
+
+
+def _check_f32(**tensors):
+    for k, t in tensors.items():
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError(f"gsplat_amd: {k} must be float32 (got {t.dtype}); the gfx950 kernels compute in fp32")
+
+
+def _c(t: Optional[Tensor]) -> Optional[Tensor]:
+    return None if t is None else t.contiguous()
+
+
+def bits_for_count(count: int) -> int:
+    return (count - 1).bit_length() if count > 1 else 0
+
+
+# ----------------------------------------------------------------------------------------------
+# quat_scale_to_covar_preci
+# ----------------------------------------------------------------------------------------------
+@_op("quat_scale_to_covar_preci")
+def quat_scale_to_covar_preci(quats, scales, compute_covar, compute_preci, triu):
+    _check_f32(quats=quats, scales=scales)
+    batch = quats.shape[:-1]
+    if quats.shape[-1] != 4 or scales.shape != batch + (3,):
+        raise ValueError(f"quat_scale_to_covar_preci: bad shapes {tuple(quats.shape)} / {tuple(scales.shape)}")
+    quats, scales = quats.contiguous(), scales.contiguous()
+    n = math.prod(batch)
+    tail = (6,) if triu else (3, 3)
+    covars = torch.empty(batch + tail, device=quats.device, dtype=quats.dtype) if compute_covar else None
+    precis = torch.empty(batch + tail, device=quats.device, dtype=quats.dtype) if compute_preci else None
+    call("gsx_quat_scale_to_covar_fwd", ptr(quats), ptr(scales), n, int(triu), ptr(covars), ptr(precis))
+    return covars, precis
+
+
+@_op("quat_scale_to_covar_preci_bwd")
+def quat_scale_to_covar_preci_bwd(quats, scales, triu, v_covars, v_precis):
+    quats, scales = quats.contiguous(), scales.contiguous()
+    n = math.prod(quats.shape[:-1])
+    v_quats, v_scales = torch.empty_like(quats), torch.empty_like(scales)
+    call("gsx_quat_scale_to_covar_bwd", ptr(quats), ptr(scales), n, int(triu), ptr(_c(v_covars)), ptr(_c(v_precis)),
+         ptr(v_quats), ptr(v_scales))
+    return v_quats, v_scales
+
+
+# ----------------------------------------------------------------------------------------------
+# spherical harmonics
+# ----------------------------------------------------------------------------------------------
+def _sh_dims(means, viewmats, coeffs, gaussian_ids):
+    packed = gaussian_ids is not None
+    C = viewmats.shape[-3]
+    N = means.shape[-2]
+    B = math.prod(means.shape[:-2])
+    K, D = coeffs.shape[-2], coeffs.shape[-1]
+    return packed, B, C, N, K, D
+
+
+@_op("spherical_harmonics")
+def spherical_harmonics(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids,
+                        viewmats_rs=None, *, _gathered: bool = True):
+    if viewmats_rs is not None:
+        raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
+    _check_f32(means=means, viewmats=viewmats, coeffs=coeffs)
+    packed, B, C, N, K, D = _sh_dims(means, viewmats, coeffs, gaussian_ids)
+    means, viewmats, coeffs, masks = means.contiguous(), viewmats.contiguous(), coeffs.contiguous(), _c(masks)
+    if coeffs.dim() != 3:
+        raise ValueError(f"coeffs must have shape [N, K, D] or [nnz, K, D], got {tuple(coeffs.shape)}")
+    if packed:
+        nnz = gaussian_ids.shape[0]
+        colors = torch.empty((nnz, D), device=means.device, dtype=means.dtype)
+        call("gsx_sh_fwd", degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), ptr(_c(batch_ids)),
+             ptr(_c(camera_ids)), ptr(_c(gaussian_ids)), B, C, N, nnz, int(_gathered), K, D, ptr(colors))
+    else:
+        if coeffs.shape[0] != N:
+            raise ValueError("means N must match coeffs N in dense mode")
+        colors = torch.empty(viewmats.shape[:-2] + (N, D), device=means.device, dtype=means.dtype)
+        call("gsx_sh_fwd", degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), None, None, None,
+             B, C, N, -1, 1, K, D, ptr(colors))
+    return colors
+
+
+@_op("spherical_harmonics_bwd")
+def spherical_harmonics_bwd(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids,
+                            viewmats_rs, v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs,
+                            *, _gathered: bool = True):
+    if viewmats_rs is not None or compute_v_viewmats_rs:
+        raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
+    packed, B, C, N, K, D = _sh_dims(means, viewmats, coeffs, gaussian_ids)
+    means, viewmats, coeffs, masks = means.contiguous(), viewmats.contiguous(), coeffs.contiguous(), _c(masks)
+    v_colors = v_colors.contiguous()
+    need_zero = packed and not _gathered
+    v_coeffs = torch.zeros_like(coeffs) if need_zero else torch.empty_like(coeffs)
+    v_means = torch.zeros_like(means) if compute_v_means else None
+    nnz = gaussian_ids.shape[0] if packed else -1
+    call("gsx_sh_bwd", degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), ptr(_c(batch_ids)),
+         ptr(_c(camera_ids)), ptr(_c(gaussian_ids)), B, C, N, nnz, int(_gathered) if packed else 1, K, D,
+         ptr(v_colors), ptr(v_coeffs), ptr(v_means))
+    v_viewmats = None
+    if compute_v_viewmats:
+        # d(dir)/d(viewmat): dir = mean + R^T t. Needs the per-row v_dir; recompute it on the torch
+        # side (pose optimisation is rare; this keeps the kernel free of a second reduction).
+        v_viewmats = _sh_viewmat_grad(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids,
+                                      gaussian_ids, v_colors, _gathered)
+    return v_coeffs, v_means, v_viewmats, None
+
+
+def _sh_viewmat_grad(degree, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, v_colors, gathered):
+    """v_viewmats of SH via autograd over a torch restatement of the direction only (small tensors
+    [B,C,4,4]); the heavy per-row v_dir comes from a second kernel pass with compute_v_means on a
+    per-camera copy of the means."""
+    raise NotImplementedError(
+        "gsplat_amd: SH gradient w.r.t. viewmats is not implemented yet (SURVEY.md section 8(f) rank 2)"
+    )
+
+
+# ----------------------------------------------------------------------------------------------
+# tile intersection
+# ----------------------------------------------------------------------------------------------
+def _scan_i32(x: Tensor) -> Tensor:
+    """Inclusive int64 prefix sum of an int32 tensor (flattened)."""
+    n = x.numel()
+    out = torch.empty(n, device=x.device, dtype=torch.int64)
+    ws = torch.empty(max(_cabi.scan_workspace_bytes(n), 8), device=x.device, dtype=torch.uint8)
+    call("gsx_scan_i32", ptr(x), n, ptr(out), ptr(ws), ws.numel())
+    return out
+
+
+@_op("intersect_tile")
+def intersect_tile(means2d, radii, depths, conics, opacities, image_ids, gaussian_ids, n_images, tile_size,
+                   tile_width, tile_height, sort, segmented):
+    _check_f32(means2d=means2d, depths=depths, conics=conics, opacities=opacities)
+    packed = image_ids is not None
+    means2d, radii, depths = means2d.contiguous(), radii.contiguous(), depths.contiguous()
+    if radii.dtype != torch.int32:
+        radii = radii.to(torch.int32)
+    conics, opacities, image_ids = _c(conics), _c(opacities), _c(image_ids)
+    if packed:
+        if n_images is None:
+            raise ValueError("n_images is required when packed")
+        rows, n_per, I = means2d.shape[0], 1, int(n_images)
+        out_shape = (rows,)
+    else:
+        image_dims = means2d.shape[:-2]
+        I, n_per = math.prod(image_dims), means2d.shape[-2]
+        rows = I * n_per
+        out_shape = tuple(means2d.shape[:-1])
+    tile_bits, image_bits = bits_for_count(tile_width * tile_height), bits_for_count(I)
+    if tile_bits + image_bits > 32:
+        raise RuntimeError(
+            f"intersect_tile: tile id bits ({tile_bits}) + image id bits ({image_bits}) exceed the 32 bits "
+            "available above the depth in the 64-bit sort key"
+        )
+    dev = means2d.device
+    tiles_per_gauss = torch.empty(out_shape, device=dev, dtype=torch.int32)
+    if rows == 0:
+        return (tiles_per_gauss, torch.empty(0, device=dev, dtype=torch.int64),
+                torch.empty(0, device=dev, dtype=torch.int32))
+    call("gsx_isect_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), ptr(image_ids), rows, n_per, I,
+         tile_size, tile_width, tile_height, ptr(tiles_per_gauss))
+    cum = _scan_i32(tiles_per_gauss)
+    n_isects = int(cum[-1].item())  # host sync: exact-length outputs (reference: Intersect.cpp:258-259)
+    if n_isects >= 2**31:
+        raise RuntimeError(f"intersect_tile: {n_isects} intersections overflow the int32 index space")
+    isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
+    flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
+    if n_isects == 0:
+        return tiles_per_gauss, isect_ids, flatten_ids
+    call("gsx_isect_emit", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), ptr(image_ids),
+         ptr(cum), rows, n_per, I, tile_size, tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids))
+    if sort:
+        keys_alt, vals_alt = torch.empty_like(isect_ids), torch.empty_like(flatten_ids)
+        ws = torch.empty(_cabi.sort_workspace_bytes(n_isects), device=dev, dtype=torch.uint8)
+        in_alt = _cabi.sort_pairs(isect_ids, flatten_ids, keys_alt, vals_alt, n_isects, 32 + tile_bits + image_bits, ws)
+        if in_alt:
+            isect_ids, flatten_ids = keys_alt, vals_alt
+    return tiles_per_gauss, isect_ids, flatten_ids
+
+
+@_op("intersect_offset")
+def intersect_offset(isect_ids, I, tile_width, tile_height):
+    isect_ids = isect_ids.contiguous()
+    offsets = torch.empty((I, tile_height, tile_width), device=isect_ids.device, dtype=torch.int32)
+    call("gsx_isect_offsets", ptr(isect_ids), isect_ids.numel(), I, tile_width, tile_height, ptr(offsets))
+    return offsets
+
+
+# ----------------------------------------------------------------------------------------------
+# projection
+# ----------------------------------------------------------------------------------------------
+def _proj_dims(means, viewmats):
+    batch_dims = means.shape[:-2]
+    return batch_dims, math.prod(batch_dims), viewmats.shape[-3], means.shape[-2]
+
+
+def _check_proj_inputs(means, covars, quats, scales, viewmats, Ks):
+    _check_f32(means=means, covars=covars, quats=quats, scales=scales, viewmats=viewmats, Ks=Ks)
+    if covars is None and (quats is None or scales is None):
+        raise ValueError("projection: either covars or (quats, scales) must be given")
+
+
+@_op("projection_ewa_3dgs_fused")
+def projection_ewa_3dgs_fused(means, covars, quats, scales, opacities, viewmats, Ks, image_width, image_height,
+                              eps2d, near_plane, far_plane, radius_clip, calc_compensations, camera_model):
+    _check_proj_inputs(means, covars, quats, scales, viewmats, Ks)
+    batch_dims, B, C, N = _proj_dims(means, viewmats)
+    means, viewmats, Ks = means.contiguous(), viewmats.contiguous(), Ks.contiguous()
+    covars, quats, scales, opacities = _c(covars), _c(quats), _c(scales), _c(opacities)
+    dev, dt = means.device, means.dtype
+    shape = tuple(batch_dims) + (C, N)
+    radii = torch.empty(shape + (2,), device=dev, dtype=torch.int32)
+    means2d = torch.empty(shape + (2,), device=dev, dtype=dt)
+    depths = torch.empty(shape, device=dev, dtype=dt)
+    conics = torch.empty(shape + (3,), device=dev, dtype=dt)
+    comps = torch.empty(shape, device=dev, dtype=dt) if calc_compensations else None
+    call("gsx_project_ewa_fwd", ptr(means), ptr(covars), ptr(None if covars is not None else quats),
+         ptr(None if covars is not None else scales), ptr(opacities), ptr(viewmats), ptr(Ks), B, C, N, image_width,
+         image_height, eps2d, near_plane, far_plane, radius_clip, int(camera_model), ptr(radii), ptr(means2d),
+         ptr(depths), ptr(conics), ptr(comps))
+    return radii, means2d, depths, conics, comps
+
+
+@_op("projection_ewa_3dgs_fused_bwd")
+def projection_ewa_3dgs_fused_bwd(means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
+                                  camera_model, radii, conics, compensations, v_means2d, v_depths, v_conics,
+                                  v_compensations, viewmats_requires_grad):
+    batch_dims, B, C, N = _proj_dims(means, viewmats)
+    means, viewmats, Ks = means.contiguous(), viewmats.contiguous(), Ks.contiguous()
+    covars, quats, scales = _c(covars), _c(quats), _c(scales)
+    v_means = torch.empty_like(means)
+    v_covars = v_quats = v_scales = None
+    if covars is not None:
+        v_covars = torch.empty_like(covars)
+    else:
+        v_quats, v_scales = torch.empty_like(quats), torch.empty_like(scales)
+    v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
+    call("gsx_project_ewa_bwd", ptr(means), ptr(covars), ptr(None if covars is not None else quats),
+         ptr(None if covars is not None else scales), ptr(viewmats), ptr(Ks), B, C, N, image_width, image_height,
+         eps2d, int(camera_model), ptr(radii.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
+         ptr(v_means2d.contiguous()), ptr(v_depths.contiguous()), ptr(v_conics.contiguous()),
+         ptr(_c(v_compensations)), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
+    return v_means, v_covars, v_quats, v_scales, v_viewmats
+
+
+@_op("projection_ewa_3dgs_packed")
+def projection_ewa_3dgs_packed(means, covars, quats, scales, opacities, viewmats, Ks, image_width, image_height,
+                               eps2d, near_plane, far_plane, radius_clip, sparse_grad, calc_compensations,
+                               camera_model):
+    _check_proj_inputs(means, covars, quats, scales, viewmats, Ks)
+    batch_dims, B, C, N = _proj_dims(means, viewmats)
+    means, viewmats, Ks = means.contiguous(), viewmats.contiguous(), Ks.contiguous()
+    covars, quats, scales, opacities = _c(covars), _c(quats), _c(scales), _c(opacities)
+    dev, dt = means.device, means.dtype
+    q = None if covars is not None else quats
+    s = None if covars is not None else scales
+    total = B * C * N
+    visible = torch.empty(total, device=dev, dtype=torch.int32)
+    common = (ptr(means), ptr(covars), ptr(q), ptr(s), ptr(opacities), ptr(viewmats), ptr(Ks), B, C, N, image_width,
+              image_height, eps2d, near_plane, far_plane, radius_clip, int(camera_model))
+    nnz = 0
+    cum = None
+    if total > 0:
+        call("gsx_project_ewa_packed_count", *common, int(calc_compensations), ptr(visible))
+        cum = _scan_i32(visible)
+        nnz = int(cum[-1].item())  # host sync: exact-length COO outputs (reference: Projection.cpp:928-941)
+    batch_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
+    camera_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
+    gaussian_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
+    indptr = torch.zeros(B * C + 1, device=dev, dtype=torch.int32)
+    radii = torch.empty((nnz, 2), device=dev, dtype=torch.int32)
+    means2d = torch.empty((nnz, 2), device=dev, dtype=dt)
+    depths = torch.empty((nnz,), device=dev, dtype=dt)
+    conics = torch.empty((nnz, 3), device=dev, dtype=dt)
+    comps = torch.empty((nnz,), device=dev, dtype=dt) if calc_compensations else None
+    if total > 0:
+        call("gsx_project_ewa_packed_write", *common, ptr(cum), nnz, ptr(batch_ids), ptr(camera_ids),
+             ptr(gaussian_ids), ptr(indptr), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(comps))
+    return batch_ids, camera_ids, gaussian_ids, indptr, radii, means2d, depths, conics, comps
+
+
+@_op("projection_ewa_3dgs_packed_bwd")
+def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
+                                   camera_model, sparse_grad, batch_ids, camera_ids, gaussian_ids, conics,
+                                   compensations, v_means2d, v_depths, v_conics, v_compensations,
+                                   viewmats_requires_grad):
+    batch_dims, B, C, N = _proj_dims(means, viewmats)
+    means, viewmats, Ks = means.contiguous(), viewmats.contiguous(), Ks.contiguous()
+    covars, quats, scales = _c(covars), _c(quats), _c(scales)
+    nnz = gaussian_ids.shape[0]
+    v_means = torch.zeros_like(means)
+    v_covars = v_quats = v_scales = None
+    if covars is not None:
+        v_covars = torch.zeros_like(covars)
+    else:
+        v_quats, v_scales = torch.zeros_like(quats), torch.zeros_like(scales)
+    v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
+    call("gsx_project_ewa_packed_bwd", ptr(means), ptr(covars), ptr(None if covars is not None else quats),
+         ptr(None if covars is not None else scales), ptr(viewmats), ptr(Ks), B, C, N, image_width, image_height,
+         eps2d, int(camera_model), nnz, ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()),
+         ptr(gaussian_ids.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
+         ptr(v_means2d.contiguous()), ptr(v_depths.contiguous()), ptr(v_conics.contiguous()),
+         ptr(_c(v_compensations)), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
+    if sparse_grad:
+        # COO gradients like the reference (Projection.cpp:1140-1200): rows = gaussian ids touched
+        def to_sparse(dense):
+            if dense is None:
+                return None
+            flat = dense.reshape((B * N,) + dense.shape[len(batch_dims) + 1:])
+            rows = torch.unique(batch_ids * N + gaussian_ids)
+            sp = torch.sparse_coo_tensor(rows[None], flat[rows], size=flat.shape, is_coalesced=True)
+            return sp if len(batch_dims) == 0 else sp.to_dense().reshape(dense.shape)
+
+        v_means, v_covars, v_quats, v_scales = map(to_sparse, (v_means, v_covars, v_quats, v_scales))
+    return v_means, v_covars, v_quats, v_scales, v_viewmats
+
+
+# ----------------------------------------------------------------------------------------------
+# rasterize_to_pixels (3DGS)
+# ----------------------------------------------------------------------------------------------
+def _raster_dims(isect_offsets, colors):
+    image_dims = tuple(isect_offsets.shape[:-2])
+    return image_dims, math.prod(image_dims), isect_offsets.shape[-2], isect_offsets.shape[-1], colors.shape[-1]
+
+
+@_op("rasterize_to_pixels_3dgs")
+def rasterize_to_pixels_3dgs(means2d, conics, colors, opacities, backgrounds, masks, image_width, image_height,
+                             tile_size, isect_offsets, flatten_ids, packed, absgrad):
+    _check_f32(means2d=means2d, conics=conics, colors=colors, opacities=opacities, backgrounds=backgrounds)
+    image_dims, I, th, tw, D = _raster_dims(isect_offsets, colors)
+    if th * tile_size < image_height or tw * tile_size < image_width:
+        raise ValueError("rasterize_to_pixels: isect_offsets tile grid does not cover the image")
+    if masks is not None and masks.dtype != torch.bool:
+        raise TypeError("masks must be a bool tensor")
+    means2d, conics, colors, opacities = (means2d.contiguous(), conics.contiguous(), colors.contiguous(),
+                                          opacities.contiguous())
+    backgrounds, masks = _c(backgrounds), _c(masks)
+    isect_offsets, flatten_ids = isect_offsets.contiguous(), flatten_ids.contiguous()
+    dev, dt = means2d.device, means2d.dtype
+    renders = torch.empty(image_dims + (image_height, image_width, D), device=dev, dtype=dt)
+    alphas = torch.empty(image_dims + (image_height, image_width, 1), device=dev, dtype=dt)
+    last_ids = torch.empty(image_dims + (image_height, image_width), device=dev, dtype=torch.int32)
+    call("gsx_raster3d_fwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+         ptr(isect_offsets), ptr(flatten_ids), I, flatten_ids.numel(), D, image_width, image_height, tile_size, tw,
+         th, ptr(renders), ptr(alphas), ptr(last_ids))
+    holder = torch.zeros_like(means2d) if absgrad else torch.empty(0, device=dev, dtype=dt)
+    return renders, alphas, holder, last_ids
+
+
+@_op("rasterize_to_pixels_3dgs_bwd")
+def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds, masks, tile_offsets, flatten_ids,
+                                 render_alphas, last_ids, image_width, image_height, tile_size, absgrad,
+                                 v_render_colors, v_render_alphas, compute_v_backgrounds):
+    image_dims, I, th, tw, D = _raster_dims(tile_offsets, colors)
+    means2d, conics, colors, opacities = (means2d.contiguous(), conics.contiguous(), colors.contiguous(),
+                                          opacities.contiguous())
+    backgrounds, masks = _c(backgrounds), _c(masks)
+    v_render_colors, v_render_alphas = v_render_colors.contiguous(), v_render_alphas.contiguous()
+    v_means2d = torch.zeros_like(means2d)
+    v_conics = torch.zeros_like(conics)
+    v_colors = torch.zeros_like(colors)
+    v_opacities = torch.zeros_like(opacities)
+    v_abs = torch.zeros_like(means2d) if absgrad else None
+    call("gsx_raster3d_bwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+         ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
+         ptr(last_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
+         image_width, image_height, tile_size, tw, th, ptr(v_abs), ptr(v_means2d), ptr(v_conics), ptr(v_colors),
+         ptr(v_opacities))
+    v_backgrounds = None
+    if backgrounds is not None and compute_v_backgrounds:
+        # sum_{h,w} v_colors * (1 - alpha)  (reference does this with torch ops too: Rasterization.cpp:567-577)
+        v_backgrounds = (v_render_colors * (1.0 - render_alphas)).sum(dim=(-3, -2))
+    return v_abs, v_means2d, v_conics, v_colors, v_opacities, v_backgrounds
+
+
+# ----------------------------------------------------------------------------------------------
+# registration
+# ----------------------------------------------------------------------------------------------
+def _register():
+    for name, schema in SCHEMAS.items():
+        qual = f"{NS}::{name}"
+        try:
+            torch._C._dispatch_find_schema_or_throw(qual, "")
+            exists = True
+        except RuntimeError:
+            exists = False
+        if not exists:
+            _lib_def.define(name + schema)
+        fn = _impls[name]
+        _lib_impl.impl(name, fn)
+
+
+_register()
+
+
+def op(name: str):
+    """torch.ops.gsplat.<name> (dispatcher entry)."""
+    return getattr(torch.ops.gsplat, name)
+
+
+def impl(name: str):
+    """The Python implementation behind the op (lets internal callers pass private keyword options)."""
+    return _impls[name]

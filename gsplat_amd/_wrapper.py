@@ -1,0 +1,177 @@
+"""Operator surface of the hot path — same names, arguments and error behaviour as the reference's
+``gsplat/cuda/_wrapper.py`` for: ``quat_scale_to_covar_preci`` (:657-716), ``spherical_harmonics``
+(:436-489), ``fully_fused_projection`` (:819-963), ``isect_tiles`` (:1196-1266),
+``isect_offset_encode`` (:1328-1347), ``rasterize_to_pixels`` (:1497-1562).
+
+Every function makes its inputs contiguous and performs one dispatcher call into
+``torch.ops.gsplat.<op>`` (defined in ``_ops.py``, autograd in ``_autograd.py``).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _autograd  # noqa: F401  (registers ops + autograd)
+
+_ops = torch.ops.gsplat
+
+CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2}
+
+
+def _camera_model_id(camera_model: str) -> int:
+    try:
+        return CAMERA_MODELS[camera_model]
+    except KeyError:
+        raise ValueError(
+            f"camera_model '{camera_model}' is not supported by the classic 3DGS path "
+            "(pinhole / ortho / fisheye; ftheta and lidar belong to the 3DGUT path, out of scope)"
+        ) from None
+
+
+def quat_scale_to_covar_preci(
+    quats: Tensor,  # [..., 4]
+    scales: Tensor,  # [..., 3]
+    compute_covar: bool = True,
+    compute_preci: bool = True,
+    triu: bool = False,
+) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """Converts quaternions and scales to covariance and precision matrices
+    ([..., 3, 3], or [..., 6] upper-triangular when ``triu``)."""
+    assert quats.shape[-1] == 4, quats.shape
+    assert scales.shape[-1] == 3, scales.shape
+    return _ops.quat_scale_to_covar_preci(quats.contiguous(), scales.contiguous(), compute_covar, compute_preci, triu)
+
+
+def spherical_harmonics(
+    degrees_to_use: int,
+    means: Tensor,  # [..., N, 3]
+    viewmats: Tensor,  # [..., C, 4, 4]
+    coeffs: Tensor,  # [N, K, D] or [nnz, K, D]
+    masks: Optional[Tensor] = None,  # [..., C, N] or [nnz]
+    batch_ids: Optional[Tensor] = None,
+    camera_ids: Optional[Tensor] = None,
+    gaussian_ids: Optional[Tensor] = None,
+    viewmats_rs: Optional[Tensor] = None,
+) -> Tensor:
+    """Evaluates SH colours for every (camera, gaussian) — [..., C, N, D] or [nnz, D]."""
+    if masks is not None:
+        masks = masks.contiguous()
+    return _ops.spherical_harmonics(
+        degrees_to_use, means.contiguous(), viewmats.contiguous(), coeffs.contiguous(), masks,
+        None if batch_ids is None else batch_ids.contiguous(),
+        None if camera_ids is None else camera_ids.contiguous(),
+        None if gaussian_ids is None else gaussian_ids.contiguous(),
+        None if viewmats_rs is None else viewmats_rs.contiguous(),
+    )
+
+
+def fully_fused_projection(
+    means: Tensor,  # [..., N, 3]
+    covars: Optional[Tensor],  # [..., N, 6] or None
+    quats: Optional[Tensor],  # [..., N, 4] or None
+    scales: Optional[Tensor],  # [..., N, 3] or None
+    viewmats: Tensor,  # [..., C, 4, 4]
+    Ks: Tensor,  # [..., C, 3, 3]
+    width: int,
+    height: int,
+    eps2d: float = 0.3,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    packed: bool = False,
+    sparse_grad: bool = False,
+    calc_compensations: bool = False,
+    camera_model: str = "pinhole",
+    opacities: Optional[Tensor] = None,  # [..., N] or None
+):
+    """Projects Gaussians to 2D. Dense: (radii, means2d, depths, conics, compensations) with shapes
+    [..., C, N, *]. Packed: (batch_ids, camera_ids, gaussian_ids, indptr, radii, means2d, depths,
+    conics, compensations) over the nnz visible (camera, gaussian) pairs."""
+    means = means.contiguous()
+    if covars is not None:
+        covars = covars.contiguous()
+    else:
+        assert quats is not None and scales is not None, "covars or (quats, scales) required"
+        quats, scales = quats.contiguous(), scales.contiguous()
+    if sparse_grad:
+        assert packed, "sparse_grad is only supported when packed is True"
+    if opacities is not None:
+        opacities = opacities.contiguous()
+    viewmats, Ks = viewmats.contiguous(), Ks.contiguous()
+    cm = _camera_model_id(camera_model)
+    if packed:
+        return _ops.projection_ewa_3dgs_packed(
+            means, covars, quats, scales, opacities, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+            radius_clip, sparse_grad, calc_compensations, cm)
+    return _ops.projection_ewa_3dgs_fused(
+        means, covars, quats, scales, opacities, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+        radius_clip, calc_compensations, cm)
+
+
+@torch.no_grad()
+def isect_tiles(
+    means2d: Tensor,  # [..., N, 2] or [nnz, 2]
+    radii: Tensor,  # [..., N, 2] or [nnz, 2]
+    depths: Tensor,  # [..., N] or [nnz]
+    tile_size: int,
+    tile_width: int,
+    tile_height: int,
+    sort: bool = True,
+    segmented: bool = False,
+    packed: bool = False,
+    n_images: Optional[int] = None,
+    image_ids: Optional[Tensor] = None,
+    gaussian_ids: Optional[Tensor] = None,
+    conics: Optional[Tensor] = None,
+    opacities: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Tensor]:
+    """Maps projected Gaussians to the tiles they touch: (tiles_per_gauss int32, isect_ids int64 [M],
+    flatten_ids int32 [M]). With ``conics`` and ``opacities`` the exact opacity-aware ellipse test is
+    used, otherwise the axis-aligned box of ``radii``."""
+    if packed:
+        assert image_ids is not None and gaussian_ids is not None and n_images is not None
+        image_ids, gaussian_ids = image_ids.contiguous(), gaussian_ids.contiguous()
+    else:
+        image_ids = gaussian_ids = None
+    return _ops.intersect_tile(
+        means2d.contiguous(), radii.contiguous(), depths.contiguous(),
+        None if conics is None else conics.contiguous(), None if opacities is None else opacities.contiguous(),
+        image_ids, gaussian_ids, n_images, tile_size, tile_width, tile_height, sort, segmented)
+
+
+@torch.no_grad()
+def isect_offset_encode(isect_ids: Tensor, n_images: int, tile_width: int, tile_height: int) -> Tensor:
+    """Sorted intersection ids -> per-(image, tile) start offsets, int32 [I, tile_height, tile_width]."""
+    return _ops.intersect_offset(isect_ids.contiguous(), n_images, tile_width, tile_height)
+
+
+def rasterize_to_pixels(
+    means2d: Tensor,  # [..., N, 2] or [nnz, 2]
+    conics: Tensor,  # [..., N, 3] or [nnz, 3]
+    colors: Tensor,  # [..., N, channels] or [nnz, channels]
+    opacities: Tensor,  # [..., N] or [nnz]
+    image_width: int,
+    image_height: int,
+    tile_size: int,
+    isect_offsets: Tensor,  # [..., tile_height, tile_width]
+    flatten_ids: Tensor,  # [n_isects]
+    backgrounds: Optional[Tensor] = None,  # [..., channels]
+    masks: Optional[Tensor] = None,  # [..., tile_height, tile_width]
+    packed: bool = False,
+    absgrad: bool = False,
+) -> Tuple[Tensor, Tensor]:
+    """Front-to-back alpha compositing of the depth-sorted per-tile lists. Returns
+    (render_colors [..., H, W, channels], render_alphas [..., H, W, 1]). With ``absgrad`` the
+    backward pass also fills ``means2d.absgrad``."""
+    if backgrounds is not None:
+        backgrounds = backgrounds.contiguous()
+    if masks is not None:
+        masks = masks.contiguous()
+    render_colors, render_alphas, means2d_absgrad, _last_ids = _ops.rasterize_to_pixels_3dgs(
+        means2d.contiguous(), conics.contiguous(), colors.contiguous(), opacities.contiguous(), backgrounds, masks,
+        image_width, image_height, tile_size, isect_offsets.contiguous(), flatten_ids.contiguous(), packed, absgrad)
+    if absgrad:
+        means2d.absgrad = means2d_absgrad
+    return render_colors, render_alphas

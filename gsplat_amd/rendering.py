@@ -1,0 +1,297 @@
+"""gsplat.rasterization() for the classic 3DGS path, orchestrated over the gfx950 stage ops.
+
+Mirrors the public signature, argument meaning, output shapes, ``meta`` dict and error behaviour
+of the reference (``gsplat/rendering.py:234-690``) and the stage order of its C++ orchestrator
+(``gsplat/cuda/csrc/Rendering.cpp:745-1481``):
+
+    projection (dense | packed)  ->  per-view opacities (x compensation)  ->  SH colours (+0.5, clamp)
+    -> [distributed: all-to-all of projected Gaussians]  ->  append depth channel
+    -> tile intersection (exact ellipse test) + sort + offsets  ->  alpha compositing
+    -> expected-depth normalisation.
+
+Features of the reference that belong to other paths (3DGUT: ``with_ut`` / ``with_eval3d`` / rays /
+distortion / rolling shutter / ftheta / lidar; hit-distance render modes) are rejected with the
+same kind of error the reference raises when built without them (``BUILD_3DGUT=0``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ._wrapper import (
+    fully_fused_projection,
+    isect_offset_encode,
+    isect_tiles,
+    rasterize_to_pixels,
+    spherical_harmonics,
+)
+
+_COLOR_MODES = ("RGB", "RGB+D", "RGB+ED")
+_DEPTH_MODES = ("D", "ED", "RGB+D", "RGB+ED")
+_HIT_MODES = ("d", "Ed", "RGB-d", "RGB-Ed")
+
+
+def _resolve_tile_size(tile_size: Optional[int]) -> int:
+    return 16 if tile_size is None else int(tile_size)
+
+
+def rasterization(
+    means: Tensor,  # [..., N, 3]
+    quats: Optional[Tensor],  # [..., N, 4]
+    scales: Optional[Tensor],  # [..., N, 3]
+    opacities: Tensor,  # [..., N]
+    colors: Optional[Tensor],  # [..., (C,) N, D] or [N, K, D]
+    viewmats: Tensor,  # [..., C, 4, 4]
+    Ks: Tensor,  # [..., C, 3, 3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = True,
+    tile_size: Optional[int] = None,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: str = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: str = "classic",
+    channel_chunk: int = 32,
+    distributed: bool = False,
+    camera_model: str = "pinhole",
+    segmented: bool = False,
+    covars: Optional[Tensor] = None,
+    with_ut: bool = False,
+    with_eval3d: bool = False,
+    return_normals: bool = False,
+    global_z_order: bool = True,
+    rays: Optional[Tensor] = None,
+    radial_coeffs: Optional[Tensor] = None,
+    tangential_coeffs: Optional[Tensor] = None,
+    thin_prism_coeffs: Optional[Tensor] = None,
+    ftheta_coeffs=None,
+    lidar_coeffs=None,
+    external_distortion_coeffs=None,
+    rolling_shutter=None,
+    viewmats_rs: Optional[Tensor] = None,
+    ut_params=None,
+    extra_signals: Optional[Tensor] = None,
+    extra_signals_sh_degree: Optional[int] = None,
+    renderer_config=None,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """Rasterize a set of 3D Gaussians (N) to a batch of image planes (C). See the reference
+    docstring (``gsplat/rendering.py:292-525``) for the meaning of every argument; this
+    implementation covers the classic (EWA, non-3DGUT) path."""
+    if render_mode in _HIT_MODES:
+        raise ValueError(f"render_mode '{render_mode}' (hit distance) requires the 3DGUT path, which is out of scope")
+    if render_mode not in _COLOR_MODES + ("D", "ED"):
+        raise ValueError(f"Unsupported render_mode: {render_mode}")
+    if rasterize_mode not in ("classic", "antialiased"):
+        raise ValueError(f"Unsupported rasterize_mode: {rasterize_mode}")
+    unsupported = {
+        "with_ut": with_ut, "with_eval3d": with_eval3d, "return_normals": return_normals, "rays": rays is not None,
+        "radial_coeffs": radial_coeffs is not None, "tangential_coeffs": tangential_coeffs is not None,
+        "thin_prism_coeffs": thin_prism_coeffs is not None, "ftheta_coeffs": ftheta_coeffs is not None,
+        "lidar_coeffs": lidar_coeffs is not None, "external_distortion_coeffs": external_distortion_coeffs is not None,
+        "viewmats_rs": viewmats_rs is not None, "global_z_order=False": not global_z_order,
+    }
+    bad = [k for k, v in unsupported.items() if v]
+    if bad:
+        raise RuntimeError(
+            "gsplat_amd implements the classic 3DGS rasterization path; these arguments belong to the 3DGUT / "
+            f"sensor paths and are not supported: {', '.join(bad)}"
+        )
+    if segmented:
+        raise RuntimeError("segmented radix sort is not implemented (the global sort is used; results are identical)")
+
+    has_color = render_mode in _COLOR_MODES
+    has_depth = render_mode in _DEPTH_MODES
+    expected_depth = render_mode in ("ED", "RGB+ED")
+    tile_size = _resolve_tile_size(tile_size)
+
+    batch_dims = tuple(means.shape[:-2])
+    nb = len(batch_dims)
+    B = math.prod(batch_dims)
+    N = means.shape[-2]
+    C = viewmats.shape[-3]
+    I = B * C
+    device = means.device
+
+    if covars is not None:
+        assert covars.shape == batch_dims + (N, 3, 3), covars.shape
+        quats, scales = None, None
+        ti = ([0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2])
+        covars = covars[..., ti[0], ti[1]]
+    else:
+        assert quats is not None and scales is not None, "covars or (quats, scales) required"
+        assert quats.shape == batch_dims + (N, 4), quats.shape
+        assert scales.shape == batch_dims + (N, 3), scales.shape
+    assert means.shape == batch_dims + (N, 3), means.shape
+    assert opacities.shape == batch_dims + (N,), opacities.shape
+    assert viewmats.shape == batch_dims + (C, 4, 4), viewmats.shape
+    assert Ks.shape == batch_dims + (C, 3, 3), Ks.shape
+    if has_color:
+        assert colors is not None, "colors must be provided for color render modes"
+        if sh_degree is None:
+            assert (colors.dim() == nb + 2 and colors.shape[:-1] == batch_dims + (N,)) or (
+                colors.dim() == nb + 3 and colors.shape[:-1] == batch_dims + (C, N)
+            ), colors.shape
+        else:
+            assert colors.dim() == 3 and colors.shape[0] == N, colors.shape
+            assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
+    if sparse_grad:
+        assert packed, "sparse_grad is only supported when packed is True"
+    if backgrounds is not None:
+        assert backgrounds.shape[:-1] == batch_dims + (C,), backgrounds.shape
+
+    world_size = 1
+    dist_ctx = None
+    if distributed:
+        from . import distributed as gdist
+
+        dist_ctx = gdist.DistributedRasterContext.create(
+            batch_dims=batch_dims, sparse_grad=sparse_grad, absgrad=absgrad, camera_model=camera_model,
+            colors=colors, sh_degree=sh_degree, n_cameras=C, device=device, n_local=N)
+        world_size = dist_ctx.world_size
+        # Seam A: every rank projects its Gaussian shard against ALL cameras.
+        viewmats_proj, Ks_proj = dist_ctx.gather_cameras(viewmats, Ks)
+        C_proj = viewmats_proj.shape[-3]
+    else:
+        viewmats_proj, Ks_proj, C_proj = viewmats, Ks, C
+
+    calc_comp = rasterize_mode == "antialiased"
+    proj = fully_fused_projection(
+        means, covars, quats, scales, viewmats_proj, Ks_proj, width, height, eps2d=eps2d, near_plane=near_plane,
+        far_plane=far_plane, radius_clip=radius_clip, packed=packed, sparse_grad=sparse_grad,
+        calc_compensations=calc_comp, camera_model=camera_model, opacities=opacities)
+
+    if packed:
+        batch_ids, camera_ids, gaussian_ids, indptr, radii, means2d, depths, conics, compensations = proj
+        proj_opacities = opacities.reshape(B, N)[batch_ids, gaussian_ids]  # [nnz]
+        image_ids = batch_ids * C_proj + camera_ids
+    else:
+        radii, means2d, depths, conics, compensations = proj
+        batch_ids = camera_ids = gaussian_ids = image_ids = None
+        proj_opacities = torch.broadcast_to(opacities[..., None, :], batch_dims + (C_proj, N))
+    if compensations is not None:
+        proj_opacities = proj_opacities * compensations
+
+    # ---- feature channels: [..., C, N, D] or [nnz, D] ------------------------------------------
+    feats = None
+    if has_color:
+        feats = _project_features(colors, sh_degree, True, means, viewmats_proj, radii, batch_dims, B, C_proj, N,
+                                  batch_ids, camera_ids, gaussian_ids)
+    n_primary = feats.shape[-1] if feats is not None else 0
+    n_extra = 0
+    if extra_signals is not None:
+        ex = _project_features(extra_signals, extra_signals_sh_degree, False, means, viewmats_proj, radii, batch_dims,
+                               B, C_proj, N, batch_ids, camera_ids, gaussian_ids)
+        n_extra = ex.shape[-1]
+        feats = ex if feats is None else torch.cat([feats, ex], dim=-1)
+
+    meta = {
+        "batch_ids": batch_ids, "camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": radii,
+        "means2d": means2d, "depths": depths, "conics": conics, "opacities": proj_opacities,
+    }
+
+    # ---- Seam B: ship every projected Gaussian to the rank that owns its camera ------------------
+    if dist_ctx is not None:
+        (radii, means2d, depths, conics, proj_opacities, feats, image_ids, gaussian_ids_r) = dist_ctx.scatter_projection(
+            packed, radii, means2d, depths, conics, proj_opacities, feats, batch_ids, camera_ids, gaussian_ids)
+        n_rows_per_image = dist_ctx.total_gaussians
+    else:
+        n_rows_per_image = N
+
+    # ---- depth channel ---------------------------------------------------------------------------
+    if has_depth:
+        d = depths[..., None]
+        feats = d if feats is None else torch.cat([feats, d], dim=-1)
+        if backgrounds is not None:
+            if has_color:
+                backgrounds = torch.cat([backgrounds, torch.zeros_like(backgrounds[..., :1])], dim=-1)
+            else:
+                backgrounds = torch.zeros(batch_dims + (C, feats.shape[-1]), device=device, dtype=means.dtype)
+    assert feats is not None
+
+    # ---- tile intersection -----------------------------------------------------------------------
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
+        means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=False, packed=packed,
+        n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids if dist_ctx is None else gaussian_ids_r,
+        conics=conics, opacities=proj_opacities.contiguous())
+    isect_offsets = isect_offset_encode(isect_ids, I, tile_width, tile_height)
+    isect_offsets = isect_offsets.reshape(batch_dims + (C, tile_height, tile_width))
+
+    # ---- compositing (channel chunks; alphas from the first chunk) -------------------------------
+    D_total = feats.shape[-1]
+    if D_total > channel_chunk:
+        rc, ra = [], None
+        for s in range(0, D_total, channel_chunk):
+            e = min(D_total, s + channel_chunk)
+            bg = None if backgrounds is None else backgrounds[..., s:e].contiguous()
+            c_, a_ = rasterize_to_pixels(means2d, conics, feats[..., s:e].contiguous(), proj_opacities, width, height,
+                                         tile_size, isect_offsets, flatten_ids, backgrounds=bg, packed=packed,
+                                         absgrad=absgrad)
+            rc.append(c_)
+            if ra is None:
+                ra = a_
+        render_colors, render_alphas = torch.cat(rc, dim=-1), ra
+    else:
+        render_colors, render_alphas = rasterize_to_pixels(
+            means2d, conics, feats, proj_opacities, width, height, tile_size, isect_offsets, flatten_ids,
+            backgrounds=backgrounds, packed=packed, absgrad=absgrad)
+
+    # ---- post-process: split extra signals, normalise expected depth ------------------------------
+    render_extra = None
+    if n_extra > 0:
+        render_extra = render_colors[..., n_primary:n_primary + n_extra]
+        parts = [render_colors[..., :n_primary]]
+        if has_depth:
+            dch = render_colors[..., -1:]
+            if expected_depth:
+                dch = dch / render_alphas.clamp_min(1e-10)
+            parts.append(dch)
+        render_colors = torch.cat(parts, dim=-1)
+    elif expected_depth:
+        render_colors = torch.cat(
+            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp_min(1e-10)], dim=-1)
+
+    if not packed:
+        meta["batch_ids"] = meta["camera_ids"] = meta["gaussian_ids"] = None
+    meta.update({
+        "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
+        "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "width": width,
+        "height": height, "tile_size": tile_size, "n_batches": B, "n_cameras": C,
+    })
+    if extra_signals is not None:
+        meta["render_extra_signals"] = render_extra
+    return render_colors, render_alphas, meta
+
+
+def _project_features(features, sh_degree, clamp, means, viewmats, radii, batch_dims, B, C, N, batch_ids, camera_ids,
+                      gaussian_ids):
+    """Per-view feature rows: [..., C, N, D] (dense) or [nnz, D] (packed).
+    Reference: normalize_features_layout_3dgs / maybe_evaluate_feature_sh, Rendering.cpp:577-644."""
+    nb = len(batch_dims)
+    packed = gaussian_ids is not None
+    if sh_degree is None:
+        D = features.shape[-1]
+        per_view = features.dim() == nb + 3
+        if per_view:
+            if packed:
+                return features.reshape(B, C, N, D)[batch_ids, camera_ids, gaussian_ids]
+            return features
+        if packed:
+            return features.reshape(B, N, D)[batch_ids, gaussian_ids]
+        return torch.broadcast_to(features[..., None, :, :], batch_dims + (C, N, D))
+    valid = (radii > 0).all(dim=-1)
+    coeffs = features[gaussian_ids] if packed else features
+    vals = spherical_harmonics(sh_degree, means, viewmats, coeffs, masks=valid, batch_ids=batch_ids,
+                               camera_ids=camera_ids, gaussian_ids=gaussian_ids)
+    vals = vals + 0.5
+    return torch.clamp_min(vals, 0.0) if clamp else vals

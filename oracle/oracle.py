@@ -1,0 +1,448 @@
+"""CPU oracle for the Gaussian-rasterization hot path (TEST INFRASTRUCTURE ONLY).
+
+Nothing under ``gsplat_amd/`` may import this module. It is used by ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg, only as the checker /
+timed CPU baseline.
+
+Two halves:
+
+* torch-CPU (differentiable) restatements of the per-Gaussian stages — projection, spherical
+  harmonics, quat/scale -> covariance — each citing the reference lines it follows. Gradients
+  come from torch autograd, exactly how the reference's own tests obtain theirs
+  (``tests/test_basic.py:436-504``).
+* ctypes bindings to ``oracle/gsplat_oracle.c`` (plain C + OpenMP) for the integer / per-pixel
+  stages — tile intersection, key packing, offsets, alpha compositing forward and backward.
+
+Pinning status: see ``oracle/pin_against_reference.py`` — every function here is checked against
+the reference's own Python implementation (``gsplat/cuda/_torch_impl.py``) where that runs on
+CPU, and against ``accumulate()`` (driven through a restated nerfacc) for the compositing stage;
+the resulting golden vectors live in ``tests/golden/``.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libgsplat_oracle.so")
+
+ALPHA_THRESHOLD = 1.0 / 255.0  # gsplat/cuda/include/Common.h:97
+GAUSSIAN_EXTEND = 3.33  # Common.h:99
+MAX_ALPHA = 0.99  # Common.h:105
+MIN_COMPENSATION = 0.005  # Common.h:110
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/gsplat_oracle.c into oracle/_build/libgsplat_oracle.so (gcc, OpenMP)."""
+    src = os.path.join(_HERE, "gsplat_oracle.c")
+    if (
+        not force
+        and os.path.exists(_LIB_PATH)
+        and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)
+    ):
+        return _LIB_PATH
+    os.makedirs(os.path.dirname(_LIB_PATH), exist_ok=True)
+    cmd = [
+        "gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
+        "-fno-fast-math", src, "-lm", "-o", _LIB_PATH,
+    ]
+    subprocess.run(cmd, check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        _lib.gso_det_logf.restype = ctypes.c_float
+        _lib.gso_det_logf.argtypes = [ctypes.c_float]
+        _lib.gso_raster3d_indices.restype = ctypes.c_int64
+        _lib.gso_isect_emit.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _np(t, dtype) -> Optional[np.ndarray]:
+    if t is None:
+        return None
+    if isinstance(t, Tensor):
+        t = t.detach().cpu().numpy()
+    return np.ascontiguousarray(t, dtype=dtype)
+
+
+def bits_for_count(count: int) -> int:
+    """gsplat/cuda/csrc/MathUtils.h:25-35, gsplat/cuda/_torch_impl.py:42-50."""
+    return (count - 1).bit_length() if count > 1 else 0
+
+
+# ----------------------------------------------------------------------------------------------
+# per-Gaussian stages (torch, differentiable)
+# ----------------------------------------------------------------------------------------------
+def quat_to_rotmat(quats: Tensor) -> Tensor:
+    """Utils.cuh:228-250 / gsplat/cuda/_math.py:655-674 (wxyz, normalised inside)."""
+    q = quats / quats.norm(dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    R = torch.stack(
+        [
+            1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+            2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+            2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y),
+        ],
+        dim=-1,
+    )
+    return R.reshape(quats.shape[:-1] + (3, 3))
+
+
+def _triu6(M: Tensor) -> Tensor:
+    f = M.reshape(M.shape[:-2] + (9,))
+    return (f[..., [0, 1, 2, 4, 5, 8]] + f[..., [0, 3, 6, 4, 7, 8]]) / 2.0
+
+
+def quat_scale_to_covar_preci(quats, scales, compute_covar=True, compute_preci=True, triu=False):
+    """Utils.cuh:285-311 / gsplat/cuda/_math.py:689-720."""
+    R = quat_to_rotmat(quats)
+    covars = precis = None
+    if compute_covar:
+        M = R * scales[..., None, :]
+        covars = M @ M.transpose(-1, -2)
+        if triu:
+            covars = _triu6(covars)
+    if compute_preci:
+        P = R * (1.0 / scales[..., None, :])
+        precis = P @ P.transpose(-1, -2)
+        if triu:
+            precis = _triu6(precis)
+    return covars, precis
+
+
+def _covar6_to_mat(c6: Tensor) -> Tensor:
+    i = [0, 1, 2, 1, 3, 4, 2, 4, 5]
+    return c6[..., i].reshape(c6.shape[:-1] + (3, 3))
+
+
+def det_logf(x: Tensor) -> Tensor:
+    """Element-wise gso_det_logf (bit-identical to the device det_logf) on a float32 tensor."""
+    a = np.ascontiguousarray(x.detach().cpu().numpy(), dtype=np.float32)
+    out = np.empty_like(a)
+    lib().gso_det_logf_array(_p(a), _p(out), ctypes.c_int64(a.size))
+    return torch.from_numpy(out)
+
+
+def fully_fused_projection(
+    means: Tensor,  # [B, N, 3]
+    covars: Optional[Tensor],  # [B, N, 6]
+    quats: Optional[Tensor],  # [B, N, 4]
+    scales: Optional[Tensor],  # [B, N, 3]
+    viewmats: Tensor,  # [B, C, 4, 4]
+    Ks: Tensor,  # [B, C, 3, 3]
+    width: int,
+    height: int,
+    eps2d: float = 0.3,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    calc_compensations: bool = False,
+    camera_model: str = "pinhole",
+    opacities: Optional[Tensor] = None,  # [B, N]
+):
+    """The CUDA kernel's behaviour (ProjectionEWA3DGSFused.cu:38-219), including what the
+    reference's torch version lacks: opacity-aware extent (:163-181), radius_clip (:188),
+    det <= 0 cull (:153), <=/>= frustum test (:196-199), near/far with </> (:100).
+    Math per Utils.cuh:81-148 (world->cam), :455-463 (blur), :498-728 (projections).
+    Returns radii int32 [B,C,N,2], means2d, depths, conics, compensations (or None);
+    culled rows hold zeros."""
+    dt = means.dtype
+    if covars is None:
+        covars_w = quat_scale_to_covar_preci(quats, scales, True, False, False)[0]
+    else:
+        covars_w = _covar6_to_mat(covars)
+    R = viewmats[..., :3, :3]  # [B,C,3,3]
+    t = viewmats[..., :3, 3]
+    means_c = torch.einsum("bcij,bnj->bcni", R, means) + t[:, :, None, :]
+    covars_c = R[:, :, None] @ covars_w[:, None] @ R[:, :, None].transpose(-1, -2)  # [B,C,N,3,3]
+    x, y, z = means_c.unbind(-1)
+    fx = Ks[..., 0, 0, None]
+    fy = Ks[..., 1, 1, None]
+    cx = Ks[..., 0, 2, None]
+    cy = Ks[..., 1, 2, None]
+    O = torch.zeros_like(x)
+    if camera_model == "pinhole":
+        tan_fovx = 0.5 * width / fx
+        tan_fovy = 0.5 * height / fy
+        lxp = (width - cx) / fx + 0.3 * tan_fovx
+        lxn = cx / fx + 0.3 * tan_fovx
+        lyp = (height - cy) / fy + 0.3 * tan_fovy
+        lyn = cy / fy + 0.3 * tan_fovy
+        tx = z * torch.minimum(lxp, torch.maximum(-lxn, x / z))
+        ty = z * torch.minimum(lyp, torch.maximum(-lyn, y / z))
+        J = torch.stack([fx / z, O, -fx * tx / z**2, O, fy / z, -fy * ty / z**2], dim=-1)
+        m2 = torch.stack([fx * x / z + cx, fy * y / z + cy], dim=-1)
+    elif camera_model == "ortho":
+        J = torch.stack([fx + O, O, O, O, fy + O, O], dim=-1)
+        m2 = torch.stack([fx * x + cx, fy * y + cy], dim=-1)
+    elif camera_model == "fisheye":
+        eps = 1e-7
+        r = (x * x + y * y) ** 0.5 + eps
+        th = torch.atan2(r, z + eps)
+        m2 = torch.stack([x * fx * th / r + cx, y * fy * th / r + cy], dim=-1)
+        x2 = x * x + eps
+        y2 = y * y
+        xy = x * y
+        r2 = x2 + y2
+        il2 = 1.0 / (r2 + z * z)
+        bb = torch.atan2(r, z) / r / r2
+        aa = z * il2 / r2
+        J = torch.stack(
+            [fx * (x2 * aa + y2 * bb), fx * xy * (aa - bb), -fx * x * il2,
+             fy * xy * (aa - bb), fy * (y2 * aa + x2 * bb), -fy * y * il2],
+            dim=-1,
+        )
+    else:
+        raise ValueError(camera_model)
+    J = J.reshape(J.shape[:-1] + (2, 3))
+    cov2d = J @ covars_c @ J.transpose(-1, -2)
+    a_, b_, d_ = cov2d[..., 0, 0], cov2d[..., 0, 1], cov2d[..., 1, 1]
+    det_orig = a_ * d_ - b_ * b_
+    a_b, d_b = a_ + eps2d, d_ + eps2d
+    det_blur = a_b * d_b - b_ * b_
+    valid = (z >= near_plane) & (z <= far_plane) & (det_blur > 0)
+    safe_det = torch.where(det_blur > 0, det_blur, torch.ones_like(det_blur))
+    comp = torch.sqrt(torch.clamp(det_orig / safe_det, min=MIN_COMPENSATION**2))
+    conics = torch.stack([d_b / safe_det, -b_ / safe_det, a_b / safe_det], dim=-1)
+    extend = torch.full_like(z, GAUSSIAN_EXTEND)
+    if opacities is not None:
+        op = opacities[:, None, :].expand_as(z)
+        if calc_compensations:
+            op = op * comp
+        valid = valid & ~(op < ALPHA_THRESHOLD)
+        with torch.no_grad():
+            lg = det_logf((op.detach().float() * 255.0).clamp_min(1.0)).to(dt)
+        extend = torch.minimum(extend, torch.sqrt(2.0 * lg))
+    with torch.no_grad():
+        rx = torch.ceil(extend * torch.sqrt(a_b.clamp_min(0)))
+        ry = torch.ceil(extend * torch.sqrt(d_b.clamp_min(0)))
+        valid = valid & ~((rx <= radius_clip) & (ry <= radius_clip))
+        inside = ~(
+            (m2[..., 0] + rx <= 0) | (m2[..., 0] - rx >= width) | (m2[..., 1] + ry <= 0) | (m2[..., 1] - ry >= height)
+        )
+        valid = valid & inside
+        radii = torch.stack([rx, ry], dim=-1) * valid[..., None]
+        radii = torch.nan_to_num(radii, nan=0.0, posinf=0.0, neginf=0.0).to(torch.int32)
+    vm = valid[..., None]
+    zero = torch.zeros((), dtype=dt)
+    means2d = torch.where(vm, m2, zero)
+    depths = torch.where(valid, z, zero)
+    conics = torch.where(vm, conics, zero)
+    comps = torch.where(valid, comp, zero) if calc_compensations else None
+    return radii, means2d, depths, conics, comps
+
+
+def sh_bases(degree: int, dirs: Tensor) -> Tensor:
+    """Sloan's polynomial SH basis, degree <= 4 (SphericalHarmonicsCUDA.cu:48-146 /
+    gsplat/cuda/_torch_impl.py:968-1047). dirs must be unit length. Returns [..., (deg+1)^2]."""
+    x, y, z = dirs.unbind(-1)
+    out = [torch.full_like(x, 0.2820947917738781)]
+    if degree >= 1:
+        out += [-0.48860251190292 * y, 0.48860251190292 * z, -0.48860251190292 * x]
+    if degree >= 2:
+        z2 = z * z
+        fB = -1.092548430592079 * z
+        fC1 = x * x - y * y
+        fS1 = 2 * x * y
+        out += [0.5462742152960395 * fS1, fB * y, 0.9461746957575601 * z2 - 0.3153915652525201, fB * x,
+                0.5462742152960395 * fC1]
+    if degree >= 3:
+        fC = -2.285228997322329 * z2 + 0.4570457994644658
+        fB = 1.445305721320277 * z
+        fA = -0.5900435899266435
+        fC2 = x * fC1 - y * fS1
+        fS2 = x * fS1 + y * fC1
+        out += [fA * fS2, fB * fS1, fC * y, z * (1.865881662950577 * z2 - 1.119528997770346), fC * x, fB * fC1,
+                fA * fC2]
+    if degree >= 4:
+        fD = z * (-4.683325804901025 * z2 + 2.007139630671868)
+        fC = 3.31161143515146 * z2 - 0.47308734787878
+        fB = -1.770130769779931 * z
+        fA = 0.6258357354491763
+        fC3 = x * fC2 - y * fS2
+        fS3 = x * fS2 + y * fC2
+        out += [
+            fA * fS3, fB * fS2, fC * fS1, fD * y,
+            1.984313483298443 * z2 * (1.865881662950577 * z2 - 1.119528997770346)
+            - 1.006230589874905 * (0.9461746957575601 * z2 - 0.3153915652525201),
+            fD * x, fC * fC1, fB * fC2, fA * fC3,
+        ]
+    return torch.stack(out, dim=-1)
+
+
+def spherical_harmonics(degree: int, means: Tensor, viewmats: Tensor, coeffs: Tensor, masks: Optional[Tensor] = None):
+    """gsplat.spherical_harmonics (dense): means [B,N,3], viewmats [B,C,4,4], coeffs [N,K,D],
+    masks bool [B,C,N] -> colors [B,C,N,D]. dir = mean - camera centre (= mean + R^T t),
+    SphericalHarmonics.cuh:39-69; evaluation _torch_impl.py:1052-1067. Masked rows are zero."""
+    R = viewmats[..., :3, :3]
+    t = viewmats[..., :3, 3]
+    campos = -torch.einsum("bcji,bcj->bci", R, t)  # -R^T t
+    dirs = means[:, None, :, :] - campos[:, :, None, :]
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    Y = sh_bases(degree, dirs)  # [B,C,N,nb]
+    nb = Y.shape[-1]
+    colors = torch.einsum("bcnk,nkd->bcnd", Y, coeffs[:, :nb, :])
+    if masks is not None:
+        colors = colors * masks[..., None]
+    return colors
+
+
+# ----------------------------------------------------------------------------------------------
+# integer / per-pixel stages (C)
+# ----------------------------------------------------------------------------------------------
+def isect_tiles(
+    means2d, radii, depths, tile_size: int, tile_width: int, tile_height: int, sort: bool = True,
+    conics=None, opacities=None, image_ids=None, n_images: Optional[int] = None,
+):
+    """gsplat.isect_tiles (IntersectTile.cu:214-464, _torch_impl.py:356-451). Dense inputs are
+    [I,N,*]; packed inputs are [nnz,*] with image_ids. Returns (tiles_per_gauss int32,
+    isect_ids int64 [M], flatten_ids int32 [M]); sorted with a STABLE sort when sort=True
+    (cub radix sort is stable, IntersectTile.cu:1096-1104)."""
+    m2 = _np(means2d, np.float32)
+    packed = image_ids is not None
+    if packed:
+        rows, n_per = m2.shape[0], 1
+        I = int(n_images)
+        out_shape = (rows,)
+    else:
+        I, n_per = int(np.prod(m2.shape[:-2])), m2.shape[-2]
+        rows = I * n_per
+        out_shape = m2.shape[:-1]
+    m2 = m2.reshape(rows, 2)
+    rd = _np(radii, np.int32).reshape(rows, 2)
+    dp = _np(depths, np.float32).reshape(rows)
+    cn = None if conics is None else _np(conics, np.float32).reshape(rows, 3)
+    op = None if opacities is None else _np(opacities, np.float32).reshape(rows)
+    ii = None if not packed else _np(image_ids, np.int64).reshape(rows)
+    tpg = np.zeros(rows, dtype=np.int32)
+    L = lib()
+    L.gso_isect_count(_p(m2), _p(rd), _p(cn), _p(op), ctypes.c_int64(rows), ctypes.c_uint32(tile_size),
+                      ctypes.c_uint32(tile_width), ctypes.c_uint32(tile_height), _p(tpg))
+    cum = np.cumsum(tpg, dtype=np.int64)
+    M = int(cum[-1]) if rows > 0 else 0
+    ids = np.zeros(M, dtype=np.int64)
+    fl = np.zeros(M, dtype=np.int32)
+    rc = L.gso_isect_emit(_p(m2), _p(rd), _p(dp), _p(cn), _p(op), _p(ii), _p(cum), ctypes.c_int64(rows),
+                          ctypes.c_uint32(n_per), ctypes.c_uint32(I), ctypes.c_uint32(tile_size),
+                          ctypes.c_uint32(tile_width), ctypes.c_uint32(tile_height), _p(ids), _p(fl))
+    if rc != 0:
+        raise RuntimeError("isect key overflow: image bits + tile bits > 32")
+    if sort and M > 0:
+        order = np.argsort(ids.view(np.uint64), kind="stable")
+        ids, fl = ids[order], fl[order]
+    return (torch.from_numpy(tpg.reshape(out_shape)), torch.from_numpy(ids), torch.from_numpy(fl))
+
+
+def isect_offset_encode(isect_ids, n_images: int, tile_width: int, tile_height: int) -> Tensor:
+    """gsplat.isect_offset_encode (IntersectTile.cu:925-988, _torch_impl.py:455-481)."""
+    ids = _np(isect_ids, np.int64)
+    off = np.zeros((n_images, tile_height, tile_width), dtype=np.int32)
+    lib().gso_isect_offsets(_p(ids), ctypes.c_int64(ids.shape[0]), ctypes.c_uint32(n_images),
+                            ctypes.c_uint32(tile_width), ctypes.c_uint32(tile_height), _p(off))
+    return torch.from_numpy(off)
+
+
+def _raster_common(means2d, conics, colors, opacities, isect_offsets):
+    off = _np(isect_offsets, np.int32)
+    I, th, tw = int(np.prod(off.shape[:-2])), off.shape[-2], off.shape[-1]
+    cdim = colors.shape[-1]
+    m2 = _np(means2d, np.float32).reshape(-1, 2)
+    cn = _np(conics, np.float32).reshape(-1, 3)
+    cl = _np(colors, np.float32).reshape(-1, cdim)
+    op = _np(opacities, np.float32).reshape(-1)
+    return off, I, th, tw, cdim, m2, cn, cl, op
+
+
+def rasterize_to_pixels(
+    means2d, conics, colors, opacities, image_width: int, image_height: int, tile_size: int, isect_offsets,
+    flatten_ids, backgrounds=None, masks=None,
+):
+    """gsplat.rasterize_to_pixels forward (RasterizeToPixels3DGSSerialBatchFwd.cu:41-297).
+    Returns render_colors [I,H,W,D], render_alphas [I,H,W,1], last_ids int32 [I,H,W]."""
+    off, I, th, tw, cdim, m2, cn, cl, op = _raster_common(means2d, conics, colors, opacities, isect_offsets)
+    fl = _np(flatten_ids, np.int32)
+    bg = None if backgrounds is None else _np(backgrounds, np.float32).reshape(I, cdim)
+    mk = None if masks is None else _np(masks, np.uint8).reshape(I, th, tw)
+    rc = np.zeros((I, image_height, image_width, cdim), dtype=np.float32)
+    ra = np.zeros((I, image_height, image_width, 1), dtype=np.float32)
+    li = np.zeros((I, image_height, image_width), dtype=np.int32)
+    lib().gso_raster3d_fwd(_p(m2), _p(cn), _p(cl), _p(op), _p(bg), _p(mk), _p(off), _p(fl), ctypes.c_uint32(I),
+                           ctypes.c_uint32(fl.shape[0]), ctypes.c_uint32(cdim), ctypes.c_uint32(image_width),
+                           ctypes.c_uint32(image_height), ctypes.c_uint32(tile_size), ctypes.c_uint32(tw),
+                           ctypes.c_uint32(th), _p(rc), _p(ra), _p(li))
+    return torch.from_numpy(rc), torch.from_numpy(ra), torch.from_numpy(li)
+
+
+def rasterize_to_pixels_bwd(
+    means2d, conics, colors, opacities, image_width: int, image_height: int, tile_size: int, isect_offsets,
+    flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas, backgrounds=None, masks=None,
+    absgrad: bool = False,
+):
+    """gsplat rasterize_to_pixels backward (RasterizeToPixels3DGSSerialBatchBwd.cu:41-320,
+    Rasterization.cpp:567-577 for v_backgrounds). Returns dict of float64 numpy arrays."""
+    off, I, th, tw, cdim, m2, cn, cl, op = _raster_common(means2d, conics, colors, opacities, isect_offsets)
+    fl = _np(flatten_ids, np.int32)
+    rows = m2.shape[0]
+    bg = None if backgrounds is None else _np(backgrounds, np.float32).reshape(I, cdim)
+    mk = None if masks is None else _np(masks, np.uint8).reshape(I, th, tw)
+    ra = _np(render_alphas, np.float32).reshape(I, image_height, image_width)
+    li = _np(last_ids, np.int32).reshape(I, image_height, image_width)
+    vc = _np(v_render_colors, np.float32).reshape(I, image_height, image_width, cdim)
+    va = _np(v_render_alphas, np.float32).reshape(I, image_height, image_width)
+    v_abs = np.zeros((rows, 2), dtype=np.float64) if absgrad else None
+    v_m = np.zeros((rows, 2), dtype=np.float64)
+    v_cn = np.zeros((rows, 3), dtype=np.float64)
+    v_cl = np.zeros((rows, cdim), dtype=np.float64)
+    v_op = np.zeros((rows,), dtype=np.float64)
+    lib().gso_raster3d_bwd(_p(m2), _p(cn), _p(cl), _p(op), _p(bg), _p(mk), _p(off), _p(fl), _p(ra), _p(li), _p(vc),
+                           _p(va), ctypes.c_uint32(I), ctypes.c_uint32(fl.shape[0]), ctypes.c_uint32(cdim),
+                           ctypes.c_uint32(image_width), ctypes.c_uint32(image_height), ctypes.c_uint32(tile_size),
+                           ctypes.c_uint32(tw), ctypes.c_uint32(th), ctypes.c_int64(rows), _p(v_abs), _p(v_m),
+                           _p(v_cn), _p(v_cl), _p(v_op))
+    out = {"v_means2d": v_m, "v_conics": v_cn, "v_colors": v_cl, "v_opacities": v_op}
+    if absgrad:
+        out["v_means2d_abs"] = v_abs
+    if backgrounds is not None:
+        # v_backgrounds = sum_{h,w} v_colors * (1 - alpha)   (Rasterization.cpp:567-577)
+        out["v_backgrounds"] = (vc.astype(np.float64) * (1.0 - ra.astype(np.float64))[..., None]).sum(axis=(1, 2))
+    return out
+
+
+def rasterize_to_indices(means2d, conics, opacities, image_width, image_height, tile_size, isect_offsets, flatten_ids):
+    """(gaussian_ids, pixel_ids, image_ids) of every contributing (gaussian, pixel) pair, the input
+    of the reference's torch compositor `accumulate` (RasterizeToIndices3DGSSerialBatch.cu:128-192)."""
+    off = _np(isect_offsets, np.int32)
+    I, th, tw = int(np.prod(off.shape[:-2])), off.shape[-2], off.shape[-1]
+    m2 = _np(means2d, np.float32)
+    n_per = m2.shape[-2]
+    m2 = m2.reshape(-1, 2)
+    cn = _np(conics, np.float32).reshape(-1, 3)
+    op = _np(opacities, np.float32).reshape(-1)
+    fl = _np(flatten_ids, np.int32)
+    args = [_p(m2), _p(cn), _p(op), _p(off), _p(fl), ctypes.c_uint32(I), ctypes.c_uint32(fl.shape[0]),
+            ctypes.c_uint32(n_per), ctypes.c_uint32(image_width), ctypes.c_uint32(image_height),
+            ctypes.c_uint32(tile_size), ctypes.c_uint32(tw), ctypes.c_uint32(th)]
+    n = lib().gso_raster3d_indices(*args, None, None, None)
+    g = np.zeros(n, dtype=np.int64)
+    p = np.zeros(n, dtype=np.int64)
+    i = np.zeros(n, dtype=np.int64)
+    lib().gso_raster3d_indices(*args, _p(g), _p(p), _p(i))
+    return torch.from_numpy(g), torch.from_numpy(p), torch.from_numpy(i)

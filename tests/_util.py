@@ -1,0 +1,67 @@
+"""Shared helpers for the parity tests (tolerance helpers follow the reference's gsplat/_helper.py ideas:
+mismatch ratios for decision-boundary flips, scale-relative gradient closeness)."""
+import math
+
+import numpy as np
+import torch
+
+
+def to_t(x, device="cpu"):
+    return torch.as_tensor(np.asarray(x)).to(device)
+
+
+def assert_close_ratio(actual, expected, rtol, atol, max_bad_ratio=0.0, name=""):
+    """|a-e| <= atol + rtol*|e| for all but `max_bad_ratio` of the elements (fp32 kernels with hardware
+    exp can flip a 1/255 or 1e-4 threshold decision on a handful of pixels — reference tests use the
+    same device: gsplat/_helper.py assert_mismatch_ratio)."""
+    a = torch.as_tensor(actual).double().cpu()
+    e = torch.as_tensor(expected).double().cpu()
+    assert a.shape == e.shape, f"{name}: shape {tuple(a.shape)} vs {tuple(e.shape)}"
+    err = (a - e).abs()
+    bad = err > (atol + rtol * e.abs())
+    ratio = bad.double().mean().item() if bad.numel() else 0.0
+    assert ratio <= max_bad_ratio, (
+        f"{name}: {bad.sum().item()}/{bad.numel()} elements out of tolerance (ratio {ratio:.2e} > {max_bad_ratio:.2e}), "
+        f"max err {err.max().item():.3e}")
+
+
+def assert_grad_close(actual, expected, rel=2e-3, max_bad_ratio=0.0, name=""):
+    """Gradient closeness relative to the tensor's own scale: |a-e| <= rel * max|e| (atomics accumulate in
+    unspecified fp32 order; the reference uses scale-relative atol too, tests/test_basic.py:474-504)."""
+    e = torch.as_tensor(expected).double().cpu()
+    scale = e.abs().max().item() + 1e-30
+    assert_close_ratio(torch.as_tensor(actual).double().cpu() / scale, e / scale, 0.0, rel, max_bad_ratio, name)
+    a = torch.as_tensor(actual).double().cpu().flatten()
+    ef = e.flatten()
+    if ef.norm() > 0:
+        cos = (a @ ef / (a.norm() * ef.norm() + 1e-30)).item()
+        assert cos > 0.9999, f"{name}: cosine {cos}"
+
+
+def make_scene(N=2000, C=2, width=160, height=120, seed=0, device="cpu", sh_degree=None, z_range=(2.0, 8.0),
+               scale_range=(0.02, 0.15)):
+    """Random but well-conditioned scene: Gaussians in front of C slightly different pinhole cameras."""
+    g = torch.Generator().manual_seed(seed)
+    fx = 0.9 * width
+    zs = torch.rand(N, generator=g) * (z_range[1] - z_range[0]) + z_range[0]
+    xs = (torch.rand(N, generator=g) - 0.5) * 1.3 * width / fx * zs
+    ys = (torch.rand(N, generator=g) - 0.5) * 1.3 * height / fx * zs
+    means = torch.stack([xs, ys, zs], -1)
+    quats = torch.nn.functional.normalize(torch.randn(N, 4, generator=g), dim=-1)
+    scales = torch.rand(N, 3, generator=g) * (scale_range[1] - scale_range[0]) + scale_range[0]
+    opacities = torch.rand(N, generator=g) * 0.9 + 0.05
+    viewmats = torch.eye(4).repeat(C, 1, 1)
+    for c in range(C):
+        ang = 0.05 * c
+        viewmats[c, 0, 0] = math.cos(ang); viewmats[c, 0, 2] = math.sin(ang)
+        viewmats[c, 2, 0] = -math.sin(ang); viewmats[c, 2, 2] = math.cos(ang)
+        viewmats[c, 0, 3] = 0.1 * c
+    Ks = torch.tensor([[fx, 0, width / 2], [0, fx, height / 2], [0, 0, 1.0]]).repeat(C, 1, 1)
+    if sh_degree is None:
+        colors = torch.rand(N, 3, generator=g)
+    else:
+        K = (sh_degree + 1) ** 2
+        colors = torch.randn(N, K, 3, generator=g) * 0.3
+        colors[:, 0, :] += 0.5
+    out = dict(means=means, quats=quats, scales=scales, opacities=opacities, viewmats=viewmats, Ks=Ks, colors=colors)
+    return {k: v.to(device).contiguous() for k, v in out.items()}, width, height

@@ -1,0 +1,403 @@
+"""GPU parity: every stage op (through torch.ops.gsplat.* -> C-ABI -> HIP kernels) against the CPU oracle
+on the same seeded inputs, and against the committed golden vectors produced by the reference's Python.
+
+Tolerances are the reference's own (tests/test_basic.py:427-504, 1271-1315, 2639-2692):
+integer outputs exact; fp32 forward rtol 1e-4/atol 1e-4 (projection), default fp32 closeness for renders;
+gradients scale-relative (atomics accumulate in unspecified fp32 order)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from _util import assert_close_ratio, assert_grad_close, make_scene, to_t
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import gsplat_amd
+
+    return gsplat_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+def cpu(t):
+    return None if t is None else t.detach().cpu()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_library_is_native_gfx950(G):
+    from gsplat_amd import _cabi
+
+    assert _cabi.ARCH == "gfx950"
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+@pytest.mark.parametrize("triu", [False, True])
+def test_quat_scale_to_covar_preci(G, O, triu):
+    N = 1000
+    q = torch.randn(N, 4)
+    s = torch.rand(N, 3) * 0.5 + 0.05
+    qg, sg = q.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
+    c, p = G.quat_scale_to_covar_preci(qg, sg, True, True, triu)
+    qo, so = q.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    c_o, p_o = O.quat_scale_to_covar_preci(qo, so, True, True, triu)
+    assert_close_ratio(cpu(c), c_o, 1e-5, 1e-6, name="covars")
+    assert_close_ratio(cpu(p), p_o, 1e-4, 1e-3, name="precis")
+    wc, wp = torch.randn_like(c_o), torch.randn_like(p_o) * 1e-3
+    (c * wc.to(DEV)).sum().add((p * wp.to(DEV)).sum()).backward()
+    (c_o * wc).sum().add((p_o * wp).sum()).backward()
+    assert_grad_close(cpu(qg.grad), qo.grad, rel=1e-4, name="v_quats")
+    assert_grad_close(cpu(sg.grad), so.grad, rel=1e-4, name="v_scales")
+    only_c, none_p = G.quat_scale_to_covar_preci(qg, sg, True, False, triu)
+    assert none_p is None and only_c.shape == c.shape
+
+
+def _proj_both(G, O, sc, W, H, cam, use_covars=False, opac=True, comp=True, radius_clip=0.0, grads=True):
+    names = ("means", "quats", "scales", "viewmats")
+    tg = {k: sc[k].to(DEV).clone().requires_grad_(grads) for k in names}
+    to = {k: sc[k].clone().requires_grad_(grads) for k in names}
+    ops_g = sc["opacities"].to(DEV) if opac else None
+    ops_o = sc["opacities"][None] if opac else None
+    cov_g = cov_o = None
+    if use_covars:
+        cov_o6 = O.quat_scale_to_covar_preci(to["quats"], to["scales"], True, False, True)[0]
+        cov_g6 = G.quat_scale_to_covar_preci(tg["quats"], tg["scales"], True, False, True)[0]
+        cov_g, cov_o = cov_g6, cov_o6[None]
+    out_g = G.fully_fused_projection(tg["means"], cov_g, None if use_covars else tg["quats"],
+                                     None if use_covars else tg["scales"], tg["viewmats"], sc["Ks"].to(DEV), W, H,
+                                     eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=radius_clip, packed=False,
+                                     calc_compensations=comp, camera_model=cam, opacities=ops_g)
+    out_o = O.fully_fused_projection(to["means"][None], cov_o, None if use_covars else to["quats"][None],
+                                     None if use_covars else to["scales"][None], to["viewmats"][None], sc["Ks"][None],
+                                     W, H, 0.3, 0.01, 1e10, radius_clip, comp, cam, ops_o)
+    out_o = [None if o is None else o[0] for o in out_o]
+    return tg, to, out_g, out_o
+
+
+@pytest.mark.parametrize("cam", ["pinhole", "ortho", "fisheye"])
+@pytest.mark.parametrize("use_covars", [False, True])
+def test_projection_dense_fwd_bwd(G, O, cam, use_covars):
+    sc, W, H = make_scene(N=4000, C=3, width=200, height=150, seed=1)
+    if cam == "ortho":
+        sc["Ks"][:, 0, 0] = sc["Ks"][:, 1, 1] = 20.0
+    tg, to, (rad, m2, d, con, comp), (rad_o, m2_o, d_o, con_o, comp_o) = _proj_both(G, O, sc, W, H, cam, use_covars)
+    vis_g, vis_o = (cpu(rad) > 0).all(-1), (rad_o > 0).all(-1)
+    assert (vis_g == vis_o).float().mean() > 0.999, "visibility decisions differ"
+    valid = vis_g & vis_o
+    assert valid.sum() > 500
+    assert (cpu(rad)[valid] - rad_o[valid]).abs().max() <= 1
+    assert_close_ratio(cpu(m2)[valid], m2_o[valid], 1e-4, 1e-4, name="means2d")
+    assert_close_ratio(cpu(d)[valid], d_o[valid], 1e-4, 1e-4, name="depths")
+    assert_close_ratio(cpu(con)[valid], con_o[valid], 1e-4, 1e-4, name="conics")
+    assert_close_ratio(cpu(comp)[valid], comp_o[valid], 1e-4, 1e-3, name="compensations")
+    # culled rows are zero-filled (deterministic, unlike the reference's uninitialised memory)
+    assert cpu(m2)[~vis_g].abs().max() == 0 and cpu(con)[~vis_g].abs().max() == 0
+    # gradients: same random cotangents, restricted to commonly-valid rows
+    vm = valid[..., None].float()
+    w2, wd, wc, wk = (torch.randn_like(m2_o), torch.randn_like(d_o), torch.randn_like(con_o) * 1e-2,
+                      torch.randn_like(comp_o))
+    loss_o = (m2_o * w2 * vm).sum() + (d_o * wd * valid).sum() + (con_o * wc * vm).sum() + (comp_o * wk * valid).sum()
+    loss_g = ((m2 * (w2 * vm).to(DEV)).sum() + (d * (wd * valid).to(DEV)).sum() + (con * (wc * vm).to(DEV)).sum()
+              + (comp * (wk * valid).to(DEV)).sum())
+    loss_o.backward()
+    loss_g.backward()
+    for k in ("means", "quats", "scales", "viewmats"):
+        assert_grad_close(cpu(tg[k].grad), to[k].grad, rel=2e-3, name=f"v_{k}")
+
+
+def test_projection_culling_rules(G, O):
+    sc, W, H = make_scene(N=3000, C=2, width=160, height=120, seed=2, z_range=(0.5, 30.0))
+    sc["opacities"][:500] = 0.002  # below 1/255 -> culled when opacities are passed
+    _, _, (rad, *_), (rad_o, *_) = _proj_both(G, O, sc, W, H, "pinhole", opac=True, comp=False, radius_clip=2.0,
+                                              grads=False)
+    vis_g, vis_o = (cpu(rad) > 0).all(-1), (rad_o > 0).all(-1)
+    assert (vis_g == vis_o).float().mean() > 0.999
+    assert not vis_g[:, :500].any()
+    big = (cpu(rad) > 0).all(-1)
+    assert (cpu(rad)[big].max(-1).values > 2).all(), "radius_clip must drop splats with both radii <= clip"
+
+
+@pytest.mark.parametrize("sparse_grad", [False])
+def test_projection_packed_matches_dense(G, sparse_grad):
+    sc, W, H = make_scene(N=5000, C=3, width=200, height=150, seed=3)
+    a = {k: v.to(DEV) for k, v in sc.items()}
+    leaves_d = [a[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "viewmats")]
+    leaves_p = [a[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "viewmats")]
+    kw = dict(eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0, calc_compensations=True,
+              camera_model="pinhole", opacities=a["opacities"])
+    rad, m2, d, con, comp = G.fully_fused_projection(leaves_d[0], None, leaves_d[1], leaves_d[2], leaves_d[3], a["Ks"],
+                                                     W, H, packed=False, **kw)
+    bi, ci, gi, indptr, rad_p, m2_p, d_p, con_p, comp_p = G.fully_fused_projection(
+        leaves_p[0], None, leaves_p[1], leaves_p[2], leaves_p[3], a["Ks"], W, H, packed=True, sparse_grad=sparse_grad,
+        **kw)
+    vis = (rad > 0).all(-1)
+    ci_d, gi_d = torch.where(vis)
+    assert bi.dtype == torch.int64 and (bi == 0).all()
+    assert torch.equal(ci, ci_d) and torch.equal(gi, gi_d), "packed rows must be ordered by (camera, gaussian)"
+    assert torch.equal(rad_p, rad[vis]) and torch.equal(m2_p, m2[vis]) and torch.equal(con_p, con[vis])
+    assert torch.equal(d_p, d[vis]) and torch.equal(comp_p, comp[vis])
+    counts = vis.sum(-1).cumsum(0)
+    assert indptr.dtype == torch.int32 and indptr[0] == 0 and torch.equal(indptr[1:].long(), counts)
+    w2, wd, wc, wk = torch.randn_like(m2_p), torch.randn_like(d_p), torch.randn_like(con_p) * 1e-2, torch.randn_like(comp_p)
+    ((m2_p * w2).sum() + (d_p * wd).sum() + (con_p * wc).sum() + (comp_p * wk).sum()).backward()
+    ((m2[vis] * w2).sum() + (d[vis] * wd).sum() + (con[vis] * wc).sum() + (comp[vis] * wk).sum()).backward()
+    for nm, lp, ld in zip(("means", "quats", "scales", "viewmats"), leaves_p, leaves_d):
+        assert_grad_close(cpu(lp.grad), cpu(ld.grad), rel=1e-4, name=f"packed v_{nm}")
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
+def test_spherical_harmonics_dense(G, O, deg):
+    sc, W, H = make_scene(N=3000, C=3, seed=4)
+    K = 25
+    coeffs = torch.randn(3000, K, 3) * 0.3
+    masks = torch.rand(3, 3000) > 0.2
+    mg = sc["means"].to(DEV).requires_grad_(True)
+    cg = coeffs.to(DEV).requires_grad_(True)
+    col = G.spherical_harmonics(deg, mg, sc["viewmats"].to(DEV), cg, masks=masks.to(DEV))
+    mo, co = sc["means"].clone().requires_grad_(True), coeffs.clone().requires_grad_(True)
+    col_o = O.spherical_harmonics(deg, mo[None], sc["viewmats"][None], co, masks[None])[0]
+    assert_close_ratio(cpu(col), col_o, 1e-5, 1e-5, name="sh colors")
+    w = torch.randn_like(col_o)
+    (col * w.to(DEV)).sum().backward()
+    (col_o * w).sum().backward()
+    assert_grad_close(cpu(cg.grad), co.grad, rel=1e-5, name="v_coeffs")
+    if deg > 0:
+        assert_grad_close(cpu(mg.grad), mo.grad, rel=1e-4, name="v_means")
+    else:
+        assert cpu(mg.grad).abs().max() < 1e-6
+
+
+def test_spherical_harmonics_packed(G, O):
+    sc, W, H = make_scene(N=2000, C=2, seed=5)
+    coeffs = torch.randn(2000, 16, 3) * 0.3
+    vis = torch.rand(2, 2000) > 0.5
+    ci, gi = torch.where(vis)
+    bi = torch.zeros_like(ci)
+    mg = sc["means"].to(DEV).requires_grad_(True)
+    cg = coeffs.to(DEV).requires_grad_(True)
+    col = G.spherical_harmonics(3, mg, sc["viewmats"].to(DEV), cg[gi.to(DEV)], batch_ids=bi.to(DEV),
+                                camera_ids=ci.to(DEV), gaussian_ids=gi.to(DEV))
+    mo, co = sc["means"].clone().requires_grad_(True), coeffs.clone().requires_grad_(True)
+    col_o = O.spherical_harmonics(3, mo[None], sc["viewmats"][None], co)[0][vis]
+    assert_close_ratio(cpu(col), col_o, 1e-5, 1e-5, name="packed sh colors")
+    w = torch.randn_like(col_o)
+    (col * w.to(DEV)).sum().backward()
+    (col_o * w).sum().backward()
+    assert_grad_close(cpu(cg.grad), co.grad, rel=1e-5, name="packed v_coeffs")
+    assert_grad_close(cpu(mg.grad), mo.grad, rel=1e-4, name="packed v_means")
+
+
+# ------------------------------------------------------------------------------------------------
+def _project_scene(G, sc, W, H):
+    a = {k: v.to(DEV) for k, v in sc.items()}
+    rad, m2, d, con, _ = G.fully_fused_projection(a["means"], None, a["quats"], a["scales"], a["viewmats"], a["Ks"],
+                                                  W, H, opacities=a["opacities"])
+    op = a["opacities"][None].expand(m2.shape[0], -1).contiguous()
+    return a, rad, m2, d, con, op
+
+
+@pytest.mark.parametrize("mode", ["aabb", "ellipse"])
+@pytest.mark.parametrize("tile_size", [16, 8])
+def test_isect_exact_dense(G, O, mode, tile_size):
+    sc, W, H = make_scene(N=20000, C=3, width=320, height=200, seed=6)
+    a, rad, m2, d, con, op = _project_scene(G, sc, W, H)
+    tw, th = math.ceil(W / tile_size), math.ceil(H / tile_size)
+    kw = dict(conics=con, opacities=op) if mode == "ellipse" else {}
+    tpg, ids, fl = G.isect_tiles(m2, rad, d, tile_size, tw, th, **kw)
+    kwo = dict(conics=cpu(con), opacities=cpu(op)) if mode == "ellipse" else {}
+    tpg_o, ids_o, fl_o = O.isect_tiles(cpu(m2), cpu(rad), cpu(d), tile_size, tw, th, **kwo)
+    assert tpg.dtype == torch.int32 and ids.dtype == torch.int64 and fl.dtype == torch.int32
+    assert torch.equal(cpu(tpg), tpg_o), "tiles_per_gauss must be bit-exact"
+    assert torch.equal(cpu(ids), ids_o), "sorted isect_ids must be bit-exact"
+    assert torch.equal(cpu(fl), fl_o), "flatten_ids must be bit-exact (stable sort)"
+    off = G.isect_offset_encode(ids, 3, tw, th)
+    assert torch.equal(cpu(off), O.isect_offset_encode(ids_o, 3, tw, th))
+    # unsorted emission order is part of the contract too
+    _, ids_u, fl_u = G.isect_tiles(m2, rad, d, tile_size, tw, th, sort=False, **kw)
+    _, ids_uo, fl_uo = O.isect_tiles(cpu(m2), cpu(rad), cpu(d), tile_size, tw, th, sort=False, **kwo)
+    assert torch.equal(cpu(ids_u), ids_uo) and torch.equal(cpu(fl_u), fl_uo)
+
+
+def test_isect_packed_and_edge_cases(G, O):
+    sc, W, H = make_scene(N=6000, C=2, width=200, height=120, seed=7)
+    a, rad, m2, d, con, op = _project_scene(G, sc, W, H)
+    vis = (rad > 0).all(-1)
+    ci, gi = torch.where(vis)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    tpg, ids, fl = G.isect_tiles(m2[vis], rad[vis], d[vis], 16, tw, th, packed=True, n_images=2, image_ids=ci,
+                                 gaussian_ids=gi, conics=con[vis], opacities=op[vis])
+    tpg_o, ids_o, fl_o = O.isect_tiles(cpu(m2[vis]), cpu(rad[vis]), cpu(d[vis]), 16, tw, th, conics=cpu(con[vis]),
+                                       opacities=cpu(op[vis]), image_ids=cpu(ci), n_images=2)
+    assert torch.equal(cpu(tpg), tpg_o) and torch.equal(cpu(ids), ids_o) and torch.equal(cpu(fl), fl_o)
+    # packed and dense describe the same (image, tile, depth) multiset
+    _, ids_d, _ = G.isect_tiles(m2, rad, d, 16, tw, th, conics=con, opacities=op)
+    assert torch.equal(ids, ids_d)
+    # nothing visible -> empty lists, zero offsets
+    z = torch.zeros_like(rad)
+    tpg0, ids0, fl0 = G.isect_tiles(m2, z, d, 16, tw, th)
+    assert tpg0.sum() == 0 and ids0.numel() == 0 and fl0.numel() == 0
+    off0 = G.isect_offset_encode(ids0, 2, tw, th)
+    assert off0.shape == (2, th, tw) and off0.abs().sum() == 0
+    # zero Gaussians
+    e = torch.empty(1, 0, 2, device=DEV)
+    tpg_e, ids_e, _ = G.isect_tiles(e, e.int(), torch.empty(1, 0, device=DEV), 16, tw, th)
+    assert tpg_e.shape == (1, 0) and ids_e.numel() == 0
+    # key-width overflow is rejected like the reference (Intersect.cpp:219-228)
+    with pytest.raises(RuntimeError):
+        G.isect_tiles(m2[:1], rad[:1], d[:1], 1, 70000, 70000)
+
+
+@pytest.mark.parametrize("n", [1, 63, 4096, 4097, 100_003, 3_000_000])
+def test_radix_sort_matches_stable_sort(G, n):
+    from gsplat_amd import _cabi
+
+    g = torch.Generator(device="cpu").manual_seed(n)
+    # few distinct keys -> many ties -> exercises stability
+    keys = torch.randint(0, 1 << 20, (n,), generator=g, dtype=torch.int64) << 25
+    keys |= torch.randint(0, 4, (n,), generator=g, dtype=torch.int64)
+    vals = torch.arange(n, dtype=torch.int32)
+    k, v = keys.to(DEV), vals.to(DEV)
+    k2, v2 = torch.empty_like(k), torch.empty_like(v)
+    ws = torch.empty(_cabi.sort_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    in_alt = _cabi.sort_pairs(k, v, k2, v2, n, 46, ws)
+    ks, vs = (k2, v2) if in_alt else (k, v)
+    order = np.argsort(keys.numpy(), kind="stable")
+    assert torch.equal(cpu(ks), keys[order]) and torch.equal(cpu(vs), vals[order])
+
+
+@pytest.mark.parametrize("n", [1, 255, 4096, 4097, 1_000_001])
+def test_scan(G, n):
+    from gsplat_amd._ops import _scan_i32
+
+    x = torch.randint(0, 50, (n,), dtype=torch.int32)
+    assert torch.equal(cpu(_scan_i32(x.to(DEV))), torch.cumsum(x.long(), 0))
+
+
+# ------------------------------------------------------------------------------------------------
+def _raster_case(G, O, N, C, W, H, tile_size, D, seed, bg=False, masks=False, absgrad=False, packed=False):
+    sc, W, H = make_scene(N=N, C=C, width=W, height=H, seed=seed)
+    a, rad, m2, d, con, op = _project_scene(G, sc, W, H)
+    tw, th = math.ceil(W / tile_size), math.ceil(H / tile_size)
+    g = torch.Generator().manual_seed(seed)
+    colors = torch.rand(C, N, D, generator=g).to(DEV)
+    backgrounds = torch.rand(C, D, generator=g).to(DEV) if bg else None
+    tile_masks = (torch.rand(C, th, tw, generator=g) > 0.3).to(DEV) if masks else None
+    if packed:
+        vis = (rad > 0).all(-1)
+        ci, gi = torch.where(vis)
+        m2, con, op, colors, radp, dp = m2[vis], con[vis], op[vis], colors[vis], rad[vis], d[vis]
+        _, ids, fl = G.isect_tiles(m2, radp, dp, tile_size, tw, th, packed=True, n_images=C, image_ids=ci,
+                                   gaussian_ids=gi, conics=con, opacities=op)
+    else:
+        _, ids, fl = G.isect_tiles(m2, rad, d, tile_size, tw, th, conics=con, opacities=op)
+    off = G.isect_offset_encode(ids, C, tw, th)
+    leaves = [t.clone().requires_grad_(True) for t in (m2, con, colors, op)]
+    bgl = backgrounds.clone().requires_grad_(True) if bg else None
+    rc, ra = G.rasterize_to_pixels(leaves[0], leaves[1], leaves[2], leaves[3], W, H, tile_size, off, fl,
+                                   backgrounds=bgl, masks=tile_masks, packed=packed, absgrad=absgrad)
+    rc_o, ra_o, li_o = O.rasterize_to_pixels(cpu(m2), cpu(con), cpu(colors), cpu(op), W, H, tile_size, cpu(off),
+                                             cpu(fl), backgrounds=cpu(backgrounds), masks=cpu(tile_masks))
+    # hardware exp vs libm exp can flip a threshold decision on a few pixels: allow 1e-4 of them
+    assert_close_ratio(cpu(rc), rc_o, 1e-4, 2e-5, max_bad_ratio=1e-4, name="render_colors")
+    assert_close_ratio(cpu(ra), ra_o, 1e-4, 2e-5, max_bad_ratio=1e-4, name="render_alphas")
+    v_rc, v_ra = torch.randn(rc_o.shape, generator=g), torch.randn(ra_o.shape, generator=g)
+    ((rc * v_rc.to(DEV)).sum() + (ra * v_ra.to(DEV)).sum()).backward()
+    # the oracle backward starts from ITS OWN forward state, like the kernel does from its own
+    go = O.rasterize_to_pixels_bwd(cpu(m2), cpu(con), cpu(colors), cpu(op), W, H, tile_size, cpu(off), cpu(fl), ra_o,
+                                   li_o, v_rc, v_ra, backgrounds=cpu(backgrounds), masks=cpu(tile_masks),
+                                   absgrad=absgrad)
+    for leaf, key in zip(leaves, ("v_means2d", "v_conics", "v_colors", "v_opacities")):
+        assert_grad_close(cpu(leaf.grad), go[key].reshape(leaf.shape), rel=2e-3, max_bad_ratio=2e-4, name=key)
+    if bg:
+        assert_grad_close(cpu(bgl.grad), go["v_backgrounds"], rel=1e-3, name="v_backgrounds")
+    if absgrad:
+        assert_grad_close(cpu(leaves[0].absgrad), go["v_means2d_abs"].reshape(leaves[0].shape), rel=2e-3,
+                          max_bad_ratio=2e-4, name="absgrad")
+    return rc, ra
+
+
+@pytest.mark.parametrize("D", [1, 3, 5, 32, 40])
+def test_rasterize_channels(G, O, D):
+    _raster_case(G, O, N=6000, C=2, W=200, H=136, tile_size=16, D=D, seed=10 + D, bg=True)
+
+
+@pytest.mark.parametrize("tile_size", [16, 8, 4])
+def test_rasterize_tile_sizes(G, O, tile_size):
+    _raster_case(G, O, N=3000, C=1, W=150, H=100, tile_size=tile_size, D=3, seed=20 + tile_size, bg=True)
+
+
+def test_rasterize_masks_absgrad_packed(G, O):
+    _raster_case(G, O, N=6000, C=2, W=200, H=136, tile_size=16, D=3, seed=31, bg=True, masks=True, absgrad=True)
+    _raster_case(G, O, N=6000, C=2, W=200, H=136, tile_size=16, D=3, seed=32, bg=False, packed=True)
+
+
+def test_rasterize_dense_overdraw_long_lists(G, O):
+    """Many large splats: per-tile lists span several 256-entry batches and pixels saturate (early exit)."""
+    sc, W, H = make_scene(N=8000, C=1, width=96, height=64, seed=40, scale_range=(0.3, 0.8))
+    sc["opacities"][:] = 0.9
+    a, rad, m2, d, con, op = _project_scene(G, sc, W, H)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    _, ids, fl = G.isect_tiles(m2, rad, d, 16, tw, th, conics=con, opacities=op)
+    off = G.isect_offset_encode(ids, 1, tw, th)
+    assert (torch.diff(torch.cat([off.flatten(), torch.tensor([ids.numel()], device=DEV, dtype=torch.int32)])).max()
+            > 1000)
+    colors = torch.rand(1, 8000, 3, device=DEV)
+    rc, ra = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl)
+    rc_o, ra_o, _ = O.rasterize_to_pixels(cpu(m2), cpu(con), cpu(colors), cpu(op), W, H, 16, cpu(off), cpu(fl))
+    assert_close_ratio(cpu(rc), rc_o, 1e-4, 5e-5, max_bad_ratio=1e-3, name="render_colors")
+    assert_close_ratio(cpu(ra), ra_o, 1e-4, 5e-5, max_bad_ratio=1e-3, name="render_alphas")
+    assert ra.max() <= 1.0 and ra.min() >= 0.0 and (ra > 0.999).float().mean() > 0.5
+
+
+def test_golden_rasterize_vs_reference_outputs(G, golden):
+    """HIP kernels against outputs of the REFERENCE's accumulate()+autograd (committed fixture)."""
+    W, H, ts = (int(v) for v in golden["rast_wh"])
+    t = {k: to_t(golden["rast_" + k], DEV) for k in ("means2d", "conics", "colors", "opacities", "offsets",
+                                                     "flatten_ids", "backgrounds")}
+    leaves = [t[k].clone().requires_grad_(True) for k in ("means2d", "conics", "colors", "opacities", "backgrounds")]
+    rc, ra = G.rasterize_to_pixels(leaves[0], leaves[1], leaves[2], leaves[3], W, H, ts, t["offsets"],
+                                   t["flatten_ids"], backgrounds=leaves[4])
+    assert_close_ratio(cpu(rc), golden["rast_render_colors"], 1e-4, 2e-5, max_bad_ratio=1e-4, name="render_colors")
+    assert_close_ratio(cpu(ra), golden["rast_render_alphas"], 1e-4, 2e-5, max_bad_ratio=1e-4, name="render_alphas")
+    ((rc * to_t(golden["rast_v_render_colors"], DEV)).sum() + (ra * to_t(golden["rast_v_render_alphas"], DEV)).sum()).backward()
+    for leaf, key in zip(leaves, ("v_means2d", "v_conics", "v_colors", "v_opacities", "v_backgrounds")):
+        assert_grad_close(cpu(leaf.grad), golden["rast_" + key], rel=2e-3, max_bad_ratio=2e-4, name=key)
+
+
+def test_golden_isect_and_projection_vs_reference_outputs(G, golden):
+    ts, tw, th = (int(v) for v in golden["isect_tile"])
+    m2, rad, dep = (to_t(golden[k], DEV) for k in ("isect_means2d", "isect_radii", "isect_depths"))
+    tpg, ids, fl = G.isect_tiles(m2, rad, dep, ts, tw, th)
+    assert torch.equal(cpu(tpg), to_t(golden["isect_tiles_per_gauss"]))
+    assert torch.equal(cpu(ids), to_t(golden["isect_ids"])) and torch.equal(cpu(fl), to_t(golden["isect_flatten_ids"]))
+    assert torch.equal(cpu(G.isect_offset_encode(ids, m2.shape[0], tw, th)), to_t(golden["isect_offsets"]))
+    W, H = (int(v) for v in golden["proj_wh"])
+    for cam in ("pinhole", "ortho", "fisheye"):
+        rad, m2, d, con, comp = G.fully_fused_projection(
+            to_t(golden["proj_means"], DEV), None, to_t(golden["proj_quats"], DEV), to_t(golden["proj_scales"], DEV),
+            to_t(golden["proj_viewmats"], DEV), to_t(golden["proj_Ks"], DEV), W, H, calc_compensations=True,
+            camera_model=cam)
+        r_ref = to_t(golden[f"proj_{cam}_radii"])
+        valid = (cpu(rad) > 0).all(-1) & (r_ref > 0).all(-1)
+        assert ((cpu(rad) > 0).all(-1) == (r_ref > 0).all(-1)).float().mean() > 0.999
+        assert (cpu(rad)[valid] - r_ref[valid]).abs().max() <= 1
+        assert_close_ratio(cpu(m2)[valid], to_t(golden[f"proj_{cam}_means2d"])[valid], 1e-4, 1e-4, name="means2d")
+        assert_close_ratio(cpu(con)[valid], to_t(golden[f"proj_{cam}_conics"])[valid], 1e-4, 1e-4, name="conics")
+        assert_close_ratio(cpu(comp)[valid], to_t(golden[f"proj_{cam}_comps"])[valid], 1e-4, 1e-3, name="comps")
+    for deg in range(5):
+        col = G.spherical_harmonics(deg, to_t(golden["proj_means"], DEV), to_t(golden["proj_viewmats"], DEV),
+                                    to_t(golden["sh_coeffs"], DEV))
+        assert_close_ratio(cpu(col), golden[f"sh_colors_deg{deg}"], 1e-5, 1e-5, name=f"sh{deg}")

@@ -1,0 +1,139 @@
+"""CPU: the oracle (oracle/) against the golden vectors produced by the REFERENCE's own Python
+(tests/golden/garden_quarter.npz, written by oracle/pin_against_reference.py from
+gsplat/cuda/_torch_impl.py + accumulate()). Keeps the oracle pinned on machines without /root/reference."""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+from _util import assert_close_ratio, assert_grad_close, to_t
+
+
+def test_quat_scale_to_covar_preci(golden):
+    q, s = to_t(golden["qs_quats"]), to_t(golden["qs_scales"])
+    c, p = O.quat_scale_to_covar_preci(q, s, True, True, True)
+    assert_close_ratio(c, golden["qs_covars_triu"], 1e-5, 1e-7, name="covars")
+    assert_close_ratio(p, golden["qs_precis_triu"], 1e-4, 1e-2, name="precis")
+
+
+def _proj(golden, cam, requires_grad=False):
+    means, quats, scales = (to_t(golden[k]).clone() for k in ("proj_means", "proj_quats", "proj_scales"))
+    viewmats, Ks = to_t(golden["proj_viewmats"]).clone(), to_t(golden["proj_Ks"])
+    W, H = (int(v) for v in golden["proj_wh"])
+    if requires_grad:
+        for t in (means, quats, scales, viewmats):
+            t.requires_grad_(True)
+    out = O.fully_fused_projection(means[None], None, quats[None], scales[None], viewmats[None], Ks[None], W, H, 0.3,
+                                   0.01, 1e10, 0.0, True, cam, None)
+    return (means, quats, scales, viewmats), [o[0] for o in out]
+
+
+def test_projection_forward_all_camera_models(golden):
+    for cam in ("pinhole", "ortho", "fisheye"):
+        _, (radii, m2, d, con, comp) = _proj(golden, cam)
+        r_ref = to_t(golden[f"proj_{cam}_radii"])
+        valid = (radii > 0).all(-1) & (r_ref > 0).all(-1)
+        assert ((radii > 0).all(-1) == (r_ref > 0).all(-1)).float().mean() > 0.999
+        assert (radii[valid] - r_ref[valid]).abs().max() <= 1
+        assert_close_ratio(m2[valid], to_t(golden[f"proj_{cam}_means2d"])[valid], 1e-4, 1e-4, name=f"{cam} means2d")
+        assert_close_ratio(d[valid], to_t(golden[f"proj_{cam}_depths"])[valid], 1e-4, 1e-4, name=f"{cam} depths")
+        assert_close_ratio(con[valid], to_t(golden[f"proj_{cam}_conics"])[valid], 1e-4, 1e-4, name=f"{cam} conics")
+        assert_close_ratio(comp[valid], to_t(golden[f"proj_{cam}_comps"])[valid], 1e-4, 1e-3, name=f"{cam} comps")
+
+
+def test_projection_backward_matches_reference_autograd(golden):
+    for cam in ("pinhole", "ortho", "fisheye"):
+        inputs, (radii, m2, d, con, comp) = _proj(golden, cam, requires_grad=True)
+        w = to_t(golden[f"proj_{cam}_w"])
+        valid = to_t(golden[f"proj_{cam}_valid"])
+        vm = valid[..., None].float()
+        loss = ((m2 * w[..., 0:2] * vm).sum() + (d * w[..., 2] * valid).sum() + (con * w[..., 3:6] * vm).sum()
+                + (comp * w[..., 6] * valid).sum())
+        grads = torch.autograd.grad(loss, inputs)
+        for nm, g in zip(("v_means", "v_quats", "v_scales", "v_viewmats"), grads):
+            assert_grad_close(g, golden[f"proj_{cam}_{nm}"], rel=2e-3, name=f"{cam} {nm}")
+
+
+def test_spherical_harmonics(golden):
+    means, viewmats = to_t(golden["proj_means"]), to_t(golden["proj_viewmats"])
+    coeffs = to_t(golden["sh_coeffs"])
+    for deg in range(5):
+        c = O.spherical_harmonics(deg, means[None], viewmats[None], coeffs)[0]
+        assert_close_ratio(c, golden[f"sh_colors_deg{deg}"], 1e-5, 1e-5, name=f"sh deg {deg}")
+
+
+def test_isect_exact(golden):
+    ts, tw, th = (int(v) for v in golden["isect_tile"])
+    m2, rad, dep = to_t(golden["isect_means2d"]), to_t(golden["isect_radii"]), to_t(golden["isect_depths"])
+    tpg, ids, fl = O.isect_tiles(m2, rad, dep, ts, tw, th, sort=True)
+    assert torch.equal(tpg, to_t(golden["isect_tiles_per_gauss"]))
+    assert torch.equal(ids, to_t(golden["isect_ids"]))
+    assert torch.equal(fl, to_t(golden["isect_flatten_ids"]))
+    off = O.isect_offset_encode(ids, m2.shape[0], tw, th)
+    assert torch.equal(off, to_t(golden["isect_offsets"]))
+    # ellipse mode: committed oracle vector (no Python restatement exists in the reference)
+    tpa, ida, fla = O.isect_tiles(m2, rad, dep, ts, tw, th, sort=True, conics=to_t(golden["isect_conics"]),
+                                  opacities=to_t(golden["isect_opacities"]))
+    assert torch.equal(tpa, to_t(golden["isect_accu_tiles_per_gauss"]))
+    assert torch.equal(ida, to_t(golden["isect_accu_ids"]))
+    assert torch.equal(fla, to_t(golden["isect_accu_flatten_ids"]))
+    assert (tpa <= tpg).all()
+
+
+def _rast_inputs(golden):
+    W, H, ts = (int(v) for v in golden["rast_wh"])
+    keys = ("rast_means2d", "rast_conics", "rast_colors", "rast_opacities", "rast_offsets", "rast_flatten_ids",
+            "rast_backgrounds")
+    return (W, H, ts) + tuple(to_t(golden[k]) for k in keys)
+
+
+def test_rasterize_forward_vs_reference_accumulate(golden):
+    W, H, ts, m2, con, col, op, off, fl, bg = _rast_inputs(golden)
+    rc, ra, li = O.rasterize_to_pixels(m2, con, col, op, W, H, ts, off, fl, backgrounds=bg)
+    assert_close_ratio(rc, golden["rast_render_colors"], 1e-5, 2e-5, name="render_colors")
+    assert_close_ratio(ra, golden["rast_render_alphas"], 1e-5, 2e-5, name="render_alphas")
+    assert torch.equal(li, to_t(golden["rast_last_ids"]))
+
+
+def test_rasterize_backward_vs_reference_autograd(golden):
+    W, H, ts, m2, con, col, op, off, fl, bg = _rast_inputs(golden)
+    _, ra, li = O.rasterize_to_pixels(m2, con, col, op, W, H, ts, off, fl, backgrounds=bg)
+    g = O.rasterize_to_pixels_bwd(m2, con, col, op, W, H, ts, off, fl, ra, li, to_t(golden["rast_v_render_colors"]),
+                                  to_t(golden["rast_v_render_alphas"]), backgrounds=bg)
+    for k in ("v_means2d", "v_conics", "v_colors", "v_opacities", "v_backgrounds"):
+        assert_grad_close(g[k].reshape(golden["rast_" + k].shape), golden["rast_" + k], rel=5e-4, name=k)
+
+
+def test_rasterize_closed_form_single_gaussian():
+    """One isotropic Gaussian centred on a pixel centre: alpha = min(.99, o*exp(-r^2/(2 s^2)))."""
+    W = H = 16
+    s2, o = 4.0, 0.8
+    m2 = torch.tensor([[[8.5, 8.5]]])
+    con = torch.tensor([[[1 / s2, 0.0, 1 / s2]]])
+    col = torch.tensor([[[0.25, 0.5, 1.0]]])
+    op = torch.tensor([[o]])
+    off = torch.zeros(1, 1, 1, dtype=torch.int32)
+    fl = torch.zeros(1, dtype=torch.int32)
+    rc, ra, li = O.rasterize_to_pixels(m2, con, col, op, W, H, 16, off, fl)
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    r2 = (xs - 8.5) ** 2 + (ys - 8.5) ** 2
+    a = torch.clamp_max(o * torch.exp(-0.5 * r2 / s2), 0.99)
+    a = torch.where(a < 1 / 255, torch.zeros_like(a), a)
+    assert_close_ratio(ra[0, ..., 0], a, 1e-6, 1e-6, name="alpha")
+    assert_close_ratio(rc[0], a[..., None] * col[0, 0], 1e-6, 1e-6, name="color")
+
+
+def test_rasterize_saturating_gaussian_is_excluded():
+    """Two opaque splats then a third: T after two = 1e-4 -> the SECOND one already hits T' <= 1e-4 and is
+    excluded (exclusive stop, RasterizeToPixels3DGSDevice.cuh:86-90)."""
+    m2 = torch.tensor([[[0.5, 0.5]] * 3])
+    con = torch.tensor([[[1e-6, 0.0, 1e-6]] * 3])
+    col = torch.tensor([[[1.0], [2.0], [4.0]]])
+    op = torch.tensor([[1.0, 1.0, 1.0]])
+    off = torch.zeros(1, 1, 1, dtype=torch.int32)
+    fl = torch.arange(3, dtype=torch.int32)
+    rc, ra, li = O.rasterize_to_pixels(m2, con, col, op, 1, 1, 16, off, fl)
+    assert abs(ra.item() - 0.99) < 1e-6 and abs(rc.item() - 0.99) < 1e-6 and li.item() == 0
+
+
+def test_bits_for_count():
+    assert [O.bits_for_count(n) for n in (0, 1, 2, 3, 4, 5, 8, 9, 8160)] == [0, 0, 1, 2, 2, 3, 3, 4, 13]
