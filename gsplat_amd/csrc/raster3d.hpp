@@ -79,4 +79,46 @@ __device__ __forceinline__ void tile_pixel(uint32_t tid, uint32_t tile_size, uin
     }
 }
 
+// ---- wave-level culling -------------------------------------------------------------------------
+// A Gaussian can only pass the reference's `alpha >= 1/255` test (Device.cuh:52-55) at offsets d with
+// sigma(d) = 1/2 d^T Q d <= L = ln(255 * opacity). The staging thread of each Gaussian computes the
+// axis-aligned half extents of that ellipse ONCE per tile (with a safety margin that dwarfs the
+// rounding of __expf/__logf), and every wave tests 64 staged Gaussians at a time (one per lane)
+// against the rectangle of ITS pixel centres; a 64-bit ballot then drives a scalar loop over the
+// survivors only. This never changes a result: a culled (wave, Gaussian) pair has no lane that
+// would have passed the alpha test.
+__device__ __forceinline__ float2 cull_half_extent(float opac, float ca, float cb, float cc)
+{
+    const float L   = __logf(255.0f * opac) + 0.01f; // NaN / -inf for opac <= 0 -> never hits
+    const float det = ca * cc - cb * cb;
+    if (!(det > 0.0f)) return make_float2(INFINITY, INFINITY); // not positive definite: do not cull
+    if (!(L > 0.0f)) return make_float2(-1.0f, -1.0f);
+    const float k = 2.0f * L / det;
+    // negative-definite conics give sqrt(negative) = NaN -> compares false -> culled (sigma < 0 everywhere)
+    return make_float2(sqrtf(k * cc) * 1.0001f + 1e-3f, sqrtf(k * ca) * 1.0001f + 1e-3f);
+}
+
+// Rectangle (centre, half size) of the pixel centres owned by the active lanes of this wave.
+struct WaveRect {
+    float cx, cy, hw, hh;
+    bool any;
+};
+__device__ __forceinline__ WaveRect wave_pixel_rect(bool inside, float px, float py)
+{
+    float xmin = inside ? px : INFINITY, xmax = inside ? px : -INFINITY;
+    float ymin = inside ? py : INFINITY, ymax = inside ? py : -INFINITY;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        xmin = fminf(xmin, __shfl_xor(xmin, o));
+        xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+        ymin = fminf(ymin, __shfl_xor(ymin, o));
+        ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    }
+    WaveRect r;
+    r.any = xmin <= xmax;
+    r.cx = 0.5f * (xmin + xmax); r.hw = 0.5f * (xmax - xmin);
+    r.cy = 0.5f * (ymin + ymax); r.hh = 0.5f * (ymax - ymin);
+    return r;
+}
+
 } // namespace gsx

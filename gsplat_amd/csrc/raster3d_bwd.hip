@@ -24,7 +24,7 @@ struct BwdCfg {
     static constexpr int KP    = (K | 1);                    // odd row stride -> conflict-free flush
     static constexpr int BATCH = (CH >= 16) ? 128 : 256;     // LDS budget for wide channel chunks
     static constexpr size_t smem =
-        (size_t)BATCH * (sizeof(float4) + sizeof(float2) + sizeof(int32_t) * 2 + sizeof(float) * (CH + KP));
+        (size_t)BATCH * (2 * sizeof(float4) + sizeof(float2) + sizeof(int32_t) * 2 + sizeof(float) * (CH + KP));
 };
 
 template <int CH, bool ABS>
@@ -39,7 +39,8 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4 *s_ga     = reinterpret_cast<float4 *>(smem_raw);       // x, y, opac, conic.a
     float2 *s_gb     = reinterpret_cast<float2 *>(s_ga + BATCH);   // conic.b, conic.c
-    int32_t *s_id    = reinterpret_cast<int32_t *>(s_gb + BATCH);  // flatten id of the row
+    float4 *s_cull   = reinterpret_cast<float4 *>(s_gb + BATCH);   // x, y, half extents of alpha>=1/255
+    int32_t *s_id    = reinterpret_cast<int32_t *>(s_cull + BATCH); // flatten id of the row
     int32_t *s_touch = s_id + BATCH;                               // any lane contributed?
     float *s_col     = reinterpret_cast<float *>(s_touch + BATCH); // [BATCH][CH]
     float *s_acc     = s_col + BATCH * CH;                         // [BATCH][KP]
@@ -93,6 +94,7 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
             if (k < (int)a.nch) bg_dot += bg[k] * v_c[k];
     }
     const int32_t wave_bin_final = wave_max_i32(bin_final);
+    const WaveRect rect          = wave_pixel_rect(inside, px, py);
 
     // zero the accumulator rows this thread owns
     for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
@@ -116,6 +118,8 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
                 s_id[s]        = g;
                 s_ga[s]        = make_float4(xy.x, xy.y, opac, ca);
                 s_gb[s]        = make_float2(cb, cc);
+                const float2 he = cull_half_extent(opac, ca, cb, cc);
+                s_cull[s]      = make_float4(xy.x, xy.y, he.x, he.y);
                 const float *c = a.colors + (size_t)g * a.cdim + a.ch_off;
 #pragma unroll
                 for (int k = 0; k < CH; ++k) s_col[s * CH + k] = (k < (int)a.nch) ? c[k] : 0.0f;
@@ -124,27 +128,37 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
         __syncthreads();
 
         // Gaussians behind every pixel's last contributor in this wave are skipped wholesale.
-        for (int32_t t = max(0, batch_end - wave_bin_final); t < batch_size; ++t) {
-            bool valid = inside && (batch_end - t <= bin_final);
-            float alpha = 0.f, opac = 0.f, vis = 0.f, dx = 0.f, dy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
-            if (valid) {
-                const float4 ga = s_ga[t];
-                const float2 gb = s_gb[t];
-                opac = ga.z; ca = ga.w; cb = gb.x; cc = gb.y;
-                dx = ga.x - px;
-                dy = ga.y - py;
-                const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
-                vis   = __expf(-sigma);
-                alpha = fminf(kMaxAlpha, opac * vis);
-                valid = !(sigma < 0.0f || alpha < kAlphaThreshold);
-            }
+        const int32_t t_first = max(0, batch_end - wave_bin_final);
+        for (int32_t j = (t_first & ~63); j < batch_size; j += 64) {
+          // cull 64 staged Gaussians at once against this wave's pixel rectangle (raster3d.hpp)
+          const int32_t tl = j + (int32_t)lane;
+          bool hit         = false;
+          if (tl >= t_first && tl < batch_size) {
+              const float4 cu = s_cull[tl];
+              hit = (fabsf(cu.x - rect.cx) - rect.hw <= cu.z) && (fabsf(cu.y - rect.cy) - rect.hh <= cu.w);
+          }
+          uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
+          while (todo) { // scalar loop over the survivors, back to front
+            const int32_t t = j + (int32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            // Branch-free body: invalid lanes run the same arithmetic with alpha = vis = 0, which makes
+            // every contribution exactly 0 and leaves T / buffer unchanged (1/(1-0) == 1 exactly).
+            const float4 ga = s_ga[t];
+            const float2 gb = s_gb[t];
+            const float opac = ga.z, ca = ga.w, cb = gb.x, cc = gb.y;
+            const float dx = ga.x - px;
+            const float dy = ga.y - py;
+            const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+            const float vis_r = __expf(-sigma);
+            const float alpha_r = fminf(kMaxAlpha, opac * vis_r);
+            const bool valid = inside && (batch_end - t <= bin_final) && !(sigma < 0.0f) && !(alpha_r < kAlphaThreshold);
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform
 
+            const float alpha = valid ? alpha_r : 0.0f;
+            const float vis   = valid ? vis_r : 0.0f;
             float loc[KQ * 4];
-#pragma unroll
-            for (int k = 0; k < KQ * 4; ++k) loc[k] = 0.0f;
-            if (valid) {
-                const float ra  = 1.0f / fmaxf(kMinOneMinusAlpha, 1.0f - alpha);
+            {
+                const float ra  = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
                 T              *= ra;
                 const float fac = alpha * T;
                 float v_alpha   = 0.0f;
@@ -155,23 +169,24 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
                     v_alpha      += (c * T - buffer[k] * ra) * v_c[k];
                     buffer[k]    += c * fac;
                 }
-                v_alpha += T_final * ra * v_a;
-                v_alpha -= T_final * ra * bg_dot;
-                if (opac * vis <= kMaxAlpha) {
-                    const float v_sigma = -opac * vis * v_alpha;
-                    loc[CH + 0]         = 0.5f * v_sigma * dx * dx;
-                    loc[CH + 1]         = v_sigma * dx * dy;
-                    loc[CH + 2]         = 0.5f * v_sigma * dy * dy;
-                    const float vx      = v_sigma * (ca * dx + cb * dy);
-                    const float vy      = v_sigma * (cb * dx + cc * dy);
-                    loc[CH + 3]         = vx;
-                    loc[CH + 4]         = vy;
-                    loc[CH + 5]         = vis * v_alpha;
-                    if constexpr (ABS) {
-                        loc[CH + 6] = fabsf(vx);
-                        loc[CH + 7] = fabsf(vy);
-                    }
+                v_alpha += T_final * ra * (v_a - bg_dot);
+                const float ov      = opac * vis;
+                const bool unclamped = ov <= kMaxAlpha; // alpha-clamp branch: geometry/opacity grads vanish
+                const float v_sigma = unclamped ? -ov * v_alpha : 0.0f;
+                loc[CH + 0]         = 0.5f * v_sigma * dx * dx;
+                loc[CH + 1]         = v_sigma * dx * dy;
+                loc[CH + 2]         = 0.5f * v_sigma * dy * dy;
+                const float vx      = v_sigma * (ca * dx + cb * dy);
+                const float vy      = v_sigma * (cb * dx + cc * dy);
+                loc[CH + 3]         = vx;
+                loc[CH + 4]         = vy;
+                loc[CH + 5]         = unclamped ? vis * v_alpha : 0.0f;
+                if constexpr (ABS) {
+                    loc[CH + 6] = fabsf(vx);
+                    loc[CH + 7] = fabsf(vy);
                 }
+#pragma unroll
+                for (int k = K; k < KQ * 4; ++k) loc[k] = 0.0f;
             }
             // reduce four values per step; row r of group j ends up with total of value 4j + r
             float mine = 0.0f;
@@ -183,6 +198,7 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
             const int vidx = 4 * (int)(lane & 15u) + (int)(lane >> 4);
             if ((int)(lane & 15u) < KQ && vidx < K) atomicAdd(&s_acc[t * KP + vidx], mine); // ds_add_f32
             if (lane == 0) s_touch[t] = 1;
+          }
         }
         __syncthreads();
 

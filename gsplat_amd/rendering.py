@@ -289,9 +289,42 @@ def _project_features(features, sh_degree, clamp, means, viewmats, radii, batch_
         if packed:
             return features.reshape(B, N, D)[batch_ids, gaussian_ids]
         return torch.broadcast_to(features[..., None, :, :], batch_dims + (C, N, D))
-    valid = (radii > 0).all(dim=-1)
-    coeffs = features[gaussian_ids] if packed else features
-    vals = spherical_harmonics(sh_degree, means, viewmats, coeffs, masks=valid, batch_ids=batch_ids,
-                               camera_ids=camera_ids, gaussian_ids=gaussian_ids)
+    if packed:
+        # Every packed row is visible by construction (projection only emits radii > 0), so no mask; the
+        # coefficient rows are read THROUGH gaussian_ids inside the kernel instead of materialising the
+        # reference's coeffs.index({gaussian_ids}) copy (Rendering.cpp:629; 4*K*D B/row each way + a sort in
+        # the index_put backward).
+        vals = _ShUngathered.apply(sh_degree, means, viewmats, features, batch_ids, camera_ids, gaussian_ids)
+    else:
+        valid = (radii > 0).all(dim=-1)
+        vals = spherical_harmonics(sh_degree, means, viewmats, features, masks=valid)
     vals = vals + 0.5
     return torch.clamp_min(vals, 0.0) if clamp else vals
+
+
+class _ShUngathered(torch.autograd.Function):
+    """spherical_harmonics on packed rows with coeffs left in their [N, K, D] layout (C-ABI
+    gsx_sh_{fwd,bwd} with coeffs_gathered=0). Same math and gradients as
+    spherical_harmonics(coeffs[gaussian_ids]) (reference _wrapper.py:553-632)."""
+
+    @staticmethod
+    def forward(ctx, degree, means, viewmats, coeffs, batch_ids, camera_ids, gaussian_ids):
+        from ._ops import impl
+
+        means, viewmats, coeffs = means.contiguous(), viewmats.contiguous(), coeffs.contiguous()
+        ctx.degree = degree
+        ctx.save_for_backward(means, viewmats, coeffs, batch_ids, camera_ids, gaussian_ids)
+        return impl("spherical_harmonics")(degree, means, viewmats, coeffs, None, batch_ids, camera_ids,
+                                           gaussian_ids, None, _gathered=False)
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        from ._ops import impl
+
+        means, viewmats, coeffs, batch_ids, camera_ids, gaussian_ids = ctx.saved_tensors
+        if ctx.needs_input_grad[2]:
+            raise NotImplementedError("gsplat_amd: SH gradient w.r.t. viewmats is not implemented")
+        v_coeffs, v_means, _, _ = impl("spherical_harmonics_bwd")(
+            ctx.degree, means, viewmats, coeffs, None, batch_ids, camera_ids, gaussian_ids, None,
+            v_colors.contiguous(), ctx.needs_input_grad[1], False, False, _gathered=False)
+        return None, v_means, None, v_coeffs, None, None, None

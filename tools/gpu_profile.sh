@@ -8,11 +8,11 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY"; do
   name=$(echo $pmc | tr ' ' '_' | cut -c1-40)
-  timeout 600 rocprofv3 --kernel-trace --pmc $pmc -d $OUT/pmc_$name -o pmc -- python $ROOT/bench.py $ARGS > $OUT/pmc_$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $pmc -d $OUT/pmc_$name -o pmc -- python $ROOT/bench.py $ARGS > $OUT/pmc_$name.log 2>&1
 done
-find $OUT -name '*.csv' | head -50
+tail -3 $OUT/*.log; find $OUT -type f ! -name '*.csv' ! -name '*.log' ! -name '*.txt' -delete; du -sh $OUT; find $OUT -name '*.csv' | head -50
 python $ROOT/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt | head -80
