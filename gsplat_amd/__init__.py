@@ -6,16 +6,30 @@ Public surface = the hot path of nerfstudio-project/gsplat with the same names a
 Importing the package loads ``csrc/libgsplat_amd.so`` (hand-written HIP kernels behind a C ABI,
 ``include/gsplat_amd.h``) and defines ``torch.ops.gsplat.*``; there is no CPU fallback.
 """
-from ._wrapper import (  # noqa: F401
-    fully_fused_projection,
-    isect_offset_encode,
-    isect_tiles,
-    quat_scale_to_covar_preci,
-    rasterize_to_pixels,
-    spherical_harmonics,
-)
-from .rendering import rasterization  # noqa: F401
-from . import distributed  # noqa: F401
+import importlib
+
+# Lazy attribute loading: `import gsplat_amd.csrc_shim` (the drop-in `gsplat.csrc` module, INTEGRATION.md) must
+# define the ops WITHOUT attaching our autograd — under the reference's Python its own `_wrapper.py` does that.
+_LAZY = {
+    "fully_fused_projection": "_wrapper", "isect_offset_encode": "_wrapper", "isect_tiles": "_wrapper",
+    "quat_scale_to_covar_preci": "_wrapper", "rasterize_to_pixels": "_wrapper", "spherical_harmonics": "_wrapper",
+    "rasterization": "rendering", "distributed": "distributed",
+}
+
+
+def __getattr__(name):
+    mod = _LAZY.get(name)
+    if mod is None:
+        raise AttributeError(f"module 'gsplat_amd' has no attribute '{name}'")
+    m = importlib.import_module(f"{__name__}.{mod}")
+    val = m if name == mod else getattr(m, name)
+    globals()[name] = val
+    return val
+
+
+def __dir__():
+    return sorted(list(globals()) + list(_LAZY))
+
 
 __version__ = "0.1.0"
 

@@ -51,3 +51,32 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "gso_" not in src, f
+
+
+def test_reference_python_accepts_the_shim_as_gsplat_csrc():
+    """INTEGRATION.md route A: with gsplat_amd.csrc_shim installed as `gsplat.csrc`, the reference's own
+    `gsplat/cuda/_backend.py:29-31` picks it up, `_wrapper.py` attaches ITS autograd to our ops and reports the 3DGS
+    feature set as available. Needs the reference checkout (this container only); runs in a subprocess so that the
+    reference's autograd registration does not collide with ours in the test process."""
+    import subprocess
+    import sys
+
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "gsplat")):
+        pytest.skip("reference checkout not present")
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import gsplat_amd.csrc_shim as shim; sys.modules['gsplat.csrc'] = shim\n"
+        "import gsplat\n"
+        "from gsplat.cuda._backend import _C\n"
+        "from gsplat.cuda import _wrapper as w\n"
+        "assert _C is shim\n"
+        "assert w.has_3dgs() and not w.has_3dgut()\n"
+        "import torch\n"
+        "for op in ('rasterize_to_pixels_3dgs', 'projection_ewa_3dgs_fused', 'intersect_tile', 'spherical_harmonics'):\n"
+        "    assert hasattr(torch.ops.gsplat, op)\n"
+        "print('OK')\n"
+    ) % (ROOT, ref)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp", env=env, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
