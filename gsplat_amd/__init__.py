@@ -13,7 +13,8 @@ import importlib
 _LAZY = {
     "fully_fused_projection": "_wrapper", "isect_offset_encode": "_wrapper", "isect_tiles": "_wrapper",
     "quat_scale_to_covar_preci": "_wrapper", "rasterize_to_pixels": "_wrapper", "spherical_harmonics": "_wrapper",
-    "rasterization": "rendering", "distributed": "distributed",
+    "fully_fused_projection_2dgs": "_wrapper", "rasterize_to_pixels_2dgs": "_wrapper",
+    "rasterization": "rendering", "rasterization_2dgs": "rendering", "distributed": "distributed",
 }
 
 

@@ -147,7 +147,69 @@ def _rast_backward(ctx, v_render_colors, v_render_alphas, v_means2d_absgrad, v_l
     return (v_means2d, v_conics, v_colors, v_opacities, v_backgrounds) + (None,) * 8
 
 
+# ---- 2DGS projection (reference _wrapper.py:2730-2915) -------------------------------------------
+def _p2_setup(ctx, inputs, output):
+    means, quats, scales, viewmats, Ks, width, height, _eps2d, _near, _far, _clip = inputs
+    radii, _means2d, _depths, ray_transforms, _normals = output
+    ctx.width, ctx.height = width, height
+    ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, ray_transforms)
+
+
+def _p2_backward(ctx, v_radii, v_means2d, v_depths, v_ray_transforms, v_normals):
+    means, quats, scales, viewmats, Ks, radii, ray_transforms = ctx.saved_tensors
+    v_means, v_quats, v_scales, v_viewmats = _bwd("projection_2dgs_fused")(
+        means, quats, scales, viewmats, Ks, ctx.width, ctx.height, radii, ray_transforms, v_means2d.contiguous(),
+        v_depths.contiguous(), v_ray_transforms.contiguous(), v_normals.contiguous(), ctx.needs_input_grad[3])
+    return (v_means, v_quats, v_scales, v_viewmats) + (None,) * 7
+
+
+def _p2p_setup(ctx, inputs, output):
+    means, quats, scales, viewmats, Ks, width, height, _near, _far, _clip, sparse_grad = inputs
+    batch_ids, camera_ids, gaussian_ids, _indptr, _radii, _means2d, _depths, ray_transforms, _normals = output
+    ctx.width, ctx.height, ctx.sparse_grad = width, height, sparse_grad
+    ctx.save_for_backward(means, quats, scales, viewmats, Ks, batch_ids, camera_ids, gaussian_ids, ray_transforms)
+
+
+def _p2p_backward(ctx, v_b, v_c, v_g, v_indptr, v_radii, v_means2d, v_depths, v_ray_transforms, v_normals):
+    means, quats, scales, viewmats, Ks, batch_ids, camera_ids, gaussian_ids, ray_transforms = ctx.saved_tensors
+    v_means, v_quats, v_scales, v_viewmats = _bwd("projection_2dgs_packed")(
+        means, quats, scales, viewmats, Ks, ctx.width, ctx.height, ctx.sparse_grad, batch_ids, camera_ids,
+        gaussian_ids, ray_transforms, v_means2d.contiguous(), v_depths.contiguous(), v_ray_transforms.contiguous(),
+        v_normals.contiguous(), ctx.needs_input_grad[3])
+    return (v_means, v_quats, v_scales, v_viewmats) + (None,) * 7
+
+
+# ---- 2DGS compositing (reference _wrapper.py:3004-3150) ------------------------------------------
+def _r2_setup(ctx, inputs, output):
+    (means2d, ray_transforms, colors, opacities, normals, densify, backgrounds, masks, image_width, image_height,
+     tile_size, tile_offsets, flatten_ids, _packed, absgrad, _distloss) = inputs
+    (render_colors, render_alphas, _rn, _rd, _rm, means2d_absgrad, last_ids, median_ids) = output
+    ctx.mark_non_differentiable(last_ids, median_ids, means2d_absgrad)
+    ctx.width, ctx.height, ctx.tile_size, ctx.absgrad = image_width, image_height, tile_size, absgrad
+    ctx.save_for_backward(means2d, ray_transforms, colors, opacities, normals, densify, backgrounds, masks,
+                          tile_offsets, flatten_ids, render_colors, render_alphas, last_ids, median_ids,
+                          means2d_absgrad)
+
+
+def _r2_backward(ctx, v_render_colors, v_render_alphas, v_render_normals, v_render_distort, v_render_median,
+                 v_absgrad, v_last_ids, v_median_ids):
+    (means2d, ray_transforms, colors, opacities, normals, densify, backgrounds, masks, tile_offsets, flatten_ids,
+     render_colors, render_alphas, last_ids, median_ids, means2d_absgrad) = ctx.saved_tensors
+    (v_means2d_abs, v_means2d, v_ray_transforms, v_colors, v_opacities, v_normals, v_densify,
+     v_backgrounds) = _bwd("rasterize_to_pixels_2dgs")(
+        means2d, ray_transforms, colors, opacities, normals, densify, backgrounds, masks, tile_offsets, flatten_ids,
+        render_colors, render_alphas, last_ids, median_ids, ctx.width, ctx.height, ctx.tile_size, ctx.absgrad,
+        v_render_colors.contiguous(), v_render_alphas.contiguous(), v_render_normals.contiguous(),
+        v_render_distort.contiguous(), v_render_median.contiguous(), ctx.needs_input_grad[6])
+    if ctx.absgrad and v_means2d_abs is not None:
+        means2d_absgrad.copy_(v_means2d_abs)
+    return (v_means2d, v_ray_transforms, v_colors, v_opacities, v_normals, v_densify, v_backgrounds) + (None,) * 9
+
+
 _TABLE = {
+    "projection_2dgs_fused": (_p2_backward, _p2_setup),
+    "projection_2dgs_packed": (_p2p_backward, _p2p_setup),
+    "rasterize_to_pixels_2dgs": (_r2_backward, _r2_setup),
     "quat_scale_to_covar_preci": (_qs_backward, _qs_setup),
     "spherical_harmonics": (_sh_backward, _sh_setup),
     "projection_ewa_3dgs_fused": (_proj_backward, _proj_setup),

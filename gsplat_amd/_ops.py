@@ -46,6 +46,13 @@ SCHEMAS = {
     # ext.cpp:1079-1089
     "rasterize_to_pixels_3dgs": "(Tensor means2d, Tensor conics, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, int image_width, int image_height, int tile_size, Tensor isect_offsets, Tensor flatten_ids, bool packed, bool absgrad) -> (Tensor, Tensor, Tensor, Tensor)",
     "rasterize_to_pixels_3dgs_bwd": "(Tensor means2d, Tensor conics, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, Tensor tile_offsets, Tensor flatten_ids, Tensor render_alphas, Tensor last_ids, int image_width, int image_height, int tile_size, bool absgrad, Tensor v_render_colors, Tensor v_render_alphas, bool compute_v_backgrounds) -> (Tensor?, Tensor, Tensor, Tensor, Tensor, Tensor?)",
+    # ext.cpp:1163-1199 (2DGS)
+    "projection_2dgs_fused": "(Tensor means, Tensor quats, Tensor scales, Tensor viewmats, Tensor Ks, int image_width, int image_height, float eps2d, float near_plane, float far_plane, float radius_clip) -> (Tensor, Tensor, Tensor, Tensor, Tensor)",
+    "projection_2dgs_fused_bwd": "(Tensor means, Tensor quats, Tensor scales, Tensor viewmats, Tensor Ks, int image_width, int image_height, Tensor radii, Tensor ray_transforms, Tensor v_means2d, Tensor v_depths, Tensor v_ray_transforms, Tensor v_normals, bool viewmats_requires_grad) -> (Tensor, Tensor, Tensor, Tensor?)",
+    "projection_2dgs_packed": "(Tensor means, Tensor quats, Tensor scales, Tensor viewmats, Tensor Ks, int image_width, int image_height, float near_plane, float far_plane, float radius_clip, bool sparse_grad) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
+    "projection_2dgs_packed_bwd": "(Tensor means, Tensor quats, Tensor scales, Tensor viewmats, Tensor Ks, int image_width, int image_height, bool sparse_grad, Tensor batch_ids, Tensor camera_ids, Tensor gaussian_ids, Tensor ray_transforms, Tensor v_means2d, Tensor v_depths, Tensor v_ray_transforms, Tensor v_normals, bool viewmats_requires_grad) -> (Tensor, Tensor, Tensor, Tensor?)",
+    "rasterize_to_pixels_2dgs": "(Tensor means2d, Tensor ray_transforms, Tensor colors, Tensor opacities, Tensor normals, Tensor densify, Tensor? backgrounds, Tensor? masks, int image_width, int image_height, int tile_size, Tensor tile_offsets, Tensor flatten_ids, bool packed, bool absgrad, bool distloss) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
+    "rasterize_to_pixels_2dgs_bwd": "(Tensor means2d, Tensor ray_transforms, Tensor colors, Tensor opacities, Tensor normals, Tensor densify, Tensor? backgrounds, Tensor? masks, Tensor tile_offsets, Tensor flatten_ids, Tensor render_colors, Tensor render_alphas, Tensor last_ids, Tensor median_ids, int image_width, int image_height, int tile_size, bool absgrad, Tensor v_render_colors, Tensor v_render_alphas, Tensor v_render_normals, Tensor v_render_distort, Tensor v_render_median, bool compute_v_backgrounds) -> (Tensor?, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor?)",
 }
 
 _impls = {}
@@ -427,6 +434,163 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
         # sum_{h,w} v_colors * (1 - alpha)  (reference does this with torch ops too: Rasterization.cpp:567-577)
         v_backgrounds = (v_render_colors * (1.0 - render_alphas)).sum(dim=(-3, -2))
     return v_abs, v_means2d, v_conics, v_colors, v_opacities, v_backgrounds
+
+
+# ----------------------------------------------------------------------------------------------
+# 2DGS: projection (Projection.cpp 2DGS section; ext.cpp:1163-1184) and compositing (ext.cpp:1186-1199)
+# ----------------------------------------------------------------------------------------------
+def _check_2dgs_inputs(means, quats, scales, viewmats, Ks):
+    _check_f32(means=means, quats=quats, scales=scales, viewmats=viewmats, Ks=Ks)
+    N = means.shape[-2]
+    if means.shape[-1] != 3 or quats.shape[-2:] != (N, 4) or scales.shape[-2:] != (N, 3):
+        raise ValueError(f"projection_2dgs: bad shapes means {tuple(means.shape)} quats {tuple(quats.shape)} "
+                         f"scales {tuple(scales.shape)}")
+
+
+@_op("projection_2dgs_fused")
+def projection_2dgs_fused(means, quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane, far_plane,
+                          radius_clip):
+    _check_2dgs_inputs(means, quats, scales, viewmats, Ks)
+    batch_dims, B, C, N = _proj_dims(means, viewmats)
+    means, quats, scales, viewmats, Ks = (t.contiguous() for t in (means, quats, scales, viewmats, Ks))
+    dev, dt = means.device, means.dtype
+    shape = tuple(batch_dims) + (C, N)
+    radii = torch.empty(shape + (2,), device=dev, dtype=torch.int32)
+    means2d = torch.empty(shape + (2,), device=dev, dtype=dt)
+    depths = torch.empty(shape, device=dev, dtype=dt)
+    ray_transforms = torch.empty(shape + (3, 3), device=dev, dtype=dt)
+    normals = torch.empty(shape + (3,), device=dev, dtype=dt)
+    call("gsx_project_2dgs_fwd", ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), B, C, N, image_width,
+         image_height, near_plane, far_plane, radius_clip, ptr(radii), ptr(means2d), ptr(depths), ptr(ray_transforms),
+         ptr(normals))
+    return radii, means2d, depths, ray_transforms, normals
+
+
+@_op("projection_2dgs_fused_bwd")
+def projection_2dgs_fused_bwd(means, quats, scales, viewmats, Ks, image_width, image_height, radii, ray_transforms,
+                              v_means2d, v_depths, v_ray_transforms, v_normals, viewmats_requires_grad):
+    batch_dims, B, C, N = _proj_dims(means, viewmats)
+    means, quats, scales, viewmats, Ks = (t.contiguous() for t in (means, quats, scales, viewmats, Ks))
+    v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
+    v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
+    call("gsx_project_2dgs_bwd", ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), B, C, N,
+         ptr(radii.contiguous()), ptr(ray_transforms.contiguous()), ptr(v_means2d.contiguous()),
+         ptr(v_depths.contiguous()), ptr(v_ray_transforms.contiguous()), ptr(v_normals.contiguous()), ptr(v_means),
+         ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
+    return v_means, v_quats, v_scales, v_viewmats
+
+
+@_op("projection_2dgs_packed")
+def projection_2dgs_packed(means, quats, scales, viewmats, Ks, image_width, image_height, near_plane, far_plane,
+                           radius_clip, sparse_grad):
+    _check_2dgs_inputs(means, quats, scales, viewmats, Ks)
+    batch_dims, B, C, N = _proj_dims(means, viewmats)
+    means, quats, scales, viewmats, Ks = (t.contiguous() for t in (means, quats, scales, viewmats, Ks))
+    dev, dt = means.device, means.dtype
+    total = B * C * N
+    common = (ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), B, C, N, image_width, image_height,
+              near_plane, far_plane, radius_clip)
+    nnz, cum = 0, None
+    if total > 0:
+        visible = torch.empty(total, device=dev, dtype=torch.int32)
+        call("gsx_project_2dgs_packed_count", *common, ptr(visible))
+        cum = _scan_i32(visible)
+        nnz = int(cum[-1].item())  # host sync: exact-length COO outputs, as the reference
+    batch_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
+    camera_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
+    gaussian_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
+    indptr = torch.zeros(B * C + 1, device=dev, dtype=torch.int32)
+    radii = torch.empty((nnz, 2), device=dev, dtype=torch.int32)
+    means2d = torch.empty((nnz, 2), device=dev, dtype=dt)
+    depths = torch.empty((nnz,), device=dev, dtype=dt)
+    ray_transforms = torch.empty((nnz, 3, 3), device=dev, dtype=dt)
+    normals = torch.empty((nnz, 3), device=dev, dtype=dt)
+    if total > 0:
+        call("gsx_project_2dgs_packed_write", *common, ptr(cum), nnz, ptr(batch_ids), ptr(camera_ids),
+             ptr(gaussian_ids), ptr(indptr), ptr(radii), ptr(means2d), ptr(depths), ptr(ray_transforms), ptr(normals))
+    return batch_ids, camera_ids, gaussian_ids, indptr, radii, means2d, depths, ray_transforms, normals
+
+
+@_op("projection_2dgs_packed_bwd")
+def projection_2dgs_packed_bwd(means, quats, scales, viewmats, Ks, image_width, image_height, sparse_grad, batch_ids,
+                               camera_ids, gaussian_ids, ray_transforms, v_means2d, v_depths, v_ray_transforms,
+                               v_normals, viewmats_requires_grad):
+    batch_dims, B, C, N = _proj_dims(means, viewmats)
+    means, quats, scales, viewmats, Ks = (t.contiguous() for t in (means, quats, scales, viewmats, Ks))
+    nnz = gaussian_ids.shape[0]
+    v_means, v_quats, v_scales = torch.zeros_like(means), torch.zeros_like(quats), torch.zeros_like(scales)
+    v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
+    call("gsx_project_2dgs_packed_bwd", ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), B, C, N, nnz,
+         ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()), ptr(gaussian_ids.contiguous()),
+         ptr(ray_transforms.contiguous()), ptr(v_means2d.contiguous()), ptr(v_depths.contiguous()),
+         ptr(v_ray_transforms.contiguous()), ptr(v_normals.contiguous()), ptr(v_means), ptr(v_quats), ptr(v_scales),
+         ptr(v_viewmats))
+    if sparse_grad and len(batch_dims) == 0:
+        rows = torch.unique(gaussian_ids)
+
+        def to_sparse(dense):
+            return torch.sparse_coo_tensor(rows[None], dense[rows], size=dense.shape, is_coalesced=True)
+
+        v_means, v_quats, v_scales = map(to_sparse, (v_means, v_quats, v_scales))
+    return v_means, v_quats, v_scales, v_viewmats
+
+
+@_op("rasterize_to_pixels_2dgs")
+def rasterize_to_pixels_2dgs(means2d, ray_transforms, colors, opacities, normals, densify, backgrounds, masks,
+                             image_width, image_height, tile_size, tile_offsets, flatten_ids, packed, absgrad, distloss):
+    _check_f32(means2d=means2d, ray_transforms=ray_transforms, colors=colors, opacities=opacities, normals=normals,
+               backgrounds=backgrounds)
+    image_dims, I, th, tw, D = _raster_dims(tile_offsets, colors)
+    if th * tile_size < image_height or tw * tile_size < image_width:
+        raise ValueError("rasterize_to_pixels_2dgs: tile grid does not cover the image")
+    if masks is not None and masks.dtype != torch.bool:
+        raise TypeError("masks must be a bool tensor")
+    means2d, ray_transforms, colors, opacities, normals = (t.contiguous() for t in (means2d, ray_transforms, colors,
+                                                                                    opacities, normals))
+    backgrounds, masks = _c(backgrounds), _c(masks)
+    tile_offsets, flatten_ids = tile_offsets.contiguous(), flatten_ids.contiguous()
+    dev, dt = means2d.device, means2d.dtype
+    hw = image_dims + (image_height, image_width)
+    renders = torch.empty(hw + (D,), device=dev, dtype=dt)
+    alphas = torch.empty(hw + (1,), device=dev, dtype=dt)
+    rnormals = torch.empty(hw + (3,), device=dev, dtype=dt)
+    rdistort = torch.empty(hw + (1,), device=dev, dtype=dt)
+    rmedian = torch.empty(hw + (1,), device=dev, dtype=dt)
+    last_ids = torch.empty(hw, device=dev, dtype=torch.int32)
+    median_ids = torch.empty(hw, device=dev, dtype=torch.int32)
+    call("gsx_raster2d_fwd", ptr(means2d), ptr(ray_transforms), ptr(colors), ptr(opacities), ptr(normals),
+         ptr(backgrounds), ptr(masks), ptr(tile_offsets), ptr(flatten_ids), I, flatten_ids.numel(), D, image_width,
+         image_height, tile_size, tw, th, int(distloss), ptr(renders), ptr(alphas), ptr(rnormals), ptr(rdistort),
+         ptr(rmedian), ptr(last_ids), ptr(median_ids))
+    holder = torch.zeros_like(means2d) if absgrad else torch.empty(0, device=dev, dtype=dt)
+    return renders, alphas, rnormals, rdistort, rmedian, holder, last_ids, median_ids
+
+
+@_op("rasterize_to_pixels_2dgs_bwd")
+def rasterize_to_pixels_2dgs_bwd(means2d, ray_transforms, colors, opacities, normals, densify, backgrounds, masks,
+                                 tile_offsets, flatten_ids, render_colors, render_alphas, last_ids, median_ids,
+                                 image_width, image_height, tile_size, absgrad, v_render_colors, v_render_alphas,
+                                 v_render_normals, v_render_distort, v_render_median, compute_v_backgrounds):
+    image_dims, I, th, tw, D = _raster_dims(tile_offsets, colors)
+    means2d, ray_transforms, colors, opacities, normals = (t.contiguous() for t in (means2d, ray_transforms, colors,
+                                                                                    opacities, normals))
+    backgrounds, masks = _c(backgrounds), _c(masks)
+    v_render_colors, v_render_alphas = v_render_colors.contiguous(), v_render_alphas.contiguous()
+    v_means2d, v_rt = torch.zeros_like(means2d), torch.zeros_like(ray_transforms)
+    v_colors, v_opacities = torch.zeros_like(colors), torch.zeros_like(opacities)
+    v_normals, v_densify = torch.zeros_like(normals), torch.zeros_like(means2d)
+    v_abs = torch.zeros_like(means2d) if absgrad else None
+    call("gsx_raster2d_bwd", ptr(means2d), ptr(ray_transforms), ptr(colors), ptr(opacities), ptr(normals),
+         ptr(backgrounds), ptr(masks), ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()),
+         ptr(render_colors.contiguous()), ptr(render_alphas.contiguous()), ptr(last_ids.contiguous()),
+         ptr(median_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), ptr(v_render_normals.contiguous()),
+         ptr(v_render_distort.contiguous()), ptr(v_render_median.contiguous()), I, flatten_ids.numel(), D, image_width,
+         image_height, tile_size, tw, th, ptr(v_abs), ptr(v_means2d), ptr(v_rt), ptr(v_colors), ptr(v_opacities),
+         ptr(v_normals), ptr(v_densify))
+    v_backgrounds = None
+    if backgrounds is not None and compute_v_backgrounds:
+        v_backgrounds = (v_render_colors * (1.0 - render_alphas)).sum(dim=(-3, -2))
+    return v_abs, v_means2d, v_rt, v_colors, v_opacities, v_normals, v_densify, v_backgrounds
 
 
 # ----------------------------------------------------------------------------------------------

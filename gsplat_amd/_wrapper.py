@@ -175,3 +175,70 @@ def rasterize_to_pixels(
     if absgrad:
         means2d.absgrad = means2d_absgrad
     return render_colors, render_alphas
+
+
+# ----------------------------------------------------------------------------------------------
+# 2DGS (reference _wrapper.py:2633-2727, 2918-3001)
+# ----------------------------------------------------------------------------------------------
+def fully_fused_projection_2dgs(
+    means: Tensor,  # [..., N, 3]
+    quats: Tensor,  # [..., N, 4]
+    scales: Tensor,  # [..., N, 3]
+    viewmats: Tensor,  # [..., C, 4, 4]
+    Ks: Tensor,  # [..., C, 3, 3]
+    width: int,
+    height: int,
+    eps2d: float = 0.3,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    packed: bool = False,
+    sparse_grad: bool = False,
+):
+    """Ray-splat intersection matrices, screen-space boxes and normals of 2D Gaussians. Dense:
+    (radii, means2d, depths, ray_transforms [..., C, N, 3, 3], normals [..., C, N, 3]); packed: (batch_ids,
+    camera_ids, gaussian_ids, indptr, radii, means2d, depths, ray_transforms, normals) over nnz rows."""
+    means, quats, scales = means.contiguous(), quats.contiguous(), scales.contiguous()
+    if sparse_grad:
+        assert packed, "sparse_grad is only supported when packed is True"
+    viewmats, Ks = viewmats.contiguous(), Ks.contiguous()
+    if packed:
+        return _ops.projection_2dgs_packed(means, quats, scales, viewmats, Ks, width, height, near_plane, far_plane,
+                                           radius_clip, sparse_grad)
+    return _ops.projection_2dgs_fused(means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                                      radius_clip)
+
+
+def rasterize_to_pixels_2dgs(
+    means2d: Tensor,  # [..., N, 2] or [nnz, 2]
+    ray_transforms: Tensor,  # [..., N, 3, 3] or [nnz, 3, 3]
+    colors: Tensor,  # [..., N, channels]
+    opacities: Tensor,  # [..., N]
+    normals: Tensor,  # [..., N, 3]
+    densify: Tensor,  # [..., N, 2]
+    image_width: int,
+    image_height: int,
+    tile_size: int,
+    isect_offsets: Tensor,
+    flatten_ids: Tensor,
+    backgrounds: Optional[Tensor] = None,
+    masks: Optional[Tensor] = None,
+    packed: bool = False,
+    absgrad: bool = False,
+    distloss: bool = False,
+) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """Composites 2D Gaussians. Returns (render_colors, render_alphas, render_normals [..., H, W, 3],
+    render_distort [..., H, W, 1], render_median [..., H, W, 1]). The last colour channel is the depth used by the
+    distortion and median outputs. ``densify`` only collects a gradient (reference ``meta["gradient_2dgs"]``)."""
+    if backgrounds is not None:
+        backgrounds = backgrounds.contiguous()
+    if masks is not None:
+        masks = masks.contiguous()
+    (render_colors, render_alphas, render_normals, render_distort, render_median, means2d_absgrad, _last_ids,
+     _median_ids) = _ops.rasterize_to_pixels_2dgs(
+        means2d.contiguous(), ray_transforms.contiguous(), colors.contiguous(), opacities.contiguous(),
+        normals.contiguous(), densify.contiguous(), backgrounds, masks, image_width, image_height, tile_size,
+        isect_offsets.contiguous(), flatten_ids.contiguous(), packed, absgrad, distloss)
+    if absgrad:
+        means2d.absgrad = means2d_absgrad
+    return render_colors, render_alphas, render_normals, render_distort, render_median

@@ -1,0 +1,532 @@
+// 2DGS (surfel) front-to-back compositing, forward + backward, gfx950.
+// C-ABI entries: gsx_raster2d_fwd / gsx_raster2d_bwd (replace torch ops gsplat::rasterize_to_pixels_2dgs{,_bwd};
+// reference kernels gsplat/cuda/csrc/RasterizeToPixels2DGSSerialBatchFwd.cu:43-465 and
+// RasterizeToPixels2DGSSerialBatchBwd.cu:41-700, constants gsplat/cuda/include/Rasterization.h:40).
+//
+// Same MI355X work decomposition as the 3DGS kernels (raster3d.hpp): one workgroup of four wave64s per 16x16 tile, a
+// wave owns an 8x8 pixel quadrant, the sorted list is walked in LDS-staged batches. The backward reduces the
+// per-Gaussian sums with the wave64 reduce-scatter (permlane swaps + DPP), accumulates them in an LDS row per Gaussian
+// (ds_add_f32) and flushes ONE global atomic per (tile, Gaussian, component). v_densify is not reduced at all: it is
+// (v_uM.z, v_vM.z) * w_M.z, a per-Gaussian factor applied to already-reduced sums at flush time.
+//
+// Per-sample math (Fwd.cu:356-428): h_u = px w_M - u_M, h_v = py w_M - v_M, zeta = h_u x h_v, s = zeta.xy / zeta.z,
+// G3 = |s|^2, G2 = 2 |mean2d - p|^2, sigma = min(G3, G2) / 2, alpha = min(0.99, opac exp(-sigma)); skip if zeta.z == 0,
+// sigma < 0 or alpha < 1/255; stop (exclusive) if T (1 - alpha) <= 1e-4.
+#include "raster3d.hpp"
+#include "../../include/gsplat_amd.h"
+
+namespace gsx {
+
+struct Raster2DArgs {
+    uint32_t n_images, n_isects, width, height, tile_size, tile_w, tile_h, cdim;
+    int distloss;
+    const float *means2d;        // [R, 2]
+    const float *ray_transforms; // [R, 9] rows u_M, v_M, w_M
+    const float *colors;         // [R, cdim]
+    const float *opacities;      // [R]
+    const float *normals;        // [R, 3]
+    const float *backgrounds;    // [I, cdim] or null
+    const uint8_t *masks;        // [I, th, tw] or null
+    const int32_t *isect_offsets;
+    const int32_t *flatten_ids;
+    // forward outputs / backward inputs
+    float *render_colors, *render_alphas, *render_normals, *render_distort, *render_median;
+    int32_t *last_ids, *median_ids;
+    // backward inputs
+    const float *v_render_colors, *v_render_alphas, *v_render_normals, *v_render_distort, *v_render_median;
+    // backward outputs (zero-initialised)
+    float *v_means2d_abs, *v_means2d, *v_ray_transforms, *v_colors, *v_opacities, *v_normals, *v_densify;
+};
+
+struct Surfel { // one pixel x one surfel
+    bool valid;
+    float alpha, vis, gw3, gw2, sx, sy, dx, dy, rcz_inv;
+    float hu[3], hv[3];
+};
+
+__device__ __forceinline__ Surfel eval_surfel(const float4 A /*uM, x*/, const float4 B /*vM, y*/, const float4 C /*wM, opac*/,
+                                              float px, float py)
+{
+    Surfel s;
+    s.hu[0] = px * C.x - A.x; s.hu[1] = px * C.y - A.y; s.hu[2] = px * C.z - A.z;
+    s.hv[0] = py * C.x - B.x; s.hv[1] = py * C.y - B.y; s.hv[2] = py * C.z - B.z;
+    const float rx = s.hu[1] * s.hv[2] - s.hu[2] * s.hv[1];
+    const float ry = s.hu[2] * s.hv[0] - s.hu[0] * s.hv[2];
+    const float rz = s.hu[0] * s.hv[1] - s.hu[1] * s.hv[0];
+    s.rcz_inv = __builtin_amdgcn_rcpf(rz);
+    s.sx  = rx * s.rcz_inv;
+    s.sy  = ry * s.rcz_inv;
+    s.gw3 = s.sx * s.sx + s.sy * s.sy;
+    s.dx  = A.w - px;
+    s.dy  = B.w - py;
+    s.gw2 = kFilterInvSquare2DGS * (s.dx * s.dx + s.dy * s.dy);
+    const float sigma = 0.5f * fminf(s.gw3, s.gw2);
+    s.vis   = __expf(-sigma);
+    s.alpha = fminf(kMaxAlpha, C.w * s.vis);
+    s.valid = (rz != 0.0f) && !(sigma < 0.0f) && !(s.alpha < kAlphaThreshold);
+    return s;
+}
+
+constexpr int kBatch2 = 256;
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+template <int CH>
+__global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4 *s_A  = reinterpret_cast<float4 *>(smem_raw);
+    float4 *s_B  = s_A + kBatch2;
+    float4 *s_C  = s_B + kBatch2;
+    float4 *s_N  = s_C + kBatch2;                             // normal xyz, pad
+    float *s_col = reinterpret_cast<float *>(s_N + kBatch2);  // [kBatch2][CH]
+
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
+    const uint32_t n_blocks        = tiles_per_image * a.n_images;
+    const uint32_t blk             = xcd_remap(blockIdx.x, n_blocks);
+    if (blk >= n_blocks) return;
+    const uint32_t image_id = blk / tiles_per_image, tile_id = blk % tiles_per_image;
+    const uint32_t tile_x = tile_id % a.tile_w, tile_y = tile_id / a.tile_w;
+    const uint32_t tid = threadIdx.x;
+    uint32_t lx, ly;
+    tile_pixel(tid, a.tile_size, lx, ly);
+    const uint32_t ox = tile_x * a.tile_size + lx, oy = tile_y * a.tile_size + ly;
+    const bool inside = (lx < a.tile_size) && (ly < a.tile_size) && (ox < a.width) && (oy < a.height);
+    const float px = (float)ox + 0.5f, py = (float)oy + 0.5f;
+    const size_t pix = ((size_t)image_id * a.height + oy) * a.width + ox;
+    const float *bg = a.backgrounds ? a.backgrounds + (size_t)image_id * a.cdim : nullptr;
+    const int nch   = (int)a.cdim;
+
+    if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) {
+        if (inside) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (k < nch) a.render_colors[pix * a.cdim + k] = bg ? bg[k] : 0.0f;
+            a.render_alphas[pix] = 0.0f;
+            for (int k = 0; k < 3; ++k) a.render_normals[pix * 3 + k] = 0.0f;
+            a.render_distort[pix] = 0.0f;
+            a.render_median[pix]  = 0.0f;
+            a.last_ids[pix]       = 0;
+            a.median_ids[pix]     = 0;
+        }
+        return;
+    }
+
+    const int32_t range_start = a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id];
+    const int32_t range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects
+                                                      : a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id + 1];
+    const int32_t n_batches   = (range_end - range_start + kBatch2 - 1) / kBatch2;
+
+    float T = 1.0f, distort = 0.0f, accum_vis_depth = 0.0f, median_depth = 0.0f;
+    uint32_t cur_idx = 0, median_idx = 0;
+    float acc[CH], nrm[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CH; ++k) acc[k] = 0.0f;
+    bool done = !inside;
+
+    for (int32_t b = 0; b < n_batches; ++b) {
+        if (__syncthreads_count(done) == (int)blockDim.x) break;
+        const int32_t batch_start = range_start + kBatch2 * b;
+        for (int s = (int)tid; s < kBatch2; s += (int)blockDim.x) {
+            const int32_t idx = batch_start + s;
+            if (idx < range_end) {
+                const int32_t g = a.flatten_ids[idx];
+                const float *M  = a.ray_transforms + 9 * (size_t)g;
+                const float2 xy = reinterpret_cast<const float2 *>(a.means2d)[g];
+                s_A[s] = make_float4(M[0], M[1], M[2], xy.x);
+                s_B[s] = make_float4(M[3], M[4], M[5], xy.y);
+                s_C[s] = make_float4(M[6], M[7], M[8], a.opacities[g]);
+                const float *n = a.normals + 3 * (size_t)g;
+                s_N[s] = make_float4(n[0], n[1], n[2], 0.0f);
+                const float *c = a.colors + (size_t)g * a.cdim;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) s_col[s * CH + k] = (k < nch) ? c[k] : 0.0f;
+            }
+        }
+        __syncthreads();
+        const int32_t batch_size = min(kBatch2, range_end - batch_start);
+        for (int32_t t = 0; t < batch_size; ++t) {
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+            const Surfel s = eval_surfel(s_A[t], s_B[t], s_C[t], px, py);
+            if (done || !s.valid) continue;
+            const float next_T = T * (1.0f - s.alpha);
+            if (next_T <= kTransmittanceThresh) {
+                done = true;
+                continue;
+            }
+            const float w = s.alpha * T;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) acc[k] += s_col[t * CH + k] * w;
+            const float4 n = s_N[t];
+            nrm[0] += n.x * w; nrm[1] += n.y * w; nrm[2] += n.z * w;
+            const float depth = s_col[t * CH + nch - 1];
+            if (a.distloss) {
+                distort += 2.0f * (w * depth * (1.0f - T) - w * accum_vis_depth);
+                accum_vis_depth += w * depth;
+            }
+            if (T > 0.5f) {
+                median_depth = depth;
+                median_idx   = (uint32_t)(batch_start + t);
+            }
+            cur_idx = (uint32_t)(batch_start + t);
+            T       = next_T;
+        }
+    }
+    if (inside) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (k < nch) a.render_colors[pix * a.cdim + k] = bg ? (acc[k] + T * bg[k]) : acc[k];
+        a.render_alphas[pix] = 1.0f - T;
+        for (int k = 0; k < 3; ++k) a.render_normals[pix * 3 + k] = nrm[k];
+        a.render_distort[pix] = a.distloss ? distort : 0.0f;
+        a.render_median[pix]  = median_depth;
+        a.last_ids[pix]       = (int32_t)cur_idx;
+        a.median_ids[pix]     = (int32_t)median_idx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------
+// accumulator row layout: [0,CH) colours | CH..CH+2 normals | CH+3..CH+11 ray_transforms | CH+12,13 means2d |
+//                         CH+14 opacity | (CH+15,16 |means2d| when ABS)
+template <int CH, bool ABS>
+struct Bwd2Cfg {
+    static constexpr int K     = CH + 15 + (ABS ? 2 : 0);
+    static constexpr int KQ    = (K + 3) / 4;
+    static constexpr int KP    = (K | 1);
+    static constexpr int BATCH = (CH >= 8) ? 64 : 128;
+    static constexpr size_t smem =
+        (size_t)BATCH * (4 * sizeof(float4) + 2 * sizeof(int32_t) + sizeof(float) * (CH + KP));
+};
+
+template <int CH, bool ABS>
+__global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
+{
+    using Cfg           = Bwd2Cfg<CH, ABS>;
+    constexpr int K     = Cfg::K;
+    constexpr int KQ    = Cfg::KQ;
+    constexpr int KP    = Cfg::KP;
+    constexpr int BATCH = Cfg::BATCH;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4 *s_A      = reinterpret_cast<float4 *>(smem_raw);
+    float4 *s_B      = s_A + BATCH;
+    float4 *s_C      = s_B + BATCH;
+    float4 *s_N      = s_C + BATCH;
+    int32_t *s_id    = reinterpret_cast<int32_t *>(s_N + BATCH);
+    int32_t *s_touch = s_id + BATCH;
+    float *s_col     = reinterpret_cast<float *>(s_touch + BATCH);
+    float *s_acc     = s_col + BATCH * CH;
+
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
+    const uint32_t n_blocks        = tiles_per_image * a.n_images;
+    const uint32_t blk             = xcd_remap(blockIdx.x, n_blocks);
+    if (blk >= n_blocks) return;
+    const uint32_t image_id = blk / tiles_per_image, tile_id = blk % tiles_per_image;
+    if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) return;
+    const uint32_t tile_x = tile_id % a.tile_w, tile_y = tile_id / a.tile_w;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t lx, ly;
+    tile_pixel(tid, a.tile_size, lx, ly);
+    const uint32_t ox = tile_x * a.tile_size + lx, oy = tile_y * a.tile_size + ly;
+    const bool inside = (lx < a.tile_size) && (ly < a.tile_size) && (ox < a.width) && (oy < a.height);
+    const float px = (float)ox + 0.5f, py = (float)oy + 0.5f;
+    const size_t pix = inside ? ((size_t)image_id * a.height + oy) * a.width + ox : 0;
+    const int nch    = (int)a.cdim;
+
+    const int32_t range_start = a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id];
+    const int32_t range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects
+                                                      : a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id + 1];
+    const int32_t n_batches   = (range_end - range_start + BATCH - 1) / BATCH;
+    if (n_batches <= 0) return;
+
+    const float T_final      = inside ? 1.0f - a.render_alphas[pix] : 1.0f;
+    float T                  = T_final;
+    const int32_t bin_final  = inside ? a.last_ids[pix] : -1;
+    const int32_t median_idx = inside ? a.median_ids[pix] : -1;
+    float v_c[CH], buffer[CH], v_n[3], buffer_n[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        v_c[k]    = (inside && k < nch) ? a.v_render_colors[pix * a.cdim + k] : 0.0f;
+        buffer[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v_n[k] = inside ? a.v_render_normals[pix * 3 + k] : 0.0f;
+    const float v_a      = inside ? a.v_render_alphas[pix] : 0.0f;
+    const float v_median = inside ? a.v_render_median[pix] : 0.0f;
+    float bg_dot = 0.0f;
+    if (a.backgrounds) {
+        const float *bg = a.backgrounds + (size_t)image_id * a.cdim;
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (k < nch) bg_dot += bg[k] * v_c[k];
+    }
+    const bool dist = a.v_render_distort != nullptr;
+    float v_distort = 0.f, accum_d = 0.f, accum_w = 0.f, accum_d_buffer = 0.f, accum_w_buffer = 0.f, distort_buffer = 0.f;
+    if (dist && inside) {
+        v_distort      = a.v_render_distort[pix];
+        accum_d_buffer = a.render_colors[pix * a.cdim + nch - 1];
+        accum_d        = accum_d_buffer;
+        accum_w_buffer = a.render_alphas[pix];
+        accum_w        = accum_w_buffer;
+    }
+    const int32_t wave_bin_final = wave_max_i32(bin_final);
+
+    for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) s_acc[s * KP + k] = 0.0f;
+        s_touch[s] = 0;
+    }
+
+    for (int32_t b = 0; b < n_batches; ++b) {
+        const int32_t batch_end  = range_end - 1 - BATCH * b;
+        const int32_t batch_size = min(BATCH, batch_end + 1 - range_start);
+        for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
+            const int32_t idx = batch_end - s;
+            if (idx >= range_start) {
+                const int32_t g = a.flatten_ids[idx];
+                const float *M  = a.ray_transforms + 9 * (size_t)g;
+                const float2 xy = reinterpret_cast<const float2 *>(a.means2d)[g];
+                s_id[s] = g;
+                s_A[s]  = make_float4(M[0], M[1], M[2], xy.x);
+                s_B[s]  = make_float4(M[3], M[4], M[5], xy.y);
+                s_C[s]  = make_float4(M[6], M[7], M[8], a.opacities[g]);
+                const float *n = a.normals + 3 * (size_t)g;
+                s_N[s]  = make_float4(n[0], n[1], n[2], 0.0f);
+                const float *c = a.colors + (size_t)g * a.cdim;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) s_col[s * CH + k] = (k < nch) ? c[k] : 0.0f;
+            }
+        }
+        __syncthreads();
+
+        for (int32_t t = max(0, batch_end - wave_bin_final); t < batch_size; ++t) {
+            const float4 A = s_A[t], B = s_B[t], C = s_C[t];
+            const Surfel s = eval_surfel(A, B, C, px, py);
+            const bool valid = inside && (batch_end - t <= bin_final) && s.valid;
+            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+
+            // branch-free: invalid lanes run with alpha = vis = 0 (every contribution becomes exactly 0)
+            const float alpha = valid ? s.alpha : 0.0f;
+            const float vis   = valid ? s.vis : 0.0f;
+            const float opac  = C.w;
+            float loc[KQ * 4];
+#pragma unroll
+            for (int k = 0; k < KQ * 4; ++k) loc[k] = 0.0f;
+
+            const float ra  = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
+            T              *= ra;
+            const float fac = alpha * T;
+            float v_alpha   = 0.0f;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const float c = s_col[t * CH + k];
+                loc[k]        = fac * v_c[k];
+                v_alpha      += (c * T - buffer[k] * ra) * v_c[k];
+                buffer[k]    += c * fac;
+            }
+            const float4 nr = s_N[t];
+            const float nrv[3] = {nr.x, nr.y, nr.z};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                loc[CH + k]  = fac * v_n[k];
+                v_alpha     += (nrv[k] * T - buffer_n[k] * ra) * v_n[k];
+                buffer_n[k] += nrv[k] * fac;
+            }
+            v_alpha += T_final * ra * (v_a - bg_dot);
+            float v_depth_ch = (valid && (batch_end - t == median_idx)) ? v_median : 0.0f; // extra grad of last channel
+            if (dist) {
+                const float depth = s_col[t * CH + nch - 1];
+                const float dl_dw = 2.0f * (2.0f * (depth * accum_w_buffer - accum_d_buffer) + (accum_d - depth * accum_w));
+                v_alpha        += (dl_dw * T - distort_buffer * ra) * v_distort;
+                accum_d_buffer -= fac * depth;
+                accum_w_buffer -= fac;
+                distort_buffer += dl_dw * fac;
+                v_depth_ch     += 2.0f * fac * (2.0f - 2.0f * T - accum_w + fac) * v_distort;
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (k == nch - 1) loc[k] += v_depth_ch;
+
+            const float ov       = opac * vis;
+            const bool unclamped = valid && (ov <= kMaxAlpha);
+            const float v_G      = unclamped ? opac * v_alpha : 0.0f;
+            const bool use3d     = s.gw3 <= s.gw2;
+            {
+                // 3D branch: through s = zeta.xy / zeta.z
+                const float g3   = use3d ? v_G * -vis : 0.0f;
+                const float a_   = g3 * s.sx * s.rcz_inv, b_ = g3 * s.sy * s.rcz_inv;
+                const float vrc[3] = {a_, b_, -(a_ * s.sx + b_ * s.sy)};
+                const float vhu[3] = {s.hv[1] * vrc[2] - s.hv[2] * vrc[1], s.hv[2] * vrc[0] - s.hv[0] * vrc[2],
+                                      s.hv[0] * vrc[1] - s.hv[1] * vrc[0]};
+                const float vhv[3] = {vrc[1] * s.hu[2] - vrc[2] * s.hu[1], vrc[2] * s.hu[0] - vrc[0] * s.hu[2],
+                                      vrc[0] * s.hu[1] - vrc[1] * s.hu[0]};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    // g3 == 0 can still meet inf/NaN geometry on invalid lanes: select, do not multiply
+                    loc[CH + 3 + k] = (use3d && unclamped) ? -vhu[k] : 0.0f;
+                    loc[CH + 6 + k] = (use3d && unclamped) ? -vhv[k] : 0.0f;
+                    loc[CH + 9 + k] = (use3d && unclamped) ? px * vhu[k] + py * vhv[k] : 0.0f;
+                }
+                // 2D (low-pass) branch
+                const float g2 = (!use3d && unclamped) ? v_G * (-vis * kFilterInvSquare2DGS) : 0.0f;
+                const float vx = g2 * s.dx, vy = g2 * s.dy;
+                loc[CH + 12] = vx;
+                loc[CH + 13] = vy;
+                loc[CH + 14] = unclamped ? vis * v_alpha : 0.0f;
+                if constexpr (ABS) {
+                    loc[CH + 15] = fabsf(vx);
+                    loc[CH + 16] = fabsf(vy);
+                }
+            }
+            float mine = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                const float r = wave_sum4_scatter(loc[4 * j], loc[4 * j + 1], loc[4 * j + 2], loc[4 * j + 3]);
+                if ((int)(lane & 15u) == j) mine = r;
+            }
+            const int vidx = 4 * (int)(lane & 15u) + (int)(lane >> 4);
+            if ((int)(lane & 15u) < KQ && vidx < K) atomicAdd(&s_acc[t * KP + vidx], mine);
+            if (lane == 0) s_touch[t] = 1;
+        }
+        __syncthreads();
+
+        for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
+            if (s < batch_size && s_touch[s]) {
+                const size_t g = (size_t)s_id[s];
+                float *row     = s_acc + s * KP;
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+                    if (k < nch) atomic_add_f32(a.v_colors + g * a.cdim + k, row[k]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) atomic_add_f32(a.v_normals + 3 * g + k, row[CH + k]);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) atomic_add_f32(a.v_ray_transforms + 9 * g + k, row[CH + 3 + k]);
+                const float wz = s_C[s].z; // w_M.z
+                atomic_add_f32(a.v_densify + 2 * g + 0, row[CH + 3 + 2] * wz);
+                atomic_add_f32(a.v_densify + 2 * g + 1, row[CH + 6 + 2] * wz);
+                atomic_add_f32(a.v_means2d + 2 * g + 0, row[CH + 12]);
+                atomic_add_f32(a.v_means2d + 2 * g + 1, row[CH + 13]);
+                atomic_add_f32(a.v_opacities + g, row[CH + 14]);
+                if constexpr (ABS) {
+                    atomic_add_f32(a.v_means2d_abs + 2 * g + 0, row[CH + 15]);
+                    atomic_add_f32(a.v_means2d_abs + 2 * g + 1, row[CH + 16]);
+                }
+#pragma unroll
+                for (int k = 0; k < KP; ++k) row[k] = 0.0f;
+                s_touch[s] = 0;
+            }
+        }
+        // (row s, s_C[s] and the staging slot s of the next batch all belong to the same thread: no barrier needed)
+    }
+}
+
+template <int CH>
+static int launch2_fwd(const Raster2DArgs &a, hipStream_t stream)
+{
+    const uint32_t n_blocks = a.tile_w * a.tile_h * a.n_images;
+    if (n_blocks == 0) return GSX_OK;
+    const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
+    const uint32_t block = a.tile_size <= 8 ? 64u : 256u;
+    const size_t smem    = kBatch2 * (4 * sizeof(float4) + sizeof(float) * CH);
+    raster2d_fwd_kernel<CH><<<dim3(grid), dim3(block), smem, stream>>>(a);
+    return check_launch("raster2d_fwd");
+}
+
+template <int CH, bool ABS>
+static int launch2_bwd(const Raster2DArgs &a, hipStream_t stream)
+{
+    const uint32_t n_blocks = a.tile_w * a.tile_h * a.n_images;
+    if (n_blocks == 0 || a.n_isects == 0) return GSX_OK;
+    const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
+    const uint32_t block = a.tile_size <= 8 ? 64u : 256u;
+    raster2d_bwd_kernel<CH, ABS><<<dim3(grid), dim3(block), Bwd2Cfg<CH, ABS>::smem, stream>>>(a);
+    return check_launch("raster2d_bwd");
+}
+
+template <bool ABS>
+static int dispatch2_bwd(const Raster2DArgs &a, hipStream_t s)
+{
+    const uint32_t n = a.cdim;
+    if (n <= 1) return launch2_bwd<1, ABS>(a, s);
+    if (n <= 2) return launch2_bwd<2, ABS>(a, s);
+    if (n <= 3) return launch2_bwd<3, ABS>(a, s);
+    if (n <= 4) return launch2_bwd<4, ABS>(a, s);
+    if (n <= 8) return launch2_bwd<8, ABS>(a, s);
+    if (n <= 16) return launch2_bwd<16, ABS>(a, s);
+    return launch2_bwd<32, ABS>(a, s);
+}
+
+} // namespace gsx
+
+using namespace gsx;
+
+extern "C" int gsx_raster2d_fwd(const float *means2d, const float *ray_transforms, const float *colors,
+                                const float *opacities, const float *normals, const float *backgrounds,
+                                const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height,
+                                uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int distloss, float *render_colors,
+                                float *render_alphas, float *render_normals, float *render_distort, float *render_median,
+                                int32_t *last_ids, int32_t *median_ids, void *stream)
+{
+    GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster2d_fwd: tile_size must be in [1,16], got %u", tile_size);
+    GSX_REQUIRE(cdim >= 1 && cdim <= 32, "gsx_raster2d_fwd: unsupported number of channels %u (1..32)", cdim);
+    GSX_REQUIRE(render_colors && render_alphas && render_normals && render_distort && render_median && last_ids
+                && median_ids, "gsx_raster2d_fwd: null output");
+    GSX_REQUIRE(n_isects == 0 || (means2d && ray_transforms && colors && opacities && normals && flatten_ids),
+                "gsx_raster2d_fwd: null input");
+    GSX_REQUIRE(isect_offsets != nullptr || n_images * tile_w * tile_h == 0, "gsx_raster2d_fwd: null isect_offsets");
+    Raster2DArgs a{};
+    a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height; a.tile_size = tile_size;
+    a.tile_w = tile_w; a.tile_h = tile_h; a.cdim = cdim; a.distloss = distloss;
+    a.means2d = means2d; a.ray_transforms = ray_transforms; a.colors = colors; a.opacities = opacities;
+    a.normals = normals; a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = isect_offsets;
+    a.flatten_ids = flatten_ids;
+    a.render_colors = render_colors; a.render_alphas = render_alphas; a.render_normals = render_normals;
+    a.render_distort = render_distort; a.render_median = render_median; a.last_ids = last_ids; a.median_ids = median_ids;
+    hipStream_t s = (hipStream_t)stream;
+    if (cdim <= 1) return launch2_fwd<1>(a, s);
+    if (cdim <= 2) return launch2_fwd<2>(a, s);
+    if (cdim <= 3) return launch2_fwd<3>(a, s);
+    if (cdim <= 4) return launch2_fwd<4>(a, s);
+    if (cdim <= 8) return launch2_fwd<8>(a, s);
+    if (cdim <= 16) return launch2_fwd<16>(a, s);
+    return launch2_fwd<32>(a, s);
+}
+
+extern "C" int gsx_raster2d_bwd(const float *means2d, const float *ray_transforms, const float *colors,
+                                const float *opacities, const float *normals, const float *backgrounds,
+                                const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                const float *render_colors, const float *render_alphas, const int32_t *last_ids,
+                                const int32_t *median_ids, const float *v_render_colors, const float *v_render_alphas,
+                                const float *v_render_normals, const float *v_render_distort,
+                                const float *v_render_median, uint32_t n_images, uint32_t n_isects, uint32_t cdim,
+                                uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                                float *v_means2d_abs, float *v_means2d, float *v_ray_transforms, float *v_colors,
+                                float *v_opacities, float *v_normals, float *v_densify, void *stream)
+{
+    GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster2d_bwd: tile_size must be in [1,16], got %u", tile_size);
+    GSX_REQUIRE(cdim >= 1 && cdim <= 32, "gsx_raster2d_bwd: unsupported number of channels %u (1..32)", cdim);
+    GSX_REQUIRE(v_means2d && v_ray_transforms && v_colors && v_opacities && v_normals && v_densify,
+                "gsx_raster2d_bwd: null gradient output");
+    GSX_REQUIRE(n_isects == 0 || (means2d && ray_transforms && colors && opacities && normals && flatten_ids
+                                  && render_colors && render_alphas && last_ids && median_ids && v_render_colors
+                                  && v_render_alphas && v_render_normals && v_render_median && isect_offsets),
+                "gsx_raster2d_bwd: null input");
+    Raster2DArgs a{};
+    a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height; a.tile_size = tile_size;
+    a.tile_w = tile_w; a.tile_h = tile_h; a.cdim = cdim;
+    a.means2d = means2d; a.ray_transforms = ray_transforms; a.colors = colors; a.opacities = opacities;
+    a.normals = normals; a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = isect_offsets;
+    a.flatten_ids = flatten_ids;
+    a.render_colors = const_cast<float *>(render_colors); a.render_alphas = const_cast<float *>(render_alphas);
+    a.last_ids = const_cast<int32_t *>(last_ids); a.median_ids = const_cast<int32_t *>(median_ids);
+    a.v_render_colors = v_render_colors; a.v_render_alphas = v_render_alphas; a.v_render_normals = v_render_normals;
+    a.v_render_distort = v_render_distort; a.v_render_median = v_render_median;
+    a.v_means2d_abs = v_means2d_abs; a.v_means2d = v_means2d; a.v_ray_transforms = v_ray_transforms;
+    a.v_colors = v_colors; a.v_opacities = v_opacities; a.v_normals = v_normals; a.v_densify = v_densify;
+    hipStream_t s = (hipStream_t)stream;
+    return v_means2d_abs ? dispatch2_bwd<true>(a, s) : dispatch2_bwd<false>(a, s);
+}

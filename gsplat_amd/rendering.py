@@ -328,3 +328,144 @@ class _ShUngathered(torch.autograd.Function):
             ctx.degree, means, viewmats, coeffs, None, batch_ids, camera_ids, gaussian_ids, None,
             v_colors.contiguous(), ctx.needs_input_grad[1], False, False, _gathered=False)
         return None, v_means, None, v_coeffs, None, None, None
+
+
+# ==================================================================================================
+# 2DGS
+# ==================================================================================================
+def _depth_to_points(depths: Tensor, camtoworlds: Tensor, Ks: Tensor) -> Tensor:
+    """z-depth map -> world-space points (reference depth_to_points_2dgs, Rendering.cpp:1653-1681)."""
+    H, W = depths.shape[-3], depths.shape[-2]
+    x, y = torch.meshgrid(torch.arange(W, device=depths.device, dtype=depths.dtype),
+                          torch.arange(H, device=depths.device, dtype=depths.dtype), indexing="xy")
+    fx, fy = Ks[..., 0, 0][..., None, None], Ks[..., 1, 1][..., None, None]
+    cx, cy = Ks[..., 0, 2][..., None, None], Ks[..., 1, 2][..., None, None]
+    dirs = torch.stack([(x - cx + 0.5) / fx, (y - cy + 0.5) / fy, torch.ones_like((x - cx) / fx)], dim=-1)
+    directions = torch.einsum("...ij,...hwj->...hwi", camtoworlds[..., :3, :3], dirs)
+    origins = camtoworlds[..., :3, 3]
+    return origins[..., None, None, :] + depths * directions
+
+
+def _depth_to_normal(depths: Tensor, camtoworlds: Tensor, Ks: Tensor) -> Tensor:
+    """Surface normals from a z-depth map (reference depth_to_normal_2dgs, Rendering.cpp:1686-1702)."""
+    points = _depth_to_points(depths, camtoworlds, Ks)
+    dx = points[..., 2:, 1:-1, :] - points[..., :-2, 1:-1, :]
+    dy = points[..., 1:-1, 2:, :] - points[..., 1:-1, :-2, :]
+    normals = torch.linalg.cross(dx, dy, dim=-1)
+    normals = normals / normals.pow(2).sum(-1, keepdim=True).sqrt().clamp_min(1e-12)
+    return torch.nn.functional.pad(normals, (0, 0, 1, 1, 1, 1), value=0.0)
+
+
+def rasterization_2dgs(
+    means: Tensor,  # [..., N, 3]
+    quats: Tensor,  # [..., N, 4]
+    scales: Tensor,  # [..., N, 3]
+    opacities: Tensor,  # [..., N]
+    colors: Tensor,  # [..., (C,) N, D] or [N, K, D]
+    viewmats: Tensor,  # [..., C, 4, 4]
+    Ks: Tensor,  # [..., C, 3, 3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = False,
+    tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: str = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    distloss: bool = False,
+    depth_mode: str = "expected",
+):
+    """Rasterize 2D Gaussians (surfels). Same signature, outputs and ``meta`` as the reference
+    (``gsplat/rendering.py:1358-1568``; orchestrator ``Rendering.cpp:1705-1960``): returns (render_colors,
+    render_alphas, render_normals [world space], surf_normals [from depth] or None, render_distort, render_median,
+    meta). Always uses the AABB tile test and never chunks channels, like the reference."""
+    from ._wrapper import fully_fused_projection_2dgs, rasterize_to_pixels_2dgs
+
+    if render_mode not in _COLOR_MODES + ("D", "ED"):
+        raise ValueError(f"Unsupported render_mode for rasterization_2dgs: {render_mode}")
+    if depth_mode not in ("expected", "median"):
+        raise ValueError(f"Unsupported depth_mode: {depth_mode}")
+    has_color = render_mode in _COLOR_MODES
+    append_depth = render_mode in _DEPTH_MODES
+    expected_depth = render_mode in ("ED", "RGB+ED")
+    if distloss and not append_depth:
+        raise RuntimeError("distloss requires a depth render mode")
+    batch_dims = tuple(means.shape[:-2])
+    nb = len(batch_dims)
+    B = math.prod(batch_dims)
+    N, C = means.shape[-2], viewmats.shape[-3]
+    I = B * C
+    assert means.shape == batch_dims + (N, 3), means.shape
+    assert quats.shape == batch_dims + (N, 4), quats.shape
+    assert scales.shape == batch_dims + (N, 3), scales.shape
+    assert opacities.shape == batch_dims + (N,), opacities.shape
+    assert viewmats.shape == batch_dims + (C, 4, 4), viewmats.shape
+    assert Ks.shape == batch_dims + (C, 3, 3), Ks.shape
+    if sh_degree is not None:
+        assert colors.dim() == 3 and colors.shape[0] == N, "SH coefficients must have shape [N, K, D]"
+        assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
+    if sparse_grad:
+        assert packed, "sparse_grad is only supported when packed is True"
+
+    proj = fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width, height, eps2d=eps2d,
+                                       near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,
+                                       packed=packed, sparse_grad=sparse_grad)
+    if packed:
+        batch_ids, camera_ids, gaussian_ids, _indptr, radii, means2d, depths, ray_transforms, normals = proj
+        proj_opacities = opacities.reshape(B, N)[batch_ids, gaussian_ids]
+        image_ids = batch_ids * C + camera_ids
+    else:
+        radii, means2d, depths, ray_transforms, normals = proj
+        batch_ids = camera_ids = gaussian_ids = image_ids = None
+        proj_opacities = torch.broadcast_to(opacities[..., None, :], batch_dims + (C, N))
+    densify = torch.zeros_like(means2d).requires_grad_(True)
+
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
+        means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=False, packed=packed,
+        n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids)
+    isect_offsets = isect_offset_encode(isect_ids, I, tile_width, tile_height)
+    isect_offsets = isect_offsets.reshape(batch_dims + (C, tile_height, tile_width))
+
+    feats = None
+    if has_color:
+        feats = _project_features(colors, sh_degree, True, means, viewmats, radii, batch_dims, B, C, N, batch_ids,
+                                  camera_ids, gaussian_ids)
+    raster_bg = backgrounds
+    if append_depth:
+        if has_color:
+            feats = torch.cat([feats, depths[..., None]], dim=-1)
+            if backgrounds is not None:
+                raster_bg = torch.cat([backgrounds, torch.zeros_like(backgrounds[..., :1])], dim=-1)
+        else:
+            feats = depths[..., None]
+    assert feats is not None, "rasterization_2dgs requires at least one color or depth channel"
+
+    render_colors, render_alphas, render_normals, render_distort, render_median = rasterize_to_pixels_2dgs(
+        means2d, ray_transforms, feats, proj_opacities, normals, densify, width, height, tile_size, isect_offsets,
+        flatten_ids, backgrounds=raster_bg, packed=packed, absgrad=absgrad, distloss=distloss)
+
+    if expected_depth:
+        ed = render_colors[..., -1:] / render_alphas.clamp_min(1e-10)
+        render_colors = torch.cat([render_colors[..., :-1], ed], dim=-1) if render_colors.shape[-1] > 1 else ed
+    camtoworlds = torch.linalg.inv(viewmats)
+    surf_normals = None
+    if append_depth and has_color:
+        depth_for_normal = render_median if depth_mode == "median" else render_colors[..., -1:]
+        surf_normals = _depth_to_normal(depth_for_normal, camtoworlds, Ks).squeeze(0)  # as Rendering.cpp:1926
+    render_normals = torch.einsum("...ij,...hwj->...hwi", camtoworlds[..., :3, :3], render_normals)
+
+    meta = {
+        "camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": radii, "means2d": means2d, "depths": depths,
+        "ray_transforms": ray_transforms, "opacities": proj_opacities, "normals": normals, "tile_width": tile_width,
+        "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids,
+        "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "width": width, "height": height,
+        "tile_size": tile_size, "n_cameras": C, "render_distort": render_distort, "gradient_2dgs": densify,
+    }
+    return render_colors, render_alphas, render_normals, surf_normals, render_distort, render_median, meta

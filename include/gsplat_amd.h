@@ -201,6 +201,65 @@ int gsx_raster3d_bwd(const float *means2d, const float *conics, const float *col
                      float *v_means2d_abs, float *v_means2d, float *v_conics, float *v_colors, float *v_opacities,
                      void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 2DGS projection: gsplat::projection_2dgs_fused{,_bwd} / projection_2dgs_packed{,_bwd}
+ * (ext.cpp:1163-1184; kernels Projection2DGSFused.cu:39-339, 341-505, Projection2DGSPacked.cu; VJP
+ * Projection2DGS.cuh:29-115). means [B,N,3], quats [B,N,4] (wxyz, normalised inside), scales [B,N,3] (the
+ * third scale is ignored), viewmats [B,C,4,4], Ks [B,C,3,3]. Outputs: radii int32 [B,C,N,2], means2d [B,C,N,2],
+ * depths [B,C,N], ray_transforms [B,C,N,3,3] (rows of K [RS0 RS1 mean_c]), normals [B,C,N,3] (camera space,
+ * facing the camera). Culled rows: radii = 0 and zeros elsewhere. Packed = same count / scan / write protocol as
+ * gsx_project_ewa_packed_*. bwd (dense) fully writes v_means/v_quats/v_scales; v_viewmats (may be NULL) must be
+ * zeroed. bwd (packed) accumulates with atomics: all outputs must be zeroed.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_project_2dgs_fwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                         const float *Ks, uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                         float near_plane, float far_plane, float radius_clip, int32_t *radii, float *means2d,
+                         float *depths, float *ray_transforms, float *normals, void *stream);
+int gsx_project_2dgs_packed_count(const float *means, const float *quats, const float *scales, const float *viewmats,
+                                  const float *Ks, uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                                  float near_plane, float far_plane, float radius_clip, int32_t *visible, void *stream);
+int gsx_project_2dgs_packed_write(const float *means, const float *quats, const float *scales, const float *viewmats,
+                                  const float *Ks, uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                                  float near_plane, float far_plane, float radius_clip, const int64_t *row_offsets,
+                                  int64_t nnz, int64_t *batch_ids, int64_t *camera_ids, int64_t *gaussian_ids,
+                                  int32_t *indptr, int32_t *radii, float *means2d, float *depths,
+                                  float *ray_transforms, float *normals, void *stream);
+int gsx_project_2dgs_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                         const float *Ks, uint32_t B, uint32_t C, uint32_t N, const int32_t *radii,
+                         const float *ray_transforms, const float *v_means2d, const float *v_depths,
+                         const float *v_ray_transforms, const float *v_normals, float *v_means, float *v_quats,
+                         float *v_scales, float *v_viewmats, void *stream);
+int gsx_project_2dgs_packed_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                                const float *Ks, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
+                                const int64_t *batch_ids, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                                const float *ray_transforms, const float *v_means2d, const float *v_depths,
+                                const float *v_ray_transforms, const float *v_normals, float *v_means, float *v_quats,
+                                float *v_scales, float *v_viewmats, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * rasterize_to_pixels (2DGS): gsplat::rasterize_to_pixels_2dgs{,_bwd} (ext.cpp:1186-1199; kernels
+ * RasterizeToPixels2DGSSerialBatch{Fwd,Bwd}.cu). 1 <= cdim <= 32 in one launch (the reference does not chunk
+ * channels on this path either); the LAST channel is the depth used by the distortion / median outputs.
+ * fwd outputs: render_colors [I,H,W,cdim], render_alphas [I,H,W,1], render_normals [I,H,W,3], render_distort
+ * [I,H,W,1] (zeros unless distloss), render_median [I,H,W,1], last_ids / median_ids int32 [I,H,W].
+ * bwd: v_render_distort NULL = distloss off; gradient outputs must be ZERO-initialised; v_means2d_abs may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_raster2d_fwd(const float *means2d, const float *ray_transforms, const float *colors, const float *opacities,
+                     const float *normals, const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                     const int32_t *flatten_ids, uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width,
+                     uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int distloss,
+                     float *render_colors, float *render_alphas, float *render_normals, float *render_distort,
+                     float *render_median, int32_t *last_ids, int32_t *median_ids, void *stream);
+int gsx_raster2d_bwd(const float *means2d, const float *ray_transforms, const float *colors, const float *opacities,
+                     const float *normals, const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                     const int32_t *flatten_ids, const float *render_colors, const float *render_alphas,
+                     const int32_t *last_ids, const int32_t *median_ids, const float *v_render_colors,
+                     const float *v_render_alphas, const float *v_render_normals, const float *v_render_distort,
+                     const float *v_render_median, uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width,
+                     uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *v_means2d_abs,
+                     float *v_means2d, float *v_ray_transforms, float *v_colors, float *v_opacities, float *v_normals,
+                     float *v_densify, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -412,3 +412,286 @@ int64_t gso_raster3d_indices(const float *means2d, const float *conics, const fl
     }
     return count;
 }
+
+/* ==========================================================================================
+ * 2DGS (surfel) compositing. Follows RasterizeToPixels2DGSSerialBatchFwd.cu:43-465 and
+ * RasterizeToPixels2DGSSerialBatchBwd.cu:41-700 (the distortion and median outputs exist only in
+ * the CUDA kernels; colours / alphas / normals also equal _torch_impl_2dgs.py:111-334).
+ * ray_transforms rows are (u_M, v_M, w_M) = rows of K*[RS0 RS1 mean_c].
+ * ========================================================================================== */
+#define FILTER_INV_SQUARE_2DGS 2.0f /* gsplat/cuda/include/Rasterization.h:40 */
+
+typedef struct {
+    int valid;
+    float alpha, vis, opac, gw3, gw2, sx, sy, dx, dy;
+    float hu[3], hv[3], rc[3], wM[3];
+} S2Sample;
+
+static S2Sample s2_eval(const float *means2d, const float *rt, const float *opacities, int32_t g, float px, float py)
+{
+    S2Sample s;
+    memset(&s, 0, sizeof(s));
+    const float *M = rt + 9 * (size_t)g;
+    for (int k = 0; k < 3; ++k) {
+        s.wM[k] = M[6 + k];
+        s.hu[k] = px * M[6 + k] - M[k];
+        s.hv[k] = py * M[6 + k] - M[3 + k];
+    }
+    s.rc[0] = s.hu[1] * s.hv[2] - s.hu[2] * s.hv[1];
+    s.rc[1] = s.hu[2] * s.hv[0] - s.hu[0] * s.hv[2];
+    s.rc[2] = s.hu[0] * s.hv[1] - s.hu[1] * s.hv[0];
+    if (s.rc[2] == 0.0f) return s; /* Fwd.cu: `if (ray_cross.z == 0.0) continue;` */
+    s.sx = s.rc[0] / s.rc[2];
+    s.sy = s.rc[1] / s.rc[2];
+    s.gw3 = s.sx * s.sx + s.sy * s.sy;
+    s.dx  = means2d[2 * (size_t)g] - px;
+    s.dy  = means2d[2 * (size_t)g + 1] - py;
+    s.gw2 = FILTER_INV_SQUARE_2DGS * (s.dx * s.dx + s.dy * s.dy);
+    const float sigma = 0.5f * fminf(s.gw3, s.gw2);
+    s.opac  = opacities[g];
+    s.vis   = expf(-sigma);
+    s.alpha = fminf(MAX_ALPHA, s.opac * s.vis);
+    s.valid = !(sigma < 0.0f || s.alpha < ALPHA_THRESHOLD);
+    return s;
+}
+
+void gso_raster2d_fwd(const float *means2d, const float *ray_transforms, const float *colors, const float *opacities,
+                      const float *normals, const float *backgrounds, const uint8_t *masks,
+                      const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images, uint32_t n_isects,
+                      uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w,
+                      uint32_t tile_h, int distloss, float *render_colors, float *render_alphas, float *render_normals,
+                      float *render_distort, float *render_median, int32_t *last_ids, int32_t *median_ids)
+{
+    const int64_t n_tiles = (int64_t)tile_w * tile_h, total = n_tiles * n_images;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t blk = 0; blk < total; ++blk) {
+        const uint32_t img = (uint32_t)(blk / n_tiles), tile = (uint32_t)(blk % n_tiles);
+        const uint32_t tx = tile % tile_w, ty = tile / tile_w;
+        const float *bg = backgrounds ? backgrounds + (size_t)img * cdim : NULL;
+        const int masked = masks && !masks[blk];
+        const int32_t start = isect_offsets[blk];
+        const int32_t end   = (blk == total - 1) ? (int32_t)n_isects : isect_offsets[blk + 1];
+        float *acc = (float *)malloc(sizeof(float) * cdim);
+        for (uint32_t ly = 0; ly < tile_size; ++ly)
+            for (uint32_t lx = 0; lx < tile_size; ++lx) {
+                const uint32_t ox = tx * tile_size + lx, oy = ty * tile_size + ly;
+                if (ox >= width || oy >= height) continue;
+                const size_t pix = ((size_t)img * height + oy) * width + ox;
+                if (masked) {
+                    for (uint32_t k = 0; k < cdim; ++k) render_colors[pix * cdim + k] = bg ? bg[k] : 0.0f;
+                    render_alphas[pix] = 0.0f;
+                    for (int k = 0; k < 3; ++k) render_normals[pix * 3 + k] = 0.0f;
+                    render_distort[pix] = 0.0f;
+                    render_median[pix]  = 0.0f;
+                    last_ids[pix] = 0;
+                    median_ids[pix] = 0;
+                    continue;
+                }
+                const float px = (float)ox + 0.5f, py = (float)oy + 0.5f;
+                float T = 1.0f, distort = 0.0f, accum_vis_depth = 0.0f, median_depth = 0.0f;
+                float nrm[3] = {0.f, 0.f, 0.f};
+                int32_t cur = 0, median_idx = 0;
+                for (uint32_t k = 0; k < cdim; ++k) acc[k] = 0.0f;
+                for (int32_t idx = start; idx < end; ++idx) {
+                    const int32_t g = flatten_ids[idx];
+                    const S2Sample s = s2_eval(means2d, ray_transforms, opacities, g, px, py);
+                    if (!s.valid) continue;
+                    const float next_T = T * (1.0f - s.alpha);
+                    if (next_T <= TRANSMITTANCE_THRESHOLD) break;
+                    const float vis = s.alpha * T;
+                    const float *c = colors + (size_t)g * cdim;
+                    for (uint32_t k = 0; k < cdim; ++k) acc[k] += c[k] * vis;
+                    for (int k = 0; k < 3; ++k) nrm[k] += normals[3 * (size_t)g + k] * vis;
+                    if (distloss) {
+                        const float depth = c[cdim - 1];
+                        const float d0 = vis * depth * (1.0f - T), d1 = vis * accum_vis_depth;
+                        distort += 2.0f * (d0 - d1);
+                        accum_vis_depth += vis * depth;
+                    }
+                    if (T > 0.5f) {
+                        median_depth = c[cdim - 1];
+                        median_idx   = idx;
+                    }
+                    cur = idx;
+                    T   = next_T;
+                }
+                for (uint32_t k = 0; k < cdim; ++k) render_colors[pix * cdim + k] = bg ? acc[k] + T * bg[k] : acc[k];
+                render_alphas[pix] = 1.0f - T;
+                for (int k = 0; k < 3; ++k) render_normals[pix * 3 + k] = nrm[k];
+                render_distort[pix] = distloss ? distort : 0.0f;
+                render_median[pix]  = median_depth;
+                last_ids[pix]   = cur;
+                median_ids[pix] = median_idx;
+            }
+        free(acc);
+    }
+}
+
+#define ATOMIC_ADD(dst, val) _Pragma("omp atomic") dst += (double)(val)
+
+/* Backward; per-sample math in fp32 like the reference, sums over pixels in fp64 (see gso_raster3d_bwd).
+ * v_render_distort may be NULL (distloss off). */
+void gso_raster2d_bwd(const float *means2d, const float *ray_transforms, const float *colors, const float *opacities,
+                      const float *normals, const float *backgrounds, const uint8_t *masks,
+                      const int32_t *isect_offsets, const int32_t *flatten_ids, const float *render_colors,
+                      const float *render_alphas, const int32_t *last_ids, const int32_t *median_ids,
+                      const float *v_render_colors, const float *v_render_alphas, const float *v_render_normals,
+                      const float *v_render_distort, const float *v_render_median, uint32_t n_images,
+                      uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+                      uint32_t tile_w, uint32_t tile_h, int64_t n_rows, double *v_means2d_abs, double *v_means2d,
+                      double *v_ray_transforms, double *v_colors, double *v_opacities, double *v_normals,
+                      double *v_densify)
+{
+    const int64_t n_tiles = (int64_t)tile_w * tile_h, total = n_tiles * n_images;
+    if (v_means2d_abs) memset(v_means2d_abs, 0, sizeof(double) * 2 * (size_t)n_rows);
+    memset(v_means2d, 0, sizeof(double) * 2 * (size_t)n_rows);
+    memset(v_ray_transforms, 0, sizeof(double) * 9 * (size_t)n_rows);
+    memset(v_colors, 0, sizeof(double) * (size_t)cdim * (size_t)n_rows);
+    memset(v_opacities, 0, sizeof(double) * (size_t)n_rows);
+    memset(v_normals, 0, sizeof(double) * 3 * (size_t)n_rows);
+    memset(v_densify, 0, sizeof(double) * 2 * (size_t)n_rows);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t blk = 0; blk < total; ++blk) {
+        if (masks && !masks[blk]) continue;
+        const uint32_t img = (uint32_t)(blk / n_tiles), tile = (uint32_t)(blk % n_tiles);
+        const uint32_t tx = tile % tile_w, ty = tile / tile_w;
+        const float *bg = backgrounds ? backgrounds + (size_t)img * cdim : NULL;
+        const int32_t start = isect_offsets[blk];
+        const int32_t end   = (blk == total - 1) ? (int32_t)n_isects : isect_offsets[blk + 1];
+        if (end <= start) continue;
+        float *buffer = (float *)malloc(sizeof(float) * cdim);
+        for (uint32_t ly = 0; ly < tile_size; ++ly)
+            for (uint32_t lx = 0; lx < tile_size; ++lx) {
+                const uint32_t ox = tx * tile_size + lx, oy = ty * tile_size + ly;
+                if (ox >= width || oy >= height) continue;
+                const size_t pix = ((size_t)img * height + oy) * width + ox;
+                const float px = (float)ox + 0.5f, py = (float)oy + 0.5f;
+                const float T_final = 1.0f - render_alphas[pix];
+                float T = T_final;
+                const int32_t bin_final = last_ids[pix], median_idx = median_ids[pix];
+                const float *v_c = v_render_colors + pix * cdim, *v_n = v_render_normals + pix * 3;
+                const float v_a = v_render_alphas[pix], v_median = v_render_median[pix];
+                float buffer_n[3] = {0.f, 0.f, 0.f};
+                for (uint32_t k = 0; k < cdim; ++k) buffer[k] = 0.0f;
+                float v_distort = 0.f, accum_d = 0.f, accum_w = 0.f, accum_d_buffer = 0.f, accum_w_buffer = 0.f,
+                      distort_buffer = 0.f;
+                if (v_render_distort) {
+                    v_distort      = v_render_distort[pix];
+                    accum_d_buffer = render_colors[pix * cdim + cdim - 1];
+                    accum_d        = accum_d_buffer;
+                    accum_w_buffer = render_alphas[pix];
+                    accum_w        = accum_w_buffer;
+                }
+                int32_t hi = bin_final < end - 1 ? bin_final : end - 1;
+                for (int32_t idx = hi; idx >= start; --idx) {
+                    const int32_t g = flatten_ids[idx];
+                    const S2Sample s = s2_eval(means2d, ray_transforms, opacities, g, px, py);
+                    if (!s.valid) continue;
+                    const float *col = colors + (size_t)g * cdim, *nr = normals + 3 * (size_t)g;
+                    if (idx == median_idx) ATOMIC_ADD(v_colors[(size_t)g * cdim + cdim - 1], v_median);
+                    const float ra = 1.0f / fmaxf(MIN_ONE_MINUS_ALPHA, 1.0f - s.alpha);
+                    T *= ra;
+                    const float fac = s.alpha * T;
+                    float v_alpha = 0.0f;
+                    for (uint32_t k = 0; k < cdim; ++k) {
+                        ATOMIC_ADD(v_colors[(size_t)g * cdim + k], fac * v_c[k]);
+                        v_alpha += (col[k] * T - buffer[k] * ra) * v_c[k];
+                    }
+                    for (int k = 0; k < 3; ++k) {
+                        ATOMIC_ADD(v_normals[3 * (size_t)g + k], fac * v_n[k]);
+                        v_alpha += (nr[k] * T - buffer_n[k] * ra) * v_n[k];
+                    }
+                    v_alpha += T_final * ra * v_a;
+                    if (bg) {
+                        float accum = 0.0f;
+                        for (uint32_t k = 0; k < cdim; ++k) accum += bg[k] * v_c[k];
+                        v_alpha += -T_final * ra * accum;
+                    }
+                    if (v_render_distort) {
+                        const float depth = col[cdim - 1];
+                        const float dl_dw =
+                            2.0f * (2.0f * (depth * accum_w_buffer - accum_d_buffer) + (accum_d - depth * accum_w));
+                        v_alpha += (dl_dw * T - distort_buffer * ra) * v_distort;
+                        accum_d_buffer -= fac * depth;
+                        accum_w_buffer -= fac;
+                        distort_buffer += dl_dw * fac;
+                        ATOMIC_ADD(v_colors[(size_t)g * cdim + cdim - 1],
+                                   2.0f * fac * (2.0f - 2.0f * T - accum_w + fac) * v_distort);
+                    }
+                    if (s.opac * s.vis <= MAX_ALPHA) {
+                        const float v_G = s.opac * v_alpha;
+                        if (s.gw3 <= s.gw2) {
+                            const float vsx = v_G * -s.vis * s.sx, vsy = v_G * -s.vis * s.sy;
+                            const float a = vsx / s.rc[2], b = vsy / s.rc[2];
+                            const float vrc[3] = {a, b, -(a * s.sx + b * s.sy)};
+                            /* v_h_u = h_v x v_rc ; v_h_v = v_rc x h_u */
+                            const float vhu[3] = {s.hv[1] * vrc[2] - s.hv[2] * vrc[1], s.hv[2] * vrc[0] - s.hv[0] * vrc[2],
+                                                  s.hv[0] * vrc[1] - s.hv[1] * vrc[0]};
+                            const float vhv[3] = {vrc[1] * s.hu[2] - vrc[2] * s.hu[1], vrc[2] * s.hu[0] - vrc[0] * s.hu[2],
+                                                  vrc[0] * s.hu[1] - vrc[1] * s.hu[0]};
+                            for (int k = 0; k < 3; ++k) {
+                                ATOMIC_ADD(v_ray_transforms[9 * (size_t)g + k], -vhu[k]);
+                                ATOMIC_ADD(v_ray_transforms[9 * (size_t)g + 3 + k], -vhv[k]);
+                                ATOMIC_ADD(v_ray_transforms[9 * (size_t)g + 6 + k], px * vhu[k] + py * vhv[k]);
+                            }
+                            ATOMIC_ADD(v_densify[2 * (size_t)g + 0], -vhu[2] * s.wM[2]);
+                            ATOMIC_ADD(v_densify[2 * (size_t)g + 1], -vhv[2] * s.wM[2]);
+                        } else {
+                            const float vx = v_G * (-s.vis * FILTER_INV_SQUARE_2DGS * s.dx);
+                            const float vy = v_G * (-s.vis * FILTER_INV_SQUARE_2DGS * s.dy);
+                            ATOMIC_ADD(v_means2d[2 * (size_t)g + 0], vx);
+                            ATOMIC_ADD(v_means2d[2 * (size_t)g + 1], vy);
+                            if (v_means2d_abs) {
+                                ATOMIC_ADD(v_means2d_abs[2 * (size_t)g + 0], fabsf(vx));
+                                ATOMIC_ADD(v_means2d_abs[2 * (size_t)g + 1], fabsf(vy));
+                            }
+                        }
+                        ATOMIC_ADD(v_opacities[g], s.vis * v_alpha);
+                    }
+                    for (uint32_t k = 0; k < cdim; ++k) buffer[k] += col[k] * fac;
+                    for (int k = 0; k < 3; ++k) buffer_n[k] += nr[k] * fac;
+                }
+            }
+        free(buffer);
+    }
+}
+
+/* (gaussian, pixel, image) triples that contribute (RasterizeToIndices2DGSSerialBatch.cu): drives the reference's
+ * accumulate_2dgs when pinning. Call with NULL outputs for the count. */
+int64_t gso_raster2d_indices(const float *means2d, const float *ray_transforms, const float *opacities,
+                             const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images,
+                             uint32_t n_isects, uint32_t n_per_image, uint32_t width, uint32_t height,
+                             uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int64_t *gaussian_ids,
+                             int64_t *pixel_ids, int64_t *image_ids)
+{
+    const int64_t n_tiles = (int64_t)tile_w * tile_h, total = n_tiles * n_images;
+    int64_t count = 0;
+    for (int64_t blk = 0; blk < total; ++blk) {
+        const uint32_t img = (uint32_t)(blk / n_tiles), tile = (uint32_t)(blk % n_tiles);
+        const uint32_t tx = tile % tile_w, ty = tile / tile_w;
+        const int32_t start = isect_offsets[blk];
+        const int32_t end   = (blk == total - 1) ? (int32_t)n_isects : isect_offsets[blk + 1];
+        for (uint32_t ly = 0; ly < tile_size; ++ly)
+            for (uint32_t lx = 0; lx < tile_size; ++lx) {
+                const uint32_t ox = tx * tile_size + lx, oy = ty * tile_size + ly;
+                if (ox >= width || oy >= height) continue;
+                const float px = (float)ox + 0.5f, py = (float)oy + 0.5f;
+                float T = 1.0f;
+                for (int32_t idx = start; idx < end; ++idx) {
+                    const int32_t g = flatten_ids[idx];
+                    const S2Sample s = s2_eval(means2d, ray_transforms, opacities, g, px, py);
+                    if (!s.valid) continue;
+                    const float next_T = T * (1.0f - s.alpha);
+                    if (next_T <= TRANSMITTANCE_THRESHOLD) break;
+                    if (gaussian_ids) {
+                        gaussian_ids[count] = g % (int64_t)n_per_image;
+                        pixel_ids[count]    = (int64_t)oy * width + ox;
+                        image_ids[count]    = img;
+                    }
+                    ++count;
+                    T = next_T;
+                }
+            }
+    }
+    return count;
+}

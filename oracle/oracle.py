@@ -67,6 +67,7 @@ def lib() -> ctypes.CDLL:
         _lib.gso_det_logf.restype = ctypes.c_float
         _lib.gso_det_logf.argtypes = [ctypes.c_float]
         _lib.gso_raster3d_indices.restype = ctypes.c_int64
+        _lib.gso_raster2d_indices.restype = ctypes.c_int64
         _lib.gso_isect_emit.restype = ctypes.c_int
     return _lib
 
@@ -445,4 +446,141 @@ def rasterize_to_indices(means2d, conics, opacities, image_width, image_height, 
     p = np.zeros(n, dtype=np.int64)
     i = np.zeros(n, dtype=np.int64)
     lib().gso_raster3d_indices(*args, _p(g), _p(p), _p(i))
+    return torch.from_numpy(g), torch.from_numpy(p), torch.from_numpy(i)
+
+
+# ----------------------------------------------------------------------------------------------
+# 2DGS (surfels)
+# ----------------------------------------------------------------------------------------------
+def fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width: int, height: int, near_plane=0.01,
+                                far_plane=1e10, radius_clip=0.0):
+    """gsplat.fully_fused_projection_2dgs, dense (Projection2DGSFused.cu:39-339; torch restatement
+    _torch_impl_2dgs.py:27-108). Differences of the CUDA kernel from the torch reference that are followed here:
+    the third scale is ignored (RS = R * Rq * diag(sx, sy, 1), :167), near/far culling uses <= / >= (:155),
+    `distance == 0` culls (:216), radius_clip (:236), image culling with <= / >= (:246-249).
+    means [..., N, 3] ... -> radii int32 [..., C, N, 2], means2d, depths, ray_transforms [..., C, N, 3, 3] (rows
+    M0, M1, M2 of K [RS0 RS1 mean_c]), normals [..., C, N, 3]. Differentiable (torch autograd = the reference's way of
+    obtaining gradients for its tests, tests/test_2dgs.py)."""
+    R_cw, t_cw = viewmats[..., :3, :3], viewmats[..., :3, 3]
+    means_c = torch.einsum("...cij,...nj->...cni", R_cw, means) + t_cw[..., None, :]
+    Rq = quat_to_rotmat(quats)
+    s2 = torch.cat([scales[..., :2], torch.ones_like(scales[..., :1])], dim=-1)
+    RS_wl = Rq * s2[..., None, :]
+    RS_cl = torch.einsum("...cij,...njk->...cnik", R_cw, RS_wl)
+    normals = RS_cl[..., 2]
+    cos = -(normals * means_c).sum(-1, keepdim=True)
+    normals = normals * torch.where(cos > 0, 1.0, -1.0)
+    T_cl = torch.cat([RS_cl[..., :2], means_c[..., None]], dim=-1)
+    Kfull = torch.zeros_like(Ks)
+    Kfull[..., 0, 0], Kfull[..., 0, 2] = Ks[..., 0, 0], Ks[..., 0, 2]
+    Kfull[..., 1, 1], Kfull[..., 1, 2] = Ks[..., 1, 1], Ks[..., 1, 2]
+    Kfull[..., 2, 2] = 1.0  # the kernel only reads Ks[0], Ks[2], Ks[4], Ks[5] (:176)
+    M = torch.einsum("...cij,...cnjk->...cnik", Kfull, T_cl)  # rows M0, M1, M2
+    test = torch.tensor([1.0, 1.0, -1.0], dtype=means.dtype)
+    d = (M[..., 2, :] * M[..., 2, :] * test).sum(-1, keepdim=True)
+    ok = d != 0
+    f = torch.where(ok, test / torch.where(ok, d, torch.ones_like(d)), torch.zeros_like(test))
+    means2d = torch.stack([(f * M[..., 0, :] * M[..., 2, :]).sum(-1), (f * M[..., 1, :] * M[..., 2, :]).sum(-1)], -1)
+    tmp = torch.stack([(f * M[..., 0, :] * M[..., 0, :]).sum(-1), (f * M[..., 1, :] * M[..., 1, :]).sum(-1)], -1)
+    ext = torch.sqrt((means2d.detach() ** 2 - tmp.detach()).clamp_min(1e-4))
+    radius = torch.ceil(GAUSSIAN_EXTEND * ext)
+    depths = means_c[..., 2]
+    valid = ok.squeeze(-1) & (depths.detach() > near_plane) & (depths.detach() < far_plane)
+    valid = valid & ~((radius[..., 0] <= radius_clip) & (radius[..., 1] <= radius_clip))
+    m = means2d.detach()
+    valid = valid & (m[..., 0] + radius[..., 0] > 0) & (m[..., 0] - radius[..., 0] < width) \
+        & (m[..., 1] + radius[..., 1] > 0) & (m[..., 1] - radius[..., 1] < height)
+    radii = torch.where(valid[..., None], radius, torch.zeros_like(radius)).to(torch.int32)
+    return radii, means2d, depths, M, normals
+
+
+def _raster2d_common(means2d, ray_transforms, colors, opacities, normals, isect_offsets):
+    off = _np(isect_offsets, np.int32)
+    I, th, tw = int(np.prod(off.shape[:-2])), off.shape[-2], off.shape[-1]
+    cdim = colors.shape[-1]
+    return (off, I, th, tw, cdim, _np(means2d, np.float32).reshape(-1, 2),
+            _np(ray_transforms, np.float32).reshape(-1, 9), _np(colors, np.float32).reshape(-1, cdim),
+            _np(opacities, np.float32).reshape(-1), _np(normals, np.float32).reshape(-1, 3))
+
+
+def rasterize_to_pixels_2dgs(means2d, ray_transforms, colors, opacities, normals, image_width, image_height, tile_size,
+                             isect_offsets, flatten_ids, backgrounds=None, masks=None, distloss=False):
+    """gsplat.rasterize_to_pixels_2dgs forward (RasterizeToPixels2DGSSerialBatchFwd.cu:43-465). Returns
+    (render_colors, render_alphas, render_normals, render_distort, render_median, last_ids, median_ids)."""
+    off, I, th, tw, cdim, m2, rt, cl, op, nr = _raster2d_common(means2d, ray_transforms, colors, opacities, normals,
+                                                                isect_offsets)
+    fl = _np(flatten_ids, np.int32)
+    bg = None if backgrounds is None else _np(backgrounds, np.float32).reshape(I, cdim)
+    mk = None if masks is None else _np(masks, np.uint8).reshape(I, th, tw)
+    H, W = image_height, image_width
+    rc = np.zeros((I, H, W, cdim), np.float32)
+    ra = np.zeros((I, H, W, 1), np.float32)
+    rn = np.zeros((I, H, W, 3), np.float32)
+    rd = np.zeros((I, H, W, 1), np.float32)
+    rm = np.zeros((I, H, W, 1), np.float32)
+    li = np.zeros((I, H, W), np.int32)
+    mi = np.zeros((I, H, W), np.int32)
+    u32 = ctypes.c_uint32
+    lib().gso_raster2d_fwd(_p(m2), _p(rt), _p(cl), _p(op), _p(nr), _p(bg), _p(mk), _p(off), _p(fl), u32(I),
+                           u32(fl.shape[0]), u32(cdim), u32(W), u32(H), u32(tile_size), u32(tw), u32(th),
+                           ctypes.c_int(int(distloss)), _p(rc), _p(ra), _p(rn), _p(rd), _p(rm), _p(li), _p(mi))
+    return tuple(torch.from_numpy(x) for x in (rc, ra, rn, rd, rm, li, mi))
+
+
+def rasterize_to_pixels_2dgs_bwd(means2d, ray_transforms, colors, opacities, normals, image_width, image_height,
+                                 tile_size, isect_offsets, flatten_ids, render_colors, render_alphas, last_ids,
+                                 median_ids, v_render_colors, v_render_alphas, v_render_normals, v_render_distort,
+                                 v_render_median, backgrounds=None, masks=None, absgrad=False):
+    """gsplat rasterize_to_pixels_2dgs backward (RasterizeToPixels2DGSSerialBatchBwd.cu:41-700). v_render_distort
+    None = distloss off. Returns dict of float64 numpy arrays."""
+    off, I, th, tw, cdim, m2, rt, cl, op, nr = _raster2d_common(means2d, ray_transforms, colors, opacities, normals,
+                                                                isect_offsets)
+    fl = _np(flatten_ids, np.int32)
+    rows = m2.shape[0]
+    H, W = image_height, image_width
+    bg = None if backgrounds is None else _np(backgrounds, np.float32).reshape(I, cdim)
+    mk = None if masks is None else _np(masks, np.uint8).reshape(I, th, tw)
+    rc = _np(render_colors, np.float32).reshape(I, H, W, cdim)
+    ra = _np(render_alphas, np.float32).reshape(I, H, W)
+    li = _np(last_ids, np.int32).reshape(I, H, W)
+    mi = _np(median_ids, np.int32).reshape(I, H, W)
+    vc = _np(v_render_colors, np.float32).reshape(I, H, W, cdim)
+    va = _np(v_render_alphas, np.float32).reshape(I, H, W)
+    vn = _np(v_render_normals, np.float32).reshape(I, H, W, 3)
+    vd = None if v_render_distort is None else _np(v_render_distort, np.float32).reshape(I, H, W)
+    vm = _np(v_render_median, np.float32).reshape(I, H, W)
+    z = lambda *s: np.zeros(s, np.float64)
+    out = {"v_means2d": z(rows, 2), "v_ray_transforms": z(rows, 9), "v_colors": z(rows, cdim), "v_opacities": z(rows),
+           "v_normals": z(rows, 3), "v_densify": z(rows, 2)}
+    v_abs = z(rows, 2) if absgrad else None
+    u32 = ctypes.c_uint32
+    lib().gso_raster2d_bwd(_p(m2), _p(rt), _p(cl), _p(op), _p(nr), _p(bg), _p(mk), _p(off), _p(fl), _p(rc), _p(ra),
+                           _p(li), _p(mi), _p(vc), _p(va), _p(vn), _p(vd), _p(vm), u32(I), u32(fl.shape[0]), u32(cdim),
+                           u32(W), u32(H), u32(tile_size), u32(tw), u32(th), ctypes.c_int64(rows), _p(v_abs),
+                           _p(out["v_means2d"]), _p(out["v_ray_transforms"]), _p(out["v_colors"]),
+                           _p(out["v_opacities"]), _p(out["v_normals"]), _p(out["v_densify"]))
+    if absgrad:
+        out["v_means2d_abs"] = v_abs
+    if backgrounds is not None:
+        out["v_backgrounds"] = (vc.astype(np.float64) * (1.0 - ra.astype(np.float64))[..., None]).sum(axis=(1, 2))
+    return out
+
+
+def rasterize_to_indices_2dgs(means2d, ray_transforms, opacities, image_width, image_height, tile_size, isect_offsets,
+                              flatten_ids):
+    """(gaussian_ids, pixel_ids, image_ids) of the contributing pairs — input of the reference's accumulate_2dgs."""
+    off = _np(isect_offsets, np.int32)
+    I, th, tw = int(np.prod(off.shape[:-2])), off.shape[-2], off.shape[-1]
+    m2 = _np(means2d, np.float32)
+    n_per = m2.shape[-2]
+    m2 = m2.reshape(-1, 2)
+    rt = _np(ray_transforms, np.float32).reshape(-1, 9)
+    op = _np(opacities, np.float32).reshape(-1)
+    fl = _np(flatten_ids, np.int32)
+    u32 = ctypes.c_uint32
+    args = [_p(m2), _p(rt), _p(op), _p(off), _p(fl), u32(I), u32(fl.shape[0]), u32(n_per), u32(image_width),
+            u32(image_height), u32(tile_size), u32(tw), u32(th)]
+    n = lib().gso_raster2d_indices(*args, None, None, None)
+    g, p, i = (np.zeros(n, np.int64) for _ in range(3))
+    lib().gso_raster2d_indices(*args, _p(g), _p(p), _p(i))
     return torch.from_numpy(g), torch.from_numpy(p), torch.from_numpy(i)

@@ -279,6 +279,86 @@ def main():
                         rast_v_means2d=g[0].numpy(), rast_v_conics=g[1].numpy(), rast_v_colors=g[2].numpy(),
                         rast_v_opacities=g[3].numpy(), rast_v_backgrounds=g[4].numpy())
 
+    # ---- 6. 2DGS: projection vs _torch_impl_2dgs.py:27-108, compositing vs accumulate_2dgs (:111-212) -------
+    print("[6] 2DGS projection / rasterize_to_pixels_2dgs vs gsplat/cuda/_torch_impl_2dgs.py + autograd")
+    from gsplat.cuda import _torch_impl_2dgs as R2
+
+    gold2 = {}
+    sc2 = scales.clone()
+    sc2[:, 2] = 1.0  # the CUDA kernel ignores the third scale (Projection2DGSFused.cu:167); the torch ref does not
+    mr, qr, sr, vr = (t.clone().requires_grad_(True) for t in (means, quats, sc2, viewmats))
+    rad_r, m2_r, d_r, M_r, n_r = R2._fully_fused_projection_2dgs(mr, qr, sr, vr, Ks, width, height, 0.01, 1e10)
+    mo, qo, so, vo = (t.clone().requires_grad_(True) for t in (means, quats, scales, viewmats))
+    rad_o, m2_o, d_o, M_o, n_o = O.fully_fused_projection_2dgs(mo, qo, so, vo, Ks, width, height, 0.01, 1e10)
+    valid = (rad_r > 0).all(-1) & (rad_o > 0).all(-1)
+    agree = ((rad_r > 0).all(-1) == (rad_o > 0).all(-1)).float().mean().item()
+    print(f"  visibility agreement {agree:.5f}, valid {valid.sum().item()}/{valid.numel()}")
+    assert agree > 0.999
+    assert (rad_r[valid] - rad_o[valid]).abs().max().item() <= 1
+    close("2dgs means2d", m2_o[valid], m2_r[valid], 1e-4, 1e-3)
+    close("2dgs depths", d_o[valid], d_r[valid], 1e-5, 1e-5)
+    close("2dgs ray_transforms", M_o[valid], M_r[valid], 1e-4, 1e-3)
+    close("2dgs normals", n_o[valid], n_r[valid], 1e-5, 1e-5)
+    w_m2, w_d, w_M, w_n = torch.randn_like(m2_r), torch.randn_like(d_r), torch.randn_like(M_r), torch.randn_like(n_r)
+    vm = valid.float()
+
+    def loss2(m2_, d_, M_, n_):
+        return ((m2_ * w_m2).sum(-1) * vm).sum() + (d_ * w_d * vm).sum() + ((M_ * w_M).sum((-1, -2)) * vm).sum() \
+            + ((n_ * w_n).sum(-1) * vm).sum()
+
+    g_r = torch.autograd.grad(loss2(m2_r, d_r, M_r, n_r), [mr, qr, sr, vr])
+    g_o = torch.autograd.grad(loss2(m2_o, d_o, M_o, n_o), [mo, qo, so, vo])
+    for nm, a, b in zip(("v_means", "v_quats", "v_scales", "v_viewmats"), g_o, g_r):
+        if nm == "v_scales":
+            a, b = a[:, :2], b[:, :2]  # third scale: ignored by the kernel
+        scl = b.abs().max().item() + 1e-12
+        close(f"2dgs {nm} (rel to max)", a / scl, b / scl, 0.0, 2e-3)
+    gold2.update(means=means.numpy(), quats=quats.numpy(), scales=scales.numpy(), viewmats=viewmats.numpy(),
+                 Ks=Ks.numpy(), wh=np.array([width, height]), proj_radii=rad_r.numpy().astype(np.int32),
+                 proj_means2d=m2_r.detach().numpy(), proj_depths=d_r.detach().numpy(),
+                 proj_ray_transforms=M_r.detach().numpy(), proj_normals=n_r.detach().numpy(),
+                 proj_valid=valid.numpy(), proj_w_means2d=w_m2.numpy(), proj_w_depths=w_d.numpy(),
+                 proj_w_ray_transforms=w_M.numpy(), proj_w_normals=w_n.numpy(), proj_v_means=g_r[0].numpy(),
+                 proj_v_quats=g_r[1].numpy(), proj_v_scales=g_r[2].numpy(), proj_v_viewmats=g_r[3].numpy())
+
+    rad2, m22, dep2, M2, nrm2 = rad_o, m2_o.detach(), d_o.detach(), M_o.detach(), n_o.detach()
+    tpg, ids, fl = O.isect_tiles(m22, rad2, dep2, tile_size, tw, th, sort=True)  # 2DGS always uses the AABB test
+    off = O.isect_offset_encode(ids, C, tw, th)
+    cols = torch.cat([colors[None].expand(C, -1, -1), dep2[..., None]], -1).contiguous()  # RGB + depth channel
+    bg = torch.cat([torch.rand(C, 3), torch.zeros(C, 1)], -1)
+    out_o = O.rasterize_to_pixels_2dgs(m22, M2, cols, op_c, nrm2, width, height, tile_size, off, fl, backgrounds=bg,
+                                       distloss=True)
+    rc_o, ra_o, rn_o, rd_o, rm_o, li_o, mi_o = out_o
+    g_ids, p_ids, i_ids = O.rasterize_to_indices_2dgs(m22, M2, op_c, width, height, tile_size, off, fl)
+    m2g, Mg, colg, nrg = (t.clone().requires_grad_(True) for t in (m22, M2, cols, nrm2))
+    opg = op_c.clone().contiguous().requires_grad_(True)
+    bgg = bg.clone().requires_grad_(True)
+    rc_r, ra_r, rn_r = R2.accumulate_2dgs(m2g, Mg, opg, colg, nrg, g_ids, p_ids, i_ids, width, height)
+    rc_r = rc_r + bgg[:, None, None, :] * (1.0 - ra_r)
+    close("2dgs render_colors", rc_o, rc_r, 1e-4, 5e-5)
+    close("2dgs render_alphas", ra_o, ra_r, 1e-5, 2e-5)
+    close("2dgs render_normals", rn_o, rn_r, 1e-4, 5e-5)
+    v_rc, v_ra, v_rn = torch.randn_like(rc_r), torch.randn_like(ra_r), torch.randn_like(rn_r)
+    g = torch.autograd.grad((rc_r * v_rc).sum() + (ra_r * v_ra).sum() + (rn_r * v_rn).sum(),
+                            [m2g, Mg, colg, opg, nrg, bgg])
+    gr = O.rasterize_to_pixels_2dgs_bwd(m22, M2, cols, op_c, nrm2, width, height, tile_size, off, fl, rc_o, ra_o, li_o,
+                                        mi_o, v_rc, v_ra, v_rn, None, torch.zeros_like(ra_o), backgrounds=bg)
+    for key, b in zip(("v_means2d", "v_ray_transforms", "v_colors", "v_opacities", "v_normals", "v_backgrounds"), g):
+        a = torch.from_numpy(gr[key]).reshape(b.shape)
+        scl = b.abs().max().item() + 1e-12
+        close(f"2dgs {key} (rel to max)", a / scl, b / scl, 0.0, 5e-4)
+    gold2.update(rast_means2d=m22.numpy(), rast_ray_transforms=M2.numpy(), rast_colors=cols.numpy(),
+                 rast_opacities=op_c.numpy().copy(), rast_normals=nrm2.numpy(), rast_backgrounds=bg.numpy(),
+                 rast_wh=np.array([width, height, tile_size]), rast_offsets=off.numpy(), rast_flatten_ids=fl.numpy(),
+                 rast_render_colors=rc_r.detach().numpy(), rast_render_alphas=ra_r.detach().numpy(),
+                 rast_render_normals=rn_r.detach().numpy(), rast_v_render_colors=v_rc.numpy(),
+                 rast_v_render_alphas=v_ra.numpy(), rast_v_render_normals=v_rn.numpy(), rast_v_means2d=g[0].numpy(),
+                 rast_v_ray_transforms=g[1].numpy(), rast_v_colors=g[2].numpy(), rast_v_opacities=g[3].numpy(),
+                 rast_v_normals=g[4].numpy(), rast_v_backgrounds=g[5].numpy())
+    path2 = os.path.join(args.out, "garden_quarter_2dgs.npz")
+    np.savez_compressed(path2, **gold2)
+    print(f"wrote {path2} ({os.path.getsize(path2) / 1e6:.2f} MB)")
+
     path = os.path.join(args.out, "garden_quarter.npz")
     np.savez_compressed(path, **gold)
     print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")

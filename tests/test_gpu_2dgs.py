@@ -1,0 +1,278 @@
+"""GPU parity of the 2DGS path (projection_2dgs_*, rasterize_to_pixels_2dgs, rasterization_2dgs) against the CPU
+oracle on the same seeded inputs and against the committed outputs of the reference's Python (tests/golden/
+garden_quarter_2dgs.npz). Tolerances: the reference's own for this path (tests/test_2dgs.py: rtol/atol 1e-4 forward,
+scale-relative gradients)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import assert_close_ratio, assert_grad_close, make_scene, to_t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import gsplat_amd
+
+    return gsplat_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def g2():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "garden_quarter_2dgs.npz")))
+
+
+def cpu(t):
+    return None if t is None else t.detach().cpu()
+
+
+def _proj_compare(G, O, sc, W, H, pose):
+    names = ("means", "quats", "scales", "viewmats")
+    lg = [sc[k].to(DEV).clone().requires_grad_(k != "viewmats" or pose) for k in names]
+    lo = [sc[k].clone().requires_grad_(k != "viewmats" or pose) for k in names]
+    rad, m2, d, M, n = G.fully_fused_projection_2dgs(*lg, sc["Ks"].to(DEV), W, H)
+    rad_o, m2_o, d_o, M_o, n_o = O.fully_fused_projection_2dgs(*lo, sc["Ks"], W, H)
+    vis_g, vis_o = (cpu(rad) > 0).all(-1), (rad_o > 0).all(-1)
+    assert (vis_g == vis_o).float().mean() > 0.999
+    valid = vis_g & vis_o
+    assert (cpu(rad)[valid] - rad_o[valid]).abs().max() <= 1
+    assert_close_ratio(cpu(m2)[valid], m2_o[valid], 1e-4, 1e-3, max_bad_ratio=5e-4, name="means2d")
+    assert_close_ratio(cpu(d)[valid], d_o[valid], 1e-5, 1e-5, name="depths")
+    assert_close_ratio(cpu(M)[valid], M_o[valid], 1e-4, 1e-3, name="ray_transforms")
+    assert_close_ratio(cpu(n)[valid], n_o[valid], 1e-5, 1e-5, name="normals")
+    assert (cpu(m2)[~vis_g] == 0).all()  # culled rows are zero-filled
+    g = torch.Generator().manual_seed(1)
+    w = [torch.randn(t.shape, generator=g) for t in (m2_o, d_o, M_o, n_o)]
+    vm = valid.float()
+
+    def loss(m2_, d_, M_, n_, dev):
+        ws = [x.to(dev) for x in w]
+        v = vm.to(dev)
+        return ((m2_ * ws[0]).sum(-1) * v).sum() + (d_ * ws[1] * v).sum() + ((M_ * ws[2]).sum((-1, -2)) * v).sum() \
+            + ((n_ * ws[3]).sum(-1) * v).sum()
+
+    loss(m2, d, M, n, DEV).backward()
+    loss(m2_o, d_o, M_o, n_o, "cpu").backward()
+    for nm, a, b in zip(names, lg, lo):
+        if b.grad is None:
+            continue
+        ga, gb = cpu(a.grad), b.grad
+        if nm == "scales":
+            assert (ga[..., 2] == 0).all()
+            ga, gb = ga[..., :2], gb[..., :2]
+        assert_grad_close(ga, gb, rel=2e-3, name="v_" + nm)
+
+
+@pytest.mark.parametrize("pose", [False, True])
+def test_projection_2dgs_dense_fwd_bwd(G, O, pose):
+    sc, W, H = make_scene(N=4000, C=3, width=200, height=136, seed=3)
+    _proj_compare(G, O, sc, W, H, pose)
+
+
+def test_projection_2dgs_packed_matches_dense(G):
+    sc, W, H = make_scene(N=3000, C=2, width=160, height=120, seed=4)
+    dsc = {k: v.to(DEV) for k, v in sc.items()}
+    names = ("means", "quats", "scales", "viewmats")
+    ld = [dsc[k].clone().requires_grad_(True) for k in names]
+    lp = [dsc[k].clone().requires_grad_(True) for k in names]
+    rad, m2, d, M, n = G.fully_fused_projection_2dgs(*ld, dsc["Ks"], W, H)
+    bi, ci, gi, indptr, rad_p, m2_p, d_p, M_p, n_p = G.fully_fused_projection_2dgs(*lp, dsc["Ks"], W, H, packed=True)
+    vis = (rad > 0).all(-1)
+    c_ref, g_ref = torch.where(vis)
+    assert torch.equal(ci, c_ref) and torch.equal(gi, g_ref) and (bi == 0).all()
+    assert torch.equal(indptr.long(), torch.cat([torch.zeros(1, device=DEV, dtype=torch.long), vis.sum(-1).cumsum(0)]))
+    for a, b in ((rad_p, rad[vis]), (m2_p, m2[vis]), (d_p, d[vis]), (M_p, M[vis]), (n_p, n[vis])):
+        assert torch.equal(a, b)
+    g = torch.Generator().manual_seed(2)
+    w = [torch.randn(t.shape, generator=g).to(DEV) for t in (m2_p, d_p, M_p, n_p)]
+    ((m2_p * w[0]).sum() + (d_p * w[1]).sum() + (M_p * w[2]).sum() + (n_p * w[3]).sum()).backward()
+    ((m2[vis] * w[0]).sum() + (d[vis] * w[1]).sum() + (M[vis] * w[2]).sum() + (n[vis] * w[3]).sum()).backward()
+    for nm, a, b in zip(names, lp, ld):
+        assert_grad_close(cpu(a.grad), cpu(b.grad), rel=1e-4, name="packed v_" + nm)
+
+
+def _raster2d_case(G, O, N, C, W, H, tile_size, D, seed, bg=False, masks=False, absgrad=False, distloss=True,
+                   scale_range=(0.02, 0.15)):
+    sc, W, H = make_scene(N=N, C=C, width=W, height=H, seed=seed, scale_range=scale_range)
+    dsc = {k: v.to(DEV) for k, v in sc.items()}
+    rad, m2, d, M, nrm = G.fully_fused_projection_2dgs(dsc["means"], dsc["quats"], dsc["scales"], dsc["viewmats"],
+                                                       dsc["Ks"], W, H)
+    op = dsc["opacities"][None].expand(C, -1).contiguous()
+    tw, th = math.ceil(W / tile_size), math.ceil(H / tile_size)
+    _, ids, fl = G.isect_tiles(m2, rad, d, tile_size, tw, th)
+    off = G.isect_offset_encode(ids, C, tw, th)
+    g = torch.Generator().manual_seed(seed)
+    colors = torch.cat([torch.rand(C, N, D - 1, generator=g).to(DEV), d[..., None]], -1).contiguous()
+    backgrounds = torch.rand(C, D, generator=g).to(DEV) if bg else None
+    tile_masks = (torch.rand(C, th, tw, generator=g) > 0.3).to(DEV) if masks else None
+    leaves = [t.clone().requires_grad_(True) for t in (m2, M, colors, op, nrm)]
+    densify = torch.zeros_like(m2).requires_grad_(True)
+    bgl = backgrounds.clone().requires_grad_(True) if bg else None
+    outs = G.rasterize_to_pixels_2dgs(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], densify, W, H, tile_size,
+                                      off, fl, backgrounds=bgl, masks=tile_masks, absgrad=absgrad, distloss=distloss)
+    ref = O.rasterize_to_pixels_2dgs(cpu(m2), cpu(M), cpu(colors), cpu(op), cpu(nrm), W, H, tile_size, cpu(off), cpu(fl),
+                                     backgrounds=cpu(backgrounds), masks=cpu(tile_masks), distloss=distloss)
+    names = ("render_colors", "render_alphas", "render_normals", "render_distort", "render_median")
+    for nm, a, b in zip(names, outs, ref[:5]):
+        # median depth flips between neighbouring surfels when T crosses 0.5 within rounding: allow a few more
+        ratio = 2e-3 if nm in ("render_median", "render_distort") else 2e-4
+        assert_close_ratio(cpu(a), b, 2e-4, 5e-5, max_bad_ratio=ratio, name=nm)
+    v = [torch.randn(b.shape, generator=g) for b in ref[:5]]
+    if not distloss:
+        v[3].zero_()
+    sum((a * b.to(DEV)).sum() for a, b in zip(outs, v)).backward()
+    go = O.rasterize_to_pixels_2dgs_bwd(cpu(m2), cpu(M), cpu(colors), cpu(op), cpu(nrm), W, H, tile_size, cpu(off),
+                                        cpu(fl), ref[0], ref[1], ref[5], ref[6], v[0], v[1], v[2],
+                                        v[3] if distloss else None, v[4], backgrounds=cpu(backgrounds),
+                                        masks=cpu(tile_masks), absgrad=absgrad)
+    for leaf, key in zip(leaves + [densify], ("v_means2d", "v_ray_transforms", "v_colors", "v_opacities", "v_normals",
+                                              "v_densify")):
+        assert_grad_close(cpu(leaf.grad), go[key].reshape(leaf.shape), rel=3e-3, max_bad_ratio=5e-4, name=key)
+    if bg:
+        assert_grad_close(cpu(bgl.grad), go["v_backgrounds"], rel=1e-3, name="v_backgrounds")
+    if absgrad:
+        assert_grad_close(cpu(leaves[0].absgrad), go["v_means2d_abs"].reshape(leaves[0].shape), rel=3e-3,
+                          max_bad_ratio=5e-4, name="absgrad")
+
+
+@pytest.mark.parametrize("D", [1, 4, 7, 20])
+def test_rasterize_2dgs_channels(G, O, D):
+    _raster2d_case(G, O, N=5000, C=2, W=200, H=136, tile_size=16, D=D, seed=50 + D, bg=True)
+
+
+@pytest.mark.parametrize("tile_size", [16, 8])
+def test_rasterize_2dgs_tile_sizes_masks_absgrad(G, O, tile_size):
+    _raster2d_case(G, O, N=3000, C=1, W=150, H=100, tile_size=tile_size, D=4, seed=60 + tile_size, bg=True, masks=True,
+                   absgrad=True)
+
+
+def test_rasterize_2dgs_no_distloss_long_lists(G, O):
+    _raster2d_case(G, O, N=6000, C=1, W=96, H=64, tile_size=16, D=4, seed=70, distloss=False, scale_range=(0.2, 0.6))
+
+
+def test_golden_2dgs_vs_reference_outputs(G, g2):
+    """HIP kernels against outputs of the REFERENCE's _torch_impl_2dgs.py (+ autograd), committed fixture."""
+    W, H = (int(v) for v in g2["wh"])
+    leaves = [to_t(g2[k], DEV).clone().requires_grad_(True) for k in ("means", "quats", "scales", "viewmats")]
+    rad, m2, d, M, n = G.fully_fused_projection_2dgs(*leaves, to_t(g2["Ks"], DEV), W, H)
+    valid = to_t(g2["proj_valid"])
+    assert ((cpu(rad) > 0).all(-1) == (to_t(g2["proj_radii"]) > 0).all(-1)).float().mean() > 0.999
+    # mean2d = sum(f M0 M2) with f = 1/distance: surfels seen almost edge-on (distance -> 0) are ill-conditioned in
+    # fp32, a handful of rows differ between any two evaluation orders
+    assert_close_ratio(cpu(m2)[valid], to_t(g2["proj_means2d"])[valid], 1e-4, 1e-3, max_bad_ratio=5e-4, name="means2d")
+    assert_close_ratio(cpu(M)[valid], to_t(g2["proj_ray_transforms"])[valid], 1e-4, 1e-3, name="ray_transforms")
+    assert_close_ratio(cpu(n)[valid], to_t(g2["proj_normals"])[valid], 1e-5, 1e-5, name="normals")
+    vm = valid.float().to(DEV)
+    loss = ((m2 * to_t(g2["proj_w_means2d"], DEV)).sum(-1) * vm).sum() + (d * to_t(g2["proj_w_depths"], DEV) * vm).sum() \
+        + ((M * to_t(g2["proj_w_ray_transforms"], DEV)).sum((-1, -2)) * vm).sum() \
+        + ((n * to_t(g2["proj_w_normals"], DEV)).sum(-1) * vm).sum()
+    loss.backward()
+    for nm, leaf in zip(("v_means", "v_quats", "v_scales", "v_viewmats"), leaves):
+        a, e = cpu(leaf.grad), to_t(g2["proj_" + nm])
+        if nm == "v_scales":
+            a, e = a[:, :2], e[:, :2]
+        assert_grad_close(a, e, rel=2e-3, name=nm)
+    Wr, Hr, ts = (int(v) for v in g2["rast_wh"])
+    t = {k: to_t(g2["rast_" + k], DEV) for k in ("means2d", "ray_transforms", "colors", "opacities", "normals",
+                                                 "offsets", "flatten_ids", "backgrounds")}
+    lv = [t[k].clone().requires_grad_(True) for k in ("means2d", "ray_transforms", "colors", "opacities", "normals",
+                                                      "backgrounds")]
+    densify = torch.zeros_like(lv[0]).requires_grad_(True)
+    rc, ra, rn, rd, rm = G.rasterize_to_pixels_2dgs(lv[0], lv[1], lv[2], lv[3], lv[4], densify, Wr, Hr, ts,
+                                                    t["offsets"], t["flatten_ids"], backgrounds=lv[5])
+    assert_close_ratio(cpu(rc), g2["rast_render_colors"], 2e-4, 5e-5, max_bad_ratio=2e-4, name="render_colors")
+    assert_close_ratio(cpu(ra), g2["rast_render_alphas"], 2e-4, 5e-5, max_bad_ratio=2e-4, name="render_alphas")
+    assert_close_ratio(cpu(rn), g2["rast_render_normals"], 2e-4, 5e-5, max_bad_ratio=2e-4, name="render_normals")
+    ((rc * to_t(g2["rast_v_render_colors"], DEV)).sum() + (ra * to_t(g2["rast_v_render_alphas"], DEV)).sum()
+     + (rn * to_t(g2["rast_v_render_normals"], DEV)).sum()).backward()
+    for leaf, key in zip(lv, ("v_means2d", "v_ray_transforms", "v_colors", "v_opacities", "v_normals", "v_backgrounds")):
+        assert_grad_close(cpu(leaf.grad), g2["rast_" + key], rel=3e-3, max_bad_ratio=5e-4, name=key)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("render_mode,sh_degree,distloss", [("RGB", None, False), ("RGB+ED", 3, True), ("D", None, False)])
+def test_rasterization_2dgs_pipeline_matches_oracle(G, O, packed, render_mode, sh_degree, distloss):
+    """End-to-end rasterization_2dgs(): forward outputs + gradients to the leaves vs the oracle stages chained with
+    torch autograd (projection: torch; compositing: C oracle backward injected)."""
+    sc, W, H = make_scene(N=2500, C=2, width=160, height=112, seed=9, sh_degree=sh_degree)
+    C, N = 2, 2500
+    names = ("means", "quats", "scales", "opacities", "colors")
+    lg = {k: sc[k].to(DEV).clone().requires_grad_(True) for k in names}
+    out = G.rasterization_2dgs(lg["means"], lg["quats"], lg["scales"], lg["opacities"], lg["colors"],
+                               sc["viewmats"].to(DEV), sc["Ks"].to(DEV), W, H, sh_degree=sh_degree, packed=packed,
+                               render_mode=render_mode, distloss=distloss)
+    rc, ra, rn, sn, rd, rm, meta = out
+    # oracle chain
+    lo = {k: sc[k].clone().requires_grad_(True) for k in names}
+    rad, m2, d, M, nrm = O.fully_fused_projection_2dgs(lo["means"], lo["quats"], lo["scales"], sc["viewmats"], sc["Ks"],
+                                                       W, H)
+    op = lo["opacities"][None].expand(C, -1)
+    has_color, has_depth = render_mode != "D", render_mode != "RGB"
+    feats = None
+    if has_color:
+        if sh_degree is None:
+            feats = lo["colors"][None].expand(C, -1, -1)
+        else:
+            feats = torch.clamp_min(O.spherical_harmonics(sh_degree, lo["means"][None], sc["viewmats"][None],
+                                                          lo["colors"], (rad > 0).all(-1)[None])[0] + 0.5, 0.0)
+    if has_depth:
+        feats = d[..., None] if feats is None else torch.cat([feats, d[..., None]], -1)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    _, ids, fl = O.isect_tiles(m2, rad, d, 16, tw, th, sort=True)
+    off = O.isect_offset_encode(ids, C, tw, th)
+    ref = O.rasterize_to_pixels_2dgs(m2, M, feats, op, nrm, W, H, 16, off, fl, distloss=distloss)
+    rc_o, ra_o, rn_o, rd_o, rm_o, li_o, mi_o = ref
+    expected = render_mode == "RGB+ED"
+    a_ = ra_o.clamp_min(1e-10)
+    rc_cmp = torch.cat([rc_o[..., :-1], rc_o[..., -1:] / a_], -1) if expected else rc_o
+    R_c2w = torch.linalg.inv(sc["viewmats"])[:, :3, :3]
+    rn_cmp = torch.einsum("cij,chwj->chwi", R_c2w, rn_o)
+    assert meta["isect_ids"].numel() == ids.numel()
+    assert_close_ratio(cpu(rc), rc_cmp, 1e-3, 1e-4, max_bad_ratio=1e-3, name="render_colors")
+    assert_close_ratio(cpu(ra), ra_o, 1e-4, 5e-5, max_bad_ratio=1e-3, name="render_alphas")
+    assert_close_ratio(cpu(rn), rn_cmp, 1e-3, 1e-4, max_bad_ratio=1e-3, name="render_normals")
+    assert_close_ratio(cpu(rd), rd_o, 1e-3, 1e-4, max_bad_ratio=3e-3, name="render_distort")
+    assert (sn is None) == (not (has_color and has_depth))
+    g = torch.Generator().manual_seed(11)
+    v_rc, v_ra, v_rn, v_rd = (torch.randn(t.shape, generator=g) for t in (rc_cmp, ra_o, rn_cmp, rd_o))
+    if not distloss:
+        v_rd.zero_()
+    ((rc * v_rc.to(DEV)).sum() + (ra * v_ra.to(DEV)).sum() + (rn * v_rn.to(DEV)).sum() + (rd * v_rd.to(DEV)).sum()).backward()
+    # oracle backward: cotangents of the raw compositing outputs
+    if expected:
+        v_feat = torch.cat([v_rc[..., :-1], v_rc[..., -1:] / a_], -1)
+        v_alpha = v_ra - (v_rc[..., -1:] * rc_o[..., -1:] / (a_ * a_)) * (ra_o > 1e-10)
+    else:
+        v_feat, v_alpha = v_rc, v_ra
+    v_rn_cam = torch.einsum("cij,chwi->chwj", R_c2w, v_rn)
+    gr = O.rasterize_to_pixels_2dgs_bwd(m2, M, feats, op, nrm, W, H, 16, off, fl, rc_o, ra_o, li_o, mi_o, v_feat, v_alpha,
+                                        v_rn_cam, v_rd if distloss else None, torch.zeros_like(ra_o))
+
+    def t(k, like):
+        return torch.from_numpy(gr[k]).to(like.dtype).reshape(like.shape)
+
+    torch.autograd.backward([m2, M, feats, op, nrm], [t("v_means2d", m2), t("v_ray_transforms", M), t("v_colors", feats),
+                                                      t("v_opacities", op), t("v_normals", nrm)])
+    for k in names:
+        if lo[k].grad is None:
+            assert lg[k].grad is None or float(lg[k].grad.abs().max()) == 0.0
+            continue
+        ga, gb = cpu(lg[k].grad), lo[k].grad
+        if k == "scales":
+            ga, gb = ga[..., :2], gb[..., :2]
+        assert_grad_close(ga, gb, rel=5e-3, max_bad_ratio=1e-3, name=f"v_{k} packed={packed} mode={render_mode}")
