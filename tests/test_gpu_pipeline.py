@@ -155,3 +155,36 @@ def test_full_size_properties_1m_1080p(G):
     r, a, _ = G.rasterization(*common, f, sc["viewmats"], sc["Ks"], W, H, packed=True)
     r.sum().backward()
     assert abs(f.grad.double().sum() - a.double().sum()) <= 1e-3 * a.double().sum()
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_distributed_single_rank_matches_local(G, packed):
+    """Reference contract tests/test_rasterization.py:819-868: with a 1-rank RCCL group, distributed=True must equal
+    the local result (exercises both seams through torch.distributed backend 'nccl' = RCCL)."""
+    import os
+
+    import torch.distributed as dist
+
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        sc, W, H = make_scene(N=3000, C=2, width=160, height=112, seed=13, sh_degree=2)
+        g = torch.Generator().manual_seed(3)
+        v_rc, v_ra = torch.randn(2, H, W, 3, generator=g), torch.randn(2, H, W, 1, generator=g)
+        rc0, ra0, _, l0 = _run(G, sc, W, H, v_rc, v_ra, sh_degree=2, packed=packed)
+        rc1, ra1, meta, l1 = _run(G, sc, W, H, v_rc, v_ra, sh_degree=2, packed=packed, distributed=True)
+        assert torch.equal(rc0, rc1) and torch.equal(ra0, ra1)
+        for k in NAMES:
+            assert_grad_close(l1[k].grad.cpu(), l0[k].grad.cpu(), rel=1e-4, name=f"distributed v_{k}")
+        with pytest.raises(ValueError):
+            G.rasterization(sc["means"].to(DEV), sc["quats"].to(DEV), sc["scales"].to(DEV), sc["opacities"].to(DEV),
+                            sc["colors"].to(DEV), sc["viewmats"].to(DEV), sc["Ks"].to(DEV), W, H, sh_degree=2,
+                            distributed=True, absgrad=True)
+    finally:
+        if created:
+            dist.destroy_process_group()
