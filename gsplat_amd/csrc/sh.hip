@@ -260,6 +260,219 @@ __global__ void __launch_bounds__(256) sh_bwd_packed_kernel(const ShArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// D == 3 fast path: ONE THREAD PER ROW. The basis is evaluated once per row (not once per channel), the coefficient
+// row ([K][3] floats, contiguous) is streamed with 16-byte loads when its size allows, and the backward writes the
+// whole v_coeffs row from one thread (16-byte stores). Degree is a template parameter so the basis unrolls.
+// ------------------------------------------------------------------------------------------
+template <int NF>
+__device__ __forceinline__ void load_row(const float *src, bool vec, float *dst)
+{
+    if (vec) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+#pragma unroll
+        for (int i = 0; i < (NF + 3) / 4; ++i) {
+            const float4 v = s4[i];
+            if (4 * i + 0 < NF) dst[4 * i + 0] = v.x;
+            if (4 * i + 1 < NF) dst[4 * i + 1] = v.y;
+            if (4 * i + 2 < NF) dst[4 * i + 2] = v.z;
+            if (4 * i + 3 < NF) dst[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) dst[i] = src[i];
+    }
+}
+
+__device__ __forceinline__ void row_ids(const ShArgs &a, int64_t row, uint32_t &b, uint32_t &c, uint32_t &g, int64_t &crow)
+{
+    if (a.nnz >= 0) {
+        b = (uint32_t)a.batch_ids[row]; c = (uint32_t)a.camera_ids[row]; g = (uint32_t)a.gaussian_ids[row];
+        crow = a.coeffs_gathered ? row : (int64_t)g;
+    } else {
+        g = (uint32_t)(row % a.N); c = (uint32_t)((row / a.N) % a.C); b = (uint32_t)(row / ((int64_t)a.N * a.C));
+        crow = g;
+    }
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(256) sh3_fwd_kernel(const ShArgs a)
+{
+    constexpr int NB = (DEG + 1) * (DEG + 1), NF = NB * 3;
+    const int64_t rows = a.nnz >= 0 ? a.nnz : (int64_t)a.B * a.C * a.N;
+    const int64_t row  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    float *out = a.colors + row * 3;
+    if (a.masks && !a.masks[row]) {
+        out[0] = out[1] = out[2] = 0.0f;
+        return;
+    }
+    uint32_t b, c, g;
+    int64_t crow;
+    row_ids(a, row, b, c, g, crow);
+    float d[3];
+    view_dir(a, b, c, g, d);
+    const float inv = safe_inv_norm(d);
+    float Y[NB];
+    sh_bases<false>(DEG, d[0] * inv, d[1] * inv, d[2] * inv, Y, nullptr, nullptr, nullptr);
+    const bool vec = ((a.K * 3u) & 3u) == 0u; // rows are 16-byte aligned iff K*3 floats is a multiple of 4
+    float co[NF];
+    load_row<NF>(a.coeffs + (size_t)crow * a.K * 3, vec, co);
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        r0 += Y[k] * co[3 * k];
+        r1 += Y[k] * co[3 * k + 1];
+        r2 += Y[k] * co[3 * k + 2];
+    }
+    out[0] = r0; out[1] = r1; out[2] = r2;
+}
+
+// store a v_coeffs row: values for the first NF floats, zeros up to K*3 (only when `fill_tail`)
+template <int NF>
+__device__ __forceinline__ void store_row(float *dst, bool vec, const float *val, uint32_t row_floats, bool fill_tail)
+{
+    if (vec) {
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+#pragma unroll
+        for (int i = 0; i < (NF + 3) / 4; ++i) {
+            float4 v;
+            v.x = (4 * i + 0 < NF) ? val[4 * i + 0] : 0.f;
+            v.y = (4 * i + 1 < NF) ? val[4 * i + 1] : 0.f;
+            v.z = (4 * i + 2 < NF) ? val[4 * i + 2] : 0.f;
+            v.w = (4 * i + 3 < NF) ? val[4 * i + 3] : 0.f;
+            // a partially filled last vector only happens when NF % 4 != 0; its tail floats belong to k >= NB
+            if (4 * i + 3 < NF || fill_tail) d4[i] = v;
+            else {
+                if (4 * i + 0 < NF) dst[4 * i + 0] = v.x;
+                if (4 * i + 1 < NF) dst[4 * i + 1] = v.y;
+                if (4 * i + 2 < NF) dst[4 * i + 2] = v.z;
+            }
+        }
+        if (fill_tail)
+            for (uint32_t i = (uint32_t)((NF + 3) / 4); i < row_floats / 4; ++i) d4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) dst[i] = val[i];
+        if (fill_tail)
+            for (uint32_t i = NF; i < row_floats; ++i) dst[i] = 0.0f;
+    }
+}
+
+// per-row VJP pieces shared by the packed and dense backward
+template <int DEG, bool WANT_MEANS>
+__device__ __forceinline__ void sh3_row_vjp(const ShArgs &a, uint32_t b, uint32_t c, uint32_t g, int64_t crow,
+                                            const float *vc, bool vec, float *vco /*[NB*3], accumulated*/,
+                                            float *v_dir /*[3], accumulated (d/dmean)*/)
+{
+    constexpr int NB = (DEG + 1) * (DEG + 1), NF = NB * 3;
+    float d[3];
+    view_dir(a, b, c, g, d);
+    const float inv = safe_inv_norm(d);
+    const float x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
+    if constexpr (WANT_MEANS) {
+        float Y[NB], Yx[NB], Yy[NB], Yz[NB];
+        sh_bases<true>(DEG, x, y, z, Y, Yx, Yy, Yz);
+        float co[NF];
+        load_row<NF>(a.coeffs + (size_t)crow * a.K * 3, vec, co);
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            vco[3 * k] += Y[k] * vc[0]; vco[3 * k + 1] += Y[k] * vc[1]; vco[3 * k + 2] += Y[k] * vc[2];
+            const float w = co[3 * k] * vc[0] + co[3 * k + 1] * vc[1] + co[3 * k + 2] * vc[2];
+            gx += Yx[k] * w; gy += Yy[k] * w; gz += Yz[k] * w;
+        }
+        const float dot = gx * x + gy * y + gz * z; // through the normalisation: (g - (g.n) n) / |d|
+        v_dir[0] += (gx - dot * x) * inv;
+        v_dir[1] += (gy - dot * y) * inv;
+        v_dir[2] += (gz - dot * z) * inv;
+    } else {
+        float Y[NB];
+        sh_bases<false>(DEG, x, y, z, Y, nullptr, nullptr, nullptr);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            vco[3 * k] += Y[k] * vc[0]; vco[3 * k + 1] += Y[k] * vc[1]; vco[3 * k + 2] += Y[k] * vc[2];
+        }
+    }
+}
+
+template <int DEG, bool WANT_MEANS>
+__global__ void __launch_bounds__(256) sh3_bwd_packed_kernel(const ShArgs a)
+{
+    constexpr int NB = (DEG + 1) * (DEG + 1), NF = NB * 3;
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.nnz) return;
+    uint32_t b, c, g;
+    int64_t crow;
+    row_ids(a, row, b, c, g, crow);
+    const bool vec = ((a.K * 3u) & 3u) == 0u;
+    float *out     = a.v_coeffs + (size_t)crow * a.K * 3;
+    float vco[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) vco[i] = 0.0f;
+    if (a.masks && !a.masks[row]) {
+        if (a.coeffs_gathered) store_row<NF>(out, vec, vco, a.K * 3, true);
+        return;
+    }
+    const float vc[3] = {a.v_colors[row * 3], a.v_colors[row * 3 + 1], a.v_colors[row * 3 + 2]};
+    float v_dir[3] = {0.f, 0.f, 0.f};
+    sh3_row_vjp<DEG, WANT_MEANS>(a, b, c, g, crow, vc, vec, vco, v_dir);
+    if (a.coeffs_gathered) store_row<NF>(out, vec, vco, a.K * 3, true);
+    else if (!a.atomic_coeffs) store_row<NF>(out, vec, vco, a.K * 3, false); // zero-initialised by the caller
+    else {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) atomic_add_f32(out + i, vco[i]);
+    }
+    if constexpr (WANT_MEANS) {
+        float *vm = a.v_means + ((size_t)b * a.N + g) * 3;
+        atomic_add_f32(vm + 0, v_dir[0]);
+        atomic_add_f32(vm + 1, v_dir[1]);
+        atomic_add_f32(vm + 2, v_dir[2]);
+    }
+}
+
+// dense: one thread per Gaussian loops over the images; v_coeffs written once, v_means via atomics per batch
+template <int DEG, bool WANT_MEANS>
+__global__ void __launch_bounds__(256) sh3_bwd_dense_kernel(const ShArgs a)
+{
+    constexpr int NB = (DEG + 1) * (DEG + 1), NF = NB * 3;
+    const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= (int64_t)a.N) return;
+    const uint32_t g = (uint32_t)gi;
+    const bool vec   = ((a.K * 3u) & 3u) == 0u;
+    float vco[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) vco[i] = 0.0f;
+    for (uint32_t b = 0; b < a.B; ++b) {
+        float v_dir[3] = {0.f, 0.f, 0.f};
+        for (uint32_t c = 0; c < a.C; ++c) {
+            const int64_t row = ((int64_t)b * a.C + c) * a.N + g;
+            if (a.masks && !a.masks[row]) continue;
+            const float vc[3] = {a.v_colors[row * 3], a.v_colors[row * 3 + 1], a.v_colors[row * 3 + 2]};
+            sh3_row_vjp<DEG, WANT_MEANS>(a, b, c, g, (int64_t)g, vc, vec, vco, v_dir);
+        }
+        if constexpr (WANT_MEANS) {
+            float *vm = a.v_means + ((size_t)b * a.N + g) * 3; // [B,N,3]: one thread per (b, g) -> plain store
+            vm[0] = v_dir[0]; vm[1] = v_dir[1]; vm[2] = v_dir[2];
+        }
+    }
+    store_row<NF>(a.v_coeffs + (size_t)g * a.K * 3, vec, vco, a.K * 3, true);
+}
+
+template <int DEG>
+static void launch_sh3_bwd(const ShArgs &a, hipStream_t s)
+{
+    if (a.nnz < 0) {
+        const dim3 grid((uint32_t)ceil_div((int64_t)a.N, 256));
+        if (a.v_means) sh3_bwd_dense_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
+        else sh3_bwd_dense_kernel<DEG, false><<<grid, dim3(256), 0, s>>>(a);
+    } else {
+        const dim3 grid((uint32_t)ceil_div(a.nnz, 256));
+        if (a.v_means) sh3_bwd_packed_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
+        else sh3_bwd_packed_kernel<DEG, false><<<grid, dim3(256), 0, s>>>(a);
+    }
+}
+
 static int check_sh(const char *fn, int degree, uint32_t K, uint32_t D, const float *means, const float *viewmats,
                     const float *coeffs, int64_t nnz, const int64_t *bi, const int64_t *ci, const int64_t *gi)
 {
@@ -289,7 +502,19 @@ extern "C" int gsx_sh_fwd(int degrees_to_use, const float *means, const float *v
     a.degree = degrees_to_use; a.means = means; a.viewmats = viewmats; a.coeffs = coeffs; a.masks = masks;
     a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
     a.B = B; a.C = C; a.N = N; a.K = K; a.D = D; a.nnz = nnz; a.coeffs_gathered = coeffs_gathered; a.colors = colors;
-    sh_fwd_kernel<<<dim3((uint32_t)ceil_div(rows * D, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 3) {
+        const dim3 grid((uint32_t)ceil_div(rows, 256));
+        switch (degrees_to_use) {
+        case 0: sh3_fwd_kernel<0><<<grid, dim3(256), 0, s>>>(a); break;
+        case 1: sh3_fwd_kernel<1><<<grid, dim3(256), 0, s>>>(a); break;
+        case 2: sh3_fwd_kernel<2><<<grid, dim3(256), 0, s>>>(a); break;
+        case 3: sh3_fwd_kernel<3><<<grid, dim3(256), 0, s>>>(a); break;
+        default: sh3_fwd_kernel<4><<<grid, dim3(256), 0, s>>>(a); break;
+        }
+    } else {
+        sh_fwd_kernel<<<dim3((uint32_t)ceil_div(rows * D, 256)), dim3(256), 0, s>>>(a);
+    }
     return check_launch("sh_fwd");
 }
 
@@ -308,6 +533,18 @@ extern "C" int gsx_sh_bwd(int degrees_to_use, const float *means, const float *v
     a.B = B; a.C = C; a.N = N; a.K = K; a.D = D; a.nnz = nnz; a.coeffs_gathered = coeffs_gathered;
     a.v_colors = v_colors; a.v_coeffs = v_coeffs; a.v_means = v_means;
     a.atomic_coeffs = (B * C) > 1;
+    if (D == 3 && (nnz < 0 ? (int64_t)N > 0 : nnz > 0)) {
+        GSX_REQUIRE(v_colors || (nnz < 0 && (int64_t)B * C == 0), "gsx_sh_bwd: null v_colors");
+        hipStream_t s = (hipStream_t)stream;
+        switch (degrees_to_use) {
+        case 0: launch_sh3_bwd<0>(a, s); break;
+        case 1: launch_sh3_bwd<1>(a, s); break;
+        case 2: launch_sh3_bwd<2>(a, s); break;
+        case 3: launch_sh3_bwd<3>(a, s); break;
+        default: launch_sh3_bwd<4>(a, s); break;
+        }
+        return check_launch("sh_bwd");
+    }
     if (nnz < 0) {
         if ((int64_t)N * D == 0) return GSX_OK;
         GSX_REQUIRE(v_colors || (int64_t)B * C == 0, "gsx_sh_bwd: null v_colors");

@@ -13,9 +13,13 @@
  * writes tests/golden/ fixtures; tests/test_oracle_golden.py re-checks them anywhere.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* number of OpenMP threads used by the parallel loops below (bench.py's cpu_baseline bounds it) */
+void gso_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 
 #define ALPHA_THRESHOLD (1.0f / 255.0f) /* gsplat/cuda/include/Common.h:97 */
 #define GAUSSIAN_EXTEND 3.33f           /* Common.h:99 */

@@ -72,6 +72,13 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+def set_threads(n: int) -> None:
+    """Threads for the OpenMP loops of the C half and for torch-CPU (very wide hosts are slower with all cores:
+    fork/join and atomic contention dominate these small kernels)."""
+    lib().gso_set_threads(ctypes.c_int(int(n)))
+    torch.set_num_threads(int(n))
+
+
 def _p(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 

@@ -14,5 +14,5 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INS
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $pmc -d $OUT/pmc_$name -o pmc -- python $ROOT/bench.py $ARGS > $OUT/pmc_$name.log 2>&1
 done
 tail -3 $OUT/*.log; find $OUT -type f ! -name '*.csv' ! -name '*.log' ! -name '*.txt' -delete; du -sh $OUT; find $OUT -name '*.csv' | head -50
-python $ROOT/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+python $ROOT/tools/summarize_prof.py $OUT --json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt | head -80

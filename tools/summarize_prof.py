@@ -49,6 +49,18 @@ def main():
                     traffic.setdefault(short(k), {})[c] = sum(v) / len(v)
     if write_json:
         json.dump(traffic, open(os.path.join(out, "pmc_counters.json"), "w"), indent=1)
+        # HBM bytes per launch for bench.py's roofline.traffic: (FETCH_SIZE + WRITE_SIZE) KiB -> bytes. The compositing
+        # kernels read through 4..16-byte gathers, for which MI355X_MICROARCH.md gives no FETCH_SIZE correction (the 2x
+        # applies to wide 16 B/lane coalesced streams only), so the raw counter is used and the 2x-corrected read side
+        # is recorded next to it as an upper bound.
+        hbm = {}
+        for k, cs in traffic.items():
+            if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                name = k.split("<")[0].split("(")[0].replace("_kernel", "")
+                hbm[name] = {"bytes": int((cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
+                             "fetch_bytes": int(cs["FETCH_SIZE"] * 1024), "write_bytes": int(cs["WRITE_SIZE"] * 1024),
+                             "bytes_if_fetch_x2": int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)}
+        json.dump(hbm, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
