@@ -158,6 +158,14 @@ def sort_workspace_bytes(n: int) -> int:
     return int(_lib.gsx_sort_pairs_workspace_bytes(n))
 
 
+def tile_sort_supported(n_images: int, tile_w: int, tile_h: int) -> bool:
+    return bool(_lib.gsx_isect_tile_sort_supported(n_images, tile_w, tile_h))
+
+
+def tile_sort_workspace_bytes(n: int, n_images: int, tile_w: int, tile_h: int) -> int:
+    return int(_lib.gsx_isect_tile_sort_workspace_bytes(n, n_images, tile_w, tile_h))
+
+
 def sort_pairs(keys, vals, keys_alt, vals_alt, n: int, end_bit: int, workspace) -> bool:
     """Returns True when the sorted data ended up in the alt buffers."""
     flag = ctypes.c_int(0)

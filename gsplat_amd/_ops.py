@@ -232,7 +232,14 @@ def intersect_tile(means2d, radii, depths, conics, opacities, image_ids, gaussia
         return tiles_per_gauss, isect_ids, flatten_ids
     call("gsx_isect_emit", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), ptr(image_ids),
          ptr(cum), rows, n_per, I, tile_size, tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids))
-    if sort:
+    if sort and _cabi.tile_sort_supported(I, tile_width, tile_height):
+        keys_s, vals_s = torch.empty_like(isect_ids), torch.empty_like(flatten_ids)
+        ws = torch.empty(_cabi.tile_sort_workspace_bytes(n_isects, I, tile_width, tile_height), device=dev,
+                         dtype=torch.uint8)
+        call("gsx_isect_tile_sort", ptr(isect_ids), ptr(flatten_ids), n_isects, I, tile_width, tile_height,
+             ptr(keys_s), ptr(vals_s), ptr(ws), ws.numel())
+        isect_ids, flatten_ids = keys_s, vals_s
+    elif sort:
         keys_alt, vals_alt = torch.empty_like(isect_ids), torch.empty_like(flatten_ids)
         ws = torch.empty(_cabi.sort_workspace_bytes(n_isects), device=dev, dtype=torch.uint8)
         in_alt = _cabi.sort_pairs(isect_ids, flatten_ids, keys_alt, vals_alt, n_isects, 32 + tile_bits + image_bits, ws)
@@ -419,11 +426,17 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
                                           opacities.contiguous())
     backgrounds, masks = _c(backgrounds), _c(masks)
     v_render_colors, v_render_alphas = v_render_colors.contiguous(), v_render_alphas.contiguous()
-    v_means2d = torch.zeros_like(means2d)
-    v_conics = torch.zeros_like(conics)
-    v_colors = torch.zeros_like(colors)
-    v_opacities = torch.zeros_like(opacities)
-    v_abs = torch.zeros_like(means2d) if absgrad else None
+    # one zero-fill for all atomically accumulated gradients (views of a single buffer are contiguous slices)
+    R = opacities.numel()
+    widths = [2, 3, D, 1] + ([2] if absgrad else [])
+    flat = torch.zeros(R * sum(widths), device=means2d.device, dtype=means2d.dtype)
+    parts, o = [], 0
+    for w in widths:
+        parts.append(flat[o:o + R * w])
+        o += R * w
+    v_means2d, v_conics = parts[0].view(means2d.shape), parts[1].view(conics.shape)
+    v_colors, v_opacities = parts[2].view(colors.shape), parts[3].view(opacities.shape)
+    v_abs = parts[4].view(means2d.shape) if absgrad else None
     call("gsx_raster3d_bwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
          ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
          ptr(last_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,

@@ -122,6 +122,13 @@ static int run_scan(const int32_t *in, int64_t n, OutT *out, void *ws, int64_t w
     return check_launch("scan");
 }
 
+// entry points for the other translation units (tile_sort.hip)
+int run_scan_i32_exclusive(const int32_t *in, int64_t n, int32_t *out, void *ws, int64_t ws_bytes, hipStream_t stream)
+{
+    return run_scan<int32_t, false>(in, n, out, ws, ws_bytes, stream);
+}
+int64_t scan_workspace_bytes_for(int64_t n) { return scan_ws_bytes(n); }
+
 // ------------------------------------------------------------------------------------------
 // radix sort of (int64 key, int32 value) pairs, 8 bits per pass.
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,419 @@
+// Sort of the (image | tile | depth) intersection keys, MI355X-native: ONE bucketing pass by (image, tile) + a per-tile
+// depth sort that never leaves LDS.
+//
+// C-ABI entry: gsx_isect_tile_sort (+ gsx_isect_tile_sort_workspace_bytes). Replaces the 6-pass device-wide
+// cub::DeviceRadixSort::SortPairs of the reference (gsplat/cuda/csrc/IntersectTile.cu:1078-1121) for the keys produced by
+// gsx_isect_emit; the result is IDENTICAL to a stable ascending sort on the full key (ties keep ascending flatten id,
+// which is the emission order), so isect_ids / flatten_ids stay bit-exact with the reference and the oracle.
+//
+// Why this shape on MI355X: a generic LSD radix sort moves every 12-byte pair through HBM once per 8 key bits
+// (6 round trips at 1080p). The key is structured — the high bits name one of I*th*tw tiles and a tile's list
+// (hundreds to a few thousand entries) fits in the 160 KiB LDS of a CU — so:
+//   A  bucket_hist    LDS-privatised histogram of tile ids per contiguous chunk of the unsorted list
+//   B  scan           exclusive scan of the [tile][chunk] table            (gsx scan kernels, scan_sort.hip)
+//   C  bucket_scatter each pair goes to its tile's segment (LDS cursor atomics give the slot; arrival order inside a
+//                     tile is arbitrary) as one 8-byte (depth bits, flatten id) store
+//   D  tile_sort      one workgroup per tile. n <= 2048: bitonic sort of the 64-bit (depth, flatten id) words in LDS (ties
+//                     come out in ascending id order). Longer tiles (work list, persistent grid): stable 4 x 8-bit LSD
+//                     radix sort of the 32 depth bits in LDS (wave64 ballot ranking, as scan_sort.hip) followed by
+//                     ordering the runs of EQUAL depth by flatten id; tiles beyond the LDS capacity run the same passes
+//                     through global ping-pong buffers (rare; correct, slower). Either way the output does not depend
+//                     on the arrival order produced by C.
+// HBM traffic: read 12 B + write 8 B (C) + read 8 B + write 12 B (D) per pair = 40 B instead of 144 B.
+#include "common.hpp"
+
+namespace gsx {
+
+int run_scan_i32_exclusive(const int32_t *in, int64_t n, int32_t *out, void *ws, int64_t ws_bytes, hipStream_t stream);
+int64_t scan_workspace_bytes_for(int64_t n);
+
+constexpr int kTsThreads   = 256;
+constexpr uint32_t kMaxBins = 36864; // LDS histogram: 144 KiB of the 160 KiB
+constexpr int kCapSmall    = 2048;  // entries sorted in 32 KiB-class LDS
+constexpr int kCapLarge    = 9216;  // entries sorted with (almost) the whole LDS
+
+struct TileSortArgs {
+    const uint64_t *keys_in;
+    const int32_t *vals_in;
+    int64_t n;
+    uint32_t n_tiles, tile_bits, n_bins, n_chunks;
+    int64_t chunk_len;
+    int32_t *table;        // [n_bins][n_chunks] histogram, then exclusive scan (in place via table_scanned)
+    int32_t *table_scanned;
+    uint2 *bucketed;       // [n] (depth bits, flatten id) grouped by bin
+    uint64_t *keys_out;
+    int32_t *vals_out;
+    uint2 *scratch;        // [n] ping-pong for oversized tiles
+    int32_t *big_count;    // number of tiles longer than kCapSmall (filled by the MODE 0 launch)
+    int32_t *big_list;     // [n_bins] their bin ids
+};
+
+__device__ __forceinline__ uint32_t key_bin(uint64_t key, uint32_t n_tiles, uint32_t tile_bits)
+{
+    const uint64_t hi = key >> 32;
+    const uint64_t tmask = tile_bits >= 32 ? 0xFFFFFFFFull : ((1ull << tile_bits) - 1ull);
+    return (uint32_t)((hi >> tile_bits) * n_tiles + (hi & tmask));
+}
+
+// A: per-chunk histogram of bins, LDS-privatised. Chunks are LARGE (>= 32 Ki pairs): the [bin][chunk] table is written
+// with a stride of n_chunks ints (one cache line per entry), so its size — not the key stream — sets the cost of A, B
+// and the cursor load of C; large chunks also put several pairs of one bin next to each other in C's output.
+constexpr int kBkThreads = 1024;
+constexpr int kBkUnroll  = 4;
+
+__global__ void __launch_bounds__(kBkThreads) bucket_hist_kernel(const TileSortArgs a)
+{
+    extern __shared__ int32_t s_hist[];
+    for (uint32_t i = threadIdx.x; i < a.n_bins; i += kBkThreads) s_hist[i] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * a.chunk_len;
+    const int64_t hi = min(a.n, lo + a.chunk_len);
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)kBkThreads * kBkUnroll) {
+        uint64_t k[kBkUnroll];
+#pragma unroll
+        for (int u = 0; u < kBkUnroll; ++u) {
+            const int64_t i = i0 + (int64_t)u * kBkThreads;
+            k[u] = i < hi ? a.keys_in[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kBkUnroll; ++u)
+            if (i0 + (int64_t)u * kBkThreads < hi) atomicAdd(&s_hist[key_bin(k[u], a.n_tiles, a.tile_bits)], 1);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < a.n_bins; i += kBkThreads) a.table[(int64_t)i * a.n_chunks + blockIdx.x] = s_hist[i];
+}
+
+// C: scatter into tile segments
+__global__ void __launch_bounds__(kBkThreads) bucket_scatter_kernel(const TileSortArgs a)
+{
+    extern __shared__ int32_t s_cur[];
+    for (uint32_t i = threadIdx.x; i < a.n_bins; i += kBkThreads)
+        s_cur[i] = a.table_scanned[(int64_t)i * a.n_chunks + blockIdx.x];
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * a.chunk_len;
+    const int64_t hi = min(a.n, lo + a.chunk_len);
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)kBkThreads * kBkUnroll) {
+        uint64_t k[kBkUnroll];
+        int32_t v[kBkUnroll];
+#pragma unroll
+        for (int u = 0; u < kBkUnroll; ++u) {
+            const int64_t i = i0 + (int64_t)u * kBkThreads;
+            k[u] = i < hi ? a.keys_in[i] : 0ull;
+            v[u] = i < hi ? a.vals_in[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kBkUnroll; ++u)
+            if (i0 + (int64_t)u * kBkThreads < hi) {
+                const int32_t dst = atomicAdd(&s_cur[key_bin(k[u], a.n_tiles, a.tile_bits)], 1);
+                a.bucketed[dst]   = make_uint2((uint32_t)k[u], (uint32_t)v[u]);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// D: per-tile stable LSD radix sort on the 32 depth bits (+ tie ordering by id)
+// ------------------------------------------------------------------------------------------
+// One stable 8-bit pass over n elements src -> dst (both LDS or both global), block of 256 threads = 4 waves, wave w
+// owns the contiguous run [w*per_wave, (w+1)*per_wave). s_cnt/s_base: [4][256].
+template <typename Ptr>
+__device__ __forceinline__ void radix_pass(Ptr src, Ptr dst, int n, int shift, int32_t (*s_cnt)[256], int32_t (*s_base)[256],
+                                           int64_t *s_scan)
+{
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    const int per_wave = ((n + 255) / 256) * 64; // multiple of 64
+    const int w_lo = wave * per_wave;
+    for (int i = threadIdx.x; i < 4 * 256; i += kTsThreads) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // count
+    for (int r = 0; r < per_wave; r += 64) {
+        const int idx   = w_lo + r + lane;
+        const bool live = idx < n;
+        const int d     = live ? (int)((src[idx].x >> shift) & 0xFFu) : 0;
+        if (live) atomicAdd(&s_cnt[wave][d], 1);
+    }
+    __syncthreads();
+    // thread d: digit totals -> exclusive scan over digits, then per-wave bases
+    {
+        const int d = (int)threadIdx.x;
+        int32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tot += s_cnt[w][d];
+        // block exclusive scan of tot over the 256 threads
+        int32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t y = __shfl_up(inc, o);
+            if (lane >= o) inc += y;
+        }
+        if (lane == 63) s_scan[wave] = inc;
+        __syncthreads();
+        int32_t base = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            if (w < wave) base += (int32_t)s_scan[w];
+        int32_t run = base + inc - tot;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            s_base[w][d] = run;
+            run += s_cnt[w][d];
+        }
+    }
+    __syncthreads();
+    // rank + scatter, round by round (s_base[wave][d] is advanced as the wave's running counter)
+    for (int r = 0; r < per_wave; r += 64) {
+        const int idx   = w_lo + r + lane;
+        const bool live = idx < n;
+        const uint2 e   = live ? src[idx] : make_uint2(0u, 0u);
+        const int d     = (int)((e.x >> shift) & 0xFFu);
+        uint64_t peers  = __builtin_amdgcn_ballot_w64(live);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool b     = (d >> bit) & 1;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(b);
+            peers &= b ? m : ~m;
+        }
+        volatile int32_t *cnt = &s_base[wave][0];
+        const int before = live ? cnt[d] : 0;
+        const int pos    = __popcll(peers & lt_mask);
+        if (live) dst[before + pos] = e;
+        if (live && pos == 0) cnt[d] = before + __popcll(peers);
+    }
+    __syncthreads();
+}
+
+// runs of equal depth: order by flatten id (ascending) — one thread per run start; runs are short (exact depth ties)
+template <typename Ptr>
+__device__ __forceinline__ void fix_ties(Ptr a, int n)
+{
+    for (int i = threadIdx.x; i < n; i += kTsThreads) {
+        const uint32_t k = a[i].x;
+        if ((i == 0 || a[i - 1].x != k) && i + 1 < n && a[i + 1].x == k) {
+            int j = i + 1;
+            while (j < n && a[j].x == k) ++j;
+            for (int p = i + 1; p < j; ++p) { // insertion sort of ids in [i, j)
+                const uint32_t v = a[p].y;
+                int q = p - 1;
+                while (q >= i && a[q].y > v) {
+                    a[q + 1].y = a[q].y;
+                    --q;
+                }
+                a[q + 1].y = v;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Small tiles (n <= kCapSmall): bitonic sort of the 64-bit (depth bits, flatten id) words in LDS. The id in the low half
+// makes exact depth ties come out in ascending id order, so no tie pass is needed. Thread t of a stage with partner
+// distance j handles the pair (i, i|j), i = t with a zero inserted at bit log2(j): for j <= 32 both elements of every
+// pair of a wave lie in the wave's own 128-element window, so those stages need no workgroup barrier (LDS operations of
+// one wave execute in order); only stages with j >= 64 are separated by __syncthreads(). Longer tiles are appended to
+// the work list for the radix kernel below.
+__global__ void __launch_bounds__(kTsThreads) tile_sort_small_kernel(const TileSortArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t *s = reinterpret_cast<uint64_t *>(smem_raw);
+    const uint32_t bin  = blockIdx.x;
+    const int64_t start = a.table_scanned[(int64_t)bin * a.n_chunks];
+    const int64_t end   = (bin + 1 == a.n_bins) ? a.n : a.table_scanned[(int64_t)(bin + 1) * a.n_chunks];
+    const int n         = (int)(end - start);
+    if (n <= 0) return;
+    if (n > kCapSmall) {
+        if (threadIdx.x == 0) a.big_list[atomicAdd(a.big_count, 1)] = (int32_t)bin;
+        return;
+    }
+    int P = 128; // a wave's window; also the smallest padded size
+    while (P < n) P <<= 1;
+    const uint2 *g_in = a.bucketed + start;
+    for (int i = threadIdx.x; i < P; i += kTsThreads) {
+        uint64_t w = ~0ull;
+        if (i < n) {
+            const uint2 e = g_in[i];
+            w = ((uint64_t)e.x << 32) | e.y;
+        }
+        s[i] = w;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += kTsThreads) {
+                const int i  = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l  = i | j;
+                const bool up = (i & k) == 0;
+                const uint64_t x = s[i], y = s[l];
+                if ((x > y) == up) {
+                    s[i] = y;
+                    s[l] = x;
+                }
+            }
+            if (j >= 64) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();
+        }
+        if (k >= 64) __syncthreads(); // next k starts with j = k: pairs may cross waves again
+    }
+    __syncthreads();
+    const uint64_t tile = bin % a.n_tiles, img = bin / a.n_tiles;
+    const uint64_t hi   = ((img << a.tile_bits) | tile) << 32;
+    for (int i = threadIdx.x; i < n; i += kTsThreads) {
+        const uint64_t w      = s[i];
+        a.keys_out[start + i] = hi | (w >> 32);
+        a.vals_out[start + i] = (int32_t)(uint32_t)w;
+    }
+}
+
+// MODE 0: one workgroup per tile; tiles with n <= CAP sort in LDS, longer ones are appended to the work list.
+// MODE 1: a small persistent grid walks the work list: n <= CAP sorts in (nearly all of) the LDS, longer tiles sort
+//         through global memory. With no oversized tile the launch costs a few microseconds.
+template <int CAP, int MODE>
+__global__ void __launch_bounds__(kTsThreads) tile_sort_kernel(const TileSortArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ int32_t s_cnt[4][256];
+    __shared__ int32_t s_base[4][256];
+    __shared__ int64_t s_scan[4];
+    uint2 *s_a = reinterpret_cast<uint2 *>(smem_raw);
+    uint2 *s_b = s_a + CAP;
+
+  const int32_t n_work = MODE == 0 ? 1 : *a.big_count;
+  for (int32_t wi = (MODE == 0 ? 0 : (int32_t)blockIdx.x); wi < n_work; wi += (int32_t)gridDim.x) {
+    const uint32_t bin  = MODE == 0 ? blockIdx.x : (uint32_t)a.big_list[wi];
+    const int64_t start = a.table_scanned[(int64_t)bin * a.n_chunks];
+    const int64_t end   = (bin + 1 == a.n_bins) ? a.n : a.table_scanned[(int64_t)(bin + 1) * a.n_chunks];
+    const int n         = (int)(end - start);
+    if (n <= 0) return; // MODE 0 only (listed tiles are never empty)
+    if (MODE == 0 && n > CAP) {
+        if (threadIdx.x == 0) a.big_list[atomicAdd(a.big_count, 1)] = (int32_t)bin;
+        return;
+    }
+    // high 32 bits of every key of this bin
+    const uint64_t tile = bin % a.n_tiles, img = bin / a.n_tiles;
+    const uint64_t hi   = ((img << a.tile_bits) | tile) << 32;
+    uint2 *g_in         = a.bucketed + start;
+
+    if (n <= CAP) {
+        for (int i = threadIdx.x; i < n; i += kTsThreads) s_a[i] = g_in[i];
+        __syncthreads();
+        radix_pass(s_a, s_b, n, 0, s_cnt, s_base, s_scan);
+        radix_pass(s_b, s_a, n, 8, s_cnt, s_base, s_scan);
+        radix_pass(s_a, s_b, n, 16, s_cnt, s_base, s_scan);
+        radix_pass(s_b, s_a, n, 24, s_cnt, s_base, s_scan);
+        fix_ties(s_a, n);
+        for (int i = threadIdx.x; i < n; i += kTsThreads) {
+            const uint2 e         = s_a[i];
+            a.keys_out[start + i] = hi | e.x;
+            a.vals_out[start + i] = (int32_t)e.y;
+        }
+    } else if (MODE == 1) {
+        // oversized tile: same passes through global memory (segment is private to this workgroup; __syncthreads
+        // orders global accesses within a workgroup)
+        uint2 *g_tmp = a.scratch + start;
+        radix_pass(g_in, g_tmp, n, 0, s_cnt, s_base, s_scan);
+        radix_pass(g_tmp, g_in, n, 8, s_cnt, s_base, s_scan);
+        radix_pass(g_in, g_tmp, n, 16, s_cnt, s_base, s_scan);
+        radix_pass(g_tmp, g_in, n, 24, s_cnt, s_base, s_scan);
+        fix_ties(g_in, n);
+        for (int i = threadIdx.x; i < n; i += kTsThreads) {
+            const uint2 e         = g_in[i];
+            a.keys_out[start + i] = hi | e.x;
+            a.vals_out[start + i] = (int32_t)e.y;
+        }
+    }
+    __syncthreads(); // LDS / counters are reused by the next work item
+  }
+}
+
+static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+static uint32_t ts_chunks(int64_t n)
+{
+    int64_t c = ceil_div(n, 32768);
+    if (c < 1) c = 1;
+    if (c > 512) c = 512;
+    return (uint32_t)c;
+}
+
+static int64_t tile_sort_ws_bytes(int64_t n, uint32_t n_bins)
+{
+    const int64_t table = (int64_t)n_bins * ts_chunks(n) * (int64_t)sizeof(int32_t);
+    return 2 * align256(table) + 2 * align256(n * (int64_t)sizeof(uint2))
+           + align256(scan_workspace_bytes_for((int64_t)n_bins * ts_chunks(n))) + align256(((int64_t)n_bins + 1) * 4) + 512;
+}
+
+static uint32_t bits_for(uint64_t count)
+{
+    uint32_t b = 0;
+    if (count <= 1) return 0;
+    uint64_t v = count - 1;
+    while (v) { ++b; v >>= 1; }
+    return b;
+}
+
+} // namespace gsx
+
+using namespace gsx;
+
+extern "C" int gsx_isect_tile_sort_supported(uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
+{
+    const uint64_t bins = (uint64_t)n_images * tile_w * tile_h;
+    return bins >= 1 && bins <= kMaxBins;
+}
+
+extern "C" int64_t gsx_isect_tile_sort_workspace_bytes(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
+{
+    return tile_sort_ws_bytes(n_isects > 0 ? n_isects : 1, n_images * tile_w * tile_h);
+}
+
+extern "C" int gsx_isect_tile_sort(const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects,
+                                   uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int64_t *isect_ids_sorted,
+                                   int32_t *flatten_ids_sorted, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    GSX_REQUIRE(n_isects >= 0 && n_isects < (1ll << 31), "gsx_isect_tile_sort: n_isects out of range");
+    if (n_isects == 0) return GSX_OK;
+    GSX_REQUIRE(gsx_isect_tile_sort_supported(n_images, tile_w, tile_h),
+                "gsx_isect_tile_sort: %u images x %u x %u tiles exceed the LDS histogram (use gsx_sort_pairs)", n_images,
+                tile_w, tile_h);
+    GSX_REQUIRE(isect_ids && flatten_ids && isect_ids_sorted && flatten_ids_sorted, "gsx_isect_tile_sort: null buffer");
+    const uint32_t n_tiles = tile_w * tile_h, n_bins = n_images * n_tiles;
+    if (workspace == nullptr || workspace_bytes < tile_sort_ws_bytes(n_isects, n_bins)) {
+        set_last_error("gsx_isect_tile_sort: workspace too small");
+        return GSX_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    TileSortArgs a{};
+    a.keys_in = reinterpret_cast<const uint64_t *>(isect_ids);
+    a.vals_in = flatten_ids;
+    a.n = n_isects; a.n_tiles = n_tiles; a.tile_bits = bits_for(n_tiles); a.n_bins = n_bins;
+    a.n_chunks  = ts_chunks(n_isects);
+    a.chunk_len = ceil_div(n_isects, (int64_t)a.n_chunks);
+    const int64_t table_elems = (int64_t)n_bins * a.n_chunks;
+    unsigned char *p = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    a.table         = reinterpret_cast<int32_t *>(p); p += align256(table_elems * 4);
+    a.table_scanned = reinterpret_cast<int32_t *>(p); p += align256(table_elems * 4);
+    a.bucketed      = reinterpret_cast<uint2 *>(p);   p += align256(n_isects * 8);
+    a.scratch       = reinterpret_cast<uint2 *>(p);   p += align256(n_isects * 8);
+    void *scan_ws   = p; p += align256(scan_workspace_bytes_for(table_elems));
+    a.big_count     = reinterpret_cast<int32_t *>(p);
+    a.big_list      = a.big_count + 1;
+    a.keys_out = reinterpret_cast<uint64_t *>(isect_ids_sorted);
+    a.vals_out = flatten_ids_sorted;
+
+    const size_t hist_lds = (size_t)n_bins * sizeof(int32_t);
+    static bool attr_done = false; // raising the dynamic-LDS limit is idempotent; racing threads set the same value
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)bucket_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        (void)hipFuncSetAttribute((const void *)bucket_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        (void)hipFuncSetAttribute((const void *)tile_sort_kernel<kCapLarge, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(2 * kCapLarge * sizeof(uint2)));
+        attr_done = true;
+    }
+    bucket_hist_kernel<<<dim3(a.n_chunks), dim3(kBkThreads), hist_lds, s>>>(a);
+    int rc = run_scan_i32_exclusive(a.table, table_elems, a.table_scanned, scan_ws, scan_workspace_bytes_for(table_elems), s);
+    if (rc != GSX_OK) return rc;
+    bucket_scatter_kernel<<<dim3(a.n_chunks), dim3(kBkThreads), hist_lds, s>>>(a);
+    if (hipMemsetAsync(a.big_count, 0, sizeof(int32_t), s) != hipSuccess) return check_launch("isect_tile_sort memset");
+    tile_sort_small_kernel<<<dim3(n_bins), dim3(kTsThreads), kCapSmall * sizeof(uint64_t), s>>>(a);
+    tile_sort_kernel<kCapLarge, 1><<<dim3(256), dim3(kTsThreads), 2 * kCapLarge * sizeof(uint2), s>>>(a);
+    return check_launch("isect_tile_sort");
+}

@@ -171,7 +171,9 @@ def rasterization(
 
     if packed:
         batch_ids, camera_ids, gaussian_ids, indptr, radii, means2d, depths, conics, compensations = proj
-        proj_opacities = opacities.reshape(B, N)[batch_ids, gaussian_ids]  # [nnz]
+        # index_select (backward = atomic index_add) instead of advanced indexing (backward = index_put, which SORTS
+        # the nnz indices first: ~0.2 ms per step at 1M Gaussians)
+        proj_opacities = opacities.reshape(-1).index_select(0, batch_ids * N + gaussian_ids if B > 1 else gaussian_ids)
         image_ids = batch_ids * C_proj + camera_ids
     else:
         radii, means2d, depths, conics, compensations = proj
@@ -417,7 +419,7 @@ def rasterization_2dgs(
                                        packed=packed, sparse_grad=sparse_grad)
     if packed:
         batch_ids, camera_ids, gaussian_ids, _indptr, radii, means2d, depths, ray_transforms, normals = proj
-        proj_opacities = opacities.reshape(B, N)[batch_ids, gaussian_ids]
+        proj_opacities = opacities.reshape(-1).index_select(0, batch_ids * N + gaussian_ids if B > 1 else gaussian_ids)
         image_ids = batch_ids * C + camera_ids
     else:
         radii, means2d, depths, ray_transforms, normals = proj

@@ -176,6 +176,15 @@ int64_t gsx_sort_pairs_workspace_bytes(int64_t n);
  * On return *result_in_alt tells whether the sorted data is in the alt buffers (1) or the primary (0). */
 int gsx_sort_pairs(int64_t *keys, int32_t *vals, int64_t *keys_alt, int32_t *vals_alt, int64_t n, int end_bit,
                    void *workspace, int64_t workspace_bytes, int *result_in_alt, void *stream);
+/* Structured sort of the emitted pairs = gsx_sort_pairs on key bits [0, 32+tile_bits+image_bits) with identical output,
+ * done as one bucketing pass by (image, tile) + a per-tile depth sort in LDS (csrc/tile_sort.hip; 40 B instead of 144 B of
+ * HBM traffic per pair). Supported while n_images*tile_w*tile_h fits the LDS histogram (gsx_isect_tile_sort_supported);
+ * inputs are not modified. */
+int gsx_isect_tile_sort_supported(uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
+int64_t gsx_isect_tile_sort_workspace_bytes(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
+int gsx_isect_tile_sort(const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects, uint32_t n_images,
+                        uint32_t tile_w, uint32_t tile_h, int64_t *isect_ids_sorted, int32_t *flatten_ids_sorted,
+                        void *workspace, int64_t workspace_bytes, void *stream);
 int gsx_isect_offsets(const int64_t *isect_ids_sorted, int64_t n_isects, uint32_t n_images, uint32_t tile_w,
                       uint32_t tile_h, int32_t *offsets /* [I,tile_h,tile_w] */, void *stream);
 

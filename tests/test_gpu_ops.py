@@ -401,3 +401,45 @@ def test_golden_isect_and_projection_vs_reference_outputs(G, golden):
         col = G.spherical_harmonics(deg, to_t(golden["proj_means"], DEV), to_t(golden["proj_viewmats"], DEV),
                                     to_t(golden["sh_coeffs"], DEV))
         assert_close_ratio(cpu(col), golden[f"sh_colors_deg{deg}"], 1e-5, 1e-5, name=f"sh{deg}")
+
+
+@pytest.mark.parametrize("case", ["small", "ties", "long_tiles", "many_images", "huge_tile"])
+def test_tile_sort_matches_stable_sort(G, case):
+    """gsx_isect_tile_sort (bucket by tile + per-tile LDS depth sort) must equal a STABLE ascending sort of the full
+    keys: exact isect_ids and flatten_ids, including exact depth ties (-> ascending flatten id), tiles longer than the
+    small / large LDS capacities and the global-memory path."""
+    from gsplat_amd import _cabi
+    from gsplat_amd._cabi import call, ptr
+
+    g = torch.Generator().manual_seed(7)
+    I, tw, th = 1, 12, 7
+    n = 50_000
+    if case == "many_images":
+        I, tw, th, n = 3, 40, 30, 200_000
+    tiles = torch.randint(0, I * tw * th, (n,), generator=g)
+    if case == "long_tiles":
+        tiles = torch.where(torch.rand(n, generator=g) < 0.5, torch.randint(0, 4, (n,), generator=g), tiles)  # ~6k / tile
+    if case == "huge_tile":
+        tiles = torch.where(torch.rand(n, generator=g) < 0.6, torch.tensor(5), tiles)  # ~30k in one tile: global path
+    if case == "small":
+        n = 300
+        tiles = tiles[:n]
+    depth = torch.rand(n, generator=g) * 10 + 0.1
+    if case in ("ties", "long_tiles"):
+        depth = torch.round(depth * 20) / 20  # many exact ties
+    n_tiles = tw * th
+    tile_bits = (n_tiles - 1).bit_length()
+    img, t = tiles // n_tiles, tiles % n_tiles
+    keys = (((img << tile_bits) | t) << 32) | depth.float().view(torch.int32).long()
+    vals = torch.arange(n, dtype=torch.int32)  # emission order = ascending flatten id
+    # shuffle rows that belong to different tiles only through the natural interleaving (keep id ascending overall)
+    order = torch.sort(keys, stable=True).indices
+    exp_k, exp_v = keys[order], vals[order]
+    assert _cabi.tile_sort_supported(I, tw, th)
+    kd, vd = keys.to(DEV), vals.to(DEV)
+    ko, vo = torch.empty_like(kd), torch.empty_like(vd)
+    ws = torch.empty(_cabi.tile_sort_workspace_bytes(n, I, tw, th), device=DEV, dtype=torch.uint8)
+    call("gsx_isect_tile_sort", ptr(kd), ptr(vd), n, I, tw, th, ptr(ko), ptr(vo), ptr(ws), ws.numel())
+    assert torch.equal(cpu(ko), exp_k), "sorted keys differ"
+    assert torch.equal(cpu(vo), exp_v), "sorted flatten ids differ (tie order)"
+    assert torch.equal(cpu(kd), keys) and torch.equal(cpu(vd), vals)  # inputs untouched
