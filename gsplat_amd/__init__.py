@@ -13,7 +13,9 @@ import importlib
 _LAZY = {
     "fully_fused_projection": "_wrapper", "isect_offset_encode": "_wrapper", "isect_tiles": "_wrapper",
     "quat_scale_to_covar_preci": "_wrapper", "rasterize_to_pixels": "_wrapper", "spherical_harmonics": "_wrapper",
-    "fully_fused_projection_2dgs": "_wrapper", "rasterize_to_pixels_2dgs": "_wrapper",
+    "fully_fused_projection_2dgs": "_wrapper", "rasterize_to_pixels_2dgs": "_wrapper", "proj": "_wrapper",
+    "spherical_harmonics_l0": "_wrapper", "spherical_harmonics_l1_plus": "_wrapper",
+    "rasterize_to_indices_in_range": "_wrapper", "rasterize_to_indices_in_range_2dgs": "_wrapper",
     "rasterization": "rendering", "rasterization_2dgs": "rendering", "distributed": "distributed",
 }
 

@@ -206,7 +206,48 @@ def _r2_backward(ctx, v_render_colors, v_render_alphas, v_render_normals, v_rend
     return (v_means2d, v_ray_transforms, v_colors, v_opacities, v_normals, v_densify, v_backgrounds) + (None,) * 9
 
 
+# ---- split SH + proj (reference _wrapper.py:782-816 and the l0 / l1_plus Register classes) -----------------
+def _l0_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0])
+
+
+def _l0_backward(ctx, v_colors):
+    (sh0,) = ctx.saved_tensors
+    return _bwd("spherical_harmonics_l0")(sh0, v_colors.contiguous())
+
+
+def _l1_setup(ctx, inputs, output):
+    (degrees_to_use, means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids, viewmats_rs) = inputs
+    ctx.degrees_to_use = degrees_to_use
+    ctx.save_for_backward(means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids, viewmats_rs)
+
+
+def _l1_backward(ctx, v_colors):
+    means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids, viewmats_rs = ctx.saved_tensors
+    v_shN, v_means, v_viewmats, v_rs = _bwd("spherical_harmonics_l1_plus")(
+        ctx.degrees_to_use, means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids, viewmats_rs,
+        v_colors.contiguous(), ctx.needs_input_grad[1], ctx.needs_input_grad[2],
+        len(ctx.needs_input_grad) > 8 and ctx.needs_input_grad[8])
+    return (None, v_means, v_viewmats, v_shN, None, None, None, None, v_rs)
+
+
+def _simple_setup(ctx, inputs, output):
+    means, covars, Ks, width, height, camera_model = inputs
+    ctx.width, ctx.height, ctx.camera_model = width, height, camera_model
+    ctx.save_for_backward(means, covars, Ks)
+
+
+def _simple_backward(ctx, v_means2d, v_covars2d):
+    means, covars, Ks = ctx.saved_tensors
+    v_means, v_covars = _bwd("projection_ewa_simple")(means, covars, Ks, ctx.width, ctx.height, ctx.camera_model,
+                                                      v_means2d.contiguous(), v_covars2d.contiguous())
+    return v_means, v_covars, None, None, None, None
+
+
 _TABLE = {
+    "spherical_harmonics_l0": (_l0_backward, _l0_setup),
+    "spherical_harmonics_l1_plus": (_l1_backward, _l1_setup),
+    "projection_ewa_simple": (_simple_backward, _simple_setup),
     "projection_2dgs_fused": (_p2_backward, _p2_setup),
     "projection_2dgs_packed": (_p2p_backward, _p2p_setup),
     "rasterize_to_pixels_2dgs": (_r2_backward, _r2_setup),

@@ -46,6 +46,15 @@ SCHEMAS = {
     # ext.cpp:1079-1089
     "rasterize_to_pixels_3dgs": "(Tensor means2d, Tensor conics, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, int image_width, int image_height, int tile_size, Tensor isect_offsets, Tensor flatten_ids, bool packed, bool absgrad) -> (Tensor, Tensor, Tensor, Tensor)",
     "rasterize_to_pixels_3dgs_bwd": "(Tensor means2d, Tensor conics, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, Tensor tile_offsets, Tensor flatten_ids, Tensor render_alphas, Tensor last_ids, int image_width, int image_height, int tile_size, bool absgrad, Tensor v_render_colors, Tensor v_render_alphas, bool compute_v_backgrounds) -> (Tensor?, Tensor, Tensor, Tensor, Tensor, Tensor?)",
+    # ext.cpp:1003-1014 (split SH), 1043-1050 (proj), 1105-1109 / 1200-1204 (rasterize_to_indices)
+    "spherical_harmonics_l0": "(Tensor sh0) -> Tensor",
+    "spherical_harmonics_l0_bwd": "(Tensor sh0, Tensor v_colors) -> Tensor",
+    "spherical_harmonics_l1_plus": "(int degrees_to_use, Tensor means, Tensor viewmats, Tensor shN, Tensor? masks, Tensor? batch_ids, Tensor? camera_ids, Tensor? gaussian_ids, Tensor? viewmats_rs=None) -> Tensor",
+    "spherical_harmonics_l1_plus_bwd": "(int degrees_to_use, Tensor means, Tensor viewmats, Tensor shN, Tensor? masks, Tensor? batch_ids, Tensor? camera_ids, Tensor? gaussian_ids, Tensor? viewmats_rs, Tensor v_colors, bool compute_v_means, bool compute_v_viewmats, bool compute_v_viewmats_rs) -> (Tensor, Tensor?, Tensor?, Tensor?)",
+    "projection_ewa_simple": "(Tensor means, Tensor covars, Tensor Ks, int width, int height, int camera_model) -> (Tensor, Tensor)",
+    "projection_ewa_simple_bwd": "(Tensor means, Tensor covars, Tensor Ks, int width, int height, int camera_model, Tensor v_means2d, Tensor v_covars2d) -> (Tensor, Tensor)",
+    "rasterize_to_indices_3dgs": "(int range_start, int range_end, Tensor transmittances, Tensor means2d, Tensor conics, Tensor opacities, int image_width, int image_height, int tile_size, Tensor tile_offsets, Tensor flatten_ids) -> (Tensor, Tensor, Tensor)",
+    "rasterize_to_indices_2dgs": "(int range_start, int range_end, Tensor transmittances, Tensor means2d, Tensor ray_transforms, Tensor opacities, int image_width, int image_height, int tile_size, Tensor tile_offsets, Tensor flatten_ids) -> (Tensor, Tensor, Tensor)",
     # ext.cpp:1163-1199 (2DGS)
     "projection_2dgs_fused": "(Tensor means, Tensor quats, Tensor scales, Tensor viewmats, Tensor Ks, int image_width, int image_height, float eps2d, float near_plane, float far_plane, float radius_clip) -> (Tensor, Tensor, Tensor, Tensor, Tensor)",
     "projection_2dgs_fused_bwd": "(Tensor means, Tensor quats, Tensor scales, Tensor viewmats, Tensor Ks, int image_width, int image_height, Tensor radii, Tensor ray_transforms, Tensor v_means2d, Tensor v_depths, Tensor v_ray_transforms, Tensor v_normals, bool viewmats_requires_grad) -> (Tensor, Tensor, Tensor, Tensor?)",
@@ -447,6 +456,122 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
         # sum_{h,w} v_colors * (1 - alpha)  (reference does this with torch ops too: Rasterization.cpp:567-577)
         v_backgrounds = (v_render_colors * (1.0 - render_alphas)).sum(dim=(-3, -2))
     return v_abs, v_means2d, v_conics, v_colors, v_opacities, v_backgrounds
+
+
+# ----------------------------------------------------------------------------------------------
+# split SH ops (reference SphericalHarmonics.cpp l0 / l1_plus): colours = Y0 * sh0 + sum_{k>=1} Y_k(dir) shN[k-1].
+# l1_plus reuses the full-band kernels on a zero-padded band 0 (same arithmetic for k >= 1).
+# ----------------------------------------------------------------------------------------------
+_SH_C0 = 0.2820947917738781
+
+
+@_op("spherical_harmonics_l0")
+def spherical_harmonics_l0(sh0):
+    _check_f32(sh0=sh0)
+    if sh0.dim() != 3 or sh0.shape[1] != 1:
+        raise ValueError(f"sh0 must have shape [N, 1, D], got {tuple(sh0.shape)}")
+    return sh0[:, 0, :] * _SH_C0
+
+
+@_op("spherical_harmonics_l0_bwd")
+def spherical_harmonics_l0_bwd(sh0, v_colors):
+    return (v_colors * _SH_C0)[:, None, :].contiguous()
+
+
+def _pad_band0(shN):
+    return torch.cat([torch.zeros_like(shN[:, :1]), shN], dim=1).contiguous()
+
+
+@_op("spherical_harmonics_l1_plus")
+def spherical_harmonics_l1_plus(degrees_to_use, means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids,
+                                viewmats_rs=None):
+    return spherical_harmonics(degrees_to_use, means, viewmats, _pad_band0(shN), masks, batch_ids, camera_ids,
+                               gaussian_ids, viewmats_rs)
+
+
+@_op("spherical_harmonics_l1_plus_bwd")
+def spherical_harmonics_l1_plus_bwd(degrees_to_use, means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids,
+                                    viewmats_rs, v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs):
+    v_coeffs, v_means, v_viewmats, v_rs = spherical_harmonics_bwd(
+        degrees_to_use, means, viewmats, _pad_band0(shN), masks, batch_ids, camera_ids, gaussian_ids, viewmats_rs,
+        v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs)
+    return v_coeffs[:, 1:].contiguous(), v_means, v_viewmats, v_rs
+
+
+# ----------------------------------------------------------------------------------------------
+# proj(): projection_ewa_simple (reference ProjectionEWASimple.cu; torch restatement _torch_impl.py:53-260)
+# ----------------------------------------------------------------------------------------------
+@_op("projection_ewa_simple")
+def projection_ewa_simple(means, covars, Ks, width, height, camera_model):
+    _check_f32(means=means, covars=covars, Ks=Ks)
+    if means.shape[-1] != 3 or covars.shape[-2:] != (3, 3) or covars.shape[:-2] != means.shape[:-1]:
+        raise ValueError(f"proj: bad shapes means {tuple(means.shape)} covars {tuple(covars.shape)}")
+    means, covars, Ks = means.contiguous(), covars.contiguous(), Ks.contiguous()
+    N = means.shape[-2]
+    rows = means.numel() // 3
+    means2d = torch.empty(means.shape[:-1] + (2,), device=means.device, dtype=means.dtype)
+    covars2d = torch.empty(means.shape[:-1] + (2, 2), device=means.device, dtype=means.dtype)
+    call("gsx_project_simple_fwd", ptr(means), ptr(covars), ptr(Ks), rows, N, width, height, int(camera_model),
+         ptr(means2d), ptr(covars2d))
+    return means2d, covars2d
+
+
+@_op("projection_ewa_simple_bwd")
+def projection_ewa_simple_bwd(means, covars, Ks, width, height, camera_model, v_means2d, v_covars2d):
+    means, covars, Ks = means.contiguous(), covars.contiguous(), Ks.contiguous()
+    N = means.shape[-2]
+    rows = means.numel() // 3
+    v_means, v_covars = torch.empty_like(means), torch.empty_like(covars)
+    call("gsx_project_simple_bwd", ptr(means), ptr(covars), ptr(Ks), rows, N, width, height, int(camera_model),
+         ptr(v_means2d.contiguous()), ptr(v_covars2d.contiguous()), ptr(v_means), ptr(v_covars))
+    return v_means, v_covars
+
+
+# ----------------------------------------------------------------------------------------------
+# rasterize_to_indices (reference Rasterization.cpp:954-1100): count, exclusive cumsum, write
+# ----------------------------------------------------------------------------------------------
+def _raster_indices(mode, range_start, range_end, transmittances, means2d, geom, opacities, image_width, image_height,
+                    tile_size, tile_offsets, flatten_ids):
+    _check_f32(transmittances=transmittances, means2d=means2d, geom=geom, opacities=opacities)
+    image_dims = tuple(means2d.shape[:-2])
+    N = means2d.shape[-2]
+    I = math.prod(image_dims)
+    if transmittances.shape != image_dims + (image_height, image_width):
+        raise ValueError(f"transmittances must have shape [*image_dims, image_height, image_width], got "
+                         f"{tuple(transmittances.shape)}")
+    th, tw = tile_offsets.shape[-2], tile_offsets.shape[-1]
+    dev = means2d.device
+    args = (int(mode), int(range_start), int(range_end), ptr(transmittances.contiguous()), ptr(means2d.contiguous()),
+            ptr(geom.contiguous()), ptr(opacities.contiguous()), ptr(tile_offsets.contiguous()),
+            ptr(flatten_ids.contiguous()), I, N, flatten_ids.numel(), image_width, image_height, tile_size, tw, th)
+    cnts = torch.zeros(I * image_height * image_width, device=dev, dtype=torch.int32)
+    n_elems = 0
+    if cnts.numel() > 0 and flatten_ids.numel() > 0:
+        call("gsx_raster_indices", *args, None, ptr(cnts), None, None)
+        cum = torch.cumsum(cnts, 0, dtype=torch.int32)
+        n_elems = int(cum[-1].item())
+        starts = (cum - cnts).contiguous()
+    gaussian_ids = torch.empty(n_elems, device=dev, dtype=torch.int64)
+    combined = torch.empty(n_elems, device=dev, dtype=torch.int64)
+    if n_elems:
+        call("gsx_raster_indices", *args, ptr(starts), None, ptr(gaussian_ids), ptr(combined))
+    pix_per_image = image_height * image_width
+    return gaussian_ids, torch.remainder(combined, pix_per_image), torch.div(combined, pix_per_image,
+                                                                            rounding_mode="floor")
+
+
+@_op("rasterize_to_indices_3dgs")
+def rasterize_to_indices_3dgs(range_start, range_end, transmittances, means2d, conics, opacities, image_width,
+                              image_height, tile_size, tile_offsets, flatten_ids):
+    return _raster_indices(0, range_start, range_end, transmittances, means2d, conics, opacities, image_width,
+                           image_height, tile_size, tile_offsets, flatten_ids)
+
+
+@_op("rasterize_to_indices_2dgs")
+def rasterize_to_indices_2dgs(range_start, range_end, transmittances, means2d, ray_transforms, opacities, image_width,
+                              image_height, tile_size, tile_offsets, flatten_ids):
+    return _raster_indices(1, range_start, range_end, transmittances, means2d, ray_transforms, opacities, image_width,
+                           image_height, tile_size, tile_offsets, flatten_ids)
 
 
 # ----------------------------------------------------------------------------------------------

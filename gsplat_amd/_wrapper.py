@@ -242,3 +242,47 @@ def rasterize_to_pixels_2dgs(
     if absgrad:
         means2d.absgrad = means2d_absgrad
     return render_colors, render_alphas, render_normals, render_distort, render_median
+
+
+# ----------------------------------------------------------------------------------------------
+# proj, split SH, rasterize_to_indices (reference _wrapper.py:493-560, 750-780, 2170-2260, 3154-3210)
+# ----------------------------------------------------------------------------------------------
+def proj(means: Tensor, covars: Tensor, Ks: Tensor, width: int, height: int, camera_model: str = "pinhole"):
+    """Camera-space Gaussians [..., C, N, 3] / [..., C, N, 3, 3] -> (means2d [..., C, N, 2], covars2d [..., C, N, 2, 2])."""
+    return _ops.projection_ewa_simple(means.contiguous(), covars.contiguous(), Ks.contiguous(), width, height,
+                                      _camera_model_id(camera_model))
+
+
+def spherical_harmonics_l0(sh0: Tensor) -> Tensor:
+    """l = 0 band only: [N, 1, D] -> [N, D]."""
+    return _ops.spherical_harmonics_l0(sh0.contiguous())
+
+
+def spherical_harmonics_l1_plus(degrees_to_use: int, means: Tensor, viewmats: Tensor, shN: Tensor,
+                                masks: Optional[Tensor] = None, batch_ids: Optional[Tensor] = None,
+                                camera_ids: Optional[Tensor] = None, gaussian_ids: Optional[Tensor] = None,
+                                viewmats_rs: Optional[Tensor] = None) -> Tensor:
+    """Bands l >= 1 only; shN [N, K-1, D] starts at the degree-one basis."""
+    c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+    return _ops.spherical_harmonics_l1_plus(degrees_to_use, means.contiguous(), viewmats.contiguous(), shN.contiguous(),
+                                            c(masks), c(batch_ids), c(camera_ids), c(gaussian_ids), c(viewmats_rs))
+
+
+@torch.no_grad()
+def rasterize_to_indices_in_range(range_start: int, range_end: int, transmittances: Tensor, means2d: Tensor,
+                                  conics: Tensor, opacities: Tensor, image_width: int, image_height: int,
+                                  tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor):
+    """(gaussian_ids, pixel_ids, image_ids) of the contributing pairs inside batches [range_start, range_end) of the
+    tile lists, given the per-pixel transmittance at range_start."""
+    return _ops.rasterize_to_indices_3dgs(range_start, range_end, transmittances.contiguous(), means2d.contiguous(),
+                                          conics.contiguous(), opacities.contiguous(), image_width, image_height,
+                                          tile_size, isect_offsets.contiguous(), flatten_ids.contiguous())
+
+
+@torch.no_grad()
+def rasterize_to_indices_in_range_2dgs(range_start: int, range_end: int, transmittances: Tensor, means2d: Tensor,
+                                       ray_transforms: Tensor, opacities: Tensor, image_width: int, image_height: int,
+                                       tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor):
+    return _ops.rasterize_to_indices_2dgs(range_start, range_end, transmittances.contiguous(), means2d.contiguous(),
+                                          ray_transforms.contiguous(), opacities.contiguous(), image_width,
+                                          image_height, tile_size, isect_offsets.contiguous(), flatten_ids.contiguous())

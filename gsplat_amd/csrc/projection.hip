@@ -456,6 +456,51 @@ __global__ void __launch_bounds__(256) qs2c_bwd_kernel(const float *quats, const
     for (int k = 0; k < 3; ++k) v_scales[3 * i + k] = v_s[k];
 }
 
+// ------------------------------------------------------------------------------------------
+// projection_ewa_simple: camera-space mean/covariance -> image-space mean / 2x2 covariance (no blur, no culling)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) proj_simple_fwd_kernel(const float *means, const float *covars, const float *Ks,
+                                                              int64_t rows, uint32_t N, uint32_t W, uint32_t H, int model,
+                                                              float *means2d, float *covars2d)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows) return;
+    const float *K = Ks + (idx / N) * 9;
+    Cam cam{};
+    cam.fx = K[0]; cam.cx = K[2]; cam.fy = K[4]; cam.cy = K[5];
+    const Proj2D pr = project_camera(model, cam, W, H, means + idx * 3, covars + idx * 9);
+    means2d[2 * idx] = pr.mx; means2d[2 * idx + 1] = pr.my;
+    covars2d[4 * idx] = pr.a; covars2d[4 * idx + 1] = pr.b; covars2d[4 * idx + 2] = pr.b; covars2d[4 * idx + 3] = pr.d;
+}
+
+__global__ void __launch_bounds__(256) proj_simple_bwd_kernel(const float *means, const float *covars, const float *Ks,
+                                                              int64_t rows, uint32_t N, uint32_t W, uint32_t H, int model,
+                                                              const float *v_means2d, const float *v_covars2d,
+                                                              float *v_means, float *v_covars)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows) return;
+    const float *K = Ks + (idx / N) * 9;
+    Cam cam{};
+    cam.fx = K[0]; cam.cx = K[2]; cam.fy = K[4]; cam.cy = K[5];
+    const float *p = means + idx * 3, *Sc = covars + idx * 9, *V = v_covars2d + idx * 4;
+    float v_p[3] = {0.f, 0.f, 0.f}, v_Sc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v_Sc[i] = 0.0f;
+    // symmetric part through the shared VJP; the antisymmetric part of V only reaches the covariance: J^T A J
+    const float g01 = 0.5f * (V[1] + V[2]), an = 0.5f * (V[1] - V[2]);
+    project_camera_vjp(model, cam, W, H, p, Sc, V[0], g01, V[3], v_means2d[2 * idx], v_means2d[2 * idx + 1], v_p, v_Sc);
+    const Proj2D pr = project_camera(model, cam, W, H, p, Sc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v_Sc[3 * i + j] += an * (pr.J[i] * pr.J[3 + j] - pr.J[3 + i] * pr.J[j]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v_means[idx * 3 + i] = v_p[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v_covars[idx * 9 + i] = v_Sc[i];
+}
+
 static int check_proj_common(const char *fn, const float *means, const float *covars, const float *quats,
                              const float *scales, const float *viewmats, const float *Ks, int camera_model)
 {
@@ -632,4 +677,28 @@ extern "C" int gsx_quat_scale_to_covar_bwd(const float *quats, const float *scal
     qs2c_bwd_kernel<<<dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(
         quats, scales, n, triu, v_covars, v_precis, v_quats, v_scales);
     return check_launch("quat_scale_to_covar_bwd");
+}
+
+extern "C" int gsx_project_simple_fwd(const float *means, const float *covars, const float *Ks, int64_t rows,
+                                      uint32_t n_per_camera, uint32_t width, uint32_t height, int camera_model,
+                                      float *means2d, float *covars2d, void *stream)
+{
+    if (rows == 0) return GSX_OK;
+    GSX_REQUIRE(means && covars && Ks && means2d && covars2d && n_per_camera > 0, "gsx_project_simple_fwd: bad argument");
+    proj_simple_fwd_kernel<<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        means, covars, Ks, rows, n_per_camera, width, height, camera_model, means2d, covars2d);
+    return check_launch("project_simple_fwd");
+}
+
+extern "C" int gsx_project_simple_bwd(const float *means, const float *covars, const float *Ks, int64_t rows,
+                                      uint32_t n_per_camera, uint32_t width, uint32_t height, int camera_model,
+                                      const float *v_means2d, const float *v_covars2d, float *v_means, float *v_covars,
+                                      void *stream)
+{
+    if (rows == 0) return GSX_OK;
+    GSX_REQUIRE(means && covars && Ks && v_means2d && v_covars2d && v_means && v_covars && n_per_camera > 0,
+                "gsx_project_simple_bwd: bad argument");
+    proj_simple_bwd_kernel<<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        means, covars, Ks, rows, n_per_camera, width, height, camera_model, v_means2d, v_covars2d, v_means, v_covars);
+    return check_launch("project_simple_bwd");
 }

@@ -211,6 +211,33 @@ int gsx_raster3d_bwd(const float *means2d, const float *conics, const float *col
                      void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * proj(): gsplat::projection_ewa_simple{,_bwd} (ext.cpp:1043-1050; ProjectionEWASimple.cu). Camera-space means
+ * [rows,3] and covariances [rows,3,3] (rows = B*C*N, camera of a row = row / n_per_camera, Ks [B*C,3,3]) -> means2d
+ * [rows,2], covars2d [rows,2,2]; no blur, no culling. bwd fully writes v_means [rows,3] and v_covars [rows,3,3].
+ * ------------------------------------------------------------------------------------------- */
+int gsx_project_simple_fwd(const float *means, const float *covars, const float *Ks, int64_t rows,
+                           uint32_t n_per_camera, uint32_t width, uint32_t height, int camera_model, float *means2d,
+                           float *covars2d, void *stream);
+int gsx_project_simple_bwd(const float *means, const float *covars, const float *Ks, int64_t rows,
+                           uint32_t n_per_camera, uint32_t width, uint32_t height, int camera_model,
+                           const float *v_means2d, const float *v_covars2d, float *v_means, float *v_covars,
+                           void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * rasterize_to_indices: gsplat::rasterize_to_indices_3dgs / _2dgs (ext.cpp:1105-1109, 1200-1204; kernels
+ * RasterizeToIndices{3DGS,2DGS}SerialBatch.cu). mode 0: geom = conics [R,3]; mode 1: geom = ray_transforms [R,9].
+ * range_start/range_end count batches of tile_size^2 entries of each tile list; transmittances [I,H,W] is the state at
+ * range_start. Pass 1 (chunk_starts NULL): chunk_cnts int32 [I,H,W]; pass 2: gaussian_ids / pixel_ids int64 [n_elems]
+ * at chunk_starts (exclusive cumsum of the counts); pixel_ids hold pixel + image*H*W.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_raster_indices(int mode, uint32_t range_start, uint32_t range_end, const float *transmittances,
+                       const float *means2d, const float *geom, const float *opacities, const int32_t *isect_offsets,
+                       const int32_t *flatten_ids, uint32_t n_images, uint32_t n_per_image, uint32_t n_isects,
+                       uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                       const int32_t *chunk_starts, int32_t *chunk_cnts, int64_t *gaussian_ids, int64_t *pixel_ids,
+                       void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * 2DGS projection: gsplat::projection_2dgs_fused{,_bwd} / projection_2dgs_packed{,_bwd}
  * (ext.cpp:1163-1184; kernels Projection2DGSFused.cu:39-339, 341-505, Projection2DGSPacked.cu; VJP
  * Projection2DGS.cuh:29-115). means [B,N,3], quats [B,N,4] (wxyz, normalised inside), scales [B,N,3] (the

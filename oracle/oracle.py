@@ -258,6 +258,43 @@ def fully_fused_projection(
     return radii, means2d, depths, conics, comps
 
 
+def proj(means_c: Tensor, covars_c: Tensor, Ks: Tensor, width: int, height: int, camera_model: str = "pinhole"):
+    """gsplat.proj / projection_ewa_simple (ProjectionEWASimple.cu; _torch_impl.py:53-260 _persp_proj / _ortho_proj /
+    _fisheye_proj): camera-space means [..., C, N, 3], covars [..., C, N, 3, 3], Ks [..., C, 3, 3] ->
+    means2d [..., C, N, 2], covars2d [..., C, N, 2, 2]. Differentiable."""
+    x, y, z = means_c.unbind(-1)
+    fx, fy = Ks[..., 0, 0, None], Ks[..., 1, 1, None]
+    cx, cy = Ks[..., 0, 2, None], Ks[..., 1, 2, None]
+    O = torch.zeros_like(x)
+    if camera_model == "pinhole":
+        tan_fovx, tan_fovy = 0.5 * width / fx, 0.5 * height / fy
+        lxp, lxn = (width - cx) / fx + 0.3 * tan_fovx, cx / fx + 0.3 * tan_fovx
+        lyp, lyn = (height - cy) / fy + 0.3 * tan_fovy, cy / fy + 0.3 * tan_fovy
+        tx = z * torch.minimum(lxp, torch.maximum(-lxn, x / z))
+        ty = z * torch.minimum(lyp, torch.maximum(-lyn, y / z))
+        J = torch.stack([fx / z, O, -fx * tx / z**2, O, fy / z, -fy * ty / z**2], dim=-1)
+        m2 = torch.stack([fx * x / z + cx, fy * y / z + cy], dim=-1)
+    elif camera_model == "ortho":
+        J = torch.stack([fx + O, O, O, O, fy + O, O], dim=-1)
+        m2 = torch.stack([fx * x + cx, fy * y + cy], dim=-1)
+    elif camera_model == "fisheye":
+        eps = 1e-7
+        r = (x * x + y * y) ** 0.5 + eps
+        th = torch.atan2(r, z + eps)
+        m2 = torch.stack([x * fx * th / r + cx, y * fy * th / r + cy], dim=-1)
+        x2, y2, xy = x * x + eps, y * y, x * y
+        r2 = x2 + y2
+        il2 = 1.0 / (r2 + z * z)
+        bb = torch.atan2(r, z) / r / r2
+        aa = z * il2 / r2
+        J = torch.stack([fx * (x2 * aa + y2 * bb), fx * xy * (aa - bb), -fx * x * il2,
+                         fy * xy * (aa - bb), fy * (y2 * aa + x2 * bb), -fy * y * il2], dim=-1)
+    else:
+        raise ValueError(camera_model)
+    J = J.reshape(J.shape[:-1] + (2, 3))
+    return m2, J @ covars_c @ J.transpose(-1, -2)
+
+
 def sh_bases(degree: int, dirs: Tensor) -> Tensor:
     """Sloan's polynomial SH basis, degree <= 4 (SphericalHarmonicsCUDA.cu:48-146 /
     gsplat/cuda/_torch_impl.py:968-1047). dirs must be unit length. Returns [..., (deg+1)^2]."""

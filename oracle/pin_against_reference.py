@@ -191,6 +191,17 @@ def main():
         for nm, b in zip(("v_means", "v_quats", "v_scales", "v_viewmats"), g_r):
             gold[f"proj_{cam}_{nm}"] = b.numpy()
 
+    # ---- 2b. proj() (projection_ewa_simple) vs _torch_impl._persp_proj / _ortho_proj / _fisheye_proj ----------
+    print("[2b] proj vs _torch_impl.py:53-260")
+    mc, cc = R._world_to_cam(means, covars_full, viewmats)
+    front = mc[..., 2] > 0.2
+    for cam, fn in (("pinhole", R._persp_proj), ("ortho", R._ortho_proj), ("fisheye", R._fisheye_proj)):
+        m_r, c_r = fn(mc, cc, Ks, width, height)
+        m_o, c_o = O.proj(mc, cc, Ks, width, height, cam)
+        close(f"proj {cam} means2d", m_o[front], m_r[front], 1e-4, 1e-3)
+        close(f"proj {cam} covars2d (rel)", c_o[front] / (c_r[front].abs().max() + 1e-12),
+              c_r[front] / (c_r[front].abs().max() + 1e-12), 0.0, 1e-5)
+
     # ---- 3. spherical harmonics ---------------------------------------------------------
     print("[3] spherical_harmonics vs _torch_impl.py:1052-1067")
     coeffs = torch.randn(N, 25, 3) * 0.3
