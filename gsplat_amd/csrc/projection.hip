@@ -59,7 +59,9 @@ __device__ __forceinline__ void load_world_covar(const ProjArgs &a, uint32_t b, 
     }
 }
 
-__device__ __forceinline__ ProjOut project_one(const ProjArgs &a, uint32_t b, uint32_t c, uint32_t g)
+// noinline: dense, count and write kernels share ONE compiled body, so packed rows are bit-identical to dense rows
+// (inlined copies may contract different multiply-adds into fma).
+__device__ __noinline__ ProjOut project_one(const ProjArgs &a, uint32_t b, uint32_t c, uint32_t g)
 {
     ProjOut o;
     o.ok = false;

@@ -276,3 +276,46 @@ def test_rasterization_2dgs_pipeline_matches_oracle(G, O, packed, render_mode, s
         if k == "scales":
             ga, gb = ga[..., :2], gb[..., :2]
         assert_grad_close(ga, gb, rel=5e-3, max_bad_ratio=1e-3, name=f"v_{k} packed={packed} mode={render_mode}")
+
+
+def test_c5_full_size_properties_1m_surfels_1080p(G):
+    """BASELINE.json configs[4] (c5): 1M surfels, 1080p, RGB+ED with distortion loss, fwd+bwd. The oracle cannot finish
+    this size in seconds: check size-independent properties (sortedness, alpha range, normals bounded by alpha, linearity
+    of the colour channels, gradient identity sum_g v_feat = sum_px alpha)."""
+    import bench
+
+    sc, W, H = bench.make_workload(1_000_000, DEV)
+    feats = torch.rand(1_000_000, 3, device=DEV)
+    leaves = {k: sc[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")}
+    f = feats.clone().requires_grad_(True)
+    rc, ra, rn, sn, rd, rm, meta = G.rasterization_2dgs(leaves["means"], leaves["quats"], leaves["scales"],
+                                                        leaves["opacities"], f, sc["viewmats"], sc["Ks"], W, H,
+                                                        render_mode="RGB+ED", distloss=True, packed=True)
+    ids, fl = meta["isect_ids"], meta["flatten_ids"]
+    assert ids.numel() > 1_000_000 and bool((ids[1:] >= ids[:-1]).all())
+    same = ids[1:] == ids[:-1]
+    assert bool((fl[1:][same] > fl[:-1][same]).all())
+    assert rc.shape == (1, H, W, 4) and sn.shape[-3:] == (H, W, 3)
+    assert float(ra.min()) >= 0.0 and float(ra.max()) <= 1.0
+    for t in (rc, rn, rd, rm):
+        assert torch.isfinite(t).all()
+    assert bool((rn.norm(dim=-1) <= ra[..., 0] * (1 + 1e-4) + 1e-5).all()), "|sum w n| <= sum w"
+    assert bool((rd >= -1e-3).all()), "the L1 distortion is a sum of non-negative pair terms"
+    (rc[..., :3].sum() + rd.sum()).backward()
+    for k, v in leaves.items():
+        assert torch.isfinite(v.grad).all(), k
+    assert torch.isfinite(meta["gradient_2dgs"].grad).all()
+    # colour channels are linear in the features; alpha / depth do not depend on them
+    with torch.no_grad():
+        f2 = torch.rand(1_000_000, 3, device=DEV)
+        common = (sc["means"], sc["quats"], sc["scales"], sc["opacities"])
+        r1 = G.rasterization_2dgs(*common, feats, sc["viewmats"], sc["Ks"], W, H, render_mode="RGB+ED")
+        r2 = G.rasterization_2dgs(*common, f2, sc["viewmats"], sc["Ks"], W, H, render_mode="RGB+ED", packed=True)
+        r12 = G.rasterization_2dgs(*common, feats + f2, sc["viewmats"], sc["Ks"], W, H, render_mode="RGB+ED")
+    assert torch.equal(r1[1], r2[1]) and torch.equal(r1[1], r12[1]), "alpha: packed == dense, independent of colour"
+    assert torch.allclose(r12[0][..., :3], r1[0][..., :3] + r2[0][..., :3], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(r12[0][..., 3], r1[0][..., 3], rtol=1e-5, atol=1e-5)
+    g1 = torch.rand(1_000_000, 1, device=DEV).requires_grad_(True)
+    r, a, *_ = G.rasterization_2dgs(*common, g1, sc["viewmats"], sc["Ks"], W, H, packed=True)
+    r.sum().backward()
+    assert abs(g1.grad.double().sum() - a.double().sum()) <= 1e-3 * a.double().sum()
