@@ -76,8 +76,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=None, help="Gaussians per rank (default 1M at N=1, 500k at N>1)")
     ap.add_argument("--cameras", type=int, default=None, help="cameras per rank (default 1 at N=1, 4 at N>1)")
-    ap.add_argument("--dense", action="store_true", help="packed=False (default packed=True like the reference)")
+    ap.add_argument("--packed", action="store_true",
+                    help="time packed=True as the headline (default: packed=False, the faster layout when nearly every "
+                         "Gaussian is visible, as in c3; the other layout is timed too and reported in 'other_layout')")
+    ap.add_argument("--dense", action="store_true", help=argparse.SUPPRESS)  # old flag, now the default
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lean", action="store_true",
+                    help="only warmup + timed steps (no stage table, no other-layout leg, no CPU baseline): for rocprofv3 runs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,9 +108,10 @@ def main():
     sc, W, H = make_workload(n_local, device, n_cameras=n_cams, rank=rank, world=world)
     names = ("means", "quats", "scales", "opacities", "colors")
     leaves = {k: sc[k].clone().requires_grad_(True) for k in names}
-    packed = not args.dense
+    # N>1 keeps the packed layout: only visible (camera, Gaussian) rows cross the all-to-all
+    packed = bool(args.packed) or (distributed and not args.dense)
 
-    def step():
+    def step(packed=packed):
         for t in leaves.values():
             t.grad = None
         rc, ra, meta = gsplat_amd.rasterization(
@@ -122,13 +128,34 @@ def main():
     for _ in range(args.warmup):
         meta = step()
     barrier()
-    _cabi.profile_begin()
+    # HIP events (on the launch stream) around the two compositing launches only: the dominant kernels are timed live
+    # inside the timed region without the bookkeeping of ~40 event pairs per step perturbing it.
+    _cabi.profile_begin(only=("gsx_raster3d_fwd", "gsx_raster3d_bwd"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         meta = step()
     barrier()
     elapsed = time.perf_counter() - t0
     prof = _cabi.profile_end()
+    # per-stage table: a few extra (untimed) steps with an event pair around every C-ABI call
+    n_stage = 0 if args.lean else min(5, args.steps)
+    _cabi.profile_begin()
+    for _ in range(n_stage):
+        step()
+    stage_prof = _cabi.profile_end()
+    # the other row layout (packed <-> dense), same workload, same timing recipe (not the headline)
+    other = None
+    if not distributed and not args.lean:
+        for _ in range(min(3, args.warmup)):
+            step(not packed)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(not packed)
+        barrier()
+        t_other = (time.perf_counter() - t1) / args.steps
+        other = {"packed": not packed, "ms_per_step": round(t_other * 1e3, 4),
+                 "value": round(n_cams * W * H / t_other / 1e6, 2)}
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -146,7 +173,7 @@ def main():
     D = 3
     b_fwd, b_bwd = algorithmic_bytes(M, V, P_local, T_local, D)
     mean_ms = {k: sum(v) / len(v) for k, v in prof.items()}
-    per_step_ms = {k: sum(v) / args.steps for k, v in prof.items()}
+    per_step_ms = {k: sum(v) / max(n_stage, 1) for k, v in stage_prof.items()}
     t_fwd = mean_ms.get("gsx_raster3d_fwd", float("nan"))
     t_bwd = mean_ms.get("gsx_raster3d_bwd", float("nan"))
     dom, dom_bytes, dom_ms = ("raster3d_bwd", b_bwd, t_bwd) if not (t_fwd > t_bwd) else ("raster3d_fwd", b_fwd, t_fwd)
@@ -181,11 +208,13 @@ def main():
         "roofline": roofline,
         "stage_ms_per_step": {k.replace("gsx_", ""): round(v, 4) for k, v in sorted(per_step_ms.items())},
     }
+    if other is not None:
+        result["other_layout"] = other
 
     # ---- CPU baseline (rank 0, N=1): the oracle pipeline, one fwd+bwd step of the SAME workload -------------
     # Bounded by construction: one step of c3 is ~10-30 s on <= 32 host threads (more threads are slower for these
     # OpenMP/torch-CPU loops: fork/join + atomic contention), so the default bench run stays within a few minutes.
-    if rank == 0 and not distributed and not args.no_cpu_baseline:
+    if rank == 0 and not distributed and not args.no_cpu_baseline and not args.lean:
         from oracle import oracle as _oracle
         from oracle.pipeline import rasterization_cpu
 

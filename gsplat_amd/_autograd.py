@@ -21,7 +21,14 @@ _registered = False
 
 
 def _bwd(name):
-    return getattr(torch.ops.gsplat, name + "_bwd")
+    """The `<name>_bwd` op body. Called directly rather than through the dispatcher: same function, but undefined
+    incoming gradients can be passed as None (= zeros) instead of being materialised as zero tensors first."""
+    return _ops.impl(name + "_bwd")
+
+
+def _z(v, shape, like):
+    """Materialise an undefined gradient (None) as zeros only where an op needs a real tensor."""
+    return like.new_zeros(shape) if v is None else v
 
 
 # ---- quat_scale_to_covar_preci (reference _wrapper.py:719-760) ----------------------------------
@@ -68,6 +75,8 @@ def _proj_setup(ctx, inputs, output):
      camera_model) = inputs
     radii, _means2d, _depths, conics, compensations = output
     ctx.width, ctx.height, ctx.eps2d, ctx.camera_model = width, height, eps2d, camera_model
+    ctx.set_materialize_grads(False)  # undefined v_depths / v_compensations stay None (no zero-fill kernels)
+    ctx.m2_shape = _means2d.shape
     ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, radii, conics, compensations)
 
 
@@ -77,8 +86,8 @@ def _proj_backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_compensations)
         v_compensations = v_compensations.contiguous()
     v_means, v_covars, v_quats, v_scales, v_viewmats = _bwd("projection_ewa_3dgs_fused")(
         means, covars, quats, scales, viewmats, Ks, ctx.width, ctx.height, ctx.eps2d, ctx.camera_model, radii, conics,
-        compensations, v_means2d.contiguous(), v_depths.contiguous(), v_conics.contiguous(), v_compensations,
-        ctx.needs_input_grad[5],
+        compensations, _z(v_means2d, ctx.m2_shape, conics).contiguous(), None if v_depths is None else v_depths.contiguous(),
+        _z(v_conics, conics.shape, conics).contiguous(), v_compensations, ctx.needs_input_grad[5],
     )
     if not ctx.needs_input_grad[0]:
         v_means = None
@@ -97,6 +106,8 @@ def _projp_setup(ctx, inputs, output):
      _calc, camera_model) = inputs
     (batch_ids, camera_ids, gaussian_ids, _indptr, _radii, _means2d, _depths, conics, compensations) = output
     ctx.width, ctx.height, ctx.eps2d, ctx.camera_model, ctx.sparse_grad = width, height, eps2d, camera_model, sparse_grad
+    ctx.set_materialize_grads(False)
+    ctx.m2_shape = _means2d.shape
     ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, batch_ids, camera_ids, gaussian_ids, conics,
                           compensations)
 
@@ -109,8 +120,9 @@ def _projp_backward(ctx, v_batch_ids, v_camera_ids, v_gaussian_ids, v_indptr, v_
         v_compensations = v_compensations.contiguous()
     v_means, v_covars, v_quats, v_scales, v_viewmats = _bwd("projection_ewa_3dgs_packed")(
         means, covars, quats, scales, viewmats, Ks, ctx.width, ctx.height, ctx.eps2d, ctx.camera_model,
-        ctx.sparse_grad, batch_ids, camera_ids, gaussian_ids, conics, compensations, v_means2d.contiguous(),
-        v_depths.contiguous(), v_conics.contiguous(), v_compensations, ctx.needs_input_grad[5],
+        ctx.sparse_grad, batch_ids, camera_ids, gaussian_ids, conics, compensations,
+        _z(v_means2d, ctx.m2_shape, conics).contiguous(), None if v_depths is None else v_depths.contiguous(),
+        _z(v_conics, conics.shape, conics).contiguous(), v_compensations, ctx.needs_input_grad[5],
     )
     if not ctx.needs_input_grad[0]:
         v_means = None
@@ -130,6 +142,8 @@ def _rast_setup(ctx, inputs, output):
     _render_colors, render_alphas, means2d_absgrad, last_ids = output
     ctx.mark_non_differentiable(last_ids, means2d_absgrad)
     ctx.width, ctx.height, ctx.tile_size, ctx.absgrad = image_width, image_height, tile_size, absgrad
+    ctx.set_materialize_grads(False)  # an unused render_alphas (or render_colors) gets no zero-filled gradient
+    ctx.rc_shape = _render_colors.shape
     ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids,
                           render_alphas, last_ids, means2d_absgrad)
 
@@ -139,8 +153,8 @@ def _rast_backward(ctx, v_render_colors, v_render_alphas, v_means2d_absgrad, v_l
      means2d_absgrad) = ctx.saved_tensors
     v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities, v_backgrounds = _bwd("rasterize_to_pixels_3dgs")(
         means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas, last_ids,
-        ctx.width, ctx.height, ctx.tile_size, ctx.absgrad, v_render_colors.contiguous(), v_render_alphas.contiguous(),
-        ctx.needs_input_grad[4],
+        ctx.width, ctx.height, ctx.tile_size, ctx.absgrad, _z(v_render_colors, ctx.rc_shape, render_alphas).contiguous(),
+        None if v_render_alphas is None else v_render_alphas.contiguous(), ctx.needs_input_grad[4],
     )
     if ctx.absgrad and v_means2d_abs is not None:
         means2d_absgrad.copy_(v_means2d_abs)

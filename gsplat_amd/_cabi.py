@@ -112,13 +112,16 @@ def current_stream() -> int:
 
 
 _profile = None  # list of (entry point, start event, end event) while profiling is on
+_profile_only = None  # optional set of entry points to record (None = all)
 
 
-def profile_begin() -> None:
-    """Start recording a HIP-event pair around every gsx_* call (events go on the stream the kernels are
-    launched on: torch's current stream). Used by bench.py for per-kernel durations."""
-    global _profile
+def profile_begin(only=None) -> None:
+    """Start recording a HIP-event pair around gsx_* calls (events go on the stream the kernels are launched on:
+    torch's current stream). `only` = iterable of entry-point names restricts the recording (bench.py times just the
+    dominant kernels inside its timed region so that event bookkeeping does not perturb the step time)."""
+    global _profile, _profile_only
     _profile = []
+    _profile_only = None if only is None else frozenset(only)
 
 
 def profile_end() -> dict:
@@ -135,7 +138,7 @@ def profile_end() -> dict:
 def call(name: str, *args) -> None:
     """Invoke a gsx_* entry point on the current stream; raise on a non-zero return code."""
     fn = getattr(_lib, name)
-    if _profile is not None:
+    if _profile is not None and (_profile_only is None or name in _profile_only):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         rc = fn(*args, current_stream())

@@ -164,7 +164,10 @@ def spherical_harmonics_bwd(degrees_to_use, means, viewmats, coeffs, masks, batc
     v_colors = v_colors.contiguous()
     need_zero = packed and not _gathered
     v_coeffs = torch.zeros_like(coeffs) if need_zero else torch.empty_like(coeffs)
-    v_means = torch.zeros_like(means) if compute_v_means else None
+    # dense D == 3 kernels store v_means for every (b, g) (sh3_bwd_dense_kernel); the other paths accumulate
+    v_means = None
+    if compute_v_means:
+        v_means = torch.empty_like(means) if (not packed and D == 3 and N > 0) else torch.zeros_like(means)
     nnz = gaussian_ids.shape[0] if packed else -1
     call("gsx_sh_bwd", degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), ptr(_c(batch_ids)),
          ptr(_c(camera_ids)), ptr(_c(gaussian_ids)), B, C, N, nnz, int(_gathered) if packed else 1, K, D,
@@ -199,9 +202,17 @@ def _scan_i32(x: Tensor) -> Tensor:
     return out
 
 
-@_op("intersect_tile")
-def intersect_tile(means2d, radii, depths, conics, opacities, image_ids, gaussian_ids, n_images, tile_size,
-                   tile_width, tile_height, sort, segmented):
+class _IsectPending:
+    """State between the two halves of intersect_tile (see isect_begin)."""
+    __slots__ = ("args", "tiles_per_gauss", "cum", "host_total", "event", "rows", "n_per", "I", "geom", "sort")
+
+
+def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_ids, n_images, tile_size,
+                tile_width, tile_height, sort, segmented) -> "_IsectPending":
+    """First half of intersect_tile: count tiles per Gaussian, prefix-sum, and START the device->host read of the
+    total (pinned buffer + event) without waiting for it. The caller may enqueue independent work (the orchestrator
+    runs the SH kernels here) before isect_finish() blocks on the event, so the host round trip for the exact output
+    length (reference: the `.item()` at Intersect.cpp:258-259) no longer idles the GPU."""
     _check_f32(means2d=means2d, depths=depths, conics=conics, opacities=opacities)
     packed = image_ids is not None
     means2d, radii, depths = means2d.contiguous(), radii.contiguous(), depths.contiguous()
@@ -225,14 +236,37 @@ def intersect_tile(means2d, radii, depths, conics, opacities, image_ids, gaussia
             "available above the depth in the 64-bit sort key"
         )
     dev = means2d.device
-    tiles_per_gauss = torch.empty(out_shape, device=dev, dtype=torch.int32)
+    st = _IsectPending()
+    st.args = (means2d, radii, depths, conics, opacities, image_ids)
+    st.rows, st.n_per, st.I, st.sort = rows, n_per, I, sort
+    st.geom = (tile_size, tile_width, tile_height, tile_bits, image_bits)
+    st.tiles_per_gauss = torch.empty(out_shape, device=dev, dtype=torch.int32)
+    st.cum = st.host_total = st.event = None
+    if rows == 0:
+        return st
+    call("gsx_isect_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), ptr(image_ids), rows, n_per, I,
+         tile_size, tile_width, tile_height, ptr(st.tiles_per_gauss))
+    st.cum = _scan_i32(st.tiles_per_gauss)
+    st.host_total = torch.empty(1, dtype=torch.int64, pin_memory=True)
+    st.host_total.copy_(st.cum[-1:], non_blocking=True)
+    st.event = torch.cuda.Event()
+    st.event.record()
+    return st
+
+
+def isect_finish(st: "_IsectPending"):
+    """Second half of intersect_tile: wait for the total, allocate exact-length outputs, emit (key, value) pairs, sort."""
+    means2d, radii, depths, conics, opacities, image_ids = st.args
+    tile_size, tile_width, tile_height, tile_bits, image_bits = st.geom
+    rows, n_per, I = st.rows, st.n_per, st.I
+    dev = means2d.device
+    tiles_per_gauss = st.tiles_per_gauss
     if rows == 0:
         return (tiles_per_gauss, torch.empty(0, device=dev, dtype=torch.int64),
                 torch.empty(0, device=dev, dtype=torch.int32))
-    call("gsx_isect_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), ptr(image_ids), rows, n_per, I,
-         tile_size, tile_width, tile_height, ptr(tiles_per_gauss))
-    cum = _scan_i32(tiles_per_gauss)
-    n_isects = int(cum[-1].item())  # host sync: exact-length outputs (reference: Intersect.cpp:258-259)
+    st.event.synchronize()  # host sync: exact-length outputs (reference: Intersect.cpp:258-259)
+    n_isects = int(st.host_total.item())
+    cum = st.cum
     if n_isects >= 2**31:
         raise RuntimeError(f"intersect_tile: {n_isects} intersections overflow the int32 index space")
     isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
@@ -241,20 +275,27 @@ def intersect_tile(means2d, radii, depths, conics, opacities, image_ids, gaussia
         return tiles_per_gauss, isect_ids, flatten_ids
     call("gsx_isect_emit", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), ptr(image_ids),
          ptr(cum), rows, n_per, I, tile_size, tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids))
-    if sort and _cabi.tile_sort_supported(I, tile_width, tile_height):
+    if st.sort and _cabi.tile_sort_supported(I, tile_width, tile_height):
         keys_s, vals_s = torch.empty_like(isect_ids), torch.empty_like(flatten_ids)
         ws = torch.empty(_cabi.tile_sort_workspace_bytes(n_isects, I, tile_width, tile_height), device=dev,
                          dtype=torch.uint8)
         call("gsx_isect_tile_sort", ptr(isect_ids), ptr(flatten_ids), n_isects, I, tile_width, tile_height,
              ptr(keys_s), ptr(vals_s), ptr(ws), ws.numel())
         isect_ids, flatten_ids = keys_s, vals_s
-    elif sort:
+    elif st.sort:
         keys_alt, vals_alt = torch.empty_like(isect_ids), torch.empty_like(flatten_ids)
         ws = torch.empty(_cabi.sort_workspace_bytes(n_isects), device=dev, dtype=torch.uint8)
         in_alt = _cabi.sort_pairs(isect_ids, flatten_ids, keys_alt, vals_alt, n_isects, 32 + tile_bits + image_bits, ws)
         if in_alt:
             isect_ids, flatten_ids = keys_alt, vals_alt
     return tiles_per_gauss, isect_ids, flatten_ids
+
+
+@_op("intersect_tile")
+def intersect_tile(means2d, radii, depths, conics, opacities, image_ids, gaussian_ids, n_images, tile_size,
+                   tile_width, tile_height, sort, segmented):
+    return isect_finish(isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_ids, n_images,
+                                    tile_size, tile_width, tile_height, sort, segmented))
 
 
 @_op("intersect_offset")
@@ -317,7 +358,7 @@ def projection_ewa_3dgs_fused_bwd(means, covars, quats, scales, viewmats, Ks, im
     call("gsx_project_ewa_bwd", ptr(means), ptr(covars), ptr(None if covars is not None else quats),
          ptr(None if covars is not None else scales), ptr(viewmats), ptr(Ks), B, C, N, image_width, image_height,
          eps2d, int(camera_model), ptr(radii.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
-         ptr(v_means2d.contiguous()), ptr(v_depths.contiguous()), ptr(v_conics.contiguous()),
+         ptr(v_means2d.contiguous()), ptr(_c(v_depths)), ptr(v_conics.contiguous()),
          ptr(_c(v_compensations)), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
     return v_means, v_covars, v_quats, v_scales, v_viewmats
 
@@ -378,7 +419,7 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
          ptr(None if covars is not None else scales), ptr(viewmats), ptr(Ks), B, C, N, image_width, image_height,
          eps2d, int(camera_model), nnz, ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()),
          ptr(gaussian_ids.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
-         ptr(v_means2d.contiguous()), ptr(v_depths.contiguous()), ptr(v_conics.contiguous()),
+         ptr(v_means2d.contiguous()), ptr(_c(v_depths)), ptr(v_conics.contiguous()),
          ptr(_c(v_compensations)), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
     if sparse_grad:
         # COO gradients like the reference (Projection.cpp:1140-1200): rows = gaussian ids touched
@@ -434,7 +475,7 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     means2d, conics, colors, opacities = (means2d.contiguous(), conics.contiguous(), colors.contiguous(),
                                           opacities.contiguous())
     backgrounds, masks = _c(backgrounds), _c(masks)
-    v_render_colors, v_render_alphas = v_render_colors.contiguous(), v_render_alphas.contiguous()
+    v_render_colors, v_render_alphas = v_render_colors.contiguous(), _c(v_render_alphas)  # None = zeros
     # one zero-fill for all atomically accumulated gradients (views of a single buffer are contiguous slices)
     R = opacities.numel()
     widths = [2, 3, D, 1] + ([2] if absgrad else [])

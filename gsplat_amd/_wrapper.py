@@ -16,6 +16,7 @@ from torch import Tensor
 from . import _autograd  # noqa: F401  (registers ops + autograd)
 
 _ops = torch.ops.gsplat
+from . import _ops as _impl  # noqa: E402  (python-side op bodies: begin/finish halves of intersect_tile)
 
 CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2}
 
@@ -139,6 +140,28 @@ def isect_tiles(
         means2d.contiguous(), radii.contiguous(), depths.contiguous(),
         None if conics is None else conics.contiguous(), None if opacities is None else opacities.contiguous(),
         image_ids, gaussian_ids, n_images, tile_size, tile_width, tile_height, sort, segmented)
+
+
+def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=False,
+                      packed=False, n_images=None, image_ids=None, gaussian_ids=None, conics=None, opacities=None):
+    """isect_tiles() split in two so that the host read of the intersection count overlaps other GPU work:
+    ``pending = isect_tiles_begin(...)``, enqueue independent kernels, then ``isect_tiles_finish(pending)`` returns
+    what isect_tiles() returns. (Extension of the reference surface; isect_tiles() itself is unchanged.)"""
+    if packed:
+        assert image_ids is not None and gaussian_ids is not None and n_images is not None
+        image_ids, gaussian_ids = image_ids.contiguous(), gaussian_ids.contiguous()
+    else:
+        image_ids = gaussian_ids = None
+    with torch.no_grad():
+        return _impl.isect_begin(
+            means2d.contiguous(), radii.contiguous(), depths.contiguous(),
+            None if conics is None else conics.contiguous(), None if opacities is None else opacities.contiguous(),
+            image_ids, gaussian_ids, n_images, tile_size, tile_width, tile_height, sort, segmented)
+
+
+def isect_tiles_finish(pending) -> Tuple[Tensor, Tensor, Tensor]:
+    with torch.no_grad():
+        return _impl.isect_finish(pending)
 
 
 @torch.no_grad()

@@ -79,6 +79,24 @@ __device__ __forceinline__ float wave_sum(float x)
     return (r0 + r1) + (r2 + r3);
 }
 
+// Sum over the 64 lanes; the total is valid in the LAST row only (lanes 48..63). 6 DPP adds, no readlane:
+// row sums, then row_bcast15 (lane 15 of the previous row -> rows 1 and 3), then row_bcast31 (lane 31 -> rows 2, 3).
+__device__ __forceinline__ float wave_sum_last_row(float x)
+{
+#if defined(GSX_SAFE_REDUCE) && GSX_SAFE_REDUCE
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+#else
+    x = row16_sum(x);
+    // all rows enabled (lets the compiler fuse v_add_f32_dpp): rows without a source read 0 (old = 0); rows 1 and
+    // 2 end up with partial sums nobody reads, row 3 = (r2 + r3) + (r0 + r1).
+    x += dpp_f32<0x142>(x); // row_bcast15: lane 15 of the previous row
+    x += dpp_f32<0x143>(x); // row_bcast31: lane 31 -> rows 2 and 3
+    return x;
+#endif
+}
+
 // Reduce FOUR per-lane values over the wave in one go ("reduce-scatter"): on return every lane of
 // 16-lane row r (= lane >> 4) holds the wave-wide sum of value r of (a, b, c, d).
 // gfx950 v_permlane16_swap / v_permlane32_swap fold two registers into one per step, so four

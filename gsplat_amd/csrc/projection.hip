@@ -59,9 +59,11 @@ __device__ __forceinline__ void load_world_covar(const ProjArgs &a, uint32_t b, 
     }
 }
 
-// noinline: dense, count and write kernels share ONE compiled body, so packed rows are bit-identical to dense rows
-// (inlined copies may contract different multiply-adds into fma).
-__device__ __noinline__ ProjOut project_one(const ProjArgs &a, uint32_t b, uint32_t c, uint32_t g)
+// Dense, count and write kernels each inline this body. The file is compiled with -ffp-contract=off (Makefile), so
+// every inlined copy performs the same sequence of IEEE operations: packed rows are bit-identical to dense rows and
+// the count / write passes always agree on visibility. (A shared __noinline__ body gave the same guarantee but cost
+// 208 B of scratch per thread and 3x the run time.)
+__device__ __forceinline__ ProjOut project_one(const ProjArgs &a, uint32_t b, uint32_t c, uint32_t g)
 {
     ProjOut o;
     o.ok = false;
@@ -214,7 +216,7 @@ __device__ __forceinline__ void pair_vjp(const ProjBwdArgs &a, const Cam &cam, c
     for (int i = 0; i < 9; ++i) v_Sc[i] = 0.0f;
     project_camera_vjp(a.camera_model, cam, a.width, a.height, pc, Sc, g00, g01, g11, a.v_means2d[2 * row],
                        a.v_means2d[2 * row + 1], v_pc, v_Sc);
-    v_pc[2] += a.v_depths[row];
+    if (a.v_depths) v_pc[2] += a.v_depths[row]; // null = no gradient reaches the depths
 
     // world mean: v_p += R^T v_pc
 #pragma unroll
@@ -622,7 +624,7 @@ extern "C" int gsx_project_ewa_bwd(const float *means, const float *covars, cons
     if (count == 0 || C == 0) return GSX_OK;
     int rc = check_proj_common("gsx_project_ewa_bwd", means, covars, quats, scales, viewmats, Ks, camera_model);
     if (rc != GSX_OK) return rc;
-    GSX_REQUIRE(radii && conics && v_means2d && v_depths && v_conics, "gsx_project_ewa_bwd: null input");
+    GSX_REQUIRE(radii && conics && v_means2d && v_conics, "gsx_project_ewa_bwd: null input");
     ProjBwdArgs a{};
     fill_bwd(a, means, covars, quats, scales, viewmats, Ks, B, C, N, width, height, eps2d, camera_model, conics,
              compensations, v_means2d, v_depths, v_conics, v_compensations, v_means, v_covars, v_quats, v_scales,
@@ -647,7 +649,7 @@ extern "C" int gsx_project_ewa_packed_bwd(const float *means, const float *covar
     if (nnz <= 0) return GSX_OK;
     int rc = check_proj_common("gsx_project_ewa_packed_bwd", means, covars, quats, scales, viewmats, Ks, camera_model);
     if (rc != GSX_OK) return rc;
-    GSX_REQUIRE(batch_ids && camera_ids && gaussian_ids && conics && v_means2d && v_depths && v_conics,
+    GSX_REQUIRE(batch_ids && camera_ids && gaussian_ids && conics && v_means2d && v_conics,
                 "gsx_project_ewa_packed_bwd: null input");
     ProjBwdArgs a{};
     fill_bwd(a, means, covars, quats, scales, viewmats, Ks, B, C, N, width, height, eps2d, camera_model, conics,

@@ -35,9 +35,9 @@ struct Proj2Out {
     float nrm[3];
 };
 
-// noinline: the dense, count and write kernels must evaluate ONE compiled body — inlined copies get different fma
-// contraction and packed rows would differ from dense rows in the last ulp (and, rarely, in the cull decision).
-__device__ __noinline__ Proj2Out project2_one(const Proj2Args &a, uint32_t b, uint32_t c, uint32_t g)
+// Inlined into the dense, count and write kernels; the file is compiled with -ffp-contract=off (Makefile) so all
+// copies perform the same IEEE operations (bit-identical rows, count/write always agree on visibility).
+__device__ __forceinline__ Proj2Out project2_one(const Proj2Args &a, uint32_t b, uint32_t c, uint32_t g)
 {
     Proj2Out o;
     o.ok = false;

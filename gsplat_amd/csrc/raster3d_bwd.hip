@@ -5,8 +5,12 @@
 //
 // Gradient accumulation is re-designed for wave64 + 160 KiB LDS instead of the reference's
 // "32-lane reduce, then 9+D global atomics per warp per Gaussian":
-//   1. each lane computes its pixel's contribution to one Gaussian (K = D+6 [+2 absgrad] values);
-//   2. the wave reduces FOUR values at a time with permlane16/32 swaps + DPP (common.hpp);
+//   1. each lane computes its pixel's contribution to one Gaussian as K = D+6 [+2 absgrad] values:
+//      D colour terms and the six MOMENTS of w = v_sigma over the pixel offsets d = mean - pixel
+//      (sum w dx^2, w dx dy, w dy^2, w dx, w dy, w); v_conics, v_means2d and v_opacities are linear in
+//      those moments and are formed once per (tile, Gaussian) at flush time instead of once per pixel;
+//   2. the wave reduces FOUR values at a time with permlane16/32 swaps + DPP (common.hpp), a single
+//      left-over value with 6 DPP adds (row_bcast);
 //   3. the K totals land in K different lanes, and ONE ds_add_f32 adds them into a per-tile LDS
 //      accumulator row for that Gaussian (4 waves -> 4-way LDS contention at most);
 //   4. after the batch, thread i flushes Gaussian i's row with global_atomic_add_f32 — one global
@@ -20,7 +24,8 @@ namespace gsx {
 template <int CH, bool ABS>
 struct BwdCfg {
     static constexpr int K     = CH + 6 + (ABS ? 2 : 0);     // values reduced per Gaussian
-    static constexpr int KQ    = (K + 3) / 4;                // groups of four
+    static constexpr bool TAIL1 = (K % 4) == 1;              // one left-over value: cheaper single reduction
+    static constexpr int KQ    = TAIL1 ? K / 4 : (K + 3) / 4; // groups of four
     static constexpr int KP    = (K | 1);                    // odd row stride -> conflict-free flush
     static constexpr int BATCH = (CH >= 16) ? 128 : 256;     // LDS budget for wide channel chunks
     static constexpr size_t smem =
@@ -85,7 +90,7 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
         buffer[k] = 0.0f;
     }
     // alpha-gradient term and background term belong to exactly one channel chunk / all chunks resp.
-    const float v_a = (inside && a.first_chunk) ? a.v_render_alphas[pix] : 0.0f;
+    const float v_a = (inside && a.first_chunk && a.v_render_alphas) ? a.v_render_alphas[pix] : 0.0f; // null = zeros
     float bg_dot    = 0.0f; // sum_k bg_k * v_c_k (this chunk)
     if (a.backgrounds) {
         const float *bg = a.backgrounds + (size_t)image_id * a.cdim + a.ch_off;
@@ -93,6 +98,7 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
         for (int k = 0; k < CH; ++k)
             if (k < (int)a.nch) bg_dot += bg[k] * v_c[k];
     }
+    const float va_minus_bg      = v_a - bg_dot;
     const int32_t wave_bin_final = wave_max_i32(bin_final);
     const WaveRect rect          = wave_pixel_rect(inside, px, py);
 
@@ -151,12 +157,13 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
             const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
             const float vis_r = __expf(-sigma);
             const float alpha_r = fminf(kMaxAlpha, opac * vis_r);
-            const bool valid = inside && (batch_end - t <= bin_final) && !(sigma < 0.0f) && !(alpha_r < kAlphaThreshold);
+            // lanes outside the image have bin_final = -1 and can never be valid
+            const bool valid = (batch_end - t <= bin_final) && !(sigma < 0.0f) && !(alpha_r < kAlphaThreshold);
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform
 
             const float alpha = valid ? alpha_r : 0.0f;
             const float vis   = valid ? vis_r : 0.0f;
-            float loc[KQ * 4];
+            float loc[(K + 3) / 4 * 4];
             {
                 const float ra  = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
                 T              *= ra;
@@ -169,24 +176,23 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
                     v_alpha      += (c * T - buffer[k] * ra) * v_c[k];
                     buffer[k]    += c * fac;
                 }
-                v_alpha += T_final * ra * (v_a - bg_dot);
-                const float ov      = opac * vis;
+                v_alpha += T_final * ra * va_minus_bg;
+                const float ov       = opac * vis;
                 const bool unclamped = ov <= kMaxAlpha; // alpha-clamp branch: geometry/opacity grads vanish
-                const float v_sigma = unclamped ? -ov * v_alpha : 0.0f;
-                loc[CH + 0]         = 0.5f * v_sigma * dx * dx;
-                loc[CH + 1]         = v_sigma * dx * dy;
-                loc[CH + 2]         = 0.5f * v_sigma * dy * dy;
-                const float vx      = v_sigma * (ca * dx + cb * dy);
-                const float vy      = v_sigma * (cb * dx + cc * dy);
-                loc[CH + 3]         = vx;
-                loc[CH + 4]         = vy;
-                loc[CH + 5]         = unclamped ? vis * v_alpha : 0.0f;
+                const float v_sigma  = unclamped ? -ov * v_alpha : 0.0f;
+                const float wdx = v_sigma * dx, wdy = v_sigma * dy;
+                loc[CH + 0]     = wdx * dx; // moments; see flush
+                loc[CH + 1]     = wdx * dy;
+                loc[CH + 2]     = wdy * dy;
+                loc[CH + 3]     = wdx;
+                loc[CH + 4]     = wdy;
+                loc[CH + 5]     = v_sigma;
                 if constexpr (ABS) {
-                    loc[CH + 6] = fabsf(vx);
-                    loc[CH + 7] = fabsf(vy);
+                    loc[CH + 6] = fabsf(ca * wdx + cb * wdy);
+                    loc[CH + 7] = fabsf(cb * wdx + cc * wdy);
                 }
 #pragma unroll
-                for (int k = K; k < KQ * 4; ++k) loc[k] = 0.0f;
+                for (int k = K; k < (K + 3) / 4 * 4; ++k) loc[k] = 0.0f;
             }
             // reduce four values per step; row r of group j ends up with total of value 4j + r
             float mine = 0.0f;
@@ -195,8 +201,17 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
                 const float r = wave_sum4_scatter(loc[4 * j], loc[4 * j + 1], loc[4 * j + 2], loc[4 * j + 3]);
                 if ((int)(lane & 15u) == j) mine = r;
             }
-            const int vidx = 4 * (int)(lane & 15u) + (int)(lane >> 4);
-            if ((int)(lane & 15u) < KQ && vidx < K) atomicAdd(&s_acc[t * KP + vidx], mine); // ds_add_f32
+            int vidx    = 4 * (int)(lane & 15u) + (int)(lane >> 4);
+            bool writer = (int)(lane & 15u) < KQ && vidx < K;
+            if constexpr (Cfg::TAIL1) { // value K-1 alone: total lands in the last row; lane 63 adds it
+                const float r = wave_sum_last_row(loc[K - 1]);
+                if (lane == 63u) {
+                    mine   = r;
+                    vidx   = K - 1;
+                    writer = true;
+                }
+            }
+            if (writer) atomicAdd(&s_acc[t * KP + vidx], mine); // ds_add_f32
             if (lane == 0) s_touch[t] = 1;
           }
         }
@@ -210,12 +225,17 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
 #pragma unroll
                 for (int k = 0; k < CH; ++k)
                     if (k < (int)a.nch) atomic_add_f32(a.v_colors + g * a.cdim + a.ch_off + k, row[k]);
-                atomic_add_f32(a.v_conics + 3 * g + 0, row[CH + 0]);
+                // moments -> gradients (linear): v_conic = (S_xx/2, S_xy, S_yy/2), v_xy = Q (S_x, S_y),
+                // v_opacity = sum vis*v_alpha = -S_w / opacity (a touched Gaussian has opacity >= 1/255)
+                const float4 ga = s_ga[s];
+                const float2 gb = s_gb[s];
+                const float sx = row[CH + 3], sy = row[CH + 4];
+                atomic_add_f32(a.v_conics + 3 * g + 0, 0.5f * row[CH + 0]);
                 atomic_add_f32(a.v_conics + 3 * g + 1, row[CH + 1]);
-                atomic_add_f32(a.v_conics + 3 * g + 2, row[CH + 2]);
-                atomic_add_f32(a.v_means2d + 2 * g + 0, row[CH + 3]);
-                atomic_add_f32(a.v_means2d + 2 * g + 1, row[CH + 4]);
-                atomic_add_f32(a.v_opacities + g, row[CH + 5]);
+                atomic_add_f32(a.v_conics + 3 * g + 2, 0.5f * row[CH + 2]);
+                atomic_add_f32(a.v_means2d + 2 * g + 0, ga.w * sx + gb.x * sy);
+                atomic_add_f32(a.v_means2d + 2 * g + 1, gb.x * sx + gb.y * sy);
+                atomic_add_f32(a.v_opacities + g, -row[CH + 5] / ga.z);
                 if constexpr (ABS) {
                     atomic_add_f32(a.v_means2d_abs + 2 * g + 0, row[CH + 6]);
                     atomic_add_f32(a.v_means2d_abs + 2 * g + 1, row[CH + 7]);
@@ -284,7 +304,7 @@ extern "C" int gsx_raster3d_bwd(
     GSX_REQUIRE(cdim >= 1, "gsx_raster3d_bwd: channels must be >= 1");
     GSX_REQUIRE(v_means2d && v_conics && v_colors && v_opacities, "gsx_raster3d_bwd: null gradient output");
     GSX_REQUIRE(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids && render_alphas && last_ids
-                                  && v_render_colors && v_render_alphas && isect_offsets),
+                                  && v_render_colors && isect_offsets),
                 "gsx_raster3d_bwd: null input");
     Raster3DArgs a{};
     a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height;

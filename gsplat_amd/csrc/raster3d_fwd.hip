@@ -13,9 +13,10 @@ template <int CH>
 __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float4 *s_ga = reinterpret_cast<float4 *>(smem_raw);                 // x, y, opac, conic.a
-    float2 *s_gb = reinterpret_cast<float2 *>(s_ga + kBatch);            // conic.b, conic.c
-    float *s_col = reinterpret_cast<float *>(s_gb + kBatch);             // [kBatch][CH]
+    float4 *s_ga   = reinterpret_cast<float4 *>(smem_raw);                 // x, y, opac, conic.a
+    float4 *s_cull = s_ga + kBatch;                                        // x, y, half extents of alpha >= 1/255
+    float2 *s_gb   = reinterpret_cast<float2 *>(s_cull + kBatch);          // conic.b, conic.c
+    float *s_col   = reinterpret_cast<float *>(s_gb + kBatch);             // [kBatch][CH]
 
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
     const uint32_t n_blocks        = tiles_per_image * a.n_images;
@@ -64,6 +65,8 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 #pragma unroll
     for (int k = 0; k < CH; ++k) acc[k] = 0.0f;
     bool done = !inside;
+    const uint32_t lane = tid & 63u;
+    const WaveRect rect = wave_pixel_rect(inside, px, py);
 
     for (int32_t b = 0; b < n_batches; ++b) {
         // block-wide early out: every pixel of the tile finished. Also fences LDS reuse.
@@ -77,9 +80,11 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 const float2 xy  = reinterpret_cast<const float2 *>(a.means2d)[g];
                 const float opac = a.opacities[g];
                 const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
-                s_ga[s]        = make_float4(xy.x, xy.y, opac, ca);
-                s_gb[s]        = make_float2(cb, cc);
-                const float *c = a.colors + (size_t)g * a.cdim + a.ch_off;
+                s_ga[s]         = make_float4(xy.x, xy.y, opac, ca);
+                s_gb[s]         = make_float2(cb, cc);
+                const float2 he = cull_half_extent(opac, ca, cb, cc);
+                s_cull[s]       = make_float4(xy.x, xy.y, he.x, he.y);
+                const float *c  = a.colors + (size_t)g * a.cdim + a.ch_off;
 #pragma unroll
                 for (int k = 0; k < CH; ++k) s_col[s * CH + k] = (k < (int)a.nch) ? c[k] : 0.0f;
             }
@@ -87,28 +92,42 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
         __syncthreads();
 
         const int32_t batch_size = min(kBatch, range_end - batch_start);
-        // wave-level early termination: a finished 8x8 quadrant stops evaluating
-        // (it still takes part in staging and in the barriers above).
-        for (int32_t t = 0; t < batch_size; ++t) {
+        // Each wave tests 64 staged Gaussians at a time (one per lane) against the rectangle of ITS 8x8 pixel
+        // centres (raster3d.hpp) and walks only the survivors, front to back, with a scalar loop over the ballot.
+        // A culled (wave, Gaussian) pair has no lane that would pass the alpha test, so results are unchanged.
+        for (int32_t j = 0; j < batch_size; j += 64) {
+            // wave-level early termination: a finished quadrant stops evaluating (it still takes part in
+            // staging and in the barriers above).
             if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-            const float4 ga = s_ga[t];
-            const float2 gb = s_gb[t];
-            const float dx  = ga.x - px;
-            const float dy  = ga.y - py;
-            const float sigma = 0.5f * (ga.w * dx * dx + gb.y * dy * dy) + gb.x * dx * dy;
-            const float vis   = __expf(-sigma);
-            const float alpha = fminf(kMaxAlpha, ga.z * vis);
-            if (done || sigma < 0.0f || alpha < kAlphaThreshold) continue;
-            const float next_T = T * (1.0f - alpha);
-            if (next_T <= kTransmittanceThresh) { // saturated: this Gaussian is excluded
-                done = true;
-                continue;
+            const int32_t tl = j + (int32_t)lane;
+            bool hit         = false;
+            if (tl < batch_size) {
+                const float4 cu = s_cull[tl];
+                hit = (fabsf(cu.x - rect.cx) - rect.hw <= cu.z) && (fabsf(cu.y - rect.cy) - rect.hh <= cu.w);
             }
-            const float w = alpha * T;
+            uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
+            while (todo) {
+                const int32_t t = j + (int32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const float4 ga = s_ga[t];
+                const float2 gb = s_gb[t];
+                const float dx  = ga.x - px;
+                const float dy  = ga.y - py;
+                const float sigma = 0.5f * (ga.w * dx * dx + gb.y * dy * dy) + gb.x * dx * dy;
+                const float vis   = __expf(-sigma);
+                const float alpha = fminf(kMaxAlpha, ga.z * vis);
+                if (done || sigma < 0.0f || alpha < kAlphaThreshold) continue;
+                const float next_T = T * (1.0f - alpha);
+                if (next_T <= kTransmittanceThresh) { // saturated: this Gaussian is excluded
+                    done = true;
+                    continue;
+                }
+                const float w = alpha * T;
 #pragma unroll
-            for (int k = 0; k < CH; ++k) acc[k] += s_col[t * CH + k] * w;
-            cur_idx = (uint32_t)(batch_start + t);
-            T       = next_T;
+                for (int k = 0; k < CH; ++k) acc[k] += s_col[t * CH + k] * w;
+                cur_idx = (uint32_t)(batch_start + t);
+                T       = next_T;
+            }
         }
     }
 
@@ -131,7 +150,7 @@ static int launch_fwd(const Raster3DArgs &a, hipStream_t stream)
     if (n_blocks == 0) return GSX_OK;
     const uint32_t grid   = ((n_blocks + 7u) / 8u) * 8u; // xcd_remap needs a multiple of 8
     const uint32_t block  = a.tile_size <= 8 ? 64u : 256u;
-    const size_t smem     = kBatch * (sizeof(float4) + sizeof(float2) + sizeof(float) * CH);
+    const size_t smem     = kBatch * (2 * sizeof(float4) + sizeof(float2) + sizeof(float) * CH);
     hipLaunchKernelGGL(raster3d_fwd_kernel<CH>, dim3(grid), dim3(block), smem, stream, a);
     return check_launch("raster3d_fwd");
 }

@@ -25,6 +25,8 @@ from ._wrapper import (
     fully_fused_projection,
     isect_offset_encode,
     isect_tiles,
+    isect_tiles_begin,
+    isect_tiles_finish,
     rasterize_to_pixels,
     spherical_harmonics,
 )
@@ -182,6 +184,18 @@ def rasterization(
     if compensations is not None:
         proj_opacities = proj_opacities * compensations
 
+    # ---- tile intersection, first half (single-process path) ----------------------------------------
+    # count + scan + asynchronous host read of the intersection total are enqueued BEFORE the SH kernels, which do
+    # not depend on them; by the time isect_tiles_finish() needs the number on the host the GPU is still busy.
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    isect_pending = None
+    if dist_ctx is None:
+        isect_pending = isect_tiles_begin(
+            means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=False, packed=packed,
+            n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids, conics=conics,
+            opacities=proj_opacities.contiguous())
+
     # ---- feature channels: [..., C, N, D] or [nnz, D] ------------------------------------------
     feats = None
     if has_color:
@@ -219,13 +233,13 @@ def rasterization(
                 backgrounds = torch.zeros(batch_dims + (C, feats.shape[-1]), device=device, dtype=means.dtype)
     assert feats is not None
 
-    # ---- tile intersection -----------------------------------------------------------------------
-    tile_width = math.ceil(width / float(tile_size))
-    tile_height = math.ceil(height / float(tile_size))
-    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
-        means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=False, packed=packed,
-        n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids if dist_ctx is None else gaussian_ids_r,
-        conics=conics, opacities=proj_opacities.contiguous())
+    # ---- tile intersection (second half) -----------------------------------------------------------
+    if isect_pending is None:
+        isect_pending = isect_tiles_begin(
+            means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=False, packed=packed,
+            n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids_r, conics=conics,
+            opacities=proj_opacities.contiguous())
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles_finish(isect_pending)
     isect_offsets = isect_offset_encode(isect_ids, I, tile_width, tile_height)
     isect_offsets = isect_offsets.reshape(batch_dims + (C, tile_height, tile_width))
 

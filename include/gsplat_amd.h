@@ -193,7 +193,8 @@ int gsx_isect_offsets(const int64_t *isect_ids_sorted, int64_t n_isects, uint32_
  * Rasterization.cpp:275-365, 484-587; kernels RasterizeToPixels3DGSSerialBatch{Fwd,Bwd}.cu).
  * Any channel count >= 1 (chunked by 32 internally); tile_size in [1,16].
  * fwd outputs: render_colors [I,H,W,cdim], render_alphas [I,H,W,1], last_ids int32 [I,H,W].
- * bwd: gradient outputs must be ZERO-initialised; v_means2d_abs may be NULL (absgrad off).
+ * bwd: gradient outputs must be ZERO-initialised; v_means2d_abs may be NULL (absgrad off); v_render_alphas may be
+ * NULL (no gradient reaches the alphas: treated as zeros). Likewise v_depths may be NULL in gsx_project_ewa*_bwd.
  * v_backgrounds is a torch-side reduction in the reference (Rasterization.cpp:567-577) and in the shim.
  * ------------------------------------------------------------------------------------------- */
 int gsx_raster3d_fwd(const float *means2d, const float *conics, const float *colors, const float *opacities,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick per-kernel time table for bench.py on the GPU box: tools/gpu_trace.sh [bench args]
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/p
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > /tmp/bench_out.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --lean "$@" > /tmp/bench_out.txt 2>&1
 tail -1 /tmp/bench_out.txt | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'], 'value', d['value'])"
 python - <<PY
 import csv,glob
