@@ -107,6 +107,13 @@ def ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+def ptr_strided(t: torch.Tensor):
+    """Device pointer of a tensor whose layout the caller has already checked (row-strided views)."""
+    if not t.is_cuda:
+        raise GsplatAmdError("gsplat_amd kernels only run on a ROCm device (got a CPU tensor); there is no CPU fallback")
+    return t.data_ptr()
+
+
 def current_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 

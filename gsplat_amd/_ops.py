@@ -19,7 +19,7 @@ import torch
 from torch import Tensor
 
 from . import _cabi
-from ._cabi import call, ptr
+from ._cabi import call, ptr, ptr_strided
 
 NS = "gsplat"
 
@@ -83,6 +83,23 @@ def _check_f32(**tensors):
 
 def _c(t: Optional[Tensor]) -> Optional[Tensor]:
     return None if t is None else t.contiguous()
+
+
+def _row_view(t: Tensor, width: int):
+    """(tensor, row stride in elements) for a [..., width] float tensor whose rows are `width` contiguous elements at
+    a uniform stride — e.g. a column view of the AoS gradient buffer returned by rasterize_to_pixels_3dgs_bwd — else a
+    contiguous copy with stride `width`. The kernels read such views in place (no gather copy)."""
+    if t.is_contiguous():
+        return t, width
+    if t.dim() >= 2 and t.shape[-1] == width and t.stride(-1) == 1 and t.numel() > 0:
+        rs = t.stride(-2)
+        ok = rs >= width
+        for d in range(t.dim() - 3, -1, -1):
+            if t.shape[d] != 1 and t.stride(d) != t.stride(d + 1) * t.shape[d + 1]:
+                ok = False
+        if ok:
+            return t, rs
+    return t.contiguous(), width
 
 
 def bits_for_count(count: int) -> int:
@@ -355,10 +372,12 @@ def projection_ewa_3dgs_fused_bwd(means, covars, quats, scales, viewmats, Ks, im
     else:
         v_quats, v_scales = torch.empty_like(quats), torch.empty_like(scales)
     v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
+    v_means2d, m2_stride = _row_view(v_means2d, 2)
+    v_conics, con_stride = _row_view(v_conics, 3)
     call("gsx_project_ewa_bwd", ptr(means), ptr(covars), ptr(None if covars is not None else quats),
          ptr(None if covars is not None else scales), ptr(viewmats), ptr(Ks), B, C, N, image_width, image_height,
          eps2d, int(camera_model), ptr(radii.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
-         ptr(v_means2d.contiguous()), ptr(_c(v_depths)), ptr(v_conics.contiguous()),
+         ptr_strided(v_means2d), m2_stride, ptr(_c(v_depths)), ptr_strided(v_conics), con_stride,
          ptr(_c(v_compensations)), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
     return v_means, v_covars, v_quats, v_scales, v_viewmats
 
@@ -415,11 +434,13 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
     else:
         v_quats, v_scales = torch.zeros_like(quats), torch.zeros_like(scales)
     v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
+    v_means2d, m2_stride = _row_view(v_means2d, 2)
+    v_conics, con_stride = _row_view(v_conics, 3)
     call("gsx_project_ewa_packed_bwd", ptr(means), ptr(covars), ptr(None if covars is not None else quats),
          ptr(None if covars is not None else scales), ptr(viewmats), ptr(Ks), B, C, N, image_width, image_height,
          eps2d, int(camera_model), nnz, ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()),
          ptr(gaussian_ids.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
-         ptr(v_means2d.contiguous()), ptr(_c(v_depths)), ptr(v_conics.contiguous()),
+         ptr_strided(v_means2d), m2_stride, ptr(_c(v_depths)), ptr_strided(v_conics), con_stride,
          ptr(_c(v_compensations)), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
     if sparse_grad:
         # COO gradients like the reference (Projection.cpp:1140-1200): rows = gaussian ids touched
@@ -476,22 +497,19 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
                                           opacities.contiguous())
     backgrounds, masks = _c(backgrounds), _c(masks)
     v_render_colors, v_render_alphas = v_render_colors.contiguous(), _c(v_render_alphas)  # None = zeros
-    # one zero-fill for all atomically accumulated gradients (views of a single buffer are contiguous slices)
+    # ONE zero-filled array-of-structures buffer [R][6 (+2) + D] (layout: include/gsplat_amd.h, gsx_raster3d_bwd); the
+    # gradients the reference returns as separate tensors are COLUMN VIEWS of it. A Gaussian's gradients share a cache
+    # line, which is what makes the kernel's atomic flush cheap; projection_ewa_3dgs_*_bwd reads the views in place.
     R = opacities.numel()
-    widths = [2, 3, D, 1] + ([2] if absgrad else [])
-    flat = torch.zeros(R * sum(widths), device=means2d.device, dtype=means2d.dtype)
-    parts, o = [], 0
-    for w in widths:
-        parts.append(flat[o:o + R * w])
-        o += R * w
-    v_means2d, v_conics = parts[0].view(means2d.shape), parts[1].view(conics.shape)
-    v_colors, v_opacities = parts[2].view(colors.shape), parts[3].view(opacities.shape)
-    v_abs = parts[4].view(means2d.shape) if absgrad else None
+    geo = 8 if absgrad else 6
+    rows = torch.zeros((R, geo + D), device=means2d.device, dtype=means2d.dtype)
     call("gsx_raster3d_bwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
          ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
          ptr(last_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
-         image_width, image_height, tile_size, tw, th, ptr(v_abs), ptr(v_means2d), ptr(v_conics), ptr(v_colors),
-         ptr(v_opacities))
+         image_width, image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D)
+    v_means2d, v_conics = rows[:, 0:2].view(means2d.shape), rows[:, 2:5].view(conics.shape)
+    v_opacities, v_colors = rows[:, 5].view(opacities.shape), rows[:, geo:].view(colors.shape)
+    v_abs = rows[:, 6:8].view(means2d.shape) if absgrad else None
     v_backgrounds = None
     if backgrounds is not None and compute_v_backgrounds:
         # sum_{h,w} v_colors * (1 - alpha)  (reference does this with torch ops too: Rasterization.cpp:567-577)

@@ -177,6 +177,8 @@ struct ProjBwdArgs {
     const int32_t *radii;
     const float *conics, *compensations;
     const float *v_means2d, *v_depths, *v_conics, *v_compensations;
+    uint32_t m2_stride, con_stride; // row strides (floats) of v_means2d / v_conics: 2 / 3 when contiguous, or the
+                                    // stride of gsx_raster3d_bwd's AoS gradient rows when they are column views of it
     int64_t nnz;
     const int64_t *batch_ids, *camera_ids, *gaussian_ids;
     float *v_means, *v_covars, *v_quats, *v_scales, *v_viewmats;
@@ -188,7 +190,8 @@ __device__ __forceinline__ void pair_vjp(const ProjBwdArgs &a, const Cam &cam, c
                                          int64_t row, float *v_p, float *v_S, float *v_R, float *v_t, bool want_pose)
 {
     const float ca = a.conics[3 * row], cb = a.conics[3 * row + 1], cc = a.conics[3 * row + 2];
-    const float va = a.v_conics[3 * row], vb = 0.5f * a.v_conics[3 * row + 1], vc = a.v_conics[3 * row + 2];
+    const float *vcon = a.v_conics + (size_t)a.con_stride * row;
+    const float va = vcon[0], vb = 0.5f * vcon[1], vc = vcon[2];
     // v_cov2d = -P V P with P = [[ca,cb],[cb,cc]], V = [[va,vb],[vb,vc]]
     const float t00 = va * ca + vb * cb, t01 = va * cb + vb * cc;
     const float t10 = vb * ca + vc * cb, t11 = vb * cb + vc * cc;
@@ -214,8 +217,8 @@ __device__ __forceinline__ void pair_vjp(const ProjBwdArgs &a, const Cam &cam, c
     float v_pc[3] = {0.f, 0.f, 0.f}, v_Sc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) v_Sc[i] = 0.0f;
-    project_camera_vjp(a.camera_model, cam, a.width, a.height, pc, Sc, g00, g01, g11, a.v_means2d[2 * row],
-                       a.v_means2d[2 * row + 1], v_pc, v_Sc);
+    const float *vm2 = a.v_means2d + (size_t)a.m2_stride * row;
+    project_camera_vjp(a.camera_model, cam, a.width, a.height, pc, Sc, g00, g01, g11, vm2[0], vm2[1], v_pc, v_Sc);
     if (a.v_depths) v_pc[2] += a.v_depths[row]; // null = no gradient reaches the depths
 
     // world mean: v_p += R^T v_pc
@@ -601,10 +604,11 @@ extern "C" int gsx_project_ewa_packed_write(const float *means, const float *cov
 static void fill_bwd(ProjBwdArgs &a, const float *means, const float *covars, const float *quats, const float *scales,
                      const float *viewmats, const float *Ks, uint32_t B, uint32_t C, uint32_t N, uint32_t width,
                      uint32_t height, float eps2d, int camera_model, const float *conics, const float *compensations,
-                     const float *v_means2d, const float *v_depths, const float *v_conics,
-                     const float *v_compensations, float *v_means, float *v_covars, float *v_quats, float *v_scales,
-                     float *v_viewmats)
+                     const float *v_means2d, uint32_t m2_stride, const float *v_depths, const float *v_conics,
+                     uint32_t con_stride, const float *v_compensations, float *v_means, float *v_covars,
+                     float *v_quats, float *v_scales, float *v_viewmats)
 {
+    a.m2_stride = m2_stride; a.con_stride = con_stride;
     a.means = means; a.covars = covars; a.quats = quats; a.scales = scales; a.viewmats = viewmats; a.Ks = Ks;
     a.B = B; a.C = C; a.N = N; a.width = width; a.height = height; a.eps2d = eps2d; a.camera_model = camera_model;
     a.conics = conics; a.compensations = compensations; a.v_means2d = v_means2d; a.v_depths = v_depths;
@@ -616,7 +620,8 @@ extern "C" int gsx_project_ewa_bwd(const float *means, const float *covars, cons
                                    const float *viewmats, const float *Ks, uint32_t B, uint32_t C, uint32_t N,
                                    uint32_t width, uint32_t height, float eps2d, int camera_model,
                                    const int32_t *radii, const float *conics, const float *compensations,
-                                   const float *v_means2d, const float *v_depths, const float *v_conics,
+                                   const float *v_means2d, uint32_t v_means2d_stride, const float *v_depths,
+                                   const float *v_conics, uint32_t v_conics_stride,
                                    const float *v_compensations, float *v_means, float *v_covars, float *v_quats,
                                    float *v_scales, float *v_viewmats, void *stream)
 {
@@ -625,10 +630,11 @@ extern "C" int gsx_project_ewa_bwd(const float *means, const float *covars, cons
     int rc = check_proj_common("gsx_project_ewa_bwd", means, covars, quats, scales, viewmats, Ks, camera_model);
     if (rc != GSX_OK) return rc;
     GSX_REQUIRE(radii && conics && v_means2d && v_conics, "gsx_project_ewa_bwd: null input");
+    GSX_REQUIRE(v_means2d_stride >= 2 && v_conics_stride >= 3, "gsx_project_ewa_bwd: row strides must be >= 2 / >= 3");
     ProjBwdArgs a{};
     fill_bwd(a, means, covars, quats, scales, viewmats, Ks, B, C, N, width, height, eps2d, camera_model, conics,
-             compensations, v_means2d, v_depths, v_conics, v_compensations, v_means, v_covars, v_quats, v_scales,
-             v_viewmats);
+             compensations, v_means2d, v_means2d_stride, v_depths, v_conics, v_conics_stride, v_compensations, v_means,
+             v_covars, v_quats, v_scales, v_viewmats);
     a.radii = radii;
     const dim3 grid((uint32_t)ceil_div(count, 256)), block(256);
     if (v_viewmats) project_bwd_kernel<true><<<grid, block, 0, (hipStream_t)stream>>>(a);
@@ -641,8 +647,9 @@ extern "C" int gsx_project_ewa_packed_bwd(const float *means, const float *covar
                                           uint32_t C, uint32_t N, uint32_t width, uint32_t height, float eps2d,
                                           int camera_model, int64_t nnz, const int64_t *batch_ids,
                                           const int64_t *camera_ids, const int64_t *gaussian_ids, const float *conics,
-                                          const float *compensations, const float *v_means2d, const float *v_depths,
-                                          const float *v_conics, const float *v_compensations, float *v_means,
+                                          const float *compensations, const float *v_means2d,
+                                          uint32_t v_means2d_stride, const float *v_depths, const float *v_conics,
+                                          uint32_t v_conics_stride, const float *v_compensations, float *v_means,
                                           float *v_covars, float *v_quats, float *v_scales, float *v_viewmats,
                                           void *stream)
 {
@@ -651,10 +658,12 @@ extern "C" int gsx_project_ewa_packed_bwd(const float *means, const float *covar
     if (rc != GSX_OK) return rc;
     GSX_REQUIRE(batch_ids && camera_ids && gaussian_ids && conics && v_means2d && v_conics,
                 "gsx_project_ewa_packed_bwd: null input");
+    GSX_REQUIRE(v_means2d_stride >= 2 && v_conics_stride >= 3,
+                "gsx_project_ewa_packed_bwd: row strides must be >= 2 / >= 3");
     ProjBwdArgs a{};
     fill_bwd(a, means, covars, quats, scales, viewmats, Ks, B, C, N, width, height, eps2d, camera_model, conics,
-             compensations, v_means2d, v_depths, v_conics, v_compensations, v_means, v_covars, v_quats, v_scales,
-             v_viewmats);
+             compensations, v_means2d, v_means2d_stride, v_depths, v_conics, v_conics_stride, v_compensations, v_means,
+             v_covars, v_quats, v_scales, v_viewmats);
     a.nnz = nnz; a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
     const dim3 grid((uint32_t)ceil_div(nnz, 256)), block(256);
     if (v_viewmats) project_packed_bwd_kernel<true><<<grid, block, 0, (hipStream_t)stream>>>(a);

@@ -47,12 +47,12 @@ struct Raster3DArgs {
     // backward inputs
     const float *v_render_colors; // [I, H, W, cdim]
     const float *v_render_alphas; // [I, H, W, 1]
-    // backward outputs (zero-initialised by the caller; accumulated with atomics)
-    float *v_means2d_abs; // [R, 2] or null
-    float *v_means2d;     // [R, 2]
-    float *v_conics;      // [R, 3]
-    float *v_colors;      // [R, cdim]
-    float *v_opacities;   // [R]
+    // backward output (zero-initialised by the caller; accumulated with atomics): ONE array-of-structures buffer
+    // [R][row_stride]; row = (v_mean2d.x, v_mean2d.y, v_conic.a, v_conic.b, v_conic.c, v_opacity,
+    // [|v_mean2d.x|, |v_mean2d.y| when has_abs], v_color[0..cdim)). A Gaussian's gradients share a cache line,
+    // and the flush writes consecutive floats from consecutive lanes (see raster3d_bwd.hip).
+    float *v_rows;
+    uint32_t row_stride;
 };
 
 // Block index -> (image, tile) with an XCD-aware remap: hardware places workgroup b on

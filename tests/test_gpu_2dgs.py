@@ -242,7 +242,9 @@ def test_rasterization_2dgs_pipeline_matches_oracle(G, O, packed, render_mode, s
     rc_cmp = torch.cat([rc_o[..., :-1], rc_o[..., -1:] / a_], -1) if expected else rc_o
     R_c2w = torch.linalg.inv(sc["viewmats"])[:, :3, :3]
     rn_cmp = torch.einsum("cij,chwj->chwi", R_c2w, rn_o)
-    assert meta["isect_ids"].numel() == ids.numel()
+    # radii are ceil() of float expressions: the reference compares them with atol=1 (tests/test_basic.py), so the
+    # intersection COUNT may differ by a few entries between the GPU and the torch-CPU oracle projection
+    assert abs(meta["isect_ids"].numel() - ids.numel()) <= max(4, ids.numel() // 2000)
     assert_close_ratio(cpu(rc), rc_cmp, 1e-3, 1e-4, max_bad_ratio=1e-3, name="render_colors")
     assert_close_ratio(cpu(ra), ra_o, 1e-4, 5e-5, max_bad_ratio=1e-3, name="render_alphas")
     assert_close_ratio(cpu(rn), rn_cmp, 1e-3, 1e-4, max_bad_ratio=1e-3, name="render_normals")
