@@ -79,6 +79,31 @@ __device__ __forceinline__ void tile_pixel(uint32_t tid, uint32_t tile_size, uin
     }
 }
 
+// ---- staged form of one Gaussian in LDS -------------------------------------------------------------
+// The compositing loops evaluate alpha in base 2 with the constants folded in at staging time (once per tile and
+// Gaussian instead of once per pixel and Gaussian):
+//   opac * exp(-sigma) = exp2(lo - q),   lo = log2(opac),   q = A dx^2 + B dx dy + C dy^2,
+//   A = log2(e)/2 * conic.a,  B = log2(e) * conic.b,  C = log2(e)/2 * conic.c          (sigma < 0  <=>  q < 0)
+// which is one v_exp_f32 and no multiply by log2(e) / opacity per pixel. Same quantity as the reference's
+// `opac * __expf(-sigma)` (RasterizeToPixels3DGSDevice.cuh:44-56) to ~1e-6 relative.
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ void stage_gaussian(float x, float y, float opac, float ca, float cb, float cc, float4 &ga,
+                                               float2 &gb)
+{
+    const float lo = opac > 0.0f ? __log2f(opac) : -INFINITY; // opac <= 0 (or NaN) can never pass the alpha test
+    ga = make_float4(x, y, lo, 0.5f * kLog2e * ca);
+    gb = make_float2(kLog2e * cb, 0.5f * kLog2e * cc);
+}
+// q and the unclamped alpha of the staged Gaussian at offset (dx, dy) = mean - pixel
+__device__ __forceinline__ float staged_q(const float4 &ga, const float2 &gb, float dx, float dy)
+{
+    return fmaf(dx, fmaf(ga.w, dx, gb.x * dy), gb.y * dy * dy);
+}
+__device__ __forceinline__ float staged_alpha_raw(const float4 &ga, float q)
+{
+    return __builtin_amdgcn_exp2f(ga.z - q);
+}
+
 // ---- wave-level culling -------------------------------------------------------------------------
 // A Gaussian can only pass the reference's `alpha >= 1/255` test (Device.cuh:52-55) at offsets d with
 // sigma(d) = 1/2 d^T Q d <= L = ln(255 * opacity). The staging thread of each Gaussian computes the

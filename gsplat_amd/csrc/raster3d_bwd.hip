@@ -44,8 +44,8 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
     constexpr int BATCH = Cfg::BATCH;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float4 *s_ga     = reinterpret_cast<float4 *>(smem_raw);       // x, y, opac, conic.a
-    float2 *s_gb     = reinterpret_cast<float2 *>(s_ga + BATCH);   // conic.b, conic.c
+    float4 *s_ga     = reinterpret_cast<float4 *>(smem_raw);       // x, y, log2(opac), A   (stage_gaussian)
+    float2 *s_gb     = reinterpret_cast<float2 *>(s_ga + BATCH);   // B, C
     float4 *s_cull   = reinterpret_cast<float4 *>(s_gb + BATCH);   // x, y, half extents of alpha>=1/255
     int32_t *s_id    = reinterpret_cast<int32_t *>(s_cull + BATCH); // flatten id of the row
     int32_t *s_touch = s_id + BATCH;                               // any lane contributed?
@@ -124,8 +124,11 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
                 const float opac = a.opacities[g];
                 const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
                 s_id[s]        = g;
-                s_ga[s]        = make_float4(xy.x, xy.y, opac, ca);
-                s_gb[s]        = make_float2(cb, cc);
+                float4 ga;
+                float2 gb;
+                stage_gaussian(xy.x, xy.y, opac, ca, cb, cc, ga, gb);
+                s_ga[s]        = ga;
+                s_gb[s]        = gb;
                 const float2 he = cull_half_extent(opac, ca, cb, cc);
                 s_cull[s]      = make_float4(xy.x, xy.y, he.x, he.y);
                 const float *c = a.colors + (size_t)g * a.cdim + a.ch_off;
@@ -153,18 +156,16 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
             // every contribution exactly 0 and leaves T / buffer unchanged (1/(1-0) == 1 exactly).
             const float4 ga = s_ga[t];
             const float2 gb = s_gb[t];
-            const float opac = ga.z, ca = ga.w, cb = gb.x, cc = gb.y;
             const float dx = ga.x - px;
             const float dy = ga.y - py;
-            const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
-            const float vis_r = __expf(-sigma);
-            const float alpha_r = fminf(kMaxAlpha, opac * vis_r);
+            const float q  = staged_q(ga, gb, dx, dy);
+            const float ov_r = staged_alpha_raw(ga, q); // opac * exp(-sigma), unclamped
             // lanes outside the image have bin_final = -1 and can never be valid
-            const bool valid = (batch_end - t <= bin_final) && !(sigma < 0.0f) && !(alpha_r < kAlphaThreshold);
+            const bool valid = (batch_end - t <= bin_final) && !(q < 0.0f) && !(fminf(kMaxAlpha, ov_r) < kAlphaThreshold);
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform
 
-            const float alpha = valid ? alpha_r : 0.0f;
-            const float vis   = valid ? vis_r : 0.0f;
+            const float ov    = valid ? ov_r : 0.0f;
+            const float alpha = fminf(kMaxAlpha, ov);
             float loc[(K + 3) / 4 * 4];
             {
                 const float ra  = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
@@ -179,7 +180,6 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
                     buffer[k]    += c * fac;
                 }
                 v_alpha += T_final * ra * va_minus_bg;
-                const float ov       = opac * vis;
                 const bool unclamped = ov <= kMaxAlpha; // alpha-clamp branch: geometry/opacity grads vanish
                 const float v_sigma  = unclamped ? -ov * v_alpha : 0.0f;
                 const float wdx = v_sigma * dx, wdy = v_sigma * dy;
@@ -190,8 +190,9 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
                 loc[CH + 4]     = wdy;
                 loc[CH + 5]     = v_sigma;
                 if constexpr (ABS) {
-                    loc[CH + 6] = fabsf(ca * wdx + cb * wdy);
-                    loc[CH + 7] = fabsf(cb * wdx + cc * wdy);
+                    // |conic . (wdx, wdy)| with conic = (2A, B; B, 2C) / log2(e); the 1/log2(e) is applied at flush
+                    loc[CH + 6] = fabsf(2.0f * ga.w * wdx + gb.x * wdy);
+                    loc[CH + 7] = fabsf(gb.x * wdx + 2.0f * gb.y * wdy);
                 }
 #pragma unroll
                 for (int k = K; k < (K + 3) / 4 * 4; ++k) loc[k] = 0.0f;
@@ -222,7 +223,9 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
         // flush, transposed: element e of the batch's [batch_size][NCOL] gradient block -> (Gaussian s, column c);
         // consecutive lanes -> consecutive floats of one AoS row. Moments become gradients here (linear maps):
         //   v_xy = Q (S_x, S_y), v_conic = (S_xx/2, S_xy, S_yy/2), v_opacity = sum vis*v_alpha = -S_w / opacity
-        // (a touched Gaussian has opacity >= 1/255).
+        // (a touched Gaussian has opacity >= 1/255), with Q = (2A, B; B, 2C) / log2(e) and opacity = exp2(lo) from
+        // the staged form.
+        constexpr float kInvLog2e = 1.0f / kLog2e;
         constexpr int GEO  = 6 + (ABS ? 2 : 0);
         constexpr int NCOL = GEO + CH;
         for (int e = (int)tid; e < batch_size * NCOL; e += (int)blockDim.x) {
@@ -235,14 +238,14 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
                 const float4 ga = s_ga[s];
                 const float2 gb = s_gb[s];
                 const float sx = row[CH + 3], sy = row[CH + 4];
-                val = (c == 0) ? (ga.w * sx + gb.x * sy) : (gb.x * sx + gb.y * sy);
+                val = kInvLog2e * ((c == 0) ? (2.0f * ga.w * sx + gb.x * sy) : (gb.x * sx + 2.0f * gb.y * sy));
             } else if (c < 5) {
                 const float m = row[CH + c - 2];
                 val           = (c == 3) ? m : 0.5f * m;
             } else if (c == 5) {
-                val = -row[CH + 5] * __builtin_amdgcn_rcpf(s_ga[s].z);
+                val = -row[CH + 5] * __builtin_amdgcn_exp2f(-s_ga[s].z);
             } else if (c < GEO) {
-                val = row[CH + c]; // |v_xy| sums (ABS): accumulator slots CH+6, CH+7 <- columns 6, 7
+                val = kInvLog2e * row[CH + c]; // |v_xy| sums (ABS): accumulator slots CH+6, CH+7 <- columns 6, 7
             } else {
                 const int k = c - GEO;
                 if (k >= (int)a.nch) continue;

@@ -13,9 +13,9 @@ template <int CH>
 __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float4 *s_ga   = reinterpret_cast<float4 *>(smem_raw);                 // x, y, opac, conic.a
+    float4 *s_ga   = reinterpret_cast<float4 *>(smem_raw);                 // x, y, log2(opac), A   (stage_gaussian)
     float4 *s_cull = s_ga + kBatch;                                        // x, y, half extents of alpha >= 1/255
-    float2 *s_gb   = reinterpret_cast<float2 *>(s_cull + kBatch);          // conic.b, conic.c
+    float2 *s_gb   = reinterpret_cast<float2 *>(s_cull + kBatch);          // B, C
     float *s_col   = reinterpret_cast<float *>(s_gb + kBatch);             // [kBatch][CH]
 
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
@@ -80,8 +80,11 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 const float2 xy  = reinterpret_cast<const float2 *>(a.means2d)[g];
                 const float opac = a.opacities[g];
                 const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
-                s_ga[s]         = make_float4(xy.x, xy.y, opac, ca);
-                s_gb[s]         = make_float2(cb, cc);
+                float4 ga;
+                float2 gb;
+                stage_gaussian(xy.x, xy.y, opac, ca, cb, cc, ga, gb);
+                s_ga[s]         = ga;
+                s_gb[s]         = gb;
                 const float2 he = cull_half_extent(opac, ca, cb, cc);
                 s_cull[s]       = make_float4(xy.x, xy.y, he.x, he.y);
                 const float *c  = a.colors + (size_t)g * a.cdim + a.ch_off;
@@ -111,12 +114,11 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 todo &= todo - 1;
                 const float4 ga = s_ga[t];
                 const float2 gb = s_gb[t];
-                const float dx  = ga.x - px;
-                const float dy  = ga.y - py;
-                const float sigma = 0.5f * (ga.w * dx * dx + gb.y * dy * dy) + gb.x * dx * dy;
-                const float vis   = __expf(-sigma);
-                const float alpha = fminf(kMaxAlpha, ga.z * vis);
-                if (done || sigma < 0.0f || alpha < kAlphaThreshold) continue;
+                const float dx    = ga.x - px;
+                const float dy    = ga.y - py;
+                const float q     = staged_q(ga, gb, dx, dy);
+                const float alpha = fminf(kMaxAlpha, staged_alpha_raw(ga, q));
+                if (done || q < 0.0f || alpha < kAlphaThreshold) continue;
                 const float next_T = T * (1.0f - alpha);
                 if (next_T <= kTransmittanceThresh) { // saturated: this Gaussian is excluded
                     done = true;
