@@ -148,7 +148,10 @@ def _sh_dims(means, viewmats, coeffs, gaussian_ids):
 
 @_op("spherical_harmonics")
 def spherical_harmonics(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids,
-                        viewmats_rs=None, *, _gathered: bool = True):
+                        viewmats_rs=None, *, _gathered: bool = True, _radii=None, _post: bool = False):
+    """Private keywords (used by rendering.py, not part of the reference schema): `_gathered=False` reads [N,K,D]
+    coefficients through gaussian_ids; `_radii` masks rows by radii > 0 instead of a bool tensor; `_post` fuses the
+    orchestrator's `clamp_min(colors + 0.5, 0)`."""
     if viewmats_rs is not None:
         raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
     _check_f32(means=means, viewmats=viewmats, coeffs=coeffs)
@@ -160,25 +163,26 @@ def spherical_harmonics(degrees_to_use, means, viewmats, coeffs, masks, batch_id
         nnz = gaussian_ids.shape[0]
         colors = torch.empty((nnz, D), device=means.device, dtype=means.dtype)
         call("gsx_sh_fwd", degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), ptr(_c(batch_ids)),
-             ptr(_c(camera_ids)), ptr(_c(gaussian_ids)), B, C, N, nnz, int(_gathered), K, D, ptr(colors))
+             ptr(_c(camera_ids)), ptr(_c(gaussian_ids)), B, C, N, nnz, int(_gathered), K, D, ptr(_c(_radii)),
+             int(_post), ptr(colors))
     else:
         if coeffs.shape[0] != N:
             raise ValueError("means N must match coeffs N in dense mode")
         colors = torch.empty(viewmats.shape[:-2] + (N, D), device=means.device, dtype=means.dtype)
         call("gsx_sh_fwd", degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), None, None, None,
-             B, C, N, -1, 1, K, D, ptr(colors))
+             B, C, N, -1, 1, K, D, ptr(_c(_radii)), int(_post), ptr(colors))
     return colors
 
 
 @_op("spherical_harmonics_bwd")
 def spherical_harmonics_bwd(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids,
                             viewmats_rs, v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs,
-                            *, _gathered: bool = True):
+                            *, _gathered: bool = True, _radii=None, _post_colors=None):
     if viewmats_rs is not None or compute_v_viewmats_rs:
         raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
     packed, B, C, N, K, D = _sh_dims(means, viewmats, coeffs, gaussian_ids)
     means, viewmats, coeffs, masks = means.contiguous(), viewmats.contiguous(), coeffs.contiguous(), _c(masks)
-    v_colors = v_colors.contiguous()
+    v_colors, vc_stride = _row_view(v_colors, D)  # may be a column view of the compositing kernel's gradient rows
     need_zero = packed and not _gathered
     v_coeffs = torch.zeros_like(coeffs) if need_zero else torch.empty_like(coeffs)
     # dense D == 3 kernels store v_means for every (b, g) (sh3_bwd_dense_kernel); the other paths accumulate
@@ -188,7 +192,7 @@ def spherical_harmonics_bwd(degrees_to_use, means, viewmats, coeffs, masks, batc
     nnz = gaussian_ids.shape[0] if packed else -1
     call("gsx_sh_bwd", degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), ptr(_c(batch_ids)),
          ptr(_c(camera_ids)), ptr(_c(gaussian_ids)), B, C, N, nnz, int(_gathered) if packed else 1, K, D,
-         ptr(v_colors), ptr(v_coeffs), ptr(v_means))
+         ptr(_c(_radii)), ptr(_c(_post_colors)), ptr_strided(v_colors), vc_stride, ptr(v_coeffs), ptr(v_means))
     v_viewmats = None
     if compute_v_viewmats:
         # d(dir)/d(viewmat): dir = mean + R^T t. Needs the per-row v_dir; recompute it on the torch

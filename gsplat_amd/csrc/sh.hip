@@ -99,11 +99,30 @@ struct ShArgs {
     uint32_t B, C, N, K, D;
     int64_t nnz; // < 0: dense
     int coeffs_gathered; // packed: 1 = coeffs is [nnz,K,D]; 0 = coeffs is [N,K,D] indexed by gaussian_ids
+    // fused pieces of the rasterization() orchestrator (all optional):
+    const int32_t *radii;       // [rows,2]: alternative to masks, row is live iff both radii > 0 (Rendering.cpp:1146)
+    int post;                   // forward: colors = max(sh + 0.5, 0)  (Rendering.cpp:1160 / rendering.py:714-718)
+    const float *post_colors;   // backward: that forward output; the gradient is cut where it is 0 (clamp_min VJP)
+    uint32_t vc_stride;         // row stride (floats) of v_colors: D when contiguous (AoS gradient rows otherwise)
     float *colors;
     const float *v_colors;
     float *v_coeffs, *v_means;
     int atomic_coeffs; // packed + !gathered + more than one image: rows of one Gaussian collide
 };
+
+__device__ __forceinline__ bool row_dead(const ShArgs &a, int64_t row)
+{
+    if (a.masks && !a.masks[row]) return true;
+    if (a.radii && !(a.radii[2 * row] > 0 && a.radii[2 * row + 1] > 0)) return true;
+    return false;
+}
+__device__ __forceinline__ float post_color(const ShArgs &a, float x) { return a.post ? fmaxf(x + 0.5f, 0.0f) : x; }
+// incoming gradient of channel ch of `row` (through the fused clamp when the forward applied it)
+__device__ __forceinline__ float load_vc(const ShArgs &a, int64_t row, uint32_t ch)
+{
+    const float v = a.v_colors[row * a.vc_stride + ch];
+    return (a.post_colors && !(a.post_colors[row * a.D + ch] > 0.0f)) ? 0.0f : v;
+}
 
 // unnormalised view direction of gaussian (b,g) seen from camera (b,c): mean + R^T t
 __device__ __forceinline__ void view_dir(const ShArgs &a, uint32_t b, uint32_t c, uint32_t g, float *d)
@@ -129,7 +148,7 @@ __global__ void __launch_bounds__(256) sh_fwd_kernel(const ShArgs a)
     if (idx >= rows * a.D) return;
     const int64_t row = idx / a.D;
     const uint32_t ch = (uint32_t)(idx % a.D);
-    if (a.masks && !a.masks[row]) {
+    if (row_dead(a, row)) {
         a.colors[idx] = 0.0f;
         return;
     }
@@ -153,7 +172,7 @@ __global__ void __launch_bounds__(256) sh_fwd_kernel(const ShArgs a)
 #pragma unroll
     for (int k = 0; k < kMaxBases; ++k)
         if (k < nb) acc += Y[k] * co[(size_t)k * a.D];
-    a.colors[idx] = acc;
+    a.colors[idx] = post_color(a, acc);
 }
 
 // dense backward: one thread per (gaussian, channel); loops over all B*C images in registers,
@@ -172,8 +191,8 @@ __global__ void __launch_bounds__(256) sh_bwd_dense_kernel(const ShArgs a)
     for (uint32_t b = 0; b < a.B; ++b)
         for (uint32_t c = 0; c < a.C; ++c) {
             const int64_t row = ((int64_t)b * a.C + c) * a.N + g;
-            if (a.masks && !a.masks[row]) continue;
-            const float vc = a.v_colors[row * a.D + ch];
+            if (row_dead(a, row)) continue;
+            const float vc = load_vc(a, row, ch);
             float d[3];
             view_dir(a, b, c, g, d);
             const float inv = safe_inv_norm(d);
@@ -218,13 +237,13 @@ __global__ void __launch_bounds__(256) sh_bwd_packed_kernel(const ShArgs a)
     const uint32_t b = (uint32_t)a.batch_ids[row], c = (uint32_t)a.camera_ids[row], g = (uint32_t)a.gaussian_ids[row];
     const int64_t crow = a.coeffs_gathered ? row : (int64_t)g;
     float *out         = a.v_coeffs + ((size_t)crow * a.K) * a.D + ch;
-    const bool masked  = a.masks && !a.masks[row];
+    const bool masked  = row_dead(a, row);
     if (masked) {
         if (a.coeffs_gathered)
             for (uint32_t k = 0; k < a.K; ++k) out[(size_t)k * a.D] = 0.0f;
         return;
     }
-    const float vc = a.v_colors[idx];
+    const float vc = load_vc(a, row, ch);
     float d[3];
     view_dir(a, b, c, g, d);
     const float inv = safe_inv_norm(d);
@@ -303,7 +322,7 @@ __global__ void __launch_bounds__(256) sh3_fwd_kernel(const ShArgs a)
     const int64_t row  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
     float *out = a.colors + row * 3;
-    if (a.masks && !a.masks[row]) {
+    if (row_dead(a, row)) {
         out[0] = out[1] = out[2] = 0.0f;
         return;
     }
@@ -325,7 +344,7 @@ __global__ void __launch_bounds__(256) sh3_fwd_kernel(const ShArgs a)
         r1 += Y[k] * co[3 * k + 1];
         r2 += Y[k] * co[3 * k + 2];
     }
-    out[0] = r0; out[1] = r1; out[2] = r2;
+    out[0] = post_color(a, r0); out[1] = post_color(a, r1); out[2] = post_color(a, r2);
 }
 
 // store a v_coeffs row: values for the first NF floats, zeros up to K*3 (only when `fill_tail`)
@@ -410,11 +429,11 @@ __global__ void __launch_bounds__(256) sh3_bwd_packed_kernel(const ShArgs a)
     float vco[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) vco[i] = 0.0f;
-    if (a.masks && !a.masks[row]) {
+    if (row_dead(a, row)) {
         if (a.coeffs_gathered) store_row<NF>(out, vec, vco, a.K * 3, true);
         return;
     }
-    const float vc[3] = {a.v_colors[row * 3], a.v_colors[row * 3 + 1], a.v_colors[row * 3 + 2]};
+    const float vc[3] = {load_vc(a, row, 0), load_vc(a, row, 1), load_vc(a, row, 2)};
     float v_dir[3] = {0.f, 0.f, 0.f};
     sh3_row_vjp<DEG, WANT_MEANS>(a, b, c, g, crow, vc, vec, vco, v_dir);
     if (a.coeffs_gathered) store_row<NF>(out, vec, vco, a.K * 3, true);
@@ -447,8 +466,8 @@ __global__ void __launch_bounds__(256) sh3_bwd_dense_kernel(const ShArgs a)
         float v_dir[3] = {0.f, 0.f, 0.f};
         for (uint32_t c = 0; c < a.C; ++c) {
             const int64_t row = ((int64_t)b * a.C + c) * a.N + g;
-            if (a.masks && !a.masks[row]) continue;
-            const float vc[3] = {a.v_colors[row * 3], a.v_colors[row * 3 + 1], a.v_colors[row * 3 + 2]};
+            if (row_dead(a, row)) continue;
+            const float vc[3] = {load_vc(a, row, 0), load_vc(a, row, 1), load_vc(a, row, 2)};
             sh3_row_vjp<DEG, WANT_MEANS>(a, b, c, g, (int64_t)g, vc, vec, vco, v_dir);
         }
         if constexpr (WANT_MEANS) {
@@ -491,7 +510,8 @@ using namespace gsx;
 extern "C" int gsx_sh_fwd(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
                           const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
                           const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
-                          int coeffs_gathered, uint32_t K, uint32_t D, float *colors, void *stream)
+                          int coeffs_gathered, uint32_t K, uint32_t D, const int32_t *radii, int post, float *colors,
+                          void *stream)
 {
     const int64_t rows = nnz >= 0 ? nnz : (int64_t)B * C * N;
     if (rows == 0) return GSX_OK;
@@ -502,6 +522,7 @@ extern "C" int gsx_sh_fwd(int degrees_to_use, const float *means, const float *v
     a.degree = degrees_to_use; a.means = means; a.viewmats = viewmats; a.coeffs = coeffs; a.masks = masks;
     a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
     a.B = B; a.C = C; a.N = N; a.K = K; a.D = D; a.nnz = nnz; a.coeffs_gathered = coeffs_gathered; a.colors = colors;
+    a.radii = radii; a.post = post;
     hipStream_t s = (hipStream_t)stream;
     if (D == 3) {
         const dim3 grid((uint32_t)ceil_div(rows, 256));
@@ -521,8 +542,9 @@ extern "C" int gsx_sh_fwd(int degrees_to_use, const float *means, const float *v
 extern "C" int gsx_sh_bwd(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
                           const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
                           const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
-                          int coeffs_gathered, uint32_t K, uint32_t D, const float *v_colors, float *v_coeffs,
-                          float *v_means, void *stream)
+                          int coeffs_gathered, uint32_t K, uint32_t D, const int32_t *radii, const float *post_colors,
+                          const float *v_colors, uint32_t v_colors_stride, float *v_coeffs, float *v_means,
+                          void *stream)
 {
     int rc = check_sh("gsx_sh_bwd", degrees_to_use, K, D, means, viewmats, coeffs, nnz, batch_ids, camera_ids, gaussian_ids);
     if (rc != GSX_OK) return rc;
@@ -532,6 +554,7 @@ extern "C" int gsx_sh_bwd(int degrees_to_use, const float *means, const float *v
     a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
     a.B = B; a.C = C; a.N = N; a.K = K; a.D = D; a.nnz = nnz; a.coeffs_gathered = coeffs_gathered;
     a.v_colors = v_colors; a.v_coeffs = v_coeffs; a.v_means = v_means;
+    a.radii = radii; a.post_colors = post_colors; a.vc_stride = v_colors_stride ? v_colors_stride : D;
     a.atomic_coeffs = (B * C) > 1;
     if (D == 3 && (nnz < 0 ? (int64_t)N > 0 : nnz > 0)) {
         GSX_REQUIRE(v_colors || (nnz < 0 && (int64_t)B * C == 0), "gsx_sh_bwd: null v_colors");

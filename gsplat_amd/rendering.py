@@ -305,6 +305,11 @@ def _project_features(features, sh_degree, clamp, means, viewmats, radii, batch_
         if packed:
             return features.reshape(B, N, D)[batch_ids, gaussian_ids]
         return torch.broadcast_to(features[..., None, :, :], batch_dims + (C, N, D))
+    if clamp:
+        # primary colours: SH + the `clamp_min(colors + 0.5, 0)` post-op + the radii > 0 row mask in ONE kernel each
+        # way (the reference runs them as separate torch ops: Rendering.cpp:1146-1160, rendering.py:714-718)
+        return _ShColors.apply(sh_degree, means, viewmats, features, None if packed else radii, batch_ids, camera_ids,
+                               gaussian_ids)
     if packed:
         # Every packed row is visible by construction (projection only emits radii > 0), so no mask; the
         # coefficient rows are read THROUGH gaussian_ids inside the kernel instead of materialising the
@@ -314,8 +319,36 @@ def _project_features(features, sh_degree, clamp, means, viewmats, radii, batch_
     else:
         valid = (radii > 0).all(dim=-1)
         vals = spherical_harmonics(sh_degree, means, viewmats, features, masks=valid)
-    vals = vals + 0.5
-    return torch.clamp_min(vals, 0.0) if clamp else vals
+    return vals + 0.5
+
+
+class _ShColors(torch.autograd.Function):
+    """colors = clamp_min(spherical_harmonics(...) + 0.5, 0) on the rows with radii > 0, fused (C-ABI gsx_sh_{fwd,bwd}
+    with `post` / `post_colors` / `radii`). Dense: rows [..., C, N]; packed: rows [nnz] read through gaussian_ids.
+    Same values and gradients as the unfused chain (the clamp VJP passes the gradient where the output is > 0)."""
+
+    @staticmethod
+    def forward(ctx, degree, means, viewmats, coeffs, radii, batch_ids, camera_ids, gaussian_ids):
+        from ._ops import impl
+
+        means, viewmats, coeffs = means.contiguous(), viewmats.contiguous(), coeffs.contiguous()
+        colors = impl("spherical_harmonics")(degree, means, viewmats, coeffs, None, batch_ids, camera_ids, gaussian_ids,
+                                             None, _gathered=False, _radii=radii, _post=True)
+        ctx.degree = degree
+        ctx.save_for_backward(means, viewmats, coeffs, radii, batch_ids, camera_ids, gaussian_ids, colors)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        from ._ops import impl
+
+        means, viewmats, coeffs, radii, batch_ids, camera_ids, gaussian_ids, colors = ctx.saved_tensors
+        if ctx.needs_input_grad[2]:
+            raise NotImplementedError("gsplat_amd: SH gradient w.r.t. viewmats is not implemented")
+        v_coeffs, v_means, _, _ = impl("spherical_harmonics_bwd")(
+            ctx.degree, means, viewmats, coeffs, None, batch_ids, camera_ids, gaussian_ids, None, v_colors,
+            ctx.needs_input_grad[1], False, False, _gathered=False, _radii=radii, _post_colors=colors)
+        return None, v_means, None, v_coeffs, None, None, None, None
 
 
 class _ShUngathered(torch.autograd.Function):

@@ -142,12 +142,18 @@ int gsx_project_ewa_packed_bwd(const float *means, const float *covars, const fl
 int gsx_sh_fwd(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
                const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
                const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz /* <0: dense */,
-               int coeffs_gathered, uint32_t K, uint32_t D, float *colors, void *stream);
+               int coeffs_gathered, uint32_t K, uint32_t D,
+               const int32_t *radii /* NULL, or [rows,2]: like masks, a row is live iff both radii > 0 */,
+               int post /* 1: colors = max(sh + 0.5, 0), the rasterization() post-op (Rendering.cpp:1160) */,
+               float *colors, void *stream);
 int gsx_sh_bwd(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
                const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
                const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
-               int coeffs_gathered, uint32_t K, uint32_t D, const float *v_colors, float *v_coeffs,
-               float *v_means, void *stream);
+               int coeffs_gathered, uint32_t K, uint32_t D,
+               const int32_t *radii /* as in gsx_sh_fwd */,
+               const float *post_colors /* NULL, or the forward output computed with post=1: cuts the gradient where 0 */,
+               const float *v_colors, uint32_t v_colors_stride /* floats per row; 0 = D (contiguous) */,
+               float *v_coeffs, float *v_means, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * isect_tiles: gsplat::intersect_tile (ext.cpp:1022-1026; host Intersect.cpp:170-329; kernel

@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""torch.profiler table of one bench step (which torch op launches which glue kernel). Run on the GPU box."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench, gsplat_amd
+from torch.profiler import profile, ProfilerActivity
+
+dev = torch.device("cuda", 0)
+sc, W, H = bench.make_workload(1_000_000, dev)
+names = ("means", "quats", "scales", "opacities", "colors")
+leaves = {k: sc[k].clone().requires_grad_(True) for k in names}
+packed = len(sys.argv) > 1 and sys.argv[1] == "packed"
+
+def step():
+    for t in leaves.values():
+        t.grad = None
+    rc, ra, meta = gsplat_amd.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
+                                            leaves["colors"], sc["viewmats"], sc["Ks"], W, H, sh_degree=3, packed=packed)
+    rc.sum().backward()
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=60, max_name_column_width=70))
+ev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU and e.cpu_parent is None]
+print("top-level CPU ops per step, self cpu us:")
+import collections
+agg = collections.Counter(); cnt = collections.Counter()
+for e in ev:
+    agg[e.name] += e.cpu_time_total; cnt[e.name] += 1
+for k, v in agg.most_common(40):
+    print(f"{k[:70]:70s} n={cnt[k]/3:5.1f} cpu_us/step={v/3:8.1f}")
