@@ -7,9 +7,13 @@ already resident in HBM. Rank 0 prints ONE JSON line.
 
 Workload at N=1 = BASELINE.json configs[2] ("c3"): 1 M synthetic Gaussians, one 1920x1080 pinhole camera,
 SH degree 3, 16x16 tiles, fwd+bwd, loss = render_colors.sum() (reference harness profiling/main.py:132-149).
-Workload at N>1 = configs[3] ("c4") shape: Gaussian-sharded distributed rasterization, 500 k Gaussians and
-4 cameras PER RANK (weak scaling: per-GPU projection work fixed; every rank composites its own 4 cameras over
-all N*500k Gaussians), all-gather cameras + all-to-all projected Gaussians (gsplat_amd/distributed.py).
+Workload at N>1 = the SAME c3 scene, Gaussian-sharded the way the reference trains multi-GPU (stride shard
+[rank::N] of the 1 M Gaussians, examples/simple_trainer.py:326-328) with ONE 1080p camera per rank: every rank
+projects its 1M/N Gaussians against all N cameras (1 M (camera, Gaussian) pairs, as at N=1), the rows travel to
+the rank that owns the camera (all-gather cameras + all-to-all, gsplat_amd/distributed.py), and every rank
+composites its own camera over the whole 1 M-Gaussian scene (as at N=1). Per-GPU work is therefore fixed and the
+job renders N images per step: weak scaling, ideal throughput = N x the N=1 value. The configs[3] ("c4") shape
+is `--gaussians 500000 --cameras 4` under an 8-rank launch (4 M Gaussians, 4 cameras per rank).
 
 metric = Mpixels/s fwd+bwd = (images * H * W * steps) / wall time, whole job.
 roofline  = dominant kernel (the compositing backward) priced against HBM: algorithmic bytes per launch
@@ -37,8 +41,9 @@ FP32_PEAK_TFLOPS = 157.3
 def make_workload(n_gaussians: int, device, n_cameras: int = 1, seed: int = 0, rank: int = 0, world: int = 1):
     """means uniform in a frustum-filling box z in [1, 20]; log-scales ~ N(log 0.01, 0.5)
     (clipped); opacities U(0.05, 0.95); SH degree-3 coefficients N(0, 0.3) (+0.5 DC); cameras 1920x1080, f=1200.
-    With world > 1 every rank draws its own shard (seed + rank) of the same distribution."""
-    g = torch.Generator().manual_seed(seed + 7919 * rank)
+    `n_gaussians` is the size of the WHOLE scene (same seed on every rank); with world > 1 this rank keeps the stride
+    shard [rank::world] and gets its own `n_cameras` cameras (small yaw / shift per camera so that views differ)."""
+    g = torch.Generator().manual_seed(seed)
     fx = 1200.0
     z = torch.rand(n_gaussians, generator=g) * 19.0 + 1.0
     x = (torch.rand(n_gaussians, generator=g) - 0.5) * (WIDTH / fx) * z * 1.05
@@ -58,6 +63,8 @@ def make_workload(n_gaussians: int, device, n_cameras: int = 1, seed: int = 0, r
         viewmats[c, 2, 0] = -math.sin(ang); viewmats[c, 2, 2] = math.cos(ang)
         viewmats[c, 0, 3] = 0.05 * (c + n_cameras * rank)
     Ks = torch.tensor([[fx, 0, WIDTH / 2], [0, fx, HEIGHT / 2], [0, 0, 1.0]]).repeat(n_cameras, 1, 1)
+    if world > 1:
+        means, quats, scales, opacities, colors = (t[rank::world] for t in (means, quats, scales, opacities, colors))
     sc = dict(means=means, quats=quats, scales=scales, opacities=opacities, colors=colors, viewmats=viewmats, Ks=Ks)
     return {k: v.to(device).contiguous() for k, v in sc.items()}, WIDTH, HEIGHT
 
@@ -74,13 +81,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--gaussians", type=int, default=None, help="Gaussians per rank (default 1M at N=1, 500k at N>1)")
-    ap.add_argument("--cameras", type=int, default=None, help="cameras per rank (default 1 at N=1, 4 at N>1)")
+    ap.add_argument("--gaussians", type=int, default=None, help="Gaussians per rank (default: 1M / N, i.e. the c3 scene)")
+    ap.add_argument("--cameras", type=int, default=None, help="cameras per rank (default 1)")
     ap.add_argument("--packed", action="store_true",
                     help="time packed=True as the headline (default: packed=False, the faster layout when nearly every "
                          "Gaussian is visible, as in c3; the other layout is timed too and reported in 'other_layout')")
     ap.add_argument("--dense", action="store_true", help=argparse.SUPPRESS)  # old flag, now the default
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the distributed=True code path in a 1-rank RCCL group (measures the seams' overhead)")
     ap.add_argument("--lean", action="store_true",
                     help="only warmup + timed steps (no stage table, no other-layout leg, no CPU baseline): for rocprofv3 runs")
     args = ap.parse_args()
@@ -88,7 +97,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_distributed
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -96,20 +105,27 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:  # --force-distributed without a launcher
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
-    n_gpus = world if distributed else 1
+    n_gpus = world
     assert args.gpus == n_gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import gsplat_amd
     from gsplat_amd import _cabi
 
-    n_local = args.gaussians or (500_000 if distributed else 1_000_000)
-    n_cams = args.cameras or (4 if distributed else 1)
-    sc, W, H = make_workload(n_local, device, n_cameras=n_cams, rank=rank, world=world)
+    n_total = args.gaussians * world if args.gaussians else 1_000_000
+    n_cams = args.cameras or 1
+    sc, W, H = make_workload(n_total, device, n_cameras=n_cams, rank=rank, world=world)
+    n_local = sc["means"].shape[0]
     names = ("means", "quats", "scales", "opacities", "colors")
     leaves = {k: sc[k].clone().requires_grad_(True) for k in names}
-    # N>1 keeps the packed layout: only visible (camera, Gaussian) rows cross the all-to-all
-    packed = bool(args.packed) or (distributed and not args.dense)
+    # dense rows by default, also at N>1: nearly every (camera, Gaussian) pair is visible in this scene, and dense
+    # rows need no id columns in the all-to-all (48 B/row instead of 64 B/visible row) and no compaction pass
+    packed = bool(args.packed)
 
     def step(packed=packed):
         for t in leaves.values():
@@ -127,15 +143,31 @@ def main():
 
     for _ in range(args.warmup):
         meta = step()
+    # Python's cyclic GC: a generation-2 sweep walks every tracked object (~170 k once torch.distributed is imported:
+    # 40-60 ms measured on the MI355X box) and lands in the middle of a step every few dozen steps. Collect once and
+    # move the survivors to the permanent generation, as a long-running trainer would; later sweeps only see objects
+    # created by the steps themselves.
+    import gc
+
+    gc.collect()
+    gc.freeze()
     barrier()
     # HIP events (on the launch stream) around the two compositing launches only: the dominant kernels are timed live
     # inside the timed region without the bookkeeping of ~40 event pairs per step perturbing it.
     _cabi.profile_begin(only=("gsx_raster3d_fwd", "gsx_raster3d_bwd"))
     t0 = time.perf_counter()
+    per_step = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         meta = step()
+        per_step.append(time.perf_counter() - ts)
+    t_enq = time.perf_counter() - t0
+    if os.environ.get("GSPLAT_BENCH_DEBUG"):
+        print("[bench] per-step enqueue ms:", " ".join(f"{x * 1e3:.2f}" for x in per_step), file=sys.stderr)
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("GSPLAT_BENCH_DEBUG"):
+        print(f"[bench rank {rank}] enqueue {t_enq * 1e3:.2f} ms, enqueue+barrier {elapsed * 1e3:.2f} ms", file=sys.stderr)
     prof = _cabi.profile_end()
     # per-stage table: a few extra (untimed) steps with an event pair around every C-ABI call
     n_stage = 0 if args.lean else min(5, args.steps)
@@ -167,7 +199,8 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0's launches) -------------------------------------
     M = int(meta["isect_ids"].numel())
-    V = int((meta["radii"] > 0).all(-1).sum().item()) if not distributed else M  # rows entering compositing
+    # rows entering compositing on this rank (distributed: the rows received for this rank's cameras)
+    V = int((meta["radii"] > 0).all(-1).sum().item()) if not distributed else int(torch.unique(meta["flatten_ids"]).numel())
     P_local = n_cams * W * H
     T_local = n_cams * math.ceil(W / TILE) * math.ceil(H / TILE)
     D = 3
@@ -194,15 +227,15 @@ def main():
     }
 
     result = {
-        "metric": "Mpixels/s fwd+bwd @1M Gaussians/1080p" if not distributed else
-                  "Mpixels/s fwd+bwd, Gaussian-sharded 500k Gaussians + 4x1080p cameras per GPU",
+        "metric": "Mpixels/s fwd+bwd @1M Gaussians/1080p",
         "value": round(mpix_s, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("c3: 1M synthetic Gaussians, 1x1920x1080, SH deg 3, 16x16 tiles, fwd+bwd"
                                 if not distributed else
-                                f"c4-shape: {n_local} Gaussians + {n_cams}x1920x1080 cameras per rank, SH deg 3, "
-                                "distributed=True (all-gather cameras + all-to-all projected Gaussians)"),
+                                f"c3 scene ({n_total} Gaussians) stride-sharded over {n_gpus} ranks ({n_local} per rank), "
+                                f"{n_cams}x1920x1080 camera(s) per rank ({n_cams * n_gpus} images per step), SH deg 3, 16x16 "
+                                "tiles, fwd+bwd, distributed=True (all-gather cameras + all-to-all projected rows)"),
                    "gaussians_per_gpu": n_local, "cameras_per_gpu": n_cams, "packed": packed,
                    "parallelism": f"gaussian-sharded x{n_gpus}" if distributed else "single"},
         "roofline": roofline,

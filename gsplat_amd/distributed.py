@@ -114,6 +114,48 @@ def _all_to_all_rows(data: Tensor, in_splits: List[int], out_splits: List[int]) 
 
 
 # ----------------------------------------------------------------------------------------------
+# control plane: per-call exchange of (Gaussians, cameras) per rank
+# ----------------------------------------------------------------------------------------------
+_meta_group_cache = {}
+
+
+def _meta_group():
+    """A CPU (gloo) process group for the two integers every rank publishes per call. The reference gathers them on
+    the device and reads them back (DistributedCollectives.cpp:299-317), which makes the host wait for ALL queued GPU
+    work at the top of every rasterization() call; over gloo the host never touches the stream, so the previous
+    step's backward keeps the GPU busy while the next forward is being enqueued. Created collectively on first use
+    (every rank enters rasterization(distributed=True) together); None if gloo is unavailable."""
+    key = id(dist.group.WORLD)
+    if key not in _meta_group_cache:
+        grp = None
+        if dist.get_backend() == "gloo":
+            grp = dist.group.WORLD
+        else:
+            try:
+                grp = dist.new_group(backend="gloo")
+            except Exception:  # no usable network interface for gloo: fall back to the device collective
+                grp = None
+        _meta_group_cache[key] = grp
+    return _meta_group_cache[key]
+
+
+def _gather_counts(W: int, n_local: int, n_cameras: int, device) -> List[List[int]]:
+    """[[N_i, C_i] for every rank i]."""
+    if W == 1:
+        return [[int(n_local), int(n_cameras)]]
+    grp = _meta_group()
+    if grp is not None:
+        mine = torch.tensor([n_local, n_cameras], dtype=torch.int64)
+        out = [torch.empty(2, dtype=torch.int64) for _ in range(W)]
+        dist.all_gather(out, mine, group=grp)
+        return [t.tolist() for t in out]
+    counts = torch.tensor([n_local, n_cameras], dtype=torch.int32, device=device)
+    gathered = torch.empty((W, 2), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(gathered, counts.reshape(1, 2))
+    return gathered.tolist()
+
+
+# ----------------------------------------------------------------------------------------------
 # the two seams of rasterization(distributed=True)
 # ----------------------------------------------------------------------------------------------
 @dataclass
@@ -153,10 +195,7 @@ class DistributedRasterContext:
         W, r = dist.get_world_size(), dist.get_rank()
         if n_local is None:
             raise ValueError("n_local is required")
-        counts = torch.tensor([n_local, n_cameras], dtype=torch.int32, device=device)
-        gathered = torch.empty((W, 2), dtype=torch.int32, device=device)
-        dist.all_gather_into_tensor(gathered, counts.reshape(1, 2))
-        gathered = gathered.tolist()
+        gathered = _gather_counts(W, n_local, n_cameras, device)
         cams = [g[1] for g in gathered]
         if any(c != cams[0] for c in cams):
             raise ValueError(f"distributed=True requires the same number of cameras on every rank, got {cams}")
@@ -180,6 +219,10 @@ class DistributedRasterContext:
                    image_ids = camera id local to this rank and gaussian_ids made global.
         Returns (radii, means2d, depths, conics, opacities, feats, image_ids, gaussian_ids)."""
         W, Cl = self.world_size, self.c_local
+        if W == 1:  # a single rank owns every camera and every Gaussian: nothing moves
+            if not packed:
+                return radii, means2d, depths, conics, opacities.contiguous(), feats, None, None
+            return radii, means2d, depths, conics, opacities, feats, camera_ids, gaussian_ids
         floats = [means2d, depths[..., None], conics, opacities[..., None]]
         if feats is not None:
             floats.append(feats)
@@ -194,9 +237,13 @@ class DistributedRasterContext:
                 out_s = [Cl * n for n in self.n_per_rank]
                 recv_f = _all_to_all_rows(payload.reshape(W * Cl * Nl, -1), in_s, out_s)
                 recv_r = _all_to_all_rows(radii.reshape(W * Cl * Nl, 2), in_s, out_s)
-                # source rank i contributed [C_local, N_i, F]; concatenate along the Gaussian axis
-                out_f = torch.cat([p.reshape(Cl, n, -1) for p, n in zip(recv_f.split(out_s), self.n_per_rank)], dim=1)
-                out_r = torch.cat([p.reshape(Cl, n, 2) for p, n in zip(recv_r.split(out_s), self.n_per_rank)], dim=1)
+                # source rank i contributed [C_local, N_i, F]; concatenate along the Gaussian axis (with one camera
+                # per rank the received buffer already IS [1, sum N_i, F])
+                if Cl == 1:
+                    out_f, out_r = recv_f.reshape(1, -1, recv_f.shape[-1]), recv_r.reshape(1, -1, 2)
+                else:
+                    out_f = torch.cat([p.reshape(Cl, n, -1) for p, n in zip(recv_f.split(out_s), self.n_per_rank)], dim=1)
+                    out_r = torch.cat([p.reshape(Cl, n, 2) for p, n in zip(recv_r.split(out_s), self.n_per_rank)], dim=1)
             pieces = out_f.split(widths, dim=-1)
             m2, dp, cn, op = pieces[0], pieces[1][..., 0], pieces[2], pieces[3][..., 0]
             ft = pieces[4] if feats is not None else None

@@ -12,7 +12,6 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 WORLD = 2
-C_LOCAL = 2
 N_PER_RANK = [5, 7]
 D = 3
 
@@ -31,7 +30,7 @@ def _row(cam, gid, width):
     return base + 0.01 * torch.arange(width, dtype=torch.float32)
 
 
-def _worker(rank, port, results):
+def _worker(rank, port, results, C_LOCAL):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
@@ -139,11 +138,12 @@ def _worker(rank, port, results):
         dist.destroy_process_group()
 
 
-def test_distributed_seams_world_size_2_gloo():
+@pytest.mark.parametrize("c_local", [2, 1])  # 1 = the bench configuration (received buffer used without a concat)
+def test_distributed_seams_world_size_2_gloo(c_local):
     mgr = mp.Manager()
     results = mgr.dict()
     port = _free_port()
-    ctx = mp.spawn(_worker, args=(port, results), nprocs=WORLD, join=False)
+    ctx = mp.spawn(_worker, args=(port, results, c_local), nprocs=WORLD, join=False)
     ok = ctx.join(timeout=240)
     while not ok:
         ok = ctx.join(timeout=240)

@@ -10,13 +10,21 @@ dev = torch.device("cuda", 0)
 sc, W, H = bench.make_workload(1_000_000, dev)
 names = ("means", "quats", "scales", "opacities", "colors")
 leaves = {k: sc[k].clone().requires_grad_(True) for k in names}
-packed = len(sys.argv) > 1 and sys.argv[1] == "packed"
+packed = "packed" in sys.argv[1:]
+distributed = "dist" in sys.argv[1:]
+if distributed:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29512")
+    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", device_id=dev)
 
 def step():
     for t in leaves.values():
         t.grad = None
     rc, ra, meta = gsplat_amd.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
-                                            leaves["colors"], sc["viewmats"], sc["Ks"], W, H, sh_degree=3, packed=packed)
+                                            leaves["colors"], sc["viewmats"], sc["Ks"], W, H, sh_degree=3, packed=packed,
+                                            distributed=distributed)
     rc.sum().backward()
 
 for _ in range(3):
