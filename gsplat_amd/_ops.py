@@ -190,25 +190,30 @@ def spherical_harmonics_bwd(degrees_to_use, means, viewmats, coeffs, masks, batc
     if compute_v_means:
         v_means = torch.empty_like(means) if (not packed and D == 3 and N > 0) else torch.zeros_like(means)
     nnz = gaussian_ids.shape[0] if packed else -1
+    # pose gradient: the kernel also returns d(loss)/d(view direction) per row; dir = mean + R^T t, so
+    # v_R = t (x) sum_rows v_dir and v_t = R sum_rows v_dir per camera (small host-side tensors)
+    v_dirs = None
+    if compute_v_viewmats:
+        n_rows = nnz if packed else B * C * N
+        v_dirs = torch.zeros((n_rows, 3), device=means.device, dtype=means.dtype)
     call("gsx_sh_bwd", degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), ptr(_c(batch_ids)),
          ptr(_c(camera_ids)), ptr(_c(gaussian_ids)), B, C, N, nnz, int(_gathered) if packed else 1, K, D,
-         ptr(_c(_radii)), ptr(_c(_post_colors)), ptr_strided(v_colors), vc_stride, ptr(v_coeffs), ptr(v_means))
+         ptr(_c(_radii)), ptr(_c(_post_colors)), ptr_strided(v_colors), vc_stride, ptr(v_coeffs), ptr(v_means),
+         ptr(v_dirs))
     v_viewmats = None
     if compute_v_viewmats:
-        # d(dir)/d(viewmat): dir = mean + R^T t. Needs the per-row v_dir; recompute it on the torch
-        # side (pose optimisation is rare; this keeps the kernel free of a second reduction).
-        v_viewmats = _sh_viewmat_grad(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids,
-                                      gaussian_ids, v_colors, _gathered)
+        if packed:
+            S = torch.zeros((B * C, 3), device=means.device, dtype=means.dtype)
+            S.index_add_(0, batch_ids * C + camera_ids, v_dirs)
+        else:
+            S = v_dirs.view(B * C, N, 3).sum(dim=1)
+        vm = viewmats.reshape(B * C, 4, 4)
+        R, t = vm[:, :3, :3], vm[:, :3, 3]
+        v_vm = torch.zeros_like(vm)
+        v_vm[:, :3, :3] = t[:, :, None] * S[:, None, :]
+        v_vm[:, :3, 3] = torch.einsum("cij,cj->ci", R, S)
+        v_viewmats = v_vm.reshape(viewmats.shape)
     return v_coeffs, v_means, v_viewmats, None
-
-
-def _sh_viewmat_grad(degree, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, v_colors, gathered):
-    """v_viewmats of SH via autograd over a torch restatement of the direction only (small tensors
-    [B,C,4,4]); the heavy per-row v_dir comes from a second kernel pass with compute_v_means on a
-    per-camera copy of the means."""
-    raise NotImplementedError(
-        "gsplat_amd: SH gradient w.r.t. viewmats is not implemented yet (SURVEY.md section 8(f) rank 2)"
-    )
 
 
 # ----------------------------------------------------------------------------------------------

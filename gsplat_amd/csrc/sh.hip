@@ -107,6 +107,7 @@ struct ShArgs {
     float *colors;
     const float *v_colors;
     float *v_coeffs, *v_means;
+    float *v_dirs; // optional [rows,3], zero-initialised: per-row d(loss)/d(view direction) (-> v_viewmats on the host)
     int atomic_coeffs; // packed + !gathered + more than one image: rows of one Gaussian collide
 };
 
@@ -122,6 +123,19 @@ __device__ __forceinline__ float load_vc(const ShArgs &a, int64_t row, uint32_t 
 {
     const float v = a.v_colors[row * a.vc_stride + ch];
     return (a.post_colors && !(a.post_colors[row * a.D + ch] > 0.0f)) ? 0.0f : v;
+}
+
+// generic kernels: accumulate one (row, channel) contribution to d(loss)/d(dir) into v_means[b,g] and / or v_dirs[row]
+__device__ __forceinline__ void add_v_dir(const ShArgs &a, int64_t row, uint32_t b, uint32_t g, float vx, float vy, float vz)
+{
+    if (a.v_means) {
+        float *vm = a.v_means + ((size_t)b * a.N + g) * 3;
+        atomic_add_f32(vm + 0, vx); atomic_add_f32(vm + 1, vy); atomic_add_f32(vm + 2, vz);
+    }
+    if (a.v_dirs) {
+        float *vd = a.v_dirs + row * 3;
+        atomic_add_f32(vd + 0, vx); atomic_add_f32(vd + 1, vy); atomic_add_f32(vd + 2, vz);
+    }
 }
 
 // unnormalised view direction of gaussian (b,g) seen from camera (b,c): mean + R^T t
@@ -197,7 +211,7 @@ __global__ void __launch_bounds__(256) sh_bwd_dense_kernel(const ShArgs a)
             view_dir(a, b, c, g, d);
             const float inv = safe_inv_norm(d);
             const float x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
-            if (a.v_means) {
+            if (a.v_means || a.v_dirs) {
                 float Y[kMaxBases], Yx[kMaxBases], Yy[kMaxBases], Yz[kMaxBases];
                 sh_bases<true>(a.degree, x, y, z, Y, Yx, Yy, Yz);
                 float gx = 0.f, gy = 0.f, gz = 0.f;
@@ -210,10 +224,7 @@ __global__ void __launch_bounds__(256) sh_bwd_dense_kernel(const ShArgs a)
                     }
                 // through the normalisation: v_d = (g - (g.n) n) / |d|
                 const float dot = gx * x + gy * y + gz * z;
-                float *vm       = a.v_means + ((size_t)b * a.N + g) * 3;
-                atomic_add_f32(vm + 0, (gx - dot * x) * inv);
-                atomic_add_f32(vm + 1, (gy - dot * y) * inv);
-                atomic_add_f32(vm + 2, (gz - dot * z) * inv);
+                add_v_dir(a, row, b, g, (gx - dot * x) * inv, (gy - dot * y) * inv, (gz - dot * z) * inv);
             } else {
                 float Y[kMaxBases];
                 sh_bases<false>(a.degree, x, y, z, Y, nullptr, nullptr, nullptr);
@@ -249,7 +260,8 @@ __global__ void __launch_bounds__(256) sh_bwd_packed_kernel(const ShArgs a)
     const float inv = safe_inv_norm(d);
     const float x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
     float Y[kMaxBases], Yx[kMaxBases], Yy[kMaxBases], Yz[kMaxBases];
-    if (a.v_means) sh_bases<true>(a.degree, x, y, z, Y, Yx, Yy, Yz);
+    const bool want_dir = a.v_means || a.v_dirs;
+    if (want_dir) sh_bases<true>(a.degree, x, y, z, Y, Yx, Yy, Yz);
     else sh_bases<false>(a.degree, x, y, z, Y, nullptr, nullptr, nullptr);
     if (a.coeffs_gathered) {
         for (uint32_t k = 0; k < a.K; ++k) out[(size_t)k * a.D] = ((int)k < nb) ? Y[k < kMaxBases ? k : 0] * vc : 0.0f;
@@ -262,7 +274,7 @@ __global__ void __launch_bounds__(256) sh_bwd_packed_kernel(const ShArgs a)
                 else out[(size_t)k * a.D] = Y[k] * vc;
             }
     }
-    if (a.v_means) {
+    if (want_dir) {
         const float *co = a.coeffs + ((size_t)crow * a.K) * a.D + ch;
         float gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll
@@ -272,10 +284,7 @@ __global__ void __launch_bounds__(256) sh_bwd_packed_kernel(const ShArgs a)
                 gx += Yx[k] * w; gy += Yy[k] * w; gz += Yz[k] * w;
             }
         const float dot = gx * x + gy * y + gz * z;
-        float *vm       = a.v_means + ((size_t)b * a.N + g) * 3;
-        atomic_add_f32(vm + 0, (gx - dot * x) * inv);
-        atomic_add_f32(vm + 1, (gy - dot * y) * inv);
-        atomic_add_f32(vm + 2, (gz - dot * z) * inv);
+        add_v_dir(a, row, b, g, (gx - dot * x) * inv, (gy - dot * y) * inv, (gz - dot * z) * inv);
     }
 }
 
@@ -443,10 +452,16 @@ __global__ void __launch_bounds__(256) sh3_bwd_packed_kernel(const ShArgs a)
         for (int i = 0; i < NF; ++i) atomic_add_f32(out + i, vco[i]);
     }
     if constexpr (WANT_MEANS) {
-        float *vm = a.v_means + ((size_t)b * a.N + g) * 3;
-        atomic_add_f32(vm + 0, v_dir[0]);
-        atomic_add_f32(vm + 1, v_dir[1]);
-        atomic_add_f32(vm + 2, v_dir[2]);
+        if (a.v_means) {
+            float *vm = a.v_means + ((size_t)b * a.N + g) * 3;
+            atomic_add_f32(vm + 0, v_dir[0]);
+            atomic_add_f32(vm + 1, v_dir[1]);
+            atomic_add_f32(vm + 2, v_dir[2]);
+        }
+        if (a.v_dirs) {
+            float *vd = a.v_dirs + row * 3;
+            vd[0] = v_dir[0]; vd[1] = v_dir[1]; vd[2] = v_dir[2];
+        }
     }
 }
 
@@ -468,11 +483,21 @@ __global__ void __launch_bounds__(256) sh3_bwd_dense_kernel(const ShArgs a)
             const int64_t row = ((int64_t)b * a.C + c) * a.N + g;
             if (row_dead(a, row)) continue;
             const float vc[3] = {load_vc(a, row, 0), load_vc(a, row, 1), load_vc(a, row, 2)};
-            sh3_row_vjp<DEG, WANT_MEANS>(a, b, c, g, (int64_t)g, vc, vec, vco, v_dir);
+            float vd[3] = {0.f, 0.f, 0.f};
+            sh3_row_vjp<DEG, WANT_MEANS>(a, b, c, g, (int64_t)g, vc, vec, vco, vd);
+            v_dir[0] += vd[0]; v_dir[1] += vd[1]; v_dir[2] += vd[2];
+            if constexpr (WANT_MEANS) {
+                if (a.v_dirs) {
+                    float *o = a.v_dirs + row * 3;
+                    o[0] = vd[0]; o[1] = vd[1]; o[2] = vd[2];
+                }
+            }
         }
         if constexpr (WANT_MEANS) {
-            float *vm = a.v_means + ((size_t)b * a.N + g) * 3; // [B,N,3]: one thread per (b, g) -> plain store
-            vm[0] = v_dir[0]; vm[1] = v_dir[1]; vm[2] = v_dir[2];
+            if (a.v_means) {
+                float *vm = a.v_means + ((size_t)b * a.N + g) * 3; // [B,N,3]: one thread per (b, g) -> plain store
+                vm[0] = v_dir[0]; vm[1] = v_dir[1]; vm[2] = v_dir[2];
+            }
         }
     }
     store_row<NF>(a.v_coeffs + (size_t)g * a.K * 3, vec, vco, a.K * 3, true);
@@ -483,11 +508,11 @@ static void launch_sh3_bwd(const ShArgs &a, hipStream_t s)
 {
     if (a.nnz < 0) {
         const dim3 grid((uint32_t)ceil_div((int64_t)a.N, 256));
-        if (a.v_means) sh3_bwd_dense_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
+        if (a.v_means || a.v_dirs) sh3_bwd_dense_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
         else sh3_bwd_dense_kernel<DEG, false><<<grid, dim3(256), 0, s>>>(a);
     } else {
         const dim3 grid((uint32_t)ceil_div(a.nnz, 256));
-        if (a.v_means) sh3_bwd_packed_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
+        if (a.v_means || a.v_dirs) sh3_bwd_packed_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
         else sh3_bwd_packed_kernel<DEG, false><<<grid, dim3(256), 0, s>>>(a);
     }
 }
@@ -544,7 +569,7 @@ extern "C" int gsx_sh_bwd(int degrees_to_use, const float *means, const float *v
                           const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
                           int coeffs_gathered, uint32_t K, uint32_t D, const int32_t *radii, const float *post_colors,
                           const float *v_colors, uint32_t v_colors_stride, float *v_coeffs, float *v_means,
-                          void *stream)
+                          float *v_dirs, void *stream)
 {
     int rc = check_sh("gsx_sh_bwd", degrees_to_use, K, D, means, viewmats, coeffs, nnz, batch_ids, camera_ids, gaussian_ids);
     if (rc != GSX_OK) return rc;
@@ -553,7 +578,7 @@ extern "C" int gsx_sh_bwd(int degrees_to_use, const float *means, const float *v
     a.degree = degrees_to_use; a.means = means; a.viewmats = viewmats; a.coeffs = coeffs; a.masks = masks;
     a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
     a.B = B; a.C = C; a.N = N; a.K = K; a.D = D; a.nnz = nnz; a.coeffs_gathered = coeffs_gathered;
-    a.v_colors = v_colors; a.v_coeffs = v_coeffs; a.v_means = v_means;
+    a.v_colors = v_colors; a.v_coeffs = v_coeffs; a.v_means = v_means; a.v_dirs = v_dirs;
     a.radii = radii; a.post_colors = post_colors; a.vc_stride = v_colors_stride ? v_colors_stride : D;
     a.atomic_coeffs = (B * C) > 1;
     if (D == 3 && (nnz < 0 ? (int64_t)N > 0 : nnz > 0)) {

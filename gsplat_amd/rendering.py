@@ -343,12 +343,11 @@ class _ShColors(torch.autograd.Function):
         from ._ops import impl
 
         means, viewmats, coeffs, radii, batch_ids, camera_ids, gaussian_ids, colors = ctx.saved_tensors
-        if ctx.needs_input_grad[2]:
-            raise NotImplementedError("gsplat_amd: SH gradient w.r.t. viewmats is not implemented")
-        v_coeffs, v_means, _, _ = impl("spherical_harmonics_bwd")(
+        v_coeffs, v_means, v_viewmats, _ = impl("spherical_harmonics_bwd")(
             ctx.degree, means, viewmats, coeffs, None, batch_ids, camera_ids, gaussian_ids, None, v_colors,
-            ctx.needs_input_grad[1], False, False, _gathered=False, _radii=radii, _post_colors=colors)
-        return None, v_means, None, v_coeffs, None, None, None, None
+            ctx.needs_input_grad[1], ctx.needs_input_grad[2], False, _gathered=False, _radii=radii,
+            _post_colors=colors)
+        return None, v_means, v_viewmats, v_coeffs, None, None, None, None
 
 
 class _ShUngathered(torch.autograd.Function):
@@ -371,12 +370,10 @@ class _ShUngathered(torch.autograd.Function):
         from ._ops import impl
 
         means, viewmats, coeffs, batch_ids, camera_ids, gaussian_ids = ctx.saved_tensors
-        if ctx.needs_input_grad[2]:
-            raise NotImplementedError("gsplat_amd: SH gradient w.r.t. viewmats is not implemented")
-        v_coeffs, v_means, _, _ = impl("spherical_harmonics_bwd")(
+        v_coeffs, v_means, v_viewmats, _ = impl("spherical_harmonics_bwd")(
             ctx.degree, means, viewmats, coeffs, None, batch_ids, camera_ids, gaussian_ids, None,
-            v_colors.contiguous(), ctx.needs_input_grad[1], False, False, _gathered=False)
-        return None, v_means, None, v_coeffs, None, None, None
+            v_colors.contiguous(), ctx.needs_input_grad[1], ctx.needs_input_grad[2], False, _gathered=False)
+        return None, v_means, v_viewmats, v_coeffs, None, None, None
 
 
 # ==================================================================================================

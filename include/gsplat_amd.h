@@ -153,7 +153,10 @@ int gsx_sh_bwd(int degrees_to_use, const float *means, const float *viewmats, co
                const int32_t *radii /* as in gsx_sh_fwd */,
                const float *post_colors /* NULL, or the forward output computed with post=1: cuts the gradient where 0 */,
                const float *v_colors, uint32_t v_colors_stride /* floats per row; 0 = D (contiguous) */,
-               float *v_coeffs, float *v_means, void *stream);
+               float *v_coeffs, float *v_means,
+               float *v_dirs /* NULL, or zero-initialised [rows,3]: per-row d(loss)/d(view direction), from which the
+                                caller forms v_viewmats (= t (x) sum v_dir for R, R sum v_dir for t) */,
+               void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * isect_tiles: gsplat::intersect_tile (ext.cpp:1022-1026; host Intersect.cpp:170-329; kernel

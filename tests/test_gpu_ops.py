@@ -200,6 +200,38 @@ def test_spherical_harmonics_packed(G, O):
     assert_grad_close(cpu(mg.grad), mo.grad, rel=1e-4, name="packed v_means")
 
 
+@pytest.mark.parametrize("D", [3, 5])  # D = 3: one-thread-per-row kernels; other widths: per-(row, channel) kernels
+@pytest.mark.parametrize("packed", [False, True])
+def test_spherical_harmonics_viewmat_gradient(G, O, D, packed):
+    """Pose gradient of the SH colours (reference SphericalHarmonicsViewDirectionCUDA.cu; autograd of the torch
+    restatement _torch_impl.py:1052-1067 is the oracle): v_viewmats from the per-row d(loss)/d(direction)."""
+    sc, W, H = make_scene(N=1500, C=3, seed=21)
+    coeffs = torch.randn(1500, 16, D) * 0.3
+    vm_g = sc["viewmats"].to(DEV).requires_grad_(True)
+    mg = sc["means"].to(DEV).requires_grad_(True)
+    cg = coeffs.to(DEV).requires_grad_(True)
+    vm_o = sc["viewmats"].clone().requires_grad_(True)
+    mo, co = sc["means"].clone().requires_grad_(True), coeffs.clone().requires_grad_(True)
+    if packed:
+        vis = torch.rand(3, 1500) > 0.4
+        ci, gi = torch.where(vis)
+        col = G.spherical_harmonics(3, mg, vm_g, cg[gi.to(DEV)], batch_ids=torch.zeros_like(ci).to(DEV),
+                                    camera_ids=ci.to(DEV), gaussian_ids=gi.to(DEV))
+        col_o = O.spherical_harmonics(3, mo[None], vm_o[None], co)[0][vis]
+    else:
+        masks = torch.rand(3, 1500) > 0.2
+        col = G.spherical_harmonics(3, mg, vm_g, cg, masks=masks.to(DEV))
+        col_o = O.spherical_harmonics(3, mo[None], vm_o[None], co, masks[None])[0]
+    assert_close_ratio(cpu(col), col_o, 1e-5, 1e-5, name="sh colors")
+    w = torch.randn_like(col_o)
+    (col * w.to(DEV)).sum().backward()
+    (col_o * w).sum().backward()
+    assert_grad_close(cpu(vm_g.grad)[:, :3], vm_o.grad[:, :3], rel=2e-4, name="v_viewmats")
+    assert cpu(vm_g.grad)[:, 3].abs().max() == 0  # the last row of a view matrix carries no gradient
+    assert_grad_close(cpu(mg.grad), mo.grad, rel=1e-4, name="v_means")
+    assert_grad_close(cpu(cg.grad), co.grad, rel=1e-5, name="v_coeffs")
+
+
 # ------------------------------------------------------------------------------------------------
 def _project_scene(G, sc, W, H):
     a = {k: v.to(DEV) for k, v in sc.items()}

@@ -69,6 +69,27 @@ def test_rasterization_matches_oracle(G, packed, render_mode, sh_degree, rasteri
     assert abs(meta["isect_ids"].numel() - ref["n_isects"]) <= max(4, ref["n_isects"] // 2000)
 
 
+@pytest.mark.parametrize("packed", [True, False])
+def test_rasterization_pose_gradient(G, packed):
+    """viewmats.requires_grad (pose optimisation): the gradient reaches the view matrices through BOTH the projection
+    (viewmats_requires_grad, ProjectionEWA3DGSFused.cu) and the SH view directions; the oracle chains torch autograd."""
+    from oracle.pipeline import rasterization_cpu
+
+    sc, W, H = make_scene(N=4000, C=2, width=176, height=120, seed=9, sh_degree=3)
+    g = torch.Generator().manual_seed(6)
+    v_rc, v_ra = torch.randn(2, H, W, 4, generator=g), torch.randn(2, H, W, 1, generator=g)
+    vm_o = sc["viewmats"].clone().requires_grad_(True)
+    rasterization_cpu(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], vm_o, sc["Ks"], W, H,
+                      sh_degree=3, render_mode="RGB+ED", v_render_colors=v_rc, v_render_alphas=v_ra)
+    vm_g = sc["viewmats"].to(DEV).requires_grad_(True)
+    rc, ra, _ = G.rasterization(sc["means"].to(DEV), sc["quats"].to(DEV), sc["scales"].to(DEV), sc["opacities"].to(DEV),
+                                sc["colors"].to(DEV), vm_g, sc["Ks"].to(DEV), W, H, sh_degree=3, packed=packed,
+                                render_mode="RGB+ED")
+    ((rc * v_rc.to(DEV)).sum() + (ra * v_ra.to(DEV)).sum()).backward()
+    assert vm_o.grad is not None and vm_g.grad is not None
+    assert_grad_close(vm_g.grad.cpu()[:, :3], vm_o.grad[:, :3], rel=1e-2, name="v_viewmats")
+
+
 def test_rasterization_batch_dims_and_channel_chunks(G):
     """[B,...] batch dims and D > channel_chunk (chunked compositing) agree with per-item / unchunked calls."""
     sc, W, H = make_scene(N=2000, C=2, width=96, height=64, seed=8)
