@@ -114,7 +114,15 @@ def ptr_strided(t: torch.Tensor):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream() -> int:
+    """Raw hipStream_t of torch's current stream on the current device. The private fast accessor costs ~0.3 us;
+    torch.cuda.current_stream() builds a Stream object through several Python layers (~9 us, measured), which adds
+    up to ~0.1 ms per step over the ~12 C-ABI calls of a step."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -102,6 +102,17 @@ def _row_view(t: Tensor, width: int):
     return t.contiguous(), width
 
 
+def _common_row_views(ts, widths):
+    """Three gradient tensors for the 2DGS projection backward: (tensors, common row stride or 0). If every one is a
+    column view with the SAME row stride (views of one AoS gradient buffer) they are used in place, otherwise they are
+    made contiguous (stride 0 = "contiguous rows" in the C-ABI)."""
+    views = [_row_view(t, w) for t, w in zip(ts, widths)]
+    strides = {st for (_t, st), w in zip(views, widths) if st != w}
+    if len(strides) == 1 and all(st != w for (_t, st), w in zip(views, widths)):
+        return [t for t, _ in views], strides.pop()
+    return [t.contiguous() for t in ts], 0
+
+
 def bits_for_count(count: int) -> int:
     return (count - 1).bit_length() if count > 1 else 0
 
@@ -679,10 +690,11 @@ def projection_2dgs_fused_bwd(means, quats, scales, viewmats, Ks, image_width, i
     means, quats, scales, viewmats, Ks = (t.contiguous() for t in (means, quats, scales, viewmats, Ks))
     v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
     v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
+    (v_means2d, v_rt, v_normals), vstride = _common_row_views(
+        (v_means2d, v_ray_transforms.reshape(v_ray_transforms.shape[:-2] + (9,)), v_normals), (2, 9, 3))
     call("gsx_project_2dgs_bwd", ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), B, C, N,
-         ptr(radii.contiguous()), ptr(ray_transforms.contiguous()), ptr(v_means2d.contiguous()),
-         ptr(v_depths.contiguous()), ptr(v_ray_transforms.contiguous()), ptr(v_normals.contiguous()), ptr(v_means),
-         ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
+         ptr(radii.contiguous()), ptr(ray_transforms.contiguous()), ptr_strided(v_means2d), ptr(_c(v_depths)),
+         ptr_strided(v_rt), ptr_strided(v_normals), vstride, ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
     return v_means, v_quats, v_scales, v_viewmats
 
 
@@ -726,11 +738,12 @@ def projection_2dgs_packed_bwd(means, quats, scales, viewmats, Ks, image_width, 
     nnz = gaussian_ids.shape[0]
     v_means, v_quats, v_scales = torch.zeros_like(means), torch.zeros_like(quats), torch.zeros_like(scales)
     v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
+    (v_means2d, v_rt, v_normals), vstride = _common_row_views(
+        (v_means2d, v_ray_transforms.reshape(v_ray_transforms.shape[:-2] + (9,)), v_normals), (2, 9, 3))
     call("gsx_project_2dgs_packed_bwd", ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), B, C, N, nnz,
          ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()), ptr(gaussian_ids.contiguous()),
-         ptr(ray_transforms.contiguous()), ptr(v_means2d.contiguous()), ptr(v_depths.contiguous()),
-         ptr(v_ray_transforms.contiguous()), ptr(v_normals.contiguous()), ptr(v_means), ptr(v_quats), ptr(v_scales),
-         ptr(v_viewmats))
+         ptr(ray_transforms.contiguous()), ptr_strided(v_means2d), ptr(_c(v_depths)), ptr_strided(v_rt),
+         ptr_strided(v_normals), vstride, ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
     if sparse_grad and len(batch_dims) == 0:
         rows = torch.unique(gaussian_ids)
 
@@ -782,17 +795,21 @@ def rasterize_to_pixels_2dgs_bwd(means2d, ray_transforms, colors, opacities, nor
                                                                                     opacities, normals))
     backgrounds, masks = _c(backgrounds), _c(masks)
     v_render_colors, v_render_alphas = v_render_colors.contiguous(), v_render_alphas.contiguous()
-    v_means2d, v_rt = torch.zeros_like(means2d), torch.zeros_like(ray_transforms)
-    v_colors, v_opacities = torch.zeros_like(colors), torch.zeros_like(opacities)
-    v_normals, v_densify = torch.zeros_like(normals), torch.zeros_like(means2d)
-    v_abs = torch.zeros_like(means2d) if absgrad else None
+    # one zero-filled AoS gradient buffer; the reference's gradient tensors are column views of it (include/gsplat_amd.h)
+    R = opacities.numel()
+    geo = 19 if absgrad else 17
+    rows = torch.zeros((R, geo + D), device=means2d.device, dtype=means2d.dtype)
     call("gsx_raster2d_bwd", ptr(means2d), ptr(ray_transforms), ptr(colors), ptr(opacities), ptr(normals),
          ptr(backgrounds), ptr(masks), ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()),
          ptr(render_colors.contiguous()), ptr(render_alphas.contiguous()), ptr(last_ids.contiguous()),
          ptr(median_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), ptr(v_render_normals.contiguous()),
-         ptr(v_render_distort.contiguous()), ptr(v_render_median.contiguous()), I, flatten_ids.numel(), D, image_width,
-         image_height, tile_size, tw, th, ptr(v_abs), ptr(v_means2d), ptr(v_rt), ptr(v_colors), ptr(v_opacities),
-         ptr(v_normals), ptr(v_densify))
+         ptr(_c(v_render_distort)), ptr(v_render_median.contiguous()), I, flatten_ids.numel(), D, image_width,
+         image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D)
+    v_means2d, v_opacities = rows[:, 0:2].view(means2d.shape), rows[:, 2].view(opacities.shape)
+    v_densify, v_normals = rows[:, 3:5].view(means2d.shape), rows[:, 5:8].view(normals.shape)
+    v_rt = rows[:, 8:17].view(ray_transforms.shape)
+    v_abs = rows[:, 17:19].view(means2d.shape) if absgrad else None
+    v_colors = rows[:, geo:].view(colors.shape)
     v_backgrounds = None
     if backgrounds is not None and compute_v_backgrounds:
         v_backgrounds = (v_render_colors * (1.0 - render_alphas)).sum(dim=(-3, -2))

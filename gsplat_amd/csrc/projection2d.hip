@@ -158,6 +158,7 @@ struct Proj2BwdArgs {
     const int32_t *radii;          // dense only
     const float *ray_transforms;   // per row
     const float *v_means2d, *v_depths, *v_ray_transforms, *v_normals;
+    uint32_t m2_stride, rt_stride, n_stride; // row strides (floats): 2 / 9 / 3, or the stride of the AoS gradient rows
     int64_t nnz;
     const int64_t *batch_ids, *camera_ids, *gaussian_ids;
     float *v_means, *v_quats, *v_scales, *v_viewmats;
@@ -172,9 +173,9 @@ __device__ __forceinline__ void pair2_vjp(const Proj2BwdArgs &a, const Cam &cam,
     const float *M = a.ray_transforms + 9 * row;
     float vM[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) vM[i] = a.v_ray_transforms[9 * row + i];
-    vM[8] += a.v_depths[row]; // depth = M2.z
-    const float vmx = a.v_means2d[2 * row], vmy = a.v_means2d[2 * row + 1];
+    for (int i = 0; i < 9; ++i) vM[i] = a.v_ray_transforms[(size_t)a.rt_stride * row + i];
+    if (a.v_depths) vM[8] += a.v_depths[row]; // depth = M2.z (null = no gradient reaches the depths)
+    const float vmx = a.v_means2d[(size_t)a.m2_stride * row], vmy = a.v_means2d[(size_t)a.m2_stride * row + 1];
     if (vmx != 0.0f || vmy != 0.0f) {
         // mean2d_x = sum(sgn M0 M2) / d, d = sum(sgn M2 M2), sgn = (1,1,-1)
         const float sg[3] = {1.0f, 1.0f, -1.0f};
@@ -210,7 +211,8 @@ __device__ __forceinline__ void pair2_vjp(const Proj2BwdArgs &a, const Cam &cam,
         RR2[i] = cam.R[3 * i] * Rq[2] + cam.R[3 * i + 1] * Rq[5] + cam.R[3 * i + 2] * Rq[8];
     }
     const float mult = (-(RR2[0] * pc[0] + RR2[1] * pc[1] + RR2[2] * pc[2])) > 0.0f ? 1.0f : -1.0f;
-    const float v_n[3] = {mult * a.v_normals[3 * row], mult * a.v_normals[3 * row + 1], mult * a.v_normals[3 * row + 2]};
+    const float *vnp  = a.v_normals + (size_t)a.n_stride * row;
+    const float v_n[3] = {mult * vnp[0], mult * vnp[1], mult * vnp[2]};
 
     // back through the camera rotation: x_cam = R x_world
     float tu[3], tv[3], tn[3];
@@ -447,19 +449,22 @@ extern "C" int gsx_project_2dgs_packed_write(const float *means, const float *qu
 extern "C" int gsx_project_2dgs_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
                                     const float *Ks, uint32_t B, uint32_t C, uint32_t N, const int32_t *radii,
                                     const float *ray_transforms, const float *v_means2d, const float *v_depths,
-                                    const float *v_ray_transforms, const float *v_normals, float *v_means, float *v_quats,
+                                    const float *v_ray_transforms, const float *v_normals, uint32_t v_row_stride,
+                                    float *v_means, float *v_quats,
                                     float *v_scales, float *v_viewmats, void *stream)
 {
     if ((int64_t)B * N == 0) return GSX_OK;
     int rc = check2("gsx_project_2dgs_bwd", means, quats, scales, viewmats, Ks);
     if (rc != GSX_OK) return rc;
-    GSX_REQUIRE(C == 0 || (radii && ray_transforms && v_means2d && v_depths && v_ray_transforms && v_normals),
+    GSX_REQUIRE(C == 0 || (radii && ray_transforms && v_means2d && v_ray_transforms && v_normals),
                 "gsx_project_2dgs_bwd: null input");
     GSX_REQUIRE(v_means && v_quats && v_scales, "gsx_project_2dgs_bwd: null output");
     Proj2BwdArgs a{};
     a.means = means; a.quats = quats; a.scales = scales; a.viewmats = viewmats; a.Ks = Ks; a.B = B; a.C = C; a.N = N;
     a.radii = radii; a.ray_transforms = ray_transforms; a.v_means2d = v_means2d; a.v_depths = v_depths;
     a.v_ray_transforms = v_ray_transforms; a.v_normals = v_normals;
+    a.m2_stride = v_row_stride ? v_row_stride : 2u; a.rt_stride = v_row_stride ? v_row_stride : 9u;
+    a.n_stride = v_row_stride ? v_row_stride : 3u;
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_viewmats = v_viewmats;
     const dim3 grid((uint32_t)ceil_div((int64_t)B * N, 256));
     if (v_viewmats) project2_bwd_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
@@ -472,13 +477,14 @@ extern "C" int gsx_project_2dgs_packed_bwd(const float *means, const float *quat
                                            int64_t nnz, const int64_t *batch_ids, const int64_t *camera_ids,
                                            const int64_t *gaussian_ids, const float *ray_transforms,
                                            const float *v_means2d, const float *v_depths, const float *v_ray_transforms,
-                                           const float *v_normals, float *v_means, float *v_quats, float *v_scales,
+                                           const float *v_normals, uint32_t v_row_stride, float *v_means,
+                                           float *v_quats, float *v_scales,
                                            float *v_viewmats, void *stream)
 {
     if (nnz == 0) return GSX_OK;
     int rc = check2("gsx_project_2dgs_packed_bwd", means, quats, scales, viewmats, Ks);
     if (rc != GSX_OK) return rc;
-    GSX_REQUIRE(batch_ids && camera_ids && gaussian_ids && ray_transforms && v_means2d && v_depths && v_ray_transforms
+    GSX_REQUIRE(batch_ids && camera_ids && gaussian_ids && ray_transforms && v_means2d && v_ray_transforms
                 && v_normals, "gsx_project_2dgs_packed_bwd: null input");
     GSX_REQUIRE(v_means && v_quats && v_scales, "gsx_project_2dgs_packed_bwd: null output");
     Proj2BwdArgs a{};
@@ -486,6 +492,8 @@ extern "C" int gsx_project_2dgs_packed_bwd(const float *means, const float *quat
     a.nnz = nnz; a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
     a.ray_transforms = ray_transforms; a.v_means2d = v_means2d; a.v_depths = v_depths;
     a.v_ray_transforms = v_ray_transforms; a.v_normals = v_normals;
+    a.m2_stride = v_row_stride ? v_row_stride : 2u; a.rt_stride = v_row_stride ? v_row_stride : 9u;
+    a.n_stride = v_row_stride ? v_row_stride : 3u;
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_viewmats = v_viewmats;
     const dim3 grid((uint32_t)ceil_div(nnz, 256));
     if (v_viewmats) project2_packed_bwd_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);

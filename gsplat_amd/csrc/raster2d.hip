@@ -6,8 +6,11 @@
 // Same MI355X work decomposition as the 3DGS kernels (raster3d.hpp): one workgroup of four wave64s per 16x16 tile, a
 // wave owns an 8x8 pixel quadrant, the sorted list is walked in LDS-staged batches. The backward reduces the
 // per-Gaussian sums with the wave64 reduce-scatter (permlane swaps + DPP), accumulates them in an LDS row per Gaussian
-// (ds_add_f32) and flushes ONE global atomic per (tile, Gaussian, component). v_densify is not reduced at all: it is
-// (v_uM.z, v_vM.z) * w_M.z, a per-Gaussian factor applied to already-reduced sums at flush time.
+// (ds_add_f32) and flushes ONE global atomic per (tile, Gaussian, component) into array-of-structures gradient rows,
+// transposed (consecutive lanes -> consecutive floats of one surfel's row; see raster3d_bwd.hip for the measurement that
+// motivates it). v_densify is not reduced at all: it is (v_uM.z, v_vM.z) * w_M.z, a per-Gaussian factor applied to
+// already-reduced sums at flush time. Forward and backward cull (wave, surfel) pairs with the staged bounding box of
+// the surfel's alpha >= 1/255 region (surfel_cull_box below).
 //
 // Per-sample math (Fwd.cu:356-428): h_u = px w_M - u_M, h_v = py w_M - v_M, zeta = h_u x h_v, s = zeta.xy / zeta.z,
 // G3 = |s|^2, G2 = 2 |mean2d - p|^2, sigma = min(G3, G2) / 2, alpha = min(0.99, opac exp(-sigma)); skip if zeta.z == 0,
@@ -34,9 +37,42 @@ struct Raster2DArgs {
     int32_t *last_ids, *median_ids;
     // backward inputs
     const float *v_render_colors, *v_render_alphas, *v_render_normals, *v_render_distort, *v_render_median;
-    // backward outputs (zero-initialised)
-    float *v_means2d_abs, *v_means2d, *v_ray_transforms, *v_colors, *v_opacities, *v_normals, *v_densify;
+    // backward output (zero-initialised): ONE array-of-structures buffer [R][row_stride]; row =
+    // (v_means2d 2 | v_opacities 1 | v_densify 2 | v_normals 3 | v_ray_transforms 9 | [v_means2d_abs 2] | v_colors cdim)
+    float *v_rows;
+    uint32_t row_stride;
 };
+
+// Bounding box (centre, half extents) of the pixels where a surfel can reach alpha >= 1/255, i.e. where
+// min(G3, G2) <= 2 L with L = ln(255 opac): the union of
+//   * the projection of the uv-disc |s| <= k, k^2 = 2 L. With rows u, v, w of the ray transform its exact screen
+//     AABB is  c = f (k^2 (u0 w0 + u1 w1) - u2 w2),  h^2 = c^2 - f (k^2 (u0^2 + u1^2) - u2^2),
+//     f = 1 / (k^2 (w0^2 + w1^2) - w2^2)  (the 2DGS bounding-box formula with (k^2, k^2, -1) in place of (1, 1, -1);
+//     it is what Projection2DGSFused.cu evaluates at k = 1), valid while the denominator is negative;
+//   * the low-pass disc |pixel - mean2d| <= sqrt(L)  (G2 = 2 |d|^2).
+// Anything degenerate (disc reaching the camera plane, NaN) returns an infinite box = never culled; opac <= 1/255
+// returns an empty one. A small margin dwarfs the rounding of the fast intrinsics.
+__device__ __forceinline__ float4 surfel_cull_box(const float *M, float mx, float my, float opac)
+{
+    const float L = __logf(255.0f * opac) + 0.01f;
+    if (!(L > 0.0f)) return make_float4(0.0f, 0.0f, -1.0f, -1.0f);
+    const float k2  = 2.0f * L;
+    const float den = k2 * (M[6] * M[6] + M[7] * M[7]) - M[8] * M[8];
+    const float4 never = make_float4(0.0f, 0.0f, INFINITY, INFINITY);
+    if (!(den < 0.0f)) return never;
+    const float f   = 1.0f / den;
+    const float cx  = f * (k2 * (M[0] * M[6] + M[1] * M[7]) - M[2] * M[8]);
+    const float cy  = f * (k2 * (M[3] * M[6] + M[4] * M[7]) - M[5] * M[8]);
+    const float hx2 = cx * cx - f * (k2 * (M[0] * M[0] + M[1] * M[1]) - M[2] * M[2]);
+    const float hy2 = cy * cy - f * (k2 * (M[3] * M[3] + M[4] * M[4]) - M[5] * M[5]);
+    if (!(hx2 >= 0.0f) || !(hy2 >= 0.0f)) return never;
+    const float hx = sqrtf(hx2), hy = sqrtf(hy2), r2 = sqrtf(L);
+    const float x0 = fminf(cx - hx, mx - r2), x1 = fmaxf(cx + hx, mx + r2);
+    const float y0 = fminf(cy - hy, my - r2), y1 = fmaxf(cy + hy, my + r2);
+    if (!(x1 - x0 < INFINITY) || !(y1 - y0 < INFINITY)) return never;
+    return make_float4(0.5f * (x0 + x1), 0.5f * (y0 + y1), 0.5f * (x1 - x0) * 1.001f + 0.02f,
+                       0.5f * (y1 - y0) * 1.001f + 0.02f);
+}
 
 struct Surfel { // one pixel x one surfel
     bool valid;
@@ -80,7 +116,8 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
     float4 *s_B  = s_A + kBatch2;
     float4 *s_C  = s_B + kBatch2;
     float4 *s_N  = s_C + kBatch2;                             // normal xyz, pad
-    float *s_col = reinterpret_cast<float *>(s_N + kBatch2);  // [kBatch2][CH]
+    float4 *s_cull = s_N + kBatch2;                           // surfel_cull_box
+    float *s_col = reinterpret_cast<float *>(s_cull + kBatch2); // [kBatch2][CH]
 
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
     const uint32_t n_blocks        = tiles_per_image * a.n_images;
@@ -124,6 +161,8 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
 #pragma unroll
     for (int k = 0; k < CH; ++k) acc[k] = 0.0f;
     bool done = !inside;
+    const uint32_t lane = tid & 63u;
+    const WaveRect rect = wave_pixel_rect(inside, px, py);
 
     for (int32_t b = 0; b < n_batches; ++b) {
         if (__syncthreads_count(done) == (int)blockDim.x) break;
@@ -136,7 +175,9 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
                 const float2 xy = reinterpret_cast<const float2 *>(a.means2d)[g];
                 s_A[s] = make_float4(M[0], M[1], M[2], xy.x);
                 s_B[s] = make_float4(M[3], M[4], M[5], xy.y);
-                s_C[s] = make_float4(M[6], M[7], M[8], a.opacities[g]);
+                const float opac = a.opacities[g];
+                s_C[s] = make_float4(M[6], M[7], M[8], opac);
+                s_cull[s] = surfel_cull_box(M, xy.x, xy.y, opac);
                 const float *n = a.normals + 3 * (size_t)g;
                 s_N[s] = make_float4(n[0], n[1], n[2], 0.0f);
                 const float *c = a.colors + (size_t)g * a.cdim;
@@ -146,8 +187,20 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
         }
         __syncthreads();
         const int32_t batch_size = min(kBatch2, range_end - batch_start);
-        for (int32_t t = 0; t < batch_size; ++t) {
-            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        // 64 staged surfels are tested per instruction against this wave's pixel rectangle; only the ballot survivors
+        // are evaluated, front to back (a culled pair has no pixel that could pass the alpha test)
+        for (int32_t j = 0; j < batch_size; j += 64) {
+          if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+          const int32_t tl = j + (int32_t)lane;
+          bool hit         = false;
+          if (tl < batch_size) {
+              const float4 cu = s_cull[tl];
+              hit = (fabsf(cu.x - rect.cx) - rect.hw <= cu.z) && (fabsf(cu.y - rect.cy) - rect.hh <= cu.w);
+          }
+          uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
+          while (todo) {
+            const int32_t t = j + (int32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
             const Surfel s = eval_surfel(s_A[t], s_B[t], s_C[t], px, py);
             if (done || !s.valid) continue;
             const float next_T = T * (1.0f - s.alpha);
@@ -171,6 +224,7 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
             }
             cur_idx = (uint32_t)(batch_start + t);
             T       = next_T;
+          }
         }
     }
     if (inside) {
@@ -198,7 +252,7 @@ struct Bwd2Cfg {
     static constexpr int KP    = (K | 1);
     static constexpr int BATCH = (CH >= 8) ? 64 : 128;
     static constexpr size_t smem =
-        (size_t)BATCH * (4 * sizeof(float4) + 2 * sizeof(int32_t) + sizeof(float) * (CH + KP));
+        (size_t)BATCH * (5 * sizeof(float4) + 2 * sizeof(int32_t) + sizeof(float) * (CH + KP));
 };
 
 template <int CH, bool ABS>
@@ -215,7 +269,8 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
     float4 *s_B      = s_A + BATCH;
     float4 *s_C      = s_B + BATCH;
     float4 *s_N      = s_C + BATCH;
-    int32_t *s_id    = reinterpret_cast<int32_t *>(s_N + BATCH);
+    float4 *s_cull   = s_N + BATCH;
+    int32_t *s_id    = reinterpret_cast<int32_t *>(s_cull + BATCH);
     int32_t *s_touch = s_id + BATCH;
     float *s_col     = reinterpret_cast<float *>(s_touch + BATCH);
     float *s_acc     = s_col + BATCH * CH;
@@ -273,6 +328,7 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
         accum_w        = accum_w_buffer;
     }
     const int32_t wave_bin_final = wave_max_i32(bin_final);
+    const WaveRect rect          = wave_pixel_rect(inside, px, py);
 
     for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
 #pragma unroll
@@ -292,7 +348,9 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
                 s_id[s] = g;
                 s_A[s]  = make_float4(M[0], M[1], M[2], xy.x);
                 s_B[s]  = make_float4(M[3], M[4], M[5], xy.y);
-                s_C[s]  = make_float4(M[6], M[7], M[8], a.opacities[g]);
+                const float opac = a.opacities[g];
+                s_C[s]  = make_float4(M[6], M[7], M[8], opac);
+                s_cull[s] = surfel_cull_box(M, xy.x, xy.y, opac);
                 const float *n = a.normals + 3 * (size_t)g;
                 s_N[s]  = make_float4(n[0], n[1], n[2], 0.0f);
                 const float *c = a.colors + (size_t)g * a.cdim;
@@ -302,7 +360,18 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
         }
         __syncthreads();
 
-        for (int32_t t = max(0, batch_end - wave_bin_final); t < batch_size; ++t) {
+        const int32_t t_first = max(0, batch_end - wave_bin_final); // surfels behind every last contributor: skipped
+        for (int32_t j = (t_first & ~63); j < batch_size; j += 64) {
+          const int32_t tl = j + (int32_t)lane;
+          bool hit         = false;
+          if (tl >= t_first && tl < batch_size) {
+              const float4 cu = s_cull[tl];
+              hit = (fabsf(cu.x - rect.cx) - rect.hw <= cu.z) && (fabsf(cu.y - rect.cy) - rect.hh <= cu.w);
+          }
+          uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
+          while (todo) { // scalar loop over the survivors, back to front
+            const int32_t t = j + (int32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
             const float4 A = s_A[t], B = s_B[t], C = s_C[t];
             const Surfel s = eval_surfel(A, B, C, px, py);
             const bool valid = inside && (batch_end - t <= bin_final) && s.valid;
@@ -390,36 +459,43 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
             const int vidx = 4 * (int)(lane & 15u) + (int)(lane >> 4);
             if ((int)(lane & 15u) < KQ && vidx < K) atomicAdd(&s_acc[t * KP + vidx], mine);
             if (lane == 0) s_touch[t] = 1;
+          }
         }
         __syncthreads();
 
+        // transposed flush into the AoS gradient rows: element e -> (surfel s, output column c); accumulator slots:
+        // [0,CH) colours | CH..CH+2 normals | CH+3..CH+11 ray transform | CH+12,13 means2d | CH+14 opacity | CH+15,16 abs
+        constexpr int GEO  = 17 + (ABS ? 2 : 0);
+        constexpr int NCOL = GEO + CH;
+        for (int e = (int)tid; e < batch_size * NCOL; e += (int)blockDim.x) {
+            const int s = e / NCOL, c = e - s * NCOL;
+            if (!s_touch[s]) continue;
+            const float *row = s_acc + s * KP;
+            float val;
+            int col = c;
+            if (c < 2) val = row[CH + 12 + c];                               // v_means2d
+            else if (c == 2) val = row[CH + 14];                             // v_opacities
+            else if (c < 5) val = row[CH + 3 + 3 * (c - 3) + 2] * s_C[s].z;  // v_densify = (v_uM.z, v_vM.z) * w_M.z
+            else if (c < 8) val = row[CH + (c - 5)];                         // v_normals
+            else if (c < 17) val = row[CH + 3 + (c - 8)];                    // v_ray_transforms
+            else if (c < GEO) val = row[CH + 15 + (c - 17)];                 // |v_means2d|
+            else {
+                const int k = c - GEO;
+                if (k >= nch) continue;
+                val = row[k];
+                col = GEO + k;
+            }
+            atomic_add_f32(a.v_rows + (size_t)s_id[s] * a.row_stride + col, val);
+        }
+        __syncthreads();
         for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
             if (s < batch_size && s_touch[s]) {
-                const size_t g = (size_t)s_id[s];
-                float *row     = s_acc + s * KP;
-#pragma unroll
-                for (int k = 0; k < CH; ++k)
-                    if (k < nch) atomic_add_f32(a.v_colors + g * a.cdim + k, row[k]);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) atomic_add_f32(a.v_normals + 3 * g + k, row[CH + k]);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) atomic_add_f32(a.v_ray_transforms + 9 * g + k, row[CH + 3 + k]);
-                const float wz = s_C[s].z; // w_M.z
-                atomic_add_f32(a.v_densify + 2 * g + 0, row[CH + 3 + 2] * wz);
-                atomic_add_f32(a.v_densify + 2 * g + 1, row[CH + 6 + 2] * wz);
-                atomic_add_f32(a.v_means2d + 2 * g + 0, row[CH + 12]);
-                atomic_add_f32(a.v_means2d + 2 * g + 1, row[CH + 13]);
-                atomic_add_f32(a.v_opacities + g, row[CH + 14]);
-                if constexpr (ABS) {
-                    atomic_add_f32(a.v_means2d_abs + 2 * g + 0, row[CH + 15]);
-                    atomic_add_f32(a.v_means2d_abs + 2 * g + 1, row[CH + 16]);
-                }
+                float *row = s_acc + s * KP;
 #pragma unroll
                 for (int k = 0; k < KP; ++k) row[k] = 0.0f;
                 s_touch[s] = 0;
             }
         }
-        // (row s, s_C[s] and the staging slot s of the next batch all belong to the same thread: no barrier needed)
     }
 }
 
@@ -430,7 +506,7 @@ static int launch2_fwd(const Raster2DArgs &a, hipStream_t stream)
     if (n_blocks == 0) return GSX_OK;
     const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
     const uint32_t block = a.tile_size <= 8 ? 64u : 256u;
-    const size_t smem    = kBatch2 * (4 * sizeof(float4) + sizeof(float) * CH);
+    const size_t smem    = kBatch2 * (5 * sizeof(float4) + sizeof(float) * CH);
     raster2d_fwd_kernel<CH><<<dim3(grid), dim3(block), smem, stream>>>(a);
     return check_launch("raster2d_fwd");
 }
@@ -504,13 +580,12 @@ extern "C" int gsx_raster2d_bwd(const float *means2d, const float *ray_transform
                                 const float *v_render_normals, const float *v_render_distort,
                                 const float *v_render_median, uint32_t n_images, uint32_t n_isects, uint32_t cdim,
                                 uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
-                                float *v_means2d_abs, float *v_means2d, float *v_ray_transforms, float *v_colors,
-                                float *v_opacities, float *v_normals, float *v_densify, void *stream)
+                                int has_abs, float *v_rows, uint32_t row_stride, void *stream)
 {
     GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster2d_bwd: tile_size must be in [1,16], got %u", tile_size);
     GSX_REQUIRE(cdim >= 1 && cdim <= 32, "gsx_raster2d_bwd: unsupported number of channels %u (1..32)", cdim);
-    GSX_REQUIRE(v_means2d && v_ray_transforms && v_colors && v_opacities && v_normals && v_densify,
-                "gsx_raster2d_bwd: null gradient output");
+    GSX_REQUIRE(v_rows, "gsx_raster2d_bwd: null gradient output");
+    GSX_REQUIRE(row_stride >= 17u + (has_abs ? 2u : 0u) + cdim, "gsx_raster2d_bwd: row_stride %u too small", row_stride);
     GSX_REQUIRE(n_isects == 0 || (means2d && ray_transforms && colors && opacities && normals && flatten_ids
                                   && render_colors && render_alphas && last_ids && median_ids && v_render_colors
                                   && v_render_alphas && v_render_normals && v_render_median && isect_offsets),
@@ -525,8 +600,7 @@ extern "C" int gsx_raster2d_bwd(const float *means2d, const float *ray_transform
     a.last_ids = const_cast<int32_t *>(last_ids); a.median_ids = const_cast<int32_t *>(median_ids);
     a.v_render_colors = v_render_colors; a.v_render_alphas = v_render_alphas; a.v_render_normals = v_render_normals;
     a.v_render_distort = v_render_distort; a.v_render_median = v_render_median;
-    a.v_means2d_abs = v_means2d_abs; a.v_means2d = v_means2d; a.v_ray_transforms = v_ray_transforms;
-    a.v_colors = v_colors; a.v_opacities = v_opacities; a.v_normals = v_normals; a.v_densify = v_densify;
+    a.v_rows = v_rows; a.row_stride = row_stride;
     hipStream_t s = (hipStream_t)stream;
-    return v_means2d_abs ? dispatch2_bwd<true>(a, s) : dispatch2_bwd<false>(a, s);
+    return has_abs ? dispatch2_bwd<true>(a, s) : dispatch2_bwd<false>(a, s);
 }

@@ -279,15 +279,17 @@ int gsx_project_2dgs_packed_write(const float *means, const float *quats, const 
                                   float *ray_transforms, float *normals, void *stream);
 int gsx_project_2dgs_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
                          const float *Ks, uint32_t B, uint32_t C, uint32_t N, const int32_t *radii,
-                         const float *ray_transforms, const float *v_means2d, const float *v_depths,
-                         const float *v_ray_transforms, const float *v_normals, float *v_means, float *v_quats,
-                         float *v_scales, float *v_viewmats, void *stream);
+                         const float *ray_transforms, const float *v_means2d, const float *v_depths /* may be NULL */,
+                         const float *v_ray_transforms, const float *v_normals,
+                         uint32_t v_row_stride /* 0: the three gradients are contiguous [rows,2] / [rows,9] / [rows,3];
+                                                  else they are column views of gsx_raster2d_bwd's v_rows with this stride */,
+                         float *v_means, float *v_quats, float *v_scales, float *v_viewmats, void *stream);
 int gsx_project_2dgs_packed_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
                                 const float *Ks, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
                                 const int64_t *batch_ids, const int64_t *camera_ids, const int64_t *gaussian_ids,
                                 const float *ray_transforms, const float *v_means2d, const float *v_depths,
-                                const float *v_ray_transforms, const float *v_normals, float *v_means, float *v_quats,
-                                float *v_scales, float *v_viewmats, void *stream);
+                                const float *v_ray_transforms, const float *v_normals, uint32_t v_row_stride,
+                                float *v_means, float *v_quats, float *v_scales, float *v_viewmats, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * rasterize_to_pixels (2DGS): gsplat::rasterize_to_pixels_2dgs{,_bwd} (ext.cpp:1186-1199; kernels
@@ -295,7 +297,10 @@ int gsx_project_2dgs_packed_bwd(const float *means, const float *quats, const fl
  * channels on this path either); the LAST channel is the depth used by the distortion / median outputs.
  * fwd outputs: render_colors [I,H,W,cdim], render_alphas [I,H,W,1], render_normals [I,H,W,3], render_distort
  * [I,H,W,1] (zeros unless distloss), render_median [I,H,W,1], last_ids / median_ids int32 [I,H,W].
- * bwd: v_render_distort NULL = distloss off; gradient outputs must be ZERO-initialised; v_means2d_abs may be NULL.
+ * bwd: v_render_distort NULL = distloss off. ONE zero-initialised array-of-structures gradient buffer v_rows
+ * [R][row_stride], row = (v_means2d 2 | v_opacities 1 | v_densify 2 | v_normals 3 | v_ray_transforms 9 |
+ * [v_means2d_abs 2 if has_abs] | v_colors cdim), row_stride >= 17 + 2*has_abs + cdim: the reference's gradient tensors
+ * are column views of it (same reason and measurement as gsx_raster3d_bwd).
  * ------------------------------------------------------------------------------------------- */
 int gsx_raster2d_fwd(const float *means2d, const float *ray_transforms, const float *colors, const float *opacities,
                      const float *normals, const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
@@ -309,9 +314,8 @@ int gsx_raster2d_bwd(const float *means2d, const float *ray_transforms, const fl
                      const int32_t *last_ids, const int32_t *median_ids, const float *v_render_colors,
                      const float *v_render_alphas, const float *v_render_normals, const float *v_render_distort,
                      const float *v_render_median, uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width,
-                     uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *v_means2d_abs,
-                     float *v_means2d, float *v_ray_transforms, float *v_colors, float *v_opacities, float *v_normals,
-                     float *v_densify, void *stream);
+                     uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows,
+                     uint32_t row_stride, void *stream);
 
 #ifdef __cplusplus
 }
