@@ -184,6 +184,18 @@ def tile_sort_workspace_bytes(n: int, n_images: int, tile_w: int, tile_h: int) -
     return int(_lib.gsx_isect_tile_sort_workspace_bytes(n, n_images, tile_w, tile_h))
 
 
+def isect_fused_supported(n_images: int, tile_w: int, tile_h: int, packed: bool) -> bool:
+    return bool(_lib.gsx_isect_fused_supported(n_images, tile_w, tile_h, int(packed)))
+
+
+def isect_fused_count_workspace_bytes(rows: int, n_images: int, tile_w: int, tile_h: int) -> int:
+    return int(_lib.gsx_isect_fused_count_workspace_bytes(rows, n_images, tile_w, tile_h))
+
+
+def isect_fused_emit_workspace_bytes(n: int, n_images: int, tile_w: int, tile_h: int) -> int:
+    return int(_lib.gsx_isect_fused_emit_workspace_bytes(n, n_images, tile_w, tile_h))
+
+
 def sort_pairs(keys, vals, keys_alt, vals_alt, n: int, end_bit: int, workspace) -> bool:
     """Returns True when the sorted data ended up in the alt buffers."""
     flag = ctypes.c_int(0)

@@ -241,7 +241,8 @@ def _scan_i32(x: Tensor) -> Tensor:
 
 class _IsectPending:
     """State between the two halves of intersect_tile (see isect_begin)."""
-    __slots__ = ("args", "tiles_per_gauss", "cum", "host_total", "event", "rows", "n_per", "I", "geom", "sort")
+    __slots__ = ("args", "tiles_per_gauss", "cum", "host_total", "event", "rows", "n_per", "I", "geom", "sort",
+                 "fused", "count_ws", "offsets", "n_dev")
 
 
 def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_ids, n_images, tile_size,
@@ -278,13 +279,29 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
     st.rows, st.n_per, st.I, st.sort = rows, n_per, I, sort
     st.geom = (tile_size, tile_width, tile_height, tile_bits, image_bits)
     st.tiles_per_gauss = torch.empty(out_shape, device=dev, dtype=torch.int32)
-    st.cum = st.host_total = st.event = None
+    st.cum = st.host_total = st.event = st.count_ws = st.offsets = st.n_dev = None
+    st.fused = False
     if rows == 0:
+        return st
+    # sort=True: fused path (csrc/isect_fused.hip) — per-(chunk, tile) histogram while counting, emission straight into
+    # tile segments, offsets as a by-product; dense rows of any image count, packed rows of a single image
+    st.fused = bool(sort) and _cabi.isect_fused_supported(I, tile_width, tile_height, packed)
+    st.host_total = torch.empty(1, dtype=torch.int64, pin_memory=True)
+    if st.fused:
+        st.count_ws = torch.empty(_cabi.isect_fused_count_workspace_bytes(rows, I, tile_width, tile_height), device=dev,
+                                  dtype=torch.uint8)
+        st.offsets = torch.empty(I * tile_width * tile_height, device=dev, dtype=torch.int32)
+        st.n_dev = torch.empty(1, device=dev, dtype=torch.int64)
+        call("gsx_isect_fused_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), rows, I, tile_size,
+             tile_width, tile_height, ptr(st.tiles_per_gauss), ptr(st.offsets), ptr(st.n_dev), ptr(st.count_ws),
+             st.count_ws.numel())
+        st.host_total.copy_(st.n_dev, non_blocking=True)
+        st.event = torch.cuda.Event()
+        st.event.record()
         return st
     call("gsx_isect_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), ptr(image_ids), rows, n_per, I,
          tile_size, tile_width, tile_height, ptr(st.tiles_per_gauss))
     st.cum = _scan_i32(st.tiles_per_gauss)
-    st.host_total = torch.empty(1, dtype=torch.int64, pin_memory=True)
     st.host_total.copy_(st.cum[-1:], non_blocking=True)
     st.event = torch.cuda.Event()
     st.event.record()
@@ -309,6 +326,13 @@ def isect_finish(st: "_IsectPending"):
     isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
     if n_isects == 0:
+        return tiles_per_gauss, isect_ids, flatten_ids
+    if st.fused:
+        ws = torch.empty(_cabi.isect_fused_emit_workspace_bytes(n_isects, I, tile_width, tile_height), device=dev,
+                         dtype=torch.uint8)
+        call("gsx_isect_fused_emit_sort", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), rows, I,
+             tile_size, tile_width, tile_height, ptr(st.count_ws), st.count_ws.numel(), ptr(st.offsets), n_isects,
+             ptr(isect_ids), ptr(flatten_ids), ptr(ws), ws.numel())
         return tiles_per_gauss, isect_ids, flatten_ids
     call("gsx_isect_emit", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), ptr(image_ids),
          ptr(cum), rows, n_per, I, tile_size, tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids))

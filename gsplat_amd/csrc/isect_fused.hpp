@@ -1,0 +1,53 @@
+// Shared declarations of the fused tile-intersection path (isect_fused.hip: walk kernels, compiled with
+// -ffp-contract=off; tile_sort.hip: column scan, per-tile sort and the C-ABI entries).
+#pragma once
+#include "common.hpp"
+
+namespace gsx {
+
+struct FusedGeom {
+    int64_t rows;           // all rows
+    int64_t rows_per_image; // dense: N; packed (single image): rows
+    uint32_t n_images, cpi /* chunks per image */, rpc /* rows per chunk */, n_chunks;
+    uint32_t tile_size, tile_w, tile_h, n_tiles /* per image */;
+};
+
+struct FusedArgs {
+    FusedGeom geom;
+    const float *means2d;         // [R,2]
+    const int32_t *radii;         // [R,2]
+    const float *depths;          // [R]   (emit)
+    const float *conics;          // [R,3] or null
+    const float *opacities;       // [R]   or null
+    int32_t *tiles_per_gauss;     // [R]   (count)
+    int32_t *table;               // [n_chunks][n_tiles]: histogram, then exclusive prefix over an image's chunks
+    const int32_t *isect_offsets; // [n_images * n_tiles] (emit)
+    uint2 *bucketed;              // [M] (emit)
+};
+
+// <= 256 chunks in total (one workgroup of 1024 threads per CU), at least 4096 rows each
+inline FusedGeom fused_geometry(int64_t rows, uint32_t n_images, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h)
+{
+    FusedGeom g{};
+    g.rows = rows; g.n_images = n_images ? n_images : 1;
+    g.rows_per_image = rows / g.n_images;
+    // measured at c3 (1M rows, 8160 tiles; count / column scan / emit+scatter in us): 256 threads x 512 rows: 56 / 153 /
+    // 105; 512 x 1024: 46 / 75 / 91; 1024 x 2048: 48 / 29 / 95; 1024 x 4096: 50 / 16 / 102 -> the table (chunks x tiles)
+    // must stay small, the walk does not care
+    constexpr int64_t kMaxChunks = 256, kMinRows = 4096;
+    const int64_t max_cpi = kMaxChunks / g.n_images > 0 ? kMaxChunks / g.n_images : 1;
+    int64_t cpi = (g.rows_per_image + kMinRows - 1) / kMinRows;
+    if (cpi < 1) cpi = 1;
+    if (cpi > max_cpi) cpi = max_cpi;
+    g.cpi = (uint32_t)cpi;
+    g.rpc = (uint32_t)((g.rows_per_image + cpi - 1) / cpi);
+    if (g.rpc == 0) g.rpc = 1;
+    g.n_chunks = g.cpi * g.n_images;
+    g.tile_size = tile_size; g.tile_w = tile_w; g.tile_h = tile_h; g.n_tiles = tile_w * tile_h;
+    return g;
+}
+
+int launch_fused_count_hist(const FusedArgs &a, hipStream_t s);
+int launch_fused_emit_scatter(const FusedArgs &a, hipStream_t s);
+
+} // namespace gsx

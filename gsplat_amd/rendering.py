@@ -240,7 +240,10 @@ def rasterization(
             n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids_r, conics=conics,
             opacities=proj_opacities.contiguous())
     tiles_per_gauss, isect_ids, flatten_ids = isect_tiles_finish(isect_pending)
-    isect_offsets = isect_offset_encode(isect_ids, I, tile_width, tile_height)
+    if isect_pending.offsets is not None:  # the fused intersection path produces the tile offsets as a by-product
+        isect_offsets = isect_pending.offsets
+    else:
+        isect_offsets = isect_offset_encode(isect_ids, I, tile_width, tile_height)
     isect_offsets = isect_offsets.reshape(batch_dims + (C, tile_height, tile_width))
 
     # ---- compositing (channel chunks; alphas from the first chunk) -------------------------------

@@ -200,6 +200,29 @@ int gsx_isect_offsets(const int64_t *isect_ids_sorted, int64_t n_isects, uint32_
                       uint32_t tile_h, int32_t *offsets /* [I,tile_h,tile_w] */, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused isect_tiles(sort=True) + isect_offset_encode (same outputs as gsx_isect_count/emit + gsx_isect_tile_sort +
+ * gsx_isect_offsets, bit for bit): the per-(chunk, tile) histogram is taken while counting and the emission writes
+ * each (depth, row) pair directly into its tile's segment, so the unsorted key/value arrays and the histogram / scatter
+ * passes never touch HBM (8 B instead of 40 B per intersection ahead of the per-tile sort; csrc/isect_fused.hip).
+ * Dense rows [n_images * N] (any n_images while n_images * tiles fits the LDS histogram), or packed rows of ONE image.
+ *   1. gsx_isect_fused_count: tiles_per_gauss int32 [rows], isect_offsets int32 [n_images * tiles] (= intersect_offset),
+ *      *n_isects (device int64). The caller reads n_isects, allocates the exact-length outputs, then
+ *   2. gsx_isect_fused_emit_sort with the SAME count workspace: isect_ids int64 [n_isects], flatten_ids int32 [n_isects].
+ * ------------------------------------------------------------------------------------------- */
+int gsx_isect_fused_supported(uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed);
+int64_t gsx_isect_fused_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
+int64_t gsx_isect_fused_emit_workspace_bytes(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
+int gsx_isect_fused_count(const float *means2d, const int32_t *radii, const float *conics, const float *opacities,
+                          int64_t rows, uint32_t n_images, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                          int32_t *tiles_per_gauss, int32_t *isect_offsets, int64_t *n_isects,
+                          void *count_workspace, int64_t count_workspace_bytes, void *stream);
+int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *radii, const float *depths, const float *conics,
+                              const float *opacities, int64_t rows, uint32_t n_images, uint32_t tile_size,
+                              uint32_t tile_w, uint32_t tile_h, void *count_workspace, int64_t count_workspace_bytes,
+                              const int32_t *isect_offsets, int64_t n_isects, int64_t *isect_ids_sorted,
+                              int32_t *flatten_ids_sorted, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * rasterize_to_pixels (3DGS): gsplat::rasterize_to_pixels_3dgs{,_bwd} (ext.cpp:1079-1089; host
  * Rasterization.cpp:275-365, 484-587; kernels RasterizeToPixels3DGSSerialBatch{Fwd,Bwd}.cu).
  * Any channel count >= 1 (chunked by 32 internally); tile_size in [1,16].
