@@ -17,6 +17,9 @@ _LAZY = {
     "spherical_harmonics_l0": "_wrapper", "spherical_harmonics_l1_plus": "_wrapper",
     "rasterize_to_indices_in_range": "_wrapper", "rasterize_to_indices_in_range_2dgs": "_wrapper",
     "rasterization": "rendering", "rasterization_2dgs": "rendering", "distributed": "distributed",
+    # the training step around the rasterizer
+    "SelectiveAdam": "optimizers", "compute_relocation": "relocation", "DefaultStrategy": "strategy",
+    "MCMCStrategy": "strategy", "strategy": "strategy", "optimizers": "optimizers", "relocation": "relocation",
 }
 
 

@@ -62,6 +62,10 @@ SCHEMAS = {
     "projection_2dgs_packed_bwd": "(Tensor means, Tensor quats, Tensor scales, Tensor viewmats, Tensor Ks, int image_width, int image_height, bool sparse_grad, Tensor batch_ids, Tensor camera_ids, Tensor gaussian_ids, Tensor ray_transforms, Tensor v_means2d, Tensor v_depths, Tensor v_ray_transforms, Tensor v_normals, bool viewmats_requires_grad) -> (Tensor, Tensor, Tensor, Tensor?)",
     "rasterize_to_pixels_2dgs": "(Tensor means2d, Tensor ray_transforms, Tensor colors, Tensor opacities, Tensor normals, Tensor densify, Tensor? backgrounds, Tensor? masks, int image_width, int image_height, int tile_size, Tensor tile_offsets, Tensor flatten_ids, bool packed, bool absgrad, bool distloss) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
     "rasterize_to_pixels_2dgs_bwd": "(Tensor means2d, Tensor ray_transforms, Tensor colors, Tensor opacities, Tensor normals, Tensor densify, Tensor? backgrounds, Tensor? masks, Tensor tile_offsets, Tensor flatten_ids, Tensor render_colors, Tensor render_alphas, Tensor last_ids, Tensor median_ids, int image_width, int image_height, int tile_size, bool absgrad, Tensor v_render_colors, Tensor v_render_alphas, Tensor v_render_normals, Tensor v_render_distort, Tensor v_render_median, bool compute_v_backgrounds) -> (Tensor?, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor?)",
+    # training-step ops around the rasterizer: ext.cpp:1217-1221, 1224-1227, 1256-1258
+    "adam": "(Tensor(a!) param, Tensor param_grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor? valid, float lr, float b1, float b2, float eps) -> ()",
+    "relocation": "(Tensor opacities, Tensor scales, Tensor ratios, Tensor binoms, int n_max, float min_opacity=0.0) -> (Tensor, Tensor)",
+    "mcmc_perturb_positions": "(Tensor(a!) positions, Tensor quats, Tensor scales, Tensor opacities, Tensor noise, float noise_scale, float t, float k) -> ()",
 }
 
 _impls = {}
@@ -838,6 +842,49 @@ def rasterize_to_pixels_2dgs_bwd(means2d, ray_transforms, colors, opacities, nor
     if backgrounds is not None and compute_v_backgrounds:
         v_backgrounds = (v_render_colors * (1.0 - render_alphas)).sum(dim=(-3, -2))
     return v_abs, v_means2d, v_rt, v_colors, v_opacities, v_normals, v_densify, v_backgrounds
+
+
+# ----------------------------------------------------------------------------------------------
+# training-step ops (optimizer / MCMC), reference gsplat/cuda/_wrapper.py:419-435, gsplat/relocation.py
+# ----------------------------------------------------------------------------------------------
+@_op("adam")
+def adam(param, param_grad, exp_avg, exp_avg_sq, valid, lr, b1, b2, eps):
+    _check_f32(param=param, param_grad=param_grad, exp_avg=exp_avg, exp_avg_sq=exp_avg_sq)
+    for name, t in (("param", param), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        if not t.is_contiguous():
+            raise ValueError(f"adam: {name} is updated in place and must be contiguous")
+    n_rows = param.shape[0] if param.dim() > 0 else 1
+    width = param.numel() // n_rows if n_rows > 0 else 0
+    if valid is not None:
+        if valid.dtype != torch.bool or valid.numel() != n_rows:
+            raise ValueError("adam: valid must be a bool tensor with one entry per row of param")
+        valid = valid.contiguous()
+    call("gsx_adam", ptr(param), ptr(param_grad.contiguous()), ptr(exp_avg), ptr(exp_avg_sq), ptr(valid), n_rows, width,
+         float(lr), float(b1), float(b2), float(eps))
+
+
+@_op("relocation")
+def relocation(opacities, scales, ratios, binoms, n_max, min_opacity=0.0):
+    _check_f32(opacities=opacities, scales=scales, binoms=binoms)
+    n = opacities.shape[0]
+    if scales.shape != (n, 3) or ratios.shape != (n,):
+        raise ValueError("relocation: scales must be [N, 3] and ratios [N]")
+    opacities, scales, binoms = opacities.contiguous(), scales.contiguous(), binoms.contiguous()
+    ratios = ratios.to(torch.int32).contiguous()
+    new_opacities, new_scales = torch.empty_like(opacities), torch.empty_like(scales)
+    call("gsx_relocation", ptr(opacities), ptr(scales), ptr(ratios), ptr(binoms), n, int(n_max), float(min_opacity),
+         ptr(new_opacities), ptr(new_scales))
+    return new_opacities, new_scales
+
+
+@_op("mcmc_perturb_positions")
+def mcmc_perturb_positions(positions, quats, scales, opacities, noise, noise_scale, t, k):
+    _check_f32(positions=positions, quats=quats, scales=scales, opacities=opacities, noise=noise)
+    if not positions.is_contiguous():
+        raise ValueError("mcmc_perturb_positions: positions is updated in place and must be contiguous")
+    n = positions.shape[0]
+    call("gsx_mcmc_perturb", ptr(positions), ptr(quats.contiguous()), ptr(scales.contiguous()),
+         ptr(opacities.reshape(-1).contiguous()), ptr(noise.contiguous()), n, float(noise_scale), float(t), float(k))
 
 
 # ----------------------------------------------------------------------------------------------

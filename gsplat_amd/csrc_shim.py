@@ -28,8 +28,8 @@ class RendererConfig(enum.IntEnum):  # ext.cpp:66-77
 
 def build_config() -> dict:
     has_2dgs = "rasterize_to_pixels_2dgs" in _ops.SCHEMAS
-    return {"3dgs": True, "2dgs": has_2dgs, "3dgut": False, "adam": False, "reloc": False, "losses": False,
-            "camera_wrappers": False}
+    return {"3dgs": True, "2dgs": has_2dgs, "3dgut": False, "adam": "adam" in _ops.SCHEMAS,
+            "reloc": "relocation" in _ops.SCHEMAS, "losses": False, "camera_wrappers": False}
 
 
 def null() -> None:  # ext.cpp:82

@@ -340,6 +340,24 @@ int gsx_raster2d_bwd(const float *means2d, const float *ray_transforms, const fl
                      uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows,
                      uint32_t row_stride, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer-side ops of the training step around the rasterizer.
+ * gsx_adam: gsplat::adam (ext.cpp:1217; csrc/AdamCUDA.cu:34-75). In-place fused Adam step without bias correction on
+ *   the rows g of [n_rows, row_width] tensors with valid[g] != 0 (valid NULL = all rows); masked rows keep parameter
+ *   and moments.
+ * gsx_relocation: gsplat::relocation (csrc/RelocationCUDA.cu:34-80; gsplat/relocation.py:23-67), MCMC Eq. 9.
+ *   ratios int32 [n] in [1, n_max], binoms float [n_max, n_max] (binoms[i][k] = C(i, k)).
+ * gsx_mcmc_perturb: gsplat::mcmc_perturb_positions (ext.cpp:1256; csrc/MCMCPerturbCUDA.cu:24-58). In place:
+ *   positions += Sigma (noise * sigmoid(-k (sigmoid(opacities_logit) - t)) * noise_scale), Sigma from quats (wxyz,
+ *   normalised inside) and LOG scales.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_adam(float *param, const float *param_grad, float *exp_avg, float *exp_avg_sq, const uint8_t *valid,
+             int64_t n_rows, uint32_t row_width, float lr, float b1, float b2, float eps, void *stream);
+int gsx_relocation(const float *opacities, const float *scales, const int32_t *ratios, const float *binoms, int64_t n,
+                   int n_max, float min_opacity, float *new_opacities, float *new_scales, void *stream);
+int gsx_mcmc_perturb(float *positions, const float *quats, const float *scales_log, const float *opacities_logit,
+                     const float *noise, int64_t n, float noise_scale, float t, float k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

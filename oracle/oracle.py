@@ -628,3 +628,45 @@ def rasterize_to_indices_2dgs(means2d, ray_transforms, opacities, image_width, i
     g, p, i = (np.zeros(n, np.int64) for _ in range(3))
     lib().gso_raster2d_indices(*args, _p(g), _p(p), _p(i))
     return torch.from_numpy(g), torch.from_numpy(p), torch.from_numpy(i)
+
+
+# --------------------------------------------------------------------------------------------------
+# training-step ops — torch-CPU restatements, TEST INFRASTRUCTURE ONLY
+# --------------------------------------------------------------------------------------------------
+def adam_step(param, grad, exp_avg, exp_avg_sq, valid, lr, b1, b2, eps):
+    """gsplat::adam (gsplat/cuda/csrc/AdamCUDA.cu:34-75): masked Adam step WITHOUT bias correction. Returns new
+    (param, exp_avg, exp_avg_sq); rows with valid == False are returned unchanged."""
+    m = b1 * exp_avg + (1.0 - b1) * grad
+    v = b2 * exp_avg_sq + (1.0 - b2) * grad * grad
+    p = param - lr * m / (torch.sqrt(v) + eps)
+    if valid is not None:
+        sel = valid.reshape((-1,) + (1,) * (param.dim() - 1)).expand_as(param)
+        p, m, v = torch.where(sel, p, param), torch.where(sel, m, exp_avg), torch.where(sel, v, exp_avg_sq)
+    return p, m, v
+
+
+def relocation(opacities, scales, ratios, binoms, min_opacity=0.0):
+    """gsplat::relocation (gsplat/cuda/csrc/RelocationCUDA.cu:34-80), MCMC Eq. 9, evaluated in float64."""
+    import math as _m
+
+    n_max = binoms.shape[0]
+    o = opacities.double()
+    eps32 = float(torch.finfo(torch.float32).eps)
+    new_o = (1.0 - (1.0 - o) ** (1.0 / ratios.double())).clamp(min_opacity, 1.0 - eps32)
+    denom = torch.zeros_like(o)
+    for idx in range(o.shape[0]):
+        s = 0.0
+        for i in range(1, int(ratios[idx]) + 1):
+            for k in range(i):
+                s += float(binoms[i - 1, k]) * ((-1.0) ** k / _m.sqrt(k + 1)) * float(new_o[idx]) ** (k + 1)
+        denom[idx] = s
+    coeff = o / denom
+    return new_o.float(), (coeff[:, None] * scales.double()).float()
+
+
+def mcmc_perturb(positions, quats, scales_log, opacities_logit, noise, noise_scale, t=0.005, k=100.0):
+    """gsplat::mcmc_perturb_positions (gsplat/cuda/csrc/MCMCPerturbCUDA.cu:24-58; torch restatement
+    tests/test_mcmc_perturb.py:22-45 and gsplat/strategy/ops.py:493-511)."""
+    covars, _ = quat_scale_to_covar_preci(quats, torch.exp(scales_log), compute_covar=True, compute_preci=False)
+    w = torch.sigmoid(-float(k) * (torch.sigmoid(opacities_logit) - float(t))) * noise_scale
+    return positions + torch.einsum("bij,bj->bi", covars, noise * w[:, None])

@@ -1,0 +1,239 @@
+"""Training-step components around the rasterizer: fused selective Adam, MCMC relocation and
+noise kernels against the CPU oracle, strategy edits (row bookkeeping of parameters / optimizer state / statistics), and
+a short end-to-end fit (rasterization + SelectiveAdam + DefaultStrategy / MCMCStrategy) whose loss must go down."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import gsplat_amd
+    import gsplat_amd._ops  # noqa: F401  (defines torch.ops.gsplat.*; the package itself loads lazily)
+
+    return gsplat_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.mark.parametrize("shape", [(1000, 3), (777,), (500, 16, 3), (64, 4)])
+@pytest.mark.parametrize("masked", [True, False])
+def test_adam_matches_oracle(G, O, shape, masked):
+    g = torch.Generator().manual_seed(1)
+    p, gr = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    m, v = torch.randn(shape, generator=g) * 0.1, torch.rand(shape, generator=g) * 0.1
+    valid = (torch.rand(shape[0], generator=g) > 0.4) if masked else None
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+    pe, me, ve = O.adam_step(p, gr, m, v, valid, lr, b1, b2, eps)
+    pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    torch.ops.gsplat.adam(pd, gr.to(DEV), md, vd, None if valid is None else valid.to(DEV), lr, b1, b2, eps)
+    torch.testing.assert_close(pd.cpu(), pe, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(md.cpu(), me, rtol=2e-5, atol=5e-7)
+    torch.testing.assert_close(vd.cpu(), ve, rtol=2e-5, atol=5e-7)  # fma contraction on the device
+    if masked:  # masked rows are bit-identical to the inputs
+        assert torch.equal(pd.cpu()[~valid], p[~valid]) and torch.equal(md.cpu()[~valid], m[~valid])
+
+
+def test_selective_adam_optimizer(G, O):
+    torch.manual_seed(0)
+    param = torch.nn.Parameter(torch.randn(300, 3, device=DEV))
+    opt = G.SelectiveAdam([param], eps=1e-8, betas=(0.9, 0.999))
+    vis = torch.rand(300, device=DEV) > 0.5
+    ref_p, ref_m, ref_v = param.detach().cpu().clone(), torch.zeros(300, 3), torch.zeros(300, 3)
+    for _ in range(3):
+        opt.zero_grad()
+        (param ** 2).sum().backward()
+        ref_p, ref_m, ref_v = O.adam_step(ref_p, 2 * ref_p, ref_m, ref_v, vis.cpu(), opt.param_groups[0]["lr"], 0.9, 0.999,
+                                          1e-8)
+        opt.step(vis)
+    torch.testing.assert_close(param.detach().cpu(), ref_p, rtol=1e-5, atol=1e-6)
+
+
+def test_relocation_matches_oracle(G, O):
+    st = G.MCMCStrategy().initialize_state()
+    binoms = st["binoms"]
+    g = torch.Generator().manual_seed(2)
+    n = 400
+    opac = torch.rand(n, generator=g) * 0.98 + 0.01
+    scales = torch.rand(n, 3, generator=g) * 0.1 + 0.01
+    ratios = torch.randint(1, 12, (n,), generator=g)
+    eo, es = O.relocation(opac, scales, ratios, binoms, min_opacity=0.005)
+    no, ns = G.compute_relocation(opac.to(DEV), scales.to(DEV), ratios.to(DEV), binoms.to(DEV), min_opacity=0.005)
+    torch.testing.assert_close(no.cpu(), eo, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(ns.cpu(), es, rtol=2e-3, atol=1e-6)  # alternating binomial sum in fp32
+    # ratio 1 keeps the Gaussian (up to the opacity clamp)
+    one = torch.ones(n, dtype=torch.long)
+    no1, ns1 = G.compute_relocation(opac.to(DEV), scales.to(DEV), one.to(DEV), binoms.to(DEV), min_opacity=0.0)
+    torch.testing.assert_close(no1.cpu(), opac, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ns1.cpu(), scales, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("scaler,t,k", [(0.01, 0.005, 100.0), (1.0, 0.005, 100.0), (0.25, 0.25, 8.0)])
+def test_mcmc_perturb_matches_oracle(G, O, scaler, t, k):
+    """Mirrors the reference's tests/test_mcmc_perturb.py (inputs, tolerances)."""
+    torch.manual_seed(42)
+    n = 1024
+    pos, quats, sl = torch.randn(n, 3), torch.randn(n, 4), torch.randn(n, 3)
+    ol, noise = torch.randn(n), torch.randn(n, 3)
+    exp = O.mcmc_perturb(pos, quats, sl, ol, noise, scaler, t, k)
+    out = pos.to(DEV).clone()
+    torch.ops.gsplat.mcmc_perturb_positions(out, quats.to(DEV), sl.to(DEV), ol.to(DEV), noise.to(DEV), scaler, t, k)
+    torch.testing.assert_close(out.cpu(), exp, atol=1e-4 if scaler >= 1.0 else 1e-5, rtol=1e-3 if scaler >= 1.0 else 1e-4)
+    assert not torch.equal(out.cpu(), pos)
+
+
+def _make_params(n, seed=0, with_opt=True):
+    g = torch.Generator().manual_seed(seed)
+    raw = {
+        "means": torch.randn(n, 3, generator=g),
+        "scales": torch.log(torch.rand(n, 3, generator=g) * 0.05 + 0.01),
+        "quats": torch.randn(n, 4, generator=g),
+        "opacities": torch.logit(torch.rand(n, generator=g) * 0.9 + 0.05),
+        "sh0": torch.rand(n, 1, 3, generator=g),
+    }
+    params = torch.nn.ParameterDict({k: torch.nn.Parameter(v.to(DEV)) for k, v in raw.items()})
+    opts = {k: torch.optim.Adam([{"params": params[k], "lr": 1e-3, "name": k}]) for k in params.keys()}
+    for k in params.keys():  # create optimizer state
+        params[k].grad = torch.ones_like(params[k])
+        opts[k].step()
+        params[k].grad = None
+    return params, opts
+
+
+def _check_consistency(params, opts, n):
+    for k, p in params.items():
+        assert p.shape[0] == n, (k, p.shape)
+        st = opts[k].state[p]
+        assert opts[k].param_groups[0]["params"][0] is p
+        assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+
+
+def test_strategy_ops_bookkeeping(G):
+    from gsplat_amd.strategy import ops
+
+    n = 50
+    params, opts = _make_params(n)
+    state = {"grad2d": torch.arange(n, device=DEV, dtype=torch.float32), "count": torch.ones(n, device=DEV)}
+    mask = torch.zeros(n, dtype=torch.bool, device=DEV)
+    mask[[3, 7, 11]] = True
+    means0 = params["means"].detach().clone()
+    ops.duplicate(params, opts, state, mask)
+    _check_consistency(params, opts, n + 3)
+    assert torch.equal(params["means"][n:], means0[[3, 7, 11]])
+    assert opts["means"].state[params["means"]]["exp_avg"][n:].abs().max() == 0  # fresh moments for the copies
+    assert torch.equal(state["grad2d"][n:], torch.tensor([3.0, 7.0, 11.0], device=DEV))
+    # split: the two selected rows are replaced by 2 samples each, unselected rows first
+    n1 = n + 3
+    mask = torch.zeros(n1, dtype=torch.bool, device=DEV)
+    mask[[0, 5]] = True
+    scales0 = params["scales"].detach().clone()
+    ops.split(params, opts, state, mask, revised_opacity=True)
+    _check_consistency(params, opts, n1 + 2)
+    torch.testing.assert_close(torch.exp(params["scales"][-4:]), (torch.exp(scales0[[0, 5]]) / 1.6).repeat(2, 1))
+    # remove
+    n2 = n1 + 2
+    mask = torch.zeros(n2, dtype=torch.bool, device=DEV)
+    mask[:10] = True
+    ops.remove(params, opts, state, mask)
+    _check_consistency(params, opts, n2 - 10)
+    assert state["count"].shape[0] == n2 - 10
+    # reset_opa
+    ops.reset_opa(params, opts, state, value=0.01)
+    assert torch.sigmoid(params["opacities"]).max() <= 0.01 + 1e-6
+    assert opts["opacities"].state[params["opacities"]]["exp_avg"].abs().max() == 0
+    # MCMC edits
+    binoms = G.MCMCStrategy().initialize_state()["binoms"].to(DEV)
+    n3 = params["means"].shape[0]
+    with torch.no_grad():
+        params["opacities"].copy_(torch.logit(torch.rand(n3, device=DEV) * 0.8 + 0.1))
+        params["opacities"][:5] = -10.0  # dead
+    dead = torch.sigmoid(params["opacities"]) <= 0.005
+    assert int(dead.sum()) == 5
+    ops.relocate(params, opts, {}, dead, binoms, min_opacity=0.005)
+    _check_consistency(params, opts, n3)
+    assert (torch.sigmoid(params["opacities"]) > 0.004).all()  # the dead ones now sit on live Gaussians
+    ops.sample_add(params, opts, {}, 7, binoms, min_opacity=0.005)
+    _check_consistency(params, opts, n3 + 7)
+    m_before = params["means"].detach().clone()
+    ops.inject_noise_to_position(params, opts, {}, scaler=0.5)
+    assert not torch.equal(params["means"].detach(), m_before)
+    assert torch.isfinite(params["means"]).all()
+
+
+def _target_scene(G, n=600, W=128, H=96, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    means = torch.stack([(torch.rand(n, generator=g) - 0.5) * 2.0, (torch.rand(n, generator=g) - 0.5) * 1.5,
+                         torch.rand(n, generator=g) * 2.0 + 3.0], -1)
+    sc = dict(means=means, quats=torch.randn(n, 4, generator=g), scales=torch.log(torch.rand(n, 3, generator=g) * 0.08 + 0.03),
+              opacities=torch.logit(torch.rand(n, generator=g) * 0.6 + 0.3), colors=torch.rand(n, 3, generator=g))
+    viewmats = torch.eye(4)[None].to(DEV)
+    Ks = torch.tensor([[[120.0, 0, W / 2], [0, 120.0, H / 2], [0, 0, 1]]], device=DEV)
+    return {k: v.to(DEV) for k, v in sc.items()}, viewmats, Ks, W, H
+
+
+def _render(G, p, viewmats, Ks, W, H, **kw):
+    return G.rasterization(p["means"], p["quats"], torch.exp(p["scales"]), torch.sigmoid(p["opacities"]), p["colors"],
+                           viewmats, Ks, W, H, **kw)
+
+
+@pytest.mark.parametrize("which", ["default", "default_absgrad_packed", "mcmc"])
+def test_short_fit_loss_decreases(G, which):
+    """rasterization() + SelectiveAdam + a densification strategy fit a target image: the loss must drop by half and the
+    strategy must have edited the Gaussian set without breaking the parameter / optimizer bookkeeping."""
+    torch.manual_seed(0)
+    tgt, viewmats, Ks, W, H = _target_scene(G)
+    with torch.no_grad():
+        target, _, _ = _render(G, tgt, viewmats, Ks, W, H)
+    n0 = 300
+    g = torch.Generator().manual_seed(9)
+    init = dict(means=torch.stack([(torch.rand(n0, generator=g) - 0.5) * 2.0, (torch.rand(n0, generator=g) - 0.5) * 1.5,
+                                   torch.rand(n0, generator=g) * 2.0 + 3.0], -1),
+                quats=torch.randn(n0, 4, generator=g), scales=torch.log(torch.full((n0, 3), 0.06)),
+                opacities=torch.logit(torch.full((n0,), 0.3)), colors=torch.rand(n0, 3, generator=g))
+    params = torch.nn.ParameterDict({k: torch.nn.Parameter(v.to(DEV)) for k, v in init.items()})
+    lrs = dict(means=2e-2, quats=1e-2, scales=2e-2, opacities=5e-2, colors=5e-2)
+    opts = {k: G.SelectiveAdam([{"params": params[k], "lr": lrs[k], "name": k}], eps=1e-15, betas=(0.9, 0.999))
+            for k in params.keys()}
+    packed = which == "default_absgrad_packed"
+    absgrad = which == "default_absgrad_packed"
+    if which == "mcmc":
+        strategy = G.MCMCStrategy(cap_max=600, refine_start_iter=20, refine_every=20, noise_lr=5e3)
+        state = strategy.initialize_state()
+    else:
+        strategy = G.DefaultStrategy(refine_start_iter=20, refine_every=20, reset_every=10_000, grow_grad2d=2e-5,
+                                     absgrad=absgrad, prune_opa=0.01)
+        state = strategy.initialize_state(scene_scale=1.0)
+    strategy.check_sanity(params, opts)
+    losses, sizes = [], set()
+    for step in range(121):
+        colors, alphas, info = _render(G, params, viewmats, Ks, W, H, packed=packed, absgrad=absgrad)
+        loss = ((colors - target) ** 2).mean()
+        if which != "mcmc":
+            strategy.step_pre_backward(params, opts, state, step, info)
+        loss.backward()
+        losses.append(float(loss))
+        vis = (info["radii"] > 0).all(-1).any(0) if not packed else torch.zeros(
+            len(params["means"]), dtype=torch.bool, device=DEV).index_fill_(0, info["gaussian_ids"], True)
+        for o in opts.values():
+            o.step(vis)
+            o.zero_grad(set_to_none=True)
+        if which == "mcmc":
+            strategy.step_post_backward(params, opts, state, step, info, lr=lrs["means"])
+        else:
+            strategy.step_post_backward(params, opts, state, step, info, packed=packed)
+        sizes.add(len(params["means"]))
+        _check_consistency(params, opts, len(params["means"]))
+    assert all(math.isfinite(x) for x in losses)
+    assert min(losses[-10:]) < 0.5 * losses[0], (losses[0], losses[-10:])
+    assert len(sizes) > 1, "the strategy never changed the number of Gaussians"
