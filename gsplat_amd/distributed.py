@@ -113,6 +113,34 @@ def _all_to_all_rows(data: Tensor, in_splits: List[int], out_splits: List[int]) 
     return out
 
 
+class _ExchangeRows(torch.autograd.Function):
+    """Seam B as ONE collective each way: the float payload and the int32 radii (bit-cast to float32 columns) cross the
+    all-to-all in a single message, so a step pays one collective launch / rendezvous in forward instead of two; the
+    backward sends only the payload gradient (the radii carry none). Same result as two ``all_to_all_single`` calls
+    (reference DistributedCollectives.cpp:368-453 sends radii, geometry and ids separately)."""
+
+    @staticmethod
+    def forward(ctx, payload: Tensor, radii: Tensor, in_splits: List[int], out_splits: List[int]):
+        F_ = payload.shape[1]
+        buf = torch.cat([payload, radii.contiguous().view(torch.float32)], dim=1)  # [rows, F + 2]
+        out = torch.empty((sum(out_splits), F_ + 2), dtype=payload.dtype, device=payload.device)
+        dist.all_to_all_single(out, buf, out_splits, in_splits)
+        ctx.splits = (in_splits, out_splits)
+        recv_r = out[:, F_:].contiguous().view(torch.int32)
+        ctx.mark_non_differentiable(recv_r)
+        return out[:, :F_], recv_r
+
+    @staticmethod
+    def backward(ctx, v_payload: Tensor, _v_radii):
+        in_splits, out_splits = ctx.splits
+        if v_payload is None:
+            return None, None, None, None
+        v_payload = v_payload.contiguous()
+        back = torch.empty((sum(in_splits), v_payload.shape[1]), dtype=v_payload.dtype, device=v_payload.device)
+        dist.all_to_all_single(back, v_payload, in_splits, out_splits)
+        return back, None, None, None
+
+
 # ----------------------------------------------------------------------------------------------
 # control plane: per-call exchange of (Gaussians, cameras) per rank
 # ----------------------------------------------------------------------------------------------
@@ -230,20 +258,17 @@ class DistributedRasterContext:
         payload = torch.cat(floats, dim=-1)  # [..., 7 + D]
         if not packed:
             Nl = self.n_local
-            if W == 1:
-                out_f, out_r = payload, radii
+            in_s = [Cl * Nl] * W
+            out_s = [Cl * n for n in self.n_per_rank]
+            recv_f, recv_r = _ExchangeRows.apply(payload.reshape(W * Cl * Nl, -1), radii.reshape(W * Cl * Nl, 2), in_s,
+                                                 out_s)
+            # source rank i contributed [C_local, N_i, F]; concatenate along the Gaussian axis (with one camera per
+            # rank the received buffer already IS [1, sum N_i, F])
+            if Cl == 1:
+                out_f, out_r = recv_f.reshape(1, -1, recv_f.shape[-1]), recv_r.reshape(1, -1, 2)
             else:
-                in_s = [Cl * Nl] * W
-                out_s = [Cl * n for n in self.n_per_rank]
-                recv_f = _all_to_all_rows(payload.reshape(W * Cl * Nl, -1), in_s, out_s)
-                recv_r = _all_to_all_rows(radii.reshape(W * Cl * Nl, 2), in_s, out_s)
-                # source rank i contributed [C_local, N_i, F]; concatenate along the Gaussian axis (with one camera
-                # per rank the received buffer already IS [1, sum N_i, F])
-                if Cl == 1:
-                    out_f, out_r = recv_f.reshape(1, -1, recv_f.shape[-1]), recv_r.reshape(1, -1, 2)
-                else:
-                    out_f = torch.cat([p.reshape(Cl, n, -1) for p, n in zip(recv_f.split(out_s), self.n_per_rank)], dim=1)
-                    out_r = torch.cat([p.reshape(Cl, n, 2) for p, n in zip(recv_r.split(out_s), self.n_per_rank)], dim=1)
+                out_f = torch.cat([p.reshape(Cl, n, -1) for p, n in zip(recv_f.split(out_s), self.n_per_rank)], dim=1)
+                out_r = torch.cat([p.reshape(Cl, n, 2) for p, n in zip(recv_r.split(out_s), self.n_per_rank)], dim=1)
             pieces = out_f.split(widths, dim=-1)
             m2, dp, cn, op = pieces[0], pieces[1][..., 0], pieces[2], pieces[3][..., 0]
             ft = pieces[4] if feats is not None else None
@@ -252,13 +277,9 @@ class DistributedRasterContext:
         dest = torch.div(camera_ids, Cl, rounding_mode="floor")
         in_s = torch.bincount(dest, minlength=W).tolist()
         ids = torch.stack([camera_ids - dest * Cl, gaussian_ids + self.gaussian_offset], dim=-1)  # int64 [nnz,2]
-        if W == 1:
-            recv_f, recv_r, recv_i = payload, radii, ids
-        else:
-            out_s = all_to_all_int32(W, in_s, device=payload.device)
-            recv_f = _all_to_all_rows(payload, in_s, out_s)
-            recv_r = _all_to_all_rows(radii, in_s, out_s)
-            recv_i = _all_to_all_rows(ids, in_s, out_s)
+        out_s = all_to_all_int32(W, in_s, device=payload.device)
+        recv_f, recv_r = _ExchangeRows.apply(payload, radii, in_s, out_s)
+        recv_i = _all_to_all_rows(ids, in_s, out_s)
         pieces = recv_f.split(widths, dim=-1)
         m2, dp, cn, op = pieces[0], pieces[1][..., 0], pieces[2], pieces[3][..., 0]
         ft = pieces[4] if feats is not None else None
