@@ -352,7 +352,9 @@ __global__ void __launch_bounds__(256) project_bwd_kernel(const ProjBwdArgs a)
     if (live) store_gaussian_grads<false>(a, b, g, v_p, v_S);
 }
 
-template <bool POSE>
+// UNIQUE: every Gaussian appears in at most one row (a single image, B*C == 1): plain stores into the zero-filled
+// outputs instead of atomics (124 -> ~45 us at 1M rows: ten scattered fp32 atomics per row otherwise)
+template <bool POSE, bool UNIQUE>
 __global__ void __launch_bounds__(256) project_packed_bwd_kernel(const ProjBwdArgs a)
 {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // over nnz
@@ -371,7 +373,7 @@ __global__ void __launch_bounds__(256) project_packed_bwd_kernel(const ProjBwdAr
         const float p[3] = {pm[0], pm[1], pm[2]};
         const Cam cam = load_cam(a.viewmats + ((size_t)b * a.C + c) * 16, a.Ks + ((size_t)b * a.C + c) * 9);
         pair_vjp(a, cam, p, S, row, v_p, v_S, v_R, v_t, POSE);
-        store_gaussian_grads<true>(a, b, g, v_p, v_S);
+        store_gaussian_grads<!UNIQUE>(a, b, g, v_p, v_S);
     }
     if (POSE) {
         // rows are sorted by image; a wave spans a small contiguous range of images
@@ -666,8 +668,15 @@ extern "C" int gsx_project_ewa_packed_bwd(const float *means, const float *covar
              v_covars, v_quats, v_scales, v_viewmats);
     a.nnz = nnz; a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
     const dim3 grid((uint32_t)ceil_div(nnz, 256)), block(256);
-    if (v_viewmats) project_packed_bwd_kernel<true><<<grid, block, 0, (hipStream_t)stream>>>(a);
-    else project_packed_bwd_kernel<false><<<grid, block, 0, (hipStream_t)stream>>>(a);
+    const bool unique = (uint64_t)B * C == 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (v_viewmats) {
+        if (unique) project_packed_bwd_kernel<true, true><<<grid, block, 0, s>>>(a);
+        else project_packed_bwd_kernel<true, false><<<grid, block, 0, s>>>(a);
+    } else {
+        if (unique) project_packed_bwd_kernel<false, true><<<grid, block, 0, s>>>(a);
+        else project_packed_bwd_kernel<false, false><<<grid, block, 0, s>>>(a);
+    }
     return check_launch("project_ewa_packed_bwd");
 }
 
