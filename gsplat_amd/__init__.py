@@ -15,6 +15,8 @@ _LAZY = {
     "quat_scale_to_covar_preci": "_wrapper", "rasterize_to_pixels": "_wrapper", "spherical_harmonics": "_wrapper",
     "fully_fused_projection_2dgs": "_wrapper", "rasterize_to_pixels_2dgs": "_wrapper", "proj": "_wrapper",
     "spherical_harmonics_l0": "_wrapper", "spherical_harmonics_l1_plus": "_wrapper",
+    "rasterize_num_contributing_gaussians": "_wrapper", "rasterize_contributing_gaussian_ids": "_wrapper",
+    "rasterize_top_contributing_gaussian_ids": "_wrapper",
     "rasterize_to_indices_in_range": "_wrapper", "rasterize_to_indices_in_range_2dgs": "_wrapper",
     "rasterization": "rendering", "rasterization_2dgs": "rendering", "distributed": "distributed",
     # the training step around the rasterizer

@@ -62,6 +62,10 @@ SCHEMAS = {
     "projection_2dgs_packed_bwd": "(Tensor means, Tensor quats, Tensor scales, Tensor viewmats, Tensor Ks, int image_width, int image_height, bool sparse_grad, Tensor batch_ids, Tensor camera_ids, Tensor gaussian_ids, Tensor ray_transforms, Tensor v_means2d, Tensor v_depths, Tensor v_ray_transforms, Tensor v_normals, bool viewmats_requires_grad) -> (Tensor, Tensor, Tensor, Tensor?)",
     "rasterize_to_pixels_2dgs": "(Tensor means2d, Tensor ray_transforms, Tensor colors, Tensor opacities, Tensor normals, Tensor densify, Tensor? backgrounds, Tensor? masks, int image_width, int image_height, int tile_size, Tensor tile_offsets, Tensor flatten_ids, bool packed, bool absgrad, bool distloss) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
     "rasterize_to_pixels_2dgs_bwd": "(Tensor means2d, Tensor ray_transforms, Tensor colors, Tensor opacities, Tensor normals, Tensor densify, Tensor? backgrounds, Tensor? masks, Tensor tile_offsets, Tensor flatten_ids, Tensor render_colors, Tensor render_alphas, Tensor last_ids, Tensor median_ids, int image_width, int image_height, int tile_size, bool absgrad, Tensor v_render_colors, Tensor v_render_alphas, Tensor v_render_normals, Tensor v_render_distort, Tensor v_render_median, bool compute_v_backgrounds) -> (Tensor?, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor?)",
+    # query rasterizers, dense tile layout: ext.cpp:1111-1134
+    "rasterize_num_contributing_gaussians": "(Tensor means2d, Tensor conics, Tensor opacities, Tensor tile_offsets, Tensor flatten_ids, int image_width, int image_height, int tile_size) -> (Tensor, Tensor)",
+    "rasterize_contributing_gaussian_ids": "(Tensor means2d, Tensor conics, Tensor opacities, Tensor tile_offsets, Tensor flatten_ids, int image_width, int image_height, int tile_size, Tensor num_contributing_gaussians) -> (Tensor, Tensor)",
+    "rasterize_top_contributing_gaussian_ids": "(Tensor means2d, Tensor conics, Tensor opacities, Tensor tile_offsets, Tensor flatten_ids, int image_width, int image_height, int tile_size, int num_depth_samples) -> (Tensor, Tensor)",
     # training-step ops around the rasterizer: ext.cpp:1217-1221, 1224-1227, 1256-1258
     "adam": "(Tensor(a!) param, Tensor param_grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor? valid, float lr, float b1, float b2, float eps) -> ()",
     "relocation": "(Tensor opacities, Tensor scales, Tensor ratios, Tensor binoms, int n_max, float min_opacity=0.0) -> (Tensor, Tensor)",
@@ -842,6 +846,57 @@ def rasterize_to_pixels_2dgs_bwd(means2d, ray_transforms, colors, opacities, nor
     if backgrounds is not None and compute_v_backgrounds:
         v_backgrounds = (v_render_colors * (1.0 - render_alphas)).sum(dim=(-3, -2))
     return v_abs, v_means2d, v_rt, v_colors, v_opacities, v_normals, v_densify, v_backgrounds
+
+
+# ----------------------------------------------------------------------------------------------
+# query rasterizers (reference gsplat/cuda/_wrapper.py:1668-1941, dense variants)
+# ----------------------------------------------------------------------------------------------
+def _query_common(means2d, conics, opacities, tile_offsets, flatten_ids, image_width, image_height, tile_size):
+    _check_f32(means2d=means2d, conics=conics, opacities=opacities)
+    image_dims = tuple(tile_offsets.shape[:-2])
+    I, th, tw = math.prod(image_dims), tile_offsets.shape[-2], tile_offsets.shape[-1]
+    if th * tile_size < image_height or tw * tile_size < image_width:
+        raise ValueError("tile grid does not cover the image")
+    packed = means2d.dim() == 2
+    n_per = 0 if packed else means2d.shape[-2]
+    args = (ptr(means2d.contiguous()), ptr(conics.contiguous()), ptr(opacities.contiguous()),
+            ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), I, flatten_ids.numel(), n_per, image_width,
+            image_height, tile_size, tw, th)
+    return image_dims + (image_height, image_width), args
+
+
+@_op("rasterize_num_contributing_gaussians")
+def rasterize_num_contributing_gaussians(means2d, conics, opacities, tile_offsets, flatten_ids, image_width,
+                                         image_height, tile_size):
+    hw, args = _query_common(means2d, conics, opacities, tile_offsets, flatten_ids, image_width, image_height, tile_size)
+    counts = torch.empty(hw, device=means2d.device, dtype=torch.int32)
+    alphas = torch.empty(hw, device=means2d.device, dtype=means2d.dtype)
+    call("gsx_raster3d_num_contributing", *args, ptr(counts), ptr(alphas))
+    return counts, alphas
+
+
+@_op("rasterize_contributing_gaussian_ids")
+def rasterize_contributing_gaussian_ids(means2d, conics, opacities, tile_offsets, flatten_ids, image_width, image_height,
+                                        tile_size, num_contributing_gaussians):
+    hw, args = _query_common(means2d, conics, opacities, tile_offsets, flatten_ids, image_width, image_height, tile_size)
+    # padded to the largest per-pixel count (host read, as the reference: RasterizeContributingGaussianIds.cu host fn)
+    kmax = int(num_contributing_gaussians.max().item()) if num_contributing_gaussians.numel() > 0 else 0
+    ids = torch.full(hw + (kmax,), -1, device=means2d.device, dtype=torch.int32)
+    weights = torch.zeros(hw + (kmax,), device=means2d.device, dtype=means2d.dtype)
+    call("gsx_raster3d_contributing_ids", *args, kmax, ptr(ids), ptr(weights))
+    return ids, weights
+
+
+@_op("rasterize_top_contributing_gaussian_ids")
+def rasterize_top_contributing_gaussian_ids(means2d, conics, opacities, tile_offsets, flatten_ids, image_width,
+                                            image_height, tile_size, num_depth_samples):
+    hw, args = _query_common(means2d, conics, opacities, tile_offsets, flatten_ids, image_width, image_height, tile_size)
+    if num_depth_samples < 0:
+        raise ValueError("num_depth_samples must be >= 0")
+    ids = torch.empty(hw + (num_depth_samples,), device=means2d.device, dtype=torch.int32)
+    weights = torch.empty(hw + (num_depth_samples,), device=means2d.device, dtype=means2d.dtype)
+    call("gsx_raster3d_top_contributing", *args, num_depth_samples, ptr(ids), ptr(weights))
+    return ids, weights
 
 
 # ----------------------------------------------------------------------------------------------

@@ -309,3 +309,35 @@ def rasterize_to_indices_in_range_2dgs(range_start: int, range_end: int, transmi
     return _ops.rasterize_to_indices_2dgs(range_start, range_end, transmittances.contiguous(), means2d.contiguous(),
                                           ray_transforms.contiguous(), opacities.contiguous(), image_width,
                                           image_height, tile_size, isect_offsets.contiguous(), flatten_ids.contiguous())
+
+
+@torch.no_grad()
+def rasterize_num_contributing_gaussians(means2d: Tensor, conics: Tensor, opacities: Tensor, tile_offsets: Tensor,
+                                         flatten_ids: Tensor, image_width: int, image_height: int, tile_size: int):
+    """(number of contributing Gaussians int32 [..., H, W], rendered alphas [..., H, W]) — reference
+    ``_wrapper.py:1668-1707``."""
+    return _ops.rasterize_num_contributing_gaussians(means2d.contiguous(), conics.contiguous(), opacities.contiguous(),
+                                                     tile_offsets.contiguous(), flatten_ids.contiguous(), image_width,
+                                                     image_height, tile_size)
+
+
+@torch.no_grad()
+def rasterize_contributing_gaussian_ids(means2d: Tensor, conics: Tensor, opacities: Tensor, tile_offsets: Tensor,
+                                        flatten_ids: Tensor, image_width: int, image_height: int, tile_size: int,
+                                        num_contributing_gaussians: Tensor):
+    """All contributing Gaussian ids and radiance weights per pixel, front to back, padded with (-1, 0) to
+    ``num_contributing_gaussians.max()`` — reference ``_wrapper.py:1776-1822``."""
+    return _ops.rasterize_contributing_gaussian_ids(means2d.contiguous(), conics.contiguous(), opacities.contiguous(),
+                                                    tile_offsets.contiguous(), flatten_ids.contiguous(), image_width,
+                                                    image_height, tile_size, num_contributing_gaussians.contiguous())
+
+
+@torch.no_grad()
+def rasterize_top_contributing_gaussian_ids(means2d: Tensor, conics: Tensor, opacities: Tensor, tile_offsets: Tensor,
+                                            flatten_ids: Tensor, image_width: int, image_height: int, tile_size: int,
+                                            num_depth_samples: int):
+    """The ``num_depth_samples`` strongest contributors (by alpha * T) per pixel, in front-to-back order —
+    reference ``_wrapper.py:1895-1940``."""
+    return _ops.rasterize_top_contributing_gaussian_ids(means2d.contiguous(), conics.contiguous(), opacities.contiguous(),
+                                                        tile_offsets.contiguous(), flatten_ids.contiguous(), image_width,
+                                                        image_height, tile_size, num_depth_samples)

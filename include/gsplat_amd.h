@@ -341,6 +341,33 @@ int gsx_raster2d_bwd(const float *means2d, const float *ray_transforms, const fl
                      uint32_t row_stride, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Query rasterizers (dense tile layout): gsplat::rasterize_num_contributing_gaussians,
+ * rasterize_contributing_gaussian_ids, rasterize_top_contributing_gaussian_ids (ext.cpp:1111-1134; kernels
+ * RasterizeContributingCommon.cuh:28-198 + the three accumulators). Same walk and thresholds as gsx_raster3d_fwd.
+ * n_per_image = N for dense rows [I*N] (returned ids are row % N), 0 for packed rows (ids are the rows).
+ *   num_contributing: counts int32 [I,H,W] and alphas float [I,H,W].
+ *   contributing_ids: ids int32 / weights float [I,H,W,max_contributing], PRE-FILLED by the caller with -1 / 0; the first
+ *     min(count, max_contributing) slots of a pixel receive (id, alpha*T) front to back.
+ *   top_contributing: the num_depth_samples strongest contributors by alpha*T (a new sample replaces the weakest kept one
+ *     only if strictly stronger; first weakest on ties), re-sorted front to back, padded with (-1, 0).
+ * ------------------------------------------------------------------------------------------- */
+int gsx_raster3d_num_contributing(const float *means2d, const float *conics, const float *opacities,
+                                  const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images,
+                                  uint32_t n_isects, uint32_t n_per_image, uint32_t width, uint32_t height,
+                                  uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int32_t *counts, float *alphas,
+                                  void *stream);
+int gsx_raster3d_contributing_ids(const float *means2d, const float *conics, const float *opacities,
+                                  const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images,
+                                  uint32_t n_isects, uint32_t n_per_image, uint32_t width, uint32_t height,
+                                  uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, uint32_t max_contributing,
+                                  int32_t *ids, float *weights, void *stream);
+int gsx_raster3d_top_contributing(const float *means2d, const float *conics, const float *opacities,
+                                  const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images,
+                                  uint32_t n_isects, uint32_t n_per_image, uint32_t width, uint32_t height,
+                                  uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, uint32_t num_depth_samples,
+                                  int32_t *ids, float *weights, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optimizer-side ops of the training step around the rasterizer.
  * gsx_adam: gsplat::adam (ext.cpp:1217; csrc/AdamCUDA.cu:34-75). In-place fused Adam step without bias correction on
  *   the rows g of [n_rows, row_width] tensors with valid[g] != 0 (valid NULL = all rows); masked rows keep parameter

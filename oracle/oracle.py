@@ -670,3 +670,53 @@ def mcmc_perturb(positions, quats, scales_log, opacities_logit, noise, noise_sca
     covars, _ = quat_scale_to_covar_preci(quats, torch.exp(scales_log), compute_covar=True, compute_preci=False)
     w = torch.sigmoid(-float(k) * (torch.sigmoid(opacities_logit) - float(t))) * noise_scale
     return positions + torch.einsum("bij,bj->bi", covars, noise * w[:, None])
+
+
+# --------------------------------------------------------------------------------------------------
+# query rasterizers — built on rasterize_to_indices; TEST INFRASTRUCTURE ONLY
+# --------------------------------------------------------------------------------------------------
+def raster_contributions(means2d, conics, opacities, image_width, image_height, tile_size, isect_offsets, flatten_ids):
+    """Per pixel, front to back: the local Gaussian ids that contribute and their radiance weights alpha * T
+    (reference RasterizeContributingCommon.cuh:28-198 walk; thresholds of RasterizeToPixels3DGSDevice.cuh:44-56).
+    Returns (lists_of_ids, lists_of_weights, alphas [I,H,W]) with one Python list per pixel (small scenes only)."""
+    gids, pids, iids = rasterize_to_indices(means2d, conics, opacities, image_width, image_height, tile_size, isect_offsets,
+                                            flatten_ids)
+    I = int(np.prod(isect_offsets.shape[:-2]))
+    n_per = means2d.shape[-2]
+    m2 = means2d.reshape(I, n_per, 2).double()
+    cn = conics.reshape(I, n_per, 3).double()
+    op = opacities.reshape(I, n_per).double()
+    px = (pids % image_width).double() + 0.5
+    py = (pids // image_width).double() + 0.5
+    dx, dy = m2[iids, gids, 0] - px, m2[iids, gids, 1] - py
+    c = cn[iids, gids]
+    sigma = 0.5 * (c[:, 0] * dx * dx + c[:, 2] * dy * dy) + c[:, 1] * dx * dy
+    alpha = torch.clamp(op[iids, gids] * torch.exp(-sigma), max=0.99)
+    P = image_width * image_height
+    key = (iids * P + pids).numpy()
+    ids = [[] for _ in range(I * P)]
+    wts = [[] for _ in range(I * P)]
+    T = np.ones(I * P)
+    a_np, g_np = alpha.numpy(), gids.numpy()
+    for j in range(key.shape[0]):  # entries of one pixel are contiguous and in front-to-back order
+        k = key[j]
+        ids[k].append(int(g_np[j]))
+        wts[k].append(float(a_np[j] * T[k]))
+        T[k] *= 1.0 - a_np[j]
+    return ids, wts, torch.from_numpy(1.0 - T).float().reshape(I, image_height, image_width)
+
+
+def top_contributions(ids, wts, K):
+    """Top-K selection rule of RasterizeTopContributingGaussianIds.cu:96-131 applied to per-pixel lists."""
+    out_i = np.full((len(ids), K), -1, dtype=np.int64)
+    out_w = np.zeros((len(ids), K), dtype=np.float64)
+    for p, (li, lw) in enumerate(zip(ids, wts)):
+        sw, sd, si = [0.0] * K, [2 ** 32 - 1] * K, [-1] * K
+        for d, (g, w) in enumerate(zip(li, lw)):
+            kmin = min(range(K), key=lambda k: (sw[k], k))
+            if w > sw[kmin]:
+                sw[kmin], sd[kmin], si[kmin] = w, d, g
+        order = sorted(range(K), key=lambda k: sd[k])  # stable: unused slots (depth 2^32-1) keep their relative order
+        out_i[p] = [si[k] for k in order]
+        out_w[p] = [sw[k] for k in order]
+    return out_i, out_w

@@ -551,3 +551,73 @@ def test_rasterize_to_indices_matches_oracle(G, O):
     g2o, p2o, i2o = O.rasterize_to_indices_2dgs(cpu(m22), cpu(M2), cpu(op), W, H, 16, cpu(off2), cpu(fl2))
     ca, cb = canon(cpu(g2), cpu(p2), cpu(i2)), canon(g2o, p2o, i2o)
     assert ca.shape == cb.shape and (ca != cb).any(-1).float().mean() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# query rasterizers (reference tests/test_basic.py contributing-ids tests compare against the
+# same front-to-back walk)
+@pytest.mark.parametrize("packed", [False, True])
+def test_query_rasterizers_match_oracle(G, O, packed):
+    sc, W, H = make_scene(N=1500, C=2, width=72, height=56, seed=31)
+    a, rad, m2, d, con, op = _project_scene(G, sc, W, H)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    C, N = m2.shape[0], m2.shape[1]
+    if packed:
+        vis = (rad > 0).all(-1)
+        ci, gi = torch.where(vis)
+        rows = ci * N + gi
+        m2p, conp, opp, radp, dp = (t.reshape(C * N, -1)[rows].squeeze(-1) if t.dim() == 2 else t.reshape(C * N, -1)[rows]
+                                    for t in (m2, con, op, rad, d))
+        opp, dp = opp.reshape(-1), dp.reshape(-1)
+        _, ids_s, fl = G.isect_tiles(m2p, radp, dp, 16, tw, th, packed=True, n_images=C, image_ids=ci, gaussian_ids=gi)
+        off = G.isect_offset_encode(ids_s, C, tw, th)
+        args = (m2p, conp, opp, off, fl, W, H, 16)
+    else:
+        _, ids_s, fl = G.isect_tiles(m2, rad, d, 16, tw, th)
+        off = G.isect_offset_encode(ids_s, C, tw, th)
+        args = (m2, con, op, off, fl, W, H, 16)
+    # oracle on the dense layout (same Gaussians; packed ids are rows of the packed arrays -> map back for comparison)
+    _, ids_o, fl_o = O.isect_tiles(cpu(m2), cpu(rad), cpu(d), 16, tw, th)
+    off_o = O.isect_offset_encode(ids_o, C, tw, th)
+    lids, lwts, alphas_o = O.raster_contributions(cpu(m2), cpu(con), cpu(op), W, H, 16, off_o, fl_o)
+    counts_o = torch.tensor([len(x) for x in lids], dtype=torch.int32).reshape(C, H, W)
+
+    counts, alphas = G.rasterize_num_contributing_gaussians(*args)
+    assert counts.dtype == torch.int32 and counts.shape == (C, H, W)
+    bad = (cpu(counts) != counts_o).float().mean().item()
+    assert bad <= 2e-3, f"per-pixel contributor counts differ on {bad:.4%} of the pixels"
+    assert_close_ratio(cpu(alphas), alphas_o, 1e-4, 5e-5, max_bad_ratio=1e-3, name="query alphas")
+
+    ids, wts = G.rasterize_contributing_gaussian_ids(*args, counts)
+    kmax = int(counts.max())
+    assert ids.shape == (C, H, W, kmax) and wts.shape == ids.shape
+    ids_c, wts_c = cpu(ids).reshape(-1, kmax), cpu(wts).reshape(-1, kmax)
+    if packed:  # packed ids are rows of the packed arrays: translate to Gaussian ids
+        gi_c = cpu(gi)
+        ids_c = torch.where(ids_c >= 0, gi_c[ids_c.clamp_min(0)], ids_c)
+    same = cpu(counts).reshape(-1) == counts_o.reshape(-1)
+    n_checked = 0
+    for p in torch.where(same)[0][::7].tolist():  # every 7th pixel with an identical count
+        k = len(lids[p])
+        assert ids_c[p, :k].tolist() == lids[p], p
+        assert (ids_c[p, k:] == -1).all() and (wts_c[p, k:] == 0).all()
+        torch.testing.assert_close(wts_c[p, :k].double(), torch.tensor(lwts[p], dtype=torch.float64), rtol=2e-3, atol=1e-6)
+        n_checked += 1
+    assert n_checked > 200
+
+    K = 4
+    tids, twts = G.rasterize_top_contributing_gaussian_ids(*args, K)
+    assert tids.shape == (C, H, W, K)
+    tids_c, twts_c = cpu(tids).reshape(-1, K), cpu(twts).reshape(-1, K)
+    if packed:
+        tids_c = torch.where(tids_c >= 0, gi_c[tids_c.clamp_min(0)], tids_c)
+    oi, ow = O.top_contributions(lids, lwts, K)
+    pix = torch.where(same)[0]
+    id_match = (tids_c[pix] == torch.from_numpy(oi)[pix]).all(-1).float().mean().item()
+    assert id_match >= 0.995, f"top-{K} ids agree on only {id_match:.4%} of the pixels"  # near-ties in alpha*T may swap
+    agree = pix[(tids_c[pix] == torch.from_numpy(oi)[pix]).all(-1)]
+    torch.testing.assert_close(twts_c[agree].double(), torch.from_numpy(ow)[agree], rtol=2e-3, atol=1e-6)
+    # the kept samples are in front-to-back order: their positions in the full list increase
+    for p in agree[::97].tolist():
+        pos = [lids[p].index(g) for g in tids_c[p].tolist() if g >= 0]
+        assert pos == sorted(pos)
