@@ -290,6 +290,8 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
     const float px = (float)ox + 0.5f, py = (float)oy + 0.5f;
     const size_t pix = inside ? ((size_t)image_id * a.height + oy) * a.width + ox : 0;
     const int nch    = (int)a.cdim;
+    const float X0 = (float)(tile_x * a.tile_size), Y0 = (float)(tile_y * a.tile_size); // tile origin
+    const float plx = px - X0, ply = py - Y0;                                           // tile-local pixel centre
 
     const int32_t range_start = a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id];
     const int32_t range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects
@@ -428,16 +430,18 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
                 const float g3   = use3d ? v_G * -vis : 0.0f;
                 const float a_   = g3 * s.sx * s.rcz_inv, b_ = g3 * s.sy * s.rcz_inv;
                 const float vrc[3] = {a_, b_, -(a_ * s.sx + b_ * s.sy)};
-                const float vhu[3] = {s.hv[1] * vrc[2] - s.hv[2] * vrc[1], s.hv[2] * vrc[0] - s.hv[0] * vrc[2],
-                                      s.hv[0] * vrc[1] - s.hv[1] * vrc[0]};
-                const float vhv[3] = {vrc[1] * s.hu[2] - vrc[2] * s.hu[1], vrc[2] * s.hu[0] - vrc[0] * s.hu[2],
-                                      vrc[0] * s.hu[1] - vrc[1] * s.hu[0]};
+                // The ray-transform gradient is LINEAR in three moments of vrc over the pixels (hu = px w - u,
+                // hv = py w - v):  v_uM = sum -(hv x vrc) = v x S0 - w x Sy,  v_vM = sum -(vrc x hu) = S0 x u - Sx x w,
+                // v_wM = sum px (hv x vrc) + py (vrc x hu) = Sx x v + u x Sy, with S0 = sum vrc, Sx = sum px vrc,
+                // Sy = sum py vrc. Only the moments are reduced (tile-local pixel coordinates keep them small); the
+                // cross products are taken once per (tile, surfel) in the flush instead of once per pixel.
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     // g3 == 0 can still meet inf/NaN geometry on invalid lanes: select, do not multiply
-                    loc[CH + 3 + k] = (use3d && unclamped) ? -vhu[k] : 0.0f;
-                    loc[CH + 6 + k] = (use3d && unclamped) ? -vhv[k] : 0.0f;
-                    loc[CH + 9 + k] = (use3d && unclamped) ? px * vhu[k] + py * vhv[k] : 0.0f;
+                    const float vr  = (use3d && unclamped) ? vrc[k] : 0.0f;
+                    loc[CH + 3 + k] = vr;
+                    loc[CH + 6 + k] = plx * vr;
+                    loc[CH + 9 + k] = ply * vr;
                 }
                 // 2D (low-pass) branch
                 const float g2 = (!use3d && unclamped) ? v_G * (-vis * kFilterInvSquare2DGS) : 0.0f;
@@ -464,7 +468,8 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
         __syncthreads();
 
         // transposed flush into the AoS gradient rows: element e -> (surfel s, output column c); accumulator slots:
-        // [0,CH) colours | CH..CH+2 normals | CH+3..CH+11 ray transform | CH+12,13 means2d | CH+14 opacity | CH+15,16 abs
+        // [0,CH) colours | CH..CH+2 normals | CH+3..5 S0, CH+6..8 S_lx, CH+9..11 S_ly (moments of vrc, tile-local) |
+        // CH+12,13 means2d | CH+14 opacity | CH+15,16 abs
         constexpr int GEO  = 17 + (ABS ? 2 : 0);
         constexpr int NCOL = GEO + CH;
         for (int e = (int)tid; e < batch_size * NCOL; e += (int)blockDim.x) {
@@ -475,9 +480,24 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
             int col = c;
             if (c < 2) val = row[CH + 12 + c];                               // v_means2d
             else if (c == 2) val = row[CH + 14];                             // v_opacities
-            else if (c < 5) val = row[CH + 3 + 3 * (c - 3) + 2] * s_C[s].z;  // v_densify = (v_uM.z, v_vM.z) * w_M.z
-            else if (c < 8) val = row[CH + (c - 5)];                         // v_normals
-            else if (c < 17) val = row[CH + 3 + (c - 8)];                    // v_ray_transforms
+            else if (c < 5 || (c >= 8 && c < 17)) {
+                // component k of row r (0 = u_M, 1 = v_M, 2 = w_M) of the ray-transform gradient from the moments;
+                // v_densify (columns 3, 4) = (v_uM.z, v_vM.z) * w_M.z
+                const int r = c < 5 ? c - 3 : (c - 8) / 3, k = c < 5 ? 2 : (c - 8) % 3;
+                const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+                const float4 A4 = s_A[s], B4 = s_B[s], C4 = s_C[s];
+                auto pick = [](const float4 &q, int i) { return i == 0 ? q.x : (i == 1 ? q.y : q.z); }; // no scratch
+                const float u1 = pick(A4, k1), u2 = pick(A4, k2), v1 = pick(B4, k1), v2 = pick(B4, k2);
+                const float w1 = pick(C4, k1), w2 = pick(C4, k2);
+                const float s01 = row[CH + 3 + k1], s02 = row[CH + 3 + k2];
+                const float sx1 = X0 * s01 + row[CH + 6 + k1], sx2 = X0 * s02 + row[CH + 6 + k2];
+                const float sy1 = Y0 * s01 + row[CH + 9 + k1], sy2 = Y0 * s02 + row[CH + 9 + k2];
+                // (p x q)_k = p_k1 q_k2 - p_k2 q_k1
+                if (r == 0) val = (v1 * s02 - v2 * s01) - (w1 * sy2 - w2 * sy1);      // v_uM = v x S0 - w x Sy
+                else if (r == 1) val = (s01 * u2 - s02 * u1) - (sx1 * w2 - sx2 * w1); // v_vM = S0 x u - Sx x w
+                else val = (sx1 * v2 - sx2 * v1) + (u1 * sy2 - u2 * sy1);             // v_wM = Sx x v + u x Sy
+                if (c < 5) val *= C4.z;
+            } else if (c < 8) val = row[CH + (c - 5)];               // v_normals
             else if (c < GEO) val = row[CH + 15 + (c - 17)];                 // |v_means2d|
             else {
                 const int k = c - GEO;
