@@ -226,6 +226,20 @@ def main():
         "note": "compositing is VALU/exp/atomic-bound, not HBM-bound (SURVEY.md 8(d)); see DESIGN.md",
     }
 
+    # HBM-bound stages: algorithmic bytes / measured stage time, against the same 8 TB/s peak
+    K_sh, N_rows = 16, n_local * (n_cams * n_gpus if distributed else n_cams)
+    stage_bytes = {
+        "gsx_project_ewa_fwd": 44 * n_local + 32 * V + 8 * N_rows,
+        "gsx_project_ewa_bwd": 88 * V + 40 * n_local,
+        "gsx_sh_fwd": (4 * K_sh * D + 12) * V + 4 * D * V,
+        "gsx_sh_bwd": (4 * K_sh * D + 12 + 4 * D) * V + 4 * K_sh * D * n_local,
+    }
+    stage_roofline = {}
+    for k, nbytes in stage_bytes.items():
+        if per_step_ms.get(k):
+            gbs = nbytes / (per_step_ms[k] * 1e-3) / 1e9
+            stage_roofline[k.replace("gsx_", "")] = {"achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
     result = {
         "metric": "Mpixels/s fwd+bwd @1M Gaussians/1080p",
         "value": round(mpix_s, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -240,6 +254,7 @@ def main():
                    "parallelism": f"gaussian-sharded x{n_gpus}" if distributed else "single"},
         "roofline": roofline,
         "stage_ms_per_step": {k.replace("gsx_", ""): round(v, 4) for k, v in sorted(per_step_ms.items())},
+        "stage_roofline_hbm": stage_roofline,
     }
     if other is not None:
         result["other_layout"] = other
