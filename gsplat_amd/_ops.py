@@ -121,6 +121,15 @@ def _common_row_views(ts, widths):
     return [t.contiguous() for t in ts], 0
 
 
+def _packed_row_map(batch_ids, camera_ids, gaussian_ids, B: int, C: int, N: int) -> Tensor:
+    """int32 [B*C*N]: packed row of every (batch, camera, gaussian), -1 where the pair is not stored. The packed
+    backward kernels walk it Gaussian-major (one thread per Gaussian, no atomics)."""
+    row_map = torch.empty(B * C * N, device=gaussian_ids.device, dtype=torch.int32)
+    call("gsx_packed_row_map", ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()), ptr(gaussian_ids.contiguous()),
+         gaussian_ids.shape[0], B, C, N, ptr(row_map))
+    return row_map
+
+
 def bits_for_count(count: int) -> int:
     return (count - 1).bit_length() if count > 1 else 0
 
@@ -202,12 +211,18 @@ def spherical_harmonics_bwd(degrees_to_use, means, viewmats, coeffs, masks, batc
     packed, B, C, N, K, D = _sh_dims(means, viewmats, coeffs, gaussian_ids)
     means, viewmats, coeffs, masks = means.contiguous(), viewmats.contiguous(), coeffs.contiguous(), _c(masks)
     v_colors, vc_stride = _row_view(v_colors, D)  # may be a column view of the compositing kernel's gradient rows
-    need_zero = packed and not _gathered
+    # packed rows read through gaussian_ids with D == 3: walk them Gaussian-major through a row map — v_coeffs / v_means
+    # are then written once per Gaussian (no atomics when several cameras see a Gaussian, no 4*K*D*N-byte zero fill)
+    row_map = None
+    if packed and not _gathered and D == 3 and N > 0 and gaussian_ids.shape[0] > 0:
+        row_map = _packed_row_map(batch_ids, camera_ids, gaussian_ids, B, C, N)
+    need_zero = packed and not _gathered and row_map is None
     v_coeffs = torch.zeros_like(coeffs) if need_zero else torch.empty_like(coeffs)
-    # dense D == 3 kernels store v_means for every (b, g) (sh3_bwd_dense_kernel); the other paths accumulate
+    # the Gaussian-major D == 3 kernels store v_means for every (b, g) (sh3_bwd_dense_kernel); the other paths accumulate
     v_means = None
     if compute_v_means:
-        v_means = torch.empty_like(means) if (not packed and D == 3 and N > 0) else torch.zeros_like(means)
+        full_write = D == 3 and N > 0 and (not packed or row_map is not None)
+        v_means = torch.empty_like(means) if full_write else torch.zeros_like(means)
     nnz = gaussian_ids.shape[0] if packed else -1
     # pose gradient: the kernel also returns d(loss)/d(view direction) per row; dir = mean + R^T t, so
     # v_R = t (x) sum_rows v_dir and v_t = R sum_rows v_dir per camera (small host-side tensors)
@@ -217,8 +232,8 @@ def spherical_harmonics_bwd(degrees_to_use, means, viewmats, coeffs, masks, batc
         v_dirs = torch.zeros((n_rows, 3), device=means.device, dtype=means.dtype)
     call("gsx_sh_bwd", degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), ptr(_c(batch_ids)),
          ptr(_c(camera_ids)), ptr(_c(gaussian_ids)), B, C, N, nnz, int(_gathered) if packed else 1, K, D,
-         ptr(_c(_radii)), ptr(_c(_post_colors)), ptr_strided(v_colors), vc_stride, ptr(v_coeffs), ptr(v_means),
-         ptr(v_dirs))
+         ptr(_c(_radii)), ptr(_c(_post_colors)), ptr_strided(v_colors), vc_stride, ptr(row_map), ptr(v_coeffs),
+         ptr(v_means), ptr(v_dirs))
     v_viewmats = None
     if compute_v_viewmats:
         if packed:
@@ -479,12 +494,16 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
     means, viewmats, Ks = means.contiguous(), viewmats.contiguous(), Ks.contiguous()
     covars, quats, scales = _c(covars), _c(quats), _c(scales)
     nnz = gaussian_ids.shape[0]
-    v_means = torch.zeros_like(means)
+    # several images: walk the packed rows Gaussian-major through a row map (each output row written once, no atomics);
+    # a single image: every Gaussian has at most one row and the row-major kernel stores without atomics
+    row_map = _packed_row_map(batch_ids, camera_ids, gaussian_ids, B, C, N) if (B * C > 1 and nnz > 0 and N > 0) else None
+    alloc = torch.empty_like if row_map is not None else torch.zeros_like
+    v_means = alloc(means)
     v_covars = v_quats = v_scales = None
     if covars is not None:
-        v_covars = torch.zeros_like(covars)
+        v_covars = alloc(covars)
     else:
-        v_quats, v_scales = torch.zeros_like(quats), torch.zeros_like(scales)
+        v_quats, v_scales = alloc(quats), alloc(scales)
     v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
     v_means2d, m2_stride = _row_view(v_means2d, 2)
     v_conics, con_stride = _row_view(v_conics, 3)
@@ -493,7 +512,8 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
          eps2d, int(camera_model), nnz, ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()),
          ptr(gaussian_ids.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
          ptr_strided(v_means2d), m2_stride, ptr(_c(v_depths)), ptr_strided(v_conics), con_stride,
-         ptr(_c(v_compensations)), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
+         ptr(_c(v_compensations)), ptr(row_map), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales),
+         ptr(v_viewmats))
     if sparse_grad:
         # COO gradients like the reference (Projection.cpp:1140-1200): rows = gaussian ids touched
         def to_sparse(dense):

@@ -181,6 +181,7 @@ struct ProjBwdArgs {
                                     // stride of gsx_raster3d_bwd's AoS gradient rows when they are column views of it
     int64_t nnz;
     const int64_t *batch_ids, *camera_ids, *gaussian_ids;
+    const int32_t *row_map; // packed rows walked Gaussian-major: [B*C*N] -> packed row or -1
     float *v_means, *v_covars, *v_quats, *v_scales, *v_viewmats;
 };
 
@@ -324,8 +325,15 @@ __global__ void __launch_bounds__(256) project_bwd_kernel(const ProjBwdArgs a)
 #pragma unroll
         for (int i = 0; i < 9; ++i) v_R[i] = 0.0f;
         if (live) {
-            const int64_t row = ((int64_t)b * a.C + c) * a.N + g;
-            if (a.radii[2 * row] > 0 && a.radii[2 * row + 1] > 0) {
+            int64_t row = ((int64_t)b * a.C + c) * a.N + g;
+            bool visible;
+            if (a.row_map) { // packed rows: every stored row is visible
+                row     = a.row_map[row];
+                visible = row >= 0;
+            } else {
+                visible = a.radii[2 * row] > 0 && a.radii[2 * row + 1] > 0;
+            }
+            if (visible) {
                 const Cam cam = load_cam(a.viewmats + ((size_t)b * a.C + c) * 16, a.Ks + ((size_t)b * a.C + c) * 9);
                 pair_vjp(a, cam, p, S, row, v_p, v_S, v_R, v_t, POSE);
             }
@@ -510,6 +518,16 @@ __global__ void __launch_bounds__(256) proj_simple_bwd_kernel(const float *means
     for (int i = 0; i < 9; ++i) v_covars[idx * 9 + i] = v_Sc[i];
 }
 
+// packed rows -> dense (b, c, g) index: row_map[(b*C + c)*N + g] = row (the caller pre-fills the map with -1)
+__global__ void __launch_bounds__(256) packed_row_map_kernel(const int64_t *batch_ids, const int64_t *camera_ids,
+                                                             const int64_t *gaussian_ids, int64_t nnz, uint32_t C, uint32_t N,
+                                                             int32_t *row_map)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nnz) return;
+    row_map[(batch_ids[r] * C + camera_ids[r]) * (int64_t)N + gaussian_ids[r]] = (int32_t)r;
+}
+
 static int check_proj_common(const char *fn, const float *means, const float *covars, const float *quats,
                              const float *scales, const float *viewmats, const float *Ks, int camera_model)
 {
@@ -651,9 +669,9 @@ extern "C" int gsx_project_ewa_packed_bwd(const float *means, const float *covar
                                           const int64_t *camera_ids, const int64_t *gaussian_ids, const float *conics,
                                           const float *compensations, const float *v_means2d,
                                           uint32_t v_means2d_stride, const float *v_depths, const float *v_conics,
-                                          uint32_t v_conics_stride, const float *v_compensations, float *v_means,
-                                          float *v_covars, float *v_quats, float *v_scales, float *v_viewmats,
-                                          void *stream)
+                                          uint32_t v_conics_stride, const float *v_compensations,
+                                          const int32_t *row_map, float *v_means, float *v_covars, float *v_quats,
+                                          float *v_scales, float *v_viewmats, void *stream)
 {
     if (nnz <= 0) return GSX_OK;
     int rc = check_proj_common("gsx_project_ewa_packed_bwd", means, covars, quats, scales, viewmats, Ks, camera_model);
@@ -667,9 +685,18 @@ extern "C" int gsx_project_ewa_packed_bwd(const float *means, const float *covar
              compensations, v_means2d, v_means2d_stride, v_depths, v_conics, v_conics_stride, v_compensations, v_means,
              v_covars, v_quats, v_scales, v_viewmats);
     a.nnz = nnz; a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
+    hipStream_t s = (hipStream_t)stream;
+    if (row_map) {
+        // Gaussian-major walk through the row map: one thread per Gaussian loops over the images, every output row is
+        // written exactly once (no atomics, no zero-initialised outputs needed) — the dense kernel on packed rows
+        a.row_map = row_map;
+        const dim3 g2((uint32_t)ceil_div((int64_t)B * N, 256));
+        if (v_viewmats) project_bwd_kernel<true><<<g2, dim3(256), 0, s>>>(a);
+        else project_bwd_kernel<false><<<g2, dim3(256), 0, s>>>(a);
+        return check_launch("project_ewa_packed_bwd");
+    }
     const dim3 grid((uint32_t)ceil_div(nnz, 256)), block(256);
     const bool unique = (uint64_t)B * C == 1;
-    hipStream_t s = (hipStream_t)stream;
     if (v_viewmats) {
         if (unique) project_packed_bwd_kernel<true, true><<<grid, block, 0, s>>>(a);
         else project_packed_bwd_kernel<true, false><<<grid, block, 0, s>>>(a);
@@ -723,4 +750,23 @@ extern "C" int gsx_project_simple_bwd(const float *means, const float *covars, c
     proj_simple_bwd_kernel<<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(
         means, covars, Ks, rows, n_per_camera, width, height, camera_model, v_means2d, v_covars2d, v_means, v_covars);
     return check_launch("project_simple_bwd");
+}
+
+extern "C" int gsx_packed_row_map(const int64_t *batch_ids, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                                  int64_t nnz, uint32_t B, uint32_t C, uint32_t N, int32_t *row_map, void *stream)
+{
+    const int64_t total = (int64_t)B * C * N;
+    if (total == 0) return GSX_OK;
+    GSX_REQUIRE(row_map, "gsx_packed_row_map: null output");
+    GSX_REQUIRE(nnz >= 0 && nnz < (1ll << 31), "gsx_packed_row_map: nnz out of range");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(row_map, 0xFF, (size_t)total * sizeof(int32_t), s) != hipSuccess) { // all bytes 0xFF = int32 -1
+        set_last_error("gsx_packed_row_map: memset failed");
+        return GSX_ERR_LAUNCH;
+    }
+    if (nnz == 0) return GSX_OK;
+    GSX_REQUIRE(batch_ids && camera_ids && gaussian_ids, "gsx_packed_row_map: null ids");
+    packed_row_map_kernel<<<dim3((uint32_t)ceil_div(nnz, 256)), dim3(256), 0, s>>>(batch_ids, camera_ids, gaussian_ids, nnz, C,
+                                                                                  N, row_map);
+    return check_launch("packed_row_map");
 }

@@ -107,6 +107,7 @@ struct ShArgs {
     float *colors;
     const float *v_colors;
     float *v_coeffs, *v_means;
+    const int32_t *row_map; // optional, packed rows only: [B*C*N] -> packed row or -1 (Gaussian-major backward)
     float *v_dirs; // optional [rows,3], zero-initialised: per-row d(loss)/d(view direction) (-> v_viewmats on the host)
     int atomic_coeffs; // packed + !gathered + more than one image: rows of one Gaussian collide
 };
@@ -465,7 +466,8 @@ __global__ void __launch_bounds__(256) sh3_bwd_packed_kernel(const ShArgs a)
     }
 }
 
-// dense: one thread per Gaussian loops over the images; v_coeffs written once, v_means via atomics per batch
+// dense (or packed rows addressed through row_map): one thread per Gaussian loops over the images; v_coeffs and
+// v_means are written once per Gaussian — no atomics, no zero-initialised outputs
 template <int DEG, bool WANT_MEANS>
 __global__ void __launch_bounds__(256) sh3_bwd_dense_kernel(const ShArgs a)
 {
@@ -480,7 +482,11 @@ __global__ void __launch_bounds__(256) sh3_bwd_dense_kernel(const ShArgs a)
     for (uint32_t b = 0; b < a.B; ++b) {
         float v_dir[3] = {0.f, 0.f, 0.f};
         for (uint32_t c = 0; c < a.C; ++c) {
-            const int64_t row = ((int64_t)b * a.C + c) * a.N + g;
+            int64_t row = ((int64_t)b * a.C + c) * a.N + g;
+            if (a.row_map) {
+                row = a.row_map[row];
+                if (row < 0) continue;
+            }
             if (row_dead(a, row)) continue;
             const float vc[3] = {load_vc(a, row, 0), load_vc(a, row, 1), load_vc(a, row, 2)};
             float vd[3] = {0.f, 0.f, 0.f};
@@ -506,7 +512,7 @@ __global__ void __launch_bounds__(256) sh3_bwd_dense_kernel(const ShArgs a)
 template <int DEG>
 static void launch_sh3_bwd(const ShArgs &a, hipStream_t s)
 {
-    if (a.nnz < 0) {
+    if (a.nnz < 0 || a.row_map) {
         const dim3 grid((uint32_t)ceil_div((int64_t)a.N, 256));
         if (a.v_means || a.v_dirs) sh3_bwd_dense_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
         else sh3_bwd_dense_kernel<DEG, false><<<grid, dim3(256), 0, s>>>(a);
@@ -568,8 +574,8 @@ extern "C" int gsx_sh_bwd(int degrees_to_use, const float *means, const float *v
                           const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
                           const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
                           int coeffs_gathered, uint32_t K, uint32_t D, const int32_t *radii, const float *post_colors,
-                          const float *v_colors, uint32_t v_colors_stride, float *v_coeffs, float *v_means,
-                          float *v_dirs, void *stream)
+                          const float *v_colors, uint32_t v_colors_stride, const int32_t *row_map, float *v_coeffs,
+                          float *v_means, float *v_dirs, void *stream)
 {
     int rc = check_sh("gsx_sh_bwd", degrees_to_use, K, D, means, viewmats, coeffs, nnz, batch_ids, camera_ids, gaussian_ids);
     if (rc != GSX_OK) return rc;
@@ -580,6 +586,7 @@ extern "C" int gsx_sh_bwd(int degrees_to_use, const float *means, const float *v
     a.B = B; a.C = C; a.N = N; a.K = K; a.D = D; a.nnz = nnz; a.coeffs_gathered = coeffs_gathered;
     a.v_colors = v_colors; a.v_coeffs = v_coeffs; a.v_means = v_means; a.v_dirs = v_dirs;
     a.radii = radii; a.post_colors = post_colors; a.vc_stride = v_colors_stride ? v_colors_stride : D;
+    a.row_map = (nnz >= 0 && D == 3 && !coeffs_gathered) ? row_map : nullptr; // Gaussian-major walk of packed rows
     a.atomic_coeffs = (B * C) > 1;
     if (D == 3 && (nnz < 0 ? (int64_t)N > 0 : nnz > 0)) {
         GSX_REQUIRE(v_colors || (nnz < 0 && (int64_t)B * C == 0), "gsx_sh_bwd: null v_colors");

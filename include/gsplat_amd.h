@@ -121,8 +121,15 @@ int gsx_project_ewa_packed_bwd(const float *means, const float *covars, const fl
                                const float *v_means2d, uint32_t v_means2d_stride, const float *v_depths,
                                const float *v_conics, uint32_t v_conics_stride,
                                const float *v_compensations,
+                               const int32_t *row_map /* NULL, or gsx_packed_row_map output: Gaussian-major walk, every output
+                                                         row written once (no atomics, outputs need no zero-fill) */,
                                float *v_means, float *v_covars, float *v_quats, float *v_scales,
                                float *v_viewmats, void *stream);
+/* row_map int32 [B*C*N]: index of the packed row of (batch, camera, gaussian), or -1 when that pair is not stored.
+ * Lets the packed backward kernels (projection, SH with D = 3) run one thread per Gaussian over its rows instead of
+ * one thread per row with atomics (10 resp. 3*K fp32 atomics per row when a Gaussian is seen by several cameras). */
+int gsx_packed_row_map(const int64_t *batch_ids, const int64_t *camera_ids, const int64_t *gaussian_ids, int64_t nnz,
+                       uint32_t B, uint32_t C, uint32_t N, int32_t *row_map, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * spherical_harmonics{,_bwd}: gsplat::spherical_harmonics{,_bwd} (ext.cpp:994-1002; host
@@ -153,6 +160,8 @@ int gsx_sh_bwd(int degrees_to_use, const float *means, const float *viewmats, co
                const int32_t *radii /* as in gsx_sh_fwd */,
                const float *post_colors /* NULL, or the forward output computed with post=1: cuts the gradient where 0 */,
                const float *v_colors, uint32_t v_colors_stride /* floats per row; 0 = D (contiguous) */,
+               const int32_t *row_map /* NULL, or gsx_packed_row_map output (packed rows, coeffs_gathered = 0, D = 3):
+                                         Gaussian-major walk, v_coeffs / v_means fully written, no atomics */,
                float *v_coeffs, float *v_means,
                float *v_dirs /* NULL, or zero-initialised [rows,3]: per-row d(loss)/d(view direction), from which the
                                 caller forms v_viewmats (= t (x) sum v_dir for R, R sum v_dir for t) */,
