@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""The reference's OWN profiling harness (profiling/main.py:43-160; scene gsplat/_helper.py:50-101) on this backend:
+assets/test_garden.npz cropped to [-2,2]^3 (committed inputs: tests/golden/garden_scene.npz), tiled scene_grid^2 times,
+random scales U(1e-4, 0.02) / quats / opacities U(0,1), colours without SH repeated to `channels`, first camera repeated
+`batch_size` times, 1080p, near 0.01, far 100, radius_clip 3.0. Timing recipe = theirs: 5 warm-ups, `repeats` forward
+calls; then `loss = render_colors.sum()` and `repeats` backward calls with retain_graph. Prints one row per configuration
+next to the number published for an NVIDIA TITAN RTX in docs/source/tests/profile.rst."""
+import argparse, json, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gsplat_amd
+
+# (batch, channels, grid, packed) -> published "FPS fwd / FPS bwd" on TITAN RTX (profile.rst:51-143)
+PUBLISHED = {(1, 3, 5, False): (171.8, 97.1), (1, 3, 5, True): (160.8, 88.4), (4, 3, 5, False): (46.1, 25.5),
+             (1, 32, 1, False): (168.4, 44.2), (4, 32, 1, False): (42.1, 10.9), (1, 3, 21, True): (62.1, 34.6)}
+
+
+def load_scene(grid, dev):
+    d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "garden_scene.npz"))
+    means = torch.from_numpy(d["means"]).to(dev)
+    colors = torch.from_numpy(d["colors_u8"].astype(np.float32) / 255.0).to(dev)
+    r = grid // 2
+    gx, gy = torch.meshgrid(torch.arange(-r, r + 1, device=dev), torch.arange(-r, r + 1, device=dev), indexing="ij")
+    offs = torch.stack([gx, gy, torch.zeros_like(gx)], -1).reshape(-1, 3).float() * 4.0  # crop edge length
+    means = (means[None] + offs[:, None]).reshape(-1, 3)
+    colors = colors.repeat(grid * grid, 1)
+    n = means.shape[0]
+    g = torch.Generator(device=dev).manual_seed(0)
+    scales = torch.rand((n, 3), device=dev, generator=g) * (0.02 - 1e-4) + 1e-4
+    quats = torch.nn.functional.normalize(torch.randn((n, 4), device=dev, generator=g), dim=-1)
+    opac = torch.rand((n,), device=dev, generator=g)
+    return means, quats, scales, opac, colors, torch.from_numpy(d["viewmats"]).to(dev), torch.from_numpy(d["Ks"]).to(dev)
+
+
+def timeit(repeats, f):
+    for _ in range(5):
+        f()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(repeats):
+        out = f()
+    torch.cuda.synchronize()
+    return (time.time() - t0) / repeats, out
+
+
+def run(batch, channels, grid, packed, repeats, dev):
+    means, quats, scales, opac, colors, viewmats, Ks = load_scene(grid, dev)
+    viewmats, Ks = viewmats[:1].repeat(batch, 1, 1), Ks[:1].repeat(batch, 1, 1)
+    colors = colors[:, :1].repeat(1, channels)
+    leaves = [t.requires_grad_(True) for t in (means, quats, scales, opac, colors)]
+
+    def fwd():
+        return gsplat_amd.rasterization(*leaves, viewmats, Ks, 1920, 1080, packed=packed, near_plane=0.01, far_plane=100.0,
+                                        radius_clip=3.0)
+
+    t_fwd, out = timeit(repeats, fwd)
+    loss = out[0].sum()
+
+    def bwd():
+        loss.backward(retain_graph=True)
+        for v in leaves:
+            v.grad = None
+
+    t_bwd, _ = timeit(repeats, bwd)
+    pub = PUBLISHED.get((batch, channels, grid, packed))
+    row = {"batch": batch, "channels": channels, "scene_grid": grid, "packed": packed, "n_gaussians": int(means.shape[0]),
+           "n_isects": int(out[2]["isect_ids"].numel()), "fps_fwd": round(1 / t_fwd, 1), "fps_bwd": round(1 / t_bwd, 1),
+           "mpix_s_fwd_bwd": round(batch * 1920 * 1080 / (t_fwd + t_bwd) / 1e6, 1),
+           "published_titan_rtx_fps_fwd_bwd": pub}
+    print(json.dumps(row), flush=True)
+    return row
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--repeats", type=int, default=20)
+    ap.add_argument("--big", action="store_true", help="also the 49M-Gaussian configuration (scene_grid 21)")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    cfgs = [(1, 3, 5, False), (1, 3, 5, True), (4, 3, 5, False), (1, 32, 1, False), (4, 32, 1, False)]
+    if a.big:
+        cfgs.append((1, 3, 21, True))
+    for c in cfgs:
+        run(*c, a.repeats, dev)
+        torch.cuda.empty_cache()
