@@ -17,6 +17,12 @@ _LAZY = {
     "spherical_harmonics_l0": "_wrapper", "spherical_harmonics_l1_plus": "_wrapper",
     "rasterize_num_contributing_gaussians": "_wrapper", "rasterize_contributing_gaussian_ids": "_wrapper",
     "rasterize_top_contributing_gaussian_ids": "_wrapper",
+    "build_sparse_tile_layout": "_wrapper",
+    "isect_tiles_sparse": "_wrapper",
+    "rasterize_to_pixels_sparse": "_wrapper",
+    "rasterize_num_contributing_gaussians_sparse": "_wrapper",
+    "rasterize_contributing_gaussian_ids_sparse": "_wrapper",
+    "rasterize_top_contributing_gaussian_ids_sparse": "_wrapper",
     "rasterize_to_indices_in_range": "_wrapper", "rasterize_to_indices_in_range_2dgs": "_wrapper",
     "rasterization": "rendering", "rasterization_2dgs": "rendering", "distributed": "distributed",
     # the training step around the rasterizer

@@ -161,6 +161,36 @@ def _rast_backward(ctx, v_render_colors, v_render_alphas, v_means2d_absgrad, v_l
     return (v_means2d, v_conics, v_colors, v_opacities, v_backgrounds) + (None,) * 8
 
 
+# ---- rasterize_to_pixels_sparse (reference _wrapper.py:2120-2260) --------------------------------
+def _rsp_setup(ctx, inputs, output):
+    (means2d, conics, colors, opacities, backgrounds, masks, image_ids, image_width, image_height, tile_size, tile_width,
+     tile_height, active_tiles, tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map, _packed,
+     absgrad) = inputs
+    _render_colors, render_alphas, means2d_absgrad, last_ids = output
+    ctx.mark_non_differentiable(last_ids, means2d_absgrad)
+    ctx.geom = (image_width, image_height, tile_size, tile_width, tile_height)
+    ctx.absgrad = absgrad
+    ctx.set_materialize_grads(False)
+    ctx.rc_shape = _render_colors.shape
+    ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, image_ids, active_tiles, tile_offsets,
+                          flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map, render_alphas, last_ids,
+                          means2d_absgrad)
+
+
+def _rsp_backward(ctx, v_render_colors, v_render_alphas, v_means2d_absgrad, v_last_ids):
+    (means2d, conics, colors, opacities, backgrounds, masks, image_ids, active_tiles, tile_offsets, flatten_ids,
+     tile_pixel_mask, tile_pixel_cumsum, pixel_map, render_alphas, last_ids, means2d_absgrad) = ctx.saved_tensors
+    v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities, v_backgrounds = _bwd("rasterize_to_pixels_sparse")(
+        means2d, conics, colors, opacities, backgrounds, masks, image_ids, active_tiles, tile_offsets, flatten_ids,
+        tile_pixel_mask, tile_pixel_cumsum, pixel_map, render_alphas, last_ids, *ctx.geom, ctx.absgrad,
+        _z(v_render_colors, ctx.rc_shape, render_alphas).contiguous(),
+        None if v_render_alphas is None else v_render_alphas.contiguous(), ctx.needs_input_grad[4],
+    )
+    if ctx.absgrad and v_means2d_abs is not None:
+        means2d_absgrad.copy_(v_means2d_abs)
+    return (v_means2d, v_conics, v_colors, v_opacities, v_backgrounds) + (None,) * 15
+
+
 # ---- 2DGS projection (reference _wrapper.py:2730-2915) -------------------------------------------
 def _p2_setup(ctx, inputs, output):
     means, quats, scales, viewmats, Ks, width, height, _eps2d, _near, _far, _clip = inputs
@@ -270,6 +300,7 @@ _TABLE = {
     "projection_ewa_3dgs_fused": (_proj_backward, _proj_setup),
     "projection_ewa_3dgs_packed": (_projp_backward, _projp_setup),
     "rasterize_to_pixels_3dgs": (_rast_backward, _rast_setup),
+    "rasterize_to_pixels_sparse": (_rsp_backward, _rsp_setup),
 }
 
 

@@ -66,6 +66,14 @@ SCHEMAS = {
     "rasterize_num_contributing_gaussians": "(Tensor means2d, Tensor conics, Tensor opacities, Tensor tile_offsets, Tensor flatten_ids, int image_width, int image_height, int tile_size) -> (Tensor, Tensor)",
     "rasterize_contributing_gaussian_ids": "(Tensor means2d, Tensor conics, Tensor opacities, Tensor tile_offsets, Tensor flatten_ids, int image_width, int image_height, int tile_size, Tensor num_contributing_gaussians) -> (Tensor, Tensor)",
     "rasterize_top_contributing_gaussian_ids": "(Tensor means2d, Tensor conics, Tensor opacities, Tensor tile_offsets, Tensor flatten_ids, int image_width, int image_height, int tile_size, int num_depth_samples) -> (Tensor, Tensor)",
+    # sparse pixel sets: ext.cpp:1028-1036, 1090-1104, 1115-1140
+    "intersect_tile_sparse": "(Tensor means2d, Tensor radii, Tensor depths, Tensor? image_ids, Tensor tile_mask, Tensor active_tiles, int I, int tile_size, int tile_width, int tile_height) -> (Tensor, Tensor)",
+    "build_sparse_tile_layout": "(Tensor pixels, Tensor image_ids, int n_images, int tile_size, int tile_width, int tile_height) -> (Tensor, Tensor, Tensor, Tensor, Tensor)",
+    "rasterize_to_pixels_sparse": "(Tensor means2d, Tensor conics, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, Tensor image_ids, int image_width, int image_height, int tile_size, int tile_width, int tile_height, Tensor active_tiles, Tensor tile_offsets, Tensor flatten_ids, Tensor tile_pixel_mask, Tensor tile_pixel_cumsum, Tensor pixel_map, bool packed, bool absgrad) -> (Tensor, Tensor, Tensor, Tensor)",
+    "rasterize_to_pixels_sparse_bwd": "(Tensor means2d, Tensor conics, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, Tensor image_ids, Tensor active_tiles, Tensor tile_offsets, Tensor flatten_ids, Tensor tile_pixel_mask, Tensor tile_pixel_cumsum, Tensor pixel_map, Tensor render_alphas, Tensor last_ids, int image_width, int image_height, int tile_size, int tile_width, int tile_height, bool absgrad, Tensor v_render_colors, Tensor v_render_alphas, bool compute_v_backgrounds) -> (Tensor?, Tensor, Tensor, Tensor, Tensor, Tensor?)",
+    "rasterize_num_contributing_gaussians_sparse": "(Tensor means2d, Tensor conics, Tensor opacities, int image_width, int image_height, int tile_size, int tile_width, int tile_height, Tensor active_tiles, Tensor tile_offsets, Tensor flatten_ids, Tensor tile_pixel_mask, Tensor tile_pixel_cumsum, Tensor pixel_map) -> (Tensor, Tensor)",
+    "rasterize_contributing_gaussian_ids_sparse": "(Tensor means2d, Tensor conics, Tensor opacities, int image_width, int image_height, int tile_size, int tile_width, int tile_height, Tensor active_tiles, Tensor tile_offsets, Tensor flatten_ids, Tensor tile_pixel_mask, Tensor tile_pixel_cumsum, Tensor pixel_map, Tensor num_contributing_gaussians) -> (Tensor, Tensor)",
+    "rasterize_top_contributing_gaussian_ids_sparse": "(Tensor means2d, Tensor conics, Tensor opacities, int image_width, int image_height, int tile_size, int tile_width, int tile_height, Tensor active_tiles, Tensor tile_offsets, Tensor flatten_ids, Tensor tile_pixel_mask, Tensor tile_pixel_cumsum, Tensor pixel_map, int num_depth_samples) -> (Tensor, Tensor)",
     # training-step ops around the rasterizer: ext.cpp:1217-1221, 1224-1227, 1256-1258
     "adam": "(Tensor(a!) param, Tensor param_grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor? valid, float lr, float b1, float b2, float eps) -> ()",
     "relocation": "(Tensor opacities, Tensor scales, Tensor ratios, Tensor binoms, int n_max, float min_opacity=0.0) -> (Tensor, Tensor)",
@@ -315,7 +323,7 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
                                   dtype=torch.uint8)
         st.offsets = torch.empty(I * tile_width * tile_height, device=dev, dtype=torch.int32)
         st.n_dev = torch.empty(1, device=dev, dtype=torch.int64)
-        call("gsx_isect_fused_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), rows, I, tile_size,
+        call("gsx_isect_fused_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), None, rows, I, tile_size,
              tile_width, tile_height, ptr(st.tiles_per_gauss), ptr(st.offsets), ptr(st.n_dev), ptr(st.count_ws),
              st.count_ws.numel())
         st.host_total.copy_(st.n_dev, non_blocking=True)
@@ -353,8 +361,8 @@ def isect_finish(st: "_IsectPending"):
     if st.fused:
         ws = torch.empty(_cabi.isect_fused_emit_workspace_bytes(n_isects, I, tile_width, tile_height), device=dev,
                          dtype=torch.uint8)
-        call("gsx_isect_fused_emit_sort", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), rows, I,
-             tile_size, tile_width, tile_height, ptr(st.count_ws), st.count_ws.numel(), ptr(st.offsets), n_isects,
+        call("gsx_isect_fused_emit_sort", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), None, rows,
+             I, tile_size, tile_width, tile_height, ptr(st.count_ws), st.count_ws.numel(), ptr(st.offsets), n_isects,
              ptr(isect_ids), ptr(flatten_ids), ptr(ws), ws.numel())
         return tiles_per_gauss, isect_ids, flatten_ids
     call("gsx_isect_emit", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), ptr(image_ids),
@@ -916,6 +924,237 @@ def rasterize_top_contributing_gaussian_ids(means2d, conics, opacities, tile_off
     ids = torch.empty(hw + (num_depth_samples,), device=means2d.device, dtype=torch.int32)
     weights = torch.empty(hw + (num_depth_samples,), device=means2d.device, dtype=means2d.dtype)
     call("gsx_raster3d_top_contributing", *args, num_depth_samples, ptr(ids), ptr(weights))
+    return ids, weights
+
+
+# ----------------------------------------------------------------------------------------------
+# sparse pixel sets (reference Intersect.cpp:563-794, Rasterization.cpp:637-856, 1196-1500): render only a caller-given
+# set of pixels. The layout is built once per pixel set with torch index ops on the device (not on the per-step path);
+# intersection and compositing run the same HIP kernels as the dense path, restricted to the active tiles.
+# ----------------------------------------------------------------------------------------------
+@_op("build_sparse_tile_layout")
+def build_sparse_tile_layout(pixels, image_ids, n_images, tile_size, tile_width, tile_height):
+    if pixels.dim() != 2 or pixels.shape[1] != 2:
+        raise ValueError("pixels must be [P, 2]")
+    P, n_tiles = pixels.shape[0], tile_width * tile_height
+    words = (tile_size * tile_size + 63) // 64
+    dev = pixels.device
+    if P == 0 or n_images == 0:
+        return (torch.empty(0, device=dev, dtype=torch.int32),
+                torch.zeros((n_images, tile_height, tile_width), device=dev, dtype=torch.bool),
+                torch.empty((0, words), device=dev, dtype=torch.uint64),
+                torch.zeros(1, device=dev, dtype=torch.int64), torch.empty(0, device=dev, dtype=torch.int64))
+    if n_images * n_tiles >= 2**31:
+        raise RuntimeError(f"build_sparse_tile_layout: n_images * n_tiles ({n_images * n_tiles}) must be < 2^31.")
+    pos_bits = bits_for_count(tile_size * tile_size)
+    row, col = pixels[:, 0].to(torch.int64), pixels[:, 1].to(torch.int64)
+    img = image_ids.reshape(P).to(torch.int64)
+    tile = img * n_tiles + torch.div(row, tile_size, rounding_mode="floor") * tile_width + torch.div(
+        col, tile_size, rounding_mode="floor")
+    in_tile = (row % tile_size) * tile_size + (col % tile_size)
+    # unique keys (callers deduplicate pixels), so the argsort is deterministic: (tile, raster position in the tile)
+    sorted_key, pixel_map = torch.sort((tile << pos_bits) | in_tile)
+    active, counts = torch.unique_consecutive(sorted_key >> pos_bits, return_counts=True)
+    cumsum = counts.cumsum(0)
+    mask = torch.zeros(n_images * n_tiles, device=dev, dtype=torch.bool)
+    mask[active] = True
+    AT = active.shape[0]
+    pos = sorted_key & ((1 << pos_bits) - 1)
+    slot = torch.repeat_interleave(torch.arange(AT, device=dev), counts, output_size=P)
+    bits = torch.zeros(AT * words, device=dev, dtype=torch.int64)
+    # distinct bits per word: integer add == bitwise or (bit 63 wraps to the sign bit, which is the same bit pattern)
+    bits.index_add_(0, slot * words + (pos >> 6), torch.ones_like(pos) << (pos & 63))
+    return (active.to(torch.int32), mask.view(n_images, tile_height, tile_width), bits.view(AT, words).view(torch.uint64),
+            cumsum, pixel_map)
+
+
+@_op("intersect_tile_sparse")
+def intersect_tile_sparse(means2d, radii, depths, image_ids, tile_mask, active_tiles, I, tile_size, tile_width,
+                          tile_height):
+    _check_f32(means2d=means2d, depths=depths)
+    if tile_mask.dtype != torch.bool:
+        raise TypeError("tile_mask must be bool")
+    if active_tiles.dtype != torch.int32:
+        raise TypeError("active_tiles must be int32")
+    packed = means2d.dim() == 2
+    if packed and image_ids is None:
+        raise ValueError("image_ids is required when means2d is packed ([nnz, 2]).")
+    n_tiles = tile_width * tile_height
+    if bits_for_count(I) + bits_for_count(n_tiles) > 32:
+        raise RuntimeError(f"intersect_tile_sparse: (image, tile) id packing needs {bits_for_count(I) + bits_for_count(n_tiles)} "
+                           f"bits but only 32 are available (I={I}, n_tiles={n_tiles}).")
+    dev = means2d.device
+    means2d, radii, depths = means2d.contiguous(), radii.contiguous(), depths.contiguous()
+    if radii.dtype != torch.int32:
+        radii = radii.to(torch.int32)
+    tile_mask, active_tiles = tile_mask.contiguous(), active_tiles.contiguous()
+    AT, rows = active_tiles.shape[0], means2d.numel() // 2
+    empty = (torch.zeros(AT + 1, device=dev, dtype=torch.int32), torch.empty(0, device=dev, dtype=torch.int32))
+    if rows == 0 or AT == 0:
+        return empty
+    sentinel = lambda n: torch.full((1,), n, device=dev, dtype=torch.int32)  # noqa: E731
+    if _cabi.isect_fused_supported(I, tile_width, tile_height, packed):
+        # the dense fused path with the tile mask applied inside the walk (AABB test: conics / opacities NULL, as the
+        # reference's sparse enumeration, Intersect.cpp:617-634): inactive tiles get empty segments, so the dense
+        # offsets of the active tiles ARE the compacted offsets
+        count_ws = torch.empty(_cabi.isect_fused_count_workspace_bytes(rows, I, tile_width, tile_height), device=dev,
+                               dtype=torch.uint8)
+        offsets = torch.empty(I * n_tiles, device=dev, dtype=torch.int32)
+        n_dev = torch.empty(1, device=dev, dtype=torch.int64)
+        call("gsx_isect_fused_count", ptr(means2d), ptr(radii), None, None, ptr(tile_mask), rows, I, tile_size, tile_width,
+             tile_height, None, ptr(offsets), ptr(n_dev), ptr(count_ws), count_ws.numel())
+        n_isects = int(n_dev.item())  # host sync: exact-length outputs (reference: Intersect.cpp:637)
+        if n_isects >= 2**31:
+            raise RuntimeError(f"intersect_tile_sparse: {n_isects} intersections overflow the int32 index space")
+        if n_isects == 0:
+            return empty
+        isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
+        flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
+        ws = torch.empty(_cabi.isect_fused_emit_workspace_bytes(n_isects, I, tile_width, tile_height), device=dev,
+                         dtype=torch.uint8)
+        call("gsx_isect_fused_emit_sort", ptr(means2d), ptr(radii), ptr(depths), None, None, ptr(tile_mask), rows, I,
+             tile_size, tile_width, tile_height, ptr(count_ws), count_ws.numel(), ptr(offsets), n_isects, ptr(isect_ids),
+             ptr(flatten_ids), ptr(ws), ws.numel())
+        return torch.cat([offsets[active_tiles.long()], sentinel(n_isects)]), flatten_ids
+    # packed rows of several images / tile grids beyond the fused path's LDS histogram: enumerate every tile with the
+    # generic kernels, then drop the intersections of inactive tiles (order within a tile is preserved)
+    if image_ids is not None:
+        image_ids = image_ids.to(torch.int64)  # callers may pass int32 camera ids (reference widens too, Intersect.cpp:607-613)
+    _tpg, isect_ids, flatten_ids = intersect_tile(means2d, radii, depths, None, None, image_ids, None, I, tile_size,
+                                                  tile_width, tile_height, True, False)
+    tile_bits = bits_for_count(n_tiles)  # key = (image << tile_bits | tile) << 32 | depth bits
+    key_hi = isect_ids >> 32
+    keep = tile_mask.reshape(-1)[(key_hi >> tile_bits) * n_tiles + (key_hi & ((1 << tile_bits) - 1))]
+    isect_ids, flatten_ids = isect_ids[keep], flatten_ids[keep]
+    offsets = intersect_offset(isect_ids, I, tile_width, tile_height).reshape(-1)
+    return torch.cat([offsets[active_tiles.long()], sentinel(flatten_ids.shape[0])]), flatten_ids
+
+
+def _sparse_layout_args(active_tiles, tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map, tile_size):
+    if tile_pixel_mask.dtype not in (torch.uint64, torch.int64):
+        raise TypeError("tile_pixel_mask must be uint64")
+    if active_tiles.dtype != torch.int32 or tile_offsets.dtype != torch.int32 or flatten_ids.dtype != torch.int32:
+        raise TypeError("active_tiles, tile_offsets and flatten_ids must be int32")
+    if tile_pixel_cumsum.dtype != torch.int64 or pixel_map.dtype != torch.int64:
+        raise TypeError("tile_pixel_cumsum and pixel_map must be int64")
+    if pixel_map.dim() != 1:
+        raise ValueError(f"pixel_map must be [P], got {tuple(pixel_map.shape)}")
+    AT = active_tiles.shape[0]
+    if tile_offsets.shape[0] != AT + 1:
+        raise ValueError("tile_offsets must be [num_active_tiles + 1]")
+    words = tile_pixel_mask.shape[1] if tile_pixel_mask.dim() == 2 else (tile_size * tile_size + 63) // 64
+    return (ptr(active_tiles.contiguous()), ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()),
+            ptr(tile_pixel_mask.contiguous()), ptr(tile_pixel_cumsum.contiguous()), ptr(pixel_map.contiguous()), AT, words)
+
+
+@_op("rasterize_to_pixels_sparse")
+def rasterize_to_pixels_sparse(means2d, conics, colors, opacities, backgrounds, masks, image_ids, image_width,
+                               image_height, tile_size, tile_width, tile_height, active_tiles, tile_offsets, flatten_ids,
+                               tile_pixel_mask, tile_pixel_cumsum, pixel_map, packed, absgrad):
+    _check_f32(means2d=means2d, conics=conics, colors=colors, opacities=opacities, backgrounds=backgrounds)
+    if means2d.shape[-1] != 2:
+        raise ValueError(f"means2d must have shape [..., N, 2] or [nnz, 2], got {tuple(means2d.shape)}")
+    if masks is not None and masks.dtype != torch.bool:
+        raise TypeError("masks must be a bool tensor")
+    layout = _sparse_layout_args(active_tiles, tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map,
+                                 tile_size)
+    means2d, conics, colors, opacities = (means2d.contiguous(), conics.contiguous(), colors.contiguous(),
+                                          opacities.contiguous())
+    backgrounds, masks = _c(backgrounds), _c(masks)
+    P, D, dev, dt = pixel_map.shape[0], colors.shape[-1], means2d.device, means2d.dtype
+    renders = torch.empty((P, D), device=dev, dtype=dt)
+    alphas = torch.empty((P, 1), device=dev, dtype=dt)
+    last_ids = torch.empty((P,), device=dev, dtype=torch.int32)
+    a_t, t_off, f_ids, p_mask, p_cum, p_map, AT, words = layout
+    call("gsx_raster3d_sparse_fwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+         a_t, t_off, f_ids, p_mask, p_cum, p_map, AT, words, 0, flatten_ids.numel(), D, image_width, image_height,
+         tile_size, tile_width, tile_height, ptr(renders), ptr(alphas), ptr(last_ids))
+    holder = torch.zeros_like(means2d) if absgrad else torch.empty(0, device=dev, dtype=dt)
+    return renders, alphas, holder, last_ids
+
+
+@_op("rasterize_to_pixels_sparse_bwd")
+def rasterize_to_pixels_sparse_bwd(means2d, conics, colors, opacities, backgrounds, masks, image_ids, active_tiles,
+                                   tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map, render_alphas,
+                                   last_ids, image_width, image_height, tile_size, tile_width, tile_height, absgrad,
+                                   v_render_colors, v_render_alphas, compute_v_backgrounds):
+    layout = _sparse_layout_args(active_tiles, tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map,
+                                 tile_size)
+    means2d, conics, colors, opacities = (means2d.contiguous(), conics.contiguous(), colors.contiguous(),
+                                          opacities.contiguous())
+    backgrounds, masks = _c(backgrounds), _c(masks)
+    v_render_colors, v_render_alphas = v_render_colors.contiguous(), _c(v_render_alphas)  # None = zeros
+    R, D = opacities.numel(), colors.shape[-1]
+    geo = 8 if absgrad else 6
+    rows = torch.zeros((R, geo + D), device=means2d.device, dtype=means2d.dtype)  # AoS rows, see rasterize_to_pixels_3dgs_bwd
+    a_t, t_off, f_ids, p_mask, p_cum, p_map, AT, words = layout
+    call("gsx_raster3d_sparse_bwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+         a_t, t_off, f_ids, p_mask, p_cum, p_map, AT, words, ptr(render_alphas.contiguous()), ptr(last_ids.contiguous()),
+         ptr(v_render_colors), ptr(v_render_alphas), 0, flatten_ids.numel(), D, image_width, image_height, tile_size,
+         tile_width, tile_height, int(bool(absgrad)), ptr(rows), geo + D)
+    v_means2d, v_conics = rows[:, 0:2].view(means2d.shape), rows[:, 2:5].view(conics.shape)
+    v_opacities, v_colors = rows[:, 5].view(opacities.shape), rows[:, geo:].view(colors.shape)
+    v_abs = rows[:, 6:8].view(means2d.shape) if absgrad else None
+    v_backgrounds = None
+    if backgrounds is not None and compute_v_backgrounds:
+        # per image: sum over its requested pixels of v_colors * (1 - alpha)  (reference Rasterization.cpp:835-846)
+        v_backgrounds = torch.zeros((backgrounds.shape[0], D), device=means2d.device, dtype=v_render_colors.dtype)
+        v_backgrounds.index_add_(0, image_ids.to(torch.int64), v_render_colors * (1.0 - render_alphas))
+    return v_abs, v_means2d, v_conics, v_colors, v_opacities, v_backgrounds
+
+
+def _sparse_query_common(means2d, conics, opacities, image_width, image_height, tile_size, tile_width, tile_height,
+                         active_tiles, tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map):
+    _check_f32(means2d=means2d, conics=conics, opacities=opacities)
+    a_t, t_off, f_ids, p_mask, p_cum, p_map, AT, words = _sparse_layout_args(
+        active_tiles, tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map, tile_size)
+    n_per = 0 if means2d.dim() == 2 else means2d.shape[-2]
+    return (ptr(means2d.contiguous()), ptr(conics.contiguous()), ptr(opacities.contiguous()), a_t, t_off, f_ids, p_mask,
+            p_cum, p_map, AT, words, 0, flatten_ids.numel(), n_per, image_width, image_height, tile_size, tile_width,
+            tile_height)
+
+
+@_op("rasterize_num_contributing_gaussians_sparse")
+def rasterize_num_contributing_gaussians_sparse(means2d, conics, opacities, image_width, image_height, tile_size,
+                                                tile_width, tile_height, active_tiles, tile_offsets, flatten_ids,
+                                                tile_pixel_mask, tile_pixel_cumsum, pixel_map):
+    args = _sparse_query_common(means2d, conics, opacities, image_width, image_height, tile_size, tile_width, tile_height,
+                                active_tiles, tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map)
+    P = pixel_map.shape[0]
+    counts = torch.empty(P, device=means2d.device, dtype=torch.int32)
+    alphas = torch.empty(P, device=means2d.device, dtype=means2d.dtype)
+    call("gsx_raster3d_sparse_num_contributing", *args, ptr(counts), ptr(alphas))
+    return counts, alphas
+
+
+@_op("rasterize_contributing_gaussian_ids_sparse")
+def rasterize_contributing_gaussian_ids_sparse(means2d, conics, opacities, image_width, image_height, tile_size,
+                                               tile_width, tile_height, active_tiles, tile_offsets, flatten_ids,
+                                               tile_pixel_mask, tile_pixel_cumsum, pixel_map, num_contributing_gaussians):
+    args = _sparse_query_common(means2d, conics, opacities, image_width, image_height, tile_size, tile_width, tile_height,
+                                active_tiles, tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map)
+    if num_contributing_gaussians.dtype != torch.int32:
+        raise ValueError("num_contributing_gaussians must have dtype int32")
+    P = pixel_map.shape[0]
+    kmax = int(num_contributing_gaussians.max().item()) if num_contributing_gaussians.numel() > 0 else 0
+    ids = torch.full((P, kmax), -1, device=means2d.device, dtype=torch.int32)
+    weights = torch.zeros((P, kmax), device=means2d.device, dtype=means2d.dtype)
+    call("gsx_raster3d_sparse_contributing_ids", *args, kmax, ptr(ids), ptr(weights))
+    return ids, weights
+
+
+@_op("rasterize_top_contributing_gaussian_ids_sparse")
+def rasterize_top_contributing_gaussian_ids_sparse(means2d, conics, opacities, image_width, image_height, tile_size,
+                                                   tile_width, tile_height, active_tiles, tile_offsets, flatten_ids,
+                                                   tile_pixel_mask, tile_pixel_cumsum, pixel_map, num_depth_samples):
+    args = _sparse_query_common(means2d, conics, opacities, image_width, image_height, tile_size, tile_width, tile_height,
+                                active_tiles, tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map)
+    if num_depth_samples < 0:
+        raise ValueError("num_depth_samples must be >= 0")
+    P = pixel_map.shape[0]
+    ids = torch.full((P, num_depth_samples), -1, device=means2d.device, dtype=torch.int32)
+    weights = torch.zeros((P, num_depth_samples), device=means2d.device, dtype=means2d.dtype)
+    call("gsx_raster3d_sparse_top_contributing", *args, num_depth_samples, ptr(ids), ptr(weights))
     return ids, weights
 
 

@@ -341,3 +341,99 @@ def rasterize_top_contributing_gaussian_ids(means2d: Tensor, conics: Tensor, opa
     return _ops.rasterize_top_contributing_gaussian_ids(means2d.contiguous(), conics.contiguous(), opacities.contiguous(),
                                                         tile_offsets.contiguous(), flatten_ids.contiguous(), image_width,
                                                         image_height, tile_size, num_depth_samples)
+
+
+# ---- sparse pixel sets (reference _wrapper.py:1351-1500, 1565-1665, 1709-2000) ----------------------------------
+def build_sparse_tile_layout(pixels: Tensor, image_ids: Tensor, n_images: int, tile_size: int, tile_width: int,
+                             tile_height: int):
+    """Per-active-tile layout of a set of pixels ``(row, col)`` [P, 2] with image index ``image_ids`` [P] (no
+    duplicates): ``(active_tiles int32 [AT], active_tile_mask bool [I, th, tw], tile_pixel_mask uint64 [AT, words],
+    tile_pixel_cumsum int64 [AT] inclusive ([1] zero when P == 0), pixel_map int64 [P])`` — reference
+    ``_wrapper.py:1433-1493``."""
+    assert pixels.dim() == 2 and pixels.shape[1] == 2, pixels.shape
+    assert image_ids.shape == (pixels.shape[0],), (image_ids.shape, pixels.shape[0])
+    return _ops.build_sparse_tile_layout(pixels.contiguous(), image_ids.contiguous(), n_images, tile_size, tile_width,
+                                         tile_height)
+
+
+def isect_tiles_sparse(means2d: Tensor, radii: Tensor, depths: Tensor, tile_mask: Tensor, active_tiles: Tensor,
+                       n_images: int, tile_size: int, tile_width: int, tile_height: int,
+                       image_ids: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Intersections restricted to the active tiles: ``(tile_offsets int32 [AT + 1] with the n_isects sentinel,
+    flatten_ids int32 [n_isects])`` sorted by (image, tile, depth) — reference ``_wrapper.py:1351-1430``."""
+    packed = means2d.dim() == 2
+    if packed:
+        nnz = means2d.size(0)
+        assert means2d.shape == (nnz, 2) and radii.shape == (nnz, 2) and depths.shape == (nnz,), means2d.shape
+        assert image_ids is not None, "image_ids is required when packed ([nnz, 2])"
+        assert image_ids.shape == (nnz,), image_ids.shape
+    else:
+        I, N = means2d.shape[0], means2d.shape[1]
+        assert means2d.shape == (I, N, 2) and radii.shape == (I, N, 2) and depths.shape == (I, N), means2d.shape
+        assert I == n_images, (I, n_images)
+    assert tile_mask.shape == (n_images, tile_height, tile_width), tile_mask.shape
+    assert tile_mask.dtype == torch.bool, tile_mask.dtype
+    assert active_tiles.dim() == 1 and active_tiles.dtype == torch.int32, (active_tiles.shape, active_tiles.dtype)
+    return _ops.intersect_tile_sparse(means2d.contiguous(), radii.contiguous(), depths.contiguous(),
+                                      image_ids.contiguous() if image_ids is not None else None, tile_mask.contiguous(),
+                                      active_tiles.contiguous(), n_images, tile_size, tile_width, tile_height)
+
+
+def rasterize_to_pixels_sparse(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor, image_ids: Tensor,
+                               active_tiles: Tensor, tile_offsets: Tensor, flatten_ids: Tensor, tile_pixel_mask: Tensor,
+                               tile_pixel_cumsum: Tensor, pixel_map: Tensor, image_width: int, image_height: int,
+                               tile_size: int, tile_width: int, tile_height: int, backgrounds: Optional[Tensor] = None,
+                               masks: Optional[Tensor] = None, packed: bool = False,
+                               absgrad: bool = False) -> Tuple[Tensor, Tensor]:
+    """Composite only the requested pixels: ``(colors [P, channels], alphas [P, 1])`` in the order of the ``pixels``
+    given to :func:`build_sparse_tile_layout` — reference ``_wrapper.py:1565-1665``. Differentiable in means2d, conics,
+    colors, opacities and backgrounds."""
+    render_colors, render_alphas, means2d_absgrad, _last_ids = _ops.rasterize_to_pixels_sparse(
+        means2d.contiguous(), conics.contiguous(), colors.contiguous(), opacities.contiguous(),
+        backgrounds.contiguous() if backgrounds is not None else None, masks.contiguous() if masks is not None else None,
+        image_ids.contiguous(), image_width, image_height, tile_size, tile_width, tile_height, active_tiles.contiguous(),
+        tile_offsets.contiguous(), flatten_ids.contiguous(), tile_pixel_mask.contiguous(), tile_pixel_cumsum.contiguous(),
+        pixel_map.contiguous(), packed, absgrad)
+    if absgrad:
+        means2d.absgrad = means2d_absgrad
+    return render_colors, render_alphas
+
+
+@torch.no_grad()
+def rasterize_num_contributing_gaussians_sparse(means2d: Tensor, conics: Tensor, opacities: Tensor, active_tiles: Tensor,
+                                                tile_offsets: Tensor, flatten_ids: Tensor, tile_pixel_mask: Tensor,
+                                                tile_pixel_cumsum: Tensor, pixel_map: Tensor, image_width: int,
+                                                image_height: int, tile_size: int, tile_width: int, tile_height: int):
+    """(count int32 [P], alpha [P]) for the requested pixels — reference ``_wrapper.py:1709-1773``."""
+    return _ops.rasterize_num_contributing_gaussians_sparse(
+        means2d.contiguous(), conics.contiguous(), opacities.contiguous(), image_width, image_height, tile_size,
+        tile_width, tile_height, active_tiles.contiguous(), tile_offsets.contiguous(), flatten_ids.contiguous(),
+        tile_pixel_mask.contiguous(), tile_pixel_cumsum.contiguous(), pixel_map.contiguous())
+
+
+@torch.no_grad()
+def rasterize_contributing_gaussian_ids_sparse(means2d: Tensor, conics: Tensor, opacities: Tensor, active_tiles: Tensor,
+                                               tile_offsets: Tensor, flatten_ids: Tensor, tile_pixel_mask: Tensor,
+                                               tile_pixel_cumsum: Tensor, pixel_map: Tensor,
+                                               num_contributing_gaussians: Tensor, image_width: int, image_height: int,
+                                               tile_size: int, tile_width: int, tile_height: int):
+    """(ids int32 [P, K], weights [P, K]), K = max count, padded with (-1, 0) — reference ``_wrapper.py:1824-1893``."""
+    return _ops.rasterize_contributing_gaussian_ids_sparse(
+        means2d.contiguous(), conics.contiguous(), opacities.contiguous(), image_width, image_height, tile_size,
+        tile_width, tile_height, active_tiles.contiguous(), tile_offsets.contiguous(), flatten_ids.contiguous(),
+        tile_pixel_mask.contiguous(), tile_pixel_cumsum.contiguous(), pixel_map.contiguous(),
+        num_contributing_gaussians.contiguous())
+
+
+@torch.no_grad()
+def rasterize_top_contributing_gaussian_ids_sparse(means2d: Tensor, conics: Tensor, opacities: Tensor,
+                                                   active_tiles: Tensor, tile_offsets: Tensor, flatten_ids: Tensor,
+                                                   tile_pixel_mask: Tensor, tile_pixel_cumsum: Tensor, pixel_map: Tensor,
+                                                   image_width: int, image_height: int, tile_size: int, tile_width: int,
+                                                   tile_height: int, num_depth_samples: int):
+    """The strongest ``num_depth_samples`` contributors of the requested pixels, front to back — reference
+    ``_wrapper.py:1942-2008``."""
+    return _ops.rasterize_top_contributing_gaussian_ids_sparse(
+        means2d.contiguous(), conics.contiguous(), opacities.contiguous(), image_width, image_height, tile_size,
+        tile_width, tile_height, active_tiles.contiguous(), tile_offsets.contiguous(), flatten_ids.contiguous(),
+        tile_pixel_mask.contiguous(), tile_pixel_cumsum.contiguous(), pixel_map.contiguous(), num_depth_samples)

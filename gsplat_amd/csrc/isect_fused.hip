@@ -65,13 +65,16 @@ __global__ void __launch_bounds__(kFusedThreads) fused_count_hist_kernel(const F
     int64_t lo, hi;
     chunk_rows(g, blockIdx.x, lo, hi);
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
+    const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)(blockIdx.x / g.cpi) * g.n_tiles : nullptr;
     for (int64_t r = lo + threadIdx.x; r < hi; r += kFusedThreads) {
         const RowGeom q = load_row_geom(a, r, has_conic);
         int32_t n       = 0;
         if (q.live)
             n = walk_tiles(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h,
-                           [&](int64_t tile) { atomicAdd(&s_hist[tile], 1); });
-        a.tiles_per_gauss[r] = n;
+                           [&](int64_t tile) {
+                               if (!tmask || tmask[tile]) atomicAdd(&s_hist[tile], 1);
+                           });
+        if (a.tiles_per_gauss) a.tiles_per_gauss[r] = n;
     }
     __syncthreads();
     int32_t *out = a.table + (int64_t)blockIdx.x * g.n_tiles;
@@ -90,12 +93,14 @@ __global__ void __launch_bounds__(kFusedThreads) fused_emit_scatter_kernel(const
     int64_t lo, hi;
     chunk_rows(g, blockIdx.x, lo, hi);
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
+    const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)img * g.n_tiles : nullptr;
     for (int64_t r = lo + threadIdx.x; r < hi; r += kFusedThreads) {
         const RowGeom q = load_row_geom(a, r, has_conic);
         if (!q.live) continue;
         const uint32_t dbits = __float_as_uint(a.depths[r]);
         walk_tiles(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h,
                    [&](int64_t tile) {
+                       if (tmask && !tmask[tile]) return;
                        const int32_t slot = atomicAdd(&s_cur[tile], 1);
                        a.bucketed[slot]   = make_uint2(dbits, (uint32_t)r);
                    });

@@ -19,6 +19,7 @@ struct FusedArgs {
     const float *depths;          // [R]   (emit)
     const float *conics;          // [R,3] or null
     const float *opacities;       // [R]   or null
+    const uint8_t *tile_mask;     // [n_images * n_tiles] or null: only tiles with a non-zero flag receive intersections
     int32_t *tiles_per_gauss;     // [R]   (count)
     int32_t *table;               // [n_chunks][n_tiles]: histogram, then exclusive prefix over an image's chunks
     const int32_t *isect_offsets; // [n_images * n_tiles] (emit)

@@ -53,6 +53,14 @@ struct Raster3DArgs {
     // and the flush writes consecutive floats from consecutive lanes (see raster3d_bwd.hip).
     float *v_rows;
     uint32_t row_stride;
+    // sparse pixel layout of gsplat::rasterize_to_pixels_sparse (all null / 0 for dense images): one workgroup per
+    // ACTIVE tile, only the pixels whose bit is set are rendered, and pixel outputs / cotangents are rows of packed
+    // [P, ...] tensors in the caller's pixel order (reference RasterizeSparseAddressing.cuh, SparseTileLayout.cu)
+    const int32_t *sp_active_tiles; // [AT] dense tile ids (image * tiles_per_image + tile), ascending
+    const uint64_t *sp_pixel_mask;  // [AT, sp_words] raster-order bitmask (bit = row_in_tile * tile_size + col_in_tile)
+    const int64_t *sp_pixel_cumsum; // [AT] inclusive number of requested pixels per active tile
+    const int64_t *sp_pixel_map;    // [P] position in (tile, in-tile) order -> caller's pixel index
+    uint32_t n_active, sp_words;
 };
 
 // Block index -> (image, tile) with an XCD-aware remap: hardware places workgroup b on
@@ -64,6 +72,56 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n_blocks)
     constexpr uint32_t kXcds = 8;
     const uint32_t per_xcd   = (n_blocks + kXcds - 1) / kXcds;
     return (b % kXcds) * per_xcd + (b / kXcds);
+}
+
+// Which tile does this workgroup own, which slice of the sorted intersection list, and which output row does this lane
+// write? Dense: tile = block, row = pixel index in the [I, H, W] image. Sparse: tile = active_tiles[block], list slice from
+// the per-active-tile offsets, row = pixel_map[first row of the tile + rank of the lane's pixel among the set bits].
+struct TileCtx {
+    uint32_t image_id, tile_id, tile_x, tile_y;
+    int32_t range_start, range_end;
+};
+template <class Args> // Raster3DArgs or QueryArgs (raster_query.hip): same grid / layout field names
+__device__ __forceinline__ bool tile_context(const Args &a, uint32_t block, TileCtx &t)
+{
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
+    if (a.sp_active_tiles) {
+        const uint32_t at = xcd_remap(block, a.n_active);
+        if (at >= a.n_active) return false;
+        const uint32_t gt = (uint32_t)a.sp_active_tiles[at];
+        t.image_id = gt / tiles_per_image;
+        t.tile_id  = gt % tiles_per_image;
+        t.range_start = a.isect_offsets[at];
+        t.range_end   = a.isect_offsets[at + 1]; // [AT + 1] with the n_isects sentinel
+    } else {
+        const uint32_t n_blocks = tiles_per_image * a.n_images;
+        const uint32_t blk      = xcd_remap(block, n_blocks);
+        if (blk >= n_blocks) return false;
+        t.image_id = blk / tiles_per_image;
+        t.tile_id  = blk % tiles_per_image;
+        t.range_start = a.isect_offsets[blk];
+        t.range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
+    }
+    t.tile_x = t.tile_id % a.tile_w;
+    t.tile_y = t.tile_id / a.tile_w;
+    return true;
+}
+// output row of pixel (lx, ly) of the tile, or -1 when the pixel is not rendered
+template <class Args>
+__device__ __forceinline__ int64_t pixel_row(const Args &a, const TileCtx &t, uint32_t block, uint32_t lx, uint32_t ly)
+{
+    if (!(lx < a.tile_size && ly < a.tile_size)) return -1;
+    const uint32_t ox = t.tile_x * a.tile_size + lx, oy = t.tile_y * a.tile_size + ly;
+    if (!(ox < a.width && oy < a.height)) return -1;
+    if (!a.sp_active_tiles) return ((int64_t)t.image_id * a.height + oy) * a.width + ox;
+    const uint32_t at      = xcd_remap(block, a.n_active);
+    const uint64_t *words  = a.sp_pixel_mask + (size_t)at * a.sp_words;
+    const uint32_t in_tile = ly * a.tile_size + lx, word = in_tile >> 6, bit = in_tile & 63u;
+    if (!((words[word] >> bit) & 1ull)) return -1;
+    uint32_t rank = __popcll(words[word] & ((1ull << bit) - 1ull));
+    for (uint32_t w = 0; w < word; ++w) rank += __popcll(words[w]);
+    const int64_t first = at == 0 ? 0 : a.sp_pixel_cumsum[at - 1];
+    return a.sp_pixel_map[first + rank];
 }
 
 // thread -> pixel inside the tile.

@@ -52,32 +52,24 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
     float *s_col     = reinterpret_cast<float *>(s_touch + BATCH); // [BATCH][CH]
     float *s_acc     = s_col + BATCH * CH;                         // [BATCH][KP]
 
+    TileCtx tc;
+    if (!tile_context(a, blockIdx.x, tc)) return;
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
-    const uint32_t n_blocks        = tiles_per_image * a.n_images;
-    const uint32_t blk             = xcd_remap(blockIdx.x, n_blocks);
-    if (blk >= n_blocks) return;
-
-    const uint32_t image_id = blk / tiles_per_image;
-    const uint32_t tile_id  = blk % tiles_per_image;
+    const uint32_t image_id = tc.image_id, tile_id = tc.tile_id;
     if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) return;
 
-    const uint32_t tile_x = tile_id % a.tile_w;
-    const uint32_t tile_y = tile_id / a.tile_w;
-    const uint32_t tid    = threadIdx.x;
-    const uint32_t lane   = tid & 63u;
+    const uint32_t tid  = threadIdx.x;
+    const uint32_t lane = tid & 63u;
 
     uint32_t lx, ly;
     tile_pixel(tid, a.tile_size, lx, ly);
-    const uint32_t ox = tile_x * a.tile_size + lx;
-    const uint32_t oy = tile_y * a.tile_size + ly;
-    const bool inside = (lx < a.tile_size) && (ly < a.tile_size) && (ox < a.width) && (oy < a.height);
-    const float px    = (float)ox + 0.5f;
-    const float py    = (float)oy + 0.5f;
-    const size_t pix  = inside ? ((size_t)image_id * a.height + oy) * a.width + ox : 0;
+    const int64_t prow = pixel_row(a, tc, blockIdx.x, lx, ly);
+    const bool inside  = prow >= 0;
+    const float px     = (float)(tc.tile_x * a.tile_size + lx) + 0.5f;
+    const float py     = (float)(tc.tile_y * a.tile_size + ly) + 0.5f;
+    const size_t pix   = inside ? (size_t)prow : 0;
 
-    const int32_t range_start = a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id];
-    const int32_t range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects
-                                                      : a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id + 1];
+    const int32_t range_start = tc.range_start, range_end = tc.range_end;
     const int32_t n_batches   = (range_end - range_start + BATCH - 1) / BATCH;
     if (n_batches <= 0) return;
 
@@ -271,7 +263,7 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
 template <int CH, bool ABS>
 static int launch_bwd(const Raster3DArgs &a, hipStream_t stream)
 {
-    const uint32_t n_blocks = a.tile_w * a.tile_h * a.n_images;
+    const uint32_t n_blocks = a.sp_active_tiles ? a.n_active : a.tile_w * a.tile_h * a.n_images;
     if (n_blocks == 0 || a.n_isects == 0) return GSX_OK;
     const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
     const uint32_t block = a.tile_size <= 8 ? 64u : 256u;
@@ -333,5 +325,38 @@ extern "C" int gsx_raster3d_bwd(
     a.render_alphas = const_cast<float *>(render_alphas); a.last_ids = const_cast<int32_t *>(last_ids);
     a.v_render_colors = v_render_colors; a.v_render_alphas = v_render_alphas;
     a.v_rows = v_rows; a.row_stride = row_stride;
+    return has_abs ? bwd_dispatch<true>(a, (hipStream_t)stream) : bwd_dispatch<false>(a, (hipStream_t)stream);
+}
+
+// Sparse pixel set (gsplat::rasterize_to_pixels_sparse_bwd, reference RasterizeToPixelsSparseBwd.cu): render_alphas,
+// last_ids and the cotangents are rows [P, ...]; gradient rows v_rows as in gsx_raster3d_bwd.
+extern "C" int gsx_raster3d_sparse_bwd(
+    const float *means2d, const float *conics, const float *colors, const float *opacities, const float *backgrounds,
+    const uint8_t *masks, const int32_t *active_tiles, const int32_t *tile_offsets, const int32_t *flatten_ids,
+    const uint64_t *tile_pixel_mask, const int64_t *tile_pixel_cumsum, const int64_t *pixel_map, uint32_t n_active,
+    uint32_t words_per_tile, const float *render_alphas, const int32_t *last_ids, const float *v_render_colors,
+    const float *v_render_alphas, uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height,
+    uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows, uint32_t row_stride, void *stream)
+{
+    using namespace gsx;
+    GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster3d_sparse_bwd: tile_size must be in [1,16], got %u", tile_size);
+    GSX_REQUIRE(cdim >= 1, "gsx_raster3d_sparse_bwd: channels must be >= 1");
+    GSX_REQUIRE(v_rows, "gsx_raster3d_sparse_bwd: null gradient output");
+    GSX_REQUIRE(row_stride >= 6u + (has_abs ? 2u : 0u) + cdim, "gsx_raster3d_sparse_bwd: row_stride %u too small", row_stride);
+    if (n_active == 0 || n_isects == 0) return GSX_OK;
+    GSX_REQUIRE(words_per_tile * 64u >= tile_size * tile_size, "gsx_raster3d_sparse_bwd: pixel mask too narrow");
+    GSX_REQUIRE(active_tiles && tile_offsets && tile_pixel_mask && tile_pixel_cumsum && pixel_map && means2d && conics
+                && colors && opacities && flatten_ids && render_alphas && last_ids && v_render_colors,
+                "gsx_raster3d_sparse_bwd: null input");
+    Raster3DArgs a{};
+    a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height;
+    a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h; a.cdim = cdim;
+    a.means2d = means2d; a.conics = conics; a.colors = colors; a.opacities = opacities;
+    a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = tile_offsets; a.flatten_ids = flatten_ids;
+    a.render_alphas = const_cast<float *>(render_alphas); a.last_ids = const_cast<int32_t *>(last_ids);
+    a.v_render_colors = v_render_colors; a.v_render_alphas = v_render_alphas;
+    a.v_rows = v_rows; a.row_stride = row_stride;
+    a.sp_active_tiles = active_tiles; a.sp_pixel_mask = tile_pixel_mask; a.sp_pixel_cumsum = tile_pixel_cumsum;
+    a.sp_pixel_map = pixel_map; a.n_active = n_active; a.sp_words = words_per_tile;
     return has_abs ? bwd_dispatch<true>(a, (hipStream_t)stream) : bwd_dispatch<false>(a, (hipStream_t)stream);
 }

@@ -18,25 +18,19 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
     float2 *s_gb   = reinterpret_cast<float2 *>(s_cull + kBatch);          // B, C
     float *s_col   = reinterpret_cast<float *>(s_gb + kBatch);             // [kBatch][CH]
 
+    TileCtx tc;
+    if (!tile_context(a, blockIdx.x, tc)) return; // uniform for the whole workgroup
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
-    const uint32_t n_blocks        = tiles_per_image * a.n_images;
-    const uint32_t blk             = xcd_remap(blockIdx.x, n_blocks);
-    if (blk >= n_blocks) return; // uniform for the whole workgroup
-
-    const uint32_t image_id = blk / tiles_per_image;
-    const uint32_t tile_id  = blk % tiles_per_image;
-    const uint32_t tile_x   = tile_id % a.tile_w;
-    const uint32_t tile_y   = tile_id / a.tile_w;
+    const uint32_t image_id = tc.image_id, tile_id = tc.tile_id;
     const uint32_t tid      = threadIdx.x;
 
     uint32_t lx, ly;
     tile_pixel(tid, a.tile_size, lx, ly);
-    const uint32_t ox = tile_x * a.tile_size + lx;
-    const uint32_t oy = tile_y * a.tile_size + ly;
-    const bool inside = (lx < a.tile_size) && (ly < a.tile_size) && (ox < a.width) && (oy < a.height);
-    const float px    = (float)ox + 0.5f;
-    const float py    = (float)oy + 0.5f;
-    const size_t pix  = ((size_t)image_id * a.height + oy) * a.width + ox;
+    const int64_t prow = pixel_row(a, tc, blockIdx.x, lx, ly); // output row, -1 = this lane renders nothing
+    const bool inside  = prow >= 0;
+    const float px     = (float)(tc.tile_x * a.tile_size + lx) + 0.5f;
+    const float py     = (float)(tc.tile_y * a.tile_size + ly) + 0.5f;
+    const size_t pix   = inside ? (size_t)prow : 0;
 
     const float *bg = a.backgrounds ? a.backgrounds + (size_t)image_id * a.cdim + a.ch_off : nullptr;
 
@@ -54,9 +48,7 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
         return;
     }
 
-    const int32_t range_start = a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id];
-    const int32_t range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects
-                                                      : a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id + 1];
+    const int32_t range_start = tc.range_start, range_end = tc.range_end;
     const int32_t n_batches   = (range_end - range_start + kBatch - 1) / kBatch;
 
     float T          = 1.0f;
@@ -148,7 +140,7 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 template <int CH>
 static int launch_fwd(const Raster3DArgs &a, hipStream_t stream)
 {
-    const uint32_t n_blocks = a.tile_w * a.tile_h * a.n_images;
+    const uint32_t n_blocks = a.sp_active_tiles ? a.n_active : a.tile_w * a.tile_h * a.n_images;
     if (n_blocks == 0) return GSX_OK;
     const uint32_t grid   = ((n_blocks + 7u) / 8u) * 8u; // xcd_remap needs a multiple of 8
     const uint32_t block  = a.tile_size <= 8 ? 64u : 256u;
@@ -205,5 +197,34 @@ extern "C" int gsx_raster3d_fwd(
     a.means2d = means2d; a.conics = conics; a.colors = colors; a.opacities = opacities;
     a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = isect_offsets; a.flatten_ids = flatten_ids;
     a.render_colors = render_colors; a.render_alphas = render_alphas; a.last_ids = last_ids;
+    return raster3d_fwd_dispatch(a, (hipStream_t)stream);
+}
+
+// Sparse pixel set (gsplat::rasterize_to_pixels_sparse, reference RasterizeToPixelsSparseFwd.cu): same kernel, one
+// workgroup per ACTIVE tile; outputs are rows [P, ...] in the caller's pixel order (raster3d.hpp: TileCtx / pixel_row).
+extern "C" int gsx_raster3d_sparse_fwd(
+    const float *means2d, const float *conics, const float *colors, const float *opacities, const float *backgrounds,
+    const uint8_t *masks, const int32_t *active_tiles, const int32_t *tile_offsets, const int32_t *flatten_ids,
+    const uint64_t *tile_pixel_mask, const int64_t *tile_pixel_cumsum, const int64_t *pixel_map, uint32_t n_active,
+    uint32_t words_per_tile, uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height,
+    uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *render_colors, float *render_alphas, int32_t *last_ids,
+    void *stream)
+{
+    using namespace gsx;
+    GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster3d_sparse_fwd: tile_size must be in [1,16], got %u", tile_size);
+    GSX_REQUIRE(cdim >= 1, "gsx_raster3d_sparse_fwd: channels must be >= 1");
+    if (n_active == 0) return GSX_OK;
+    GSX_REQUIRE(words_per_tile * 64u >= tile_size * tile_size, "gsx_raster3d_sparse_fwd: pixel mask too narrow");
+    GSX_REQUIRE(active_tiles && tile_offsets && tile_pixel_mask && tile_pixel_cumsum && pixel_map && render_colors
+                && render_alphas && last_ids, "gsx_raster3d_sparse_fwd: null layout / output");
+    GSX_REQUIRE(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids), "gsx_raster3d_sparse_fwd: null input");
+    Raster3DArgs a{};
+    a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height;
+    a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h; a.cdim = cdim;
+    a.means2d = means2d; a.conics = conics; a.colors = colors; a.opacities = opacities;
+    a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = tile_offsets; a.flatten_ids = flatten_ids;
+    a.render_colors = render_colors; a.render_alphas = render_alphas; a.last_ids = last_ids;
+    a.sp_active_tiles = active_tiles; a.sp_pixel_mask = tile_pixel_mask; a.sp_pixel_cumsum = tile_pixel_cumsum;
+    a.sp_pixel_map = pixel_map; a.n_active = n_active; a.sp_words = words_per_tile;
     return raster3d_fwd_dispatch(a, (hipStream_t)stream);
 }

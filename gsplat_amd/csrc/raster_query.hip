@@ -20,6 +20,11 @@ struct QueryArgs {
     uint32_t K;           // ids: slots per pixel (max count); top: number of samples
     const float *means2d, *conics, *opacities;
     const int32_t *isect_offsets, *flatten_ids;
+    // sparse pixel set (raster3d.hpp TileCtx / pixel_row); all null / 0 for the dense layout. Outputs are then rows [P, ...]
+    const int32_t *sp_active_tiles;
+    const uint64_t *sp_pixel_mask;
+    const int64_t *sp_pixel_cumsum, *sp_pixel_map;
+    uint32_t n_active, sp_words;
     int32_t *counts; // mode 0: [I,H,W]
     float *alphas;   // mode 0: [I,H,W]
     int32_t *ids;    // mode 1/2: [I,H,W,K]  (mode 1: pre-filled with -1 by the caller)
@@ -42,23 +47,17 @@ __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
     uint32_t *s_d  = reinterpret_cast<uint32_t *>(s_w + (MODE == kQTop ? a.K * blockDim.x : 0));
     int32_t *s_i   = reinterpret_cast<int32_t *>(s_d + (MODE == kQTop ? a.K * blockDim.x : 0));
 
-    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
-    const uint32_t n_blocks        = tiles_per_image * a.n_images;
-    const uint32_t blk             = xcd_remap(blockIdx.x, n_blocks);
-    if (blk >= n_blocks) return;
-    const uint32_t image_id = blk / tiles_per_image, tile_id = blk % tiles_per_image;
-    const uint32_t tile_x = tile_id % a.tile_w, tile_y = tile_id / a.tile_w;
+    TileCtx tc;
+    if (!tile_context(a, blockIdx.x, tc)) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, nthr = blockDim.x;
     uint32_t lx, ly;
     tile_pixel(tid, a.tile_size, lx, ly);
-    const uint32_t ox = tile_x * a.tile_size + lx, oy = tile_y * a.tile_size + ly;
-    const bool inside = (lx < a.tile_size) && (ly < a.tile_size) && (ox < a.width) && (oy < a.height);
-    const float px = (float)ox + 0.5f, py = (float)oy + 0.5f;
-    const size_t pix = ((size_t)image_id * a.height + oy) * a.width + ox;
+    const int64_t prow = pixel_row(a, tc, blockIdx.x, lx, ly);
+    const bool inside  = prow >= 0;
+    const float px = (float)(tc.tile_x * a.tile_size + lx) + 0.5f, py = (float)(tc.tile_y * a.tile_size + ly) + 0.5f;
+    const size_t pix = inside ? (size_t)prow : 0;
 
-    const int32_t range_start = a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id];
-    const int32_t range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects
-                                                      : a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id + 1];
+    const int32_t range_start = tc.range_start, range_end = tc.range_end;
     const int32_t n_batches   = (range_end - range_start + kQBatch - 1) / kQBatch;
 
     float T        = 1.0f;
@@ -177,7 +176,7 @@ __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
 template <int MODE>
 static int launch_query(const QueryArgs &a, hipStream_t stream)
 {
-    const uint32_t n_blocks = a.tile_w * a.tile_h * a.n_images;
+    const uint32_t n_blocks = a.sp_active_tiles ? a.n_active : a.tile_w * a.tile_h * a.n_images;
     if (n_blocks == 0) return GSX_OK;
     const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
     const uint32_t block = a.tile_size <= 8 ? 64u : 256u;
@@ -211,6 +210,16 @@ static int fill_query(const char *fn, QueryArgs &a, const float *means2d, const 
     a.tile_w = tile_w; a.tile_h = tile_h; a.n_per_image = n_per_image;
     a.means2d = means2d; a.conics = conics; a.opacities = opacities; a.isect_offsets = isect_offsets;
     a.flatten_ids = flatten_ids;
+    return GSX_OK;
+}
+
+static int fill_sparse(const char *fn, QueryArgs &a, const int32_t *active_tiles, const uint64_t *tile_pixel_mask,
+                       const int64_t *tile_pixel_cumsum, const int64_t *pixel_map, uint32_t n_active, uint32_t words)
+{
+    GSX_REQUIRE(n_active == 0 || (active_tiles && tile_pixel_mask && tile_pixel_cumsum && pixel_map), "%s: null layout", fn);
+    GSX_REQUIRE(n_active == 0 || words * 64u >= a.tile_size * a.tile_size, "%s: pixel mask too narrow", fn);
+    a.sp_active_tiles = active_tiles; a.sp_pixel_mask = tile_pixel_mask; a.sp_pixel_cumsum = tile_pixel_cumsum;
+    a.sp_pixel_map = pixel_map; a.n_active = n_active; a.sp_words = words;
     return GSX_OK;
 }
 
@@ -261,6 +270,50 @@ extern "C" int gsx_raster3d_top_contributing(const float *means2d, const float *
                         n_isects, n_per_image, width, height, tile_size, tile_w, tile_h);
     if (rc != GSX_OK) return rc;
     GSX_REQUIRE(ids && weights, "gsx_raster3d_top_contributing: null output");
+    a.K = num_depth_samples; a.ids = ids; a.weights = weights;
+    return launch_query<kQTop>(a, (hipStream_t)stream);
+}
+
+// ---- sparse pixel sets: gsplat::rasterize_*_sparse (ext.cpp:1115-1140); outputs are rows [P, ...] in the caller's order ----
+#define GSX_SPARSE_QUERY_PARAMS                                                                                              \
+    const float *means2d, const float *conics, const float *opacities, const int32_t *active_tiles,                          \
+        const int32_t *tile_offsets, const int32_t *flatten_ids, const uint64_t *tile_pixel_mask,                            \
+        const int64_t *tile_pixel_cumsum, const int64_t *pixel_map, uint32_t n_active, uint32_t words_per_tile,              \
+        uint32_t n_images, uint32_t n_isects, uint32_t n_per_image, uint32_t width, uint32_t height, uint32_t tile_size,     \
+        uint32_t tile_w, uint32_t tile_h
+#define GSX_SPARSE_QUERY_FILL(fn)                                                                                            \
+    if (n_active == 0) return GSX_OK;                                                                                        \
+    QueryArgs a{};                                                                                                           \
+    int rc = fill_query(fn, a, means2d, conics, opacities, tile_offsets, flatten_ids, n_images, n_isects, n_per_image,       \
+                        width, height, tile_size, tile_w, tile_h);                                                           \
+    if (rc == GSX_OK) rc = fill_sparse(fn, a, active_tiles, tile_pixel_mask, tile_pixel_cumsum, pixel_map, n_active,         \
+                                       words_per_tile);                                                                      \
+    if (rc != GSX_OK) return rc;
+
+extern "C" int gsx_raster3d_sparse_num_contributing(GSX_SPARSE_QUERY_PARAMS, int32_t *counts, float *alphas, void *stream)
+{
+    GSX_SPARSE_QUERY_FILL("gsx_raster3d_sparse_num_contributing")
+    GSX_REQUIRE(counts && alphas, "gsx_raster3d_sparse_num_contributing: null output");
+    a.counts = counts; a.alphas = alphas;
+    return launch_query<kQCount>(a, (hipStream_t)stream);
+}
+
+extern "C" int gsx_raster3d_sparse_contributing_ids(GSX_SPARSE_QUERY_PARAMS, uint32_t max_contributing, int32_t *ids,
+                                                    float *weights, void *stream)
+{
+    if (max_contributing == 0) return GSX_OK;
+    GSX_SPARSE_QUERY_FILL("gsx_raster3d_sparse_contributing_ids")
+    GSX_REQUIRE(ids && weights, "gsx_raster3d_sparse_contributing_ids: null output");
+    a.K = max_contributing; a.ids = ids; a.weights = weights;
+    return launch_query<kQIds>(a, (hipStream_t)stream);
+}
+
+extern "C" int gsx_raster3d_sparse_top_contributing(GSX_SPARSE_QUERY_PARAMS, uint32_t num_depth_samples, int32_t *ids,
+                                                    float *weights, void *stream)
+{
+    if (num_depth_samples == 0) return GSX_OK;
+    GSX_SPARSE_QUERY_FILL("gsx_raster3d_sparse_top_contributing")
+    GSX_REQUIRE(ids && weights, "gsx_raster3d_sparse_top_contributing: null output");
     a.K = num_depth_samples; a.ids = ids; a.weights = weights;
     return launch_query<kQTop>(a, (hipStream_t)stream);
 }

@@ -533,7 +533,8 @@ static int fused_setup(const char *fn, FusedArgs &a, int64_t rows, uint32_t n_im
 }
 
 extern "C" int gsx_isect_fused_count(const float *means2d, const int32_t *radii, const float *conics, const float *opacities,
-                                     int64_t rows, uint32_t n_images, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                                     const uint8_t *tile_mask, int64_t rows, uint32_t n_images, uint32_t tile_size,
+                                     uint32_t tile_w, uint32_t tile_h,
                                      int32_t *tiles_per_gauss, int32_t *isect_offsets, int64_t *n_isects,
                                      void *count_workspace, int64_t count_workspace_bytes, void *stream)
 {
@@ -548,13 +549,14 @@ extern "C" int gsx_isect_fused_count(const float *means2d, const int32_t *radii,
         }
         return GSX_OK;
     }
-    GSX_REQUIRE(means2d && radii && tiles_per_gauss, "gsx_isect_fused_count: null pointer");
+    GSX_REQUIRE(means2d && radii, "gsx_isect_fused_count: null pointer");
     FusedArgs a{};
     int32_t *totals = nullptr;
     int rc = fused_setup("gsx_isect_fused_count", a, rows, n_images, tile_size, tile_w, tile_h, count_workspace,
                          count_workspace_bytes, &totals);
     if (rc != GSX_OK) return rc;
     a.means2d = means2d; a.radii = radii; a.conics = conics; a.opacities = opacities; a.tiles_per_gauss = tiles_per_gauss;
+    a.tile_mask = tile_mask;
     rc = launch_fused_count_hist(a, s);
     if (rc != GSX_OK) return rc;
     const uint32_t tile_groups = (a.geom.n_tiles + kCsTiles - 1) / kCsTiles;
@@ -565,7 +567,8 @@ extern "C" int gsx_isect_fused_count(const float *means2d, const int32_t *radii,
 }
 
 extern "C" int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *radii, const float *depths,
-                                         const float *conics, const float *opacities, int64_t rows, uint32_t n_images,
+                                         const float *conics, const float *opacities, const uint8_t *tile_mask,
+                                         int64_t rows, uint32_t n_images,
                                          uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, void *count_workspace,
                                          int64_t count_workspace_bytes, const int32_t *isect_offsets, int64_t n_isects,
                                          int64_t *isect_ids_sorted, int32_t *flatten_ids_sorted, void *workspace,
@@ -598,7 +601,7 @@ extern "C" int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *ra
     a.keys_out = reinterpret_cast<uint64_t *>(isect_ids_sorted);
     a.vals_out = flatten_ids_sorted;
     f.means2d = means2d; f.radii = radii; f.depths = depths; f.conics = conics; f.opacities = opacities;
-    f.isect_offsets = isect_offsets; f.bucketed = a.bucketed;
+    f.isect_offsets = isect_offsets; f.bucketed = a.bucketed; f.tile_mask = tile_mask;
     rc = launch_fused_emit_scatter(f, s);
     if (rc != GSX_OK) return rc;
     static bool attr_done = false;

@@ -222,11 +222,13 @@ int gsx_isect_fused_supported(uint32_t n_images, uint32_t tile_w, uint32_t tile_
 int64_t gsx_isect_fused_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
 int64_t gsx_isect_fused_emit_workspace_bytes(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
 int gsx_isect_fused_count(const float *means2d, const int32_t *radii, const float *conics, const float *opacities,
+                          const uint8_t *tile_mask /* NULL, or [n_images * tiles] flags: only flagged tiles receive
+                                                      intersections (gsplat::intersect_tile_sparse); tiles_per_gauss may then be NULL */,
                           int64_t rows, uint32_t n_images, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                           int32_t *tiles_per_gauss, int32_t *isect_offsets, int64_t *n_isects,
                           void *count_workspace, int64_t count_workspace_bytes, void *stream);
 int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *radii, const float *depths, const float *conics,
-                              const float *opacities, int64_t rows, uint32_t n_images, uint32_t tile_size,
+                              const float *opacities, const uint8_t *tile_mask, int64_t rows, uint32_t n_images, uint32_t tile_size,
                               uint32_t tile_w, uint32_t tile_h, void *count_workspace, int64_t count_workspace_bytes,
                               const int32_t *isect_offsets, int64_t n_isects, int64_t *isect_ids_sorted,
                               int32_t *flatten_ids_sorted, void *workspace, int64_t workspace_bytes, void *stream);
@@ -258,6 +260,28 @@ int gsx_raster3d_bwd(const float *means2d, const float *conics, const float *col
                      uint32_t n_images, uint32_t n_isects, uint32_t cdim,
                      uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                      int has_abs, float *v_rows, uint32_t row_stride, void *stream);
+
+/* Sparse pixel sets: gsplat::rasterize_to_pixels_sparse{,_bwd} (ext.cpp:1090-1104; RasterizeToPixelsSparse{Fwd,Bwd}.cu,
+ * RasterizeSparseAddressing.cuh). One workgroup per ACTIVE tile (active_tiles int32 [AT], ascending dense tile ids;
+ * tile_offsets int32 [AT+1] from the masked intersection); tile_pixel_mask uint64 [AT, words] = raster-order bitmask of the
+ * requested pixels, tile_pixel_cumsum int64 [AT] inclusive, pixel_map int64 [P]: position in (tile, in-tile) order ->
+ * caller's pixel index = the ROW of the [P, ...] outputs / cotangents. Everything else as gsx_raster3d_{fwd,bwd}. */
+int gsx_raster3d_sparse_fwd(const float *means2d, const float *conics, const float *colors, const float *opacities,
+                            const float *backgrounds, const uint8_t *masks, const int32_t *active_tiles,
+                            const int32_t *tile_offsets, const int32_t *flatten_ids, const uint64_t *tile_pixel_mask,
+                            const int64_t *tile_pixel_cumsum, const int64_t *pixel_map, uint32_t n_active,
+                            uint32_t words_per_tile, uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width,
+                            uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *render_colors,
+                            float *render_alphas, int32_t *last_ids, void *stream);
+int gsx_raster3d_sparse_bwd(const float *means2d, const float *conics, const float *colors, const float *opacities,
+                            const float *backgrounds, const uint8_t *masks, const int32_t *active_tiles,
+                            const int32_t *tile_offsets, const int32_t *flatten_ids, const uint64_t *tile_pixel_mask,
+                            const int64_t *tile_pixel_cumsum, const int64_t *pixel_map, uint32_t n_active,
+                            uint32_t words_per_tile, const float *render_alphas, const int32_t *last_ids,
+                            const float *v_render_colors, const float *v_render_alphas, uint32_t n_images,
+                            uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+                            uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows, uint32_t row_stride,
+                            void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * proj(): gsplat::projection_ewa_simple{,_bwd} (ext.cpp:1043-1050; ProjectionEWASimple.cu). Camera-space means
@@ -375,6 +399,27 @@ int gsx_raster3d_top_contributing(const float *means2d, const float *conics, con
                                   uint32_t n_isects, uint32_t n_per_image, uint32_t width, uint32_t height,
                                   uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, uint32_t num_depth_samples,
                                   int32_t *ids, float *weights, void *stream);
+
+/* Sparse pixel sets: gsplat::rasterize_num_contributing_gaussians_sparse / rasterize_contributing_gaussian_ids_sparse /
+ * rasterize_top_contributing_gaussian_ids_sparse (ext.cpp:1115-1140; Rasterization.cpp:1196-1250, 1393-...). Layout as
+ * gsx_raster3d_sparse_fwd; outputs are rows [P] / [P, K] in the caller's pixel order. */
+int gsx_raster3d_sparse_num_contributing(const float *means2d, const float *conics, const float *opacities,
+        const int32_t *active_tiles, const int32_t *tile_offsets, const int32_t *flatten_ids,
+        const uint64_t *tile_pixel_mask, const int64_t *tile_pixel_cumsum, const int64_t *pixel_map,
+        uint32_t n_active, uint32_t words_per_tile, uint32_t n_images, uint32_t n_isects, uint32_t n_per_image,
+        uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int32_t *counts, float *alphas, void *stream);
+int gsx_raster3d_sparse_contributing_ids(const float *means2d, const float *conics, const float *opacities,
+        const int32_t *active_tiles, const int32_t *tile_offsets, const int32_t *flatten_ids,
+        const uint64_t *tile_pixel_mask, const int64_t *tile_pixel_cumsum, const int64_t *pixel_map,
+        uint32_t n_active, uint32_t words_per_tile, uint32_t n_images, uint32_t n_isects, uint32_t n_per_image,
+        uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, uint32_t max_contributing, int32_t *ids, float *weights,
+        void *stream);
+int gsx_raster3d_sparse_top_contributing(const float *means2d, const float *conics, const float *opacities,
+        const int32_t *active_tiles, const int32_t *tile_offsets, const int32_t *flatten_ids,
+        const uint64_t *tile_pixel_mask, const int64_t *tile_pixel_cumsum, const int64_t *pixel_map,
+        uint32_t n_active, uint32_t words_per_tile, uint32_t n_images, uint32_t n_isects, uint32_t n_per_image,
+        uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, uint32_t num_depth_samples, int32_t *ids, float *weights,
+        void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer-side ops of the training step around the rasterizer.

@@ -720,3 +720,51 @@ def top_contributions(ids, wts, K):
         out_i[p] = [si[k] for k in order]
         out_w[p] = [sw[k] for k in order]
     return out_i, out_w
+
+
+# ---- sparse pixel sets -----------------------------------------------------------------------------------------------
+def sparse_tile_layout(pixels, image_ids, n_images: int, tile_size: int, tile_width: int, tile_height: int):
+    """gsplat.build_sparse_tile_layout (Intersect.cpp:696-794; key / bitmask kernels in SparseTileLayout.cu; contract in
+    _wrapper.py:1433-1493), restated with python loops. Returns numpy (active_tiles int32 [AT], active_tile_mask bool
+    [I, th, tw], tile_pixel_mask uint64 [AT, words], tile_pixel_cumsum int64 [AT] inclusive ([1] zero when empty),
+    pixel_map int64 [P])."""
+    px = _np(pixels, np.int64).reshape(-1, 2)
+    im = _np(image_ids, np.int64).reshape(-1)
+    P, n_tiles, words = px.shape[0], tile_width * tile_height, (tile_size * tile_size + 63) // 64
+    if P == 0 or n_images == 0:
+        return (np.zeros(0, np.int32), np.zeros((n_images, tile_height, tile_width), bool), np.zeros((0, words), np.uint64),
+                np.zeros(1, np.int64), np.zeros(0, np.int64))
+    entries = []
+    for p in range(P):
+        r, c = int(px[p, 0]), int(px[p, 1])
+        tile = int(im[p]) * n_tiles + (r // tile_size) * tile_width + (c // tile_size)
+        entries.append((tile, (r % tile_size) * tile_size + (c % tile_size), p))
+    entries.sort()  # (tile id, raster position inside the tile); keys are unique -> deterministic
+    pixel_map = np.array([e[2] for e in entries], np.int64)
+    active = sorted({e[0] for e in entries})
+    slot = {t: i for i, t in enumerate(active)}
+    mask = np.zeros((len(active), words), np.uint64)
+    counts = np.zeros(len(active), np.int64)
+    for tile, pos, _p in entries:
+        mask[slot[tile], pos >> 6] |= np.uint64(1) << np.uint64(pos & 63)
+        counts[slot[tile]] += 1
+    tmask = np.zeros(n_images * n_tiles, bool)
+    tmask[active] = True
+    return (np.array(active, np.int32), tmask.reshape(n_images, tile_height, tile_width), mask, np.cumsum(counts), pixel_map)
+
+
+def isect_tiles_sparse(means2d, radii, depths, tile_mask, active_tiles, n_images: int, tile_size: int, tile_width: int,
+                       tile_height: int, image_ids=None):
+    """gsplat.isect_tiles_sparse (Intersect.cpp:563-690): the AABB enumeration of isect_tiles restricted to the tiles
+    flagged in tile_mask, sorted by (image, tile, depth), with offsets compacted to the active tiles + a sentinel."""
+    _tpg, ids, fl = isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, image_ids=image_ids,
+                                n_images=n_images)
+    ids, fl = ids.numpy(), fl.numpy()
+    n_tiles, tile_bits = tile_width * tile_height, bits_for_count(tile_width * tile_height)
+    hi = (ids >> 32).astype(np.int64)  # image << tile_bits | tile
+    tile_of = (hi >> tile_bits) * n_tiles + (hi & ((1 << tile_bits) - 1))
+    keep = _np(tile_mask, bool).reshape(-1)[tile_of]
+    ids, fl, tile_of = ids[keep], fl[keep], tile_of[keep]
+    act = _np(active_tiles, np.int64)
+    offsets = np.concatenate([np.searchsorted(tile_of, act, side="left"), [len(fl)]]).astype(np.int32)
+    return torch.from_numpy(offsets), torch.from_numpy(fl)
