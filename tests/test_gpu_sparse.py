@@ -114,6 +114,31 @@ def test_isect_sparse_edge_cases(G):
     assert off.tolist() == [0, 0, 0] and fl.numel() == 0
 
 
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_layout_and_isect_sparse_vs_reference_golden(G, case):
+    """Outputs of the reference's own looped torch references (_torch_impl.py:485-708), tests/golden/sparse_ref.npz."""
+    import os
+
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sparse_ref.npz")))
+    C, N, W, H, ts, P = g[f"{case}_dims"].tolist()
+    tw, th = math.ceil(W / ts), math.ceil(H / ts)
+    t = lambda k: torch.from_numpy(g[f"{case}_{k}"]).to(DEV)  # noqa: E731
+    out = G.build_sparse_tile_layout(t("pixels"), t("image_ids"), C, ts, tw, th)
+    for got, k in zip(out, ("active_tiles", "tile_mask", "pixel_mask", "pixel_cumsum", "pixel_map")):
+        got = cpu(got)
+        got = got.view(torch.int64).numpy().view(np.uint64) if got.dtype == torch.uint64 else got.numpy()
+        assert np.array_equal(got, g[f"{case}_{k}"]), k
+    m2, rad, d = t("means2d"), t("radii"), t("depths")
+    off, fl = G.isect_tiles_sparse(m2, rad, d, out[1], out[0], C, ts, tw, th)
+    assert np.array_equal(cpu(off).numpy(), g[f"{case}_tile_offsets"])
+    assert np.array_equal(cpu(fl).numpy(), g[f"{case}_flatten_ids"])
+    vis = (rad > 0).all(-1)
+    ci, _ = torch.where(vis)
+    off, fl = G.isect_tiles_sparse(m2[vis], rad[vis], d[vis], out[1], out[0], C, ts, tw, th, image_ids=ci.to(torch.int32))
+    assert np.array_equal(cpu(off).numpy(), g[f"{case}_tile_offsets_packed"])
+    assert np.array_equal(cpu(fl).numpy(), g[f"{case}_flatten_ids_packed"])
+
+
 def _sparse_vs_dense(G, O, N, C, W, H, ts, D, seed, packed=False, bg=False, masks=False, absgrad=False, clustered=True,
                      P=900):
     rad, m2, d, con, op, ci = _scene(G, N, C, W, H, seed=seed, packed=packed)

@@ -54,3 +54,35 @@ def test_layout_empty():
                                            16, 3, 2)
     assert act.shape == (0,) and tmask.shape == (2, 2, 3) and not tmask.any()
     assert pmask.shape == (0, 4) and cum.tolist() == [0] and pmap.shape == (0,)
+
+
+# ---- golden vectors: outputs of the REFERENCE's looped torch references (oracle/pin_sparse_against_reference.py) ----
+def _gold():
+    import os
+
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sparse_ref.npz")))
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_oracle_and_layout_builder_match_reference_golden(case):
+    from oracle import oracle
+
+    g = _gold()
+    C, N, W, H, ts, P = g[f"{case}_dims"].tolist()
+    tw, th = -(-W // ts), -(-H // ts)
+    pixels, image_ids = torch.from_numpy(g[f"{case}_pixels"]), torch.from_numpy(g[f"{case}_image_ids"])
+    want = [g[f"{case}_{k}"] for k in ("active_tiles", "tile_mask", "pixel_mask", "pixel_cumsum", "pixel_map")]
+    for got, w in zip(oracle.sparse_tile_layout(pixels, image_ids, C, ts, tw, th), want):
+        assert np.array_equal(got, w)
+    for got, w in zip(_impl()(pixels, image_ids, C, ts, tw, th), want):
+        got = got.view(torch.int64).numpy().view(np.uint64) if got.dtype == torch.uint64 else got.numpy()
+        assert np.array_equal(got, w)
+    m2, rad, d = (torch.from_numpy(g[f"{case}_{k}"]) for k in ("means2d", "radii", "depths"))
+    tmask, act = torch.from_numpy(g[f"{case}_tile_mask"]), torch.from_numpy(g[f"{case}_active_tiles"])
+    off, fl = oracle.isect_tiles_sparse(m2, rad, d, tmask, act, C, ts, tw, th)
+    assert np.array_equal(off.numpy(), g[f"{case}_tile_offsets"]) and np.array_equal(fl.numpy(), g[f"{case}_flatten_ids"])
+    vis = (rad > 0).all(-1)
+    ci, _ = torch.where(vis)
+    off, fl = oracle.isect_tiles_sparse(m2[vis], rad[vis], d[vis], tmask, act, C, ts, tw, th, image_ids=ci)
+    assert np.array_equal(off.numpy(), g[f"{case}_tile_offsets_packed"])
+    assert np.array_equal(fl.numpy(), g[f"{case}_flatten_ids_packed"])
