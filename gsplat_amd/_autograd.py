@@ -82,12 +82,14 @@ def _proj_setup(ctx, inputs, output):
 
 def _proj_backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_compensations):
     means, covars, quats, scales, viewmats, Ks, radii, conics, compensations = ctx.saved_tensors
+    # v_means2d / v_conics are NOT made contiguous here: when they are column views of the compositing backward's AoS
+    # gradient rows the op reads them in place through a row stride (_ops._row_view)
     if v_compensations is not None:
         v_compensations = v_compensations.contiguous()
     v_means, v_covars, v_quats, v_scales, v_viewmats = _bwd("projection_ewa_3dgs_fused")(
         means, covars, quats, scales, viewmats, Ks, ctx.width, ctx.height, ctx.eps2d, ctx.camera_model, radii, conics,
-        compensations, _z(v_means2d, ctx.m2_shape, conics).contiguous(), None if v_depths is None else v_depths.contiguous(),
-        _z(v_conics, conics.shape, conics).contiguous(), v_compensations, ctx.needs_input_grad[5],
+        compensations, _z(v_means2d, ctx.m2_shape, conics), None if v_depths is None else v_depths.contiguous(),
+        _z(v_conics, conics.shape, conics), v_compensations, ctx.needs_input_grad[5],
     )
     if not ctx.needs_input_grad[0]:
         v_means = None
@@ -121,8 +123,8 @@ def _projp_backward(ctx, v_batch_ids, v_camera_ids, v_gaussian_ids, v_indptr, v_
     v_means, v_covars, v_quats, v_scales, v_viewmats = _bwd("projection_ewa_3dgs_packed")(
         means, covars, quats, scales, viewmats, Ks, ctx.width, ctx.height, ctx.eps2d, ctx.camera_model,
         ctx.sparse_grad, batch_ids, camera_ids, gaussian_ids, conics, compensations,
-        _z(v_means2d, ctx.m2_shape, conics).contiguous(), None if v_depths is None else v_depths.contiguous(),
-        _z(v_conics, conics.shape, conics).contiguous(), v_compensations, ctx.needs_input_grad[5],
+        _z(v_means2d, ctx.m2_shape, conics), None if v_depths is None else v_depths.contiguous(),
+        _z(v_conics, conics.shape, conics), v_compensations, ctx.needs_input_grad[5],
     )
     if not ctx.needs_input_grad[0]:
         v_means = None
@@ -202,8 +204,8 @@ def _p2_setup(ctx, inputs, output):
 def _p2_backward(ctx, v_radii, v_means2d, v_depths, v_ray_transforms, v_normals):
     means, quats, scales, viewmats, Ks, radii, ray_transforms = ctx.saved_tensors
     v_means, v_quats, v_scales, v_viewmats = _bwd("projection_2dgs_fused")(
-        means, quats, scales, viewmats, Ks, ctx.width, ctx.height, radii, ray_transforms, v_means2d.contiguous(),
-        v_depths.contiguous(), v_ray_transforms.contiguous(), v_normals.contiguous(), ctx.needs_input_grad[3])
+        means, quats, scales, viewmats, Ks, ctx.width, ctx.height, radii, ray_transforms, v_means2d,
+        v_depths.contiguous(), v_ray_transforms, v_normals, ctx.needs_input_grad[3])  # row views are read in place
     return (v_means, v_quats, v_scales, v_viewmats) + (None,) * 7
 
 
@@ -218,8 +220,8 @@ def _p2p_backward(ctx, v_b, v_c, v_g, v_indptr, v_radii, v_means2d, v_depths, v_
     means, quats, scales, viewmats, Ks, batch_ids, camera_ids, gaussian_ids, ray_transforms = ctx.saved_tensors
     v_means, v_quats, v_scales, v_viewmats = _bwd("projection_2dgs_packed")(
         means, quats, scales, viewmats, Ks, ctx.width, ctx.height, ctx.sparse_grad, batch_ids, camera_ids,
-        gaussian_ids, ray_transforms, v_means2d.contiguous(), v_depths.contiguous(), v_ray_transforms.contiguous(),
-        v_normals.contiguous(), ctx.needs_input_grad[3])
+        gaussian_ids, ray_transforms, v_means2d, v_depths.contiguous(), v_ray_transforms, v_normals,
+        ctx.needs_input_grad[3])  # row views are read in place
     return (v_means, v_quats, v_scales, v_viewmats) + (None,) * 7
 
 

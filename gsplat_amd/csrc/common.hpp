@@ -32,6 +32,22 @@ constexpr int kWave = 64;
 void set_last_error(const char *fmt, ...);
 int check_launch(const char *what);
 
+// hipFuncSetAttribute applies to the CURRENT device, so "already raised the dynamic-LDS limit" is tracked per device
+// (one process per GPU is the normal deployment, but a process that drives several devices must still work).
+// Idempotent; racing threads set the same value.
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool first()
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64) return true;
+        const bool f = !done[dev];
+        done[dev]    = true;
+        return f;
+    }
+};
+
 #define GSX_REQUIRE(cond, ...)                 \
     do {                                       \
         if (!(cond)) {                         \

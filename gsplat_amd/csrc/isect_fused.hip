@@ -109,11 +109,10 @@ __global__ void __launch_bounds__(kFusedThreads) fused_emit_scatter_kernel(const
 
 static void set_lds_limit_once()
 {
-    static bool done = false; // idempotent; racing threads set the same value
-    if (!done) {
+    static PerDeviceOnce once;
+    if (once.first()) {
         (void)hipFuncSetAttribute((const void *)fused_count_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         (void)hipFuncSetAttribute((const void *)fused_emit_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        done = true;
     }
 }
 

@@ -187,11 +187,10 @@ static int launch_query(const QueryArgs &a, hipStream_t stream)
             set_last_error("gsx_raster3d_top_contributing: num_depth_samples %u needs %zu bytes of LDS per tile", a.K, smem);
             return GSX_ERR_ARG;
         }
-        static bool attr_done = false;
-        if (!attr_done) {
+        static PerDeviceOnce once;
+        if (once.first()) {
             (void)hipFuncSetAttribute((const void *)raster3d_query_kernel<kQTop>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024 - 4096);
-            attr_done = true;
         }
     }
     raster3d_query_kernel<MODE><<<dim3(grid), dim3(block), smem, stream>>>(a);

@@ -476,13 +476,12 @@ extern "C" int gsx_isect_tile_sort(const int64_t *isect_ids, const int32_t *flat
     a.vals_out = flatten_ids_sorted;
 
     const size_t hist_lds = (size_t)n_bins * sizeof(int32_t);
-    static bool attr_done = false; // raising the dynamic-LDS limit is idempotent; racing threads set the same value
-    if (!attr_done) {
+    static PerDeviceOnce once;
+    if (once.first()) {
         (void)hipFuncSetAttribute((const void *)bucket_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         (void)hipFuncSetAttribute((const void *)bucket_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         (void)hipFuncSetAttribute((const void *)tile_sort_kernel<kCapLarge, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(2 * kCapLarge * sizeof(uint2)));
-        attr_done = true;
     }
     bucket_hist_kernel<<<dim3(a.n_chunks), dim3(kBkThreads), hist_lds, s>>>(a);
     int rc = run_scan_i32_exclusive(a.table, table_elems, a.table_scanned, scan_ws, scan_workspace_bytes_for(table_elems), s);
@@ -604,11 +603,10 @@ extern "C" int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *ra
     f.isect_offsets = isect_offsets; f.bucketed = a.bucketed; f.tile_mask = tile_mask;
     rc = launch_fused_emit_scatter(f, s);
     if (rc != GSX_OK) return rc;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce once_fused;
+    if (once_fused.first()) {
         (void)hipFuncSetAttribute((const void *)tile_sort_kernel<kCapLarge, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(2 * kCapLarge * sizeof(uint2)));
-        attr_done = true;
     }
     if (hipMemsetAsync(a.big_count, 0, sizeof(int32_t), s) != hipSuccess) return check_launch("isect_fused memset");
     tile_sort_small_kernel<<<dim3(n_bins), dim3(kTsThreads), kCapSmall * sizeof(uint64_t), s>>>(a);

@@ -159,6 +159,10 @@ def _meta_group():
         if dist.get_backend() == "gloo":
             grp = dist.group.WORLD
         else:
+            # single-node rendezvous over loopback (the launch contract of bench.py / cli()): pin gloo to `lo` instead of
+            # letting it resolve the container's hostname, which need not resolve
+            if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             try:
                 grp = dist.new_group(backend="gloo")
             except Exception:  # no usable network interface for gloo: fall back to the device collective

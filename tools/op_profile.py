@@ -30,7 +30,7 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -43,3 +43,14 @@ for e in ev:
     agg[e.name] += e.cpu_time_total; cnt[e.name] += 1
 for k, v in agg.most_common(40):
     print(f"{k[:70]:70s} n={cnt[k]/3:5.1f} cpu_us/step={v/3:8.1f}")
+
+print("copy-like ops by input shape (per step):")
+shp = collections.Counter()
+for e in prof.events():
+    if e.device_type == torch.autograd.DeviceType.CPU and e.name in ("aten::copy_", "aten::clone", "aten::contiguous",
+                                                                     "aten::add", "aten::add_", "aten::zeros", "aten::fill_",
+                                                                     "aten::zero_", "aten::sum", "aten::cat", "aten::index_select"):
+        par = e.cpu_parent.name if e.cpu_parent is not None else "-"
+        shp[(e.name, str(e.input_shapes)[:90], par[:50])] += 1
+for (name, shapes, par), n in sorted(shp.items(), key=lambda kv: -kv[1]):
+    print(f"  {name:18s} n={n/3:4.1f}  parent={par:50s} {shapes}")
