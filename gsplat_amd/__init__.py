@@ -28,6 +28,8 @@ _LAZY = {
     # the training step around the rasterizer
     "SelectiveAdam": "optimizers", "compute_relocation": "relocation", "DefaultStrategy": "strategy",
     "MCMCStrategy": "strategy", "strategy": "strategy", "optimizers": "optimizers", "relocation": "relocation",
+    # on-disk formats
+    "export_splats": "exporter", "exporter": "exporter",
 }
 
 
