@@ -207,11 +207,49 @@ __device__ __forceinline__ void fix_ties(Ptr a, int n)
 }
 
 // Small tiles (n <= kCapSmall): bitonic sort of the 64-bit (depth bits, flatten id) words in LDS. The id in the low half
-// makes exact depth ties come out in ascending id order, so no tie pass is needed. Thread t of a stage with partner
-// distance j handles the pair (i, i|j), i = t with a zero inserted at bit log2(j): for j <= 32 both elements of every
-// pair of a wave lie in the wave's own 128-element window, so those stages need no workgroup barrier (LDS operations of
-// one wave execute in order); only stages with j >= 64 are separated by __syncthreads(). Longer tiles are appended to
-// the work list for the radix kernel below.
+// makes exact depth ties come out in ascending id order, so no tie pass is needed. Longer tiles are appended to the work
+// list for the radix kernel below.
+//
+// The network is LDS-bandwidth bound (one read + write of the whole array per stride when done stride by stride: 45
+// round trips for 512 entries), so each thread resolves up to THREE consecutive strides per round trip on eight words
+// held in registers: the phases k = 2, 4, 8 run entirely in registers on 8 consecutive words, and every later phase
+// (strides k/2 ... 1) is cut into groups of three strides (j, j/2, j/4): a thread owns the 8 words i | b * (j/4),
+// b = 0..7, for which all three compare-exchange levels are internal. 512 entries: 16 round trips instead of 45.
+// Words live at ts_phys(i) = i + i/8 (one pad word per eight), which spreads the 8-word-strided accesses of the lowest
+// group over the banks.
+constexpr int kTsGroup = 3;
+constexpr int kTsSmallWords = kCapSmall + kCapSmall / 8;
+__device__ __forceinline__ int ts_phys(int i) { return i + (i >> 3); }
+__device__ __forceinline__ void ts_cmpx(uint64_t &x, uint64_t &y, bool up)
+{
+    const bool sw     = (x > y) == up;
+    const uint64_t lo = sw ? y : x, hi = sw ? x : y;
+    x = lo;
+    y = hi;
+}
+
+// strides 2^(lj+G-1) ... 2^lj of phase k on 2^G words per thread
+template <int G>
+__device__ __forceinline__ void bitonic_group(uint64_t *s, int P, int k, int lj)
+{
+    constexpr int R = 1 << G;
+    for (int t = threadIdx.x; t < (P >> G); t += kTsThreads) {
+        const int i   = ((t >> lj) << (lj + G)) | (t & ((1 << lj) - 1));
+        const bool up = (i & k) == 0;
+        uint64_t e[R];
+#pragma unroll
+        for (int b = 0; b < R; ++b) e[b] = s[ts_phys(i | (b << lj))];
+#pragma unroll
+        for (int q = G - 1; q >= 0; --q)
+#pragma unroll
+            for (int b = 0; b < R; ++b)
+                if (!(b & (1 << q))) ts_cmpx(e[b], e[b | (1 << q)], up);
+#pragma unroll
+        for (int b = 0; b < R; ++b) s[ts_phys(i | (b << lj))] = e[b];
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(kTsThreads) tile_sort_small_kernel(const TileSortArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -225,8 +263,9 @@ __global__ void __launch_bounds__(kTsThreads) tile_sort_small_kernel(const TileS
         if (threadIdx.x == 0) a.big_list[atomicAdd(a.big_count, 1)] = (int32_t)bin;
         return;
     }
-    int P = 128; // a wave's window; also the smallest padded size
-    while (P < n) P <<= 1;
+    int lp = 7; // at least 128 words
+    while ((1 << lp) < n) ++lp;
+    const int P = 1 << lp;
     const uint2 *g_in = a.bucketed + start;
     for (int i = threadIdx.x; i < P; i += kTsThreads) {
         uint64_t w = ~0ull;
@@ -234,31 +273,43 @@ __global__ void __launch_bounds__(kTsThreads) tile_sort_small_kernel(const TileS
             const uint2 e = g_in[i];
             w = ((uint64_t)e.x << 32) | e.y;
         }
-        s[i] = w;
+        s[ts_phys(i)] = w;
     }
     __syncthreads();
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (P >> 1); t += kTsThreads) {
-                const int i  = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l  = i | j;
-                const bool up = (i & k) == 0;
-                const uint64_t x = s[i], y = s[l];
-                if ((x > y) == up) {
-                    s[i] = y;
-                    s[l] = x;
-                }
-            }
-            if (j >= 64) __syncthreads();
-            else __builtin_amdgcn_wave_barrier();
+    // phases k = 2, 4, 8 on 8 consecutive words per thread
+    for (int t = threadIdx.x; t < (P >> 3); t += kTsThreads) {
+        uint64_t e[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) e[b] = s[ts_phys(8 * t + b)];
+#pragma unroll
+        for (int lk = 1; lk <= 3; ++lk)
+#pragma unroll
+            for (int q = lk - 1; q >= 0; --q)
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (!(b & (1 << q))) {
+                        const bool up = lk < 3 ? ((b & (1 << lk)) == 0) : ((t & 1) == 0); // ((8 t + b) & k) == 0
+                        ts_cmpx(e[b], e[b | (1 << q)], up);
+                    }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) s[ts_phys(8 * t + b)] = e[b];
+    }
+    __syncthreads();
+    for (int lk = 4; lk <= lp; ++lk) {
+        const int k = 1 << lk;
+        for (int top = lk - 1; top >= 0;) { // log2 of the largest stride still to do in this phase
+            const int g = top + 1 < kTsGroup ? top + 1 : kTsGroup;
+            const int lj = top - g + 1;
+            if (g == 3) bitonic_group<3>(s, P, k, lj);
+            else if (g == 2) bitonic_group<2>(s, P, k, lj);
+            else bitonic_group<1>(s, P, k, lj);
+            top -= g;
         }
-        if (k >= 64) __syncthreads(); // next k starts with j = k: pairs may cross waves again
     }
-    __syncthreads();
     const uint64_t tile = bin % a.n_tiles, img = bin / a.n_tiles;
     const uint64_t hi   = ((img << a.tile_bits) | tile) << 32;
     for (int i = threadIdx.x; i < n; i += kTsThreads) {
-        const uint64_t w      = s[i];
+        const uint64_t w      = s[ts_phys(i)];
         a.keys_out[start + i] = hi | (w >> 32);
         a.vals_out[start + i] = (int32_t)(uint32_t)w;
     }
@@ -488,7 +539,7 @@ extern "C" int gsx_isect_tile_sort(const int64_t *isect_ids, const int32_t *flat
     if (rc != GSX_OK) return rc;
     bucket_scatter_kernel<<<dim3(a.n_chunks), dim3(kBkThreads), hist_lds, s>>>(a);
     if (hipMemsetAsync(a.big_count, 0, sizeof(int32_t), s) != hipSuccess) return check_launch("isect_tile_sort memset");
-    tile_sort_small_kernel<<<dim3(n_bins), dim3(kTsThreads), kCapSmall * sizeof(uint64_t), s>>>(a);
+    tile_sort_small_kernel<<<dim3(n_bins), dim3(kTsThreads), kTsSmallWords * sizeof(uint64_t), s>>>(a);
     tile_sort_kernel<kCapLarge, 1><<<dim3(256), dim3(kTsThreads), 2 * kCapLarge * sizeof(uint2), s>>>(a);
     return check_launch("isect_tile_sort");
 }
@@ -609,7 +660,7 @@ extern "C" int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *ra
                                   (int)(2 * kCapLarge * sizeof(uint2)));
     }
     if (hipMemsetAsync(a.big_count, 0, sizeof(int32_t), s) != hipSuccess) return check_launch("isect_fused memset");
-    tile_sort_small_kernel<<<dim3(n_bins), dim3(kTsThreads), kCapSmall * sizeof(uint64_t), s>>>(a);
+    tile_sort_small_kernel<<<dim3(n_bins), dim3(kTsThreads), kTsSmallWords * sizeof(uint64_t), s>>>(a);
     tile_sort_kernel<kCapLarge, 1><<<dim3(256), dim3(kTsThreads), 2 * kCapLarge * sizeof(uint2), s>>>(a);
     return check_launch("isect_fused_emit_sort");
 }
