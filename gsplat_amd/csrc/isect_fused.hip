@@ -15,6 +15,7 @@
 // row order), because the per-tile sort does not depend on the arrival order inside a segment. HBM traffic per
 // intersection drops from 12 (emit) + 8 (hist) + 12 + 8 (scatter) to 8 bytes before the per-tile sort.
 //
+// Both walk kernels visit the rows of a chunk in a load-balanced order (for_rows_balanced below).
 // Chunks are image-aligned (dense rows: N per image; packed rows are supported for a single image), so a chunk's
 // histogram only needs the tiles of ONE image: the table is [n_chunks][tiles per image].
 // Compiled with -ffp-contract=off (the walk must be bit-exact with the oracle; see isect_walk.hpp).
@@ -56,6 +57,72 @@ __device__ __forceinline__ RowGeom load_row_geom(const FusedArgs &a, int64_t r, 
     return q;
 }
 
+// ---- load balancing of the walk ------------------------------------------------------------------------------------
+// The walk of one row costs (slabs + tiles) of that row, and a wave pays for its LARGEST row: with rows in storage order
+// (near, large Gaussians scattered among thousands of 1-4 tile ones) most lanes idle most of the time. So every
+// kFusedSub rows of a chunk are first ordered by a size class — the tile area of the radius box, 63 = largest — with an
+// LDS counting sort, and thread t walks the t-th row of that order: waves get rows of similar cost, the big ones first.
+// Which thread walks a row changes nothing in the outputs (counts per row; slots inside a tile segment are sorted later).
+constexpr int kFusedSub = 4096;
+// dynamic LDS = one int32 per tile of an image (<= kMaxBins = 36864 of tile_sort.hip) next to ~8.3 KiB of static LDS below
+constexpr int kFusedMaxDynLds = 36864 * 4;
+static_assert(kFusedSub % kFusedThreads == 0 && kFusedSub <= 65536, "order entries are uint16");
+
+__device__ __forceinline__ int size_class(const FusedArgs &a, int64_t r)
+{
+    const FusedGeom &g = a.geom;
+    const float rx = (float)a.radii[2 * r], ry = (float)a.radii[2 * r + 1];
+    if (!(rx > 0.0f && ry > 0.0f)) return 63; // dead rows last
+    const float mx = a.means2d[2 * r], my = a.means2d[2 * r + 1], ts = (float)g.tile_size;
+    const int x0 = clampi(f2i_trunc_sat((mx - rx) / ts), 0, (int)g.tile_w), x1 = clampi(f2i_trunc_sat((mx + rx) / ts) + 1, 0, (int)g.tile_w);
+    const int y0 = clampi(f2i_trunc_sat((my - ry) / ts), 0, (int)g.tile_h), y1 = clampi(f2i_trunc_sat((my + ry) / ts) + 1, 0, (int)g.tile_h);
+    const int area = max(x1 - x0, 0) * max(y1 - y0, 0);
+    return 62 - min(area, 62); // 0 = the largest boxes, 62 = nothing on screen
+}
+
+// visits the rows [lo, hi) of a chunk, `body(row)` once per row, in balanced order
+template <typename Body>
+__device__ __forceinline__ void for_rows_balanced(const FusedArgs &a, int64_t lo, int64_t hi, Body &&body)
+{
+    __shared__ uint16_t s_order[kFusedSub];
+    __shared__ int32_t s_cnt[64];
+    constexpr int kPer = kFusedSub / kFusedThreads;
+    for (int64_t sub = lo; sub < hi; sub += kFusedSub) {
+        const int n = (int)min((int64_t)kFusedSub, hi - sub);
+        if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        int cls[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int i = (int)threadIdx.x + q * kFusedThreads;
+            cls[q]      = i < n ? size_class(a, sub + i) : -1;
+            if (cls[q] >= 0) atomicAdd(&s_cnt[cls[q]], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) { // exclusive scan of the 64 class counts by the first wave
+            const int c = s_cnt[threadIdx.x];
+            int incl    = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if ((int)threadIdx.x >= o) incl += up;
+            }
+            s_cnt[threadIdx.x] = incl - c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kPer; ++q)
+            if (cls[q] >= 0) s_order[atomicAdd(&s_cnt[cls[q]], 1)] = (uint16_t)((int)threadIdx.x + q * kFusedThreads);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int i = (int)threadIdx.x + q * kFusedThreads;
+            if (i < n) body(sub + (int64_t)s_order[i]);
+        }
+        __syncthreads(); // s_order / s_cnt are reused by the next sub-chunk
+    }
+}
+
 __global__ void __launch_bounds__(kFusedThreads) fused_count_hist_kernel(const FusedArgs a)
 {
     extern __shared__ int32_t s_hist[];
@@ -66,7 +133,7 @@ __global__ void __launch_bounds__(kFusedThreads) fused_count_hist_kernel(const F
     chunk_rows(g, blockIdx.x, lo, hi);
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)(blockIdx.x / g.cpi) * g.n_tiles : nullptr;
-    for (int64_t r = lo + threadIdx.x; r < hi; r += kFusedThreads) {
+    for_rows_balanced(a, lo, hi, [&](int64_t r) {
         const RowGeom q = load_row_geom(a, r, has_conic);
         int32_t n       = 0;
         if (q.live)
@@ -75,7 +142,7 @@ __global__ void __launch_bounds__(kFusedThreads) fused_count_hist_kernel(const F
                                if (!tmask || tmask[tile]) atomicAdd(&s_hist[tile], 1);
                            });
         if (a.tiles_per_gauss) a.tiles_per_gauss[r] = n;
-    }
+    });
     __syncthreads();
     int32_t *out = a.table + (int64_t)blockIdx.x * g.n_tiles;
     for (uint32_t t = threadIdx.x; t < g.n_tiles; t += kFusedThreads) out[t] = s_hist[t];
@@ -94,9 +161,9 @@ __global__ void __launch_bounds__(kFusedThreads) fused_emit_scatter_kernel(const
     chunk_rows(g, blockIdx.x, lo, hi);
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)img * g.n_tiles : nullptr;
-    for (int64_t r = lo + threadIdx.x; r < hi; r += kFusedThreads) {
+    for_rows_balanced(a, lo, hi, [&](int64_t r) {
         const RowGeom q = load_row_geom(a, r, has_conic);
-        if (!q.live) continue;
+        if (!q.live) return;
         const uint32_t dbits = __float_as_uint(a.depths[r]);
         walk_tiles(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h,
                    [&](int64_t tile) {
@@ -104,15 +171,15 @@ __global__ void __launch_bounds__(kFusedThreads) fused_emit_scatter_kernel(const
                        const int32_t slot = atomicAdd(&s_cur[tile], 1);
                        a.bucketed[slot]   = make_uint2(dbits, (uint32_t)r);
                    });
-    }
+    });
 }
 
 static void set_lds_limit_once()
 {
     static PerDeviceOnce once;
     if (once.first()) {
-        (void)hipFuncSetAttribute((const void *)fused_count_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        (void)hipFuncSetAttribute((const void *)fused_emit_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        (void)hipFuncSetAttribute((const void *)fused_count_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxDynLds);
+        (void)hipFuncSetAttribute((const void *)fused_emit_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxDynLds);
     }
 }
 
