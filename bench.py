@@ -98,6 +98,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or args.force_distributed
+    # The ONE JSON line goes to the real stdout; everything else written to fd 1 by libraries (RCCL prints a version
+    # banner to stdout when the first communicator is created) is sent to stderr.
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -279,7 +284,7 @@ def main():
             "t_fwd_s": round(ref["t_fwd"], 3), "t_bwd_s": round(ref["t_bwd"], 3), "n_isects": ref["n_isects"],
         }
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), file=json_out, flush=True)
     if distributed:
         dist.destroy_process_group()
 

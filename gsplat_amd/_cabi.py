@@ -196,6 +196,18 @@ def isect_fused_emit_workspace_bytes(n: int, n_images: int, tile_w: int, tile_h:
     return int(_lib.gsx_isect_fused_emit_workspace_bytes(n, n_images, tile_w, tile_h))
 
 
+def copy_column_groups(groups, rows: int) -> None:
+    """One launch of gsx_copy_column_groups. `groups`: list of (src_ptr, src_row_stride, dst_ptr, dst_row_stride, width)
+    in 32-bit words (device pointers as ints)."""
+    n = len(groups)
+    src = (ctypes.c_void_p * n)(*[g[0] for g in groups])
+    dst = (ctypes.c_void_p * n)(*[g[2] for g in groups])
+    ss = (ctypes.c_uint32 * n)(*[g[1] for g in groups])
+    ds = (ctypes.c_uint32 * n)(*[g[3] for g in groups])
+    w = (ctypes.c_uint32 * n)(*[g[4] for g in groups])
+    call("gsx_copy_column_groups", n, src, ss, dst, ds, w, rows)
+
+
 def sort_pairs(keys, vals, keys_alt, vals_alt, n: int, end_bit: int, workspace) -> bool:
     """Returns True when the sorted data ended up in the alt buffers."""
     flag = ctypes.c_int(0)

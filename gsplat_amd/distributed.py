@@ -141,6 +141,160 @@ class _ExchangeRows(torch.autograd.Function):
         return back, None, None, None
 
 
+class _Pending:
+    """Handle of an exchange launched with async_op=True. wait() orders the CURRENT stream after the collective (RCCL:
+    a stream-side wait, the host does not block; gloo: the host blocks) and is idempotent."""
+    __slots__ = ("work",)
+
+    def __init__(self):
+        self.work = None
+
+    def wait(self) -> None:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+
+class _AsyncExchange(torch.autograd.Function):
+    """A personalised row exchange that is LAUNCHED here and waited for by the caller (``fwd.wait()`` before the
+    returned views are read), so that independent kernels run while the rows cross xGMI. Optional int32 ``radii`` ride
+    along as two bit-cast columns. The backward launches the reverse exchange of the payload gradient; with
+    ``bwd`` given it returns without waiting and the ``_WaitGrad`` node upstream waits (the autograd engine runs nodes
+    created later in the forward first, so everything created between the two — the SH backward — overlaps it)."""
+
+    @staticmethod
+    def forward(ctx, payload: Tensor, radii: Optional[Tensor], in_splits: List[int], out_splits: List[int],
+                fwd: _Pending, bwd: Optional[_Pending], message: Optional[Tensor] = None):
+        F_ = payload.shape[1]
+        if message is not None:  # payload is message[:, :F_] and the radii already sit behind it (_PackGeometry)
+            buf = message
+        else:
+            buf = payload.contiguous() if radii is None else torch.cat([payload, radii.contiguous().view(torch.float32)], dim=1)
+        out = torch.empty((sum(out_splits), buf.shape[1]), dtype=payload.dtype, device=payload.device)
+        fwd.work = dist.all_to_all_single(out, buf, out_splits, in_splits, async_op=True)
+        ctx.splits, ctx.bwd = (in_splits, out_splits), bwd
+        recv_r = out[:, F_:]  # float32 VIEW of the radii bits (no data is touched before the caller waits)
+        ctx.mark_non_differentiable(recv_r)
+        return out[:, :F_], recv_r
+
+    @staticmethod
+    def backward(ctx, v_payload: Tensor, _v_radii):
+        if v_payload is None:
+            return None, None, None, None, None, None, None
+        in_splits, out_splits = ctx.splits
+        v_payload = v_payload.contiguous()
+        back = torch.empty((sum(in_splits), v_payload.shape[1]), dtype=v_payload.dtype, device=v_payload.device)
+        work = dist.all_to_all_single(back, v_payload, in_splits, out_splits, async_op=True)
+        if ctx.bwd is None:
+            work.wait()
+        else:
+            ctx.bwd.work = work
+        return back, None, None, None, None, None, None
+
+
+class _WaitGrad(torch.autograd.Function):
+    """Identity whose backward first waits for a pending reverse exchange (see _AsyncExchange)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, pending: _Pending):
+        ctx.pending = pending
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, v):
+        ctx.pending.wait()
+        return v, None
+
+
+def _row_source(t: Tensor, width: int):
+    """(tensor to keep alive, data pointer, row stride in words) of a [rows, width] 4-byte tensor; column views with a
+    uniform row stride (e.g. slices of the AoS gradient rows) are read in place, anything else through a contiguous copy."""
+    if not (t.dim() == 2 and t.shape[1] == width and (width == 1 or t.stride(1) == 1) and t.stride(0) >= width):
+        t = t.contiguous()
+    return t, t.data_ptr(), t.stride(0)
+
+
+def _copy_groups(srcs, dsts, rows: int) -> None:
+    """srcs / dsts: lists of [rows, w] 4-byte tensors (any uniform row stride). HIP kernel on the GPU (csrc/rows.hip); on
+    CPU tensors — the gloo tests of the seams — plain torch copies."""
+    if rows == 0:
+        return
+    if srcs[0].is_cuda:
+        from . import _cabi
+
+        keep, groups = [], []
+        for s_, d_ in zip(srcs, dsts):
+            w = d_.shape[1]
+            s_, sp, ss = _row_source(s_, w)
+            keep.append(s_)
+            groups.append((sp, ss, d_.data_ptr(), d_.stride(0), w))
+        _cabi.copy_column_groups(groups, rows)
+    else:
+        for s_, d_ in zip(srcs, dsts):
+            d_.copy_(s_)
+
+
+class _PackGeometry(torch.autograd.Function):
+    """(means2d [R,2], depths [R], conics [R,3], opacities [R], radii int32 [R,2]) -> the seam-B message [R, 9] in ONE
+    kernel, returned as (message, its differentiable payload view message[:, :7]). Backward: one kernel back."""
+
+    @staticmethod
+    def forward(ctx, means2d, depths, conics, opacities, radii):
+        R = means2d.shape[0]
+        msg = torch.empty((R, 9), dtype=means2d.dtype, device=means2d.device)
+        srcs = [means2d, depths.reshape(R, 1), conics, opacities.reshape(R, 1), radii.view(torch.float32)]
+        _copy_groups(srcs, [msg[:, 0:2], msg[:, 2:3], msg[:, 3:6], msg[:, 6:7], msg[:, 7:9]], R)
+        ctx.mark_non_differentiable(msg)
+        ctx.shapes = (depths.shape, opacities.shape)
+        return msg, msg[:, :7]
+
+    @staticmethod
+    def backward(ctx, _v_msg, v):
+        if v is None:
+            return None, None, None, None, None
+        R = v.shape[0]
+        v_m2, v_dp = v.new_empty((R, 2)), v.new_empty((R, 1))
+        v_cn, v_op = v.new_empty((R, 3)), v.new_empty((R, 1))
+        _copy_groups([v[:, 0:2], v[:, 2:3], v[:, 3:6], v[:, 6:7]], [v_m2, v_dp, v_cn, v_op], R)
+        return v_m2, v_dp.reshape(ctx.shapes[0]), v_cn, v_op.reshape(ctx.shapes[1]), None
+
+
+class _UnpackGeometry(torch.autograd.Function):
+    """Received message views (payload [R,7], radii bits [R,2], both with the message's row stride) -> contiguous
+    means2d, depths, conics, opacities, radii in ONE kernel; backward packs the four gradients (column views of the
+    compositing backward's gradient rows are read in place) into the [R,7] buffer the reverse exchange sends."""
+
+    @staticmethod
+    def forward(ctx, payload, radii_bits):
+        R, dev = payload.shape[0], payload.device
+        m2, dp = payload.new_empty((R, 2)), payload.new_empty((R, 1))
+        cn, op = payload.new_empty((R, 3)), payload.new_empty((R, 1))
+        rad = torch.empty((R, 2), dtype=torch.int32, device=dev)
+        _copy_groups([payload[:, 0:2], payload[:, 2:3], payload[:, 3:6], payload[:, 6:7], radii_bits],
+                     [m2, dp, cn, op, rad.view(torch.float32)], R)
+        ctx.mark_non_differentiable(rad)
+        ctx.like = (R, payload.dtype, dev)
+        return m2, dp.reshape(R), cn, op.reshape(R), rad
+
+    @staticmethod
+    def backward(ctx, v_m2, v_dp, v_cn, v_op, _v_rad):
+        R, dt, dev = ctx.like
+        parts = [(v_m2, 0, 2), (v_dp, 2, 1), (v_cn, 3, 3), (v_op, 6, 1)]
+        if all(p[0] is None for p in parts):
+            return None, None
+        full = all(p[0] is not None for p in parts)
+        v = (torch.empty if full else torch.zeros)((R, 7), dtype=dt, device=dev)
+        srcs = [p[0].reshape(R, p[2]) for p in parts if p[0] is not None]
+        dsts = [v[:, p[1]:p[1] + p[2]] for p in parts if p[0] is not None]
+        _copy_groups(srcs, dsts, R)
+        return v, None
+
+
+def _force_exchange() -> bool:
+    """GSPLAT_AMD_FORCE_EXCHANGE=1: run the exchanges even in a world of one rank (single-GPU smoke test of seam B)."""
+    return os.environ.get("GSPLAT_AMD_FORCE_EXCHANGE", "") not in ("", "0")
+
+
 # ----------------------------------------------------------------------------------------------
 # control plane: per-call exchange of (Gaussians, cameras) per rank
 # ----------------------------------------------------------------------------------------------
@@ -251,7 +405,7 @@ class DistributedRasterContext:
                    image_ids = camera id local to this rank and gaussian_ids made global.
         Returns (radii, means2d, depths, conics, opacities, feats, image_ids, gaussian_ids)."""
         W, Cl = self.world_size, self.c_local
-        if W == 1:  # a single rank owns every camera and every Gaussian: nothing moves
+        if W == 1 and not _force_exchange():  # a single rank owns every camera and every Gaussian: nothing moves
             if not packed:
                 return radii, means2d, depths, conics, opacities.contiguous(), feats, None, None
             return radii, means2d, depths, conics, opacities, feats, camera_ids, gaussian_ids
@@ -289,6 +443,62 @@ class DistributedRasterContext:
         ft = pieces[4] if feats is not None else None
         return (recv_r.contiguous(), m2.contiguous(), dp.contiguous(), cn.contiguous(), op.contiguous(), ft,
                 recv_i[:, 0].contiguous(), recv_i[:, 1].contiguous())
+
+
+    # -- seam B, dense rows, overlapped with compute ------------------------------------------------
+    def overlaps(self, packed: bool) -> bool:
+        """Dense rows on more than one rank use the two-message exchange below."""
+        return (not packed) and (self.world_size > 1 or _force_exchange())
+
+    def geometry_payload(self, radii, means2d, depths, conics, opacities):
+        """The geometry message of seam B, [C * N, 9] = means2d | depth | conic | opacity | radii bits, packed by one
+        kernel. Call it right after the projection and BEFORE the colours are computed: its autograd nodes carry the wait
+        for the reverse geometry exchange, and nodes created after them (the SH evaluation) run before them in the
+        backward pass. Returns an opaque handle for scatter_dense_begin."""
+        self._geo_bwd = _Pending()
+        R = radii.numel() // 2
+        msg, payload = _PackGeometry.apply(means2d.reshape(R, 2), depths.reshape(R), conics.reshape(R, 3),
+                                           opacities.reshape(R), radii.reshape(R, 2))
+        return msg, _WaitGrad.apply(payload, self._geo_bwd)
+
+    def scatter_dense_begin(self, geometry, feats):
+        """Launch seam B as TWO messages — geometry (+ radii), then feature rows — and wait only for the first:
+        tile intersection needs nothing but geometry, so the feature rows travel while it runs; in the backward pass the
+        feature gradients come back first and the SH backward overlaps the return of the geometry gradients.
+        Returns (radii, means2d, depths, conics, opacities, features) where ``features()`` waits for and returns the
+        received [C_local, sum N_i, D] rows (None without features). Same values as scatter_projection(False, ...)."""
+        W, Cl, Nl = self.world_size, self.c_local, self.n_local
+        in_s, out_s = [Cl * Nl] * W, [Cl * n for n in self.n_per_rank]
+        geo_fwd, col_fwd = _Pending(), _Pending()
+        msg, payload = geometry
+        recv_g, recv_r = _AsyncExchange.apply(payload, None, in_s, out_s, geo_fwd, getattr(self, "_geo_bwd", None), msg)
+        recv_c = None
+        if feats is not None:
+            recv_c, _ = _AsyncExchange.apply(feats.reshape(W * Cl * Nl, -1), None, in_s, out_s, col_fwd, None)
+
+        def gather(rows, width):  # source rank i contributed [C_local, N_i, width]: concatenate along the Gaussian axis
+            if Cl == 1:
+                return rows.reshape(1, -1, width)
+            return torch.cat([p.reshape(Cl, n, width) for p, n in zip(rows.split(out_s), self.n_per_rank)], dim=1)
+
+        geo_fwd.wait()
+        if Cl == 1:  # the received rows already are [1, sum N_i, *]: one unpack kernel
+            m2, dp, cn, op, rad = _UnpackGeometry.apply(recv_g, recv_r)
+            N = m2.shape[0]
+            out = (rad.reshape(1, N, 2), m2.reshape(1, N, 2), dp.reshape(1, N), cn.reshape(1, N, 3), op.reshape(1, N))
+        else:
+            out_g = gather(recv_g, recv_g.shape[-1])
+            m2, dp, cn, op = out_g.split([2, 1, 3, 1], dim=-1)
+            out = (gather(recv_r, 2).contiguous().view(torch.int32), m2.contiguous(), dp[..., 0].contiguous(),
+                   cn.contiguous(), op[..., 0].contiguous())
+
+        def features():
+            if recv_c is None:
+                return None
+            col_fwd.wait()
+            return gather(recv_c, recv_c.shape[-1])
+
+        return out + (features,)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -184,6 +184,11 @@ def rasterization(
     if compensations is not None:
         proj_opacities = proj_opacities * compensations
 
+    # Distributed, dense rows: the geometry rows for seam B are assembled HERE, before the colours exist, so that in the
+    # backward pass the wait for their returning gradients sits after the SH backward (distributed.py: _AsyncExchange)
+    overlap_exchange = dist_ctx is not None and dist_ctx.overlaps(packed)
+    geo_payload = dist_ctx.geometry_payload(radii, means2d, depths, conics, proj_opacities) if overlap_exchange else None
+
     # ---- tile intersection, first half (single-process path) ----------------------------------------
     # count + scan + asynchronous host read of the intersection total are enqueued BEFORE the SH kernels, which do
     # not depend on them; by the time isect_tiles_finish() needs the number on the host the GPU is still busy.
@@ -215,23 +220,18 @@ def rasterization(
     }
 
     # ---- Seam B: ship every projected Gaussian to the rank that owns its camera ------------------
-    if dist_ctx is not None:
+    recv_features = None
+    if overlap_exchange:
+        # two messages: geometry (waited for here), feature rows (in flight until compositing needs them)
+        radii, means2d, depths, conics, proj_opacities, recv_features = dist_ctx.scatter_dense_begin(geo_payload, feats)
+        image_ids = gaussian_ids_r = None
+        n_rows_per_image = dist_ctx.total_gaussians
+    elif dist_ctx is not None:
         (radii, means2d, depths, conics, proj_opacities, feats, image_ids, gaussian_ids_r) = dist_ctx.scatter_projection(
             packed, radii, means2d, depths, conics, proj_opacities, feats, batch_ids, camera_ids, gaussian_ids)
         n_rows_per_image = dist_ctx.total_gaussians
     else:
         n_rows_per_image = N
-
-    # ---- depth channel ---------------------------------------------------------------------------
-    if has_depth:
-        d = depths[..., None]
-        feats = d if feats is None else torch.cat([feats, d], dim=-1)
-        if backgrounds is not None:
-            if has_color:
-                backgrounds = torch.cat([backgrounds, torch.zeros_like(backgrounds[..., :1])], dim=-1)
-            else:
-                backgrounds = torch.zeros(batch_dims + (C, feats.shape[-1]), device=device, dtype=means.dtype)
-    assert feats is not None
 
     # ---- tile intersection (second half) -----------------------------------------------------------
     if isect_pending is None:
@@ -245,6 +245,21 @@ def rasterization(
     else:
         isect_offsets = isect_offset_encode(isect_ids, I, tile_width, tile_height)
     isect_offsets = isect_offsets.reshape(batch_dims + (C, tile_height, tile_width))
+
+    # ---- feature rows still in flight (distributed, dense): needed from here on -----------------------
+    if recv_features is not None:
+        feats = recv_features()
+
+    # ---- depth channel ---------------------------------------------------------------------------
+    if has_depth:
+        d = depths[..., None]
+        feats = d if feats is None else torch.cat([feats, d], dim=-1)
+        if backgrounds is not None:
+            if has_color:
+                backgrounds = torch.cat([backgrounds, torch.zeros_like(backgrounds[..., :1])], dim=-1)
+            else:
+                backgrounds = torch.zeros(batch_dims + (C, feats.shape[-1]), device=device, dtype=means.dtype)
+    assert feats is not None
 
     # ---- compositing (channel chunks; alphas from the first chunk) -------------------------------
     D_total = feats.shape[-1]

@@ -422,6 +422,16 @@ int gsx_raster3d_sparse_top_contributing(const float *means2d, const float *coni
         void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Pack / unpack around the personalised row exchange of the Gaussian-sharded multi-GPU path (seam B; the reference
+ * builds its send buffers and splits the received ones with at::cat / index / contiguous:
+ * gsplat/cuda/csrc/DistributedCollectives.cpp:368-453). For k < n_groups (<= 8), row < rows, j < widths[k], on 32-bit words:
+ *     dst[k][row * dst_strides[k] + j] = src[k][row * src_strides[k] + j]
+ * src / dst / strides / widths are HOST tables of n_groups entries; the pointers in src / dst are device pointers.
+ * Pack: dst[k] = message + column offset of group k, dst_strides[k] = message row width; unpack: the other way round. */
+int gsx_copy_column_groups(uint32_t n_groups, const void *const *src, const uint32_t *src_strides, void *const *dst,
+                           const uint32_t *dst_strides, const uint32_t *widths, int64_t rows, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optimizer-side ops of the training step around the rasterizer.
  * gsx_adam: gsplat::adam (ext.cpp:1217; csrc/AdamCUDA.cu:34-75). In-place fused Adam step without bias correction on
  *   the rows g of [n_rows, row_width] tensors with valid[g] != 0 (valid NULL = all rows); masked rows keep parameter

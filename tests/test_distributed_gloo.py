@@ -92,6 +92,23 @@ def _worker(rank, port, results, C_LOCAL):
         wexp = torch.cat([torch.full((C_LOCAL, n_local, 7 + D), float(d + 1)) for d in range(WORLD)], 0)
         assert torch.equal(pay.grad, wexp)
 
+        # ---- seam B, dense, as two overlapped messages (geometry first, features in flight) ------------
+        assert ctx.overlaps(False) and not ctx.overlaps(True)
+        pay2 = pay.detach().clone().requires_grad_(True)
+        geo = ctx.geometry_payload(radii, pay2[..., 0:2], pay2[..., 2], pay2[..., 3:6], pay2[..., 6])
+        feats2 = pay2[..., 7:] * 1.0  # stands for the SH evaluation: created AFTER the geometry payload
+        r2, m2b, dpb, cnb, opb, features = ctx.scatter_dense_begin(geo, feats2)
+        assert m2b.is_contiguous() and cnb.is_contiguous() and r2.dtype == torch.int32
+        got2 = torch.cat([m2b, dpb[..., None], cnb, opb[..., None], features()], -1)
+        assert torch.equal(got2.detach(), exp) and torch.equal(r2, r_)
+        (got2 * (rank + 1)).sum().backward()
+        assert torch.equal(pay2.grad, wexp)
+        assert ctx._geo_bwd.work is None  # the reverse geometry exchange was waited for by the _WaitGrad node
+        # without feature rows (depth-only render modes)
+        geo = ctx.geometry_payload(radii, pay2[..., 0:2], pay2[..., 2], pay2[..., 3:6], pay2[..., 6])
+        r3, m3, _d3, _c3, _o3, features = ctx.scatter_dense_begin(geo, None)
+        assert features() is None and torch.equal(m3.detach(), exp[..., 0:2]) and torch.equal(r3, r_)
+
         # ---- seam B, packed ----------------------------------------------------------------------
         g = torch.Generator().manual_seed(100 + rank)
         vis = torch.rand(C_all, n_local, generator=g) > 0.4

@@ -223,11 +223,17 @@ def test_c2_garden_scene_1080p_matches_oracle(G):
                               name=f"c2 v_{k} packed={packed}")
 
 
+@pytest.mark.parametrize("force_exchange", [False, True])
 @pytest.mark.parametrize("packed", [True, False])
-def test_distributed_single_rank_matches_local(G, packed):
+def test_distributed_single_rank_matches_local(G, packed, force_exchange, monkeypatch):
     """Reference contract tests/test_rasterization.py:819-868: with a 1-rank RCCL group, distributed=True must equal
-    the local result (exercises both seams through torch.distributed backend 'nccl' = RCCL)."""
+    the local result (exercises both seams through torch.distributed backend 'nccl' = RCCL). force_exchange: the
+    one-rank shortcuts are disabled, so the all-to-all messages of seam B (dense: the two overlapped asynchronous ones)
+    really run through RCCL and their autograd-side waits order the streams."""
     import os
+
+    if force_exchange:
+        monkeypatch.setenv("GSPLAT_AMD_FORCE_EXCHANGE", "1")
 
     import torch.distributed as dist
 
@@ -247,6 +253,15 @@ def test_distributed_single_rank_matches_local(G, packed):
         assert torch.equal(rc0, rc1) and torch.equal(ra0, ra1)
         for k in NAMES:
             assert_grad_close(l1[k].grad.cpu(), l0[k].grad.cpu(), rel=1e-4, name=f"distributed v_{k}")
+        if force_exchange and not packed:
+            # one camera per rank (the bench configuration): received rows are unpacked by the fused kernel (csrc/rows.hip)
+            sc1, W1, H1 = make_scene(N=3000, C=1, width=160, height=112, seed=14, sh_degree=2)
+            v1c, v1a = v_rc[:1], v_ra[:1]
+            rc0, ra0, _, l0 = _run(G, sc1, W1, H1, v1c, v1a, sh_degree=2, packed=False)
+            rc1, ra1, _, l1 = _run(G, sc1, W1, H1, v1c, v1a, sh_degree=2, packed=False, distributed=True)
+            assert torch.equal(rc0, rc1) and torch.equal(ra0, ra1)
+            for k in NAMES:
+                assert_grad_close(l1[k].grad.cpu(), l0[k].grad.cpu(), rel=1e-4, name=f"distributed (1 camera) v_{k}")
         with pytest.raises(ValueError):
             G.rasterization(sc["means"].to(DEV), sc["quats"].to(DEV), sc["scales"].to(DEV), sc["opacities"].to(DEV),
                             sc["colors"].to(DEV), sc["viewmats"].to(DEV), sc["Ks"].to(DEV), W, H, sh_degree=2,
