@@ -27,6 +27,33 @@ NS = "gsplat"
 # namespace; we then FRAGMENT-define only the missing ops (none, normally) and override impls.
 _lib_def = torch.library.Library(NS, "FRAGMENT")
 _lib_impl = torch.library.Library(NS, "IMPL", "CUDA")
+_lib_impl_autograd = torch.library.Library(NS, "IMPL", "AutogradCUDA")  # whole-pipeline ops only (see COMPOSITE_SCHEMAS)
+
+
+
+def _load_torch_classes() -> Optional[str]:
+    """Load libgsplat_amd_torch.so (csrc/torch_classes.cpp): the torch custom classes that the composite schemas below
+    name by type (``torch.classes.gsplat.UnscentedTransformParameters`` ...). Returns None on success, else the reason
+    the composite ops are not defined (every stage op stays available without it)."""
+    import os
+
+    path = os.environ.get("GSPLAT_AMD_TORCH_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                                                                  "libgsplat_amd_torch.so")
+    try:
+        torch.classes.gsplat.UnscentedTransformParameters  # already registered (e.g. by the reference's own extension)
+        return None
+    except RuntimeError:
+        pass
+    if not os.path.exists(path):
+        return f"{path} not built (make -C gsplat_amd/csrc torch)"
+    try:
+        torch.classes.load_library(path)
+    except OSError as e:
+        return f"cannot load {path}: {e}"
+    return None
+
+
+COMPOSITE_UNAVAILABLE = _load_torch_classes()
 
 SCHEMAS = {
     # gsplat/cuda/ext.cpp:984-991
@@ -73,11 +100,22 @@ SCHEMAS = {
     "rasterize_to_pixels_sparse_bwd": "(Tensor means2d, Tensor conics, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, Tensor image_ids, Tensor active_tiles, Tensor tile_offsets, Tensor flatten_ids, Tensor tile_pixel_mask, Tensor tile_pixel_cumsum, Tensor pixel_map, Tensor render_alphas, Tensor last_ids, int image_width, int image_height, int tile_size, int tile_width, int tile_height, bool absgrad, Tensor v_render_colors, Tensor v_render_alphas, bool compute_v_backgrounds) -> (Tensor?, Tensor, Tensor, Tensor, Tensor, Tensor?)",
     "rasterize_num_contributing_gaussians_sparse": "(Tensor means2d, Tensor conics, Tensor opacities, int image_width, int image_height, int tile_size, int tile_width, int tile_height, Tensor active_tiles, Tensor tile_offsets, Tensor flatten_ids, Tensor tile_pixel_mask, Tensor tile_pixel_cumsum, Tensor pixel_map) -> (Tensor, Tensor)",
     "rasterize_contributing_gaussian_ids_sparse": "(Tensor means2d, Tensor conics, Tensor opacities, int image_width, int image_height, int tile_size, int tile_width, int tile_height, Tensor active_tiles, Tensor tile_offsets, Tensor flatten_ids, Tensor tile_pixel_mask, Tensor tile_pixel_cumsum, Tensor pixel_map, Tensor num_contributing_gaussians) -> (Tensor, Tensor)",
-    "rasterize_top_contributing_gaussian_ids_sparse": "(Tensor means2d, Tensor conics, Tensor opacities, int image_width, int image_height, int tile_size, int tile_width, int tile_height, Tensor active_tiles, Tensor tile_offsets, Tensor flatten_ids, Tensor tile_pixel_mask, Tensor tile_pixel_cumsum, Tensor pixel_map, int num_depth_samples) -> (Tensor, Tensor)",
+    "rasterize_top_contributing_gaussian_ids_sparse": "(Tensor means2d, Tensor conics, Tensor opacities, int image_width, int image_height, int tile_size, int tile_width, int tile_height, int num_depth_samples, Tensor active_tiles, Tensor tile_offsets, Tensor flatten_ids, Tensor tile_pixel_mask, Tensor tile_pixel_cumsum, Tensor pixel_map) -> (Tensor, Tensor)",
+    # fused feature-row assembly (ext.cpp:1015-1020)
+    "assemble_proj_features_unpacked_fwd": "(int degrees_to_use, int B, int C, int N, int Dc, int E, int color_post, int extra_post, bool has_depth, bool depth_is_zero, bool extra_has_c, Tensor means, Tensor viewmats, Tensor? viewmats_rs, Tensor coeffs, Tensor? extra, Tensor? depths, Tensor? masks, Tensor(a!) out, Tensor(b!)? relu_mask) -> ()",
     # training-step ops around the rasterizer: ext.cpp:1217-1221, 1224-1227, 1256-1258
     "adam": "(Tensor(a!) param, Tensor param_grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor? valid, float lr, float b1, float b2, float eps) -> ()",
     "relocation": "(Tensor opacities, Tensor scales, Tensor ratios, Tensor binoms, int n_max, float min_opacity=0.0) -> (Tensor, Tensor)",
-    "mcmc_perturb_positions": "(Tensor(a!) positions, Tensor quats, Tensor scales, Tensor opacities, Tensor noise, float noise_scale, float t, float k) -> ()",
+    "mcmc_perturb_positions": "(Tensor(a!) positions, Tensor quats, Tensor scales, Tensor opacities, Tensor noise, float noise_scale, float t=0.005, float k=100.) -> ()",
+}
+
+# The whole-pipeline ops that gsplat.rasterization() / rasterization_2dgs() call (ext.cpp:1144-1159, 1205-1212). Their
+# schemas name torch custom classes, so they are only defined once csrc/torch_classes.cpp is loaded. Registered on the
+# CUDA key and, like the reference (Rendering.cpp:1972-1980), on AutogradCUDA with the same function, so that the stage
+# ops inside record their own autograd nodes.
+COMPOSITE_SCHEMAS = {
+    "rasterization_3dgs": "(Tensor means, Tensor? covars, Tensor? quats, Tensor? scales, Tensor opacities, Tensor? colors, Tensor viewmats, Tensor Ks, int image_width, int image_height, int tile_size, float eps2d, float near_plane, float far_plane, float radius_clip, Tensor? backgrounds, bool packed, bool sparse_grad, bool absgrad, bool calc_compensations, bool rasterize_mode_is_classic, int camera_model, bool segmented, int channel_chunk, bool has_color, int sh_degree, Tensor? extra_signals, int extra_signals_sh_degree, bool append_depth, bool expected_depth, bool with_eval3d, bool with_ut, Tensor? rays, Tensor? viewmats_rs, __torch__.torch.classes.gsplat.UnscentedTransformParameters ut_params, int rolling_shutter, Tensor? radial_coeffs, Tensor? tangential_coeffs, Tensor? thin_prism_coeffs, __torch__.torch.classes.gsplat.FThetaCameraDistortionParameters ftheta_coeffs, __torch__.torch.classes.gsplat.RowOffsetStructuredSpinningLidarModelParametersExt? lidar_coeffs, __torch__.torch.classes.gsplat.BivariateWindshieldModelParameters? external_distortion_params, bool global_z_order, bool use_hit_distance, bool return_normals, int renderer_config, str? process_group_name, int world_size) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, int, int)",
+    "rasterization_2dgs": "(Tensor means, Tensor quats, Tensor scales, Tensor opacities, Tensor colors, Tensor viewmats, Tensor Ks, int image_width, int image_height, int tile_size, float eps2d, float near_plane, float far_plane, float radius_clip, Tensor? backgrounds, bool packed, bool sparse_grad, bool absgrad, bool distloss, int? sh_degree, str render_mode, str depth_mode) -> (Tensor, Tensor, Tensor, Tensor?, Tensor, Tensor, Tensor, Tensor?, Tensor?, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, int, int, int)",
 }
 
 _impls = {}
@@ -1145,8 +1183,9 @@ def rasterize_contributing_gaussian_ids_sparse(means2d, conics, opacities, image
 
 @_op("rasterize_top_contributing_gaussian_ids_sparse")
 def rasterize_top_contributing_gaussian_ids_sparse(means2d, conics, opacities, image_width, image_height, tile_size,
-                                                   tile_width, tile_height, active_tiles, tile_offsets, flatten_ids,
-                                                   tile_pixel_mask, tile_pixel_cumsum, pixel_map, num_depth_samples):
+                                                   tile_width, tile_height, num_depth_samples, active_tiles,
+                                                   tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum,
+                                                   pixel_map):
     args = _sparse_query_common(means2d, conics, opacities, image_width, image_height, tile_size, tile_width, tile_height,
                                 active_tiles, tile_offsets, flatten_ids, tile_pixel_mask, tile_pixel_cumsum, pixel_map)
     if num_depth_samples < 0:
@@ -1202,6 +1241,128 @@ def mcmc_perturb_positions(positions, quats, scales, opacities, noise, noise_sca
 
 
 # ----------------------------------------------------------------------------------------------
+# fused feature-row assembly (dense rows): [SH colours | extra signals | depth] in one pass
+# ----------------------------------------------------------------------------------------------
+@_op("assemble_proj_features_unpacked_fwd")
+def assemble_proj_features_unpacked_fwd(degrees_to_use, B, C, N, Dc, E, color_post, extra_post, has_depth, depth_is_zero,
+                                        extra_has_c, means, viewmats, viewmats_rs, coeffs, extra, depths, masks, out,
+                                        relu_mask):
+    """Checks follow the reference host op (SphericalHarmonics.cpp:572-676). Writes ``out`` (and ``relu_mask``) in place."""
+    if viewmats_rs is not None:
+        raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
+    _check_f32(means=means, viewmats=viewmats, coeffs=coeffs, out=out, extra=extra, depths=depths)
+    width, lead = Dc + E + (1 if has_depth else 0), B * C * N
+    if coeffs.dim() != 3 or coeffs.shape[0] != N or coeffs.shape[2] != Dc:
+        raise ValueError(f"coeffs must be [N={N}, K, Dc={Dc}], got {tuple(coeffs.shape)}")
+    if means.numel() != B * N * 3 or viewmats.numel() != B * C * 16:
+        raise ValueError("means / viewmats numel mismatch")
+    if not out.is_contiguous() or out.shape[-1] != width or out.numel() != lead * width:
+        raise ValueError(f"out must be contiguous [B, C, N, {width}], got {tuple(out.shape)}")
+    if not (0 <= color_post <= 2 and 0 <= extra_post <= 2):
+        raise ValueError(f"bad color_post / extra_post {color_post} / {extra_post}")
+    if E > 0:
+        if extra is None or extra.numel() != (lead if extra_has_c else B * N) * E:
+            raise ValueError("extra is required when E > 0 and must be [B, C, N, E] or [B, N, E]")
+    use_depths = has_depth and not depth_is_zero
+    if use_depths and (depths is None or depths.numel() != lead):
+        raise ValueError("depths [B, C, N] is required when has_depth and not depth_is_zero")
+    if masks is not None and masks.numel() != lead:
+        raise ValueError("masks numel mismatch")
+    if relu_mask is not None:
+        if relu_mask.dtype != torch.bool or not relu_mask.is_contiguous() or relu_mask.numel() != lead * Dc:
+            raise ValueError("relu_mask must be a contiguous bool [B, C, N, Dc] tensor")
+        if color_post != 2:
+            raise ValueError("relu_mask is only valid with color_post = 2 (shift + relu)")
+    call("gsx_assemble_features_fwd", int(degrees_to_use), B, C, N, coeffs.shape[1], Dc, E, int(color_post),
+         int(extra_post), int(has_depth), int(extra_has_c), ptr(means.contiguous()), ptr(viewmats.contiguous()),
+         ptr(coeffs.contiguous()), ptr(_c(extra)) if E > 0 else None, ptr(_c(depths)) if use_depths else None,
+         ptr(_c(masks)), ptr(out), ptr(relu_mask))
+
+
+# ----------------------------------------------------------------------------------------------
+# whole-pipeline ops (what the reference's gsplat.rasterization() / rasterization_2dgs() call)
+# ----------------------------------------------------------------------------------------------
+_CAMERA_MODEL_NAMES = {0: "pinhole", 1: "ortho", 2: "fisheye", 3: "ftheta", 4: "lidar"}  # Common.h:75-82
+_ROLLING_SHUTTER_GLOBAL = 4  # _wrapper.py RollingShutterType.GLOBAL
+
+
+def _empty(like: Tensor, dtype=None) -> Tensor:
+    """The reference returns ``at::empty({0})`` for outputs a mode does not produce (Rendering.cpp:688, 713, 1348)."""
+    return torch.empty(0, device=like.device, dtype=like.dtype if dtype is None else dtype)
+
+
+@_op("rasterization_3dgs")
+def rasterization_3dgs(means, covars, quats, scales, opacities, colors, viewmats, Ks, image_width, image_height,
+                       tile_size, eps2d, near_plane, far_plane, radius_clip, backgrounds, packed, sparse_grad, absgrad,
+                       calc_compensations, rasterize_mode_is_classic, camera_model, segmented, channel_chunk, has_color,
+                       sh_degree, extra_signals, extra_signals_sh_degree, append_depth, expected_depth, with_eval3d,
+                       with_ut, rays, viewmats_rs, ut_params, rolling_shutter, radial_coeffs, tangential_coeffs,
+                       thin_prism_coeffs, ftheta_coeffs, lidar_coeffs, external_distortion_params, global_z_order,
+                       use_hit_distance, return_normals, renderer_config, process_group_name, world_size):
+    """gsplat::rasterization_3dgs (host ``Rendering.cpp:745-1481``): the flattened argument list of
+    ``gsplat.rasterization()`` (``gsplat/rendering.py:601-650``) mapped back onto the orchestrator in ``rendering.py``.
+    ``ut_params`` / ``ftheta_coeffs`` are always passed by the reference (default-constructed records) and only read by
+    the 3DGUT / f-theta paths, which are rejected like every other out-of-scope argument."""
+    from .rendering import rasterization
+
+    if renderer_config != 0:
+        raise ValueError("RendererConfig PARALLEL_BATCH requires with_eval3d=True; the classic path only supports "
+                         "MIXED_BATCH")
+    if rolling_shutter != _ROLLING_SHUTTER_GLOBAL:
+        raise RuntimeError("gsplat_amd implements the classic 3DGS rasterization path; rolling shutter belongs to the "
+                           "3DGUT path and is not supported")
+    if camera_model not in _CAMERA_MODEL_NAMES:
+        raise ValueError(f"unknown camera_model id {camera_model}")
+    depth = ""
+    if append_depth or use_hit_distance:
+        depth = ("Ed" if expected_depth else "d") if use_hit_distance else ("ED" if expected_depth else "D")
+    if has_color:
+        render_mode = "RGB" + (("-" if use_hit_distance else "+") + depth if depth else "")
+    else:
+        render_mode = depth
+    rc, ra, meta = rasterization(
+        means, quats, scales, opacities, colors if has_color else None, viewmats, Ks, image_width, image_height,
+        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d,
+        sh_degree=None if sh_degree < 0 else sh_degree, packed=packed, tile_size=tile_size, backgrounds=backgrounds,
+        render_mode=render_mode, sparse_grad=sparse_grad, absgrad=absgrad,
+        rasterize_mode="antialiased" if calc_compensations else "classic", channel_chunk=channel_chunk,
+        distributed=process_group_name is not None or world_size > 1, camera_model=_CAMERA_MODEL_NAMES[camera_model],
+        segmented=segmented, covars=covars, with_ut=with_ut, with_eval3d=with_eval3d, return_normals=return_normals,
+        global_z_order=global_z_order, rays=rays, radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs,
+        thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=None, lidar_coeffs=lidar_coeffs,
+        external_distortion_coeffs=external_distortion_params, viewmats_rs=viewmats_rs, extra_signals=extra_signals,
+        extra_signals_sh_degree=None if extra_signals_sh_degree < 0 else extra_signals_sh_degree, _covars_triu=True)
+    extra = meta.get("render_extra_signals")
+    absgrad_holder = getattr(meta["means2d"], "absgrad", None) if absgrad else None
+    ids = [meta["batch_ids"], meta["camera_ids"], meta["gaussian_ids"]]
+    return (rc, ra, _empty(rc) if extra is None else extra, _empty(rc),
+            _empty(rc) if absgrad_holder is None else absgrad_holder,
+            *[_empty(rc, torch.long) if t is None else t for t in ids],
+            meta["radii"], meta["means2d"], meta["depths"], meta["conics"], meta["opacities"], meta["tiles_per_gauss"],
+            meta["isect_ids"], meta["flatten_ids"], meta["isect_offsets"], meta["tile_width"], meta["tile_height"])
+
+
+@_op("rasterization_2dgs")
+def rasterization_2dgs(means, quats, scales, opacities, colors, viewmats, Ks, image_width, image_height, tile_size,
+                       eps2d, near_plane, far_plane, radius_clip, backgrounds, packed, sparse_grad, absgrad, distloss,
+                       sh_degree, render_mode, depth_mode):
+    """gsplat::rasterization_2dgs (host ``Rendering.cpp:1705-1960``; caller ``gsplat/rendering.py:1509-1532``)."""
+    from .rendering import rasterization_2dgs as run
+
+    rc, ra, normals, surf_normals, distort, median, meta = run(
+        means, quats, scales, opacities, colors, viewmats, Ks, image_width, image_height, near_plane=near_plane,
+        far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, sh_degree=sh_degree, packed=packed,
+        tile_size=tile_size, backgrounds=backgrounds, render_mode=render_mode, sparse_grad=sparse_grad, absgrad=absgrad,
+        distloss=distloss, depth_mode=depth_mode)
+    absgrad_holder = getattr(meta["means2d"], "absgrad", None) if absgrad else None
+    return (rc, ra, normals, surf_normals, distort, median, _empty(rc) if absgrad_holder is None else absgrad_holder,
+            meta["camera_ids"], meta["gaussian_ids"], meta["radii"], meta["means2d"], meta["depths"],
+            meta["ray_transforms"], meta["opacities"], meta["normals"], meta["tiles_per_gauss"], meta["isect_ids"],
+            meta["flatten_ids"], meta["isect_offsets"], meta["gradient_2dgs"], meta["tile_width"], meta["tile_height"],
+            meta["n_cameras"])
+
+
+# ----------------------------------------------------------------------------------------------
 # registration
 # ----------------------------------------------------------------------------------------------
 def _register():
@@ -1216,6 +1377,14 @@ def _register():
             _lib_def.define(name + schema)
         fn = _impls[name]
         _lib_impl.impl(name, fn)
+    if COMPOSITE_UNAVAILABLE is None:
+        for name, schema in COMPOSITE_SCHEMAS.items():
+            try:
+                torch._C._dispatch_find_schema_or_throw(f"{NS}::{name}", "")
+            except RuntimeError:
+                _lib_def.define(name + schema)
+            _lib_impl.impl(name, _impls[name])
+            _lib_impl_autograd.impl(name, _impls[name])
 
 
 _register()

@@ -435,5 +435,5 @@ def rasterize_top_contributing_gaussian_ids_sparse(means2d: Tensor, conics: Tens
     ``_wrapper.py:1942-2008``."""
     return _ops.rasterize_top_contributing_gaussian_ids_sparse(
         means2d.contiguous(), conics.contiguous(), opacities.contiguous(), image_width, image_height, tile_size,
-        tile_width, tile_height, active_tiles.contiguous(), tile_offsets.contiguous(), flatten_ids.contiguous(),
-        tile_pixel_mask.contiguous(), tile_pixel_cumsum.contiguous(), pixel_map.contiguous(), num_depth_samples)
+        tile_width, tile_height, num_depth_samples, active_tiles.contiguous(), tile_offsets.contiguous(),
+        flatten_ids.contiguous(), tile_pixel_mask.contiguous(), tile_pixel_cumsum.contiguous(), pixel_map.contiguous())

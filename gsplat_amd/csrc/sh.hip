@@ -523,6 +523,83 @@ static void launch_sh3_bwd(const ShArgs &a, hipStream_t s)
     }
 }
 
+// ---- assemble_proj_features_unpacked_fwd: [SH colours | extra signals | depth] rows in one pass -----------------------
+// (reference SphericalHarmonicsCUDA.cu:1100-1250). One thread per dense row (b, c, g); DEG >= 0 selects the D = 3
+// row loader, DEG < 0 the generic channel loop. Rows whose mask is clear get zero colours (extra / depth columns are
+// still written) and leave relu_mask untouched, like the reference kernel.
+struct AssembleArgs {
+    uint32_t Dc, E, width;
+    int color_post, extra_post, has_depth, extra_has_c; // post: 0 none, 1 x + 0.5, 2 max(x + 0.5, 0)
+    const float *extra, *depths;                          // depths NULL with has_depth: the column is zero
+    float *out;
+    uint8_t *relu_mask;
+};
+
+__device__ __forceinline__ float assemble_post(float v, int post)
+{
+    if (post == 1) return v + 0.5f;
+    if (post == 2) return fmaxf(v + 0.5f, 0.0f);
+    return v;
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(256) assemble_features_kernel(const ShArgs a, const AssembleArgs f)
+{
+    const int64_t rows = (int64_t)a.B * a.C * a.N;
+    const int64_t row  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const uint32_t g = (uint32_t)(row % a.N), c = (uint32_t)((row / a.N) % a.C), b = (uint32_t)(row / ((int64_t)a.N * a.C));
+    float *dst = f.out + row * f.width;
+    if (a.masks && !a.masks[row]) {
+        for (uint32_t ch = 0; ch < f.Dc; ++ch) dst[ch] = 0.0f;
+    } else {
+        float d[3];
+        view_dir(a, b, c, g, d);
+        const float inv = safe_inv_norm(d);
+        uint8_t *rm = f.relu_mask ? f.relu_mask + row * f.Dc : nullptr;
+        if constexpr (DEG >= 0) {
+            constexpr int NB = (DEG + 1) * (DEG + 1), NF = NB * 3;
+            float Y[NB];
+            sh_bases<false>(DEG, d[0] * inv, d[1] * inv, d[2] * inv, Y, nullptr, nullptr, nullptr);
+            float co[NF];
+            load_row<NF>(a.coeffs + (size_t)g * a.K * 3, ((a.K * 3u) & 3u) == 0u, co);
+            float r[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                r[0] += Y[k] * co[3 * k];
+                r[1] += Y[k] * co[3 * k + 1];
+                r[2] += Y[k] * co[3 * k + 2];
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float v = assemble_post(r[ch], f.color_post);
+                dst[ch] = v;
+                if (rm) rm[ch] = v > 0.0f;
+            }
+        } else {
+            float Y[kMaxBases];
+            sh_bases<false>(a.degree, d[0] * inv, d[1] * inv, d[2] * inv, Y, nullptr, nullptr, nullptr);
+            const int nb = (a.degree + 1) * (a.degree + 1);
+            for (uint32_t ch = 0; ch < f.Dc; ++ch) {
+                const float *co = a.coeffs + ((size_t)g * a.K) * f.Dc + ch;
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kMaxBases; ++k)
+                    if (k < nb) acc += Y[k] * co[(size_t)k * f.Dc];
+                const float v = assemble_post(acc, f.color_post);
+                dst[ch] = v;
+                if (rm) rm[ch] = v > 0.0f;
+            }
+        }
+    }
+    if (f.E) {
+        const float shift = f.extra_post == 1 ? 0.5f : 0.0f;
+        const float *src  = f.extra + (f.extra_has_c ? (size_t)row : (size_t)b * a.N + g) * f.E;
+        for (uint32_t e = 0; e < f.E; ++e) dst[f.Dc + e] = src[e] + shift;
+    }
+    if (f.has_depth) dst[f.Dc + f.E] = f.depths ? f.depths[row] : 0.0f;
+}
+
 static int check_sh(const char *fn, int degree, uint32_t K, uint32_t D, const float *means, const float *viewmats,
                     const float *coeffs, int64_t nnz, const int64_t *bi, const int64_t *ci, const int64_t *gi)
 {
@@ -610,4 +687,42 @@ extern "C" int gsx_sh_bwd(int degrees_to_use, const float *means, const float *v
         sh_bwd_packed_kernel<<<dim3((uint32_t)ceil_div(nnz * D, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
     }
     return check_launch("sh_bwd");
+}
+
+extern "C" int gsx_assemble_features_fwd(int degrees_to_use, uint32_t B, uint32_t C, uint32_t N, uint32_t K, uint32_t Dc,
+                                         uint32_t E, int color_post, int extra_post, int has_depth, int extra_has_c,
+                                         const float *means, const float *viewmats, const float *coeffs,
+                                         const float *extra, const float *depths, const uint8_t *masks, float *out,
+                                         uint8_t *relu_mask, void *stream)
+{
+    const int64_t rows = (int64_t)B * C * N;
+    if (rows == 0) return GSX_OK;
+    int rc = check_sh("gsx_assemble_features_fwd", degrees_to_use, K, Dc, means, viewmats, coeffs, -1, nullptr, nullptr, nullptr);
+    if (rc != GSX_OK) return rc;
+    GSX_REQUIRE(out, "gsx_assemble_features_fwd: null output");
+    GSX_REQUIRE(color_post >= 0 && color_post <= 2 && extra_post >= 0 && extra_post <= 2,
+                "gsx_assemble_features_fwd: post ops must be 0 (none), 1 (shift) or 2 (shift + relu)");
+    GSX_REQUIRE(E == 0 || extra, "gsx_assemble_features_fwd: extra is required when E > 0");
+    GSX_REQUIRE(!relu_mask || color_post == 2, "gsx_assemble_features_fwd: relu_mask needs color_post = 2");
+    ShArgs a{};
+    a.degree = degrees_to_use; a.means = means; a.viewmats = viewmats; a.coeffs = coeffs; a.masks = masks;
+    a.B = B; a.C = C; a.N = N; a.K = K; a.D = Dc; a.nnz = -1; a.coeffs_gathered = 1;
+    AssembleArgs f{};
+    f.Dc = Dc; f.E = E; f.width = Dc + E + (has_depth ? 1u : 0u);
+    f.color_post = color_post; f.extra_post = extra_post; f.has_depth = has_depth; f.extra_has_c = extra_has_c;
+    f.extra = extra; f.depths = depths; f.out = out; f.relu_mask = relu_mask;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((uint32_t)ceil_div(rows, 256)), block(256);
+    if (Dc == 3) {
+        switch (degrees_to_use) {
+        case 0: assemble_features_kernel<0><<<grid, block, 0, s>>>(a, f); break;
+        case 1: assemble_features_kernel<1><<<grid, block, 0, s>>>(a, f); break;
+        case 2: assemble_features_kernel<2><<<grid, block, 0, s>>>(a, f); break;
+        case 3: assemble_features_kernel<3><<<grid, block, 0, s>>>(a, f); break;
+        default: assemble_features_kernel<4><<<grid, block, 0, s>>>(a, f); break;
+        }
+    } else {
+        assemble_features_kernel<-1><<<grid, block, 0, s>>>(a, f);
+    }
+    return check_launch("assemble_features_fwd");
 }

@@ -84,6 +84,7 @@ def rasterization(
     extra_signals: Optional[Tensor] = None,
     extra_signals_sh_degree: Optional[int] = None,
     renderer_config=None,
+    _covars_triu: bool = False,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize a set of 3D Gaussians (N) to a batch of image planes (C). See the reference
     docstring (``gsplat/rendering.py:292-525``) for the meaning of every argument; this
@@ -123,7 +124,11 @@ def rasterization(
     I = B * C
     device = means.device
 
-    if covars is not None:
+    if covars is not None and _covars_triu:
+        # gsplat::rasterization_3dgs receives the upper-triangular 6-vectors (gsplat/rendering.py:540-544 converts)
+        assert covars.shape == batch_dims + (N, 6), covars.shape
+        quats, scales = None, None
+    elif covars is not None:
         assert covars.shape == batch_dims + (N, 3, 3), covars.shape
         quats, scales = None, None
         ti = ([0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2])

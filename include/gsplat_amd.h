@@ -167,6 +167,18 @@ int gsx_sh_bwd(int degrees_to_use, const float *means, const float *viewmats, co
                                 caller forms v_viewmats (= t (x) sum v_dir for R, R sum v_dir for t) */,
                void *stream);
 
+/* assemble_proj_features_unpacked_fwd: gsplat::assemble_proj_features_unpacked_fwd (ext.cpp:1015-1020; host
+ * SphericalHarmonics.cpp:572-676; kernel SphericalHarmonicsCUDA.cu:1100-1250). Dense rows only. Writes
+ * out [B,C,N, Dc + E + has_depth] = [ post(SH colours of coeffs [N,K,Dc]) | extra (+0.5 when extra_post == 1) | depth ]
+ * in one pass. color_post / extra_post: 0 none, 1 x + 0.5, 2 max(x + 0.5, 0). extra is [B,C,N,E] (extra_has_c) or
+ * [B,N,E]; depths [B,C,N], or NULL with has_depth for a zero column; masks bool [B,C,N] or NULL: masked rows get zero
+ * colours (their extra / depth columns are still written). relu_mask bool [B,C,N,Dc] or NULL (only with color_post = 2):
+ * out > 0 on the unmasked rows, untouched elsewhere (the caller zero-fills it). */
+int gsx_assemble_features_fwd(int degrees_to_use, uint32_t B, uint32_t C, uint32_t N, uint32_t K, uint32_t Dc, uint32_t E,
+                              int color_post, int extra_post, int has_depth, int extra_has_c,
+                              const float *means, const float *viewmats, const float *coeffs, const float *extra,
+                              const float *depths, const uint8_t *masks, float *out, uint8_t *relu_mask, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * isect_tiles: gsplat::intersect_tile (ext.cpp:1022-1026; host Intersect.cpp:170-329; kernel
  * IntersectTile.cu:214-464) split into its stages so that allocation stays with the caller:

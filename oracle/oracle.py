@@ -350,6 +350,30 @@ def spherical_harmonics(degree: int, means: Tensor, viewmats: Tensor, coeffs: Te
     return colors
 
 
+def assemble_proj_features(degree: int, means: Tensor, viewmats: Tensor, coeffs: Tensor, extra: Optional[Tensor],
+                           depths: Optional[Tensor], masks: Optional[Tensor], color_post: int, extra_post: int,
+                           has_depth: bool, extra_has_c: bool) -> Tensor:
+    """gsplat::assemble_proj_features_unpacked_fwd (kernel SphericalHarmonicsCUDA.cu:1100-1250; host
+    SphericalHarmonics.cpp:572-676): rows [B,C,N, Dc+E+has_depth] = [ post(SH colours) | extra | depth ].
+    post (apply_sh_post, :1017-1029): 0 none, 1 x + 0.5, 2 max(x + 0.5, 0). Masked rows get ZERO colours - the post op is
+    not applied to them (:1225-1231) - while their extra / depth columns are still written; extras are shifted by 0.5
+    only when extra_post == 1 (:1155); depths None with has_depth = the zero column of `depth_is_zero`.
+    means [B,N,3], viewmats [B,C,4,4], coeffs [N,K,Dc], extra [B,C,N,E] or [B,N,E], depths / masks [B,C,N]."""
+    sh = spherical_harmonics(degree, means, viewmats, coeffs)
+    col = sh if color_post == 0 else sh + 0.5
+    if color_post == 2:
+        col = col.clamp_min(0)
+    if masks is not None:
+        col = torch.where(masks[..., None], col, torch.zeros_like(col))
+    parts = [col]
+    if extra is not None:
+        e = extra + (0.5 if extra_post == 1 else 0.0)
+        parts.append(e if extra_has_c else e[:, None].expand(col.shape[:-1] + (e.shape[-1],)))
+    if has_depth:
+        parts.append(torch.zeros_like(col[..., :1]) if depths is None else depths[..., None])
+    return torch.cat(parts, dim=-1)
+
+
 # ----------------------------------------------------------------------------------------------
 # integer / per-pixel stages (C)
 # ----------------------------------------------------------------------------------------------
