@@ -1231,7 +1231,8 @@ def relocation(opacities, scales, ratios, binoms, n_max, min_opacity=0.0):
 
 
 @_op("mcmc_perturb_positions")
-def mcmc_perturb_positions(positions, quats, scales, opacities, noise, noise_scale, t, k):
+def mcmc_perturb_positions(positions, quats, scales, opacities, noise, noise_scale, t=0.005, k=100.0):
+    # the dispatcher strips trailing arguments that equal the schema's defaults before calling a Python kernel
     _check_f32(positions=positions, quats=quats, scales=scales, opacities=opacities, noise=noise)
     if not positions.is_contiguous():
         raise ValueError("mcmc_perturb_positions: positions is updated in place and must be contiguous")

@@ -82,6 +82,19 @@ def test_schemas_are_the_references(ops):
         assert str(getattr(torch.ops.gsplat, name).default._schema) == str(b), name
 
 
+def test_python_kernels_carry_the_schema_defaults(ops):
+    """The dispatcher strips trailing arguments equal to the schema default before it calls a Python kernel, so every
+    defaulted schema argument needs the same default on the Python function."""
+    import inspect
+
+    for name in dict(ops.SCHEMAS, **ops.COMPOSITE_SCHEMAS):
+        schema = getattr(torch.ops.gsplat, name).default._schema
+        params = list(inspect.signature(ops.impl(name)).parameters.values())
+        for i, arg in enumerate(schema.arguments):
+            if arg.has_default_value():
+                assert params[i].name == arg.name and params[i].default == arg.default_value, (name, arg.name)
+
+
 class _Stub:
     """Stands in for rendering.rasterization(): records the call, returns tensors of the right kinds."""
 
