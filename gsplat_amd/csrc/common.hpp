@@ -143,6 +143,35 @@ __device__ __forceinline__ float wave_sum4_scatter(float a, float b, float c, fl
 #endif
 }
 
+// The cross-row half of wave_sum4_scatter: lane (row r, column c) returns the sum over the four 16-lane rows, taken at
+// column c, of value r of (a, b, c, d) - i.e. four independent 4-way sums per column in 3 swaps + 3 adds.
+__device__ __forceinline__ float rows_sum4_scatter(float a, float b, float c, float d)
+{
+#if defined(GSX_SAFE_REDUCE) && GSX_SAFE_REDUCE
+    a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+    b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+    c += __shfl_xor(c, 16); c += __shfl_xor(c, 32);
+    d += __shfl_xor(d, 16); d += __shfl_xor(d, 32);
+    const int row = (int)(threadIdx.x & 63u) >> 4;
+    return row == 0 ? a : (row == 1 ? b : (row == 2 ? c : d));
+#else
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    const float P = __uint_as_float(p[0]) + __uint_as_float(p[1]); // rows: a01, b01, a23, b23
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(d), false, false);
+    const float Q = __uint_as_float(q[0]) + __uint_as_float(q[1]); // rows: c01, d01, c23, d23
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(P), __float_as_uint(Q), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);          // rows: a, b, c, d (per column)
+#endif
+}
+
+// Order LDS traffic between the lanes of ONE wave (data handed from lane to lane through a wave-private LDS region).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int wave_max_i32(int x)
 {
     // butterfly with DPP inside rows, then readlane across rows

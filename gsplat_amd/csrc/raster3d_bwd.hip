@@ -18,6 +18,8 @@
 //      [R][6 (+2) + D], TRANSPOSED: consecutive lanes add consecutive floats of one row, so a wave-level atomic
 //      touches ~6 cache lines instead of 64. Measured on c3: the per-tensor layout (64 lines per instruction)
 //      cost 160 us of exposed L2-atomic time out of 707 us; the AoS flush costs < 5 us.
+#include <cstdlib>
+
 #include "raster3d.hpp"
 #include "../../include/gsplat_amd.h"
 
@@ -260,12 +262,389 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
     }
 }
 
+// ---- variant T: per-Gaussian sums by a TRANSPOSED walk instead of cross-lane reductions ---------------------------------
+// The kernel above spends about half of its VALU instructions turning 64 per-pixel values into one per-Gaussian value
+// (K = CH + 6 wave reductions per (wave, Gaussian)). Every one of those sums has the form
+//     sum over pixels p of  fac(p, g) * v_c[k](p)        (colour columns)
+//     sum over pixels p of  w(p, g)   * phi_m(p)         (moments: phi = 1, u, v, u^2, u v, v^2 of the pixel position)
+// i.e. (one scalar per pixel and Gaussian) x (a quantity of the pixel alone). So the pixel loop only produces the two
+// scalars fac = alpha * T and w = v_sigma and parks them in a wave-private LDS matrix W[slot][pixel] (one ds_write_b64 per
+// Gaussian). Every 8 Gaussians the wave turns round: lane (g, v) owns Gaussian slot g and the 8 pixels of quadrant row v,
+// streams its 8 (fac, w) pairs back with four b128 reads and accumulates the K sums with plain FMAs - the pixel columns
+// u are compile-time constants, the row's cotangents sit in registers for the whole kernel - then the eight rows are
+// folded (one DPP add + 3 permlane swaps per four values) and added to the per-tile accumulator. Moments are taken about
+// the TILE origin (the same for the four waves) and moved to the Gaussian's mean once per (tile, Gaussian) in the flush:
+// d = mean - pixel = a - (u, v) with a = mean - origin. LDS traffic is what bounds this variant (MI355X_MICROARCH.md, LDS:
+// ds_write_b32 costs 4 cycles, a single-lane store as much as a full one, ds_read_b96 8), hence: one b64 store per
+// Gaussian, no per-Gaussian single-lane stores (the slot -> Gaussian map lives in a VGPR, lane s = slot s), no cotangent
+// table in LDS, and a W layout (row pitch 176, row-of-pixels pitch 20 floats) whose b128 reads are conflict-free.
+// Without absgrad (|.| per pixel is not a product of that form), CH <= 4, 16 x 16 tiles.
+// Tunables (A/B builds: make SUFFIX=_x EXTRA=-DGSX_BWD_T_...=..; measured on c3, MI355X, profiles/r04_ab_variant_t.md).
+// The defaults keep a workgroup at 30.4 KiB of LDS and <= 102 VGPRs, i.e. 5 workgroups per CU: occupancy and batch length
+// pull in opposite directions (BATCH 128 / 144 / 160 -> 533 / 526 / 572 us: 160 drops to 4 workgroups per CU).
+#ifndef GSX_BWD_T_BATCH
+#define GSX_BWD_T_BATCH 144
+#endif
+#ifndef GSX_BWD_T_WROW // 176 / 20: conflict-free b128 reads; 132 / 16: 2-way conflicts but 5.6 KiB less LDS per workgroup
+#define GSX_BWD_T_WROW 132
+#define GSX_BWD_T_WGRP 16
+#endif
+#ifndef GSX_BWD_T_WAVES // waves per SIMD the register allocation aims at
+#define GSX_BWD_T_WAVES 5
+#endif
+#ifndef GSX_BWD_T_PIPE // 0: LDS reads where they are used; 1: colours with the geometry; 2: next survivor prefetched
+#define GSX_BWD_T_PIPE 1
+#endif
+template <int CH>
+struct BwdTCfg {
+    static constexpr int K     = CH + 6;
+    static constexpr int KP    = (K | 1);
+    static constexpr int KG    = (K + 3) / 4;      // groups of four for the fold
+    static constexpr int BATCH = GSX_BWD_T_BATCH;
+    static constexpr int SLOTS = 8;                // Gaussians per turn
+    static constexpr int WROW  = GSX_BWD_T_WROW;   // floats per slot: 8 pixel rows x WGRP
+    static constexpr int WGRP  = GSX_BWD_T_WGRP;   // floats per row of 8 pixels: 8 x (fac, w) + 4 (bank spread)
+    static constexpr size_t stage_bytes =
+        (size_t)BATCH * (2 * sizeof(float4) + sizeof(float2) + sizeof(int32_t) * 2 + sizeof(float) * (CH + KP));
+    static constexpr size_t smem = stage_bytes + sizeof(float) * (4 * SLOTS * WROW);
+};
+
+template <int CH>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSX_BWD_T_WAVES)))
+raster3d_bwd_t_kernel(const Raster3DArgs a)
+{
+    using Cfg           = BwdTCfg<CH>;
+    constexpr int K     = Cfg::K;
+    constexpr int KP    = Cfg::KP;
+    constexpr int BATCH = Cfg::BATCH;
+    constexpr int SLOTS = Cfg::SLOTS;
+    constexpr int WROW  = Cfg::WROW;
+    constexpr int WGRP  = Cfg::WGRP;
+    static_assert(CH <= 4, "cotangent rows are staged as float4");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4 *s_ga     = reinterpret_cast<float4 *>(smem_raw);
+    float2 *s_gb     = reinterpret_cast<float2 *>(s_ga + BATCH);
+    float4 *s_cull   = reinterpret_cast<float4 *>(s_gb + BATCH);
+    int32_t *s_id    = reinterpret_cast<int32_t *>(s_cull + BATCH);
+    int32_t *s_touch = s_id + BATCH;
+    float *s_col     = reinterpret_cast<float *>(s_touch + BATCH); // [BATCH][CH]
+    float *s_acc     = s_col + BATCH * CH;                         // [BATCH][KP]: colours | S0 Su Sv Suu Suv Svv
+    float *s_w       = s_acc + BATCH * KP;                         // [4 waves][SLOTS][WROW]
+
+    TileCtx tc;
+    if (!tile_context(a, blockIdx.x, tc)) return;
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
+    const uint32_t image_id = tc.image_id, tile_id = tc.tile_id;
+    if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) return;
+
+    const uint32_t tid  = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+
+    uint32_t lx, ly;
+    tile_pixel(tid, 16u, lx, ly);
+    const int64_t prow = pixel_row(a, tc, blockIdx.x, lx, ly);
+    const bool inside  = prow >= 0;
+    const float tile_px0 = (float)(tc.tile_x * 16u) + 0.5f, tile_py0 = (float)(tc.tile_y * 16u) + 0.5f;
+    const float px     = tile_px0 + (float)lx;
+    const float py     = tile_py0 + (float)ly;
+    const size_t pix   = inside ? (size_t)prow : 0;
+
+    const int32_t range_start = tc.range_start, range_end = tc.range_end;
+    const int32_t n_batches   = (range_end - range_start + BATCH - 1) / BATCH;
+    if (n_batches <= 0) return;
+
+    const float T_final     = inside ? 1.0f - a.render_alphas[pix] : 1.0f;
+    float T                 = T_final;
+    const int32_t bin_final = inside ? a.last_ids[pix] : -1;
+    float v_c[CH], buffer[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        v_c[k]    = (inside && k < (int)a.nch) ? a.v_render_colors[pix * a.cdim + a.ch_off + k] : 0.0f;
+        buffer[k] = 0.0f;
+    }
+    const float v_a = (inside && a.first_chunk && a.v_render_alphas) ? a.v_render_alphas[pix] : 0.0f;
+    float bg_dot    = 0.0f;
+    if (a.backgrounds) {
+        const float *bg = a.backgrounds + (size_t)image_id * a.cdim + a.ch_off;
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (k < (int)a.nch) bg_dot += bg[k] * v_c[k];
+    }
+    const float va_minus_bg      = v_a - bg_dot;
+    const int32_t wave_bin_final = wave_max_i32(bin_final);
+    const WaveRect rect          = wave_pixel_rect(inside, px, py);
+
+    // roles in a turn: this lane owns slot bg and quadrant row bv (pixels 8 bv .. 8 bv + 7 of the wave, u = 0..7)
+    const int bg = (int)(lane & 7u), bv = (int)(lane >> 3);
+    float *s_ww = s_w + wave * (SLOTS * WROW); // this wave's W: element (slot, pixel p) = float2 at slot * WROW + (p / 8) * WGRP + 2 (p % 8)
+    const int w_off = (int)(lane >> 3) * WGRP + 2 * (int)(lane & 7u); // where this lane's pixel lives inside a slot row
+
+    // the cotangents of this lane's turn pixels, in registers for the whole kernel (handed over through the still unused W)
+    float vcr[8][CH];
+    {
+        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+        float *r   = reinterpret_cast<float *>(&row);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) r[k] = v_c[k];
+        float4 *tmp = reinterpret_cast<float4 *>(s_ww);
+        tmp[lane]   = row;
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 o   = tmp[8 * bv + u];
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int k = 0; k < CH; ++k) vcr[u][k] = ov[k];
+        }
+        wave_lds_sync();
+    }
+    for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) s_acc[s * KP + k] = 0.0f;
+        s_touch[s] = 0;
+    }
+
+    const float u0 = (float)((wave & 1u) << 3), v0 = (float)((wave >> 1) << 3); // quadrant origin inside the tile
+    int slot   = 0; // wave-uniform: slots filled since the last turn
+    int slot_t = 0; // lane s < SLOTS: staged index of the Gaussian in slot s
+
+    // one turn: sums of the filled slots -> s_acc (all lanes of the wave take part)
+    auto turn = [&](int n_slots) {
+        wave_lds_sync();
+        float acc[Cfg::KG * 4];
+#pragma unroll
+        for (int k = 0; k < Cfg::KG * 4; ++k) acc[k] = 0.0f;
+        const float4 *wr = reinterpret_cast<const float4 *>(s_ww + bg * WROW + bv * WGRP);
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f; // sum w, sum w u, sum w u^2 over the row
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const float4 x = wr[h]; // (fac, w) of u = 2h, 2h + 1
+            const float ff[2] = {x.x, x.z}, ww[2] = {x.y, x.w};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ui  = 2 * h + e;
+                const float u = (float)ui;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) acc[k] = fmaf(ff[e], vcr[ui][k], acc[k]);
+                s0 += ww[e];
+                s1 = fmaf(ww[e], u, s1);
+                s2 = fmaf(ww[e], u * u, s2);
+            }
+        }
+        // quadrant coordinates -> tile coordinates: u' = u + u0, v' = bv + v0 (one row per lane, so v' is a constant here)
+        {
+            const float vt = (float)bv + v0;
+            const float Su = fmaf(u0, s0, s1);
+            acc[CH + 0]    = s0;
+            acc[CH + 1]    = Su;
+            acc[CH + 2]    = vt * s0;
+            acc[CH + 3]    = s2 + u0 * (2.0f * s1 + u0 * s0);
+            acc[CH + 4]    = vt * Su;
+            acc[CH + 5]    = vt * vt * s0;
+        }
+        // fold the eight rows: lanes c and c ^ 8 share a 16-lane row, then the four rows; afterwards lane (row r, column c)
+        // holds sum number 4 j + r of slot c % 8
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += dpp_f32<0x128>(acc[k]); // row_ror:8
+        const int frow = (int)(lane >> 4), fcol = (int)(lane & 15u);
+        const int t_g  = __shfl(slot_t, fcol & 7);
+        const bool wr_lane = fcol < SLOTS && fcol < n_slots;
+#pragma unroll
+        for (int j = 0; j < Cfg::KG; ++j) {
+            const float tot = rows_sum4_scatter(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+            const int idx   = 4 * j + frow;
+            if (idx < K && wr_lane) atomicAdd(&s_acc[t_g * KP + idx], tot); // ds_add_f32
+        }
+        if (frow == 0 && wr_lane) s_touch[t_g] = 1;
+        wave_lds_sync();
+    };
+
+    for (int32_t b = 0; b < n_batches; ++b) {
+        const int32_t batch_end  = range_end - 1 - BATCH * b;
+        const int32_t batch_size = min(BATCH, batch_end + 1 - range_start);
+
+        for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
+            const int32_t idx = batch_end - s;
+            if (idx >= range_start) {
+                const int32_t g  = a.flatten_ids[idx];
+                const float2 xy  = reinterpret_cast<const float2 *>(a.means2d)[g];
+                const float opac = a.opacities[g];
+                const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
+                s_id[s]        = g;
+                float4 ga;
+                float2 gb;
+                stage_gaussian(xy.x, xy.y, opac, ca, cb, cc, ga, gb);
+                s_ga[s]        = ga;
+                s_gb[s]        = gb;
+                const float2 he = cull_half_extent(opac, ca, cb, cc);
+                s_cull[s]      = make_float4(xy.x, xy.y, he.x, he.y);
+                const float *c = a.colors + (size_t)g * a.cdim + a.ch_off;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) s_col[s * CH + k] = (k < (int)a.nch) ? c[k] : 0.0f;
+            }
+        }
+        __syncthreads();
+
+        const int32_t t_first = max(0, batch_end - wave_bin_final);
+        for (int32_t j = (t_first & ~63); j < batch_size; j += 64) {
+          const int32_t tl = j + (int32_t)lane;
+          bool hit         = false;
+          if (tl >= t_first && tl < batch_size) {
+              const float4 cu = s_cull[tl];
+              hit = (fabsf(cu.x - rect.cx) - rect.hw <= cu.z) && (fabsf(cu.y - rect.cy) - rect.hh <= cu.w);
+          }
+          uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
+#if GSX_BWD_T_PIPE == 2 // the staged data of the NEXT survivor is requested before the current one is evaluated
+          int32_t t_n = 0;
+          float4 ga_n = make_float4(0.f, 0.f, 0.f, 0.f);
+          float2 gb_n = make_float2(0.f, 0.f);
+          float col_n[CH];
+#pragma unroll
+          for (int k = 0; k < CH; ++k) col_n[k] = 0.0f;
+          if (todo) {
+              t_n  = j + (int32_t)__builtin_ctzll(todo);
+              ga_n = s_ga[t_n];
+              gb_n = s_gb[t_n];
+#pragma unroll
+              for (int k = 0; k < CH; ++k) col_n[k] = s_col[t_n * CH + k];
+          }
+#endif
+          while (todo) {
+#if GSX_BWD_T_PIPE == 2
+            const int32_t t = t_n;
+            const float4 ga = ga_n;
+            const float2 gb = gb_n;
+            float col[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) col[k] = col_n[k];
+            todo &= todo - 1;
+            if (todo) {
+                t_n  = j + (int32_t)__builtin_ctzll(todo);
+                ga_n = s_ga[t_n];
+                gb_n = s_gb[t_n];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) col_n[k] = s_col[t_n * CH + k];
+            }
+#else
+            const int32_t t = j + (int32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float4 ga = s_ga[t];
+            const float2 gb = s_gb[t];
+#if GSX_BWD_T_PIPE == 1 // colours requested together with the geometry: one LDS latency on the chain instead of two
+            float col[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) col[k] = s_col[t * CH + k];
+#endif
+#endif
+            const float dx = ga.x - px;
+            const float dy = ga.y - py;
+            const float q  = staged_q(ga, gb, dx, dy);
+            const float ov_r = staged_alpha_raw(ga, q);
+            const bool valid = (batch_end - t <= bin_final) && !(q < 0.0f) && !(fminf(kMaxAlpha, ov_r) < kAlphaThreshold);
+            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform
+
+            // invalid lanes: alpha = 0 -> fac = 0, w = 0, T and buffer unchanged (1 / (1 - 0) == 1 exactly)
+            const float ov    = valid ? ov_r : 0.0f;
+            const float alpha = fminf(kMaxAlpha, ov);
+            const float ra    = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
+            T                *= ra;
+            const float fac   = alpha * T;
+            float v_alpha     = 0.0f;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+#if GSX_BWD_T_PIPE >= 1
+                const float c = col[k];
+#else
+                const float c = s_col[t * CH + k];
+#endif
+                v_alpha      += (c * T - buffer[k] * ra) * v_c[k];
+                buffer[k]    += c * fac;
+            }
+            v_alpha += T_final * ra * va_minus_bg;
+            const float v_sigma = (ov <= kMaxAlpha) ? -ov * v_alpha : 0.0f; // alpha-clamp branch: no geometry gradient
+            *reinterpret_cast<float2 *>(s_ww + slot * WROW + w_off) = make_float2(fac, v_sigma); // ds_write_b64
+            slot_t = ((int)lane == slot) ? t : slot_t;
+            if (++slot == SLOTS) {
+                turn(SLOTS);
+                slot = 0;
+            }
+          }
+        }
+        if (slot) { // the accumulator rows of this batch are flushed below: finish the open turn first
+            turn(slot);
+            slot = 0;
+        }
+        __syncthreads();
+
+        // flush, transposed (see the kernel above). Raw tile-origin moments -> moments of d = mean - pixel = a - (u, v):
+        //   S_w = S0, S_x = ax S0 - Su, S_xx = ax^2 S0 - 2 ax Su + Suu, S_xy = ax ay S0 - ax Sv - ay Su + Suv, ...
+        constexpr float kInvLog2e = 1.0f / kLog2e;
+        constexpr int NCOL = 6 + CH;
+        for (int e = (int)tid; e < batch_size * NCOL; e += (int)blockDim.x) {
+            const int s = e / NCOL, c = e - s * NCOL;
+            if (!s_touch[s]) continue;
+            const float *row = s_acc + s * KP;
+            const float4 ga  = s_ga[s];
+            const float ax = ga.x - tile_px0, ay = ga.y - tile_py0;
+            const float S0 = row[CH], Su = row[CH + 1], Sv = row[CH + 2];
+            float val;
+            int col = c;
+            if (c < 2) {
+                const float2 gb = s_gb[s];
+                const float sx = fmaf(ax, S0, -Su), sy = fmaf(ay, S0, -Sv);
+                val = kInvLog2e * ((c == 0) ? (2.0f * ga.w * sx + gb.x * sy) : (gb.x * sx + 2.0f * gb.y * sy));
+            } else if (c == 2) {
+                val = 0.5f * (ax * (ax * S0 - 2.0f * Su) + row[CH + 3]);
+            } else if (c == 3) {
+                val = ax * (ay * S0 - Sv) - ay * Su + row[CH + 4];
+            } else if (c == 4) {
+                val = 0.5f * (ay * (ay * S0 - 2.0f * Sv) + row[CH + 5]);
+            } else if (c == 5) {
+                val = -S0 * __builtin_amdgcn_exp2f(-ga.z);
+            } else {
+                const int k = c - 6;
+                if (k >= (int)a.nch) continue;
+                val = row[k];
+                col = 6 + (int)a.ch_off + k;
+            }
+            atomic_add_f32(a.v_rows + (size_t)s_id[s] * a.row_stride + col, val);
+        }
+        __syncthreads();
+        for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
+            if (s < batch_size && s_touch[s]) {
+                float *row = s_acc + s * KP;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) row[k] = 0.0f;
+                s_touch[s] = 0;
+            }
+        }
+    }
+}
+
+// Variant T is the default where it applies; GSX_RASTER3D_BWD=r selects the reduction kernel (read once per process).
+static bool use_variant_t()
+{
+    static const bool on = [] {
+        const char *e = getenv("GSX_RASTER3D_BWD");
+        return !(e && (e[0] == 'r' || e[0] == 'R'));
+    }();
+    return on;
+}
+
 template <int CH, bool ABS>
 static int launch_bwd(const Raster3DArgs &a, hipStream_t stream)
 {
     const uint32_t n_blocks = a.sp_active_tiles ? a.n_active : a.tile_w * a.tile_h * a.n_images;
     if (n_blocks == 0 || a.n_isects == 0) return GSX_OK;
     const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
+    if constexpr (!ABS && CH <= 4) {
+        if (a.tile_size == 16 && use_variant_t()) {
+            raster3d_bwd_t_kernel<CH><<<dim3(grid), dim3(256), BwdTCfg<CH>::smem, stream>>>(a);
+            return check_launch("raster3d_bwd_t");
+        }
+    }
     const uint32_t block = a.tile_size <= 8 ? 64u : 256u;
     using Cfg = BwdCfg<CH, ABS>;
     const size_t smem = Cfg::smem;

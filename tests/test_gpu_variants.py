@@ -1,0 +1,86 @@
+"""GPU: alternative kernel variants selected by environment switches must reproduce the default kernels.
+
+GSX_RASTER3D_BWD=r — compositing backward with wave reductions (csrc/raster3d_bwd.hip) instead of the default transposed
+per-Gaussian accumulation (variant T; used for <= 4 channels per launch, 16 x 16 tiles, no absgrad). The switch is read
+once per process, so the other kernel runs in a subprocess on the same seeded scenes and its gradients are compared with
+the default kernel's (scale-relative: the sums are taken in a different order). Both kernels are also what the
+oracle-parity tests exercise: T through every default test, R through absgrad / wide-channel / small-tile cases."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from _util import assert_grad_close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    # N, C, W, H, sh_degree, render_mode, packed, backgrounds
+    (6000, 2, 208, 144, 3, "RGB", False, True),
+    (6000, 2, 208, 144, None, "RGB+ED", True, False),
+    (3000, 1, 100, 70, None, "ED", False, False),      # 1 channel, image not a multiple of the tile
+    (40000, 1, 320, 240, 0, "RGB", False, False),      # long per-tile lists: several batches and turns per tile
+]
+
+_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import gsplat_amd
+from _util import make_scene
+from test_gpu_variants import CASES, run_case
+out = {}
+for i, case in enumerate(CASES):
+    for k, v in run_case(gsplat_amd, case).items():
+        out[f"{i}_{k}"] = v
+np.savez(sys.argv[1], **out)
+'''
+
+
+def run_case(G, case):
+    from _util import make_scene
+
+    N, C, W, H, sh_degree, mode, packed, with_bg = case
+    sc, W, H = make_scene(N=N, C=C, width=W, height=H, seed=N % 97, sh_degree=sh_degree)
+    nch = {"RGB": 3, "RGB+ED": 4, "ED": 1}[mode]
+    g = torch.Generator().manual_seed(7)
+    v_rc, v_ra = torch.randn(C, H, W, nch, generator=g).cuda(), torch.randn(C, H, W, 1, generator=g).cuda()
+    bg = torch.rand(C, 3, generator=g).cuda() if with_bg else None
+    names = ("means", "quats", "scales", "opacities", "colors")
+    leaves = {k: sc[k].cuda().clone().requires_grad_(True) for k in names}
+    rc, ra, _ = G.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
+                                sc["viewmats"].cuda(), sc["Ks"].cuda(), W, H, sh_degree=sh_degree, packed=packed,
+                                render_mode=mode, backgrounds=bg)
+    ((rc * v_rc).sum() + (ra * v_ra).sum()).backward()
+    out = {k: leaves[k].grad.cpu().numpy() for k in names if leaves[k].grad is not None}
+    out["render"] = rc.detach().cpu().numpy()
+    return out
+
+
+def test_raster3d_bwd_reduction_kernel_matches_default_variant_t():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    assert os.environ.get("GSX_RASTER3D_BWD", "") == "", "run this test with the default kernel selection"
+    import gsplat_amd
+
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "t.npz")
+        code = _SCRIPT % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+        env = dict(os.environ, GSX_RASTER3D_BWD="r")
+        if os.environ.get("GSX_VARIANT_LIB"):  # an alternative build of the library for the variant side (A/B builds)
+            env["GSPLAT_AMD_LIB"] = os.environ["GSX_VARIANT_LIB"]
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        alt = dict(np.load(path))
+    for i, case in enumerate(CASES):
+        ref = run_case(gsplat_amd, case)
+        assert np.array_equal(alt[f"{i}_render"], ref["render"]), f"case {i}: the forward pass must not change"
+        for k, v in ref.items():
+            if k == "render":
+                continue
+            assert_grad_close(torch.from_numpy(alt[f"{i}_{k}"]), torch.from_numpy(v), rel=3e-4, max_bad_ratio=1e-5,
+                              name=f"case {i} v_{k}")
