@@ -220,7 +220,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("bytes")
+            pmc = json.load(open(tpath))
+            # the backward runs as variant T for <= 4 channels (csrc/raster3d_bwd.hip): its counters are filed under that name
+            traffic = (pmc.get(dom + "_t") or pmc.get(dom) or {}).get("bytes")
         except Exception:
             traffic = None
     roofline = {
