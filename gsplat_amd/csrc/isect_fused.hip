@@ -136,21 +136,12 @@ __global__ void __launch_bounds__(kFusedThreads) fused_count_hist_kernel(const F
     for_rows_balanced(a, lo, hi, [&](int64_t r) {
         const RowGeom q = load_row_geom(a, r, has_conic);
         int32_t n       = 0;
-        TileBox box{0, 0, 0, 0};
-        uint64_t mask = 0;
         if (q.live)
-            n = walk_tiles_xy(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h,
-                              [&](int64_t tile, int x, int y) {
-                                  if (!tmask || tmask[tile]) atomicAdd(&s_hist[tile], 1);
-                                  if (box.xspan <= 8 && box.yspan <= 8) mask |= 1ull << (8 * (y - box.y0) + (x - box.x0));
-                              },
-                              &box);
+            n = walk_tiles(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h,
+                           [&](int64_t tile) {
+                               if (!tmask || tmask[tile]) atomicAdd(&s_hist[tile], 1);
+                           });
         if (a.tiles_per_gauss) a.tiles_per_gauss[r] = n;
-        if (a.walk_cache) { // dead / off-screen rows: an empty, valid mask
-            const bool small = box.xspan <= 8 && box.yspan <= 8;
-            a.walk_cache[r]  = make_uint4((uint32_t)mask, (uint32_t)(mask >> 32), (uint32_t)box.x0 | ((uint32_t)box.y0 << 16),
-                                          small ? 1u : 0u);
-        }
     });
     __syncthreads();
     int32_t *out = a.table + (int64_t)blockIdx.x * g.n_tiles;
@@ -171,24 +162,6 @@ __global__ void __launch_bounds__(kFusedThreads) fused_emit_scatter_kernel(const
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)img * g.n_tiles : nullptr;
     for_rows_balanced(a, lo, hi, [&](int64_t r) {
-        if (a.walk_cache) { // the count pass left this row's tiles as a bit mask: no second walk of the ellipse
-            const uint4 c = a.walk_cache[r];
-            if (c.w & 1u) {
-                uint64_t m = (uint64_t)c.x | ((uint64_t)c.y << 32);
-                if (!m) return;
-                const uint32_t dbits = __float_as_uint(a.depths[r]);
-                const int x0 = (int)(c.z & 0xffffu), y0 = (int)(c.z >> 16);
-                while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int64_t tile = (int64_t)(y0 + (b >> 3)) * g.tile_w + (x0 + (b & 7));
-                    if (tmask && !tmask[tile]) continue;
-                    const int32_t slot = atomicAdd(&s_cur[tile], 1);
-                    a.bucketed[slot]   = make_uint2(dbits, (uint32_t)r);
-                }
-                return;
-            }
-        }
         const RowGeom q = load_row_geom(a, r, has_conic);
         if (!q.live) return;
         const uint32_t dbits = __float_as_uint(a.depths[r]);

@@ -24,10 +24,6 @@ struct FusedArgs {
     int32_t *table;               // [n_chunks][n_tiles]: histogram, then exclusive prefix over an image's chunks
     const int32_t *isect_offsets; // [n_images * n_tiles] (emit)
     uint2 *bucketed;              // [M] (emit)
-    // [R] written by the count pass, read by the emit pass: the tiles of a row whose tile box fits 8 x 8 as a 64-bit mask
-    // (bit = 8 (y - y0) + (x - x0)), so that the second pass does not walk the ellipse again:
-    //   .x/.y = mask, .z = x0 | y0 << 16, .w bit 0 = "mask is valid" (clear: the row is walked again)
-    uint4 *walk_cache;
 };
 
 // <= 256 chunks in total (one workgroup of 1024 threads per CU), at least 4096 rows each

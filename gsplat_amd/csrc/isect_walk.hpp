@@ -33,17 +33,11 @@ __host__ __device__ __forceinline__ void ellipse_cut(float B, float coeff, float
     hi               = (mbh + root) / coeff + pv;
 }
 
-// Tile box of a walk: every visited tile (x, y) has x0 <= x < x0 + xspan, y0 <= y < y0 + yspan.
-struct TileBox {
-    int x0, y0, xspan, yspan;
-};
-
-// Visits every tile touched by the Gaussian; calls emit(tile_id, x, y). Returns the tile count. `box` (optional) receives
-// the tile box BEFORE the first emit; it is left untouched when nothing can be visited.
+// Visits every tile touched by the Gaussian; calls emit(tile_id). Returns the tile count.
 template <typename Emit>
-__host__ __device__ __forceinline__ int32_t walk_tiles_xy(
+__host__ __device__ __forceinline__ int32_t walk_tiles(
     float mx, float my, float rx, float ry, bool has_conic, float A, float B, float C, float opacity,
-    uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, Emit &&emit, TileBox *box = nullptr)
+    uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, Emit &&emit)
 {
     const float ts = (float)tile_size;
     // x / ts, bit for bit: for a power-of-two tile size the product with the (exact) reciprocal IS the correctly
@@ -73,7 +67,6 @@ __host__ __device__ __forceinline__ int32_t walk_tiles_xy(
         const int rmaxy = clampi(f2i_trunc_sat(div_ts(bmaxy) + 1.0f), 0, (int)tile_h);
         const int yspan = rmaxy - rminy, xspan = rmaxx - rminx;
         if (yspan <= 0 || xspan <= 0) return 0;
-        if (box) *box = TileBox{rminx, rminy, xspan, yspan};
 
         // iterate slabs along the SHORTER span (u), solve the covered range on the other axis (v)
         const bool alongY = yspan < xspan;
@@ -100,8 +93,7 @@ __host__ __device__ __forceinline__ int32_t walk_tiles_xy(
             const int tv0    = clampi(f2i_trunc_sat(div_ts(vmin)), v0, v1);
             const int tv1    = clampi(f2i_trunc_sat(div_ts(vmax) + 1.0f), v0, v1);
             for (int v = tv0; v < tv1; ++v) {
-                const int x = alongY ? v : u, y = alongY ? u : v;
-                emit((int64_t)y * tile_w + x, x, y);
+                emit(alongY ? (int64_t)u * tile_w + v : (int64_t)v * tile_w + u);
                 ++count;
             }
             lo_lo   = hi_lo;
@@ -116,23 +108,12 @@ __host__ __device__ __forceinline__ int32_t walk_tiles_xy(
     const int y0 = clampi(f2i_trunc_sat(floorf(ty - try_)), 0, (int)tile_h);
     const int x1 = clampi(f2i_trunc_sat(ceilf(tx + trx)), 0, (int)tile_w);
     const int y1 = clampi(f2i_trunc_sat(ceilf(ty + try_)), 0, (int)tile_h);
-    if (box && x1 > x0 && y1 > y0) *box = TileBox{x0, y0, x1 - x0, y1 - y0};
     for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {
-            emit((int64_t)y * tile_w + x, x, y);
+            emit((int64_t)y * tile_w + x);
             ++count;
         }
     return count;
-}
-
-// Same walk, emit(tile_id) only.
-template <typename Emit>
-__host__ __device__ __forceinline__ int32_t walk_tiles(
-    float mx, float my, float rx, float ry, bool has_conic, float A, float B, float C, float opacity,
-    uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, Emit &&emit)
-{
-    return walk_tiles_xy(mx, my, rx, ry, has_conic, A, B, C, opacity, tile_size, tile_w, tile_h,
-                         [&](int64_t tile, int, int) { emit(tile); });
 }
 
 } // namespace gsx

@@ -461,8 +461,7 @@ __global__ void __launch_bounds__(1024) fused_totals_scan_kernel(const int32_t *
 
 static int64_t fused_count_ws_bytes(const FusedGeom &g)
 {
-    return align256((int64_t)g.n_chunks * g.n_tiles * 4) + align256((int64_t)g.n_images * g.n_tiles * 4)
-           + align256(g.rows * (int64_t)sizeof(uint4)) /* walk cache */ + 512;
+    return align256((int64_t)g.n_chunks * g.n_tiles * 4) + align256((int64_t)g.n_images * g.n_tiles * 4) + 512;
 }
 static int64_t fused_emit_ws_bytes(int64_t n, uint32_t n_bins)
 {
@@ -579,8 +578,7 @@ static int fused_setup(const char *fn, FusedArgs &a, int64_t rows, uint32_t n_im
     }
     unsigned char *p = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(count_ws) + 255) & ~(uintptr_t)255);
     a.table = reinterpret_cast<int32_t *>(p); p += align256((int64_t)a.geom.n_chunks * a.geom.n_tiles * 4);
-    *totals = reinterpret_cast<int32_t *>(p); p += align256((int64_t)a.geom.n_images * a.geom.n_tiles * 4);
-    a.walk_cache = reinterpret_cast<uint4 *>(p);
+    *totals = reinterpret_cast<int32_t *>(p);
     return GSX_OK;
 }
 

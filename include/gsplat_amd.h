@@ -228,9 +228,7 @@ int gsx_isect_offsets(const int64_t *isect_ids_sorted, int64_t n_isects, uint32_
  * Dense rows [n_images * N] (any n_images while n_images * tiles fits the LDS histogram), or packed rows of ONE image.
  *   1. gsx_isect_fused_count: tiles_per_gauss int32 [rows], isect_offsets int32 [n_images * tiles] (= intersect_offset),
  *      *n_isects (device int64). The caller reads n_isects, allocates the exact-length outputs, then
- *   2. gsx_isect_fused_emit_sort with the SAME inputs and the SAME count workspace (it also carries, per row, the tiles
- *      found by the count pass as a 64-bit mask, so that rows whose tile box fits 8 x 8 are not walked a second time):
- *      isect_ids int64 [n_isects], flatten_ids int32 [n_isects].
+ *   2. gsx_isect_fused_emit_sort with the SAME count workspace: isect_ids int64 [n_isects], flatten_ids int32 [n_isects].
  * ------------------------------------------------------------------------------------------- */
 int gsx_isect_fused_supported(uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed);
 int64_t gsx_isect_fused_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
