@@ -292,15 +292,6 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
 #ifndef GSX_BWD_T_WAVES // waves per SIMD the register allocation aims at
 #define GSX_BWD_T_WAVES 5
 #endif
-#ifndef GSX_BWD_T_PIPE // 0: LDS reads where they are used; 1: colours with the geometry; 2: next survivor prefetched
-#define GSX_BWD_T_PIPE 1
-#endif
-#ifndef GSX_BWD_T_PACK // 1: (B, C, colour 0, colour 1) staged as one float4 (b128 + b128 + b32 per Gaussian at 3 channels)
-#define GSX_BWD_T_PACK 1
-#endif
-#if GSX_BWD_T_PACK && GSX_BWD_T_PIPE == 2
-#error "GSX_BWD_T_PACK is not combined with GSX_BWD_T_PIPE=2"
-#endif
 template <int CH>
 struct BwdTCfg {
     static constexpr int K     = CH + 6;
@@ -311,13 +302,8 @@ struct BwdTCfg {
     static constexpr int WROW  = GSX_BWD_T_WROW;   // floats per slot: 8 pixel rows x WGRP
     static constexpr int WGRP  = GSX_BWD_T_WGRP;   // floats per row of 8 pixels: 8 x (fac, w) + 4 (bank spread)
     static constexpr int CX    = CH > 2 ? CH - 2 : 0; // colour channels that do not fit next to (B, C) in the second float4
-#if GSX_BWD_T_PACK
     static constexpr size_t stage_bytes =
         (size_t)BATCH * (3 * sizeof(float4) + sizeof(int32_t) * 2 + sizeof(float) * (CX + KP));
-#else
-    static constexpr size_t stage_bytes =
-        (size_t)BATCH * (2 * sizeof(float4) + sizeof(float2) + sizeof(int32_t) * 2 + sizeof(float) * (CH + KP));
-#endif
     static constexpr size_t smem = stage_bytes + sizeof(float) * (4 * SLOTS * WROW);
 };
 
@@ -336,15 +322,9 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4 *s_ga     = reinterpret_cast<float4 *>(smem_raw);
-#if GSX_BWD_T_PACK // (B, C, colour 0, colour 1) in ONE b128 read; further channels in s_col
     constexpr int CX = Cfg::CX;
     float4 *s_gbc    = s_ga + BATCH;
     float4 *s_cull   = s_gbc + BATCH;
-#else
-    constexpr int CX = CH;
-    float2 *s_gb     = reinterpret_cast<float2 *>(s_ga + BATCH);
-    float4 *s_cull   = reinterpret_cast<float4 *>(s_gb + BATCH);
-#endif
     int32_t *s_id    = reinterpret_cast<int32_t *>(s_cull + BATCH);
     int32_t *s_touch = s_id + BATCH;
     float *s_col     = reinterpret_cast<float *>(s_touch + BATCH); // [BATCH][CX]
@@ -502,15 +482,9 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
                 float cv[CH];
 #pragma unroll
                 for (int k = 0; k < CH; ++k) cv[k] = (k < (int)a.nch) ? c[k] : 0.0f;
-#if GSX_BWD_T_PACK
-                s_gbc[s] = make_float4(gb.x, gb.y, cv[0], CH > 1 ? cv[CH > 1 ? 1 : 0] : 0.0f);
+                s_gbc[s] = make_float4(gb.x, gb.y, cv[0], CH > 1 ? cv[CH > 1 ? 1 : 0] : 0.0f); // (B, C, colour 0, colour 1)
 #pragma unroll
                 for (int k = 2; k < CH; ++k) s_col[s * CX + k - 2] = cv[k];
-#else
-                s_gb[s] = gb;
-#pragma unroll
-                for (int k = 0; k < CH; ++k) s_col[s * CH + k] = cv[k];
-#endif
             }
         }
         __syncthreads();
@@ -524,42 +498,10 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
               hit = (fabsf(cu.x - rect.cx) - rect.hw <= cu.z) && (fabsf(cu.y - rect.cy) - rect.hh <= cu.w);
           }
           uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
-#if GSX_BWD_T_PIPE == 2 // the staged data of the NEXT survivor is requested before the current one is evaluated
-          int32_t t_n = 0;
-          float4 ga_n = make_float4(0.f, 0.f, 0.f, 0.f);
-          float2 gb_n = make_float2(0.f, 0.f);
-          float col_n[CH];
-#pragma unroll
-          for (int k = 0; k < CH; ++k) col_n[k] = 0.0f;
-          if (todo) {
-              t_n  = j + (int32_t)__builtin_ctzll(todo);
-              ga_n = s_ga[t_n];
-              gb_n = s_gb[t_n];
-#pragma unroll
-              for (int k = 0; k < CH; ++k) col_n[k] = s_col[t_n * CH + k];
-          }
-#endif
           while (todo) {
-#if GSX_BWD_T_PIPE == 2
-            const int32_t t = t_n;
-            const float4 ga = ga_n;
-            const float2 gb = gb_n;
-            float col[CH];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) col[k] = col_n[k];
-            todo &= todo - 1;
-            if (todo) {
-                t_n  = j + (int32_t)__builtin_ctzll(todo);
-                ga_n = s_ga[t_n];
-                gb_n = s_gb[t_n];
-#pragma unroll
-                for (int k = 0; k < CH; ++k) col_n[k] = s_col[t_n * CH + k];
-            }
-#else
             const int32_t t = j + (int32_t)__builtin_ctzll(todo);
             todo &= todo - 1;
             const float4 ga = s_ga[t];
-#if GSX_BWD_T_PACK
             const float4 gbc = s_gbc[t];
             const float2 gb  = make_float2(gbc.x, gbc.y);
             float col[CH];
@@ -567,15 +509,6 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
             if constexpr (CH > 1) col[1] = gbc.w;
 #pragma unroll
             for (int k = 2; k < CH; ++k) col[k] = s_col[t * CX + k - 2];
-#else
-            const float2 gb = s_gb[t];
-#if GSX_BWD_T_PIPE == 1 // colours requested together with the geometry: one LDS latency on the chain instead of two
-            float col[CH];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) col[k] = s_col[t * CH + k];
-#endif
-#endif
-#endif
             const float dx = ga.x - px;
             const float dy = ga.y - py;
             const float q  = staged_q(ga, gb, dx, dy);
@@ -592,11 +525,7 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
             float v_alpha     = 0.0f;
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
-#if GSX_BWD_T_PIPE >= 1 || GSX_BWD_T_PACK
                 const float c = col[k];
-#else
-                const float c = s_col[t * CH + k];
-#endif
                 v_alpha      += (c * T - buffer[k] * ra) * v_c[k];
                 buffer[k]    += c * fac;
             }
@@ -630,12 +559,8 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
             float val;
             int col = c;
             if (c < 2) {
-#if GSX_BWD_T_PACK
                 const float4 g4 = s_gbc[s];
                 const float2 gb = make_float2(g4.x, g4.y);
-#else
-                const float2 gb = s_gb[s];
-#endif
                 const float sx = fmaf(ax, S0, -Su), sy = fmaf(ay, S0, -Sv);
                 val = kInvLog2e * ((c == 0) ? (2.0f * ga.w * sx + gb.x * sy) : (gb.x * sx + 2.0f * gb.y * sy));
             } else if (c == 2) {
