@@ -31,6 +31,56 @@ def _camera_model_id(camera_model: str) -> int:
         ) from None
 
 
+def world_to_cam(means: Tensor, covars: Tensor, viewmats: Tensor) -> Tuple[Tensor, Tensor]:
+    """Gaussians from world to camera coordinates: means [..., N, 3], covars [..., N, 3, 3], viewmats [..., C, 4, 4] ->
+    ([..., C, N, 3], [..., C, N, 3, 3]). Plain tensor algebra on whatever device the inputs live on — the reference
+    removed its kernel for this too (``gsplat/cuda/_wrapper.py:381-416`` forwards to ``_torch_impl._world_to_cam``)."""
+    batch_dims = means.shape[:-2]
+    N, C = means.shape[-2], viewmats.shape[-3]
+    assert means.shape == batch_dims + (N, 3), means.shape
+    assert covars.shape == batch_dims + (N, 3, 3), covars.shape
+    assert viewmats.shape == batch_dims + (C, 4, 4), viewmats.shape
+    R, t = viewmats[..., :3, :3], viewmats[..., :3, 3]
+    means_c = torch.einsum("...cij,...nj->...cni", R, means) + t[..., None, :]
+    covars_c = torch.einsum("...cij,...njk,...clk->...cnil", R, covars, R)
+    return means_c, covars_c
+
+
+def _has(feature: str) -> bool:
+    from . import csrc_shim
+
+    return bool(csrc_shim.build_config().get(feature, False))
+
+
+def has_3dgs() -> bool:
+    """Feature probes with the reference's names (``gsplat/cuda/_wrapper.py:261-286``), answered from build_config()."""
+    return _has("3dgs")
+
+
+def has_2dgs() -> bool:
+    return _has("2dgs")
+
+
+def has_3dgut() -> bool:
+    return _has("3dgut")
+
+
+def has_adam() -> bool:
+    return _has("adam")
+
+
+def has_reloc() -> bool:
+    return _has("reloc")
+
+
+def has_losses() -> bool:
+    return _has("losses")
+
+
+def has_camera_wrappers() -> bool:
+    return _has("camera_wrappers")
+
+
 def quat_scale_to_covar_preci(
     quats: Tensor,  # [..., 4]
     scales: Tensor,  # [..., 3]

@@ -297,7 +297,7 @@ struct BwdTCfg {
     static constexpr int K     = CH + 6;
     static constexpr int KP    = (K | 1);
     static constexpr int KG    = (K + 3) / 4;      // groups of four for the fold
-    static constexpr int BATCH = GSX_BWD_T_BATCH;
+    static constexpr int BATCH = CH <= 3 ? GSX_BWD_T_BATCH : GSX_BWD_T_BATCH - 16; // <= 30.7 KiB of LDS per workgroup for every CH
     static constexpr int SLOTS = 8;                // Gaussians per turn
     static constexpr int WROW  = GSX_BWD_T_WROW;   // floats per slot: 8 pixel rows x WGRP
     static constexpr int WGRP  = GSX_BWD_T_WGRP;   // floats per row of 8 pixels: 8 x (fac, w) + 4 (bank spread)
