@@ -604,6 +604,7 @@ extern "C" int gsx_raster2d_bwd(const float *means2d, const float *ray_transform
 {
     GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster2d_bwd: tile_size must be in [1,16], got %u", tile_size);
     GSX_REQUIRE(cdim >= 1 && cdim <= 32, "gsx_raster2d_bwd: unsupported number of channels %u (1..32)", cdim);
+    if (n_isects == 0) return GSX_OK; // no intersections: nothing to add to the (zero-filled, possibly empty) gradient rows
     GSX_REQUIRE(v_rows, "gsx_raster2d_bwd: null gradient output");
     GSX_REQUIRE(row_stride >= 17u + (has_abs ? 2u : 0u) + cdim, "gsx_raster2d_bwd: row_stride %u too small", row_stride);
     GSX_REQUIRE(n_isects == 0 || (means2d && ray_transforms && colors && opacities && normals && flatten_ids

@@ -658,6 +658,7 @@ extern "C" int gsx_raster3d_bwd(
     using namespace gsx;
     GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster3d_bwd: tile_size must be in [1,16], got %u", tile_size);
     GSX_REQUIRE(cdim >= 1, "gsx_raster3d_bwd: channels must be >= 1");
+    if (n_isects == 0) return GSX_OK; // no intersections: nothing to add to the (zero-filled, possibly empty) gradient rows
     GSX_REQUIRE(v_rows, "gsx_raster3d_bwd: null gradient output");
     GSX_REQUIRE(row_stride >= 6u + (has_abs ? 2u : 0u) + cdim,
                 "gsx_raster3d_bwd: row_stride %u too small for 6%s + %u channels", row_stride, has_abs ? " + 2" : "", cdim);
@@ -688,6 +689,7 @@ extern "C" int gsx_raster3d_sparse_bwd(
     using namespace gsx;
     GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster3d_sparse_bwd: tile_size must be in [1,16], got %u", tile_size);
     GSX_REQUIRE(cdim >= 1, "gsx_raster3d_sparse_bwd: channels must be >= 1");
+    if (n_isects == 0) return GSX_OK; // no intersections: nothing to add to the (zero-filled, possibly empty) gradient rows
     GSX_REQUIRE(v_rows, "gsx_raster3d_sparse_bwd: null gradient output");
     GSX_REQUIRE(row_stride >= 6u + (has_abs ? 2u : 0u) + cdim, "gsx_raster3d_sparse_bwd: row_stride %u too small", row_stride);
     if (n_active == 0 || n_isects == 0) return GSX_OK;

@@ -321,3 +321,33 @@ def test_c5_full_size_properties_1m_surfels_1080p(G):
     r, a, *_ = G.rasterization_2dgs(*common, g1, sc["viewmats"], sc["Ks"], W, H, packed=True)
     r.sum().backward()
     assert abs(g1.grad.double().sum() - a.double().sum()) <= 1e-3 * a.double().sum()
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_rasterization_2dgs_empty_and_invisible_scenes(packed):
+    """No surfels / every surfel behind the camera: background images, zero alpha, empty lists, zero gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import gsplat_amd as G
+    from _util import make_scene
+
+    W, H, C = 80, 48, 1
+    names = ("means", "quats", "scales", "opacities", "colors")
+    for empty in (True, False):
+        sc, _, _ = make_scene(N=40, C=C, width=W, height=H, seed=5)
+        if empty:
+            sc = {k: (v[:0] if k in names else v) for k, v in sc.items()}
+        else:
+            sc["means"] = sc["means"] * torch.tensor([1.0, 1.0, -1.0])
+        leaves = {k: sc[k].cuda().clone().requires_grad_(True) for k in names}
+        bg = torch.tensor([[0.3, 0.5, 0.7]]).cuda()
+        rc, ra, rn, sn, rd, rm, meta = G.rasterization_2dgs(
+            leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
+            sc["viewmats"].cuda(), sc["Ks"].cuda(), W, H, packed=packed, backgrounds=bg, render_mode="RGB+D", distloss=True)
+        assert rc.shape == (C, H, W, 4) and float(ra.abs().max()) == 0.0 and meta["isect_ids"].numel() == 0
+        assert torch.equal(rc[..., :3], bg[:, None, None, :].expand(C, H, W, 3))
+        assert float(rn.abs().max()) == 0.0 and float(rd.abs().max()) == 0.0
+        (rc.sum() + ra.sum() + rn.sum() + rd.sum()).backward()
+        for k in names:
+            g = leaves[k].grad
+            assert g is None or float(g.abs().sum()) == 0.0, k

@@ -269,3 +269,51 @@ def test_distributed_single_rank_matches_local(G, packed, force_exchange, monkey
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("case", ["no_gaussians", "nothing_visible", "one_gaussian"])
+def test_rasterization_degenerate_scenes(G, packed, case):
+    """Edge cases of the whole pipeline: an empty scene and a scene entirely behind the camera render the background
+    (alpha 0, zero gradients, empty intersection lists); a single Gaussian renders like the oracle."""
+    from oracle.pipeline import rasterization_cpu
+
+    W, H, C = 96, 64, 2
+    sc, _, _ = make_scene(N=1 if case == "one_gaussian" else 50, C=C, width=W, height=H, seed=2)
+    if case == "no_gaussians":
+        sc = {k: (v[:0] if k in NAMES else v) for k, v in sc.items()}
+    elif case == "nothing_visible":
+        sc["means"] = sc["means"] * torch.tensor([1.0, 1.0, -1.0])  # behind every camera
+    else:
+        sc["means"] = torch.tensor([[0.05, -0.02, 3.0]])
+        sc["scales"] = torch.tensor([[0.4, 0.2, 0.3]])
+    N = sc["means"].shape[0]
+    bg = torch.tensor([[0.2, 0.4, 0.6], [0.9, 0.1, 0.3]])
+    leaves = {k: sc[k].to(DEV).clone().requires_grad_(True) for k in NAMES}
+    rc, ra, meta = G.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
+                                   leaves["colors"], sc["viewmats"].to(DEV), sc["Ks"].to(DEV), W, H, packed=packed,
+                                   backgrounds=bg.to(DEV), render_mode="RGB+ED", absgrad=True)
+    assert rc.shape == (C, H, W, 4) and ra.shape == (C, H, W, 1)
+    (rc.sum() + ra.sum()).backward()
+    if case != "one_gaussian":
+        assert meta["isect_ids"].numel() == 0 and meta["flatten_ids"].numel() == 0
+        assert int(meta["isect_offsets"].abs().sum()) == 0
+        assert float(ra.abs().max()) == 0.0
+        assert torch.equal(rc[..., :3], bg.to(DEV)[:, None, None, :].expand(C, H, W, 3))
+        assert float(rc[..., 3].abs().max()) == 0.0
+        for k in NAMES:
+            g = leaves[k].grad
+            assert g is None or (g.shape == leaves[k].shape and float(g.abs().sum()) == 0.0), k
+        if packed:
+            assert meta["gaussian_ids"].numel() == 0 and meta["means2d"].shape == (0, 2)
+        else:
+            assert meta["means2d"].shape == (C, N, 2) and int(meta["radii"].sum()) == 0
+    else:
+        ref = rasterization_cpu(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], sc["viewmats"],
+                                sc["Ks"], W, H, render_mode="RGB+ED", backgrounds=bg,
+                                v_render_colors=torch.ones(C, H, W, 4), v_render_alphas=torch.ones(C, H, W, 1))
+        assert_close_ratio(rc.detach().cpu(), ref["render_colors"], 1e-3, 1e-4, max_bad_ratio=1e-3, name="colors")
+        assert_close_ratio(ra.detach().cpu(), ref["render_alphas"], 1e-4, 5e-5, max_bad_ratio=1e-3, name="alphas")
+        for k in NAMES:
+            assert_grad_close(leaves[k].grad.cpu(), ref["grads"][k], rel=5e-3, max_bad_ratio=1e-3, name=f"v_{k}")
+        assert float(meta["means2d"].absgrad.abs().sum()) > 0
