@@ -363,28 +363,33 @@ class DistributedRasterContext:
     @staticmethod
     def create(batch_dims, sparse_grad, absgrad, camera_model, colors, sh_degree, n_cameras, device,
                n_local: Optional[int] = None) -> "DistributedRasterContext":
-        """Validation follows Rendering.cpp:190-233 (what distributed mode rejects)."""
-        if not dist.is_available() or not dist.is_initialized():
-            raise RuntimeError("distributed=True requires an initialized torch.distributed process group")
+        """Process-group checks as ``gsplat/rendering.py:178-198`` (ValueError); mode checks as the reference's C++
+        validation (``Rendering.cpp:187-233``: RuntimeError, same messages). rasterization() has already run the full
+        validation (``rendering._validate_rasterization_inputs``); the mode checks are repeated here for direct users."""
+        if not dist.is_available():
+            raise ValueError("distributed=True requires torch.distributed to be available.")
+        if not dist.is_initialized():
+            raise ValueError("distributed=True requires an initialized default torch.distributed process group.")
         if device.type == "cuda" and dist.get_backend() != "nccl":
-            raise RuntimeError("distributed rasterization on GPUs requires the 'nccl' backend (RCCL on ROCm)")
+            raise ValueError("distributed=True currently supports only the default NCCL process group "
+                             f"(RCCL on ROCm); got backend '{dist.get_backend()}'.")
         if len(batch_dims) != 0:
-            raise ValueError("distributed=True does not support batch dimensions")
+            raise RuntimeError("distributed=True does not support batch dimensions")
         if sparse_grad:
-            raise ValueError("distributed=True does not support sparse_grad")
+            raise RuntimeError("distributed=True does not support sparse_grad=True")
         if absgrad:
-            raise ValueError("distributed=True does not support absgrad")
+            raise RuntimeError("distributed=True does not support absgrad=True")
         if camera_model != "pinhole":
-            raise ValueError("distributed=True only supports the pinhole camera model")
+            raise RuntimeError("distributed=True only supports camera_model='pinhole'")
         if colors is not None and sh_degree is None and colors.dim() == 3:
-            raise ValueError("distributed=True does not support per-view colors [C, N, D]")
+            raise RuntimeError("distributed=True only supports per-Gaussian colors")
         W, r = dist.get_world_size(), dist.get_rank()
         if n_local is None:
             raise ValueError("n_local is required")
         gathered = _gather_counts(W, n_local, n_cameras, device)
         cams = [g[1] for g in gathered]
         if any(c != cams[0] for c in cams):
-            raise ValueError(f"distributed=True requires the same number of cameras on every rank, got {cams}")
+            raise RuntimeError(f"distributed=True requires the same number of cameras on every rank, got {cams}")
         return DistributedRasterContext(W, r, n_local, [g[0] for g in gathered], n_cameras)
 
     # -- seam A ------------------------------------------------------------------------------

@@ -89,29 +89,11 @@ def rasterization(
     """Rasterize a set of 3D Gaussians (N) to a batch of image planes (C). See the reference
     docstring (``gsplat/rendering.py:292-525``) for the meaning of every argument; this
     implementation covers the classic (EWA, non-3DGUT) path."""
-    if render_mode in _HIT_MODES:
-        raise ValueError(f"render_mode '{render_mode}' (hit distance) requires the 3DGUT path, which is out of scope")
-    if render_mode not in _COLOR_MODES + ("D", "ED"):
+    if render_mode not in _COLOR_MODES + ("D", "ED") + _HIT_MODES:
         raise ValueError(f"Unsupported render_mode: {render_mode}")
     if rasterize_mode not in ("classic", "antialiased"):
         raise ValueError(f"Unsupported rasterize_mode: {rasterize_mode}")
-    unsupported = {
-        "with_ut": with_ut, "with_eval3d": with_eval3d, "return_normals": return_normals, "rays": rays is not None,
-        "radial_coeffs": radial_coeffs is not None, "tangential_coeffs": tangential_coeffs is not None,
-        "thin_prism_coeffs": thin_prism_coeffs is not None, "ftheta_coeffs": ftheta_coeffs is not None,
-        "lidar_coeffs": lidar_coeffs is not None, "external_distortion_coeffs": external_distortion_coeffs is not None,
-        "viewmats_rs": viewmats_rs is not None, "global_z_order=False": not global_z_order,
-    }
-    bad = [k for k, v in unsupported.items() if v]
-    if bad:
-        raise RuntimeError(
-            "gsplat_amd implements the classic 3DGS rasterization path; these arguments belong to the 3DGUT / "
-            f"sensor paths and are not supported: {', '.join(bad)}"
-        )
-    if segmented:
-        raise RuntimeError("segmented radix sort is not implemented (the global sort is used; results are identical)")
-
-    has_color = render_mode in _COLOR_MODES
+    has_color = render_mode in _COLOR_MODES or render_mode.startswith("RGB")
     has_depth = render_mode in _DEPTH_MODES
     expected_depth = render_mode in ("ED", "RGB+ED")
     tile_size = _resolve_tile_size(tile_size)
@@ -119,41 +101,42 @@ def rasterization(
     batch_dims = tuple(means.shape[:-2])
     nb = len(batch_dims)
     B = math.prod(batch_dims)
-    N = means.shape[-2]
-    C = viewmats.shape[-3]
+    N = means.shape[-2] if means.dim() >= 2 else 0
+    C = viewmats.shape[-3] if viewmats.dim() >= 3 else 0
     I = B * C
     device = means.device
+    _validate_rasterization_inputs(
+        means, covars, quats, scales, opacities, colors, viewmats, Ks, render_mode=render_mode,
+        rasterize_mode=rasterize_mode, sh_degree=sh_degree, packed=packed, sparse_grad=sparse_grad, absgrad=absgrad,
+        distributed=distributed, camera_model=camera_model, with_ut=with_ut, with_eval3d=with_eval3d,
+        return_normals=return_normals, global_z_order=global_z_order, rays=rays, radial_coeffs=radial_coeffs,
+        tangential_coeffs=tangential_coeffs, thin_prism_coeffs=thin_prism_coeffs, lidar_coeffs=lidar_coeffs,
+        external_distortion_coeffs=external_distortion_coeffs, rolling_shutter=rolling_shutter, viewmats_rs=viewmats_rs,
+        extra_signals=extra_signals, extra_signals_sh_degree=extra_signals_sh_degree, backgrounds=backgrounds,
+        channel_chunk=channel_chunk, covars_triu=_covars_triu)
+    # what validates but belongs to paths this backend does not build (a reference build with BUILD_3DGUT=0)
+    unsupported = {
+        "with_ut": with_ut, "with_eval3d": with_eval3d, "ftheta_coeffs": ftheta_coeffs is not None,
+        "camera_model='ftheta'": camera_model == "ftheta", "camera_model='lidar'": camera_model == "lidar",
+    }
+    bad = [k for k, v in unsupported.items() if v]
+    if bad:
+        raise RuntimeError(
+            "gsplat_amd implements the classic 3DGS rasterization path; these arguments belong to the 3DGUT / "
+            f"sensor paths and are not supported: {', '.join(bad)}"
+        )
+    if camera_model not in ("pinhole", "ortho", "fisheye"):
+        raise ValueError(f"camera_model '{camera_model}' is not supported (pinhole / ortho / fisheye)")
+    if segmented:
+        raise RuntimeError("segmented radix sort is not implemented (the global sort is used; results are identical)")
 
     if covars is not None and _covars_triu:
         # gsplat::rasterization_3dgs receives the upper-triangular 6-vectors (gsplat/rendering.py:540-544 converts)
-        assert covars.shape == batch_dims + (N, 6), covars.shape
         quats, scales = None, None
     elif covars is not None:
-        assert covars.shape == batch_dims + (N, 3, 3), covars.shape
         quats, scales = None, None
         ti = ([0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2])
         covars = covars[..., ti[0], ti[1]]
-    else:
-        assert quats is not None and scales is not None, "covars or (quats, scales) required"
-        assert quats.shape == batch_dims + (N, 4), quats.shape
-        assert scales.shape == batch_dims + (N, 3), scales.shape
-    assert means.shape == batch_dims + (N, 3), means.shape
-    assert opacities.shape == batch_dims + (N,), opacities.shape
-    assert viewmats.shape == batch_dims + (C, 4, 4), viewmats.shape
-    assert Ks.shape == batch_dims + (C, 3, 3), Ks.shape
-    if has_color:
-        assert colors is not None, "colors must be provided for color render modes"
-        if sh_degree is None:
-            assert (colors.dim() == nb + 2 and colors.shape[:-1] == batch_dims + (N,)) or (
-                colors.dim() == nb + 3 and colors.shape[:-1] == batch_dims + (C, N)
-            ), colors.shape
-        else:
-            assert colors.dim() == 3 and colors.shape[0] == N, colors.shape
-            assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
-    if sparse_grad:
-        assert packed, "sparse_grad is only supported when packed is True"
-    if backgrounds is not None:
-        assert backgrounds.shape[:-1] == batch_dims + (C,), backgrounds.shape
 
     world_size = 1
     dist_ctx = None
@@ -312,6 +295,111 @@ def rasterization(
     return render_colors, render_alphas, meta
 
 
+def _check(cond: bool, *msg) -> None:
+    """TORCH_CHECK: the reference's C++ validation surfaces as RuntimeError."""
+    if not cond:
+        raise RuntimeError("".join(str(m) for m in msg))
+
+
+_ROLLING_SHUTTER_GLOBAL = 4  # gsplat/cuda/_wrapper.py RollingShutterType.GLOBAL
+
+
+def _validate_rasterization_inputs(means, covars, quats, scales, opacities, colors, viewmats, Ks, *, render_mode,
+                                   rasterize_mode, sh_degree, packed, sparse_grad, absgrad, distributed, camera_model,
+                                   with_ut, with_eval3d, return_normals, global_z_order, rays, radial_coeffs,
+                                   tangential_coeffs, thin_prism_coeffs, lidar_coeffs, external_distortion_coeffs,
+                                   rolling_shutter, viewmats_rs, extra_signals, extra_signals_sh_degree, backgrounds,
+                                   channel_chunk, covars_triu) -> None:
+    """Host-side restatement of the reference's input validation (``Rendering.cpp:120-480``): same conditions, same
+    order, same messages, RuntimeError like ``TORCH_CHECK`` (the reference's tests match on the messages,
+    ``tests/test_rasterization.py:723-800``). Two deliberate differences: tile sizes 1..16 are accepted (the reference's
+    classic kernels are compiled for 4 and 16 only), and the checks run before any kernel or collective."""
+    has_color = render_mode.startswith("RGB")
+    hit = render_mode in _HIT_MODES
+    rs_global = rolling_shutter is None or int(rolling_shutter) == _ROLLING_SHUTTER_GLOBAL
+    if distributed:  # named first, so that the error is about the distributed limitation (Rendering.cpp:187-233)
+        _check(means.dim() == 2, "distributed=True does not support batch dimensions")
+        _check(not sparse_grad, "distributed=True does not support sparse_grad=True")
+        _check(not absgrad, "distributed=True does not support absgrad=True")
+        _check(not with_ut, "distributed=True does not support with_ut=True")
+        _check(not with_eval3d, "distributed=True does not support with_eval3d=True")
+        _check(not return_normals, "distributed=True does not support return_normals=True")
+        _check(rays is None, "distributed=True does not support rays")
+        _check(camera_model == "pinhole", "distributed=True only supports camera_model='pinhole'")
+        _check(global_z_order, "distributed=True does not support global_z_order=False")
+        _check(rs_global and viewmats_rs is None, "distributed=True does not support rolling shutter")
+        _check(radial_coeffs is None and tangential_coeffs is None and thin_prism_coeffs is None
+               and external_distortion_coeffs is None, "distributed=True does not support camera distortion")
+        _check(lidar_coeffs is None, "distributed=True does not support lidar coefficients")
+        if has_color and sh_degree is None:
+            _check(colors is not None and colors.dim() == 2, "distributed=True only supports per-Gaussian colors")
+        if extra_signals is not None and extra_signals_sh_degree is None:
+            _check(extra_signals.dim() == 2, "distributed=True only supports per-Gaussian extra signals")
+    if rasterize_mode != "classic" and (with_ut or with_eval3d):  # gsplat/rendering.py:170-175
+        raise ValueError("3DGUT rendering only supports rasterize_mode='classic'. "
+                         f"Got rasterize_mode='{rasterize_mode}' with with_ut={with_ut} and with_eval3d={with_eval3d}.")
+    _check(global_z_order or with_ut, "global_z_order can be false only if with_ut=True")
+    _check(with_ut or camera_model != "ftheta",
+           "ftheta camera is only supported via UT, please set with_ut=True in the rasterization()")
+    _check((camera_model == "lidar") == (lidar_coeffs is not None),
+           "Lidar coefficients must be given if and only if camera model is lidar")
+    _check(camera_model != "lidar" or with_ut, "Lidar camera model requires with_ut=True")
+    _check(channel_chunk > 0, "channel_chunk must be > 0")
+    _check(not hit or with_eval3d, "hit-distance render modes require with_eval3d=True")
+    _check(not return_normals or with_eval3d, "return_normals=True requires with_eval3d=True")
+    _check(not sparse_grad or packed, "sparse_grad is only supported when packed is True")
+    _check(not sparse_grad or means.dim() == 2, "sparse_grad does not support batch dimensions")
+    _check(camera_model != "ortho" or (radial_coeffs is None and tangential_coeffs is None and thin_prism_coeffs is None),
+           "ortho camera model does not support radial_coeffs, tangential_coeffs, or thin_prism_coeffs parameters")
+
+    _check(means.dim() >= 2 and means.shape[-1] == 3, "means must have shape [..., N, 3], got ", list(means.shape))
+    batch, N = tuple(means.shape[:-2]), means.shape[-2]
+    nb = len(batch)
+    _check(opacities.dim() == nb + 1, "opacities must have shape [..., N], got ", list(opacities.shape))
+    _check(viewmats.dim() == nb + 3, "viewmats must have shape [..., C, 4, 4], got ", list(viewmats.shape))
+    _check(Ks.dim() == nb + 3, "Ks must have shape [..., C, 3, 3], got ", list(Ks.shape))
+    C = viewmats.shape[nb]
+    _check(tuple(opacities.shape) == batch + (N,), "opacities must have shape [..., N], got ", list(opacities.shape))
+    _check(tuple(viewmats.shape) == batch + (C, 4, 4), "viewmats must have shape [..., C, 4, 4], got ",
+           list(viewmats.shape))
+    _check(tuple(Ks.shape) == batch + (C, 3, 3), "Ks must have shape [..., C, 3, 3], got ", list(Ks.shape))
+    if covars is not None:
+        _check(not with_eval3d and not with_ut, "UT and Eval3D rasterization require quats and scales, not covars")
+        want = batch + ((N, 6) if covars_triu else (N, 3, 3))
+        _check(tuple(covars.shape) == want, "covars must have shape [..., N, 3, 3] or [..., N, 6], got ",
+               list(covars.shape))
+    else:
+        _check(quats is not None, "covars or quats is required")
+        _check(scales is not None, "covars or scales is required")
+        _check(tuple(quats.shape) == batch + (N, 4), "quats must have shape [..., N, 4], got ", list(quats.shape))
+        _check(tuple(scales.shape) == batch + (N, 3), "scales must have shape [..., N, 3], got ", list(scales.shape))
+    if rs_global:
+        _check(viewmats_rs is None, "viewmats_rs should be None for global rolling shutter")
+    else:
+        _check(with_ut, "Rolling shutter requires with_ut=True")
+        _check(viewmats_rs is not None, "Rolling shutter requires viewmats_rs")
+    _check(rays is None or with_eval3d, "Rays input is only supported with Eval3D")
+    _check(radial_coeffs is None or with_ut, "Radial distortion requires with_ut=True")
+    _check(tangential_coeffs is None or with_ut, "Tangential distortion requires with_ut=True")
+    _check(thin_prism_coeffs is None or with_ut, "Thin-prism distortion requires with_ut=True")
+    _check(external_distortion_coeffs is None or with_ut, "External distortion requires with_ut=True")
+    if has_color:
+        _check(colors is not None, "colors must be provided for color render modes")
+        if sh_degree is not None:
+            _check(colors.dim() == 3 and colors.shape[0] == N, "SH colors must have shape [N, K, D], got ",
+                   list(colors.shape))
+            _check((sh_degree + 1) ** 2 <= colors.shape[-2], "sh_degree requires more color SH coefficients than provided")
+        else:
+            per_gaussian = colors.dim() == nb + 2 and colors.shape[nb] == N
+            per_view = colors.dim() == nb + 3 and colors.shape[nb] == C and colors.shape[nb + 1] == N
+            _check(per_gaussian or per_view, "colors must have shape [..., N, D] or [..., C, N, D], got ",
+                   list(colors.shape))
+    _check(has_color or sh_degree is None, "sh_degree must be None when colors is None")
+    if backgrounds is not None:
+        _check(tuple(backgrounds.shape[:-1]) == batch + (C,), "backgrounds must have shape [..., C, D], got ",
+               list(backgrounds.shape))
+
+
 def _project_features(features, sh_degree, clamp, means, viewmats, radii, batch_dims, B, C, N, batch_ids, camera_ids,
                       gaussian_ids):
     """Per-view feature rows: [..., C, N, D] (dense) or [nnz, D] (packed).
@@ -462,24 +550,34 @@ def rasterization_2dgs(
     has_color = render_mode in _COLOR_MODES
     append_depth = render_mode in _DEPTH_MODES
     expected_depth = render_mode in ("ED", "RGB+ED")
-    if distloss and not append_depth:
-        raise RuntimeError("distloss requires a depth render mode")
+    # check_rasterization_2dgs_inputs (Rendering.cpp:1588-1636): same conditions and messages, RuntimeError like TORCH_CHECK
+    _check(means.dim() >= 2 and means.shape[-1] == 3, "means must have shape [..., N, 3], got ", list(means.shape))
     batch_dims = tuple(means.shape[:-2])
     nb = len(batch_dims)
     B = math.prod(batch_dims)
-    N, C = means.shape[-2], viewmats.shape[-3]
+    N = means.shape[-2]
+    _check(quats.dim() >= 2 and tuple(quats.shape[-2:]) == (N, 4), "quats must have shape [..., N, 4], got ",
+           list(quats.shape))
+    _check(scales.dim() >= 2 and tuple(scales.shape[-2:]) == (N, 3), "scales must have shape [..., N, 3], got ",
+           list(scales.shape))
+    _check(opacities.dim() >= 1 and opacities.shape[-1] == N, "opacities must have shape [..., N], got ",
+           list(opacities.shape))
+    _check(viewmats.dim() >= 3 and tuple(viewmats.shape[-2:]) == (4, 4), "viewmats must have shape [..., C, 4, 4], got ",
+           list(viewmats.shape))
+    _check(Ks.dim() >= 3 and tuple(Ks.shape[-2:]) == (3, 3), "Ks must have shape [..., C, 3, 3], got ", list(Ks.shape))
+    C = viewmats.shape[-3]
     I = B * C
-    assert means.shape == batch_dims + (N, 3), means.shape
-    assert quats.shape == batch_dims + (N, 4), quats.shape
-    assert scales.shape == batch_dims + (N, 3), scales.shape
-    assert opacities.shape == batch_dims + (N,), opacities.shape
-    assert viewmats.shape == batch_dims + (C, 4, 4), viewmats.shape
-    assert Ks.shape == batch_dims + (C, 3, 3), Ks.shape
     if sh_degree is not None:
-        assert colors.dim() == 3 and colors.shape[0] == N, "SH coefficients must have shape [N, K, D]"
-        assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
-    if sparse_grad:
-        assert packed, "sparse_grad is only supported when packed is True"
+        _check(colors.dim() == 3 and colors.shape[0] == N, "SH coefficients must have shape [N, K, D], got ",
+               list(colors.shape))
+        _check((sh_degree + 1) ** 2 <= colors.shape[-2], "SH degree ", sh_degree, " too high for ", colors.shape[-2],
+               " coefficient bands")
+    _check(not distloss or append_depth, "distloss requires a depth render mode")
+    _check(not sparse_grad or packed, "sparse_grad is only supported when packed is True")
+    _check(tuple(quats.shape) == batch_dims + (N, 4) and tuple(scales.shape) == batch_dims + (N, 3)
+           and tuple(opacities.shape) == batch_dims + (N,) and tuple(viewmats.shape) == batch_dims + (C, 4, 4)
+           and tuple(Ks.shape) == batch_dims + (C, 3, 3), "inputs must share the batch dimensions of means ",
+           list(batch_dims))
 
     proj = fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width, height, eps2d=eps2d,
                                        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,

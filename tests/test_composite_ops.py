@@ -173,13 +173,19 @@ def test_rasterization_3dgs_argument_mapping(ops, monkeypatch):
 
 def test_covars_triu_layout_is_what_the_reference_python_sends():
     """gsplat/rendering.py:540-544 flattens [..., 3, 3] to the six upper-triangular entries before the op call; the
-    orchestrator takes them as they are (no second conversion)."""
-    import inspect
+    orchestrator takes them as they are: [N, 6] passes validation under `_covars_triu` (and only there), after which the
+    call reaches the kernels - which refuse CPU tensors."""
+    import gsplat_amd
+    from gsplat_amd._cabi import GsplatAmdError
 
-    from gsplat_amd import rendering
-
-    src = inspect.getsource(rendering.rasterization)
-    assert "_covars_triu" in src and "(N, 6)" in src
+    N = 4
+    args = (torch.rand(N, 3), None, None, torch.rand(N), torch.rand(N, 3), torch.eye(4)[None], torch.eye(3)[None], 8, 8)
+    with pytest.raises((GsplatAmdError, NotImplementedError), match="ROCm device|CPU"):
+        gsplat_amd.rasterization(*args, covars=torch.rand(N, 6), _covars_triu=True)
+    with pytest.raises(RuntimeError, match="covars must have shape"):
+        gsplat_amd.rasterization(*args, covars=torch.rand(N, 3, 3), _covars_triu=True)
+    with pytest.raises(RuntimeError, match="covars must have shape"):
+        gsplat_amd.rasterization(*args, covars=torch.rand(N, 6))
 
 
 def test_reference_rasterization_python_drives_the_composite_op(ops):

@@ -142,7 +142,7 @@ def _worker(rank, port, results, C_LOCAL):
             args = dict(batch_dims=(), sparse_grad=False, absgrad=False, camera_model="pinhole", colors=None,
                         sh_degree=None, n_cameras=C_LOCAL, device=dev, n_local=n_local)
             args.update(kw)
-            with pytest.raises(ValueError):
+            with pytest.raises(RuntimeError, match="distributed=True"):
                 gd.DistributedRasterContext.create(**args)
         results[rank] = "ok"
     except Exception as e:  # surface the failure to the parent
@@ -171,7 +171,7 @@ def test_unequal_camera_counts_are_rejected():
     """World size 1 sanity of the validation path that needs no peers."""
     from gsplat_amd import distributed as gd
 
-    with pytest.raises(RuntimeError):
+    with pytest.raises(ValueError, match="initialized default torch.distributed process group"):
         gd.DistributedRasterContext.create(batch_dims=(), sparse_grad=False, absgrad=False, camera_model="pinhole",
                                            colors=None, sh_degree=None, n_cameras=1, device=torch.device("cpu"),
                                            n_local=4)  # no process group initialised

@@ -117,11 +117,11 @@ def test_rasterization_rejects_out_of_scope_arguments(G):
         G.rasterization(*args, with_ut=True)
     with pytest.raises(RuntimeError):
         G.rasterization(*args, with_eval3d=True)
-    with pytest.raises(ValueError):
+    with pytest.raises(RuntimeError, match="hit-distance render modes require with_eval3d=True"):
         G.rasterization(*args, render_mode="RGB-Ed")
-    with pytest.raises(ValueError):
+    with pytest.raises(RuntimeError, match="ftheta camera is only supported via UT"):
         G.rasterization(*args, camera_model="ftheta")
-    with pytest.raises(AssertionError):
+    with pytest.raises(RuntimeError, match="sparse_grad is only supported when packed is True"):
         G.rasterization(*args, sparse_grad=True, packed=False)
 
 
@@ -262,7 +262,7 @@ def test_distributed_single_rank_matches_local(G, packed, force_exchange, monkey
             assert torch.equal(rc0, rc1) and torch.equal(ra0, ra1)
             for k in NAMES:
                 assert_grad_close(l1[k].grad.cpu(), l0[k].grad.cpu(), rel=1e-4, name=f"distributed (1 camera) v_{k}")
-        with pytest.raises(ValueError):
+        with pytest.raises(RuntimeError, match="absgrad=True"):
             G.rasterization(sc["means"].to(DEV), sc["quats"].to(DEV), sc["scales"].to(DEV), sc["opacities"].to(DEV),
                             sc["colors"].to(DEV), sc["viewmats"].to(DEV), sc["Ks"].to(DEV), W, H, sh_degree=2,
                             distributed=True, absgrad=True)
