@@ -240,6 +240,13 @@ def main():
         "gsx_project_ewa_bwd": 88 * V + 40 * n_local,
         "gsx_sh_fwd": (4 * K_sh * D + 12) * V + 4 * D * V,
         "gsx_sh_bwd": (4 * K_sh * D + 12 + 4 * D) * V + 4 * K_sh * D * n_local,
+        # fused intersection: count reads 36 B per live row and writes the per-row tile counts; emit
+        # reads 44 B per live row, writes and re-reads the 8-byte (depth, row) pairs, and writes 12 B of key + value each
+        "gsx_isect_fused_count": 36 * V + 4 * N_rows,
+        "gsx_isect_fused_emit_sort": 44 * V + 28 * M,
+        # compositing (not HBM-bound: listed so that every stage of the step has its line)
+        "gsx_raster3d_fwd": b_fwd,
+        "gsx_raster3d_bwd": b_bwd,
     }
     stage_roofline = {}
     for k, nbytes in stage_bytes.items():
