@@ -1,0 +1,165 @@
+"""CPU oracle for the Unscented-Transform projection of 3DGUT (TEST INFRASTRUCTURE ONLY; nothing under gsplat_amd/ may
+import it).
+
+Restates the behaviour of ``gsplat::projection_ut_3dgs_fused`` (reference kernel
+``gsplat/cuda/csrc/ProjectionUT3DGSFused.cu``; the reference's own torch statement of it is
+``gsplat/cuda/_torch_impl_ut.py:69-644`` with the camera models of ``gsplat/cuda/_torch_cameras.py``) for the camera
+models built so far: perfect pinhole (``_torch_cameras.py:696-757``), OpenCV pinhole with radial / tangential / thin-prism
+distortion (``:927-1086``) and orthographic (``:793-848``), global shutter. Fisheye, f-theta, lidar, rolling shutter and
+the windshield model are not restated yet.
+
+Pinned: ``oracle/pin_ut_against_reference.py`` runs the reference's ``_fully_fused_projection_with_ut`` on the CPU — its
+parameter records (``torch.classes.gsplat.UnscentedTransformParameters``) come from this backend's
+``libgsplat_amd_torch.so`` installed as ``gsplat.csrc`` — and writes ``tests/golden/ut_ref.npz``;
+``tests/test_oracle_ut.py`` checks this module against those vectors.
+
+The algorithm, per (camera, Gaussian):
+  1. seven sigma points: the mean and mean +- sqrt(3 + lambda) * scale_i * R[:, i], lambda = alpha^2 (3 + kappa) - 3
+     (``_torch_impl_ut.py:111-170``);
+  2. each is moved to the camera frame and projected by the camera model, which also says whether the point is valid
+     (in front, distortion factor > 0.8, inside the image grown by ``in_image_margin_factor``);
+  3. mean2d = sum w_m p_i, cov2d = sum w_c (p_i - mean2d)(p_i - mean2d)^T with the UT weights (``:69-108``); when
+     ``require_all_sigma_points_valid`` the sums stop at the first invalid point (the kernel's early exit, ``:222-262``);
+  4. blur + compensation, determinant / diagonal checks, conic = inverse, opacity-aware extent, eigenvalue-bounded radii,
+     radius clip, image-bounds cull (``:470-644``). Invalid rows are zero.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+ALPHA_THRESHOLD = 1.0 / 255.0
+MIN_COMPENSATION = 0.005  # gsplat/cuda/_constants.py
+
+
+def ut_weights(alpha: float, beta: float, kappa: float) -> Tuple[float, float, float, float]:
+    """(centre weight of the mean, centre weight of the covariance, weight of the six others, sigma-point spread)."""
+    lam = alpha * alpha * (3.0 + kappa) - 3.0
+    w0 = lam / (3.0 + lam)
+    return w0, w0 + (1.0 - alpha * alpha + beta), 1.0 / (2.0 * (3.0 + lam)), math.sqrt(3.0 + lam)
+
+
+def _rotmat(quats: Tensor) -> Tensor:
+    """Unit quaternion (w, x, y, z) -> rotation matrix; zero-length quaternions stay zero (culled by the caller)."""
+    n = quats.norm(dim=-1, keepdim=True)
+    q = quats / torch.where(n > 0, n, torch.ones_like(n))
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(q.shape[:-1] + (3, 3))
+
+
+def project_points(p: Tensor, camera_model: str, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor, width: int, height: int,
+                   margin: float, radial: Optional[Tensor], tangential: Optional[Tensor], thin_prism: Optional[Tensor]):
+    """Camera-frame points p [..., C, M, 3] -> (pixels [..., C, M, 2], valid [..., C, M]). Per-camera parameters are
+    [..., C, 1] (broadcast over M)."""
+    front = p[..., 2] > 0.0
+    if camera_model == "ortho":
+        u, v = p[..., 0], p[..., 1]
+        ok = front
+    else:
+        u, v = p[..., 0] / p[..., 2], p[..., 1] / p[..., 2]
+        ok = front
+        if radial is not None or tangential is not None or thin_prism is not None:
+            z = torch.zeros_like(fx)
+            k = [z] * 6 if radial is None else [radial[..., i:i + 1] if i < radial.shape[-1] else z for i in range(6)]
+            p1, p2 = (z, z) if tangential is None else (tangential[..., 0:1], tangential[..., 1:2])
+            s = [z] * 4 if thin_prism is None else [thin_prism[..., i:i + 1] for i in range(4)]
+            uu, vv = u * u, v * v
+            r2 = uu + vv
+            a1, a2, a3 = 2.0 * u * v, r2 + 2.0 * uu, r2 + 2.0 * vv
+            icd = (1.0 + r2 * (k[0] + r2 * (k[1] + r2 * k[2]))) / (1.0 + r2 * (k[3] + r2 * (k[4] + r2 * k[5])))
+            du = p1 * a1 + p2 * a2 + r2 * (s[0] + r2 * s[1])
+            dv = p1 * a3 + p2 * a1 + r2 * (s[2] + r2 * s[3])
+            u, v = icd * u + du, icd * v + dv
+            ok = ok & (icd > 0.8)  # the distorted model does NOT zero points behind the camera (_torch_cameras.py:1052-1086)
+            px, py = u * fx + cx, v * fy + cy
+            inb = (px >= -width * margin) & (px < width + width * margin) & (py >= -height * margin) & (py < height + height * margin)
+            return torch.stack([px, py], -1), ok & inb
+    px, py = u * fx + cx, v * fy + cy
+    px, py = torch.where(front, px, torch.zeros_like(px)), torch.where(front, py, torch.zeros_like(py))
+    inb = (px >= -width * margin) & (px < width + width * margin) & (py >= -height * margin) & (py < height + height * margin)
+    return torch.stack([px, py], -1), ok & inb
+
+
+def fully_fused_projection_with_ut(
+    means: Tensor, quats: Tensor, scales: Tensor, opacities: Optional[Tensor], viewmats: Tensor, Ks: Tensor, width: int,
+    height: int, eps2d: float = 0.3, near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0,
+    calc_compensations: bool = False, camera_model: str = "pinhole", alpha: float = 0.1, beta: float = 2.0,
+    kappa: float = 0.0, in_image_margin_factor: float = 0.1, require_all_sigma_points_valid: bool = False,
+    radial_coeffs: Optional[Tensor] = None, tangential_coeffs: Optional[Tensor] = None,
+    thin_prism_coeffs: Optional[Tensor] = None,
+):
+    """means [..., N, 3], quats [..., N, 4], scales [..., N, 3], opacities [..., N] or None, viewmats [..., C, 4, 4],
+    Ks [..., C, 3, 3] -> radii int32 [..., C, N, 2], means2d [..., C, N, 2], depths [..., C, N], conics [..., C, N, 3],
+    compensations [..., C, N] or None."""
+    if camera_model not in ("pinhole", "ortho"):
+        raise NotImplementedError(f"oracle.ut: camera model '{camera_model}' is not restated yet")
+    dt = means.dtype
+    w_m0, w_c0, w_i, spread = ut_weights(alpha, beta, kappa)
+    R = _rotmat(quats)  # [..., N, 3, 3], columns = principal axes
+    axes = (spread * R * scales[..., None, :]).transpose(-1, -2)  # rows = the three offsets
+    sigma = torch.cat([means[..., None, :], means[..., None, :] + axes, means[..., None, :] - axes], dim=-2)  # [..., N, 7, 3]
+
+    Rc, tc = viewmats[..., :3, :3], viewmats[..., :3, 3]
+    cam = torch.einsum("...cij,...nkj->...cnki", Rc, sigma) + tc[..., None, None, :]  # [..., C, N, 7, 3]
+    lead = cam.shape[:-3]
+    N = means.shape[-2]
+    par = lambda t: t[..., None]  # noqa: E731  [..., C] -> [..., C, 1]
+    pts, ok = project_points(cam.reshape(lead + (N * 7, 3)), camera_model, par(Ks[..., 0, 0]), par(Ks[..., 1, 1]),
+                             par(Ks[..., 0, 2]), par(Ks[..., 1, 2]), width, height, in_image_margin_factor,
+                             radial_coeffs, tangential_coeffs, thin_prism_coeffs)
+    pts, ok = pts.reshape(lead + (N, 7, 2)), ok.reshape(lead + (N, 7))
+
+    wm = torch.tensor([w_m0] + [w_i] * 6, dtype=dt)
+    wc = torch.tensor([w_c0] + [w_i] * 6, dtype=dt)
+    if require_all_sigma_points_valid:
+        upto = torch.cumprod(ok.to(dt), dim=-1)  # 1 until the first invalid point
+        valid = upto[..., -1] > 0
+        wm, wc = wm * upto, wc * upto
+    else:
+        valid = ok.any(dim=-1)
+    mean2d = (wm[..., None] * pts).sum(dim=-2)
+    d = pts - mean2d[..., None, :]
+    cxx, cxy, cyy = (wc * d[..., 0] * d[..., 0]).sum(-1), (wc * d[..., 0] * d[..., 1]).sum(-1), (wc * d[..., 1] * d[..., 1]).sum(-1)
+
+    centre = cam[..., 0, :]  # sigma point 0 is the mean
+    z = centre[..., 2]
+    eps = torch.finfo(dt).eps
+    alive = ((quats * quats).sum(-1) > eps) & (scales > eps).all(-1)  # [..., N]
+    valid = valid & (z >= near_plane) & (z <= far_plane) & alive[..., None, :]
+
+    det0 = cxx * cyy - cxy * cxy
+    cxx, cyy = cxx + eps2d, cyy + eps2d
+    det = cxx * cyy - cxy * cxy
+    comp = torch.sqrt(torch.clamp(det0 / det, min=MIN_COMPENSATION * MIN_COMPENSATION))
+    valid = valid & (det > 0.0) & (cxx > 0.0) & (cyy > 0.0)
+
+    ixx, iyy = cxx + 1e-6, cyy + 1e-6  # the reference inverts cov + 1e-6 I (_torch_impl_ut.py:526-528)
+    idet = ixx * iyy - cxy * cxy
+    conics = torch.stack([iyy / idet, -cxy / idet, ixx / idet], dim=-1)
+
+    extend = torch.full_like(det, 3.33)
+    if opacities is not None:
+        op = opacities[..., None, :] * comp
+        valid = valid & (op >= ALPHA_THRESHOLD)
+        extend = torch.minimum(extend, torch.sqrt(2.0 * torch.log(torch.clamp(op / ALPHA_THRESHOLD, min=1.0))))
+    b = 0.5 * (cxx + cyy)
+    lam_max = b + torch.sqrt(torch.clamp(b * b - det, min=0.01))
+    r_eig = extend * torch.sqrt(lam_max.clamp(min=0.0))
+    rx = torch.ceil(torch.minimum(extend * torch.sqrt(cxx.clamp(min=0.0)), r_eig))
+    ry = torch.ceil(torch.minimum(extend * torch.sqrt(cyy.clamp(min=0.0)), r_eig))
+    valid = valid & (torch.maximum(rx, ry) > radius_clip)
+    valid = valid & (mean2d[..., 0] + rx > 0) & (mean2d[..., 0] - rx < width) & (mean2d[..., 1] + ry > 0) & (mean2d[..., 1] - ry < height)
+
+    zero = torch.zeros_like(z)
+    radii = torch.where(valid[..., None], torch.stack([rx, ry], -1), zero[..., None]).to(torch.int32)
+    means2d = torch.where(valid[..., None], mean2d, zero[..., None])
+    depths = torch.where(valid, z, zero)
+    conics = torch.where(valid[..., None], conics, zero[..., None])
+    comps = torch.where(valid, comp, zero) if calc_compensations else None
+    return radii, means2d, depths, conics, comps
