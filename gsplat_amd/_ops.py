@@ -118,6 +118,12 @@ COMPOSITE_SCHEMAS = {
     "rasterization_2dgs": "(Tensor means, Tensor quats, Tensor scales, Tensor opacities, Tensor colors, Tensor viewmats, Tensor Ks, int image_width, int image_height, int tile_size, float eps2d, float near_plane, float far_plane, float radius_clip, Tensor? backgrounds, bool packed, bool sparse_grad, bool absgrad, bool distloss, int? sh_degree, str render_mode, str depth_mode) -> (Tensor, Tensor, Tensor, Tensor?, Tensor, Tensor, Tensor, Tensor?, Tensor?, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, int, int, int)",
 }
 
+# Ops whose schemas name the custom classes but carry no gradient (CUDA key only).
+CLASS_SCHEMAS = {
+    # Unscented-Transform projection of 3DGUT (ext.cpp:1230-1239)
+    "projection_ut_3dgs_fused": "(Tensor means, Tensor quats, Tensor scales, Tensor? opacities, Tensor viewmats0, Tensor? viewmats1, Tensor Ks, int image_width, int image_height, float eps2d, float near_plane, float far_plane, float radius_clip, bool calc_compensations, int camera_model, bool global_z_order, __torch__.torch.classes.gsplat.UnscentedTransformParameters? ut_params, int rs_type, Tensor? radial_coeffs, Tensor? tangential_coeffs, Tensor? thin_prism_coeffs, __torch__.torch.classes.gsplat.FThetaCameraDistortionParameters? ftheta_coeffs, __torch__.torch.classes.gsplat.RowOffsetStructuredSpinningLidarModelParametersExt? lidar_coeffs, __torch__.torch.classes.gsplat.BivariateWindshieldModelParameters? external_distortion_params) -> (Tensor, Tensor, Tensor, Tensor, Tensor?)",
+}
+
 _impls = {}
 
 
@@ -1281,6 +1287,62 @@ def assemble_proj_features_unpacked_fwd(degrees_to_use, B, C, N, Dc, E, color_po
 
 
 # ----------------------------------------------------------------------------------------------
+# Unscented-Transform projection (3DGUT)
+# ----------------------------------------------------------------------------------------------
+@_op("projection_ut_3dgs_fused")
+def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmats1, Ks, image_width, image_height,
+                             eps2d, near_plane, far_plane, radius_clip, calc_compensations, camera_model, global_z_order,
+                             ut_params, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, ftheta_coeffs,
+                             lidar_coeffs, external_distortion_params):
+    """gsplat::projection_ut_3dgs_fused (kernel ``ProjectionUT3DGSFused.cu``): perfect / OpenCV pinhole and orthographic
+    cameras, global shutter. What is not built yet is refused, never approximated."""
+    if viewmats1 is not None or rs_type != _ROLLING_SHUTTER_GLOBAL:
+        raise NotImplementedError("gsplat_amd: rolling-shutter UT projection is not built yet")
+    if camera_model not in (0, 1):
+        raise NotImplementedError(f"gsplat_amd: UT projection is built for pinhole and ortho cameras, not "
+                                  f"'{_CAMERA_MODEL_NAMES.get(camera_model, camera_model)}'")
+    if lidar_coeffs is not None or external_distortion_params is not None:
+        raise NotImplementedError("gsplat_amd: lidar / external-distortion UT projection is not built yet")
+    if not global_z_order:
+        raise NotImplementedError("gsplat_amd: UT projection with global_z_order=False is not built yet")
+    _check_f32(means=means, quats=quats, scales=scales, opacities=opacities, viewmats=viewmats0, Ks=Ks,
+               radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs, thin_prism_coeffs=thin_prism_coeffs)
+    batch = tuple(means.shape[:-2])
+    N, C, B = means.shape[-2], viewmats0.shape[-3], math.prod(means.shape[:-2])
+    if quats.shape != batch + (N, 4) or scales.shape != batch + (N, 3) or viewmats0.shape != batch + (C, 4, 4) \
+            or Ks.shape != batch + (C, 3, 3) or (opacities is not None and opacities.shape != batch + (N,)):
+        raise ValueError("projection_ut_3dgs_fused: inconsistent input shapes")
+    if radial_coeffs is not None:
+        if radial_coeffs.shape[:-1] != batch + (C,) or radial_coeffs.shape[-1] not in (4, 6):
+            raise ValueError(f"radial_coeffs must have shape [..., C, 6] or [..., C, 4], got {tuple(radial_coeffs.shape)}")
+        if radial_coeffs.shape[-1] == 4:
+            radial_coeffs = torch.nn.functional.pad(radial_coeffs, (0, 2))
+    if tangential_coeffs is not None and tangential_coeffs.shape != batch + (C, 2):
+        raise ValueError(f"tangential_coeffs must have shape [..., C, 2], got {tuple(tangential_coeffs.shape)}")
+    if thin_prism_coeffs is not None and thin_prism_coeffs.shape != batch + (C, 4):
+        raise ValueError(f"thin_prism_coeffs must have shape [..., C, 4], got {tuple(thin_prism_coeffs.shape)}")
+    if camera_model == 1 and (radial_coeffs is not None or tangential_coeffs is not None or thin_prism_coeffs is not None):
+        raise RuntimeError("ortho camera model does not support radial_coeffs, tangential_coeffs, or thin_prism_coeffs "
+                           "parameters")
+    alpha, beta, kappa, margin, all_valid = 0.1, 2.0, 0.0, 0.1, False  # Cameras.h:59-64
+    if ut_params is not None:
+        alpha, beta, kappa = float(ut_params.alpha), float(ut_params.beta), float(ut_params.kappa)
+        margin, all_valid = float(ut_params.in_image_margin_factor), bool(ut_params.require_all_sigma_points_valid)
+    dev, dt = means.device, means.dtype
+    radii = torch.empty(batch + (C, N, 2), device=dev, dtype=torch.int32)
+    means2d = torch.empty(batch + (C, N, 2), device=dev, dtype=dt)
+    depths = torch.empty(batch + (C, N), device=dev, dtype=dt)
+    conics = torch.empty(batch + (C, N, 3), device=dev, dtype=dt)
+    comps = torch.empty(batch + (C, N), device=dev, dtype=dt) if calc_compensations else None
+    call("gsx_project_ut_fwd", ptr(means.contiguous()), ptr(quats.contiguous()), ptr(scales.contiguous()),
+         ptr(_c(opacities)), ptr(viewmats0.contiguous()), ptr(Ks.contiguous()), ptr(_c(radial_coeffs)),
+         ptr(_c(tangential_coeffs)), ptr(_c(thin_prism_coeffs)), B, C, N, int(image_width), int(image_height),
+         float(eps2d), float(near_plane), float(far_plane), float(radius_clip), int(camera_model), alpha, beta, kappa,
+         margin, int(all_valid), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(comps))
+    return radii, means2d, depths, conics, comps
+
+
+# ----------------------------------------------------------------------------------------------
 # whole-pipeline ops (what the reference's gsplat.rasterization() / rasterization_2dgs() call)
 # ----------------------------------------------------------------------------------------------
 _CAMERA_MODEL_NAMES = {0: "pinhole", 1: "ortho", 2: "fisheye", 3: "ftheta", 4: "lidar"}  # Common.h:75-82
@@ -1330,7 +1392,7 @@ def rasterization_3dgs(means, covars, quats, scales, opacities, colors, viewmats
         distributed=process_group_name is not None or world_size > 1, camera_model=_CAMERA_MODEL_NAMES[camera_model],
         segmented=segmented, covars=covars, with_ut=with_ut, with_eval3d=with_eval3d, return_normals=return_normals,
         global_z_order=global_z_order, rays=rays, radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs,
-        thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=None, lidar_coeffs=lidar_coeffs,
+        thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=None, lidar_coeffs=lidar_coeffs, ut_params=ut_params,
         external_distortion_coeffs=external_distortion_params, viewmats_rs=viewmats_rs, extra_signals=extra_signals,
         extra_signals_sh_degree=None if extra_signals_sh_degree < 0 else extra_signals_sh_degree, _covars_triu=True)
     extra = meta.get("render_extra_signals")
@@ -1386,6 +1448,12 @@ def _register():
                 _lib_def.define(name + schema)
             _lib_impl.impl(name, _impls[name])
             _lib_impl_autograd.impl(name, _impls[name])
+        for name, schema in CLASS_SCHEMAS.items():
+            try:
+                torch._C._dispatch_find_schema_or_throw(f"{NS}::{name}", "")
+            except RuntimeError:
+                _lib_def.define(name + schema)
+            _lib_impl.impl(name, _impls[name])
 
 
 _register()

@@ -46,6 +46,48 @@ def world_to_cam(means: Tensor, covars: Tensor, viewmats: Tensor) -> Tuple[Tenso
     return means_c, covars_c
 
 
+@torch.no_grad()
+def fully_fused_projection_with_ut(
+    means: Tensor,  # [..., N, 3]
+    quats: Tensor,  # [..., N, 4]
+    scales: Tensor,  # [..., N, 3]
+    opacities: Optional[Tensor],  # [..., N]
+    viewmats: Tensor,  # [..., C, 4, 4]
+    Ks: Tensor,  # [..., C, 3, 3]
+    width: int,
+    height: int,
+    eps2d: float = 0.3,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    calc_compensations: bool = False,
+    camera_model: str = "pinhole",
+    ut_params=None,
+    radial_coeffs: Optional[Tensor] = None,  # [..., C, 6] or [..., C, 4]
+    tangential_coeffs: Optional[Tensor] = None,  # [..., C, 2]
+    thin_prism_coeffs: Optional[Tensor] = None,  # [..., C, 4]
+    ftheta_coeffs=None,
+    lidar_coeffs=None,
+    external_distortion_coeffs=None,
+    rolling_shutter: int = 4,  # RollingShutterType.GLOBAL
+    viewmats_rs: Optional[Tensor] = None,
+    global_z_order: bool = True,
+) -> Tuple[Tensor, Tensor, Tensor, Tensor, Optional[Tensor]]:
+    """Projects Gaussians to 2D with the Unscented Transform — like ``fully_fused_projection`` but through a camera model
+    with lens distortion; not differentiable (reference ``gsplat/cuda/_wrapper.py:2545-2633``). Returns
+    (radii [..., C, N, 2], means2d, depths, conics, compensations or None). Built: pinhole (perfect or OpenCV-distorted)
+    and ortho cameras with a global shutter."""
+    models = {"pinhole": 0, "ortho": 1, "fisheye": 2, "ftheta": 3, "lidar": 4}
+    if camera_model not in models:
+        raise ValueError(f"unknown camera_model '{camera_model}'")
+    c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+    return _ops.projection_ut_3dgs_fused(
+        means.contiguous(), quats.contiguous(), scales.contiguous(), c(opacities), viewmats.contiguous(), c(viewmats_rs),
+        Ks.contiguous(), width, height, eps2d, near_plane, far_plane, radius_clip, calc_compensations,
+        models[camera_model], global_z_order, ut_params, int(rolling_shutter), c(radial_coeffs), c(tangential_coeffs),
+        c(thin_prism_coeffs), ftheta_coeffs, lidar_coeffs, external_distortion_coeffs)
+
+
 def _has(feature: str) -> bool:
     from . import csrc_shim
 

@@ -1,0 +1,244 @@
+// Unscented-Transform projection of 3D Gaussians (3DGUT), forward only (the op carries no gradient), gfx950.
+// C-ABI entry: gsx_project_ut_fwd (replaces torch op gsplat::projection_ut_3dgs_fused, gsplat/cuda/ext.cpp:1230-1239;
+// host fn gsplat/cuda/csrc/Projection.cpp; kernel gsplat/cuda/csrc/ProjectionUT3DGSFused.cu; the reference's torch
+// statement of the algorithm: gsplat/cuda/_torch_impl_ut.py:69-644 with the camera models of
+// gsplat/cuda/_torch_cameras.py:696-757 (perfect pinhole), :927-1086 (OpenCV pinhole), :793-848 (orthographic)).
+//
+// One thread per (camera, Gaussian): a streaming kernel, 44 B read + 32 B written per row like the EWA projection.
+//   1. seven sigma points: mean, mean +- sqrt(3 + lambda) scale_i R[:, i], lambda = alpha^2 (3 + kappa) - 3;
+//   2. each one goes to the camera frame and through the camera model (valid = in front, distortion factor > 0.8,
+//      inside the image grown by margin);
+//   3. mean2d = sum w_m p_i, cov2d = sum w_c (p_i - mean2d)(p_i - mean2d)^T; with require_all_valid the sums stop at the
+//      first invalid point;
+//   4. blur + compensation, determinant / diagonal checks, conic = inverse (of cov + 1e-6 I, like the reference),
+//      opacity-aware extent, eigenvalue-bounded radii, radius clip, image-bounds cull. Invalid rows are zero.
+// Built so far: camera_model 0 (pinhole, with optional radial[6] / tangential[2] / thin-prism[4] coefficients) and
+// 1 (orthographic), global shutter. Fisheye, f-theta, lidar, rolling shutter and the windshield model are rejected.
+#include "projmath.hpp"
+#include "../../include/gsplat_amd.h"
+
+namespace gsx {
+
+struct ProjUtArgs {
+    const float *means, *quats, *scales, *opacities; // [B,N,3] [B,N,4] [B,N,3] [B,N] or null
+    const float *viewmats, *Ks;                      // [B,C,4,4] [B,C,3,3]
+    const float *radial, *tangential, *thin_prism;   // [B,C,6] [B,C,2] [B,C,4] or null
+    uint32_t B, C, N, width, height;
+    float eps2d, near_plane, far_plane, radius_clip;
+    int camera_model, require_all_valid, distorted;
+    float w_m0, w_c0, w_i, spread, margin;
+    int32_t *radii;       // [B,C,N,2]
+    float *means2d;       // [B,C,N,2]
+    float *depths;        // [B,C,N]
+    float *conics;        // [B,C,N,3]
+    float *compensations; // [B,C,N] or null
+};
+
+struct UtDistortion {
+    float k[6], p[2], s[4];
+};
+
+// camera-frame point -> pixel; returns validity
+__device__ __forceinline__ bool ut_project_point(const ProjUtArgs &a, const Cam &c, const UtDistortion &d, const float *p,
+                                                 float &px, float &py)
+{
+    const bool front = p[2] > 0.0f;
+    bool ok          = front;
+    float u, v;
+    bool zero_behind = true;
+    if (a.camera_model == 1) { // orthographic
+        u = p[0];
+        v = p[1];
+    } else {
+        u = p[0] / p[2];
+        v = p[1] / p[2];
+        if (a.distorted) {
+            const float uu = u * u, vv = v * v, r2 = uu + vv;
+            const float a1 = 2.0f * u * v, a2 = r2 + 2.0f * uu, a3 = r2 + 2.0f * vv;
+            const float icd = (1.0f + r2 * (d.k[0] + r2 * (d.k[1] + r2 * d.k[2])))
+                              / (1.0f + r2 * (d.k[3] + r2 * (d.k[4] + r2 * d.k[5])));
+            const float du = d.p[0] * a1 + d.p[1] * a2 + r2 * (d.s[0] + r2 * d.s[1]);
+            const float dv = d.p[0] * a3 + d.p[1] * a1 + r2 * (d.s[2] + r2 * d.s[3]);
+            u  = icd * u + du;
+            v  = icd * v + dv;
+            ok = ok && (icd > 0.8f);
+            zero_behind = false; // the distorted model keeps the coordinates of points behind the camera
+        }
+    }
+    px = u * c.fx + c.cx;
+    py = v * c.fy + c.cy;
+    if (zero_behind && !front) px = py = 0.0f;
+    const float mx = (float)a.width * a.margin, my = (float)a.height * a.margin;
+    const bool inb = (px >= -mx) && (px < (float)a.width + mx) && (py >= -my) && (py < (float)a.height + my);
+    return ok && inb;
+}
+
+__global__ void __launch_bounds__(256) project_ut_kernel(const ProjUtArgs a)
+{
+    const int64_t rows = (int64_t)a.B * a.C * a.N;
+    const int64_t row  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const uint32_t g = (uint32_t)(row % a.N), bc = (uint32_t)(row / a.N), b = bc / a.C;
+    const size_t gi  = (size_t)b * a.N + g;
+
+    auto write_invalid = [&]() {
+        a.radii[2 * row] = a.radii[2 * row + 1] = 0;
+        a.means2d[2 * row] = a.means2d[2 * row + 1] = 0.0f;
+        a.depths[row] = 0.0f;
+        a.conics[3 * row] = a.conics[3 * row + 1] = a.conics[3 * row + 2] = 0.0f;
+        if (a.compensations) a.compensations[row] = 0.0f;
+    };
+
+    const Cam c = load_cam(a.viewmats + (size_t)bc * 16, a.Ks + (size_t)bc * 9);
+    UtDistortion d{};
+    if (a.distorted) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d.k[i] = a.radial ? a.radial[(size_t)bc * 6 + i] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) d.p[i] = a.tangential ? a.tangential[(size_t)bc * 2 + i] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d.s[i] = a.thin_prism ? a.thin_prism[(size_t)bc * 4 + i] : 0.0f;
+    }
+
+    const float *m = a.means + gi * 3, *q = a.quats + gi * 4, *s = a.scales + gi * 3;
+    const float eps = 1.1920929e-07f; // float32 machine epsilon (torch.finfo(float32).eps)
+    const float qn2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    const bool alive = (qn2 > eps) && (s[0] > eps) && (s[1] > eps) && (s[2] > eps);
+    if (!alive) {
+        write_invalid();
+        return;
+    }
+    float qn[4], Rq[9];
+    quat_normalize(q, qn);
+    quat_to_rotmat(qn, Rq); // columns = principal axes
+
+    // sigma points in the camera frame: centre + the three scaled axes (camera-frame axis = R_cam * axis)
+    float pc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pc[i] = c.R[3 * i] * m[0] + c.R[3 * i + 1] * m[1] + c.R[3 * i + 2] * m[2] + c.t[i];
+    const float z = pc[2];
+
+    float px[7], py[7];
+    bool okp[7];
+    okp[0] = ut_project_point(a, c, d, pc, px[0], py[0]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // world-space sigma points are mean +- offset_k; they are moved to the camera frame as points (not as
+        // centre + R offset) so that the rounding matches the reference's statement point by point
+        const float ox = a.spread * s[k] * Rq[k], oy = a.spread * s[k] * Rq[3 + k], oz = a.spread * s[k] * Rq[6 + k];
+        float wp[3], cp[3];
+        wp[0] = m[0] + ox; wp[1] = m[1] + oy; wp[2] = m[2] + oz;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cp[i] = c.R[3 * i] * wp[0] + c.R[3 * i + 1] * wp[1] + c.R[3 * i + 2] * wp[2] + c.t[i];
+        okp[1 + k] = ut_project_point(a, c, d, cp, px[1 + k], py[1 + k]);
+        wp[0] = m[0] - ox; wp[1] = m[1] - oy; wp[2] = m[2] - oz;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cp[i] = c.R[3 * i] * wp[0] + c.R[3 * i + 1] * wp[1] + c.R[3 * i + 2] * wp[2] + c.t[i];
+        okp[4 + k] = ut_project_point(a, c, d, cp, px[4 + k], py[4 + k]);
+    }
+
+    // UT weights; with require_all_valid the sums stop at the first invalid point (weights of the rest are zero)
+    float wm[7], wc[7];
+    bool valid;
+    {
+        bool run = true, any = false;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            any = any || okp[i];
+            run = run && okp[i];
+            const bool use = a.require_all_valid ? run : true;
+            wm[i] = use ? (i == 0 ? a.w_m0 : a.w_i) : 0.0f;
+            wc[i] = use ? (i == 0 ? a.w_c0 : a.w_i) : 0.0f;
+        }
+        valid = a.require_all_valid ? run : any;
+    }
+    float mx = 0.0f, my = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        mx += wm[i] * px[i];
+        my += wm[i] * py[i];
+    }
+    float cxx = 0.0f, cxy = 0.0f, cyy = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const float dx = px[i] - mx, dy = py[i] - my;
+        cxx += wc[i] * dx * dx;
+        cxy += wc[i] * dx * dy;
+        cyy += wc[i] * dy * dy;
+    }
+    valid = valid && (z >= a.near_plane) && (z <= a.far_plane);
+
+    const float det0 = cxx * cyy - cxy * cxy;
+    cxx += a.eps2d;
+    cyy += a.eps2d;
+    const float det  = cxx * cyy - cxy * cxy;
+    const float comp = sqrtf(fmaxf(det0 / det, kMinCompensation * kMinCompensation));
+    valid = valid && (det > 0.0f) && (cxx > 0.0f) && (cyy > 0.0f);
+
+    float extend = kGaussianExtend;
+    if (a.opacities) {
+        const float op = a.opacities[gi] * comp;
+        valid = valid && (op >= kAlphaThreshold);
+        extend = fminf(extend, sqrtf(2.0f * logf(fmaxf(op / kAlphaThreshold, 1.0f))));
+    }
+    const float hb = 0.5f * (cxx + cyy);
+    const float lam_max = hb + sqrtf(fmaxf(hb * hb - det, 0.01f));
+    const float r_eig = extend * sqrtf(fmaxf(lam_max, 0.0f));
+    const float rx = ceilf(fminf(extend * sqrtf(fmaxf(cxx, 0.0f)), r_eig));
+    const float ry = ceilf(fminf(extend * sqrtf(fmaxf(cyy, 0.0f)), r_eig));
+    valid = valid && (fmaxf(rx, ry) > a.radius_clip);
+    valid = valid && (mx + rx > 0.0f) && (mx - rx < (float)a.width) && (my + ry > 0.0f) && (my - ry < (float)a.height);
+    if (!valid) {
+        write_invalid();
+        return;
+    }
+    const float ixx = cxx + 1e-6f, iyy = cyy + 1e-6f;
+    const float idet = ixx * iyy - cxy * cxy;
+    a.radii[2 * row]       = (int32_t)rx;
+    a.radii[2 * row + 1]   = (int32_t)ry;
+    a.means2d[2 * row]     = mx;
+    a.means2d[2 * row + 1] = my;
+    a.depths[row]          = z;
+    a.conics[3 * row]      = iyy / idet;
+    a.conics[3 * row + 1]  = -cxy / idet;
+    a.conics[3 * row + 2]  = ixx / idet;
+    if (a.compensations) a.compensations[row] = comp;
+}
+
+} // namespace gsx
+
+extern "C" int gsx_project_ut_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                                  const float *viewmats, const float *Ks, const float *radial, const float *tangential,
+                                  const float *thin_prism, uint32_t B, uint32_t C, uint32_t N, uint32_t width,
+                                  uint32_t height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                                  int camera_model, float ut_alpha, float ut_beta, float ut_kappa,
+                                  float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii,
+                                  float *means2d, float *depths, float *conics, float *compensations, void *stream)
+{
+    using namespace gsx;
+    const int64_t rows = (int64_t)B * C * N;
+    if (rows == 0) return GSX_OK;
+    GSX_REQUIRE(means && quats && scales && viewmats && Ks, "gsx_project_ut_fwd: null input");
+    GSX_REQUIRE(radii && means2d && depths && conics, "gsx_project_ut_fwd: null output");
+    GSX_REQUIRE(camera_model == 0 || camera_model == 1,
+                "gsx_project_ut_fwd: camera model %d is not built (pinhole = 0 and orthographic = 1 are)", camera_model);
+    GSX_REQUIRE(camera_model == 0 || (!radial && !tangential && !thin_prism),
+                "gsx_project_ut_fwd: the orthographic model takes no distortion coefficients");
+    const double lam = (double)ut_alpha * ut_alpha * (3.0 + ut_kappa) - 3.0;
+    GSX_REQUIRE(3.0 + lam > 0.0, "gsx_project_ut_fwd: alpha^2 (3 + kappa) must be positive");
+    ProjUtArgs a{};
+    a.means = means; a.quats = quats; a.scales = scales; a.opacities = opacities; a.viewmats = viewmats; a.Ks = Ks;
+    a.radial = radial; a.tangential = tangential; a.thin_prism = thin_prism;
+    a.B = B; a.C = C; a.N = N; a.width = width; a.height = height;
+    a.eps2d = eps2d; a.near_plane = near_plane; a.far_plane = far_plane; a.radius_clip = radius_clip;
+    a.camera_model = camera_model; a.require_all_valid = require_all_sigma_points_valid;
+    a.distorted = (radial || tangential || thin_prism) ? 1 : 0;
+    a.w_m0 = (float)(lam / (3.0 + lam));
+    a.w_c0 = (float)(lam / (3.0 + lam) + (1.0 - (double)ut_alpha * ut_alpha + ut_beta));
+    a.w_i  = (float)(1.0 / (2.0 * (3.0 + lam)));
+    a.spread = (float)sqrt(3.0 + lam);
+    a.margin = in_image_margin_factor;
+    a.radii = radii; a.means2d = means2d; a.depths = depths; a.conics = conics; a.compensations = compensations;
+    project_ut_kernel<<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    return check_launch("project_ut_fwd");
+}

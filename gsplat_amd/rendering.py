@@ -116,8 +116,10 @@ def rasterization(
         channel_chunk=channel_chunk, covars_triu=_covars_triu)
     # what validates but belongs to paths this backend does not build (a reference build with BUILD_3DGUT=0)
     unsupported = {
-        "with_ut": with_ut, "with_eval3d": with_eval3d, "ftheta_coeffs": ftheta_coeffs is not None,
+        "with_eval3d": with_eval3d, "ftheta_coeffs": ftheta_coeffs is not None,
         "camera_model='ftheta'": camera_model == "ftheta", "camera_model='lidar'": camera_model == "lidar",
+        "camera_model='fisheye' with with_ut": with_ut and camera_model == "fisheye",
+        "rolling shutter": viewmats_rs is not None, "external_distortion_coeffs": external_distortion_coeffs is not None,
     }
     bad = [k for k, v in unsupported.items() if v]
     if bad:
@@ -154,10 +156,21 @@ def rasterization(
         viewmats_proj, Ks_proj, C_proj = viewmats, Ks, C
 
     calc_comp = rasterize_mode == "antialiased"
-    proj = fully_fused_projection(
-        means, covars, quats, scales, viewmats_proj, Ks_proj, width, height, eps2d=eps2d, near_plane=near_plane,
-        far_plane=far_plane, radius_clip=radius_clip, packed=packed, sparse_grad=sparse_grad,
-        calc_compensations=calc_comp, camera_model=camera_model, opacities=opacities)
+    if with_ut:
+        # Unscented-Transform projection through the (possibly distorted) camera model; no gradient reaches the geometry
+        # on this path (the reference runs the op under no_grad as well, Rendering.cpp:890-925)
+        from ._wrapper import fully_fused_projection_with_ut
+
+        proj = fully_fused_projection_with_ut(
+            means, quats, scales, opacities, viewmats_proj, Ks_proj, width, height, eps2d=eps2d, near_plane=near_plane,
+            far_plane=far_plane, radius_clip=radius_clip, calc_compensations=calc_comp, camera_model=camera_model,
+            ut_params=ut_params, radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs,
+            thin_prism_coeffs=thin_prism_coeffs, global_z_order=global_z_order)
+    else:
+        proj = fully_fused_projection(
+            means, covars, quats, scales, viewmats_proj, Ks_proj, width, height, eps2d=eps2d, near_plane=near_plane,
+            far_plane=far_plane, radius_clip=radius_clip, packed=packed, sparse_grad=sparse_grad,
+            calc_compensations=calc_comp, camera_model=camera_model, opacities=opacities)
 
     if packed:
         batch_ids, camera_ids, gaussian_ids, indptr, radii, means2d, depths, conics, compensations = proj
@@ -186,8 +199,8 @@ def rasterization(
     if dist_ctx is None:
         isect_pending = isect_tiles_begin(
             means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=False, packed=packed,
-            n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids, conics=conics,
-            opacities=proj_opacities.contiguous())
+            n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids, conics=None if with_ut else conics,
+            opacities=None if with_ut else proj_opacities.contiguous())  # UT: plain radius boxes (Rendering.cpp:1307-1308)
 
     # ---- feature channels: [..., C, N, D] or [nnz, D] ------------------------------------------
     feats = None
@@ -363,6 +376,9 @@ def _validate_rasterization_inputs(means, covars, quats, scales, opacities, colo
     _check(tuple(viewmats.shape) == batch + (C, 4, 4), "viewmats must have shape [..., C, 4, 4], got ",
            list(viewmats.shape))
     _check(tuple(Ks.shape) == batch + (C, 3, 3), "Ks must have shape [..., C, 3, 3], got ", list(Ks.shape))
+    if with_ut:
+        _check(not packed, "Packed mode is not supported with UT")
+        _check(not sparse_grad, "Sparse grad is not supported with UT")
     if covars is not None:
         _check(not with_eval3d and not with_ut, "UT and Eval3D rasterization require quats and scales, not covars")
         want = batch + ((N, 6) if covars_triu else (N, 3, 3))

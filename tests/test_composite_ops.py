@@ -71,7 +71,7 @@ def test_schemas_are_the_references(ops):
     if not os.path.isdir(os.path.join(REF, "gsplat")):
         pytest.skip("reference checkout not present")
     ref = _reference_schemas()
-    ours = dict(ops.SCHEMAS, **ops.COMPOSITE_SCHEMAS)
+    ours = dict(ops.SCHEMAS, **ops.COMPOSITE_SCHEMAS, **ops.CLASS_SCHEMAS)
     assert {"rasterization_3dgs", "rasterization_2dgs", "assemble_proj_features_unpacked_fwd"} <= set(ours)
     missing = [n for n in ours if n not in ref]
     assert not missing, f"ops without a reference schema: {missing}"
@@ -87,7 +87,7 @@ def test_python_kernels_carry_the_schema_defaults(ops):
     defaulted schema argument needs the same default on the Python function."""
     import inspect
 
-    for name in dict(ops.SCHEMAS, **ops.COMPOSITE_SCHEMAS):
+    for name in dict(ops.SCHEMAS, **ops.COMPOSITE_SCHEMAS, **ops.CLASS_SCHEMAS):
         schema = getattr(torch.ops.gsplat, name).default._schema
         params = list(inspect.signature(ops.impl(name)).parameters.values())
         for i, arg in enumerate(schema.arguments):

@@ -123,7 +123,7 @@ def test_rasterization_3dgs_op_rejects_out_of_scope_arguments(G):
             vals[names.index(k)] = v
         return torch.ops.gsplat.rasterization_3dgs(*vals)
 
-    for over in (dict(with_ut=True), dict(with_eval3d=True), dict(rolling_shutter=0), dict(use_hit_distance=True,
+    for over in (dict(with_ut=True, packed=True), dict(with_eval3d=True), dict(rolling_shutter=0), dict(use_hit_distance=True,
                  append_depth=True), dict(radial_coeffs=torch.zeros(1, 6, device=DEV)), dict(camera_model=3)):
         with pytest.raises((RuntimeError, ValueError)):
             call(**over)

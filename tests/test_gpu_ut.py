@@ -1,0 +1,92 @@
+"""GPU: Unscented-Transform projection (gsx_project_ut_fwd / gsplat::projection_ut_3dgs_fused) against the golden vectors
+of the reference's torch implementation and against the CPU oracle, and rasterization(with_ut=True) on top of it."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import make_scene
+from test_oracle_ut import CASES, check_against_reference, ut_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import gsplat_amd
+
+    return gsplat_amd
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "ut_ref.npz")))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_ut_projection_matches_reference_outputs(G, gold, name):
+    kw, ut, dist, use_op, (N, C, W, H) = ut_case(name)
+    sc = {k: torch.from_numpy(gold[f"{name}.{k}"]).to(DEV) for k in ("means", "quats", "scales", "opacities", "viewmats", "Ks")}
+    cam = {k + "_coeffs": (None if v is None else torch.tensor(v, device=DEV).repeat(C, 1)) for k, v in dist.items()}
+    got = G.fully_fused_projection_with_ut(
+        sc["means"], sc["quats"], sc["scales"], sc["opacities"] if use_op else None, sc["viewmats"], sc["Ks"], W, H,
+        ut_params=torch.classes.gsplat.UnscentedTransformParameters(**ut), **cam, **kw)
+    assert got[0].dtype == torch.int32 and got[0].shape == (C, N, 2) and got[3].shape == (C, N, 3)
+    got = tuple(None if t is None else t.cpu() for t in got)
+    # the reference's CUDA-vs-torch tolerances for this op (tests/test_basic.py:838-960): validity mismatches < 0.1 %,
+    # radii atol 2, means2d atol 5e-2; the data allow tighter bounds
+    check_against_reference(got, gold, name, radii_atol=1, means_atol=2e-2, conic_rel=3e-2, max_flips=2)
+
+
+def test_ut_projection_larger_scene_vs_oracle(G):
+    """100k Gaussians, 3 distorted cameras: kernel vs CPU oracle (same tolerances, a few boundary rows may flip)."""
+    from oracle import ut as O
+
+    sc, W, H = make_scene(N=100_000, C=3, width=320, height=200, seed=21)
+    rad = torch.tensor([[-0.12, 0.03, 0.0, 0.0, 0.0, 0.0]]).repeat(3, 1)
+    tan = torch.tensor([[0.002, -0.001]]).repeat(3, 1)
+    ref = O.fully_fused_projection_with_ut(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["viewmats"], sc["Ks"],
+                                           W, H, calc_compensations=True, radial_coeffs=rad, tangential_coeffs=tan)
+    got = G.fully_fused_projection_with_ut(
+        sc["means"].to(DEV), sc["quats"].to(DEV), sc["scales"].to(DEV), sc["opacities"].to(DEV), sc["viewmats"].to(DEV),
+        sc["Ks"].to(DEV), W, H, calc_compensations=True, radial_coeffs=rad.to(DEV), tangential_coeffs=tan.to(DEV))
+    got = [t.cpu() for t in got]
+    vr, vg = (ref[0] > 0).all(-1), (got[0] > 0).all(-1)
+    assert float((vr != vg).float().mean()) < 1e-3
+    both = vr & vg
+    assert both.sum() > 50_000
+    assert int((ref[0] - got[0]).abs()[both].max()) <= 2
+    assert float(((ref[0] - got[0]).abs()[both] > 0).float().mean()) < 5e-3
+    assert float((ref[1] - got[1]).abs()[both].max()) < 5e-2
+    torch.testing.assert_close(got[2][both], ref[2][both], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got[4][both], ref[4][both], rtol=5e-3, atol=1e-4)
+
+
+def test_rasterization_with_ut(G):
+    """with_ut=True (classic compositing on UT-projected Gaussians): close to the EWA render for an undistorted pinhole,
+    zero distortion coefficients change nothing, colours / opacities still receive gradients, packed rows are refused."""
+    sc, W, H = make_scene(N=4000, C=2, width=160, height=112, seed=6)
+    a = {k: v.to(DEV) for k, v in sc.items()}
+    args = (a["means"], a["quats"], a["scales"], a["opacities"], a["colors"], a["viewmats"], a["Ks"], W, H)
+    rc0, ra0, _ = G.rasterization(*args, packed=False)
+    rc1, ra1, meta = G.rasterization(*args, packed=False, with_ut=True)
+    assert rc1.shape == rc0.shape and meta["radii"].shape == (2, 4000, 2)
+    assert float((rc1 - rc0).abs().mean()) < 2e-2 and float((ra1 - ra0).abs().mean()) < 2e-2
+    rc2, ra2, _ = G.rasterization(*args, packed=False, with_ut=True, radial_coeffs=torch.zeros(2, 6, device=DEV))
+    assert float((rc2 - rc1).abs().max()) < 1e-5
+    rc3, _, _ = G.rasterization(*args, packed=False, with_ut=True,
+                                radial_coeffs=torch.tensor([[-0.2, 0.05, 0, 0, 0, 0.0]], device=DEV).repeat(2, 1))
+    assert float((rc3 - rc1).abs().mean()) > 1e-3  # the distortion moves things
+    colors = a["colors"].clone().requires_grad_(True)
+    opac = a["opacities"].clone().requires_grad_(True)
+    rc4, ra4, _ = G.rasterization(a["means"], a["quats"], a["scales"], opac, colors, a["viewmats"], a["Ks"], W, H,
+                                  packed=False, with_ut=True)
+    (rc4.sum() + ra4.sum()).backward()
+    assert float(colors.grad.abs().sum()) > 0 and float(opac.grad.abs().sum()) > 0
+    with pytest.raises(RuntimeError, match="Packed mode is not supported with UT"):
+        G.rasterization(*args, packed=True, with_ut=True)

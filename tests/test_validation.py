@@ -88,8 +88,11 @@ def test_distributed_needs_a_process_group():
     (dict(colors=torch.rand(6, 4, 3), sh_degree=2), RuntimeError, "sh_degree requires more color SH coefficients"),
     (dict(colors=torch.rand(5, 16, 3), sh_degree=1), RuntimeError, r"SH colors must have shape \[N, K, D\]"),
     (dict(covars=torch.rand(6, 2, 2)), RuntimeError, "covars must have shape"),
-    (dict(with_ut=True), RuntimeError, "3DGUT"),  # validates, but this backend does not build that path
-    (dict(with_eval3d=True, packed=False), RuntimeError, "3DGUT"),
+    (dict(with_ut=True), RuntimeError, "Packed mode is not supported with UT"),  # packed defaults to True
+    (dict(with_ut=True, packed=False, covars=torch.rand(6, 3, 3), quats=None, scales=None), RuntimeError,
+     "UT and Eval3D rasterization require quats and scales, not covars"),
+    (dict(with_ut=True, packed=False, camera_model="fisheye"), RuntimeError, "not supported"),  # validates; not built yet
+    (dict(with_eval3d=True, packed=False), RuntimeError, "3DGUT"),  # validates; this backend does not build that path
 ])
 def test_classic_path_validation(over, exc, match):
     import gsplat_amd
