@@ -1289,6 +1289,59 @@ def assemble_proj_features_unpacked_fwd(degrees_to_use, B, C, N, Dc, E, color_po
 # ----------------------------------------------------------------------------------------------
 # Unscented-Transform projection (3DGUT)
 # ----------------------------------------------------------------------------------------------
+def _cubic_first_positive_root(a: Tensor, b: Tensor, c: Tensor) -> Tensor:
+    """Per camera: the smallest positive x with 1 + a x + b x^2 + c x^3 = 0, or inf. Closed forms by degree; a cubic with
+    one real root by Cardano, with three by the cosine form."""
+    inf = torch.full_like(a, float("inf"))
+    degree1 = torch.where(a < 0.0, -1.0 / a, inf)
+    disc2 = a * a - 4.0 * b
+    den = torch.sqrt(disc2.clamp_min(0.0)) - a
+    degree2 = torch.where((disc2 >= 0.0) & (den > 0.0), 2.0 / den, inf)
+    cs = torch.where(c.abs() < 1e-10, torch.ones_like(c), c)  # placeholder where the cubic branch is not taken
+    r = b / cs
+    u = (9.0 * a * r - 2.0 * b * r * r - 27.0) / cs
+    w = 3.0 * a / cs - r * r
+    disc3 = u * u + 4.0 * w * w * w
+    half = (torch.sqrt(disc3.clamp_min(0.0)) + u) * 0.5
+    cbrt = torch.sign(half) * half.abs().pow(1.0 / 3.0)
+    single = torch.where(cbrt != 0.0, (cbrt - w / torch.where(cbrt != 0.0, cbrt, torch.ones_like(cbrt)) - r) / 3.0, inf)
+    single = torch.where(single > 0.0, single, inf)
+    phi = torch.atan2(torch.sqrt((-disc3).clamp_min(0.0)), u) / 3.0
+    amp = 2.0 * torch.sqrt((-w).clamp_min(0.0))
+    triple = inf
+    for turn in (-1.0, 0.0, 1.0):
+        x = (amp * torch.cos(phi + turn * (2.0 * math.pi / 3.0)) - r) / 3.0
+        triple = torch.minimum(triple, torch.where(x > 0.0, x, inf))
+    cubic = torch.where(disc3 >= 0.0, single, triple)
+    is_quadratic, is_linear = c.abs() < 1e-10, (c.abs() < 1e-10) & (b.abs() < 1e-10)
+    return torch.where(is_linear, degree1, torch.where(is_quadratic, degree2, cubic))
+
+
+def fisheye_max_angle(radial_coeffs: Tensor, Ks: Tensor, width: int, height: int) -> Tensor:
+    """[..., C] largest ray angle an OpenCV fisheye camera projects: the first zero of the derivative of
+    theta (1 + k1 theta^2 + k2 theta^4 + k3 theta^6 + k4 theta^8) - a cubic in theta^2 when k4 vanishes, otherwise Newton
+    from 1.57 rad (20 steps; accepted when a step fell below 1e-6 and the result is positive) - capped at the angle of the
+    image corner. Restates the constructor of the reference's fisheye model (gsplat/cuda/_torch_cameras.py:1344-1521);
+    a handful of scalars per camera, evaluated with tensor ops on the cameras' device."""
+    k1, k2, k3, k4 = radial_coeffs.unbind(-1)
+    from_cubic = torch.sqrt(_cubic_first_positive_root(3.0 * k1, 5.0 * k2, 7.0 * k3))
+    x = torch.full_like(k1, 1.57)
+    settled = torch.zeros_like(k1, dtype=torch.bool)
+    for _ in range(20):
+        q = x * x
+        value = 1.0 + q * (3.0 * k1 + q * (5.0 * k2 + q * (7.0 * k3 + q * (9.0 * k4))))
+        slope = x * (6.0 * k1 + q * (20.0 * k2 + q * (42.0 * k3 + q * (72.0 * k4))))
+        step = value / slope
+        x = torch.where(settled, x, x - step)
+        settled = settled | (step.abs() < 1e-6)
+    from_newton = torch.where(settled & (x > 0.0), x, torch.full_like(x, float("inf")))
+    angle = torch.where(k4.abs() < 1e-10, from_cubic, from_newton)
+    fx, fy, cx, cy = Ks[..., 0, 0], Ks[..., 1, 1], Ks[..., 0, 2], Ks[..., 1, 2]
+    half_w, half_h = torch.maximum(width - cx, cx), torch.maximum(height - cy, cy)
+    corner = torch.sqrt(half_w * half_w + half_h * half_h)
+    return torch.minimum(angle, torch.maximum(corner / fx, corner / fy))
+
+
 @_op("projection_ut_3dgs_fused")
 def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmats1, Ks, image_width, image_height,
                              eps2d, near_plane, far_plane, radius_clip, calc_compensations, camera_model, global_z_order,
@@ -1298,8 +1351,8 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
     cameras, global shutter. What is not built yet is refused, never approximated."""
     if viewmats1 is not None or rs_type != _ROLLING_SHUTTER_GLOBAL:
         raise NotImplementedError("gsplat_amd: rolling-shutter UT projection is not built yet")
-    if camera_model not in (0, 1):
-        raise NotImplementedError(f"gsplat_amd: UT projection is built for pinhole and ortho cameras, not "
+    if camera_model not in (0, 1, 2):
+        raise NotImplementedError(f"gsplat_amd: UT projection is built for pinhole, ortho and fisheye cameras, not "
                                   f"'{_CAMERA_MODEL_NAMES.get(camera_model, camera_model)}'")
     if lidar_coeffs is not None or external_distortion_params is not None:
         raise NotImplementedError("gsplat_amd: lidar / external-distortion UT projection is not built yet")
@@ -1312,6 +1365,15 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
     if quats.shape != batch + (N, 4) or scales.shape != batch + (N, 3) or viewmats0.shape != batch + (C, 4, 4) \
             or Ks.shape != batch + (C, 3, 3) or (opacities is not None and opacities.shape != batch + (N,)):
         raise ValueError("projection_ut_3dgs_fused: inconsistent input shapes")
+    max_angle = None
+    if camera_model == 2:  # fisheye: k1..k4 only, plus the per-camera angle limit
+        if tangential_coeffs is not None or thin_prism_coeffs is not None:
+            raise ValueError("the fisheye camera model takes radial_coeffs [..., C, 4] only")
+        if radial_coeffs is None:
+            radial_coeffs = torch.zeros(batch + (C, 4), device=means.device, dtype=means.dtype)
+        if radial_coeffs.shape != batch + (C, 4):
+            raise ValueError(f"fisheye radial_coeffs must have shape [..., C, 4], got {tuple(radial_coeffs.shape)}")
+        max_angle = fisheye_max_angle(radial_coeffs, Ks, int(image_width), int(image_height)).contiguous()
     if radial_coeffs is not None:
         if radial_coeffs.shape[:-1] != batch + (C,) or radial_coeffs.shape[-1] not in (4, 6):
             raise ValueError(f"radial_coeffs must have shape [..., C, 6] or [..., C, 4], got {tuple(radial_coeffs.shape)}")
@@ -1336,7 +1398,8 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
     comps = torch.empty(batch + (C, N), device=dev, dtype=dt) if calc_compensations else None
     call("gsx_project_ut_fwd", ptr(means.contiguous()), ptr(quats.contiguous()), ptr(scales.contiguous()),
          ptr(_c(opacities)), ptr(viewmats0.contiguous()), ptr(Ks.contiguous()), ptr(_c(radial_coeffs)),
-         ptr(_c(tangential_coeffs)), ptr(_c(thin_prism_coeffs)), B, C, N, int(image_width), int(image_height),
+         ptr(_c(tangential_coeffs)), ptr(_c(thin_prism_coeffs)), ptr(max_angle), B, C, N, int(image_width),
+         int(image_height),
          float(eps2d), float(near_plane), float(far_plane), float(radius_clip), int(camera_model), alpha, beta, kappa,
          margin, int(all_valid), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(comps))
     return radii, means2d, depths, conics, comps

@@ -12,8 +12,10 @@
 //      first invalid point;
 //   4. blur + compensation, determinant / diagonal checks, conic = inverse (of cov + 1e-6 I, like the reference),
 //      opacity-aware extent, eigenvalue-bounded radii, radius clip, image-bounds cull. Invalid rows are zero.
-// Built so far: camera_model 0 (pinhole, with optional radial[6] / tangential[2] / thin-prism[4] coefficients) and
-// 1 (orthographic), global shutter. Fisheye, f-theta, lidar, rolling shutter and the windshield model are rejected.
+// Built so far: camera_model 0 (pinhole, with optional radial[6] / tangential[2] / thin-prism[4] coefficients),
+// 1 (orthographic) and 2 (OpenCV fisheye, _torch_cameras.py:1335-1697: k1..k4 in radial[0..3]; the largest angle the
+// model projects is a per-camera quantity computed by the caller), global shutter. F-theta, lidar, rolling shutter and
+// the windshield model are rejected.
 #include "projmath.hpp"
 #include "../../include/gsplat_amd.h"
 
@@ -23,6 +25,7 @@ struct ProjUtArgs {
     const float *means, *quats, *scales, *opacities; // [B,N,3] [B,N,4] [B,N,3] [B,N] or null
     const float *viewmats, *Ks;                      // [B,C,4,4] [B,C,3,3]
     const float *radial, *tangential, *thin_prism;   // [B,C,6] [B,C,2] [B,C,4] or null
+    const float *max_angle;                          // [B,C]: fisheye only (largest ray angle the model projects)
     uint32_t B, C, N, width, height;
     float eps2d, near_plane, far_plane, radius_clip;
     int camera_model, require_all_valid, distorted;
@@ -36,6 +39,7 @@ struct ProjUtArgs {
 
 struct UtDistortion {
     float k[6], p[2], s[4];
+    float max_angle;
 };
 
 // camera-frame point -> pixel; returns validity
@@ -46,6 +50,22 @@ __device__ __forceinline__ bool ut_project_point(const ProjUtArgs &a, const Cam 
     bool ok          = front;
     float u, v;
     bool zero_behind = true;
+    if (a.camera_model == 2) { // OpenCV fisheye: r = theta (1 + k1 theta^2 + ... + k4 theta^8), theta clamped at max_angle
+        const float ax = fabsf(p[0]), ay = fabsf(p[1]);
+        const float big = fmaxf(ax, ay), small = fminf(ax, ay);
+        const float ratio = big > 0.0f ? small / big : 0.0f;
+        float rxy = big > 0.0f ? big * sqrtf(1.0f + ratio * ratio) : 0.0f; // overflow-safe hypot, like the reference
+        if (!(rxy > 0.0f)) rxy = 1.1920929e-07f;
+        const float th_full = atan2f(rxy, p[2]);
+        const float th = fminf(th_full, d.max_angle), t2 = th * th;
+        const float poly  = th * (1.0f + t2 * (d.k[0] + t2 * (d.k[1] + t2 * (d.k[2] + t2 * d.k[3]))));
+        const float delta = poly / rxy;
+        px = delta * p[0] * c.fx + c.cx;
+        py = delta * p[1] * c.fy + c.cy;
+        const float mx = (float)a.width * a.margin, my = (float)a.height * a.margin;
+        const bool inb = (px >= -mx) && (px < (float)a.width + mx) && (py >= -my) && (py < (float)a.height + my);
+        return front && (delta > 0.0f) && (th_full < d.max_angle) && inb;
+    }
     if (a.camera_model == 1) { // orthographic
         u = p[0];
         v = p[1];
@@ -91,6 +111,7 @@ __global__ void __launch_bounds__(256) project_ut_kernel(const ProjUtArgs a)
 
     const Cam c = load_cam(a.viewmats + (size_t)bc * 16, a.Ks + (size_t)bc * 9);
     UtDistortion d{};
+    d.max_angle = a.max_angle ? a.max_angle[bc] : 0.0f;
     if (a.distorted) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) d.k[i] = a.radial ? a.radial[(size_t)bc * 6 + i] : 0.0f;
@@ -209,7 +230,7 @@ __global__ void __launch_bounds__(256) project_ut_kernel(const ProjUtArgs a)
 
 extern "C" int gsx_project_ut_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
                                   const float *viewmats, const float *Ks, const float *radial, const float *tangential,
-                                  const float *thin_prism, uint32_t B, uint32_t C, uint32_t N, uint32_t width,
+                                  const float *thin_prism, const float *fisheye_max_angle, uint32_t B, uint32_t C, uint32_t N, uint32_t width,
                                   uint32_t height, float eps2d, float near_plane, float far_plane, float radius_clip,
                                   int camera_model, float ut_alpha, float ut_beta, float ut_kappa,
                                   float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii,
@@ -220,15 +241,18 @@ extern "C" int gsx_project_ut_fwd(const float *means, const float *quats, const 
     if (rows == 0) return GSX_OK;
     GSX_REQUIRE(means && quats && scales && viewmats && Ks, "gsx_project_ut_fwd: null input");
     GSX_REQUIRE(radii && means2d && depths && conics, "gsx_project_ut_fwd: null output");
-    GSX_REQUIRE(camera_model == 0 || camera_model == 1,
-                "gsx_project_ut_fwd: camera model %d is not built (pinhole = 0 and orthographic = 1 are)", camera_model);
-    GSX_REQUIRE(camera_model == 0 || (!radial && !tangential && !thin_prism),
+    GSX_REQUIRE(camera_model >= 0 && camera_model <= 2,
+                "gsx_project_ut_fwd: camera model %d is not built (pinhole = 0, orthographic = 1 and fisheye = 2 are)",
+                camera_model);
+    GSX_REQUIRE(camera_model != 1 || (!radial && !tangential && !thin_prism),
                 "gsx_project_ut_fwd: the orthographic model takes no distortion coefficients");
+    GSX_REQUIRE(camera_model != 2 || (fisheye_max_angle && !tangential && !thin_prism),
+                "gsx_project_ut_fwd: the fisheye model needs fisheye_max_angle and takes radial coefficients only");
     const double lam = (double)ut_alpha * ut_alpha * (3.0 + ut_kappa) - 3.0;
     GSX_REQUIRE(3.0 + lam > 0.0, "gsx_project_ut_fwd: alpha^2 (3 + kappa) must be positive");
     ProjUtArgs a{};
     a.means = means; a.quats = quats; a.scales = scales; a.opacities = opacities; a.viewmats = viewmats; a.Ks = Ks;
-    a.radial = radial; a.tangential = tangential; a.thin_prism = thin_prism;
+    a.radial = radial; a.tangential = tangential; a.thin_prism = thin_prism; a.max_angle = fisheye_max_angle;
     a.B = B; a.C = C; a.N = N; a.width = width; a.height = height;
     a.eps2d = eps2d; a.near_plane = near_plane; a.far_plane = far_plane; a.radius_clip = radius_clip;
     a.camera_model = camera_model; a.require_all_valid = require_all_sigma_points_valid;

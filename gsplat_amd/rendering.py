@@ -118,7 +118,6 @@ def rasterization(
     unsupported = {
         "with_eval3d": with_eval3d, "ftheta_coeffs": ftheta_coeffs is not None,
         "camera_model='ftheta'": camera_model == "ftheta", "camera_model='lidar'": camera_model == "lidar",
-        "camera_model='fisheye' with with_ut": with_ut and camera_model == "fisheye",
         "rolling shutter": viewmats_rs is not None, "external_distortion_coeffs": external_distortion_coeffs is not None,
     }
     bad = [k for k, v in unsupported.items() if v]

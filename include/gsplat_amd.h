@@ -171,16 +171,20 @@ int gsx_sh_bwd(int degrees_to_use, const float *means, const float *viewmats, co
  * Unscented-Transform projection (3DGUT): gsplat::projection_ut_3dgs_fused (ext.cpp:1230-1239; kernel
  * ProjectionUT3DGSFused.cu; algorithm as gsplat/cuda/_torch_impl_ut.py:69-644). Forward only - the op carries no gradient.
  * Dense rows [B,C,N]. camera_model 0 = pinhole (optionally OpenCV-distorted: radial [B,C,6] (k1..k6; pad 4 -> 6 with
- * zeros), tangential [B,C,2], thin_prism [B,C,4]; NULL = absent), 1 = orthographic (no coefficients). Global shutter.
+ * zeros), tangential [B,C,2], thin_prism [B,C,4]; NULL = absent), 1 = orthographic (no coefficients), 2 = OpenCV fisheye
+ * (k1..k4 in radial[..., 0:4]; fisheye_max_angle [B,C] = largest ray angle the model projects, i.e. where
+ * d/dtheta of theta (1 + k1 theta^2 + .. + k4 theta^8) first vanishes, capped at the image corner - computed by the
+ * caller, _torch_cameras.py:1344-1521). Global shutter.
  * Seven sigma points mean, mean +- sqrt(3 + lambda) scale_i R[:, i] (lambda = alpha^2 (3 + kappa) - 3) go through the
  * camera model; mean2d / cov2d are the UT-weighted moments of their pixels (sums stop at the first invalid point when
  * require_all_sigma_points_valid). Then blur (+eps2d I) and compensation, conic = inverse, opacity-aware extent (opacities
  * NULL = none), eigenvalue-bounded radii, radius clip, image cull. Rows that fail a check are written as zeros.
- * compensations may be NULL. Other camera models (fisheye, f-theta, lidar) and rolling shutter are not built: -1.
+ * compensations may be NULL. Other camera models (f-theta, lidar) and rolling shutter are not built: -1.
  * ------------------------------------------------------------------------------------------- */
 int gsx_project_ut_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
                        const float *viewmats, const float *Ks, const float *radial, const float *tangential,
-                       const float *thin_prism, uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                       const float *thin_prism, const float *fisheye_max_angle, uint32_t B, uint32_t C, uint32_t N,
+                       uint32_t width, uint32_t height,
                        float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
                        float ut_alpha, float ut_beta, float ut_kappa, float in_image_margin_factor,
                        int require_all_sigma_points_valid, int32_t *radii, float *means2d, float *depths,

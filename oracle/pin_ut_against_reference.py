@@ -53,6 +53,11 @@ CASES = {
     "opencv_radial4": (6, dict(radial=[-0.2, 0.05, 0.0, 0.0], require_all_sigma_points_valid=True)),
     "opencv_strong": (7, dict(radial=[-0.45, 0.1, 0.0, 0.0, 0.0, 0.0], tangential=[0.01, 0.01])),  # icD < 0.8 at the rim
     "ortho": (8, dict(camera_model="ortho")),
+    "fisheye_plain": (9, dict(camera_model="fisheye")),
+    "fisheye_k": (10, dict(camera_model="fisheye", radial=[-0.04, 0.012, -0.003, 0.0])),   # k4 = 0: cubic branch
+    "fisheye_k4": (11, dict(camera_model="fisheye", radial=[0.05, -0.02, 0.004, -0.0015],  # k4 != 0: Newton branch
+                            require_all_sigma_points_valid=True)),
+    "fisheye_tight": (12, dict(camera_model="fisheye", radial=[-0.35, 0.0, 0.0, 0.0])),     # monotonic only up to ~0.98 rad
 }
 N, C, W, H = 400, 2, 96, 64
 
@@ -111,6 +116,25 @@ def main():
         for k, v in zip(("radii", "means2d", "depths", "conics", "compensations"), ref):
             if v is not None:
                 gold[f"{name}.ref.{k}"] = v.numpy()
+    # the per-camera angle limit of the fisheye model (every branch: linear, quadratic, Cardano, three roots, Newton)
+    from gsplat.cuda._torch_cameras import _OpenCVFisheyeCameraModel
+    from gsplat.cuda._wrapper import RollingShutterType
+
+    g = torch.Generator().manual_seed(3)
+    ks = torch.cat([
+        torch.tensor([[0, 0, 0, 0.0], [-0.04, 0.012, -0.003, 0], [0.05, -0.02, 0.004, -0.0015], [-0.35, 0, 0, 0],
+                      [0.1, 0, 0, 0], [0, -0.2, 0, 0], [0.02, 0.01, -0.05, 0], [0, 0, 0, -0.01], [-0.1, -0.1, 0, 0]]),
+        torch.randn(40, 4, generator=g) * torch.tensor([0.2, 0.1, 0.05, 0.02]),
+        torch.cat([torch.randn(20, 3, generator=g) * torch.tensor([0.2, 0.1, 0.05]), torch.zeros(20, 1)], 1)])
+    Kf = torch.tensor([[76.8, 0, 1000.0], [0, 69.1, 800.0], [0, 0, 1]]).repeat(len(ks), 1, 1)
+    cam = _OpenCVFisheyeCameraModel(focal_lengths=torch.stack([Kf[:, 0, 0], Kf[:, 1, 1]], -1), principal_points=Kf[:, :2, 2],
+                                    width=2000, height=1600, rs_type=RollingShutterType.GLOBAL, radial_coeffs=ks)
+    mine = O.fisheye_max_angle(ks, Kf[:, 0, 0], Kf[:, 1, 1], Kf[:, 0, 2], Kf[:, 1, 2], 2000, 1600)
+    fin = torch.isfinite(cam.max_angle)
+    assert bool((torch.isfinite(mine) == fin).all()) and float((mine - cam.max_angle)[fin].abs().max()) < 1e-5
+    gold["fisheye_limit.k"], gold["fisheye_limit.Ks"] = ks.numpy(), Kf.numpy()
+    gold["fisheye_limit.ref.max_angle"] = cam.max_angle.numpy()
+    print("fisheye angle limit: %d coefficient sets, oracle == reference" % len(ks))
     np.savez_compressed(args.out, **gold)
     print("wrote", args.out, os.path.getsize(args.out), "bytes")
 

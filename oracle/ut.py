@@ -5,8 +5,9 @@ Restates the behaviour of ``gsplat::projection_ut_3dgs_fused`` (reference kernel
 ``gsplat/cuda/csrc/ProjectionUT3DGSFused.cu``; the reference's own torch statement of it is
 ``gsplat/cuda/_torch_impl_ut.py:69-644`` with the camera models of ``gsplat/cuda/_torch_cameras.py``) for the camera
 models built so far: perfect pinhole (``_torch_cameras.py:696-757``), OpenCV pinhole with radial / tangential / thin-prism
-distortion (``:927-1086``) and orthographic (``:793-848``), global shutter. Fisheye, f-theta, lidar, rolling shutter and
-the windshield model are not restated yet.
+distortion (``:927-1086``), orthographic (``:793-848``) and OpenCV fisheye (``:1335-1697``: odd 9th-degree polynomial in
+the ray angle, clamped at the angle where the polynomial stops being monotonic), global shutter. F-theta, lidar, rolling
+shutter and the windshield model are not restated yet.
 
 Pinned: ``oracle/pin_ut_against_reference.py`` runs the reference's ``_fully_fused_projection_with_ut`` on the CPU — its
 parameter records (``torch.classes.gsplat.UnscentedTransformParameters``) come from this backend's
@@ -53,11 +54,78 @@ def _rotmat(quats: Tensor) -> Tensor:
         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(q.shape[:-1] + (3, 3))
 
 
+def _smallest_positive_root(a: Tensor, b: Tensor, c: Tensor) -> Tensor:
+    """Smallest positive root of 1 + a x + b x^2 + c x^3 (inf when there is none), branch by branch like the reference
+    (``_torch_cameras.py:1531-1621``): linear, quadratic, one real cubic root (Cardano), three real roots (trigonometric)."""
+    inf = torch.full_like(a, float("inf"))
+    lin = torch.where(a >= 0.0, inf, -1.0 / a)
+    dq = a * a - 4.0 * b
+    dt = torch.sqrt(dq) - a
+    quad = torch.where(dt > 0.0, 2.0 / dt, inf)
+    boc = b / c
+    t1 = (9.0 * a * boc - 2.0 * b * boc * boc - 27.0) / c
+    t2 = 3.0 * a / c - boc * boc
+    dc = t1 * t1 + 4.0 * t2 * t2 * t2
+    h = (torch.sqrt(dc) + t1) / 2.0
+    cr = torch.sign(h) * torch.abs(h) ** (1.0 / 3.0)
+    one = torch.where(cr != 0, (cr - t2 / cr - boc) / 3.0, inf)
+    one = torch.where(one > 0.0, one, inf)
+    th = torch.atan2(torch.sqrt(-dc), t1) / 3.0
+    t3 = 2.0 * torch.sqrt(-t2)
+    three = inf
+    for i in (-1, 0, 1):
+        r = (t3 * torch.cos(th + i * (2.0 * math.pi / 3.0)) - boc) / 3.0
+        three = torch.minimum(three, torch.where(r > 0.0, r, inf))
+    c0, b0 = c.abs() < 1e-10, b.abs() < 1e-10
+    out = torch.where(dc < 0.0, three, inf)
+    out = torch.where(dc >= 0.0, one, out)
+    out = torch.where(c0, torch.where(dq >= 0.0, quad, inf), out)
+    return torch.where(c0 & b0, lin, out)
+
+
+def fisheye_max_angle(k: Tensor, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor, width: int, height: int) -> Tensor:
+    """Largest ray angle the OpenCV fisheye model projects (``_torch_cameras.py:1344-1521``): where the derivative of
+    theta (1 + k1 theta^2 + k2 theta^4 + k3 theta^6 + k4 theta^8) first vanishes - a cubic in theta^2 when k4 = 0, Newton
+    from 1.57 otherwise (20 steps, |step| < 1e-6 = converged) - and never beyond the image corner. k [..., 4]."""
+    k1, k2, k3, k4 = k.unbind(-1)
+    cubic = torch.sqrt(_smallest_positive_root(3.0 * k1, 5.0 * k2, 7.0 * k3))
+    x = torch.full_like(k1, 1.57)
+    done = torch.zeros_like(k1, dtype=torch.bool)
+    for _ in range(20):
+        x2 = x * x
+        f = 1.0 + x2 * (3.0 * k1 + x2 * (5.0 * k2 + x2 * (7.0 * k3 + x2 * 9.0 * k4)))
+        df = x * (6.0 * k1 + x2 * (20.0 * k2 + x2 * (42.0 * k3 + x2 * 72.0 * k4)))
+        dx = f / df
+        x = torch.where(done, x, x - dx)
+        done = done | (dx.abs() < 1e-6)
+    newton = torch.where(done & (x > 0.0), x, torch.full_like(x, float("inf")))
+    ang = torch.where(k4.abs() < 1e-10, cubic, newton)
+    rx, ry = torch.maximum(width - cx, cx), torch.maximum(height - cy, cy)
+    rmax = torch.sqrt(rx * rx + ry * ry)
+    return torch.minimum(ang, torch.maximum(rmax / fx, rmax / fy))
+
+
 def project_points(p: Tensor, camera_model: str, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor, width: int, height: int,
                    margin: float, radial: Optional[Tensor], tangential: Optional[Tensor], thin_prism: Optional[Tensor]):
     """Camera-frame points p [..., C, M, 3] -> (pixels [..., C, M, 2], valid [..., C, M]). Per-camera parameters are
     [..., C, 1] (broadcast over M)."""
     front = p[..., 2] > 0.0
+    if camera_model == "fisheye":
+        k = radial if radial is not None else torch.zeros(fx.shape[:-1] + (4,), dtype=p.dtype)
+        amax = fisheye_max_angle(k, fx[..., 0], fy[..., 0], cx[..., 0], cy[..., 0], width, height)[..., None]
+        ax_, ay_ = p[..., 0].abs(), p[..., 1].abs()
+        big, small = torch.maximum(ax_, ay_), torch.minimum(ax_, ay_)
+        ratio = torch.where(big > 0.0, small / big, torch.zeros_like(big))
+        rxy = torch.where(big > 0.0, big * torch.sqrt(1.0 + ratio * ratio), torch.zeros_like(big))
+        rxy = torch.where(rxy <= 0.0, torch.full_like(rxy, torch.finfo(p.dtype).eps), rxy)
+        th_full = torch.atan2(rxy, p[..., 2])
+        th = torch.minimum(th_full, amax)
+        t2 = th * th
+        poly = th * (1.0 + t2 * (k[..., 0:1] + t2 * (k[..., 1:2] + t2 * (k[..., 2:3] + t2 * k[..., 3:4]))))
+        delta = poly / rxy
+        px, py = delta * p[..., 0] * fx + cx, delta * p[..., 1] * fy + cy
+        inb = (px >= -width * margin) & (px < width + width * margin) & (py >= -height * margin) & (py < height + height * margin)
+        return torch.stack([px, py], -1), front & (delta > 0.0) & (th_full < amax) & inb
     if camera_model == "ortho":
         u, v = p[..., 0], p[..., 1]
         ok = front
@@ -97,7 +165,7 @@ def fully_fused_projection_with_ut(
     """means [..., N, 3], quats [..., N, 4], scales [..., N, 3], opacities [..., N] or None, viewmats [..., C, 4, 4],
     Ks [..., C, 3, 3] -> radii int32 [..., C, N, 2], means2d [..., C, N, 2], depths [..., C, N], conics [..., C, N, 3],
     compensations [..., C, N] or None."""
-    if camera_model not in ("pinhole", "ortho"):
+    if camera_model not in ("pinhole", "ortho", "fisheye"):
         raise NotImplementedError(f"oracle.ut: camera model '{camera_model}' is not restated yet")
     dt = means.dtype
     w_m0, w_c0, w_i, spread = ut_weights(alpha, beta, kappa)

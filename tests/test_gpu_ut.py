@@ -90,3 +90,10 @@ def test_rasterization_with_ut(G):
     assert float(colors.grad.abs().sum()) > 0 and float(opac.grad.abs().sum()) > 0
     with pytest.raises(RuntimeError, match="Packed mode is not supported with UT"):
         G.rasterization(*args, packed=True, with_ut=True)
+    # fisheye: UT render vs the EWA fisheye render, and with distortion coefficients
+    f0, fa0, _ = G.rasterization(*args, packed=False, camera_model="fisheye")
+    f1, fa1, _ = G.rasterization(*args, packed=False, camera_model="fisheye", with_ut=True)
+    assert float((f1 - f0).abs().mean()) < 2e-2 and float((fa1 - fa0).abs().mean()) < 2e-2
+    f2, _, _ = G.rasterization(*args, packed=False, camera_model="fisheye", with_ut=True,
+                               radial_coeffs=torch.tensor([[-0.05, 0.01, 0.0, 0.0]], device=DEV).repeat(2, 1))
+    assert torch.isfinite(f2).all() and float((f2 - f1).abs().mean()) > 1e-4

@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = ["pinhole", "pinhole_all_valid", "pinhole_comp_clip", "pinhole_no_opacity", "opencv_full", "opencv_radial4",
-         "opencv_strong", "ortho"]
+         "opencv_strong", "ortho", "fisheye_plain", "fisheye_k", "fisheye_k4", "fisheye_tight"]
 
 
 @pytest.fixture(scope="module")
@@ -66,3 +66,20 @@ def test_ut_weights_sum_to_one():
         w0, c0, wi, spread = O.ut_weights(a, b, k)
         assert abs(w0 + 6 * wi - 1.0) < 1e-9 and spread > 0
         assert abs(c0 - w0 - (1 - a * a + b)) < 1e-12
+
+
+def test_fisheye_angle_limit_matches_reference(gold):
+    """Largest projected ray angle of the OpenCV fisheye model (the reference camera's `max_angle`,
+    _torch_cameras.py:1344-1521) for 69 coefficient sets covering every branch: the oracle's restatement AND the
+    product's (gsplat_amd._ops.fisheye_max_angle, host-side tensor code that feeds gsx_project_ut_fwd)."""
+    from gsplat_amd import _ops
+    from oracle import ut as O
+
+    k, Ks = torch.from_numpy(gold["fisheye_limit.k"]), torch.from_numpy(gold["fisheye_limit.Ks"])
+    ref = torch.from_numpy(gold["fisheye_limit.ref.max_angle"])
+    fin = torch.isfinite(ref)
+    for got in (O.fisheye_max_angle(k, Ks[:, 0, 0], Ks[:, 1, 1], Ks[:, 0, 2], Ks[:, 1, 2], 2000, 1600),
+                _ops.fisheye_max_angle(k, Ks, 2000, 1600)):
+        assert bool((torch.isfinite(got) == fin).all())
+        torch.testing.assert_close(got[fin], ref[fin], rtol=1e-5, atol=1e-6)
+    assert len(set(ref.tolist())) > 30  # the table really exercises different limits
