@@ -121,6 +121,8 @@ COMPOSITE_SCHEMAS = {
 # Ops whose schemas name the custom classes but carry no gradient (CUDA key only).
 CLASS_SCHEMAS = {
     # Unscented-Transform projection of 3DGUT (ext.cpp:1230-1239)
+    # from-world compositing of 3DGUT (ext.cpp:1241-1252); forward only so far
+    "rasterize_to_pixels_from_world_3dgs": "(Tensor means, Tensor quats, Tensor scales, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, int image_width, int image_height, int tile_size, Tensor viewmats0, Tensor? viewmats1, Tensor Ks, int camera_model, __torch__.torch.classes.gsplat.UnscentedTransformParameters ut_params, int rs_type, Tensor? rays, Tensor? radial_coeffs, Tensor? tangential_coeffs, Tensor? thin_prism_coeffs, __torch__.torch.classes.gsplat.FThetaCameraDistortionParameters ftheta_coeffs, __torch__.torch.classes.gsplat.RowOffsetStructuredSpinningLidarModelParametersExt? lidar_coeffs, __torch__.torch.classes.gsplat.BivariateWindshieldModelParameters? external_distortion_params, Tensor tile_offsets, Tensor flatten_ids, bool return_sample_counts, bool use_hit_distance, bool return_normals, int renderer_config, bool return_last_ids, bool unsafe_masked_tile_outputs=False) -> (Tensor, Tensor, Tensor?, Tensor?, Tensor?)",
     "projection_ut_3dgs_fused": "(Tensor means, Tensor quats, Tensor scales, Tensor? opacities, Tensor viewmats0, Tensor? viewmats1, Tensor Ks, int image_width, int image_height, float eps2d, float near_plane, float far_plane, float radius_clip, bool calc_compensations, int camera_model, bool global_z_order, __torch__.torch.classes.gsplat.UnscentedTransformParameters? ut_params, int rs_type, Tensor? radial_coeffs, Tensor? tangential_coeffs, Tensor? thin_prism_coeffs, __torch__.torch.classes.gsplat.FThetaCameraDistortionParameters? ftheta_coeffs, __torch__.torch.classes.gsplat.RowOffsetStructuredSpinningLidarModelParametersExt? lidar_coeffs, __torch__.torch.classes.gsplat.BivariateWindshieldModelParameters? external_distortion_params) -> (Tensor, Tensor, Tensor, Tensor, Tensor?)",
 }
 
@@ -1403,6 +1405,67 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
          float(eps2d), float(near_plane), float(far_plane), float(radius_clip), int(camera_model), alpha, beta, kappa,
          margin, int(all_valid), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(comps))
     return radii, means2d, depths, conics, comps
+
+
+def pinhole_pixel_rays(viewmats: Tensor, Ks: Tensor, width: int, height: int) -> Tensor:
+    """[..., C, H, W, 6]: world-space origin | unit direction of the ray through every pixel centre of perfect pinhole
+    cameras with a global shutter (what the reference's `_generate_rays` yields for that model,
+    gsplat/cuda/_torch_impl_eval3d.py:91-132): direction = R^T normalise(K^-1 (x + 0.5, y + 0.5, 1)), origin = -R^T t."""
+    dt, dev = viewmats.dtype, viewmats.device
+    xs = torch.arange(width, device=dev, dtype=dt) + 0.5
+    ys = torch.arange(height, device=dev, dtype=dt) + 0.5
+    fx, fy, cx, cy = (Ks[..., 0, 0, None, None], Ks[..., 1, 1, None, None], Ks[..., 0, 2, None, None],
+                      Ks[..., 1, 2, None, None])
+    dx = ((xs[None, :] - cx) / fx).expand(Ks.shape[:-2] + (height, width))
+    dy = ((ys[:, None] - cy) / fy).expand(Ks.shape[:-2] + (height, width))
+    d = torch.stack([dx, dy, torch.ones_like(dx)], dim=-1)
+    d = d / d.norm(dim=-1, keepdim=True)
+    R, t = viewmats[..., :3, :3], viewmats[..., :3, 3]
+    d_world = torch.einsum("...ji,...hwj->...hwi", R, d)
+    o_world = -torch.einsum("...ji,...j->...i", R, t)
+    return torch.cat([o_world[..., None, None, :].expand_as(d_world), d_world], dim=-1).contiguous()
+
+
+@_op("rasterize_to_pixels_from_world_3dgs")
+def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities, backgrounds, masks, image_width,
+                                        image_height, tile_size, viewmats0, viewmats1, Ks, camera_model, ut_params, rs_type,
+                                        rays, radial_coeffs, tangential_coeffs, thin_prism_coeffs, ftheta_coeffs,
+                                        lidar_coeffs, external_distortion_params, tile_offsets, flatten_ids,
+                                        return_sample_counts, use_hit_distance, return_normals, renderer_config,
+                                        return_last_ids, unsafe_masked_tile_outputs=False):
+    """gsplat::rasterize_to_pixels_from_world_3dgs, FORWARD ONLY so far: dense rows, MixedBatch renderer, rays either given
+    or generated for perfect pinhole cameras with a global shutter. Everything else is refused; so is a call whose inputs
+    require gradients (the backward kernel is not built yet - failing beats silently dropping gradients)."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (means, quats, scales, colors, opacities)):
+        raise NotImplementedError("gsplat_amd: the backward pass of the from-world (eval3d) compositing is not built yet; "
+                                  "call it under torch.no_grad()")
+    if return_sample_counts or use_hit_distance or return_normals or renderer_config != 0:
+        raise NotImplementedError("gsplat_amd: sample counts / hit distance / normals / ParallelBatch are not built yet")
+    if viewmats1 is not None or rs_type != _ROLLING_SHUTTER_GLOBAL or lidar_coeffs is not None \
+            or external_distortion_params is not None:
+        raise NotImplementedError("gsplat_amd: rolling shutter / lidar / external distortion eval3d is not built yet")
+    if rays is None:
+        if camera_model != 0 or radial_coeffs is not None or tangential_coeffs is not None or thin_prism_coeffs is not None:
+            raise NotImplementedError("gsplat_amd: eval3d generates rays for perfect pinhole cameras only; pass `rays` "
+                                      "for other camera models")
+        rays = pinhole_pixel_rays(viewmats0, Ks, int(image_width), int(image_height))
+    _check_f32(means=means, quats=quats, scales=scales, colors=colors, opacities=opacities, rays=rays)
+    batch = tuple(means.shape[:-2])
+    N, C, D = means.shape[-2], viewmats0.shape[-3], colors.shape[-1]
+    if colors.shape != batch + (C, N, D) or opacities.shape != batch + (C, N):
+        raise ValueError("eval3d takes dense rows: colors [..., C, N, D] and opacities [..., C, N]")
+    image_dims, I, th, tw, _ = _raster_dims(tile_offsets, colors)
+    if tuple(rays.shape[-3:]) != (image_height, image_width, 6) or rays.numel() != I * image_height * image_width * 6:
+        raise ValueError(f"rays must be [..., C, H, W, 6], got {tuple(rays.shape)}")
+    dev, dt = means.device, means.dtype
+    renders = torch.empty(image_dims + (image_height, image_width, D), device=dev, dtype=dt)
+    alphas = torch.empty(image_dims + (image_height, image_width, 1), device=dev, dtype=dt)
+    last_ids = torch.empty(image_dims + (image_height, image_width), device=dev, dtype=torch.int32)
+    call("gsx_raster_world_fwd", ptr(means.contiguous()), ptr(quats.contiguous()), ptr(scales.contiguous()),
+         ptr(colors.contiguous()), ptr(opacities.contiguous()), ptr(rays.contiguous()), ptr(_c(backgrounds)), ptr(_c(masks)),
+         ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), I, C, N, flatten_ids.numel(), D, int(image_width),
+         int(image_height), int(tile_size), tw, th, ptr(renders), ptr(alphas), ptr(last_ids))
+    return renders, alphas, (last_ids if return_last_ids else None), None, None
 
 
 # ----------------------------------------------------------------------------------------------

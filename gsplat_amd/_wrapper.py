@@ -88,6 +88,54 @@ def fully_fused_projection_with_ut(
         c(thin_prism_coeffs), ftheta_coeffs, lidar_coeffs, external_distortion_coeffs)
 
 
+@torch.no_grad()
+def rasterize_to_pixels_eval3d(
+    means: Tensor,  # [..., N, 3]
+    quats: Tensor,  # [..., N, 4]
+    scales: Tensor,  # [..., N, 3]
+    colors: Tensor,  # [..., C, N, channels]
+    opacities: Tensor,  # [..., C, N]
+    viewmats: Tensor,  # [..., C, 4, 4]
+    Ks: Tensor,  # [..., C, 3, 3]
+    image_width: int,
+    image_height: int,
+    tile_size: int,
+    isect_offsets: Tensor,  # [..., C, tile_height, tile_width]
+    flatten_ids: Tensor,  # [n_isects]
+    backgrounds: Optional[Tensor] = None,
+    masks: Optional[Tensor] = None,
+    camera_model: str = "pinhole",
+    ut_params=None,
+    rays: Optional[Tensor] = None,  # [..., C, H, W, 6]
+    radial_coeffs: Optional[Tensor] = None,
+    tangential_coeffs: Optional[Tensor] = None,
+    thin_prism_coeffs: Optional[Tensor] = None,
+    ftheta_coeffs=None,
+    lidar_coeffs=None,
+    external_distortion_coeffs=None,
+    rolling_shutter: int = 4,
+    viewmats_rs: Optional[Tensor] = None,
+    use_hit_distance: bool = False,
+    return_normals: bool = False,
+    renderer_config=None,
+) -> Tuple[Tensor, Tensor]:
+    """Like ``rasterize_to_pixels`` but every sample is the Gaussian's response along the pixel's ray in world space
+    (reference ``gsplat/cuda/_wrapper.py:2263-2353``). FORWARD ONLY so far (runs under no_grad): perfect pinhole cameras
+    or caller-provided ``rays``, global shutter. Returns (render_colors, render_alphas)."""
+    models = {"pinhole": 0, "ortho": 1, "fisheye": 2, "ftheta": 3, "lidar": 4}
+    c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+    cls = torch.classes.gsplat
+    out = _ops.rasterize_to_pixels_from_world_3dgs(
+        means.contiguous(), quats.contiguous(), scales.contiguous(), colors.contiguous(), opacities.contiguous(),
+        c(backgrounds), c(masks), image_width, image_height, tile_size, viewmats.contiguous(), c(viewmats_rs),
+        Ks.contiguous(), models[camera_model], ut_params if ut_params is not None else cls.UnscentedTransformParameters(),
+        int(rolling_shutter), c(rays), c(radial_coeffs), c(tangential_coeffs), c(thin_prism_coeffs),
+        ftheta_coeffs if ftheta_coeffs is not None else cls.FThetaCameraDistortionParameters(), lidar_coeffs,
+        external_distortion_coeffs, isect_offsets.contiguous(), flatten_ids.contiguous(), False, use_hit_distance,
+        return_normals, 0 if renderer_config is None else int(renderer_config), False)
+    return out[0], out[1]
+
+
 def _has(feature: str) -> bool:
     from . import csrc_shim
 

@@ -190,6 +190,24 @@ int gsx_project_ut_fwd(const float *means, const float *quats, const float *scal
                        int require_all_sigma_points_valid, int32_t *radii, float *means2d, float *depths,
                        float *conics, float *compensations, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * From-world ("eval3d") compositing of 3DGUT, FORWARD: the compositing half of gsplat::rasterize_to_pixels_from_world_3dgs
+ * (ext.cpp:1241-1252; kernels RasterizeToPixelsFromWorld3DGS*Fwd.cu; math as gsplat/cuda/_torch_impl_eval3d.py:135-495).
+ * A sample is the response of the 3D Gaussian along the pixel's ray: M = S^-1 R^T, o' = M (ray_o - mean),
+ * d' = M ray_d / |M ray_d|, alpha = min(opacity * exp(-|d' x o'|^2 / 2), 0.99), nothing when -d' . o' < 0; then the
+ * classic front-to-back rule (skip alpha < 1/255, stop before transmittance <= 1e-4).
+ * means [B,N,3], quats [B,N,4], scales [B,N,3]; colors [I,N,D], opacities [I,N] with I = B * cameras_per_batch and list rows
+ * = image * N + gaussian (flatten_ids, isect_offsets as for gsx_raster3d_fwd); rays [I,H,W,6] = world-space origin | unit
+ * direction per pixel (the caller generates them from its camera model). Outputs as gsx_raster3d_fwd, except
+ * last_ids = -1 where no sample contributed. The backward pass is not built yet.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_raster_world_fwd(const float *means, const float *quats, const float *scales, const float *colors,
+                         const float *opacities, const float *rays, const float *backgrounds, const uint8_t *masks,
+                         const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images,
+                         uint32_t cameras_per_batch, uint32_t n_gaussians, uint32_t n_isects, uint32_t cdim, uint32_t width,
+                         uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *render_colors,
+                         float *render_alphas, int32_t *last_ids, void *stream);
+
 /* assemble_proj_features_unpacked_fwd: gsplat::assemble_proj_features_unpacked_fwd (ext.cpp:1015-1020; host
  * SphericalHarmonics.cpp:572-676; kernel SphericalHarmonicsCUDA.cu:1100-1250). Dense rows only. Writes
  * out [B,C,N, Dc + E + has_depth] = [ post(SH colours of coeffs [N,K,Dc]) | extra (+0.5 when extra_post == 1) | depth ]
