@@ -88,7 +88,6 @@ def fully_fused_projection_with_ut(
         c(thin_prism_coeffs), ftheta_coeffs, lidar_coeffs, external_distortion_coeffs)
 
 
-@torch.no_grad()
 def rasterize_to_pixels_eval3d(
     means: Tensor,  # [..., N, 3]
     quats: Tensor,  # [..., N, 4]
@@ -120,8 +119,9 @@ def rasterize_to_pixels_eval3d(
     renderer_config=None,
 ) -> Tuple[Tensor, Tensor]:
     """Like ``rasterize_to_pixels`` but every sample is the Gaussian's response along the pixel's ray in world space
-    (reference ``gsplat/cuda/_wrapper.py:2263-2353``). FORWARD ONLY so far (runs under no_grad): perfect pinhole cameras
-    or caller-provided ``rays``, global shutter. Returns (render_colors, render_alphas)."""
+    (reference ``gsplat/cuda/_wrapper.py:2263-2353``). FORWARD ONLY so far - the op raises when an input requires a
+    gradient instead of dropping it: perfect pinhole cameras or caller-provided ``rays``, global shutter.
+    Returns (render_colors, render_alphas)."""
     models = {"pinhole": 0, "ortho": 1, "fisheye": 2, "ftheta": 3, "lidar": 4}
     c = lambda t: None if t is None else t.contiguous()  # noqa: E731
     cls = torch.classes.gsplat

@@ -36,8 +36,14 @@ _DEPTH_MODES = ("D", "ED", "RGB+D", "RGB+ED")
 _HIT_MODES = ("d", "Ed", "RGB-d", "RGB-Ed")
 
 
-def _resolve_tile_size(tile_size: Optional[int]) -> int:
-    return 16 if tile_size is None else int(tile_size)
+def _resolve_tile_size(tile_size: Optional[int], with_eval3d: bool = False, width: int = 0, height: int = 0) -> int:
+    """None -> the path's default: 16 for the classic path; for the from-world path 16 at 1080p and above, else 8
+    (reference gsplat/rendering.py:201-231)."""
+    if tile_size is not None:
+        return int(tile_size)
+    if with_eval3d:
+        return 16 if min(width, height) >= 1080 else 8
+    return 16
 
 
 def rasterization(
@@ -96,7 +102,7 @@ def rasterization(
     has_color = render_mode in _COLOR_MODES or render_mode.startswith("RGB")
     has_depth = render_mode in _DEPTH_MODES
     expected_depth = render_mode in ("ED", "RGB+ED")
-    tile_size = _resolve_tile_size(tile_size)
+    tile_size = _resolve_tile_size(tile_size, with_eval3d, width, height)
 
     batch_dims = tuple(means.shape[:-2])
     nb = len(batch_dims)
@@ -116,7 +122,10 @@ def rasterization(
         channel_chunk=channel_chunk, covars_triu=_covars_triu)
     # what validates but belongs to paths this backend does not build (a reference build with BUILD_3DGUT=0)
     unsupported = {
-        "with_eval3d": with_eval3d, "ftheta_coeffs": ftheta_coeffs is not None,
+        "with_eval3d with distortion (ray generation is built for perfect pinhole cameras; pass rays)":
+            with_eval3d and rays is None and (camera_model != "pinhole" or radial_coeffs is not None
+                                              or tangential_coeffs is not None or thin_prism_coeffs is not None),
+        "ftheta_coeffs": ftheta_coeffs is not None,
         "camera_model='ftheta'": camera_model == "ftheta", "camera_model='lidar'": camera_model == "lidar",
         "rolling shutter": viewmats_rs is not None, "external_distortion_coeffs": external_distortion_coeffs is not None,
     }
@@ -263,7 +272,7 @@ def rasterization(
 
     # ---- compositing (channel chunks; alphas from the first chunk) -------------------------------
     D_total = feats.shape[-1]
-    if D_total > channel_chunk:
+    if D_total > channel_chunk and not with_eval3d:  # the from-world kernel chunks channels itself
         rc, ra = [], None
         for s in range(0, D_total, channel_chunk):
             e = min(D_total, s + channel_chunk)
@@ -276,9 +285,19 @@ def rasterization(
                 ra = a_
         render_colors, render_alphas = torch.cat(rc, dim=-1), ra
     else:
-        render_colors, render_alphas = rasterize_to_pixels(
-            means2d, conics, feats, proj_opacities, width, height, tile_size, isect_offsets, flatten_ids,
-            backgrounds=backgrounds, packed=packed, absgrad=absgrad)
+        if with_eval3d:
+            # from-world compositing: every sample is the Gaussian's response along the pixel's ray (forward only so far:
+            # the op refuses inputs that require gradients)
+            from ._wrapper import rasterize_to_pixels_eval3d
+
+            render_colors, render_alphas = rasterize_to_pixels_eval3d(
+                means, quats, scales, feats.contiguous(), proj_opacities.contiguous(), viewmats, Ks, width, height,
+                tile_size, isect_offsets, flatten_ids, backgrounds=backgrounds, camera_model=camera_model,
+                ut_params=ut_params, rays=rays)
+        else:
+            render_colors, render_alphas = rasterize_to_pixels(
+                means2d, conics, feats, proj_opacities, width, height, tile_size, isect_offsets, flatten_ids,
+                backgrounds=backgrounds, packed=packed, absgrad=absgrad)
 
     # ---- post-process: split extra signals, normalise expected depth ------------------------------
     render_extra = None
@@ -375,6 +394,9 @@ def _validate_rasterization_inputs(means, covars, quats, scales, opacities, colo
     _check(tuple(viewmats.shape) == batch + (C, 4, 4), "viewmats must have shape [..., C, 4, 4], got ",
            list(viewmats.shape))
     _check(tuple(Ks.shape) == batch + (C, 3, 3), "Ks must have shape [..., C, 3, 3], got ", list(Ks.shape))
+    if with_eval3d:
+        _check(not packed, "Packed mode is not supported with Eval3D")
+        _check(not sparse_grad, "Sparse grad is not supported with Eval3D")
     if with_ut:
         _check(not packed, "Packed mode is not supported with UT")
         _check(not sparse_grad, "Sparse grad is not supported with UT")

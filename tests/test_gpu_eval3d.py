@@ -78,3 +78,20 @@ def test_eval3d_forward_larger_scene_vs_oracle(G):
             a["viewmats"], None, a["Ks"], 0, torch.classes.gsplat.UnscentedTransformParameters(), 4, None, None, None, None,
             torch.classes.gsplat.FThetaCameraDistortionParameters(), None, None, offsets, flatten_ids, False, False, False,
             0, False)
+
+
+def test_rasterization_with_eval3d_forward(G):
+    """rasterization(with_eval3d=True) under no_grad: UT or EWA projection for the tile lists, from-world compositing for the
+    image; close to the classic render (the two footprint models differ slightly), and loud when gradients are requested."""
+    sc, W, H = make_scene(N=3000, C=2, width=144, height=96, seed=8, scale_range=(0.05, 0.15))
+    a = {k: v.to(DEV) for k, v in sc.items()}
+    args = (a["means"], a["quats"], a["scales"], a["opacities"], a["colors"], a["viewmats"], a["Ks"], W, H)
+    with torch.no_grad():
+        rc0, ra0, _ = G.rasterization(*args, packed=False)
+        rc1, ra1, meta = G.rasterization(*args, packed=False, with_eval3d=True, with_ut=True, render_mode="RGB+ED")
+        rc2, ra2, _ = G.rasterization(*args, packed=False, with_eval3d=True)
+    assert meta["tile_size"] == 8 and rc1.shape == (2, H, W, 4) and torch.isfinite(rc1).all()
+    assert float((rc1[..., :3] - rc0).abs().mean()) < 4e-2 and float((ra1 - ra0).abs().mean()) < 4e-2
+    assert float((rc2 - rc0).abs().mean()) < 4e-2
+    with pytest.raises(NotImplementedError, match="backward"):
+        G.rasterization(a["means"].clone().requires_grad_(True), *args[1:], packed=False, with_eval3d=True)

@@ -91,7 +91,8 @@ def test_distributed_needs_a_process_group():
     (dict(with_ut=True), RuntimeError, "Packed mode is not supported with UT"),  # packed defaults to True
     (dict(with_ut=True, packed=False, covars=torch.rand(6, 3, 3), quats=None, scales=None), RuntimeError,
      "UT and Eval3D rasterization require quats and scales, not covars"),
-    (dict(with_eval3d=True, packed=False), RuntimeError, "3DGUT"),  # validates; this backend does not build that path
+    (dict(with_eval3d=True), RuntimeError, "Packed mode is not supported with Eval3D"),
+    (dict(with_eval3d=True, packed=False, camera_model="fisheye"), RuntimeError, "ray generation is built for perfect pinhole"),
 ])
 def test_classic_path_validation(over, exc, match):
     import gsplat_amd
