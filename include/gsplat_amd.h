@@ -208,6 +208,19 @@ int gsx_raster_world_fwd(const float *means, const float *quats, const float *sc
                          uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *render_colors,
                          float *render_alphas, int32_t *last_ids, void *stream);
 
+/* EXPERIMENTAL - written at the end of round 1, not yet validated on a GPU: backward of gsx_raster_world_fwd. Gradient
+ * rows v_rows [I * N][row_stride >= 13 + cdim], ZEROED by the caller: v_mean (3) | v_M (9, row-major, M = S^-1 R^T) |
+ * v_opacity | v_colors[cdim]; rows of the cameras of one batch are summed by the caller for v_mean / v_M, and v_quats /
+ * v_scales follow from v_M (M is a per-Gaussian function of the two). render_alphas / last_ids are the forward outputs;
+ * v_render_alphas may be NULL. */
+int gsx_raster_world_bwd(const float *means, const float *quats, const float *scales, const float *colors,
+                         const float *opacities, const float *rays, const float *backgrounds, const uint8_t *masks,
+                         const int32_t *isect_offsets, const int32_t *flatten_ids, const float *render_alphas,
+                         const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+                         uint32_t n_images, uint32_t cameras_per_batch, uint32_t n_gaussians, uint32_t n_isects,
+                         uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w,
+                         uint32_t tile_h, float *v_rows, uint32_t row_stride, void *stream);
+
 /* assemble_proj_features_unpacked_fwd: gsplat::assemble_proj_features_unpacked_fwd (ext.cpp:1015-1020; host
  * SphericalHarmonics.cpp:572-676; kernel SphericalHarmonicsCUDA.cu:1100-1250). Dense rows only. Writes
  * out [B,C,N, Dc + E + has_depth] = [ post(SH colours of coeffs [N,K,Dc]) | extra (+0.5 when extra_post == 1) | depth ]

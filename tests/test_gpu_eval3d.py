@@ -95,3 +95,24 @@ def test_rasterization_with_eval3d_forward(G):
     assert float((rc2 - rc0).abs().mean()) < 4e-2
     with pytest.raises(NotImplementedError, match="backward"):
         G.rasterization(a["means"].clone().requires_grad_(True), *args[1:], packed=False, with_eval3d=True)
+
+
+@pytest.mark.skip(reason="gsx_raster_world_bwd was written at the end of round 1 with no GPU time left to validate it; "
+                         "enable (and run with GSPLAT_AMD_EXPERIMENTAL_EVAL3D_BWD=1) once it has been checked")
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_eval3d_backward_matches_reference_gradients(G, name, monkeypatch):
+    """The experimental backward against the gradients the reference's autograd gives (tests/golden/eval3d_ref.npz)."""
+    monkeypatch.setenv("GSPLAT_AMD_EXPERIMENTAL_EVAL3D_BWD", "1")
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "eval3d_ref.npz")))
+    N, C, W, H, ts = (int(v) for v in gold[f"{name}.shape"])
+    t = lambda k: torch.from_numpy(gold[f"{name}.{k}"]).to(DEV)  # noqa: E731
+    leaves = {k: t(k).clone().requires_grad_(True) for k in ("means", "quats", "scales", "colors", "opacities")}
+    bg = t("backgrounds") if f"{name}.backgrounds" in gold else None
+    ren, alp = G.rasterize_to_pixels_eval3d(leaves["means"], leaves["quats"], leaves["scales"], leaves["colors"],
+                                            leaves["opacities"], t("viewmats"), t("Ks"), W, H, ts, t("isect_offsets"),
+                                            t("flatten_ids"), backgrounds=bg, rays=t("rays"))
+    ((ren * t("v_render")).sum() + (alp * t("v_alpha")).sum()).backward()
+    from _util import assert_grad_close
+
+    for k, leaf in leaves.items():
+        assert_grad_close(leaf.grad.cpu(), torch.from_numpy(gold[f"{name}.ref.v_{k}"]), rel=5e-3, max_bad_ratio=1e-3, name=f"v_{k}")
