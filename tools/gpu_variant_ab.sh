@@ -14,7 +14,7 @@ done
 run() { name=$1; shift; env "$@" timeout 120 python bench.py --lean --steps 30 > $OUT/bench_$name.json 2> $OUT/bench_$name.err; python - <<PY
 import json
 try:
-    r = json.load(open("$OUT/bench_$name.json")); print("$name", r["value"], "Mpix/s", r["ms_per_step"], "ms/step  bwd launch", r["roofline"]["launch_ms"], "ms")
+    r = json.load(open("$OUT/bench_$name.json")); print("$name", r["value"], "Mpix/s", r["ms_per_step"], "ms/step  raster fwd / bwd launch", r.get("raster_launch_ms", r["roofline"]["launch_ms"]), "ms")
 except Exception as e:
     print("$name FAILED", e); print(open("$OUT/bench_$name.err").read()[-1500:])
 PY
