@@ -58,6 +58,13 @@ CASES = {
     "fisheye_k4": (11, dict(camera_model="fisheye", radial=[0.05, -0.02, 0.004, -0.0015],  # k4 != 0: Newton branch
                             require_all_sigma_points_valid=True)),
     "fisheye_tight": (12, dict(camera_model="fisheye", radial=[-0.35, 0.0, 0.0, 0.0])),     # monotonic only up to ~0.98 rad
+    # f-theta (oracle only so far): pixel distance ~ 76.8 theta - 2 theta^3; both polynomial directions as the reference one
+    "ftheta_forward": (13, dict(camera_model="ftheta", ftheta=dict(
+        reference_poly=1, pixeldist_to_angle_poly=[0.0, 1 / 76.8, 0.0, 2 / 76.8 ** 4, 0.0, 0.0],
+        angle_to_pixeldist_poly=[0.0, 76.8, 0.0, -2.0, 0.0, 0.0], max_angle=1.2, linear_cde=[1.0, 0.0, 0.0]))),
+    "ftheta_inverse": (14, dict(camera_model="ftheta", require_all_sigma_points_valid=True, ftheta=dict(
+        reference_poly=0, pixeldist_to_angle_poly=[0.0, 1 / 76.8, 0.0, 2 / 76.8 ** 4, 0.0, 0.0],
+        angle_to_pixeldist_poly=[0.0, 76.8, 0.0, -2.0, 0.0, 0.0], max_angle=0.9, linear_cde=[1.002, 0.001, -0.0015]))),
 }
 N, C, W, H = 400, 2, 96, 64
 
@@ -69,7 +76,7 @@ def split(kw):
               require_all_sigma_points_valid=kw.pop("require_all_sigma_points_valid", False))
     dist = {k: kw.pop(k, None) for k in ("radial", "tangential", "thin_prism")}
     use_op = kw.pop("use_opacities", True)
-    return kw, ut, dist, use_op
+    return kw, ut, dist, use_op  # kw may still hold camera_model / ftheta / eps2d / near_plane / ...
 
 
 def main():
@@ -94,8 +101,14 @@ def main():
             sc["Ks"][:, 0, 0] *= 0.1
             sc["Ks"][:, 1, 1] *= 0.1
         op = sc["opacities"] if use_op else None
+        ft = kw.get("ftheta")
+        kw_ref = {k: v for k, v in kw.items() if k != "ftheta"}
+        if ft is not None:
+            kw_ref["ftheta_coeffs"] = torch.classes.gsplat.FThetaCameraDistortionParameters(
+                ft["reference_poly"], ft["pixeldist_to_angle_poly"], ft["angle_to_pixeldist_poly"], ft["max_angle"],
+                ft["linear_cde"])
         ref = ref_ut(sc["means"], sc["quats"], sc["scales"], op, sc["viewmats"], sc["Ks"], W, H,
-                     ut_params=torch.classes.gsplat.UnscentedTransformParameters(**ut), **cam, **kw)
+                     ut_params=torch.classes.gsplat.UnscentedTransformParameters(**ut), **cam, **kw_ref)
         got = O.fully_fused_projection_with_ut(sc["means"], sc["quats"], sc["scales"], op, sc["viewmats"], sc["Ks"], W, H,
                                                **ut, **cam, **kw)
         vis_r, vis_g = (ref[0] > 0).all(-1), (got[0] > 0).all(-1)

@@ -6,8 +6,10 @@ Restates the behaviour of ``gsplat::projection_ut_3dgs_fused`` (reference kernel
 ``gsplat/cuda/_torch_impl_ut.py:69-644`` with the camera models of ``gsplat/cuda/_torch_cameras.py``) for the camera
 models built so far: perfect pinhole (``_torch_cameras.py:696-757``), OpenCV pinhole with radial / tangential / thin-prism
 distortion (``:927-1086``), orthographic (``:793-848``) and OpenCV fisheye (``:1335-1697``: odd 9th-degree polynomial in
-the ray angle, clamped at the angle where the polynomial stops being monotonic), global shutter. F-theta, lidar, rolling
-shutter and the windshield model are not restated yet.
+the ray angle, clamped at the angle where the polynomial stops being monotonic) and f-theta (``:1786-2056``: pixel distance
+as a degree-5 polynomial of the ray angle, or the 3-step Newton inverse of the angle-of-pixel-distance polynomial; affine
+(c, d, e) sensor map; principal point shifted by half a pixel), global shutter. Lidar, rolling shutter and the windshield
+model are not restated yet. (The product kernel covers pinhole / OpenCV pinhole / ortho / fisheye; f-theta is oracle-only.)
 
 Pinned: ``oracle/pin_ut_against_reference.py`` runs the reference's ``_fully_fused_projection_with_ut`` on the CPU — its
 parameter records (``torch.classes.gsplat.UnscentedTransformParameters``) come from this backend's
@@ -105,11 +107,44 @@ def fisheye_max_angle(k: Tensor, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor,
     return torch.minimum(ang, torch.maximum(rmax / fx, rmax / fy))
 
 
+def _polyval(coeffs, x: Tensor) -> Tensor:
+    """c0 + c1 x + ... by Horner (coeffs: python floats, lowest degree first)."""
+    y = torch.full_like(x, float(coeffs[-1]))
+    for c in reversed(coeffs[:-1]):
+        y = y * x + float(c)
+    return y
+
+
 def project_points(p: Tensor, camera_model: str, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor, width: int, height: int,
-                   margin: float, radial: Optional[Tensor], tangential: Optional[Tensor], thin_prism: Optional[Tensor]):
+                   margin: float, radial: Optional[Tensor], tangential: Optional[Tensor], thin_prism: Optional[Tensor],
+                   ftheta: Optional[dict] = None):
     """Camera-frame points p [..., C, M, 3] -> (pixels [..., C, M, 2], valid [..., C, M]). Per-camera parameters are
     [..., C, 1] (broadcast over M)."""
     front = p[..., 2] > 0.0
+    if camera_model == "ftheta":
+        ax_, ay_ = p[..., 0].abs(), p[..., 1].abs()
+        big, small = torch.maximum(ax_, ay_), torch.minimum(ax_, ay_)
+        ratio = torch.where(big > 0.0, small / big, torch.zeros_like(big))
+        rxy = torch.where(big > 0.0, big * torch.sqrt(1.0 + ratio * ratio), torch.zeros_like(big))
+        rxy = torch.where(rxy <= 0.0, torch.full_like(rxy, torch.finfo(p.dtype).eps), rxy)
+        th_full = torch.atan2(rxy, p[..., 2])
+        th = th_full.clamp(max=float(ftheta["max_angle"]))
+        a2p, p2a = list(ftheta["angle_to_pixeldist_poly"]), list(ftheta["pixeldist_to_angle_poly"])
+        if int(ftheta["reference_poly"]) == 0:  # the angle-of-distance polynomial is the calibrated one: invert it
+            dist = _polyval(a2p, th)
+            slope = [k * p2a[k] for k in range(1, 6)]
+            done = torch.zeros_like(dist, dtype=torch.bool)
+            for _ in range(3):
+                step = (_polyval(p2a, dist) - th) / _polyval(slope, dist)
+                dist = torch.where(done, dist, dist - step)
+                done = done | (step.abs() < 1e-6)
+        else:
+            dist = _polyval(a2p, th)
+        ix, iy = dist * p[..., 0] / rxy, dist * p[..., 1] / rxy
+        c_, d_, e_ = (float(v) for v in ftheta["linear_cde"])
+        px, py = c_ * ix + d_ * iy + (cx + 0.5), e_ * ix + iy + (cy + 0.5)
+        inb = (px >= -width * margin) & (px < width + width * margin) & (py >= -height * margin) & (py < height + height * margin)
+        return torch.stack([px, py], -1), (th_full < float(ftheta["max_angle"])) & inb  # no "in front" test for this model
     if camera_model == "fisheye":
         k = radial if radial is not None else torch.zeros(fx.shape[:-1] + (4,), dtype=p.dtype)
         amax = fisheye_max_angle(k, fx[..., 0], fy[..., 0], cx[..., 0], cy[..., 0], width, height)[..., None]
@@ -160,12 +195,12 @@ def fully_fused_projection_with_ut(
     calc_compensations: bool = False, camera_model: str = "pinhole", alpha: float = 0.1, beta: float = 2.0,
     kappa: float = 0.0, in_image_margin_factor: float = 0.1, require_all_sigma_points_valid: bool = False,
     radial_coeffs: Optional[Tensor] = None, tangential_coeffs: Optional[Tensor] = None,
-    thin_prism_coeffs: Optional[Tensor] = None,
+    thin_prism_coeffs: Optional[Tensor] = None, ftheta: Optional[dict] = None,
 ):
     """means [..., N, 3], quats [..., N, 4], scales [..., N, 3], opacities [..., N] or None, viewmats [..., C, 4, 4],
     Ks [..., C, 3, 3] -> radii int32 [..., C, N, 2], means2d [..., C, N, 2], depths [..., C, N], conics [..., C, N, 3],
     compensations [..., C, N] or None."""
-    if camera_model not in ("pinhole", "ortho", "fisheye"):
+    if camera_model not in ("pinhole", "ortho", "fisheye", "ftheta"):
         raise NotImplementedError(f"oracle.ut: camera model '{camera_model}' is not restated yet")
     dt = means.dtype
     w_m0, w_c0, w_i, spread = ut_weights(alpha, beta, kappa)
@@ -180,7 +215,7 @@ def fully_fused_projection_with_ut(
     par = lambda t: t[..., None]  # noqa: E731  [..., C] -> [..., C, 1]
     pts, ok = project_points(cam.reshape(lead + (N * 7, 3)), camera_model, par(Ks[..., 0, 0]), par(Ks[..., 1, 1]),
                              par(Ks[..., 0, 2]), par(Ks[..., 1, 2]), width, height, in_image_margin_factor,
-                             radial_coeffs, tangential_coeffs, thin_prism_coeffs)
+                             radial_coeffs, tangential_coeffs, thin_prism_coeffs, ftheta)
     pts, ok = pts.reshape(lead + (N, 7, 2)), ok.reshape(lead + (N, 7))
 
     wm = torch.tensor([w_m0] + [w_i] * 6, dtype=dt)
