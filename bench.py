@@ -267,7 +267,8 @@ def main():
                    "gaussians_per_gpu": n_local, "cameras_per_gpu": n_cams, "packed": packed,
                    "parallelism": f"gaussian-sharded x{n_gpus}" if distributed else "single"},
         "roofline": roofline,
-        "raster_launch_ms": {"fwd": round(t_fwd, 4), "bwd": round(t_bwd, 4)},  # HIP events inside the timed region
+        "raster_launch_ms": {"fwd": round(t_fwd, 4) if t_fwd == t_fwd else None,
+                             "bwd": round(t_bwd, 4) if t_bwd == t_bwd else None},  # HIP events inside the timed region
         "stage_ms_per_step": {k.replace("gsx_", ""): round(v, 4) for k, v in sorted(per_step_ms.items())},
         "stage_roofline_hbm": stage_roofline,
     }
