@@ -7,7 +7,9 @@ on the current device/stream.
 from __future__ import annotations
 
 import ctypes
+import json
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -74,7 +76,27 @@ def _parse_header(path: str):
     return sigs
 
 
-SIGNATURES = _parse_header(_HEADER)
+_SIG_TABLE = os.path.join(_HERE, "csrc", "abi_signatures.json")  # written by write_signature_table() at build time
+
+
+def _load_signatures():
+    """The header is the source of truth in a checkout; an installed copy of the package (no ../include) reads the table
+    that build() generated from it next to the library."""
+    if os.path.exists(_HEADER):
+        return _parse_header(_HEADER)
+    if os.path.exists(_SIG_TABLE):
+        with open(_SIG_TABLE) as f:
+            return {k: (v[0], list(v[1])) for k, v in json.load(f).items()}
+    raise ImportError(f"gsplat_amd: neither {_HEADER} nor {_SIG_TABLE} found; rebuild with __graft_entry__.build()")
+
+
+def write_signature_table() -> str:
+    with open(_SIG_TABLE, "w") as f:
+        json.dump({k: [v[0], v[1]] for k, v in _parse_header(_HEADER).items()}, f)
+    return _SIG_TABLE
+
+
+SIGNATURES = _load_signatures()
 
 
 def _bind():
@@ -94,8 +116,13 @@ def exported_symbols():
     return list(SIGNATURES)
 
 
+_tls = threading.local()  # .dev = device index of the tensors marshalled for the next call (per thread: _bwd ops run on
+#                           autograd worker threads)
+
+
 def ptr(t: Optional[torch.Tensor]):
-    """Device pointer of a tensor (None -> NULL). The tensor must be contiguous and on the GPU."""
+    """Device pointer of a tensor (None -> NULL). The tensor must be contiguous and on the GPU. Remembers the tensor's
+    device so that call() launches on THAT device's current stream (the reference's DEVICE_GUARD, Common.h:40)."""
     if t is None:
         return None
     if not t.is_cuda:
@@ -104,6 +131,7 @@ def ptr(t: Optional[torch.Tensor]):
         )
     if not t.is_contiguous():
         raise GsplatAmdError("gsplat_amd: tensor must be contiguous")
+    _tls.dev = t.device.index
     return t.data_ptr()
 
 
@@ -111,6 +139,7 @@ def ptr_strided(t: torch.Tensor):
     """Device pointer of a tensor whose layout the caller has already checked (row-strided views)."""
     if not t.is_cuda:
         raise GsplatAmdError("gsplat_amd kernels only run on a ROCm device (got a CPU tensor); there is no CPU fallback")
+    _tls.dev = t.device.index
     return t.data_ptr()
 
 
@@ -151,7 +180,14 @@ def profile_end() -> dict:
 
 
 def call(name: str, *args) -> None:
-    """Invoke a gsx_* entry point on the current stream; raise on a non-zero return code."""
+    """Invoke a gsx_* entry point on the current stream of the device that owns the tensors marshalled by ptr() for it
+    (device guard: if that is not the current device it becomes current for the duration of the launch); raise on a
+    non-zero return code."""
+    dev = getattr(_tls, "dev", None)
+    if dev is not None and dev != torch.cuda.current_device():
+        _tls.dev = None
+        with torch.cuda.device(dev):
+            return call(name, *args)
     fn = getattr(_lib, name)
     if _profile is not None and (_profile_only is None or name in _profile_only):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

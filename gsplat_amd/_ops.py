@@ -121,7 +121,7 @@ COMPOSITE_SCHEMAS = {
 # Ops whose schemas name the custom classes but carry no gradient (CUDA key only).
 CLASS_SCHEMAS = {
     # Unscented-Transform projection of 3DGUT (ext.cpp:1230-1239)
-    # from-world compositing of 3DGUT (ext.cpp:1241-1252); forward only so far
+    # from-world compositing of 3DGUT (ext.cpp:1241-1252); differentiable (the body builds its own autograd graph)
     "rasterize_to_pixels_from_world_3dgs": "(Tensor means, Tensor quats, Tensor scales, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, int image_width, int image_height, int tile_size, Tensor viewmats0, Tensor? viewmats1, Tensor Ks, int camera_model, __torch__.torch.classes.gsplat.UnscentedTransformParameters ut_params, int rs_type, Tensor? rays, Tensor? radial_coeffs, Tensor? tangential_coeffs, Tensor? thin_prism_coeffs, __torch__.torch.classes.gsplat.FThetaCameraDistortionParameters ftheta_coeffs, __torch__.torch.classes.gsplat.RowOffsetStructuredSpinningLidarModelParametersExt? lidar_coeffs, __torch__.torch.classes.gsplat.BivariateWindshieldModelParameters? external_distortion_params, Tensor tile_offsets, Tensor flatten_ids, bool return_sample_counts, bool use_hit_distance, bool return_normals, int renderer_config, bool return_last_ids, bool unsafe_masked_tile_outputs=False) -> (Tensor, Tensor, Tensor?, Tensor?, Tensor?)",
     "projection_ut_3dgs_fused": "(Tensor means, Tensor quats, Tensor scales, Tensor? opacities, Tensor viewmats0, Tensor? viewmats1, Tensor Ks, int image_width, int image_height, float eps2d, float near_plane, float far_plane, float radius_clip, bool calc_compensations, int camera_model, bool global_z_order, __torch__.torch.classes.gsplat.UnscentedTransformParameters? ut_params, int rs_type, Tensor? radial_coeffs, Tensor? tangential_coeffs, Tensor? thin_prism_coeffs, __torch__.torch.classes.gsplat.FThetaCameraDistortionParameters? ftheta_coeffs, __torch__.torch.classes.gsplat.RowOffsetStructuredSpinningLidarModelParametersExt? lidar_coeffs, __torch__.torch.classes.gsplat.BivariateWindshieldModelParameters? external_distortion_params) -> (Tensor, Tensor, Tensor, Tensor, Tensor?)",
 }
@@ -1426,6 +1426,68 @@ def pinhole_pixel_rays(viewmats: Tensor, Ks: Tensor, width: int, height: int) ->
     return torch.cat([o_world[..., None, None, :].expand_as(d_world), d_world], dim=-1).contiguous()
 
 
+class _FromWorldCompositing(torch.autograd.Function):
+    """Autograd of the from-world compositing (the reference attaches it in C++: Rasterization.cpp:3266-3340 around
+    rasterize_to_pixels_from_world_3dgs_bwd, kernel RasterizeToPixelsFromWorld3DGSBwd.cu). Gradients reach means / quats /
+    scales / colors / opacities; rays, cameras and backgrounds are constants. The kernel returns per-(image, Gaussian) rows
+    [v_mean(3) | v_M(9) | v_opacity | v_colors(D)] with M = S^-1 R^T; v_quats / v_scales follow from v_M on the host side.
+    Validated against the gradients the reference's own autograd gives (tests/golden/eval3d_ref.npz)."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, colors, opacities, rays, backgrounds, masks, width, height, tile_size,
+                tile_offsets, flatten_ids):
+        batch = tuple(means.shape[:-2])
+        N, C, D = means.shape[-2], colors.shape[-3], colors.shape[-1]
+        I = math.prod(batch) * C
+        th, tw = tile_offsets.shape[-2], tile_offsets.shape[-1]
+        dev, dt = means.device, means.dtype
+        renders = torch.empty(batch + (C, height, width, D), device=dev, dtype=dt)
+        alphas = torch.empty(batch + (C, height, width, 1), device=dev, dtype=dt)
+        last_ids = torch.empty(batch + (C, height, width), device=dev, dtype=torch.int32)
+        args = [t.contiguous() for t in (means, quats, scales, colors, opacities, rays)]
+        bg, mk = _c(backgrounds), _c(masks)
+        off, fl = tile_offsets.contiguous(), flatten_ids.contiguous()
+        call("gsx_raster_world_fwd", *[ptr(t) for t in args], ptr(bg), ptr(mk), ptr(off), ptr(fl), I, C, N, fl.numel(), D,
+             int(width), int(height), int(tile_size), tw, th, ptr(renders), ptr(alphas), ptr(last_ids))
+        ctx.save_for_backward(*args, off, fl, alphas, last_ids, *([bg] if bg is not None else []),
+                              *([mk] if mk is not None else []))
+        ctx.flags = (bg is not None, mk is not None, I, C, N, D, int(width), int(height), int(tile_size), tw, th, batch)
+        ctx.mark_non_differentiable(last_ids)
+        return renders, alphas, last_ids
+
+    @staticmethod
+    def backward(ctx, v_renders, v_alphas, _v_last):
+        has_bg, has_mk, I, C, N, D, width, height, tile_size, tw, th, batch = ctx.flags
+        saved = list(ctx.saved_tensors)
+        means, quats, scales, colors, opacities, rays, off, fl, alphas, last_ids = saved[:10]
+        rest = saved[10:]
+        bg = rest.pop(0) if has_bg else None
+        mk = rest.pop(0) if has_mk else None
+        rows = torch.zeros((I * N, 13 + D), device=means.device, dtype=means.dtype)
+        v_r = (torch.zeros_like(alphas).expand(alphas.shape[:-1] + (D,)) if v_renders is None else v_renders).contiguous()
+        v_a = None if v_alphas is None else v_alphas.contiguous()
+        call("gsx_raster_world_bwd", ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities), ptr(rays), ptr(bg),
+             ptr(mk), ptr(off), ptr(fl), ptr(alphas), ptr(last_ids), ptr(v_r), ptr(v_a), I, C, N, fl.numel(), D, width,
+             height, tile_size, tw, th, ptr(rows), 13 + D)
+        B = I // C
+        per = rows.view(B, C, N, 13 + D)
+        v_means = per[..., 0:3].sum(1).reshape(means.shape)
+        v_M = per[..., 3:12].sum(1).reshape(batch + (N, 3, 3))
+        with torch.enable_grad():  # M = S^-1 R^T as a function of (quats, scales): chain v_M through it
+            q = quats.detach().requires_grad_(True)
+            sc = scales.detach().requires_grad_(True)
+            qn = torch.nn.functional.normalize(q, dim=-1)
+            w, x, y, z = qn.unbind(-1)
+            R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                             2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                             2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(q.shape[:-1] + (3, 3))
+            M = R.transpose(-1, -2) / sc[..., :, None]
+            v_quats, v_scales = torch.autograd.grad(M, (q, sc), v_M)
+        v_opac = per[..., 12].reshape(opacities.shape)
+        v_cols = per[..., 13:].reshape(colors.shape)
+        return (v_means, v_quats, v_scales, v_cols, v_opac) + (None,) * 8
+
+
 @_op("rasterize_to_pixels_from_world_3dgs")
 def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities, backgrounds, masks, image_width,
                                         image_height, tile_size, viewmats0, viewmats1, Ks, camera_model, ut_params, rs_type,
@@ -1433,12 +1495,9 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
                                         lidar_coeffs, external_distortion_params, tile_offsets, flatten_ids,
                                         return_sample_counts, use_hit_distance, return_normals, renderer_config,
                                         return_last_ids, unsafe_masked_tile_outputs=False):
-    """gsplat::rasterize_to_pixels_from_world_3dgs, FORWARD ONLY so far: dense rows, MixedBatch renderer, rays either given
-    or generated for perfect pinhole cameras with a global shutter. Everything else is refused; so is a call whose inputs
-    require gradients (the backward kernel is not built yet - failing beats silently dropping gradients)."""
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (means, quats, scales, colors, opacities)):
-        raise NotImplementedError("gsplat_amd: the backward pass of the from-world (eval3d) compositing is not built yet; "
-                                  "call it under torch.no_grad()")
+    """gsplat::rasterize_to_pixels_from_world_3dgs (forward + autograd, like the reference's C++ autograd function,
+    Rasterization.cpp:3266-3340): dense rows, MixedBatch renderer, rays either given or generated for perfect pinhole
+    cameras with a global shutter. Everything else is refused, never approximated."""
     if return_sample_counts or use_hit_distance or return_normals or renderer_config != 0:
         raise NotImplementedError("gsplat_amd: sample counts / hit distance / normals / ParallelBatch are not built yet")
     if viewmats1 is not None or rs_type != _ROLLING_SHUTTER_GLOBAL or lidar_coeffs is not None \
@@ -1448,7 +1507,8 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
         if camera_model != 0 or radial_coeffs is not None or tangential_coeffs is not None or thin_prism_coeffs is not None:
             raise NotImplementedError("gsplat_amd: eval3d generates rays for perfect pinhole cameras only; pass `rays` "
                                       "for other camera models")
-        rays = pinhole_pixel_rays(viewmats0, Ks, int(image_width), int(image_height))
+        with torch.no_grad():
+            rays = pinhole_pixel_rays(viewmats0, Ks, int(image_width), int(image_height))
     _check_f32(means=means, quats=quats, scales=scales, colors=colors, opacities=opacities, rays=rays)
     batch = tuple(means.shape[:-2])
     N, C, D = means.shape[-2], viewmats0.shape[-3], colors.shape[-1]
@@ -1457,14 +1517,9 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
     image_dims, I, th, tw, _ = _raster_dims(tile_offsets, colors)
     if tuple(rays.shape[-3:]) != (image_height, image_width, 6) or rays.numel() != I * image_height * image_width * 6:
         raise ValueError(f"rays must be [..., C, H, W, 6], got {tuple(rays.shape)}")
-    dev, dt = means.device, means.dtype
-    renders = torch.empty(image_dims + (image_height, image_width, D), device=dev, dtype=dt)
-    alphas = torch.empty(image_dims + (image_height, image_width, 1), device=dev, dtype=dt)
-    last_ids = torch.empty(image_dims + (image_height, image_width), device=dev, dtype=torch.int32)
-    call("gsx_raster_world_fwd", ptr(means.contiguous()), ptr(quats.contiguous()), ptr(scales.contiguous()),
-         ptr(colors.contiguous()), ptr(opacities.contiguous()), ptr(rays.contiguous()), ptr(_c(backgrounds)), ptr(_c(masks)),
-         ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), I, C, N, flatten_ids.numel(), D, int(image_width),
-         int(image_height), int(tile_size), tw, th, ptr(renders), ptr(alphas), ptr(last_ids))
+    renders, alphas, last_ids = _FromWorldCompositing.apply(
+        means, quats, scales, colors, opacities, rays.detach(), backgrounds, masks, int(image_width), int(image_height),
+        int(tile_size), tile_offsets, flatten_ids)
     return renders, alphas, (last_ids if return_last_ids else None), None, None
 
 
@@ -1473,6 +1528,7 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
 # ----------------------------------------------------------------------------------------------
 _CAMERA_MODEL_NAMES = {0: "pinhole", 1: "ortho", 2: "fisheye", 3: "ftheta", 4: "lidar"}  # Common.h:75-82
 _ROLLING_SHUTTER_GLOBAL = 4  # _wrapper.py RollingShutterType.GLOBAL
+_SELF_DIFFERENTIABLE = ("rasterize_to_pixels_from_world_3dgs",)
 
 
 def _empty(like: Tensor, dtype=None) -> Tensor:
@@ -1580,6 +1636,8 @@ def _register():
             except RuntimeError:
                 _lib_def.define(name + schema)
             _lib_impl.impl(name, _impls[name])
+            if name in _SELF_DIFFERENTIABLE:  # the body builds its own autograd graph (torch.autograd.Function inside)
+                _lib_impl_autograd.impl(name, _impls[name])
 
 
 _register()

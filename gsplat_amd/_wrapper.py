@@ -89,71 +89,6 @@ def fully_fused_projection_with_ut(
         c(thin_prism_coeffs), ftheta_coeffs, lidar_coeffs, external_distortion_coeffs)
 
 
-class _Eval3DExperimental(torch.autograd.Function):
-    """EXPERIMENTAL autograd of the from-world compositing (enabled with GSPLAT_AMD_EXPERIMENTAL_EVAL3D_BWD=1): the
-    backward kernel gsx_raster_world_bwd was written at the end of round 1 and has NOT been validated on a GPU yet - the
-    default path refuses gradients instead. Gradients reach means / quats / scales / colors / opacities; rays, cameras and
-    backgrounds are treated as constants."""
-
-    @staticmethod
-    def forward(ctx, means, quats, scales, colors, opacities, rays, backgrounds, masks, width, height, tile_size,
-                isect_offsets, flatten_ids):
-        from ._cabi import call, ptr
-
-        batch = tuple(means.shape[:-2])
-        N, C, D = means.shape[-2], colors.shape[-3], colors.shape[-1]
-        I = math.prod(batch) * C
-        th, tw = isect_offsets.shape[-2], isect_offsets.shape[-1]
-        dev, dt = means.device, means.dtype
-        renders = torch.empty(batch + (C, height, width, D), device=dev, dtype=dt)
-        alphas = torch.empty(batch + (C, height, width, 1), device=dev, dtype=dt)
-        last_ids = torch.empty(batch + (C, height, width), device=dev, dtype=torch.int32)
-        args = [t.contiguous() for t in (means, quats, scales, colors, opacities, rays)]
-        bg, mk = (None if backgrounds is None else backgrounds.contiguous()), (None if masks is None else masks.contiguous())
-        off, fl = isect_offsets.contiguous(), flatten_ids.contiguous()
-        call("gsx_raster_world_fwd", *[ptr(t) for t in args], ptr(bg), ptr(mk), ptr(off), ptr(fl), I, C, N, fl.numel(), D,
-             int(width), int(height), int(tile_size), tw, th, ptr(renders), ptr(alphas), ptr(last_ids))
-        ctx.save_for_backward(*args, off, fl, alphas, last_ids, *([bg] if bg is not None else []),
-                              *([mk] if mk is not None else []))
-        ctx.flags = (bg is not None, mk is not None, I, C, N, D, int(width), int(height), int(tile_size), tw, th, batch)
-        ctx.mark_non_differentiable(last_ids)
-        return renders, alphas, last_ids
-
-    @staticmethod
-    def backward(ctx, v_renders, v_alphas, _v_last):
-        from ._cabi import call, ptr
-
-        has_bg, has_mk, I, C, N, D, width, height, tile_size, tw, th, batch = ctx.flags
-        saved = list(ctx.saved_tensors)
-        means, quats, scales, colors, opacities, rays, off, fl, alphas, last_ids = saved[:10]
-        rest = saved[10:]
-        bg = rest.pop(0) if has_bg else None
-        mk = rest.pop(0) if has_mk else None
-        rows = torch.zeros((I * N, 13 + D), device=means.device, dtype=means.dtype)
-        v_r = v_renders.contiguous()
-        v_a = None if v_alphas is None else v_alphas.contiguous()
-        call("gsx_raster_world_bwd", ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities), ptr(rays), ptr(bg),
-             ptr(mk), ptr(off), ptr(fl), ptr(alphas), ptr(last_ids), ptr(v_r), ptr(v_a), I, C, N, fl.numel(), D, width,
-             height, tile_size, tw, th, ptr(rows), 13 + D)
-        B = I // C
-        per = rows.view(B, C, N, 13 + D)
-        v_means = per[..., 0:3].sum(1).reshape(means.shape)
-        v_M = per[..., 3:12].sum(1).reshape(batch + (N, 3, 3))
-        with torch.enable_grad():  # M = S^-1 R^T as a function of (quats, scales): chain v_M through it
-            q = quats.detach().requires_grad_(True)
-            sc = scales.detach().requires_grad_(True)
-            qn = torch.nn.functional.normalize(q, dim=-1)
-            w, x, y, z = qn.unbind(-1)
-            R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
-                             2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
-                             2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(q.shape[:-1] + (3, 3))
-            M = R.transpose(-1, -2) / sc[..., :, None]
-            v_quats, v_scales = torch.autograd.grad(M, (q, sc), v_M)
-        v_opac = per[..., 12].reshape(opacities.shape)
-        v_cols = per[..., 13:].reshape(colors.shape)
-        return (v_means, v_quats, v_scales, v_cols, v_opac) + (None,) * 8
-
-
 def rasterize_to_pixels_eval3d(
     means: Tensor,  # [..., N, 3]
     quats: Tensor,  # [..., N, 4]
@@ -185,24 +120,12 @@ def rasterize_to_pixels_eval3d(
     renderer_config=None,
 ) -> Tuple[Tensor, Tensor]:
     """Like ``rasterize_to_pixels`` but every sample is the Gaussian's response along the pixel's ray in world space
-    (reference ``gsplat/cuda/_wrapper.py:2263-2353``). FORWARD ONLY so far - the op raises when an input requires a
-    gradient instead of dropping it: perfect pinhole cameras or caller-provided ``rays``, global shutter.
-    Returns (render_colors, render_alphas)."""
+    (reference ``gsplat/cuda/_wrapper.py:2263-2353``): perfect pinhole cameras or caller-provided ``rays``, global
+    shutter. Differentiable w.r.t. means / quats / scales / colors / opacities (rays, cameras and backgrounds are constants,
+    like the reference's from-world backward, RasterizeToPixelsFromWorld3DGSBwd.cu). Returns (render_colors, render_alphas)."""
     models = {"pinhole": 0, "ortho": 1, "fisheye": 2, "ftheta": 3, "lidar": 4}
     c = lambda t: None if t is None else t.contiguous()  # noqa: E731
     cls = torch.classes.gsplat
-    import os
-
-    if (os.environ.get("GSPLAT_AMD_EXPERIMENTAL_EVAL3D_BWD", "") not in ("", "0") and torch.is_grad_enabled()
-            and any(t.requires_grad for t in (means, quats, scales, colors, opacities))):
-        if rays is None:
-            if camera_model != "pinhole" or radial_coeffs is not None or tangential_coeffs is not None \
-                    or thin_prism_coeffs is not None or viewmats_rs is not None:
-                raise NotImplementedError("gsplat_amd: eval3d generates rays for perfect pinhole cameras only")
-            rays = _impl.pinhole_pixel_rays(viewmats, Ks, int(image_width), int(image_height))
-        ren, alp, _ = _Eval3DExperimental.apply(means, quats, scales, colors, opacities, rays, backgrounds, masks,
-                                                image_width, image_height, tile_size, isect_offsets, flatten_ids)
-        return ren, alp
     out = _ops.rasterize_to_pixels_from_world_3dgs(
         means.contiguous(), quats.contiguous(), scales.contiguous(), colors.contiguous(), opacities.contiguous(),
         c(backgrounds), c(masks), image_width, image_height, tile_size, viewmats.contiguous(), c(viewmats_rs),

@@ -8,11 +8,8 @@
 namespace gsx {
 
 constexpr int kBatch = 256;
-// A/B candidate (default off, not measured yet): stage (B, C, colour 0, colour 1) as ONE float4 like the backward's variant T
-// (b128 + b128 + b32 per Gaussian at 3 channels instead of b128 + b64 + 3 x b32). Build: make SUFFIX=_fp EXTRA=-DGSX_FWD_PACK=1
-#ifndef GSX_FWD_PACK
-#define GSX_FWD_PACK 0
-#endif
+// Staged layout: (x, y, log2 opac, A) | (B, C, colour 0, colour 1) | colours 2.. - b128 + b128 + b32 per surviving Gaussian
+// at 3 channels instead of b128 + b64 + 3 x b32 (r05 A/B on c3: 0.304 -> 0.280 ms per launch, profiles/r05_ab.md).
 
 template <int CH>
 __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
@@ -20,14 +17,9 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4 *s_ga   = reinterpret_cast<float4 *>(smem_raw);                 // x, y, log2(opac), A   (stage_gaussian)
     float4 *s_cull = s_ga + kBatch;                                        // x, y, half extents of alpha >= 1/255
-#if GSX_FWD_PACK
     constexpr int CX = CH > 2 ? CH - 2 : 0;
     float4 *s_gbc  = s_cull + kBatch;                                      // B, C, colour 0, colour 1
     float *s_col   = reinterpret_cast<float *>(s_gbc + kBatch);            // [kBatch][CX]: colours 2..
-#else
-    float2 *s_gb   = reinterpret_cast<float2 *>(s_cull + kBatch);          // B, C
-    float *s_col   = reinterpret_cast<float *>(s_gb + kBatch);             // [kBatch][CH]
-#endif
 
     TileCtx tc;
     if (!tile_context(a, blockIdx.x, tc)) return; // uniform for the whole workgroup
@@ -87,7 +79,6 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 float2 gb;
                 stage_gaussian(xy.x, xy.y, opac, ca, cb, cc, ga, gb);
                 s_ga[s]         = ga;
-#if GSX_FWD_PACK
                 const float2 he = cull_half_extent(opac, ca, cb, cc);
                 s_cull[s]       = make_float4(xy.x, xy.y, he.x, he.y);
                 const float *c  = a.colors + (size_t)g * a.cdim + a.ch_off;
@@ -97,14 +88,6 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 s_gbc[s] = make_float4(gb.x, gb.y, cv[0], CH > 1 ? cv[CH > 1 ? 1 : 0] : 0.0f);
 #pragma unroll
                 for (int k = 2; k < CH; ++k) s_col[s * CX + k - 2] = cv[k];
-#else
-                s_gb[s]         = gb;
-                const float2 he = cull_half_extent(opac, ca, cb, cc);
-                s_cull[s]       = make_float4(xy.x, xy.y, he.x, he.y);
-                const float *c  = a.colors + (size_t)g * a.cdim + a.ch_off;
-#pragma unroll
-                for (int k = 0; k < CH; ++k) s_col[s * CH + k] = (k < (int)a.nch) ? c[k] : 0.0f;
-#endif
             }
         }
         __syncthreads();
@@ -128,12 +111,8 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 const int32_t t = j + (int32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
                 const float4 ga = s_ga[t];
-#if GSX_FWD_PACK
                 const float4 gbc = s_gbc[t];
                 const float2 gb  = make_float2(gbc.x, gbc.y);
-#else
-                const float2 gb = s_gb[t];
-#endif
                 const float dx    = ga.x - px;
                 const float dy    = ga.y - py;
                 const float q     = staged_q(ga, gb, dx, dy);
@@ -145,15 +124,10 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                     continue;
                 }
                 const float w = alpha * T;
-#if GSX_FWD_PACK
                 acc[0] += gbc.z * w;
                 if constexpr (CH > 1) acc[1] += gbc.w * w;
 #pragma unroll
                 for (int k = 2; k < CH; ++k) acc[k] += s_col[t * CX + k - 2] * w;
-#else
-#pragma unroll
-                for (int k = 0; k < CH; ++k) acc[k] += s_col[t * CH + k] * w;
-#endif
                 cur_idx = (uint32_t)(batch_start + t);
                 T       = next_T;
             }
@@ -179,11 +153,7 @@ static int launch_fwd(const Raster3DArgs &a, hipStream_t stream)
     if (n_blocks == 0) return GSX_OK;
     const uint32_t grid   = ((n_blocks + 7u) / 8u) * 8u; // xcd_remap needs a multiple of 8
     const uint32_t block  = a.tile_size <= 8 ? 64u : 256u;
-#if GSX_FWD_PACK
     const size_t smem     = kBatch * (3 * sizeof(float4) + sizeof(float) * (CH > 2 ? CH - 2 : 0));
-#else
-    const size_t smem     = kBatch * (2 * sizeof(float4) + sizeof(float2) + sizeof(float) * CH);
-#endif
     hipLaunchKernelGGL(raster3d_fwd_kernel<CH>, dim3(grid), dim3(block), smem, stream, a);
     return check_launch("raster3d_fwd");
 }

@@ -28,7 +28,10 @@ class RendererConfig(enum.IntEnum):  # ext.cpp:66-77
 
 def build_config() -> dict:
     has_2dgs = "rasterize_to_pixels_2dgs" in _ops.SCHEMAS
-    return {"3dgs": True, "2dgs": has_2dgs, "3dgut": False, "adam": "adam" in _ops.SCHEMAS,
+    # 3dgut: UT projection + from-world compositing fwd / bwd for pinhole / distorted pinhole / ortho / fisheye cameras with
+    # a global shutter; f-theta, lidar, rolling shutter, hit distances and normals are refused by the ops themselves
+    has_3dgut = _ops.COMPOSITE_UNAVAILABLE is None and "rasterize_to_pixels_from_world_3dgs" in _ops.CLASS_SCHEMAS
+    return {"3dgs": True, "2dgs": has_2dgs, "3dgut": has_3dgut, "adam": "adam" in _ops.SCHEMAS,
             "reloc": "relocation" in _ops.SCHEMAS, "losses": False, "camera_wrappers": False}
 
 

@@ -9,9 +9,10 @@ of the reference (``gsplat/rendering.py:234-690``) and the stage order of its C+
     -> tile intersection (exact ellipse test) + sort + offsets  ->  alpha compositing
     -> expected-depth normalisation.
 
-Features of the reference that belong to other paths (3DGUT: ``with_ut`` / ``with_eval3d`` / rays /
-distortion / rolling shutter / ftheta / lidar; hit-distance render modes) are rejected with the
-same kind of error the reference raises when built without them (``BUILD_3DGUT=0``).
+3DGUT: ``with_ut`` (Unscented-Transform projection through pinhole / distorted-pinhole / ortho / fisheye cameras,
+global shutter) and ``with_eval3d`` (from-world compositing) are built; what is NOT built is refused up front, before
+any kernel launches, never approximated: f-theta / lidar cameras, rolling shutter, external (windshield) distortion,
+ray generation for distorted cameras (pass ``rays``), the hit-distance render modes and ``return_normals``.
 """
 from __future__ import annotations
 
@@ -125,6 +126,8 @@ def rasterization(
         "with_eval3d with distortion (ray generation is built for perfect pinhole cameras; pass rays)":
             with_eval3d and rays is None and (camera_model != "pinhole" or radial_coeffs is not None
                                               or tangential_coeffs is not None or thin_prism_coeffs is not None),
+        "hit-distance render modes ('d', 'Ed', 'RGB-d', 'RGB-Ed')": render_mode in _HIT_MODES,
+        "return_normals": bool(return_normals),
         "ftheta_coeffs": ftheta_coeffs is not None,
         "camera_model='ftheta'": camera_model == "ftheta", "camera_model='lidar'": camera_model == "lidar",
         "rolling shutter": viewmats_rs is not None, "external_distortion_coeffs": external_distortion_coeffs is not None,

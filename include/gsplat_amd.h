@@ -208,8 +208,8 @@ int gsx_raster_world_fwd(const float *means, const float *quats, const float *sc
                          uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *render_colors,
                          float *render_alphas, int32_t *last_ids, void *stream);
 
-/* EXPERIMENTAL - written at the end of round 1, not yet validated on a GPU: backward of gsx_raster_world_fwd. Gradient
- * rows v_rows [I * N][row_stride >= 13 + cdim], ZEROED by the caller: v_mean (3) | v_M (9, row-major, M = S^-1 R^T) |
+/* Backward of gsx_raster_world_fwd (reference host fn rasterize_to_pixels_from_world_3dgs_bwd, Rasterization.cpp:2920;
+ * kernel RasterizeToPixelsFromWorld3DGSBwd.cu). Gradient rows v_rows [I * N][row_stride >= 13 + cdim], ZEROED by the caller: v_mean (3) | v_M (9, row-major, M = S^-1 R^T) |
  * v_opacity | v_colors[cdim]; rows of the cameras of one batch are summed by the caller for v_mean / v_M, and v_quats /
  * v_scales follow from v_M (M is a per-Gaussian function of the two). render_alphas / last_ids are the forward outputs;
  * v_render_alphas may be NULL. */

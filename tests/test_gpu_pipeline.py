@@ -113,10 +113,21 @@ def test_rasterization_rejects_out_of_scope_arguments(G):
     sc, W, H = make_scene(N=100, C=1, width=32, height=32, seed=9)
     a = {k: v.to(DEV) for k, v in sc.items()}
     args = (a["means"], a["quats"], a["scales"], a["opacities"], a["colors"], a["viewmats"], a["Ks"], W, H)
-    with pytest.raises(RuntimeError):
-        G.rasterization(*args, with_ut=True)
-    with pytest.raises(RuntimeError):
-        G.rasterization(*args, with_eval3d=True)
+    # built 3DGUT pieces render (dense rows) ...
+    for kw in (dict(with_ut=True), dict(with_eval3d=True)):
+        rc, ra, _ = G.rasterization(*args, packed=False, **kw)
+        assert rc.shape == (1, H, W, 3) and bool(torch.isfinite(rc).all())
+    # ... and are refused with packed rows like the reference (Rendering.cpp: "Packed mode is not supported with ...")
+    with pytest.raises(RuntimeError, match="Packed mode is not supported with UT"):
+        G.rasterization(*args, with_ut=True, packed=True)
+    with pytest.raises(RuntimeError, match="Packed mode is not supported with Eval3D"):
+        G.rasterization(*args, with_eval3d=True, packed=True)
+    # not built: refused before any kernel launches, never a result with the wrong channel count
+    for kw in (dict(render_mode="RGB-Ed"), dict(render_mode="d"), dict(return_normals=True)):
+        with pytest.raises(RuntimeError, match="not supported"):
+            G.rasterization(*args, with_eval3d=True, packed=False, **kw)
+    with pytest.raises(RuntimeError, match="not supported"):
+        G.rasterization(*args, with_eval3d=True, packed=False, camera_model="fisheye")
     with pytest.raises(RuntimeError, match="hit-distance render modes require with_eval3d=True"):
         G.rasterization(*args, render_mode="RGB-Ed")
     with pytest.raises(RuntimeError, match="ftheta camera is only supported via UT"):
@@ -177,6 +188,35 @@ def test_full_size_properties_1m_1080p(G):
     r, a, _ = G.rasterization(*common, f, sc["viewmats"], sc["Ks"], W, H, packed=True)
     r.sum().backward()
     assert abs(f.grad.double().sum() - a.double().sum()) <= 1e-3 * a.double().sum()
+
+
+def test_c3_matches_oracle(G):
+    """BASELINE.json configs[2] (c3), the headline config bench.py times: 1 M Gaussians, 1080p, SH degree 3, 16 x 16 tiles,
+    against the CPU oracle pipeline (one step of the OpenMP C oracle takes ~2-20 s depending on the host's cores).
+    Images at the reference's CUDA-vs-torch tolerances (tests/test_basic.py:427-504), all five leaf gradients relative to
+    the tensor's scale, and the intersection count within 1e-5 (a radius / ellipse exactly on a tile edge may differ between
+    the two fp32 evaluation orders of the projection; the integer stage itself is bit-exact: test_isect_exact_dense)."""
+    import os
+
+    from oracle import oracle as O
+    from oracle.pipeline import rasterization_cpu
+
+    O.set_threads(min(os.cpu_count() or 1, 32))
+    sc, W, H = _bench_scene(1_000_000, "cpu")
+    g = torch.Generator().manual_seed(3)
+    v_rc, v_ra = torch.randn(1, H, W, 3, generator=g), torch.randn(1, H, W, 1, generator=g)
+    ref = rasterization_cpu(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], sc["viewmats"],
+                            sc["Ks"], W, H, sh_degree=3, render_mode="RGB", v_render_colors=v_rc, v_render_alphas=v_ra)
+    assert ref["n_isects"] > 3_000_000 and ref["n_visible"] > 800_000
+    for packed in (False, True):
+        rc, ra, meta, leaves = _run(G, sc, W, H, v_rc, v_ra, sh_degree=3, packed=packed)
+        M = meta["isect_ids"].numel()
+        assert abs(M - ref["n_isects"]) <= 1e-5 * ref["n_isects"], (M, ref["n_isects"])
+        assert_close_ratio(rc.detach().cpu(), ref["render_colors"], 1e-3, 1e-4, max_bad_ratio=1e-3, name="c3 colors")
+        assert_close_ratio(ra.detach().cpu(), ref["render_alphas"], 1e-4, 5e-5, max_bad_ratio=1e-3, name="c3 alphas")
+        for k in NAMES:
+            assert_grad_close(leaves[k].grad.cpu(), ref["grads"][k], rel=5e-3, max_bad_ratio=1e-3,
+                              name=f"c3 v_{k} packed={packed}")
 
 
 def test_c2_garden_scene_1080p_matches_oracle(G):

@@ -24,7 +24,7 @@ def test_feature_probes_follow_build_config():
     cfg = gsplat_amd.build_config()
     assert set(cfg) == {"3dgs", "2dgs", "3dgut", "adam", "reloc", "losses", "camera_wrappers"}  # ext.cpp:83-97
     assert gsplat_amd.has_3dgs() and gsplat_amd.has_2dgs() and gsplat_amd.has_adam() and gsplat_amd.has_reloc()
-    assert not gsplat_amd.has_3dgut() and not gsplat_amd.has_losses() and not gsplat_amd.has_camera_wrappers()
+    assert gsplat_amd.has_3dgut() and not gsplat_amd.has_losses() and not gsplat_amd.has_camera_wrappers()
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
