@@ -162,6 +162,40 @@ __device__ __forceinline__ float staged_alpha_raw(const float4 &ga, float q)
     return __builtin_amdgcn_exp2f(ga.z - q);
 }
 
+// ---- staged form, tile-centre polynomial ("e-form"; raster3d_fwd.hip and variant T of raster3d_bwd.hip) -------------------
+// With a = mean - c (c = centre of the tile) and a lane's pixel at u = pixel - c (|u|, |v| <= 7.5, exact in fp32):
+//   q(u, v) = A (a.x - u)^2 + B (a.x - u)(a.y - v) + C (a.y - v)^2
+//           = q0 - u gu - v gv + A u^2 + B u v + C v^2,   q0 = q(0, 0),  gu = 2 A a.x + B a.y,  gv = B a.x + 2 C a.y
+// so the exponent of alpha = exp2(lo - q) is
+//   e(u, v) = e0 + u (gu + nA u + nB v) + v (gv + nC v),   e0 = lo - q0,  (nA, nB, nC) = -(A, B, C)
+// i.e. FIVE fmas per (pixel, Gaussian) instead of 2 subtractions + 5 for q + 1 for lo - q; e0 / gu / gv are formed once
+// per (tile, Gaussian) by the staging thread. sigma < 0  <=>  q < 0  <=>  e > lo. Conditioning: the terms that cancel are
+// bounded by |u| (|gu| + ...) with |u| <= 7.5 and, for the Gaussians that can pass the alpha test at all, |a| <= 7.5 +
+// extent: a few hundred at most for the tightest footprint (eps2d = 0.3) -> ~2e-5 absolute on e, ~1.5e-5 relative on alpha
+// (the tolerance of the parity tests is 1e-4 .. 1e-3; variant T's moments about the tile centre are conditioned alike).
+typedef float v4f __attribute__((ext_vector_type(4))); // true vector types: one ds_read_b128 / b64 per load (a HIP float4 is
+typedef float v2f __attribute__((ext_vector_type(2))); // a struct of scalars that the backend re-merges as it sees fit)
+struct StagedRow { // one staged Gaussian in LDS: 48 bytes, read as b128 + b128 + b64 from ONE address register
+    v4f p0;        // e0, gu, gv, lo
+    v4f p1;        // nA, nB, nC, colour 2
+    v4f p2;        // colour 0, colour 1, colour 3, -
+};
+__device__ __forceinline__ void stage_gaussian_e(float ax, float ay, float opac, float ca, float cb, float cc, v4f &p0,
+                                                 float &nA, float &nB, float &nC)
+{
+    const float lo = opac > 0.0f ? __log2f(opac) : -INFINITY; // opac <= 0 (or NaN) can never pass the alpha test
+    const float A = 0.5f * kLog2e * ca, B = kLog2e * cb, C = 0.5f * kLog2e * cc;
+    const float q0 = fmaf(ax, fmaf(A, ax, B * ay), C * ay * ay);
+    p0 = v4f{lo - q0, fmaf(2.0f * A, ax, B * ay), fmaf(B, ax, 2.0f * C * ay), lo};
+    nA = -A; nB = -B; nC = -C;
+}
+__device__ __forceinline__ float staged_e(const v4f &p0, float nA, float nB, float nC, float u, float v)
+{
+    const float t1 = fmaf(nB, v, fmaf(nA, u, p0.y));
+    const float t2 = fmaf(nC, v, p0.z);
+    return fmaf(v, t2, fmaf(u, t1, p0.x));
+}
+
 // ---- wave-level culling -------------------------------------------------------------------------
 // A Gaussian can only pass the reference's `alpha >= 1/255` test (Device.cuh:52-55) at offsets d with
 // sigma(d) = 1/2 d^T Q d <= L = ln(255 * opacity). The staging thread of each Gaussian computes the

@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
 // The defaults keep a workgroup at 30.4 KiB of LDS and <= 102 VGPRs, i.e. 5 workgroups per CU: occupancy and batch length
 // pull in opposite directions (BATCH 128 / 144 / 160 -> 533 / 526 / 572 us: 160 drops to 4 workgroups per CU).
 #ifndef GSX_BWD_T_BATCH
-#define GSX_BWD_T_BATCH 144
+#define GSX_BWD_T_BATCH 128
 #endif
 #ifndef GSX_BWD_T_WROW // 176 / 20: conflict-free b128 reads; 132 / 16: 2-way conflicts but 5.6 KiB less LDS per workgroup
 #define GSX_BWD_T_WROW 132
@@ -301,9 +301,8 @@ struct BwdTCfg {
     static constexpr int SLOTS = 8;                // Gaussians per turn
     static constexpr int WROW  = GSX_BWD_T_WROW;   // floats per slot: 8 pixel rows x WGRP
     static constexpr int WGRP  = GSX_BWD_T_WGRP;   // floats per row of 8 pixels: 8 x (fac, w) + 4 (bank spread)
-    static constexpr int CX    = CH > 2 ? CH - 2 : 0; // colour channels that do not fit next to (B, C) in the second float4
     static constexpr size_t stage_bytes =
-        (size_t)BATCH * (3 * sizeof(float4) + sizeof(int32_t) * 2 + sizeof(float) * (CX + KP));
+        (size_t)BATCH * (sizeof(StagedRow) + sizeof(float4) + sizeof(int32_t) * 2 + sizeof(float) * KP);
     static constexpr size_t smem = stage_bytes + sizeof(float) * (4 * SLOTS * WROW);
 };
 
@@ -319,16 +318,14 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
     constexpr int WROW  = Cfg::WROW;
     constexpr int WGRP  = Cfg::WGRP;
     static_assert(CH <= 4, "cotangent rows are staged as float4");
+    static_assert(BATCH <= 255, "staged indices are packed one byte per slot");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float4 *s_ga     = reinterpret_cast<float4 *>(smem_raw);
-    constexpr int CX = Cfg::CX;
-    float4 *s_gbc    = s_ga + BATCH;
-    float4 *s_cull   = s_gbc + BATCH;
+    StagedRow *s_st  = reinterpret_cast<StagedRow *>(smem_raw);    // tile-centre polynomial of the exponent + colours (raster3d.hpp)
+    float4 *s_cull   = reinterpret_cast<float4 *>(s_st + BATCH);   // mean - tile centre, half extents of alpha >= 1/255
     int32_t *s_id    = reinterpret_cast<int32_t *>(s_cull + BATCH);
     int32_t *s_touch = s_id + BATCH;
-    float *s_col     = reinterpret_cast<float *>(s_touch + BATCH); // [BATCH][CX]
-    float *s_acc     = s_col + BATCH * CX;                         // [BATCH][KP]: colours | S0 Su Sv Suu Suv Svv
+    float *s_acc     = reinterpret_cast<float *>(s_touch + BATCH); // [BATCH][KP]: colours | S0 Su Sv Suu Suv Svv
     float *s_w       = s_acc + BATCH * KP;                         // [4 waves][SLOTS][WROW]
 
     TileCtx tc;
@@ -345,10 +342,10 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
     tile_pixel(tid, 16u, lx, ly);
     const int64_t prow = pixel_row(a, tc, blockIdx.x, lx, ly);
     const bool inside  = prow >= 0;
-    const float tile_px0 = (float)(tc.tile_x * 16u) + 0.5f, tile_py0 = (float)(tc.tile_y * 16u) + 0.5f;
-    const float px     = tile_px0 + (float)lx;
-    const float py     = tile_py0 + (float)ly;
-    const size_t pix   = inside ? (size_t)prow : 0;
+    // tile centre in pixel coordinates; this lane's pixel centre relative to it (multiples of 0.5 in [-7.5, 7.5]: exact)
+    const float tile_cx = (float)(tc.tile_x * 16u) + 8.0f, tile_cy = (float)(tc.tile_y * 16u) + 8.0f;
+    const float pu      = (float)lx - 7.5f, pv = (float)ly - 7.5f;
+    const size_t pix    = inside ? (size_t)prow : 0;
 
     const int32_t range_start = tc.range_start, range_end = tc.range_end;
     const int32_t n_batches   = (range_end - range_start + BATCH - 1) / BATCH;
@@ -373,7 +370,7 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
     }
     const float va_minus_bg      = v_a - bg_dot;
     const int32_t wave_bin_final = wave_max_i32(bin_final);
-    const WaveRect rect          = wave_pixel_rect(inside, px, py);
+    const WaveRect rect          = wave_pixel_rect(inside, pu, pv); // tile-centre coordinates, like s_cull
 
     // roles in a turn: this lane owns slot bg and quadrant row bv (pixels 8 bv .. 8 bv + 7 of the wave, u = 0..7)
     const int bg = (int)(lane & 7u), bv = (int)(lane >> 3);
@@ -405,9 +402,10 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
         s_touch[s] = 0;
     }
 
-    const float u0 = (float)((wave & 1u) << 3), v0 = (float)((wave >> 1) << 3); // quadrant origin inside the tile
+    // quadrant origin in tile-CENTRE coordinates: the moments are taken about the tile centre (same for the four waves)
+    const float u0 = (float)((wave & 1u) << 3) - 7.5f, v0 = (float)((wave >> 1) << 3) - 7.5f;
     int slot   = 0; // wave-uniform: slots filled since the last turn
-    int slot_t = 0; // lane s < SLOTS: staged index of the Gaussian in slot s
+    uint32_t slot_lo = 0, slot_hi = 0; // wave-uniform: byte s & 3 of word s >> 2 = staged index (< BATCH <= 255) of the Gaussian in slot s
 
     // one turn: sums of the filled slots -> s_acc (all lanes of the wave take part)
     auto turn = [&](int n_slots) {
@@ -448,7 +446,8 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] += dpp_f32<0x128>(acc[k]); // row_ror:8
         const int frow = (int)(lane >> 4), fcol = (int)(lane & 15u);
-        const int t_g  = __shfl(slot_t, fcol & 7);
+        const uint32_t st_w = (fcol & 4) ? slot_hi : slot_lo; // slots 0..3 in one word, 4..7 in the other
+        const int t_g  = (int)((st_w >> (8 * (fcol & 3))) & 0xFFu);
         const bool wr_lane = fcol < SLOTS && fcol < n_slots;
 #pragma unroll
         for (int j = 0; j < Cfg::KG; ++j) {
@@ -472,24 +471,25 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
                 const float opac = a.opacities[g];
                 const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
                 s_id[s]        = g;
-                float4 ga;
-                float2 gb;
-                stage_gaussian(xy.x, xy.y, opac, ca, cb, cc, ga, gb);
-                s_ga[s]        = ga;
+                const float ax = xy.x - tile_cx, ay = xy.y - tile_cy;
+                v4f p0;
+                float nA, nB, nC;
+                stage_gaussian_e(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
                 const float2 he = cull_half_extent(opac, ca, cb, cc);
-                s_cull[s]      = make_float4(xy.x, xy.y, he.x, he.y);
+                s_cull[s]      = make_float4(ax, ay, he.x, he.y);
                 const float *c = a.colors + (size_t)g * a.cdim + a.ch_off;
-                float cv[CH];
+                float cv[4];
 #pragma unroll
-                for (int k = 0; k < CH; ++k) cv[k] = (k < (int)a.nch) ? c[k] : 0.0f;
-                s_gbc[s] = make_float4(gb.x, gb.y, cv[0], CH > 1 ? cv[CH > 1 ? 1 : 0] : 0.0f); // (B, C, colour 0, colour 1)
-#pragma unroll
-                for (int k = 2; k < CH; ++k) s_col[s * CX + k - 2] = cv[k];
+                for (int k = 0; k < 4; ++k) cv[k] = (k < CH && k < (int)a.nch) ? c[k] : 0.0f;
+                s_st[s].p0 = p0;
+                s_st[s].p1 = v4f{nA, nB, nC, cv[2]};
+                s_st[s].p2 = v4f{cv[0], cv[1], cv[3], 0.0f};
             }
         }
         __syncthreads();
 
         const int32_t t_first = __builtin_amdgcn_readfirstlane(max(0, batch_end - wave_bin_final)); // keeps j, t and the LDS addresses in SGPRs
+        const int32_t behind_s = __builtin_amdgcn_readfirstlane(batch_end); // list index of staged slot t = behind_s - t
         for (int32_t j = (t_first & ~63); j < batch_size; j += 64) {
           const int32_t tl = j + (int32_t)lane;
           bool hit         = false;
@@ -501,24 +501,28 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
           while (todo) {
             const int32_t t = j + (int32_t)__builtin_ctzll(todo);
             todo &= todo - 1;
-            const float4 ga = s_ga[t];
-            const float4 gbc = s_gbc[t];
-            const float2 gb  = make_float2(gbc.x, gbc.y);
-            float col[CH];
-            col[0] = gbc.z;
-            if constexpr (CH > 1) col[1] = gbc.w;
-#pragma unroll
-            for (int k = 2; k < CH; ++k) col[k] = s_col[t * CX + k - 2];
-            const float dx = ga.x - px;
-            const float dy = ga.y - py;
-            const float q  = staged_q(ga, gb, dx, dy);
-            const float ov_r = staged_alpha_raw(ga, q);
-            const bool valid = (batch_end - t <= bin_final) && !(q < 0.0f) && !(fminf(kMaxAlpha, ov_r) < kAlphaThreshold);
+            const v4f p0 = s_st[t].p0;
+            const v4f p1 = s_st[t].p1;
+            const float e     = staged_e(p0, p1.x, p1.y, p1.z, pu, pv);
+            const float ov_r  = __builtin_amdgcn_exp2f(e); // opac * exp(-sigma), unclamped
+            const float al_r  = fminf(kMaxAlpha, ov_r);
+            // lanes outside the image have bin_final = -1 and can never be valid; e > lo <=> sigma < 0
+            const bool valid = (bin_final >= behind_s - t) && !(e > p0.w) && !(al_r < kAlphaThreshold);
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform
 
+            float col[CH];
+            if constexpr (CH <= 3) {
+                const v2f c01 = *reinterpret_cast<const v2f *>(&s_st[t].p2);
+                col[0] = c01.x;
+                if constexpr (CH > 1) col[1] = c01.y;
+                if constexpr (CH > 2) col[2] = p1.w;
+            } else {
+                const v4f p2 = s_st[t].p2;
+                col[0] = p2.x; col[1] = p2.y; col[2] = p1.w; col[3] = p2.z;
+            }
             // invalid lanes: alpha = 0 -> fac = 0, w = 0, T and buffer unchanged (1 / (1 - 0) == 1 exactly)
             const float ov    = valid ? ov_r : 0.0f;
-            const float alpha = fminf(kMaxAlpha, ov);
+            const float alpha = valid ? al_r : 0.0f;
             const float ra    = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
             T                *= ra;
             const float fac   = alpha * T;
@@ -532,16 +536,22 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
             v_alpha += T_final * ra * va_minus_bg;
             const float v_sigma = (ov <= kMaxAlpha) ? -ov * v_alpha : 0.0f; // alpha-clamp branch: no geometry gradient
             *reinterpret_cast<float2 *>(s_ww + slot * WROW + w_off) = make_float2(fac, v_sigma); // ds_write_b64
-            slot_t = ((int)lane == slot) ? t : slot_t;
+{ // scalar ALU only: which Gaussian sits in that slot
+                const uint32_t sh = (uint32_t)t << (8 * (slot & 3));
+                slot_lo |= (slot & 4) ? 0u : sh;
+                slot_hi |= (slot & 4) ? sh : 0u;
+            }
             if (++slot == SLOTS) {
                 turn(SLOTS);
-                slot = 0;
+                slot    = 0;
+                slot_lo = slot_hi = 0;
             }
           }
         }
         if (slot) { // the accumulator rows of this batch are flushed below: finish the open turn first
             turn(slot);
-            slot = 0;
+            slot    = 0;
+            slot_lo = slot_hi = 0;
         }
         __syncthreads();
 
@@ -553,16 +563,15 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
             const int s = e / NCOL, c = e - s * NCOL;
             if (!s_touch[s]) continue;
             const float *row = s_acc + s * KP;
-            const float4 ga  = s_ga[s];
-            const float ax = ga.x - tile_px0, ay = ga.y - tile_py0;
+            const float4 cu  = s_cull[s];
+            const float ax = cu.x, ay = cu.y; // mean - tile centre: the moments are about the tile centre too
             const float S0 = row[CH], Su = row[CH + 1], Sv = row[CH + 2];
             float val;
             int col = c;
             if (c < 2) {
-                const float4 g4 = s_gbc[s];
-                const float2 gb = make_float2(g4.x, g4.y);
+                const v4f p1 = s_st[s].p1; // (-A, -B, -C) of the staged form: Q = (2A, B; B, 2C) / log2(e)
                 const float sx = fmaf(ax, S0, -Su), sy = fmaf(ay, S0, -Sv);
-                val = kInvLog2e * ((c == 0) ? (2.0f * ga.w * sx + gb.x * sy) : (gb.x * sx + 2.0f * gb.y * sy));
+                val = -kInvLog2e * ((c == 0) ? (2.0f * p1.x * sx + p1.y * sy) : (p1.y * sx + 2.0f * p1.z * sy));
             } else if (c == 2) {
                 val = 0.5f * (ax * (ax * S0 - 2.0f * Su) + row[CH + 3]);
             } else if (c == 3) {
@@ -570,7 +579,7 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
             } else if (c == 4) {
                 val = 0.5f * (ay * (ay * S0 - 2.0f * Sv) + row[CH + 5]);
             } else if (c == 5) {
-                val = -S0 * __builtin_amdgcn_exp2f(-ga.z);
+                val = -S0 * __builtin_amdgcn_exp2f(-s_st[s].p0.w);
             } else {
                 const int k = c - 6;
                 if (k >= (int)a.nch) continue;

@@ -8,18 +8,18 @@
 namespace gsx {
 
 constexpr int kBatch = 256;
-// Staged layout: (x, y, log2 opac, A) | (B, C, colour 0, colour 1) | colours 2.. - b128 + b128 + b32 per surviving Gaussian
-// at 3 channels instead of b128 + b64 + 3 x b32 (r05 A/B on c3: 0.304 -> 0.280 ms per launch, profiles/r05_ab.md).
+// Staged layout: one 48-byte row per Gaussian (raster3d.hpp StagedRow: the tile-centre polynomial of the exponent + up to
+// four colours) read with b128 + b128 + b64 from one address register; colours 4.. in a separate table.
+// r05 A/B on c3 (profiles/r05_ab.md): float4 + float2 + 3 floats 0.304 ms -> packed float4s 0.280 -> e-form see there.
 
 template <int CH>
 __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float4 *s_ga   = reinterpret_cast<float4 *>(smem_raw);                 // x, y, log2(opac), A   (stage_gaussian)
-    float4 *s_cull = s_ga + kBatch;                                        // x, y, half extents of alpha >= 1/255
-    constexpr int CX = CH > 2 ? CH - 2 : 0;
-    float4 *s_gbc  = s_cull + kBatch;                                      // B, C, colour 0, colour 1
-    float *s_col   = reinterpret_cast<float *>(s_gbc + kBatch);            // [kBatch][CX]: colours 2..
+    constexpr int CX = CH > 4 ? CH - 4 : 0;
+    StagedRow *s_st = reinterpret_cast<StagedRow *>(smem_raw);              // [kBatch]
+    float4 *s_cull  = reinterpret_cast<float4 *>(s_st + kBatch);            // mean - tile centre, half extents of alpha >= 1/255
+    float *s_col    = reinterpret_cast<float *>(s_cull + kBatch);           // [kBatch][CX]: colours 4..
 
     TileCtx tc;
     if (!tile_context(a, blockIdx.x, tc)) return; // uniform for the whole workgroup
@@ -31,9 +31,11 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
     tile_pixel(tid, a.tile_size, lx, ly);
     const int64_t prow = pixel_row(a, tc, blockIdx.x, lx, ly); // output row, -1 = this lane renders nothing
     const bool inside  = prow >= 0;
-    const float px     = (float)(tc.tile_x * a.tile_size + lx) + 0.5f;
-    const float py     = (float)(tc.tile_y * a.tile_size + ly) + 0.5f;
-    const size_t pix   = inside ? (size_t)prow : 0;
+    // tile centre in pixel coordinates, and this lane's pixel centre relative to it (multiples of 0.5: exact)
+    const float half = 0.5f * (float)a.tile_size;
+    const float cx   = (float)(tc.tile_x * a.tile_size) + half, cy = (float)(tc.tile_y * a.tile_size) + half;
+    const float u    = (float)lx + 0.5f - half, v = (float)ly + 0.5f - half;
+    const size_t pix = inside ? (size_t)prow : 0;
 
     const float *bg = a.backgrounds ? a.backgrounds + (size_t)image_id * a.cdim + a.ch_off : nullptr;
 
@@ -59,13 +61,13 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
     float acc[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) acc[k] = 0.0f;
-    bool done = !inside;
+    float thr = inside ? kAlphaThreshold : INFINITY; // alpha threshold of this pixel; +inf = done (or not rendered)
     const uint32_t lane = tid & 63u;
-    const WaveRect rect = wave_pixel_rect(inside, px, py);
+    const WaveRect rect = wave_pixel_rect(inside, u, v); // in tile-centre coordinates, like s_cull
 
     for (int32_t b = 0; b < n_batches; ++b) {
         // block-wide early out: every pixel of the tile finished. Also fences LDS reuse.
-        if (__syncthreads_count(done) == (int)blockDim.x) break;
+        if (__syncthreads_count(!(thr < INFINITY)) == (int)blockDim.x) break;
 
         const int32_t batch_start = range_start + kBatch * b;
         for (int s = (int)tid; s < kBatch; s += (int)blockDim.x) {
@@ -75,19 +77,21 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 const float2 xy  = reinterpret_cast<const float2 *>(a.means2d)[g];
                 const float opac = a.opacities[g];
                 const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
-                float4 ga;
-                float2 gb;
-                stage_gaussian(xy.x, xy.y, opac, ca, cb, cc, ga, gb);
-                s_ga[s]         = ga;
+                const float ax = xy.x - cx, ay = xy.y - cy;
+                v4f p0;
+                float nA, nB, nC;
+                stage_gaussian_e(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
                 const float2 he = cull_half_extent(opac, ca, cb, cc);
-                s_cull[s]       = make_float4(xy.x, xy.y, he.x, he.y);
+                s_cull[s]       = make_float4(ax, ay, he.x, he.y);
                 const float *c  = a.colors + (size_t)g * a.cdim + a.ch_off;
-                float cv[CH];
+                float cv[CH > 4 ? CH : 4];
 #pragma unroll
-                for (int k = 0; k < CH; ++k) cv[k] = (k < (int)a.nch) ? c[k] : 0.0f;
-                s_gbc[s] = make_float4(gb.x, gb.y, cv[0], CH > 1 ? cv[CH > 1 ? 1 : 0] : 0.0f);
+                for (int k = 0; k < (CH > 4 ? CH : 4); ++k) cv[k] = (k < CH && k < (int)a.nch) ? c[k] : 0.0f;
+                s_st[s].p0 = p0;
+                s_st[s].p1 = v4f{nA, nB, nC, cv[2]};
+                s_st[s].p2 = v4f{cv[0], cv[1], cv[3], 0.0f};
 #pragma unroll
-                for (int k = 2; k < CH; ++k) s_col[s * CX + k - 2] = cv[k];
+                for (int k = 4; k < CH; ++k) s_col[s * CX + k - 4] = cv[k];
             }
         }
         __syncthreads();
@@ -99,7 +103,7 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
         for (int32_t j = 0; j < batch_size; j += 64) {
             // wave-level early termination: a finished quadrant stops evaluating (it still takes part in
             // staging and in the barriers above).
-            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+            if (__builtin_amdgcn_ballot_w64(thr < INFINITY) == 0ull) break;
             const int32_t tl = j + (int32_t)lane;
             bool hit         = false;
             if (tl < batch_size) {
@@ -110,26 +114,37 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
             while (todo) {
                 const int32_t t = j + (int32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
-                const float4 ga = s_ga[t];
-                const float4 gbc = s_gbc[t];
-                const float2 gb  = make_float2(gbc.x, gbc.y);
-                const float dx    = ga.x - px;
-                const float dy    = ga.y - py;
-                const float q     = staged_q(ga, gb, dx, dy);
-                const float alpha = fminf(kMaxAlpha, staged_alpha_raw(ga, q));
-                if (done || q < 0.0f || alpha < kAlphaThreshold) continue;
-                const float next_T = T * (1.0f - alpha);
-                if (next_T <= kTransmittanceThresh) { // saturated: this Gaussian is excluded
-                    done = true;
-                    continue;
+                const v4f p0 = s_st[t].p0;
+                const v4f p1 = s_st[t].p1;
+                const float e     = staged_e(p0, p1.x, p1.y, p1.z, u, v);
+                const float alpha = fminf(kMaxAlpha, __builtin_amdgcn_exp2f(e));
+                // Branch-free body. The scalar unit, not the vector ALU, was the busiest pipe of this kernel when "pixel is
+                // done" lived in an EXEC-style mask (25 scalar instructions per surviving Gaussian, r05 PMC): the state now
+                // lives in vector registers - `thr` is the pixel's alpha threshold and becomes +inf once it is done.
+                const bool ok = !(e > p0.w) && !(alpha < thr); // e > lo <=> sigma < 0
+                if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue; // wave-uniform
+                float a_m          = ok ? alpha : 0.0f;
+                const float next_T = fmaf(-T, a_m, T);                    // == T when a_m == 0, and T > 1e-4 while not done
+                const bool sat     = next_T <= kTransmittanceThresh;      // saturated: this Gaussian is excluded
+                thr                = sat ? INFINITY : thr;
+                a_m                = sat ? 0.0f : a_m;
+                const float w      = a_m * T;
+                if constexpr (CH <= 3) { // colours 0, 1 as one b64 (one v_pk_fma_f32), colour 2 came with p1
+                    const v2f c01 = *reinterpret_cast<const v2f *>(&s_st[t].p2);
+                    acc[0] += c01.x * w;
+                    if constexpr (CH > 1) acc[1] += c01.y * w;
+                    if constexpr (CH > 2) acc[2] += p1.w * w;
+                } else {
+                    const v4f p2 = s_st[t].p2;
+                    acc[0] += p2.x * w;
+                    acc[1] += p2.y * w;
+                    acc[2] += p1.w * w;
+                    acc[3] += p2.z * w;
                 }
-                const float w = alpha * T;
-                acc[0] += gbc.z * w;
-                if constexpr (CH > 1) acc[1] += gbc.w * w;
 #pragma unroll
-                for (int k = 2; k < CH; ++k) acc[k] += s_col[t * CX + k - 2] * w;
-                cur_idx = (uint32_t)(batch_start + t);
-                T       = next_T;
+                for (int k = 4; k < CH; ++k) acc[k] += s_col[t * CX + k - 4] * w;
+                cur_idx = a_m > 0.0f ? (uint32_t)(batch_start + t) : cur_idx;
+                T       = sat ? T : next_T;
             }
         }
     }
@@ -153,7 +168,7 @@ static int launch_fwd(const Raster3DArgs &a, hipStream_t stream)
     if (n_blocks == 0) return GSX_OK;
     const uint32_t grid   = ((n_blocks + 7u) / 8u) * 8u; // xcd_remap needs a multiple of 8
     const uint32_t block  = a.tile_size <= 8 ? 64u : 256u;
-    const size_t smem     = kBatch * (3 * sizeof(float4) + sizeof(float) * (CH > 2 ? CH - 2 : 0));
+    const size_t smem     = kBatch * (sizeof(StagedRow) + sizeof(float4) + sizeof(float) * (CH > 4 ? CH - 4 : 0));
     hipLaunchKernelGGL(raster3d_fwd_kernel<CH>, dim3(grid), dim3(block), smem, stream, a);
     return check_launch("raster3d_fwd");
 }

@@ -262,7 +262,10 @@ def _pipeline_2dgs_vs_oracle(G, O, sc, W, H, packed, render_mode, sh_degree, dis
     assert abs(meta["isect_ids"].numel() - ids.numel()) <= max(4, ids.numel() // 2000)
     if full_size and not packed:  # ... and nothing but those +-1 radii is behind the difference
         r_g, r_o = cpu(meta["radii"]).reshape(-1, 2), rad.reshape(-1, 2)
-        assert int((r_g - r_o).abs().max()) <= 1 and float((r_g != r_o).any(-1).float().mean()) < 1e-3
+        vis_g, vis_o = (r_g > 0).all(-1), (r_o > 0).all(-1)
+        both = vis_g & vis_o  # a surfel exactly on a culling threshold may be visible on one side only
+        assert float((vis_g != vis_o).float().mean()) < 1e-3  # same bound as the projection test above (_proj_compare)
+        assert int((r_g[both] - r_o[both]).abs().max()) <= 1 and float((r_g[both] != r_o[both]).any(-1).float().mean()) < 1e-3
     assert_close_ratio(cpu(rc), rc_cmp, 1e-3, 1e-4, max_bad_ratio=1e-3, name="render_colors")
     assert_close_ratio(cpu(ra), ra_o, 1e-4, 5e-5, max_bad_ratio=1e-3, name="render_alphas")
     assert_close_ratio(cpu(rn), rn_cmp, 1e-3, 1e-4, max_bad_ratio=1e-3, name="render_normals")
