@@ -308,7 +308,7 @@ struct BwdTCfg {
 
 template <int CH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSX_BWD_T_WAVES)))
-raster3d_bwd_t_kernel(const Raster3DArgs a)
+raster3d_bwd_t_kernel(Raster3DArgs a)
 {
     using Cfg           = BwdTCfg<CH>;
     constexpr int K     = Cfg::K;
@@ -318,7 +318,6 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
     constexpr int WROW  = Cfg::WROW;
     constexpr int WGRP  = Cfg::WGRP;
     static_assert(CH <= 4, "cotangent rows are staged as float4");
-    static_assert(BATCH <= 255, "staged indices are packed one byte per slot");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     StagedRow *s_st  = reinterpret_cast<StagedRow *>(smem_raw);    // tile-centre polynomial of the exponent + colours (raster3d.hpp)
@@ -347,13 +346,27 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
     const float pu      = (float)lx - 7.5f, pv = (float)ly - 7.5f;
     const size_t pix    = inside ? (size_t)prow : 0;
 
-    const int32_t range_start = tc.range_start, range_end = tc.range_end;
-    const int32_t n_batches   = (range_end - range_start + BATCH - 1) / BATCH;
-    if (n_batches <= 0) return;
+    const int32_t range_start = tc.range_start;
+    if (tc.range_end <= range_start) return;
 
     const float T_final     = inside ? 1.0f - a.render_alphas[pix] : 1.0f;
     float T                 = T_final;
     const int32_t bin_final = inside ? a.last_ids[pix] : -1;
+    // The forward pass stopped every pixel at its last contributor (early termination at T <= 1e-4 cuts the lists of a
+    // dense scene to a fraction of their length): nothing behind the LAST contributor of the whole tile is ever needed, so
+    // those list entries are not even staged.
+    const int32_t wave_bin_final = wave_max_i32(bin_final);
+    {
+        int32_t *s_m = reinterpret_cast<int32_t *>(smem_raw); // staging area, not in use yet
+        if (lane == 0) s_m[wave] = wave_bin_final;
+        __syncthreads();
+        const int32_t m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        __syncthreads();
+        tc.range_end = min(tc.range_end, m + 1);
+    }
+    const int32_t range_end = tc.range_end;
+    const int32_t n_batches = (range_end - range_start + BATCH - 1) / BATCH;
+    if (n_batches <= 0) return; // uniform: no pixel of the tile has a contributor
     float v_c[CH], buffer[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
@@ -369,7 +382,6 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
             if (k < (int)a.nch) bg_dot += bg[k] * v_c[k];
     }
     const float va_minus_bg      = v_a - bg_dot;
-    const int32_t wave_bin_final = wave_max_i32(bin_final);
     const WaveRect rect          = wave_pixel_rect(inside, pu, pv); // tile-centre coordinates, like s_cull
 
     // roles in a turn: this lane owns slot bg and quadrant row bv (pixels 8 bv .. 8 bv + 7 of the wave, u = 0..7)
@@ -405,7 +417,9 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
     // quadrant origin in tile-CENTRE coordinates: the moments are taken about the tile centre (same for the four waves)
     const float u0 = (float)((wave & 1u) << 3) - 7.5f, v0 = (float)((wave >> 1) << 3) - 7.5f;
     int slot   = 0; // wave-uniform: slots filled since the last turn
-    uint32_t slot_lo = 0, slot_hi = 0; // wave-uniform: byte s & 3 of word s >> 2 = staged index (< BATCH <= 255) of the Gaussian in slot s
+    float *const w_ptr0 = s_ww + w_off; // this lane's (fac, w) cell in slot 0 ...
+    float *w_ptr        = w_ptr0;       // ... and in the next free slot (a vector add per Gaussian instead of scalar address math)
+    int slot_t = 0; // lanes with lane % 8 == s: staged index of the Gaussian in slot s
 
     // one turn: sums of the filled slots -> s_acc (all lanes of the wave take part)
     auto turn = [&](int n_slots) {
@@ -446,8 +460,7 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] += dpp_f32<0x128>(acc[k]); // row_ror:8
         const int frow = (int)(lane >> 4), fcol = (int)(lane & 15u);
-        const uint32_t st_w = (fcol & 4) ? slot_hi : slot_lo; // slots 0..3 in one word, 4..7 in the other
-        const int t_g  = (int)((st_w >> (8 * (fcol & 3))) & 0xFFu);
+        const int t_g  = slot_t; // every lane with lane % 8 == s tracks slot s (the writer lanes have lane % 16 < 8)
         const bool wr_lane = fcol < SLOTS && fcol < n_slots;
 #pragma unroll
         for (int j = 0; j < Cfg::KG; ++j) {
@@ -499,8 +512,9 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
           }
           uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
           while (todo) {
-            const int32_t t = j + (int32_t)__builtin_ctzll(todo);
-            todo &= todo - 1;
+            const int32_t bit = (int32_t)__builtin_ctzll(todo);
+            const int32_t t   = j + bit;
+            asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in ONE scalar instruction (the compiler emits three)
             const v4f p0 = s_st[t].p0;
             const v4f p1 = s_st[t].p1;
             const float e     = staged_e(p0, p1.x, p1.y, p1.z, pu, pv);
@@ -535,23 +549,20 @@ raster3d_bwd_t_kernel(const Raster3DArgs a)
             }
             v_alpha += T_final * ra * va_minus_bg;
             const float v_sigma = (ov <= kMaxAlpha) ? -ov * v_alpha : 0.0f; // alpha-clamp branch: no geometry gradient
-            *reinterpret_cast<float2 *>(s_ww + slot * WROW + w_off) = make_float2(fac, v_sigma); // ds_write_b64
-{ // scalar ALU only: which Gaussian sits in that slot
-                const uint32_t sh = (uint32_t)t << (8 * (slot & 3));
-                slot_lo |= (slot & 4) ? 0u : sh;
-                slot_hi |= (slot & 4) ? sh : 0u;
-            }
+            *reinterpret_cast<float2 *>(w_ptr) = make_float2(fac, v_sigma); // ds_write_b64 into slot `slot`
+            w_ptr += WROW;
+            slot_t = ((int)(lane & 7u) == slot) ? t : slot_t;
             if (++slot == SLOTS) {
                 turn(SLOTS);
-                slot    = 0;
-                slot_lo = slot_hi = 0;
+                slot  = 0;
+                w_ptr = w_ptr0;
             }
           }
         }
         if (slot) { // the accumulator rows of this batch are flushed below: finish the open turn first
             turn(slot);
-            slot    = 0;
-            slot_lo = slot_hi = 0;
+            slot  = 0;
+            w_ptr = w_ptr0;
         }
         __syncthreads();
 

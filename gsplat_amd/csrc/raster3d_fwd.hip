@@ -112,8 +112,10 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
             }
             uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
             while (todo) {
-                const int32_t t = j + (int32_t)__builtin_ctzll(todo);
-                todo &= todo - 1;
+                const int32_t bit = (int32_t)__builtin_ctzll(todo);
+                const int32_t t   = j + bit;
+                asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction
+
                 const v4f p0 = s_st[t].p0;
                 const v4f p1 = s_st[t].p1;
                 const float e     = staged_e(p0, p1.x, p1.y, p1.z, u, v);

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
-if [ -n "${TESTS:-}" ]; then timeout 600 python -m pytest $TESTS -m gpu -q -x -p no:cacheprovider 2>&1 | tail -5; fi
+if [ -n "${TESTS:-}" ]; then timeout 600 python -m pytest $TESTS -m gpu -q -x -p no:cacheprovider > $OUT/tests.log 2>&1; tail -4 $OUT/tests.log; fi
 run() { name=$1; shift; for rep in 1 2; do env "$@" timeout 120 python bench.py --lean --steps 30 > $OUT/bench_${name}_$rep.json 2> $OUT/bench_${name}_$rep.err; done; python - <<PY
 import json
 for rep in (1, 2):
