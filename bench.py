@@ -7,23 +7,29 @@ already resident in HBM. Rank 0 prints ONE JSON line.
 
 Workload at N=1 = BASELINE.json configs[2] ("c3"): 1 M synthetic Gaussians, one 1920x1080 pinhole camera,
 SH degree 3, 16x16 tiles, fwd+bwd, loss = render_colors.sum() (reference harness profiling/main.py:132-149).
-Workload at N>1 = the SAME c3 scene, Gaussian-sharded the way the reference trains multi-GPU (stride shard
-[rank::N] of the 1 M Gaussians, examples/simple_trainer.py:326-328) with ONE 1080p camera per rank: every rank
-projects its 1M/N Gaussians against all N cameras (1 M (camera, Gaussian) pairs, as at N=1), the rows travel to
-the rank that owns the camera (all-gather cameras + all-to-all, gsplat_amd/distributed.py), and every rank
-composites its own camera over the whole 1 M-Gaussian scene (as at N=1). Per-GPU work is therefore fixed and the
-job renders N images per step: weak scaling, ideal throughput = N x the N=1 value. The configs[3] ("c4") shape
-is `--gaussians 500000 --cameras 4` under an 8-rank launch (4 M Gaussians, 4 cameras per rank).
+The same line carries two sub-records timed with the same recipe: "c5" (configs[4]: rasterization_2dgs, 1 M surfels,
+RGB+ED + normals + distortion) and "c4_single_gpu" (the per-rank work of configs[3] on ONE GPU: 4 M Gaussians,
+4 x 1080p cameras batched) - the N=1 point of the multi-GPU curve below.
+
+Workload at N>1 = BASELINE.json configs[3] ("c4"): a 4 M-Gaussian scene, Gaussian-sharded the way the reference trains
+multi-GPU (stride shard [rank::N], examples/simple_trainer.py:326-328; 500 k per rank at N=8), FOUR 1080p cameras per
+rank: every rank projects its 4M/N Gaussians against all 4N cameras (16 M (camera, Gaussian) pairs per rank at any N),
+the rows travel to the rank that owns the camera (all-gather cameras + all-to-all, gsplat_amd/distributed.py), and
+every rank composites its four cameras over the whole 4 M-Gaussian scene. Per-GPU work is therefore fixed and the job
+renders 4N images per step: weak scaling, ideal throughput = N x the "c4_single_gpu" value of the N=1 line.
+`--workload c3shard` keeps the older shape (the 1 M c3 scene sharded, one camera per rank).
 
 metric = Mpixels/s fwd+bwd = (images * H * W * steps) / wall time, whole job.
 roofline  = dominant kernel (the compositing backward) priced against HBM: algorithmic bytes per launch
-             / its mean launch duration measured live with HIP events on the launch stream.
+            (SURVEY.md §8(d)) / its mean launch duration measured live with HIP events on the launch stream;
+            `valu` prices the two compositing kernels against the fp32 vector peak with counted (pixel, Gaussian) pairs.
 cpu_baseline = the CPU oracle pipeline (oracle/pipeline.py, OpenMP C + torch-CPU) on the same workload, rank 0, N=1.
 """
 import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -36,6 +42,7 @@ if ROOT not in sys.path:
 WIDTH, HEIGHT, TILE = 1920, 1080, 16
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 FP32_PEAK_TFLOPS = 157.3
+NAMES = ("means", "quats", "scales", "opacities", "colors")
 
 
 def make_workload(n_gaussians: int, device, n_cameras: int = 1, seed: int = 0, rank: int = 0, world: int = 1):
@@ -56,7 +63,6 @@ def make_workload(n_gaussians: int, device, n_cameras: int = 1, seed: int = 0, r
     colors = torch.randn(n_gaussians, 16, 3, generator=g) * 0.3
     colors[:, 0, :] += 0.5
     viewmats = torch.eye(4).repeat(n_cameras, 1, 1)
-    cam_g = torch.Generator().manual_seed(seed + 13 * rank)
     for c in range(n_cameras):  # small yaw / shift per camera so views differ
         ang = 0.02 * (c + n_cameras * rank)
         viewmats[c, 0, 0] = math.cos(ang); viewmats[c, 0, 2] = math.sin(ang)
@@ -76,22 +82,66 @@ def algorithmic_bytes(M, V, P, T, D):
     return fwd, bwd
 
 
+def _git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def timed(step_fn, steps, warmup, barrier, profile_only=None):
+    """W untimed warm-up steps, then exactly K timed steps between barrier + synchronize pairs. Returns
+    (seconds, last meta, {entry point: [ms per call]} for the entry points in `profile_only`)."""
+    from gsplat_amd import _cabi
+
+    meta = None
+    for _ in range(warmup):
+        meta = step_fn()
+    barrier()
+    if profile_only:
+        _cabi.profile_begin(only=profile_only)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        meta = step_fn()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _cabi.profile_end() if profile_only else {}
+    return elapsed, meta, prof
+
+
+def pair_stats(meta, n_images, W, H):
+    """Work counters of the compositing pass (C-ABI gsx_raster3d_pair_stats: instrumentation, replays the forward walk)."""
+    from gsplat_amd._cabi import call, ptr
+
+    stats = torch.zeros(4, dtype=torch.int64, device=meta["means2d"].device)
+    tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
+    call("gsx_raster3d_pair_stats", ptr(meta["means2d"].contiguous()), ptr(meta["conics"].contiguous()),
+         ptr(meta["opacities"].contiguous()), ptr(meta["isect_offsets"].contiguous()), ptr(meta["flatten_ids"]),
+         n_images, meta["flatten_ids"].numel(), W, H, TILE, tw, th, ptr(stats))
+    return [int(v) for v in stats.tolist()]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--gaussians", type=int, default=None, help="Gaussians per rank (default: 1M / N, i.e. the c3 scene)")
-    ap.add_argument("--cameras", type=int, default=None, help="cameras per rank (default 1)")
+    ap.add_argument("--gaussians", type=int, default=None, help="Gaussians per rank (overrides the workload's default)")
+    ap.add_argument("--cameras", type=int, default=None, help="cameras per rank (overrides the workload's default)")
+    ap.add_argument("--workload", choices=("auto", "c3", "c4", "c3shard"), default="auto",
+                    help="auto: c3 at N=1, c4 (4 M Gaussians sharded, 4 cameras per rank) at N>1; c3shard: the 1 M c3 scene "
+                         "sharded with one camera per rank")
     ap.add_argument("--packed", action="store_true",
                     help="time packed=True as the headline (default: packed=False, the faster layout when nearly every "
                          "Gaussian is visible, as in c3; the other layout is timed too and reported in 'other_layout')")
     ap.add_argument("--dense", action="store_true", help=argparse.SUPPRESS)  # old flag, now the default
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c5 and c4_single_gpu sub-records")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the distributed=True code path in a 1-rank RCCL group (measures the seams' overhead)")
     ap.add_argument("--lean", action="store_true",
-                    help="only warmup + timed steps (no stage table, no other-layout leg, no CPU baseline): for rocprofv3 runs")
+                    help="only warmup + timed steps (no stage table, no sub-records, no CPU baseline): for rocprofv3 runs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,24 +172,36 @@ def main():
     import gsplat_amd
     from gsplat_amd import _cabi
 
-    n_total = args.gaussians * world if args.gaussians else 1_000_000
-    n_cams = args.cameras or 1
+    workload = args.workload
+    if workload == "auto":
+        workload = "c4" if world > 1 else "c3"
+    if workload == "c4":
+        n_total, n_cams = 4_000_000, 4
+    else:
+        n_total, n_cams = 1_000_000, 1
+    if args.gaussians:
+        n_total = args.gaussians * world
+    if args.cameras:
+        n_cams = args.cameras
     sc, W, H = make_workload(n_total, device, n_cameras=n_cams, rank=rank, world=world)
     n_local = sc["means"].shape[0]
-    names = ("means", "quats", "scales", "opacities", "colors")
-    leaves = {k: sc[k].clone().requires_grad_(True) for k in names}
+    leaves = {k: sc[k].clone().requires_grad_(True) for k in NAMES}
     # dense rows by default, also at N>1: nearly every (camera, Gaussian) pair is visible in this scene, and dense
     # rows need no id columns in the all-to-all (48 B/row instead of 64 B/visible row) and no compaction pass
     packed = bool(args.packed)
 
-    def step(packed=packed):
-        for t in leaves.values():
-            t.grad = None
-        rc, ra, meta = gsplat_amd.rasterization(
-            leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"], sc["viewmats"],
-            sc["Ks"], W, H, sh_degree=3, packed=packed, tile_size=TILE, distributed=distributed)
-        rc.sum().backward()
-        return meta
+    def make_step(leaves, sc, packed=packed, distributed=distributed):
+        def step():
+            for t in leaves.values():
+                t.grad = None
+            rc, ra, meta = gsplat_amd.rasterization(
+                leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"], sc["viewmats"],
+                sc["Ks"], W, H, sh_degree=3, packed=packed, tile_size=TILE, distributed=distributed)
+            rc.sum().backward()
+            return meta
+        return step
+
+    step = make_step(leaves, sc)
 
     def barrier():
         if distributed:
@@ -156,24 +218,9 @@ def main():
 
     gc.collect()
     gc.freeze()
-    barrier()
     # HIP events (on the launch stream) around the two compositing launches only: the dominant kernels are timed live
     # inside the timed region without the bookkeeping of ~40 event pairs per step perturbing it.
-    _cabi.profile_begin(only=("gsx_raster3d_fwd", "gsx_raster3d_bwd"))
-    t0 = time.perf_counter()
-    per_step = []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        meta = step()
-        per_step.append(time.perf_counter() - ts)
-    t_enq = time.perf_counter() - t0
-    if os.environ.get("GSPLAT_BENCH_DEBUG"):
-        print("[bench] per-step enqueue ms:", " ".join(f"{x * 1e3:.2f}" for x in per_step), file=sys.stderr)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if os.environ.get("GSPLAT_BENCH_DEBUG"):
-        print(f"[bench rank {rank}] enqueue {t_enq * 1e3:.2f} ms, enqueue+barrier {elapsed * 1e3:.2f} ms", file=sys.stderr)
-    prof = _cabi.profile_end()
+    elapsed, meta, prof = timed(step, args.steps, 0, barrier, profile_only=("gsx_raster3d_fwd", "gsx_raster3d_bwd"))
     # per-stage table: a few extra (untimed) steps with an event pair around every C-ABI call
     n_stage = 0 if args.lean else min(5, args.steps)
     _cabi.profile_begin()
@@ -183,14 +230,8 @@ def main():
     # the other row layout (packed <-> dense), same workload, same timing recipe (not the headline)
     other = None
     if not distributed and not args.lean:
-        for _ in range(min(3, args.warmup)):
-            step(not packed)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(not packed)
-        barrier()
-        t_other = (time.perf_counter() - t1) / args.steps
+        t_other, _, _ = timed(make_step(leaves, sc, packed=not packed), args.steps, min(3, args.warmup), barrier)
+        t_other /= args.steps
         other = {"packed": not packed, "ms_per_step": round(t_other * 1e3, 4),
                  "value": round(n_cams * W * H / t_other / 1e6, 2)}
     if distributed:
@@ -216,21 +257,41 @@ def main():
     t_bwd = mean_ms.get("gsx_raster3d_bwd", float("nan"))
     dom, dom_bytes, dom_ms = ("raster3d_bwd", b_bwd, t_bwd) if not (t_fwd > t_bwd) else ("raster3d_fwd", b_fwd, t_fwd)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch from the rocprofv3 PMC passes (tools/gpu_profile.sh -> profiles/pmc_traffic.json); the file
+    # names the commit it was measured at, so a stale number is visible as such
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             pmc = json.load(open(tpath))
             # the backward runs as variant T for <= 4 channels (csrc/raster3d_bwd.hip): its counters are filed under that name
             traffic = (pmc.get(dom + "_t") or pmc.get(dom) or {}).get("bytes")
+            traffic_src = {"file": "profiles/pmc_traffic.json", "measured_at_commit": (pmc.get("_meta") or {}).get("commit"),
+                           "bench_commit": _git_head()}
         except Exception:
             traffic = None
+    # vector-ALU view of the same two kernels: counted (pixel, Gaussian) pairs x (14 + 2 D) flop / time
+    valu = None
+    if not distributed:
+        ps = pair_stats(meta, n_cams, W, H)
+        fl = 14 + 2 * D
+        valu = {
+            "pairs_reference_walk": ps[0], "lane_evaluations": ps[1], "lane_evaluations_open_pixels": ps[2],
+            "contributing_pairs": ps[3], "flop_per_pair": fl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            # the reference kernel's work (every list entry up to saturation, per pixel) done in this kernel's time ...
+            "fwd_reference_work_TFLOPs": round(ps[0] * fl / (t_fwd * 1e-3) / 1e12, 2) if t_fwd == t_fwd else None,
+            # ... and what the vector ALU really executed (after wave-level culling), forward only
+            "fwd_executed_TFLOPs": round(ps[1] * fl / (t_fwd * 1e-3) / 1e12, 2) if t_fwd == t_fwd else None,
+        }
+        if t_fwd == t_fwd:
+            valu["fwd_frac_of_peak_reference_work"] = round(valu["fwd_reference_work_TFLOPs"] / FP32_PEAK_TFLOPS, 4)
+            valu["fwd_frac_of_peak_executed"] = round(valu["fwd_executed_TFLOPs"] / FP32_PEAK_TFLOPS, 4)
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": int(dom_bytes), "launch_ms": round(dom_ms, 4),
-        "n_isects": M, "rows": V, "pixels_per_launch": P_local,
-        "note": "compositing is VALU/exp/atomic-bound, not HBM-bound (SURVEY.md 8(d)); see DESIGN.md",
+        "n_isects": M, "rows": V, "pixels_per_launch": P_local, "valu": valu,
+        "note": "compositing is bound by instruction issue (scalar + vector) and LDS, not by HBM (SURVEY.md 8(d)); see DESIGN.md",
     }
 
     # HBM-bound stages: algorithmic bytes / measured stage time, against the same 8 TB/s peak
@@ -254,17 +315,19 @@ def main():
             gbs = nbytes / (per_step_ms[k] * 1e-3) / 1e9
             stage_roofline[k.replace("gsx_", "")] = {"achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
 
+    if workload == "c3" and not distributed:
+        wl = "c3: 1M synthetic Gaussians, 1x1920x1080, SH deg 3, 16x16 tiles, fwd+bwd"
+    else:
+        wl = (f"{workload}: {n_total} synthetic Gaussians stride-sharded over {n_gpus} rank(s) ({n_local} per rank), "
+              f"{n_cams}x1920x1080 camera(s) per rank ({n_cams * n_gpus} images per step), SH deg 3, 16x16 tiles, fwd+bwd"
+              + (", distributed=True (all-gather cameras + all-to-all projected rows)" if distributed else ""))
     result = {
-        "metric": "Mpixels/s fwd+bwd @1M Gaussians/1080p",
+        "metric": "Mpixels/s fwd+bwd @1M Gaussians/1080p" if workload != "c4" else
+                  "Mpixels/s fwd+bwd @4M Gaussians sharded / 4x1080p cameras per GPU",
         "value": round(mpix_s, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("c3: 1M synthetic Gaussians, 1x1920x1080, SH deg 3, 16x16 tiles, fwd+bwd"
-                                if not distributed else
-                                f"c3 scene ({n_total} Gaussians) stride-sharded over {n_gpus} ranks ({n_local} per rank), "
-                                f"{n_cams}x1920x1080 camera(s) per rank ({n_cams * n_gpus} images per step), SH deg 3, 16x16 "
-                                "tiles, fwd+bwd, distributed=True (all-gather cameras + all-to-all projected rows)"),
-                   "gaussians_per_gpu": n_local, "cameras_per_gpu": n_cams, "packed": packed,
+        "config": {"workload": wl, "gaussians_per_gpu": n_local, "cameras_per_gpu": n_cams, "packed": packed,
                    "parallelism": f"gaussian-sharded x{n_gpus}" if distributed else "single"},
         "roofline": roofline,
         "raster_launch_ms": {"fwd": round(t_fwd, 4) if t_fwd == t_fwd else None,
@@ -275,10 +338,62 @@ def main():
     if other is not None:
         result["other_layout"] = other
 
+    extras = rank == 0 and not distributed and not args.lean and not args.no_extra and workload == "c3"
+    # ---- c5 (BASELINE.json configs[4]): 2DGS, same scene, RGB+ED + normals + distortion, same timing recipe -------------
+    if extras:
+        l5 = {k: sc[k].clone().requires_grad_(True) for k in NAMES}
+
+        def step5():
+            for t in l5.values():
+                t.grad = None
+            rc, ra, rn, sn, rd, rm, m5 = gsplat_amd.rasterization_2dgs(
+                l5["means"], l5["quats"], l5["scales"], l5["opacities"], l5["colors"], sc["viewmats"], sc["Ks"], W, H,
+                sh_degree=3, packed=False, render_mode="RGB+ED", distloss=True)
+            (rc.sum() + rn.sum() + rd.sum()).backward()
+            return m5
+
+        steps5 = max(3, args.steps // 2)
+        t5, m5, p5 = timed(step5, steps5, 3, barrier, profile_only=("gsx_raster2d_fwd", "gsx_raster2d_bwd"))
+        M5, D5 = int(m5["isect_ids"].numel()), 4
+        V5 = int((m5["radii"] > 0).all(-1).sum().item())
+        ms5 = {k.replace("gsx_", ""): round(sum(v) / len(v), 4) for k, v in p5.items()}
+        # algorithmic bytes of the 2DGS compositing (52 + 4 D bytes staged per intersection; pixels:
+        # colours + alpha + normals + distortion + median (+ ids); rows: 17 + D gradient floats written once, zeroed once)
+        b5f = (52 + 4 * D5) * M5 + (4 * D5 + 4 + 12 + 4 + 4 + 8) * W * H
+        b5b = (52 + 4 * D5) * M5 + (4 * D5 + 4 + 12 + 4 + 4 + 8 + 4 * D5 + 4 + 12 + 4) * W * H + 2 * 4 * (17 + D5) * V5
+        t5b = ms5.get("raster2d_bwd")
+        result["c5"] = {
+            "workload": "c5: rasterization_2dgs, 1M surfels, 1x1920x1080, SH deg 3, RGB+ED + normals + distortion, fwd+bwd",
+            "value": round(W * H * steps5 / t5 / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(t5 / steps5 * 1e3, 4),
+            "steps": steps5, "n_isects": M5, "raster_launch_ms": ms5,
+            "roofline": {"bound": "hbm", "kernel": "raster2d_bwd", "algorithmic_bytes_per_launch": int(b5b),
+                         "achieved": round(b5b / (t5b * 1e-3) / 1e9, 2) if t5b else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(b5b / (t5b * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if t5b else None,
+                         "fwd_algorithmic_bytes_per_launch": int(b5f)},
+        }
+        del l5, m5
+    # ---- c4 on one GPU: the per-rank work of BASELINE.json configs[3] (4 M Gaussians, 4 cameras batched) ----------------
+    if extras:
+        torch.cuda.empty_cache()
+        sc4, _, _ = make_workload(4_000_000, device, n_cameras=4)
+        l4 = {k: sc4[k].clone().requires_grad_(True) for k in NAMES}
+        steps4 = max(3, args.steps // 4)
+        t4, m4, p4 = timed(make_step(l4, sc4, packed=False, distributed=False), steps4, 2, barrier,
+                           profile_only=("gsx_raster3d_fwd", "gsx_raster3d_bwd"))
+        result["c4_single_gpu"] = {
+            "workload": "c4 per-rank work on one GPU: 4M synthetic Gaussians, 4x1920x1080 cameras batched, SH deg 3, fwd+bwd",
+            "value": round(4 * W * H * steps4 / t4 / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(t4 / steps4 * 1e3, 4),
+            "steps": steps4, "n_isects": int(m4["isect_ids"].numel()),
+            "raster_launch_ms": {k.replace("gsx_", ""): round(sum(v) / len(v), 4) for k, v in p4.items()},
+            "note": "N=1 point of the `--gpus N` curve (same per-GPU work at every N; ideal value at N GPUs = N x this)",
+        }
+        del sc4, l4, m4
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline (rank 0, N=1): the oracle pipeline, one fwd+bwd step of the SAME workload -------------
     # Bounded by construction: one step of c3 is ~10-30 s on <= 32 host threads (more threads are slower for these
     # OpenMP/torch-CPU loops: fork/join + atomic contention), so the default bench run stays within a few minutes.
-    if rank == 0 and not distributed and not args.no_cpu_baseline and not args.lean:
+    if rank == 0 and not distributed and not args.no_cpu_baseline and not args.lean and workload == "c3":
         from oracle import oracle as _oracle
         from oracle.pipeline import rasterization_cpu
 

@@ -81,7 +81,7 @@ struct Surfel { // one pixel x one surfel
 };
 
 __device__ __forceinline__ Surfel eval_surfel(const float4 A /*uM, x*/, const float4 B /*vM, y*/, const float4 C /*wM, opac*/,
-                                              float px, float py)
+                                              float px, float py, float thr = kAlphaThreshold)
 {
     Surfel s;
     s.hu[0] = px * C.x - A.x; s.hu[1] = px * C.y - A.y; s.hu[2] = px * C.z - A.z;
@@ -99,7 +99,7 @@ __device__ __forceinline__ Surfel eval_surfel(const float4 A /*uM, x*/, const fl
     const float sigma = 0.5f * fminf(s.gw3, s.gw2);
     s.vis   = __expf(-sigma);
     s.alpha = fminf(kMaxAlpha, C.w * s.vis);
-    s.valid = (rz != 0.0f) && !(sigma < 0.0f) && !(s.alpha < kAlphaThreshold);
+    s.valid = (rz != 0.0f) && !(sigma < 0.0f) && !(s.alpha < thr);
     return s;
 }
 
@@ -160,12 +160,12 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
     float acc[CH], nrm[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < CH; ++k) acc[k] = 0.0f;
-    bool done = !inside;
+    float thr = inside ? kAlphaThreshold : INFINITY; // alpha threshold of this pixel; +inf = done (or not rendered)
     const uint32_t lane = tid & 63u;
     const WaveRect rect = wave_pixel_rect(inside, px, py);
 
     for (int32_t b = 0; b < n_batches; ++b) {
-        if (__syncthreads_count(done) == (int)blockDim.x) break;
+        if (__syncthreads_count(!(thr < INFINITY)) == (int)blockDim.x) break;
         const int32_t batch_start = range_start + kBatch2 * b;
         for (int s = (int)tid; s < kBatch2; s += (int)blockDim.x) {
             const int32_t idx = batch_start + s;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
         // 64 staged surfels are tested per instruction against this wave's pixel rectangle; only the ballot survivors
         // are evaluated, front to back (a culled pair has no pixel that could pass the alpha test)
         for (int32_t j = 0; j < batch_size; j += 64) {
-          if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+          if (__builtin_amdgcn_ballot_w64(thr < INFINITY) == 0ull) break;
           const int32_t tl = j + (int32_t)lane;
           bool hit         = false;
           if (tl < batch_size) {
@@ -199,16 +199,19 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
           }
           uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
           while (todo) {
-            const int32_t t = j + (int32_t)__builtin_ctzll(todo);
-            todo &= todo - 1;
-            const Surfel s = eval_surfel(s_A[t], s_B[t], s_C[t], px, py);
-            if (done || !s.valid) continue;
-            const float next_T = T * (1.0f - s.alpha);
-            if (next_T <= kTransmittanceThresh) {
-                done = true;
-                continue;
-            }
-            const float w = s.alpha * T;
+            const int32_t bit = (int32_t)__builtin_ctzll(todo);
+            const int32_t t   = j + bit;
+            asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction
+            const Surfel s = eval_surfel(s_A[t], s_B[t], s_C[t], px, py, thr);
+            // Branch-free body (raster3d_fwd.hip: the scalar unit, not the vector ALU, is the busy pipe when the pixel's
+            // state lives in exec-style masks): `thr` is this pixel's alpha threshold, +inf once it is done.
+            if (__builtin_amdgcn_ballot_w64(s.valid) == 0ull) continue; // wave-uniform
+            float a_m          = s.valid ? s.alpha : 0.0f;
+            const float next_T = fmaf(-T, a_m, T);               // == T when a_m == 0, and T > 1e-4 while not done
+            const bool sat     = next_T <= kTransmittanceThresh; // saturated: this surfel is excluded
+            thr                = sat ? INFINITY : thr;
+            a_m                = sat ? 0.0f : a_m;
+            const float w      = a_m * T;
 #pragma unroll
             for (int k = 0; k < CH; ++k) acc[k] += s_col[t * CH + k] * w;
             const float4 n = s_N[t];
@@ -218,12 +221,12 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
                 distort += 2.0f * (w * depth * (1.0f - T) - w * accum_vis_depth);
                 accum_vis_depth += w * depth;
             }
-            if (T > 0.5f) {
-                median_depth = depth;
-                median_idx   = (uint32_t)(batch_start + t);
-            }
-            cur_idx = (uint32_t)(batch_start + t);
-            T       = next_T;
+            const bool contrib = a_m > 0.0f;
+            const bool med     = contrib && T > 0.5f;
+            median_depth = med ? depth : median_depth;
+            median_idx   = med ? (uint32_t)(batch_start + t) : median_idx;
+            cur_idx      = contrib ? (uint32_t)(batch_start + t) : cur_idx;
+            T            = sat ? T : next_T;
           }
         }
     }
@@ -294,14 +297,26 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
     const float plx = px - X0, ply = py - Y0;                                           // tile-local pixel centre
 
     const int32_t range_start = a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id];
-    const int32_t range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects
+    int32_t range_end         = (blk == n_blocks - 1) ? (int32_t)a.n_isects
                                                       : a.isect_offsets[(size_t)image_id * tiles_per_image + tile_id + 1];
-    const int32_t n_batches   = (range_end - range_start + BATCH - 1) / BATCH;
-    if (n_batches <= 0) return;
+    if (range_end <= range_start) return;
 
     const float T_final      = inside ? 1.0f - a.render_alphas[pix] : 1.0f;
     float T                  = T_final;
     const int32_t bin_final  = inside ? a.last_ids[pix] : -1;
+    // nothing behind the last contributor of the whole tile is needed (see raster3d_bwd.hip): those entries are not staged
+    const int32_t wave_bin_final = wave_max_i32(bin_final);
+    {
+        int32_t *s_m = reinterpret_cast<int32_t *>(smem_raw); // staging area, not in use yet
+        if (lane == 0) s_m[tid >> 6] = wave_bin_final;
+        __syncthreads();
+        int32_t m = s_m[0];
+        for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) m = max(m, s_m[w]);
+        __syncthreads();
+        range_end = min(range_end, m + 1);
+    }
+    const int32_t n_batches = (range_end - range_start + BATCH - 1) / BATCH;
+    if (n_batches <= 0) return;
     const int32_t median_idx = inside ? a.median_ids[pix] : -1;
     float v_c[CH], buffer[CH], v_n[3], buffer_n[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -329,7 +344,6 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
         accum_w_buffer = a.render_alphas[pix];
         accum_w        = accum_w_buffer;
     }
-    const int32_t wave_bin_final = wave_max_i32(bin_final);
     const WaveRect rect          = wave_pixel_rect(inside, px, py);
 
     for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
@@ -372,8 +386,9 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
           }
           uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
           while (todo) { // scalar loop over the survivors, back to front
-            const int32_t t = j + (int32_t)__builtin_ctzll(todo);
-            todo &= todo - 1;
+            const int32_t bit = (int32_t)__builtin_ctzll(todo);
+            const int32_t t   = j + bit;
+            asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction
             const float4 A = s_A[t], B = s_B[t], C = s_C[t];
             const Surfel s = eval_surfel(A, B, C, px, py);
             const bool valid = inside && (batch_end - t <= bin_final) && s.valid;

@@ -29,10 +29,11 @@ struct QueryArgs {
     float *alphas;   // mode 0: [I,H,W]
     int32_t *ids;    // mode 1/2: [I,H,W,K]  (mode 1: pre-filled with -1 by the caller)
     float *weights;  // mode 1/2: [I,H,W,K]  (mode 1: pre-filled with 0)
+    unsigned long long *stats; // mode 3: [4] work counters, added to with atomics (see gsx_raster3d_pair_stats)
 };
 
 constexpr int kQBatch = 256;
-enum { kQCount = 0, kQIds = 1, kQTop = 2 };
+enum { kQCount = 0, kQIds = 1, kQTop = 2, kQStats = 3 };
 
 template <int MODE>
 __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
@@ -62,6 +63,7 @@ __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
 
     float T        = 1.0f;
     uint32_t count = 0; // contributions so far (= depth index of the next one)
+    uint32_t walked = 0, wave_evals = 0, lane_evals = 0; // kQStats: see gsx_raster3d_pair_stats
     bool done      = !inside;
     if constexpr (MODE == kQTop) {
         for (uint32_t k = 0; k < a.K; ++k) {
@@ -111,10 +113,15 @@ __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
                 const float dx = ga.x - px, dy = ga.y - py;
                 const float q     = staged_q(ga, gb, dx, dy);
                 const float alpha = fminf(kMaxAlpha, staged_alpha_raw(ga, q));
+                if constexpr (MODE == kQStats) {
+                    ++wave_evals;
+                    lane_evals += done ? 0u : 1u;
+                }
                 if (done || q < 0.0f || alpha < kAlphaThreshold) continue;
                 const float next_T = T * (1.0f - alpha);
                 if (next_T <= kTransmittanceThresh) {
                     done = true;
+                    if constexpr (MODE == kQStats) walked = (uint32_t)(batch_start + t - range_start + 1);
                     continue;
                 }
                 const float w = alpha * T;
@@ -144,6 +151,26 @@ __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
                 T = next_T;
             }
         }
+    }
+    if constexpr (MODE == kQStats) {
+        // [0] (pixel, Gaussian) pairs a per-pixel serial walk of the tile lists evaluates (every list entry up to and including
+        //     the one that saturates the pixel; no culling) - the reference kernel's work, SURVEY.md 8(d) "pairs"
+        // [1] lane evaluations of this backend: 64 x (wave, Gaussian) pairs that survive the wave-level culling
+        // [2] of those, lanes whose pixel was still open   [3] contributing pairs (alpha >= 1/255, before saturation)
+        if (inside && !done) walked = (uint32_t)(range_end - range_start);
+        unsigned long long v0 = inside ? walked : 0u, v2 = lane_evals, v3 = inside ? count : 0u;
+        for (int o = 32; o >= 1; o >>= 1) {
+            v0 += __shfl_xor(v0, o);
+            v2 += __shfl_xor(v2, o);
+            v3 += __shfl_xor(v3, o);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.stats[0], v0);
+            atomicAdd(&a.stats[1], 64ull * wave_evals);
+            atomicAdd(&a.stats[2], v2);
+            atomicAdd(&a.stats[3], v3);
+        }
+        return;
     }
     if (!inside) return;
     if constexpr (MODE == kQCount) {
@@ -271,6 +298,23 @@ extern "C" int gsx_raster3d_top_contributing(const float *means2d, const float *
     GSX_REQUIRE(ids && weights, "gsx_raster3d_top_contributing: null output");
     a.K = num_depth_samples; a.ids = ids; a.weights = weights;
     return launch_query<kQTop>(a, (hipStream_t)stream);
+}
+
+// Instrumentation (not a reference op): how much work the compositing pass of this scene is. Replays the forward walk and
+// adds four counters to stats[0..3] (zeroed by the caller; see the kernel): bench.py prices the vector ALU with them
+// (pairs x (14 + 2 D) flop against the fp32 peak).
+extern "C" int gsx_raster3d_pair_stats(const float *means2d, const float *conics, const float *opacities,
+                                       const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images,
+                                       uint32_t n_isects, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w,
+                                       uint32_t tile_h, uint64_t *stats, void *stream)
+{
+    QueryArgs a{};
+    int rc = fill_query("gsx_raster3d_pair_stats", a, means2d, conics, opacities, isect_offsets, flatten_ids, n_images, n_isects,
+                        0, width, height, tile_size, tile_w, tile_h);
+    if (rc != GSX_OK) return rc;
+    GSX_REQUIRE(stats, "gsx_raster3d_pair_stats: null output");
+    a.stats = reinterpret_cast<unsigned long long *>(stats);
+    return launch_query<kQStats>(a, (hipStream_t)stream);
 }
 
 // ---- sparse pixel sets: gsplat::rasterize_*_sparse (ext.cpp:1115-1140); outputs are rows [P, ...] in the caller's order ----

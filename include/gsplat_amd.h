@@ -439,6 +439,17 @@ int gsx_raster2d_bwd(const float *means2d, const float *ray_transforms, const fl
                      uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows,
                      uint32_t row_stride, void *stream);
 
+/* Instrumentation (no reference counterpart): work counters of the compositing pass, for the vector-ALU roofline of
+ * bench.py (pairs x (14 + 2 D) flop against the fp32 peak). Replays the forward walk of
+ * gsx_raster3d_fwd and ADDS to stats[0..3] (caller zeroes them):
+ *   [0] (pixel, Gaussian) pairs a per-pixel serial walk evaluates (the reference kernel's work: every list entry up to
+ *       and including the one that saturates the pixel), [1] lane evaluations of this backend (64 x (wave, Gaussian) pairs
+ *       surviving the wave-level culling), [2] of those the lanes whose pixel was still open, [3] contributing pairs. */
+int gsx_raster3d_pair_stats(const float *means2d, const float *conics, const float *opacities,
+                            const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images,
+                            uint32_t n_isects, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w,
+                            uint32_t tile_h, uint64_t *stats, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Query rasterizers (dense tile layout): gsplat::rasterize_num_contributing_gaussians,
  * rasterize_contributing_gaussian_ids, rasterize_top_contributing_gaussian_ids (ext.cpp:1111-1134; kernels

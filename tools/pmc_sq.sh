@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counter passes over bench.py --lean for the compositing kernels (separate rocprofv3 passes, 8 counters max each).
-# usage: gpurun -- 'bash tools/pmc_sq.sh <tag> [kernel-substring]'
+# usage: gpurun -- '[CMD="python tools/bench_2dgs.py"] bash tools/pmc_sq.sh <tag> [kernel-substring]'
 TAG=${1:-pmc}; PAT=${2:-raster3d}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
@@ -11,7 +11,7 @@ for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CY
            "SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_LDS_ADDR_CONFLICT SQ_BUSY_CU_CYCLES" \
            "GRBM_GUI_ACTIVE SQ_CYCLES SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INST_LEVEL_LDS"; do
   i=$((i+1)); rm -rf /tmp/pmc_$i
-  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $pmc -d /tmp/pmc_$i -o p -- python $ROOT/bench.py --lean --steps 5 --warmup 2 > $OUT/pass_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $pmc -d /tmp/pmc_$i -o p -- ${CMD:-python $ROOT/bench.py --lean --steps 5 --warmup 2} > $OUT/pass_$i.log 2>&1
 done
 python - "$PAT" > $OUT/sq_counters.txt <<'PY'
 import csv, glob, sys

@@ -60,6 +60,17 @@ def main():
                 hbm[name] = {"bytes": int((cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
                              "fetch_bytes": int(cs["FETCH_SIZE"] * 1024), "write_bytes": int(cs["WRITE_SIZE"] * 1024),
                              "bytes_if_fetch_x2": int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)}
+        import subprocess
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        try:
+            commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                    timeout=5).stdout.strip() or os.environ.get("GSX_COMMIT")
+        except Exception:
+            commit = os.environ.get("GSX_COMMIT")
+        # the GPU box has no .git: tools/gpu_profile.sh is told the commit through GSX_COMMIT
+        hbm["_meta"] = {"commit": commit or os.environ.get("GSX_COMMIT"), "tag": os.path.basename(os.path.normpath(out)),
+                        "workload": "bench.py --lean (c3)"}
         json.dump(hbm, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 
 
