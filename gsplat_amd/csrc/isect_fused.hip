@@ -39,21 +39,20 @@ struct RowGeom {
 };
 __device__ __forceinline__ RowGeom load_row_geom(const FusedArgs &a, int64_t r, bool has_conic)
 {
+    // every field is read unconditionally (dead rows included): no read depends on another one's result
     RowGeom q;
     q.rx = (float)a.radii[2 * r];
     q.ry = (float)a.radii[2 * r + 1];
-    q.live = q.rx > 0.0f && q.ry > 0.0f;
-    q.mx = q.my = q.A = q.B = q.C = q.op = 0.0f;
-    if (q.live) {
-        q.mx = a.means2d[2 * r];
-        q.my = a.means2d[2 * r + 1];
-        if (has_conic) {
-            q.A  = a.conics[3 * r];
-            q.B  = a.conics[3 * r + 1];
-            q.C  = a.conics[3 * r + 2];
-            q.op = a.opacities[r];
-        }
+    q.mx = a.means2d[2 * r];
+    q.my = a.means2d[2 * r + 1];
+    q.A = q.B = q.C = q.op = 0.0f;
+    if (has_conic) {
+        q.A  = a.conics[3 * r];
+        q.B  = a.conics[3 * r + 1];
+        q.C  = a.conics[3 * r + 2];
+        q.op = a.opacities[r];
     }
+    q.live = q.rx > 0.0f && q.ry > 0.0f;
     return q;
 }
 
@@ -80,9 +79,12 @@ __device__ __forceinline__ int size_class(const FusedArgs &a, int64_t r)
     return 62 - min(area, 62); // 0 = the largest boxes, 62 = nothing on screen
 }
 
-// visits the rows [lo, hi) of a chunk, `body(row)` once per row, in balanced order
-template <typename Body>
-__device__ __forceinline__ void for_rows_balanced(const FusedArgs &a, int64_t lo, int64_t hi, Body &&body)
+// visits the rows [lo, hi) of a chunk in balanced order: `load(row)` for ALL rows of this thread first, then
+// `body(row, data)` once per row. The walk of a row starts with two dependent global reads (radii, then the geometry of a
+// live row); issued row by row they cost two full memory latencies per row at 16 waves per CU - 46 of the 62 us of the
+// counting kernel on c3 (r05 ablation). Loading the kPer rows of a thread up front turns eight serial latencies into one.
+template <typename Load, typename Body>
+__device__ __forceinline__ void for_rows_balanced(const FusedArgs &a, int64_t lo, int64_t hi, Load &&load, Body &&body)
 {
     __shared__ uint16_t s_order[kFusedSub];
     __shared__ int32_t s_cnt[64];
@@ -114,11 +116,17 @@ __device__ __forceinline__ void for_rows_balanced(const FusedArgs &a, int64_t lo
         for (int q = 0; q < kPer; ++q)
             if (cls[q] >= 0) s_order[atomicAdd(&s_cnt[cls[q]], 1)] = (uint16_t)((int)threadIdx.x + q * kFusedThreads);
         __syncthreads();
+        int64_t rows[kPer];
+        decltype(load((int64_t)0)) data[kPer];
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
             const int i = (int)threadIdx.x + q * kFusedThreads;
-            if (i < n) body(sub + (int64_t)s_order[i]);
+            rows[q]     = i < n ? sub + (int64_t)s_order[i] : -1;
+            if (rows[q] >= 0) data[q] = load(rows[q]);
         }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q)
+            if (rows[q] >= 0) body(rows[q], data[q]);
         __syncthreads(); // s_order / s_cnt are reused by the next sub-chunk
     }
 }
@@ -133,16 +141,17 @@ __global__ void __launch_bounds__(kFusedThreads) fused_count_hist_kernel(const F
     chunk_rows(g, blockIdx.x, lo, hi);
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)(blockIdx.x / g.cpi) * g.n_tiles : nullptr;
-    for_rows_balanced(a, lo, hi, [&](int64_t r) {
-        const RowGeom q = load_row_geom(a, r, has_conic);
-        int32_t n       = 0;
-        if (q.live)
-            n = walk_tiles(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h,
-                           [&](int64_t tile) {
-                               if (!tmask || tmask[tile]) atomicAdd(&s_hist[tile], 1);
-                           });
-        if (a.tiles_per_gauss) a.tiles_per_gauss[r] = n;
-    });
+    for_rows_balanced(
+        a, lo, hi, [&](int64_t r) { return load_row_geom(a, r, has_conic); },
+        [&](int64_t r, const RowGeom &q) {
+            int32_t n = 0;
+            if (q.live)
+                n = walk_tiles(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h,
+                               [&](int64_t tile) {
+                                   if (!tmask || tmask[tile]) atomicAdd(&s_hist[tile], 1);
+                               });
+            if (a.tiles_per_gauss) a.tiles_per_gauss[r] = n;
+        });
     __syncthreads();
     int32_t *out = a.table + (int64_t)blockIdx.x * g.n_tiles;
     for (uint32_t t = threadIdx.x; t < g.n_tiles; t += kFusedThreads) out[t] = s_hist[t];
@@ -161,17 +170,29 @@ __global__ void __launch_bounds__(kFusedThreads) fused_emit_scatter_kernel(const
     chunk_rows(g, blockIdx.x, lo, hi);
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)img * g.n_tiles : nullptr;
-    for_rows_balanced(a, lo, hi, [&](int64_t r) {
-        const RowGeom q = load_row_geom(a, r, has_conic);
-        if (!q.live) return;
-        const uint32_t dbits = __float_as_uint(a.depths[r]);
-        walk_tiles(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h,
-                   [&](int64_t tile) {
-                       if (tmask && !tmask[tile]) return;
-                       const int32_t slot = atomicAdd(&s_cur[tile], 1);
-                       a.bucketed[slot]   = make_uint2(dbits, (uint32_t)r);
-                   });
-    });
+    struct RowEmit {
+        RowGeom q;
+        uint32_t dbits;
+    };
+    for_rows_balanced(
+        a, lo, hi,
+        [&](int64_t r) {
+            RowEmit e;
+            e.q     = load_row_geom(a, r, has_conic);
+            e.dbits = __float_as_uint(a.depths[r]);
+            return e;
+        },
+        [&](int64_t r, const RowEmit &e) {
+            const RowGeom &q = e.q;
+            if (!q.live) return;
+            const uint32_t dbits = e.dbits;
+            walk_tiles(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h,
+                       [&](int64_t tile) {
+                           if (tmask && !tmask[tile]) return;
+                           const int32_t slot = atomicAdd(&s_cur[tile], 1);
+                           a.bucketed[slot]   = make_uint2(dbits, (uint32_t)r);
+                       });
+        });
 }
 
 static void set_lds_limit_once()
