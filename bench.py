@@ -104,8 +104,11 @@ def timed(step_fn, steps, warmup, barrier, profile_only=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         meta = step_fn()
+    t_enq = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("GSPLAT_BENCH_DEBUG"):  # host-side enqueue time vs. wall time of the timed steps
+        print(f"[bench] enqueue {t_enq / steps * 1e3:.3f} ms/step, wall {elapsed / steps * 1e3:.3f} ms/step", file=sys.stderr)
     prof = _cabi.profile_end() if profile_only else {}
     return elapsed, meta, prof
 
