@@ -1,26 +1,35 @@
-"""The densification schedule of the original 3DGS paper, optionally with AbsGS gradients (reference
-``gsplat/strategy/default.py:30-377``): duplicate small Gaussians and split large ones whose screen-space gradient is
-high, prune transparent / oversized ones, reset opacities periodically. Consumes the ``meta`` dict returned by
-``gsplat_amd.rasterization`` (``means2d`` with its ``.grad`` / ``.absgrad``, ``radii``, ``gaussian_ids``, ``width``,
-``height``, ``n_cameras``)."""
+"""The densification schedule of the original 3DGS paper, optionally with AbsGS gradients - same class name, fields,
+defaults and callbacks as the reference (``gsplat/strategy/default.py:30-377``), so a training script switches by changing
+an import. Consumes the ``meta`` dict of ``gsplat_amd.rasterization`` (``means2d`` with ``.grad`` / ``.absgrad``, ``radii``,
+``gaussian_ids``, ``width``, ``height``, ``n_cameras``).
+
+What differs is HOW a refinement is carried out. The reference edits the model three times in a row (duplicate, split,
+prune), each time rebuilding every parameter and every optimizer moment. Here a refinement is PLANNED on four per-row
+vectors - mean screen-space gradient, largest scale, opacity, largest screen radius - and executed as one ``RowPlan``
+(``strategy/ops.py``): which old row every surviving new row copies, which rows start with fresh optimizer moments, and the
+few values that are not copies (sampled positions and shrunken scales of split children, revised opacities). The pruning
+test of the reference runs AFTER growth, on the children too; since a child's opacity and scale are known functions of its
+parent's, the same test is evaluated on the plan before anything is materialised."""
 from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import Any, Dict, Tuple, Union
 
 import torch
+import torch.nn.functional as F
+from torch import Tensor
 
 from .base import Strategy
-from .ops import duplicate, remove, reset_opa, split
+from .ops import RowPlan, _quat_to_rotmat, apply_plan, reset_opa
 
 Params = Union[Dict[str, torch.nn.Parameter], torch.nn.ParameterDict]
+
+_SPLIT_SHRINK = 1.6  # scale of a split child = parent's / 1.6 (reference ops.py: split)
 
 
 @dataclass
 class DefaultStrategy(Strategy):
-    """Same fields and defaults as the reference class.
-
-    >>> strategy = DefaultStrategy(); strategy.check_sanity(params, optimizers); state = strategy.initialize_state()
+    """>>> strategy = DefaultStrategy(); strategy.check_sanity(params, optimizers); state = strategy.initialize_state()
     >>> for step in range(n):
     ...     colors, alphas, info = rasterization(...)
     ...     strategy.step_pre_backward(params, optimizers, state, step, info)
@@ -45,6 +54,7 @@ class DefaultStrategy(Strategy):
     verbose: bool = False
     key_for_gradient: str = "means2d"  # "gradient_2dgs" for rasterization_2dgs
 
+    # ---- interface -----------------------------------------------------------------------------------------------------
     def initialize_state(self, scene_scale: float = 1.0) -> Dict[str, Any]:
         state: Dict[str, Any] = {"grad2d": None, "count": None, "scene_scale": scene_scale}
         if self.refine_scale2d_stop_iter > 0:
@@ -53,92 +63,107 @@ class DefaultStrategy(Strategy):
 
     def check_sanity(self, params: Params, optimizers: Dict[str, torch.optim.Optimizer]):
         super().check_sanity(params, optimizers)
-        for key in ("means", "scales", "quats", "opacities"):
-            assert key in params, f"{key} is required in params but missing."
+        missing = [k for k in ("means", "scales", "quats", "opacities") if k not in params]
+        assert not missing, f"params lacks {missing}"
 
     def step_pre_backward(self, params: Params, optimizers, state: Dict[str, Any], step: int, info: Dict[str, Any]):
-        assert self.key_for_gradient in info, "The 2D means of the Gaussians is required but missing."
+        assert self.key_for_gradient in info, f"info['{self.key_for_gradient}'] (the projected means) is needed"
         info[self.key_for_gradient].retain_grad()
 
     def step_post_backward(self, params: Params, optimizers, state: Dict[str, Any], step: int, info: Dict[str, Any],
                            packed: bool = False):
         if step >= self.refine_stop_iter:
             return
-        self._update_state(params, state, info, packed=packed)
-        refine_now = (step > self.refine_start_iter and step % self.refine_every == 0
-                      and step % self.reset_every >= self.pause_refine_after_reset)
-        if refine_now:
-            n_dupli, n_split = self._grow_gs(params, optimizers, state, step)
+        self._accumulate(params, state, info, packed)
+        due = step > self.refine_start_iter and step % self.refine_every == 0
+        if due and step % self.reset_every >= self.pause_refine_after_reset:
+            counts = self._refine(params, optimizers, state, step)
             if self.verbose:
-                print(f"Step {step}: {n_dupli} GSs duplicated, {n_split} GSs split. Now having {len(params['means'])} GSs.")
-            n_prune = self._prune_gs(params, optimizers, state, step)
-            if self.verbose:
-                print(f"Step {step}: {n_prune} GSs pruned. Now having {len(params['means'])} GSs.")
-            state["grad2d"].zero_()
-            state["count"].zero_()
-            if self.refine_scale2d_stop_iter > 0:
-                state["radii"].zero_()
+                print("step {}: +{} duplicated, +{} split, -{} pruned -> {} Gaussians".format(step, *counts,
+                                                                                              len(params["means"])))
             torch.cuda.empty_cache()
-        if step % self.reset_every == 0 and step > 0:
+        if step > 0 and step % self.reset_every == 0:
             reset_opa(params=params, optimizers=optimizers, state=state, value=self.prune_opa * 2.0)
 
-    # -- running statistics: summed screen-space gradient norm and visibility count per Gaussian ---------------------
-    def _update_state(self, params: Params, state: Dict[str, Any], info: Dict[str, Any], packed: bool = False):
-        for key in ("width", "height", "n_cameras", "radii", "gaussian_ids", self.key_for_gradient):
-            assert key in info, f"{key} is required but missing."
+    # ---- statistics ----------------------------------------------------------------------------------------------------
+    def _accumulate(self, params: Params, state: Dict[str, Any], info: Dict[str, Any], packed: bool) -> None:
+        """Per Gaussian: summed norm of the screen-space gradient (in [-1, 1] image units, 1/C of a mean loss undone),
+        number of views it was visible in, largest relative screen radius."""
+        need = ("width", "height", "n_cameras", "radii", "gaussian_ids", self.key_for_gradient)
+        lacking = [k for k in need if k not in info]
+        assert not lacking, f"info lacks {lacking}"
         g = info[self.key_for_gradient]
-        grads = (g.absgrad if self.absgrad else g.grad).clone()
-        # gradients are w.r.t. pixel coordinates: normalise to [-1, 1] image coordinates, undo the 1/C of a mean loss
-        grads[..., 0] *= info["width"] / 2.0 * info["n_cameras"]
-        grads[..., 1] *= info["height"] / 2.0 * info["n_cameras"]
-        n = len(next(iter(params.values())))
-        dev = grads.device
-        if state["grad2d"] is None:
-            state["grad2d"] = torch.zeros(n, device=dev)
-        if state["count"] is None:
-            state["count"] = torch.zeros(n, device=dev)
-        if self.refine_scale2d_stop_iter > 0 and state["radii"] is None:
-            state["radii"] = torch.zeros(n, device=dev)
+        grad = g.absgrad if self.absgrad else g.grad
+        half = grad.new_tensor([0.5 * info["width"], 0.5 * info["height"]]) * info["n_cameras"]
+        n, dev = len(params["means"]), grad.device
+        for key in ("grad2d", "count") + (("radii",) if self.refine_scale2d_stop_iter > 0 else ()):
+            if state[key] is None:
+                state[key] = torch.zeros(n, device=dev)
         if packed:
-            ids = info["gaussian_ids"]
-            radii = info["radii"].max(dim=-1).values
+            rows, norms, radius = info["gaussian_ids"], (grad * half).norm(dim=-1), info["radii"].amax(dim=-1)
         else:
-            visible = (info["radii"] > 0.0).all(dim=-1)  # [C, N]
-            ids = torch.where(visible)[1]
-            grads = grads[visible]
-            radii = info["radii"][visible].max(dim=-1).values
-        state["grad2d"].index_add_(0, ids, grads.norm(dim=-1))
-        state["count"].index_add_(0, ids, torch.ones_like(ids, dtype=torch.float32))
+            seen = (info["radii"] > 0).all(dim=-1)  # [C, N]
+            rows = seen.nonzero(as_tuple=True)[1]
+            norms, radius = (grad[seen] * half).norm(dim=-1), info["radii"][seen].amax(dim=-1)
+        state["grad2d"].index_add_(0, rows, norms)
+        state["count"].index_add_(0, rows, torch.ones_like(norms))
         if self.refine_scale2d_stop_iter > 0:
-            state["radii"][ids] = torch.maximum(state["radii"][ids], radii / float(max(info["width"], info["height"])))
+            rel = radius.to(state["radii"].dtype) / float(max(info["width"], info["height"]))
+            state["radii"].scatter_reduce_(0, rows, rel, reduce="amax", include_self=True)
 
+    # ---- one refinement = one plan -------------------------------------------------------------------------------------
     @torch.no_grad()
-    def _grow_gs(self, params: Params, optimizers, state: Dict[str, Any], step: int) -> Tuple[int, int]:
-        mean_grad = state["grad2d"] / state["count"].clamp_min(1)
-        high = mean_grad > self.grow_grad2d
-        small = torch.exp(params["scales"]).max(dim=-1).values <= self.grow_scale3d * state["scene_scale"]
-        is_dupli = high & small
-        is_split = high & ~small
+    def _refine(self, params: Params, optimizers, state: Dict[str, Any], step: int) -> Tuple[int, int, int]:
+        dev = params["means"].device
+        n = len(params["means"])
+        scale = torch.exp(params["scales"])
+        largest = scale.amax(dim=-1)
+        opacity = torch.sigmoid(params["opacities"].flatten())
+        track_radii = self.refine_scale2d_stop_iter > 0
+        screen = state["radii"] if track_radii else None
+
+        hot = state["grad2d"] / state["count"].clamp_min(1) > self.grow_grad2d
+        small = largest <= self.grow_scale3d * state["scene_scale"]
+        clone = hot & small
+        split = hot & ~small
         if step < self.refine_scale2d_stop_iter:
-            is_split |= state["radii"] > self.grow_scale2d
-        n_dupli, n_split = int(is_dupli.sum().item()), int(is_split.sum().item())
-        if n_dupli > 0:
-            duplicate(params=params, optimizers=optimizers, state=state, mask=is_dupli)
-        # the duplicates were appended at the end: they are never split in the same round
-        is_split = torch.cat([is_split, torch.zeros(n_dupli, dtype=torch.bool, device=is_split.device)])
-        if n_split > 0:
-            split(params=params, optimizers=optimizers, state=state, mask=is_split, revised_opacity=self.revised_opacity)
-        return n_dupli, n_split
+            split = split | (screen > self.grow_scale2d)
+        stay_rows = (~split).nonzero(as_tuple=True)[0]
+        clone_rows = clone.nonzero(as_tuple=True)[0]
+        split_rows = split.nonzero(as_tuple=True)[0]
+        n_stay, n_clone, n_split = len(stay_rows), len(clone_rows), len(split_rows)
 
-    @torch.no_grad()
-    def _prune_gs(self, params: Params, optimizers, state: Dict[str, Any], step: int) -> int:
-        is_prune = torch.sigmoid(params["opacities"].flatten()) < self.prune_opa
+        # grown set = originals that are not split | clones | two children per split row
+        src = torch.cat([stay_rows, clone_rows, split_rows, split_rows])
+        fresh = torch.cat([torch.zeros(n_stay, dtype=torch.bool, device=dev),
+                           torch.ones(n_clone + 2 * n_split, dtype=torch.bool, device=dev)])
+        plan = RowPlan(src, fresh)
+        child_rows = torch.arange(n_stay + n_clone, len(src), device=dev)
+        new_opacity, new_largest = opacity[src], largest[src]
+        if n_split:
+            rot = _quat_to_rotmat(F.normalize(params["quats"][split_rows], dim=-1))
+            jitter = torch.einsum("nij,nj,bnj->bni", rot, scale[split_rows], torch.randn(2, n_split, 3, device=dev))
+            plan.set("means", child_rows, (params["means"][split_rows] + jitter).reshape(-1, 3))
+            plan.set("scales", child_rows, torch.log(scale[split_rows] / _SPLIT_SHRINK).repeat(2, 1))
+            new_largest[child_rows] = new_largest[child_rows] / _SPLIT_SHRINK
+            if self.revised_opacity:  # arXiv 2404.06109
+                revised = 1.0 - torch.sqrt(1.0 - opacity[split_rows])
+                plan.set("opacities", child_rows, torch.logit(revised).repeat(2).reshape(
+                    (2 * n_split,) + tuple(params["opacities"].shape[1:])))
+                new_opacity[child_rows] = revised.repeat(2)
+
+        # the reference prunes AFTER growing: the same test, evaluated on the planned rows
+        doomed = new_opacity < self.prune_opa
         if step > self.reset_every:
-            too_big = torch.exp(params["scales"]).max(dim=-1).values > self.prune_scale3d * state["scene_scale"]
+            doomed = doomed | (new_largest > self.prune_scale3d * state["scene_scale"])
             if step < self.refine_scale2d_stop_iter:
-                too_big |= state["radii"] > self.prune_scale2d
-            is_prune |= too_big
-        n_prune = int(is_prune.sum().item())
-        if n_prune > 0:
-            remove(params=params, optimizers=optimizers, state=state, mask=is_prune)
-        return n_prune
+                doomed = doomed | (screen[src] > self.prune_scale2d)
+        n_prune = int(doomed.sum().item())
+        if n_prune:
+            plan = plan.select(~doomed)
+        if n_clone or n_split or n_prune:
+            apply_plan(params, optimizers, state, plan, zero_state=True)
+        else:
+            for key in ("grad2d", "count") + (("radii",) if track_radii else ()):
+                state[key].zero_()
+        return n_clone, n_split, n_prune

@@ -198,3 +198,66 @@ def inject_noise_to_position(params: Params, optimizers: Dict[str, torch.optim.O
     noise = torch.randn_like(means)
     torch.ops.gsplat.mcmc_perturb_positions(means.data, params["quats"].data, params["scales"].data,
                                             params["opacities"].data.reshape(-1), noise, float(scaler), float(t), float(k))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Row plans: ONE rewrite of the model per refinement
+# ----------------------------------------------------------------------------------------------------------------------
+# The reference refines in stages (duplicate, then split, then remove; relocate, then sample_add), and every stage rebuilds
+# every parameter, both Adam moments of every optimizer and the running statistics - three full passes over a model of
+# millions of rows (59 floats per row with degree-3 SH, x3 with the moments). The strategies of this package instead derive
+# a single RowPlan for the whole refinement from a few per-row vectors (opacity, largest scale, statistics) and apply it
+# once: every tensor is gathered exactly one time.
+class RowPlan:
+    """New row j of the Gaussian set is a copy of old row ``src[j]``.
+
+    ``fresh[j]``: its optimizer moments start at zero instead of being inherited. ``values[name]`` = (rows, tensor):
+    after the gather, ``new[name][rows] = tensor`` (rows index the NEW set)."""
+
+    def __init__(self, src: Tensor, fresh: Tensor):
+        self.src, self.fresh = src, fresh
+        self.values: Dict[str, tuple] = {}
+
+    def set(self, name: str, rows: Tensor, values: Tensor) -> None:
+        self.values[name] = (rows, values)
+
+    def select(self, keep: Tensor) -> "RowPlan":
+        """The plan restricted to the new rows selected by the bool mask ``keep`` (row overrides are renumbered)."""
+        out = RowPlan(self.src[keep], self.fresh[keep])
+        new_index = torch.cumsum(keep, 0) - 1
+        for name, (rows, vals) in self.values.items():
+            k = keep[rows]
+            out.values[name] = (new_index[rows[k]], vals[k])
+        return out
+
+    def __len__(self) -> int:
+        return int(self.src.numel())
+
+
+@torch.no_grad()
+def apply_plan(params: Params, optimizers: Dict[str, torch.optim.Optimizer], state: Dict[str, Tensor], plan: RowPlan,
+               zero_state: bool = False) -> None:
+    """Rebuild every parameter, its optimizer moments and the per-Gaussian statistics in ``state`` through ``plan``
+    (statistics: inherited through the plan, or zeroed when ``zero_state``)."""
+    src, fresh = plan.src, plan.fresh
+    n_old = len(next(iter(params.values())))
+    any_fresh = bool(fresh.any().item()) if fresh.numel() else False
+
+    def param_fn(name: str, p: Tensor) -> Tensor:
+        new = p.detach()[src]
+        if name in plan.values:
+            rows, vals = plan.values[name]
+            new[rows] = vals.to(new.dtype).reshape((rows.numel(),) + tuple(new.shape[1:]))
+        return _as_param(new, p)
+
+    def optimizer_fn(key: str, v: Tensor) -> Tensor:
+        new = v[src]
+        if any_fresh:
+            new[fresh] = 0
+        return new
+
+    _update_param_with_optimizer(param_fn, optimizer_fn, params, optimizers)
+    for k, v in state.items():
+        if isinstance(v, Tensor) and v.dim() >= 1 and v.shape[0] == n_old:
+            state[k] = (torch.zeros((len(plan),) + tuple(v.shape[1:]), device=v.device, dtype=v.dtype) if zero_state
+                        else v[src])
