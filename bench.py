@@ -117,7 +117,7 @@ def pair_stats(meta, n_images, W, H):
     """Work counters of the compositing pass (C-ABI gsx_raster3d_pair_stats: instrumentation, replays the forward walk)."""
     from gsplat_amd._cabi import call, ptr
 
-    stats = torch.zeros(4, dtype=torch.int64, device=meta["means2d"].device)
+    stats = torch.zeros(8, dtype=torch.int64, device=meta["means2d"].device)
     tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
     call("gsx_raster3d_pair_stats", ptr(meta["means2d"].contiguous()), ptr(meta["conics"].contiguous()),
          ptr(meta["opacities"].contiguous()), ptr(meta["isect_offsets"].contiguous()), ptr(meta["flatten_ids"]),
@@ -280,7 +280,7 @@ def main():
         fl = 14 + 2 * D
         valu = {
             "pairs_reference_walk": ps[0], "lane_evaluations": ps[1], "lane_evaluations_open_pixels": ps[2],
-            "contributing_pairs": ps[3], "flop_per_pair": fl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "contributing_pairs": ps[3], "lane_evaluations_of_empty_wave_pairs": ps[4], "flop_per_pair": fl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             # the reference kernel's work (every list entry up to saturation, per pixel) done in this kernel's time ...
             "fwd_reference_work_TFLOPs": round(ps[0] * fl / (t_fwd * 1e-3) / 1e12, 2) if t_fwd == t_fwd else None,
             # ... and what the vector ALU really executed (after wave-level culling), forward only

@@ -135,6 +135,14 @@ def ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+def ptr_host(t: torch.Tensor):
+    """Address of a PINNED host tensor, for the few scalar results a kernel writes straight into host memory (pinned
+    memory is mapped into the device's address space: no device-to-host copy kernel is needed for 8 bytes)."""
+    if t.is_cuda or not t.is_pinned():
+        raise GsplatAmdError("gsplat_amd: expected a pinned host tensor")
+    return t.data_ptr()
+
+
 def ptr_strided(t: torch.Tensor):
     """Device pointer of a tensor whose layout the caller has already checked (row-strided views)."""
     if not t.is_cuda:

@@ -368,11 +368,10 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
         st.count_ws = torch.empty(_cabi.isect_fused_count_workspace_bytes(rows, I, tile_width, tile_height), device=dev,
                                   dtype=torch.uint8)
         st.offsets = torch.empty(I * tile_width * tile_height, device=dev, dtype=torch.int32)
-        st.n_dev = torch.empty(1, device=dev, dtype=torch.int64)
+        # the grand total is written by the scan kernel straight into the pinned host word (no copy kernel)
         call("gsx_isect_fused_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), None, rows, I, tile_size,
-             tile_width, tile_height, ptr(st.tiles_per_gauss), ptr(st.offsets), ptr(st.n_dev), ptr(st.count_ws),
-             st.count_ws.numel())
-        st.host_total.copy_(st.n_dev, non_blocking=True)
+             tile_width, tile_height, ptr(st.tiles_per_gauss), ptr(st.offsets), _cabi.ptr_host(st.host_total),
+             ptr(st.count_ws), st.count_ws.numel())
         st.event = torch.cuda.Event()
         st.event.record()
         return st

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
 
     float T        = 1.0f;
     uint32_t count = 0; // contributions so far (= depth index of the next one)
-    uint32_t walked = 0, wave_evals = 0, lane_evals = 0; // kQStats: see gsx_raster3d_pair_stats
+    uint32_t walked = 0, wave_evals = 0, lane_evals = 0, empty_evals = 0; // kQStats: see gsx_raster3d_pair_stats
     bool done      = !inside;
     if constexpr (MODE == kQTop) {
         for (uint32_t k = 0; k < a.K; ++k) {
@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
                 if constexpr (MODE == kQStats) {
                     ++wave_evals;
                     lane_evals += done ? 0u : 1u;
+                    empty_evals += __builtin_amdgcn_ballot_w64(inside && !(q < 0.0f) && !(alpha < kAlphaThreshold)) == 0ull ? 1u : 0u;
                 }
                 if (done || q < 0.0f || alpha < kAlphaThreshold) continue;
                 const float next_T = T * (1.0f - alpha);
@@ -169,6 +170,7 @@ __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
             atomicAdd(&a.stats[1], 64ull * wave_evals);
             atomicAdd(&a.stats[2], v2);
             atomicAdd(&a.stats[3], v3);
+            atomicAdd(&a.stats[4], 64ull * empty_evals);
         }
         return;
     }

@@ -281,7 +281,8 @@ int gsx_isect_offsets(const int64_t *isect_ids_sorted, int64_t n_isects, uint32_
  * passes never touch HBM (8 B instead of 40 B per intersection ahead of the per-tile sort; csrc/isect_fused.hip).
  * Dense rows [n_images * N] (any n_images while n_images * tiles fits the LDS histogram), or packed rows of ONE image.
  *   1. gsx_isect_fused_count: tiles_per_gauss int32 [rows], isect_offsets int32 [n_images * tiles] (= intersect_offset),
- *      *n_isects (device int64). The caller reads n_isects, allocates the exact-length outputs, then
+ *      *n_isects (int64 in device memory OR in pinned, device-mapped host memory: 8 bytes need no copy kernel). The caller
+ *      reads n_isects, allocates the exact-length outputs, then
  *   2. gsx_isect_fused_emit_sort with the SAME count workspace: isect_ids int64 [n_isects], flatten_ids int32 [n_isects].
  * ------------------------------------------------------------------------------------------- */
 int gsx_isect_fused_supported(uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed);
@@ -444,7 +445,8 @@ int gsx_raster2d_bwd(const float *means2d, const float *ray_transforms, const fl
  * gsx_raster3d_fwd and ADDS to stats[0..3] (caller zeroes them):
  *   [0] (pixel, Gaussian) pairs a per-pixel serial walk evaluates (the reference kernel's work: every list entry up to
  *       and including the one that saturates the pixel), [1] lane evaluations of this backend (64 x (wave, Gaussian) pairs
- *       surviving the wave-level culling), [2] of those the lanes whose pixel was still open, [3] contributing pairs. */
+ *       surviving the wave-level culling), [2] of those the lanes whose pixel was still open, [3] contributing pairs,
+ *   [4] lane evaluations of (wave, Gaussian) pairs in which no lane passes the alpha test. stats has 8 words. */
 int gsx_raster3d_pair_stats(const float *means2d, const float *conics, const float *opacities,
                             const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images,
                             uint32_t n_isects, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w,
