@@ -50,7 +50,26 @@ def _load_torch_classes() -> Optional[str]:
         torch.classes.load_library(path)
     except OSError as e:
         return f"cannot load {path}: {e}"
+    _read_compiled_ops(path)
     return None
+
+
+COMPILED_OPS: frozenset = frozenset()  # ops whose CUDA-key body is C++ (csrc/torch_ops.cpp) rather than a function of this file
+
+
+def _read_compiled_ops(path: str) -> None:
+    """libgsplat_amd_torch.so also carries compiled op bodies (csrc/torch_ops.cpp: TORCH_LIBRARY_IMPL(gsplat, CUDA) for the
+    hot stage ops, INTEGRATION.md route B). It names them through gsx_torch_compiled_ops(); _register() below keeps the
+    Python body of every OTHER op. GSPLAT_AMD_COMPILED_OPS=0 puts the Python bodies back (A/B of the host overhead)."""
+    global COMPILED_OPS
+    import ctypes
+
+    try:
+        fn = ctypes.CDLL(path).gsx_torch_compiled_ops
+    except (OSError, AttributeError):
+        return
+    fn.restype = ctypes.c_char_p
+    COMPILED_OPS = frozenset(fn().decode().split())
 
 
 COMPOSITE_UNAVAILABLE = _load_torch_classes()
@@ -1609,6 +1628,12 @@ def rasterization_2dgs(means, quats, scales, opacities, colors, viewmats, Ks, im
 # ----------------------------------------------------------------------------------------------
 # registration
 # ----------------------------------------------------------------------------------------------
+def _os_environ_get(k, d):
+    import os
+
+    return os.environ.get(k, d)
+
+
 def _register():
     for name, schema in SCHEMAS.items():
         qual = f"{NS}::{name}"
@@ -1620,7 +1645,10 @@ def _register():
         if not exists:
             _lib_def.define(name + schema)
         fn = _impls[name]
-        _lib_impl.impl(name, fn)
+        if name not in COMPILED_OPS:
+            _lib_impl.impl(name, fn)
+        elif _os_environ_get("GSPLAT_AMD_COMPILED_OPS", "1") in ("0", ""):
+            _lib_impl.impl(name, fn, allow_override=True)
     if COMPOSITE_UNAVAILABLE is None:
         for name, schema in COMPOSITE_SCHEMAS.items():
             try:

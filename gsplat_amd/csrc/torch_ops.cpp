@@ -1,0 +1,476 @@
+// Compiled op bodies: TORCH_LIBRARY_IMPL(gsplat, CUDA, ...) for the hot stage ops, calling the C-ABI of libgsplat_amd.so
+// (INTEGRATION.md route B). Host C++ only - no device code here; the kernels stay behind include/gsplat_amd.h.
+//
+// What an op body does is what the reference's host functions do around their kernels (shape checks, output allocation
+// from the inputs' options, current stream, device guard, error translation):
+//   projection_ewa_3dgs_fused{,_bwd}   gsplat/cuda/csrc/Projection.cpp:366-440, 579-694
+//   spherical_harmonics{,_bwd}         gsplat/cuda/csrc/SphericalHarmonics.cpp (ext.cpp:994-1014)
+//   intersect_tile, intersect_offset   gsplat/cuda/csrc/Intersect.cpp:170-329
+//   rasterize_to_pixels_3dgs{,_bwd}    gsplat/cuda/csrc/Rasterization.cpp:275-365, 484-587
+// The Python bodies in gsplat_amd/_ops.py remain the implementation of every other op and of the private fast paths of
+// gsplat_amd/rendering.py; _ops.py skips registering its own body for an op listed by gsx_torch_compiled_ops().
+// Schemas are defined by _ops.py (verbatim from ext.cpp); an IMPL block may be loaded before or after the definitions.
+#include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
+#include <torch/library.h>
+
+#include <cmath>
+#include <string>
+#include <tuple>
+
+#include "../../include/gsplat_amd.h"
+
+namespace gsplat_amd {
+namespace {
+
+using at::Tensor;
+using OptTensor = std::optional<Tensor>;
+
+// ---- plumbing ----------------------------------------------------------------------------------------------------------
+struct Launch { // device guard + the tensor's device's current stream (the reference's DEVICE_GUARD + getCurrentCUDAStream)
+    c10::DeviceGuard guard;
+    void *stream;
+    explicit Launch(const Tensor &t)
+        : guard(t.device()), stream((void *)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream())
+    {
+        TORCH_CHECK(t.is_cuda(), "gsplat_amd kernels only run on a ROCm device (got a CPU tensor); there is no CPU fallback");
+    }
+};
+
+void check(int rc, const char *fn)
+{
+    if (rc == 0) return;
+    const std::string msg = gsx_last_error();
+    TORCH_CHECK_VALUE(rc != -1, fn, ": ", msg); // GSX_ERR_ARG -> ValueError, like TORCH_CHECK_VALUE in the reference
+    TORCH_CHECK(false, fn, " failed (code ", rc, "): ", msg);
+}
+
+Tensor contig(const Tensor &t) { return t.is_contiguous() ? t : t.contiguous(); }
+OptTensor contig(const OptTensor &t) { return t.has_value() && t->defined() ? OptTensor(contig(*t)) : OptTensor(); }
+bool has(const OptTensor &t) { return t.has_value() && t->defined(); }
+
+void want_f32(const Tensor &t, const char *name)
+{
+    TORCH_CHECK_TYPE(t.scalar_type() == at::kFloat, "gsplat_amd: ", name, " must be float32 (got ", t.scalar_type(),
+                     "); the gfx950 kernels compute in fp32");
+}
+void want_f32(const OptTensor &t, const char *name)
+{
+    if (has(t)) want_f32(*t, name);
+}
+
+template <class T> const T *cp(const Tensor &t) { return t.defined() && t.numel() ? t.const_data_ptr<T>() : nullptr; }
+template <class T> const T *cp(const OptTensor &t) { return has(t) ? cp<T>(*t) : nullptr; }
+template <class T> T *mp(Tensor &t) { return t.defined() && t.numel() ? t.mutable_data_ptr<T>() : nullptr; }
+const float *fp(const Tensor &t) { return cp<float>(t); }
+const float *fp(const OptTensor &t) { return cp<float>(t); }
+
+// (tensor, row stride in floats) of a [..., width] float tensor whose rows are `width` contiguous floats at a uniform stride -
+// e.g. a column view of the array-of-structures gradient rows returned by rasterize_to_pixels_3dgs_bwd - else a copy
+std::pair<Tensor, uint32_t> row_view(const Tensor &t, int64_t width)
+{
+    if (t.is_contiguous()) return {t, (uint32_t)width};
+    if (t.dim() >= 2 && t.size(-1) == width && t.stride(-1) == 1) {
+        const int64_t rs = t.stride(-2);
+        bool uniform = rs >= width;
+        int64_t expect = rs * t.size(-2);
+        for (int64_t d = t.dim() - 3; d >= 0 && uniform; --d) {
+            if (t.size(d) != 1 && t.stride(d) != expect) uniform = false;
+            expect *= t.size(d);
+        }
+        if (uniform) return {t, (uint32_t)rs};
+    }
+    return {t.contiguous(), (uint32_t)width};
+}
+std::pair<Tensor, uint32_t> row_view_1(const Tensor &t) // [...] scalars per row
+{
+    return {t.contiguous(), 1u};
+}
+
+int64_t prod(c10::IntArrayRef dims)
+{
+    int64_t p = 1;
+    for (auto d : dims) p *= d;
+    return p;
+}
+
+uint32_t bits_for_count(int64_t count) // MathUtils.h:25-35
+{
+    uint32_t b = 0;
+    if (count <= 1) return 0;
+    uint64_t v = (uint64_t)count - 1;
+    while (v) {
+        ++b;
+        v >>= 1;
+    }
+    return b;
+}
+
+// ---- projection (dense) ------------------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor, Tensor, OptTensor>
+projection_ewa_3dgs_fused(const Tensor &means_, const OptTensor &covars_, const OptTensor &quats_, const OptTensor &scales_,
+                          const OptTensor &opacities_, const Tensor &viewmats_, const Tensor &Ks_, int64_t width,
+                          int64_t height, double eps2d, double near_plane, double far_plane, double radius_clip,
+                          bool calc_compensations, int64_t camera_model)
+{
+    want_f32(means_, "means"); want_f32(covars_, "covars"); want_f32(quats_, "quats"); want_f32(scales_, "scales");
+    want_f32(viewmats_, "viewmats"); want_f32(Ks_, "Ks");
+    TORCH_CHECK_VALUE(has(covars_) || (has(quats_) && has(scales_)), "projection: either covars or (quats, scales) must be given");
+    Launch L(means_);
+    const Tensor means = contig(means_), viewmats = contig(viewmats_), Ks = contig(Ks_);
+    const OptTensor covars = contig(covars_), opac = contig(opacities_);
+    const OptTensor quats = has(covars) ? OptTensor() : contig(quats_), scales = has(covars) ? OptTensor() : contig(scales_);
+    auto batch = means.sizes().slice(0, means.dim() - 2);
+    const int64_t B = prod(batch), C = viewmats.size(-3), N = means.size(-2);
+    std::vector<int64_t> shape(batch.begin(), batch.end());
+    shape.push_back(C); shape.push_back(N);
+    auto with = [&](int64_t last) { auto s = shape; s.push_back(last); return s; };
+    Tensor radii = at::empty(with(2), means.options().dtype(at::kInt));
+    Tensor means2d = at::empty(with(2), means.options()), depths = at::empty(shape, means.options());
+    Tensor conics = at::empty(with(3), means.options());
+    OptTensor comps;
+    if (calc_compensations) comps = at::empty(shape, means.options());
+    check(gsx_project_ewa_fwd(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
+                              (uint32_t)C, (uint32_t)N, (uint32_t)width, (uint32_t)height, (float)eps2d, (float)near_plane,
+                              (float)far_plane, (float)radius_clip, (int)camera_model, mp<int32_t>(radii), mp<float>(means2d),
+                              mp<float>(depths), mp<float>(conics), comps ? mp<float>(*comps) : nullptr, L.stream),
+          "gsx_project_ewa_fwd");
+    return {radii, means2d, depths, conics, comps};
+}
+
+std::tuple<Tensor, OptTensor, OptTensor, OptTensor, OptTensor>
+projection_ewa_3dgs_fused_bwd(const Tensor &means_, const OptTensor &covars_, const OptTensor &quats_, const OptTensor &scales_,
+                              const Tensor &viewmats_, const Tensor &Ks_, int64_t width, int64_t height, double eps2d,
+                              int64_t camera_model, const Tensor &radii, const Tensor &conics, const OptTensor &compensations,
+                              const Tensor &v_means2d_, const Tensor &v_depths_, const Tensor &v_conics_,
+                              const OptTensor &v_compensations, bool viewmats_requires_grad)
+{
+    Launch L(means_);
+    const Tensor means = contig(means_), viewmats = contig(viewmats_), Ks = contig(Ks_);
+    const OptTensor covars = contig(covars_);
+    const OptTensor quats = has(covars) ? OptTensor() : contig(quats_), scales = has(covars) ? OptTensor() : contig(scales_);
+    auto batch = means.sizes().slice(0, means.dim() - 2);
+    const int64_t B = prod(batch), C = viewmats.size(-3), N = means.size(-2);
+    Tensor v_means = at::empty_like(means);
+    OptTensor v_covars, v_quats, v_scales, v_viewmats;
+    if (has(covars)) v_covars = at::empty_like(*covars);
+    else { v_quats = at::empty_like(*quats); v_scales = at::empty_like(*scales); }
+    if (viewmats_requires_grad) v_viewmats = at::zeros_like(viewmats);
+    auto [vm2, m2s] = row_view(v_means2d_, 2);
+    auto [vcn, cns] = row_view(v_conics_, 3);
+    const Tensor vdep = v_depths_.defined() ? contig(v_depths_) : Tensor();
+    const Tensor rad = contig(radii), con = contig(conics);
+    const OptTensor comp = contig(compensations), vcomp = contig(v_compensations);
+    check(gsx_project_ewa_bwd(fp(means), fp(covars), fp(quats), fp(scales), fp(viewmats), fp(Ks), (uint32_t)B, (uint32_t)C,
+                              (uint32_t)N, (uint32_t)width, (uint32_t)height, (float)eps2d, (int)camera_model,
+                              cp<int32_t>(rad), fp(con), fp(comp), vm2.const_data_ptr<float>(), m2s, fp(vdep),
+                              vcn.const_data_ptr<float>(), cns, fp(vcomp), mp<float>(v_means),
+                              v_covars ? mp<float>(*v_covars) : nullptr, v_quats ? mp<float>(*v_quats) : nullptr,
+                              v_scales ? mp<float>(*v_scales) : nullptr, v_viewmats ? mp<float>(*v_viewmats) : nullptr,
+                              L.stream),
+          "gsx_project_ewa_bwd");
+    return {v_means, v_covars, v_quats, v_scales, v_viewmats};
+}
+
+// ---- spherical harmonics ------------------------------------------------------------------------------------------------
+struct ShDims {
+    bool packed;
+    int64_t B, C, N, K, D;
+};
+ShDims sh_dims(const Tensor &means, const Tensor &viewmats, const Tensor &coeffs, const OptTensor &gaussian_ids)
+{
+    ShDims d;
+    d.packed = has(gaussian_ids);
+    TORCH_CHECK_VALUE(coeffs.dim() == 3, "coeffs must have shape [N, K, D] or [nnz, K, D], got ", coeffs.sizes());
+    d.B = prod(means.sizes().slice(0, means.dim() - 2));
+    d.C = viewmats.size(-3);
+    d.N = means.size(-2);
+    d.K = coeffs.size(-2);
+    d.D = coeffs.size(-1);
+    return d;
+}
+
+Tensor spherical_harmonics(int64_t degrees_to_use, const Tensor &means_, const Tensor &viewmats_, const Tensor &coeffs_,
+                           const OptTensor &masks_, const OptTensor &batch_ids_, const OptTensor &camera_ids_,
+                           const OptTensor &gaussian_ids_, const OptTensor &viewmats_rs)
+{
+    TORCH_CHECK_NOT_IMPLEMENTED(!has(viewmats_rs), "gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path");
+    want_f32(means_, "means"); want_f32(viewmats_, "viewmats"); want_f32(coeffs_, "coeffs");
+    Launch L(means_);
+    const Tensor means = contig(means_), viewmats = contig(viewmats_), coeffs = contig(coeffs_);
+    const OptTensor masks = contig(masks_), bi = contig(batch_ids_), ci = contig(camera_ids_), gi = contig(gaussian_ids_);
+    const ShDims d = sh_dims(means, viewmats, coeffs, gi);
+    Tensor colors;
+    int64_t nnz = -1;
+    if (d.packed) {
+        nnz = gi->size(0);
+        colors = at::empty({nnz, d.D}, means.options());
+    } else {
+        TORCH_CHECK_VALUE(coeffs.size(0) == d.N, "means N must match coeffs N in dense mode");
+        std::vector<int64_t> shape(viewmats.sizes().begin(), viewmats.sizes().end() - 2);
+        shape.push_back(d.N); shape.push_back(d.D);
+        colors = at::empty(shape, means.options());
+    }
+    check(gsx_sh_fwd((int)degrees_to_use, fp(means), fp(viewmats), fp(coeffs), has(masks) ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr,
+                     cp<int64_t>(bi), cp<int64_t>(ci), cp<int64_t>(gi), (uint32_t)d.B, (uint32_t)d.C, (uint32_t)d.N, nnz, 1,
+                     (uint32_t)d.K, (uint32_t)d.D, nullptr, 0, mp<float>(colors), L.stream),
+          "gsx_sh_fwd");
+    return colors;
+}
+
+std::tuple<Tensor, OptTensor, OptTensor, OptTensor>
+spherical_harmonics_bwd(int64_t degrees_to_use, const Tensor &means_, const Tensor &viewmats_, const Tensor &coeffs_,
+                        const OptTensor &masks_, const OptTensor &batch_ids_, const OptTensor &camera_ids_,
+                        const OptTensor &gaussian_ids_, const OptTensor &viewmats_rs, const Tensor &v_colors_,
+                        bool compute_v_means, bool compute_v_viewmats, bool compute_v_viewmats_rs)
+{
+    TORCH_CHECK_NOT_IMPLEMENTED(!has(viewmats_rs) && !compute_v_viewmats_rs,
+                                "gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path");
+    Launch L(means_);
+    const Tensor means = contig(means_), viewmats = contig(viewmats_), coeffs = contig(coeffs_);
+    const OptTensor masks = contig(masks_), bi = contig(batch_ids_), ci = contig(camera_ids_), gi = contig(gaussian_ids_);
+    const ShDims d = sh_dims(means, viewmats, coeffs, gi);
+    auto [vcol, vstride] = row_view(v_colors_, d.D); // may be a column view of the compositing kernel's gradient rows
+    Tensor v_coeffs = at::empty_like(coeffs);        // gathered coefficient rows: fully written by the kernel
+    OptTensor v_means, v_viewmats;
+    if (compute_v_means) {
+        const bool full_write = d.D == 3 && d.N > 0 && !d.packed; // sh3_bwd_dense_kernel stores every (b, g)
+        v_means = full_write ? at::empty_like(means) : at::zeros_like(means);
+    }
+    const int64_t nnz = d.packed ? gi->size(0) : -1;
+    Tensor v_dirs;
+    if (compute_v_viewmats) v_dirs = at::zeros({d.packed ? nnz : d.B * d.C * d.N, 3}, means.options());
+    check(gsx_sh_bwd((int)degrees_to_use, fp(means), fp(viewmats), fp(coeffs), has(masks) ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr,
+                     cp<int64_t>(bi), cp<int64_t>(ci), cp<int64_t>(gi), (uint32_t)d.B, (uint32_t)d.C, (uint32_t)d.N, nnz, 1,
+                     (uint32_t)d.K, (uint32_t)d.D, nullptr, nullptr, vcol.const_data_ptr<float>(), vstride, nullptr,
+                     mp<float>(v_coeffs), v_means ? mp<float>(*v_means) : nullptr, v_dirs.defined() ? mp<float>(v_dirs) : nullptr,
+                     L.stream),
+          "gsx_sh_bwd");
+    if (compute_v_viewmats) {
+        // dir = mean + R^T t  =>  v_R = t (x) sum_rows v_dir,  v_t = R sum_rows v_dir per camera (small host-side tensors)
+        Tensor S;
+        if (d.packed) {
+            S = at::zeros({d.B * d.C, 3}, means.options());
+            S.index_add_(0, *bi * d.C + *ci, v_dirs);
+        } else {
+            S = v_dirs.view({d.B * d.C, d.N, 3}).sum(1);
+        }
+        const Tensor vm = viewmats.reshape({d.B * d.C, 4, 4});
+        const Tensor R = vm.slice(1, 0, 3).slice(2, 0, 3), t = vm.slice(1, 0, 3).select(2, 3);
+        Tensor v_vm = at::zeros_like(vm);
+        v_vm.slice(1, 0, 3).slice(2, 0, 3).copy_(t.unsqueeze(2) * S.unsqueeze(1));
+        v_vm.slice(1, 0, 3).select(2, 3).copy_(at::einsum("cij,cj->ci", {R, S}));
+        v_viewmats = v_vm.reshape(viewmats.sizes());
+    }
+    return {v_coeffs, v_means, v_viewmats, OptTensor()};
+}
+
+// ---- tile intersection --------------------------------------------------------------------------------------------------
+Tensor bytes(int64_t n, const Tensor &like) { return at::empty({n < 8 ? 8 : n}, like.options().dtype(at::kByte)); }
+
+std::tuple<Tensor, Tensor, Tensor>
+intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depths_, const OptTensor &conics_,
+               const OptTensor &opacities_, const OptTensor &image_ids_, const OptTensor &gaussian_ids, std::optional<int64_t> n_images,
+               int64_t tile_size, int64_t tile_w, int64_t tile_h, bool sort, bool segmented)
+{
+    (void)gaussian_ids; (void)segmented; // the global sort is used (results are identical to the segmented one)
+    want_f32(means2d_, "means2d"); want_f32(depths_, "depths"); want_f32(conics_, "conics"); want_f32(opacities_, "opacities");
+    Launch L(means2d_);
+    const bool packed = has(image_ids_);
+    const Tensor means2d = contig(means2d_), depths = contig(depths_);
+    const Tensor radii = contig(radii_.scalar_type() == at::kInt ? radii_ : radii_.to(at::kInt));
+    const OptTensor conics = contig(conics_), opac = contig(opacities_), image_ids = contig(image_ids_);
+    int64_t rows, n_per, I;
+    std::vector<int64_t> out_shape;
+    if (packed) {
+        TORCH_CHECK_VALUE(n_images.has_value(), "n_images is required when packed");
+        rows = means2d.size(0); n_per = 1; I = *n_images;
+        out_shape = {rows};
+    } else {
+        auto image_dims = means2d.sizes().slice(0, means2d.dim() - 2);
+        I = prod(image_dims); n_per = means2d.size(-2); rows = I * n_per;
+        out_shape.assign(means2d.sizes().begin(), means2d.sizes().end() - 1);
+    }
+    const uint32_t tile_bits = bits_for_count(tile_w * tile_h), image_bits = bits_for_count(I);
+    TORCH_CHECK(tile_bits + image_bits <= 32, "intersect_tile: tile id bits (", tile_bits, ") + image id bits (", image_bits,
+                ") exceed the 32 bits available above the depth in the 64-bit sort key");
+    Tensor tiles_per_gauss = at::empty(out_shape, means2d.options().dtype(at::kInt));
+    auto none = [&]() {
+        return std::make_tuple(tiles_per_gauss, at::empty({0}, means2d.options().dtype(at::kLong)),
+                               at::empty({0}, means2d.options().dtype(at::kInt)));
+    };
+    if (rows == 0) return none();
+    const uint32_t uI = (uint32_t)I, uts = (uint32_t)tile_size, utw = (uint32_t)tile_w, uth = (uint32_t)tile_h;
+    // the grand total comes back through pinned host memory (the one host sync of this op: Intersect.cpp:258-259)
+    Tensor host_total = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    auto hip_stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means2d.device().index());
+    if (sort && gsx_isect_fused_supported(uI, utw, uth, packed ? 1 : 0)) {
+        Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
+        Tensor offsets = at::empty({I * tile_w * tile_h}, means2d.options().dtype(at::kInt));
+        check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
+                                    mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(),
+                                    count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
+              "gsx_isect_fused_count");
+        hip_stream.synchronize();
+        const int64_t M = *host_total.const_data_ptr<int64_t>();
+        TORCH_CHECK(M < (1ll << 31), "intersect_tile: ", M, " intersections overflow the int32 index space");
+        Tensor ids = at::empty({M}, means2d.options().dtype(at::kLong)), flat = at::empty({M}, means2d.options().dtype(at::kInt));
+        if (M == 0) return {tiles_per_gauss, ids, flat};
+        Tensor ws = bytes(gsx_isect_fused_emit_workspace_bytes(M, uI, utw, uth), means2d);
+        check(gsx_isect_fused_emit_sort(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI, uts,
+                                        utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(), cp<int32_t>(offsets), M,
+                                        mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
+              "gsx_isect_fused_emit_sort");
+        return {tiles_per_gauss, ids, flat};
+    }
+    check(gsx_isect_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), cp<int64_t>(image_ids), rows, (uint32_t)n_per, uI,
+                          uts, utw, uth, mp<int32_t>(tiles_per_gauss), L.stream),
+          "gsx_isect_count");
+    Tensor cum = at::empty({rows}, means2d.options().dtype(at::kLong));
+    {
+        Tensor ws = bytes(gsx_scan_workspace_bytes(rows), means2d);
+        check(gsx_scan_i32(cp<int32_t>(tiles_per_gauss), rows, mp<int64_t>(cum), ws.mutable_data_ptr(), ws.numel(), L.stream),
+              "gsx_scan_i32");
+    }
+    host_total.copy_(cum.slice(0, rows - 1, rows), /*non_blocking=*/true);
+    hip_stream.synchronize();
+    const int64_t M = *host_total.const_data_ptr<int64_t>();
+    TORCH_CHECK(M < (1ll << 31), "intersect_tile: ", M, " intersections overflow the int32 index space");
+    Tensor ids = at::empty({M}, means2d.options().dtype(at::kLong)), flat = at::empty({M}, means2d.options().dtype(at::kInt));
+    if (M == 0) return {tiles_per_gauss, ids, flat};
+    check(gsx_isect_emit(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), cp<int64_t>(image_ids),
+                         cp<int64_t>(cum), rows, (uint32_t)n_per, uI, uts, utw, uth, mp<int64_t>(ids), mp<int32_t>(flat), L.stream),
+          "gsx_isect_emit");
+    if (!sort) return {tiles_per_gauss, ids, flat};
+    Tensor ids2 = at::empty_like(ids), flat2 = at::empty_like(flat);
+    if (gsx_isect_tile_sort_supported(uI, utw, uth)) {
+        Tensor ws = bytes(gsx_isect_tile_sort_workspace_bytes(M, uI, utw, uth), means2d);
+        check(gsx_isect_tile_sort(cp<int64_t>(ids), cp<int32_t>(flat), M, uI, utw, uth, mp<int64_t>(ids2), mp<int32_t>(flat2),
+                                  ws.mutable_data_ptr(), ws.numel(), L.stream),
+              "gsx_isect_tile_sort");
+        return {tiles_per_gauss, ids2, flat2};
+    }
+    Tensor ws = bytes(gsx_sort_pairs_workspace_bytes(M), means2d);
+    int in_alt = 0;
+    check(gsx_sort_pairs(mp<int64_t>(ids), mp<int32_t>(flat), mp<int64_t>(ids2), mp<int32_t>(flat2), M,
+                         (int)(32 + tile_bits + image_bits), ws.mutable_data_ptr(), ws.numel(), &in_alt, L.stream),
+          "gsx_sort_pairs");
+    if (in_alt) return {tiles_per_gauss, ids2, flat2};
+    return {tiles_per_gauss, ids, flat};
+}
+
+Tensor intersect_offset(const Tensor &isect_ids_, int64_t I, int64_t tile_w, int64_t tile_h)
+{
+    Launch L(isect_ids_);
+    const Tensor ids = contig(isect_ids_);
+    Tensor offsets = at::empty({I, tile_h, tile_w}, ids.options().dtype(at::kInt));
+    check(gsx_isect_offsets(cp<int64_t>(ids), ids.numel(), (uint32_t)I, (uint32_t)tile_w, (uint32_t)tile_h, mp<int32_t>(offsets),
+                            L.stream),
+          "gsx_isect_offsets");
+    return offsets;
+}
+
+// ---- compositing --------------------------------------------------------------------------------------------------------
+struct RasterDims {
+    std::vector<int64_t> image_dims;
+    int64_t I, th, tw, D;
+};
+RasterDims raster_dims(const Tensor &isect_offsets, const Tensor &colors)
+{
+    RasterDims r;
+    r.image_dims.assign(isect_offsets.sizes().begin(), isect_offsets.sizes().end() - 2);
+    r.I = prod(r.image_dims);
+    r.th = isect_offsets.size(-2);
+    r.tw = isect_offsets.size(-1);
+    r.D = colors.size(-1);
+    return r;
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor>
+rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Tensor &colors_, const Tensor &opacities_,
+                         const OptTensor &backgrounds_, const OptTensor &masks_, int64_t width, int64_t height, int64_t tile_size,
+                         const Tensor &isect_offsets_, const Tensor &flatten_ids_, bool packed, bool absgrad)
+{
+    (void)packed;
+    want_f32(means2d_, "means2d"); want_f32(conics_, "conics"); want_f32(colors_, "colors"); want_f32(opacities_, "opacities");
+    want_f32(backgrounds_, "backgrounds");
+    Launch L(means2d_);
+    const RasterDims r = raster_dims(isect_offsets_, colors_);
+    TORCH_CHECK_VALUE(r.th * tile_size >= height && r.tw * tile_size >= width,
+                      "rasterize_to_pixels: isect_offsets tile grid does not cover the image");
+    TORCH_CHECK_TYPE(!has(masks_) || masks_->scalar_type() == at::kBool, "masks must be a bool tensor");
+    const Tensor means2d = contig(means2d_), conics = contig(conics_), colors = contig(colors_), opac = contig(opacities_);
+    const OptTensor bg = contig(backgrounds_), masks = contig(masks_);
+    const Tensor offsets = contig(isect_offsets_), flat = contig(flatten_ids_);
+    auto shape = [&](std::initializer_list<int64_t> tail) {
+        auto s = r.image_dims;
+        s.insert(s.end(), tail);
+        return s;
+    };
+    Tensor renders = at::empty(shape({height, width, r.D}), means2d.options());
+    Tensor alphas = at::empty(shape({height, width, 1}), means2d.options());
+    Tensor last_ids = at::empty(shape({height, width}), means2d.options().dtype(at::kInt));
+    check(gsx_raster3d_fwd(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
+                           masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
+                           cp<int32_t>(flat), (uint32_t)r.I, (uint32_t)flat.numel(), (uint32_t)r.D, (uint32_t)width,
+                           (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th, mp<float>(renders),
+                           mp<float>(alphas), mp<int32_t>(last_ids), L.stream),
+          "gsx_raster3d_fwd");
+    Tensor holder = absgrad ? at::zeros_like(means2d) : at::empty({0}, means2d.options());
+    return {renders, alphas, holder, last_ids};
+}
+
+std::tuple<OptTensor, Tensor, Tensor, Tensor, Tensor, OptTensor>
+rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, const Tensor &colors_, const Tensor &opacities_,
+                             const OptTensor &backgrounds_, const OptTensor &masks_, const Tensor &tile_offsets_,
+                             const Tensor &flatten_ids_, const Tensor &render_alphas_, const Tensor &last_ids_, int64_t width,
+                             int64_t height, int64_t tile_size, bool absgrad, const Tensor &v_render_colors_,
+                             const Tensor &v_render_alphas_, bool compute_v_backgrounds)
+{
+    Launch L(means2d_);
+    const RasterDims r = raster_dims(tile_offsets_, colors_);
+    const Tensor means2d = contig(means2d_), conics = contig(conics_), colors = contig(colors_), opac = contig(opacities_);
+    const OptTensor bg = contig(backgrounds_), masks = contig(masks_);
+    const Tensor offsets = contig(tile_offsets_), flat = contig(flatten_ids_), ra = contig(render_alphas_), li = contig(last_ids_);
+    const Tensor v_rc = contig(v_render_colors_);
+    const Tensor v_ra = v_render_alphas_.defined() ? contig(v_render_alphas_) : Tensor(); // undefined = zeros
+    // ONE zero-filled array-of-structures buffer [R][6 (+2) + D]; the gradients are COLUMN VIEWS of it (gsplat_amd.h)
+    const int64_t R = opac.numel(), geo = absgrad ? 8 : 6;
+    Tensor rows = at::zeros({R, geo + r.D}, means2d.options());
+    check(gsx_raster3d_bwd(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
+                           masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
+                           cp<int32_t>(flat), fp(ra), cp<int32_t>(li), fp(v_rc), fp(v_ra), (uint32_t)r.I, (uint32_t)flat.numel(),
+                           (uint32_t)r.D, (uint32_t)width, (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th,
+                           absgrad ? 1 : 0, mp<float>(rows), (uint32_t)(geo + r.D), L.stream),
+          "gsx_raster3d_bwd");
+    Tensor v_means2d = rows.slice(1, 0, 2).view(means2d.sizes()), v_conics = rows.slice(1, 2, 5).view(conics.sizes());
+    Tensor v_opac = rows.select(1, 5).view(opac.sizes()), v_colors = rows.slice(1, geo, geo + r.D).view(colors.sizes());
+    OptTensor v_abs, v_bg;
+    if (absgrad) v_abs = rows.slice(1, 6, 8).view(means2d.sizes());
+    if (has(bg) && compute_v_backgrounds) v_bg = (v_rc * (1.0 - ra)).sum(at::IntArrayRef({-3, -2})); // Rasterization.cpp:567-577
+    return {v_abs, v_means2d, v_conics, v_colors, v_opac, v_bg};
+}
+
+} // namespace
+} // namespace gsplat_amd
+
+TORCH_LIBRARY_IMPL(gsplat, CUDA, m)
+{
+    using namespace gsplat_amd;
+    m.impl("projection_ewa_3dgs_fused", &projection_ewa_3dgs_fused);
+    m.impl("projection_ewa_3dgs_fused_bwd", &projection_ewa_3dgs_fused_bwd);
+    m.impl("spherical_harmonics", &spherical_harmonics);
+    m.impl("spherical_harmonics_bwd", &spherical_harmonics_bwd);
+    m.impl("intersect_tile", &intersect_tile);
+    m.impl("intersect_offset", &intersect_offset);
+    m.impl("rasterize_to_pixels_3dgs", &rasterize_to_pixels_3dgs);
+    m.impl("rasterize_to_pixels_3dgs_bwd", &rasterize_to_pixels_3dgs_bwd);
+}
+
+// the ops above, for gsplat_amd/_ops.py (which keeps its Python body for every op NOT named here)
+extern "C" const char *gsx_torch_compiled_ops()
+{
+    return "projection_ewa_3dgs_fused projection_ewa_3dgs_fused_bwd spherical_harmonics spherical_harmonics_bwd "
+           "intersect_tile intersect_offset rasterize_to_pixels_3dgs rasterize_to_pixels_3dgs_bwd";
+}
