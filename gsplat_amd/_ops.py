@@ -521,6 +521,10 @@ def projection_ewa_3dgs_fused_bwd(means, covars, quats, scales, viewmats, Ks, im
     return v_means, v_covars, v_quats, v_scales, v_viewmats
 
 
+_PACKED_ROW_BYTES = 64  # 3 int64 ids + radii + means2d + depth + conic (+ compensation) per packed row
+_PACKED_PREALLOC_LIMIT = 1 << 30  # upper-bound row buffers are only used below this size
+
+
 @_op("projection_ewa_3dgs_packed")
 def projection_ewa_3dgs_packed(means, covars, quats, scales, opacities, viewmats, Ks, image_width, image_height,
                                eps2d, near_plane, far_plane, radius_clip, sparse_grad, calc_compensations,
@@ -541,6 +545,26 @@ def projection_ewa_3dgs_packed(means, covars, quats, scales, opacities, viewmats
     if total > 0:
         call("gsx_project_ewa_packed_count", *common, int(calc_compensations), ptr(visible))
         cum = _scan_i32(visible)
+        if total * _PACKED_ROW_BYTES <= _PACKED_PREALLOC_LIMIT:
+            # The write pass only needs the DEVICE-side offsets: enqueue it into row buffers sized for the upper bound
+            # (every (image, Gaussian) pair visible) before the host learns nnz, and hand out the first nnz rows. The GPU
+            # no longer idles through the host round trip + nine allocations + a launch (r05 timeline: ~60 us per step).
+            # Scenes whose upper bound would not be small next to the model keep the exact-length path below - saving
+            # that memory is what packed rows are for.
+            host_nnz = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            host_nnz.copy_(cum[-1:], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ub = total
+            bufs = (torch.empty(ub, device=dev, dtype=torch.int64), torch.empty(ub, device=dev, dtype=torch.int64),
+                    torch.empty(ub, device=dev, dtype=torch.int64), torch.zeros(B * C + 1, device=dev, dtype=torch.int32),
+                    torch.empty((ub, 2), device=dev, dtype=torch.int32), torch.empty((ub, 2), device=dev, dtype=dt),
+                    torch.empty((ub,), device=dev, dtype=dt), torch.empty((ub, 3), device=dev, dtype=dt),
+                    torch.empty((ub,), device=dev, dtype=dt) if calc_compensations else None)
+            call("gsx_project_ewa_packed_write", *common, ptr(cum), ub, *[ptr(t) for t in bufs])
+            ev.synchronize()  # host sync: exact-length COO outputs (reference: Projection.cpp:928-941)
+            nnz = int(host_nnz.item())
+            return tuple(t if (t is None or i == 3) else t[:nnz] for i, t in enumerate(bufs))
         nnz = int(cum[-1].item())  # host sync: exact-length COO outputs (reference: Projection.cpp:928-941)
     batch_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
     camera_ids = torch.empty(nnz, device=dev, dtype=torch.int64)

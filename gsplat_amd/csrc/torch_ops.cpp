@@ -15,6 +15,7 @@
 #include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
 
+#include <algorithm>
 #include <cmath>
 #include <string>
 #include <tuple>
@@ -171,6 +172,77 @@ projection_ewa_3dgs_fused_bwd(const Tensor &means_, const OptTensor &covars_, co
                               L.stream),
           "gsx_project_ewa_bwd");
     return {v_means, v_covars, v_quats, v_scales, v_viewmats};
+}
+
+// ---- projection (packed rows) ----------------------------------------------------------------------------------------------
+// Two passes (count -> scan -> write) and ONE host round trip for the exact number of rows (Projection.cpp:928-941). When the
+// upper bound (every (image, Gaussian) pair visible) is small next to the model, the write pass is enqueued into row buffers
+// of that size BEFORE the host learns nnz - it only needs the device-side offsets - and the first nnz rows are handed out:
+// the GPU does not idle through the round trip, the allocations and the launch. Larger scenes allocate exact lengths
+// (saving that memory is what packed rows are for).
+constexpr int64_t kPackedRowBytes = 64, kPackedPreallocLimit = 1ll << 30;
+
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, OptTensor>
+projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const OptTensor &quats_, const OptTensor &scales_,
+                           const OptTensor &opacities_, const Tensor &viewmats_, const Tensor &Ks_, int64_t width,
+                           int64_t height, double eps2d, double near_plane, double far_plane, double radius_clip,
+                           bool sparse_grad, bool calc_compensations, int64_t camera_model)
+{
+    (void)sparse_grad;
+    want_f32(means_, "means"); want_f32(covars_, "covars"); want_f32(quats_, "quats"); want_f32(scales_, "scales");
+    want_f32(viewmats_, "viewmats"); want_f32(Ks_, "Ks");
+    TORCH_CHECK_VALUE(has(covars_) || (has(quats_) && has(scales_)), "projection: either covars or (quats, scales) must be given");
+    Launch L(means_);
+    const Tensor means = contig(means_), viewmats = contig(viewmats_), Ks = contig(Ks_);
+    const OptTensor covars = contig(covars_), opac = contig(opacities_);
+    const OptTensor quats = has(covars) ? OptTensor() : contig(quats_), scales = has(covars) ? OptTensor() : contig(scales_);
+    const int64_t B = prod(means.sizes().slice(0, means.dim() - 2)), C = viewmats.size(-3), N = means.size(-2);
+    const int64_t total = B * C * N;
+    const auto f32 = means.options(), i32 = means.options().dtype(at::kInt), i64 = means.options().dtype(at::kLong);
+    auto outputs = [&](int64_t rows) {
+        return std::make_tuple(at::empty({rows}, i64), at::empty({rows}, i64), at::empty({rows}, i64), at::zeros({B * C + 1}, i32),
+                               at::empty({rows, 2}, i32), at::empty({rows, 2}, f32), at::empty({rows}, f32),
+                               at::empty({rows, 3}, f32), calc_compensations ? OptTensor(at::empty({rows}, f32)) : OptTensor());
+    };
+    if (total == 0) return outputs(0);
+    auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means.device().index());
+    Tensor visible = at::empty({total}, i32), cum = at::empty({total}, i64);
+    check(gsx_project_ewa_packed_count(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
+                                       (uint32_t)C, (uint32_t)N, (uint32_t)width, (uint32_t)height, (float)eps2d,
+                                       (float)near_plane, (float)far_plane, (float)radius_clip, (int)camera_model,
+                                       calc_compensations ? 1 : 0, mp<int32_t>(visible), L.stream),
+          "gsx_project_ewa_packed_count");
+    {
+        Tensor ws = at::empty({std::max<int64_t>(gsx_scan_workspace_bytes(total), 8)}, means.options().dtype(at::kByte));
+        check(gsx_scan_i32(cp<int32_t>(visible), total, mp<int64_t>(cum), ws.mutable_data_ptr(), ws.numel(), L.stream), "gsx_scan_i32");
+    }
+    Tensor host_nnz = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    host_nnz.copy_(cum.slice(0, total - 1, total), /*non_blocking=*/true);
+    auto write = [&](int64_t rows, decltype(outputs(0)) &o) {
+        auto &[bi, ci, gi, indptr, radii, m2, dep, con, comp] = o;
+        check(gsx_project_ewa_packed_write(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
+                                           (uint32_t)C, (uint32_t)N, (uint32_t)width, (uint32_t)height, (float)eps2d,
+                                           (float)near_plane, (float)far_plane, (float)radius_clip, (int)camera_model,
+                                           cp<int64_t>(cum), rows, mp<int64_t>(bi), mp<int64_t>(ci), mp<int64_t>(gi),
+                                           mp<int32_t>(indptr), mp<int32_t>(radii), mp<float>(m2), mp<float>(dep), mp<float>(con),
+                                           comp ? mp<float>(*comp) : nullptr, L.stream),
+              "gsx_project_ewa_packed_write");
+    };
+    if (total * kPackedRowBytes <= kPackedPreallocLimit) {
+        auto o = outputs(total);
+        write(total, o);
+        stream.synchronize(); // host sync: exact-length COO outputs
+        const int64_t nnz = *host_nnz.const_data_ptr<int64_t>();
+        auto &[bi, ci, gi, indptr, radii, m2, dep, con, comp] = o;
+        auto head = [&](const Tensor &t) { return t.narrow(0, 0, nnz); };
+        return {head(bi), head(ci), head(gi), indptr, head(radii), head(m2), head(dep), head(con),
+                comp ? OptTensor(head(*comp)) : OptTensor()};
+    }
+    stream.synchronize();
+    const int64_t nnz = *host_nnz.const_data_ptr<int64_t>();
+    auto o = outputs(nnz);
+    if (nnz > 0 || true) write(nnz, o);
+    return o;
 }
 
 // ---- spherical harmonics ------------------------------------------------------------------------------------------------
@@ -460,6 +532,7 @@ TORCH_LIBRARY_IMPL(gsplat, CUDA, m)
     using namespace gsplat_amd;
     m.impl("projection_ewa_3dgs_fused", &projection_ewa_3dgs_fused);
     m.impl("projection_ewa_3dgs_fused_bwd", &projection_ewa_3dgs_fused_bwd);
+    m.impl("projection_ewa_3dgs_packed", &projection_ewa_3dgs_packed);
     m.impl("spherical_harmonics", &spherical_harmonics);
     m.impl("spherical_harmonics_bwd", &spherical_harmonics_bwd);
     m.impl("intersect_tile", &intersect_tile);
@@ -471,6 +544,6 @@ TORCH_LIBRARY_IMPL(gsplat, CUDA, m)
 // the ops above, for gsplat_amd/_ops.py (which keeps its Python body for every op NOT named here)
 extern "C" const char *gsx_torch_compiled_ops()
 {
-    return "projection_ewa_3dgs_fused projection_ewa_3dgs_fused_bwd spherical_harmonics spherical_harmonics_bwd "
+    return "projection_ewa_3dgs_fused projection_ewa_3dgs_fused_bwd projection_ewa_3dgs_packed spherical_harmonics spherical_harmonics_bwd "
            "intersect_tile intersect_offset rasterize_to_pixels_3dgs rasterize_to_pixels_3dgs_bwd";
 }

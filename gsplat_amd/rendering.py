@@ -188,7 +188,7 @@ def rasterization(
         # index_select (backward = atomic index_add) instead of advanced indexing (backward = index_put, which SORTS
         # the nnz indices first: ~0.2 ms per step at 1M Gaussians)
         proj_opacities = opacities.reshape(-1).index_select(0, batch_ids * N + gaussian_ids if B > 1 else gaussian_ids)
-        image_ids = batch_ids * C_proj + camera_ids
+        image_ids = camera_ids if B == 1 else batch_ids * C_proj + camera_ids
     else:
         radii, means2d, depths, conics, compensations = proj
         batch_ids = camera_ids = gaussian_ids = image_ids = None
