@@ -167,6 +167,28 @@ _profile = None  # list of (entry point, start event, end event) while profiling
 _profile_only = None  # optional set of entry points to record (None = all)
 
 
+_torch_lib = None
+
+
+def _compiled_ops_lib():
+    """libgsplat_amd_torch.so (csrc/torch_ops.cpp), when it is loaded: its op bodies call the C-ABI without passing through
+    call() below, so they carry their own event-pair hooks."""
+    global _torch_lib
+    if _torch_lib is None:
+        path = os.environ.get("GSPLAT_AMD_TORCH_LIB") or os.path.join(_HERE, "csrc", "libgsplat_amd_torch.so")
+        _torch_lib = False
+        if os.path.exists(path):
+            try:
+                lib = ctypes.CDLL(path)
+                lib.gsx_torch_profile_begin.argtypes = [ctypes.c_char_p]
+                lib.gsx_torch_profile_begin.restype = None
+                lib.gsx_torch_profile_end.restype = ctypes.c_char_p
+                _torch_lib = lib
+            except (OSError, AttributeError):
+                _torch_lib = False
+    return _torch_lib or None
+
+
 def profile_begin(only=None) -> None:
     """Start recording a HIP-event pair around gsx_* calls (events go on the stream the kernels are launched on:
     torch's current stream). `only` = iterable of entry-point names restricts the recording (bench.py times just the
@@ -174,6 +196,9 @@ def profile_begin(only=None) -> None:
     global _profile, _profile_only
     _profile = []
     _profile_only = None if only is None else frozenset(only)
+    lib = _compiled_ops_lib()
+    if lib is not None:
+        lib.gsx_torch_profile_begin(" ".join(sorted(_profile_only or ())).encode())
 
 
 def profile_end() -> dict:
@@ -184,6 +209,11 @@ def profile_end() -> dict:
     out = {}
     for name, a, b in rec:
         out.setdefault(name, []).append(a.elapsed_time(b))
+    lib = _compiled_ops_lib()
+    if lib is not None:  # the calls made by the compiled op bodies
+        for line in lib.gsx_torch_profile_end().decode().splitlines():
+            name, ms = line.split()
+            out.setdefault(name, []).append(float(ms))
     return out
 
 

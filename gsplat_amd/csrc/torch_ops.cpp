@@ -15,10 +15,15 @@
 #include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
 
+#include <hip/hip_runtime_api.h>
+
 #include <algorithm>
 #include <cmath>
+#include <mutex>
+#include <set>
 #include <string>
 #include <tuple>
+#include <vector>
 
 #include "../../include/gsplat_amd.h"
 
@@ -36,6 +41,38 @@ struct Launch { // device guard + the tensor's device's current stream (the refe
         : guard(t.device()), stream((void *)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream())
     {
         TORCH_CHECK(t.is_cuda(), "gsplat_amd kernels only run on a ROCm device (got a CPU tensor); there is no CPU fallback");
+    }
+};
+
+// ---- optional timing of the C-ABI calls made from here (what gsplat_amd._cabi.profile_begin / profile_end do for the Python
+// bodies): a HIP event pair on the launch stream around every call whose entry point is selected. Off by default. ---------------
+struct ProfRecord {
+    std::string name;
+    hipEvent_t a, b;
+};
+std::mutex g_prof_mutex;
+bool g_prof_on = false;
+std::set<std::string> g_prof_only; // empty = every entry point
+std::vector<ProfRecord> g_prof;
+
+struct Timed { // RAII: start event now, stop event at scope exit (after the C-ABI call has enqueued its kernels)
+    hipEvent_t a = nullptr, b = nullptr;
+    void *stream;
+    const char *name;
+    Timed(const char *fn, void *s) : stream(s), name(fn)
+    {
+        if (!g_prof_on) return;
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        if (!g_prof_on || (!g_prof_only.empty() && !g_prof_only.count(fn))) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, (hipStream_t)stream);
+    }
+    ~Timed()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, (hipStream_t)stream);
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        g_prof.push_back({name, a, b});
     }
 };
 
@@ -132,11 +169,11 @@ projection_ewa_3dgs_fused(const Tensor &means_, const OptTensor &covars_, const 
     Tensor conics = at::empty(with(3), means.options());
     OptTensor comps;
     if (calc_compensations) comps = at::empty(shape, means.options());
-    check(gsx_project_ewa_fwd(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
+    { Timed timed_("gsx_project_ewa_fwd", L.stream); check(gsx_project_ewa_fwd(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
                               (uint32_t)C, (uint32_t)N, (uint32_t)width, (uint32_t)height, (float)eps2d, (float)near_plane,
                               (float)far_plane, (float)radius_clip, (int)camera_model, mp<int32_t>(radii), mp<float>(means2d),
                               mp<float>(depths), mp<float>(conics), comps ? mp<float>(*comps) : nullptr, L.stream),
-          "gsx_project_ewa_fwd");
+          "gsx_project_ewa_fwd"); }
     return {radii, means2d, depths, conics, comps};
 }
 
@@ -163,14 +200,14 @@ projection_ewa_3dgs_fused_bwd(const Tensor &means_, const OptTensor &covars_, co
     const Tensor vdep = v_depths_.defined() ? contig(v_depths_) : Tensor();
     const Tensor rad = contig(radii), con = contig(conics);
     const OptTensor comp = contig(compensations), vcomp = contig(v_compensations);
-    check(gsx_project_ewa_bwd(fp(means), fp(covars), fp(quats), fp(scales), fp(viewmats), fp(Ks), (uint32_t)B, (uint32_t)C,
+    { Timed timed_("gsx_project_ewa_bwd", L.stream); check(gsx_project_ewa_bwd(fp(means), fp(covars), fp(quats), fp(scales), fp(viewmats), fp(Ks), (uint32_t)B, (uint32_t)C,
                               (uint32_t)N, (uint32_t)width, (uint32_t)height, (float)eps2d, (int)camera_model,
                               cp<int32_t>(rad), fp(con), fp(comp), vm2.const_data_ptr<float>(), m2s, fp(vdep),
                               vcn.const_data_ptr<float>(), cns, fp(vcomp), mp<float>(v_means),
                               v_covars ? mp<float>(*v_covars) : nullptr, v_quats ? mp<float>(*v_quats) : nullptr,
                               v_scales ? mp<float>(*v_scales) : nullptr, v_viewmats ? mp<float>(*v_viewmats) : nullptr,
                               L.stream),
-          "gsx_project_ewa_bwd");
+          "gsx_project_ewa_bwd"); }
     return {v_means, v_covars, v_quats, v_scales, v_viewmats};
 }
 
@@ -207,26 +244,26 @@ projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const
     if (total == 0) return outputs(0);
     auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means.device().index());
     Tensor visible = at::empty({total}, i32), cum = at::empty({total}, i64);
-    check(gsx_project_ewa_packed_count(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
+    { Timed timed_("gsx_project_ewa_packed_count", L.stream); check(gsx_project_ewa_packed_count(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
                                        (uint32_t)C, (uint32_t)N, (uint32_t)width, (uint32_t)height, (float)eps2d,
                                        (float)near_plane, (float)far_plane, (float)radius_clip, (int)camera_model,
                                        calc_compensations ? 1 : 0, mp<int32_t>(visible), L.stream),
-          "gsx_project_ewa_packed_count");
+          "gsx_project_ewa_packed_count"); }
     {
         Tensor ws = at::empty({std::max<int64_t>(gsx_scan_workspace_bytes(total), 8)}, means.options().dtype(at::kByte));
-        check(gsx_scan_i32(cp<int32_t>(visible), total, mp<int64_t>(cum), ws.mutable_data_ptr(), ws.numel(), L.stream), "gsx_scan_i32");
+        { Timed timed_("gsx_scan_i32", L.stream); check(gsx_scan_i32(cp<int32_t>(visible), total, mp<int64_t>(cum), ws.mutable_data_ptr(), ws.numel(), L.stream), "gsx_scan_i32"); }
     }
     Tensor host_nnz = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
     host_nnz.copy_(cum.slice(0, total - 1, total), /*non_blocking=*/true);
     auto write = [&](int64_t rows, decltype(outputs(0)) &o) {
         auto &[bi, ci, gi, indptr, radii, m2, dep, con, comp] = o;
-        check(gsx_project_ewa_packed_write(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
+        { Timed timed_("gsx_project_ewa_packed_write", L.stream); check(gsx_project_ewa_packed_write(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
                                            (uint32_t)C, (uint32_t)N, (uint32_t)width, (uint32_t)height, (float)eps2d,
                                            (float)near_plane, (float)far_plane, (float)radius_clip, (int)camera_model,
                                            cp<int64_t>(cum), rows, mp<int64_t>(bi), mp<int64_t>(ci), mp<int64_t>(gi),
                                            mp<int32_t>(indptr), mp<int32_t>(radii), mp<float>(m2), mp<float>(dep), mp<float>(con),
                                            comp ? mp<float>(*comp) : nullptr, L.stream),
-              "gsx_project_ewa_packed_write");
+              "gsx_project_ewa_packed_write"); }
     };
     if (total * kPackedRowBytes <= kPackedPreallocLimit) {
         auto o = outputs(total);
@@ -284,10 +321,10 @@ Tensor spherical_harmonics(int64_t degrees_to_use, const Tensor &means_, const T
         shape.push_back(d.N); shape.push_back(d.D);
         colors = at::empty(shape, means.options());
     }
-    check(gsx_sh_fwd((int)degrees_to_use, fp(means), fp(viewmats), fp(coeffs), has(masks) ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr,
+    { Timed timed_("gsx_sh_fwd", L.stream); check(gsx_sh_fwd((int)degrees_to_use, fp(means), fp(viewmats), fp(coeffs), has(masks) ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr,
                      cp<int64_t>(bi), cp<int64_t>(ci), cp<int64_t>(gi), (uint32_t)d.B, (uint32_t)d.C, (uint32_t)d.N, nnz, 1,
                      (uint32_t)d.K, (uint32_t)d.D, nullptr, 0, mp<float>(colors), L.stream),
-          "gsx_sh_fwd");
+          "gsx_sh_fwd"); }
     return colors;
 }
 
@@ -313,12 +350,12 @@ spherical_harmonics_bwd(int64_t degrees_to_use, const Tensor &means_, const Tens
     const int64_t nnz = d.packed ? gi->size(0) : -1;
     Tensor v_dirs;
     if (compute_v_viewmats) v_dirs = at::zeros({d.packed ? nnz : d.B * d.C * d.N, 3}, means.options());
-    check(gsx_sh_bwd((int)degrees_to_use, fp(means), fp(viewmats), fp(coeffs), has(masks) ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr,
+    { Timed timed_("gsx_sh_bwd", L.stream); check(gsx_sh_bwd((int)degrees_to_use, fp(means), fp(viewmats), fp(coeffs), has(masks) ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr,
                      cp<int64_t>(bi), cp<int64_t>(ci), cp<int64_t>(gi), (uint32_t)d.B, (uint32_t)d.C, (uint32_t)d.N, nnz, 1,
                      (uint32_t)d.K, (uint32_t)d.D, nullptr, nullptr, vcol.const_data_ptr<float>(), vstride, nullptr,
                      mp<float>(v_coeffs), v_means ? mp<float>(*v_means) : nullptr, v_dirs.defined() ? mp<float>(v_dirs) : nullptr,
                      L.stream),
-          "gsx_sh_bwd");
+          "gsx_sh_bwd"); }
     if (compute_v_viewmats) {
         // dir = mean + R^T t  =>  v_R = t (x) sum_rows v_dir,  v_t = R sum_rows v_dir per camera (small host-side tensors)
         Tensor S;
@@ -380,30 +417,30 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
     if (sort && gsx_isect_fused_supported(uI, utw, uth, packed ? 1 : 0)) {
         Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
         Tensor offsets = at::empty({I * tile_w * tile_h}, means2d.options().dtype(at::kInt));
-        check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
+        { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
                                     mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(),
                                     count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
-              "gsx_isect_fused_count");
+              "gsx_isect_fused_count"); }
         hip_stream.synchronize();
         const int64_t M = *host_total.const_data_ptr<int64_t>();
         TORCH_CHECK(M < (1ll << 31), "intersect_tile: ", M, " intersections overflow the int32 index space");
         Tensor ids = at::empty({M}, means2d.options().dtype(at::kLong)), flat = at::empty({M}, means2d.options().dtype(at::kInt));
         if (M == 0) return {tiles_per_gauss, ids, flat};
         Tensor ws = bytes(gsx_isect_fused_emit_workspace_bytes(M, uI, utw, uth), means2d);
-        check(gsx_isect_fused_emit_sort(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI, uts,
+        { Timed timed_("gsx_isect_fused_emit_sort", L.stream); check(gsx_isect_fused_emit_sort(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI, uts,
                                         utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(), cp<int32_t>(offsets), M,
                                         mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
-              "gsx_isect_fused_emit_sort");
+              "gsx_isect_fused_emit_sort"); }
         return {tiles_per_gauss, ids, flat};
     }
-    check(gsx_isect_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), cp<int64_t>(image_ids), rows, (uint32_t)n_per, uI,
+    { Timed timed_("gsx_isect_count", L.stream); check(gsx_isect_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), cp<int64_t>(image_ids), rows, (uint32_t)n_per, uI,
                           uts, utw, uth, mp<int32_t>(tiles_per_gauss), L.stream),
-          "gsx_isect_count");
+          "gsx_isect_count"); }
     Tensor cum = at::empty({rows}, means2d.options().dtype(at::kLong));
     {
         Tensor ws = bytes(gsx_scan_workspace_bytes(rows), means2d);
-        check(gsx_scan_i32(cp<int32_t>(tiles_per_gauss), rows, mp<int64_t>(cum), ws.mutable_data_ptr(), ws.numel(), L.stream),
-              "gsx_scan_i32");
+        { Timed timed_("gsx_scan_i32", L.stream); check(gsx_scan_i32(cp<int32_t>(tiles_per_gauss), rows, mp<int64_t>(cum), ws.mutable_data_ptr(), ws.numel(), L.stream),
+              "gsx_scan_i32"); }
     }
     host_total.copy_(cum.slice(0, rows - 1, rows), /*non_blocking=*/true);
     hip_stream.synchronize();
@@ -411,23 +448,23 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
     TORCH_CHECK(M < (1ll << 31), "intersect_tile: ", M, " intersections overflow the int32 index space");
     Tensor ids = at::empty({M}, means2d.options().dtype(at::kLong)), flat = at::empty({M}, means2d.options().dtype(at::kInt));
     if (M == 0) return {tiles_per_gauss, ids, flat};
-    check(gsx_isect_emit(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), cp<int64_t>(image_ids),
+    { Timed timed_("gsx_isect_emit", L.stream); check(gsx_isect_emit(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), cp<int64_t>(image_ids),
                          cp<int64_t>(cum), rows, (uint32_t)n_per, uI, uts, utw, uth, mp<int64_t>(ids), mp<int32_t>(flat), L.stream),
-          "gsx_isect_emit");
+          "gsx_isect_emit"); }
     if (!sort) return {tiles_per_gauss, ids, flat};
     Tensor ids2 = at::empty_like(ids), flat2 = at::empty_like(flat);
     if (gsx_isect_tile_sort_supported(uI, utw, uth)) {
         Tensor ws = bytes(gsx_isect_tile_sort_workspace_bytes(M, uI, utw, uth), means2d);
-        check(gsx_isect_tile_sort(cp<int64_t>(ids), cp<int32_t>(flat), M, uI, utw, uth, mp<int64_t>(ids2), mp<int32_t>(flat2),
+        { Timed timed_("gsx_isect_tile_sort", L.stream); check(gsx_isect_tile_sort(cp<int64_t>(ids), cp<int32_t>(flat), M, uI, utw, uth, mp<int64_t>(ids2), mp<int32_t>(flat2),
                                   ws.mutable_data_ptr(), ws.numel(), L.stream),
-              "gsx_isect_tile_sort");
+              "gsx_isect_tile_sort"); }
         return {tiles_per_gauss, ids2, flat2};
     }
     Tensor ws = bytes(gsx_sort_pairs_workspace_bytes(M), means2d);
     int in_alt = 0;
-    check(gsx_sort_pairs(mp<int64_t>(ids), mp<int32_t>(flat), mp<int64_t>(ids2), mp<int32_t>(flat2), M,
+    { Timed timed_("gsx_sort_pairs", L.stream); check(gsx_sort_pairs(mp<int64_t>(ids), mp<int32_t>(flat), mp<int64_t>(ids2), mp<int32_t>(flat2), M,
                          (int)(32 + tile_bits + image_bits), ws.mutable_data_ptr(), ws.numel(), &in_alt, L.stream),
-          "gsx_sort_pairs");
+          "gsx_sort_pairs"); }
     if (in_alt) return {tiles_per_gauss, ids2, flat2};
     return {tiles_per_gauss, ids, flat};
 }
@@ -437,9 +474,9 @@ Tensor intersect_offset(const Tensor &isect_ids_, int64_t I, int64_t tile_w, int
     Launch L(isect_ids_);
     const Tensor ids = contig(isect_ids_);
     Tensor offsets = at::empty({I, tile_h, tile_w}, ids.options().dtype(at::kInt));
-    check(gsx_isect_offsets(cp<int64_t>(ids), ids.numel(), (uint32_t)I, (uint32_t)tile_w, (uint32_t)tile_h, mp<int32_t>(offsets),
+    { Timed timed_("gsx_isect_offsets", L.stream); check(gsx_isect_offsets(cp<int64_t>(ids), ids.numel(), (uint32_t)I, (uint32_t)tile_w, (uint32_t)tile_h, mp<int32_t>(offsets),
                             L.stream),
-          "gsx_isect_offsets");
+          "gsx_isect_offsets"); }
     return offsets;
 }
 
@@ -483,12 +520,12 @@ rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Te
     Tensor renders = at::empty(shape({height, width, r.D}), means2d.options());
     Tensor alphas = at::empty(shape({height, width, 1}), means2d.options());
     Tensor last_ids = at::empty(shape({height, width}), means2d.options().dtype(at::kInt));
-    check(gsx_raster3d_fwd(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
+    { Timed timed_("gsx_raster3d_fwd", L.stream); check(gsx_raster3d_fwd(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
                            masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
                            cp<int32_t>(flat), (uint32_t)r.I, (uint32_t)flat.numel(), (uint32_t)r.D, (uint32_t)width,
                            (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th, mp<float>(renders),
                            mp<float>(alphas), mp<int32_t>(last_ids), L.stream),
-          "gsx_raster3d_fwd");
+          "gsx_raster3d_fwd"); }
     Tensor holder = absgrad ? at::zeros_like(means2d) : at::empty({0}, means2d.options());
     return {renders, alphas, holder, last_ids};
 }
@@ -510,12 +547,12 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
     // ONE zero-filled array-of-structures buffer [R][6 (+2) + D]; the gradients are COLUMN VIEWS of it (gsplat_amd.h)
     const int64_t R = opac.numel(), geo = absgrad ? 8 : 6;
     Tensor rows = at::zeros({R, geo + r.D}, means2d.options());
-    check(gsx_raster3d_bwd(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
+    { Timed timed_("gsx_raster3d_bwd", L.stream); check(gsx_raster3d_bwd(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
                            masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
                            cp<int32_t>(flat), fp(ra), cp<int32_t>(li), fp(v_rc), fp(v_ra), (uint32_t)r.I, (uint32_t)flat.numel(),
                            (uint32_t)r.D, (uint32_t)width, (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th,
                            absgrad ? 1 : 0, mp<float>(rows), (uint32_t)(geo + r.D), L.stream),
-          "gsx_raster3d_bwd");
+          "gsx_raster3d_bwd"); }
     Tensor v_means2d = rows.slice(1, 0, 2).view(means2d.sizes()), v_conics = rows.slice(1, 2, 5).view(conics.sizes());
     Tensor v_opac = rows.select(1, 5).view(opac.sizes()), v_colors = rows.slice(1, geo, geo + r.D).view(colors.sizes());
     OptTensor v_abs, v_bg;
@@ -539,6 +576,42 @@ TORCH_LIBRARY_IMPL(gsplat, CUDA, m)
     m.impl("intersect_offset", &intersect_offset);
     m.impl("rasterize_to_pixels_3dgs", &rasterize_to_pixels_3dgs);
     m.impl("rasterize_to_pixels_3dgs_bwd", &rasterize_to_pixels_3dgs_bwd);
+}
+
+// timing hooks for gsplat_amd/_cabi.py: begin(only = space-separated entry points or "" for all); end() returns
+// "name ms\n" per timed call (synchronises the events) in a buffer owned by this library until the next call
+extern "C" void gsx_torch_profile_begin(const char *only)
+{
+    using namespace gsplat_amd;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_only.clear();
+    std::string w;
+    for (const char *p = only ? only : ""; ; ++p) {
+        if (*p == ' ' || *p == 0) {
+            if (!w.empty()) g_prof_only.insert(w);
+            w.clear();
+            if (*p == 0) break;
+        } else w.push_back(*p);
+    }
+    g_prof_on = true;
+}
+
+extern "C" const char *gsx_torch_profile_end()
+{
+    using namespace gsplat_amd;
+    static std::string out;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_on = false;
+    out.clear();
+    for (auto &r : g_prof) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess)
+            out += r.name + " " + std::to_string(ms) + "\n";
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return out.c_str();
 }
 
 // the ops above, for gsplat_amd/_ops.py (which keeps its Python body for every op NOT named here)
