@@ -509,6 +509,7 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
           if (tl >= t_first && tl < batch_size) {
               const float4 cu = s_cull[tl];
               hit = (fabsf(cu.x - rect.cx) - rect.hw <= cu.z) && (fabsf(cu.y - rect.cy) - rect.hh <= cu.w);
+              if (hit) hit = rect_reaches_level(s_st[tl].p0, s_st[tl].p1, cu.x, cu.y, rect); // exact second stage
           }
           uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
           while (todo) {
