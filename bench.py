@@ -108,15 +108,25 @@ def timed(step_fn, steps, warmup, barrier, profile_only=None):
     barrier()
     if profile_only:
         _cabi.profile_begin(only=profile_only)
+    import gc
+
+    gc_was_on = gc.isenabled()
+    gc.disable()  # no cyclic-GC sweep inside the timed steps (a full sweep is 40-60 ms once torch.distributed is imported)
     t0 = time.perf_counter()
+    per = []
     for _ in range(steps):
+        ts = time.perf_counter()
         meta = step_fn()
+        per.append(time.perf_counter() - ts)
     t_enq = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
     if os.environ.get("GSPLAT_BENCH_DEBUG"):  # host-side enqueue time vs. wall time of the timed steps
-        print(f"[bench] enqueue {t_enq / steps * 1e3:.3f} ms/step, wall {elapsed / steps * 1e3:.3f} ms/step", file=sys.stderr)
+        print(f"[bench] enqueue {t_enq / steps * 1e3:.3f} ms/step, wall {elapsed / steps * 1e3:.3f} ms/step; per step: "
+              + " ".join(f"{x * 1e3:.1f}" for x in per), file=sys.stderr)
     prof = _cabi.profile_end() if profile_only else {}
+    if gc_was_on:
+        gc.enable()
     return elapsed, meta, prof
 
 
