@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
         // block-wide early out: every pixel of the tile finished. Also fences LDS reuse.
         if (__syncthreads_count(!(thr < INFINITY)) == (int)blockDim.x) break;
 
-        const int32_t batch_start = range_start + kBatch * b;
+        const int32_t batch_start = __builtin_amdgcn_readfirstlane(range_start + kBatch * b); // wave-uniform: keep it scalar
         for (int s = (int)tid; s < kBatch; s += (int)blockDim.x) {
             const int32_t idx = batch_start + s;
             if (idx < range_end) {
@@ -119,35 +119,28 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 
                 const v4f p0 = s_st[t].p0;
                 const v4f p1 = s_st[t].p1;
+                const v4f p2 = s_st[t].p2; // one address register for the three reads (b128 + b128 + b64 / b128)
                 const float e     = staged_e(p0, p1.x, p1.y, p1.z, u, v);
                 const float alpha = fminf(kMaxAlpha, __builtin_amdgcn_exp2f(e));
                 // Branch-free body. The scalar unit, not the vector ALU, was the busiest pipe of this kernel when "pixel is
                 // done" lived in an EXEC-style mask (25 scalar instructions per surviving Gaussian, r05 PMC): the state now
-                // lives in vector registers - `thr` is the pixel's alpha threshold and becomes +inf once it is done.
+                // lives in vector registers - `thr` is the pixel's alpha threshold and becomes +inf once it is done - and the
+                // three decisions (passes / saturates / is blended) are lane masks combined on the scalar side.
                 const bool ok = !(e > p0.w) && !(alpha < thr); // e > lo <=> sigma < 0
                 if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue; // wave-uniform
-                float a_m          = ok ? alpha : 0.0f;
-                const float next_T = fmaf(-T, a_m, T);                    // == T when a_m == 0, and T > 1e-4 while not done
-                const bool sat     = next_T <= kTransmittanceThresh;      // saturated: this Gaussian is excluded
-                thr                = sat ? INFINITY : thr;
-                a_m                = sat ? 0.0f : a_m;
-                const float w      = a_m * T;
-                if constexpr (CH <= 3) { // colours 0, 1 as one b64 (one v_pk_fma_f32), colour 2 came with p1
-                    const v2f c01 = *reinterpret_cast<const v2f *>(&s_st[t].p2);
-                    acc[0] += c01.x * w;
-                    if constexpr (CH > 1) acc[1] += c01.y * w;
-                    if constexpr (CH > 2) acc[2] += p1.w * w;
-                } else {
-                    const v4f p2 = s_st[t].p2;
-                    acc[0] += p2.x * w;
-                    acc[1] += p2.y * w;
-                    acc[2] += p1.w * w;
-                    acc[3] += p2.z * w;
-                }
+                const float next_T = fmaf(-T, alpha, T);
+                const bool low     = next_T <= kTransmittanceThresh; // saturated: this Gaussian is excluded
+                const bool sat = ok && low, take = ok && !sat;
+                const float w  = take ? alpha * T : 0.0f;
+                acc[0] += p2.x * w;
+                if constexpr (CH > 1) acc[1] += p2.y * w;
+                if constexpr (CH > 2) acc[2] += p1.w * w;
+                if constexpr (CH > 3) acc[3] += p2.z * w;
 #pragma unroll
                 for (int k = 4; k < CH; ++k) acc[k] += s_col[t * CX + k - 4] * w;
-                cur_idx = a_m > 0.0f ? (uint32_t)(batch_start + t) : cur_idx;
-                T       = sat ? T : next_T;
+                cur_idx = take ? (uint32_t)(batch_start + t) : cur_idx;
+                T       = take ? next_T : T;
+                thr     = sat ? INFINITY : thr;
             }
         }
     }
