@@ -367,12 +367,9 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
     const int32_t range_end = tc.range_end;
     const int32_t n_batches = (range_end - range_start + BATCH - 1) / BATCH;
     if (n_batches <= 0) return; // uniform: no pixel of the tile has a contributor
-    float v_c[CH], buffer[CH];
+    float v_c[CH];
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-        v_c[k]    = (inside && k < (int)a.nch) ? a.v_render_colors[pix * a.cdim + a.ch_off + k] : 0.0f;
-        buffer[k] = 0.0f;
-    }
+    for (int k = 0; k < CH; ++k) v_c[k] = (inside && k < (int)a.nch) ? a.v_render_colors[pix * a.cdim + a.ch_off + k] : 0.0f;
     const float v_a = (inside && a.first_chunk && a.v_render_alphas) ? a.v_render_alphas[pix] : 0.0f;
     float bg_dot    = 0.0f;
     if (a.backgrounds) {
@@ -381,7 +378,8 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
         for (int k = 0; k < CH; ++k)
             if (k < (int)a.nch) bg_dot += bg[k] * v_c[k];
     }
-    const float va_minus_bg      = v_a - bg_dot;
+    const float tail_term = T_final * (v_a - bg_dot); // T_final (v_a - bg . v_c): what lies behind the whole list
+    float behind          = 0.0f;                     // B = sum_k buffer_k v_c,k (see the pixel loop)
     const WaveRect rect          = wave_pixel_rect(inside, pu, pv); // tile-centre coordinates, like s_cull
 
     // roles in a turn: this lane owns slot bg and quadrant row bv (pixels 8 bv .. 8 bv + 7 of the wave, u = 0..7)
@@ -541,14 +539,14 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
             const float ra    = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
             T                *= ra;
             const float fac   = alpha * T;
-            float v_alpha     = 0.0f;
+            // v_alpha = sum_k (c_k T - buffer_k / (1 - alpha)) v_c,k + T_final / (1 - alpha) (v_a - bg . v_c)  (Device.cuh:105-173)
+            // with buffer_k = sum over the Gaussians behind of c_k fac. Only the dot product B = sum_k buffer_k v_c,k is ever
+            // used, and it obeys B += fac (c . v_c): one scalar per pixel instead of D, 7 instructions instead of 14.
+            float cv = col[0] * v_c[0];
 #pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const float c = col[k];
-                v_alpha      += (c * T - buffer[k] * ra) * v_c[k];
-                buffer[k]    += c * fac;
-            }
-            v_alpha += T_final * ra * va_minus_bg;
+            for (int k = 1; k < CH; ++k) cv = fmaf(col[k], v_c[k], cv);
+            const float v_alpha = fmaf(ra, tail_term - behind, cv * T);
+            behind              = fmaf(fac, cv, behind);
             const float v_sigma = (ov <= kMaxAlpha) ? -ov * v_alpha : 0.0f; // alpha-clamp branch: no geometry gradient
             *reinterpret_cast<float2 *>(w_ptr) = make_float2(fac, v_sigma); // ds_write_b64 into slot `slot`
             w_ptr += WROW;
