@@ -426,7 +426,12 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
 #pragma unroll
         for (int k = 0; k < Cfg::KG * 4; ++k) acc[k] = 0.0f;
         const float4 *wr = reinterpret_cast<const float4 *>(s_ww + bg * WROW + bv * WGRP);
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f; // sum w, sum w u, sum w u^2 over the row
+        // Packed fp32 (v_pk_fma_f32: two FMAs per issue slot): the colour sums in pairs, (sum w u, sum w u^2) as a pair whose
+        // multiplier (u, u^2) is a compile-time constant. 4 (D = 3) instead of 6 instructions per pixel.
+        v2f cpair[(CH + 1) / 2], s12 = v2f{0.0f, 0.0f}; // colour sums 2k, 2k+1 | sum w u, sum w u^2 over the row
+#pragma unroll
+        for (int k = 0; k < (CH + 1) / 2; ++k) cpair[k] = v2f{0.0f, 0.0f};
+        float s0 = 0.0f; // sum w
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const float4 x = wr[h]; // (fac, w) of u = 2h, 2h + 1
@@ -436,12 +441,17 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
                 const int ui  = 2 * h + e;
                 const float u = (float)ui;
 #pragma unroll
-                for (int k = 0; k < CH; ++k) acc[k] = fmaf(ff[e], vcr[ui][k], acc[k]);
+                for (int k = 0; k < (CH + 1) / 2; ++k) {
+                    const v2f vc = v2f{vcr[ui][2 * k], 2 * k + 1 < CH ? vcr[ui][2 * k + 1 < CH ? 2 * k + 1 : 0] : 0.0f};
+                    cpair[k]     = v2f{ff[e], ff[e]} * vc + cpair[k];
+                }
                 s0 += ww[e];
-                s1 = fmaf(ww[e], u, s1);
-                s2 = fmaf(ww[e], u * u, s2);
+                s12 = v2f{ww[e], ww[e]} * v2f{u, u * u} + s12;
             }
         }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) acc[k] = (k & 1) ? cpair[k / 2].y : cpair[k / 2].x;
+        const float s1 = s12.x, s2 = s12.y;
         // quadrant coordinates -> tile coordinates: u' = u + u0, v' = bv + v0 (one row per lane, so v' is a constant here)
         {
             const float vt = (float)bv + v0;
