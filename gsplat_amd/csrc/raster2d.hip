@@ -318,12 +318,9 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
     const int32_t n_batches = (range_end - range_start + BATCH - 1) / BATCH;
     if (n_batches <= 0) return;
     const int32_t median_idx = inside ? a.median_ids[pix] : -1;
-    float v_c[CH], buffer[CH], v_n[3], buffer_n[3] = {0.f, 0.f, 0.f};
+    float v_c[CH], v_n[3];
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-        v_c[k]    = (inside && k < nch) ? a.v_render_colors[pix * a.cdim + k] : 0.0f;
-        buffer[k] = 0.0f;
-    }
+    for (int k = 0; k < CH; ++k) v_c[k] = (inside && k < nch) ? a.v_render_colors[pix * a.cdim + k] : 0.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) v_n[k] = inside ? a.v_render_normals[pix * 3 + k] : 0.0f;
     const float v_a      = inside ? a.v_render_alphas[pix] : 0.0f;
@@ -335,6 +332,8 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
         for (int k = 0; k < CH; ++k)
             if (k < nch) bg_dot += bg[k] * v_c[k];
     }
+    const float tail_term = T_final * (v_a - bg_dot); // what lies behind the whole list
+    float behind          = 0.0f;                     // B (see the pixel loop)
     const bool dist = a.v_render_distort != nullptr;
     float v_distort = 0.f, accum_d = 0.f, accum_w = 0.f, accum_d_buffer = 0.f, accum_w_buffer = 0.f, distort_buffer = 0.f;
     if (dist && inside) {
@@ -405,23 +404,23 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
             const float ra  = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
             T              *= ra;
             const float fac = alpha * T;
-            float v_alpha   = 0.0f;
+            // The back-buffers of the colour and normal channels only enter through their dot product with the pixel's
+            // cotangents, B = sum_k buffer_k v_k, and B += fac (c . v_c + n . v_n): one scalar per pixel (raster3d_bwd.hip).
+            float cv = 0.0f;
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
-                const float c = s_col[t * CH + k];
-                loc[k]        = fac * v_c[k];
-                v_alpha      += (c * T - buffer[k] * ra) * v_c[k];
-                buffer[k]    += c * fac;
+                loc[k] = fac * v_c[k];
+                cv     = fmaf(s_col[t * CH + k], v_c[k], cv);
             }
             const float4 nr = s_N[t];
             const float nrv[3] = {nr.x, nr.y, nr.z};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                loc[CH + k]  = fac * v_n[k];
-                v_alpha     += (nrv[k] * T - buffer_n[k] * ra) * v_n[k];
-                buffer_n[k] += nrv[k] * fac;
+                loc[CH + k] = fac * v_n[k];
+                cv          = fmaf(nrv[k], v_n[k], cv);
             }
-            v_alpha += T_final * ra * (v_a - bg_dot);
+            float v_alpha = fmaf(ra, tail_term - behind, cv * T);
+            behind        = fmaf(fac, cv, behind);
             float v_depth_ch = (valid && (batch_end - t == median_idx)) ? v_median : 0.0f; // extra grad of last channel
             if (dist) {
                 const float depth = s_col[t * CH + nch - 1];
