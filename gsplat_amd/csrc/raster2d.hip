@@ -77,24 +77,36 @@ __device__ __forceinline__ float4 surfel_cull_box(const float *M, float mx, floa
 struct Surfel { // one pixel x one surfel
     bool valid;
     float alpha, vis, gw3, gw2, sx, sy, dx, dy, rcz_inv;
-    float hu[3], hv[3];
 };
 
-__device__ __forceinline__ Surfel eval_surfel(const float4 A /*uM, x*/, const float4 B /*vM, y*/, const float4 C /*wM, opac*/,
-                                              float px, float py, float thr = kAlphaThreshold)
+// zeta = h_u x h_v with h_u = px w - u, h_v = py w - v is AFFINE in the pixel: (px w - u) x (py w - v) = u x v + px (v x w) +
+// py (w x u) (the px py term is w x w = 0). So per (tile, surfel) the staging thread forms zeta at the TILE CENTRE with the
+// well-conditioned product of the two small vectors h_u(c), h_v(c), plus the two gradients Z1 = v x w and Z2 = w x u, and a
+// pixel at q = pixel - centre (|q| <= 7.5) costs 6 FMAs for zeta instead of 6 + 9 for the two rays and their cross product.
+// Staged as three float4: (zeta_c, mean.x - c.x), (Z1, mean.y - c.y), (Z2, opacity).
+__device__ __forceinline__ void stage_surfel(const float *M, float mx, float my, float opac, float cx, float cy, float4 &a,
+                                             float4 &b, float4 &c)
+{
+    const float hu[3] = {cx * M[6] - M[0], cx * M[7] - M[1], cx * M[8] - M[2]};
+    const float hv[3] = {cy * M[6] - M[3], cy * M[7] - M[4], cy * M[8] - M[5]};
+    a = make_float4(hu[1] * hv[2] - hu[2] * hv[1], hu[2] * hv[0] - hu[0] * hv[2], hu[0] * hv[1] - hu[1] * hv[0], mx - cx);
+    b = make_float4(M[4] * M[8] - M[5] * M[7], M[5] * M[6] - M[3] * M[8], M[3] * M[7] - M[4] * M[6], my - cy); // v x w
+    c = make_float4(M[7] * M[2] - M[8] * M[1], M[8] * M[0] - M[6] * M[2], M[6] * M[1] - M[7] * M[0], opac);    // w x u
+}
+
+__device__ __forceinline__ Surfel eval_surfel(const float4 A /*zeta_c, x'*/, const float4 B /*Z1, y'*/, const float4 C /*Z2, opac*/,
+                                              float qx, float qy, float thr = kAlphaThreshold)
 {
     Surfel s;
-    s.hu[0] = px * C.x - A.x; s.hu[1] = px * C.y - A.y; s.hu[2] = px * C.z - A.z;
-    s.hv[0] = py * C.x - B.x; s.hv[1] = py * C.y - B.y; s.hv[2] = py * C.z - B.z;
-    const float rx = s.hu[1] * s.hv[2] - s.hu[2] * s.hv[1];
-    const float ry = s.hu[2] * s.hv[0] - s.hu[0] * s.hv[2];
-    const float rz = s.hu[0] * s.hv[1] - s.hu[1] * s.hv[0];
+    const float rx = fmaf(qy, C.x, fmaf(qx, B.x, A.x));
+    const float ry = fmaf(qy, C.y, fmaf(qx, B.y, A.y));
+    const float rz = fmaf(qy, C.z, fmaf(qx, B.z, A.z));
     s.rcz_inv = __builtin_amdgcn_rcpf(rz);
     s.sx  = rx * s.rcz_inv;
     s.sy  = ry * s.rcz_inv;
     s.gw3 = s.sx * s.sx + s.sy * s.sy;
-    s.dx  = A.w - px;
-    s.dy  = B.w - py;
+    s.dx  = A.w - qx;
+    s.dy  = B.w - qy;
     s.gw2 = kFilterInvSquare2DGS * (s.dx * s.dx + s.dy * s.dy);
     const float sigma = 0.5f * fminf(s.gw3, s.gw2);
     s.vis   = __expf(-sigma);
@@ -131,6 +143,9 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
     const uint32_t ox = tile_x * a.tile_size + lx, oy = tile_y * a.tile_size + ly;
     const bool inside = (lx < a.tile_size) && (ly < a.tile_size) && (ox < a.width) && (oy < a.height);
     const float px = (float)ox + 0.5f, py = (float)oy + 0.5f;
+    const float half = 0.5f * (float)a.tile_size; // tile centre, and this lane's pixel centre relative to it (exact)
+    const float tcx = (float)(tile_x * a.tile_size) + half, tcy = (float)(tile_y * a.tile_size) + half;
+    const float qx = (float)lx + 0.5f - half, qy = (float)ly + 0.5f - half;
     const size_t pix = ((size_t)image_id * a.height + oy) * a.width + ox;
     const float *bg = a.backgrounds ? a.backgrounds + (size_t)image_id * a.cdim : nullptr;
     const int nch   = (int)a.cdim;
@@ -173,10 +188,8 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
                 const int32_t g = a.flatten_ids[idx];
                 const float *M  = a.ray_transforms + 9 * (size_t)g;
                 const float2 xy = reinterpret_cast<const float2 *>(a.means2d)[g];
-                s_A[s] = make_float4(M[0], M[1], M[2], xy.x);
-                s_B[s] = make_float4(M[3], M[4], M[5], xy.y);
                 const float opac = a.opacities[g];
-                s_C[s] = make_float4(M[6], M[7], M[8], opac);
+                stage_surfel(M, xy.x, xy.y, opac, tcx, tcy, s_A[s], s_B[s], s_C[s]);
                 s_cull[s] = surfel_cull_box(M, xy.x, xy.y, opac);
                 const float *n = a.normals + 3 * (size_t)g;
                 s_N[s] = make_float4(n[0], n[1], n[2], 0.0f);
@@ -202,7 +215,7 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
             const int32_t bit = (int32_t)__builtin_ctzll(todo);
             const int32_t t   = j + bit;
             asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction
-            const Surfel s = eval_surfel(s_A[t], s_B[t], s_C[t], px, py, thr);
+            const Surfel s = eval_surfel(s_A[t], s_B[t], s_C[t], qx, qy, thr);
             // Branch-free body (raster3d_fwd.hip: the scalar unit, not the vector ALU, is the busy pipe when the pixel's
             // state lives in exec-style masks): `thr` is this pixel's alpha threshold, +inf once it is done.
             if (__builtin_amdgcn_ballot_w64(s.valid) == 0ull) continue; // wave-uniform
@@ -255,7 +268,7 @@ struct Bwd2Cfg {
     static constexpr int KP    = (K | 1);
     static constexpr int BATCH = (CH >= 8) ? 64 : 128;
     static constexpr size_t smem =
-        (size_t)BATCH * (5 * sizeof(float4) + 2 * sizeof(int32_t) + sizeof(float) * (CH + KP));
+        (size_t)BATCH * (8 * sizeof(float4) + 2 * sizeof(int32_t) + sizeof(float) * (CH + KP));
 };
 
 template <int CH, bool ABS>
@@ -273,7 +286,10 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
     float4 *s_C      = s_B + BATCH;
     float4 *s_N      = s_C + BATCH;
     float4 *s_cull   = s_N + BATCH;
-    int32_t *s_id    = reinterpret_cast<int32_t *>(s_cull + BATCH);
+    float4 *s_Za     = s_cull + BATCH; // evaluation form (stage_surfel): zeta at the tile centre | Z1 | Z2
+    float4 *s_Zb     = s_Za + BATCH;
+    float4 *s_Zc     = s_Zb + BATCH;
+    int32_t *s_id    = reinterpret_cast<int32_t *>(s_Zc + BATCH);
     int32_t *s_touch = s_id + BATCH;
     float *s_col     = reinterpret_cast<float *>(s_touch + BATCH);
     float *s_acc     = s_col + BATCH * CH;
@@ -291,6 +307,9 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
     const uint32_t ox = tile_x * a.tile_size + lx, oy = tile_y * a.tile_size + ly;
     const bool inside = (lx < a.tile_size) && (ly < a.tile_size) && (ox < a.width) && (oy < a.height);
     const float px = (float)ox + 0.5f, py = (float)oy + 0.5f;
+    const float half = 0.5f * (float)a.tile_size;
+    const float tcx = (float)(tile_x * a.tile_size) + half, tcy = (float)(tile_y * a.tile_size) + half;
+    const float qx = (float)lx + 0.5f - half, qy = (float)ly + 0.5f - half;
     const size_t pix = inside ? ((size_t)image_id * a.height + oy) * a.width + ox : 0;
     const int nch    = (int)a.cdim;
     const float X0 = (float)(tile_x * a.tile_size), Y0 = (float)(tile_y * a.tile_size); // tile origin
@@ -365,6 +384,7 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
                 s_B[s]  = make_float4(M[3], M[4], M[5], xy.y);
                 const float opac = a.opacities[g];
                 s_C[s]  = make_float4(M[6], M[7], M[8], opac);
+                stage_surfel(M, xy.x, xy.y, opac, tcx, tcy, s_Za[s], s_Zb[s], s_Zc[s]);
                 s_cull[s] = surfel_cull_box(M, xy.x, xy.y, opac);
                 const float *n = a.normals + 3 * (size_t)g;
                 s_N[s]  = make_float4(n[0], n[1], n[2], 0.0f);
@@ -388,8 +408,8 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
             const int32_t bit = (int32_t)__builtin_ctzll(todo);
             const int32_t t   = j + bit;
             asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction
-            const float4 A = s_A[t], B = s_B[t], C = s_C[t];
-            const Surfel s = eval_surfel(A, B, C, px, py);
+            const float4 C = s_Zc[t];
+            const Surfel s = eval_surfel(s_Za[t], s_Zb[t], C, qx, qy);
             const bool valid = inside && (batch_end - t <= bin_final) && s.valid;
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
 
