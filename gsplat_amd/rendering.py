@@ -553,6 +553,57 @@ def _depth_to_normal(depths: Tensor, camtoworlds: Tensor, Ks: Tensor) -> Tensor:
     return torch.nn.functional.pad(normals, (0, 0, 1, 1, 1, 1), value=0.0)
 
 
+class _SurfelPost(torch.autograd.Function):
+    """The per-pixel tail of rasterization_2dgs as one launch per direction (csrc/surfel_post.hip): expected-depth
+    normalisation, camera->world rotation of the rendered normals, normals from the depth map. Same maths as the tensor-op
+    composition below it in rasterization_2dgs (the reference's: gsplat/rendering.py:1519-1552); no gradient to the cameras,
+    so the caller uses it only when viewmats / Ks do not require one."""
+
+    @staticmethod
+    def forward(ctx, colors, alphas, normals, median, viewmats, Ks, expected_depth: bool, depth_source: int):
+        from ._cabi import call, ptr
+
+        I = viewmats.numel() // 16
+        H, W, D = colors.shape[-3], colors.shape[-2], colors.shape[-1]
+        colors, alphas, normals = colors.contiguous(), alphas.contiguous(), normals.contiguous()
+        median = median.contiguous() if depth_source == 2 else None
+        viewmats, Ks = viewmats.contiguous(), Ks.contiguous()
+        colors_out = torch.empty_like(colors) if expected_depth else None
+        normals_world = torch.empty_like(normals)
+        surf = torch.empty_like(normals) if depth_source else None
+        call("gsx_surfel_post_fwd", ptr(colors), ptr(alphas), ptr(normals), ptr(median), ptr(viewmats), ptr(Ks), I, W, H, D,
+             int(expected_depth), depth_source, ptr(colors_out), ptr(normals_world), ptr(surf))
+        ctx.save_for_backward(colors, alphas, normals, median, viewmats, Ks)
+        ctx.cfg = (I, W, H, D, bool(expected_depth), depth_source)
+        unused = [colors.new_empty(0) for _ in range(2)]  # placeholders for the outputs this mode does not produce
+        if not expected_depth:
+            colors_out = unused[0]
+            ctx.mark_non_differentiable(colors_out)
+        if not depth_source:
+            surf = unused[1]
+            ctx.mark_non_differentiable(surf)
+        return colors_out, normals_world, surf
+
+    @staticmethod
+    def backward(ctx, v_colors_out, v_normals_world, v_surf):
+        from ._cabi import call, ptr
+
+        colors, alphas, normals, median, viewmats, Ks = ctx.saved_tensors
+        I, W, H, D, expected_depth, depth_source = ctx.cfg
+        v_colors_out = v_colors_out.contiguous() if expected_depth and v_colors_out is not None else None
+        if expected_depth and v_colors_out is None:
+            v_colors_out = torch.zeros_like(colors)
+        v_normals_world = torch.zeros_like(normals) if v_normals_world is None else v_normals_world.contiguous()
+        v_surf = v_surf.contiguous() if depth_source and v_surf is not None else None
+        v_colors, v_normals = torch.empty_like(colors), torch.empty_like(normals)
+        v_alphas = torch.empty_like(alphas) if expected_depth else None
+        v_median = torch.empty_like(median) if depth_source == 2 else None
+        call("gsx_surfel_post_bwd", ptr(colors), ptr(alphas), ptr(normals), ptr(median), ptr(viewmats), ptr(Ks), I, W, H, D,
+             int(expected_depth), depth_source, ptr(v_colors_out), ptr(v_normals_world), ptr(v_surf), ptr(v_colors),
+             ptr(v_alphas), ptr(v_normals), ptr(v_median))
+        return v_colors, v_alphas, v_normals, v_median, None, None, None, None
+
+
 def rasterization_2dgs(
     means: Tensor,  # [..., N, 3]
     quats: Tensor,  # [..., N, 4]
@@ -658,15 +709,26 @@ def rasterization_2dgs(
         means2d, ray_transforms, feats, proj_opacities, normals, densify, width, height, tile_size, isect_offsets,
         flatten_ids, backgrounds=raster_bg, packed=packed, absgrad=absgrad, distloss=distloss)
 
-    if expected_depth:
-        ed = render_colors[..., -1:] / render_alphas.clamp_min(1e-10)
-        render_colors = torch.cat([render_colors[..., :-1], ed], dim=-1) if render_colors.shape[-1] > 1 else ed
-    camtoworlds = torch.linalg.inv(viewmats)
+    want_surf = append_depth and has_color
     surf_normals = None
-    if append_depth and has_color:
-        depth_for_normal = render_median if depth_mode == "median" else render_colors[..., -1:]
-        surf_normals = _depth_to_normal(depth_for_normal, camtoworlds, Ks).squeeze(0)  # as Rendering.cpp:1926
-    render_normals = torch.einsum("...ij,...hwj->...hwi", camtoworlds[..., :3, :3], render_normals)
+    if not (viewmats.requires_grad or Ks.requires_grad) and render_colors.dtype == torch.float32:
+        # one launch per direction for the whole per-pixel tail (csrc/surfel_post.hip)
+        depth_source = (2 if depth_mode == "median" else 1) if want_surf else 0
+        colors_out, render_normals, surf = _SurfelPost.apply(render_colors, render_alphas, render_normals, render_median,
+                                                              viewmats, Ks, expected_depth, depth_source)
+        if expected_depth:
+            render_colors = colors_out
+        if want_surf:
+            surf_normals = surf.squeeze(0)  # as Rendering.cpp:1926
+    else:  # cameras are being optimised: the same maths from tensor ops, so that autograd reaches viewmats / Ks
+        if expected_depth:
+            ed = render_colors[..., -1:] / render_alphas.clamp_min(1e-10)
+            render_colors = torch.cat([render_colors[..., :-1], ed], dim=-1) if render_colors.shape[-1] > 1 else ed
+        camtoworlds = torch.linalg.inv(viewmats)
+        if want_surf:
+            depth_for_normal = render_median if depth_mode == "median" else render_colors[..., -1:]
+            surf_normals = _depth_to_normal(depth_for_normal, camtoworlds, Ks).squeeze(0)
+        render_normals = torch.einsum("...ij,...hwj->...hwi", camtoworlds[..., :3, :3], render_normals)
 
     meta = {
         "camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": radii, "means2d": means2d, "depths": depths,

@@ -440,6 +440,31 @@ int gsx_raster2d_bwd(const float *means2d, const float *ray_transforms, const fl
                      uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows,
                      uint32_t row_stride, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 2DGS per-pixel post-processing (reference: gsplat/rendering.py:1519-1552; C++ orchestrator
+ * gsplat/cuda/csrc/Rendering.cpp:1653-1702 depth_to_points_2dgs / depth_to_normal_2dgs and :1905-1935, composed there from
+ * ATen ops). One launch per direction:
+ *   expected_depth != 0: colors_out = colors with the last channel divided by max(alpha, 1e-10)   (else colors_out = NULL)
+ *   normals_world      = inv(viewmat)[:3,:3] . normals                                            (always)
+ *   depth_source 1 | 2 : surf_normals = normalize(cross(P(y+1,x) - P(y-1,x), P(y,x+1) - P(y,x-1))) of the points
+ *                        unprojected from the depth map (1: the last colour channel AFTER the normalisation above,
+ *                        2: the median depth map), zero on the one-pixel border                   (0: surf_normals = NULL)
+ * colors [I,H,W,cdim], alphas / median [I,H,W], normals [I,H,W,3], viewmats [I,4,4] (world-to-camera, last row 0 0 0 1;
+ * inverted in the kernel), Ks [I,3,3]. The backward takes the output gradients (v_colors_out NULL iff !expected_depth,
+ * v_surf_normals NULL when that output got no gradient) and WRITES v_colors [I,H,W,cdim], v_alphas (may be NULL unless
+ * expected_depth), v_normals, v_median (may be NULL). No gradient reaches viewmats / Ks: callers that differentiate the
+ * cameras compose the same maths from tensor ops instead.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_surfel_post_fwd(const float *colors, const float *alphas, const float *normals, const float *median,
+                        const float *viewmats, const float *Ks, uint32_t n_images, uint32_t width, uint32_t height,
+                        uint32_t cdim, int expected_depth, int depth_source, float *colors_out, float *normals_world,
+                        float *surf_normals, void *stream);
+int gsx_surfel_post_bwd(const float *colors, const float *alphas, const float *normals, const float *median,
+                        const float *viewmats, const float *Ks, uint32_t n_images, uint32_t width, uint32_t height,
+                        uint32_t cdim, int expected_depth, int depth_source, const float *v_colors_out,
+                        const float *v_normals_world, const float *v_surf_normals, float *v_colors, float *v_alphas,
+                        float *v_normals, float *v_median, void *stream);
+
 /* Instrumentation (no reference counterpart): work counters of the compositing pass, for the vector-ALU roofline of
  * bench.py (pairs x (14 + 2 D) flop against the fp32 peak). Replays the forward walk of
  * gsx_raster3d_fwd and ADDS to stats[0..3] (caller zeroes them):

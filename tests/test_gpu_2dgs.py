@@ -378,3 +378,65 @@ def test_rasterization_2dgs_empty_and_invisible_scenes(packed):
         for k in names:
             g = leaves[k].grad
             assert g is None or float(g.abs().sum()) == 0.0, k
+
+
+@pytest.mark.parametrize("expected_depth,depth_source", [(True, 1), (False, 1), (True, 2), (True, 0), (False, 0)])
+@pytest.mark.parametrize("C,W,H", [(2, 150, 37), (1, 64, 4), (1, 3, 3)])
+def test_surfel_post_matches_tensor_ops(G, expected_depth, depth_source, C, W, H):
+    """The fused per-pixel tail of rasterization_2dgs (csrc/surfel_post.hip) against the tensor-op composition it replaces
+    (the reference's: gsplat/rendering.py:1519-1552, utils.py depth_to_normal with F.normalize), evaluated in float64 on the
+    same inputs: outputs and every gradient. Includes pixels with alpha 0 / depth 0 (zero-length cross products)."""
+    from gsplat_amd.rendering import _SurfelPost, _depth_to_points
+
+    g = torch.Generator().manual_seed(W * 31 + H)
+    D = 4
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    alphas = (0.3 + 0.7 * torch.rand(C, H, W, 1, generator=g))
+    depth = 2.0 + 0.02 * xx[None, :, :, None] + 0.03 * yy[None, :, :, None] + 0.2 * torch.rand(C, H, W, 1, generator=g)
+    colors = torch.cat([torch.rand(C, H, W, D - 1, generator=g), depth * (alphas if expected_depth else 1.0)], -1)
+    median = depth + 0.1 * torch.rand(C, H, W, 1, generator=g)
+    if H > 8:  # an empty region: nothing composited
+        alphas[:, :6, :9] = 0.0
+        colors[:, :6, :9] = 0.0
+        median[:, :6, :9] = 0.0
+    normals = torch.randn(C, H, W, 3, generator=g)
+    sc, _, _ = make_scene(N=4, C=C, width=W, height=H, seed=5)
+    viewmats, Ks = sc["viewmats"], sc["Ks"]
+    w = [torch.randn(C, H, W, k, generator=g) for k in (D, 3, 3)]
+
+    def reference(colors, alphas, normals, median, dt):
+        vm, K = viewmats.to(DEV, dt), Ks.to(DEV, dt)
+        if expected_depth:
+            colors = torch.cat([colors[..., :-1], colors[..., -1:] / alphas.clamp_min(1e-10)], -1)
+        c2w = torch.linalg.inv(vm)
+        surf = None
+        if depth_source:
+            pts = _depth_to_points(median if depth_source == 2 else colors[..., -1:], c2w, K)
+            du = pts[..., 2:, 1:-1, :] - pts[..., :-2, 1:-1, :]
+            dv = pts[..., 1:-1, 2:, :] - pts[..., 1:-1, :-2, :]
+            surf = torch.nn.functional.pad(torch.nn.functional.normalize(torch.linalg.cross(du, dv, dim=-1), dim=-1),
+                                           (0, 0, 1, 1, 1, 1))
+        return colors, torch.einsum("...ij,...hwj->...hwi", c2w[..., :3, :3], normals), surf
+
+    def loss(outs):
+        return sum((o * x.to(o)).sum() for o, x in zip(outs, w) if o is not None and o.numel())
+
+    leaves = [t.to(DEV).clone().requires_grad_(True) for t in (colors, alphas, normals, median)]
+    co, nw, sn = _SurfelPost.apply(*leaves, viewmats.to(DEV), Ks.to(DEV), expected_depth, depth_source)
+    got = (co if expected_depth else None, nw, sn if depth_source else None)
+    loss(got).backward()
+    ref_leaves = [t.to(DEV, torch.float64).clone().requires_grad_(True) for t in (colors, alphas, normals, median)]
+    want = reference(*ref_leaves, torch.float64)
+    loss((want[0] if expected_depth else None, want[1], want[2])).backward()
+    for nm, a, b in zip(("colors", "normals_world", "surf_normals"), got, want):
+        if a is None:
+            continue
+        # the normal of a nearly flat patch is a difference of nearly equal products: fp32 carries ~1e-4 of it
+        tol = 2e-3 if nm == "surf_normals" else 1e-5
+        assert_close_ratio(cpu(a), cpu(b).float(), tol, tol, max_bad_ratio=2e-3 if nm == "surf_normals" else 0.0, name=nm)
+    for nm, a, b in zip(("v_colors", "v_alphas", "v_normals", "v_median"), leaves, ref_leaves):
+        if b.grad is None:
+            assert a.grad is None or float(a.grad.abs().max()) == 0.0, nm
+            continue
+        assert torch.isfinite(a.grad).all(), nm
+        assert_grad_close(cpu(a.grad), cpu(b.grad).float(), rel=5e-3 if depth_source else 1e-5, max_bad_ratio=2e-3, name=nm)
