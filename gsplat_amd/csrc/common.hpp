@@ -13,6 +13,9 @@
 
 namespace gsx {
 
+typedef float v4f __attribute__((ext_vector_type(4))); // true vector types: one ds_read_b128 / b64 per load (a HIP float4 is
+typedef float v2f __attribute__((ext_vector_type(2))); // a struct of scalars that the backend re-merges as it sees fit)
+
 // ---- constants of the rasterization contract --------------------------------
 constexpr float kAlphaThreshold      = 1.0f / 255.0f; // skip if alpha < this
 constexpr float kGaussianExtend      = 3.33f;         // truncation in std-devs

@@ -173,8 +173,6 @@ __device__ __forceinline__ float staged_alpha_raw(const float4 &ga, float q)
 // bounded by |u| (|gu| + ...) with |u| <= 7.5 and, for the Gaussians that can pass the alpha test at all, |a| <= 7.5 +
 // extent: a few hundred at most for the tightest footprint (eps2d = 0.3) -> ~2e-5 absolute on e, ~1.5e-5 relative on alpha
 // (the tolerance of the parity tests is 1e-4 .. 1e-3; variant T's moments about the tile centre are conditioned alike).
-typedef float v4f __attribute__((ext_vector_type(4))); // true vector types: one ds_read_b128 / b64 per load (a HIP float4 is
-typedef float v2f __attribute__((ext_vector_type(2))); // a struct of scalars that the backend re-merges as it sees fit)
 struct StagedRow { // one staged Gaussian in LDS: 48 bytes, read as b128 + b128 + b64 from ONE address register
     v4f p0;        // e0, gu, gv, lo
     v4f p1;        // nA, nB, nC, colour 2

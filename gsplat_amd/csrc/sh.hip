@@ -324,29 +324,122 @@ __device__ __forceinline__ void row_ids(const ShArgs &a, int64_t row, uint32_t &
     }
 }
 
+// ---- wave-cooperative coefficient tiles ---------------------------------------------------------------------------------
+// A thread that streams its own [K][3] row touches 16 bytes of 64 different cache lines per load / store instruction. When
+// the 64 rows of a wave are consecutive in memory (dense rows, or packed rows with gathered coefficients) the wave moves them
+// as ONE contiguous block instead: lane l moves float4 number (it * 64 + l) of the block, 1 KiB per instruction, through a
+// wave-private LDS tile in which every lane then reads (or has written) its own row. Row stride Q + 1 float4: a lane's 16-byte
+// accesses at stride 13 (degree 3) fall on 16 distinct bank quads per group of 16 lanes.
+template <int NF>
+struct ShTile {
+    static constexpr int Q = (NF + 3) / 4, STRIDE = Q + 1;
+    static constexpr size_t kBytesPerWave = 64 * STRIDE * sizeof(v4f);
+};
+
+// true iff the wave's coefficient rows are crow(lane 0) + lane (rows past the end count as consecutive)
+__device__ __forceinline__ bool wave_rows_consecutive(int64_t crow, bool have, uint32_t lane)
+{
+    const int64_t first = __shfl(crow, 0) ;
+    return __builtin_amdgcn_ballot_w64(have && crow != first + (int64_t)lane) == 0ull;
+}
+
+// rows whose bit in `mask` is set: global -> tile (first Q float4 of each row; row_q = float4 per row in memory)
+template <int NF>
+__device__ __forceinline__ void tile_load(const float *block, uint32_t row_q, uint64_t mask, v4f *tile, uint32_t lane)
+{
+    constexpr int Q = ShTile<NF>::Q, STRIDE = ShTile<NF>::STRIDE;
+    const v4f *src = reinterpret_cast<const v4f *>(block);
+    v4f v[Q];
+    bool on[Q];
+#pragma unroll
+    for (int it = 0; it < Q; ++it) {
+        const uint32_t idx = it * 64 + lane, r = idx / Q, q = idx - r * Q;
+        on[it] = (mask >> r) & 1ull;
+        if (on[it]) v[it] = __builtin_nontemporal_load(src + (size_t)r * row_q + q);
+    }
+#pragma unroll
+    for (int it = 0; it < Q; ++it) {
+        const uint32_t idx = it * 64 + lane, r = idx / Q, q = idx - r * Q;
+        if (on[it]) tile[r * STRIDE + q] = v[it];
+    }
+}
+
+template <int NF>
+__device__ __forceinline__ void tile_read_row(const v4f *tile, uint32_t lane, float *dst)
+{
+    constexpr int Q = ShTile<NF>::Q, STRIDE = ShTile<NF>::STRIDE;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        const v4f v = tile[lane * STRIDE + i];
+        if (4 * i + 0 < NF) dst[4 * i + 0] = v.x;
+        if (4 * i + 1 < NF) dst[4 * i + 1] = v.y;
+        if (4 * i + 2 < NF) dst[4 * i + 2] = v.z;
+        if (4 * i + 3 < NF) dst[4 * i + 3] = v.w;
+    }
+}
+
+// the tile rows (each written by its own lane) -> the wave's rows in memory, zero-filled up to row_q float4 per row; rows
+// whose bit in `mask` is clear (past the end) are not written
+template <int NF>
+__device__ __forceinline__ void tile_flush_rows(float *block, uint32_t row_q, uint64_t mask, const v4f *tile, uint32_t lane)
+{
+    constexpr int Q = ShTile<NF>::Q, STRIDE = ShTile<NF>::STRIDE;
+    wave_lds_sync();
+    v4f *dst = reinterpret_cast<v4f *>(block);
+    if (row_q == (uint32_t)Q) {
+#pragma unroll
+        for (int it = 0; it < Q; ++it) {
+            const uint32_t idx = it * 64 + lane, r = idx / Q, q = idx - r * Q;
+            if ((mask >> r) & 1ull) __builtin_nontemporal_store(tile[r * STRIDE + q], dst + idx);
+        }
+    } else {
+        for (uint32_t idx = lane; idx < 64u * row_q; idx += 64u) {
+            const uint32_t r = idx / row_q, q = idx - r * row_q;
+            if ((mask >> r) & 1ull) dst[idx] = q < (uint32_t)Q ? tile[r * STRIDE + q] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 template <int DEG>
 __global__ void __launch_bounds__(256) sh3_fwd_kernel(const ShArgs a)
 {
     constexpr int NB = (DEG + 1) * (DEG + 1), NF = NB * 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_smem[];
     const int64_t rows = a.nnz >= 0 ? a.nnz : (int64_t)a.B * a.C * a.N;
     const int64_t row  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool have = row < rows;
+    const bool live = have && !row_dead(a, row);
+    uint32_t b = 0, c = 0, g = 0;
+    int64_t crow = 0;
+    if (have) row_ids(a, row, b, c, g, crow);
+    const bool vec = ((a.K * 3u) & 3u) == 0u; // rows are 16-byte aligned iff K*3 floats is a multiple of 4
+    float co[NF];
+    const uint64_t live_mask = __builtin_amdgcn_ballot_w64(live);
+    if (live_mask == 0ull) { // nothing to evaluate in this wave
+        if (have) a.colors[row * 3] = a.colors[row * 3 + 1] = a.colors[row * 3 + 2] = 0.0f;
+        return;
+    }
+    const bool tiled = DEG < 4 && vec && wave_rows_consecutive(crow, have, lane); // wave-uniform
+    if (tiled) {
+        v4f *tile = reinterpret_cast<v4f *>(sh_smem + (threadIdx.x >> 6) * ShTile<NF>::kBytesPerWave);
+        const int64_t crow0 = __shfl(crow, 0);
+        tile_load<NF>(a.coeffs + (size_t)crow0 * a.K * 3, a.K * 3u / 4u, live_mask, tile, lane);
+        wave_lds_sync();
+        if (live) tile_read_row<NF>(tile, lane, co);
+    }
+    if (!have) return;
     float *out = a.colors + row * 3;
-    if (row_dead(a, row)) {
+    if (!live) {
         out[0] = out[1] = out[2] = 0.0f;
         return;
     }
-    uint32_t b, c, g;
-    int64_t crow;
-    row_ids(a, row, b, c, g, crow);
     float d[3];
     view_dir(a, b, c, g, d);
     const float inv = safe_inv_norm(d);
     float Y[NB];
     sh_bases<false>(DEG, d[0] * inv, d[1] * inv, d[2] * inv, Y, nullptr, nullptr, nullptr);
-    const bool vec = ((a.K * 3u) & 3u) == 0u; // rows are 16-byte aligned iff K*3 floats is a multiple of 4
-    float co[NF];
-    load_row<NF>(a.coeffs + (size_t)crow * a.K * 3, vec, co);
+    if (!tiled) load_row<NF>(a.coeffs + (size_t)crow * a.K * 3, vec, co);
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
@@ -467,7 +560,8 @@ __global__ void __launch_bounds__(256) sh3_bwd_packed_kernel(const ShArgs a)
 }
 
 // dense (or packed rows addressed through row_map): one thread per Gaussian loops over the images; v_coeffs and
-// v_means are written once per Gaussian — no atomics, no zero-initialised outputs
+// v_means are written once per Gaussian — no atomics, no zero-initialised outputs. This version streams every row from its
+// own thread (rows of 75 floats, degree 4); sh3_bwd_tiled_kernel below is the one that normally runs.
 template <int DEG, bool WANT_MEANS>
 __global__ void __launch_bounds__(256) sh3_bwd_dense_kernel(const ShArgs a)
 {
@@ -509,16 +603,140 @@ __global__ void __launch_bounds__(256) sh3_bwd_dense_kernel(const ShArgs a)
     store_row<NF>(a.v_coeffs + (size_t)g * a.K * 3, vec, vco, a.K * 3, true);
 }
 
+// The same walk with the coefficient rows of a wave (Gaussians g0 .. g0 + 63: one contiguous block of [N, K, 3]) moved as
+// wave-cooperative tiles. The coefficient row is never held in registers: the 16 sums w_k = coeffs[k] . v_colour that the
+// mean gradient needs are formed straight from the lane's LDS row. MULTI = more than one image: the gradient row accumulates
+// in registers over the images; otherwise it is the outer product Y (x) v_colour of the single live row, written straight
+// into the lane's tile row once the coefficients in it have been consumed.
+template <int DEG, bool WANT_MEANS, bool MULTI>
+__global__ void __launch_bounds__(256) sh3_bwd_tiled_kernel(const ShArgs a)
+{
+    constexpr int NB = (DEG + 1) * (DEG + 1), NF = NB * 3, Q = ShTile<NF>::Q, STRIDE = ShTile<NF>::STRIDE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_smem[];
+    const int64_t gi    = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool have     = gi < (int64_t)a.N;
+    const uint32_t g    = (uint32_t)gi;
+    v4f *tile           = reinterpret_cast<v4f *>(sh_smem + (threadIdx.x >> 6) * ShTile<NF>::kBytesPerWave);
+    v4f *mine           = tile + lane * STRIDE;
+    const uint64_t have_mask = __builtin_amdgcn_ballot_w64(have);
+    const size_t block0 = (size_t)(gi - lane) * a.K * 3;
+    const uint32_t row_q = a.K * 3u / 4u;
+    const uint32_t n_img = MULTI ? a.B * a.C : 1u;
+
+    if constexpr (WANT_MEANS) {
+        // the coefficient row is needed (for d/d mean) iff the Gaussian is live in some image
+        bool any = false;
+        if (have)
+            for (uint32_t i = 0; i < n_img && !any; ++i) {
+                int64_t row = (int64_t)i * a.N + g;
+                if (a.row_map) row = a.row_map[row];
+                any = row >= 0 && !row_dead(a, row);
+            }
+        const uint64_t any_mask = __builtin_amdgcn_ballot_w64(any);
+        if (any_mask) {
+            tile_load<NF>(a.coeffs + block0, row_q, any_mask, tile, lane);
+            wave_lds_sync();
+        }
+    }
+    float vco[MULTI ? NF : 1];
+#pragma unroll
+    for (int i = 0; i < (MULTI ? NF : 1); ++i) vco[i] = 0.0f;
+    float Y[NB], vc[3] = {0.f, 0.f, 0.f}; // !MULTI: the live row's basis and cotangent, for the outer product at the end
+#pragma unroll
+    for (int k = 0; k < NB; ++k) Y[k] = 0.0f;
+    for (uint32_t b = 0; have && b < (MULTI ? a.B : 1u); ++b) {
+        float v_dir[3] = {0.f, 0.f, 0.f};
+        for (uint32_t c = 0; c < (MULTI ? a.C : 1u); ++c) {
+            int64_t row = ((int64_t)b * a.C + c) * a.N + g;
+            if (a.row_map) {
+                row = a.row_map[row];
+                if (row < 0) continue;
+            }
+            if (row_dead(a, row)) continue;
+            vc[0] = load_vc(a, row, 0); vc[1] = load_vc(a, row, 1); vc[2] = load_vc(a, row, 2);
+            float d[3];
+            view_dir(a, b, c, g, d);
+            const float inv = safe_inv_norm(d);
+            const float x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
+            if constexpr (WANT_MEANS) {
+                float w[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) w[k] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) {
+                    const v4f v = mine[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * i + j < NF) w[(4 * i + j) / 3] = fmaf(v[j], vc[(4 * i + j) % 3], w[(4 * i + j) / 3]);
+                }
+                float Yx[NB], Yy[NB], Yz[NB];
+                sh_bases<true>(DEG, x, y, z, Y, Yx, Yy, Yz);
+                float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    gx = fmaf(Yx[k], w[k], gx); gy = fmaf(Yy[k], w[k], gy); gz = fmaf(Yz[k], w[k], gz);
+                }
+                const float dot = gx * x + gy * y + gz * z; // through the normalisation: (g - (g.n) n) / |d|
+                const float vd[3] = {(gx - dot * x) * inv, (gy - dot * y) * inv, (gz - dot * z) * inv};
+                v_dir[0] += vd[0]; v_dir[1] += vd[1]; v_dir[2] += vd[2];
+                if (a.v_dirs) {
+                    float *o = a.v_dirs + row * 3;
+                    o[0] = vd[0]; o[1] = vd[1]; o[2] = vd[2];
+                }
+            } else {
+                sh_bases<false>(DEG, x, y, z, Y, nullptr, nullptr, nullptr);
+            }
+            if constexpr (MULTI) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    vco[3 * k] = fmaf(Y[k], vc[0], vco[3 * k]);
+                    vco[3 * k + 1] = fmaf(Y[k], vc[1], vco[3 * k + 1]);
+                    vco[3 * k + 2] = fmaf(Y[k], vc[2], vco[3 * k + 2]);
+                }
+            }
+        }
+        if constexpr (WANT_MEANS) {
+            if (a.v_means) {
+                float *vm = a.v_means + ((size_t)b * a.N + g) * 3; // [B,N,3]: one thread per (b, g) -> plain store
+                vm[0] = v_dir[0]; vm[1] = v_dir[1]; vm[2] = v_dir[2];
+            }
+        }
+    }
+    // the lane's gradient row -> its tile row (which only this lane has read) -> memory, as one block per wave
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        v4f v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = 4 * i + j;
+            if constexpr (MULTI) v[j] = f < NF ? vco[f < NF ? f : 0] : 0.0f;
+            else v[j] = f < NF ? Y[(f < NF ? f : 0) / 3] * vc[f % 3] : 0.0f; // no live row: vc = 0
+        }
+        mine[i] = v;
+    }
+    tile_flush_rows<NF>(a.v_coeffs + block0, row_q, have_mask, tile, lane);
+}
+
 template <int DEG>
 static void launch_sh3_bwd(const ShArgs &a, hipStream_t s)
 {
+    constexpr int NF = (DEG + 1) * (DEG + 1) * 3;
+    const bool want_means = a.v_means || a.v_dirs;
     if (a.nnz < 0 || a.row_map) {
         const dim3 grid((uint32_t)ceil_div((int64_t)a.N, 256));
-        if (a.v_means || a.v_dirs) sh3_bwd_dense_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
+        if (DEG < 4 && ((a.K * 3u) & 3u) == 0u) { // 16-byte rows: wave-cooperative tiles
+            const size_t smem = 4 * ShTile<NF>::kBytesPerWave;
+            const bool multi  = a.B * a.C > 1;
+            if (want_means && multi) sh3_bwd_tiled_kernel<DEG < 4 ? DEG : 0, true, true><<<grid, dim3(256), smem, s>>>(a);
+            else if (want_means) sh3_bwd_tiled_kernel<DEG < 4 ? DEG : 0, true, false><<<grid, dim3(256), smem, s>>>(a);
+            else if (multi) sh3_bwd_tiled_kernel<DEG < 4 ? DEG : 0, false, true><<<grid, dim3(256), smem, s>>>(a);
+            else sh3_bwd_tiled_kernel<DEG < 4 ? DEG : 0, false, false><<<grid, dim3(256), smem, s>>>(a);
+        } else if (want_means) sh3_bwd_dense_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
         else sh3_bwd_dense_kernel<DEG, false><<<grid, dim3(256), 0, s>>>(a);
     } else {
         const dim3 grid((uint32_t)ceil_div(a.nnz, 256));
-        if (a.v_means || a.v_dirs) sh3_bwd_packed_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
+        if (want_means) sh3_bwd_packed_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
         else sh3_bwd_packed_kernel<DEG, false><<<grid, dim3(256), 0, s>>>(a);
     }
 }
@@ -635,10 +853,10 @@ extern "C" int gsx_sh_fwd(int degrees_to_use, const float *means, const float *v
     if (D == 3) {
         const dim3 grid((uint32_t)ceil_div(rows, 256));
         switch (degrees_to_use) {
-        case 0: sh3_fwd_kernel<0><<<grid, dim3(256), 0, s>>>(a); break;
-        case 1: sh3_fwd_kernel<1><<<grid, dim3(256), 0, s>>>(a); break;
-        case 2: sh3_fwd_kernel<2><<<grid, dim3(256), 0, s>>>(a); break;
-        case 3: sh3_fwd_kernel<3><<<grid, dim3(256), 0, s>>>(a); break;
+        case 0: sh3_fwd_kernel<0><<<grid, dim3(256), 4 * ShTile<3>::kBytesPerWave, s>>>(a); break;
+        case 1: sh3_fwd_kernel<1><<<grid, dim3(256), 4 * ShTile<12>::kBytesPerWave, s>>>(a); break;
+        case 2: sh3_fwd_kernel<2><<<grid, dim3(256), 4 * ShTile<27>::kBytesPerWave, s>>>(a); break;
+        case 3: sh3_fwd_kernel<3><<<grid, dim3(256), 4 * ShTile<48>::kBytesPerWave, s>>>(a); break;
         default: sh3_fwd_kernel<4><<<grid, dim3(256), 0, s>>>(a); break;
         }
     } else {

@@ -158,10 +158,12 @@ def test_projection_packed_matches_dense(G, sparse_grad):
         assert_grad_close(cpu(lp.grad), cpu(ld.grad), rel=1e-4, name=f"packed v_{nm}")
 
 
-@pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
-def test_spherical_harmonics_dense(G, O, deg):
+# K * 3 floats per row a multiple of four: rows move as wave-cooperative tiles (K == bands in use, or with unused bands
+# behind them); K = 25: 75 floats per row, every thread streams its own row
+@pytest.mark.parametrize("deg,K", [(0, 25), (1, 25), (2, 25), (3, 25), (4, 25), (3, 16), (1, 16), (2, 28), (0, 4), (1, 4),
+                                   (4, 28)])
+def test_spherical_harmonics_dense(G, O, deg, K):
     sc, W, H = make_scene(N=3000, C=3, seed=4)
-    K = 25
     coeffs = torch.randn(3000, K, 3) * 0.3
     masks = torch.rand(3, 3000) > 0.2
     mg = sc["means"].to(DEV).requires_grad_(True)
