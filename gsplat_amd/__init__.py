@@ -31,7 +31,7 @@ _LAZY = {
     "SelectiveAdam": "optimizers", "compute_relocation": "relocation", "DefaultStrategy": "strategy",
     "MCMCStrategy": "strategy", "strategy": "strategy", "optimizers": "optimizers", "relocation": "relocation",
     # on-disk formats
-    "export_splats": "exporter", "exporter": "exporter",
+    "export_splats": "exporter", "exporter": "exporter", "PngCompression": "compression", "compression": "compression",
 }
 
 
