@@ -323,3 +323,49 @@ def register(extra=None) -> None:
 
 
 register()
+
+
+# ---- the same autograd without the dispatcher's Python trampoline --------------------------------
+# An op called through torch.ops with autograd attached by torch.library.register_autograd passes through
+# torch/_library/autograd.py (autograd_impl -> fill_defaults -> a generated Function): ~70 us of interpreter time per call,
+# more than the launch of the kernel behind it (tools/host_time.py: 0.14 ms of a 0.42 ms host-bound step for two ops).
+# gsplat_amd's own wrappers therefore attach the SAME setup / backward pair through a plain torch.autograd.Function and call
+# the op body below the Autograd dispatch key. torch.ops.gsplat.<op> itself keeps the registration above (that is what a
+# caller of the raw op - or the reference's tests - gets).
+class _FastOps:
+    """`torch.ops.gsplat` with direct autograd Functions for the ops in _TABLE; every other attribute passes through."""
+
+    def __init__(self, extra=None):
+        self._table = dict(_TABLE)
+        if extra:
+            self._table.update(extra)
+        self._ns = getattr(torch.ops, NS)
+
+    def __getattr__(self, name):
+        entry = self._table.get(name)
+        op = getattr(self._ns, name)
+        if entry is None:
+            fn = op
+        else:
+            bwd, setup = entry
+            overload = op.default
+
+            class _Fn(torch.autograd.Function):
+                @staticmethod
+                def forward(ctx, *args):
+                    with torch._C._AutoDispatchBelowAutograd():
+                        out = overload(*args)
+                    setup(ctx, args, out)
+                    return out
+
+                @staticmethod
+                def backward(ctx, *grads):
+                    return bwd(ctx, *grads)
+
+            _Fn.__name__ = _Fn.__qualname__ = f"gsplat_{name}"
+            fn = _Fn.apply
+        setattr(self, name, fn)  # next lookup is a plain attribute
+        return fn
+
+
+fast_ops = _FastOps()

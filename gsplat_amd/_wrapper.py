@@ -16,7 +16,7 @@ from torch import Tensor
 
 from . import _autograd  # noqa: F401  (registers ops + autograd)
 
-_ops = torch.ops.gsplat
+_ops = _autograd.fast_ops  # torch.ops.gsplat, with direct autograd Functions for the differentiable ops
 from . import _ops as _impl  # noqa: E402  (python-side op bodies: begin/finish halves of intersect_tile)
 
 CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2}
