@@ -106,6 +106,8 @@ def timed(step_fn, steps, warmup, barrier, profile_only=None):
     for _ in range(warmup):
         meta = step_fn()
     barrier()
+    if os.environ.get("GSPLAT_BENCH_NO_PROFILE"):  # debugging aid: no HIP events inside the timed region
+        profile_only = None
     if profile_only:
         _cabi.profile_begin(only=profile_only)
     import gc
@@ -240,6 +242,10 @@ def main():
     gc.freeze()
     # HIP events (on the launch stream) around the two compositing launches only: the dominant kernels are timed live
     # inside the timed region without the bookkeeping of ~40 event pairs per step perturbing it.
+    # The warm-up's last `meta` pins one set of per-step buffers (sorted intersection lists: 0.7 GB at c4). Left alive next to
+    # the timed loop's own previous-step `meta` it forces a THIRD set in the second timed step: fresh hipMallocs of that size
+    # stall the host for ~45 ms, once (seen as a 55 ms second step on a fresh box). Steady state holds two sets.
+    meta = None
     elapsed, meta, prof = timed(step, args.steps, 0, barrier, profile_only=("gsx_raster3d_fwd", "gsx_raster3d_bwd"))
     # per-stage table: a few extra (untimed) steps with an event pair around every C-ABI call
     n_stage = 0 if args.lean else min(5, args.steps)

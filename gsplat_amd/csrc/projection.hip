@@ -63,21 +63,27 @@ __device__ __forceinline__ void load_world_covar(const ProjArgs &a, uint32_t b, 
 // every inlined copy performs the same sequence of IEEE operations: packed rows are bit-identical to dense rows and
 // the count / write passes always agree on visibility. (A shared __noinline__ body gave the same guarantee but cost
 // 208 B of scratch per thread and 3x the run time.)
-__device__ __forceinline__ ProjOut project_one(const ProjArgs &a, uint32_t b, uint32_t c, uint32_t g)
+// `world`: the caller's cache of the Gaussian's world covariance (valid once *have_world is set): a thread that projects one
+// Gaussian into several cameras forms it once. One camera per thread: pass a fresh cache.
+__device__ __forceinline__ ProjOut project_one(const ProjArgs &a, uint32_t b, uint32_t c, uint32_t g, const float *p,
+                                               float *world, bool *have_world)
 {
     ProjOut o;
     o.ok = false;
     o.rx = o.ry = 0;
     o.mx = o.my = o.depth = o.ca = o.cb = o.cc = o.comp = 0.0f;
     const Cam cam  = load_cam(a.viewmats + ((size_t)b * a.C + c) * 16, a.Ks + ((size_t)b * a.C + c) * 9);
-    const float *p = a.means + ((size_t)b * a.N + g) * 3;
     float pc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) pc[i] = cam.R[3 * i] * p[0] + cam.R[3 * i + 1] * p[1] + cam.R[3 * i + 2] * p[2] + cam.t[i];
     if (pc[2] < a.near_plane || pc[2] > a.far_plane) return o;
 
-    float S[9], RS[9], Sc[9];
-    load_world_covar(a, b, g, S);
+    float RS[9], Sc[9];
+    if (!*have_world) {
+        load_world_covar(a, b, g, world);
+        *have_world = true;
+    }
+    const float *S = world;
     mm3(cam.R, S, RS);
     mm3_nt(RS, cam.R, Sc);
 
@@ -108,6 +114,13 @@ __device__ __forceinline__ ProjOut project_one(const ProjArgs &a, uint32_t b, ui
     return o;
 }
 
+__device__ __forceinline__ ProjOut project_one(const ProjArgs &a, uint32_t b, uint32_t c, uint32_t g)
+{
+    float world[9];
+    bool have_world = false;
+    return project_one(a, b, c, g, a.means + ((size_t)b * a.N + g) * 3, world, &have_world);
+}
+
 __global__ void __launch_bounds__(256) project_fwd_kernel(const ProjArgs a)
 {
     const int64_t idx   = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -124,6 +137,33 @@ __global__ void __launch_bounds__(256) project_fwd_kernel(const ProjArgs a)
     a.conics[3 * idx + 1]  = o.cb;
     a.conics[3 * idx + 2]  = o.cc;
     if (a.compensations) a.compensations[idx] = o.comp;
+}
+
+// Several cameras over the same Gaussians: one thread per Gaussian walks the cameras - mean, rotation and scale are read,
+// and the world covariance formed, once per Gaussian instead of once per (camera, Gaussian). Same arithmetic per row as the
+// kernel above (bit-identical outputs); rows of one camera are written by consecutive lanes.
+__global__ void __launch_bounds__(256) project_fwd_gaussian_major_kernel(const ProjArgs a)
+{
+    const int64_t bg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // over B * N
+    if (bg >= (int64_t)a.B * a.N) return;
+    const uint32_t b = (uint32_t)(bg / a.N), g = (uint32_t)(bg % a.N);
+    const float *pm = a.means + (size_t)bg * 3;
+    const float p[3] = {pm[0], pm[1], pm[2]};
+    float world[9];
+    bool have_world = false;
+    for (uint32_t c = 0; c < a.C; ++c) {
+        const ProjOut o   = project_one(a, b, c, g, p, world, &have_world);
+        const int64_t idx = ((int64_t)b * a.C + c) * a.N + g;
+        a.radii[2 * idx]       = o.rx;
+        a.radii[2 * idx + 1]   = o.ry;
+        a.means2d[2 * idx]     = o.mx;
+        a.means2d[2 * idx + 1] = o.my;
+        a.depths[idx]          = o.depth;
+        a.conics[3 * idx]      = o.ca;
+        a.conics[3 * idx + 1]  = o.cb;
+        a.conics[3 * idx + 2]  = o.cc;
+        if (a.compensations) a.compensations[idx] = o.comp;
+    }
 }
 
 __global__ void __launch_bounds__(256) project_count_kernel(const ProjArgs a)
@@ -560,7 +600,10 @@ extern "C" int gsx_project_ewa_fwd(const float *means, const float *covars, cons
     a.eps2d = eps2d; a.near_plane = near_plane; a.far_plane = far_plane; a.radius_clip = radius_clip;
     a.camera_model = camera_model; a.calc_compensations = compensations != nullptr;
     a.radii = radii; a.means2d = means2d; a.depths = depths; a.conics = conics; a.compensations = compensations;
-    project_fwd_kernel<<<dim3((uint32_t)ceil_div(count, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    if (C > 1)
+        project_fwd_gaussian_major_kernel<<<dim3((uint32_t)ceil_div((int64_t)B * N, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    else
+        project_fwd_kernel<<<dim3((uint32_t)ceil_div(count, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
     return check_launch("project_ewa_fwd");
 }
 

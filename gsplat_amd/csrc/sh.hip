@@ -450,6 +450,57 @@ __global__ void __launch_bounds__(256) sh3_fwd_kernel(const ShArgs a)
     out[0] = post_color(a, r0); out[1] = post_color(a, r1); out[2] = post_color(a, r2);
 }
 
+// Dense rows of SEVERAL images: one thread per Gaussian walks the images, so that the [K][3] coefficient row (192 of the
+// ~220 bytes a row touches at degree 3) is fetched once per Gaussian instead of once per (image, Gaussian) - with 4 M
+// Gaussians the images' rows are 768 MB apart, no cache holds them in between (c4: 550 -> 2xx us per launch). The 64
+// coefficient rows of a wave move as one tile (see ShTile); colours are written row by row, consecutive lanes to
+// consecutive rows of the same image.
+template <int DEG>
+__global__ void __launch_bounds__(256) sh3_fwd_gaussian_major_kernel(const ShArgs a)
+{
+    constexpr int NB = (DEG + 1) * (DEG + 1), NF = NB * 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_smem[];
+    const int64_t gi    = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool have     = gi < (int64_t)a.N;
+    const uint32_t g    = (uint32_t)gi;
+    const uint32_t n_img = a.B * a.C;
+    bool any = false;
+    if (have)
+        for (uint32_t i = 0; i < n_img && !any; ++i) any = !row_dead(a, (int64_t)i * a.N + g);
+    const uint64_t any_mask = __builtin_amdgcn_ballot_w64(any);
+    float co[NF];
+    if (any_mask) {
+        v4f *tile = reinterpret_cast<v4f *>(sh_smem + (threadIdx.x >> 6) * ShTile<NF>::kBytesPerWave);
+        tile_load<NF>(a.coeffs + (size_t)(gi - lane) * a.K * 3, a.K * 3u / 4u, any_mask, tile, lane);
+        wave_lds_sync();
+        if (any) tile_read_row<NF>(tile, lane, co);
+    }
+    if (!have) return;
+    for (uint32_t b = 0; b < a.B; ++b)
+        for (uint32_t c = 0; c < a.C; ++c) {
+            const int64_t row = ((int64_t)b * a.C + c) * a.N + g;
+            float *out        = a.colors + row * 3;
+            if (row_dead(a, row)) {
+                out[0] = out[1] = out[2] = 0.0f;
+                continue;
+            }
+            float d[3];
+            view_dir(a, b, c, g, d);
+            const float inv = safe_inv_norm(d);
+            float Y[NB];
+            sh_bases<false>(DEG, d[0] * inv, d[1] * inv, d[2] * inv, Y, nullptr, nullptr, nullptr);
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                r0 += Y[k] * co[3 * k];
+                r1 += Y[k] * co[3 * k + 1];
+                r2 += Y[k] * co[3 * k + 2];
+            }
+            out[0] = post_color(a, r0); out[1] = post_color(a, r1); out[2] = post_color(a, r2);
+        }
+}
+
 // store a v_coeffs row: values for the first NF floats, zeros up to K*3 (only when `fill_tail`)
 template <int NF>
 __device__ __forceinline__ void store_row(float *dst, bool vec, const float *val, uint32_t row_floats, bool fill_tail)
@@ -608,7 +659,8 @@ __global__ void __launch_bounds__(256) sh3_bwd_dense_kernel(const ShArgs a)
 // mean gradient needs are formed straight from the lane's LDS row. MULTI = more than one image: the gradient row accumulates
 // in registers over the images; otherwise it is the outer product Y (x) v_colour of the single live row, written straight
 // into the lane's tile row once the coefficients in it have been consumed.
-template <int DEG, bool WANT_MEANS, bool MULTI>
+// WANT_COEFFS = false: only the mean / direction gradients (the several-image case runs as two launches, see launch_sh3_bwd).
+template <int DEG, bool WANT_MEANS, bool MULTI, bool WANT_COEFFS = true>
 __global__ void __launch_bounds__(256) sh3_bwd_tiled_kernel(const ShArgs a)
 {
     constexpr int NB = (DEG + 1) * (DEG + 1), NF = NB * 3, Q = ShTile<NF>::Q, STRIDE = ShTile<NF>::STRIDE;
@@ -687,7 +739,7 @@ __global__ void __launch_bounds__(256) sh3_bwd_tiled_kernel(const ShArgs a)
             } else {
                 sh_bases<false>(DEG, x, y, z, Y, nullptr, nullptr, nullptr);
             }
-            if constexpr (MULTI) {
+            if constexpr (MULTI && WANT_COEFFS) {
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
                     vco[3 * k] = fmaf(Y[k], vc[0], vco[3 * k]);
@@ -703,6 +755,7 @@ __global__ void __launch_bounds__(256) sh3_bwd_tiled_kernel(const ShArgs a)
             }
         }
     }
+    if constexpr (!WANT_COEFFS) return;
     // the lane's gradient row -> its tile row (which only this lane has read) -> memory, as one block per wave
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
@@ -728,8 +781,13 @@ static void launch_sh3_bwd(const ShArgs &a, hipStream_t s)
         if (DEG < 4 && ((a.K * 3u) & 3u) == 0u) { // 16-byte rows: wave-cooperative tiles
             const size_t smem = 4 * ShTile<NF>::kBytesPerWave;
             const bool multi  = a.B * a.C > 1;
-            if (want_means && multi) sh3_bwd_tiled_kernel<DEG < 4 ? DEG : 0, true, true><<<grid, dim3(256), smem, s>>>(a);
-            else if (want_means) sh3_bwd_tiled_kernel<DEG < 4 ? DEG : 0, true, false><<<grid, dim3(256), smem, s>>>(a);
+            if (want_means && multi) {
+                // One launch although it needs 172 VGPRs (the gradient row accumulates in 48 registers across the images):
+                // split into a mean-gradient launch and a coefficient-gradient launch (80 / 96 VGPRs) it was slower, 0.77
+                // instead of 0.62 ms on c4 - both halves read the cotangents out of the 36-byte gradient rows again, and
+                // that traffic (576 MB at 4 M Gaussians x 4 images), not occupancy, is what bounds the kernel.
+                sh3_bwd_tiled_kernel<DEG < 4 ? DEG : 0, true, true><<<grid, dim3(256), smem, s>>>(a);
+            } else if (want_means) sh3_bwd_tiled_kernel<DEG < 4 ? DEG : 0, true, false><<<grid, dim3(256), smem, s>>>(a);
             else if (multi) sh3_bwd_tiled_kernel<DEG < 4 ? DEG : 0, false, true><<<grid, dim3(256), smem, s>>>(a);
             else sh3_bwd_tiled_kernel<DEG < 4 ? DEG : 0, false, false><<<grid, dim3(256), smem, s>>>(a);
         } else if (want_means) sh3_bwd_dense_kernel<DEG, true><<<grid, dim3(256), 0, s>>>(a);
@@ -850,7 +908,16 @@ extern "C" int gsx_sh_fwd(int degrees_to_use, const float *means, const float *v
     a.B = B; a.C = C; a.N = N; a.K = K; a.D = D; a.nnz = nnz; a.coeffs_gathered = coeffs_gathered; a.colors = colors;
     a.radii = radii; a.post = post;
     hipStream_t s = (hipStream_t)stream;
-    if (D == 3) {
+    if (D == 3 && nnz < 0 && (uint64_t)B * C > 1 && degrees_to_use < 4 && ((K * 3u) & 3u) == 0u) {
+        // several images over the same Gaussians: Gaussian-major walk, one coefficient fetch per Gaussian
+        const dim3 grid((uint32_t)ceil_div((int64_t)N, 256));
+        switch (degrees_to_use) {
+        case 0: sh3_fwd_gaussian_major_kernel<0><<<grid, dim3(256), 4 * ShTile<3>::kBytesPerWave, s>>>(a); break;
+        case 1: sh3_fwd_gaussian_major_kernel<1><<<grid, dim3(256), 4 * ShTile<12>::kBytesPerWave, s>>>(a); break;
+        case 2: sh3_fwd_gaussian_major_kernel<2><<<grid, dim3(256), 4 * ShTile<27>::kBytesPerWave, s>>>(a); break;
+        default: sh3_fwd_gaussian_major_kernel<3><<<grid, dim3(256), 4 * ShTile<48>::kBytesPerWave, s>>>(a); break;
+        }
+    } else if (D == 3) {
         const dim3 grid((uint32_t)ceil_div(rows, 256));
         switch (degrees_to_use) {
         case 0: sh3_fwd_kernel<0><<<grid, dim3(256), 4 * ShTile<3>::kBytesPerWave, s>>>(a); break;
