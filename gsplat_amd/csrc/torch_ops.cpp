@@ -10,6 +10,7 @@
 // The Python bodies in gsplat_amd/_ops.py remain the implementation of every other op and of the private fast paths of
 // gsplat_amd/rendering.py; _ops.py skips registering its own body for an op listed by gsx_torch_compiled_ops().
 // Schemas are defined by _ops.py (verbatim from ext.cpp); an IMPL block may be loaded before or after the definitions.
+#include <chrono>
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/core/DeviceGuard.h>
@@ -254,7 +255,22 @@ projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const
         { Timed timed_("gsx_scan_i32", L.stream); check(gsx_scan_i32(cp<int32_t>(visible), total, mp<int64_t>(cum), ws.mutable_data_ptr(), ws.numel(), L.stream), "gsx_scan_i32"); }
     }
     Tensor host_nnz = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    volatile int64_t *nnz_slot = host_nnz.mutable_data_ptr<int64_t>();
+    *nnz_slot = -1; // sentinel: the copy below overwrites it as soon as the scan has run
     host_nnz.copy_(cum.slice(0, total - 1, total), /*non_blocking=*/true);
+    // The row count is on the host once the SCAN has run - the write kernel enqueued after it does not have to finish first.
+    // Polling the pinned word instead of synchronising the stream lets the caller slice the outputs and enqueue the next
+    // kernels while the write kernel still runs (everything stays stream-ordered behind it).
+    auto wait_nnz = [&]() -> int64_t {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint64_t spin = 0;; ++spin) {
+            const int64_t v = *nnz_slot;
+            if (v >= 0) return v;
+            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        }
+        stream.synchronize(); // never seen; keeps the function correct if the copy is not host-visible before the stream drains
+        return *nnz_slot;
+    };
     auto write = [&](int64_t rows, decltype(outputs(0)) &o) {
         auto &[bi, ci, gi, indptr, radii, m2, dep, con, comp] = o;
         { Timed timed_("gsx_project_ewa_packed_write", L.stream); check(gsx_project_ewa_packed_write(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
@@ -268,15 +284,13 @@ projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const
     if (total * kPackedRowBytes <= kPackedPreallocLimit) {
         auto o = outputs(total);
         write(total, o);
-        stream.synchronize(); // host sync: exact-length COO outputs
-        const int64_t nnz = *host_nnz.const_data_ptr<int64_t>();
+        const int64_t nnz = wait_nnz(); // host round trip: exact-length COO outputs
         auto &[bi, ci, gi, indptr, radii, m2, dep, con, comp] = o;
         auto head = [&](const Tensor &t) { return t.narrow(0, 0, nnz); };
         return {head(bi), head(ci), head(gi), indptr, head(radii), head(m2), head(dep), head(con),
                 comp ? OptTensor(head(*comp)) : OptTensor()};
     }
-    stream.synchronize();
-    const int64_t nnz = *host_nnz.const_data_ptr<int64_t>();
+    const int64_t nnz = wait_nnz();
     auto o = outputs(nnz);
     if (nnz > 0 || true) write(nnz, o);
     return o;
