@@ -683,18 +683,24 @@ def rasterization_2dgs(
         proj_opacities = torch.broadcast_to(opacities[..., None, :], batch_dims + (C, N))
     densify = torch.zeros_like(means2d).requires_grad_(True)
 
+    # tile intersection in two halves around the SH kernels, as in rasterization(): the host round trip for the number of
+    # intersections is hidden behind work that does not depend on it
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
-    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
+    isect_pending = isect_tiles_begin(
         means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=False, packed=packed,
         n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids)
-    isect_offsets = isect_offset_encode(isect_ids, I, tile_width, tile_height)
-    isect_offsets = isect_offsets.reshape(batch_dims + (C, tile_height, tile_width))
 
     feats = None
     if has_color:
         feats = _project_features(colors, sh_degree, True, means, viewmats, radii, batch_dims, B, C, N, batch_ids,
                                   camera_ids, gaussian_ids)
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles_finish(isect_pending)
+    if isect_pending.offsets is not None:  # the fused intersection path produces the tile offsets as a by-product
+        isect_offsets = isect_pending.offsets
+    else:
+        isect_offsets = isect_offset_encode(isect_ids, I, tile_width, tile_height)
+    isect_offsets = isect_offsets.reshape(batch_dims + (C, tile_height, tile_width))
     raster_bg = backgrounds
     if append_depth:
         if has_color:
