@@ -575,6 +575,80 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
     return {v_abs, v_means2d, v_conics, v_colors, v_opac, v_bg};
 }
 
+// ---- 2DGS: the two forward ops on the critical host path of rasterization_2dgs (the backward bodies stay in _ops.py: the
+// GPU has the whole compositing backward queued while they run) -------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor>
+projection_2dgs_fused(const Tensor &means_, const Tensor &quats_, const Tensor &scales_, const Tensor &viewmats_, const Tensor &Ks_,
+                      int64_t width, int64_t height, double eps2d, double near_plane, double far_plane, double radius_clip)
+{
+    (void)eps2d; // accepted and unused, as in the reference (Projection2DGSFused.cu evaluates the box at one sigma)
+    want_f32(means_, "means"); want_f32(quats_, "quats"); want_f32(scales_, "scales"); want_f32(viewmats_, "viewmats");
+    want_f32(Ks_, "Ks");
+    const int64_t N = means_.size(-2);
+    TORCH_CHECK_VALUE(means_.size(-1) == 3 && quats_.dim() >= 2 && quats_.size(-2) == N && quats_.size(-1) == 4
+                          && scales_.dim() >= 2 && scales_.size(-2) == N && scales_.size(-1) == 3,
+                      "projection_2dgs: bad shapes means ", means_.sizes(), " quats ", quats_.sizes(), " scales ", scales_.sizes());
+    Launch L(means_);
+    const Tensor means = contig(means_), quats = contig(quats_), scales = contig(scales_), viewmats = contig(viewmats_),
+                 Ks = contig(Ks_);
+    const int64_t B = prod(means.sizes().slice(0, means.dim() - 2)), C = viewmats.size(-3);
+    std::vector<int64_t> shape(means.sizes().begin(), means.sizes().end() - 2);
+    shape.push_back(C); shape.push_back(N);
+    auto with = [&](std::initializer_list<int64_t> tail) {
+        auto s = shape;
+        s.insert(s.end(), tail);
+        return s;
+    };
+    Tensor radii = at::empty(with({2}), means.options().dtype(at::kInt)), means2d = at::empty(with({2}), means.options());
+    Tensor depths = at::empty(shape, means.options()), rt = at::empty(with({3, 3}), means.options());
+    Tensor normals = at::empty(with({3}), means.options());
+    { Timed timed_("gsx_project_2dgs_fwd", L.stream); check(gsx_project_2dgs_fwd(fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), (uint32_t)B, (uint32_t)C, (uint32_t)N,
+                               (uint32_t)width, (uint32_t)height, (float)near_plane, (float)far_plane, (float)radius_clip,
+                               mp<int32_t>(radii), mp<float>(means2d), mp<float>(depths), mp<float>(rt), mp<float>(normals),
+                               L.stream),
+          "gsx_project_2dgs_fwd"); }
+    return {radii, means2d, depths, rt, normals};
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>
+rasterize_to_pixels_2dgs(const Tensor &means2d_, const Tensor &ray_transforms_, const Tensor &colors_, const Tensor &opacities_,
+                         const Tensor &normals_, const Tensor &densify, const OptTensor &backgrounds_, const OptTensor &masks_,
+                         int64_t width, int64_t height, int64_t tile_size, const Tensor &tile_offsets_, const Tensor &flatten_ids_,
+                         bool packed, bool absgrad, bool distloss)
+{
+    (void)packed; (void)densify;
+    want_f32(means2d_, "means2d"); want_f32(ray_transforms_, "ray_transforms"); want_f32(colors_, "colors");
+    want_f32(opacities_, "opacities"); want_f32(normals_, "normals"); want_f32(backgrounds_, "backgrounds");
+    Launch L(means2d_);
+    const RasterDims r = raster_dims(tile_offsets_, colors_);
+    TORCH_CHECK_VALUE(r.th * tile_size >= height && r.tw * tile_size >= width,
+                      "rasterize_to_pixels_2dgs: tile grid does not cover the image");
+    TORCH_CHECK_TYPE(!has(masks_) || masks_->scalar_type() == at::kBool, "masks must be a bool tensor");
+    const Tensor means2d = contig(means2d_), rt = contig(ray_transforms_), colors = contig(colors_), opac = contig(opacities_),
+                 normals = contig(normals_);
+    const OptTensor bg = contig(backgrounds_), masks = contig(masks_);
+    const Tensor offsets = contig(tile_offsets_), flat = contig(flatten_ids_);
+    auto shape = [&](std::initializer_list<int64_t> tail) {
+        auto s = r.image_dims;
+        s.insert(s.end(), tail);
+        return s;
+    };
+    const auto f32 = means2d.options(), i32 = means2d.options().dtype(at::kInt);
+    Tensor renders = at::empty(shape({height, width, r.D}), f32), alphas = at::empty(shape({height, width, 1}), f32);
+    Tensor rnormals = at::empty(shape({height, width, 3}), f32), rdistort = at::empty(shape({height, width, 1}), f32);
+    Tensor rmedian = at::empty(shape({height, width, 1}), f32);
+    Tensor last_ids = at::empty(shape({height, width}), i32), median_ids = at::empty(shape({height, width}), i32);
+    { Timed timed_("gsx_raster2d_fwd", L.stream); check(gsx_raster2d_fwd(fp(means2d), fp(rt), fp(colors), fp(opac), fp(normals), fp(bg),
+                           masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
+                           cp<int32_t>(flat), (uint32_t)r.I, (uint32_t)flat.numel(), (uint32_t)r.D, (uint32_t)width,
+                           (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th, distloss ? 1 : 0,
+                           mp<float>(renders), mp<float>(alphas), mp<float>(rnormals), mp<float>(rdistort), mp<float>(rmedian),
+                           mp<int32_t>(last_ids), mp<int32_t>(median_ids), L.stream),
+          "gsx_raster2d_fwd"); }
+    Tensor holder = absgrad ? at::zeros_like(means2d) : at::empty({0}, f32);
+    return {renders, alphas, rnormals, rdistort, rmedian, holder, last_ids, median_ids};
+}
+
 } // namespace
 } // namespace gsplat_amd
 
@@ -590,6 +664,8 @@ TORCH_LIBRARY_IMPL(gsplat, CUDA, m)
     m.impl("intersect_offset", &intersect_offset);
     m.impl("rasterize_to_pixels_3dgs", &rasterize_to_pixels_3dgs);
     m.impl("rasterize_to_pixels_3dgs_bwd", &rasterize_to_pixels_3dgs_bwd);
+    m.impl("projection_2dgs_fused", &projection_2dgs_fused);
+    m.impl("rasterize_to_pixels_2dgs", &rasterize_to_pixels_2dgs);
 }
 
 // timing hooks for gsplat_amd/_cabi.py: begin(only = space-separated entry points or "" for all); end() returns
@@ -632,5 +708,6 @@ extern "C" const char *gsx_torch_profile_end()
 extern "C" const char *gsx_torch_compiled_ops()
 {
     return "projection_ewa_3dgs_fused projection_ewa_3dgs_fused_bwd projection_ewa_3dgs_packed spherical_harmonics spherical_harmonics_bwd "
-           "intersect_tile intersect_offset rasterize_to_pixels_3dgs rasterize_to_pixels_3dgs_bwd";
+           "intersect_tile intersect_offset rasterize_to_pixels_3dgs rasterize_to_pixels_3dgs_bwd "
+           "projection_2dgs_fused rasterize_to_pixels_2dgs";
 }
