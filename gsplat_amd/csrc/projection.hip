@@ -340,8 +340,17 @@ __device__ __forceinline__ void reduce_pose_grads(float *v_viewmat /*[16]*/, con
     if (row < 3) atomic_add_f32(v_viewmat + 4 * row + col, mine);
 }
 
+// Register budget of the dense backward: left alone the allocator takes 153 VGPRs (3 waves per SIMD); capped at 128 (4 waves,
+// 72 bytes of scratch per lane) the kernel is faster - c4 (16 M rows): 380 -> 336 us, c3: 41 -> 38 us (profiles/r05_ab.md #22)
+#ifndef GSX_PROJ_BWD_WAVES
+#define GSX_PROJ_BWD_WAVES 4
+#endif
 template <bool POSE>
-__global__ void __launch_bounds__(256) project_bwd_kernel(const ProjBwdArgs a)
+__global__ void __launch_bounds__(256)
+#if GSX_PROJ_BWD_WAVES
+__attribute__((amdgpu_waves_per_eu(GSX_PROJ_BWD_WAVES)))
+#endif
+project_bwd_kernel(const ProjBwdArgs a)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // over B*N
     const bool live   = idx < (int64_t)a.B * a.N;
