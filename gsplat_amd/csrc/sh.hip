@@ -660,8 +660,11 @@ __global__ void __launch_bounds__(256) sh3_bwd_dense_kernel(const ShArgs a)
 // in registers over the images; otherwise it is the outer product Y (x) v_colour of the single live row, written straight
 // into the lane's tile row once the coefficients in it have been consumed.
 // WANT_COEFFS = false: only the mean / direction gradients (the several-image case runs as two launches, see launch_sh3_bwd).
+// waves_per_eu(3): the tile (13 KiB per wave at degree 3) allows three workgroups per CU; without the hint the several-image
+// variant takes 172 VGPRs, four more than three waves per SIMD leave.
 template <int DEG, bool WANT_MEANS, bool MULTI, bool WANT_COEFFS = true>
-__global__ void __launch_bounds__(256) sh3_bwd_tiled_kernel(const ShArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+sh3_bwd_tiled_kernel(const ShArgs a)
 {
     constexpr int NB = (DEG + 1) * (DEG + 1), NF = NB * 3, Q = ShTile<NF>::Q, STRIDE = ShTile<NF>::STRIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_smem[];
