@@ -85,6 +85,8 @@ def algorithmic_bytes(M, V, P, T, D):
 def _git_head():
     """Commit of this tree: git when there is a checkout, else the stamp __graft_entry__.build() leaves next to the library
     (the GPU box receives a snapshot without .git)."""
+    if os.environ.get("GSX_COMMIT"):
+        return os.environ["GSX_COMMIT"]
     try:
         out = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5)
         if out.returncode == 0 and out.stdout.strip():
@@ -94,7 +96,7 @@ def _git_head():
     try:
         return json.load(open(os.path.join(ROOT, "gsplat_amd", "csrc", "build_info.json"))).get("commit")
     except Exception:
-        return os.environ.get("GSX_COMMIT")
+        return None
 
 
 def timed(step_fn, steps, warmup, barrier, profile_only=None):
