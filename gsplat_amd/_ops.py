@@ -13,6 +13,7 @@ There is no CPU implementation: calling these ops with CPU tensors raises.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -54,6 +55,7 @@ def _load_torch_classes() -> Optional[str]:
     return None
 
 
+_COMPILED_ISECT = False  # torch.ops.gsplat_amd.isect_fused_{begin,finish} available (set by _read_compiled_ops)
 COMPILED_OPS: frozenset = frozenset()  # ops whose CUDA-key body is C++ (csrc/torch_ops.cpp) rather than a function of this file
 
 
@@ -70,6 +72,10 @@ def _read_compiled_ops(path: str) -> None:
         return
     fn.restype = ctypes.c_char_p
     COMPILED_OPS = frozenset(fn().decode().split())
+    global _COMPILED_ISECT
+    _COMPILED_ISECT = (hasattr(torch.ops, "gsplat_amd") and hasattr(torch.ops.gsplat_amd, "isect_fused_begin")
+                       and os.environ.get("GSPLAT_AMD_COMPILED_OPS", "1") not in ("0", "")
+                       and os.environ.get("GSPLAT_AMD_COMPILED_ISECT", "1") not in ("0", ""))  # A/B switch
 
 
 COMPOSITE_UNAVAILABLE = _load_torch_classes()
@@ -382,6 +388,13 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
     # sort=True: fused path (csrc/isect_fused.hip) — per-(chunk, tile) histogram while counting, emission straight into
     # tile segments, offsets as a by-product; dense rows of any image count, packed rows of a single image
     st.fused = bool(sort) and _cabi.isect_fused_supported(I, tile_width, tile_height, packed)
+    if st.fused and _COMPILED_ISECT:
+        # compiled halves (csrc/torch_ops.cpp): same launches, ~30 us less interpreter time per step, and the count comes
+        # back through a polled pinned word instead of an event
+        st.tiles_per_gauss, st.offsets, st.count_ws, st.host_total = torch.ops.gsplat_amd.isect_fused_begin(
+            means2d, radii, conics, opacities, rows, I, tile_size, tile_width, tile_height, list(out_shape))
+        st.event = "polled"
+        return st
     st.host_total = torch.empty(1, dtype=torch.int64, pin_memory=True)
     if st.fused:
         st.count_ws = torch.empty(_cabi.isect_fused_count_workspace_bytes(rows, I, tile_width, tile_height), device=dev,
@@ -413,6 +426,11 @@ def isect_finish(st: "_IsectPending"):
     if rows == 0:
         return (tiles_per_gauss, torch.empty(0, device=dev, dtype=torch.int64),
                 torch.empty(0, device=dev, dtype=torch.int32))
+    if st.event == "polled":  # compiled second half: waits for the count (the one host round trip), allocates, emits, sorts
+        isect_ids, flatten_ids = torch.ops.gsplat_amd.isect_fused_finish(
+            means2d, radii, depths, conics, opacities, rows, I, tile_size, tile_width, tile_height, st.count_ws, st.offsets,
+            st.host_total)
+        return tiles_per_gauss, isect_ids, flatten_ids
     st.event.synchronize()  # host sync: exact-length outputs (reference: Intersect.cpp:258-259)
     n_isects = int(st.host_total.item())
     cum = st.cum

@@ -575,6 +575,62 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
     return {v_abs, v_means2d, v_conics, v_colors, v_opac, v_bg};
 }
 
+// ---- the two halves of the fused intersection, for the orchestrators (rendering.py) --------------------------------------
+// intersect_tile above blocks on the intersection count between its halves. The orchestrators enqueue the SH kernels in
+// between instead (gsplat_amd/_ops.py: isect_begin / isect_finish); these are the same two halves as private ops
+// (namespace gsplat_amd: not part of the reference's surface). The count travels through a pinned host word initialised to a
+// sentinel: the second half polls it - no event, no stream synchronisation, and the kernels enqueued in between keep running.
+std::tuple<Tensor, Tensor, Tensor, Tensor>
+isect_fused_begin(const Tensor &means2d, const Tensor &radii, const OptTensor &conics, const OptTensor &opac, int64_t rows,
+                  int64_t I, int64_t tile_size, int64_t tile_w, int64_t tile_h, c10::IntArrayRef out_shape)
+{
+    Launch L(means2d);
+    const uint32_t uI = (uint32_t)I, uts = (uint32_t)tile_size, utw = (uint32_t)tile_w, uth = (uint32_t)tile_h;
+    Tensor tiles_per_gauss = at::empty(out_shape, means2d.options().dtype(at::kInt));
+    Tensor host_total = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    *host_total.mutable_data_ptr<int64_t>() = -1;
+    Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
+    Tensor offsets = at::empty({I * tile_w * tile_h}, means2d.options().dtype(at::kInt));
+    { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
+                                mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(),
+                                count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
+          "gsx_isect_fused_count"); }
+    return {tiles_per_gauss, offsets, count_ws, host_total};
+}
+
+std::tuple<Tensor, Tensor>
+isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &depths, const OptTensor &conics, const OptTensor &opac,
+                   int64_t rows, int64_t I, int64_t tile_size, int64_t tile_w, int64_t tile_h, Tensor count_ws,
+                   const Tensor &offsets, const Tensor &host_total)
+{
+    Launch L(means2d);
+    const uint32_t uI = (uint32_t)I, uts = (uint32_t)tile_size, utw = (uint32_t)tile_w, uth = (uint32_t)tile_h;
+    volatile const int64_t *slot = host_total.const_data_ptr<int64_t>();
+    int64_t M = -1;
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint64_t spin = 0;; ++spin) {
+            M = *slot;
+            if (M >= 0) break;
+            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means2d.device().index()).synchronize();
+                M = *slot;
+                break;
+            }
+        }
+    }
+    TORCH_CHECK(M >= 0, "intersect_tile: the intersection count never reached the host");
+    TORCH_CHECK(M < (1ll << 31), "intersect_tile: ", M, " intersections overflow the int32 index space");
+    Tensor ids = at::empty({M}, means2d.options().dtype(at::kLong)), flat = at::empty({M}, means2d.options().dtype(at::kInt));
+    if (M == 0) return {ids, flat};
+    Tensor ws = bytes(gsx_isect_fused_emit_workspace_bytes(M, uI, utw, uth), means2d);
+    { Timed timed_("gsx_isect_fused_emit_sort", L.stream); check(gsx_isect_fused_emit_sort(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI, uts,
+                                    utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(), cp<int32_t>(offsets), M,
+                                    mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
+          "gsx_isect_fused_emit_sort"); }
+    return {ids, flat};
+}
+
 // ---- 2DGS: the two forward ops on the critical host path of rasterization_2dgs (the backward bodies stay in _ops.py: the
 // GPU has the whole compositing backward queued while they run) -------------------------------------------------------------
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor>
@@ -651,6 +707,20 @@ rasterize_to_pixels_2dgs(const Tensor &means2d_, const Tensor &ray_transforms_, 
 
 } // namespace
 } // namespace gsplat_amd
+
+TORCH_LIBRARY(gsplat_amd, m)
+{
+    m.def("isect_fused_begin(Tensor means2d, Tensor radii, Tensor? conics, Tensor? opacities, int rows, int n_images, int tile_size, "
+          "int tile_w, int tile_h, int[] out_shape) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("isect_fused_finish(Tensor means2d, Tensor radii, Tensor depths, Tensor? conics, Tensor? opacities, int rows, int n_images, "
+          "int tile_size, int tile_w, int tile_h, Tensor count_ws, Tensor offsets, Tensor host_total) -> (Tensor, Tensor)");
+}
+
+TORCH_LIBRARY_IMPL(gsplat_amd, CUDA, m)
+{
+    m.impl("isect_fused_begin", &gsplat_amd::isect_fused_begin);
+    m.impl("isect_fused_finish", &gsplat_amd::isect_fused_finish);
+}
 
 TORCH_LIBRARY_IMPL(gsplat, CUDA, m)
 {
