@@ -11,6 +11,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gsplat_amd
 
+STAGES = False
+
 # (batch, channels, grid, packed) -> published "FPS fwd / FPS bwd" on TITAN RTX (profile.rst:51-143)
 PUBLISHED = {(1, 3, 5, False): (171.8, 97.1), (1, 3, 5, True): (160.8, 88.4), (4, 3, 5, False): (46.1, 25.5),
              (1, 32, 1, False): (168.4, 44.2), (4, 32, 1, False): (42.1, 10.9), (1, 3, 21, True): (62.1, 34.6)}
@@ -63,11 +65,26 @@ def run(batch, channels, grid, packed, repeats, dev):
             v.grad = None
 
     t_bwd, _ = timeit(repeats, bwd)
+    stages = None
+    if STAGES:  # per-entry-point HIP-event times of 5 forward and 5 backward calls
+        from gsplat_amd import _cabi
+        _cabi.profile_begin()
+        for _ in range(5):
+            fwd()
+        pf = _cabi.profile_end()
+        _cabi.profile_begin()
+        for _ in range(5):
+            bwd()
+        pb = _cabi.profile_end()
+        stages = {"fwd_ms": {k.replace("gsx_", ""): round(sum(v) / 5, 4) for k, v in sorted(pf.items())},
+                  "bwd_ms": {k.replace("gsx_", ""): round(sum(v) / 5, 4) for k, v in sorted(pb.items())}}
     pub = PUBLISHED.get((batch, channels, grid, packed))
     row = {"batch": batch, "channels": channels, "scene_grid": grid, "packed": packed, "n_gaussians": int(means.shape[0]),
            "n_isects": int(out[2]["isect_ids"].numel()), "fps_fwd": round(1 / t_fwd, 1), "fps_bwd": round(1 / t_bwd, 1),
            "mpix_s_fwd_bwd": round(batch * 1920 * 1080 / (t_fwd + t_bwd) / 1e6, 1),
            "published_titan_rtx_fps_fwd_bwd": pub}
+    if stages:
+        row["stages"] = stages
     print(json.dumps(row), flush=True)
     return row
 
@@ -76,11 +93,16 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--repeats", type=int, default=20)
     ap.add_argument("--big", action="store_true", help="also the 49M-Gaussian configuration (scene_grid 21)")
+    ap.add_argument("--stages", action="store_true", help="add per-entry-point kernel times (HIP events) to every row")
+    ap.add_argument("--only", type=int, default=None, help="run only configuration number i")
     a = ap.parse_args()
+    STAGES = a.stages
     dev = torch.device("cuda", 0)
     cfgs = [(1, 3, 5, False), (1, 3, 5, True), (4, 3, 5, False), (1, 32, 1, False), (4, 32, 1, False)]
     if a.big:
         cfgs.append((1, 3, 21, True))
-    for c in cfgs:
+    for i, c in enumerate(cfgs):
+        if a.only is not None and i != a.only:
+            continue
         run(*c, a.repeats, dev)
         torch.cuda.empty_cache()
