@@ -115,6 +115,45 @@ __device__ __forceinline__ Surfel eval_surfel(const float4 A /*zeta_c, x'*/, con
     return s;
 }
 
+// Second, exact stage of the wave-level culling. The box of surfel_cull_box() lets through every (wave, surfel) pair whose
+// footprint misses the wave's 8 x 8 pixel rectangle diagonally: 31 % of the pairs the c5 backward evaluated had no lane that
+// passes the alpha test. A pixel passes iff min(G3, G2) <= 2 L (L = ln(255 opac)), i.e. iff it lies
+//   * in the low-pass disc |pixel - mean| <= sqrt(L)   -> distance from the mean to the rectangle, or
+//   * where G3 = |zeta.xy|^2 / zeta.z^2 <= 2 L. zeta is affine in the pixel (stage_surfel), so that is F(q) <= 0 for the
+//     quadratic F = zeta^T diag(1, 1, -2L) zeta in q = pixel - tile centre: its minimum over the rectangle, exactly - at the
+//     unconstrained minimiser if that lies inside, else on the edges facing it (one clamped 1-D minimisation per edge).
+// Conservative: the level carries the same +0.01 as the box, the comparison a margin of 1e-4 of the magnitude of F's terms;
+// a quadratic that is not convex (a surfel seen nearly edge-on: the footprint is a hyperbola branch) is never culled.
+__device__ __forceinline__ bool surfel_reaches_rect(const float4 A /*zeta_c, mean.x'*/, const float4 B /*Z1, mean.y'*/,
+                                                    const float4 C /*Z2, opacity*/, float rcx, float rcy, float hw, float hh)
+{
+    const float L = __logf(255.0f * C.w) + 0.01f;
+    if (!(L > 0.0f)) return false;
+    const float x0 = rcx - hw, x1 = rcx + hw, y0 = rcy - hh, y1 = rcy + hh;
+    {   // low-pass disc
+        const float dx = fmaxf(fmaxf(x0 - A.w, A.w - x1), 0.0f), dy = fmaxf(fmaxf(y0 - B.w, B.w - y1), 0.0f);
+        if (dx * dx + dy * dy <= L) return true;
+    }
+    const float k2 = 2.0f * L;
+    const float a = fmaf(B.x, B.x, fmaf(B.y, B.y, -k2 * B.z * B.z));
+    const float c = fmaf(C.x, C.x, fmaf(C.y, C.y, -k2 * C.z * C.z));
+    const float b = 2.0f * fmaf(B.x, C.x, fmaf(B.y, C.y, -k2 * B.z * C.z));
+    const float d = 2.0f * fmaf(A.x, B.x, fmaf(A.y, B.y, -k2 * A.z * B.z));
+    const float e = 2.0f * fmaf(A.x, C.x, fmaf(A.y, C.y, -k2 * A.z * C.z));
+    const float f = fmaf(A.x, A.x, fmaf(A.y, A.y, -k2 * A.z * A.z));
+    const float det = 4.0f * a * c - b * b;
+    if (!(a > 0.0f && c > 0.0f && det > 0.0f)) return true; // not an ellipse: keep
+    const float inv = __builtin_amdgcn_rcpf(det);
+    const float xm = (b * e - 2.0f * c * d) * inv, ym = (b * d - 2.0f * a * e) * inv; // unconstrained minimiser
+    const float xe = fminf(fmaxf(xm, x0), x1), ye = fminf(fmaxf(ym, y0), y1);
+    const float ys = fminf(fmaxf(-0.5f * fmaf(b, xe, e) * __builtin_amdgcn_rcpf(c), y0), y1); // along x = xe
+    const float xs = fminf(fmaxf(-0.5f * fmaf(b, ye, d) * __builtin_amdgcn_rcpf(a), x0), x1); // along y = ye
+    auto F = [&](float x, float y) { return fmaf(x, fmaf(a, x, fmaf(b, y, d)), fmaf(y, fmaf(c, y, e), f)); };
+    const float X = fmaxf(fabsf(x0), fabsf(x1)), Y = fmaxf(fabsf(y0), fabsf(y1));
+    const float mag = fmaf(X, fmaf(a, X, fmaf(fabsf(b), Y, fabsf(d))), fmaf(Y, fmaf(c, Y, fabsf(e)), fabsf(f)));
+    return !(fminf(F(xe, ys), F(xs, ye)) > 1e-4f * mag); // NaN: keep
+}
+
 constexpr int kBatch2 = 256;
 
 // ------------------------------------------------------------------------------------------
@@ -177,7 +216,6 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
     for (int k = 0; k < CH; ++k) acc[k] = 0.0f;
     float thr = inside ? kAlphaThreshold : INFINITY; // alpha threshold of this pixel; +inf = done (or not rendered)
     const uint32_t lane = tid & 63u;
-    const WaveRect rect = wave_pixel_rect(inside, px, py);
 
     for (int32_t b = 0; b < n_batches; ++b) {
         if (__syncthreads_count(!(thr < INFINITY)) == (int)blockDim.x) break;
@@ -200,6 +238,8 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
         }
         __syncthreads();
         const int32_t batch_size = min(kBatch2, range_end - batch_start);
+        // the rectangle shrinks with the pixels that are still open (refreshed once per batch: ~50 instructions)
+        const WaveRect rect = wave_pixel_rect(thr < INFINITY, px, py);
         // 64 staged surfels are tested per instruction against this wave's pixel rectangle; only the ballot survivors
         // are evaluated, front to back (a culled pair has no pixel that could pass the alpha test)
         for (int32_t j = 0; j < batch_size; j += 64) {
@@ -209,6 +249,7 @@ __global__ void __launch_bounds__(256) raster2d_fwd_kernel(const Raster2DArgs a)
           if (tl < batch_size) {
               const float4 cu = s_cull[tl];
               hit = (fabsf(cu.x - rect.cx) - rect.hw <= cu.z) && (fabsf(cu.y - rect.cy) - rect.hh <= cu.w);
+              if (hit) hit = surfel_reaches_rect(s_A[tl], s_B[tl], s_C[tl], rect.cx - tcx, rect.cy - tcy, rect.hw, rect.hh);
           }
           uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
           while (todo) {
@@ -362,7 +403,6 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
         accum_w_buffer = a.render_alphas[pix];
         accum_w        = accum_w_buffer;
     }
-    const WaveRect rect          = wave_pixel_rect(inside, px, py);
 
     for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
 #pragma unroll
@@ -396,12 +436,16 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
         __syncthreads();
 
         const int32_t t_first = max(0, batch_end - wave_bin_final); // surfels behind every last contributor: skipped
+        // pixels whose last contributor lies in front of this whole batch take no part in it: the rectangle is the box of
+        // the others (it grows from batch to batch as the walk moves towards the front)
+        const WaveRect rect = wave_pixel_rect(inside && bin_final >= batch_end - (batch_size - 1), px, py);
         for (int32_t j = (t_first & ~63); j < batch_size; j += 64) {
           const int32_t tl = j + (int32_t)lane;
           bool hit         = false;
           if (tl >= t_first && tl < batch_size) {
               const float4 cu = s_cull[tl];
               hit = (fabsf(cu.x - rect.cx) - rect.hw <= cu.z) && (fabsf(cu.y - rect.cy) - rect.hh <= cu.w);
+              if (hit) hit = surfel_reaches_rect(s_Za[tl], s_Zb[tl], s_Zc[tl], rect.cx - tcx, rect.cy - tcy, rect.hw, rect.hh);
           }
           uint64_t todo = __builtin_amdgcn_ballot_w64(hit);
           while (todo) { // scalar loop over the survivors, back to front
