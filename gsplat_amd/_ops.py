@@ -353,7 +353,16 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
     total (pinned buffer + event) without waiting for it. The caller may enqueue independent work (the orchestrator
     runs the SH kernels here) before isect_finish() blocks on the event, so the host round trip for the exact output
     length (reference: the `.item()` at Intersect.cpp:258-259) no longer idles the GPU."""
-    _check_f32(means2d=means2d, depths=depths, conics=conics, opacities=opacities)
+    f64 = means2d.dtype == torch.float64
+    if f64:
+        # float64 rows (the reference dispatches this op over float and double): radius boxes in double, keys carry the
+        # depth narrowed to float32; the exact ellipse test is fp32 only
+        if conics is not None or opacities is not None:
+            raise TypeError("gsplat_amd: intersect_tile with float64 rows supports the radius-box test only "
+                            "(conics / opacities select the exact test, which is computed in fp32)")
+        depths = depths.to(torch.float64)
+    else:
+        _check_f32(means2d=means2d, depths=depths, conics=conics, opacities=opacities)
     packed = image_ids is not None
     means2d, radii, depths = means2d.contiguous(), radii.contiguous(), depths.contiguous()
     if radii.dtype != torch.int32:
@@ -387,7 +396,7 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
         return st
     # sort=True: fused path (csrc/isect_fused.hip) — per-(chunk, tile) histogram while counting, emission straight into
     # tile segments, offsets as a by-product; dense rows of any image count, packed rows of a single image
-    st.fused = bool(sort) and _cabi.isect_fused_supported(I, tile_width, tile_height, packed)
+    st.fused = bool(sort) and not f64 and _cabi.isect_fused_supported(I, tile_width, tile_height, packed)
     if st.fused and _COMPILED_ISECT:
         # compiled halves (csrc/torch_ops.cpp): same launches, ~30 us less interpreter time per step, and the count comes
         # back through a polled pinned word instead of an event
@@ -407,8 +416,12 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
         st.event = torch.cuda.Event()
         st.event.record()
         return st
-    call("gsx_isect_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), ptr(image_ids), rows, n_per, I,
-         tile_size, tile_width, tile_height, ptr(st.tiles_per_gauss))
+    if f64:
+        call("gsx_isect_count_f64", ptr(means2d), ptr(radii), ptr(image_ids), rows, n_per, I, tile_size, tile_width,
+             tile_height, ptr(st.tiles_per_gauss))
+    else:
+        call("gsx_isect_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), ptr(image_ids), rows, n_per, I,
+             tile_size, tile_width, tile_height, ptr(st.tiles_per_gauss))
     st.cum = _scan_i32(st.tiles_per_gauss)
     st.host_total.copy_(st.cum[-1:], non_blocking=True)
     st.event = torch.cuda.Event()
@@ -447,8 +460,12 @@ def isect_finish(st: "_IsectPending"):
              I, tile_size, tile_width, tile_height, ptr(st.count_ws), st.count_ws.numel(), ptr(st.offsets), n_isects,
              ptr(isect_ids), ptr(flatten_ids), ptr(ws), ws.numel())
         return tiles_per_gauss, isect_ids, flatten_ids
-    call("gsx_isect_emit", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), ptr(image_ids),
-         ptr(cum), rows, n_per, I, tile_size, tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids))
+    if means2d.dtype == torch.float64:
+        call("gsx_isect_emit_f64", ptr(means2d), ptr(radii), ptr(depths), ptr(image_ids), ptr(cum), rows, n_per, I,
+             tile_size, tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids))
+    else:
+        call("gsx_isect_emit", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), ptr(image_ids),
+             ptr(cum), rows, n_per, I, tile_size, tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids))
     if st.sort and _cabi.tile_sort_supported(I, tile_width, tile_height):
         keys_s, vals_s = torch.empty_like(isect_ids), torch.empty_like(flatten_ids)
         ws = torch.empty(_cabi.tile_sort_workspace_bytes(n_isects, I, tile_width, tile_height), device=dev,

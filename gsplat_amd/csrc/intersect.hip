@@ -64,6 +64,38 @@ __global__ void __launch_bounds__(256) isect_kernel(const IsectArgs a)
     }
 }
 
+// float64 rows: radius boxes only (the exact ellipse test stays fp32), keys carry the depth narrowed to float32 - the 32 key
+// bits must stay a monotonic function of the depth (a bare reinterpretation of half a double is not; test_basic.py:1282-1287)
+template <bool EMIT>
+__global__ void __launch_bounds__(256) isect_f64_kernel(const double *means2d, const int32_t *radii, const double *depths,
+                                                        const int64_t *image_ids, const int64_t *cum, int64_t rows,
+                                                        uint32_t n_per_image, uint32_t tile_size, uint32_t tile_w,
+                                                        uint32_t tile_h, uint32_t tile_n_bits, int32_t *tiles_per_gauss,
+                                                        int64_t *isect_ids, int32_t *flatten_ids)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows) return;
+    const double rx = (double)radii[2 * idx], ry = (double)radii[2 * idx + 1];
+    if (rx <= 0.0 || ry <= 0.0) {
+        if (!EMIT) tiles_per_gauss[idx] = 0;
+        return;
+    }
+    const double mx = means2d[2 * idx], my = means2d[2 * idx + 1];
+    if (!EMIT) {
+        tiles_per_gauss[idx] = walk_tiles_aabb_f64(mx, my, rx, ry, tile_size, tile_w, tile_h, [](int64_t) {});
+    } else {
+        const int64_t iid   = image_ids ? image_ids[idx] : idx / n_per_image;
+        const uint64_t hi   = (uint64_t)iid << (32 + tile_n_bits);
+        const uint64_t dkey = (uint64_t)__float_as_uint((float)depths[idx]);
+        int64_t cur         = idx == 0 ? 0 : cum[idx - 1];
+        walk_tiles_aabb_f64(mx, my, rx, ry, tile_size, tile_w, tile_h, [&](int64_t tile) {
+            isect_ids[cur]   = (int64_t)(hi | ((uint64_t)tile << 32) | dkey);
+            flatten_ids[cur] = (int32_t)idx;
+            ++cur;
+        });
+    }
+}
+
 // offsets[k] = first index of the sorted list whose (image, tile) >= k.
 __global__ void __launch_bounds__(256) isect_offsets_kernel(
     const int64_t *sorted_ids, int64_t n_isects, uint32_t n_tiles, uint32_t tile_n_bits, int64_t total_tiles,
@@ -111,6 +143,44 @@ extern "C" int gsx_isect_count(const float *means2d, const int32_t *radii, const
     a.tile_h = tile_h; a.tiles_per_gauss = tiles_per_gauss;
     isect_kernel<false><<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
     return check_launch("isect_count");
+}
+
+extern "C" int gsx_isect_count_f64(const double *means2d, const int32_t *radii, const int64_t *image_ids, int64_t rows,
+                                   uint32_t n_per_image, uint32_t n_images, uint32_t tile_size, uint32_t tile_w,
+                                   uint32_t tile_h, int32_t *tiles_per_gauss, void *stream)
+{
+    using namespace gsx;
+    (void)n_images;
+    GSX_REQUIRE(rows >= 0, "gsx_isect_count_f64: negative rows");
+    GSX_REQUIRE(tile_size > 0, "gsx_isect_count_f64: tile_size must be positive");
+    if (rows == 0) return GSX_OK;
+    GSX_REQUIRE(means2d && radii && tiles_per_gauss, "gsx_isect_count_f64: null pointer");
+    isect_f64_kernel<false><<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        means2d, radii, nullptr, image_ids, nullptr, rows, n_per_image ? n_per_image : 1, tile_size, tile_w, tile_h, 0,
+        tiles_per_gauss, nullptr, nullptr);
+    return check_launch("isect_count_f64");
+}
+
+extern "C" int gsx_isect_emit_f64(const double *means2d, const int32_t *radii, const double *depths, const int64_t *image_ids,
+                                  const int64_t *cum_tiles_per_gauss, int64_t rows, uint32_t n_per_image, uint32_t n_images,
+                                  uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int64_t *isect_ids,
+                                  int32_t *flatten_ids, void *stream)
+{
+    using namespace gsx;
+    GSX_REQUIRE(rows >= 0, "gsx_isect_emit_f64: negative rows");
+    GSX_REQUIRE(tile_size > 0, "gsx_isect_emit_f64: tile_size must be positive");
+    const uint32_t tile_bits = bits_for_count((uint64_t)tile_w * tile_h), image_bits = bits_for_count(n_images);
+    if (tile_bits + image_bits > 32) {
+        set_last_error("gsx_isect_emit_f64: tile bits (%u) + image bits (%u) exceed the 32 key bits above the depth",
+                       tile_bits, image_bits);
+        return GSX_ERR_OVERFLOW;
+    }
+    if (rows == 0) return GSX_OK;
+    GSX_REQUIRE(means2d && radii && depths && cum_tiles_per_gauss, "gsx_isect_emit_f64: null pointer");
+    isect_f64_kernel<true><<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        means2d, radii, depths, image_ids, cum_tiles_per_gauss, rows, n_per_image ? n_per_image : 1, tile_size, tile_w, tile_h,
+        tile_bits, nullptr, isect_ids, flatten_ids);
+    return check_launch("isect_emit_f64");
 }
 
 extern "C" int gsx_isect_emit(const float *means2d, const int32_t *radii, const float *depths, const float *conics,

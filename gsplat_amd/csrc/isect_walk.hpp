@@ -116,4 +116,33 @@ __host__ __device__ __forceinline__ int32_t walk_tiles(
     return count;
 }
 
+// float64 rows (the reference instantiates its intersection kernel for double as well, AT_DISPATCH_FLOATING_TYPES in
+// IntersectTile.cu, and tests it: tests/test_basic.py:1268-1316): the radius-box enumeration of the branch above in double -
+// quotient, floor / ceil, clamp: every step a single IEEE operation, identical on host and device.
+__host__ __device__ __forceinline__ int f2i_trunc_sat(double x)
+{
+    if (!(x == x)) return 0;
+    if (x >= 2.0e9) return 2000000000;
+    if (x <= -2.0e9) return -2000000000;
+    return (int)x;
+}
+template <typename Emit>
+__host__ __device__ __forceinline__ int32_t walk_tiles_aabb_f64(double mx, double my, double rx, double ry, uint32_t tile_size,
+                                                                uint32_t tile_w, uint32_t tile_h, Emit &&emit)
+{
+    const double ts = (double)tile_size;
+    const double tx = mx / ts, ty = my / ts, trx = rx / ts, try_ = ry / ts;
+    const int x0 = clampi(f2i_trunc_sat(floor(tx - trx)), 0, (int)tile_w);
+    const int y0 = clampi(f2i_trunc_sat(floor(ty - try_)), 0, (int)tile_h);
+    const int x1 = clampi(f2i_trunc_sat(ceil(tx + trx)), 0, (int)tile_w);
+    const int y1 = clampi(f2i_trunc_sat(ceil(ty + try_)), 0, (int)tile_h);
+    int32_t count = 0;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            emit((int64_t)y * tile_w + x);
+            ++count;
+        }
+    return count;
+}
+
 } // namespace gsx

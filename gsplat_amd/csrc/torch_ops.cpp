@@ -398,10 +398,16 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
                int64_t tile_size, int64_t tile_w, int64_t tile_h, bool sort, bool segmented)
 {
     (void)gaussian_ids; (void)segmented; // the global sort is used (results are identical to the segmented one)
-    want_f32(means2d_, "means2d"); want_f32(depths_, "depths"); want_f32(conics_, "conics"); want_f32(opacities_, "opacities");
+    const bool f64 = means2d_.scalar_type() == at::kDouble; // radius boxes in double, depth narrowed to float32 in the key
+    if (f64) {
+        TORCH_CHECK_TYPE(!has(conics_) && !has(opacities_), "gsplat_amd: intersect_tile with float64 rows supports the "
+                         "radius-box test only (conics / opacities select the exact test, which is computed in fp32)");
+    } else {
+        want_f32(means2d_, "means2d"); want_f32(depths_, "depths"); want_f32(conics_, "conics"); want_f32(opacities_, "opacities");
+    }
     Launch L(means2d_);
     const bool packed = has(image_ids_);
-    const Tensor means2d = contig(means2d_), depths = contig(depths_);
+    const Tensor means2d = contig(means2d_), depths = contig(f64 ? depths_.to(at::kDouble) : depths_);
     const Tensor radii = contig(radii_.scalar_type() == at::kInt ? radii_ : radii_.to(at::kInt));
     const OptTensor conics = contig(conics_), opac = contig(opacities_), image_ids = contig(image_ids_);
     int64_t rows, n_per, I;
@@ -428,7 +434,7 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
     // the grand total comes back through pinned host memory (the one host sync of this op: Intersect.cpp:258-259)
     Tensor host_total = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
     auto hip_stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means2d.device().index());
-    if (sort && gsx_isect_fused_supported(uI, utw, uth, packed ? 1 : 0)) {
+    if (sort && !f64 && gsx_isect_fused_supported(uI, utw, uth, packed ? 1 : 0)) {
         Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
         Tensor offsets = at::empty({I * tile_w * tile_h}, means2d.options().dtype(at::kInt));
         { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
@@ -447,6 +453,12 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
               "gsx_isect_fused_emit_sort"); }
         return {tiles_per_gauss, ids, flat};
     }
+    if (f64) {
+        Timed timed_("gsx_isect_count_f64", L.stream);
+        check(gsx_isect_count_f64(cp<double>(means2d), cp<int32_t>(radii), cp<int64_t>(image_ids), rows, (uint32_t)n_per, uI, uts,
+                                  utw, uth, mp<int32_t>(tiles_per_gauss), L.stream),
+              "gsx_isect_count_f64");
+    } else
     { Timed timed_("gsx_isect_count", L.stream); check(gsx_isect_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), cp<int64_t>(image_ids), rows, (uint32_t)n_per, uI,
                           uts, utw, uth, mp<int32_t>(tiles_per_gauss), L.stream),
           "gsx_isect_count"); }
@@ -462,6 +474,13 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
     TORCH_CHECK(M < (1ll << 31), "intersect_tile: ", M, " intersections overflow the int32 index space");
     Tensor ids = at::empty({M}, means2d.options().dtype(at::kLong)), flat = at::empty({M}, means2d.options().dtype(at::kInt));
     if (M == 0) return {tiles_per_gauss, ids, flat};
+    if (f64) {
+        Timed timed_("gsx_isect_emit_f64", L.stream);
+        check(gsx_isect_emit_f64(cp<double>(means2d), cp<int32_t>(radii), cp<double>(depths), cp<int64_t>(image_ids),
+                                 cp<int64_t>(cum), rows, (uint32_t)n_per, uI, uts, utw, uth, mp<int64_t>(ids), mp<int32_t>(flat),
+                                 L.stream),
+              "gsx_isect_emit_f64");
+    } else
     { Timed timed_("gsx_isect_emit", L.stream); check(gsx_isect_emit(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), cp<int64_t>(image_ids),
                          cp<int64_t>(cum), rows, (uint32_t)n_per, uI, uts, utw, uth, mp<int64_t>(ids), mp<int32_t>(flat), L.stream),
           "gsx_isect_emit"); }

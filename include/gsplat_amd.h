@@ -254,6 +254,16 @@ int gsx_isect_emit(const float *means2d, const int32_t *radii, const float *dept
                    int64_t rows, uint32_t n_per_image, uint32_t n_images,
                    uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                    int64_t *isect_ids, int32_t *flatten_ids, void *stream);
+/* float64 rows (the reference dispatches intersect_tile over float and double, IntersectTile.cu AT_DISPATCH_FLOATING_TYPES;
+ * tests/test_basic.py:1268-1316): radius-box enumeration in double, the depth in the key narrowed to float32. The exact
+ * ellipse test (conics + opacities) is fp32 only. */
+int gsx_isect_count_f64(const double *means2d, const int32_t *radii, const int64_t *image_ids, int64_t rows,
+                        uint32_t n_per_image, uint32_t n_images, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                        int32_t *tiles_per_gauss, void *stream);
+int gsx_isect_emit_f64(const double *means2d, const int32_t *radii, const double *depths, const int64_t *image_ids,
+                       const int64_t *cum_tiles_per_gauss, int64_t rows, uint32_t n_per_image, uint32_t n_images,
+                       uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int64_t *isect_ids, int32_t *flatten_ids,
+                       void *stream);
 int64_t gsx_scan_workspace_bytes(int64_t n);
 int gsx_scan_i32(const int32_t *in, int64_t n, int64_t *out_inclusive, void *workspace, int64_t workspace_bytes,
                  void *stream);

@@ -385,6 +385,9 @@ def isect_tiles(
     [I,N,*]; packed inputs are [nnz,*] with image_ids. Returns (tiles_per_gauss int32,
     isect_ids int64 [M], flatten_ids int32 [M]); sorted with a STABLE sort when sort=True
     (cub radix sort is stable, IntersectTile.cu:1096-1104)."""
+    if _is_f64(means2d):
+        return _isect_tiles_f64(means2d, radii, depths, tile_size, tile_width, tile_height, sort, conics, opacities, image_ids,
+                                n_images)
     m2 = _np(means2d, np.float32)
     packed = image_ids is not None
     if packed:
@@ -418,6 +421,57 @@ def isect_tiles(
         order = np.argsort(ids.view(np.uint64), kind="stable")
         ids, fl = ids[order], fl[order]
     return (torch.from_numpy(tpg.reshape(out_shape)), torch.from_numpy(ids), torch.from_numpy(fl))
+
+
+def _is_f64(x) -> bool:
+    return getattr(x, "dtype", None) in (torch.float64, np.float64) or (isinstance(x, np.ndarray) and x.dtype == np.float64)
+
+
+def _isect_tiles_f64(means2d, radii, depths, tile_size, tile_width, tile_height, sort, conics, opacities, image_ids, n_images):
+    """float64 rows (the reference instantiates intersect_tile for double: IntersectTile.cu AT_DISPATCH_FLOATING_TYPES; its
+    torch restatement _torch_impl.py:356-451 runs in the input dtype): radius boxes floor((m - r) / ts) .. ceil((m + r) / ts) in
+    double, clamped to the tile grid; rows enumerated y-major; the key carries the depth narrowed to float32
+    (tests/test_basic.py:1282-1287). The exact ellipse test is fp32 only."""
+    if conics is not None or opacities is not None:
+        raise TypeError("float64 rows: radius-box test only")
+    m2 = _np(means2d, np.float64)
+    packed = image_ids is not None
+    if packed:
+        rows, n_per, I, out_shape = m2.shape[0], 1, int(n_images), (m2.shape[0],)
+    else:
+        I, n_per = int(np.prod(m2.shape[:-2])), m2.shape[-2]
+        rows, out_shape = I * n_per, m2.shape[:-1]
+    m2 = m2.reshape(rows, 2)
+    rd = _np(radii, np.int32).reshape(rows, 2)
+    dp = _np(depths, np.float64).reshape(rows)
+    iid = _np(image_ids, np.int64).reshape(rows) if packed else np.arange(rows, dtype=np.int64) // max(n_per, 1)
+    ts = float(tile_size)
+    t, r = m2 / ts, rd.astype(np.float64) / ts
+
+    def to_int(x, hi):  # f2i_trunc_sat + clamp (csrc/isect_walk.hpp)
+        x = np.where(np.isnan(x), 0.0, np.clip(x, -2.0e9, 2.0e9))
+        return np.clip(x.astype(np.int64), 0, hi)
+
+    x0, y0 = to_int(np.floor(t[:, 0] - r[:, 0]), tile_width), to_int(np.floor(t[:, 1] - r[:, 1]), tile_height)
+    x1, y1 = to_int(np.ceil(t[:, 0] + r[:, 0]), tile_width), to_int(np.ceil(t[:, 1] + r[:, 1]), tile_height)
+    live = (rd[:, 0] > 0) & (rd[:, 1] > 0)
+    w, h = np.maximum(x1 - x0, 0), np.maximum(y1 - y0, 0)
+    tpg = np.where(live, w * h, 0).astype(np.int32)
+    tile_bits, image_bits = bits_for_count(tile_width * tile_height), bits_for_count(I)
+    if tile_bits + image_bits > 32:
+        raise RuntimeError("isect key overflow: image bits + tile bits > 32")
+    M = int(tpg.sum())
+    row = np.repeat(np.arange(rows, dtype=np.int64), tpg)
+    k = np.arange(M, dtype=np.int64) - np.repeat(np.cumsum(tpg, dtype=np.int64) - tpg, tpg)
+    wr = np.maximum(w[row], 1)
+    tile = (y0[row] + k // wr) * tile_width + (x0[row] + k % wr)
+    dbits = dp.astype(np.float32).view(np.uint32).astype(np.uint64)
+    ids = ((iid[row].astype(np.uint64) << np.uint64(32 + tile_bits)) | (tile.astype(np.uint64) << np.uint64(32)) | dbits[row])
+    fl = row.astype(np.int32)
+    if sort and M > 0:
+        order = np.argsort(ids, kind="stable")
+        ids, fl = ids[order], fl[order]
+    return (torch.from_numpy(tpg.reshape(out_shape)), torch.from_numpy(ids.view(np.int64).copy()), torch.from_numpy(fl))
 
 
 def isect_offset_encode(isect_ids, n_images: int, tile_width: int, tile_height: int) -> Tensor:

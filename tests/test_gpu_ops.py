@@ -623,3 +623,42 @@ def test_query_rasterizers_match_oracle(G, O, packed):
     for p in agree[::97].tolist():
         pos = [lids[p].index(g) for g in tids_c[p].tolist() if g >= 0]
         assert pos == sorted(pos)
+
+
+@pytest.mark.parametrize("batch_dims", [(), (2,)])
+@pytest.mark.parametrize("via", ["wrapper", "op"])
+def test_isect_tiles_float64_rows(G, O, batch_dims, via):
+    """float64 rows (the reference instantiates intersect_tile for double, tests/test_basic.py:1268-1316): bit-exact against
+    the oracle's double branch (itself pinned against the reference's torch restatement), dense with batch dimensions and
+    packed, through isect_tiles() and through the raw op (the compiled body); the exact test stays fp32 (TypeError)."""
+    g = torch.Generator().manual_seed(42)
+    C, N, width, height, ts = 3, 1000, 40, 60, 16
+    shape = tuple(batch_dims) + (C, N)
+    means2d = torch.randn(shape + (2,), generator=g, dtype=torch.float64) * width
+    radii = torch.randint(0, width, shape + (2,), generator=g, dtype=torch.int32)
+    depths = torch.rand(shape, generator=g, dtype=torch.float64)
+    tw, th = math.ceil(width / ts), math.ceil(height / ts)
+    I = math.prod(batch_dims) * C
+    want = O.isect_tiles(means2d, radii, depths, ts, tw, th)
+    if via == "wrapper":
+        got = G.isect_tiles(means2d.to(DEV), radii.to(DEV), depths.to(DEV), ts, tw, th)
+    else:
+        got = torch.ops.gsplat.intersect_tile(means2d.to(DEV), radii.to(DEV), depths.to(DEV), None, None, None, None, None, ts,
+                                              tw, th, True, False)
+    for a, b, nm in zip(got, want, ("tiles_per_gauss", "isect_ids", "flatten_ids")):
+        assert a.dtype == b.dtype and torch.equal(cpu(a), b), nm
+    assert torch.equal(cpu(G.isect_offset_encode(got[1], I, tw, th)).reshape(-1), O.isect_offset_encode(want[1], I, tw, th).reshape(-1))
+    # packed rows of several images
+    flat = lambda t, k: t.reshape((-1,) + t.shape[len(shape):]) if k else t.reshape(-1)
+    keep = torch.rand(I * N, generator=g) > 0.4
+    image_ids = (torch.arange(I * N) // N)[keep]
+    m_p, r_p, d_p = flat(means2d, 1)[keep], flat(radii, 1)[keep], flat(depths, 0)[keep]
+    want_p = O.isect_tiles(m_p, r_p, d_p, ts, tw, th, image_ids=image_ids, n_images=I)
+    got_p = G.isect_tiles(m_p.to(DEV), r_p.to(DEV), d_p.to(DEV), ts, tw, th, packed=True, n_images=I,
+                          image_ids=image_ids.to(DEV), gaussian_ids=torch.zeros_like(image_ids).to(DEV))
+    for a, b in zip(got_p, want_p):
+        assert torch.equal(cpu(a), b)
+    with pytest.raises(TypeError):
+        torch.ops.gsplat.intersect_tile(means2d.to(DEV), radii.to(DEV), depths.to(DEV),
+                                        torch.ones(shape + (3,), dtype=torch.float64, device=DEV),
+                                        torch.ones(shape, dtype=torch.float64, device=DEV), None, None, None, ts, tw, th, True, False)

@@ -1,10 +1,15 @@
 """CPU: the oracle (oracle/) against the golden vectors produced by the REFERENCE's own Python
 (tests/golden/garden_quarter.npz, written by oracle/pin_against_reference.py from
 gsplat/cuda/_torch_impl.py + accumulate()). Keeps the oracle pinned on machines without /root/reference."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from _util import assert_close_ratio, assert_grad_close, to_t
 
 
@@ -137,3 +142,20 @@ def test_rasterize_saturating_gaussian_is_excluded():
 
 def test_bits_for_count():
     assert [O.bits_for_count(n) for n in (0, 1, 2, 3, 4, 5, 8, 9, 8160)] == [0, 0, 1, 2, 2, 3, 3, 4, 13]
+
+
+def test_isect_tiles_float64_matches_reference_torch_restatement():
+    """float64 rows: the oracle's double branch against outputs of the reference's _isect_tiles / _isect_offset_encode run in
+    float64 (tests/golden/isect_f64_ref.npz, oracle/pin_isect_f64_against_reference.py) - bit for bit."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "isect_f64_ref.npz"))
+    for name in ("a", "b", "c"):
+        C, N, width, height, ts, tw, th = (int(v) for v in g[f"{name}_cfg"])
+        m, r, d = (torch.from_numpy(g[f"{name}_{k}"]) for k in ("means2d", "radii", "depths"))
+        assert m.dtype == torch.float64
+        tpg, ids, fl = O.isect_tiles(m, r, d, ts, tw, th)
+        assert torch.equal(tpg.reshape(-1), torch.from_numpy(g[f"{name}_tpg"]).reshape(-1))
+        assert torch.equal(ids, torch.from_numpy(g[f"{name}_ids"])) and torch.equal(fl, torch.from_numpy(g[f"{name}_flat"]))
+        off = O.isect_offset_encode(ids, C, tw, th)
+        assert torch.equal(off.reshape(-1), torch.from_numpy(g[f"{name}_offsets"]).reshape(-1))
+    with pytest.raises(TypeError):
+        O.isect_tiles(m, r, d, ts, tw, th, conics=torch.ones(C, N, 3), opacities=torch.ones(C, N))
