@@ -449,12 +449,14 @@ def _project_features(features, sh_degree, clamp, means, viewmats, radii, batch_
     if sh_degree is None:
         D = features.shape[-1]
         per_view = features.dim() == nb + 3
+        # packed rows: index_select on the flattened row index (backward = atomic index_add) instead of advanced indexing
+        # (backward = index_put, which SORTS the nnz indices first: 0.77 ms per step at 49 M Gaussians / 7 M visible rows)
         if per_view:
             if packed:
-                return features.reshape(B, C, N, D)[batch_ids, camera_ids, gaussian_ids]
+                return features.reshape(B * C * N, D).index_select(0, (batch_ids * C + camera_ids) * N + gaussian_ids)
             return features
         if packed:
-            return features.reshape(B, N, D)[batch_ids, gaussian_ids]
+            return features.reshape(B * N, D).index_select(0, gaussian_ids if B == 1 else batch_ids * N + gaussian_ids)
         return torch.broadcast_to(features[..., None, :, :], batch_dims + (C, N, D))
     if clamp:
         # primary colours: SH + the `clamp_min(colors + 0.5, 0)` post-op + the radii > 0 row mask in ONE kernel each
