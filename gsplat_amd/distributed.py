@@ -171,7 +171,10 @@ class _AsyncExchange(torch.autograd.Function):
         else:
             buf = payload.contiguous() if radii is None else torch.cat([payload, radii.contiguous().view(torch.float32)], dim=1)
         out = torch.empty((sum(out_splits), buf.shape[1]), dtype=payload.dtype, device=payload.device)
-        fwd.work = dist.all_to_all_single(out, buf, out_splits, in_splits, async_op=True)
+        # The collective writes `out` AFTER the views below exist. A backend that bumps the tensor's version counter when
+        # the work completes (gloo does; RCCL bumps it at launch) would make autograd reject every later view of those
+        # views ("its base has been modified inplace"). `.data` aliases the storage with a version counter of its own.
+        fwd.work = dist.all_to_all_single(out.data, buf, out_splits, in_splits, async_op=True)
         ctx.splits, ctx.bwd = (in_splits, out_splits), bwd
         recv_r = out[:, F_:]  # float32 VIEW of the radii bits (no data is touched before the caller waits)
         ctx.mark_non_differentiable(recv_r)
@@ -370,7 +373,9 @@ class DistributedRasterContext:
             raise ValueError("distributed=True requires torch.distributed to be available.")
         if not dist.is_initialized():
             raise ValueError("distributed=True requires an initialized default torch.distributed process group.")
-        if device.type == "cuda" and dist.get_backend() != "nccl":
+        # GSPLAT_AMD_ALLOW_NON_NCCL=1: test hook - two ranks on ONE GPU cannot form an RCCL group, gloo moves the same
+        # messages through the host (tests/test_gpu_distributed_2rank.py)
+        if device.type == "cuda" and dist.get_backend() != "nccl" and os.environ.get("GSPLAT_AMD_ALLOW_NON_NCCL") != "1":
             raise ValueError("distributed=True currently supports only the default NCCL process group "
                              f"(RCCL on ROCm); got backend '{dist.get_backend()}'.")
         if len(batch_dims) != 0:

@@ -1,0 +1,93 @@
+"""GPU, world_size 2 on ONE device: rasterization(distributed=True) with the real kernels, both seams and the
+autograd-generated reverse exchange, against the single-process render of the whole scene.
+
+RCCL refuses two ranks on one GPU, so the process group is gloo (which moves the CUDA buffers through the host): what
+is under test is everything around the collectives - Gaussian sharding, camera all-gather, the personalised all-to-all of
+projected rows (dense: the two overlapped asynchronous messages; packed: variable-length messages), row order on the
+receiving side, the gradients that travel back to the rank that owns the Gaussian - with the kernels in the loop.
+Contract: reference tests/test_rasterization.py:819-868 (distributed == local on the same scene)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORLD = 2
+NAMES = ("means", "quats", "scales", "opacities", "colors")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, port, results, packed, c_local):
+    import traceback
+
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GSPLAT_AMD_ALLOW_NON_NCCL="1")
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+        import gsplat_amd as G
+        from _util import assert_close_ratio, assert_grad_close, make_scene
+
+        dev = torch.device("cuda", 0)
+        C = WORLD * c_local
+        sc, W, H = make_scene(N=4001, C=C, width=176, height=112, seed=21, sh_degree=2)
+        g = torch.Generator().manual_seed(9)
+        v_rc, v_ra = torch.randn(C, H, W, 3, generator=g), torch.randn(C, H, W, 1, generator=g)
+        mine = slice(rank * c_local, (rank + 1) * c_local)  # this rank's cameras
+        shard = slice(rank, None, WORLD)                     # this rank's Gaussians
+
+        # reference: ONE process renders every camera with every Gaussian. Gaussians in the order the ranks hold them
+        # (rank 0's shard, then rank 1's): flatten ids - the tie-break of equal depths - then agree with the exchange.
+        order = torch.cat([torch.arange(r, 4001, WORLD) for r in range(WORLD)])
+        full = {k: sc[k][order].to(dev).clone().requires_grad_(True) for k in NAMES}
+        rc0, ra0, _ = G.rasterization(full["means"], full["quats"], full["scales"], full["opacities"], full["colors"],
+                                      sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H, sh_degree=2, packed=packed)
+        ((rc0 * v_rc.to(dev)).sum() + (ra0 * v_ra.to(dev)).sum()).backward()
+        n0 = len(range(0, 4001, WORLD))
+        rows = slice(0, n0) if rank == 0 else slice(n0, 4001)
+
+        # distributed: this rank owns a shard of the Gaussians and c_local cameras
+        loc = {k: sc[k][shard].to(dev).clone().requires_grad_(True) for k in NAMES}
+        rc1, ra1, meta = G.rasterization(loc["means"], loc["quats"], loc["scales"], loc["opacities"], loc["colors"],
+                                         sc["viewmats"][mine].to(dev), sc["Ks"][mine].to(dev), W, H, sh_degree=2,
+                                         packed=packed, distributed=True)
+        ((rc1 * v_rc[mine].to(dev)).sum() + (ra1 * v_ra[mine].to(dev)).sum()).backward()
+        torch.cuda.synchronize()
+        assert rc1.shape == (c_local, H, W, 3)
+        assert_close_ratio(rc1.detach().cpu(), rc0[mine].detach().cpu(), 1e-5, 1e-5, max_bad_ratio=1e-4, name="colors")
+        assert_close_ratio(ra1.detach().cpu(), ra0[mine].detach().cpu(), 1e-5, 1e-5, max_bad_ratio=1e-4, name="alphas")
+        for k in NAMES:  # gradients of MY Gaussians from EVERY rank's images came back through the reverse exchange
+            assert_grad_close(loc[k].grad.cpu(), full[k].grad[rows].cpu(), rel=2e-4, name=f"rank {rank} v_{k}")
+        results[rank] = "ok"
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        results[rank] = traceback.format_exc()
+        raise
+
+
+@pytest.mark.parametrize("c_local", [2, 1])
+@pytest.mark.parametrize("packed", [False, True])
+def test_two_ranks_on_one_gpu_match_the_single_process_render(packed, c_local):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    mgr = mp.Manager()
+    results = mgr.dict()
+    ctx = mp.spawn(_worker, args=(_free_port(), results, packed, c_local), nprocs=WORLD, join=False)
+    ok = ctx.join(timeout=300)
+    while not ok:
+        ok = ctx.join(timeout=300)
+    assert dict(results) == {0: "ok", 1: "ok"}, "\n".join(f"rank {r}: {m}" for r, m in dict(results).items())
