@@ -178,6 +178,13 @@ def main():
     sys.stdout.flush()
     os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (there is no CPU fallback for the product path)"
+    # GSPLAT_BENCH_REHEARSAL=1: N ranks share GPU 0 and talk over gloo (RCCL refuses two ranks per device). It exists to
+    # run the N > 1 code path - sharding, both seams, barriers, max over ranks, the one JSON line - on a box with one GPU;
+    # the line is tagged "rehearsal": true and its timings mean nothing (messages cross the host).
+    rehearsal = os.environ.get("GSPLAT_BENCH_REHEARSAL") == "1" and world > 1
+    if rehearsal:
+        local_rank = 0
+        os.environ["GSPLAT_AMD_ALLOW_NON_NCCL"] = "1"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
@@ -189,7 +196,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29511")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
     n_gpus = world
     assert args.gpus == n_gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -358,6 +368,8 @@ def main():
         "config": {"workload": wl, "gaussians_per_gpu": n_local, "cameras_per_gpu": n_cams, "packed": packed,
                    "parallelism": f"gaussian-sharded x{n_gpus}" if distributed else "single"},
         "roofline": roofline,
+        **({"rehearsal": True, "rehearsal_note": "all ranks on ONE GPU over gloo: code-path check, timings meaningless"}
+           if rehearsal else {}),
         "raster_launch_ms": {"fwd": round(t_fwd, 4) if t_fwd == t_fwd else None,
                              "bwd": round(t_bwd, 4) if t_bwd == t_bwd else None},  # HIP events inside the timed region
         "stage_ms_per_step": {k.replace("gsx_", ""): round(v, 4) for k, v in sorted(per_step_ms.items())},

@@ -91,3 +91,27 @@ def test_two_ranks_on_one_gpu_match_the_single_process_render(packed, c_local):
     while not ok:
         ok = ctx.join(timeout=300)
     assert dict(results) == {0: "ok", 1: "ok"}, "\n".join(f"rank {r}: {m}" for r, m in dict(results).items())
+
+
+def test_bench_two_rank_path_rehearsal():
+    """bench.py's N > 1 path (c4-shaped: Gaussian-sharded scene, 4 cameras per rank, both seams, barriers, max over ranks,
+    ONE JSON line from rank 0) launched exactly as the driver launches it, with two ranks sharing the GPU over gloo
+    (GSPLAT_BENCH_REHEARSAL=1). Timings of a rehearsal mean nothing; the structure of the line is what is checked."""
+    import json
+    import subprocess
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    env = dict(os.environ, GSPLAT_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--gaussians", "60000"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak" and r["rehearsal"] is True
+    assert r["config"]["cameras_per_gpu"] == 4 and r["config"]["gaussians_per_gpu"] == 60000
+    assert r["config"]["parallelism"] == "gaussian-sharded x2" and r["value"] > 0 and r["unit"] == "Mpixels/s"
+    assert "cpu_baseline" not in r and "roofline" in r  # the CPU baseline is an N = 1 leg
