@@ -374,7 +374,7 @@ class DistributedRasterContext:
         if not dist.is_initialized():
             raise ValueError("distributed=True requires an initialized default torch.distributed process group.")
         # GSPLAT_AMD_ALLOW_NON_NCCL=1: test hook - two ranks on ONE GPU cannot form an RCCL group, gloo moves the same
-        # messages through the host (tests/test_gpu_distributed_2rank.py)
+        # messages through the host (tests/test_gpu_distributed_multirank.py)
         if device.type == "cuda" and dist.get_backend() != "nccl" and os.environ.get("GSPLAT_AMD_ALLOW_NON_NCCL") != "1":
             raise ValueError("distributed=True currently supports only the default NCCL process group "
                              f"(RCCL on ROCm); got backend '{dist.get_backend()}'.")

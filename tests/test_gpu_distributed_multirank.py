@@ -1,4 +1,4 @@
-"""GPU, world_size 2 on ONE device: rasterization(distributed=True) with the real kernels, both seams and the
+"""GPU, world_size 2 - 4 on ONE device: rasterization(distributed=True) with the real kernels, both seams and the
 autograd-generated reverse exchange, against the single-process render of the whole scene.
 
 RCCL refuses two ranks on one GPU, so the process group is gloo (which moves the CUDA buffers through the host): what
@@ -16,7 +16,6 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WORLD = 2
 NAMES = ("means", "quats", "scales", "opacities", "colors")
 
 
@@ -28,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, port, results, packed, c_local):
+def _worker(rank, port, results, packed, c_local, WORLD):
     import traceback
 
     try:
@@ -56,8 +55,8 @@ def _worker(rank, port, results, packed, c_local):
         rc0, ra0, _ = G.rasterization(full["means"], full["quats"], full["scales"], full["opacities"], full["colors"],
                                       sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H, sh_degree=2, packed=packed)
         ((rc0 * v_rc.to(dev)).sum() + (ra0 * v_ra.to(dev)).sum()).backward()
-        n0 = len(range(0, 4001, WORLD))
-        rows = slice(0, n0) if rank == 0 else slice(n0, 4001)
+        counts = [len(range(r, 4001, WORLD)) for r in range(WORLD)]
+        rows = slice(sum(counts[:rank]), sum(counts[:rank + 1]))
 
         # distributed: this rank owns a shard of the Gaussians and c_local cameras
         loc = {k: sc[k][shard].to(dev).clone().requires_grad_(True) for k in NAMES}
@@ -79,18 +78,19 @@ def _worker(rank, port, results, packed, c_local):
         raise
 
 
-@pytest.mark.parametrize("c_local", [2, 1])
-@pytest.mark.parametrize("packed", [False, True])
-def test_two_ranks_on_one_gpu_match_the_single_process_render(packed, c_local):
+@pytest.mark.parametrize("world,c_local,packed", [(2, 2, False), (2, 1, False), (2, 2, True), (2, 1, True), (3, 2, False),
+                                                  (3, 1, True), (4, 1, False)])
+def test_ranks_sharing_one_gpu_match_the_single_process_render(world, packed, c_local):
+    """world 3: shards of unequal size (1334 / 1334 / 1333 Gaussians); world 4: three peers per rank."""
     if not torch.cuda.is_available():
         pytest.skip("needs a ROCm GPU")
     mgr = mp.Manager()
     results = mgr.dict()
-    ctx = mp.spawn(_worker, args=(_free_port(), results, packed, c_local), nprocs=WORLD, join=False)
+    ctx = mp.spawn(_worker, args=(_free_port(), results, packed, c_local, world), nprocs=world, join=False)
     ok = ctx.join(timeout=300)
     while not ok:
         ok = ctx.join(timeout=300)
-    assert dict(results) == {0: "ok", 1: "ok"}, "\n".join(f"rank {r}: {m}" for r, m in dict(results).items())
+    assert dict(results) == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {m}" for r, m in dict(results).items())
 
 
 def test_bench_two_rank_path_rehearsal():
