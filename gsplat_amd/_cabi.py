@@ -282,6 +282,33 @@ def copy_column_groups(groups, rows: int) -> None:
     call("gsx_copy_column_groups", n, src, ss, dst, ds, w, rows)
 
 
+def copy_column_groups_mapped(groups, seg_rows, seg_n, map_dst: bool) -> None:
+    """gsx_copy_column_groups_mapped: `groups` as in copy_column_groups; seg_rows[k] = C_local * N_k, seg_n[k] = N_k."""
+    n, m = len(groups), len(seg_rows)
+    src = (ctypes.c_void_p * n)(*[g[0] for g in groups])
+    dst = (ctypes.c_void_p * n)(*[g[2] for g in groups])
+    ss = (ctypes.c_uint32 * n)(*[g[1] for g in groups])
+    ds = (ctypes.c_uint32 * n)(*[g[3] for g in groups])
+    w = (ctypes.c_uint32 * n)(*[g[4] for g in groups])
+    sr = (ctypes.c_int64 * m)(*[int(v) for v in seg_rows])
+    sn = (ctypes.c_int64 * m)(*[int(v) for v in seg_n])
+    call("gsx_copy_column_groups_mapped", n, src, ss, dst, ds, w, m, sr, sn, int(bool(map_dst)))
+
+
+def copy_message_columns(msg_ptr: int, msg_stride: int, rows: int, groups, to_message: bool, seg_rows=None, seg_n=None) -> None:
+    """gsx_copy_message_columns. `groups`: list of (column, width, field_ptr, field_row_stride) in 32-bit words."""
+    n = len(groups)
+    cols = (ctypes.c_uint32 * n)(*[g[0] for g in groups])
+    w = (ctypes.c_uint32 * n)(*[g[1] for g in groups])
+    fields = (ctypes.c_void_p * n)(*[g[2] for g in groups])
+    fs = (ctypes.c_uint32 * n)(*[g[3] for g in groups])
+    m = 0 if seg_rows is None else len(seg_rows)
+    sr = (ctypes.c_int64 * max(m, 1))(*([int(v) for v in seg_rows] if m else [0]))
+    sn = (ctypes.c_int64 * max(m, 1))(*([int(v) for v in seg_n] if m else [0]))
+    call("gsx_copy_message_columns", ctypes.c_void_p(msg_ptr), msg_stride, rows, n, cols, w, fields, fs, int(bool(to_message)), m,
+         sr, sn)
+
+
 def sort_pairs(keys, vals, keys_alt, vals_alt, n: int, end_bit: int, workspace) -> bool:
     """Returns True when the sorted data ended up in the alt buffers."""
     flag = ctypes.c_int(0)

@@ -544,6 +544,25 @@ int gsx_raster3d_sparse_top_contributing(const float *means2d, const float *coni
  * Pack: dst[k] = message + column offset of group k, dst_strides[k] = message row width; unpack: the other way round. */
 int gsx_copy_column_groups(uint32_t n_groups, const void *const *src, const uint32_t *src_strides, void *const *dst,
                            const uint32_t *dst_strides, const uint32_t *widths, int64_t rows, void *stream);
+/* The same copy with a ROW MAP for ranks that own several cameras: one side holds the rows source rank by source rank, each
+ * source's block camera-major ([C_local][N_k] rows for source k: seg_cameras_times_n[k] = C_local * N_k rows, seg_n[k] = N_k),
+ * the other ("mapped") side holds them as [C_local][sum N_k]: row (c, n) of source k <-> mapped row c * sum N + offset_k + n.
+ * map_dst != 0: the destination is the mapped side (unpack after the exchange), else the source is (pack gradients for the
+ * reverse exchange). Replaces the reference's at::cat of per-source pieces + per-field contiguous copies
+ * (DistributedCollectives.cpp:420-453) by one pass; segment tables are HOST arrays, n_segments <= 64. */
+int gsx_copy_column_groups_mapped(uint32_t n_groups, const void *const *src, const uint32_t *src_strides, void *const *dst,
+                                  const uint32_t *dst_strides, const uint32_t *widths, uint32_t n_segments,
+                                  const int64_t *seg_cameras_times_n, const int64_t *seg_n, int map_dst, void *stream);
+
+/* Message <-> field arrays, both sides coalesced: `message` is a contiguous [rows][message_stride] array of 32-bit words (what
+ * the exchange sends / receives; message_stride <= 16); group k is its columns [columns[k], columns[k] + widths[k]) and, on the
+ * other side, the field array fields[k] with row stride field_strides[k] (>= widths[k]: contiguous arrays or column views).
+ * to_message != 0: fields -> message (the groups must cover every column), else message -> fields. A workgroup moves 256
+ * message rows through LDS. n_segments > 0: the FIELD side is in [C_local][sum N] order (row map as in
+ * gsx_copy_column_groups_mapped), the message in exchange order. */
+int gsx_copy_message_columns(void *message, uint32_t message_stride, int64_t rows, uint32_t n_groups, const uint32_t *columns,
+                             const uint32_t *widths, void *const *fields, const uint32_t *field_strides, int to_message,
+                             uint32_t n_segments, const int64_t *seg_cameras_times_n, const int64_t *seg_n, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer-side ops of the training step around the rasterizer.
