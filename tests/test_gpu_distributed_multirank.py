@@ -115,3 +115,5 @@ def test_bench_two_rank_path_rehearsal():
     assert r["config"]["cameras_per_gpu"] == 4 and r["config"]["gaussians_per_gpu"] == 60000
     assert r["config"]["parallelism"] == "gaussian-sharded x2" and r["value"] > 0 and r["unit"] == "Mpixels/s"
     assert "cpu_baseline" not in r and "roofline" in r  # the CPU baseline is an N = 1 leg
+    ref = r["c4_single_gpu"]  # rank 0's single-GPU reference of the same workload, measured after the timed region
+    assert ref["value"] > 0 and "120000 synthetic Gaussians" in ref["workload"] and "rank 0" in ref["note"]
