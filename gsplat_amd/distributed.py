@@ -317,9 +317,14 @@ class _PackGeometry(torch.autograd.Function):
     def backward(ctx, _v_msg, v):
         if v is None:
             return None, None, None, None, None
-        # no copy: the projection backward reads v_means2d / v_conics through a row stride (they usually are column views
-        # of the compositing kernel's gradient rows; here they are column views of the returned gradient message)
-        return v[:, 0:2], v[:, 2].reshape(ctx.shapes[0]), v[:, 3:6], v[:, 6].reshape(ctx.shapes[1]), None
+        # v_means2d / v_conics: no copy - the projection backward reads them through a row stride (they usually are column
+        # views of the compositing kernel's gradient rows; here they are column views of the returned gradient message).
+        # The two one-column fields are consumed by torch ops (a sum over the cameras, a contiguous() in the projection
+        # op) that would each re-read the whole 28-byte rows: one kernel makes both contiguous.
+        R = v.shape[0]
+        v_dp, v_op = v.new_empty((R, 1)), v.new_empty((R, 1))
+        _copy_message(v, [2, 6], [v_dp, v_op], to_msg=False)
+        return v[:, 0:2], v_dp.reshape(ctx.shapes[0]), v[:, 3:6], v_op.reshape(ctx.shapes[1]), None
 
 
 class _UnpackGeometry(torch.autograd.Function):
