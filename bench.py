@@ -418,23 +418,30 @@ def main():
     # workload without the exchange) next to `value`; the N = 1 line's `value` is the c3 headline workload, not this one.
     scale_ref = distributed and world > 1 and workload == "c4" and not args.lean and not args.no_extra
     if extras or (scale_ref and rank == 0):
-        torch.cuda.empty_cache()
-        n4, c4n = (4_000_000, 4) if extras else (n_total, n_cams)
-        sc4, _, _ = make_workload(n4, device, n_cameras=c4n)
-        l4 = {k: sc4[k].clone().requires_grad_(True) for k in NAMES}
-        steps4 = max(3, args.steps // 4)
-        t4, m4, p4 = timed(make_step(l4, sc4, packed=False, distributed=False), steps4, 2, torch.cuda.synchronize,
-                           profile_only=("gsx_raster3d_fwd", "gsx_raster3d_bwd"))
-        result["c4_single_gpu"] = {
-            "workload": f"c4 per-rank work on one GPU: {n4} synthetic Gaussians, {c4n}x1920x1080 cameras batched, SH deg 3, "
-                        "fwd+bwd, no exchange",
-            "value": round(c4n * W * H * steps4 / t4 / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(t4 / steps4 * 1e3, 4),
-            "steps": steps4, "n_isects": int(m4["isect_ids"].numel()),
-            "raster_launch_ms": {k.replace("gsx_", ""): round(sum(v) / len(v), 4) for k, v in p4.items()},
-            "note": "N=1 point of the `--gpus N` curve (same per-GPU work at every N; ideal value at N GPUs = N x this)"
-                    + ("; measured on rank 0 of this run, after the timed region" if scale_ref else ""),
-        }
-        del sc4, l4, m4
+        def c4_single_gpu_record():
+            torch.cuda.empty_cache()
+            n4, c4n = (4_000_000, 4) if extras else (n_total, n_cams)
+            sc4, _, _ = make_workload(n4, device, n_cameras=c4n)
+            l4 = {k: sc4[k].clone().requires_grad_(True) for k in NAMES}
+            steps4 = max(3, args.steps // 4)
+            t4, m4, p4 = timed(make_step(l4, sc4, packed=False, distributed=False), steps4, 2, torch.cuda.synchronize,
+                               profile_only=("gsx_raster3d_fwd", "gsx_raster3d_bwd"))
+            return {
+                "workload": f"c4 per-rank work on one GPU: {n4} synthetic Gaussians, {c4n}x1920x1080 cameras batched, SH deg 3, "
+                            "fwd+bwd, no exchange",
+                "value": round(c4n * W * H * steps4 / t4 / 1e6, 2), "unit": "Mpixels/s",
+                "ms_per_step": round(t4 / steps4 * 1e3, 4), "steps": steps4, "n_isects": int(m4["isect_ids"].numel()),
+                "raster_launch_ms": {k.replace("gsx_", ""): round(sum(v) / len(v), 4) for k, v in p4.items()},
+                "note": "N=1 point of the `--gpus N` curve (same per-GPU work at every N; ideal value at N GPUs = N x this)"
+                        + ("; measured on rank 0 of this run, after the timed region" if scale_ref else ""),
+            }
+
+        try:
+            result["c4_single_gpu"] = c4_single_gpu_record()
+        except Exception as e:  # at N > 1 an extra must not strand the other ranks at the barrier below
+            if not scale_ref:
+                raise
+            result["c4_single_gpu"] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
     if scale_ref:
         dist.barrier()
