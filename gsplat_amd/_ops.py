@@ -66,6 +66,10 @@ def _read_compiled_ops(path: str) -> None:
     global COMPILED_OPS
     import ctypes
 
+    if os.environ.get("GSPLAT_AMD_LIB"):
+        # An A/B build of the kernel library is in use (tools/mkvariant.sh): the compiled bodies are linked against the
+        # DEFAULT libgsplat_amd.so and would silently run its kernels instead - keep every op on the ctypes path.
+        return
     try:
         fn = ctypes.CDLL(path).gsx_torch_compiled_ops
     except (OSError, AttributeError):
