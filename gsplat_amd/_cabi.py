@@ -270,6 +270,18 @@ def isect_fused_emit_workspace_bytes(n: int, n_images: int, tile_w: int, tile_h:
     return int(_lib.gsx_isect_fused_emit_workspace_bytes(n, n_images, tile_w, tile_h))
 
 
+def isect_binned_supported(rows: int, n_images: int, tile_w: int, tile_h: int, packed: bool) -> bool:
+    return bool(_lib.gsx_isect_binned_supported(rows, n_images, tile_w, tile_h, int(packed)))
+
+
+def isect_binned_count_workspace_bytes(rows: int, n_images: int, tile_w: int, tile_h: int) -> int:
+    return int(_lib.gsx_isect_binned_count_workspace_bytes(rows, n_images, tile_w, tile_h))
+
+
+def isect_binned_emit_workspace_bytes(n: int) -> int:
+    return int(_lib.gsx_isect_binned_emit_workspace_bytes(n))
+
+
 def copy_column_groups(groups, rows: int) -> None:
     """One launch of gsx_copy_column_groups. `groups`: list of (src_ptr, src_row_stride, dst_ptr, dst_row_stride, width)
     in 32-bit words (device pointers as ints)."""

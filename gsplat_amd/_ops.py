@@ -345,10 +345,67 @@ def _scan_i32(x: Tensor) -> Tensor:
     return out
 
 
+def _isect_fused_count(st, tile_mask):
+    """Count half of the fused intersection through the C-ABI: the tile-owner-major path (csrc/isect_binned.hip) when
+    st.binned, else the Gaussian-major one (csrc/isect_fused.hip). The grand total is written by the last kernel straight
+    into the pinned host word st.host_total (no copy kernel)."""
+    means2d, radii, depths, conics, opacities, _ = st.args
+    tile_size, tile_width, tile_height = st.geom[:3]
+    dev = means2d.device
+    tpg = None if st.tiles_per_gauss is None else ptr(st.tiles_per_gauss)
+    if st.binned:
+        st.count_ws = torch.empty(_cabi.isect_binned_count_workspace_bytes(st.rows, st.I, tile_width, tile_height), device=dev,
+                                  dtype=torch.uint8)
+        call("gsx_isect_binned_count", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), ptr(tile_mask),
+             st.rows, st.I, tile_size, tile_width, tile_height, tpg, ptr(st.offsets), _cabi.ptr_host(st.host_total),
+             ptr(st.count_ws), st.count_ws.numel())
+    else:
+        st.count_ws = torch.empty(_cabi.isect_fused_count_workspace_bytes(st.rows, st.I, tile_width, tile_height), device=dev,
+                                  dtype=torch.uint8)
+        call("gsx_isect_fused_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), ptr(tile_mask), st.rows, st.I,
+             tile_size, tile_width, tile_height, tpg, ptr(st.offsets), _cabi.ptr_host(st.host_total), ptr(st.count_ws),
+             st.count_ws.numel())
+
+
+def _isect_fused_emit(st, tile_mask, n_isects):
+    """Emit + sort half (after the host read n_isects); returns (isect_ids, flatten_ids)."""
+    means2d, radii, depths, conics, opacities, _ = st.args
+    tile_size, tile_width, tile_height = st.geom[:3]
+    dev = means2d.device
+    isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
+    flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
+    if n_isects == 0:
+        return isect_ids, flatten_ids
+    if st.binned:
+        ws = torch.empty(_cabi.isect_binned_emit_workspace_bytes(n_isects), device=dev, dtype=torch.uint8)
+        call("gsx_isect_binned_emit_sort", st.rows, st.I, tile_size, tile_width, tile_height, ptr(st.count_ws),
+             st.count_ws.numel(), ptr(st.offsets), n_isects, ptr(isect_ids), ptr(flatten_ids), ptr(ws), ws.numel())
+    else:
+        ws = torch.empty(_cabi.isect_fused_emit_workspace_bytes(n_isects, st.I, tile_width, tile_height), device=dev,
+                         dtype=torch.uint8)
+        call("gsx_isect_fused_emit_sort", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), ptr(tile_mask),
+             st.rows, st.I, tile_size, tile_width, tile_height, ptr(st.count_ws), st.count_ws.numel(), ptr(st.offsets),
+             n_isects, ptr(isect_ids), ptr(flatten_ids), ptr(ws), ws.numel())
+    return isect_ids, flatten_ids
+
+
+def _isect_fused_total(st, tile_mask):
+    """Host sync on the count; reruns the Gaussian-major count when the binned path reports GSX_ISECT_RETRY (-2)."""
+    n_isects = int(st.host_total.item())
+    if st.binned and n_isects == -2:
+        st.binned = False
+        _isect_fused_count(st, tile_mask)
+        torch.cuda.current_stream(st.args[0].device).synchronize()
+        n_isects = int(st.host_total.item())
+    if n_isects >= 2**31:
+        raise RuntimeError(f"intersect_tile: {n_isects} intersections overflow the int32 index space")
+    return n_isects
+
+
 class _IsectPending:
     """State between the two halves of intersect_tile (see isect_begin)."""
     __slots__ = ("args", "tiles_per_gauss", "cum", "host_total", "event", "rows", "n_per", "I", "geom", "sort",
-                 "fused", "count_ws", "offsets", "n_dev")
+                 "fused", "binned", "count_ws", "offsets", "n_dev")
 
 
 def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_ids, n_images, tile_size,
@@ -395,7 +452,7 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
     st.geom = (tile_size, tile_width, tile_height, tile_bits, image_bits)
     st.tiles_per_gauss = torch.empty(out_shape, device=dev, dtype=torch.int32)
     st.cum = st.host_total = st.event = st.count_ws = st.offsets = st.n_dev = None
-    st.fused = False
+    st.fused = st.binned = False
     if rows == 0:
         return st
     # sort=True: fused path (csrc/isect_fused.hip) — per-(chunk, tile) histogram while counting, emission straight into
@@ -405,18 +462,14 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
         # compiled halves (csrc/torch_ops.cpp): same launches, ~30 us less interpreter time per step, and the count comes
         # back through a polled pinned word instead of an event
         st.tiles_per_gauss, st.offsets, st.count_ws, st.host_total = torch.ops.gsplat_amd.isect_fused_begin(
-            means2d, radii, conics, opacities, rows, I, tile_size, tile_width, tile_height, list(out_shape))
+            means2d, radii, depths, conics, opacities, rows, I, tile_size, tile_width, tile_height, list(out_shape))
         st.event = "polled"
         return st
     st.host_total = torch.empty(1, dtype=torch.int64, pin_memory=True)
     if st.fused:
-        st.count_ws = torch.empty(_cabi.isect_fused_count_workspace_bytes(rows, I, tile_width, tile_height), device=dev,
-                                  dtype=torch.uint8)
         st.offsets = torch.empty(I * tile_width * tile_height, device=dev, dtype=torch.int32)
-        # the grand total is written by the scan kernel straight into the pinned host word (no copy kernel)
-        call("gsx_isect_fused_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), None, rows, I, tile_size,
-             tile_width, tile_height, ptr(st.tiles_per_gauss), ptr(st.offsets), _cabi.ptr_host(st.host_total),
-             ptr(st.count_ws), st.count_ws.numel())
+        st.binned = _cabi.isect_binned_supported(rows, I, tile_width, tile_height, packed)
+        _isect_fused_count(st, None)
         st.event = torch.cuda.Event()
         st.event.record()
         return st
@@ -446,9 +499,13 @@ def isect_finish(st: "_IsectPending"):
     if st.event == "polled":  # compiled second half: waits for the count (the one host round trip), allocates, emits, sorts
         isect_ids, flatten_ids = torch.ops.gsplat_amd.isect_fused_finish(
             means2d, radii, depths, conics, opacities, rows, I, tile_size, tile_width, tile_height, st.count_ws, st.offsets,
-            st.host_total)
+            st.host_total, tiles_per_gauss)
         return tiles_per_gauss, isect_ids, flatten_ids
     st.event.synchronize()  # host sync: exact-length outputs (reference: Intersect.cpp:258-259)
+    if st.fused:
+        n_isects = _isect_fused_total(st, None)
+        isect_ids, flatten_ids = _isect_fused_emit(st, None, n_isects)
+        return tiles_per_gauss, isect_ids, flatten_ids
     n_isects = int(st.host_total.item())
     cum = st.cum
     if n_isects >= 2**31:
@@ -456,13 +513,6 @@ def isect_finish(st: "_IsectPending"):
     isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
     if n_isects == 0:
-        return tiles_per_gauss, isect_ids, flatten_ids
-    if st.fused:
-        ws = torch.empty(_cabi.isect_fused_emit_workspace_bytes(n_isects, I, tile_width, tile_height), device=dev,
-                         dtype=torch.uint8)
-        call("gsx_isect_fused_emit_sort", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), None, rows,
-             I, tile_size, tile_width, tile_height, ptr(st.count_ws), st.count_ws.numel(), ptr(st.offsets), n_isects,
-             ptr(isect_ids), ptr(flatten_ids), ptr(ws), ws.numel())
         return tiles_per_gauss, isect_ids, flatten_ids
     if means2d.dtype == torch.float64:
         call("gsx_isect_emit_f64", ptr(means2d), ptr(radii), ptr(depths), ptr(image_ids), ptr(cum), rows, n_per, I,
@@ -1124,24 +1174,19 @@ def intersect_tile_sparse(means2d, radii, depths, image_ids, tile_mask, active_t
         # the dense fused path with the tile mask applied inside the walk (AABB test: conics / opacities NULL, as the
         # reference's sparse enumeration, Intersect.cpp:617-634): inactive tiles get empty segments, so the dense
         # offsets of the active tiles ARE the compacted offsets
-        count_ws = torch.empty(_cabi.isect_fused_count_workspace_bytes(rows, I, tile_width, tile_height), device=dev,
-                               dtype=torch.uint8)
-        offsets = torch.empty(I * n_tiles, device=dev, dtype=torch.int32)
-        n_dev = torch.empty(1, device=dev, dtype=torch.int64)
-        call("gsx_isect_fused_count", ptr(means2d), ptr(radii), None, None, ptr(tile_mask), rows, I, tile_size, tile_width,
-             tile_height, None, ptr(offsets), ptr(n_dev), ptr(count_ws), count_ws.numel())
-        n_isects = int(n_dev.item())  # host sync: exact-length outputs (reference: Intersect.cpp:637)
-        if n_isects >= 2**31:
-            raise RuntimeError(f"intersect_tile_sparse: {n_isects} intersections overflow the int32 index space")
+        st = _IsectPending()
+        st.args = (means2d, radii, depths, None, None, None)
+        st.rows, st.I, st.geom = rows, I, (tile_size, tile_width, tile_height)
+        st.tiles_per_gauss = None
+        st.offsets = offsets = torch.empty(I * n_tiles, device=dev, dtype=torch.int32)
+        st.host_total = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        st.binned = _cabi.isect_binned_supported(rows, I, tile_width, tile_height, packed)
+        _isect_fused_count(st, tile_mask)
+        torch.cuda.current_stream(dev).synchronize()  # host sync: exact-length outputs (reference: Intersect.cpp:637)
+        n_isects = _isect_fused_total(st, tile_mask)
         if n_isects == 0:
             return empty
-        isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
-        flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
-        ws = torch.empty(_cabi.isect_fused_emit_workspace_bytes(n_isects, I, tile_width, tile_height), device=dev,
-                         dtype=torch.uint8)
-        call("gsx_isect_fused_emit_sort", ptr(means2d), ptr(radii), ptr(depths), None, None, ptr(tile_mask), rows, I,
-             tile_size, tile_width, tile_height, ptr(count_ws), count_ws.numel(), ptr(offsets), n_isects, ptr(isect_ids),
-             ptr(flatten_ids), ptr(ws), ws.numel())
+        isect_ids, flatten_ids = _isect_fused_emit(st, tile_mask, n_isects)
         return torch.cat([offsets[active_tiles.long()], sentinel(n_isects)]), flatten_ids
     # packed rows of several images / tile grids beyond the fused path's LDS histogram: enumerate every tile with the
     # generic kernels, then drop the intersections of inactive tiles (order within a tile is preserved)

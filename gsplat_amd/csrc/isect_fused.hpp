@@ -48,7 +48,25 @@ inline FusedGeom fused_geometry(int64_t rows, uint32_t n_images, uint32_t tile_s
     return g;
 }
 
+struct TileSortArgs {
+    const uint64_t *keys_in;
+    const int32_t *vals_in;
+    int64_t n;
+    uint32_t n_tiles, tile_bits, n_bins, n_chunks;
+    int64_t chunk_len;
+    int32_t *table;        // [n_bins][n_chunks] histogram, then exclusive scan (in place via table_scanned)
+    int32_t *table_scanned;
+    uint2 *bucketed;       // [n] (depth bits, flatten id) grouped by bin
+    uint64_t *keys_out;
+    int32_t *vals_out;
+    uint2 *scratch;        // [n] ping-pong for oversized tiles
+    int32_t *big_count;    // number of tiles longer than kCapSmall (filled by the MODE 0 launch)
+    int32_t *big_list;     // [n_bins] their bin ids
+};
+
 int launch_fused_count_hist(const FusedArgs &a, hipStream_t s);
 int launch_fused_emit_scatter(const FusedArgs &a, hipStream_t s);
+int launch_colscan(int32_t *table, int32_t *totals, uint32_t n_cols, uint32_t cpi, uint32_t n_images, hipStream_t s);
+int launch_big_tile_sort(const TileSortArgs &a, hipStream_t s); // tiles listed in a.big_list[0 .. *a.big_count)
 
 } // namespace gsx

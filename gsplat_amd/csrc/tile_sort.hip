@@ -33,21 +33,7 @@ constexpr uint32_t kMaxBins = 36864; // LDS histogram: 144 KiB of the 160 KiB
 constexpr int kCapSmall    = 2048;  // entries sorted in 32 KiB-class LDS
 constexpr int kCapLarge    = 9216;  // entries sorted with (almost) the whole LDS
 
-struct TileSortArgs {
-    const uint64_t *keys_in;
-    const int32_t *vals_in;
-    int64_t n;
-    uint32_t n_tiles, tile_bits, n_bins, n_chunks;
-    int64_t chunk_len;
-    int32_t *table;        // [n_bins][n_chunks] histogram, then exclusive scan (in place via table_scanned)
-    int32_t *table_scanned;
-    uint2 *bucketed;       // [n] (depth bits, flatten id) grouped by bin
-    uint64_t *keys_out;
-    int32_t *vals_out;
-    uint2 *scratch;        // [n] ping-pong for oversized tiles
-    int32_t *big_count;    // number of tiles longer than kCapSmall (filled by the MODE 0 launch)
-    int32_t *big_list;     // [n_bins] their bin ids
-};
+// struct TileSortArgs: isect_fused.hpp (shared with isect_binned.hip)
 
 __device__ __forceinline__ uint32_t key_bin(uint64_t key, uint32_t n_tiles, uint32_t tile_bits)
 {
@@ -457,6 +443,23 @@ __global__ void __launch_bounds__(1024) fused_totals_scan_kernel(const int32_t *
         run += totals[b];
     }
     if (threadIdx.x == 1023) *n_isects = s_part[1023];
+}
+
+// shared with isect_binned.hip: the same column scan over a [chunk][bin] table, and the work-list sort of oversized tiles
+int launch_colscan(int32_t *table, int32_t *totals, uint32_t n_cols, uint32_t cpi, uint32_t n_images, hipStream_t s)
+{
+    const uint32_t groups = (n_cols + kCsTiles - 1) / kCsTiles;
+    fused_colscan_kernel<<<dim3(groups * n_images), dim3(kCsTiles * kCsSegs), 0, s>>>(table, totals, n_cols, cpi, groups);
+    return check_launch("isect colscan");
+}
+int launch_big_tile_sort(const TileSortArgs &a, hipStream_t s)
+{
+    static PerDeviceOnce once;
+    if (once.first())
+        (void)hipFuncSetAttribute((const void *)tile_sort_kernel<kCapLarge, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(2 * kCapLarge * sizeof(uint2)));
+    tile_sort_kernel<kCapLarge, 1><<<dim3(256), dim3(kTsThreads), 2 * kCapLarge * sizeof(uint2), s>>>(a);
+    return check_launch("isect big tile sort");
 }
 
 static int64_t fused_count_ws_bytes(const FusedGeom &g)

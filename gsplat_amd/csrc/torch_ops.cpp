@@ -435,14 +435,35 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
     Tensor host_total = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
     auto hip_stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means2d.device().index());
     if (sort && !f64 && gsx_isect_fused_supported(uI, utw, uth, packed ? 1 : 0)) {
-        Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
         Tensor offsets = at::empty({I * tile_w * tile_h}, means2d.options().dtype(at::kInt));
+        int64_t M = GSX_ISECT_RETRY;
+        if (gsx_isect_binned_supported(rows, uI, utw, uth, packed ? 1 : 0)) {
+            // tile-owner-major path (csrc/isect_binned.hip); GSX_ISECT_RETRY = its entry workspace was too small
+            Tensor count_ws = bytes(gsx_isect_binned_count_workspace_bytes(rows, uI, utw, uth), means2d);
+            { Timed timed_("gsx_isect_binned_count", L.stream); check(gsx_isect_binned_count(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI,
+                                         uts, utw, uth, mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets),
+                                         host_total.mutable_data_ptr<int64_t>(), count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
+                  "gsx_isect_binned_count"); }
+            hip_stream.synchronize();
+            M = *host_total.const_data_ptr<int64_t>();
+            if (M != GSX_ISECT_RETRY) {
+                TORCH_CHECK(M < (1ll << 31), "intersect_tile: ", M, " intersections overflow the int32 index space");
+                Tensor ids = at::empty({M}, means2d.options().dtype(at::kLong)), flat = at::empty({M}, means2d.options().dtype(at::kInt));
+                if (M == 0) return {tiles_per_gauss, ids, flat};
+                Tensor ws = bytes(gsx_isect_binned_emit_workspace_bytes(M), means2d);
+                { Timed timed_("gsx_isect_binned_emit_sort", L.stream); check(gsx_isect_binned_emit_sort(rows, uI, uts, utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(),
+                                                 cp<int32_t>(offsets), M, mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
+                      "gsx_isect_binned_emit_sort"); }
+                return {tiles_per_gauss, ids, flat};
+            }
+        }
+        Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
         { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
                                     mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(),
                                     count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
               "gsx_isect_fused_count"); }
         hip_stream.synchronize();
-        const int64_t M = *host_total.const_data_ptr<int64_t>();
+        M = *host_total.const_data_ptr<int64_t>();
         TORCH_CHECK(M < (1ll << 31), "intersect_tile: ", M, " intersections overflow the int32 index space");
         Tensor ids = at::empty({M}, means2d.options().dtype(at::kLong)), flat = at::empty({M}, means2d.options().dtype(at::kInt));
         if (M == 0) return {tiles_per_gauss, ids, flat};
@@ -600,16 +621,24 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
 // (namespace gsplat_amd: not part of the reference's surface). The count travels through a pinned host word initialised to a
 // sentinel: the second half polls it - no event, no stream synchronisation, and the kernels enqueued in between keep running.
 std::tuple<Tensor, Tensor, Tensor, Tensor>
-isect_fused_begin(const Tensor &means2d, const Tensor &radii, const OptTensor &conics, const OptTensor &opac, int64_t rows,
-                  int64_t I, int64_t tile_size, int64_t tile_w, int64_t tile_h, c10::IntArrayRef out_shape)
+isect_fused_begin(const Tensor &means2d, const Tensor &radii, const Tensor &depths, const OptTensor &conics, const OptTensor &opac,
+                  int64_t rows, int64_t I, int64_t tile_size, int64_t tile_w, int64_t tile_h, c10::IntArrayRef out_shape)
 {
     Launch L(means2d);
     const uint32_t uI = (uint32_t)I, uts = (uint32_t)tile_size, utw = (uint32_t)tile_w, uth = (uint32_t)tile_h;
     Tensor tiles_per_gauss = at::empty(out_shape, means2d.options().dtype(at::kInt));
     Tensor host_total = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
     *host_total.mutable_data_ptr<int64_t>() = -1;
-    Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
     Tensor offsets = at::empty({I * tile_w * tile_h}, means2d.options().dtype(at::kInt));
+    if (gsx_isect_binned_supported(rows, uI, utw, uth, 0)) { // tile-owner-major path (csrc/isect_binned.hip)
+        Tensor count_ws = bytes(gsx_isect_binned_count_workspace_bytes(rows, uI, utw, uth), means2d);
+        { Timed timed_("gsx_isect_binned_count", L.stream); check(gsx_isect_binned_count(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI, uts,
+                                     utw, uth, mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(),
+                                     count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
+              "gsx_isect_binned_count"); }
+        return {tiles_per_gauss, offsets, count_ws, host_total};
+    }
+    Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
     { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
                                 mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(),
                                 count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
@@ -620,28 +649,48 @@ isect_fused_begin(const Tensor &means2d, const Tensor &radii, const OptTensor &c
 std::tuple<Tensor, Tensor>
 isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &depths, const OptTensor &conics, const OptTensor &opac,
                    int64_t rows, int64_t I, int64_t tile_size, int64_t tile_w, int64_t tile_h, Tensor count_ws,
-                   const Tensor &offsets, const Tensor &host_total)
+                   const Tensor &offsets, const Tensor &host_total, Tensor tiles_per_gauss)
 {
     Launch L(means2d);
     const uint32_t uI = (uint32_t)I, uts = (uint32_t)tile_size, utw = (uint32_t)tile_w, uth = (uint32_t)tile_h;
     volatile const int64_t *slot = host_total.const_data_ptr<int64_t>();
+    auto hip_stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means2d.device().index());
     int64_t M = -1;
     {
         const auto t0 = std::chrono::steady_clock::now();
         for (uint64_t spin = 0;; ++spin) {
             M = *slot;
-            if (M >= 0) break;
+            if (M != -1) break;
             if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
-                c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means2d.device().index()).synchronize();
+                hip_stream.synchronize();
                 M = *slot;
                 break;
             }
         }
     }
+    bool binned = gsx_isect_binned_supported(rows, uI, utw, uth, 0) != 0;
+    if (binned && M == GSX_ISECT_RETRY) {
+        // the binned path's entry workspace was too small for this scene (very large Gaussians): count again Gaussian-major
+        binned   = false;
+        count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
+        { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
+                                    mp<int32_t>(tiles_per_gauss), offsets.mutable_data_ptr<int32_t>(),
+                                    host_total.mutable_data_ptr<int64_t>(), count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
+              "gsx_isect_fused_count"); }
+        hip_stream.synchronize();
+        M = *slot;
+    }
     TORCH_CHECK(M >= 0, "intersect_tile: the intersection count never reached the host");
     TORCH_CHECK(M < (1ll << 31), "intersect_tile: ", M, " intersections overflow the int32 index space");
     Tensor ids = at::empty({M}, means2d.options().dtype(at::kLong)), flat = at::empty({M}, means2d.options().dtype(at::kInt));
     if (M == 0) return {ids, flat};
+    if (binned) {
+        Tensor ws = bytes(gsx_isect_binned_emit_workspace_bytes(M), means2d);
+        { Timed timed_("gsx_isect_binned_emit_sort", L.stream); check(gsx_isect_binned_emit_sort(rows, uI, uts, utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(),
+                                         cp<int32_t>(offsets), M, mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
+              "gsx_isect_binned_emit_sort"); }
+        return {ids, flat};
+    }
     Tensor ws = bytes(gsx_isect_fused_emit_workspace_bytes(M, uI, utw, uth), means2d);
     { Timed timed_("gsx_isect_fused_emit_sort", L.stream); check(gsx_isect_fused_emit_sort(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI, uts,
                                     utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(), cp<int32_t>(offsets), M,
@@ -729,10 +778,10 @@ rasterize_to_pixels_2dgs(const Tensor &means2d_, const Tensor &ray_transforms_, 
 
 TORCH_LIBRARY(gsplat_amd, m)
 {
-    m.def("isect_fused_begin(Tensor means2d, Tensor radii, Tensor? conics, Tensor? opacities, int rows, int n_images, int tile_size, "
+    m.def("isect_fused_begin(Tensor means2d, Tensor radii, Tensor depths, Tensor? conics, Tensor? opacities, int rows, int n_images, int tile_size, "
           "int tile_w, int tile_h, int[] out_shape) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("isect_fused_finish(Tensor means2d, Tensor radii, Tensor depths, Tensor? conics, Tensor? opacities, int rows, int n_images, "
-          "int tile_size, int tile_w, int tile_h, Tensor count_ws, Tensor offsets, Tensor host_total) -> (Tensor, Tensor)");
+          "int tile_size, int tile_w, int tile_h, Tensor count_ws, Tensor offsets, Tensor host_total, Tensor tiles_per_gauss) -> (Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(gsplat_amd, CUDA, m)

@@ -311,6 +311,33 @@ int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *radii, const 
                               int32_t *flatten_ids_sorted, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Binned isect_tiles(sort=True) + isect_offset_encode (csrc/isect_binned.hip): the same outputs as the fused pair above,
+ * bit for bit (= gsplat::intersect_tile with sort + gsplat::intersect_offset: ext.cpp:1022-1027; Intersect.cpp:170-329;
+ * IntersectTile.cu:214-464, 925-988, 1078-1121), built tile-owner-major: the screen is cut into bins of 4 x 4 tiles, every
+ * row is entered once per bin its tile rectangle overlaps, the exact walk runs clipped to the bin and yields a 16-bit tile
+ * mask per entry, and ONE workgroup per bin (or run of a bin's tiles) gathers its entries, sorts them once by (depth, row)
+ * in LDS, splits the sorted run into the tile lists and writes keys and row ids contiguously. No scattered stores, no
+ * intermediate pair array, no per-chunk tile table. Dense rows [n_images * N] or packed rows of ONE image.
+ *   1. gsx_isect_binned_count (needs depths already): tiles_per_gauss int32 [rows] (or NULL), isect_offsets int32
+ *      [n_images * tiles], *n_isects (device or pinned host memory). *n_isects == GSX_ISECT_RETRY (-2): the entries did
+ *      not fit the workspace (a scene of very large Gaussians) - nothing else was written, run gsx_isect_fused_* instead.
+ *   2. gsx_isect_binned_emit_sort with the SAME count workspace (untouched in between).
+ * ------------------------------------------------------------------------------------------- */
+#define GSX_ISECT_RETRY (-2)
+int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed);
+int64_t gsx_isect_binned_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
+int64_t gsx_isect_binned_emit_workspace_bytes(int64_t n_isects);
+int gsx_isect_binned_count(const float *means2d, const int32_t *radii, const float *depths, const float *conics,
+                           const float *opacities, const uint8_t *tile_mask, int64_t rows, uint32_t n_images,
+                           uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int32_t *tiles_per_gauss,
+                           int32_t *isect_offsets, int64_t *n_isects, void *count_workspace,
+                           int64_t count_workspace_bytes, void *stream);
+int gsx_isect_binned_emit_sort(int64_t rows, uint32_t n_images, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                               void *count_workspace, int64_t count_workspace_bytes, const int32_t *isect_offsets,
+                               int64_t n_isects, int64_t *isect_ids_sorted, int32_t *flatten_ids_sorted, void *workspace,
+                               int64_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * rasterize_to_pixels (3DGS): gsplat::rasterize_to_pixels_3dgs{,_bwd} (ext.cpp:1079-1089; host
  * Rasterization.cpp:275-365, 484-587; kernels RasterizeToPixels3DGSSerialBatch{Fwd,Bwd}.cu).
  * Any channel count >= 1 (chunked by 32 internally); tile_size in [1,16].
