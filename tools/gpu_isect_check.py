@@ -128,9 +128,8 @@ def bench_all(c4):
     C = sc["viewmats"].shape[0]
     tw, th = (W + 15) // 16, (H + 15) // 16
     variants = [("legacy", {"GSX_ISECT_LEGACY": "1"})]
-    for b in ("4x4", "4x2", "2x2", "8x2"):
-        for cap in ("4096", "2048"):
-            variants.append((f"bin{b}_cap{cap}", {"GSX_ISECT_BIN": b, "GSX_ISECT_CAP": cap}))
+    for b in ("4x4", "4x2", "2x2", "8x2", "2x4"):
+        variants.append((f"bin{b}", {"GSX_ISECT_BIN": b}))
     for name, env in variants:
         for k in ("GSX_ISECT_LEGACY", "GSX_ISECT_BIN", "GSX_ISECT_CAP"):
             os.environ.pop(k, None)

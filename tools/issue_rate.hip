@@ -15,11 +15,13 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum Op { FMA, PK_FMA, MUL, ADD, CNDMASK, EXP, RCP, MAD_U32_U24, ADD_U32, LSHL_ADD, CMP_BALLOT, DS_ADD_F32, DS_ADD_F32_SAME, DS_READ_B64, DS_READ_B128, DS_WRITE_B64, S_ADD, S_AND_B64, MIX_V_S, DPP_ADD, READLANE, N_OPS };
+enum Op { FMA, PK_FMA, MUL, ADD, CNDMASK, EXP, RCP, MAD_U32_U24, ADD_U32, LSHL_ADD, CMP_BALLOT, DS_ADD_F32, DS_ADD_F32_SAME, DS_READ_B64, DS_READ_B128, DS_WRITE_B64, S_ADD, S_AND_B64, MIX_V_S, DPP_ADD, READLANE, CNDMASK_SGPR, CMP_E64, CMP_CNDMASK, DS_ADD_U32, DS_ADD_RTN_U32, DS_BPERMUTE, PERMLANE32_SWAP, GLOBAL_ATOMIC_ADD, N_OPS };
 static const char *kNames[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_add_f32", "v_cndmask_b32", "v_exp_f32", "v_rcp_f32",
                                     "v_mad_u32_u24", "v_add_u32", "v_lshl_add_u32", "v_cmp+s_and(ballot)", "ds_add_f32(distinct)",
                                     "ds_add_f32(same addr)", "ds_read_b64", "ds_read_b128", "ds_write_b64", "s_add_u32", "s_and_b64",
-                                    "v_fma_f32+s_add_u32", "v_add_f32_dpp", "v_readlane_b32"};
+                                    "v_fma_f32+s_add_u32", "v_add_f32_dpp", "v_readlane_b32", "v_cndmask_b32_e64(sgpr pair)", "v_cmp_lt_f32_e64->sgpr",
+                                    "v_cmp(vcc)+v_cndmask(vcc)", "ds_add_u32(distinct)", "ds_add_rtn_u32(distinct)", "ds_bpermute_b32", "v_permlane32_swap_b32",
+                                    "global_atomic_add_u32(no return, distinct dwords)"};
 
 // One asm statement holds the whole 64-instruction block: the compiler cannot see into it, so it neither reorders it nor
 // pads it with s_nop (it does pad BETWEEN separate asm statements, which would be measured as issue slots).
@@ -57,11 +59,19 @@ static const char *kNames[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v
 #define I_MIX(r) "v_fma_f32 %" #r ", %" #r ", %8, %9\n s_add_u32 %10, %10, 1\n"
 #define I_DPP(r) "v_add_f32_dpp %" #r ", %" #r ", %" #r " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
 #define I_RDL(r) "v_readlane_b32 %10, %" #r ", 3\n"
+#define I_CNDS(r) "v_cndmask_b32_e64 %" #r ", %" #r ", %8, %10\n"
+#define I_CMP64(r) "v_cmp_lt_f32_e64 %10, %" #r ", %8\n"
+#define I_CMPCND(r) "v_cmp_lt_f32 vcc, %" #r ", %8\n v_cndmask_b32 %" #r ", %" #r ", %9, vcc\n"
+#define I_DSADDU(r) "ds_add_u32 %10, %9\n"
+#define I_DSADDRTN(r) "ds_add_rtn_u32 %" #r ", %10, %9\n"
+#define I_BPERM(r) "ds_bpermute_b32 %" #r ", %10, %" #r "\n"
+#define I_PL32(r) "v_permlane32_swap_b32 %" #r ", %8\n"
+#define I_GATOM(r) "global_atomic_add %10, %9, off\n"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <int OP, bool DEP>
-__global__ void __launch_bounds__(1024) rate_kernel(int iters, uint64_t *cycles, uint64_t *real, float *sink)
+__global__ void __launch_bounds__(1024) rate_kernel(int iters, uint64_t *cycles, uint64_t *real, float *sink, uint32_t *gbuf)
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
@@ -79,6 +89,8 @@ __global__ void __launch_bounds__(1024) rate_kernel(int iters, uint64_t *cycles,
     uint32_t saddr = (OP == DS_ADD_F32_SAME) ? 0u : (uint32_t)(threadIdx.x * 16u);
     uint32_t s0 = 1, s1 = 2;
     uint64_t sm = ~0ull;
+    uint32_t *gaddr = gbuf + (size_t)blockIdx.x * 1024 + threadIdx.x; // one dword per lane: a wave adds into 2 cache lines
+    asm volatile("s_mov_b64 vcc, exec" ::: "vcc");
     lds[threadIdx.x * 4] = 0.f; lds[threadIdx.x * 4 + 1] = 0.f; lds[threadIdx.x * 4 + 2] = 0.f; lds[threadIdx.x * 4 + 3] = 0.f;
     __syncthreads();
     const uint64_t t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
@@ -103,6 +115,14 @@ __global__ void __launch_bounds__(1024) rate_kernel(int iters, uint64_t *cycles,
         if (OP == MIX_V_S) { if (DEP) asm volatile(DEP64(I_MIX) : VREGS, "+v"(a), "+v"(b), "+s"(s0) : : "scc"); else asm volatile(IND64(I_MIX) : VREGS, "+v"(a), "+v"(b), "+s"(s0) : : "scc"); }
         if (OP == DPP_ADD) BLOCK(I_DPP, VREGS, "v"(a), "v"(b));
         if (OP == READLANE) asm volatile(IND64(I_RDL) : UREGS, "+v"(a), "+v"(b), "+s"(s0) : : );
+        if (OP == CNDMASK_SGPR) { if (DEP) asm volatile(DEP64(I_CNDS) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : ); else asm volatile(IND64(I_CNDS) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : ); }
+        if (OP == CMP_E64) asm volatile(IND64(I_CMP64) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : );
+        if (OP == CMP_CNDMASK) { if (DEP) asm volatile(DEP64(I_CMPCND) : VREGS, "+v"(a), "+v"(b) : : "vcc"); else asm volatile(IND64(I_CMPCND) : VREGS, "+v"(a), "+v"(b) : : "vcc"); }
+        if (OP == DS_ADD_U32) asm volatile(DEP64(I_DSADDU) "s_waitcnt lgkmcnt(0)\n" : UREGS, "+v"(a), "+v"(c), "+v"(saddr) : : "memory");
+        if (OP == DS_ADD_RTN_U32) asm volatile(IND64(I_DSADDRTN) "s_waitcnt lgkmcnt(0)\n" : UREGS, "+v"(a), "+v"(c), "+v"(saddr) : : "memory");
+        if (OP == DS_BPERMUTE) asm volatile(IND64(I_BPERM) "s_waitcnt lgkmcnt(0)\n" : UREGS, "+v"(a), "+v"(c), "+v"(saddr) : : "memory");
+        if (OP == PERMLANE32_SWAP) { if (DEP) asm volatile(DEP64(I_PL32) : UREGS, "+v"(c) : : ); else asm volatile(IND64(I_PL32) : UREGS, "+v"(c) : : ); }
+        if (OP == GLOBAL_ATOMIC_ADD) asm volatile(DEP64(I_GATOM) "s_waitcnt vmcnt(0)\n" : UREGS, "+v"(a), "+v"(c), "+v"(gaddr) : : "memory");
     }
     const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
     float acc = a + b + (float)c;
@@ -122,18 +142,23 @@ static void run_op(std::string &out, bool &first)
     const int n_cu = 256;
     uint64_t *cyc, *real;
     float *sink;
-    hipMalloc(&cyc, n_cu * 16 * 8); hipMalloc(&real, n_cu * 16 * 8); hipMalloc(&sink, 64);
-    const bool lds_op = OP == DS_ADD_F32 || OP == DS_ADD_F32_SAME || OP == DS_READ_B64 || OP == DS_READ_B128 || OP == DS_WRITE_B64;
+    uint32_t *gbuf;
+    hipMalloc(&cyc, n_cu * 32 * 8); hipMalloc(&real, n_cu * 32 * 8); hipMalloc(&sink, 64); hipMalloc(&gbuf, 512 * 1024 * 4);
+    hipMemset(gbuf, 0, 512 * 1024 * 4);
+    const bool lds_op = OP == DS_ADD_F32 || OP == DS_ADD_F32_SAME || OP == DS_READ_B64 || OP == DS_READ_B128 || OP == DS_WRITE_B64
+                        || OP == DS_ADD_U32 || OP == DS_ADD_RTN_U32 || OP == DS_BPERMUTE || OP == GLOBAL_ATOMIC_ADD;
     const int iters = (OP == EXP || OP == RCP || lds_op) ? 2000 : 8000;
     for (int dep = 1; dep >= 0; --dep) {
-        if (!dep && (OP == DS_ADD_F32 || OP == DS_ADD_F32_SAME || OP == S_AND_B64 || OP == CMP_BALLOT)) continue;
-        if (dep && (OP == READLANE || OP == DS_WRITE_B64)) continue;
-        for (int w : {1, 2, 4}) { // waves per SIMD; block = 256 * w threads, one block per CU (LDS-limited)
-            const int threads = 256 * w;
+        if (!dep && (OP == DS_ADD_F32 || OP == DS_ADD_F32_SAME || OP == S_AND_B64 || OP == CMP_BALLOT || OP == DS_ADD_U32 || OP == GLOBAL_ATOMIC_ADD)) continue;
+        if (dep && (OP == READLANE || OP == DS_WRITE_B64 || OP == CMP_E64 || OP == DS_ADD_RTN_U32 || OP == DS_BPERMUTE)) continue;
+        for (int w : {1, 2, 4, 8}) { // waves per SIMD; one block per CU (LDS-limited), two blocks of 1024 threads for w = 8
+            const int blocks_per_cu = w == 8 ? 2 : 1;
+            const int threads = 256 * (w / blocks_per_cu);
+            const size_t lds = blocks_per_cu == 2 ? 72 * 1024 : 128 * 1024;
             auto k = dep ? rate_kernel<OP, true> : rate_kernel<OP, false>;
             hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            hipLaunchKernelGGL(k, dim3(n_cu), dim3(threads), 128 * 1024, 0, 50, cyc, real, sink); // warm-up
-            hipLaunchKernelGGL(k, dim3(n_cu), dim3(threads), 128 * 1024, 0, iters, cyc, real, sink);
+            hipLaunchKernelGGL(k, dim3(n_cu * blocks_per_cu), dim3(threads), lds, 0, 50, cyc, real, sink, gbuf); // warm-up
+            hipLaunchKernelGGL(k, dim3(n_cu * blocks_per_cu), dim3(threads), lds, 0, iters, cyc, real, sink, gbuf);
             hipDeviceSynchronize();
             const int n_waves = n_cu * 4 * w;
             std::vector<uint64_t> hc(n_waves), hr(n_waves);
@@ -142,7 +167,7 @@ static void run_op(std::string &out, bool &first)
             double mc = 0, mr = 0;
             for (int i = 0; i < n_waves; ++i) { mc += (double)hc[i]; mr += (double)hr[i]; }
             mc /= n_waves; mr /= n_waves;
-            const double instr = (double)iters * 64 * ((OP == MIX_V_S || OP == CMP_BALLOT || (OP == S_ADD && !dep)) ? 2 : 1);
+            const double instr = (double)iters * 64 * ((OP == MIX_V_S || OP == CMP_BALLOT || OP == CMP_CNDMASK || (OP == S_ADD && !dep)) ? 2 : 1);
             const double ns = mr * 10.0; // 100 MHz real-time counter
             char buf[512];
             snprintf(buf, sizeof buf,
@@ -153,7 +178,7 @@ static void run_op(std::string &out, bool &first)
             out += buf;
         }
     }
-    hipFree(cyc); hipFree(real); hipFree(sink);
+    hipFree(cyc); hipFree(real); hipFree(sink); hipFree(gbuf);
 }
 
 template <int OP>
