@@ -38,8 +38,6 @@ namespace gsx {
 constexpr int kBnThreads      = 256;
 constexpr int kBnMaxBins      = 16384; // bins in total (images x bins per image)
 constexpr uint32_t kBnMaxTiles = 36864;
-constexpr int kWaveCap        = 1024;  // tile entries one wave sorts on its own
-constexpr int kGroupCap       = 4096;  // ... the four waves of a workgroup together (same LDS)
 
 struct BinHeader { // device memory
     int32_t overflow, n_entries, big_count, pad[5];
@@ -235,9 +233,37 @@ __global__ void __launch_bounds__(1024) bin_plan_kernel(const BinArgs a)
 }
 
 // ---- D: entries (depth, row | mask) grouped by bin ----------------------------------------------------------------------
+// A row's cost is the number of bins and tiles it covers, and a wave pays for its most expensive lane: with one row per lane a
+// single near Gaussian (hundreds of tiles) stalls 63 lanes. So only rows inside ONE bin (at most bw x bh tiles) are walked by
+// the thread that loaded them; a row over several bins parks its nine input words in LDS and pushes one (row, bin) pair per
+// bin on an LDS queue, and the workgroup then shares the pairs out evenly: every unit of work is one walk clipped to one bin.
+constexpr int kDRows = 2 * kBnThreads; // rows per iteration
+constexpr int kDQueue = 4096;          // (row, bin) pairs per iteration; a row that does not fit is walked by its own thread
+
+__device__ __forceinline__ uint32_t bn_entry(const BinArgs &a, const WalkPrep &p, uint32_t bx, uint32_t by, const uint8_t *tmask,
+                                            uint32_t dbits, int64_t r, int32_t *s_cur)
+{
+    const BinGeom &g = a.g;
+    const int cx0 = (int)(bx * g.bw), cy0 = (int)(by * g.bh);
+    const int cx1 = min(cx0 + (int)g.bw, (int)g.tile_w), cy1 = min(cy0 + (int)g.bh, (int)g.tile_h);
+    uint32_t mask = 0;
+    walk_clipped(p, g.tile_size, cx0, cy0, cx1, cy1, [&](int x, int y) {
+        if (tmask && !tmask[(size_t)y * g.tile_w + x]) return;
+        mask |= 1u << ((y - cy0) * (int)g.bw + (x - cx0));
+    });
+    const int32_t slot = atomicAdd(&s_cur[by * g.bins_x + bx], 1);
+    a.b.e_pair[slot]   = make_uint2(dbits, (uint32_t)r);
+    a.b.e_mask[slot]   = (uint16_t)mask;
+    return (uint32_t)__popc(mask);
+}
+
 __global__ void __launch_bounds__(kBnThreads) bin_scatter_kernel(const BinArgs a)
 {
     extern __shared__ int32_t s_cur[];
+    __shared__ uint32_t s_q[kDQueue];
+    __shared__ float s_row[kDRows][9];
+    __shared__ int32_t s_tpg[kDRows];
+    __shared__ int32_t s_qn, s_qlim;
     const BinGeom &g = a.g;
     if (a.b.hdr->overflow) return;
     int64_t lo, hi;
@@ -246,11 +272,11 @@ __global__ void __launch_bounds__(kBnThreads) bin_scatter_kernel(const BinArgs a
     const int32_t *pre   = a.b.table + (int64_t)blockIdx.x * g.n_bins; // exclusive prefix over this image's chunks
     const int32_t *start = a.b.bin_start + (int64_t)img * g.n_bins;
     for (uint32_t i = threadIdx.x; i < g.n_bins; i += kBnThreads) s_cur[i] = start[i] + pre[i];
-    __syncthreads();
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)img * g.n_tiles : nullptr;
-    constexpr int kU = 4;
-    for (int64_t base = lo; base < hi; base += kBnThreads * kU) {
+    constexpr int kU = kDRows / kBnThreads;
+    for (int64_t base = lo; base < hi; base += kDRows) {
+        if (threadIdx.x == 0) { s_qn = 0; s_qlim = kDQueue; }
         BnRow q[kU];
         uint32_t dbits[kU];
 #pragma unroll
@@ -262,33 +288,61 @@ __global__ void __launch_bounds__(kBnThreads) bin_scatter_kernel(const BinArgs a
                 q[u]     = bn_load_row(a, r, has_conic);
                 dbits[u] = __float_as_uint(a.depths[r]);
             }
+            s_tpg[u * kBnThreads + threadIdx.x] = 0;
         }
+        __syncthreads(); // s_cur (first iteration), s_qn, s_tpg
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int64_t r = base + u * kBnThreads + threadIdx.x;
             if (r >= hi) continue;
+            const int slot   = u * kBnThreads + (int)threadIdx.x;
             const WalkPrep p = bn_prepare(q[u], has_conic, g);
-            int32_t n_tiles  = 0;
-            if (p.any) {
-                const uint32_t bx0 = (uint32_t)p.x0 / g.bw, bx1 = ((uint32_t)p.x1 + g.bw - 1) / g.bw;
-                const uint32_t by0 = (uint32_t)p.y0 / g.bh, by1 = ((uint32_t)p.y1 + g.bh - 1) / g.bh;
-                for (uint32_t by = by0; by < by1; ++by)
-                    for (uint32_t bx = bx0; bx < bx1; ++bx) {
-                        const int cx0 = (int)(bx * g.bw), cy0 = (int)(by * g.bh);
-                        const int cx1 = min(cx0 + (int)g.bw, (int)g.tile_w), cy1 = min(cy0 + (int)g.bh, (int)g.tile_h);
-                        uint32_t mask = 0;
-                        walk_clipped(p, g.tile_size, cx0, cy0, cx1, cy1, [&](int x, int y) {
-                            if (tmask && !tmask[(size_t)y * g.tile_w + x]) return;
-                            mask |= 1u << ((y - cy0) * (int)g.bw + (x - cx0));
-                        });
-                        const int32_t slot = atomicAdd(&s_cur[by * g.bins_x + bx], 1);
-                        a.b.e_pair[slot]   = make_uint2(dbits[u], (uint32_t)r);
-                        a.b.e_mask[slot]   = (uint16_t)mask;
-                        n_tiles += (int32_t)__popc(mask);
-                    }
+            if (!p.any) continue;
+            const uint32_t bx0 = (uint32_t)p.x0 / g.bw, bx1 = ((uint32_t)p.x1 + g.bw - 1) / g.bw;
+            const uint32_t by0 = (uint32_t)p.y0 / g.bh, by1 = ((uint32_t)p.y1 + g.bh - 1) / g.bh;
+            const uint32_t area = (bx1 - bx0) * (by1 - by0);
+            if (area == 1u) {
+                s_tpg[slot] = (int32_t)bn_entry(a, p, bx0, by0, tmask, dbits[u], r, s_cur);
+                continue;
             }
-            if (a.tiles_per_gauss) a.tiles_per_gauss[r] = n_tiles;
+            const int32_t qpos = atomicAdd(&s_qn, (int32_t)area);
+            if (qpos + (int32_t)area <= kDQueue) {
+                float *w = s_row[slot];
+                w[0] = q[u].mx; w[1] = q[u].my; w[2] = q[u].rx; w[3] = q[u].ry; w[4] = q[u].A; w[5] = q[u].B; w[6] = q[u].C;
+                w[7] = q[u].op; w[8] = __uint_as_float(dbits[u]);
+                int32_t k = qpos;
+                for (uint32_t by = by0; by < by1; ++by)
+                    for (uint32_t bx = bx0; bx < bx1; ++bx) s_q[k++] = (uint32_t)slot | (bx << 9) | (by << 17);
+            } else { // the queue is full (a screen of giant Gaussians): this thread walks all of the row's bins itself
+                atomicMin(&s_qlim, qpos); // pairs are valid below the first reservation that did not fit
+                int32_t n = 0;
+                for (uint32_t by = by0; by < by1; ++by)
+                    for (uint32_t bx = bx0; bx < bx1; ++bx) n += (int32_t)bn_entry(a, p, bx, by, tmask, dbits[u], r, s_cur);
+                atomicAdd(&s_tpg[slot], n);
+            }
         }
+        __syncthreads();
+        const int32_t n_q = min(s_qn, s_qlim); // reservations that did not fit wrote nothing
+        for (int32_t k = (int32_t)threadIdx.x; k < n_q; k += kBnThreads) {
+            const uint32_t pr = s_q[k];
+            const int slot    = (int)(pr & 511u);
+            const float *w    = s_row[slot];
+            BnRow qq;
+            qq.mx = w[0]; qq.my = w[1]; qq.rx = w[2]; qq.ry = w[3]; qq.A = w[4]; qq.B = w[5]; qq.C = w[6]; qq.op = w[7];
+            const WalkPrep p = bn_prepare(qq, has_conic, g);
+            const int64_t r  = base + slot;
+            const uint32_t n = bn_entry(a, p, (pr >> 9) & 255u, pr >> 17, tmask, __float_as_uint(w[8]), r, s_cur);
+            if (n) atomicAdd(&s_tpg[slot], (int32_t)n);
+        }
+        __syncthreads();
+        if (a.tiles_per_gauss) {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int64_t r = base + u * kBnThreads + threadIdx.x;
+                if (r < hi) a.tiles_per_gauss[r] = s_tpg[u * kBnThreads + threadIdx.x];
+            }
+        }
+        __syncthreads(); // s_tpg / s_row / s_q are rewritten by the next iteration
     }
 }
 
@@ -412,23 +466,34 @@ __device__ __forceinline__ void bn_bitonic(uint64_t *s, int lp, int tid, Sync &&
     }
 }
 
-__global__ void __launch_bounds__(kBnThreads) bin_sort_kernel(const BinArgs a)
+// One workgroup per bin, ONE WAVE PER TILE (bw * bh waves). The bin's entries pass through an LDS stage once per batch of
+// tiles: every wave scans the staged masks for its tile's bit and appends the (depth, row) words of the hits to its tile's
+// slice of the LDS arena at a cursor it keeps in a scalar register (no atomics); then every wave sorts its slice (bitonic, no
+// workgroup barrier) and writes keys (image|tile|depth) and row ids contiguously. The arena is cut by the exact tile counts
+// (padded to powers of two), tiles that do not fit together go in further batches; a tile longer than the arena goes
+// through the work-list sort of tile_sort.hip (unsorted segment + list entry).
+constexpr int kArenaPerWave = 576; // arena words per wave: 16 waves -> 9216 sort words (+ 1/8 padding)
+constexpr int kStagePerWave = 128; // staged entries per wave and step
+
+__global__ void __launch_bounds__(1024) bin_sort_kernel(const BinArgs a)
 {
-    constexpr int kWaveWords = kWaveCap + kWaveCap / 8;
-    __shared__ __attribute__((aligned(16))) uint64_t s_buf[4 * kWaveWords]; // 4 x 1152 words = kGroupCap + kGroupCap / 8
-    __shared__ int32_t s_tcnt[16], s_goff[16];
-    __shared__ uint64_t s_hi[16];
-    __shared__ int32_t s_n;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const BinGeom &g = a.g;
+    const int n_bits = (int)(g.bw * g.bh), n_thr = n_bits * 64;
+    const int arena_words = kArenaPerWave * n_bits, stage_n = kStagePerWave * n_bits;
+    uint64_t *s_arena = reinterpret_cast<uint64_t *>(smem_raw);                       // [arena_words + arena_words / 8]
+    uint2 *s_spair    = reinterpret_cast<uint2 *>(s_arena + arena_words + arena_words / 8); // [stage_n]
+    uint16_t *s_smask = reinterpret_cast<uint16_t *>(s_spair + stage_n);               // [stage_n]
+    __shared__ int32_t s_tcnt[16], s_goff[16], s_base[16], s_batch[16], s_nbatch, s_n;
+    __shared__ uint64_t s_hi[16];
     const uint32_t bin = blockIdx.x;
     const int32_t e0 = a.b.bin_start[bin], e1 = a.b.bin_start[bin + 1];
     if (e0 == e1) return;
     const uint32_t img = bin / g.n_bins, lb = bin % g.n_bins;
     const uint32_t tx0 = (lb % g.bins_x) * g.bw, ty0 = (lb / g.bins_x) * g.bh;
-    const int n_bits = (int)(g.bw * g.bh);
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (threadIdx.x < 16) {
+    if ((int)threadIdx.x < 16) {
         const int t       = (int)threadIdx.x;
         const uint32_t tx = tx0 + (uint32_t)t % g.bw, ty = ty0 + (uint32_t)t / g.bw;
         const bool in     = t < n_bits && tx < g.tile_w && ty < g.tile_h;
@@ -438,49 +503,73 @@ __global__ void __launch_bounds__(kBnThreads) bin_sort_kernel(const BinArgs a)
         s_hi[t]           = in ? ((((uint64_t)img << g.tile_bits) | ((uint64_t)ty * g.tile_w + tx)) << 32) : 0ull;
     }
     __syncthreads();
-    // (1) tiles of <= kWaveCap entries: one wave each, no workgroup barrier
-    uint64_t *sw = s_buf + wave * kWaveWords;
-    for (int t = wave; t < n_bits; t += kBnThreads / 64) {
-        const int n = s_tcnt[t];
-        if (n <= 0 || n > kWaveCap) continue;
-        int32_t cnt = 0; // wave-uniform cursor
-        for (int32_t base = e0; base < e1; base += 64) {
-            const int32_t e    = base + lane;
-            const bool has     = e < e1 && (((uint32_t)a.b.e_mask[e] >> t) & 1u);
-            const uint64_t bal = __builtin_amdgcn_ballot_w64(has);
-            if (has) {
-                const uint2 pr = a.b.e_pair[e];
-                sw[bn_phys(cnt + (int32_t)__popcll(bal & lt_mask))] = ((uint64_t)pr.x << 32) | pr.y;
-            }
-            cnt += (int32_t)__popcll(bal);
+    if (threadIdx.x == 0) { // cut the arena: tile t of batch s_batch[t] sorts at physical word s_base[t]
+        int batch = 0, used = 0;
+        for (int t = 0; t < 16; ++t) {
+            const int n = s_tcnt[t];
+            s_batch[t]  = -1; // empty
+            if (n <= 0) continue;
+            int P = 64;
+            while (P < n) P <<= 1;
+            if (P > arena_words) { s_batch[t] = -2; continue; } // longer than the arena: work-list sort
+            if (used + P > arena_words) { ++batch; used = 0; }
+            s_batch[t] = batch;
+            s_base[t]  = used + (used >> 3);
+            used += P;
         }
-        int lp = 6;
-        while ((1 << lp) < n) ++lp;
-        for (int i = n + lane; i < (1 << lp); i += 64) sw[bn_phys(i)] = ~0ull;
-        wave_lds_sync();
-        bn_bitonic<64>(sw, lp, lane, [] { wave_lds_sync(); });
-        const int64_t off = s_goff[t];
-        const uint64_t hi = s_hi[t];
-        for (int i = lane; i < n; i += 64) {
-            const uint64_t w    = sw[bn_phys(i)];
-            a.keys_out[off + i] = hi | (w >> 32);
-            a.vals_out[off + i] = (int32_t)(uint32_t)w;
-        }
-        wave_lds_sync(); // the buffer is reused by this wave's next tile
+        s_nbatch = batch + 1;
     }
-    // (2) longer tiles: the four waves together (<= kGroupCap) or through the work-list sort (unsorted segment + list entry)
-    bool any_long = false;
-    for (int t = 0; t < n_bits; ++t) any_long |= s_tcnt[t] > kWaveCap;
-    if (!any_long) return;
-    __syncthreads(); // every wave is done with its private part of s_buf
+    __syncthreads();
+    const int n_batch = s_nbatch;
+    const int my_n = wave < 16 ? s_tcnt[wave] : 0;
+    for (int b = 0; b < n_batch; ++b) {
+        const bool mine = wave < n_bits && s_batch[wave] == b; // wave-uniform
+        uint64_t *sw    = s_arena + (mine ? s_base[wave] : 0);
+        int32_t cnt     = 0;
+        for (int32_t cb = e0; cb < e1; cb += stage_n) {
+            const int32_t cn = min(stage_n, e1 - cb);
+            for (int i = threadIdx.x; i < cn; i += n_thr) {
+                s_smask[i] = a.b.e_mask[cb + i];
+                s_spair[i] = a.b.e_pair[cb + i];
+            }
+            __syncthreads();
+            if (mine)
+                for (int i0 = 0; i0 < cn; i0 += 64) {
+                    const int i        = i0 + lane;
+                    const bool has     = i < cn && (((uint32_t)s_smask[i] >> wave) & 1u);
+                    const uint64_t bal = __builtin_amdgcn_ballot_w64(has);
+                    if (has) {
+                        const uint2 pr = s_spair[i];
+                        sw[bn_phys(cnt + (int32_t)__popcll(bal & lt_mask))] = ((uint64_t)pr.x << 32) | pr.y;
+                    }
+                    cnt += (int32_t)__popcll(bal);
+                }
+            __syncthreads();
+        }
+        if (mine) {
+            const int n = my_n;
+            int lp = 6;
+            while ((1 << lp) < n) ++lp;
+            for (int i = n + lane; i < (1 << lp); i += 64) sw[bn_phys(i)] = ~0ull;
+            wave_lds_sync();
+            bn_bitonic<64>(sw, lp, lane, [] { wave_lds_sync(); });
+            const int64_t off = s_goff[wave];
+            const uint64_t hi = s_hi[wave];
+            for (int i = lane; i < n; i += 64) {
+                const uint64_t w    = sw[bn_phys(i)];
+                a.keys_out[off + i] = hi | (w >> 32);
+                a.vals_out[off + i] = (int32_t)(uint32_t)w;
+            }
+        }
+        __syncthreads(); // the arena is cut anew for the next batch
+    }
+    // tiles longer than the arena: their unsorted segment goes through the work-list sort
     for (int t = 0; t < n_bits; ++t) {
-        const int n = s_tcnt[t];
-        if (n <= kWaveCap) continue;
-        const bool big = n > kGroupCap;
+        if (s_batch[t] != -2) continue;
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
         const int64_t off = s_goff[t];
-        for (int32_t base = e0; base < e1; base += kBnThreads) {
+        for (int32_t base = e0; base < e1; base += n_thr) {
             const int32_t e    = base + (int32_t)threadIdx.x;
             const bool has     = e < e1 && (((uint32_t)a.b.e_mask[e] >> t) & 1u);
             const uint64_t bal = __builtin_amdgcn_ballot_w64(has);
@@ -489,31 +578,11 @@ __global__ void __launch_bounds__(kBnThreads) bin_sort_kernel(const BinArgs a)
             int32_t wbase   = 0;
             if (lane == first) wbase = atomicAdd(&s_n, (int32_t)__popcll(bal));
             wbase = __builtin_amdgcn_readlane(wbase, first);
-            if (has) {
-                const uint2 pr  = a.b.e_pair[e];
-                const int32_t j = wbase + (int32_t)__popcll(bal & lt_mask);
-                if (big) a.bucketed[off + j] = pr;
-                else s_buf[bn_phys(j)] = ((uint64_t)pr.x << 32) | pr.y;
-            }
+            if (has) a.bucketed[off + wbase + (int32_t)__popcll(bal & lt_mask)] = a.b.e_pair[e];
         }
-        __syncthreads();
-        if (big) {
-            if (threadIdx.x == 0) {
-                const uint32_t tx = tx0 + (uint32_t)t % g.bw, ty = ty0 + (uint32_t)t / g.bw;
-                a.b.big_list[atomicAdd(&a.b.hdr->big_count, 1)] = (int32_t)(img * g.n_tiles + ty * g.tile_w + tx);
-            }
-            continue;
-        }
-        int lp = 10;
-        while ((1 << lp) < n) ++lp;
-        for (int i = n + (int)threadIdx.x; i < (1 << lp); i += kBnThreads) s_buf[bn_phys(i)] = ~0ull;
-        __syncthreads();
-        bn_bitonic<kBnThreads>(s_buf, lp, (int)threadIdx.x, [] { __syncthreads(); });
-        const uint64_t hi = s_hi[t];
-        for (int i = threadIdx.x; i < n; i += kBnThreads) {
-            const uint64_t w    = s_buf[bn_phys(i)];
-            a.keys_out[off + i] = hi | (w >> 32);
-            a.vals_out[off + i] = (int32_t)(uint32_t)w;
+        if (threadIdx.x == 0) {
+            const uint32_t tx = tx0 + (uint32_t)t % g.bw, ty = ty0 + (uint32_t)t / g.bw;
+            a.b.big_list[atomicAdd(&a.b.hdr->big_count, 1)] = (int32_t)(img * g.n_tiles + ty * g.tile_w + tx);
         }
         __syncthreads();
     }
@@ -560,7 +629,8 @@ static bool bin_geometry(BinGeom &g, int64_t rows, uint32_t n_images, uint32_t t
     if (g.rpc == 0) g.rpc = 1;
     g.n_chunks    = g.cpi * g.n_images;
     g.cap_entries = cap_entries;
-    return g.n_bins_total <= (uint32_t)kBnMaxBins && (uint64_t)g.n_images * g.n_tiles <= kBnMaxTiles && rows < (1ll << 28);
+    return g.n_bins_total <= (uint32_t)kBnMaxBins && (uint64_t)g.n_images * g.n_tiles <= kBnMaxTiles && rows < (1ll << 28)
+           && g.bins_x <= 256 && g.bins_y <= 256; // (row slot, bin x, bin y) pairs of kernel D: 9 + 8 + 8 bits
 }
 
 // entries the workspace is sized for: a row costs one entry per bin its tile rectangle overlaps
@@ -690,7 +760,12 @@ extern "C" int gsx_isect_binned_emit_sort(int64_t rows, uint32_t n_images, uint3
     a.isect_offsets = const_cast<int32_t *>(isect_offsets);
     a.keys_out = reinterpret_cast<uint64_t *>(isect_ids_sorted);
     a.vals_out = flatten_ids_sorted;
-    bin_sort_kernel<<<dim3(a.g.n_bins_total), dim3(kBnThreads), 0, s>>>(a);
+    const int n_bits = (int)(a.g.bw * a.g.bh);
+    const size_t sort_lds = (size_t)(kArenaPerWave * n_bits) * 9 + (size_t)(kStagePerWave * n_bits) * 10;
+    static PerDeviceOnce once;
+    if (once.first())
+        (void)hipFuncSetAttribute((const void *)bin_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    bin_sort_kernel<<<dim3(a.g.n_bins_total), dim3(64 * n_bits), sort_lds, s>>>(a);
     rc = check_launch("isect_binned_emit");
     if (rc != GSX_OK) return rc;
     TileSortArgs t{};
