@@ -1,6 +1,6 @@
-// Binned tile intersection: isect_tiles(sort=True) + isect_offset_encode with every tile list gathered, sorted and written
-// by ONE wave (or workgroup) that owns the tile - no scattered 8-byte stores into tile segments, no [chunk][tile] table, no
-// LDS atomics per intersection, no intermediate pair array.
+// Binned tile intersection: isect_tiles(sort=True) + isect_offset_encode with every tile list assembled, sorted and written
+// from LDS by the workgroup that owns the tile - no scattered 8-byte stores into tile segments in HBM, no [chunk][tile]
+// table, no intermediate pair array.
 //
 // Replaces, for the same outputs bit for bit, the reference's count -> cumsum -> emit -> 6-pass device radix sort -> offsets
 // (gsplat/cuda/csrc/IntersectTile.cu:214-464, 1078-1121, 925-988; host Intersect.cpp:170-329) and this backend's earlier
@@ -15,16 +15,20 @@
 //   C  bin_plan      one workgroup: scan of the bin totals -> bin_start; capacity check
 //   D  bin_scatter   per row again (its data is in registers: no gather): for every overlapped bin the walk CLIPPED to the
 //                    bin (walk_clipped: only the slabs inside it) -> 16-bit mask of the bin's tiles the Gaussian touches;
-//                    entry = (depth, row) + mask written at an LDS cursor (bin_start + chunk prefix); tiles_per_gauss
+//                    entry = (depth, row) + mask written at an LDS cursor (bin_start + chunk prefix); tiles_per_gauss.
+//                    Rows over several bins are shared out over the workgroup as (row, bin) pairs through an LDS queue.
 //   E  bin_tiles     one workgroup per bin: per-tile counts from the masks (wave ballots) -> tile_count
 //   F  tile_plan     one workgroup: scan of the tile counts -> isect_offsets, n_isects (pinned host word)
 //   after the host allocated the exact-length outputs
-//   G  bin_sort      one workgroup per bin. Every WAVE takes tiles of the bin: it scans the bin's masks (2 bytes per entry,
-//                    L2-resident), appends the (depth, row) words of the entries that touch its tile to a wave-private LDS
-//                    buffer at a cursor it keeps in a scalar register, sorts them there with a bitonic network that needs no
-//                    workgroup barrier, and writes keys (image|tile|depth) and row ids contiguously. Tiles of 1025..4096
-//                    entries are done by the four waves together in the same LDS; longer ones go through the work-list
-//                    sort of tile_sort.hip (launch_big_tile_sort).
+//   G  bin_sort      one workgroup per bin: every entry is dealt to the LDS lists of the tiles in its mask (LDS cursors:
+//                    integer LDS atomics run at the rate of LDS writes on gfx950), then ONE WAVE PER TILE sorts its list
+//                    with a bitonic network that needs no workgroup barrier and writes keys (image|tile|depth) and row ids
+//                    contiguously. Tiles that do not fit the LDS arena together go in further batches; a tile longer than
+//                    the arena goes through the work-list sort of tile_sort.hip (launch_big_tile_sort).
+//
+// Measured on MI355X (tools/issue_rate.hip): ONE wave issues an instruction every ~5 cycles whatever the dependencies, a SIMD
+// reaches ~0.6 / 0.77 instructions per cycle only with 4 / 8 waves. These kernels are chains of dependent, divergent work, so
+// they are laid out for WAVES, not for work per thread: 1024-thread workgroups, two rows per thread, two workgroups per CU.
 //
 // The 64-bit sort word is (depth bits << 32 | row), so equal depths come out in ascending row order = the emission order
 // of the reference (stable sort on the key).
@@ -35,7 +39,8 @@
 
 namespace gsx {
 
-constexpr int kBnThreads      = 256;
+constexpr int kRowThreads     = 1024;  // kernels A, D (row-major)
+constexpr int kBnThreads      = 256;   // kernel E
 constexpr int kBnMaxBins      = 16384; // bins in total (images x bins per image)
 constexpr uint32_t kBnMaxTiles = 36864;
 
@@ -58,7 +63,7 @@ struct BinBuffers {
     uint2 *e_pair;       // [cap] (depth bits, row)
     uint16_t *e_mask;    // [cap]
     int32_t *tile_count; // [n_images * n_tiles]
-    int32_t *big_list;   // [n_images * n_tiles] tiles longer than kGroupCap (kernel G -> work-list sort)
+    int32_t *big_list;   // [n_images * n_tiles] tiles longer than the LDS arena (kernel G -> work-list sort)
 };
 
 struct BinArgs {
@@ -116,22 +121,22 @@ __device__ __forceinline__ WalkPrep bn_prepare(const BnRow &q, bool has_conic, c
 }
 
 // ---- A: rectangle of bins per row, histogram ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBnThreads) bin_rect_kernel(const BinArgs a)
+__global__ void __launch_bounds__(kRowThreads) bin_rect_kernel(const BinArgs a)
 {
     extern __shared__ int32_t s_hist[];
     const BinGeom &g = a.g;
-    for (uint32_t i = threadIdx.x; i < g.n_bins; i += kBnThreads) s_hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < g.n_bins; i += kRowThreads) s_hist[i] = 0;
     __syncthreads();
     int64_t lo, hi;
     uint32_t img;
     bn_chunk_rows(g, blockIdx.x, lo, hi, img);
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
-    constexpr int kU = 4;
-    for (int64_t base = lo; base < hi; base += kBnThreads * kU) {
+    constexpr int kU = 2;
+    for (int64_t base = lo; base < hi; base += kRowThreads * kU) {
         BnRow q[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) { // every load of the thread's rows is in flight before any is used
-            const int64_t r = base + u * kBnThreads + threadIdx.x;
+            const int64_t r = base + u * kRowThreads + threadIdx.x;
             q[u].rx = q[u].ry = 0.0f;
             if (r < hi) q[u] = bn_load_row(a, r, has_conic);
         }
@@ -148,7 +153,7 @@ __global__ void __launch_bounds__(kBnThreads) bin_rect_kernel(const BinArgs a)
     }
     __syncthreads();
     int32_t *out = a.b.table + (int64_t)blockIdx.x * g.n_bins;
-    for (uint32_t i = threadIdx.x; i < g.n_bins; i += kBnThreads) out[i] = s_hist[i];
+    for (uint32_t i = threadIdx.x; i < g.n_bins; i += kRowThreads) out[i] = s_hist[i];
 }
 
 // ---- B: exclusive running sum over an image's chunks for every (image, bin), in place; totals[bin] ---------------------
@@ -183,13 +188,21 @@ __global__ void __launch_bounds__(kCsCols *kCsSegs2) bin_colscan_kernel(int32_t 
     }
 }
 
-// ---- one-workgroup exclusive scan helper (1024 threads, thread-contiguous runs) ----------------------------------------
+// ---- one-workgroup exclusive scan (1024 threads, thread-contiguous runs; runs of <= 16 stay in registers) -------------
 __device__ __forceinline__ int64_t block_scan_1024(const int32_t *in, int32_t *out, uint32_t n, int64_t *s_part)
 {
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n);
+    constexpr uint32_t kKeep = 16;
+    int32_t v[kKeep];
     int64_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += in[i];
+    if (per <= kKeep) {
+#pragma unroll
+        for (uint32_t k = 0; k < kKeep; ++k) v[k] = (k < per && lo + k < hi) ? in[lo + k] : 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kKeep; ++k) sum += v[k];
+    } else
+        for (uint32_t i = lo; i < hi; ++i) sum += in[i];
     int64_t inc    = sum;
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
 #pragma unroll
@@ -202,16 +215,24 @@ __device__ __forceinline__ int64_t block_scan_1024(const int32_t *in, int32_t *o
     int64_t base = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-        const int64_t v = s_part[w];
-        if (w < wave) base += v;
-        total += v;
+        const int64_t x = s_part[w];
+        if (w < wave) base += x;
+        total += x;
     }
     int64_t run = base + inc - sum;
-    for (uint32_t i = lo; i < hi; ++i) {
-        const int32_t v = in[i];
-        out[i]          = (int32_t)run;
-        run += v;
-    }
+    if (per <= kKeep) {
+#pragma unroll
+        for (uint32_t k = 0; k < kKeep; ++k)
+            if (k < per && lo + k < hi) {
+                out[lo + k] = (int32_t)run;
+                run += v[k];
+            }
+    } else
+        for (uint32_t i = lo; i < hi; ++i) {
+            const int32_t x = in[i];
+            out[i]          = (int32_t)run;
+            run += x;
+        }
     __syncthreads(); // s_part may be reused
     return total;
 }
@@ -235,10 +256,11 @@ __global__ void __launch_bounds__(1024) bin_plan_kernel(const BinArgs a)
 // ---- D: entries (depth, row | mask) grouped by bin ----------------------------------------------------------------------
 // A row's cost is the number of bins and tiles it covers, and a wave pays for its most expensive lane: with one row per lane a
 // single near Gaussian (hundreds of tiles) stalls 63 lanes. So only rows inside ONE bin (at most bw x bh tiles) are walked by
-// the thread that loaded them; a row over several bins parks its nine input words in LDS and pushes one (row, bin) pair per
+// the thread that loaded them; a row over several bins parks its ten input words in LDS and pushes one (row, bin) pair per
 // bin on an LDS queue, and the workgroup then shares the pairs out evenly: every unit of work is one walk clipped to one bin.
-constexpr int kDRows = 2 * kBnThreads; // rows per iteration
-constexpr int kDQueue = 4096;          // (row, bin) pairs per iteration; a row that does not fit is walked by its own thread
+constexpr int kDRows  = 2 * kRowThreads; // rows per iteration
+constexpr int kDMulti = 640;             // rows over several bins parked per iteration
+constexpr int kDQueue = 4096;            // (row, bin) pairs per iteration; a row that does not fit is walked by its own thread
 
 __device__ __forceinline__ uint32_t bn_entry(const BinArgs &a, const WalkPrep &p, uint32_t bx, uint32_t by, const uint8_t *tmask,
                                             uint32_t dbits, int64_t r, int32_t *s_cur)
@@ -257,13 +279,13 @@ __device__ __forceinline__ uint32_t bn_entry(const BinArgs &a, const WalkPrep &p
     return (uint32_t)__popc(mask);
 }
 
-__global__ void __launch_bounds__(kBnThreads) bin_scatter_kernel(const BinArgs a)
+__global__ void __launch_bounds__(kRowThreads) bin_scatter_kernel(const BinArgs a)
 {
     extern __shared__ int32_t s_cur[];
     __shared__ uint32_t s_q[kDQueue];
-    __shared__ float s_row[kDRows][9];
+    __shared__ float s_row[kDMulti][10]; // mean, radii, conic, opacity, depth bits, row slot
     __shared__ int32_t s_tpg[kDRows];
-    __shared__ int32_t s_qn, s_qlim;
+    __shared__ int32_t s_qn, s_qlim, s_mn;
     const BinGeom &g = a.g;
     if (a.b.hdr->overflow) return;
     int64_t lo, hi;
@@ -271,31 +293,31 @@ __global__ void __launch_bounds__(kBnThreads) bin_scatter_kernel(const BinArgs a
     bn_chunk_rows(g, blockIdx.x, lo, hi, img);
     const int32_t *pre   = a.b.table + (int64_t)blockIdx.x * g.n_bins; // exclusive prefix over this image's chunks
     const int32_t *start = a.b.bin_start + (int64_t)img * g.n_bins;
-    for (uint32_t i = threadIdx.x; i < g.n_bins; i += kBnThreads) s_cur[i] = start[i] + pre[i];
+    for (uint32_t i = threadIdx.x; i < g.n_bins; i += kRowThreads) s_cur[i] = start[i] + pre[i];
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)img * g.n_tiles : nullptr;
-    constexpr int kU = kDRows / kBnThreads;
+    constexpr int kU = kDRows / kRowThreads;
     for (int64_t base = lo; base < hi; base += kDRows) {
-        if (threadIdx.x == 0) { s_qn = 0; s_qlim = kDQueue; }
+        if (threadIdx.x == 0) { s_qn = 0; s_qlim = kDQueue; s_mn = 0; }
         BnRow q[kU];
         uint32_t dbits[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-            const int64_t r = base + u * kBnThreads + threadIdx.x;
+            const int64_t r = base + u * kRowThreads + threadIdx.x;
             q[u].rx = q[u].ry = 0.0f;
             dbits[u] = 0;
             if (r < hi) {
                 q[u]     = bn_load_row(a, r, has_conic);
                 dbits[u] = __float_as_uint(a.depths[r]);
             }
-            s_tpg[u * kBnThreads + threadIdx.x] = 0;
+            s_tpg[u * kRowThreads + threadIdx.x] = 0;
         }
         __syncthreads(); // s_cur (first iteration), s_qn, s_tpg
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-            const int64_t r = base + u * kBnThreads + threadIdx.x;
+            const int64_t r = base + u * kRowThreads + threadIdx.x;
             if (r >= hi) continue;
-            const int slot   = u * kBnThreads + (int)threadIdx.x;
+            const int slot   = u * kRowThreads + (int)threadIdx.x;
             const WalkPrep p = bn_prepare(q[u], has_conic, g);
             if (!p.any) continue;
             const uint32_t bx0 = (uint32_t)p.x0 / g.bw, bx1 = ((uint32_t)p.x1 + g.bw - 1) / g.bw;
@@ -305,41 +327,41 @@ __global__ void __launch_bounds__(kBnThreads) bin_scatter_kernel(const BinArgs a
                 s_tpg[slot] = (int32_t)bn_entry(a, p, bx0, by0, tmask, dbits[u], r, s_cur);
                 continue;
             }
-            const int32_t qpos = atomicAdd(&s_qn, (int32_t)area);
-            if (qpos + (int32_t)area <= kDQueue) {
-                float *w = s_row[slot];
+            const int32_t ms   = atomicAdd(&s_mn, 1);
+            const int32_t qpos = ms < kDMulti ? atomicAdd(&s_qn, (int32_t)area) : kDQueue;
+            if (ms < kDMulti && qpos + (int32_t)area <= kDQueue) {
+                float *w = s_row[ms];
                 w[0] = q[u].mx; w[1] = q[u].my; w[2] = q[u].rx; w[3] = q[u].ry; w[4] = q[u].A; w[5] = q[u].B; w[6] = q[u].C;
-                w[7] = q[u].op; w[8] = __uint_as_float(dbits[u]);
+                w[7] = q[u].op; w[8] = __uint_as_float(dbits[u]); w[9] = __int_as_float(slot);
                 int32_t k = qpos;
                 for (uint32_t by = by0; by < by1; ++by)
-                    for (uint32_t bx = bx0; bx < bx1; ++bx) s_q[k++] = (uint32_t)slot | (bx << 9) | (by << 17);
-            } else { // the queue is full (a screen of giant Gaussians): this thread walks all of the row's bins itself
-                atomicMin(&s_qlim, qpos); // pairs are valid below the first reservation that did not fit
+                    for (uint32_t bx = bx0; bx < bx1; ++bx) s_q[k++] = (uint32_t)ms | (bx << 10) | (by << 18);
+            } else { // no room (a screen of giant Gaussians): this thread walks all of the row's bins itself
+                if (ms < kDMulti) atomicMin(&s_qlim, qpos); // pairs are valid below the first reservation that did not fit
                 int32_t n = 0;
                 for (uint32_t by = by0; by < by1; ++by)
                     for (uint32_t bx = bx0; bx < bx1; ++bx) n += (int32_t)bn_entry(a, p, bx, by, tmask, dbits[u], r, s_cur);
-                atomicAdd(&s_tpg[slot], n);
+                s_tpg[slot] = n;
             }
         }
         __syncthreads();
-        const int32_t n_q = min(s_qn, s_qlim); // reservations that did not fit wrote nothing
-        for (int32_t k = (int32_t)threadIdx.x; k < n_q; k += kBnThreads) {
+        const int32_t n_q = min(s_qn, s_qlim);
+        for (int32_t k = (int32_t)threadIdx.x; k < n_q; k += kRowThreads) {
             const uint32_t pr = s_q[k];
-            const int slot    = (int)(pr & 511u);
-            const float *w    = s_row[slot];
+            const float *w    = s_row[pr & 1023u];
             BnRow qq;
             qq.mx = w[0]; qq.my = w[1]; qq.rx = w[2]; qq.ry = w[3]; qq.A = w[4]; qq.B = w[5]; qq.C = w[6]; qq.op = w[7];
+            const int slot   = __float_as_int(w[9]);
             const WalkPrep p = bn_prepare(qq, has_conic, g);
-            const int64_t r  = base + slot;
-            const uint32_t n = bn_entry(a, p, (pr >> 9) & 255u, pr >> 17, tmask, __float_as_uint(w[8]), r, s_cur);
+            const uint32_t n = bn_entry(a, p, (pr >> 10) & 255u, pr >> 18, tmask, __float_as_uint(w[8]), base + slot, s_cur);
             if (n) atomicAdd(&s_tpg[slot], (int32_t)n);
         }
         __syncthreads();
         if (a.tiles_per_gauss) {
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                const int64_t r = base + u * kBnThreads + threadIdx.x;
-                if (r < hi) a.tiles_per_gauss[r] = s_tpg[u * kBnThreads + threadIdx.x];
+                const int64_t r = base + u * kRowThreads + threadIdx.x;
+                if (r < hi) a.tiles_per_gauss[r] = s_tpg[u * kRowThreads + threadIdx.x];
             }
         }
         __syncthreads(); // s_tpg / s_row / s_q are rewritten by the next iteration
@@ -359,12 +381,21 @@ __global__ void __launch_bounds__(kBnThreads) bin_tiles_kernel(const BinArgs a)
     if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     int32_t mine = 0; // lane t < n_bits: entries seen by this wave that touch tile t
-    for (int32_t base = e0; base < e1; base += kBnThreads) {
-        const int32_t e  = base + (int32_t)threadIdx.x;
-        const uint32_t m = e < e1 ? (uint32_t)a.b.e_mask[e] : 0u;
-        for (int t = 0; t < n_bits; ++t) {
-            const uint64_t b = __builtin_amdgcn_ballot_w64((m >> t) & 1u);
-            if (lane == t) mine += (int32_t)__popcll(b);
+    constexpr int kU = 8;
+    for (int32_t base = e0; base < e1; base += kBnThreads * kU) {
+        uint32_t m[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int32_t e = base + u * kBnThreads + (int32_t)threadIdx.x;
+            m[u]            = e < e1 ? (uint32_t)a.b.e_mask[e] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (base + u * kBnThreads >= e1) break; // wave-uniform
+            for (int t = 0; t < n_bits; ++t) {
+                const uint64_t b = __builtin_amdgcn_ballot_w64((m[u] >> t) & 1u);
+                if (lane == t) mine += (int32_t)__popcll(b);
+            }
         }
     }
     if (lane < n_bits && mine) atomicAdd(&s_cnt[lane], mine);
@@ -395,7 +426,7 @@ __global__ void __launch_bounds__(1024) tile_plan_kernel(const BinArgs a)
     }
 }
 
-// ---- G: per tile: gather by mask bit, sort in LDS, write ---------------------------------------------------------------------
+// ---- G: per bin: deal the entries to the tiles' LDS lists, one wave sorts each list, write ---------------------------------
 __device__ __forceinline__ int bn_phys(int i) { return i + (i >> 3); }
 __device__ __forceinline__ void bn_cmpx(uint64_t &x, uint64_t &y, bool up)
 {
@@ -466,25 +497,16 @@ __device__ __forceinline__ void bn_bitonic(uint64_t *s, int lp, int tid, Sync &&
     }
 }
 
-// One workgroup per bin, ONE WAVE PER TILE (bw * bh waves). The bin's entries pass through an LDS stage once per batch of
-// tiles: every wave scans the staged masks for its tile's bit and appends the (depth, row) words of the hits to its tile's
-// slice of the LDS arena at a cursor it keeps in a scalar register (no atomics); then every wave sorts its slice (bitonic, no
-// workgroup barrier) and writes keys (image|tile|depth) and row ids contiguously. The arena is cut by the exact tile counts
-// (padded to powers of two), tiles that do not fit together go in further batches; a tile longer than the arena goes
-// through the work-list sort of tile_sort.hip (unsorted segment + list entry).
-constexpr int kArenaPerWave = 576; // arena words per wave: 16 waves -> 9216 sort words (+ 1/8 padding)
-constexpr int kStagePerWave = 128; // staged entries per wave and step
+constexpr int kArenaPerWave = 512; // arena sort words per tile-wave: 16 waves -> 8192 words (+ 1/8 padding) = 72 KiB
 
-__global__ void __launch_bounds__(1024) bin_sort_kernel(const BinArgs a)
+__global__ void __launch_bounds__(1024, 8) bin_sort_kernel(const BinArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const BinGeom &g = a.g;
     const int n_bits = (int)(g.bw * g.bh), n_thr = n_bits * 64;
-    const int arena_words = kArenaPerWave * n_bits, stage_n = kStagePerWave * n_bits;
-    uint64_t *s_arena = reinterpret_cast<uint64_t *>(smem_raw);                       // [arena_words + arena_words / 8]
-    uint2 *s_spair    = reinterpret_cast<uint2 *>(s_arena + arena_words + arena_words / 8); // [stage_n]
-    uint16_t *s_smask = reinterpret_cast<uint16_t *>(s_spair + stage_n);               // [stage_n]
-    __shared__ int32_t s_tcnt[16], s_goff[16], s_base[16], s_batch[16], s_nbatch, s_n;
+    const int arena_words = kArenaPerWave * n_bits;
+    uint64_t *s_arena = reinterpret_cast<uint64_t *>(smem_raw); // [arena_words + arena_words / 8]
+    __shared__ int32_t s_tcnt[16], s_goff[16], s_base[16], s_batch[16], s_cur[16], s_nbatch, s_n;
     __shared__ uint64_t s_hi[16];
     const uint32_t bin = blockIdx.x;
     const int32_t e0 = a.b.bin_start[bin], e1 = a.b.bin_start[bin + 1];
@@ -498,56 +520,54 @@ __global__ void __launch_bounds__(1024) bin_sort_kernel(const BinArgs a)
         const uint32_t tx = tx0 + (uint32_t)t % g.bw, ty = ty0 + (uint32_t)t / g.bw;
         const bool in     = t < n_bits && tx < g.tile_w && ty < g.tile_h;
         const size_t gid  = (size_t)img * g.n_tiles + (size_t)ty * g.tile_w + tx;
-        s_tcnt[t]         = in ? a.b.tile_count[gid] : 0;
+        const int n       = in ? a.b.tile_count[gid] : 0;
+        s_tcnt[t]         = n;
         s_goff[t]         = in ? a.isect_offsets[gid] : 0;
         s_hi[t]           = in ? ((((uint64_t)img << g.tile_bits) | ((uint64_t)ty * g.tile_w + tx)) << 32) : 0ull;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { // cut the arena: tile t of batch s_batch[t] sorts at physical word s_base[t]
-        int batch = 0, used = 0;
-        for (int t = 0; t < 16; ++t) {
-            const int n = s_tcnt[t];
-            s_batch[t]  = -1; // empty
-            if (n <= 0) continue;
-            int P = 64;
+        // cut the arena: tile t of batch s_batch[t] sorts at physical word s_base[t] (16 lanes of the first wave)
+        int P = 0;
+        if (n > 0) {
+            P = 64;
             while (P < n) P <<= 1;
-            if (P > arena_words) { s_batch[t] = -2; continue; } // longer than the arena: work-list sort
-            if (used + P > arena_words) { ++batch; used = 0; }
-            s_batch[t] = batch;
-            s_base[t]  = used + (used >> 3);
-            used += P;
         }
-        s_nbatch = batch + 1;
+        const bool big = P > arena_words;
+        if (big) P = 0;
+        int batch = 0, used = 0, my_batch = n > 0 ? 0 : -1, my_base = 0;
+        for (int k = 0; k < 16; ++k) { // every lane replays the greedy cut over the 16 sizes
+            const int Pk = __shfl(P, k, 16);
+            if (Pk == 0) continue;
+            if (used + Pk > arena_words) { ++batch; used = 0; }
+            if (k == t) { my_batch = batch; my_base = used + (used >> 3); }
+            used += Pk;
+        }
+        s_batch[t] = big ? -2 : my_batch;
+        s_base[t]  = my_base;
+        if (t == 15) s_nbatch = batch + 1;
     }
     __syncthreads();
     const int n_batch = s_nbatch;
-    const int my_n = wave < 16 ? s_tcnt[wave] : 0;
     for (int b = 0; b < n_batch; ++b) {
-        const bool mine = wave < n_bits && s_batch[wave] == b; // wave-uniform
-        uint64_t *sw    = s_arena + (mine ? s_base[wave] : 0);
-        int32_t cnt     = 0;
-        for (int32_t cb = e0; cb < e1; cb += stage_n) {
-            const int32_t cn = min(stage_n, e1 - cb);
-            for (int i = threadIdx.x; i < cn; i += n_thr) {
-                s_smask[i] = a.b.e_mask[cb + i];
-                s_spair[i] = a.b.e_pair[cb + i];
+        if (threadIdx.x < 16) s_cur[threadIdx.x] = 0;
+        uint32_t bmask = 0;
+        for (int t = 0; t < n_bits; ++t) bmask |= (s_batch[t] == b) ? (1u << t) : 0u;
+        __syncthreads();
+        // deal every entry to the lists of the tiles in its mask (LDS cursor per tile)
+        for (int32_t e = e0 + (int32_t)threadIdx.x; e < e1; e += n_thr) {
+            uint32_t m = (uint32_t)a.b.e_mask[e] & bmask;
+            if (m == 0u) continue;
+            const uint2 pr     = a.b.e_pair[e];
+            const uint64_t key = ((uint64_t)pr.x << 32) | pr.y;
+            while (m) {
+                const int t = __builtin_ctz(m);
+                m &= m - 1u;
+                const int32_t pos = atomicAdd(&s_cur[t], 1);
+                s_arena[s_base[t] + bn_phys(pos)] = key;
             }
-            __syncthreads();
-            if (mine)
-                for (int i0 = 0; i0 < cn; i0 += 64) {
-                    const int i        = i0 + lane;
-                    const bool has     = i < cn && (((uint32_t)s_smask[i] >> wave) & 1u);
-                    const uint64_t bal = __builtin_amdgcn_ballot_w64(has);
-                    if (has) {
-                        const uint2 pr = s_spair[i];
-                        sw[bn_phys(cnt + (int32_t)__popcll(bal & lt_mask))] = ((uint64_t)pr.x << 32) | pr.y;
-                    }
-                    cnt += (int32_t)__popcll(bal);
-                }
-            __syncthreads();
         }
-        if (mine) {
-            const int n = my_n;
+        __syncthreads();
+        if (wave < n_bits && s_batch[wave] == b) { // one wave per tile: pad, sort, write
+            uint64_t *sw = s_arena + s_base[wave];
+            const int n  = s_tcnt[wave];
             int lp = 6;
             while ((1 << lp) < n) ++lp;
             for (int i = n + lane; i < (1 << lp); i += 64) sw[bn_phys(i)] = ~0ull;
@@ -630,7 +650,7 @@ static bool bin_geometry(BinGeom &g, int64_t rows, uint32_t n_images, uint32_t t
     g.n_chunks    = g.cpi * g.n_images;
     g.cap_entries = cap_entries;
     return g.n_bins_total <= (uint32_t)kBnMaxBins && (uint64_t)g.n_images * g.n_tiles <= kBnMaxTiles && rows < (1ll << 28)
-           && g.bins_x <= 256 && g.bins_y <= 256; // (row slot, bin x, bin y) pairs of kernel D: 9 + 8 + 8 bits
+           && g.bins_x <= 256 && g.bins_y <= 256; // (parked row, bin x, bin y) pairs of kernel D: 10 + 8 + 8 bits
 }
 
 // entries the workspace is sized for: a row costs one entry per bin its tile rectangle overlaps
@@ -726,12 +746,12 @@ extern "C" int gsx_isect_binned_count(const float *means2d, const int32_t *radii
     a.means2d = means2d; a.radii = radii; a.depths = depths; a.conics = conics; a.opacities = opacities;
     a.tile_mask = tile_mask; a.tiles_per_gauss = tiles_per_gauss; a.isect_offsets = isect_offsets; a.n_isects = n_isects;
     const size_t bins_lds = (size_t)a.g.n_bins * sizeof(int32_t);
-    bin_rect_kernel<<<dim3(a.g.n_chunks), dim3(kBnThreads), bins_lds, s>>>(a);
+    bin_rect_kernel<<<dim3(a.g.n_chunks), dim3(kRowThreads), bins_lds, s>>>(a);
     const uint32_t col_groups = (a.g.n_bins + kCsCols - 1) / kCsCols;
     bin_colscan_kernel<<<dim3(col_groups * a.g.n_images), dim3(kCsCols * kCsSegs2), 0, s>>>(a.b.table, a.b.bin_count, a.g.n_bins,
                                                                                              a.g.cpi, col_groups);
     bin_plan_kernel<<<dim3(1), dim3(1024), 0, s>>>(a);
-    bin_scatter_kernel<<<dim3(a.g.n_chunks), dim3(kBnThreads), bins_lds, s>>>(a);
+    bin_scatter_kernel<<<dim3(a.g.n_chunks), dim3(kRowThreads), bins_lds, s>>>(a);
     bin_tiles_kernel<<<dim3(a.g.n_bins_total), dim3(kBnThreads), 0, s>>>(a);
     tile_plan_kernel<<<dim3(1), dim3(1024), 0, s>>>(a);
     return check_launch("isect_binned_count");
@@ -761,7 +781,7 @@ extern "C" int gsx_isect_binned_emit_sort(int64_t rows, uint32_t n_images, uint3
     a.keys_out = reinterpret_cast<uint64_t *>(isect_ids_sorted);
     a.vals_out = flatten_ids_sorted;
     const int n_bits = (int)(a.g.bw * a.g.bh);
-    const size_t sort_lds = (size_t)(kArenaPerWave * n_bits) * 9 + (size_t)(kStagePerWave * n_bits) * 10;
+    const size_t sort_lds = (size_t)(kArenaPerWave * n_bits) * 9;
     static PerDeviceOnce once;
     if (once.first())
         (void)hipFuncSetAttribute((const void *)bin_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
