@@ -82,6 +82,7 @@ struct BinArgs {
     uint64_t *keys_out;
     int32_t *vals_out;
     uint2 *bucketed;
+    uint32_t dbg; // GSX_ISECT_DBG ablation bits (timing experiments only; outputs are wrong when set)
 };
 
 __device__ __forceinline__ void bn_chunk_rows(const BinGeom &g, uint32_t chunk, int64_t &lo, int64_t &hi, uint32_t &img)
@@ -259,8 +260,9 @@ __global__ void __launch_bounds__(1024) bin_plan_kernel(const BinArgs a)
 // the thread that loaded them; a row over several bins parks its ten input words in LDS and pushes one (row, bin) pair per
 // bin on an LDS queue, and the workgroup then shares the pairs out evenly: every unit of work is one walk clipped to one bin.
 constexpr int kDRows  = 2 * kRowThreads; // rows per iteration
-constexpr int kDMulti = 640;             // rows over several bins parked per iteration
-constexpr int kDQueue = 4096;            // (row, bin) pairs per iteration; a row that does not fit is walked by its own thread
+constexpr int kDMulti = 1024;            // rows over several bins parked per round
+constexpr int kDQueue = 6144;            // (row, bin) pairs per round
+constexpr int kDTake  = 128;             // pairs one row may push per round (bounds the serial work of the pushing thread)
 
 __device__ __forceinline__ uint32_t bn_entry(const BinArgs &a, const WalkPrep &p, uint32_t bx, uint32_t by, const uint8_t *tmask,
                                             uint32_t dbits, int64_t r, int32_t *s_cur)
@@ -269,13 +271,17 @@ __device__ __forceinline__ uint32_t bn_entry(const BinArgs &a, const WalkPrep &p
     const int cx0 = (int)(bx * g.bw), cy0 = (int)(by * g.bh);
     const int cx1 = min(cx0 + (int)g.bw, (int)g.tile_w), cy1 = min(cy0 + (int)g.bh, (int)g.tile_h);
     uint32_t mask = 0;
+    if (a.dbg & 4u) mask = 1u;
+    else
     walk_clipped(p, g.tile_size, cx0, cy0, cx1, cy1, [&](int x, int y) {
         if (tmask && !tmask[(size_t)y * g.tile_w + x]) return;
         mask |= 1u << ((y - cy0) * (int)g.bw + (x - cx0));
     });
     const int32_t slot = atomicAdd(&s_cur[by * g.bins_x + bx], 1);
+    if (!(a.dbg & 8u)) {
     a.b.e_pair[slot]   = make_uint2(dbits, (uint32_t)r);
     a.b.e_mask[slot]   = (uint16_t)mask;
+    }
     return (uint32_t)__popc(mask);
 }
 
@@ -298,65 +304,80 @@ __global__ void __launch_bounds__(kRowThreads) bin_scatter_kernel(const BinArgs 
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)img * g.n_tiles : nullptr;
     constexpr int kU = kDRows / kRowThreads;
     for (int64_t base = lo; base < hi; base += kDRows) {
-        if (threadIdx.x == 0) { s_qn = 0; s_qlim = kDQueue; s_mn = 0; }
         BnRow q[kU];
-        uint32_t dbits[kU];
+        uint32_t dbits[kU], rect[kU], wh[kU], done[kU]; // bin rectangle of a row over several bins (wh == 0: nothing pending)
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int64_t r = base + u * kRowThreads + threadIdx.x;
             q[u].rx = q[u].ry = 0.0f;
-            dbits[u] = 0;
+            dbits[u] = rect[u] = wh[u] = done[u] = 0;
             if (r < hi) {
                 q[u]     = bn_load_row(a, r, has_conic);
                 dbits[u] = __float_as_uint(a.depths[r]);
             }
             s_tpg[u * kRowThreads + threadIdx.x] = 0;
         }
-        __syncthreads(); // s_cur (first iteration), s_qn, s_tpg
+        __syncthreads(); // s_cur (first iteration), s_tpg
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
+        for (int u = 0; u < kU; ++u) { // rows inside one bin: walked here
             const int64_t r = base + u * kRowThreads + threadIdx.x;
             if (r >= hi) continue;
-            const int slot   = u * kRowThreads + (int)threadIdx.x;
             const WalkPrep p = bn_prepare(q[u], has_conic, g);
             if (!p.any) continue;
             const uint32_t bx0 = (uint32_t)p.x0 / g.bw, bx1 = ((uint32_t)p.x1 + g.bw - 1) / g.bw;
             const uint32_t by0 = (uint32_t)p.y0 / g.bh, by1 = ((uint32_t)p.y1 + g.bh - 1) / g.bh;
-            const uint32_t area = (bx1 - bx0) * (by1 - by0);
-            if (area == 1u) {
-                s_tpg[slot] = (int32_t)bn_entry(a, p, bx0, by0, tmask, dbits[u], r, s_cur);
-                continue;
-            }
-            const int32_t ms   = atomicAdd(&s_mn, 1);
-            const int32_t qpos = ms < kDMulti ? atomicAdd(&s_qn, (int32_t)area) : kDQueue;
-            if (ms < kDMulti && qpos + (int32_t)area <= kDQueue) {
-                float *w = s_row[ms];
-                w[0] = q[u].mx; w[1] = q[u].my; w[2] = q[u].rx; w[3] = q[u].ry; w[4] = q[u].A; w[5] = q[u].B; w[6] = q[u].C;
-                w[7] = q[u].op; w[8] = __uint_as_float(dbits[u]); w[9] = __int_as_float(slot);
-                int32_t k = qpos;
-                for (uint32_t by = by0; by < by1; ++by)
-                    for (uint32_t bx = bx0; bx < bx1; ++bx) s_q[k++] = (uint32_t)ms | (bx << 10) | (by << 18);
-            } else { // no room (a screen of giant Gaussians): this thread walks all of the row's bins itself
-                if (ms < kDMulti) atomicMin(&s_qlim, qpos); // pairs are valid below the first reservation that did not fit
-                int32_t n = 0;
-                for (uint32_t by = by0; by < by1; ++by)
-                    for (uint32_t bx = bx0; bx < bx1; ++bx) n += (int32_t)bn_entry(a, p, bx, by, tmask, dbits[u], r, s_cur);
-                s_tpg[slot] = n;
+            if ((bx1 - bx0) * (by1 - by0) == 1u)
+                s_tpg[u * kRowThreads + threadIdx.x] = (int32_t)bn_entry(a, p, bx0, by0, tmask, dbits[u], r, s_cur);
+            else {
+                rect[u] = bx0 | (by0 << 8);
+                wh[u]   = (bx1 - bx0) | ((by1 - by0) << 16);
             }
         }
-        __syncthreads();
-        const int32_t n_q = min(s_qn, s_qlim);
-        for (int32_t k = (int32_t)threadIdx.x; k < n_q; k += kRowThreads) {
-            const uint32_t pr = s_q[k];
-            const float *w    = s_row[pr & 1023u];
-            BnRow qq;
-            qq.mx = w[0]; qq.my = w[1]; qq.rx = w[2]; qq.ry = w[3]; qq.A = w[4]; qq.B = w[5]; qq.C = w[6]; qq.op = w[7];
-            const int slot   = __float_as_int(w[9]);
-            const WalkPrep p = bn_prepare(qq, has_conic, g);
-            const uint32_t n = bn_entry(a, p, (pr >> 10) & 255u, pr >> 18, tmask, __float_as_uint(w[8]), base + slot, s_cur);
-            if (n) atomicAdd(&s_tpg[slot], (int32_t)n);
+        // rows over several bins: rounds of { park the row, push up to kDTake (row, bin) pairs } / { drain the queue together }
+        for (;;) {
+            if (threadIdx.x == 0) { s_qn = 0; s_qlim = kDQueue; s_mn = 0; }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                if (wh[u] == 0u) continue;
+                const uint32_t w = wh[u] & 0xFFFFu, h = wh[u] >> 16;
+                const uint32_t rem = w * h - done[u];
+                const int32_t take = (int32_t)min(rem, (uint32_t)kDTake);
+                const int32_t ms   = atomicAdd(&s_mn, 1);
+                if (ms >= kDMulti) continue; // next round
+                const int32_t qpos = atomicAdd(&s_qn, take);
+                if (qpos + take > kDQueue) {
+                    atomicMin(&s_qlim, qpos); // pairs are valid below the first reservation that did not fit
+                    continue;
+                }
+                float *rw = s_row[ms];
+                rw[0] = q[u].mx; rw[1] = q[u].my; rw[2] = q[u].rx; rw[3] = q[u].ry; rw[4] = q[u].A; rw[5] = q[u].B; rw[6] = q[u].C;
+                rw[7] = q[u].op; rw[8] = __uint_as_float(dbits[u]); rw[9] = __int_as_float(u * kRowThreads + (int)threadIdx.x);
+                const uint32_t bx0 = rect[u] & 255u, by0 = (rect[u] >> 8) & 255u;
+                for (int32_t k = 0; k < take; ++k) {
+                    const uint32_t idx = done[u] + (uint32_t)k;
+                    s_q[qpos + k]      = (uint32_t)ms | ((bx0 + idx % w) << 10) | ((by0 + idx / w) << 18);
+                }
+                done[u] += (uint32_t)take;
+                if (done[u] == w * h) wh[u] = 0u;
+            }
+            __syncthreads();
+            const int32_t n_q = min(s_qn, s_qlim);
+            for (int32_t k = (int32_t)threadIdx.x; k < n_q; k += kRowThreads) {
+                const uint32_t pr = s_q[k];
+                const float *rw   = s_row[pr & 1023u];
+                BnRow qq;
+                qq.mx = rw[0]; qq.my = rw[1]; qq.rx = rw[2]; qq.ry = rw[3]; qq.A = rw[4]; qq.B = rw[5]; qq.C = rw[6]; qq.op = rw[7];
+                const int slot   = __float_as_int(rw[9]);
+                const WalkPrep p = bn_prepare(qq, has_conic, g);
+                const uint32_t n = bn_entry(a, p, (pr >> 10) & 255u, pr >> 18, tmask, __float_as_uint(rw[8]), base + slot, s_cur);
+                if (n) atomicAdd(&s_tpg[slot], (int32_t)n);
+            }
+            bool pending = false;
+#pragma unroll
+            for (int u = 0; u < kU; ++u) pending |= wh[u] != 0u;
+            if (!__syncthreads_or(pending)) break; // also orders this round's reads of s_q / s_row before the next round
         }
-        __syncthreads();
         if (a.tiles_per_gauss) {
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
@@ -364,7 +385,7 @@ __global__ void __launch_bounds__(kRowThreads) bin_scatter_kernel(const BinArgs 
                 if (r < hi) a.tiles_per_gauss[r] = s_tpg[u * kRowThreads + threadIdx.x];
             }
         }
-        __syncthreads(); // s_tpg / s_row / s_q are rewritten by the next iteration
+        __syncthreads(); // s_tpg is rewritten by the next iteration
     }
 }
 
@@ -552,7 +573,7 @@ __global__ void __launch_bounds__(1024, 8) bin_sort_kernel(const BinArgs a)
         for (int t = 0; t < n_bits; ++t) bmask |= (s_batch[t] == b) ? (1u << t) : 0u;
         __syncthreads();
         // deal every entry to the lists of the tiles in its mask (LDS cursor per tile)
-        for (int32_t e = e0 + (int32_t)threadIdx.x; e < e1; e += n_thr) {
+        for (int32_t e = e0 + (int32_t)threadIdx.x; e < e1 && !(a.dbg & 2u); e += n_thr) {
             uint32_t m = (uint32_t)a.b.e_mask[e] & bmask;
             if (m == 0u) continue;
             const uint2 pr     = a.b.e_pair[e];
@@ -572,7 +593,7 @@ __global__ void __launch_bounds__(1024, 8) bin_sort_kernel(const BinArgs a)
             while ((1 << lp) < n) ++lp;
             for (int i = n + lane; i < (1 << lp); i += 64) sw[bn_phys(i)] = ~0ull;
             wave_lds_sync();
-            bn_bitonic<64>(sw, lp, lane, [] { wave_lds_sync(); });
+            if (!(a.dbg & 1u)) bn_bitonic<64>(sw, lp, lane, [] { wave_lds_sync(); });
             const int64_t off = s_goff[wave];
             const uint64_t hi = s_hi[wave];
             for (int i = lane; i < n; i += 64) {
@@ -713,6 +734,7 @@ static int binned_setup(const char *fn, BinArgs &a, int64_t rows, uint32_t n_ima
                 (long long)rows, n_images);
     GSX_REQUIRE(bin_geometry(a.g, rows, n_images, tile_size, tile_w, tile_h, bin_cap_entries(rows)),
                 "%s: %u images x %u x %u tiles not supported", fn, n_images, tile_w, tile_h);
+    if (const char *e = getenv("GSX_ISECT_DBG")) a.dbg = (uint32_t)atoi(e);
     unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
     if (ws == nullptr || (base - reinterpret_cast<unsigned char *>(ws)) + bin_layout(a.g, base, &a.b) > ws_bytes) {
         set_last_error("%s: count workspace too small", fn);
