@@ -461,6 +461,26 @@ __device__ __forceinline__ void bn_cmpx(uint64_t &x, uint64_t &y, bool up)
 // traffic between the steps (a workgroup barrier, or nothing but a compiler fence when one wave owns the array).
 // Phases k = 2, 4, 8 run in registers on 8 consecutive words; every later phase is cut into groups of three strides for
 // which a thread owns all 8 words (see tile_sort.hip: 512 entries in 16 round trips instead of 45).
+template <int G, int NT>
+__device__ __forceinline__ void bn_group(uint64_t *s, int P, int k, int lj, int tid)
+{
+    constexpr int R = 1 << G;
+    for (int t = tid; t < (P >> G); t += NT) {
+        const int i   = ((t >> lj) << (lj + G)) | (t & ((1 << lj) - 1));
+        const bool up = (i & k) == 0;
+        uint64_t e[R];
+#pragma unroll
+        for (int b = 0; b < R; ++b) e[b] = s[bn_phys(i | (b << lj))];
+#pragma unroll
+        for (int q = G - 1; q >= 0; --q)
+#pragma unroll
+            for (int b = 0; b < R; ++b)
+                if (!(b & (1 << q))) bn_cmpx(e[b], e[b | (1 << q)], up);
+#pragma unroll
+        for (int b = 0; b < R; ++b) s[bn_phys(i | (b << lj))] = e[b];
+    }
+}
+
 template <int NT, typename Sync>
 __device__ __forceinline__ void bn_bitonic(uint64_t *s, int lp, int tid, Sync &&SYNC)
 {
@@ -488,30 +508,9 @@ __device__ __forceinline__ void bn_bitonic(uint64_t *s, int lp, int tid, Sync &&
         for (int top = lk - 1; top >= 0;) {
             const int gsz = top + 1 < 3 ? top + 1 : 3;
             const int lj  = top - gsz + 1;
-            const int R   = 1 << gsz;
-            for (int t = tid; t < (P >> gsz); t += NT) {
-                const int i   = ((t >> lj) << (lj + gsz)) | (t & ((1 << lj) - 1));
-                const bool up = (i & k) == 0;
-                uint64_t e[8];
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (b < R) e[b] = s[bn_phys(i | (b << lj))];
-                if (gsz == 3) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) bn_cmpx(e[b], e[b + 4], up);
-                }
-                if (gsz >= 2) {
-#pragma unroll
-                    for (int b = 0; b < 8; ++b)
-                        if (b < R && !(b & 2)) bn_cmpx(e[b], e[b | 2], up);
-                }
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (b < R && !(b & 1)) bn_cmpx(e[b], e[b | 1], up);
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (b < R) s[bn_phys(i | (b << lj))] = e[b];
-            }
+            if (gsz == 3) bn_group<3, NT>(s, P, k, lj, tid);
+            else if (gsz == 2) bn_group<2, NT>(s, P, k, lj, tid);
+            else bn_group<1, NT>(s, P, k, lj, tid);
             SYNC();
             top -= gsz;
         }
@@ -520,7 +519,7 @@ __device__ __forceinline__ void bn_bitonic(uint64_t *s, int lp, int tid, Sync &&
 
 constexpr int kArenaPerWave = 512; // arena sort words per tile-wave: 16 waves -> 8192 words (+ 1/8 padding) = 72 KiB
 
-__global__ void __launch_bounds__(1024, 8) bin_sort_kernel(const BinArgs a)
+__global__ void __launch_bounds__(1024) bin_sort_kernel(const BinArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const BinGeom &g = a.g;
