@@ -461,23 +461,35 @@ __device__ __forceinline__ void bn_cmpx(uint64_t &x, uint64_t &y, bool up)
 // traffic between the steps (a workgroup barrier, or nothing but a compiler fence when one wave owns the array).
 // Phases k = 2, 4, 8 run in registers on 8 consecutive words; every later phase is cut into groups of three strides for
 // which a thread owns all 8 words (see tile_sort.hip: 512 entries in 16 round trips instead of 45).
+// ascending compare-exchange: the select masks come straight from the vector compare (a mask that passes through the scalar
+// unit first - e.g. xor-ed with a per-lane direction flag - stalls every dependent v_cndmask on gfx950)
+__device__ __forceinline__ void bn_cmpx_up(uint64_t &x, uint64_t &y)
+{
+    const bool sw    = x > y;
+    const uint64_t t = sw ? y : x;
+    y                = sw ? x : y;
+    x                = t;
+}
+
 template <int G, int NT>
-__device__ __forceinline__ void bn_group(uint64_t *s, int P, int k, int lj, int tid)
+__device__ __forceinline__ void bn_group(uint64_t *s, int P, int lk, int lj, int tid)
 {
     constexpr int R = 1 << G;
     for (int t = tid; t < (P >> G); t += NT) {
-        const int i   = ((t >> lj) << (lj + G)) | (t & ((1 << lj) - 1));
-        const bool up = (i & k) == 0;
+        const int i = ((t >> lj) << (lj + G)) | (t & ((1 << lj) - 1));
+        // a descending block is an ascending one on the complemented words: m = all ones where (i & k) != 0
+        const uint32_t m32 = 0u - (((uint32_t)i >> lk) & 1u);
+        const uint64_t m   = ((uint64_t)m32 << 32) | m32;
         uint64_t e[R];
 #pragma unroll
-        for (int b = 0; b < R; ++b) e[b] = s[bn_phys(i | (b << lj))];
+        for (int b = 0; b < R; ++b) e[b] = s[bn_phys(i | (b << lj))] ^ m;
 #pragma unroll
         for (int q = G - 1; q >= 0; --q)
 #pragma unroll
             for (int b = 0; b < R; ++b)
-                if (!(b & (1 << q))) bn_cmpx(e[b], e[b | (1 << q)], up);
+                if (!(b & (1 << q))) bn_cmpx_up(e[b], e[b | (1 << q)]);
 #pragma unroll
-        for (int b = 0; b < R; ++b) s[bn_phys(i | (b << lj))] = e[b];
+        for (int b = 0; b < R; ++b) s[bn_phys(i | (b << lj))] = e[b] ^ m;
     }
 }
 
@@ -504,13 +516,12 @@ __device__ __forceinline__ void bn_bitonic(uint64_t *s, int lp, int tid, Sync &&
     }
     SYNC();
     for (int lk = 4; lk <= lp; ++lk) {
-        const int k = 1 << lk;
         for (int top = lk - 1; top >= 0;) {
             const int gsz = top + 1 < 3 ? top + 1 : 3;
             const int lj  = top - gsz + 1;
-            if (gsz == 3) bn_group<3, NT>(s, P, k, lj, tid);
-            else if (gsz == 2) bn_group<2, NT>(s, P, k, lj, tid);
-            else bn_group<1, NT>(s, P, k, lj, tid);
+            if (gsz == 3) bn_group<3, NT>(s, P, lk, lj, tid);
+            else if (gsz == 2) bn_group<2, NT>(s, P, lk, lj, tid);
+            else bn_group<1, NT>(s, P, lk, lj, tid);
             SYNC();
             top -= gsz;
         }

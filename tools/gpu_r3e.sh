@@ -7,6 +7,12 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
+timeout 120 tools/bin/issue_rate 29 > $OUT/issue_rate_masks.json 2>/dev/null; python3 -c "
+import json,sys
+d=json.load(open("$OUT/issue_rate_masks.json"))
+for c in d["cases"]:
+    print(c["op"],c["chain"],c["waves_per_simd"],c["counter_ticks_per_instr"])
+"
 timeout 900 python tools/gpu_isect_check.py check > $OUT/isect_check.log 2>&1; echo "check rc=$?"; grep -v "^OK" $OUT/isect_check.log | tail -20
 timeout 600 python tools/gpu_isect_check.py bench > $OUT/isect_bench_c3.jsonl 2> $OUT/isect_bench_c3.err; echo "bench c3 rc=$?"; cat $OUT/isect_bench_c3.jsonl
 for dbg in 1 2 3 4 8 12; do

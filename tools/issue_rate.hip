@@ -15,13 +15,14 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum Op { FMA, PK_FMA, MUL, ADD, CNDMASK, EXP, RCP, MAD_U32_U24, ADD_U32, LSHL_ADD, CMP_BALLOT, DS_ADD_F32, DS_ADD_F32_SAME, DS_READ_B64, DS_READ_B128, DS_WRITE_B64, S_ADD, S_AND_B64, MIX_V_S, DPP_ADD, READLANE, CNDMASK_SGPR, CMP_E64, CMP_CNDMASK, DS_ADD_U32, DS_ADD_RTN_U32, DS_BPERMUTE, PERMLANE32_SWAP, GLOBAL_ATOMIC_ADD, N_OPS };
+enum Op { FMA, PK_FMA, MUL, ADD, CNDMASK, EXP, RCP, MAD_U32_U24, ADD_U32, LSHL_ADD, CMP_BALLOT, DS_ADD_F32, DS_ADD_F32_SAME, DS_READ_B64, DS_READ_B128, DS_WRITE_B64, S_ADD, S_AND_B64, MIX_V_S, DPP_ADD, READLANE, CNDMASK_SGPR, CMP_E64, CMP_CNDMASK, DS_ADD_U32, DS_ADD_RTN_U32, DS_BPERMUTE, PERMLANE32_SWAP, GLOBAL_ATOMIC_ADD, SALU_VCC_CND, SALU_SGPR_CND, VCMP_SGPR_CND, VCMP_SXOR_CND, N_OPS };
 static const char *kNames[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_add_f32", "v_cndmask_b32", "v_exp_f32", "v_rcp_f32",
                                     "v_mad_u32_u24", "v_add_u32", "v_lshl_add_u32", "v_cmp+s_and(ballot)", "ds_add_f32(distinct)",
                                     "ds_add_f32(same addr)", "ds_read_b64", "ds_read_b128", "ds_write_b64", "s_add_u32", "s_and_b64",
                                     "v_fma_f32+s_add_u32", "v_add_f32_dpp", "v_readlane_b32", "v_cndmask_b32_e64(sgpr pair)", "v_cmp_lt_f32_e64->sgpr",
                                     "v_cmp(vcc)+v_cndmask(vcc)", "ds_add_u32(distinct)", "ds_add_rtn_u32(distinct)", "ds_bpermute_b32", "v_permlane32_swap_b32",
-                                    "global_atomic_add_u32(no return, distinct dwords)"};
+                                    "global_atomic_add_u32(no return, distinct dwords)", "s_and_b64(vcc)+v_cndmask(vcc)", "s_and_b64(sgpr)+v_cndmask_e64(sgpr)",
+                                    "v_cmp_e64(sgpr)+v_cndmask_e64(sgpr)", "v_cmp_e64(sgpr)+s_xor_b64+v_cndmask_e64(sgpr)"};
 
 // One asm statement holds the whole 64-instruction block: the compiler cannot see into it, so it neither reorders it nor
 // pads it with s_nop (it does pad BETWEEN separate asm statements, which would be measured as issue slots).
@@ -67,6 +68,10 @@ static const char *kNames[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v
 #define I_BPERM(r) "ds_bpermute_b32 %" #r ", %10, %" #r "\n"
 #define I_PL32(r) "v_permlane32_swap_b32 %" #r ", %8\n"
 #define I_GATOM(r) "global_atomic_add %10, %9, off\n"
+#define I_SVCC(r) "s_and_b64 vcc, vcc, exec\n v_cndmask_b32 %" #r ", %" #r ", %8, vcc\n"
+#define I_SSGPR(r) "s_and_b64 %10, %10, exec\n v_cndmask_b32_e64 %" #r ", %" #r ", %8, %10\n"
+#define I_VSGPR(r) "v_cmp_lt_f32_e64 %10, %" #r ", %8\n v_cndmask_b32_e64 %" #r ", %" #r ", %9, %10\n"
+#define I_VXOR(r) "v_cmp_lt_f32_e64 %10, %" #r ", %8\n s_xor_b64 %10, %10, exec\n v_cndmask_b32_e64 %" #r ", %" #r ", %9, %10\n"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -122,6 +127,10 @@ __global__ void __launch_bounds__(1024) rate_kernel(int iters, uint64_t *cycles,
         if (OP == DS_ADD_RTN_U32) asm volatile(IND64(I_DSADDRTN) "s_waitcnt lgkmcnt(0)\n" : UREGS, "+v"(a), "+v"(c), "+v"(saddr) : : "memory");
         if (OP == DS_BPERMUTE) asm volatile(IND64(I_BPERM) "s_waitcnt lgkmcnt(0)\n" : UREGS, "+v"(a), "+v"(c), "+v"(saddr) : : "memory");
         if (OP == PERMLANE32_SWAP) { if (DEP) asm volatile(DEP64(I_PL32) : UREGS, "+v"(c) : : ); else asm volatile(IND64(I_PL32) : UREGS, "+v"(c) : : ); }
+        if (OP == SALU_VCC_CND) { if (DEP) asm volatile(DEP64(I_SVCC) : VREGS, "+v"(a), "+v"(b) : : "vcc", "scc"); else asm volatile(IND64(I_SVCC) : VREGS, "+v"(a), "+v"(b) : : "vcc", "scc"); }
+        if (OP == SALU_SGPR_CND) { if (DEP) asm volatile(DEP64(I_SSGPR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : "scc"); else asm volatile(IND64(I_SSGPR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : "scc"); }
+        if (OP == VCMP_SGPR_CND) { if (DEP) asm volatile(DEP64(I_VSGPR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : ); else asm volatile(IND64(I_VSGPR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : ); }
+        if (OP == VCMP_SXOR_CND) { if (DEP) asm volatile(DEP64(I_VXOR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : "scc"); else asm volatile(IND64(I_VXOR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : "scc"); }
         if (OP == GLOBAL_ATOMIC_ADD) asm volatile(DEP64(I_GATOM) "s_waitcnt vmcnt(0)\n" : UREGS, "+v"(a), "+v"(c), "+v"(gaddr) : : "memory");
     }
     const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
@@ -167,7 +176,7 @@ static void run_op(std::string &out, bool &first)
             double mc = 0, mr = 0;
             for (int i = 0; i < n_waves; ++i) { mc += (double)hc[i]; mr += (double)hr[i]; }
             mc /= n_waves; mr /= n_waves;
-            const double instr = (double)iters * 64 * ((OP == MIX_V_S || OP == CMP_BALLOT || OP == CMP_CNDMASK || (OP == S_ADD && !dep)) ? 2 : 1);
+            const double instr = (double)iters * 64 * (OP == VCMP_SXOR_CND ? 3 : (OP == MIX_V_S || OP == CMP_BALLOT || OP == CMP_CNDMASK || OP == SALU_VCC_CND || OP == SALU_SGPR_CND || OP == VCMP_SGPR_CND || (OP == S_ADD && !dep)) ? 2 : 1);
             const double ns = mr * 10.0; // 100 MHz real-time counter
             char buf[512];
             snprintf(buf, sizeof buf,
@@ -181,15 +190,17 @@ static void run_op(std::string &out, bool &first)
     hipFree(cyc); hipFree(real); hipFree(sink); hipFree(gbuf);
 }
 
+static int g_first_op = 0;
 template <int OP>
 static void run_all(std::string &out, bool &first)
 {
-    run_op<OP>(out, first);
+    if (OP >= g_first_op) run_op<OP>(out, first);
     if constexpr (OP + 1 < N_OPS) run_all<OP + 1>(out, first);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1) g_first_op = atoi(argv[1]);
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     int clk_khz = 0;
