@@ -12,13 +12,13 @@
 //   A  bin_rect      per row: the walk's tile rectangle (walk_prepare) -> rectangle of bins; LDS histogram of bins per chunk
 //                    of rows -> table[chunk][bin]
 //   B  bin_colscan   running sum over an image's chunks per bin (in place) + bin totals
-//   C  bin_plan      (the last workgroup of B) scan of the bin totals -> bin_start; capacity check
+//   C  bin_plan      one workgroup: scan of the bin totals -> bin_start; capacity check
 //   D  bin_scatter   per row again (its data is in registers: no gather): for every overlapped bin the walk CLIPPED to the
 //                    bin (walk_clipped: only the slabs inside it) -> 16-bit mask of the bin's tiles the Gaussian touches;
 //                    entry = (depth, row) + mask written at an LDS cursor (bin_start + chunk prefix); tiles_per_gauss.
 //                    Rows over several bins are shared out over the workgroup as (row, bin) pairs through an LDS queue.
 //   E  bin_tiles     one workgroup per bin: per-tile counts from the masks (wave ballots) -> tile_count
-//   F  tile_plan     (the last workgroup of E) scan of the tile counts -> isect_offsets, n_isects (pinned host word)
+//   F  tile_plan     one workgroup: scan of the tile counts -> isect_offsets, n_isects (pinned host word)
 //   after the host allocated the exact-length outputs
 //   G  bin_sort      one workgroup per bin: every entry is dealt to the LDS lists of the tiles in its mask (LDS cursors:
 //                    integer LDS atomics run at the rate of LDS writes on gfx950), then ONE WAVE PER TILE sorts its list
@@ -40,11 +40,12 @@
 namespace gsx {
 
 constexpr int kRowThreads     = 1024;  // kernels A, D (row-major)
+constexpr int kBnThreads      = 256;   // kernel E
 constexpr int kBnMaxBins      = 16384; // bins in total (images x bins per image)
 constexpr uint32_t kBnMaxTiles = 36864;
 
 struct BinHeader { // device memory
-    int32_t overflow, n_entries, big_count, done_b, done_e, pad[3]; // done_*: finished workgroups of kernels B / E
+    int32_t overflow, n_entries, big_count, pad[5];
 };
 
 struct BinGeom {
@@ -154,12 +155,40 @@ __global__ void __launch_bounds__(kRowThreads) bin_rect_kernel(const BinArgs a)
     __syncthreads();
     int32_t *out = a.b.table + (int64_t)blockIdx.x * g.n_bins;
     for (uint32_t i = threadIdx.x; i < g.n_bins; i += kRowThreads) out[i] = s_hist[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.b.hdr->done_b = 0; // kernel B counts its finished workgroups here
 }
 
 // ---- B: exclusive running sum over an image's chunks for every (image, bin), in place; totals[bin] ---------------------
 // The table is short and wide in the wrong direction (hundreds of chunks x a few hundred bins): 32 bins x 32 chunk segments
 // per workgroup, two passes over a segment of ~cpi / 32 entries.
+constexpr int kCsCols = 32, kCsSegs2 = 32;
+__global__ void __launch_bounds__(kCsCols *kCsSegs2) bin_colscan_kernel(int32_t *table, int32_t *totals, uint32_t n_cols,
+                                                                        uint32_t cpi, uint32_t col_groups)
+{
+    __shared__ int32_t s_seg[kCsSegs2][kCsCols + 1];
+    const uint32_t img = blockIdx.x / col_groups, cg = blockIdx.x % col_groups;
+    const uint32_t lane_c = threadIdx.x % kCsCols, seg = threadIdx.x / kCsCols;
+    const uint32_t c      = cg * kCsCols + lane_c;
+    const bool live       = c < n_cols;
+    const uint32_t per    = (cpi + kCsSegs2 - 1) / kCsSegs2;
+    const uint32_t r0 = seg * per, r1 = min(r0 + per, cpi);
+    int32_t *col = table + (int64_t)img * cpi * n_cols + c;
+    int32_t sum  = 0;
+    if (live)
+        for (uint32_t r = r0; r < r1; ++r) sum += col[(int64_t)r * n_cols];
+    s_seg[seg][lane_c] = sum;
+    __syncthreads();
+    int32_t run = 0;
+    for (uint32_t k = 0; k < seg; ++k) run += s_seg[k][lane_c];
+    if (live) {
+        for (uint32_t r = r0; r < r1; ++r) {
+            const int32_t v           = col[(int64_t)r * n_cols];
+            col[(int64_t)r * n_cols] = run;
+            run += v;
+        }
+        if (seg == kCsSegs2 - 1) totals[(int64_t)img * n_cols + c] = run;
+    }
+}
+
 // ---- one-workgroup exclusive scan (1024 threads, thread-contiguous runs; runs of <= 16 stay in registers) -------------
 __device__ __forceinline__ int64_t block_scan_1024(const int32_t *in, int32_t *out, uint32_t n, int64_t *s_part)
 {
@@ -209,50 +238,10 @@ __device__ __forceinline__ int64_t block_scan_1024(const int32_t *in, int32_t *o
     return total;
 }
 
-constexpr int kCsCols = 32, kCsSegs2 = 32;
-__device__ __forceinline__ void bin_plan(const BinArgs &a, int64_t *s_part);
-__global__ void __launch_bounds__(kCsCols *kCsSegs2) bin_colscan_kernel(const BinArgs a, uint32_t col_groups)
+// ---- C: bin starts --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) bin_plan_kernel(const BinArgs a)
 {
-    __shared__ int32_t s_seg[kCsSegs2][kCsCols + 1];
     __shared__ int64_t s_part[16];
-    __shared__ int32_t s_last;
-    int32_t *table = a.b.table, *totals = a.b.bin_count;
-    const uint32_t n_cols = a.g.n_bins, cpi = a.g.cpi;
-    const uint32_t img = blockIdx.x / col_groups, cg = blockIdx.x % col_groups;
-    const uint32_t lane_c = threadIdx.x % kCsCols, seg = threadIdx.x / kCsCols;
-    const uint32_t c      = cg * kCsCols + lane_c;
-    const bool live       = c < n_cols;
-    const uint32_t per    = (cpi + kCsSegs2 - 1) / kCsSegs2;
-    const uint32_t r0 = seg * per, r1 = min(r0 + per, cpi);
-    int32_t *col = table + (int64_t)img * cpi * n_cols + c;
-    int32_t sum  = 0;
-    if (live)
-        for (uint32_t r = r0; r < r1; ++r) sum += col[(int64_t)r * n_cols];
-    s_seg[seg][lane_c] = sum;
-    __syncthreads();
-    int32_t run = 0;
-    for (uint32_t k = 0; k < seg; ++k) run += s_seg[k][lane_c];
-    if (live) {
-        for (uint32_t r = r0; r < r1; ++r) {
-            const int32_t v           = col[(int64_t)r * n_cols];
-            col[(int64_t)r * n_cols] = run;
-            run += v;
-        }
-        if (seg == kCsSegs2 - 1) totals[(int64_t)img * n_cols + c] = run;
-    }
-    // C: the workgroup that finishes last scans the bin totals (saves a launch of a one-workgroup kernel)
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&a.b.hdr->done_b, 1) == (int32_t)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    bin_plan(a, s_part);
-}
-
-// ---- C: bin starts (run by the last workgroup of kernel B) ----------------------------------------------------------------
-__device__ __forceinline__ void bin_plan(const BinArgs &a, int64_t *s_part)
-{
     const BinGeom &g = a.g;
     const uint32_t nb = g.n_bins_total;
     const int64_t n_entries = block_scan_1024(a.b.bin_count, a.b.bin_start, nb, s_part);
@@ -262,7 +251,6 @@ __device__ __forceinline__ void bin_plan(const BinArgs &a, int64_t *s_part)
         a.b.hdr->overflow  = overflow ? 1 : 0;
         a.b.hdr->n_entries = overflow ? 0 : (int32_t)n_entries;
         a.b.hdr->big_count = 0;
-        a.b.hdr->done_e    = 0;
     }
 }
 
@@ -401,20 +389,12 @@ __global__ void __launch_bounds__(kRowThreads) bin_scatter_kernel(const BinArgs 
     }
 }
 
-// ---- E: per-tile counts of one bin; F (last workgroup): offsets, n_isects ------------------------------------------------
-__global__ void __launch_bounds__(1024) bin_tiles_kernel(const BinArgs a)
+// ---- E: per-tile counts of one bin --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBnThreads) bin_tiles_kernel(const BinArgs a)
 {
     __shared__ int32_t s_cnt[16];
-    __shared__ int64_t s_part[16];
-    __shared__ int32_t s_last;
     const BinGeom &g = a.g;
-    if (a.b.hdr->overflow) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            __threadfence_system();
-            *a.n_isects = GSX_ISECT_RETRY; // the caller reruns the Gaussian-major path (gsx_isect_binned_count's contract)
-        }
-        return;
-    }
+    if (a.b.hdr->overflow) return;
     const uint32_t bin = blockIdx.x;
     const int32_t e0 = a.b.bin_start[bin], e1 = a.b.bin_start[bin + 1];
     const int lane = (int)(threadIdx.x & 63u);
@@ -422,17 +402,17 @@ __global__ void __launch_bounds__(1024) bin_tiles_kernel(const BinArgs a)
     if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     int32_t mine = 0; // lane t < n_bits: entries seen by this wave that touch tile t
-    constexpr int kU = 4;
-    for (int32_t base = e0; base < e1; base += 1024 * kU) {
+    constexpr int kU = 8;
+    for (int32_t base = e0; base < e1; base += kBnThreads * kU) {
         uint32_t m[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-            const int32_t e = base + u * 1024 + (int32_t)threadIdx.x;
+            const int32_t e = base + u * kBnThreads + (int32_t)threadIdx.x;
             m[u]            = e < e1 ? (uint32_t)a.b.e_mask[e] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-            if (base + u * 1024 + (int32_t)(threadIdx.x & ~63u) >= e1) break; // wave-uniform
+            if (base + u * kBnThreads >= e1) break; // wave-uniform
             for (int t = 0; t < n_bits; ++t) {
                 const uint64_t b = __builtin_amdgcn_ballot_w64((m[u] >> t) & 1u);
                 if (lane == t) mine += (int32_t)__popcll(b);
@@ -446,13 +426,20 @@ __global__ void __launch_bounds__(1024) bin_tiles_kernel(const BinArgs a)
         const uint32_t tx = (lb % g.bins_x) * g.bw + threadIdx.x % g.bw, ty = (lb / g.bins_x) * g.bh + threadIdx.x / g.bw;
         if (tx < g.tile_w && ty < g.tile_h) a.b.tile_count[(size_t)img * g.n_tiles + (size_t)ty * g.tile_w + tx] = s_cnt[threadIdx.x];
     }
-    // F: the workgroup that finishes last scans the tile counts
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&a.b.hdr->done_e, 1) == (int32_t)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
+}
+
+// ---- F: offsets, n_isects -----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) tile_plan_kernel(const BinArgs a)
+{
+    __shared__ int64_t s_part[16];
+    const BinGeom &g = a.g;
+    if (a.b.hdr->overflow) {
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            *a.n_isects = GSX_ISECT_RETRY; // the caller reruns the Gaussian-major path (gsx_isect_binned_count's contract)
+        }
+        return;
+    }
     const int64_t total = block_scan_1024(a.b.tile_count, a.isect_offsets, g.n_images * g.n_tiles, s_part);
     if (threadIdx.x == 0) {
         __threadfence_system();
@@ -478,13 +465,10 @@ __device__ __forceinline__ void bn_cmpx(uint64_t &x, uint64_t &y, bool up)
 // unit first - e.g. xor-ed with a per-lane direction flag - stalls every dependent v_cndmask on gfx950)
 __device__ __forceinline__ void bn_cmpx_up(uint64_t &x, uint64_t &y)
 {
-    // one 64-bit compare + four 32-bit selects (written on the halves: as 64-bit selects the compiler turns the pair into
-    // umin / umax and emits a second compare)
-    const bool sw     = x > y;
-    const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32), yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
-    const uint32_t al = sw ? yl : xl, ah = sw ? yh : xh, bl = sw ? xl : yl, bh = sw ? xh : yh;
-    x = ((uint64_t)ah << 32) | al;
-    y = ((uint64_t)bh << 32) | bl;
+    const bool sw    = x > y;
+    const uint64_t t = sw ? y : x;
+    y                = sw ? x : y;
+    x                = t;
 }
 
 template <int G, int NT>
@@ -518,23 +502,15 @@ __device__ __forceinline__ void bn_bitonic(uint64_t *s, int lp, int tid, Sync &&
 #pragma unroll
         for (int b = 0; b < 8; ++b) e[b] = s[bn_phys(8 * t + b)];
 #pragma unroll
-        for (int lk = 1; lk <= 3; ++lk) {
-            // direction of word 8 t + b in phase k = 2^lk: descending where ((8 t + b) & k) != 0 -> complement those words
-            uint64_t m[8];
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool down = lk < 3 ? ((b >> lk) & 1) : (t & 1);
-                m[b]            = down ? ~0ull : 0ull;
-                e[b] ^= m[b];
-            }
+        for (int lk = 1; lk <= 3; ++lk)
 #pragma unroll
             for (int q = lk - 1; q >= 0; --q)
 #pragma unroll
                 for (int b = 0; b < 8; ++b)
-                    if (!(b & (1 << q))) bn_cmpx_up(e[b], e[b | (1 << q)]);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) e[b] ^= m[b];
-        }
+                    if (!(b & (1 << q))) {
+                        const bool up = lk < 3 ? ((b & (1 << lk)) == 0) : ((t & 1) == 0); // ((8 t + b) & k) == 0
+                        bn_cmpx(e[b], e[b | (1 << q)], up);
+                    }
 #pragma unroll
         for (int b = 0; b < 8; ++b) s[bn_phys(8 * t + b)] = e[b];
     }
@@ -676,7 +652,7 @@ static uint32_t bits_for(uint64_t count)
 
 static void bin_dims(uint32_t &bw, uint32_t &bh)
 {
-    bw = 4; bh = 2; // measured on c3 (r3f): 4x4 0.233, 4x2 0.206, 2x4 0.209, 2x2 0.225, 8x2 0.235 ms
+    bw = 4; bh = 2; // measured on c3 (r3f / r3g): 4x4 0.233, 4x2 0.206, 2x4 0.209, 2x2 0.225, 8x2 0.235 ms
     if (const char *e = getenv("GSX_ISECT_BIN")) { // "WxH" (tiles), W * H <= 16: A/B switch
         unsigned w = 0, h = 0;
         if (sscanf(e, "%ux%u", &w, &h) == 2 && w >= 1 && h >= 1 && w * h <= 16) { bw = w; bh = h; }
@@ -804,9 +780,12 @@ extern "C" int gsx_isect_binned_count(const float *means2d, const int32_t *radii
     const size_t bins_lds = (size_t)a.g.n_bins * sizeof(int32_t);
     bin_rect_kernel<<<dim3(a.g.n_chunks), dim3(kRowThreads), bins_lds, s>>>(a);
     const uint32_t col_groups = (a.g.n_bins + kCsCols - 1) / kCsCols;
-    bin_colscan_kernel<<<dim3(col_groups * a.g.n_images), dim3(kCsCols * kCsSegs2), 0, s>>>(a, col_groups); // + C
+    bin_colscan_kernel<<<dim3(col_groups * a.g.n_images), dim3(kCsCols * kCsSegs2), 0, s>>>(a.b.table, a.b.bin_count, a.g.n_bins,
+                                                                                             a.g.cpi, col_groups);
+    bin_plan_kernel<<<dim3(1), dim3(1024), 0, s>>>(a);
     bin_scatter_kernel<<<dim3(a.g.n_chunks), dim3(kRowThreads), bins_lds, s>>>(a);
-    bin_tiles_kernel<<<dim3(a.g.n_bins_total), dim3(1024), 0, s>>>(a); // + F
+    bin_tiles_kernel<<<dim3(a.g.n_bins_total), dim3(kBnThreads), 0, s>>>(a);
+    tile_plan_kernel<<<dim3(1), dim3(1024), 0, s>>>(a);
     return check_launch("isect_binned_count");
 }
 
