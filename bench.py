@@ -343,6 +343,9 @@ def main():
         # reads 44 B per live row, writes and re-reads the 8-byte (depth, row) pairs, and writes 12 B of key + value each
         "gsx_isect_fused_count": 36 * V + 4 * N_rows,
         "gsx_isect_fused_emit_sort": 44 * V + 28 * M,
+        # tile-owner-major path (csrc/isect_binned.hip), the same algorithmic bytes: what one pass has to read and write
+        "gsx_isect_binned_count": 36 * V + 4 * N_rows,
+        "gsx_isect_binned_emit_sort": 44 * V + 28 * M,
         # compositing (not HBM-bound: listed so that every stage of the step has its line)
         "gsx_raster3d_fwd": b_fwd,
         "gsx_raster3d_bwd": b_bwd,

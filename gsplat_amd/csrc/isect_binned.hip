@@ -714,12 +714,18 @@ using namespace gsx;
 
 extern "C" int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed)
 {
-    if (getenv("GSX_ISECT_LEGACY")) return 0;
+    // GSX_ISECT_PATH = binned | legacy forces the choice (tests, A/B); GSX_ISECT_LEGACY is the older spelling of "legacy"
+    const char *force = getenv("GSX_ISECT_PATH");
+    if (getenv("GSX_ISECT_LEGACY") || (force && force[0] == 'l')) return 0;
     if (packed && n_images != 1) return 0; // packed rows: per-image row counts live on the device
     if (n_images < 1 || tile_w < 1 || tile_h < 1 || rows < 0) return 0;
     if (rows % n_images != 0) return 0;
     BinGeom g;
-    return bin_geometry(g, rows > 0 ? rows : 1, n_images, 16, tile_w, tile_h, 1) ? 1 : 0;
+    if (!bin_geometry(g, rows > 0 ? rows : 1, n_images, 16, tile_w, tile_h, 1)) return 0;
+    if (force && force[0] == 'b') return 1;
+    // measured (MI355X, profiles/r07_isect_ab.md): 1 M rows x 8160 tiles (c3) 0.214 vs 0.249 ms; 4 M rows per image (c4:
+    // ~1800 entries per tile, one wave sorting 2048 words) 4.3 vs 2.5 ms -> dense images and small calls stay Gaussian-major
+    return rows >= 65536 && g.rows_per_image <= 256ll * (int64_t)g.n_tiles;
 }
 
 extern "C" int64_t gsx_isect_binned_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)

@@ -265,6 +265,58 @@ def test_isect_exact_dense(G, O, mode, tile_size):
     assert torch.equal(cpu(ids_u), ids_uo) and torch.equal(cpu(fl_u), fl_uo)
 
 
+_ISECT_CASES = {
+    # name: (N, C, width, height, tile_size, mode, variant)
+    "ellipse-3img": (20000, 3, 320, 200, 16, "ellipse", None),
+    "aabb-3img-ts8": (20000, 3, 320, 200, 8, "aabb", None),
+    "ellipse-ts4": (3000, 2, 160, 112, 4, "ellipse", None),
+    "packed": (20000, 1, 320, 200, 16, "ellipse", "packed"),
+    "depth-ties": (20000, 2, 320, 200, 16, "ellipse", "ties"),
+    "one-depth": (6000, 1, 320, 200, 16, "aabb", "flat"),
+    "cluster-long-tiles": (40000, 1, 640, 360, 16, "ellipse", "cluster"),  # tiles beyond the LDS arena: work-list sort
+    "giants-retry": (20000, 1, 640, 360, 16, "ellipse", "giant"),  # more (row, bin) entries than the workspace: retry path
+}
+
+
+@pytest.mark.parametrize("path", ["binned", "legacy"])
+@pytest.mark.parametrize("case", sorted(_ISECT_CASES))
+def test_isect_paths_match_oracle(G, O, monkeypatch, path, case):
+    """Both implementations of isect_tiles(sort=True) - tile-owner-major (csrc/isect_binned.hip) and Gaussian-major
+    (csrc/isect_fused.hip), normally chosen by density - are forced in turn (GSX_ISECT_PATH) and must equal the C oracle
+    bit for bit: tiles_per_gauss, sorted keys, row ids, offsets."""
+    N, C, W, H, ts, mode, variant = _ISECT_CASES[case]
+    sc, W, H = make_scene(N=N, C=C, width=W, height=H, seed=11)
+    if variant == "cluster":
+        sc["means"][:, :2] *= 0.05
+    if variant == "giant":
+        sc["scales"] = torch.full_like(sc["scales"], 0.4)
+    a, rad, m2, d, con, op = _project_scene(G, sc, W, H)
+    if variant == "ties":
+        d = (d * 2).round() / 2 + 0.25
+    if variant == "flat":
+        d = torch.ones_like(d)
+    tw, th = math.ceil(W / ts), math.ceil(H / ts)
+    kw, kwo = {}, {}
+    if variant == "packed":
+        vis = (rad[0] > 0).all(-1)
+        gi = torch.where(vis)[0]
+        m2, rad, d, con, op = m2[0][vis], rad[0][vis], d[0][vis], con[0][vis], op[0][vis]
+        kw = dict(packed=True, n_images=1, image_ids=torch.zeros_like(gi), gaussian_ids=gi)
+        kwo = dict(image_ids=torch.zeros_like(gi).cpu(), n_images=1)
+    if mode == "ellipse":
+        kw.update(conics=con, opacities=op)
+        kwo.update(conics=cpu(con), opacities=cpu(op))
+    monkeypatch.setenv("GSX_ISECT_PATH", path)
+    tpg, ids, fl = G.isect_tiles(m2, rad, d, ts, tw, th, **kw)
+    off = G.isect_offset_encode(ids, C, tw, th)
+    monkeypatch.delenv("GSX_ISECT_PATH")
+    tpg_o, ids_o, fl_o = O.isect_tiles(cpu(m2), cpu(rad), cpu(d), ts, tw, th, **kwo)
+    assert torch.equal(cpu(tpg), tpg_o), "tiles_per_gauss must be bit-exact"
+    assert torch.equal(cpu(ids), ids_o), "sorted isect_ids must be bit-exact"
+    assert torch.equal(cpu(fl), fl_o), "flatten_ids must be bit-exact (stable sort)"
+    assert torch.equal(cpu(off), O.isect_offset_encode(ids_o, C, tw, th))
+
+
 def test_isect_packed_and_edge_cases(G, O):
     sc, W, H = make_scene(N=6000, C=2, width=200, height=120, seed=7)
     a, rad, m2, d, con, op = _project_scene(G, sc, W, H)

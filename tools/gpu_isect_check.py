@@ -17,16 +17,13 @@ dev = torch.device("cuda", 0)
 
 
 def isect(m2, rad, d, ts, tw, th, legacy, **kw):
-    if legacy:
-        os.environ["GSX_ISECT_LEGACY"] = "1"
-    else:
-        os.environ.pop("GSX_ISECT_LEGACY", None)
+    os.environ["GSX_ISECT_PATH"] = "legacy" if legacy else "binned"
     try:
         tpg, ids, fl = isect_tiles_finish(isect_tiles_begin(m2, rad, d, ts, tw, th, **kw))
         I = kw.get("n_images") or (math.prod(m2.shape[:-2]) if m2.dim() > 2 else 1)
         off = gsplat_amd.isect_offset_encode(ids, I, tw, th)
     finally:
-        os.environ.pop("GSX_ISECT_LEGACY", None)
+        os.environ.pop("GSX_ISECT_PATH", None)
     return tpg, ids, fl, off
 
 
@@ -127,15 +124,15 @@ def bench_all(c4):
     rad, m2, d, con, op = project(sc, W, H)
     C = sc["viewmats"].shape[0]
     tw, th = (W + 15) // 16, (H + 15) // 16
-    variants = [("legacy", {"GSX_ISECT_LEGACY": "1"})]
+    variants = [("auto", {}), ("legacy", {"GSX_ISECT_PATH": "legacy"})]
     for b in ("4x4", "4x2", "2x2", "8x2", "2x4"):
-        variants.append((f"bin{b}", {"GSX_ISECT_BIN": b}))
+        variants.append((f"bin{b}", {"GSX_ISECT_BIN": b, "GSX_ISECT_PATH": "binned"}))
     for name, env in variants:
-        for k in ("GSX_ISECT_LEGACY", "GSX_ISECT_BIN", "GSX_ISECT_CAP"):
+        for k in ("GSX_ISECT_PATH", "GSX_ISECT_BIN"):
             os.environ.pop(k, None)
         os.environ.update(env)
         print(json.dumps({"scene": "c4" if c4 else "c3", "variant": name, **timed(m2, rad, d, con, op, C, tw, th)}), flush=True)
-    for k in ("GSX_ISECT_LEGACY", "GSX_ISECT_BIN", "GSX_ISECT_CAP"):
+    for k in ("GSX_ISECT_PATH", "GSX_ISECT_BIN"):
         os.environ.pop(k, None)
 
 
