@@ -155,13 +155,10 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
             const float q  = staged_q(ga, gb, dx, dy);
             const float ov_r = staged_alpha_raw(ga, q); // opac * exp(-sigma), unclamped
             // lanes outside the image have bin_final = -1 and can never be valid
-            // each test zeroes ov through a select fed STRAIGHT by its own vector compare: a mask combined on the scalar unit
-            // lands in VCC, and a v_cndmask reading a scalar-written VCC stalls the SIMD on gfx950 (tools/issue_rate.hip)
-            const float ov1 = (q < 0.0f) ? 0.0f : ov_r;
-            const float ov2 = (batch_end - t > bin_final) ? 0.0f : ov1;
-            const float ov  = (ov2 < kAlphaThreshold) ? 0.0f : ov2; // min(kMaxAlpha, ov) < threshold <=> ov < threshold
-            if (__builtin_amdgcn_ballot_w64(ov > 0.0f) == 0ull) continue; // wave-uniform
+            const bool valid = (batch_end - t <= bin_final) && !(q < 0.0f) && !(fminf(kMaxAlpha, ov_r) < kAlphaThreshold);
+            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform
 
+            const float ov    = valid ? ov_r : 0.0f;
             const float alpha = fminf(kMaxAlpha, ov);
             float loc[(K + 3) / 4 * 4];
             {
@@ -531,13 +528,10 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
             const v4f p1 = s_st[t].p1;
             const float e     = staged_e(p0, p1.x, p1.y, p1.z, pu, pv);
             const float ov_r  = __builtin_amdgcn_exp2f(e); // opac * exp(-sigma), unclamped
+            const float al_r  = fminf(kMaxAlpha, ov_r);
             // lanes outside the image have bin_final = -1 and can never be valid; e > lo <=> sigma < 0
-            // each test zeroes ov through a select fed STRAIGHT by its own vector compare (see the kernel above: no lane mask
-            // goes through the scalar unit on its way to a v_cndmask)
-            const float ov1 = (e > p0.w) ? 0.0f : ov_r;
-            const float ov2 = (bin_final < behind_s - t) ? 0.0f : ov1;
-            const float ov  = (ov2 < kAlphaThreshold) ? 0.0f : ov2; // min(kMaxAlpha, ov) < threshold <=> ov < threshold
-            if (__builtin_amdgcn_ballot_w64(ov > 0.0f) == 0ull) continue; // wave-uniform
+            const bool valid = (bin_final >= behind_s - t) && !(e > p0.w) && !(al_r < kAlphaThreshold);
+            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform
 
             float col[CH];
             if constexpr (CH <= 3) {
@@ -550,7 +544,8 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
                 col[0] = p2.x; col[1] = p2.y; col[2] = p1.w; col[3] = p2.z;
             }
             // invalid lanes: alpha = 0 -> fac = 0, w = 0, T and buffer unchanged (1 / (1 - 0) == 1 exactly)
-            const float alpha = fminf(kMaxAlpha, ov);
+            const float ov    = valid ? ov_r : 0.0f;
+            const float alpha = valid ? al_r : 0.0f;
             const float ra    = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
             T                *= ra;
             const float fac   = alpha * T;

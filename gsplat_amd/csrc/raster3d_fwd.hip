@@ -124,28 +124,25 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 const v4f p2 = s_st[t].p2; // one address register for the three reads (b128 + b128 + b64 / b128)
                 const float e     = staged_e(p0, p1.x, p1.y, p1.z, u, v);
                 const float alpha = fminf(kMaxAlpha, __builtin_amdgcn_exp2f(e));
-                // Branch-free body. The state lives in vector registers - `thr` is the pixel's alpha threshold and becomes +inf
-                // once it is done - and every select takes its mask STRAIGHT from one vector compare: a lane mask that is
-                // combined on the scalar unit first (ok = a && b, take = ok && !sat) lands in VCC, and on gfx950 a v_cndmask
-                // that reads a VCC written by the scalar unit stalls the whole SIMD (tools/issue_rate.hip: 0.11 instructions
-                // per cycle and SIMD whatever the number of waves, against 0.86 for the same select from an SGPR pair).
-                // So the two tests are folded into alpha itself (a failed test makes it 0), "saturated" needs no `ok` (a
-                // Gaussian that is not blended leaves T, which is above the threshold, unchanged), and "blended" is w > 0.
-                const float a0    = (e > p0.w) ? 0.0f : alpha; // e > lo <=> sigma < 0
-                const float a_eff = (a0 < thr) ? 0.0f : a0;    // below the pixel's threshold, or the pixel is done
-                if (__builtin_amdgcn_ballot_w64(a_eff > 0.0f) == 0ull) continue; // wave-uniform
-                const float next_T = fmaf(-T, a_eff, T);
+                // Branch-free body. The scalar unit, not the vector ALU, was the busiest pipe of this kernel when "pixel is
+                // done" lived in an EXEC-style mask (25 scalar instructions per surviving Gaussian, r05 PMC): the state now
+                // lives in vector registers - `thr` is the pixel's alpha threshold and becomes +inf once it is done - and the
+                // three decisions (passes / saturates / is blended) are lane masks combined on the scalar side.
+                const bool ok = !(e > p0.w) && !(alpha < thr); // e > lo <=> sigma < 0
+                if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue; // wave-uniform
+                const float next_T = fmaf(-T, alpha, T);
                 const bool low     = next_T <= kTransmittanceThresh; // saturated: this Gaussian is excluded
-                const float w      = low ? 0.0f : a_eff * T;
+                const bool sat = ok && low, take = ok && !sat;
+                const float w  = take ? alpha * T : 0.0f;
                 acc[0] += p2.x * w;
                 if constexpr (CH > 1) acc[1] += p2.y * w;
                 if constexpr (CH > 2) acc[2] += p1.w * w;
                 if constexpr (CH > 3) acc[3] += p2.z * w;
 #pragma unroll
                 for (int k = 4; k < CH; ++k) acc[k] += s_col[t * CX + k - 4] * w;
-                cur_idx = (w > 0.0f) ? (uint32_t)(batch_start + t) : cur_idx;
-                T       = low ? T : next_T;
-                thr     = low ? INFINITY : thr;
+                cur_idx = take ? (uint32_t)(batch_start + t) : cur_idx;
+                T       = take ? next_T : T;
+                thr     = sat ? INFINITY : thr;
             }
         }
     }
