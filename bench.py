@@ -168,6 +168,20 @@ def main():
                     help="only warmup + timed steps (no stage table, no sub-records, no CPU baseline): for rocprofv3 runs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves, one per GPU, the way gsplat/distributed.py:319-375
+        # (cli) spawns its workers - here by re-executing under torch.distributed.run on the loopback address
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -446,8 +460,23 @@ def main():
                 raise
             result["c4_single_gpu"] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
+        if scale_ref and result["c4_single_gpu"].get("value"):
+            # same workload on both sides of the ratio: the per-GPU work of this run on ONE GPU without the exchange
+            result["speedup_vs_1gpu"] = round(result["value"] / result["c4_single_gpu"]["value"], 3)
+            result["efficiency"] = round(result["speedup_vs_1gpu"] / n_gpus, 3)
     if scale_ref:
         dist.barrier()
+    # ---- the training step around the rasterizer: tools/train_step_bench.py ----------------
+    if extras:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import train_step_bench
+
+            torch.cuda.empty_cache()
+            result["train_step"] = train_step_bench.run(steps=100, device=device)
+        except Exception as e:
+            result["train_step"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
 
     # ---- CPU baseline (rank 0, N=1): the oracle pipeline, one fwd+bwd step of the SAME workload -------------
     # Bounded by construction: one step of c3 is ~10-30 s on <= 32 host threads (more threads are slower for these

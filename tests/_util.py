@@ -10,19 +10,25 @@ def to_t(x, device="cpu"):
     return torch.as_tensor(np.asarray(x)).to(device)
 
 
-def assert_close_ratio(actual, expected, rtol, atol, max_bad_ratio=0.0, name=""):
+def assert_close_ratio(actual, expected, rtol, atol, max_bad_ratio=0.0, name="", outlier_cap=5e-2):
     """|a-e| <= atol + rtol*|e| for all but `max_bad_ratio` of the elements (fp32 kernels with hardware
     exp can flip a 1/255 or 1e-4 threshold decision on a handful of pixels — reference tests use the
-    same device: gsplat/_helper.py assert_mismatch_ratio)."""
+    same device: gsplat/_helper.py assert_mismatch_ratio). The elements let through by `max_bad_ratio` are NOT
+    unbounded: a flipped decision adds or drops one Gaussian of alpha ~ 1/255 (or a contribution behind T ~ 1e-4), so
+    even an outlier must stay within `outlier_cap` (absolute, on top of the tolerance) - a grossly wrong pixel fails."""
     a = torch.as_tensor(actual).double().cpu()
     e = torch.as_tensor(expected).double().cpu()
     assert a.shape == e.shape, f"{name}: shape {tuple(a.shape)} vs {tuple(e.shape)}"
     err = (a - e).abs()
-    bad = err > (atol + rtol * e.abs())
+    tol = atol + rtol * e.abs()
+    bad = err > tol
     ratio = bad.double().mean().item() if bad.numel() else 0.0
     assert ratio <= max_bad_ratio, (
         f"{name}: {bad.sum().item()}/{bad.numel()} elements out of tolerance (ratio {ratio:.2e} > {max_bad_ratio:.2e}), "
         f"max err {err.max().item():.3e}")
+    if bad.any() and outlier_cap is not None:
+        worst = (err - tol)[bad].max().item()
+        assert worst <= outlier_cap, f"{name}: an out-of-tolerance element is off by {worst:.3e} > cap {outlier_cap:.1e}"
 
 
 def assert_grad_close(actual, expected, rel=2e-3, max_bad_ratio=0.0, name=""):

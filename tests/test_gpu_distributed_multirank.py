@@ -117,3 +117,25 @@ def test_bench_two_rank_path_rehearsal():
     assert "cpu_baseline" not in r and "roofline" in r  # the CPU baseline is an N = 1 leg
     ref = r["c4_single_gpu"]  # rank 0's single-GPU reference of the same workload, measured after the timed region
     assert ref["value"] > 0 and "120000 synthetic Gaussians" in ref["workload"] and "rank 0" in ref["note"]
+    assert r["speedup_vs_1gpu"] == pytest.approx(r["value"] / ref["value"], rel=1e-2) and r["efficiency"] > 0
+
+
+def test_bench_plain_form_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (the form the driver records): bench.py re-executes itself under
+    torch.distributed.run - one rank per GPU - instead of failing on WORLD_SIZE (gsplat/distributed.py:319-375 spawns its
+    ranks itself too). Rehearsed with both ranks on the one GPU over gloo."""
+    import json
+    import subprocess
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GSPLAT_BENCH_REHEARSAL"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gaussians", "40000",
+           "--no-extra"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["rehearsal"] is True and r["value"] > 0

@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""One TRAINING step around the rasterizer on the MI355X, timed end to end: what examples/simple_trainer.py does per
+iteration (reference examples/simple_trainer.py:795-1170: rasterization :722, L1 loss, backward, the optimizers' step
+:1137-1150, strategy.step_post_backward :1156-1166), on the c3-sized model - 1 M Gaussians, one 1080p camera, SH degree 3,
+parameters in the trainer's layout (log-scales, logit-opacities, sh0 / shN stored apart and optimised with their own
+rates), SelectiveAdam (visibility-masked fused Adam) and DefaultStrategy (densification statistics every step, ONE
+refinement inside the timed window).
+
+Prints one JSON object; `bench.py` embeds it as the "train_step" sub-record of the N = 1 line.
+usage: train_step_bench.py [--steps 100] [--gaussians 1000000] [--packed]"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_at=None):
+    import bench
+    import gsplat_amd
+
+    dev = device or torch.device("cuda", 0)
+    sc, W, H = bench.make_workload(n_gaussians, dev)
+    with torch.no_grad():
+        target, _, _ = gsplat_amd.rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"],
+                                                sc["viewmats"], sc["Ks"], W, H, sh_degree=3, packed=packed)
+        target = target.clamp(0, 1)
+    g = torch.Generator().manual_seed(1)
+    noise = lambda t, s: (t + s * torch.randn(t.shape, generator=g).to(dev))  # noqa: E731
+    params = torch.nn.ParameterDict({
+        "means": torch.nn.Parameter(noise(sc["means"], 1e-3)),
+        "quats": torch.nn.Parameter(sc["quats"].clone()),
+        "scales": torch.nn.Parameter(torch.log(sc["scales"])),
+        "opacities": torch.nn.Parameter(torch.logit(sc["opacities"].clamp(1e-3, 1 - 1e-3))),
+        "sh0": torch.nn.Parameter(noise(sc["colors"][:, :1, :], 0.05)),
+        "shN": torch.nn.Parameter(sc["colors"][:, 1:, :].clone()),
+    })
+    lrs = dict(means=1.6e-4, quats=1e-3, scales=5e-3, opacities=5e-2, sh0=2.5e-3, shN=2.5e-3 / 20)  # simple_trainer.py:232-241
+    opts = {k: gsplat_amd.SelectiveAdam([{"params": params[k], "lr": lrs[k], "name": k}], eps=1e-15, betas=(0.9, 0.999))
+            for k in params.keys()}
+    refine_at = steps // 2 if refine_at is None else refine_at
+    strategy = gsplat_amd.DefaultStrategy(refine_start_iter=refine_at, refine_every=max(refine_at, 1), reset_every=10**9,
+                                          refine_stop_iter=refine_at + 1, verbose=False)
+    strategy.check_sanity(params, opts)
+    state = strategy.initialize_state(scene_scale=1.0)
+
+    def step(i):
+        colors = torch.cat([params["sh0"], params["shN"]], 1)
+        rc, ra, info = gsplat_amd.rasterization(params["means"], params["quats"], torch.exp(params["scales"]),
+                                                torch.sigmoid(params["opacities"]), colors, sc["viewmats"], sc["Ks"], W, H,
+                                                sh_degree=3, packed=packed)
+        loss = (rc - target).abs().mean()
+        strategy.step_pre_backward(params, opts, state, i, info)
+        loss.backward()
+        if packed:
+            vis = torch.zeros(len(params["means"]), dtype=torch.bool, device=dev).index_fill_(0, info["gaussian_ids"], True)
+        else:
+            vis = (info["radii"] > 0).all(-1).any(0)
+        for o in opts.values():
+            o.step(vis)
+            o.zero_grad(set_to_none=True)
+        strategy.step_post_backward(params, opts, state, i, info, packed=packed)
+        return loss
+
+    n0 = len(params["means"])
+    for i in range(3):  # warm-up outside the window (allocator, lazy optimizer state)
+        step(-10 + i)
+    torch.cuda.synchronize()
+    per_step = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ts = time.perf_counter()
+        loss = step(i)
+        if i == refine_at or i == refine_at - 1:
+            torch.cuda.synchronize()
+            per_step.append((i, time.perf_counter() - ts))
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    n1 = len(params["means"])
+    refine_ms = [round(t * 1e3, 3) for (i, t) in per_step if i == refine_at]
+    return {
+        "workload": f"training step on the c3-sized model: {n0} Gaussians, 1x{W}x{H}, SH deg 3, sh0 / shN apart, "
+                    f"packed={packed}; rasterization + L1 + backward + SelectiveAdam (6 tensors) + DefaultStrategy",
+        "steps": steps, "ms_per_step": round(wall / steps * 1e3, 4), "steps_per_s": round(steps / wall, 2),
+        "mpixels_per_s": round(W * H * steps / wall / 1e6, 2),
+        "refinement_at_step": refine_at, "refinement_step_ms": refine_ms[0] if refine_ms else None,
+        "gaussians_before": n0, "gaussians_after": n1, "final_loss": round(float(loss), 6),
+        "reference": "examples/simple_trainer.py:795-1170 (rasterization :722, optimizer + strategy steps :1137-1166)",
+    }
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--packed", action="store_true")
+    a = ap.parse_args()
+    print(json.dumps(run(a.steps, a.gaussians, a.packed)))
