@@ -75,6 +75,18 @@ def make_workload(n_gaussians: int, device, n_cameras: int = 1, seed: int = 0, r
     return {k: v.to(device).contiguous() for k, v in sc.items()}, WIDTH, HEIGHT
 
 
+def raster_source_hash():
+    """Fingerprint of the compositing kernels' sources: the PMC traffic in profiles/pmc_traffic.json is only quoted while it
+    belongs to THESE sources (the GPU box has no git history to compare commits with)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("raster3d_fwd.hip", "raster3d_bwd.hip", "raster3d.hpp", "common.hpp"):
+        with open(os.path.join(ROOT, "gsplat_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(M, V, P, T, D):
     """SURVEY.md §8(d), fp32, compulsory traffic only."""
     fwd = (28 + 4 * D) * M + 4 * T + (4 * D + 8) * P
@@ -318,8 +330,13 @@ def main():
             pmc = json.load(open(tpath))
             # the backward runs as variant T for <= 4 channels (csrc/raster3d_bwd.hip): its counters are filed under that name
             traffic = (pmc.get(dom + "_t") or pmc.get(dom) or {}).get("bytes")
-            traffic_src = {"file": "profiles/pmc_traffic.json", "measured_at_commit": (pmc.get("_meta") or {}).get("commit"),
-                           "bench_commit": _git_head()}
+            meta_pmc = pmc.get("_meta") or {}
+            traffic_src = {"file": "profiles/pmc_traffic.json", "measured_at_commit": meta_pmc.get("commit"),
+                           "bench_commit": _git_head(), "kernel_sources": raster_source_hash()}
+            if meta_pmc.get("kernel_sources") != traffic_src["kernel_sources"]:
+                # counters of OTHER kernel sources are not this run's traffic: report none rather than a stale number
+                traffic_src["stale"] = f"measured on kernel sources {meta_pmc.get('kernel_sources')}: re-run tools/gpu_profile.sh"
+                traffic = None
         except Exception:
             traffic = None
     # vector-ALU view of the same two kernels: counted (pixel, Gaussian) pairs x (14 + 2 D) flop / time
@@ -497,6 +514,18 @@ def main():
                       f"compositing/intersection + torch-CPU projection/SH) on {cores} host threads",
             "t_fwd_s": round(ref["t_fwd"], 3), "t_bwd_s": round(ref["t_bwd"], 3), "n_isects": ref["n_isects"],
         }
+        # the reference's OWN CPU path can only run configs[0] (c1) and only where its checkout is (the build container):
+        # tools/time_c1_reference_cpu.py timed it there next to this port; quoted from the committed record, host stated
+        c1p = os.path.join(ROOT, "profiles", "c1_reference_cpu.json")
+        if os.path.exists(c1p):
+            try:
+                c1 = json.load(open(c1p))
+                result["cpu_baseline"]["c1_reference"] = {
+                    "config": c1["config"], "reference_mpixels_per_s": c1["reference_cpu"]["mpixels_per_s"],
+                    "port_mpixels_per_s": c1["port_cpu"]["mpixels_per_s"], "host": c1["host"],
+                    "source": "profiles/c1_reference_cpu.json (not measured in this run)"}
+            except Exception:
+                pass
     if rank == 0:
         print(json.dumps(result), file=json_out, flush=True)
     if distributed:

@@ -69,8 +69,11 @@ def main():
         except Exception:
             commit = os.environ.get("GSX_COMMIT")
         # the GPU box has no .git: tools/gpu_profile.sh is told the commit through GSX_COMMIT
+        sys.path.insert(0, root)
+        import bench
+
         hbm["_meta"] = {"commit": commit or os.environ.get("GSX_COMMIT"), "tag": os.path.basename(os.path.normpath(out)),
-                        "workload": "bench.py --lean (c3)"}
+                        "workload": "bench.py --lean (c3)", "kernel_sources": bench.raster_source_hash()}
         json.dump(hbm, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 
 
