@@ -265,6 +265,15 @@ def spherical_harmonics(degrees_to_use, means, viewmats, coeffs, masks, batch_id
     orchestrator's `clamp_min(colors + 0.5, 0)`."""
     if viewmats_rs is not None:
         raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
+    if coeffs.dtype == torch.float16:
+        # half coefficients, float arithmetic and colours (reference SphericalHarmonicsCUDA.cu:609-638): the band kernels
+        # read [N, K, 3] half rows in place; gathered packed rows / D != 3 widen first (rare layouts)
+        _check_f32(means=means, viewmats=viewmats)
+        packed = gaussian_ids is not None
+        if _band_kernels_apply(coeffs) and _radii is None and not _post and (not packed or not _gathered):
+            return _sh_band_fwd(degrees_to_use, 0, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids)
+        return spherical_harmonics(degrees_to_use, means, viewmats, coeffs.float(), masks, batch_ids, camera_ids, gaussian_ids,
+                                   None, _gathered=_gathered, _radii=_radii, _post=_post)
     _check_f32(means=means, viewmats=viewmats, coeffs=coeffs)
     packed, B, C, N, K, D = _sh_dims(means, viewmats, coeffs, gaussian_ids)
     means, viewmats, coeffs, masks = means.contiguous(), viewmats.contiguous(), coeffs.contiguous(), _c(masks)
@@ -291,6 +300,16 @@ def spherical_harmonics_bwd(degrees_to_use, means, viewmats, coeffs, masks, batc
                             *, _gathered: bool = True, _radii=None, _post_colors=None):
     if viewmats_rs is not None or compute_v_viewmats_rs:
         raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
+    if coeffs.dtype == torch.float16:  # see spherical_harmonics: v_coeffs comes back in the coefficients' own type
+        packed = gaussian_ids is not None
+        if _band_kernels_apply(coeffs) and _radii is None and _post_colors is None and (not packed or not _gathered):
+            v_co, v_me, v_vm = _sh_band_bwd(degrees_to_use, 0, means, viewmats, coeffs, masks, batch_ids, camera_ids,
+                                            gaussian_ids, v_colors, compute_v_means, compute_v_viewmats)
+            return v_co, v_me, v_vm, None
+        v_co, v_me, v_vm, v_rs = spherical_harmonics_bwd(
+            degrees_to_use, means, viewmats, coeffs.float(), masks, batch_ids, camera_ids, gaussian_ids, None, v_colors,
+            compute_v_means, compute_v_viewmats, False, _gathered=_gathered, _radii=_radii, _post_colors=_post_colors)
+        return v_co.half(), v_me, v_vm, v_rs
     packed, B, C, N, K, D = _sh_dims(means, viewmats, coeffs, gaussian_ids)
     means, viewmats, coeffs, masks = means.contiguous(), viewmats.contiguous(), coeffs.contiguous(), _c(masks)
     v_colors, vc_stride = _row_view(v_colors, D)  # may be a column view of the compositing kernel's gradient rows
@@ -798,19 +817,93 @@ def _pad_band0(shN):
     return torch.cat([torch.zeros_like(shN[:, :1]), shN], dim=1).contiguous()
 
 
+_BAND_DTYPES = {torch.float32: 0, torch.float16: 1}
+
+
+def _sh_band_fwd(degrees_to_use, first_band, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids):
+    """gsx_sh_band_fwd (csrc/sh_band.hip): bands first_band .. of [N, K - first_band, 3] coefficient rows (fp32 / fp16) read in
+    place, indexed by Gaussian (packed rows through gaussian_ids)."""
+    packed, B, C, N, KM, D = _sh_dims(means, viewmats, coeffs, gaussian_ids)
+    means, viewmats, coeffs, masks = means.contiguous(), viewmats.contiguous(), coeffs.contiguous(), _c(masks)
+    if coeffs.shape[0] != N:
+        raise ValueError(f"coefficient rows are indexed by Gaussian: expected {N} rows, got {coeffs.shape[0]}")
+    K = KM + first_band
+    if packed:
+        nnz = gaussian_ids.shape[0]
+        colors = torch.empty((nnz, 3), device=means.device, dtype=means.dtype)
+        call("gsx_sh_band_fwd", degrees_to_use, first_band, _BAND_DTYPES[coeffs.dtype], ptr(means), ptr(viewmats), ptr(coeffs),
+             ptr(masks), ptr(_c(batch_ids)), ptr(_c(camera_ids)), ptr(_c(gaussian_ids)), B, C, N, nnz, K, ptr(colors))
+    else:
+        colors = torch.empty(viewmats.shape[:-2] + (N, 3), device=means.device, dtype=means.dtype)
+        call("gsx_sh_band_fwd", degrees_to_use, first_band, _BAND_DTYPES[coeffs.dtype], ptr(means), ptr(viewmats), ptr(coeffs),
+             ptr(masks), None, None, None, B, C, N, -1, K, ptr(colors))
+    return colors
+
+
+def _sh_band_bwd(degrees_to_use, first_band, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, v_colors,
+                 compute_v_means, compute_v_viewmats):
+    packed, B, C, N, KM, D = _sh_dims(means, viewmats, coeffs, gaussian_ids)
+    means, viewmats, coeffs, masks = means.contiguous(), viewmats.contiguous(), coeffs.contiguous(), _c(masks)
+    K = KM + first_band
+    nnz = gaussian_ids.shape[0] if packed else -1
+    row_map = _packed_row_map(batch_ids, camera_ids, gaussian_ids, B, C, N) if (packed and nnz > 0 and N > 0) else None
+    if packed and row_map is None:  # no rows at all: nothing reaches the coefficients
+        return torch.zeros_like(coeffs), (torch.zeros_like(means) if compute_v_means else None), \
+            (torch.zeros_like(viewmats) if compute_v_viewmats else None)
+    v_coeffs = torch.empty_like(coeffs)  # every row is written by the thread that owns the Gaussian
+    v_means = torch.empty_like(means) if compute_v_means else None
+    v_dirs = None
+    if compute_v_viewmats:
+        v_dirs = torch.zeros(((nnz if packed else B * C * N), 3), device=means.device, dtype=means.dtype)
+    call("gsx_sh_band_bwd", degrees_to_use, first_band, _BAND_DTYPES[coeffs.dtype], ptr(means), ptr(viewmats), ptr(coeffs),
+         ptr(masks), B, C, N, nnz, K, ptr(v_colors.contiguous()), ptr(row_map), ptr(v_coeffs), ptr(v_means), ptr(v_dirs))
+    v_viewmats = None
+    if compute_v_viewmats:
+        if packed:
+            S = torch.zeros((B * C, 3), device=means.device, dtype=means.dtype)
+            S.index_add_(0, batch_ids * C + camera_ids, v_dirs)
+        else:
+            S = v_dirs.view(B * C, N, 3).sum(dim=1)
+        vm = viewmats.reshape(B * C, 4, 4)
+        R, t = vm[:, :3, :3], vm[:, :3, 3]
+        v_vm = torch.zeros_like(vm)
+        v_vm[:, :3, :3] = t[:, :, None] * S[:, None, :]
+        v_vm[:, :3, 3] = torch.einsum("cij,cj->ci", R, S)
+        v_viewmats = v_vm.reshape(viewmats.shape)
+    return v_coeffs, v_means, v_viewmats
+
+
+def _band_kernels_apply(coeffs) -> bool:
+    return coeffs.dim() == 3 and coeffs.shape[-1] == 3 and coeffs.shape[-2] >= 1 and coeffs.dtype in _BAND_DTYPES
+
+
 @_op("spherical_harmonics_l1_plus")
 def spherical_harmonics_l1_plus(degrees_to_use, means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids,
                                 viewmats_rs=None):
+    """colours of bands l >= 1 from shN [N, K - 1, D] read IN PLACE (csrc/sh_band.hip; reference
+    SphericalHarmonicsL1PlusCUDA.cu:441): no concatenation with a zero band. D != 3 goes through the general kernels on a
+    zero-padded band 0 (same arithmetic for k >= 1)."""
+    if viewmats_rs is not None:
+        raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
+    _check_f32(means=means, viewmats=viewmats)
+    if _band_kernels_apply(shN):
+        return _sh_band_fwd(degrees_to_use, 1, means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids)
     return spherical_harmonics(degrees_to_use, means, viewmats, _pad_band0(shN), masks, batch_ids, camera_ids,
-                               gaussian_ids, viewmats_rs)
+                               gaussian_ids, None, _gathered=False)
 
 
 @_op("spherical_harmonics_l1_plus_bwd")
 def spherical_harmonics_l1_plus_bwd(degrees_to_use, means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids,
                                     viewmats_rs, v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs):
+    if viewmats_rs is not None or compute_v_viewmats_rs:
+        raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
+    if _band_kernels_apply(shN):
+        v_shN, v_means, v_viewmats = _sh_band_bwd(degrees_to_use, 1, means, viewmats, shN, masks, batch_ids, camera_ids,
+                                                  gaussian_ids, v_colors, compute_v_means, compute_v_viewmats)
+        return v_shN, v_means, v_viewmats, None
     v_coeffs, v_means, v_viewmats, v_rs = spherical_harmonics_bwd(
         degrees_to_use, means, viewmats, _pad_band0(shN), masks, batch_ids, camera_ids, gaussian_ids, viewmats_rs,
-        v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs)
+        v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs, _gathered=False)
     return v_coeffs[:, 1:].contiguous(), v_means, v_viewmats, v_rs
 
 

@@ -319,7 +319,29 @@ Tensor spherical_harmonics(int64_t degrees_to_use, const Tensor &means_, const T
                            const OptTensor &gaussian_ids_, const OptTensor &viewmats_rs)
 {
     TORCH_CHECK_NOT_IMPLEMENTED(!has(viewmats_rs), "gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path");
-    want_f32(means_, "means"); want_f32(viewmats_, "viewmats"); want_f32(coeffs_, "coeffs");
+    want_f32(means_, "means"); want_f32(viewmats_, "viewmats");
+    if (coeffs_.scalar_type() == at::kHalf) {
+        // half coefficients, float arithmetic and colours (reference SphericalHarmonicsCUDA.cu:609-638): the band kernels of
+        // csrc/sh_band.hip read dense [N, K, 3] half rows in place; gathered packed rows / D != 3 widen first (rare layouts)
+        if (coeffs_.dim() == 3 && coeffs_.size(-1) == 3 && !has(gaussian_ids_)) {
+            Launch L(means_);
+            const Tensor means = contig(means_), viewmats = contig(viewmats_), coeffs = contig(coeffs_);
+            const OptTensor masks = contig(masks_);
+            const ShDims d = sh_dims(means, viewmats, coeffs, gaussian_ids_);
+            TORCH_CHECK_VALUE(coeffs.size(0) == d.N, "means N must match coeffs N in dense mode");
+            std::vector<int64_t> shape(viewmats.sizes().begin(), viewmats.sizes().end() - 2);
+            shape.push_back(d.N); shape.push_back(3);
+            Tensor colors = at::empty(shape, means.options());
+            { Timed timed_("gsx_sh_band_fwd", L.stream); check(gsx_sh_band_fwd((int)degrees_to_use, 0, 1, fp(means), fp(viewmats), coeffs.const_data_ptr(),
+                                  has(masks) ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, nullptr, nullptr, nullptr,
+                                  (uint32_t)d.B, (uint32_t)d.C, (uint32_t)d.N, -1, (uint32_t)d.K, mp<float>(colors), L.stream),
+                  "gsx_sh_band_fwd"); }
+            return colors;
+        }
+        return spherical_harmonics(degrees_to_use, means_, viewmats_, coeffs_.to(at::kFloat), masks_, batch_ids_, camera_ids_,
+                                   gaussian_ids_, viewmats_rs);
+    }
+    want_f32(coeffs_, "coeffs");
     Launch L(means_);
     const Tensor means = contig(means_), viewmats = contig(viewmats_), coeffs = contig(coeffs_);
     const OptTensor masks = contig(masks_), bi = contig(batch_ids_), ci = contig(camera_ids_), gi = contig(gaussian_ids_);
@@ -350,6 +372,37 @@ spherical_harmonics_bwd(int64_t degrees_to_use, const Tensor &means_, const Tens
 {
     TORCH_CHECK_NOT_IMPLEMENTED(!has(viewmats_rs) && !compute_v_viewmats_rs,
                                 "gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path");
+    if (coeffs_.scalar_type() == at::kHalf) { // see spherical_harmonics: v_coeffs comes back in the coefficients' own type
+        if (coeffs_.dim() == 3 && coeffs_.size(-1) == 3 && !has(gaussian_ids_)) {
+            Launch L(means_);
+            const Tensor means = contig(means_), viewmats = contig(viewmats_), coeffs = contig(coeffs_), vcol = contig(v_colors_);
+            const OptTensor masks = contig(masks_);
+            const ShDims d = sh_dims(means, viewmats, coeffs, gaussian_ids_);
+            Tensor v_coeffs = at::empty_like(coeffs);
+            OptTensor v_means, v_viewmats;
+            if (compute_v_means) v_means = at::empty_like(means);
+            Tensor v_dirs;
+            if (compute_v_viewmats) v_dirs = at::zeros({d.B * d.C * d.N, 3}, means.options());
+            { Timed timed_("gsx_sh_band_bwd", L.stream); check(gsx_sh_band_bwd((int)degrees_to_use, 0, 1, fp(means), fp(viewmats), coeffs.const_data_ptr(),
+                                  has(masks) ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, (uint32_t)d.B, (uint32_t)d.C,
+                                  (uint32_t)d.N, -1, (uint32_t)d.K, vcol.const_data_ptr<float>(), nullptr, v_coeffs.mutable_data_ptr(),
+                                  v_means ? mp<float>(*v_means) : nullptr, v_dirs.defined() ? mp<float>(v_dirs) : nullptr, L.stream),
+                  "gsx_sh_band_bwd"); }
+            if (compute_v_viewmats) {
+                const Tensor S = v_dirs.view({d.B * d.C, d.N, 3}).sum(1);
+                const Tensor vm = viewmats.reshape({d.B * d.C, 4, 4});
+                const Tensor R = vm.slice(1, 0, 3).slice(2, 0, 3), t = vm.slice(1, 0, 3).select(2, 3);
+                Tensor v_vm = at::zeros_like(vm);
+                v_vm.slice(1, 0, 3).slice(2, 0, 3).copy_(t.unsqueeze(2) * S.unsqueeze(1));
+                v_vm.slice(1, 0, 3).select(2, 3).copy_(at::einsum("cij,cj->ci", {R, S}));
+                v_viewmats = v_vm.reshape(viewmats.sizes());
+            }
+            return {v_coeffs, v_means, v_viewmats, OptTensor()};
+        }
+        auto r = spherical_harmonics_bwd(degrees_to_use, means_, viewmats_, coeffs_.to(at::kFloat), masks_, batch_ids_, camera_ids_,
+                                         gaussian_ids_, viewmats_rs, v_colors_, compute_v_means, compute_v_viewmats, false);
+        return {std::get<0>(r).to(at::kHalf), std::get<1>(r), std::get<2>(r), std::get<3>(r)};
+    }
     Launch L(means_);
     const Tensor means = contig(means_), viewmats = contig(viewmats_), coeffs = contig(coeffs_);
     const OptTensor masks = contig(masks_), bi = contig(batch_ids_), ci = contig(camera_ids_), gi = contig(gaussian_ids_);

@@ -234,6 +234,27 @@ int gsx_assemble_features_fwd(int degrees_to_use, uint32_t B, uint32_t C, uint32
                               const float *depths, const uint8_t *masks, float *out, uint8_t *relu_mask, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Spherical harmonics over a window of bands, fp32 or fp16 coefficients, D = 3 (csrc/sh_band.hip):
+ *   first_band = 1: gsplat::spherical_harmonics_l1_plus{,_bwd} (ext.cpp:1005-1014; SphericalHarmonicsL1PlusCUDA.cu:441
+ *                   fwd, :648 bwd): coeffs = shN [N, K-1, 3], bands 1 .. K-1, read IN PLACE (no concatenation with sh0);
+ *   first_band = 0, coeff_dtype = 1: gsplat::spherical_harmonics{,_bwd} with at::kHalf coefficients
+ *                   (SphericalHarmonicsCUDA.cu:609-638, 1306-1328): coefficients half, arithmetic and colours float.
+ * K counts bases INCLUDING band 0 (K >= (degrees_to_use + 1)^2); coefficient rows in memory hold K - first_band bases and are
+ * indexed by Gaussian (packed rows through gaussian_ids). coeff_dtype: 0 float32, 1 float16 (v_coeffs has the same type).
+ * Forward: colours [rows, 3] (masked rows 0). Backward: one thread per Gaussian walks the images - v_coeffs
+ * [N, K - first_band, 3] and v_means [B, N, 3] are written once per Gaussian (no atomics, no zero fill needed), v_dirs
+ * [rows, 3] (optional) receives d(loss)/d(view direction) per row; packed rows need row_map = gsx_packed_row_map.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_sh_band_fwd(int degrees_to_use, int first_band, int coeff_dtype, const float *means, const float *viewmats,
+                    const void *coeffs, const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
+                    const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz, uint32_t K,
+                    float *colors, void *stream);
+int gsx_sh_band_bwd(int degrees_to_use, int first_band, int coeff_dtype, const float *means, const float *viewmats,
+                    const void *coeffs, const uint8_t *masks, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
+                    uint32_t K, const float *v_colors, const int32_t *row_map, void *v_coeffs, float *v_means,
+                    float *v_dirs, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * isect_tiles: gsplat::intersect_tile (ext.cpp:1022-1026; host Intersect.cpp:170-329; kernel
  * IntersectTile.cu:214-464) split into its stages so that allocation stays with the caller:
  *   gsx_isect_count  -> tiles_per_gauss int32 [R]

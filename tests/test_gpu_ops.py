@@ -555,23 +555,77 @@ def test_proj_simple_fwd_bwd(G, O, cam):
     assert_grad_close(cpu(lg[1].grad), lo[1].grad, rel=1e-4, name="v_covars")
 
 
-def test_split_sh_matches_full(G):
-    """spherical_harmonics_l0 + spherical_harmonics_l1_plus == spherical_harmonics (reference tests/test_basic.py
-    test_sh split variants), forward and gradients."""
-    sc, W, H = make_scene(N=2000, C=2, width=64, height=48, seed=6, sh_degree=3)
+@pytest.mark.parametrize("layout", ["dense", "dense-masked", "packed"])
+@pytest.mark.parametrize("deg,K", [(3, 16), (2, 16), (1, 4), (4, 25)])
+def test_split_sh_matches_oracle(G, O, layout, deg, K):
+    """spherical_harmonics_l0 + spherical_harmonics_l1_plus (shN [N, K-1, 3] read in place: csrc/sh_band.hip) against the
+    ORACLE's full evaluation on the concatenated coefficients (reference tests/test_basic.py split-SH variants;
+    SphericalHarmonicsL1PlusCUDA.cu:441, 648): colours, v_sh0, v_shN, v_means, and the pose gradient."""
+    N, C = 3011, 3  # not a multiple of 64: the last wave's block is ragged
+    sc, W, H = make_scene(N=N, C=C, seed=6)
+    g = torch.Generator().manual_seed(deg * 100 + K)
+    coeffs = torch.randn(N, K, 3, generator=g) * 0.3
+    masks = (torch.rand(C, N, generator=g) > 0.3) if layout != "dense" else None
     d = {k: v.to(DEV) for k, v in sc.items()}
-    full = d["colors"].clone().requires_grad_(True)
-    sh0 = d["colors"][:, :1].clone().requires_grad_(True)
-    shN = d["colors"][:, 1:].clone().requires_grad_(True)
-    m_a, m_b = d["means"].clone().requires_grad_(True), d["means"].clone().requires_grad_(True)
-    ref = G.spherical_harmonics(3, m_a, d["viewmats"], full)
-    got = G.spherical_harmonics_l0(sh0)[None] + G.spherical_harmonics_l1_plus(3, m_b, d["viewmats"], shN)
-    assert_close_ratio(cpu(got), cpu(ref), 1e-5, 1e-6, name="split sh")
-    w = torch.randn(ref.shape, generator=torch.Generator().manual_seed(2)).to(DEV)
+    sh0 = coeffs[:, :1].to(DEV).requires_grad_(True)
+    shN = coeffs[:, 1:].contiguous().to(DEV).requires_grad_(True)
+    mg = d["means"].clone().requires_grad_(True)
+    vg = d["viewmats"].clone().requires_grad_(True)
+    if layout == "packed":
+        ci, gi = torch.where(masks)
+        bi = torch.zeros_like(ci)
+        got = G.spherical_harmonics_l0(sh0)[gi.to(DEV)] + G.spherical_harmonics_l1_plus(
+            deg, mg, vg, shN, batch_ids=bi.to(DEV), camera_ids=ci.to(DEV), gaussian_ids=gi.to(DEV))
+    else:
+        got = G.spherical_harmonics_l1_plus(deg, mg, vg, shN, masks=None if masks is None else masks.to(DEV))
+        l0 = G.spherical_harmonics_l0(sh0)[None].expand_as(got)
+        got = got + (l0 if masks is None else l0 * masks.to(DEV)[..., None])
+    co = coeffs.clone().requires_grad_(True)
+    mo, vo = sc["means"].clone().requires_grad_(True), sc["viewmats"].clone().requires_grad_(True)
+    ref = O.spherical_harmonics(deg, mo[None], vo[None], co, None if masks is None else masks[None])[0]
+    if layout == "packed":
+        ref = ref[masks]
+    assert_close_ratio(cpu(got), ref, 1e-5, 1e-5, name="split sh colours")
+    w = torch.randn(ref.shape, generator=g)
+    (got * w.to(DEV)).sum().backward()
     (ref * w).sum().backward()
-    (got * w).sum().backward()
-    assert_grad_close(cpu(torch.cat([sh0.grad, shN.grad], 1)), cpu(full.grad), rel=1e-5, name="v_coeffs")
-    assert_grad_close(cpu(m_b.grad), cpu(m_a.grad), rel=1e-4, name="v_means")
+    assert_grad_close(cpu(torch.cat([sh0.grad, shN.grad], 1)), co.grad, rel=1e-5, name="v_sh0 | v_shN")
+    assert_grad_close(cpu(mg.grad), mo.grad, rel=1e-4, name="v_means")
+    assert_grad_close(cpu(vg.grad), vo.grad, rel=2e-4, name="v_viewmats")
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_sh_half_coefficients(G, O, split):
+    """fp16 coefficient rows (reference SphericalHarmonicsCUDA.cu:609-638 / SphericalHarmonicsL1PlusCUDA.cu:569): read in
+    place as halves, float arithmetic and colours; the oracle evaluates the SAME (exactly widened) coefficients, so the
+    colours agree to fp32 tolerance; the coefficient gradient comes back in half precision."""
+    N, C, deg, K = 2500, 2, 3, 16
+    sc, W, H = make_scene(N=N, C=C, seed=8)
+    g = torch.Generator().manual_seed(5)
+    coeffs = (torch.randn(N, K, 3, generator=g) * 0.3).half()
+    masks = torch.rand(C, N, generator=g) > 0.2
+    d = {k: v.to(DEV) for k, v in sc.items()}
+    mg = d["means"].clone().requires_grad_(True)
+    if split:
+        shN = coeffs[:, 1:].contiguous().to(DEV).requires_grad_(True)
+        got = G.spherical_harmonics_l1_plus(deg, mg, d["viewmats"], shN, masks=masks.to(DEV))
+        co = torch.cat([torch.zeros(N, 1, 3), coeffs[:, 1:].float()], 1).requires_grad_(True)
+    else:
+        cg = coeffs.to(DEV).requires_grad_(True)
+        got = G.spherical_harmonics(deg, mg, d["viewmats"], cg, masks=masks.to(DEV))
+        co = coeffs.float().requires_grad_(True)
+    assert got.dtype == torch.float32
+    mo = sc["means"].clone().requires_grad_(True)
+    ref = O.spherical_harmonics(deg, mo[None], sc["viewmats"][None], co, masks[None])[0]
+    assert_close_ratio(cpu(got), ref, 1e-5, 1e-5, name="half-coefficient colours")
+    w = torch.randn(ref.shape, generator=g)
+    (got * w.to(DEV)).sum().backward()
+    (ref * w).sum().backward()
+    v = shN.grad if split else cg.grad
+    assert v.dtype == torch.float16
+    want = co.grad[:, 1:] if split else co.grad
+    assert_grad_close(cpu(v).float(), want, rel=2e-3, name="v_coeffs (half)")
+    assert_grad_close(cpu(mg.grad), mo.grad, rel=1e-4, name="v_means")
 
 
 def test_rasterize_to_indices_matches_oracle(G, O):

@@ -20,7 +20,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_at=None):
+def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_at=None, grow_grad2d=2e-7):
     import bench
     import gsplat_amd
 
@@ -33,7 +33,7 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_at=N
     g = torch.Generator().manual_seed(1)
     noise = lambda t, s: (t + s * torch.randn(t.shape, generator=g).to(dev))  # noqa: E731
     params = torch.nn.ParameterDict({
-        "means": torch.nn.Parameter(noise(sc["means"], 1e-3)),
+        "means": torch.nn.Parameter(noise(sc["means"], 5e-3)),
         "quats": torch.nn.Parameter(sc["quats"].clone()),
         "scales": torch.nn.Parameter(torch.log(sc["scales"])),
         "opacities": torch.nn.Parameter(torch.logit(sc["opacities"].clamp(1e-3, 1 - 1e-3))),
@@ -44,8 +44,10 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_at=N
     opts = {k: gsplat_amd.SelectiveAdam([{"params": params[k], "lr": lrs[k], "name": k}], eps=1e-15, betas=(0.9, 0.999))
             for k in params.keys()}
     refine_at = steps // 2 if refine_at is None else refine_at
+    # thresholds low enough that the one refinement really edits the model (the fit starts next to its optimum, so the
+    # screen-space gradients are far below the trainer's default 2e-4)
     strategy = gsplat_amd.DefaultStrategy(refine_start_iter=refine_at, refine_every=max(refine_at, 1), reset_every=10**9,
-                                          refine_stop_iter=refine_at + 1, verbose=False)
+                                          refine_stop_iter=refine_at + 1, grow_grad2d=grow_grad2d, verbose=False)
     strategy.check_sanity(params, opts)
     state = strategy.initialize_state(scene_scale=1.0)
 
@@ -89,7 +91,7 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_at=N
         "steps": steps, "ms_per_step": round(wall / steps * 1e3, 4), "steps_per_s": round(steps / wall, 2),
         "mpixels_per_s": round(W * H * steps / wall / 1e6, 2),
         "refinement_at_step": refine_at, "refinement_step_ms": refine_ms[0] if refine_ms else None,
-        "gaussians_before": n0, "gaussians_after": n1, "final_loss": round(float(loss), 6),
+        "gaussians_before": n0, "gaussians_after": n1, "final_loss": round(float(loss.detach()), 6),
         "reference": "examples/simple_trainer.py:795-1170 (rasterization :722, optimizer + strategy steps :1137-1166)",
     }
 
