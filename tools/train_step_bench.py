@@ -46,7 +46,7 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_at=N
     refine_at = steps // 2 if refine_at is None else refine_at
     # thresholds low enough that the one refinement really edits the model (the fit starts next to its optimum, so the
     # screen-space gradients are far below the trainer's default 2e-4)
-    strategy = gsplat_amd.DefaultStrategy(refine_start_iter=refine_at, refine_every=max(refine_at, 1), reset_every=10**9,
+    strategy = gsplat_amd.DefaultStrategy(refine_start_iter=refine_at - 1, refine_every=max(refine_at, 1), reset_every=10**9,
                                           refine_stop_iter=refine_at + 1, grow_grad2d=grow_grad2d, verbose=False)
     strategy.check_sanity(params, opts)
     state = strategy.initialize_state(scene_scale=1.0)
