@@ -672,7 +672,11 @@ def projection_ewa_3dgs_packed(means, covars, quats, scales, opacities, viewmats
             call("gsx_project_ewa_packed_write", *common, ptr(cum), ub, *[ptr(t) for t in bufs])
             ev.synchronize()  # host sync: exact-length COO outputs (reference: Projection.cpp:928-941)
             nnz = int(host_nnz.item())
-            return tuple(t if (t is None or i == 3) else t[:nnz] for i, t in enumerate(bufs))
+            # a view pins the whole upper-bound buffer for as long as the step (and its autograd graph) holds the rows: when
+            # few pairs are visible - the case packed rows exist for - copy the heads out and let the big buffers go
+            compact = 2 * nnz < ub
+            return tuple(t if (t is None or i == 3) else (t[:nnz].clone() if compact else t[:nnz])
+                         for i, t in enumerate(bufs))
         nnz = int(cum[-1].item())  # host sync: exact-length COO outputs (reference: Projection.cpp:928-941)
     batch_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
     camera_ids = torch.empty(nnz, device=dev, dtype=torch.int64)

@@ -442,7 +442,10 @@ __global__ void __launch_bounds__(1024) fused_totals_scan_kernel(const int32_t *
         offsets[b] = (int32_t)run;
         run += totals[b];
     }
-    if (threadIdx.x == 1023) *n_isects = s_part[1023];
+    if (threadIdx.x == 1023) {
+        __threadfence_system(); // n_isects may live in pinned host memory that the host polls: one 8-byte system-scope store
+        *n_isects = s_part[1023];
+    }
 }
 
 // shared with isect_binned.hip: the same column scan over a [chunk][bin] table, and the work-list sort of oversized tiles

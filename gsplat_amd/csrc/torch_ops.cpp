@@ -11,6 +11,7 @@
 // gsplat_amd/rendering.py; _ops.py skips registering its own body for an op listed by gsx_torch_compiled_ops().
 // Schemas are defined by _ops.py (verbatim from ext.cpp); an IMPL block may be loaded before or after the definitions.
 #include <chrono>
+#include <thread>
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/core/DeviceGuard.h>
@@ -266,6 +267,7 @@ projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const
         for (uint64_t spin = 0;; ++spin) {
             const int64_t v = *nnz_slot;
             if (v >= 0) return v;
+            if ((spin & 63u) == 63u) std::this_thread::yield();
             if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
         }
         stream.synchronize(); // never seen; keeps the function correct if the copy is not host-visible before the stream drains
@@ -286,7 +288,10 @@ projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const
         write(total, o);
         const int64_t nnz = wait_nnz(); // host round trip: exact-length COO outputs
         auto &[bi, ci, gi, indptr, radii, m2, dep, con, comp] = o;
-        auto head = [&](const Tensor &t) { return t.narrow(0, 0, nnz); };
+        // a view pins the whole upper-bound buffer for as long as the step (and its autograd graph) holds the rows: when
+        // few pairs are visible - the case packed rows exist for - copy the heads out and let the big buffers go
+        const bool compact = 2 * nnz < total;
+        auto head = [&](const Tensor &t) { return compact ? t.narrow(0, 0, nnz).clone() : t.narrow(0, 0, nnz); };
         return {head(bi), head(ci), head(gi), indptr, head(radii), head(m2), head(dep), head(con),
                 comp ? OptTensor(head(*comp)) : OptTensor()};
     }
@@ -714,6 +719,7 @@ isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &dep
         for (uint64_t spin = 0;; ++spin) {
             M = *slot;
             if (M != -1) break;
+            if ((spin & 63u) == 63u) std::this_thread::yield(); // the wait is ~10-100 us: do not pin a core at 100 % for it
             if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                 hip_stream.synchronize();
                 M = *slot;

@@ -239,13 +239,16 @@ class _RowMap:
         return self._index.to(device)
 
 
+_MAX_KERNEL_SEGMENTS = 64  # csrc/rows.hip kMaxSegments: source ranks the mapped copy kernels take in their argument block
+
+
 def _copy_groups(srcs, dsts, rows: int, row_map: Optional[_RowMap] = None, map_dst: bool = True) -> None:
     """srcs / dsts: lists of [rows, w] 4-byte tensors (any uniform row stride). HIP kernel on the GPU (csrc/rows.hip); on
     CPU tensors — the gloo tests of the seams — plain torch copies. With `row_map`, one side is in exchange order and the
     other in [C_local][sum N] order (map_dst: the destination is the latter)."""
     if rows == 0:
         return
-    if srcs[0].is_cuda:
+    if srcs[0].is_cuda and not (row_map is not None and len(row_map.seg_n) > _MAX_KERNEL_SEGMENTS):
         from . import _cabi
 
         keep, groups = [], []
@@ -281,6 +284,8 @@ def _copy_message(msg: Tensor, cols, fields, to_msg: bool, row_map: Optional[_Ro
     views = [msg[:, c:c + f.shape[1]] for c, f in zip(cols, fields)]
     stride = msg.stride(0)
     whole = msg.is_cuda and msg.stride(1) == 1 and stride <= 16 and (not to_msg or sum(f.shape[1] for f in fields) == stride)
+    if row_map is not None and len(row_map.seg_n) > _MAX_KERNEL_SEGMENTS:
+        whole = False  # the mapped kernels take the segment table by value (64 source ranks); beyond: index-based copies
     if not whole:
         if to_msg:
             _copy_groups(fields, views, R, row_map, map_dst=False)

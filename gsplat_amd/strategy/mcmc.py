@@ -66,6 +66,7 @@ class MCMCStrategy(Strategy):
         opacity = torch.sigmoid(params["opacities"].flatten()).clone()
         scale = torch.exp(params["scales"]).clone()
         src = torch.arange(n, device=dev)
+        msrc = torch.arange(n, device=dev)  # optimizer moments: a teleported (dead) row keeps its own, as in the reference
         fresh = torch.zeros(n, dtype=torch.bool, device=dev)
 
         def share(rows: Tensor) -> None:
@@ -94,11 +95,12 @@ class MCMCStrategy(Strategy):
             share(pick2)
             touched[pick2] = True
             rows_src = torch.cat([src, src[pick2]])
-            plan = RowPlan(rows_src, torch.cat([fresh, torch.ones(n_new, dtype=torch.bool, device=dev)]))
+            plan = RowPlan(rows_src, torch.cat([fresh, torch.ones(n_new, dtype=torch.bool, device=dev)]),
+                           torch.cat([msrc, msrc[pick2]]))
             opacity, scale = torch.cat([opacity, opacity[pick2]]), torch.cat([scale, scale[pick2]])
             touched = torch.cat([touched, torch.ones(n_new, dtype=torch.bool, device=dev)])
         else:
-            plan = RowPlan(src, fresh)
+            plan = RowPlan(src, fresh, msrc)
         rows = touched.nonzero(as_tuple=True)[0]
         if len(rows):
             plan.set("opacities", rows, torch.logit(opacity[rows]).reshape((len(rows),) + tuple(params["opacities"].shape[1:])))

@@ -212,10 +212,13 @@ class RowPlan:
     """New row j of the Gaussian set is a copy of old row ``src[j]``.
 
     ``fresh[j]``: its optimizer moments start at zero instead of being inherited. ``values[name]`` = (rows, tensor):
-    after the gather, ``new[name][rows] = tensor`` (rows index the NEW set)."""
+    after the gather, ``new[name][rows] = tensor`` (rows index the NEW set). ``moment_src[j]`` (default ``src``): the old
+    row whose optimizer moments new row j inherits - MCMC relocation teleports a dead row onto a live one but leaves the
+    dead row's OWN Adam moments in place (reference ``gsplat/strategy/ops.py`` ``relocate``: only ``v[sampled_idxs] = 0``)."""
 
-    def __init__(self, src: Tensor, fresh: Tensor):
+    def __init__(self, src: Tensor, fresh: Tensor, moment_src: Tensor = None):
         self.src, self.fresh = src, fresh
+        self.moment_src = moment_src
         self.values: Dict[str, tuple] = {}
 
     def set(self, name: str, rows: Tensor, values: Tensor) -> None:
@@ -223,7 +226,7 @@ class RowPlan:
 
     def select(self, keep: Tensor) -> "RowPlan":
         """The plan restricted to the new rows selected by the bool mask ``keep`` (row overrides are renumbered)."""
-        out = RowPlan(self.src[keep], self.fresh[keep])
+        out = RowPlan(self.src[keep], self.fresh[keep], None if self.moment_src is None else self.moment_src[keep])
         new_index = torch.cumsum(keep, 0) - 1
         for name, (rows, vals) in self.values.items():
             k = keep[rows]
@@ -240,6 +243,7 @@ def apply_plan(params: Params, optimizers: Dict[str, torch.optim.Optimizer], sta
     """Rebuild every parameter, its optimizer moments and the per-Gaussian statistics in ``state`` through ``plan``
     (statistics: inherited through the plan, or zeroed when ``zero_state``)."""
     src, fresh = plan.src, plan.fresh
+    msrc = src if plan.moment_src is None else plan.moment_src
     n_old = len(next(iter(params.values())))
     any_fresh = bool(fresh.any().item()) if fresh.numel() else False
 
@@ -251,7 +255,7 @@ def apply_plan(params: Params, optimizers: Dict[str, torch.optim.Optimizer], sta
         return _as_param(new, p)
 
     def optimizer_fn(key: str, v: Tensor) -> Tensor:
-        new = v[src]
+        new = v[msrc]
         if any_fresh:
             new[fresh] = 0
         return new

@@ -237,3 +237,41 @@ def test_short_fit_loss_decreases(G, which):
     assert all(math.isfinite(x) for x in losses)
     assert min(losses[-10:]) < 0.5 * losses[0], (losses[0], losses[-10:])
     assert len(sizes) > 1, "the strategy never changed the number of Gaussians"
+
+
+def test_mcmc_relocation_keeps_the_dead_rows_own_moments(G):
+    """MCMC relocation (reference gsplat/strategy/ops.py relocate: `v[sampled_idxs] = 0` and nothing else): a dead row takes
+    the PARAMETERS of the live row it is teleported onto but keeps its own Adam moments; the sampled live rows restart from
+    zero moments; untouched rows keep everything. The one-plan refinement must reproduce that."""
+    torch.manual_seed(0)
+    n = 64
+    g = torch.Generator().manual_seed(3)
+    raw = dict(means=torch.randn(n, 3, generator=g), scales=torch.log(torch.rand(n, 3, generator=g) * 0.05 + 0.001),
+               quats=torch.randn(n, 4, generator=g), opacities=torch.logit(torch.rand(n, generator=g) * 0.9 + 0.05),
+               sh0=torch.randn(n, 1, 3, generator=g))
+    raw["opacities"][:10] = torch.logit(torch.tensor(0.001))  # 10 dead rows (min_opacity = 0.005)
+    params = torch.nn.ParameterDict({k: torch.nn.Parameter(v.to(DEV)) for k, v in raw.items()})
+    opts = {k: torch.optim.Adam([p], lr=1e-3) for k, p in params.items()}
+    for k, p in params.items():
+        p.grad = torch.randn(p.shape, generator=g).to(DEV)
+        opts[k].step()
+        p.grad = None
+    before = {k: {m: opts[k].state[params[k]][m].clone() for m in ("exp_avg", "exp_avg_sq")} for k in params.keys()}
+    old_means = params["means"].detach().clone()
+    strat = G.MCMCStrategy(cap_max=n, min_opacity=0.005)  # cap_max = n: no stage-2 growth, relocation only
+    binoms = torch.zeros((51, 51), device=DEV)
+    for i in range(51):
+        for j in range(i + 1):
+            binoms[i, j] = math.comb(i, j)
+    n_dead, n_new = strat._refine(params, opts, binoms)
+    assert n_dead == 10 and n_new == 0
+    for k in params.keys():
+        for m in ("exp_avg", "exp_avg_sq"):
+            now = opts[k].state[params[k]][m]
+            assert torch.equal(now[:10], before[k][m][:10]), f"{k}.{m}: a teleported row must keep its own moments"
+            live = now[10:]
+            zeroed = (live.reshape(len(live), -1) == 0).all(1)
+            same = (live == before[k][m][10:]).reshape(len(live), -1).all(1)
+            assert bool((zeroed | same).all()), f"{k}.{m}: live rows are either sampled sources (zeroed) or untouched"
+            assert bool(zeroed.any()), "the sampled sources restart from zero moments"
+    assert not torch.equal(params["means"][:10].detach(), old_means[:10])  # and the dead rows carry live parameters now

@@ -85,3 +85,4 @@ def test_row_plan_select_renumbers_overrides():
     m = opts["x"].state[params["x"]]["exp_avg"].flatten().tolist()
     assert m[0] != 0.0 and m[1:] == [0.0, 0.0]
     assert state["stat"].tolist() == [7.0, 8.0, 9.0] and state["scalar"] == 3.0
+
