@@ -483,6 +483,32 @@ def main():
             result["efficiency"] = round(result["speedup_vs_1gpu"] / n_gpus, 3)
     if scale_ref:
         dist.barrier()
+    # ---- c2: the garden scene of BASELINE.json configs[1], by the reference's own profiling recipe ------------------------
+    # (profiling/main.py:43-52, 132-149 through tools/bench_reference_profile.py: assets/test_garden.npz cropped and tiled
+    # 5 x 5 = 2.8 M Gaussians, 1080p, 3 channels without SH, radius_clip 3; forward and backward timed apart). Unlike the
+    # synthetic c3 scene its tile lists are skewed (mean ~390 entries, longest ~8800): it is the real-scene counterweight
+    # to the headline number.
+    if extras:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_reference_profile as _brp
+
+            torch.cuda.empty_cache()
+            g2 = _brp.run(1, 3, 5, False, 10, device, stages=True, quiet=True)
+            t2 = 1.0 / g2["fps_fwd"] + 1.0 / g2["fps_bwd"]
+            result["c2_garden"] = {
+                "workload": "c2: garden (tests/golden/garden_scene.npz) x 25 = %d Gaussians, 1x1920x1080, 3 channels, "
+                            "radius_clip 3, fwd and bwd timed apart (the reference's profiling/main.py recipe)" % g2["n_gaussians"],
+                "value": g2["mpix_s_fwd_bwd"], "unit": "Mpixels/s", "ms_fwd_plus_bwd": round(t2 * 1e3, 4),
+                "fps_fwd": g2["fps_fwd"], "fps_bwd": g2["fps_bwd"], "n_isects": g2["n_isects"],
+                "raster_launch_ms": {"raster3d_fwd": g2["stages"]["fwd_ms"].get("raster3d_fwd"),
+                                     "raster3d_bwd": g2["stages"]["bwd_ms"].get("raster3d_bwd")},
+                "stages_ms": g2["stages"],
+                "published_titan_rtx_fps_fwd_bwd": g2["published_titan_rtx_fps_fwd_bwd"],
+            }
+        except Exception as e:
+            result["c2_garden"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     # ---- the training step around the rasterizer: tools/train_step_bench.py ----------------
     if extras:
         try:

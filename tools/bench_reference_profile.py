@@ -46,7 +46,7 @@ def timeit(repeats, f):
     return (time.time() - t0) / repeats, out
 
 
-def run(batch, channels, grid, packed, repeats, dev):
+def run(batch, channels, grid, packed, repeats, dev, stages=None, quiet=False):
     means, quats, scales, opac, colors, viewmats, Ks = load_scene(grid, dev)
     viewmats, Ks = viewmats[:1].repeat(batch, 1, 1), Ks[:1].repeat(batch, 1, 1)
     colors = colors[:, :1].repeat(1, channels)
@@ -65,8 +65,9 @@ def run(batch, channels, grid, packed, repeats, dev):
             v.grad = None
 
     t_bwd, _ = timeit(repeats, bwd)
+    want_stages = STAGES if stages is None else stages
     stages = None
-    if STAGES:  # per-entry-point HIP-event times of 5 forward and 5 backward calls
+    if want_stages:  # per-entry-point HIP-event times of 5 forward and 5 backward calls
         from gsplat_amd import _cabi
         _cabi.profile_begin()
         for _ in range(5):
@@ -85,7 +86,8 @@ def run(batch, channels, grid, packed, repeats, dev):
            "published_titan_rtx_fps_fwd_bwd": pub}
     if stages:
         row["stages"] = stages
-    print(json.dumps(row), flush=True)
+    if not quiet:
+        print(json.dumps(row), flush=True)
     return row
 
 
