@@ -289,6 +289,12 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
 #define GSX_BWD_T_WROW 132
 #define GSX_BWD_T_WGRP 16
 #endif
+// GSX_BWD_T_PRIVATE=1: one accumulator table PER WAVE, added to with plain LDS read-modify-write, instead of one per workgroup
+// hit with ds_add_f32: on gfx950 a float LDS atomic retires ~0.75 lanes per cycle and CU - 28x slower than an integer one
+// or a plain write (tools/issue_rate.hip) - and variant T issues 72 of them per turn of 8 Gaussians.
+#ifndef GSX_BWD_T_PRIVATE
+#define GSX_BWD_T_PRIVATE 0
+#endif
 #ifndef GSX_BWD_T_WAVES // waves per SIMD the register allocation aims at
 #define GSX_BWD_T_WAVES 5
 #endif
@@ -301,8 +307,9 @@ struct BwdTCfg {
     static constexpr int SLOTS = 8;                // Gaussians per turn
     static constexpr int WROW  = GSX_BWD_T_WROW;   // floats per slot: 8 pixel rows x WGRP
     static constexpr int WGRP  = GSX_BWD_T_WGRP;   // floats per row of 8 pixels: 8 x (fac, w) + 4 (bank spread)
+    static constexpr int NACC  = GSX_BWD_T_PRIVATE ? 4 : 1; // accumulator tables
     static constexpr size_t stage_bytes =
-        (size_t)BATCH * (sizeof(StagedRow) + sizeof(float4) + sizeof(int32_t) * 2 + sizeof(float) * KP);
+        (size_t)BATCH * (sizeof(StagedRow) + sizeof(float4) + sizeof(int32_t) * 2 + sizeof(float) * KP * NACC);
     static constexpr size_t smem = stage_bytes + sizeof(float) * (4 * SLOTS * WROW);
 };
 
@@ -324,8 +331,8 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
     float4 *s_cull   = reinterpret_cast<float4 *>(s_st + BATCH);   // mean - tile centre, half extents of alpha >= 1/255
     int32_t *s_id    = reinterpret_cast<int32_t *>(s_cull + BATCH);
     int32_t *s_touch = s_id + BATCH;
-    float *s_acc     = reinterpret_cast<float *>(s_touch + BATCH); // [BATCH][KP]: colours | S0 Su Sv Suu Suv Svv
-    float *s_w       = s_acc + BATCH * KP;                         // [4 waves][SLOTS][WROW]
+    float *s_acc     = reinterpret_cast<float *>(s_touch + BATCH); // [NACC][BATCH][KP]: colours | S0 Su Sv Suu Suv Svv
+    float *s_w       = s_acc + Cfg::NACC * BATCH * KP;             // [4 waves][SLOTS][WROW]
 
     TileCtx tc;
     if (!tile_context(a, blockIdx.x, tc)) return;
@@ -408,7 +415,9 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
     }
     for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
 #pragma unroll
-        for (int k = 0; k < KP; ++k) s_acc[s * KP + k] = 0.0f;
+        for (int w = 0; w < Cfg::NACC; ++w)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) s_acc[(w * BATCH + s) * KP + k] = 0.0f;
         s_touch[s] = 0;
     }
 
@@ -474,7 +483,10 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
         for (int j = 0; j < Cfg::KG; ++j) {
             const float tot = rows_sum4_scatter(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
             const int idx   = 4 * j + frow;
-            if (idx < K && wr_lane) atomicAdd(&s_acc[t_g * KP + idx], tot); // ds_add_f32
+            if (idx < K && wr_lane) {
+                if constexpr (GSX_BWD_T_PRIVATE) s_acc[((int)wave * BATCH + t_g) * KP + idx] += tot; // this wave's own table
+                else atomicAdd(&s_acc[t_g * KP + idx], tot);                                        // ds_add_f32
+            }
         }
         if (frow == 0 && wr_lane) s_touch[t_g] = 1;
         wave_lds_sync();
@@ -582,7 +594,15 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
         for (int e = (int)tid; e < batch_size * NCOL; e += (int)blockDim.x) {
             const int s = e / NCOL, c = e - s * NCOL;
             if (!s_touch[s]) continue;
-            const float *row = s_acc + s * KP;
+            float rowv[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                float v = s_acc[s * KP + k];
+#pragma unroll
+                for (int w = 1; w < Cfg::NACC; ++w) v += s_acc[(w * BATCH + s) * KP + k];
+                rowv[k] = v;
+            }
+            const float *row = rowv;
             const float4 cu  = s_cull[s];
             const float ax = cu.x, ay = cu.y; // mean - tile centre: the moments are about the tile centre too
             const float S0 = row[CH], Su = row[CH + 1], Sv = row[CH + 2];
@@ -611,9 +631,10 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
         __syncthreads();
         for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
             if (s < batch_size && s_touch[s]) {
-                float *row = s_acc + s * KP;
 #pragma unroll
-                for (int k = 0; k < KP; ++k) row[k] = 0.0f;
+                for (int w = 0; w < Cfg::NACC; ++w)
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) s_acc[(w * BATCH + s) * KP + k] = 0.0f;
                 s_touch[s] = 0;
             }
         }
