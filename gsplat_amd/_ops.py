@@ -56,6 +56,25 @@ def _load_torch_classes() -> Optional[str]:
 
 
 _COMPILED_ISECT = False  # torch.ops.gsplat_amd.isect_fused_{begin,finish} available (set by _read_compiled_ops)
+
+# ---- longest tile list: a hint from the orchestrator to the compositing ops ------------------------------------------------
+# rendering.py learns the longest tile list from the intersection's pinned host words; the reference's op schemas have no
+# room for it, so it travels as a per-thread hint around the op call: above SEG_MIN_LONGEST the forward / backward cut long
+# lists into segments that separate workgroups composite (csrc/raster3d_seg.hip). No hint (0) = one workgroup per tile.
+SEG_LEN, SEG_MIN_LONGEST = 1024, 2048
+_hint = __import__("threading").local()
+_set_hint_compiled = None  # gsx_torch_set_long_tile_hint of libgsplat_amd_torch.so (the compiled op bodies read it)
+
+
+def long_tile_hint() -> int:
+    return getattr(_hint, "longest", 0)
+
+
+def set_long_tile_hint(longest: int) -> None:
+    _hint.longest = int(longest)
+    if _set_hint_compiled is not None:
+        _set_hint_compiled(int(longest))
+
 COMPILED_OPS: frozenset = frozenset()  # ops whose CUDA-key body is C++ (csrc/torch_ops.cpp) rather than a function of this file
 
 
@@ -76,7 +95,12 @@ def _read_compiled_ops(path: str) -> None:
         return
     fn.restype = ctypes.c_char_p
     COMPILED_OPS = frozenset(fn().decode().split())
-    global _COMPILED_ISECT
+    global _COMPILED_ISECT, _set_hint_compiled
+    try:
+        _set_hint_compiled = ctypes.CDLL(path).gsx_torch_set_long_tile_hint
+        _set_hint_compiled.argtypes, _set_hint_compiled.restype = [ctypes.c_int64], None
+    except (OSError, AttributeError):
+        _set_hint_compiled = None
     _COMPILED_ISECT = (hasattr(torch.ops, "gsplat_amd") and hasattr(torch.ops.gsplat_amd, "isect_fused_begin")
                        and os.environ.get("GSPLAT_AMD_COMPILED_OPS", "1") not in ("0", "")
                        and os.environ.get("GSPLAT_AMD_COMPILED_ISECT", "1") not in ("0", ""))  # A/B switch
@@ -377,13 +401,13 @@ def _isect_fused_count(st, tile_mask):
                                   dtype=torch.uint8)
         call("gsx_isect_binned_count", ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), ptr(tile_mask),
              st.rows, st.I, tile_size, tile_width, tile_height, tpg, ptr(st.offsets), _cabi.ptr_host(st.host_total),
-             ptr(st.count_ws), st.count_ws.numel())
+             _cabi.ptr_host(st.host_total) + 8, ptr(st.count_ws), st.count_ws.numel())
     else:
         st.count_ws = torch.empty(_cabi.isect_fused_count_workspace_bytes(st.rows, st.I, tile_width, tile_height), device=dev,
                                   dtype=torch.uint8)
         call("gsx_isect_fused_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), ptr(tile_mask), st.rows, st.I,
-             tile_size, tile_width, tile_height, tpg, ptr(st.offsets), _cabi.ptr_host(st.host_total), ptr(st.count_ws),
-             st.count_ws.numel())
+             tile_size, tile_width, tile_height, tpg, ptr(st.offsets), _cabi.ptr_host(st.host_total),
+             _cabi.ptr_host(st.host_total) + 8, ptr(st.count_ws), st.count_ws.numel())
 
 
 def _isect_fused_emit(st, tile_mask, n_isects):
@@ -410,12 +434,12 @@ def _isect_fused_emit(st, tile_mask, n_isects):
 
 def _isect_fused_total(st, tile_mask):
     """Host sync on the count; reruns the Gaussian-major count when the binned path reports GSX_ISECT_RETRY (-2)."""
-    n_isects = int(st.host_total.item())
+    n_isects = int(st.host_total[0].item())
     if st.binned and n_isects == -2:
         st.binned = False
         _isect_fused_count(st, tile_mask)
         torch.cuda.current_stream(st.args[0].device).synchronize()
-        n_isects = int(st.host_total.item())
+        n_isects = int(st.host_total[0].item())
     if n_isects >= 2**31:
         raise RuntimeError(f"intersect_tile: {n_isects} intersections overflow the int32 index space")
     return n_isects
@@ -484,7 +508,7 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
             means2d, radii, depths, conics, opacities, rows, I, tile_size, tile_width, tile_height, list(out_shape))
         st.event = "polled"
         return st
-    st.host_total = torch.empty(1, dtype=torch.int64, pin_memory=True)
+    st.host_total = torch.zeros(2, dtype=torch.int64, pin_memory=True)  # [n_isects, longest tile list]
     if st.fused:
         st.offsets = torch.empty(I * tile_width * tile_height, device=dev, dtype=torch.int32)
         st.binned = _cabi.isect_binned_supported(rows, I, tile_width, tile_height, packed)
@@ -499,10 +523,17 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
         call("gsx_isect_count", ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), ptr(image_ids), rows, n_per, I,
              tile_size, tile_width, tile_height, ptr(st.tiles_per_gauss))
     st.cum = _scan_i32(st.tiles_per_gauss)
-    st.host_total.copy_(st.cum[-1:], non_blocking=True)
+    st.host_total[:1].copy_(st.cum[-1:], non_blocking=True)
     st.event = torch.cuda.Event()
     st.event.record()
     return st
+
+
+def isect_max_tile_len(st: "_IsectPending") -> int:
+    """Length of the longest tile list (0 when the path taken does not report it). Valid after isect_finish()."""
+    if st.host_total is None or st.host_total.numel() < 2 or not st.fused:
+        return 0
+    return int(st.host_total[1].item())
 
 
 def isect_finish(st: "_IsectPending"):
@@ -525,7 +556,7 @@ def isect_finish(st: "_IsectPending"):
         n_isects = _isect_fused_total(st, None)
         isect_ids, flatten_ids = _isect_fused_emit(st, None, n_isects)
         return tiles_per_gauss, isect_ids, flatten_ids
-    n_isects = int(st.host_total.item())
+    n_isects = int(st.host_total[0].item())
     cum = st.cum
     if n_isects >= 2**31:
         raise RuntimeError(f"intersect_tile: {n_isects} intersections overflow the int32 index space")
@@ -761,9 +792,18 @@ def rasterize_to_pixels_3dgs(means2d, conics, colors, opacities, backgrounds, ma
     renders = torch.empty(image_dims + (image_height, image_width, D), device=dev, dtype=dt)
     alphas = torch.empty(image_dims + (image_height, image_width, 1), device=dev, dtype=dt)
     last_ids = torch.empty(image_dims + (image_height, image_width), device=dev, dtype=torch.int32)
-    call("gsx_raster3d_fwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
-         ptr(isect_offsets), ptr(flatten_ids), I, flatten_ids.numel(), D, image_width, image_height, tile_size, tw,
-         th, ptr(renders), ptr(alphas), ptr(last_ids))
+    longest = long_tile_hint()
+    set_long_tile_hint(0)  # consumed
+    if longest > SEG_MIN_LONGEST:
+        ws = torch.empty(_cabi._lib.gsx_raster3d_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN), device=dev,
+                         dtype=torch.uint8)
+        call("gsx_raster3d_fwd_seg", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+             ptr(isect_offsets), ptr(flatten_ids), I, flatten_ids.numel(), D, image_width, image_height, tile_size, tw,
+             th, ptr(renders), ptr(alphas), ptr(last_ids), SEG_LEN, ptr(ws), ws.numel())
+    else:
+        call("gsx_raster3d_fwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+             ptr(isect_offsets), ptr(flatten_ids), I, flatten_ids.numel(), D, image_width, image_height, tile_size, tw,
+             th, ptr(renders), ptr(alphas), ptr(last_ids))
     holder = torch.zeros_like(means2d) if absgrad else torch.empty(0, device=dev, dtype=dt)
     return renders, alphas, holder, last_ids
 
@@ -1276,7 +1316,7 @@ def intersect_tile_sparse(means2d, radii, depths, image_ids, tile_mask, active_t
         st.rows, st.I, st.geom = rows, I, (tile_size, tile_width, tile_height)
         st.tiles_per_gauss = None
         st.offsets = offsets = torch.empty(I * n_tiles, device=dev, dtype=torch.int32)
-        st.host_total = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        st.host_total = torch.zeros(2, dtype=torch.int64, pin_memory=True)
         st.binned = _cabi.isect_binned_supported(rows, I, tile_width, tile_height, packed)
         _isect_fused_count(st, tile_mask)
         torch.cuda.current_stream(dev).synchronize()  # host sync: exact-length outputs (reference: Intersect.cpp:637)

@@ -325,17 +325,21 @@ def rasterize_to_pixels(
     masks: Optional[Tensor] = None,  # [..., tile_height, tile_width]
     packed: bool = False,
     absgrad: bool = False,
+    _longest_tile_list: int = 0,
 ) -> Tuple[Tensor, Tensor]:
     """Front-to-back alpha compositing of the depth-sorted per-tile lists. Returns
     (render_colors [..., H, W, channels], render_alphas [..., H, W, 1]). With ``absgrad`` the
-    backward pass also fills ``means2d.absgrad``."""
+    backward pass also fills ``means2d.absgrad``. ``_longest_tile_list`` (private; rendering.py passes what the
+    intersection reported): above ``_ops.SEG_MIN_LONGEST`` long lists are cut into segments composited in parallel."""
     if backgrounds is not None:
         backgrounds = backgrounds.contiguous()
     if masks is not None:
         masks = masks.contiguous()
+    _impl.set_long_tile_hint(_longest_tile_list)
     render_colors, render_alphas, means2d_absgrad, _last_ids = _ops.rasterize_to_pixels_3dgs(
         means2d.contiguous(), conics.contiguous(), colors.contiguous(), opacities.contiguous(), backgrounds, masks,
         image_width, image_height, tile_size, isect_offsets.contiguous(), flatten_ids.contiguous(), packed, absgrad)
+    _impl.set_long_tile_hint(0)
     if absgrad:
         means2d.absgrad = means2d_absgrad
     return render_colors, render_alphas

@@ -78,6 +78,7 @@ struct BinArgs {
     int32_t *tiles_per_gauss;
     int32_t *isect_offsets;
     int64_t *n_isects;
+    int64_t *max_tile_len; // optional: longest tile list (lets the caller cut long lists into segments, raster3d_seg.hip)
     // emit
     uint64_t *keys_out;
     int32_t *vals_out;
@@ -440,7 +441,21 @@ __global__ void __launch_bounds__(1024) tile_plan_kernel(const BinArgs a)
         }
         return;
     }
-    const int64_t total = block_scan_1024(a.b.tile_count, a.isect_offsets, g.n_images * g.n_tiles, s_part);
+    const uint32_t nt = g.n_images * g.n_tiles;
+    if (a.max_tile_len) { // written BEFORE n_isects: the host reads it once n_isects has arrived
+        int32_t mx = 0;
+        for (uint32_t t = threadIdx.x; t < nt; t += 1024) mx = max(mx, a.b.tile_count[t]);
+        mx = wave_max_i32(mx);
+        if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t m = 0;
+            for (int w = 0; w < 16; ++w) m = max(m, s_part[w]);
+            *a.max_tile_len = m;
+        }
+        __syncthreads();
+    }
+    const int64_t total = block_scan_1024(a.b.tile_count, a.isect_offsets, nt, s_part);
     if (threadIdx.x == 0) {
         __threadfence_system();
         *a.n_isects = total;
@@ -762,13 +777,14 @@ static int binned_setup(const char *fn, BinArgs &a, int64_t rows, uint32_t n_ima
 extern "C" int gsx_isect_binned_count(const float *means2d, const int32_t *radii, const float *depths, const float *conics,
                                       const float *opacities, const uint8_t *tile_mask, int64_t rows, uint32_t n_images,
                                       uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int32_t *tiles_per_gauss,
-                                      int32_t *isect_offsets, int64_t *n_isects, void *count_workspace,
+                                      int32_t *isect_offsets, int64_t *n_isects, int64_t *max_tile_len, void *count_workspace,
                                       int64_t count_workspace_bytes, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
     const uint32_t n_bins = n_images * tile_w * tile_h;
     GSX_REQUIRE(isect_offsets && n_isects, "gsx_isect_binned_count: null output");
     if (rows == 0) {
+        if (max_tile_len && hipMemsetAsync(max_tile_len, 0, 8, s) != hipSuccess) return check_launch("isect_binned_count memset");
         if (hipMemsetAsync(isect_offsets, 0, (size_t)n_bins * 4, s) != hipSuccess
             || hipMemsetAsync(n_isects, 0, 8, s) != hipSuccess) {
             set_last_error("gsx_isect_binned_count: memset failed");
@@ -783,6 +799,7 @@ extern "C" int gsx_isect_binned_count(const float *means2d, const int32_t *radii
     if (rc != GSX_OK) return rc;
     a.means2d = means2d; a.radii = radii; a.depths = depths; a.conics = conics; a.opacities = opacities;
     a.tile_mask = tile_mask; a.tiles_per_gauss = tiles_per_gauss; a.isect_offsets = isect_offsets; a.n_isects = n_isects;
+    a.max_tile_len = max_tile_len;
     const size_t bins_lds = (size_t)a.g.n_bins * sizeof(int32_t);
     bin_rect_kernel<<<dim3(a.g.n_chunks), dim3(kRowThreads), bins_lds, s>>>(a);
     const uint32_t col_groups = (a.g.n_bins + kCsCols - 1) / kCsCols;

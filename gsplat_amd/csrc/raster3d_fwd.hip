@@ -22,7 +22,8 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
     float *s_col    = reinterpret_cast<float *>(s_cull + kBatch);           // [kBatch][CX]: colours 4..
 
     TileCtx tc;
-    if (!tile_context(a, blockIdx.x, tc)) return; // uniform for the whole workgroup
+    uint32_t seg_item;
+    if (!tile_context_seg(a, blockIdx.x, tc, seg_item)) return; // uniform for the whole workgroup
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
     const uint32_t image_id = tc.image_id, tile_id = tc.tile_id;
     const uint32_t tid      = threadIdx.x;
@@ -41,6 +42,12 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 
     // masked-off tile: background colour, zero alpha, last_id 0 (reference Fwd.cu:141-159)
     if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) {
+        if (a.seg_mode == 1u) { // a masked tile's segments contribute nothing; the combine step writes the background
+            for (uint32_t k = 0; k < a.nch; ++k) a.seg_out[((size_t)seg_item * (a.nch + 1) + k) * 256 + tid] = 0.0f;
+            a.seg_out[((size_t)seg_item * (a.nch + 1) + a.nch) * 256 + tid] = 1.0f;
+            a.seg_last[(size_t)seg_item * 256 + tid] = -1;
+            return;
+        }
         if (inside) {
 #pragma unroll
             for (int k = 0; k < CH; ++k)
@@ -57,7 +64,7 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
     const int32_t n_batches   = (range_end - range_start + kBatch - 1) / kBatch;
 
     float T          = 1.0f;
-    uint32_t cur_idx = 0;
+    uint32_t cur_idx = a.seg_mode == 1u ? 0xFFFFFFFFu : 0u; // a segment reports "no contributor" as -1
     float acc[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) acc[k] = 0.0f;
@@ -147,6 +154,14 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
         }
     }
 
+    if (a.seg_mode == 1u) { // partial result of this segment, pixel-major planes (raster3d_seg.hip combines them)
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (k < (int)a.nch) a.seg_out[((size_t)seg_item * (a.nch + 1) + k) * 256 + tid] = acc[k];
+        a.seg_out[((size_t)seg_item * (a.nch + 1) + a.nch) * 256 + tid] = T;
+        a.seg_last[(size_t)seg_item * 256 + tid] = (int32_t)cur_idx;
+        return;
+    }
     if (inside) {
 #pragma unroll
         for (int k = 0; k < CH; ++k)
@@ -162,13 +177,26 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 template <int CH>
 static int launch_fwd(const Raster3DArgs &a, hipStream_t stream)
 {
-    const uint32_t n_blocks = a.sp_active_tiles ? a.n_active : a.tile_w * a.tile_h * a.n_images;
+    const uint32_t n_blocks = a.seg_mode ? a.seg_grid : (a.sp_active_tiles ? a.n_active : a.tile_w * a.tile_h * a.n_images);
     if (n_blocks == 0) return GSX_OK;
     const uint32_t grid   = ((n_blocks + 7u) / 8u) * 8u; // xcd_remap needs a multiple of 8
     const uint32_t block  = a.tile_size <= 8 ? 64u : 256u;
     const size_t smem     = kBatch * (sizeof(StagedRow) + sizeof(float4) + sizeof(float) * (CH > 4 ? CH - 4 : 0));
     hipLaunchKernelGGL(raster3d_fwd_kernel<CH>, dim3(grid), dim3(block), smem, stream, a);
     return check_launch("raster3d_fwd");
+}
+
+// one launch for the channel chunk described by a.ch_off / a.nch / a.first_chunk
+int raster3d_fwd_launch_chunk(const Raster3DArgs &a, hipStream_t stream)
+{
+    const uint32_t n = a.nch;
+    if (n <= 1) return launch_fwd<1>(a, stream);
+    if (n <= 2) return launch_fwd<2>(a, stream);
+    if (n <= 3) return launch_fwd<3>(a, stream);
+    if (n <= 4) return launch_fwd<4>(a, stream);
+    if (n <= 8) return launch_fwd<8>(a, stream);
+    if (n <= 16) return launch_fwd<16>(a, stream);
+    return launch_fwd<32>(a, stream);
 }
 
 int raster3d_fwd_dispatch(Raster3DArgs a, hipStream_t stream)
@@ -183,14 +211,7 @@ int raster3d_fwd_dispatch(Raster3DArgs a, hipStream_t stream)
         a.ch_off           = off;
         a.nch              = n;
         a.first_chunk      = first ? 1u : 0u;
-        int rc;
-        if (n <= 1) rc = launch_fwd<1>(a, stream);
-        else if (n <= 2) rc = launch_fwd<2>(a, stream);
-        else if (n <= 3) rc = launch_fwd<3>(a, stream);
-        else if (n <= 4) rc = launch_fwd<4>(a, stream);
-        else if (n <= 8) rc = launch_fwd<8>(a, stream);
-        else if (n <= 16) rc = launch_fwd<16>(a, stream);
-        else rc = launch_fwd<32>(a, stream);
+        const int rc = raster3d_fwd_launch_chunk(a, stream);
         if (rc != GSX_OK) return rc;
         off += n;
         first = false;

@@ -1,0 +1,211 @@
+// Long tile lists cut into segments that separate workgroups composite (forward), gfx950.
+// C-ABI entries: gsx_raster3d_seg_workspace_bytes, gsx_raster3d_fwd_seg.
+//
+// One workgroup per tile (the reference's decomposition too: RasterizeToPixels3DGSSerialBatchFwd.cu:41) makes the launch as
+// long as its LONGEST list. Real scenes have skewed lists - the reference's garden profile: mean 386 entries, 99th percentile
+// 4107, longest 8822 on 8160 tiles, 2.7x the ideal per-slot load whatever the launch order - so a tile whose list exceeds
+// `seg_len` is cut into segments of seg_len entries:
+//   1. seg_plan       one thread per tile: tiles longer than seg_len -> segment items (tile, first index) + a long-tile record
+//   2. raster3d_fwd   seg_mode 0: the ordinary per-tile launch, minus the long tiles
+//   3. raster3d_fwd   seg_mode 1: one workgroup per segment composites it from transmittance 1 and stores, per pixel, its
+//                     partial colours C_k, its transmittance T_k and its last contributor
+//   4. seg_combine    one workgroup per long tile, front to back over its segments: C = sum_k P_k C_k, P_{k+1} = P_k T_k -
+//                     compositing is an affine recurrence, so the segments compose exactly (up to fp32 rounding of the
+//                     products)
+//   5. raster3d_fwd   seg_mode 2: the tiles step 4 hands back (below)
+// Early termination is the one thing that does NOT decompose: the reference stops a pixel at the first Gaussian that would
+// bring its transmittance to <= 1e-4 and excludes it, and a segment that starts at T = 1 cannot know the transmittance in
+// front of it. Transmittance only decreases, so the rule fires somewhere iff the product over the WHOLE list is <= 1e-4:
+// step 4 computes that product anyway, and a tile with any pixel at or below 1e-4 (1 + 1e-5) - the margin covers the
+// rounding of the product order - is not written but listed for step 5, which walks its list the ordinary way. Scenes that
+// saturate (the dense synthetic c3 scene) have short effective lists anyway - whole waves exit early - and scenes with long
+// lists of faint Gaussians (the garden profile) do not saturate: the certificate is cheap and almost always holds.
+#include "raster3d.hpp"
+#include "../../include/gsplat_amd.h"
+
+namespace gsx {
+
+int raster3d_fwd_launch_chunk(const Raster3DArgs &a, hipStream_t stream); // raster3d_fwd.hip
+
+struct SegHeader { // device memory, zeroed before every use
+    int32_t n_items, n_long, n_back, pad;
+};
+
+struct SegPlan {
+    SegHeader *hdr;
+    int32_t *items; // [max_items][2] (tile block, first list index)
+    int32_t *longs; // [max_long][3]  (tile block, first item, number of segments)
+    int32_t *back;  // [max_long]     tile blocks handed back to the per-tile walk
+    int32_t *last;  // [max_items][256]
+    float *out;     // [max_items][nch_max + 1][256]
+    uint32_t max_items, max_long;
+};
+
+static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+static void seg_bounds(int64_t n_isects, uint32_t n_tiles_total, uint32_t seg_len, uint32_t &max_items, uint32_t &max_long)
+{
+    const int64_t by_len = n_isects / seg_len; // a long tile has more than seg_len entries
+    max_long  = (uint32_t)(by_len < (int64_t)n_tiles_total ? by_len : (int64_t)n_tiles_total);
+    max_items = (uint32_t)(by_len + max_long); // ceil(len / seg_len) <= len / seg_len + 1 per long tile
+}
+
+static int64_t seg_layout(int64_t n_isects, uint32_t n_tiles_total, uint32_t nch_max, uint32_t seg_len, unsigned char *base,
+                          SegPlan *p)
+{
+    SegPlan t{};
+    seg_bounds(n_isects, n_tiles_total, seg_len, t.max_items, t.max_long);
+    unsigned char *q = base;
+    auto take = [&](int64_t bytes) {
+        unsigned char *r = q;
+        q += align256(bytes);
+        return r;
+    };
+    t.hdr   = reinterpret_cast<SegHeader *>(take(sizeof(SegHeader)));
+    t.items = reinterpret_cast<int32_t *>(take((int64_t)t.max_items * 8));
+    t.longs = reinterpret_cast<int32_t *>(take((int64_t)t.max_long * 12));
+    t.back  = reinterpret_cast<int32_t *>(take((int64_t)t.max_long * 4));
+    t.last  = reinterpret_cast<int32_t *>(take((int64_t)t.max_items * 256 * 4));
+    t.out   = reinterpret_cast<float *>(take((int64_t)t.max_items * (nch_max + 1) * 256 * 4));
+    if (p) *p = t;
+    return (int64_t)(q - base);
+}
+
+__global__ void __launch_bounds__(256) seg_plan_kernel(const int32_t *offsets, uint32_t n_blocks, uint32_t n_isects,
+                                                       uint32_t seg_len, SegPlan p)
+{
+    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= n_blocks) return;
+    const int32_t start = offsets[blk], end = (blk == n_blocks - 1) ? (int32_t)n_isects : offsets[blk + 1];
+    const uint32_t len  = (uint32_t)(end - start);
+    if (len <= seg_len) return;
+    const uint32_t n_seg = (len + seg_len - 1) / seg_len;
+    const int32_t li = atomicAdd(&p.hdr->n_long, 1);
+    const int32_t s0 = atomicAdd(&p.hdr->n_items, (int32_t)n_seg);
+    p.longs[3 * li] = (int32_t)blk; p.longs[3 * li + 1] = s0; p.longs[3 * li + 2] = (int32_t)n_seg;
+    for (uint32_t k = 0; k < n_seg; ++k) {
+        p.items[2 * (s0 + (int32_t)k)]     = (int32_t)blk;
+        p.items[2 * (s0 + (int32_t)k) + 1] = start + (int32_t)(k * seg_len);
+    }
+}
+
+// one workgroup per long tile; thread = pixel in the per-tile launch's order (tile_pixel)
+__global__ void __launch_bounds__(256) seg_combine_kernel(const Raster3DArgs a, SegPlan p)
+{
+    const int32_t li = (int32_t)blockIdx.x;
+    if (li >= p.hdr->n_long) return;
+    const uint32_t blk = (uint32_t)p.longs[3 * li];
+    const int32_t s0 = p.longs[3 * li + 1], n_seg = p.longs[3 * li + 2];
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
+    TileCtx tc;
+    tc.image_id = blk / tiles_per_image; tc.tile_id = blk % tiles_per_image;
+    tc.tile_x = tc.tile_id % a.tile_w; tc.tile_y = tc.tile_id / a.tile_w;
+    tc.range_start = tc.range_end = 0;
+    const uint32_t tid = threadIdx.x;
+    uint32_t lx, ly;
+    tile_pixel(tid, a.tile_size, lx, ly);
+    const int64_t prow = pixel_row(a, tc, 0u, lx, ly);
+    const bool inside  = prow >= 0;
+    const uint32_t planes = a.nch + 1;
+    // transmittance in front of every segment, last contributor
+    float P = 1.0f;
+    int32_t last = -1;
+    for (int32_t k = 0; k < n_seg; ++k) {
+        const size_t it = (size_t)(s0 + k);
+        const int32_t l = p.last[it * 256 + tid];
+        last = l >= 0 ? l : last;
+        P *= p.out[(it * planes + a.nch) * 256 + tid];
+    }
+    // would the reference's early termination have fired anywhere in this tile? (see the file header)
+    const bool saturates = inside && !(P > kTransmittanceThresh * (1.0f + 1e-5f));
+    if (__syncthreads_or(saturates)) {
+        if (tid == 0 && a.first_chunk) p.back[atomicAdd(&p.hdr->n_back, 1)] = (int32_t)blk;
+        return; // every channel chunk reaches the same verdict (it only depends on the transmittances)
+    }
+    if (!inside) return;
+    const size_t pix = (size_t)prow;
+    const float *bg  = a.backgrounds ? a.backgrounds + (size_t)tc.image_id * a.cdim + a.ch_off : nullptr;
+    const bool masked = a.masks && !a.masks[(size_t)tc.image_id * tiles_per_image + tc.tile_id];
+    for (uint32_t c = 0; c < a.nch; ++c) {
+        float acc = 0.0f, Pk = 1.0f;
+        for (int32_t k = 0; k < n_seg; ++k) {
+            const size_t it = (size_t)(s0 + k);
+            acc = fmaf(Pk, p.out[(it * planes + c) * 256 + tid], acc);
+            Pk *= p.out[(it * planes + a.nch) * 256 + tid];
+        }
+        a.render_colors[pix * a.cdim + a.ch_off + c] = masked ? (bg ? bg[c] : 0.0f) : (bg ? acc + P * bg[c] : acc);
+    }
+    if (a.first_chunk) {
+        a.render_alphas[pix] = masked ? 0.0f : 1.0f - P;
+        a.last_ids[pix]      = masked ? 0 : (last >= 0 ? last : 0);
+    }
+}
+
+} // namespace gsx
+
+using namespace gsx;
+
+extern "C" int64_t gsx_raster3d_seg_workspace_bytes(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h,
+                                                    uint32_t cdim, uint32_t seg_len)
+{
+    if (seg_len == 0 || n_isects <= 0) return 512;
+    const uint32_t nch_max = cdim > 32 ? 32 : cdim;
+    return seg_layout(n_isects, n_images * tile_w * tile_h, nch_max, seg_len, nullptr, nullptr) + 512;
+}
+
+extern "C" int gsx_raster3d_fwd_seg(
+    const float *means2d, const float *conics, const float *colors, const float *opacities, const float *backgrounds,
+    const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images, uint32_t n_isects,
+    uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *render_colors,
+    float *render_alphas, int32_t *last_ids, uint32_t seg_len, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster3d_fwd_seg: tile_size must be in [1,16], got %u", tile_size);
+    GSX_REQUIRE(cdim >= 1, "gsx_raster3d_fwd_seg: channels must be >= 1");
+    GSX_REQUIRE(seg_len >= 256, "gsx_raster3d_fwd_seg: seg_len must be >= 256 (one staged batch), got %u", seg_len);
+    GSX_REQUIRE(render_colors && render_alphas && last_ids, "gsx_raster3d_fwd_seg: null output");
+    GSX_REQUIRE(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids), "gsx_raster3d_fwd_seg: null input");
+    GSX_REQUIRE(isect_offsets != nullptr || n_images * tile_w * tile_h == 0, "gsx_raster3d_fwd_seg: null isect_offsets");
+    hipStream_t s = (hipStream_t)stream;
+    Raster3DArgs a{};
+    a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height;
+    a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h; a.cdim = cdim;
+    a.means2d = means2d; a.conics = conics; a.colors = colors; a.opacities = opacities;
+    a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = isect_offsets; a.flatten_ids = flatten_ids;
+    a.render_colors = render_colors; a.render_alphas = render_alphas; a.last_ids = last_ids;
+    const uint32_t n_blocks = n_images * tile_w * tile_h;
+    if (n_blocks == 0) return GSX_OK;
+    const uint32_t nch_max = cdim > 32 ? 32 : cdim;
+    SegPlan p{};
+    unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    if (workspace == nullptr
+        || (base - reinterpret_cast<unsigned char *>(workspace)) + seg_layout(n_isects, n_blocks, nch_max, seg_len, base, &p) > workspace_bytes) {
+        set_last_error("gsx_raster3d_fwd_seg: workspace too small");
+        return GSX_ERR_WORKSPACE;
+    }
+    if (hipMemsetAsync(p.hdr, 0, sizeof(SegHeader), s) != hipSuccess) return check_launch("raster3d_fwd_seg memset");
+    seg_plan_kernel<<<dim3((n_blocks + 255) / 256), dim3(256), 0, s>>>(isect_offsets, n_blocks, n_isects, seg_len, p);
+    uint32_t off = 0;
+    bool first   = true;
+    do {
+        const uint32_t rem = cdim - off;
+        a.ch_off = off; a.nch = rem > 32 ? 32 : rem; a.first_chunk = first ? 1u : 0u;
+        a.seg_len = seg_len;
+        a.seg_mode = 0; // short tiles, one workgroup each
+        int rc = raster3d_fwd_launch_chunk(a, s);
+        if (rc != GSX_OK) return rc;
+        if (p.max_items > 0) {
+            a.seg_mode = 1; a.seg_grid = p.max_items; a.seg_items = p.items; a.seg_count = &p.hdr->n_items;
+            a.seg_out = p.out; a.seg_last = p.last;
+            rc = raster3d_fwd_launch_chunk(a, s);
+            if (rc != GSX_OK) return rc;
+            a.seg_mode = 0;
+            seg_combine_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(a, p);
+            a.seg_mode = 2; a.seg_grid = p.max_long; a.seg_items = p.back; a.seg_count = &p.hdr->n_back;
+            rc = raster3d_fwd_launch_chunk(a, s);
+            if (rc != GSX_OK) return rc;
+        }
+        off += a.nch;
+        first = false;
+    } while (off < cdim);
+    return check_launch("raster3d_fwd_seg");
+}

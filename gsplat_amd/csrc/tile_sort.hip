@@ -421,13 +421,25 @@ __global__ void __launch_bounds__(kCsTiles *kCsSegs) fused_colscan_kernel(int32_
 // Exclusive scan of the (image, tile) totals by ONE workgroup (n_bins <= kMaxBins): offsets[b] = start of segment b,
 // *n_isects = grand total (int64; the caller rejects >= 2^31 before any int32 offset is used).
 __global__ void __launch_bounds__(1024) fused_totals_scan_kernel(const int32_t *totals, uint32_t n_bins, int32_t *offsets,
-                                                                 int64_t *n_isects)
+                                                                 int64_t *n_isects, int64_t *max_tile_len)
 {
     __shared__ int64_t s_part[1024];
     const uint32_t per = (n_bins + 1023u) / 1024u;
     const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n_bins);
     int64_t sum = 0;
     for (uint32_t b = lo; b < hi; ++b) sum += totals[b];
+    if (max_tile_len) { // longest tile list, written before n_isects (the host reads it once n_isects has arrived)
+        int64_t mx = 0;
+        for (uint32_t b = lo; b < hi; ++b) mx = max(mx, (int64_t)totals[b]);
+        s_part[threadIdx.x] = mx;
+        __syncthreads();
+        for (int o = 512; o >= 1; o >>= 1) {
+            if ((int)threadIdx.x < o) s_part[threadIdx.x] = max(s_part[threadIdx.x], s_part[threadIdx.x + o]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *max_tile_len = s_part[0];
+        __syncthreads();
+    }
     s_part[threadIdx.x] = sum;
     __syncthreads();
     // Hillis-Steele inclusive scan over the 1024 partial sums
@@ -591,7 +603,7 @@ static int fused_setup(const char *fn, FusedArgs &a, int64_t rows, uint32_t n_im
 extern "C" int gsx_isect_fused_count(const float *means2d, const int32_t *radii, const float *conics, const float *opacities,
                                      const uint8_t *tile_mask, int64_t rows, uint32_t n_images, uint32_t tile_size,
                                      uint32_t tile_w, uint32_t tile_h,
-                                     int32_t *tiles_per_gauss, int32_t *isect_offsets, int64_t *n_isects,
+                                     int32_t *tiles_per_gauss, int32_t *isect_offsets, int64_t *n_isects, int64_t *max_tile_len,
                                      void *count_workspace, int64_t count_workspace_bytes, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
@@ -599,7 +611,8 @@ extern "C" int gsx_isect_fused_count(const float *means2d, const int32_t *radii,
     GSX_REQUIRE(isect_offsets && n_isects, "gsx_isect_fused_count: null output");
     if (rows == 0) {
         if (hipMemsetAsync(isect_offsets, 0, (size_t)n_bins * 4, s) != hipSuccess
-            || hipMemsetAsync(n_isects, 0, 8, s) != hipSuccess) {
+            || hipMemsetAsync(n_isects, 0, 8, s) != hipSuccess
+            || (max_tile_len && hipMemsetAsync(max_tile_len, 0, 8, s) != hipSuccess)) {
             set_last_error("gsx_isect_fused_count: memset failed");
             return GSX_ERR_LAUNCH;
         }
@@ -618,7 +631,7 @@ extern "C" int gsx_isect_fused_count(const float *means2d, const int32_t *radii,
     const uint32_t tile_groups = (a.geom.n_tiles + kCsTiles - 1) / kCsTiles;
     fused_colscan_kernel<<<dim3(tile_groups * n_images), dim3(kCsTiles * kCsSegs), 0, s>>>(a.table, totals, a.geom.n_tiles,
                                                                                          a.geom.cpi, tile_groups);
-    fused_totals_scan_kernel<<<dim3(1), dim3(1024), 0, s>>>(totals, n_bins, isect_offsets, n_isects);
+    fused_totals_scan_kernel<<<dim3(1), dim3(1024), 0, s>>>(totals, n_bins, isect_offsets, n_isects, max_tile_len);
     return check_launch("isect_fused_count scans");
 }
 

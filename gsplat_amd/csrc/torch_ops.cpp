@@ -500,7 +500,7 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
             Tensor count_ws = bytes(gsx_isect_binned_count_workspace_bytes(rows, uI, utw, uth), means2d);
             { Timed timed_("gsx_isect_binned_count", L.stream); check(gsx_isect_binned_count(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI,
                                          uts, utw, uth, mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets),
-                                         host_total.mutable_data_ptr<int64_t>(), count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
+                                         host_total.mutable_data_ptr<int64_t>(), nullptr, count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
                   "gsx_isect_binned_count"); }
             hip_stream.synchronize();
             M = *host_total.const_data_ptr<int64_t>();
@@ -517,7 +517,7 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
         }
         Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
         { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
-                                    mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(),
+                                    mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(), nullptr,
                                     count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
               "gsx_isect_fused_count"); }
         hip_stream.synchronize();
@@ -608,6 +608,12 @@ RasterDims raster_dims(const Tensor &isect_offsets, const Tensor &colors)
     return r;
 }
 
+// Longest tile list of the intersection the NEXT compositing call consumes, set by the orchestrator (rendering.py knows it
+// from the intersection's host word; the reference's op schema has no room for it). Above kSegMinLongest the forward cuts
+// long lists into segments (csrc/raster3d_seg.hip). 0 = unknown: one workgroup per tile. Consumed (reset) by the call.
+thread_local int64_t g_long_tile_hint = 0;
+constexpr int64_t kSegLen = 1024, kSegMinLongest = 2048;
+
 std::tuple<Tensor, Tensor, Tensor, Tensor>
 rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Tensor &colors_, const Tensor &opacities_,
                          const OptTensor &backgrounds_, const OptTensor &masks_, int64_t width, int64_t height, int64_t tile_size,
@@ -632,6 +638,19 @@ rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Te
     Tensor renders = at::empty(shape({height, width, r.D}), means2d.options());
     Tensor alphas = at::empty(shape({height, width, 1}), means2d.options());
     Tensor last_ids = at::empty(shape({height, width}), means2d.options().dtype(at::kInt));
+    const int64_t longest = g_long_tile_hint;
+    g_long_tile_hint = 0;
+    if (longest > kSegMinLongest) {
+        Tensor ws = at::empty({gsx_raster3d_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
+                                                              (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
+        Timed timed_("gsx_raster3d_fwd", L.stream); // same stage name: it IS the compositing forward
+        check(gsx_raster3d_fwd_seg(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
+                                   masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
+                                   cp<int32_t>(flat), (uint32_t)r.I, (uint32_t)flat.numel(), (uint32_t)r.D, (uint32_t)width,
+                                   (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th, mp<float>(renders),
+                                   mp<float>(alphas), mp<int32_t>(last_ids), (uint32_t)kSegLen, ws.mutable_data_ptr(), ws.numel(), L.stream),
+              "gsx_raster3d_fwd_seg");
+    } else
     { Timed timed_("gsx_raster3d_fwd", L.stream); check(gsx_raster3d_fwd(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
                            masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
                            cp<int32_t>(flat), (uint32_t)r.I, (uint32_t)flat.numel(), (uint32_t)r.D, (uint32_t)width,
@@ -685,21 +704,23 @@ isect_fused_begin(const Tensor &means2d, const Tensor &radii, const Tensor &dept
     Launch L(means2d);
     const uint32_t uI = (uint32_t)I, uts = (uint32_t)tile_size, utw = (uint32_t)tile_w, uth = (uint32_t)tile_h;
     Tensor tiles_per_gauss = at::empty(out_shape, means2d.options().dtype(at::kInt));
-    Tensor host_total = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
-    *host_total.mutable_data_ptr<int64_t>() = -1;
+    // pinned host words: [0] n_isects (sentinel -1 until the count has run), [1] the longest tile list (written first)
+    Tensor host_total = at::empty({2}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    host_total.mutable_data_ptr<int64_t>()[0] = -1;
+    host_total.mutable_data_ptr<int64_t>()[1] = 0;
     Tensor offsets = at::empty({I * tile_w * tile_h}, means2d.options().dtype(at::kInt));
     if (gsx_isect_binned_supported(rows, uI, utw, uth, 0)) { // tile-owner-major path (csrc/isect_binned.hip)
         Tensor count_ws = bytes(gsx_isect_binned_count_workspace_bytes(rows, uI, utw, uth), means2d);
         { Timed timed_("gsx_isect_binned_count", L.stream); check(gsx_isect_binned_count(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI, uts,
                                      utw, uth, mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(),
-                                     count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
+                                     host_total.mutable_data_ptr<int64_t>() + 1, count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
               "gsx_isect_binned_count"); }
         return {tiles_per_gauss, offsets, count_ws, host_total};
     }
     Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
     { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
                                 mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(),
-                                count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
+                                host_total.mutable_data_ptr<int64_t>() + 1, count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
           "gsx_isect_fused_count"); }
     return {tiles_per_gauss, offsets, count_ws, host_total};
 }
@@ -734,7 +755,8 @@ isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &dep
         count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
         { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
                                     mp<int32_t>(tiles_per_gauss), offsets.mutable_data_ptr<int32_t>(),
-                                    host_total.mutable_data_ptr<int64_t>(), count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
+                                    host_total.mutable_data_ptr<int64_t>(), host_total.mutable_data_ptr<int64_t>() + 1,
+                                    count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
               "gsx_isect_fused_count"); }
         hip_stream.synchronize();
         M = *slot;
@@ -833,7 +855,11 @@ rasterize_to_pixels_2dgs(const Tensor &means2d_, const Tensor &ray_transforms_, 
 }
 
 } // namespace
+void set_long_tile_hint(int64_t longest) { g_long_tile_hint = longest; }
 } // namespace gsplat_amd
+
+// gsplat_amd/_ops.py (ctypes): the longest tile list of the intersection that the next compositing call of THIS thread consumes
+extern "C" void gsx_torch_set_long_tile_hint(int64_t longest) { gsplat_amd::set_long_tile_hint(longest); }
 
 TORCH_LIBRARY(gsplat_amd, m)
 {

@@ -32,6 +32,8 @@ from ._wrapper import (
     spherical_harmonics,
 )
 
+from ._ops import isect_max_tile_len as _isect_max_tile_len
+
 _COLOR_MODES = ("RGB", "RGB+D", "RGB+ED")
 _DEPTH_MODES = ("D", "ED", "RGB+D", "RGB+ED")
 _HIT_MODES = ("d", "Ed", "RGB-d", "RGB-Ed")
@@ -258,6 +260,9 @@ def rasterization(
     else:
         isect_offsets = isect_offset_encode(isect_ids, I, tile_width, tile_height)
     isect_offsets = isect_offsets.reshape(batch_dims + (C, tile_height, tile_width))
+    # the intersection also reports its longest tile list (same host words as n_isects): long lists are composited in
+    # segments (csrc/raster3d_seg.hip); 0 when the path taken does not report it
+    longest_list = _isect_max_tile_len(isect_pending)
 
     # ---- feature rows still in flight (distributed, dense): needed from here on -----------------------
     if recv_features is not None:
@@ -283,7 +288,7 @@ def rasterization(
             bg = None if backgrounds is None else backgrounds[..., s:e].contiguous()
             c_, a_ = rasterize_to_pixels(means2d, conics, feats[..., s:e].contiguous(), proj_opacities, width, height,
                                          tile_size, isect_offsets, flatten_ids, backgrounds=bg, packed=packed,
-                                         absgrad=absgrad)
+                                         absgrad=absgrad, _longest_tile_list=longest_list)
             rc.append(c_)
             if ra is None:
                 ra = a_
@@ -301,7 +306,7 @@ def rasterization(
         else:
             render_colors, render_alphas = rasterize_to_pixels(
                 means2d, conics, feats, proj_opacities, width, height, tile_size, isect_offsets, flatten_ids,
-                backgrounds=backgrounds, packed=packed, absgrad=absgrad)
+                backgrounds=backgrounds, packed=packed, absgrad=absgrad, _longest_tile_list=longest_list)
 
     # ---- post-process: split extra signals, normalise expected depth ------------------------------
     render_extra = None

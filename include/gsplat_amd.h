@@ -324,6 +324,7 @@ int gsx_isect_fused_count(const float *means2d, const int32_t *radii, const floa
                                                       intersections (gsplat::intersect_tile_sparse); tiles_per_gauss may then be NULL */,
                           int64_t rows, uint32_t n_images, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                           int32_t *tiles_per_gauss, int32_t *isect_offsets, int64_t *n_isects,
+                          int64_t *max_tile_len /* optional (NULL): length of the longest tile list, written before n_isects */,
                           void *count_workspace, int64_t count_workspace_bytes, void *stream);
 int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *radii, const float *depths, const float *conics,
                               const float *opacities, const uint8_t *tile_mask, int64_t rows, uint32_t n_images, uint32_t tile_size,
@@ -351,8 +352,8 @@ int64_t gsx_isect_binned_emit_workspace_bytes(int64_t n_isects);
 int gsx_isect_binned_count(const float *means2d, const int32_t *radii, const float *depths, const float *conics,
                            const float *opacities, const uint8_t *tile_mask, int64_t rows, uint32_t n_images,
                            uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int32_t *tiles_per_gauss,
-                           int32_t *isect_offsets, int64_t *n_isects, void *count_workspace,
-                           int64_t count_workspace_bytes, void *stream);
+                           int32_t *isect_offsets, int64_t *n_isects, int64_t *max_tile_len /* optional, as above */,
+                           void *count_workspace, int64_t count_workspace_bytes, void *stream);
 int gsx_isect_binned_emit_sort(int64_t rows, uint32_t n_images, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                                void *count_workspace, int64_t count_workspace_bytes, const int32_t *isect_offsets,
                                int64_t n_isects, int64_t *isect_ids_sorted, int32_t *flatten_ids_sorted, void *workspace,
@@ -378,6 +379,19 @@ int gsx_raster3d_fwd(const float *means2d, const float *conics, const float *col
                      const int32_t *flatten_ids, uint32_t n_images, uint32_t n_isects, uint32_t cdim,
                      uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                      float *render_colors, float *render_alphas, int32_t *last_ids, void *stream);
+/* Forward with long tile lists cut into segments of seg_len entries that separate workgroups composite and a per-pixel
+ * combine (csrc/raster3d_seg.hip): same outputs as gsx_raster3d_fwd up to fp32 rounding of the transmittance products. For
+ * scenes with skewed lists (the reference's garden profile: mean 386, longest 8822 entries) the per-tile launch is as long
+ * as its longest list; tiles on which the reference's early termination would fire are walked the ordinary way. The caller
+ * decides when it pays (gsx_isect_*_count report the longest list) and provides the workspace. */
+int64_t gsx_raster3d_seg_workspace_bytes(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, uint32_t cdim,
+                                         uint32_t seg_len);
+int gsx_raster3d_fwd_seg(const float *means2d, const float *conics, const float *colors, const float *opacities,
+                         const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                         const int32_t *flatten_ids, uint32_t n_images, uint32_t n_isects, uint32_t cdim,
+                         uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                         float *render_colors, float *render_alphas, int32_t *last_ids, uint32_t seg_len, void *workspace,
+                         int64_t workspace_bytes, void *stream);
 int gsx_raster3d_bwd(const float *means2d, const float *conics, const float *colors, const float *opacities,
                      const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
                      const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,

@@ -1,0 +1,79 @@
+"""GPU: long tile lists composited in SEGMENTS (csrc/raster3d_seg.hip) against the one-workgroup-per-tile walk of the same
+lists, which the other suites pin to the oracle - and against the oracle directly on a small scene. Scenes: faint Gaussians
+(no pixel saturates: every long tile takes the segment path), opaque ones (early termination fires: the tiles are handed back
+to the ordinary walk), a mix, backgrounds, tile masks, more than 32 channels (two channel chunks), several images."""
+import math
+
+import pytest
+import torch
+
+from _util import assert_close_ratio, assert_grad_close, make_scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import gsplat_amd
+
+    return gsplat_amd
+
+
+def _lists(G, N, C, W, H, opacity, seed, shrink=0.25):
+    """Projected scene squeezed into the image centre so that tile lists run to several thousand entries."""
+    sc, W, H = make_scene(N=N, C=C, width=W, height=H, seed=seed)
+    a = {k: v.to(DEV) for k, v in sc.items()}
+    a["means"][:, :2] *= shrink
+    if opacity is not None:
+        a["opacities"] = torch.full_like(a["opacities"], opacity) if not callable(opacity) else opacity(a["opacities"])
+    rad, m2, d, con, _ = G.fully_fused_projection(a["means"], None, a["quats"], a["scales"], a["viewmats"], a["Ks"], W, H,
+                                                  opacities=a["opacities"])
+    op = a["opacities"][None].expand(C, -1).contiguous()
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    _, ids, fl = G.isect_tiles(m2, rad, d, 16, tw, th, conics=con, opacities=op)
+    off = G.isect_offset_encode(ids, C, tw, th)
+    counts = torch.diff(torch.cat([off.flatten(), torch.tensor([fl.numel()], device=DEV, dtype=off.dtype)]))
+    return m2, con, op, off, fl, int(counts.max()), W, H, tw, th
+
+
+@pytest.mark.parametrize("kind", ["faint", "opaque", "mixed"])
+@pytest.mark.parametrize("D", [3, 35])
+def test_segmented_forward_matches_per_tile_walk(G, kind, D):
+    opacity = {"faint": 0.004 * 2, "opaque": 0.9, "mixed": (lambda o: torch.where(torch.rand_like(o) < 0.5, o * 0.02 + 0.004, o))}[kind]
+    m2, con, op, off, fl, longest, W, H, tw, th = _lists(G, 40000, 2, 320, 192, opacity, seed=21)
+    assert longest > 3000, longest  # several segments per long tile
+    g = torch.Generator().manual_seed(D)
+    colors = torch.rand(m2.shape[:-1] + (D,), generator=g).to(DEV)
+    bg = torch.rand(2, D, generator=g).to(DEV)
+    masks = torch.ones(2, th, tw, dtype=torch.bool, device=DEV)
+    masks[0, th // 2, tw // 2] = False  # a masked tile in the crowded centre
+    for kw in (dict(), dict(backgrounds=bg), dict(backgrounds=bg, masks=masks)):
+        ref_c, ref_a = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl, **kw)
+        seg_c, seg_a = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl, _longest_tile_list=longest, **kw)
+        # the two differ only in the association order of the transmittance products (and, on saturating tiles, not at all)
+        assert_close_ratio(seg_c.cpu(), ref_c.cpu(), 2e-5, 2e-6, max_bad_ratio=1e-5, name=f"{kind} colours {sorted(kw)}")
+        assert_close_ratio(seg_a.cpu(), ref_a.cpu(), 2e-5, 2e-6, max_bad_ratio=1e-5, name=f"{kind} alphas {sorted(kw)}")
+
+
+def test_segmented_forward_last_ids_and_oracle(G):
+    """last_ids (consumed by the backward) must be the per-tile walk's; and the segmented render against the CPU oracle."""
+    from oracle import oracle as O
+
+    m2, con, op, off, fl, longest, W, H, tw, th = _lists(G, 30000, 1, 256, 160, 0.01, seed=5)
+    assert longest > 2500
+    colors = torch.rand(m2.shape[:-1] + (3,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    from gsplat_amd import _ops
+
+    outs = {}
+    for name, hint in (("tile", 0), ("seg", longest)):
+        _ops.set_long_tile_hint(hint)
+        outs[name] = torch.ops.gsplat.rasterize_to_pixels_3dgs(m2, con, colors, op, None, None, W, H, 16, off, fl, False, False)
+        _ops.set_long_tile_hint(0)
+    assert torch.equal(outs["seg"][3], outs["tile"][3]), "last_ids differ"
+    cpu = lambda t: t.detach().cpu()  # noqa: E731
+    rc_o, ra_o = O.rasterize_to_pixels(cpu(m2), cpu(con), cpu(colors), cpu(op), W, H, 16, cpu(off), cpu(fl))[:2]
+    assert_close_ratio(cpu(outs["seg"][0]), rc_o, 1e-3, 1e-4, max_bad_ratio=1e-3, name="segmented colours vs oracle")
+    assert_close_ratio(cpu(outs["seg"][1]), ra_o, 1e-3, 1e-4, max_bad_ratio=1e-3, name="segmented alphas vs oracle")
