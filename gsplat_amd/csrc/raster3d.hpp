@@ -64,13 +64,15 @@ struct Raster3DArgs {
     // long tile lists cut into SEGMENTS that separate workgroups composite (raster3d_seg.hip; dense layouts only). All
     // zero / null: one workgroup per tile walks its whole list.
     //   seg_mode 0  per-tile launch; with seg_len > 0 it leaves the tiles longer than seg_len to the launches below
-    //   seg_mode 1  one workgroup per SEGMENT item (tile block, first list index): list slice [first, first + seg_len)
-    //   seg_mode 2  one workgroup per listed tile block, whole list (the tiles the segment path hands back)
+    //   seg_mode 1  one workgroup per SEGMENT item (tile block, first list index), list slice [first, first + seg_len):
+    //               transmittance pass - the product of (1 - alpha) over the slice, from 1 (0 = the pixel stops inside)
+    //   seg_mode 2  same items: compositing pass, every pixel starts at the transmittance in front of its segment
     uint32_t seg_mode, seg_len, seg_grid;
-    const int32_t *seg_items; // mode 1: [n][2]; mode 2: [n]
+    const int32_t *seg_items; // [n][2]
     const int32_t *seg_count; // number of items, on the device
-    float *seg_out;           // mode 1, forward: [item][nch + 1][256] partial colours (transmittance 1 at the start) and T
-    int32_t *seg_last;        // mode 1, forward: [item][256] last contributing list index, -1 = none
+    float *seg_T;             // [item][256]  mode 1 out: transmittance of the slice; then (prefix kernel) in front of it: mode 2 in
+    float *seg_out;           // [item][nch + 1][256]  mode 2 out: partial colours, transmittance at the end of the slice
+    int32_t *seg_last;        // [item][256]  mode 2 out: last contributing list index, -1 = none
 };
 
 // Block index -> (image, tile) with an XCD-aware remap: hardware places workgroup b on
@@ -116,8 +118,8 @@ __device__ __forceinline__ bool tile_context(const Args &a, uint32_t block, Tile
     t.tile_y = t.tile_id / a.tile_w;
     return true;
 }
-// The compositing launches' version: segment items / handed-back tiles (seg_mode 1 / 2), else tile_context minus the tiles
-// that are left to the segment launches. `item` = index of the workgroup's item (modes 1, 2).
+// The compositing launches' version: segment items (seg_mode 1 / 2), else tile_context minus the tiles that are left to
+// the segment launches. `item` = index of the workgroup's item (modes 1, 2).
 __device__ __forceinline__ bool tile_context_seg(const Raster3DArgs &a, uint32_t block, TileCtx &t, uint32_t &item)
 {
     item = 0;
@@ -128,19 +130,14 @@ __device__ __forceinline__ bool tile_context_seg(const Raster3DArgs &a, uint32_t
     if ((int32_t)block >= *a.seg_count) return false;
     item = block;
     const uint32_t tiles_per_image = a.tile_w * a.tile_h, n_blocks = tiles_per_image * a.n_images;
-    const uint32_t blk = (uint32_t)(a.seg_mode == 1u ? a.seg_items[2 * block] : a.seg_items[block]);
+    const uint32_t blk = (uint32_t)a.seg_items[2 * block];
     t.image_id = blk / tiles_per_image;
     t.tile_id  = blk % tiles_per_image;
     t.tile_x   = t.tile_id % a.tile_w;
     t.tile_y   = t.tile_id / a.tile_w;
     const int32_t tile_end = (blk == n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
-    if (a.seg_mode == 1u) {
-        t.range_start = a.seg_items[2 * block + 1];
-        t.range_end   = min(t.range_start + (int32_t)a.seg_len, tile_end);
-    } else {
-        t.range_start = a.isect_offsets[blk];
-        t.range_end   = tile_end;
-    }
+    t.range_start = a.seg_items[2 * block + 1];
+    t.range_end   = min(t.range_start + (int32_t)a.seg_len, tile_end);
     return true;
 }
 

@@ -42,7 +42,11 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 
     // masked-off tile: background colour, zero alpha, last_id 0 (reference Fwd.cu:141-159)
     if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) {
-        if (a.seg_mode == 1u) { // a masked tile's segments contribute nothing; the combine step writes the background
+        if (a.seg_mode == 1u) { // a masked tile's segments contribute nothing: transmittance 1 everywhere
+            a.seg_T[(size_t)seg_item * 256 + tid] = 1.0f;
+            return;
+        }
+        if (a.seg_mode == 2u) {
             for (uint32_t k = 0; k < a.nch; ++k) a.seg_out[((size_t)seg_item * (a.nch + 1) + k) * 256 + tid] = 0.0f;
             a.seg_out[((size_t)seg_item * (a.nch + 1) + a.nch) * 256 + tid] = 1.0f;
             a.seg_last[(size_t)seg_item * 256 + tid] = -1;
@@ -64,11 +68,15 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
     const int32_t n_batches   = (range_end - range_start + kBatch - 1) / kBatch;
 
     float T          = 1.0f;
-    uint32_t cur_idx = a.seg_mode == 1u ? 0xFFFFFFFFu : 0u; // a segment reports "no contributor" as -1
+    uint32_t cur_idx = a.seg_mode ? 0xFFFFFFFFu : 0u; // a segment reports "no contributor" as -1
     float acc[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) acc[k] = 0.0f;
     float thr = inside ? kAlphaThreshold : INFINITY; // alpha threshold of this pixel; +inf = done (or not rendered)
+    if (a.seg_mode == 2u) { // compositing pass of a segment: the transmittance in front of it (raster3d_seg.hip: seg_prefix)
+        T = a.seg_T[(size_t)seg_item * 256 + tid];
+        if (!(T > kTransmittanceThresh)) thr = INFINITY; // the pixel stopped in an earlier segment
+    }
     const uint32_t lane = tid & 63u;
 
     for (int32_t b = 0; b < n_batches; ++b) {
@@ -154,7 +162,11 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
         }
     }
 
-    if (a.seg_mode == 1u) { // partial result of this segment, pixel-major planes (raster3d_seg.hip combines them)
+    if (a.seg_mode == 1u) { // transmittance of this slice from 1; 0 = the early-termination rule fired inside it
+        a.seg_T[(size_t)seg_item * 256 + tid] = (inside && !(thr < INFINITY)) ? 0.0f : T;
+        return;
+    }
+    if (a.seg_mode == 2u) { // partial result of this segment, pixel-major planes (raster3d_seg.hip combines them)
 #pragma unroll
         for (int k = 0; k < CH; ++k)
             if (k < (int)a.nch) a.seg_out[((size_t)seg_item * (a.nch + 1) + k) * 256 + tid] = acc[k];

@@ -4,22 +4,23 @@
 // One workgroup per tile (the reference's decomposition too: RasterizeToPixels3DGSSerialBatchFwd.cu:41) makes the launch as
 // long as its LONGEST list. Real scenes have skewed lists - the reference's garden profile: mean 386 entries, 99th percentile
 // 4107, longest 8822 on 8160 tiles, 2.7x the ideal per-slot load whatever the launch order - so a tile whose list exceeds
-// `seg_len` is cut into segments of seg_len entries:
+// `seg_len` is cut into segments of seg_len entries, one workgroup each:
 //   1. seg_plan       one thread per tile: tiles longer than seg_len -> segment items (tile, first index) + a long-tile record
 //   2. raster3d_fwd   seg_mode 0: the ordinary per-tile launch, minus the long tiles
-//   3. raster3d_fwd   seg_mode 1: one workgroup per segment composites it from transmittance 1 and stores, per pixel, its
-//                     partial colours C_k, its transmittance T_k and its last contributor
-//   4. seg_combine    one workgroup per long tile, front to back over its segments: C = sum_k P_k C_k, P_{k+1} = P_k T_k -
-//                     compositing is an affine recurrence, so the segments compose exactly (up to fp32 rounding of the
-//                     products)
-//   5. raster3d_fwd   seg_mode 2: the tiles step 4 hands back (below)
-// Early termination is the one thing that does NOT decompose: the reference stops a pixel at the first Gaussian that would
-// bring its transmittance to <= 1e-4 and excludes it, and a segment that starts at T = 1 cannot know the transmittance in
-// front of it. Transmittance only decreases, so the rule fires somewhere iff the product over the WHOLE list is <= 1e-4:
-// step 4 computes that product anyway, and a tile with any pixel at or below 1e-4 (1 + 1e-5) - the margin covers the
-// rounding of the product order - is not written but listed for step 5, which walks its list the ordinary way. Scenes that
-// saturate (the dense synthetic c3 scene) have short effective lists anyway - whole waves exit early - and scenes with long
-// lists of faint Gaussians (the garden profile) do not saturate: the certificate is cheap and almost always holds.
+//   3. raster3d_fwd   seg_mode 1: TRANSMITTANCE pass - per segment and pixel the product of (1 - alpha) over the slice
+//                     (0 if the reference's early termination fires inside the slice even when entered at T = 1)
+//   4. seg_prefix     one workgroup per long tile: running product over its segments -> the transmittance IN FRONT of every
+//                     segment, per pixel
+//   5. raster3d_fwd   seg_mode 2: compositing pass - every pixel of a segment starts at that transmittance, so colours,
+//                     the early-termination rule (T' <= 1e-4 stops the pixel and excludes the Gaussian: compared on the true
+//                     running transmittance) and last_ids are those of the sequential walk; a pixel whose prefix is already
+//                     <= 1e-4 stopped in an earlier segment and does nothing (transmittance only decreases)
+//   6. seg_combine    one workgroup per long tile: colours add up, the final transmittance / last contributor come from the
+//                     last segment the pixel was alive in
+// The only difference to the sequential walk is the association order of the transmittance products (segment products
+// first): ~1e-7 relative, which can move a threshold decision on a pixel that sits exactly on it - the class of difference
+// the reference's own CUDA-vs-torch tolerances cover. The price is pass 3: the alphas of a long tile are evaluated twice
+// (~0.6 of a forward); in exchange its critical path is one segment instead of the whole list.
 #include "raster3d.hpp"
 #include "../../include/gsplat_amd.h"
 
@@ -28,15 +29,15 @@ namespace gsx {
 int raster3d_fwd_launch_chunk(const Raster3DArgs &a, hipStream_t stream); // raster3d_fwd.hip
 
 struct SegHeader { // device memory, zeroed before every use
-    int32_t n_items, n_long, n_back, pad;
+    int32_t n_items, n_long, pad[2];
 };
 
 struct SegPlan {
     SegHeader *hdr;
     int32_t *items; // [max_items][2] (tile block, first list index)
     int32_t *longs; // [max_long][3]  (tile block, first item, number of segments)
-    int32_t *back;  // [max_long]     tile blocks handed back to the per-tile walk
     int32_t *last;  // [max_items][256]
+    float *T;       // [max_items][256]
     float *out;     // [max_items][nch_max + 1][256]
     uint32_t max_items, max_long;
 };
@@ -64,8 +65,8 @@ static int64_t seg_layout(int64_t n_isects, uint32_t n_tiles_total, uint32_t nch
     t.hdr   = reinterpret_cast<SegHeader *>(take(sizeof(SegHeader)));
     t.items = reinterpret_cast<int32_t *>(take((int64_t)t.max_items * 8));
     t.longs = reinterpret_cast<int32_t *>(take((int64_t)t.max_long * 12));
-    t.back  = reinterpret_cast<int32_t *>(take((int64_t)t.max_long * 4));
     t.last  = reinterpret_cast<int32_t *>(take((int64_t)t.max_items * 256 * 4));
+    t.T     = reinterpret_cast<float *>(take((int64_t)t.max_items * 256 * 4));
     t.out   = reinterpret_cast<float *>(take((int64_t)t.max_items * (nch_max + 1) * 256 * 4));
     if (p) *p = t;
     return (int64_t)(q - base);
@@ -89,6 +90,21 @@ __global__ void __launch_bounds__(256) seg_plan_kernel(const int32_t *offsets, u
     }
 }
 
+// one workgroup per long tile, thread = pixel: slice transmittances -> transmittance in front of every slice (in place)
+__global__ void __launch_bounds__(256) seg_prefix_kernel(SegPlan p)
+{
+    const int32_t li = (int32_t)blockIdx.x;
+    if (li >= p.hdr->n_long) return;
+    const int32_t s0 = p.longs[3 * li + 1], n_seg = p.longs[3 * li + 2];
+    float P = 1.0f;
+    for (int32_t k = 0; k < n_seg; ++k) {
+        float *slot   = p.T + (size_t)(s0 + k) * 256 + threadIdx.x;
+        const float t = *slot;
+        *slot         = P;
+        P *= t;
+    }
+}
+
 // one workgroup per long tile; thread = pixel in the per-tile launch's order (tile_pixel)
 __global__ void __launch_bounds__(256) seg_combine_kernel(const Raster3DArgs a, SegPlan p)
 {
@@ -105,38 +121,28 @@ __global__ void __launch_bounds__(256) seg_combine_kernel(const Raster3DArgs a, 
     uint32_t lx, ly;
     tile_pixel(tid, a.tile_size, lx, ly);
     const int64_t prow = pixel_row(a, tc, 0u, lx, ly);
-    const bool inside  = prow >= 0;
+    if (prow < 0) return;
+    const size_t pix      = (size_t)prow;
     const uint32_t planes = a.nch + 1;
-    // transmittance in front of every segment, last contributor
-    float P = 1.0f;
-    int32_t last = -1;
+    // the last segment the pixel was alive in gives the final transmittance; contributors only exist in such segments
+    float T_final = 1.0f;
+    int32_t last  = -1;
     for (int32_t k = 0; k < n_seg; ++k) {
         const size_t it = (size_t)(s0 + k);
+        if (!(p.T[it * 256 + tid] > kTransmittanceThresh)) break; // stopped before this segment (and all later ones)
+        T_final         = p.out[(it * planes + a.nch) * 256 + tid];
         const int32_t l = p.last[it * 256 + tid];
-        last = l >= 0 ? l : last;
-        P *= p.out[(it * planes + a.nch) * 256 + tid];
+        last            = l >= 0 ? l : last;
     }
-    // would the reference's early termination have fired anywhere in this tile? (see the file header)
-    const bool saturates = inside && !(P > kTransmittanceThresh * (1.0f + 1e-5f));
-    if (__syncthreads_or(saturates)) {
-        if (tid == 0 && a.first_chunk) p.back[atomicAdd(&p.hdr->n_back, 1)] = (int32_t)blk;
-        return; // every channel chunk reaches the same verdict (it only depends on the transmittances)
-    }
-    if (!inside) return;
-    const size_t pix = (size_t)prow;
-    const float *bg  = a.backgrounds ? a.backgrounds + (size_t)tc.image_id * a.cdim + a.ch_off : nullptr;
+    const float *bg   = a.backgrounds ? a.backgrounds + (size_t)tc.image_id * a.cdim + a.ch_off : nullptr;
     const bool masked = a.masks && !a.masks[(size_t)tc.image_id * tiles_per_image + tc.tile_id];
     for (uint32_t c = 0; c < a.nch; ++c) {
-        float acc = 0.0f, Pk = 1.0f;
-        for (int32_t k = 0; k < n_seg; ++k) {
-            const size_t it = (size_t)(s0 + k);
-            acc = fmaf(Pk, p.out[(it * planes + c) * 256 + tid], acc);
-            Pk *= p.out[(it * planes + a.nch) * 256 + tid];
-        }
-        a.render_colors[pix * a.cdim + a.ch_off + c] = masked ? (bg ? bg[c] : 0.0f) : (bg ? acc + P * bg[c] : acc);
+        float acc = 0.0f;
+        for (int32_t k = 0; k < n_seg; ++k) acc += p.out[((size_t)(s0 + k) * planes + c) * 256 + tid]; // front to back
+        a.render_colors[pix * a.cdim + a.ch_off + c] = masked ? (bg ? bg[c] : 0.0f) : (bg ? acc + T_final * bg[c] : acc);
     }
     if (a.first_chunk) {
-        a.render_alphas[pix] = masked ? 0.0f : 1.0f - P;
+        a.render_alphas[pix] = masked ? 0.0f : 1.0f - T_final;
         a.last_ids[pix]      = masked ? 0 : (last >= 0 ? last : 0);
     }
 }
@@ -194,15 +200,20 @@ extern "C" int gsx_raster3d_fwd_seg(
         int rc = raster3d_fwd_launch_chunk(a, s);
         if (rc != GSX_OK) return rc;
         if (p.max_items > 0) {
-            a.seg_mode = 1; a.seg_grid = p.max_items; a.seg_items = p.items; a.seg_count = &p.hdr->n_items;
-            a.seg_out = p.out; a.seg_last = p.last;
+            a.seg_grid = p.max_items; a.seg_items = p.items; a.seg_count = &p.hdr->n_items;
+            a.seg_T = p.T; a.seg_out = p.out; a.seg_last = p.last;
+            if (first) { // the transmittances do not depend on the channel chunk
+                Raster3DArgs t = a;
+                t.seg_mode = 1; t.nch = 1; // one channel is the cheapest instantiation; its colour sum is not stored
+                rc = raster3d_fwd_launch_chunk(t, s);
+                if (rc != GSX_OK) return rc;
+                seg_prefix_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(p);
+            }
+            a.seg_mode = 2;
             rc = raster3d_fwd_launch_chunk(a, s);
             if (rc != GSX_OK) return rc;
             a.seg_mode = 0;
             seg_combine_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(a, p);
-            a.seg_mode = 2; a.seg_grid = p.max_long; a.seg_items = p.back; a.seg_count = &p.hdr->n_back;
-            rc = raster3d_fwd_launch_chunk(a, s);
-            if (rc != GSX_OK) return rc;
         }
         off += a.nch;
         first = false;

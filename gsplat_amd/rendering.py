@@ -139,7 +139,7 @@ def rasterization(
         raise RuntimeError(
             "gsplat_amd builds the classic 3DGS path and, of 3DGUT, the unscented projection and the from-world rasterizer for "
             "global-shutter pinhole / distorted-pinhole / orthographic / fisheye cameras (build_config()['3dgut'] is True); "
-            f"these sub-features are not built and are refused rather than approximated: {', '.join(bad)}"
+            f"these sub-features are not built - not supported, refused rather than approximated: {', '.join(bad)}"
         )
     if camera_model not in ("pinhole", "ortho", "fisheye"):
         raise ValueError(f"camera_model '{camera_model}' is not supported (pinhole / ortho / fisheye)")
