@@ -127,9 +127,24 @@ __device__ __forceinline__ bool tile_context_seg(const Raster3DArgs &a, uint32_t
         if (!tile_context(a, block, t)) return false;
         return !(a.seg_len && !a.sp_active_tiles && (uint32_t)(t.range_end - t.range_start) > a.seg_len);
     }
-    if ((int32_t)block >= *a.seg_count) return false;
-    item = block;
+    const int32_t n_items = *a.seg_count;
     const uint32_t tiles_per_image = a.tile_w * a.tile_h, n_blocks = tiles_per_image * a.n_images;
+    if ((int32_t)block >= n_items) {
+        // compositing pass: the workgroups behind the segment items take the SHORT tiles, whole list, straight into the
+        // image (item = ~0) - one launch for everything, the long segments first
+        if (a.seg_mode != 2u) return false;
+        const uint32_t blk = block - (uint32_t)n_items;
+        if (blk >= n_blocks) return false;
+        item       = 0xFFFFFFFFu;
+        t.image_id = blk / tiles_per_image;
+        t.tile_id  = blk % tiles_per_image;
+        t.tile_x   = t.tile_id % a.tile_w;
+        t.tile_y   = t.tile_id / a.tile_w;
+        t.range_start = a.isect_offsets[blk];
+        t.range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
+        return (uint32_t)(t.range_end - t.range_start) <= a.seg_len;
+    }
+    item = block;
     const uint32_t blk = (uint32_t)a.seg_items[2 * block];
     t.image_id = blk / tiles_per_image;
     t.tile_id  = blk % tiles_per_image;

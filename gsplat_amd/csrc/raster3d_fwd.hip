@@ -24,6 +24,9 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
     TileCtx tc;
     uint32_t seg_item;
     if (!tile_context_seg(a, blockIdx.x, tc, seg_item)) return; // uniform for the whole workgroup
+    // what this workgroup is: a whole tile (also the short tiles of a compositing-pass launch), or a segment in the
+    // transmittance / compositing pass
+    const uint32_t seg_mode = seg_item == 0xFFFFFFFFu ? 0u : a.seg_mode;
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
     const uint32_t image_id = tc.image_id, tile_id = tc.tile_id;
     const uint32_t tid      = threadIdx.x;
@@ -42,11 +45,11 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 
     // masked-off tile: background colour, zero alpha, last_id 0 (reference Fwd.cu:141-159)
     if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) {
-        if (a.seg_mode == 1u) { // a masked tile's segments contribute nothing: transmittance 1 everywhere
+        if (seg_mode == 1u) { // a masked tile's segments contribute nothing: transmittance 1 everywhere
             a.seg_T[(size_t)seg_item * 256 + tid] = 1.0f;
             return;
         }
-        if (a.seg_mode == 2u) {
+        if (seg_mode == 2u) {
             for (uint32_t k = 0; k < a.nch; ++k) a.seg_out[((size_t)seg_item * (a.nch + 1) + k) * 256 + tid] = 0.0f;
             a.seg_out[((size_t)seg_item * (a.nch + 1) + a.nch) * 256 + tid] = 1.0f;
             a.seg_last[(size_t)seg_item * 256 + tid] = -1;
@@ -68,12 +71,12 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
     const int32_t n_batches   = (range_end - range_start + kBatch - 1) / kBatch;
 
     float T          = 1.0f;
-    uint32_t cur_idx = a.seg_mode ? 0xFFFFFFFFu : 0u; // a segment reports "no contributor" as -1
+    uint32_t cur_idx = seg_mode ? 0xFFFFFFFFu : 0u; // a segment reports "no contributor" as -1
     float acc[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) acc[k] = 0.0f;
     float thr = inside ? kAlphaThreshold : INFINITY; // alpha threshold of this pixel; +inf = done (or not rendered)
-    if (a.seg_mode == 2u) { // compositing pass of a segment: the transmittance in front of it (raster3d_seg.hip: seg_prefix)
+    if (seg_mode == 2u) { // compositing pass of a segment: the transmittance in front of it (raster3d_seg.hip: seg_prefix)
         T = a.seg_T[(size_t)seg_item * 256 + tid];
         if (!(T > kTransmittanceThresh)) thr = INFINITY; // the pixel stopped in an earlier segment
     }
@@ -162,11 +165,11 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
         }
     }
 
-    if (a.seg_mode == 1u) { // transmittance of this slice from 1; 0 = the early-termination rule fired inside it
+    if (seg_mode == 1u) { // transmittance of this slice from 1; 0 = the early-termination rule fired inside it
         a.seg_T[(size_t)seg_item * 256 + tid] = (inside && !(thr < INFINITY)) ? 0.0f : T;
         return;
     }
-    if (a.seg_mode == 2u) { // partial result of this segment, pixel-major planes (raster3d_seg.hip combines them)
+    if (seg_mode == 2u) { // partial result of this segment, pixel-major planes (raster3d_seg.hip combines them)
 #pragma unroll
         for (int k = 0; k < CH; ++k)
             if (k < (int)a.nch) a.seg_out[((size_t)seg_item * (a.nch + 1) + k) * 256 + tid] = acc[k];

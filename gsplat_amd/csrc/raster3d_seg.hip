@@ -6,12 +6,12 @@
 // 4107, longest 8822 on 8160 tiles, 2.7x the ideal per-slot load whatever the launch order - so a tile whose list exceeds
 // `seg_len` is cut into segments of seg_len entries, one workgroup each:
 //   1. seg_plan       one thread per tile: tiles longer than seg_len -> segment items (tile, first index) + a long-tile record
-//   2. raster3d_fwd   seg_mode 0: the ordinary per-tile launch, minus the long tiles
 //   3. raster3d_fwd   seg_mode 1: TRANSMITTANCE pass - per segment and pixel the product of (1 - alpha) over the slice
 //                     (0 if the reference's early termination fires inside the slice even when entered at T = 1)
 //   4. seg_prefix     one workgroup per long tile: running product over its segments -> the transmittance IN FRONT of every
 //                     segment, per pixel
-//   5. raster3d_fwd   seg_mode 2: compositing pass - every pixel of a segment starts at that transmittance, so colours,
+//   5. raster3d_fwd   seg_mode 2: compositing pass - ONE launch for the segments (first) and the short tiles (behind them,
+//                     whole list, straight into the image); every pixel of a segment starts at that transmittance, so colours,
 //                     the early-termination rule (T' <= 1e-4 stops the pixel and excludes the Gaussian: compared on the true
 //                     running transmittance) and last_ids are those of the sequential walk; a pixel whose prefix is already
 //                     <= 1e-4 stopped in an earlier segment and does nothing (transmittance only decreases)
@@ -196,24 +196,28 @@ extern "C" int gsx_raster3d_fwd_seg(
         const uint32_t rem = cdim - off;
         a.ch_off = off; a.nch = rem > 32 ? 32 : rem; a.first_chunk = first ? 1u : 0u;
         a.seg_len = seg_len;
-        a.seg_mode = 0; // short tiles, one workgroup each
-        int rc = raster3d_fwd_launch_chunk(a, s);
-        if (rc != GSX_OK) return rc;
+        int rc;
         if (p.max_items > 0) {
-            a.seg_grid = p.max_items; a.seg_items = p.items; a.seg_count = &p.hdr->n_items;
+            a.seg_items = p.items; a.seg_count = &p.hdr->n_items;
             a.seg_T = p.T; a.seg_out = p.out; a.seg_last = p.last;
             if (first) { // the transmittances do not depend on the channel chunk
                 Raster3DArgs t = a;
-                t.seg_mode = 1; t.nch = 1; // one channel is the cheapest instantiation; its colour sum is not stored
+                t.seg_mode = 1; t.seg_grid = p.max_items;
+                t.nch = 1; // one channel is the cheapest instantiation; its colour sum is not stored
                 rc = raster3d_fwd_launch_chunk(t, s);
                 if (rc != GSX_OK) return rc;
                 seg_prefix_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(p);
             }
-            a.seg_mode = 2;
+            // ONE compositing launch: the segment items first (the longest units of work), the short tiles behind them
+            a.seg_mode = 2; a.seg_grid = p.max_items + n_blocks;
             rc = raster3d_fwd_launch_chunk(a, s);
             if (rc != GSX_OK) return rc;
             a.seg_mode = 0;
             seg_combine_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(a, p);
+        } else {
+            a.seg_mode = 0;
+            rc = raster3d_fwd_launch_chunk(a, s);
+            if (rc != GSX_OK) return rc;
         }
         off += a.nch;
         first = false;
