@@ -146,6 +146,7 @@ def _rast_setup(ctx, inputs, output):
     ctx.width, ctx.height, ctx.tile_size, ctx.absgrad = image_width, image_height, tile_size, absgrad
     ctx.set_materialize_grads(False)  # an unused render_alphas (or render_colors) gets no zero-filled gradient
     ctx.rc_shape = _render_colors.shape
+    ctx.longest = _ops.long_tile_hint_of_call()  # the backward cuts the same long lists into segments
     ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids,
                           render_alphas, last_ids, means2d_absgrad)
 
@@ -153,11 +154,16 @@ def _rast_setup(ctx, inputs, output):
 def _rast_backward(ctx, v_render_colors, v_render_alphas, v_means2d_absgrad, v_last_ids):
     (means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas, last_ids,
      means2d_absgrad) = ctx.saved_tensors
-    v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities, v_backgrounds = _bwd("rasterize_to_pixels_3dgs")(
-        means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas, last_ids,
-        ctx.width, ctx.height, ctx.tile_size, ctx.absgrad, _z(v_render_colors, ctx.rc_shape, render_alphas).contiguous(),
-        None if v_render_alphas is None else v_render_alphas.contiguous(), ctx.needs_input_grad[4],
-    )
+    hint = _ops
+    hint.set_long_tile_hint(ctx.longest)  # this (autograd) thread's hint; the op body consumes it
+    try:
+        v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities, v_backgrounds = _bwd("rasterize_to_pixels_3dgs")(
+            means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas, last_ids,
+            ctx.width, ctx.height, ctx.tile_size, ctx.absgrad, _z(v_render_colors, ctx.rc_shape, render_alphas).contiguous(),
+            None if v_render_alphas is None else v_render_alphas.contiguous(), ctx.needs_input_grad[4],
+        )
+    finally:
+        hint.set_long_tile_hint(0)
     if ctx.absgrad and v_means2d_abs is not None:
         means2d_absgrad.copy_(v_means2d_abs)
     return (v_means2d, v_conics, v_colors, v_opacities, v_backgrounds) + (None,) * 8

@@ -61,7 +61,8 @@ _COMPILED_ISECT = False  # torch.ops.gsplat_amd.isect_fused_{begin,finish} avail
 # rendering.py learns the longest tile list from the intersection's pinned host words; the reference's op schemas have no
 # room for it, so it travels as a per-thread hint around the op call: above SEG_MIN_LONGEST the forward / backward cut long
 # lists into segments that separate workgroups composite (csrc/raster3d_seg.hip). No hint (0) = one workgroup per tile.
-SEG_LEN, SEG_MIN_LONGEST = 1024, 2048
+SEG_LEN = int(os.environ.get("GSPLAT_AMD_SEG_LEN", "1024"))  # 0 switches segmenting off (A/B)
+SEG_MIN_LONGEST = 2 * SEG_LEN if SEG_LEN > 0 else 1 << 62
 _hint = __import__("threading").local()
 _set_hint_compiled = None  # gsx_torch_set_long_tile_hint of libgsplat_amd_torch.so (the compiled op bodies read it)
 
@@ -70,8 +71,14 @@ def long_tile_hint() -> int:
     return getattr(_hint, "longest", 0)
 
 
+def long_tile_hint_of_call() -> int:
+    """What the caller set around the op call in flight - still readable after the op body consumed long_tile_hint()
+    (the autograd setup_context stores it for the backward)."""
+    return getattr(_hint, "of_call", 0)
+
+
 def set_long_tile_hint(longest: int) -> None:
-    _hint.longest = int(longest)
+    _hint.longest = _hint.of_call = int(longest)
     if _set_hint_compiled is not None:
         _set_hint_compiled(int(longest))
 
@@ -823,10 +830,20 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     R = opacities.numel()
     geo = 8 if absgrad else 6
     rows = torch.zeros((R, geo + D), device=means2d.device, dtype=means2d.dtype)
-    call("gsx_raster3d_bwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
-         ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
-         ptr(last_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
-         image_width, image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D)
+    longest = long_tile_hint()  # set by the autograd formula around this call
+    set_long_tile_hint(0)
+    if longest > SEG_MIN_LONGEST and not absgrad and D <= 4 and tile_size == 16:
+        ws = torch.empty(_cabi._lib.gsx_raster3d_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN),
+                         device=means2d.device, dtype=torch.uint8)
+        call("gsx_raster3d_bwd_seg", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+             ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
+             ptr(last_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
+             image_width, image_height, tile_size, tw, th, ptr(rows), geo + D, SEG_LEN, ptr(ws), ws.numel())
+    else:
+        call("gsx_raster3d_bwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+             ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
+             ptr(last_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
+             image_width, image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D)
     v_means2d, v_conics = rows[:, 0:2].view(means2d.shape), rows[:, 2:5].view(conics.shape)
     v_opacities, v_colors = rows[:, 5].view(opacities.shape), rows[:, geo:].view(colors.shape)
     v_abs = rows[:, 6:8].view(means2d.shape) if absgrad else None

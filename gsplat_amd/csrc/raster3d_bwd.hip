@@ -335,7 +335,9 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
     float *s_w       = s_acc + Cfg::NACC * BATCH * KP;             // [4 waves][SLOTS][WROW]
 
     TileCtx tc;
-    if (!tile_context(a, blockIdx.x, tc)) return;
+    uint32_t seg_item;
+    if (!tile_context_seg(a, blockIdx.x, tc, seg_item)) return;
+    const bool in_segment = a.seg_mode != 0u && seg_item != 0xFFFFFFFFu; // a slice of a long tile list (raster3d_seg.hip)
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
     const uint32_t image_id = tc.image_id, tile_id = tc.tile_id;
     if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) return;
@@ -357,7 +359,8 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
     if (tc.range_end <= range_start) return;
 
     const float T_final     = inside ? 1.0f - a.render_alphas[pix] : 1.0f;
-    float T                 = T_final;
+    // a slice starts (back to front) from the transmittance at ITS end and from what lies behind it (raster3d_seg.hip)
+    float T                 = in_segment ? a.seg_T[(size_t)seg_item * 256 + tid] : T_final;
     const int32_t bin_final = inside ? a.last_ids[pix] : -1;
     // The forward pass stopped every pixel at its last contributor (early termination at T <= 1e-4 cuts the lists of a
     // dense scene to a fraction of their length): nothing behind the LAST contributor of the whole tile is ever needed, so
@@ -386,7 +389,7 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
             if (k < (int)a.nch) bg_dot += bg[k] * v_c[k];
     }
     const float tail_term = T_final * (v_a - bg_dot); // T_final (v_a - bg . v_c): what lies behind the whole list
-    float behind          = 0.0f;                     // B = sum_k buffer_k v_c,k (see the pixel loop)
+    float behind          = in_segment ? a.seg_out[(size_t)seg_item * 256 + tid] : 0.0f; // B = sum_k buffer_k v_c,k (pixel loop)
     const WaveRect rect          = wave_pixel_rect(inside, pu, pv); // tile-centre coordinates, like s_cull
 
     // roles in a turn: this lane owns slot bg and quadrant row bv (pixels 8 bv .. 8 bv + 7 of the wave, u = 0..7)
@@ -669,6 +672,19 @@ static int launch_bwd(const Raster3DArgs &a, hipStream_t stream)
     raster3d_bwd_kernel<CH, ABS><<<dim3(grid), dim3(block), smem, stream>>>(a);
     return check_launch("raster3d_bwd");
 }
+
+// variant T over a segment item list + the short tiles behind it (raster3d_seg.hip); a.nch <= 4, tile size 16, no absgrad
+int raster3d_bwd_t_launch_items(const Raster3DArgs &a, hipStream_t stream)
+{
+    const uint32_t grid = ((a.seg_grid + 7u) / 8u) * 8u;
+    if (grid == 0) return GSX_OK;
+    if (a.nch <= 1) raster3d_bwd_t_kernel<1><<<dim3(grid), dim3(256), BwdTCfg<1>::smem, stream>>>(a);
+    else if (a.nch <= 2) raster3d_bwd_t_kernel<2><<<dim3(grid), dim3(256), BwdTCfg<2>::smem, stream>>>(a);
+    else if (a.nch <= 3) raster3d_bwd_t_kernel<3><<<dim3(grid), dim3(256), BwdTCfg<3>::smem, stream>>>(a);
+    else raster3d_bwd_t_kernel<4><<<dim3(grid), dim3(256), BwdTCfg<4>::smem, stream>>>(a);
+    return check_launch("raster3d_bwd_t(segments)");
+}
+bool raster3d_bwd_uses_variant_t() { return use_variant_t(); }
 
 template <bool ABS>
 static int bwd_dispatch(Raster3DArgs a, hipStream_t stream)

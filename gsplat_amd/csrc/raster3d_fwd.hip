@@ -12,7 +12,10 @@ constexpr int kBatch = 256;
 // four colours) read with b128 + b128 + b64 from one address register; colours 4.. in a separate table.
 // r05 A/B on c3 (profiles/r05_ab.md): float4 + float2 + 3 floats 0.304 ms -> packed float4s 0.280 -> e-form see there.
 
-template <int CH>
+// PRE = true: the pre-pass of the SEGMENTED BACKWARD (raster3d_seg.hip) - one workgroup per segment item walks its slice
+// front to back from transmittance 1 with the contributors the forward pass fixed (alpha test, list index <= last_ids; no
+// early-termination rule) and stores, per pixel, the slice's transmittance and S = sum_i alpha_i T_i (c_i . v_colour).
+template <int CH, bool PRE = false>
 __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -45,6 +48,11 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 
     // masked-off tile: background colour, zero alpha, last_id 0 (reference Fwd.cu:141-159)
     if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) {
+        if constexpr (PRE) {
+            a.seg_T[(size_t)seg_item * 256 + tid]   = 1.0f;
+            a.seg_out[(size_t)seg_item * 256 + tid] = 0.0f;
+            return;
+        }
         if (seg_mode == 1u) { // a masked tile's segments contribute nothing: transmittance 1 everywhere
             a.seg_T[(size_t)seg_item * 256 + tid] = 1.0f;
             return;
@@ -67,8 +75,18 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
         return;
     }
 
-    const int32_t range_start = tc.range_start, range_end = tc.range_end;
-    const int32_t n_batches   = (range_end - range_start + kBatch - 1) / kBatch;
+    const int32_t range_start = tc.range_start;
+    int32_t range_end = tc.range_end;
+    int32_t last_id   = -1; // PRE: this pixel's last contributor (list index); entries behind it belong to other pixels
+    if constexpr (PRE) {
+        last_id = inside ? a.last_ids[pix] : -1;
+        __shared__ int32_t s_m[4];
+        const int32_t wm = wave_max_i32(last_id);
+        if ((tid & 63u) == 0) s_m[tid >> 6] = wm;
+        __syncthreads();
+        range_end = min(range_end, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])) + 1); // nothing behind the tile's last one
+    }
+    const int32_t n_batches = range_end > range_start ? (range_end - range_start + kBatch - 1) / kBatch : 0;
 
     float T          = 1.0f;
     uint32_t cur_idx = seg_mode ? 0xFFFFFFFFu : 0u; // a segment reports "no contributor" as -1
@@ -146,10 +164,11 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 // done" lived in an EXEC-style mask (25 scalar instructions per surviving Gaussian, r05 PMC): the state now
                 // lives in vector registers - `thr` is the pixel's alpha threshold and becomes +inf once it is done - and the
                 // three decisions (passes / saturates / is blended) are lane masks combined on the scalar side.
-                const bool ok = !(e > p0.w) && !(alpha < thr); // e > lo <=> sigma < 0
+                bool ok = !(e > p0.w) && !(alpha < thr); // e > lo <=> sigma < 0
+                if constexpr (PRE) ok = ok && (batch_start + t <= last_id);
                 if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue; // wave-uniform
                 const float next_T = fmaf(-T, alpha, T);
-                const bool low     = next_T <= kTransmittanceThresh; // saturated: this Gaussian is excluded
+                const bool low     = PRE ? false : next_T <= kTransmittanceThresh; // saturated: this Gaussian is excluded
                 const bool sat = ok && low, take = ok && !sat;
                 const float w  = take ? alpha * T : 0.0f;
                 acc[0] += p2.x * w;
@@ -165,6 +184,17 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
         }
     }
 
+    if constexpr (PRE) {
+        float S = 0.0f;
+        if (inside) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (k < (int)a.nch) S = fmaf(acc[k], a.v_render_colors[pix * a.cdim + a.ch_off + k], S);
+        }
+        a.seg_T[(size_t)seg_item * 256 + tid]   = T;
+        a.seg_out[(size_t)seg_item * 256 + tid] = S;
+        return;
+    }
     if (seg_mode == 1u) { // transmittance of this slice from 1; 0 = the early-termination rule fired inside it
         a.seg_T[(size_t)seg_item * 256 + tid] = (inside && !(thr < INFINITY)) ? 0.0f : T;
         return;
@@ -199,6 +229,19 @@ static int launch_fwd(const Raster3DArgs &a, hipStream_t stream)
     const size_t smem     = kBatch * (sizeof(StagedRow) + sizeof(float4) + sizeof(float) * (CH > 4 ? CH - 4 : 0));
     hipLaunchKernelGGL(raster3d_fwd_kernel<CH>, dim3(grid), dim3(block), smem, stream, a);
     return check_launch("raster3d_fwd");
+}
+
+// pre-pass of the segmented backward (<= 4 channels: the backward's variant T): a.seg_mode = 1 item list, grid a.seg_grid
+int raster3d_bwd_prepass_launch(const Raster3DArgs &a, hipStream_t stream)
+{
+    const uint32_t grid = ((a.seg_grid + 7u) / 8u) * 8u;
+    if (grid == 0) return GSX_OK;
+    const size_t smem = kBatch * (sizeof(StagedRow) + sizeof(float4));
+    if (a.nch <= 1) hipLaunchKernelGGL((raster3d_fwd_kernel<1, true>), dim3(grid), dim3(256), smem, stream, a);
+    else if (a.nch <= 2) hipLaunchKernelGGL((raster3d_fwd_kernel<2, true>), dim3(grid), dim3(256), smem, stream, a);
+    else if (a.nch <= 3) hipLaunchKernelGGL((raster3d_fwd_kernel<3, true>), dim3(grid), dim3(256), smem, stream, a);
+    else hipLaunchKernelGGL((raster3d_fwd_kernel<4, true>), dim3(grid), dim3(256), smem, stream, a);
+    return check_launch("raster3d_bwd_prepass");
 }
 
 // one launch for the channel chunk described by a.ch_off / a.nch / a.first_chunk

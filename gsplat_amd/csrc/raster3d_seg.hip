@@ -26,7 +26,10 @@
 
 namespace gsx {
 
-int raster3d_fwd_launch_chunk(const Raster3DArgs &a, hipStream_t stream); // raster3d_fwd.hip
+int raster3d_fwd_launch_chunk(const Raster3DArgs &a, hipStream_t stream);   // raster3d_fwd.hip
+int raster3d_bwd_prepass_launch(const Raster3DArgs &a, hipStream_t stream); // raster3d_fwd.hip (forward kernel, PRE = true)
+int raster3d_bwd_t_launch_items(const Raster3DArgs &a, hipStream_t stream); // raster3d_bwd.hip
+bool raster3d_bwd_uses_variant_t();
 
 struct SegHeader { // device memory, zeroed before every use
     int32_t n_items, n_long, pad[2];
@@ -102,6 +105,34 @@ __global__ void __launch_bounds__(256) seg_prefix_kernel(SegPlan p)
         const float t = *slot;
         *slot         = P;
         P *= t;
+    }
+}
+
+// BACKWARD. The sequential backward walks a list back to front carrying, per pixel, the transmittance T (divided back Gaussian
+// by Gaussian) and B = sum over the Gaussians BEHIND of alpha_i T_i (c_i . v_colour). A slice can start on its own once it
+// knows both at its end: the pre-pass (forward kernel, PRE) gives every slice's own transmittance T_k and
+// S_k = sum_i alpha_i T_i^(from 1) (c_i . v_colour); with P_k = T_0 ... T_(k-1) the transmittance in front of slice k,
+//   T at the END of slice k = P_k T_k,      B at the end of slice k = sum_(j > k) P_j S_j.
+// One workgroup per long tile, thread = pixel: T[item] <- end transmittance, S[item] <- B at the end (both in place).
+__global__ void __launch_bounds__(256) seg_bwd_prefix_kernel(SegPlan p)
+{
+    const int32_t li = (int32_t)blockIdx.x;
+    if (li >= p.hdr->n_long) return;
+    const int32_t s0 = p.longs[3 * li + 1], n_seg = p.longs[3 * li + 2];
+    float P = 1.0f;
+    for (int32_t k = 0; k < n_seg; ++k) {
+        const size_t at = (size_t)(s0 + k) * 256 + threadIdx.x;
+        const float t   = p.T[at];
+        p.out[at]       = P * p.out[at]; // P_k S_k
+        P *= t;
+        p.T[at] = P;                     // transmittance at the end of slice k
+    }
+    float behind = 0.0f;
+    for (int32_t k = n_seg - 1; k >= 0; --k) {
+        const size_t at = (size_t)(s0 + k) * 256 + threadIdx.x;
+        const float ps  = p.out[at];
+        p.out[at]       = behind;
+        behind += ps;
     }
 }
 
@@ -223,4 +254,61 @@ extern "C" int gsx_raster3d_fwd_seg(
         first = false;
     } while (off < cdim);
     return check_launch("raster3d_fwd_seg");
+}
+
+// Backward with long tile lists cut into segments (see seg_bwd_prefix_kernel). Applies where the backward runs its variant T
+// (<= 4 channels, 16 x 16 tiles, no absgrad); anything else is the caller's to send to gsx_raster3d_bwd.
+extern "C" int gsx_raster3d_bwd_seg(
+    const float *means2d, const float *conics, const float *colors, const float *opacities, const float *backgrounds,
+    const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids, const float *render_alphas,
+    const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas, uint32_t n_images, uint32_t n_isects,
+    uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *v_rows,
+    uint32_t row_stride, uint32_t seg_len, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    GSX_REQUIRE(tile_size == 16 && cdim >= 1 && cdim <= 4,
+                "gsx_raster3d_bwd_seg: needs 16 x 16 tiles and <= 4 channels (got tile %u, %u channels): use gsx_raster3d_bwd",
+                tile_size, cdim);
+    if (!raster3d_bwd_uses_variant_t()) // GSX_RASTER3D_BWD=r (A/B switch): the reduction kernel has no segment support
+        return gsx_raster3d_bwd(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas,
+                                last_ids, v_render_colors, v_render_alphas, n_images, n_isects, cdim, width, height, tile_size,
+                                tile_w, tile_h, 0, v_rows, row_stride, stream);
+    GSX_REQUIRE(seg_len >= 256, "gsx_raster3d_bwd_seg: seg_len must be >= 256, got %u", seg_len);
+    if (n_isects == 0) return GSX_OK;
+    GSX_REQUIRE(v_rows && row_stride >= 6u + cdim, "gsx_raster3d_bwd_seg: gradient rows missing / too narrow");
+    GSX_REQUIRE(means2d && conics && colors && opacities && flatten_ids && render_alphas && last_ids && v_render_colors
+                && isect_offsets, "gsx_raster3d_bwd_seg: null input");
+    hipStream_t s = (hipStream_t)stream;
+    Raster3DArgs a{};
+    a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height;
+    a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h; a.cdim = cdim;
+    a.means2d = means2d; a.conics = conics; a.colors = colors; a.opacities = opacities;
+    a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = isect_offsets; a.flatten_ids = flatten_ids;
+    a.render_alphas = const_cast<float *>(render_alphas); a.last_ids = const_cast<int32_t *>(last_ids);
+    a.v_render_colors = v_render_colors; a.v_render_alphas = v_render_alphas;
+    a.v_rows = v_rows; a.row_stride = row_stride;
+    a.ch_off = 0; a.nch = cdim; a.first_chunk = 1;
+    const uint32_t n_blocks = n_images * tile_w * tile_h;
+    if (n_blocks == 0) return GSX_OK;
+    SegPlan p{};
+    unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    if (workspace == nullptr
+        || (base - reinterpret_cast<unsigned char *>(workspace)) + seg_layout(n_isects, n_blocks, cdim, seg_len, base, &p) > workspace_bytes) {
+        set_last_error("gsx_raster3d_bwd_seg: workspace too small");
+        return GSX_ERR_WORKSPACE;
+    }
+    if (hipMemsetAsync(p.hdr, 0, sizeof(SegHeader), s) != hipSuccess) return check_launch("raster3d_bwd_seg memset");
+    seg_plan_kernel<<<dim3((n_blocks + 255) / 256), dim3(256), 0, s>>>(isect_offsets, n_blocks, n_isects, seg_len, p);
+    a.seg_len = seg_len; a.seg_items = p.items; a.seg_count = &p.hdr->n_items;
+    a.seg_T = p.T; a.seg_out = p.out; a.seg_last = p.last;
+    int rc;
+    if (p.max_items > 0) {
+        a.seg_mode = 1; a.seg_grid = p.max_items;
+        rc = raster3d_bwd_prepass_launch(a, s);
+        if (rc != GSX_OK) return rc;
+        seg_bwd_prefix_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(p);
+    }
+    a.seg_mode = 2; a.seg_grid = p.max_items + n_blocks; // the slices first, the short tiles behind them
+    rc = raster3d_bwd_t_launch_items(a, s);
+    if (rc != GSX_OK) return rc;
+    return check_launch("raster3d_bwd_seg");
 }

@@ -11,6 +11,7 @@
 // gsplat_amd/rendering.py; _ops.py skips registering its own body for an op listed by gsx_torch_compiled_ops().
 // Schemas are defined by _ops.py (verbatim from ext.cpp); an IMPL block may be loaded before or after the definitions.
 #include <chrono>
+#include <cstdlib>
 #include <thread>
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
@@ -612,7 +613,17 @@ RasterDims raster_dims(const Tensor &isect_offsets, const Tensor &colors)
 // from the intersection's host word; the reference's op schema has no room for it). Above kSegMinLongest the forward cuts
 // long lists into segments (csrc/raster3d_seg.hip). 0 = unknown: one workgroup per tile. Consumed (reset) by the call.
 thread_local int64_t g_long_tile_hint = 0;
-constexpr int64_t kSegLen = 1024, kSegMinLongest = 2048;
+// segment length / the longest list from which segmenting starts; GSPLAT_AMD_SEG_LEN overrides (A/B), 0 switches it off
+static int64_t seg_len_env()
+{
+    static const int64_t v = [] {
+        const char *e = std::getenv("GSPLAT_AMD_SEG_LEN");
+        return e ? (int64_t)std::atoll(e) : (int64_t)1024;
+    }();
+    return v;
+}
+#define kSegLen (seg_len_env())
+#define kSegMinLongest (seg_len_env() > 0 ? 2 * seg_len_env() : (int64_t)1 << 62)
 
 std::tuple<Tensor, Tensor, Tensor, Tensor>
 rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Tensor &colors_, const Tensor &opacities_,
@@ -678,6 +689,19 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
     // ONE zero-filled array-of-structures buffer [R][6 (+2) + D]; the gradients are COLUMN VIEWS of it (gsplat_amd.h)
     const int64_t R = opac.numel(), geo = absgrad ? 8 : 6;
     Tensor rows = at::zeros({R, geo + r.D}, means2d.options());
+    const int64_t longest = g_long_tile_hint; // set by the autograd formula around this call (gsplat_amd/_autograd.py)
+    g_long_tile_hint = 0;
+    if (longest > kSegMinLongest && !absgrad && r.D <= 4 && tile_size == 16) {
+        Tensor ws = at::empty({gsx_raster3d_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
+                                                              (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
+        Timed timed_("gsx_raster3d_bwd", L.stream);
+        check(gsx_raster3d_bwd_seg(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
+                                   masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
+                                   cp<int32_t>(flat), fp(ra), cp<int32_t>(li), fp(v_rc), fp(v_ra), (uint32_t)r.I, (uint32_t)flat.numel(),
+                                   (uint32_t)r.D, (uint32_t)width, (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th,
+                                   mp<float>(rows), (uint32_t)(geo + r.D), (uint32_t)kSegLen, ws.mutable_data_ptr(), ws.numel(), L.stream),
+              "gsx_raster3d_bwd_seg");
+    } else
     { Timed timed_("gsx_raster3d_bwd", L.stream); check(gsx_raster3d_bwd(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
                            masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
                            cp<int32_t>(flat), fp(ra), cp<int32_t>(li), fp(v_rc), fp(v_ra), (uint32_t)r.I, (uint32_t)flat.numel(),

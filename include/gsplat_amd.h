@@ -392,6 +392,17 @@ int gsx_raster3d_fwd_seg(const float *means2d, const float *conics, const float 
                          uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                          float *render_colors, float *render_alphas, int32_t *last_ids, uint32_t seg_len, void *workspace,
                          int64_t workspace_bytes, void *stream);
+/* Backward counterpart of gsx_raster3d_fwd_seg (<= 4 channels, 16 x 16 tiles, no absgrad - where the backward runs its
+ * variant T): a pre-pass gives every slice its own transmittance and colour-cotangent sum, a per-pixel prefix turns them
+ * into the transmittance and the "behind" sum at the END of every slice, and the slices are then walked back to front
+ * independently, together with the short tiles. Same workspace size function as the forward. */
+int gsx_raster3d_bwd_seg(const float *means2d, const float *conics, const float *colors, const float *opacities,
+                         const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                         const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,
+                         const float *v_render_colors, const float *v_render_alphas, uint32_t n_images, uint32_t n_isects,
+                         uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w,
+                         uint32_t tile_h, float *v_rows, uint32_t row_stride, uint32_t seg_len, void *workspace,
+                         int64_t workspace_bytes, void *stream);
 int gsx_raster3d_bwd(const float *means2d, const float *conics, const float *colors, const float *opacities,
                      const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
                      const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,

@@ -1,7 +1,8 @@
 """GPU: long tile lists composited in SEGMENTS (csrc/raster3d_seg.hip) against the one-workgroup-per-tile walk of the same
 lists, which the other suites pin to the oracle - and against the oracle directly on a small scene. Scenes: faint Gaussians
-(no pixel saturates: every long tile takes the segment path), opaque ones (early termination fires: the tiles are handed back
-to the ordinary walk), a mix, backgrounds, tile masks, more than 32 channels (two channel chunks), several images."""
+(no pixel saturates: every slice contributes), opaque ones (early termination fires inside the first slices: the later ones
+carry transmittance 0 and stop at once), a mix, backgrounds, tile masks, more than 32 channels (two channel chunks),
+several images. The backward (pre-pass + per-pixel prefix + slices walked back to front) against the per-tile backward."""
 import math
 
 import pytest
@@ -77,3 +78,61 @@ def test_segmented_forward_last_ids_and_oracle(G):
     rc_o, ra_o = O.rasterize_to_pixels(cpu(m2), cpu(con), cpu(colors), cpu(op), W, H, 16, cpu(off), cpu(fl))[:2]
     assert_close_ratio(cpu(outs["seg"][0]), rc_o, 1e-3, 1e-4, max_bad_ratio=1e-3, name="segmented colours vs oracle")
     assert_close_ratio(cpu(outs["seg"][1]), ra_o, 1e-3, 1e-4, max_bad_ratio=1e-3, name="segmented alphas vs oracle")
+
+
+@pytest.mark.parametrize("kind", ["faint", "opaque", "mixed"])
+@pytest.mark.parametrize("D", [1, 3, 4])
+def test_segmented_backward_matches_per_tile_walk(G, kind, D):
+    opacity = {"faint": 0.008, "opaque": 0.9, "mixed": (lambda o: torch.where(torch.rand_like(o) < 0.5, o * 0.02 + 0.004, o))}[kind]
+    m2, con, op, off, fl, longest, W, H, tw, th = _lists(G, 40000, 2, 320, 192, opacity, seed=22)
+    assert longest > 3000, longest
+    g = torch.Generator().manual_seed(10 + D)
+    colors = torch.rand(m2.shape[:-1] + (D,), generator=g).to(DEV)
+    bg = torch.rand(2, D, generator=g).to(DEV)
+    masks = torch.ones(2, th, tw, dtype=torch.bool, device=DEV)
+    masks[1, th // 2, tw // 2] = False
+    w_c = torch.randn(2, H, W, D, generator=g).to(DEV)
+    w_a = torch.randn(2, H, W, 1, generator=g).to(DEV)
+    for kw in (dict(), dict(backgrounds=bg, masks=masks)):
+        grads = {}
+        for name, hint in (("tile", 0), ("seg", longest)):
+            leaves = [t.detach().clone().requires_grad_(True) for t in (m2, con, colors, op)]
+            extra = dict(kw)
+            if "backgrounds" in extra:
+                extra["backgrounds"] = bg.detach().clone().requires_grad_(True)
+                leaves.append(extra["backgrounds"])
+            rc, ra = G.rasterize_to_pixels(*leaves[:4], W, H, 16, off, fl, _longest_tile_list=hint, **extra)
+            ((rc * w_c).sum() + (ra * w_a).sum()).backward()
+            grads[name] = [t.grad.cpu() for t in leaves]
+        for nm, a, b in zip(("means2d", "conics", "colors", "opacities", "backgrounds"), grads["seg"], grads["tile"]):
+            # same sums in another association order (float atomics make either side run-to-run noisy at this level too)
+            assert_grad_close(a, b, name=f"{kind} D={D} {sorted(kw)} v_{nm}")
+
+
+def test_segmented_backward_through_rasterization(G):
+    """rendering.py hands the intersection's longest list to forward AND backward; the per-tile side of the comparison
+    is the same call with that report suppressed."""
+    from gsplat_amd import rendering
+
+    sc, W, H = make_scene(N=30000, C=1, width=256, height=160, seed=9)
+    a = {k: v.to(DEV) for k, v in sc.items()}
+    a["means"][:, :2] *= 0.25
+    a["opacities"] = a["opacities"] * 0.05 + 0.004
+    names = ("means", "quats", "scales", "opacities", "colors")
+    out = {}
+    seen = []
+    saved = rendering._isect_max_tile_len
+    for mode in ("seg", "tile"):
+        rendering._isect_max_tile_len = (lambda st: seen.append(saved(st)) or seen[-1]) if mode == "seg" else (lambda st: 0)
+        try:
+            leaves = {k: a[k].detach().clone().requires_grad_(True) for k in names}
+            rc, ra, info = G.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
+                                           a["viewmats"], a["Ks"], W, H)
+            (rc.square().sum() + ra.sum()).backward()
+            out[mode] = (rc.detach().cpu(), [leaves[k].grad.cpu() for k in names])
+        finally:
+            rendering._isect_max_tile_len = saved
+    assert seen and seen[0] > 2500, seen  # the segment path really ran
+    assert_close_ratio(out["seg"][0], out["tile"][0], 2e-5, 2e-6, max_bad_ratio=1e-5, name="render")
+    for nm, x, y in zip(names, out["seg"][1], out["tile"][1]):
+        assert_grad_close(x, y, name=f"v_{nm}")
