@@ -502,7 +502,7 @@ def main():
                 "value": g2["mpix_s_fwd_bwd"], "unit": "Mpixels/s", "ms_fwd_plus_bwd": round(t2 * 1e3, 4),
                 "fps_fwd": g2["fps_fwd"], "fps_bwd": g2["fps_bwd"], "n_isects": g2["n_isects"],
                 "raster_launch_ms": {"raster3d_fwd": g2["stages"]["fwd_ms"].get("raster3d_fwd"),
-                                     "raster3d_bwd": g2["stages"]["bwd_ms"].get("raster3d_bwd")},
+                                     "raster3d_bwd": g2["stages"]["bwd_ms"].get("raster3d_bwd_seg", g2["stages"]["bwd_ms"].get("raster3d_bwd"))},
                 "stages_ms": g2["stages"],
                 "published_titan_rtx_fps_fwd_bwd": g2["published_titan_rtx_fps_fwd_bwd"],
             }

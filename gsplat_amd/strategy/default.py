@@ -53,6 +53,11 @@ class DefaultStrategy(Strategy):
     revised_opacity: bool = False
     verbose: bool = False
     key_for_gradient: str = "means2d"  # "gradient_2dgs" for rasterization_2dgs
+    # The reference returns the allocator's cached blocks to the driver after every refinement (torch.cuda.empty_cache(),
+    # sized for 24 GB cards). That is a hipFree / hipMalloc round trip for the working set in the steps that follow (measured
+    # on the 1 M-Gaussian training step: 7.3 instead of 5.4 ms for the refinement step), and 288 GB of HBM has no use for it:
+    # opt-in here.
+    release_cached_memory: bool = False
 
     # ---- interface -----------------------------------------------------------------------------------------------------
     def initialize_state(self, scene_scale: float = 1.0) -> Dict[str, Any]:
@@ -81,7 +86,8 @@ class DefaultStrategy(Strategy):
             if self.verbose:
                 print("step {}: +{} duplicated, +{} split, -{} pruned -> {} Gaussians".format(step, *counts,
                                                                                               len(params["means"])))
-            torch.cuda.empty_cache()
+            if self.release_cached_memory:
+                torch.cuda.empty_cache()
         if step > 0 and step % self.reset_every == 0:
             reset_opa(params=params, optimizers=optimizers, state=state, value=self.prune_opa * 2.0)
 

@@ -36,6 +36,11 @@ class MCMCStrategy(Strategy):
     verbose: bool = False
     noise_opacity_t: float = 0.005
     noise_opacity_k: float = 100.0
+    # The reference returns the allocator's cached blocks to the driver after every refinement (torch.cuda.empty_cache(),
+    # sized for 24 GB cards). That is a hipFree / hipMalloc round trip for the working set in the steps that follow (measured
+    # on the 1 M-Gaussian training step: 7.3 instead of 5.4 ms for the refinement step), and 288 GB of HBM has no use for it:
+    # opt-in here.
+    release_cached_memory: bool = False
 
     def initialize_state(self) -> Dict[str, Any]:
         top = 51  # binomial coefficients C(n, k) for n < 51 (Eq. 9 of the paper sums over the copies of a Gaussian)
@@ -54,7 +59,8 @@ class MCMCStrategy(Strategy):
             n_moved, n_new = self._refine(params, optimizers, state["binoms"])
             if self.verbose:
                 print(f"step {step}: {n_moved} relocated, {n_new} added -> {len(params['means'])} Gaussians")
-            torch.cuda.empty_cache()
+            if self.release_cached_memory:
+                torch.cuda.empty_cache()
         if self.noise_injection_stop_iter < 0 or step < self.noise_injection_stop_iter:
             inject_noise_to_position(params=params, optimizers=optimizers, state={}, scaler=lr * self.noise_lr,
                                      t=self.noise_opacity_t, k=self.noise_opacity_k)

@@ -131,7 +131,9 @@ def _raster2d_case(G, O, N, C, W, H, tile_size, D, seed, bg=False, masks=False, 
     for nm, a, b in zip(names, outs, ref[:5]):
         # median depth flips between neighbouring surfels when T crosses 0.5 within rounding: allow a few more
         ratio = 2e-3 if nm in ("render_median", "render_distort") else 2e-4
-        assert_close_ratio(cpu(a), b, 2e-4, 5e-5, max_bad_ratio=ratio, name=nm)
+        # ... and no cap on HOW far such a flipped pixel is off: it carries another surfel's depth (a step, not an error)
+        assert_close_ratio(cpu(a), b, 2e-4, 5e-5, max_bad_ratio=ratio, name=nm,
+                           **({"outlier_cap": None} if nm == "render_median" else {}))
     v = [torch.randn(b.shape, generator=g) for b in ref[:5]]
     if not distloss:
         v[3].zero_()

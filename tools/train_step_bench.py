@@ -20,7 +20,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_at=None, grow_grad2d=2e-7):
+def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_every=None, grow_grad2d=2e-7,
+        release_cached_memory=False):
     import bench
     import gsplat_amd
 
@@ -43,11 +44,15 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_at=N
     lrs = dict(means=1.6e-4, quats=1e-3, scales=5e-3, opacities=5e-2, sh0=2.5e-3, shN=2.5e-3 / 20)  # simple_trainer.py:232-241
     opts = {k: gsplat_amd.SelectiveAdam([{"params": params[k], "lr": lrs[k], "name": k}], eps=1e-15, betas=(0.9, 0.999))
             for k in params.keys()}
-    refine_at = steps // 2 if refine_at is None else refine_at
-    # thresholds low enough that the one refinement really edits the model (the fit starts next to its optimum, so the
-    # screen-space gradients are far below the trainer's default 2e-4)
-    strategy = gsplat_amd.DefaultStrategy(refine_start_iter=refine_at - 1, refine_every=max(refine_at, 1), reset_every=10**9,
-                                          refine_stop_iter=refine_at + 1, grow_grad2d=grow_grad2d, verbose=False)
+    # Refinements at steps R, 2 R, ...: the first one falls into the warm-up (first-use costs of the refinement's own
+    # kernels and allocations), the second one into the timed window - steps R + 1 .. R + steps, R = steps / 2.
+    # Thresholds low enough that a refinement really edits the model (the fit starts next to its optimum, so the
+    # screen-space gradients are far below the trainer's default 2e-4).
+    R = max(steps // 2 if refine_every is None else refine_every, 1)
+    refine_at = 2 * R
+    strategy = gsplat_amd.DefaultStrategy(refine_start_iter=R - 1, refine_every=R, reset_every=10**9,
+                                          refine_stop_iter=refine_at + 1, grow_grad2d=grow_grad2d, verbose=False,
+                                          release_cached_memory=release_cached_memory)
     strategy.check_sanity(params, opts)
     state = strategy.initialize_state(scene_scale=1.0)
 
@@ -69,13 +74,14 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_at=N
         strategy.step_post_backward(params, opts, state, i, info, packed=packed)
         return loss
 
-    n0 = len(params["means"])
-    for i in range(3):  # warm-up outside the window (allocator, lazy optimizer state)
-        step(-10 + i)
+    n_start = len(params["means"])
+    for i in range(R + 1):  # warm-up outside the window: allocator, lazy optimizer state, and the FIRST refinement (step R)
+        step(i)
     torch.cuda.synchronize()
+    n0 = len(params["means"])
     per_step = []
     t0 = time.perf_counter()
-    for i in range(steps):
+    for i in range(R + 1, R + 1 + steps):
         ts = time.perf_counter()
         loss = step(i)
         if i == refine_at or i == refine_at - 1:
@@ -91,7 +97,8 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_at=N
         "steps": steps, "ms_per_step": round(wall / steps * 1e3, 4), "steps_per_s": round(steps / wall, 2),
         "mpixels_per_s": round(W * H * steps / wall / 1e6, 2),
         "refinement_at_step": refine_at, "refinement_step_ms": refine_ms[0] if refine_ms else None,
-        "gaussians_before": n0, "gaussians_after": n1, "final_loss": round(float(loss.detach()), 6),
+        "gaussians_at_start": n_start, "gaussians_before": n0, "gaussians_after": n1,
+        "release_cached_memory": release_cached_memory, "final_loss": round(float(loss.detach()), 6),
         "reference": "examples/simple_trainer.py:795-1170 (rasterization :722, optimizer + strategy steps :1137-1166)",
     }
 
@@ -101,5 +108,6 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--packed", action="store_true")
+    ap.add_argument("--release-cached-memory", action="store_true", help="torch.cuda.empty_cache() after a refinement, as the reference does")
     a = ap.parse_args()
-    print(json.dumps(run(a.steps, a.gaussians, a.packed)))
+    print(json.dumps(run(a.steps, a.gaussians, a.packed, release_cached_memory=a.release_cached_memory)))
