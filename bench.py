@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 WIDTH, HEIGHT, TILE = 1920, 1080, 16
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 FP32_PEAK_TFLOPS = 157.3
+N_SIMDS = 256 * 4  # 256 CUs x 4 SIMDs
 NAMES = ("means", "quats", "scales", "opacities", "colors")
 
 
@@ -339,6 +340,24 @@ def main():
                 traffic = None
         except Exception:
             traffic = None
+    # Instruction-issue view of the dominant kernel: its VALU wave-instructions per launch (SQ_INSTS_VALU of the same PMC
+    # passes) over launch time and the chip's 1024 SIMDs, against the best VALU issue rate tools/issue_rate.hip measured on
+    # this GPU (profiles/issue_rate.json: v_add_f32, 8 waves per SIMD) - the roof the compositing kernels are priced by.
+    valu_issue = None
+    try:
+        rate = json.load(open(os.path.join(ROOT, "profiles", "issue_rate.json")))["summary"]
+        sq = (pmc.get(dom + "_t") or pmc.get(dom) or {}).get("sq") if traffic is not None else None
+        if sq and sq.get("SQ_INSTS_VALU") and dom_ms == dom_ms:
+            per_simd_ns = sq["SQ_INSTS_VALU"] / N_SIMDS / (dom_ms * 1e6)
+            valu_issue = {"valu_instructions_per_launch": int(sq["SQ_INSTS_VALU"]),
+                          "salu_instructions_per_launch": int(sq.get("SQ_INSTS_SALU", 0)) or None,
+                          "lds_instructions_per_launch": int(sq.get("SQ_INSTS_LDS", 0)) or None,
+                          "achieved_instr_per_ns_per_simd": round(per_simd_ns, 4),
+                          "peak_instr_per_ns_per_simd": rate["valu_peak_instr_per_ns_per_simd"],
+                          "peak_source": "profiles/issue_rate.json (tools/issue_rate.hip on MI355X)",
+                          "frac": round(per_simd_ns / rate["valu_peak_instr_per_ns_per_simd"], 4)}
+    except Exception:
+        valu_issue = None
     # vector-ALU view of the same two kernels: counted (pixel, Gaussian) pairs x (14 + 2 D) flop / time
     valu = None
     if not distributed:
@@ -360,6 +379,7 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": int(dom_bytes), "launch_ms": round(dom_ms, 4),
         "n_isects": M, "rows": V, "pixels_per_launch": P_local, "valu": valu,
+        "valu_issue_frac": valu_issue["frac"] if valu_issue else None, "valu_issue": valu_issue,
         "note": "compositing is bound by instruction issue (scalar + vector) and LDS, not by HBM (SURVEY.md 8(d)); see DESIGN.md",
     }
 

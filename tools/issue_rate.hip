@@ -167,8 +167,15 @@ static void run_op(std::string &out, bool &first)
             auto k = dep ? rate_kernel<OP, true> : rate_kernel<OP, false>;
             hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             hipLaunchKernelGGL(k, dim3(n_cu * blocks_per_cu), dim3(threads), lds, 0, 50, cyc, real, sink, gbuf); // warm-up
+            hipEvent_t e0, e1; // wall clock of the whole launch: an independent check of the in-kernel counters
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, 0);
             hipLaunchKernelGGL(k, dim3(n_cu * blocks_per_cu), dim3(threads), lds, 0, iters, cyc, real, sink, gbuf);
+            hipEventRecord(e1, 0);
             hipDeviceSynchronize();
+            float wall_ms = 0.0f;
+            hipEventElapsedTime(&wall_ms, e0, e1);
+            hipEventDestroy(e0); hipEventDestroy(e1);
             const int n_waves = n_cu * 4 * w;
             std::vector<uint64_t> hc(n_waves), hr(n_waves);
             hipMemcpy(hc.data(), cyc, n_waves * 8, hipMemcpyDeviceToHost);
@@ -181,8 +188,9 @@ static void run_op(std::string &out, bool &first)
             char buf[512];
             snprintf(buf, sizeof buf,
                      "%s\n  {\"op\": \"%s\", \"chain\": \"%s\", \"waves_per_simd\": %d, \"counter_ticks_per_instr\": %.3f, \"ns_per_instr_per_wave\": %.4f, "
-                     "\"instr_per_ns_per_simd\": %.4f}",
-                     first ? "" : ",", kNames[OP], dep ? "dependent" : "independent x8", w, mc / instr, ns / instr, w * instr / ns);
+                     "\"instr_per_ns_per_simd\": %.4f, \"launch_wall_us\": %.1f, \"instr_per_ns_per_simd_by_wall_clock\": %.4f}",
+                     first ? "" : ",", kNames[OP], dep ? "dependent" : "independent x8", w, mc / instr, ns / instr, w * instr / ns,
+                     wall_ms * 1e3, (double)n_waves * instr / (wall_ms * 1e6) / (n_cu * 4));
             first = false;
             out += buf;
         }

@@ -60,6 +60,11 @@ def main():
                 hbm[name] = {"bytes": int((cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
                              "fetch_bytes": int(cs["FETCH_SIZE"] * 1024), "write_bytes": int(cs["WRITE_SIZE"] * 1024),
                              "bytes_if_fetch_x2": int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)}
+                # instruction counters of the same launches (bench.py: roofline.valu_issue_frac)
+                sq = {c: cs[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES",
+                                         "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_LDS_BANK_CONFLICT") if c in cs}
+                if sq:
+                    hbm[name]["sq"] = sq
         import subprocess
 
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
