@@ -738,7 +738,7 @@ extern "C" int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint3
     BinGeom g;
     if (!bin_geometry(g, rows > 0 ? rows : 1, n_images, 16, tile_w, tile_h, 1)) return 0;
     if (force && force[0] == 'b') return 1;
-    // measured (MI355X, profiles/r07_isect_ab.md): 1 M rows x 8160 tiles (c3) 0.214 vs 0.249 ms; 4 M rows per image (c4:
+    // measured (MI355X, profiles/r07_ab.md): 1 M rows x 8160 tiles (c3) 0.214 vs 0.249 ms; 4 M rows per image (c4:
     // ~1800 entries per tile, one wave sorting 2048 words) 4.3 vs 2.5 ms -> dense images and small calls stay Gaussian-major
     return rows >= 65536 && g.rows_per_image <= 256ll * (int64_t)g.n_tiles;
 }

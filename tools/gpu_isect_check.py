@@ -136,9 +136,32 @@ def bench_all(c4):
         os.environ.pop(k, None)
 
 
+def bench_one(c4):
+    """The auto path only (for rocprofv3 per-kernel traces and the GSX_ISECT_DBG ablations) + the list-length distribution."""
+    sc, W, H = bench.make_workload(4_000_000 if c4 else 1_000_000, dev, n_cameras=4 if c4 else 1)
+    rad, m2, d, con, op = project(sc, W, H)
+    C = sc["viewmats"].shape[0]
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    rec = timed(m2, rad, d, con, op, C, tw, th)
+    tpg, ids, fl = isect_tiles_finish(isect_tiles_begin(m2, rad, d, 16, tw, th, n_images=C, conics=con, opacities=op))
+    off = gsplat_amd.isect_offset_encode(ids, C, tw, th).flatten()
+    n = torch.diff(torch.cat([off, torch.tensor([fl.numel()], device=dev, dtype=off.dtype)])).float()
+    q = lambda t, p: int(torch.quantile(t, p).item())  # noqa: E731
+    rec["tile_list"] = {"mean": round(float(n.mean()), 1), "p50": q(n, 0.5), "p90": q(n, 0.9), "p99": q(n, 0.99), "max": int(n.max())}
+    bins = n.view(C, th, tw)[:, : th // 2 * 2, : tw // 4 * 4].reshape(C, th // 2, 2, tw // 4, 4).sum((2, 4)).flatten()
+    rec["bin_4x2"] = {"mean": round(float(bins.mean()), 1), "p50": q(bins, 0.5), "p90": q(bins, 0.9), "p99": q(bins, 0.99), "max": int(bins.max())}
+    t = tpg.flatten()[tpg.flatten() > 0].float()
+    rec["tiles_per_row"] = {"mean": round(float(t.mean()), 2), "p50": q(t, 0.5), "p90": q(t, 0.9), "p99": q(t, 0.99), "max": int(t.max()),
+                            "rows": int(t.numel())}
+    print(json.dumps({"scene": "c4" if c4 else "c3", "dbg": os.environ.get("GSX_ISECT_DBG", "0"), **rec}), flush=True)
+
+
 if __name__ == "__main__":
     args = sys.argv[1:] or ["check", "bench"]
     rc = 0
+    if "benchone" in args:
+        bench_one("c4" in args)
+        sys.exit(0)
     if "check" in args:
         rc = 0 if check() else 1
     if "bench" in args:

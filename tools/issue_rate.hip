@@ -15,14 +15,15 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum Op { FMA, PK_FMA, MUL, ADD, CNDMASK, EXP, RCP, MAD_U32_U24, ADD_U32, LSHL_ADD, CMP_BALLOT, DS_ADD_F32, DS_ADD_F32_SAME, DS_READ_B64, DS_READ_B128, DS_WRITE_B64, S_ADD, S_AND_B64, MIX_V_S, DPP_ADD, READLANE, CNDMASK_SGPR, CMP_E64, CMP_CNDMASK, DS_ADD_U32, DS_ADD_RTN_U32, DS_BPERMUTE, PERMLANE32_SWAP, GLOBAL_ATOMIC_ADD, SALU_VCC_CND, SALU_SGPR_CND, VCMP_SGPR_CND, VCMP_SXOR_CND, N_OPS };
+enum Op { FMA, PK_FMA, MUL, ADD, CNDMASK, EXP, RCP, MAD_U32_U24, ADD_U32, LSHL_ADD, CMP_BALLOT, DS_ADD_F32, DS_ADD_F32_SAME, DS_READ_B64, DS_READ_B128, DS_WRITE_B64, S_ADD, S_AND_B64, MIX_V_S, DPP_ADD, READLANE, CNDMASK_SGPR, CMP_E64, CMP_CNDMASK, DS_ADD_U32, DS_ADD_RTN_U32, DS_BPERMUTE, PERMLANE32_SWAP, GLOBAL_ATOMIC_ADD, SALU_VCC_CND, SALU_SGPR_CND, VCMP_SGPR_CND, VCMP_SXOR_CND, V_MOV, V_MIN, V_AND, V_CMP_E32, CND_VALU_VCC, V_MAC, N_OPS };
 static const char *kNames[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_add_f32", "v_cndmask_b32", "v_exp_f32", "v_rcp_f32",
                                     "v_mad_u32_u24", "v_add_u32", "v_lshl_add_u32", "v_cmp+s_and(ballot)", "ds_add_f32(distinct)",
                                     "ds_add_f32(same addr)", "ds_read_b64", "ds_read_b128", "ds_write_b64", "s_add_u32", "s_and_b64",
                                     "v_fma_f32+s_add_u32", "v_add_f32_dpp", "v_readlane_b32", "v_cndmask_b32_e64(sgpr pair)", "v_cmp_lt_f32_e64->sgpr",
                                     "v_cmp(vcc)+v_cndmask(vcc)", "ds_add_u32(distinct)", "ds_add_rtn_u32(distinct)", "ds_bpermute_b32", "v_permlane32_swap_b32",
                                     "global_atomic_add_u32(no return, distinct dwords)", "s_and_b64(vcc)+v_cndmask(vcc)", "s_and_b64(sgpr)+v_cndmask_e64(sgpr)",
-                                    "v_cmp_e64(sgpr)+v_cndmask_e64(sgpr)", "v_cmp_e64(sgpr)+s_xor_b64+v_cndmask_e64(sgpr)"};
+                                    "v_cmp_e64(sgpr)+v_cndmask_e64(sgpr)", "v_cmp_e64(sgpr)+s_xor_b64+v_cndmask_e64(sgpr)",
+                                    "v_mov_b32", "v_min_f32", "v_and_b32", "v_cmp_lt_f32_e32(vcc)", "v_cndmask_b32(vcc written by one v_cmp)", "v_fmac_f32_e32"};
 
 // One asm statement holds the whole 64-instruction block: the compiler cannot see into it, so it neither reorders it nor
 // pads it with s_nop (it does pad BETWEEN separate asm statements, which would be measured as issue slots).
@@ -72,6 +73,12 @@ static const char *kNames[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v
 #define I_SSGPR(r) "s_and_b64 %10, %10, exec\n v_cndmask_b32_e64 %" #r ", %" #r ", %8, %10\n"
 #define I_VSGPR(r) "v_cmp_lt_f32_e64 %10, %" #r ", %8\n v_cndmask_b32_e64 %" #r ", %" #r ", %9, %10\n"
 #define I_VXOR(r) "v_cmp_lt_f32_e64 %10, %" #r ", %8\n s_xor_b64 %10, %10, exec\n v_cndmask_b32_e64 %" #r ", %" #r ", %9, %10\n"
+
+#define I_MOV(r) "v_mov_b32 %" #r ", %8\n"
+#define I_MIN(r) "v_min_f32 %" #r ", %" #r ", %8\n"
+#define I_AND(r) "v_and_b32 %" #r ", %" #r ", %8\n"
+#define I_CMP32(r) "v_cmp_lt_f32 vcc, %" #r ", %8\n"
+#define I_MAC(r) "v_fmac_f32 %" #r ", %8, %9\n"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -131,6 +138,15 @@ __global__ void __launch_bounds__(1024) rate_kernel(int iters, uint64_t *cycles,
         if (OP == SALU_SGPR_CND) { if (DEP) asm volatile(DEP64(I_SSGPR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : "scc"); else asm volatile(IND64(I_SSGPR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : "scc"); }
         if (OP == VCMP_SGPR_CND) { if (DEP) asm volatile(DEP64(I_VSGPR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : ); else asm volatile(IND64(I_VSGPR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : ); }
         if (OP == VCMP_SXOR_CND) { if (DEP) asm volatile(DEP64(I_VXOR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : "scc"); else asm volatile(IND64(I_VXOR) : VREGS, "+v"(a), "+v"(b), "+s"(sm) : : "scc"); }
+        if (OP == V_MOV) BLOCK(I_MOV, VREGS, "v"(a), "v"(b));
+        if (OP == V_MIN) BLOCK(I_MIN, VREGS, "v"(a), "v"(b));
+        if (OP == V_AND) BLOCK(I_AND, UREGS, "v"(c));
+        if (OP == V_CMP_E32) { if (DEP) asm volatile(DEP64(I_CMP32) : VREGS, "+v"(a), "+v"(b) : : "vcc"); else asm volatile(IND64(I_CMP32) : VREGS, "+v"(a), "+v"(b) : : "vcc"); }
+        if (OP == CND_VALU_VCC) {
+            if (it == 0) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n" : : "v"(a), "v"(x[0]) : "vcc");
+            BLOCK(I_CND, VREGS, "v"(a), "v"(b));
+        }
+        if (OP == V_MAC) BLOCK(I_MAC, VREGS, "v"(a), "v"(b));
         if (OP == GLOBAL_ATOMIC_ADD) asm volatile(DEP64(I_GATOM) "s_waitcnt vmcnt(0)\n" : UREGS, "+v"(a), "+v"(c), "+v"(gaddr) : : "memory");
     }
     const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
