@@ -62,7 +62,13 @@ _COMPILED_ISECT = False  # torch.ops.gsplat_amd.isect_fused_{begin,finish} avail
 # room for it, so it travels as a per-thread hint around the op call: above SEG_MIN_LONGEST the forward / backward cut long
 # lists into segments that separate workgroups composite (csrc/raster3d_seg.hip). No hint (0) = one workgroup per tile.
 SEG_LEN = int(os.environ.get("GSPLAT_AMD_SEG_LEN", "1024"))  # 0 switches segmenting off (A/B)
-SEG_MIN_LONGEST = 2 * SEG_LEN if SEG_LEN > 0 else 1 << 62
+SEG_MIN_LONGEST = 2 * SEG_LEN if SEG_LEN > 0 else 1 << 62  # lower bound of the cut (csrc/raster3d_seg.hip: seg_cut_for)
+
+
+def _seg_cut(n_isects: int, n_images: int, tw: int, th: int) -> int:
+    """Lists longer than this are cut into slices: max(2 slices, 3 x the mean list) - segments are for outliers."""
+    return _cabi._lib.gsx_raster3d_seg_cut(int(n_isects), int(n_images), int(tw), int(th), SEG_LEN) if SEG_LEN > 0 else 1 << 62
+
 _hint = __import__("threading").local()
 _set_hint_compiled = None  # gsx_torch_set_long_tile_hint of libgsplat_amd_torch.so (the compiled op bodies read it)
 
@@ -801,7 +807,7 @@ def rasterize_to_pixels_3dgs(means2d, conics, colors, opacities, backgrounds, ma
     last_ids = torch.empty(image_dims + (image_height, image_width), device=dev, dtype=torch.int32)
     longest = long_tile_hint()
     set_long_tile_hint(0)  # consumed
-    if longest > SEG_MIN_LONGEST:
+    if longest > SEG_MIN_LONGEST and longest > _seg_cut(flatten_ids.numel(), I, tw, th):
         ws = torch.empty(_cabi._lib.gsx_raster3d_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN), device=dev,
                          dtype=torch.uint8)
         call("gsx_raster3d_fwd_seg", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
@@ -832,7 +838,8 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     rows = torch.zeros((R, geo + D), device=means2d.device, dtype=means2d.dtype)
     longest = long_tile_hint()  # set by the autograd formula around this call
     set_long_tile_hint(0)
-    if longest > SEG_MIN_LONGEST and not absgrad and D <= 4 and tile_size == 16:
+    if (longest > SEG_MIN_LONGEST and not absgrad and D <= 4 and tile_size == 16
+            and longest > _seg_cut(flatten_ids.numel(), I, tw, th)):
         ws = torch.empty(_cabi._lib.gsx_raster3d_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN),
                          device=means2d.device, dtype=torch.uint8)
         call("gsx_raster3d_bwd_seg", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),

@@ -68,6 +68,7 @@ struct Raster3DArgs {
     //               transmittance pass - the product of (1 - alpha) over the slice, from 1 (0 = the pixel stops inside)
     //   seg_mode 2  same items: compositing pass, every pixel starts at the transmittance in front of its segment
     uint32_t seg_mode, seg_len, seg_grid;
+    uint32_t seg_cut; // lists LONGER than this are cut into slices of seg_len (raster3d_seg.hip: seg_cut_for)
     const int32_t *seg_items; // [n][2]
     const int32_t *seg_count; // number of items, on the device
     float *seg_T;             // [item][256]  mode 1 out: transmittance of the slice; then (prefix kernel) in front of it: mode 2 in
@@ -125,7 +126,7 @@ __device__ __forceinline__ bool tile_context_seg(const Raster3DArgs &a, uint32_t
     item = 0;
     if (a.seg_mode == 0u) {
         if (!tile_context(a, block, t)) return false;
-        return !(a.seg_len && !a.sp_active_tiles && (uint32_t)(t.range_end - t.range_start) > a.seg_len);
+        return !(a.seg_len && !a.sp_active_tiles && (uint32_t)(t.range_end - t.range_start) > a.seg_cut);
     }
     const int32_t n_items = *a.seg_count;
     const uint32_t tiles_per_image = a.tile_w * a.tile_h, n_blocks = tiles_per_image * a.n_images;
@@ -142,7 +143,7 @@ __device__ __forceinline__ bool tile_context_seg(const Raster3DArgs &a, uint32_t
         t.tile_y   = t.tile_id / a.tile_w;
         t.range_start = a.isect_offsets[blk];
         t.range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
-        return (uint32_t)(t.range_end - t.range_start) <= a.seg_len;
+        return (uint32_t)(t.range_end - t.range_start) <= a.seg_cut;
     }
     item = block;
     const uint32_t blk = (uint32_t)a.seg_items[2 * block];

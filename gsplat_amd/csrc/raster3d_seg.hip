@@ -47,9 +47,26 @@ struct SegPlan {
 
 static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
+// Which lists are cut: those longer than max(2 slices, 3 x the mean list). Segments pay off for OUTLIERS - a few crowded tiles
+// that would otherwise bound the launch (garden: mean 386, longest 8822). When every list is long (c4: 4 M Gaussians per
+// image, mean 1800, longest ~2100) the per-tile walk with its early termination is the faster one: cutting everything
+// there took the forward from 0.64 to 3.4 ms.
+static uint32_t seg_cut_for(int64_t n_isects, uint32_t n_tiles_total, uint32_t seg_len)
+{
+    const int64_t mean3 = n_tiles_total ? 3 * (n_isects / (int64_t)n_tiles_total) : 0;
+    const int64_t cut   = mean3 > 2 * (int64_t)seg_len ? mean3 : 2 * (int64_t)seg_len;
+    return (uint32_t)(cut > 0x7FFFFFFF ? 0x7FFFFFFF : cut);
+}
+
+extern "C" int64_t gsx_raster3d_seg_cut(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, uint32_t seg_len)
+{
+    if (seg_len == 0) return INT64_MAX;
+    return (int64_t)seg_cut_for(n_isects, n_images * tile_w * tile_h, seg_len);
+}
+
 static void seg_bounds(int64_t n_isects, uint32_t n_tiles_total, uint32_t seg_len, uint32_t &max_items, uint32_t &max_long)
 {
-    const int64_t by_len = n_isects / seg_len; // a long tile has more than seg_len entries
+    const int64_t by_len = n_isects / seg_len; // a long tile has more than seg_cut >= 2 seg_len entries
     max_long  = (uint32_t)(by_len < (int64_t)n_tiles_total ? by_len : (int64_t)n_tiles_total);
     max_items = (uint32_t)(by_len + max_long); // ceil(len / seg_len) <= len / seg_len + 1 per long tile
 }
@@ -76,13 +93,13 @@ static int64_t seg_layout(int64_t n_isects, uint32_t n_tiles_total, uint32_t nch
 }
 
 __global__ void __launch_bounds__(256) seg_plan_kernel(const int32_t *offsets, uint32_t n_blocks, uint32_t n_isects,
-                                                       uint32_t seg_len, SegPlan p)
+                                                       uint32_t seg_len, uint32_t seg_cut, SegPlan p)
 {
     const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
     if (blk >= n_blocks) return;
     const int32_t start = offsets[blk], end = (blk == n_blocks - 1) ? (int32_t)n_isects : offsets[blk + 1];
     const uint32_t len  = (uint32_t)(end - start);
-    if (len <= seg_len) return;
+    if (len <= seg_cut) return;
     const uint32_t n_seg = (len + seg_len - 1) / seg_len;
     const int32_t li = atomicAdd(&p.hdr->n_long, 1);
     const int32_t s0 = atomicAdd(&p.hdr->n_items, (int32_t)n_seg);
@@ -212,6 +229,7 @@ extern "C" int gsx_raster3d_fwd_seg(
     const uint32_t n_blocks = n_images * tile_w * tile_h;
     if (n_blocks == 0) return GSX_OK;
     const uint32_t nch_max = cdim > 32 ? 32 : cdim;
+    const uint32_t seg_cut = seg_cut_for(n_isects, n_blocks, seg_len);
     SegPlan p{};
     unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     if (workspace == nullptr
@@ -220,13 +238,13 @@ extern "C" int gsx_raster3d_fwd_seg(
         return GSX_ERR_WORKSPACE;
     }
     if (hipMemsetAsync(p.hdr, 0, sizeof(SegHeader), s) != hipSuccess) return check_launch("raster3d_fwd_seg memset");
-    seg_plan_kernel<<<dim3((n_blocks + 255) / 256), dim3(256), 0, s>>>(isect_offsets, n_blocks, n_isects, seg_len, p);
+    seg_plan_kernel<<<dim3((n_blocks + 255) / 256), dim3(256), 0, s>>>(isect_offsets, n_blocks, n_isects, seg_len, seg_cut, p);
     uint32_t off = 0;
     bool first   = true;
     do {
         const uint32_t rem = cdim - off;
         a.ch_off = off; a.nch = rem > 32 ? 32 : rem; a.first_chunk = first ? 1u : 0u;
-        a.seg_len = seg_len;
+        a.seg_len = seg_len; a.seg_cut = seg_cut;
         int rc;
         if (p.max_items > 0) {
             a.seg_items = p.items; a.seg_count = &p.hdr->n_items;
@@ -289,6 +307,7 @@ extern "C" int gsx_raster3d_bwd_seg(
     a.ch_off = 0; a.nch = cdim; a.first_chunk = 1;
     const uint32_t n_blocks = n_images * tile_w * tile_h;
     if (n_blocks == 0) return GSX_OK;
+    const uint32_t seg_cut = seg_cut_for(n_isects, n_blocks, seg_len);
     SegPlan p{};
     unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     if (workspace == nullptr
@@ -297,8 +316,8 @@ extern "C" int gsx_raster3d_bwd_seg(
         return GSX_ERR_WORKSPACE;
     }
     if (hipMemsetAsync(p.hdr, 0, sizeof(SegHeader), s) != hipSuccess) return check_launch("raster3d_bwd_seg memset");
-    seg_plan_kernel<<<dim3((n_blocks + 255) / 256), dim3(256), 0, s>>>(isect_offsets, n_blocks, n_isects, seg_len, p);
-    a.seg_len = seg_len; a.seg_items = p.items; a.seg_count = &p.hdr->n_items;
+    seg_plan_kernel<<<dim3((n_blocks + 255) / 256), dim3(256), 0, s>>>(isect_offsets, n_blocks, n_isects, seg_len, seg_cut, p);
+    a.seg_len = seg_len; a.seg_cut = seg_cut; a.seg_items = p.items; a.seg_count = &p.hdr->n_items;
     a.seg_T = p.T; a.seg_out = p.out; a.seg_last = p.last;
     int rc;
     if (p.max_items > 0) {

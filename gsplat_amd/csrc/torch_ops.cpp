@@ -610,7 +610,7 @@ RasterDims raster_dims(const Tensor &isect_offsets, const Tensor &colors)
 }
 
 // Longest tile list of the intersection the NEXT compositing call consumes, set by the orchestrator (rendering.py knows it
-// from the intersection's host word; the reference's op schema has no room for it). Above kSegMinLongest the forward cuts
+// from the intersection's host word; the reference's op schema has no room for it). Above gsx_raster3d_seg_cut() the forward cuts
 // long lists into segments (csrc/raster3d_seg.hip). 0 = unknown: one workgroup per tile. Consumed (reset) by the call.
 thread_local int64_t g_long_tile_hint = 0;
 // segment length / the longest list from which segmenting starts; GSPLAT_AMD_SEG_LEN overrides (A/B), 0 switches it off
@@ -623,7 +623,6 @@ static int64_t seg_len_env()
     return v;
 }
 #define kSegLen (seg_len_env())
-#define kSegMinLongest (seg_len_env() > 0 ? 2 * seg_len_env() : (int64_t)1 << 62)
 
 std::tuple<Tensor, Tensor, Tensor, Tensor>
 rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Tensor &colors_, const Tensor &opacities_,
@@ -651,7 +650,7 @@ rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Te
     Tensor last_ids = at::empty(shape({height, width}), means2d.options().dtype(at::kInt));
     const int64_t longest = g_long_tile_hint;
     g_long_tile_hint = 0;
-    if (longest > kSegMinLongest) {
+    if (kSegLen > 0 && longest > gsx_raster3d_seg_cut(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)kSegLen)) {
         Tensor ws = at::empty({gsx_raster3d_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
                                                               (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
         Timed timed_("gsx_raster3d_fwd", L.stream); // same stage name: it IS the compositing forward
@@ -691,7 +690,8 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
     Tensor rows = at::zeros({R, geo + r.D}, means2d.options());
     const int64_t longest = g_long_tile_hint; // set by the autograd formula around this call (gsplat_amd/_autograd.py)
     g_long_tile_hint = 0;
-    if (longest > kSegMinLongest && !absgrad && r.D <= 4 && tile_size == 16) {
+    if (kSegLen > 0 && !absgrad && r.D <= 4 && tile_size == 16
+        && longest > gsx_raster3d_seg_cut(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)kSegLen)) {
         Tensor ws = at::empty({gsx_raster3d_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
                                                               (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
         Timed timed_("gsx_raster3d_bwd", L.stream);

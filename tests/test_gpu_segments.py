@@ -37,6 +37,10 @@ def _lists(G, N, C, W, H, opacity, seed, shrink=0.25):
     _, ids, fl = G.isect_tiles(m2, rad, d, 16, tw, th, conics=con, opacities=op)
     off = G.isect_offset_encode(ids, C, tw, th)
     counts = torch.diff(torch.cat([off.flatten(), torch.tensor([fl.numel()], device=DEV, dtype=off.dtype)]))
+    from gsplat_amd import _ops
+
+    # the scene must really take the segment path: its longest list is an outlier by the library's own rule
+    assert int(counts.max()) > _ops._seg_cut(fl.numel(), C, tw, th), (int(counts.max()), _ops._seg_cut(fl.numel(), C, tw, th))
     return m2, con, op, off, fl, int(counts.max()), W, H, tw, th
 
 
@@ -136,3 +140,25 @@ def test_segmented_backward_through_rasterization(G):
     assert_close_ratio(out["seg"][0], out["tile"][0], 2e-5, 2e-6, max_bad_ratio=1e-5, name="render")
     for nm, x, y in zip(names, out["seg"][1], out["tile"][1]):
         assert_grad_close(x, y, name=f"v_{nm}")
+
+
+def test_uniformly_long_lists_stay_on_the_per_tile_walk(G):
+    """Segments are for outliers: when EVERY list is long (the c4 regime) the cut moves up with the mean and the plain
+    entries run - bit-identical results with and without the hint."""
+    from gsplat_amd import _ops
+
+    sc, W, H = make_scene(N=60000, C=1, width=64, height=64, seed=3, scale_range=(0.05, 0.2))
+    a = {k: v.to(DEV) for k, v in sc.items()}
+    a["opacities"] = torch.full_like(a["opacities"], 0.01)
+    rad, m2, d, con, _ = G.fully_fused_projection(a["means"], None, a["quats"], a["scales"], a["viewmats"], a["Ks"], W, H,
+                                                  opacities=a["opacities"])
+    op = a["opacities"][None].contiguous()
+    _, ids, fl = G.isect_tiles(m2, rad, d, 16, 4, 4, conics=con, opacities=op)
+    off = G.isect_offset_encode(ids, 1, 4, 4)
+    counts = torch.diff(torch.cat([off.flatten(), torch.tensor([fl.numel()], device=DEV, dtype=off.dtype)]))
+    longest = int(counts.max())
+    assert longest > _ops.SEG_MIN_LONGEST and longest <= _ops._seg_cut(fl.numel(), 1, 4, 4), (longest, fl.numel())
+    colors = torch.rand(m2.shape[:-1] + (3,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    ref = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl)
+    hinted = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl, _longest_tile_list=longest)
+    assert torch.equal(ref[0], hinted[0]) and torch.equal(ref[1], hinted[1])
