@@ -190,62 +190,13 @@ __global__ void __launch_bounds__(kCsCols *kCsSegs2) bin_colscan_kernel(int32_t 
     }
 }
 
-// ---- one-workgroup exclusive scan (1024 threads, thread-contiguous runs; runs of <= 16 stay in registers) -------------
-__device__ __forceinline__ int64_t block_scan_1024(const int32_t *in, int32_t *out, uint32_t n, int64_t *s_part)
-{
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n);
-    constexpr uint32_t kKeep = 16;
-    int32_t v[kKeep];
-    int64_t sum = 0;
-    if (per <= kKeep) {
-#pragma unroll
-        for (uint32_t k = 0; k < kKeep; ++k) v[k] = (k < per && lo + k < hi) ? in[lo + k] : 0;
-#pragma unroll
-        for (uint32_t k = 0; k < kKeep; ++k) sum += v[k];
-    } else
-        for (uint32_t i = lo; i < hi; ++i) sum += in[i];
-    int64_t inc    = sum;
-    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int64_t y = __shfl_up(inc, o);
-        if (lane >= o) inc += y;
-    }
-    if (lane == 63) s_part[wave] = inc;
-    __syncthreads();
-    int64_t base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        const int64_t x = s_part[w];
-        if (w < wave) base += x;
-        total += x;
-    }
-    int64_t run = base + inc - sum;
-    if (per <= kKeep) {
-#pragma unroll
-        for (uint32_t k = 0; k < kKeep; ++k)
-            if (k < per && lo + k < hi) {
-                out[lo + k] = (int32_t)run;
-                run += v[k];
-            }
-    } else
-        for (uint32_t i = lo; i < hi; ++i) {
-            const int32_t x = in[i];
-            out[i]          = (int32_t)run;
-            run += x;
-        }
-    __syncthreads(); // s_part may be reused
-    return total;
-}
-
 // ---- C: bin starts --------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) bin_plan_kernel(const BinArgs a)
 {
     __shared__ int64_t s_part[16];
     const BinGeom &g = a.g;
     const uint32_t nb = g.n_bins_total;
-    const int64_t n_entries = block_scan_1024(a.b.bin_count, a.b.bin_start, nb, s_part);
+    const int64_t n_entries = block_scan_i32_1024(a.b.bin_count, a.b.bin_start, nb, s_part, nullptr);
     const bool overflow     = n_entries > g.cap_entries;
     if (threadIdx.x == 0) {
         a.b.bin_start[nb]  = (int32_t)(overflow ? 0 : n_entries);
@@ -433,6 +384,7 @@ __global__ void __launch_bounds__(kBnThreads) bin_tiles_kernel(const BinArgs a)
 __global__ void __launch_bounds__(1024) tile_plan_kernel(const BinArgs a)
 {
     __shared__ int64_t s_part[16];
+    __shared__ int32_t s_max;
     const BinGeom &g = a.g;
     if (a.b.hdr->overflow) {
         if (threadIdx.x == 0) {
@@ -441,22 +393,10 @@ __global__ void __launch_bounds__(1024) tile_plan_kernel(const BinArgs a)
         }
         return;
     }
-    const uint32_t nt = g.n_images * g.n_tiles;
-    if (a.max_tile_len) { // written BEFORE n_isects: the host reads it once n_isects has arrived
-        int32_t mx = 0;
-        for (uint32_t t = threadIdx.x; t < nt; t += 1024) mx = max(mx, a.b.tile_count[t]);
-        mx = wave_max_i32(mx);
-        if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = mx;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int64_t m = 0;
-            for (int w = 0; w < 16; ++w) m = max(m, s_part[w]);
-            *a.max_tile_len = m;
-        }
-        __syncthreads();
-    }
-    const int64_t total = block_scan_1024(a.b.tile_count, a.isect_offsets, nt, s_part);
+    const uint32_t nt   = g.n_images * g.n_tiles;
+    const int64_t total = block_scan_i32_1024(a.b.tile_count, a.isect_offsets, nt, s_part, a.max_tile_len ? &s_max : nullptr);
     if (threadIdx.x == 0) {
+        if (a.max_tile_len) *a.max_tile_len = (int64_t)s_max; // written BEFORE n_isects: the host reads it once that arrived
         __threadfence_system();
         *a.n_isects = total;
     }

@@ -423,40 +423,15 @@ __global__ void __launch_bounds__(kCsTiles *kCsSegs) fused_colscan_kernel(int32_
 __global__ void __launch_bounds__(1024) fused_totals_scan_kernel(const int32_t *totals, uint32_t n_bins, int32_t *offsets,
                                                                  int64_t *n_isects, int64_t *max_tile_len)
 {
-    __shared__ int64_t s_part[1024];
-    const uint32_t per = (n_bins + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n_bins);
-    int64_t sum = 0;
-    for (uint32_t b = lo; b < hi; ++b) sum += totals[b];
-    if (max_tile_len) { // longest tile list, written before n_isects (the host reads it once n_isects has arrived)
-        int64_t mx = 0;
-        for (uint32_t b = lo; b < hi; ++b) mx = max(mx, (int64_t)totals[b]);
-        s_part[threadIdx.x] = mx;
-        __syncthreads();
-        for (int o = 512; o >= 1; o >>= 1) {
-            if ((int)threadIdx.x < o) s_part[threadIdx.x] = max(s_part[threadIdx.x], s_part[threadIdx.x + o]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) *max_tile_len = s_part[0];
-        __syncthreads();
-    }
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partial sums
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int64_t add = (int)threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
-        __syncthreads();
-        s_part[threadIdx.x] += add;
-        __syncthreads();
-    }
-    int64_t run = s_part[threadIdx.x] - sum; // exclusive base of this thread's run
-    for (uint32_t b = lo; b < hi; ++b) {
-        offsets[b] = (int32_t)run;
-        run += totals[b];
-    }
-    if (threadIdx.x == 1023) {
-        __threadfence_system(); // n_isects may live in pinned host memory that the host polls: one 8-byte system-scope store
-        *n_isects = s_part[1023];
+    __shared__ int64_t s_part[16];
+    __shared__ int32_t s_max;
+    const int64_t total = block_scan_i32_1024(totals, offsets, n_bins, s_part, max_tile_len ? &s_max : nullptr);
+    if (threadIdx.x == 0) {
+        // the longest tile list is written before n_isects (the host reads it once n_isects has arrived); n_isects may live
+        // in pinned host memory that the host polls: one 8-byte system-scope store behind a system-scope fence
+        if (max_tile_len) *max_tile_len = (int64_t)s_max;
+        __threadfence_system();
+        *n_isects = total;
     }
 }
 
@@ -467,15 +442,20 @@ int launch_colscan(int32_t *table, int32_t *totals, uint32_t n_cols, uint32_t cp
     fused_colscan_kernel<<<dim3(groups * n_images), dim3(kCsTiles * kCsSegs), 0, s>>>(table, totals, n_cols, cpi, groups);
     return check_launch("isect colscan");
 }
-int launch_big_tile_sort(const TileSortArgs &a, hipStream_t s)
+// The work list (lists longer than kCapSmall) on a persistent grid of one 147 KiB workgroup per CU. Two size classes (a
+// second instantiation with half the LDS for lists up to 4608 entries, two workgroups per CU) were measured and dropped:
+// c4 110 vs 114 us, garden x25 +45 us - the launches run one after the other and each has its own tail.
+static int launch_work_list_sorts(TileSortArgs a, hipStream_t s)
 {
     static PerDeviceOnce once;
     if (once.first())
         (void)hipFuncSetAttribute((const void *)tile_sort_kernel<kCapLarge, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(2 * kCapLarge * sizeof(uint2)));
     tile_sort_kernel<kCapLarge, 1><<<dim3(256), dim3(kTsThreads), 2 * kCapLarge * sizeof(uint2), s>>>(a);
-    return check_launch("isect big tile sort");
+    return check_launch("isect work-list tile sort");
 }
+
+int launch_big_tile_sort(const TileSortArgs &a, hipStream_t s) { return launch_work_list_sorts(a, s); }
 
 static int64_t fused_count_ws_bytes(const FusedGeom &g)
 {
@@ -549,8 +529,6 @@ extern "C" int gsx_isect_tile_sort(const int64_t *isect_ids, const int32_t *flat
     if (once.first()) {
         (void)hipFuncSetAttribute((const void *)bucket_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         (void)hipFuncSetAttribute((const void *)bucket_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        (void)hipFuncSetAttribute((const void *)tile_sort_kernel<kCapLarge, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(2 * kCapLarge * sizeof(uint2)));
     }
     bucket_hist_kernel<<<dim3(a.n_chunks), dim3(kBkThreads), hist_lds, s>>>(a);
     int rc = run_scan_i32_exclusive(a.table, table_elems, a.table_scanned, scan_ws, scan_workspace_bytes_for(table_elems), s);
@@ -558,8 +536,7 @@ extern "C" int gsx_isect_tile_sort(const int64_t *isect_ids, const int32_t *flat
     bucket_scatter_kernel<<<dim3(a.n_chunks), dim3(kBkThreads), hist_lds, s>>>(a);
     if (hipMemsetAsync(a.big_count, 0, sizeof(int32_t), s) != hipSuccess) return check_launch("isect_tile_sort memset");
     tile_sort_small_kernel<<<dim3(n_bins), dim3(kTsThreads), kTsSmallWords * sizeof(uint64_t), s>>>(a);
-    tile_sort_kernel<kCapLarge, 1><<<dim3(256), dim3(kTsThreads), 2 * kCapLarge * sizeof(uint2), s>>>(a);
-    return check_launch("isect_tile_sort");
+    return launch_work_list_sorts(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -673,13 +650,7 @@ extern "C" int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *ra
     f.isect_offsets = isect_offsets; f.bucketed = a.bucketed; f.tile_mask = tile_mask;
     rc = launch_fused_emit_scatter(f, s);
     if (rc != GSX_OK) return rc;
-    static PerDeviceOnce once_fused;
-    if (once_fused.first()) {
-        (void)hipFuncSetAttribute((const void *)tile_sort_kernel<kCapLarge, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(2 * kCapLarge * sizeof(uint2)));
-    }
     if (hipMemsetAsync(a.big_count, 0, sizeof(int32_t), s) != hipSuccess) return check_launch("isect_fused memset");
     tile_sort_small_kernel<<<dim3(n_bins), dim3(kTsThreads), kTsSmallWords * sizeof(uint64_t), s>>>(a);
-    tile_sort_kernel<kCapLarge, 1><<<dim3(256), dim3(kTsThreads), 2 * kCapLarge * sizeof(uint2), s>>>(a);
-    return check_launch("isect_fused_emit_sort");
+    return launch_work_list_sorts(a, s);
 }
