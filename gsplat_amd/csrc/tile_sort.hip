@@ -31,7 +31,7 @@ int64_t scan_workspace_bytes_for(int64_t n);
 constexpr int kTsThreads   = 256;
 constexpr uint32_t kMaxBins = 36864; // LDS histogram: 144 KiB of the 160 KiB
 constexpr int kCapSmall    = 2048;  // entries sorted in 32 KiB-class LDS
-constexpr int kCapLarge    = 9216;  // entries sorted with (almost) the whole LDS
+constexpr int kCapLarge    = 9152;  // entries sorted with (almost) the whole LDS: 2 x 9152 x 8 B + the 16 KiB of per-wave digit bases < 160 KiB
 
 // struct TileSortArgs: isect_fused.hpp (shared with isect_binned.hip)
 
@@ -100,16 +100,16 @@ __global__ void __launch_bounds__(kBkThreads) bucket_scatter_kernel(const TileSo
 // ------------------------------------------------------------------------------------------
 // D: per-tile stable LSD radix sort on the 32 depth bits (+ tie ordering by id)
 // ------------------------------------------------------------------------------------------
-// One stable 8-bit pass over n elements src -> dst (both LDS or both global), block of 256 threads = 4 waves, wave w
-// owns the contiguous run [w*per_wave, (w+1)*per_wave). s_cnt/s_base: [4][256].
-template <typename Ptr>
-__device__ __forceinline__ void radix_pass(Ptr src, Ptr dst, int n, int shift, int32_t (*s_cnt)[256], int32_t (*s_base)[256],
-                                           int64_t *s_scan)
+// One stable 8-bit pass over n elements src -> dst (both LDS or both global) by a workgroup of NW waves; wave w owns the
+// contiguous run [w*per_wave, (w+1)*per_wave). s_base [NW][256]: per-wave digit counts, turned in place into per-wave bases.
+template <int NW, typename Ptr>
+__device__ __forceinline__ void radix_pass(Ptr src, Ptr dst, int n, int shift, int32_t (*s_base)[256], int64_t *s_scan)
 {
+    static_assert(NW >= 4, "the digit scan runs on the first four waves");
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-    const int per_wave = ((n + 255) / 256) * 64; // multiple of 64
+    const int per_wave = ((n + 64 * NW - 1) / (64 * NW)) * 64; // multiple of 64
     const int w_lo = wave * per_wave;
-    for (int i = threadIdx.x; i < 4 * 256; i += kTsThreads) (&s_cnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < NW * 256; i += NW * 64) (&s_base[0][0])[i] = 0;
     __syncthreads();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // count
@@ -117,33 +117,36 @@ __device__ __forceinline__ void radix_pass(Ptr src, Ptr dst, int n, int shift, i
         const int idx   = w_lo + r + lane;
         const bool live = idx < n;
         const int d     = live ? (int)((src[idx].x >> shift) & 0xFFu) : 0;
-        if (live) atomicAdd(&s_cnt[wave][d], 1);
+        if (live) atomicAdd(&s_base[wave][d], 1);
     }
     __syncthreads();
-    // thread d: digit totals -> exclusive scan over digits, then per-wave bases
-    {
+    // thread d < 256: digit totals -> exclusive scan over the digits, then per-wave bases (in place)
+    int32_t tot = 0, inc = 0;
+    if (threadIdx.x < 256u) {
         const int d = (int)threadIdx.x;
-        int32_t tot = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) tot += s_cnt[w][d];
-        // block exclusive scan of tot over the 256 threads
-        int32_t inc = tot;
+        for (int w = 0; w < NW; ++w) tot += s_base[w][d];
+        inc = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int32_t y = __shfl_up(inc, o);
             if (lane >= o) inc += y;
         }
         if (lane == 63) s_scan[wave] = inc;
-        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x < 256u) {
+        const int d = (int)threadIdx.x;
         int32_t base = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w)
             if (w < wave) base += (int32_t)s_scan[w];
         int32_t run = base + inc - tot;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            s_base[w][d] = run;
-            run += s_cnt[w][d];
+        for (int w = 0; w < NW; ++w) {
+            const int32_t c = s_base[w][d];
+            s_base[w][d]    = run;
+            run += c;
         }
     }
     __syncthreads();
@@ -173,7 +176,7 @@ __device__ __forceinline__ void radix_pass(Ptr src, Ptr dst, int n, int shift, i
 template <typename Ptr>
 __device__ __forceinline__ void fix_ties(Ptr a, int n)
 {
-    for (int i = threadIdx.x; i < n; i += kTsThreads) {
+    for (int i = threadIdx.x; i < n; i += (int)blockDim.x) {
         const uint32_t k = a[i].x;
         if ((i == 0 || a[i - 1].x != k) && i + 1 < n && a[i + 1].x == k) {
             int j = i + 1;
@@ -301,58 +304,55 @@ __global__ void __launch_bounds__(kTsThreads) tile_sort_small_kernel(const TileS
     }
 }
 
-// MODE 0: one workgroup per tile; tiles with n <= CAP sort in LDS, longer ones are appended to the work list.
-// MODE 1: a small persistent grid walks the work list: n <= CAP sorts in (nearly all of) the LDS, longer tiles sort
+// A small persistent grid walks the work list (tile_sort_small_kernel appends the lists longer than kCapSmall): n <= CAP
+// sorts in (nearly all of) the LDS, longer tiles sort
 //         through global memory. With no oversized tile the launch costs a few microseconds.
+constexpr int kWlWaves = 16; // work-list sort: 1024 threads (four waves per workgroup left 3/4 of the CU's issue slots empty)
 template <int CAP, int MODE>
-__global__ void __launch_bounds__(kTsThreads) tile_sort_kernel(const TileSortArgs a)
+__global__ void __launch_bounds__(kWlWaves * 64) tile_sort_kernel(const TileSortArgs a)
 {
+    static_assert(MODE == 1, "only the work-list mode is instantiated");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ int32_t s_cnt[4][256];
-    __shared__ int32_t s_base[4][256];
+    __shared__ int32_t s_base[kWlWaves][256];
     __shared__ int64_t s_scan[4];
     uint2 *s_a = reinterpret_cast<uint2 *>(smem_raw);
     uint2 *s_b = s_a + CAP;
+    constexpr int NT = kWlWaves * 64;
 
-  const int32_t n_work = MODE == 0 ? 1 : *a.big_count;
-  for (int32_t wi = (MODE == 0 ? 0 : (int32_t)blockIdx.x); wi < n_work; wi += (int32_t)gridDim.x) {
-    const uint32_t bin  = MODE == 0 ? blockIdx.x : (uint32_t)a.big_list[wi];
+  const int32_t n_work = *a.big_count;
+  for (int32_t wi = (int32_t)blockIdx.x; wi < n_work; wi += (int32_t)gridDim.x) {
+    const uint32_t bin  = (uint32_t)a.big_list[wi];
     const int64_t start = a.table_scanned[(int64_t)bin * a.n_chunks];
     const int64_t end   = (bin + 1 == a.n_bins) ? a.n : a.table_scanned[(int64_t)(bin + 1) * a.n_chunks];
     const int n         = (int)(end - start);
-    if (n <= 0) return; // MODE 0 only (listed tiles are never empty)
-    if (MODE == 0 && n > CAP) {
-        if (threadIdx.x == 0) a.big_list[atomicAdd(a.big_count, 1)] = (int32_t)bin;
-        return;
-    }
     // high 32 bits of every key of this bin
     const uint64_t tile = bin % a.n_tiles, img = bin / a.n_tiles;
     const uint64_t hi   = ((img << a.tile_bits) | tile) << 32;
     uint2 *g_in         = a.bucketed + start;
 
     if (n <= CAP) {
-        for (int i = threadIdx.x; i < n; i += kTsThreads) s_a[i] = g_in[i];
+        for (int i = threadIdx.x; i < n; i += NT) s_a[i] = g_in[i];
         __syncthreads();
-        radix_pass(s_a, s_b, n, 0, s_cnt, s_base, s_scan);
-        radix_pass(s_b, s_a, n, 8, s_cnt, s_base, s_scan);
-        radix_pass(s_a, s_b, n, 16, s_cnt, s_base, s_scan);
-        radix_pass(s_b, s_a, n, 24, s_cnt, s_base, s_scan);
+        radix_pass<kWlWaves>(s_a, s_b, n, 0, s_base, s_scan);
+        radix_pass<kWlWaves>(s_b, s_a, n, 8, s_base, s_scan);
+        radix_pass<kWlWaves>(s_a, s_b, n, 16, s_base, s_scan);
+        radix_pass<kWlWaves>(s_b, s_a, n, 24, s_base, s_scan);
         fix_ties(s_a, n);
-        for (int i = threadIdx.x; i < n; i += kTsThreads) {
+        for (int i = threadIdx.x; i < n; i += NT) {
             const uint2 e         = s_a[i];
             a.keys_out[start + i] = hi | e.x;
             a.vals_out[start + i] = (int32_t)e.y;
         }
-    } else if (MODE == 1) {
+    } else {
         // oversized tile: same passes through global memory (segment is private to this workgroup; __syncthreads
         // orders global accesses within a workgroup)
         uint2 *g_tmp = a.scratch + start;
-        radix_pass(g_in, g_tmp, n, 0, s_cnt, s_base, s_scan);
-        radix_pass(g_tmp, g_in, n, 8, s_cnt, s_base, s_scan);
-        radix_pass(g_in, g_tmp, n, 16, s_cnt, s_base, s_scan);
-        radix_pass(g_tmp, g_in, n, 24, s_cnt, s_base, s_scan);
+        radix_pass<kWlWaves>(g_in, g_tmp, n, 0, s_base, s_scan);
+        radix_pass<kWlWaves>(g_tmp, g_in, n, 8, s_base, s_scan);
+        radix_pass<kWlWaves>(g_in, g_tmp, n, 16, s_base, s_scan);
+        radix_pass<kWlWaves>(g_tmp, g_in, n, 24, s_base, s_scan);
         fix_ties(g_in, n);
-        for (int i = threadIdx.x; i < n; i += kTsThreads) {
+        for (int i = threadIdx.x; i < n; i += NT) {
             const uint2 e         = g_in[i];
             a.keys_out[start + i] = hi | e.x;
             a.vals_out[start + i] = (int32_t)e.y;
@@ -451,7 +451,7 @@ static int launch_work_list_sorts(TileSortArgs a, hipStream_t s)
     if (once.first())
         (void)hipFuncSetAttribute((const void *)tile_sort_kernel<kCapLarge, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(2 * kCapLarge * sizeof(uint2)));
-    tile_sort_kernel<kCapLarge, 1><<<dim3(256), dim3(kTsThreads), 2 * kCapLarge * sizeof(uint2), s>>>(a);
+    tile_sort_kernel<kCapLarge, 1><<<dim3(256), dim3(kWlWaves * 64), 2 * kCapLarge * sizeof(uint2), s>>>(a);
     return check_launch("isect work-list tile sort");
 }
 
