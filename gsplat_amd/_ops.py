@@ -689,52 +689,44 @@ def projection_ewa_3dgs_packed(means, covars, quats, scales, opacities, viewmats
     q = None if covars is not None else quats
     s = None if covars is not None else scales
     total = B * C * N
-    visible = torch.empty(total, device=dev, dtype=torch.int32)
     common = (ptr(means), ptr(covars), ptr(q), ptr(s), ptr(opacities), ptr(viewmats), ptr(Ks), B, C, N, image_width,
               image_height, eps2d, near_plane, far_plane, radius_clip, int(camera_model))
-    nnz = 0
-    cum = None
-    if total > 0:
-        call("gsx_project_ewa_packed_count", *common, int(calc_compensations), ptr(visible))
-        cum = _scan_i32(visible)
-        if total * _PACKED_ROW_BYTES <= _PACKED_PREALLOC_LIMIT:
-            # The write pass only needs the DEVICE-side offsets: enqueue it into row buffers sized for the upper bound
-            # (every (image, Gaussian) pair visible) before the host learns nnz, and hand out the first nnz rows. The GPU
-            # no longer idles through the host round trip + nine allocations + a launch (r05 timeline: ~60 us per step).
-            # Scenes whose upper bound would not be small next to the model keep the exact-length path below - saving
-            # that memory is what packed rows are for.
-            host_nnz = torch.empty(1, dtype=torch.int64, pin_memory=True)
-            host_nnz.copy_(cum[-1:], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            ub = total
-            bufs = (torch.empty(ub, device=dev, dtype=torch.int64), torch.empty(ub, device=dev, dtype=torch.int64),
-                    torch.empty(ub, device=dev, dtype=torch.int64), torch.zeros(B * C + 1, device=dev, dtype=torch.int32),
-                    torch.empty((ub, 2), device=dev, dtype=torch.int32), torch.empty((ub, 2), device=dev, dtype=dt),
-                    torch.empty((ub,), device=dev, dtype=dt), torch.empty((ub, 3), device=dev, dtype=dt),
-                    torch.empty((ub,), device=dev, dtype=dt) if calc_compensations else None)
-            call("gsx_project_ewa_packed_write", *common, ptr(cum), ub, *[ptr(t) for t in bufs])
-            ev.synchronize()  # host sync: exact-length COO outputs (reference: Projection.cpp:928-941)
-            nnz = int(host_nnz.item())
-            # a view pins the whole upper-bound buffer for as long as the step (and its autograd graph) holds the rows: when
-            # few pairs are visible - the case packed rows exist for - copy the heads out and let the big buffers go
-            compact = 2 * nnz < ub
-            return tuple(t if (t is None or i == 3) else (t[:nnz].clone() if compact else t[:nnz])
-                         for i, t in enumerate(bufs))
-        nnz = int(cum[-1].item())  # host sync: exact-length COO outputs (reference: Projection.cpp:928-941)
-    batch_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
-    camera_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
-    gaussian_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
-    indptr = torch.zeros(B * C + 1, device=dev, dtype=torch.int32)
-    radii = torch.empty((nnz, 2), device=dev, dtype=torch.int32)
-    means2d = torch.empty((nnz, 2), device=dev, dtype=dt)
-    depths = torch.empty((nnz,), device=dev, dtype=dt)
-    conics = torch.empty((nnz, 3), device=dev, dtype=dt)
-    comps = torch.empty((nnz,), device=dev, dtype=dt) if calc_compensations else None
-    if total > 0:
-        call("gsx_project_ewa_packed_write", *common, ptr(cum), nnz, ptr(batch_ids), ptr(camera_ids),
-             ptr(gaussian_ids), ptr(indptr), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(comps))
-    return batch_ids, camera_ids, gaussian_ids, indptr, radii, means2d, depths, conics, comps
+
+    def outputs(rows):
+        return (torch.empty(rows, device=dev, dtype=torch.int64), torch.empty(rows, device=dev, dtype=torch.int64),
+                torch.empty(rows, device=dev, dtype=torch.int64), torch.zeros(B * C + 1, device=dev, dtype=torch.int32),
+                torch.empty((rows, 2), device=dev, dtype=torch.int32), torch.empty((rows, 2), device=dev, dtype=dt),
+                torch.empty((rows,), device=dev, dtype=dt), torch.empty((rows, 3), device=dev, dtype=dt),
+                torch.empty((rows,), device=dev, dtype=dt) if calc_compensations else None)
+
+    if total == 0:
+        return outputs(0)
+    # Rows are placed from BLOCK counts (csrc/projection.hip: PackedBlocks): one int32 per 256 (image, Gaussian) pairs, scanned
+    # by one workgroup that stores the row count straight into a pinned host word - no per-pair flags, no cumsum tensor.
+    n_blocks = _cabi._lib.gsx_project_packed_blocks(total)
+    blocks = torch.empty((2, n_blocks), device=dev, dtype=torch.int32)
+    host_nnz = torch.full((1,), -1, dtype=torch.int64).pin_memory()
+    call("gsx_project_ewa_packed_count_blocks", *common, int(calc_compensations), ptr(blocks[0]), ptr(blocks[1]), None,
+         host_nnz.data_ptr())
+    ev = torch.cuda.Event()
+    ev.record()
+    prealloc = total * _PACKED_ROW_BYTES <= _PACKED_PREALLOC_LIMIT
+    if prealloc:
+        # The write pass only needs the DEVICE-side offsets: enqueue it into row buffers sized for the upper bound (every
+        # pair visible) before the host learns nnz, and hand out the first nnz rows. Scenes whose upper bound would not be
+        # small next to the model keep the exact-length path below - saving that memory is what packed rows are for.
+        bufs = outputs(total)
+        call("gsx_project_ewa_packed_write_blocks", *common, ptr(blocks[1]), *[ptr(t) for t in bufs])
+    ev.synchronize()  # host round trip: exact-length COO outputs (reference: Projection.cpp:928-941)
+    nnz = int(host_nnz.item())
+    if prealloc:
+        # a view pins the whole upper-bound buffer for as long as the step (and its autograd graph) holds the rows: when
+        # few pairs are visible - the case packed rows exist for - copy the heads out and let the big buffers go
+        compact = 2 * nnz < total
+        return tuple(t if (t is None or i == 3) else (t[:nnz].clone() if compact else t[:nnz]) for i, t in enumerate(bufs))
+    bufs = outputs(nnz)
+    call("gsx_project_ewa_packed_write_blocks", *common, ptr(blocks[1]), *[ptr(t) for t in bufs])
+    return bufs
 
 
 @_op("projection_ewa_3dgs_packed_bwd")

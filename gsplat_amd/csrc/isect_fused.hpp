@@ -48,77 +48,6 @@ inline FusedGeom fused_geometry(int64_t rows, uint32_t n_images, uint32_t tile_s
     return g;
 }
 
-// Exclusive scan of n int32 counts by ONE workgroup of 1024 threads, 4096 elements per trip: 16-byte coalesced loads and
-// stores (thread t owns elements 4 t .. 4 t + 3 of the trip), a wave scan, 16 wave totals, a running carry. Returns the
-// grand total (int64: the callers reject >= 2^31 before any int32 offset is used) and, when `max_out` is set, the largest
-// element in the same pass. s_part: 16 int64 of LDS. Replaces thread-contiguous runs read with a 128-byte lane stride
-// (c4, 32640 tiles: 71 -> ~12 us; c3: 16 -> ~4 us).
-__device__ __forceinline__ int64_t block_scan_i32_1024(const int32_t *in, int32_t *out, uint32_t n, int64_t *s_part,
-                                                       int32_t *max_out)
-{
-    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-    const bool vec = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
-    int64_t carry  = 0;
-    int32_t mx     = 0;
-    for (uint32_t base = 0; base < n; base += 4096u) {
-        const uint32_t i = base + 4u * threadIdx.x;
-        int32_t v[4]     = {0, 0, 0, 0};
-        if (vec && i + 3u < n) {
-            const int4 q = *reinterpret_cast<const int4 *>(in + i);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k)
-                if (i + k < n) v[k] = in[i + k];
-        }
-        mx              = max(max(mx, max(v[0], v[1])), max(v[2], v[3]));
-        const int64_t s = (int64_t)v[0] + v[1] + v[2] + v[3];
-        int64_t inc     = s;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int64_t y = __shfl_up(inc, o);
-            if (lane >= o) inc += y;
-        }
-        if (lane == 63) s_part[wave] = inc;
-        __syncthreads();
-        int64_t before = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int64_t x = s_part[w];
-            if (w < wave) before += x;
-            all += x;
-        }
-        int64_t run = carry + before + inc - s;
-        if (vec && i + 3u < n) {
-            int4 q;
-            q.x = (int32_t)run; q.y = (int32_t)(run + v[0]); q.z = (int32_t)(run + v[0] + v[1]);
-            q.w = (int32_t)(run + v[0] + v[1] + v[2]);
-            *reinterpret_cast<int4 *>(out + i) = q;
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k)
-                if (i + k < n) {
-                    out[i + k] = (int32_t)run;
-                    run += v[k];
-                }
-        }
-        carry += all;
-        __syncthreads(); // s_part is rewritten by the next trip
-    }
-    if (max_out) {
-        mx = wave_max_i32(mx);
-        if (lane == 0) s_part[wave] = mx;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int64_t m = 0;
-            for (int w = 0; w < 16; ++w) m = max(m, s_part[w]);
-            *max_out = (int32_t)m;
-        }
-        __syncthreads();
-    }
-    return carry;
-}
-
 struct TileSortArgs {
     const uint64_t *keys_in;
     const int32_t *vals_in;

@@ -205,6 +205,86 @@ __global__ void __launch_bounds__(256) project_write_kernel(const ProjArgs a)
     if (a.compensations) a.compensations[row] = o.comp;
 }
 
+// ---- packed rows from BLOCK counts -----------------------------------------------------------------------------------------
+// The count pass above writes one flag per (image, Gaussian) pair and the caller scans all of them (three launches over
+// 4 B x B C N) before the write pass can place a row. A row's place only needs (a) the number of visible pairs in the
+// 256-pair blocks before its own - one int32 per block, scanned by ONE workgroup that also publishes the total - and
+// (b) its rank inside its block, which the write pass re-derives with a ballot from the visibility it recomputes anyway.
+// Blocks cover pairs [256 k, 256 k + 256) of the flattened (b, c, g) order; there is one block more than pairs need when
+// B C N is a multiple of 256, so that the one-past-the-end position (indptr's last entry) has a block too.
+struct PackedBlocks {
+    int32_t *block_counts;        // [n_blocks]      (count pass)
+    const int32_t *block_offsets; // [n_blocks]      (write pass: exclusive scan of the counts)
+};
+
+__global__ void __launch_bounds__(256) project_count_blocks_kernel(const ProjArgs a, PackedBlocks pb)
+{
+    __shared__ int32_t s_n[4];
+    const int64_t idx   = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t count = (int64_t)a.B * a.C * a.N;
+    bool ok = false;
+    if (idx < count) {
+        const uint32_t g = (uint32_t)(idx % a.N), c = (uint32_t)((idx / a.N) % a.C), b = (uint32_t)(idx / ((int64_t)a.N * a.C));
+        ok = project_one(a, b, c, g).ok;
+    }
+    const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+    if ((threadIdx.x & 63u) == 0) s_n[threadIdx.x >> 6] = (int32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) pb.block_counts[blockIdx.x] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+}
+
+// one workgroup: exclusive scan of the block counts; the total goes to device memory and (optionally) straight into a
+// pinned host word the caller polls - no copy kernel, no stream synchronisation
+__global__ void __launch_bounds__(1024) packed_block_scan_kernel(const int32_t *counts, uint32_t n_blocks, int32_t *offsets,
+                                                                int64_t *nnz_device, int64_t *nnz_host)
+{
+    __shared__ int64_t s_part[16];
+    const int64_t total = block_scan_i32_1024(counts, offsets, n_blocks, s_part, nullptr);
+    if (threadIdx.x == 0) {
+        if (nnz_device) *nnz_device = total;
+        if (nnz_host) {
+            __threadfence_system();
+            *nnz_host = total;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) project_write_blocks_kernel(const ProjArgs a, PackedBlocks pb)
+{
+    __shared__ int32_t s_n[4];
+    const int64_t idx   = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t count = (int64_t)a.B * a.C * a.N;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t b = 0, c = 0, g = 0;
+    ProjOut o;
+    o.ok = false;
+    if (idx < count) {
+        g = (uint32_t)(idx % a.N); c = (uint32_t)((idx / a.N) % a.C); b = (uint32_t)(idx / ((int64_t)a.N * a.C));
+        o = project_one(a, b, c, g);
+    }
+    const uint64_t m = __builtin_amdgcn_ballot_w64(o.ok);
+    if (lane == 0) s_n[wave] = (int32_t)__popcll(m);
+    __syncthreads();
+    int32_t before = pb.block_offsets[blockIdx.x];
+    for (uint32_t w = 0; w < wave; ++w) before += s_n[w];
+    const int64_t row = (int64_t)before + (int64_t)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    // CSR pointer over images: indptr[i] = #visible rows before image i (the one-past-the-end pair closes it)
+    if (idx <= count && idx % a.N == 0) a.indptr[idx / a.N] = (int32_t)row;
+    if (!o.ok) return;
+    a.batch_ids[row]       = b;
+    a.camera_ids[row]      = c;
+    a.gaussian_ids[row]    = g;
+    a.radii[2 * row]       = o.rx;
+    a.radii[2 * row + 1]   = o.ry;
+    a.means2d[2 * row]     = o.mx;
+    a.means2d[2 * row + 1] = o.my;
+    a.depths[row]          = o.depth;
+    a.conics[3 * row]      = o.ca;
+    a.conics[3 * row + 1]  = o.cb;
+    a.conics[3 * row + 2]  = o.cc;
+    if (a.compensations) a.compensations[row] = o.comp;
+}
+
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
@@ -671,6 +751,78 @@ extern "C" int gsx_project_ewa_packed_write(const float *means, const float *cov
     a.gaussian_ids = gaussian_ids; a.indptr = indptr;
     project_write_kernel<<<dim3((uint32_t)ceil_div(count + 1, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
     return check_launch("project_ewa_packed_write");
+}
+
+extern "C" int64_t gsx_project_packed_blocks(int64_t pairs) { return (pairs + 1 + 255) / 256; }
+
+// gsx_project_ewa_packed_count + scan in block form (see PackedBlocks): block_counts / block_offsets are
+// [gsx_project_packed_blocks(B C N)] int32; nnz_device / nnz_host (either may be null) receive the row count, the host word
+// (pinned memory) as one 8-byte system-scope store that a polling caller sees as soon as the scan has run.
+extern "C" int gsx_project_ewa_packed_count_blocks(const float *means, const float *covars, const float *quats,
+                                                   const float *scales, const float *opacities, const float *viewmats,
+                                                   const float *Ks, uint32_t B, uint32_t C, uint32_t N, uint32_t width,
+                                                   uint32_t height, float eps2d, float near_plane, float far_plane,
+                                                   float radius_clip, int camera_model, int calc_compensations,
+                                                   int32_t *block_counts, int32_t *block_offsets, int64_t *nnz_device,
+                                                   int64_t *nnz_host, void *stream)
+{
+    const int64_t count = (int64_t)B * C * N;
+    GSX_REQUIRE(count < (1ll << 31) - 256, "gsx_project_ewa_packed_count_blocks: %lld (image, Gaussian) pairs exceed int32 offsets",
+                (long long)count);
+    GSX_REQUIRE(block_counts && block_offsets, "gsx_project_ewa_packed_count_blocks: null block buffer");
+    if (count > 0) {
+        int rc = check_proj_common("gsx_project_ewa_packed_count_blocks", means, covars, quats, scales, viewmats, Ks, camera_model);
+        if (rc != GSX_OK) return rc;
+    }
+    ProjArgs a{};
+    a.means = means; a.covars = covars; a.quats = quats; a.scales = scales; a.opacities = opacities;
+    a.viewmats = viewmats; a.Ks = Ks; a.B = B; a.C = C; a.N = N; a.width = width; a.height = height;
+    a.eps2d = eps2d; a.near_plane = near_plane; a.far_plane = far_plane; a.radius_clip = radius_clip;
+    a.camera_model = camera_model; a.calc_compensations = calc_compensations;
+    PackedBlocks pb{block_counts, block_offsets};
+    const uint32_t n_blocks = (uint32_t)gsx_project_packed_blocks(count);
+    project_count_blocks_kernel<<<dim3(n_blocks), dim3(256), 0, (hipStream_t)stream>>>(a, pb);
+    packed_block_scan_kernel<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(block_counts, n_blocks, block_offsets, nnz_device,
+                                                                            nnz_host);
+    return check_launch("project_ewa_packed_count_blocks");
+}
+
+// gsx_project_ewa_packed_write with the rows placed from the block offsets above (same outputs, bit for bit)
+extern "C" int gsx_project_ewa_packed_write_blocks(const float *means, const float *covars, const float *quats,
+                                                   const float *scales, const float *opacities, const float *viewmats,
+                                                   const float *Ks, uint32_t B, uint32_t C, uint32_t N, uint32_t width,
+                                                   uint32_t height, float eps2d, float near_plane, float far_plane,
+                                                   float radius_clip, int camera_model, const int32_t *block_offsets,
+                                                   int64_t *batch_ids, int64_t *camera_ids, int64_t *gaussian_ids,
+                                                   int32_t *indptr, int32_t *radii, float *means2d, float *depths,
+                                                   float *conics, float *compensations, void *stream)
+{
+    const int64_t count = (int64_t)B * C * N;
+    GSX_REQUIRE(indptr && block_offsets, "gsx_project_ewa_packed_write_blocks: null indptr / block offsets");
+    GSX_REQUIRE(count < (1ll << 31) - 256, "gsx_project_ewa_packed_write_blocks: too many (image, Gaussian) pairs");
+    if (count == 0) { // indptr [B*C+1] all zeros
+        if (hipMemsetAsync(indptr, 0, ((size_t)B * C + 1) * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
+            set_last_error("gsx_project_ewa_packed_write_blocks: memset failed");
+            return GSX_ERR_LAUNCH;
+        }
+        return GSX_OK;
+    }
+    if (count > 0) {
+        int rc = check_proj_common("gsx_project_ewa_packed_write_blocks", means, covars, quats, scales, viewmats, Ks, camera_model);
+        if (rc != GSX_OK) return rc;
+        GSX_REQUIRE(batch_ids && camera_ids && gaussian_ids && radii && means2d && depths && conics,
+                    "gsx_project_ewa_packed_write_blocks: null output");
+    }
+    ProjArgs a{};
+    a.means = means; a.covars = covars; a.quats = quats; a.scales = scales; a.opacities = opacities;
+    a.viewmats = viewmats; a.Ks = Ks; a.B = B; a.C = C; a.N = N; a.width = width; a.height = height;
+    a.eps2d = eps2d; a.near_plane = near_plane; a.far_plane = far_plane; a.radius_clip = radius_clip;
+    a.camera_model = camera_model; a.calc_compensations = compensations != nullptr;
+    a.radii = radii; a.means2d = means2d; a.depths = depths; a.conics = conics; a.compensations = compensations;
+    a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids; a.indptr = indptr;
+    PackedBlocks pb{nullptr, block_offsets};
+    project_write_blocks_kernel<<<dim3((uint32_t)gsx_project_packed_blocks(count)), dim3(256), 0, (hipStream_t)stream>>>(a, pb);
+    return check_launch("project_ewa_packed_write_blocks");
 }
 
 static void fill_bwd(ProjBwdArgs &a, const float *means, const float *covars, const float *quats, const float *scales,

@@ -246,20 +246,19 @@ projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const
     };
     if (total == 0) return outputs(0);
     auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means.device().index());
-    Tensor visible = at::empty({total}, i32), cum = at::empty({total}, i64);
-    { Timed timed_("gsx_project_ewa_packed_count", L.stream); check(gsx_project_ewa_packed_count(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
-                                       (uint32_t)C, (uint32_t)N, (uint32_t)width, (uint32_t)height, (float)eps2d,
-                                       (float)near_plane, (float)far_plane, (float)radius_clip, (int)camera_model,
-                                       calc_compensations ? 1 : 0, mp<int32_t>(visible), L.stream),
-          "gsx_project_ewa_packed_count"); }
-    {
-        Tensor ws = at::empty({std::max<int64_t>(gsx_scan_workspace_bytes(total), 8)}, means.options().dtype(at::kByte));
-        { Timed timed_("gsx_scan_i32", L.stream); check(gsx_scan_i32(cp<int32_t>(visible), total, mp<int64_t>(cum), ws.mutable_data_ptr(), ws.numel(), L.stream), "gsx_scan_i32"); }
-    }
+    // rows are placed from BLOCK counts (csrc/projection.hip: PackedBlocks): one int32 per 256 pairs, scanned by one workgroup
+    // that stores the row count straight into the pinned word below - no per-pair flags, no cumsum tensor, no copy kernel
+    const int64_t n_blocks = gsx_project_packed_blocks(total);
+    Tensor blocks = at::empty({2, n_blocks}, i32);
     Tensor host_nnz = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
     volatile int64_t *nnz_slot = host_nnz.mutable_data_ptr<int64_t>();
-    *nnz_slot = -1; // sentinel: the copy below overwrites it as soon as the scan has run
-    host_nnz.copy_(cum.slice(0, total - 1, total), /*non_blocking=*/true);
+    *nnz_slot = -1; // sentinel: the scan kernel overwrites it
+    { Timed timed_("gsx_project_ewa_packed_count", L.stream); check(gsx_project_ewa_packed_count_blocks(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
+                                       (uint32_t)C, (uint32_t)N, (uint32_t)width, (uint32_t)height, (float)eps2d,
+                                       (float)near_plane, (float)far_plane, (float)radius_clip, (int)camera_model,
+                                       calc_compensations ? 1 : 0, mp<int32_t>(blocks), mp<int32_t>(blocks) + n_blocks, nullptr,
+                                       host_nnz.mutable_data_ptr<int64_t>(), L.stream),
+          "gsx_project_ewa_packed_count_blocks"); }
     // The row count is on the host once the SCAN has run - the write kernel enqueued after it does not have to finish first.
     // Polling the pinned word instead of synchronising the stream lets the caller slice the outputs and enqueue the next
     // kernels while the write kernel still runs (everything stays stream-ordered behind it).
@@ -276,13 +275,14 @@ projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const
     };
     auto write = [&](int64_t rows, decltype(outputs(0)) &o) {
         auto &[bi, ci, gi, indptr, radii, m2, dep, con, comp] = o;
-        { Timed timed_("gsx_project_ewa_packed_write", L.stream); check(gsx_project_ewa_packed_write(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
+        (void)rows;
+        { Timed timed_("gsx_project_ewa_packed_write", L.stream); check(gsx_project_ewa_packed_write_blocks(fp(means), fp(covars), fp(quats), fp(scales), fp(opac), fp(viewmats), fp(Ks), (uint32_t)B,
                                            (uint32_t)C, (uint32_t)N, (uint32_t)width, (uint32_t)height, (float)eps2d,
                                            (float)near_plane, (float)far_plane, (float)radius_clip, (int)camera_model,
-                                           cp<int64_t>(cum), rows, mp<int64_t>(bi), mp<int64_t>(ci), mp<int64_t>(gi),
+                                           cp<int32_t>(blocks) + n_blocks, mp<int64_t>(bi), mp<int64_t>(ci), mp<int64_t>(gi),
                                            mp<int32_t>(indptr), mp<int32_t>(radii), mp<float>(m2), mp<float>(dep), mp<float>(con),
                                            comp ? mp<float>(*comp) : nullptr, L.stream),
-              "gsx_project_ewa_packed_write"); }
+              "gsx_project_ewa_packed_write_blocks"); }
     };
     if (total * kPackedRowBytes <= kPackedPreallocLimit) {
         auto o = outputs(total);

@@ -112,6 +112,26 @@ int gsx_project_ewa_packed_write(const float *means, const float *covars, const 
                                  int64_t *batch_ids, int64_t *camera_ids, int64_t *gaussian_ids, int32_t *indptr,
                                  int32_t *radii, float *means2d, float *depths, float *conics,
                                  float *compensations, void *stream);
+
+/* The same two passes with the rows placed from BLOCK counts (one int32 per 256 (image, Gaussian) pairs, scanned by one
+ * workgroup that also publishes the row count) instead of one flag per pair scanned by the caller: identical outputs, no
+ * [B C N] temporaries, three launches instead of five. block_counts / block_offsets: [gsx_project_packed_blocks(B C N)]
+ * int32. nnz_device / nnz_host may be NULL; nnz_host must be pinned host memory (one 8-byte system-scope store: a caller
+ * that set it to -1 beforehand can poll it instead of synchronising the stream). */
+int64_t gsx_project_packed_blocks(int64_t pairs);
+int gsx_project_ewa_packed_count_blocks(const float *means, const float *covars, const float *quats, const float *scales,
+                                        const float *opacities, const float *viewmats, const float *Ks, uint32_t B,
+                                        uint32_t C, uint32_t N, uint32_t width, uint32_t height, float eps2d,
+                                        float near_plane, float far_plane, float radius_clip, int camera_model,
+                                        int calc_compensations, int32_t *block_counts, int32_t *block_offsets,
+                                        int64_t *nnz_device, int64_t *nnz_host, void *stream);
+int gsx_project_ewa_packed_write_blocks(const float *means, const float *covars, const float *quats, const float *scales,
+                                        const float *opacities, const float *viewmats, const float *Ks, uint32_t B,
+                                        uint32_t C, uint32_t N, uint32_t width, uint32_t height, float eps2d,
+                                        float near_plane, float far_plane, float radius_clip, int camera_model,
+                                        const int32_t *block_offsets, int64_t *batch_ids, int64_t *camera_ids,
+                                        int64_t *gaussian_ids, int32_t *indptr, int32_t *radii, float *means2d,
+                                        float *depths, float *conics, float *compensations, void *stream);
 int gsx_project_ewa_packed_bwd(const float *means, const float *covars, const float *quats, const float *scales,
                                const float *viewmats, const float *Ks,
                                uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
