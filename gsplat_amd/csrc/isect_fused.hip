@@ -24,7 +24,6 @@
 
 namespace gsx {
 
-constexpr int kFusedThreads = 1024;
 
 __device__ __forceinline__ void chunk_rows(const FusedGeom &g, uint32_t chunk, int64_t &lo, int64_t &hi)
 {
@@ -62,10 +61,9 @@ __device__ __forceinline__ RowGeom load_row_geom(const FusedArgs &a, int64_t r, 
 // kFusedSub rows of a chunk are first ordered by a size class — the tile area of the radius box, 63 = largest — with an
 // LDS counting sort, and thread t walks the t-th row of that order: waves get rows of similar cost, the big ones first.
 // Which thread walks a row changes nothing in the outputs (counts per row; slots inside a tile segment are sorted later).
-constexpr int kFusedSub = 4096;
+constexpr int kFusedPer = 4; // rows per thread and round: a sub-chunk is kFusedPer x THREADS rows
 // dynamic LDS = one int32 per tile of an image (<= kMaxBins = 36864 of tile_sort.hip) next to ~8.3 KiB of static LDS below
 constexpr int kFusedMaxDynLds = 36864 * 4;
-static_assert(kFusedSub % kFusedThreads == 0 && kFusedSub <= 65536, "order entries are uint16");
 
 __device__ __forceinline__ int size_class(const FusedArgs &a, int64_t r)
 {
@@ -83,12 +81,14 @@ __device__ __forceinline__ int size_class(const FusedArgs &a, int64_t r)
 // `body(row, data)` once per row. The walk of a row starts with two dependent global reads (radii, then the geometry of a
 // live row); issued row by row they cost two full memory latencies per row at 16 waves per CU - 46 of the 62 us of the
 // counting kernel on c3 (r05 ablation). Loading the kPer rows of a thread up front turns eight serial latencies into one.
-template <typename Load, typename Body>
+template <int kFusedThreads, typename Load, typename Body>
 __device__ __forceinline__ void for_rows_balanced(const FusedArgs &a, int64_t lo, int64_t hi, Load &&load, Body &&body)
 {
+    constexpr int kFusedSub = kFusedPer * kFusedThreads;
+    static_assert(kFusedSub <= 65536, "order entries are uint16");
     __shared__ uint16_t s_order[kFusedSub];
     __shared__ int32_t s_cnt[64];
-    constexpr int kPer = kFusedSub / kFusedThreads;
+    constexpr int kPer = kFusedPer;
     for (int64_t sub = lo; sub < hi; sub += kFusedSub) {
         const int n = (int)min((int64_t)kFusedSub, hi - sub);
         if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
@@ -131,6 +131,7 @@ __device__ __forceinline__ void for_rows_balanced(const FusedArgs &a, int64_t lo
     }
 }
 
+template <int kFusedThreads>
 __global__ void __launch_bounds__(kFusedThreads) fused_count_hist_kernel(const FusedArgs a)
 {
     extern __shared__ int32_t s_hist[];
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(kFusedThreads) fused_count_hist_kernel(const F
     chunk_rows(g, blockIdx.x, lo, hi);
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)(blockIdx.x / g.cpi) * g.n_tiles : nullptr;
-    for_rows_balanced(
+    for_rows_balanced<kFusedThreads>(
         a, lo, hi, [&](int64_t r) { return load_row_geom(a, r, has_conic); },
         [&](int64_t r, const RowGeom &q) {
             int32_t n = 0;
@@ -157,6 +158,7 @@ __global__ void __launch_bounds__(kFusedThreads) fused_count_hist_kernel(const F
     for (uint32_t t = threadIdx.x; t < g.n_tiles; t += kFusedThreads) out[t] = s_hist[t];
 }
 
+template <int kFusedThreads>
 __global__ void __launch_bounds__(kFusedThreads) fused_emit_scatter_kernel(const FusedArgs a)
 {
     extern __shared__ int32_t s_cur[];
@@ -174,7 +176,7 @@ __global__ void __launch_bounds__(kFusedThreads) fused_emit_scatter_kernel(const
         RowGeom q;
         uint32_t dbits;
     };
-    for_rows_balanced(
+    for_rows_balanced<kFusedThreads>(
         a, lo, hi,
         [&](int64_t r) {
             RowEmit e;
@@ -195,26 +197,39 @@ __global__ void __launch_bounds__(kFusedThreads) fused_emit_scatter_kernel(const
         });
 }
 
+template <int T>
 static void set_lds_limit_once()
 {
     static PerDeviceOnce once;
     if (once.first()) {
-        (void)hipFuncSetAttribute((const void *)fused_count_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxDynLds);
-        (void)hipFuncSetAttribute((const void *)fused_emit_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxDynLds);
+        (void)hipFuncSetAttribute((const void *)fused_count_hist_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxDynLds);
+        (void)hipFuncSetAttribute((const void *)fused_emit_scatter_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxDynLds);
     }
 }
 
 int launch_fused_count_hist(const FusedArgs &a, hipStream_t s)
 {
-    set_lds_limit_once();
-    fused_count_hist_kernel<<<dim3(a.geom.n_chunks), dim3(kFusedThreads), (size_t)a.geom.n_tiles * sizeof(int32_t), s>>>(a);
+    const size_t lds = (size_t)a.geom.n_tiles * sizeof(int32_t);
+    if (a.geom.threads == 512) {
+        set_lds_limit_once<512>();
+        fused_count_hist_kernel<512><<<dim3(a.geom.n_chunks), dim3(512), lds, s>>>(a);
+    } else {
+        set_lds_limit_once<1024>();
+        fused_count_hist_kernel<1024><<<dim3(a.geom.n_chunks), dim3(1024), lds, s>>>(a);
+    }
     return check_launch("isect_fused_count");
 }
 
 int launch_fused_emit_scatter(const FusedArgs &a, hipStream_t s)
 {
-    set_lds_limit_once();
-    fused_emit_scatter_kernel<<<dim3(a.geom.n_chunks), dim3(kFusedThreads), (size_t)a.geom.n_tiles * sizeof(int32_t), s>>>(a);
+    const size_t lds = (size_t)a.geom.n_tiles * sizeof(int32_t);
+    if (a.geom.threads == 512) {
+        set_lds_limit_once<512>();
+        fused_emit_scatter_kernel<512><<<dim3(a.geom.n_chunks), dim3(512), lds, s>>>(a);
+    } else {
+        set_lds_limit_once<1024>();
+        fused_emit_scatter_kernel<1024><<<dim3(a.geom.n_chunks), dim3(1024), lds, s>>>(a);
+    }
     return check_launch("isect_fused_emit");
 }
 

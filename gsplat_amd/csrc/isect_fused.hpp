@@ -2,6 +2,8 @@
 // -ffp-contract=off; tile_sort.hip: column scan, per-tile sort and the C-ABI entries).
 #pragma once
 #include "common.hpp"
+#include <cstdio>
+#include <cstdlib>
 
 namespace gsx {
 
@@ -9,6 +11,7 @@ struct FusedGeom {
     int64_t rows;           // all rows
     int64_t rows_per_image; // dense: N; packed (single image): rows
     uint32_t n_images, cpi /* chunks per image */, rpc /* rows per chunk */, n_chunks;
+    uint32_t threads;       // workgroup size of the two walk kernels: 1024 (one per CU) or 512 (two per CU)
     uint32_t tile_size, tile_w, tile_h, n_tiles /* per image */;
 };
 
@@ -26,7 +29,7 @@ struct FusedArgs {
     uint2 *bucketed;              // [M] (emit)
 };
 
-// <= 256 chunks in total (one workgroup of 1024 threads per CU), at least 4096 rows each
+// workgroups of 1024 threads, one chunk of rows each: at least 4096 rows per chunk, at most 768 (256 for huge inputs) chunks
 inline FusedGeom fused_geometry(int64_t rows, uint32_t n_images, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h)
 {
     FusedGeom g{};
@@ -34,8 +37,20 @@ inline FusedGeom fused_geometry(int64_t rows, uint32_t n_images, uint32_t tile_s
     g.rows_per_image = rows / g.n_images;
     // measured at c3 (1M rows, 8160 tiles; count / column scan / emit+scatter in us): 256 threads x 512 rows: 56 / 153 /
     // 105; 512 x 1024: 46 / 75 / 91; 1024 x 2048: 48 / 29 / 95; 1024 x 4096: 50 / 16 / 102 -> the table (chunks x tiles)
-    // must stay small, the walk does not care
-    constexpr int64_t kMaxChunks = 256, kMinRows = 4096;
+    // must stay small, the walk does not care: at least 4096 rows per chunk
+    // Chunks are what the 256 CUs schedule dynamically: a real scene's rows come spatially clustered (garden x25: chunks over
+    // crowded regions run several times longer), so up to 768 chunks of >= 4096 rows while the [chunk][tile] table stays
+    // small; very large inputs (c4: 16 M random rows) keep one chunk per CU - more only lengthens the table.
+    // measured (count + emit+sort, ms): garden x25 256 chunks 0.423, 384 0.344, 768 0.310, 2048 0.310; c4 256 2.44, 768 2.60
+    // A/B: GSX_FUSED_WG = "<threads>x<chunks>" (e.g. 512x512); 512-thread workgroups (two per CU) gained nothing
+    int64_t kMaxChunks = rows <= 6000000 ? 768 : 256;
+    g.threads = 1024;
+    static const char *const wg_env = getenv("GSX_FUSED_WG");
+    if (wg_env) {
+        unsigned t = 0, c = 0;
+        if (sscanf(wg_env, "%ux%u", &t, &c) == 2 && (t == 512 || t == 1024) && c >= 64 && c <= 2048) { g.threads = t; kMaxChunks = c; }
+    }
+    constexpr int64_t kMinRows = 4096;
     const int64_t max_cpi = kMaxChunks / g.n_images > 0 ? kMaxChunks / g.n_images : 1;
     int64_t cpi = (g.rows_per_image + kMinRows - 1) / kMinRows;
     if (cpi < 1) cpi = 1;
