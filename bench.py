@@ -356,6 +356,23 @@ def main():
                           "peak_instr_per_ns_per_simd": rate["valu_peak_instr_per_ns_per_simd"],
                           "peak_source": "profiles/issue_rate.json (tools/issue_rate.hip on MI355X)",
                           "frac": round(per_simd_ns / rate["valu_peak_instr_per_ns_per_simd"], 4)}
+            # The same count priced by instruction class (rates of profiles/issue_rate.json): fma, mul / add and
+            # transcendental are counted by the hardware; everything else - compares, selects, min / max, moves, integer,
+            # DPP - is priced at the mean of the full-rate (v_mov, v_and, v_add_u32) and half-rate (v_cmp, v_cndmask,
+            # v_min, VOP3 integer, DPP) classes.
+            cls = rate.get("by_class_instr_per_ns_per_simd", {})
+            if all(k in sq for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32",
+                                     "SQ_INSTS_VALU_TRANS_F32")) and cls:
+                fma, mul, add, trans = (sq["SQ_INSTS_VALU_FMA_F32"], sq["SQ_INSTS_VALU_MUL_F32"], sq["SQ_INSTS_VALU_ADD_F32"],
+                                        sq["SQ_INSTS_VALU_TRANS_F32"])
+                other = max(sq["SQ_INSTS_VALU"] - fma - mul - add - trans, 0.0)
+                r_fma, r_full = cls["v_fma_f32 (VOP3)"], cls["VOP2 fp32 / int add, mul"]
+                r_trans, r_half = cls["v_exp_f32 / v_rcp_f32 / v_permlane32_swap"], cls["v_cmp_e64 -> sgpr pair"]
+                r_other = 2.0 / (1.0 / r_full + 1.0 / r_half)
+                ns = (fma / r_fma + (mul + add) / r_full + trans / r_trans + other / r_other) / N_SIMDS
+                valu_issue["by_class"] = {"fma": int(fma), "mul_add": int(mul + add), "transcendental": int(trans),
+                                          "other": int(other), "issue_ns_per_simd": round(ns, 1),
+                                          "frac_of_launch": round(ns / (dom_ms * 1e6), 4)}
     except Exception:
         valu_issue = None
     # vector-ALU view of the same two kernels: counted (pixel, Gaussian) pairs x (14 + 2 D) flop / time

@@ -62,7 +62,9 @@ def main():
                              "bytes_if_fetch_x2": int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)}
                 # instruction counters of the same launches (bench.py: roofline.valu_issue_frac)
                 sq = {c: cs[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES",
-                                         "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_LDS_BANK_CONFLICT") if c in cs}
+                                         "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU_FMA_F32",
+                                         "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32",
+                                         "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR") if c in cs}
                 if sq:
                     hbm[name]["sq"] = sq
         import subprocess
