@@ -71,6 +71,14 @@ __device__ __forceinline__ float dpp_f32(float x)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, BANK_MASK, false));
 }
 
+// x of the lane eight places further on in the same 16-lane row (row_ror:8). Every lane has a source, so `old` never shows:
+// passing x itself (instead of dpp_f32's 0) with bound_ctrl set lets the compiler fold the move into v_add_f32_dpp without
+// first materialising a zero (one instruction instead of three per value).
+__device__ __forceinline__ float dpp_ror8(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x128, 0xF, 0xF, true));
+}
+
 // Sum over each row of 16 lanes; every lane of the row ends up with the row sum.
 __device__ __forceinline__ float row16_sum(float x)
 {

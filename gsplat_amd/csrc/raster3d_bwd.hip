@@ -478,7 +478,7 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
         // fold the eight rows: lanes c and c ^ 8 share a 16-lane row, then the four rows; afterwards lane (row r, column c)
         // holds sum number 4 j + r of slot c % 8
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] += dpp_f32<0x128>(acc[k]); // row_ror:8
+        for (int k = 0; k < K; ++k) acc[k] += dpp_ror8(acc[k]); // row_ror:8
         const int frow = (int)(lane >> 4), fcol = (int)(lane & 15u);
         const int t_g  = slot_t; // every lane with lane % 8 == s tracks slot s (the writer lanes have lane % 16 < 8)
         const bool wr_lane = fcol < SLOTS && fcol < n_slots;
@@ -559,9 +559,8 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
                 col[0] = p2.x; col[1] = p2.y; col[2] = p1.w; col[3] = p2.z;
             }
             // invalid lanes: alpha = 0 -> fac = 0, w = 0, T and buffer unchanged (1 / (1 - 0) == 1 exactly)
-            const float ov    = valid ? ov_r : 0.0f;
             const float alpha = valid ? al_r : 0.0f;
-            const float ra    = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
+            const float ra    = __builtin_amdgcn_rcpf(1.0f - alpha); // alpha <= kMaxAlpha = 0.999: no guard needed
             T                *= ra;
             const float fac   = alpha * T;
             // v_alpha = sum_k (c_k T - buffer_k / (1 - alpha)) v_c,k + T_final / (1 - alpha) (v_a - bg . v_c)  (Device.cuh:105-173)
@@ -572,7 +571,8 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
             for (int k = 1; k < CH; ++k) cv = fmaf(col[k], v_c[k], cv);
             const float v_alpha = fmaf(ra, tail_term - behind, cv * T);
             behind              = fmaf(fac, cv, behind);
-            const float v_sigma = (ov <= kMaxAlpha) ? -ov * v_alpha : 0.0f; // alpha-clamp branch: no geometry gradient
+            // alpha-clamp branch (opac exp(-sigma) > 0.999): no geometry gradient; invalid lanes: none either
+            const float v_sigma = (valid && ov_r <= kMaxAlpha) ? -ov_r * v_alpha : 0.0f;
             *reinterpret_cast<float2 *>(w_ptr) = make_float2(fac, v_sigma); // ds_write_b64 into slot `slot`
             w_ptr += WROW;
             slot_t = ((int)(lane & 7u) == slot) ? t : slot_t;
