@@ -429,7 +429,7 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
     int slot   = 0; // wave-uniform: slots filled since the last turn
     float *const w_ptr0 = s_ww + w_off; // this lane's (fac, w) cell in slot 0 ...
     float *w_ptr        = w_ptr0;       // ... and in the next free slot (a vector add per Gaussian instead of scalar address math)
-    int slot_t = 0; // lanes with lane % 8 == s: staged index of the Gaussian in slot s
+    int slot_t = 0; // LANE s (s < 8) holds the staged index of the Gaussian in slot s (v_writelane); the turn broadcasts it
 
     // one turn: sums of the filled slots -> s_acc (all lanes of the wave take part)
     auto turn = [&](int n_slots) {
@@ -480,7 +480,9 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] += dpp_ror8(acc[k]); // row_ror:8
         const int frow = (int)(lane >> 4), fcol = (int)(lane & 15u);
-        const int t_g  = slot_t; // every lane with lane % 8 == s tracks slot s (the writer lanes have lane % 16 < 8)
+        // the writer lanes (lane % 16 < 8, in all four rows) fetch the staged index of THEIR slot from lane (lane % 8): one
+        // ds_bpermute per turn instead of a move + compare + select per Gaussian in the pixel loop
+        const int t_g = __builtin_amdgcn_ds_bpermute((int)((lane & 7u) << 2), slot_t);
         const bool wr_lane = fcol < SLOTS && fcol < n_slots;
 #pragma unroll
         for (int j = 0; j < Cfg::KG; ++j) {
@@ -541,6 +543,11 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
             asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in ONE scalar instruction (the compiler emits three)
             const v4f p0 = s_st[t].p0;
             const v4f p1 = s_st[t].p1;
+            // the colours ride along with the two reads above (one address register, their latency under the exponent's
+            // chain) although a pair in which no lane passes does not need them
+            const v2f c01 = *reinterpret_cast<const v2f *>(&s_st[t].p2);
+            [[maybe_unused]] const v4f p2 = CH > 3 ? s_st[t].p2 : v4f{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" ::"v"(c01.x), "v"(c01.y)); // keeps the read HERE (the compiler would sink it below the branch)
             const float e     = staged_e(p0, p1.x, p1.y, p1.z, pu, pv);
             const float ov_r  = __builtin_amdgcn_exp2f(e); // opac * exp(-sigma), unclamped
             const float al_r  = fminf(kMaxAlpha, ov_r);
@@ -550,12 +557,10 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
 
             float col[CH];
             if constexpr (CH <= 3) {
-                const v2f c01 = *reinterpret_cast<const v2f *>(&s_st[t].p2);
                 col[0] = c01.x;
                 if constexpr (CH > 1) col[1] = c01.y;
                 if constexpr (CH > 2) col[2] = p1.w;
             } else {
-                const v4f p2 = s_st[t].p2;
                 col[0] = p2.x; col[1] = p2.y; col[2] = p1.w; col[3] = p2.z;
             }
             // invalid lanes: alpha = 0 -> fac = 0, w = 0, T and buffer unchanged (1 / (1 - 0) == 1 exactly)
@@ -575,7 +580,14 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
             const float v_sigma = (valid && ov_r <= kMaxAlpha) ? -ov_r * v_alpha : 0.0f;
             *reinterpret_cast<float2 *>(w_ptr) = make_float2(fac, v_sigma); // ds_write_b64 into slot `slot`
             w_ptr += WROW;
-            slot_t = ((int)(lane & 7u) == slot) ? t : slot_t;
+            // t and slot are wave-uniform; gfx9 allows one SGPR per VALU instruction, so the lane select travels in M0
+            // (saved and restored: the compiler treats M0 as reserved)
+            {
+                uint32_t m0_saved;
+                asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                    : "+v"(slot_t), "=&s"(m0_saved)
+                    : "s"(t), "s"(slot));
+            }
             if (++slot == SLOTS) {
                 turn(SLOTS);
                 slot  = 0;
