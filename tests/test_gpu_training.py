@@ -275,3 +275,36 @@ def test_mcmc_relocation_keeps_the_dead_rows_own_moments(G):
             assert bool((zeroed | same).all()), f"{k}.{m}: live rows are either sampled sources (zeroed) or untouched"
             assert bool(zeroed.any()), "the sampled sources restart from zero moments"
     assert not torch.equal(params["means"][:10].detach(), old_means[:10])  # and the dead rows carry live parameters now
+
+
+def test_default_strategy_statistics_dense_equals_gathered(G):
+    """The densification statistics of dense rows (masked reductions over the camera axis, nothing leaves the device) against
+    the gather-then-index_add form the reference uses (gsplat/strategy/default.py:210-262) - written out here with torch."""
+    from _util import make_scene
+
+    sc, W, H = make_scene(N=5000, C=3, width=160, height=96, seed=4)
+    a = {k: v.to(DEV) for k, v in sc.items()}
+    params = {k: a[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    strategy = G.DefaultStrategy(refine_scale2d_stop_iter=10**9, verbose=False)
+    state = strategy.initialize_state(scene_scale=1.0)
+    for _ in range(2):  # two accumulations: the running sums really accumulate
+        rc, ra, info = G.rasterization(params["means"], params["quats"], params["scales"], params["opacities"], params["colors"],
+                                       a["viewmats"], a["Ks"], W, H, packed=False)
+        strategy.step_pre_backward(params, {}, state, 0, info)
+        rc.square().sum().backward()
+        strategy._accumulate(params, state, info, packed=False)
+        grad = info["means2d"].grad.clone()
+        for p in params.values():
+            p.grad = None
+    # the reference's form, for the last gradient twice (same render both times)
+    half = grad.new_tensor([0.5 * W, 0.5 * H]) * 3
+    sel = (info["radii"] > 0).all(dim=-1)
+    gs_ids = torch.where(sel)[1]
+    norms = (grad[sel] * half).norm(dim=-1)
+    want_g = torch.zeros(5000, device=DEV).index_add_(0, gs_ids, norms) * 2
+    want_c = torch.zeros(5000, device=DEV).index_add_(0, gs_ids, torch.ones_like(norms)) * 2
+    want_r = torch.zeros(5000, device=DEV).scatter_reduce_(0, gs_ids, info["radii"][sel].amax(-1).float() / float(max(W, H)),
+                                                           reduce="amax", include_self=True)
+    torch.testing.assert_close(state["grad2d"], want_g, rtol=1e-5, atol=1e-7)
+    assert torch.equal(state["count"], want_c)
+    torch.testing.assert_close(state["radii"], want_r, rtol=0, atol=0)

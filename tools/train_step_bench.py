@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_every=None, grow_grad2d=2e-7,
-        release_cached_memory=False):
+        release_cached_memory=False, refine=True):
     import bench
     import gsplat_amd
 
@@ -50,7 +50,9 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_ever
     # screen-space gradients are far below the trainer's default 2e-4).
     R = max(steps // 2 if refine_every is None else refine_every, 1)
     refine_at = 2 * R
-    strategy = gsplat_amd.DefaultStrategy(refine_start_iter=R - 1, refine_every=R, reset_every=10**9,
+    if not refine:  # profiling runs: plain steps only (three warm-up steps, no refinement anywhere)
+        R, refine_at = 2, 10**9
+    strategy = gsplat_amd.DefaultStrategy(refine_start_iter=(R - 1) if refine else 10**9, refine_every=R, reset_every=10**9,
                                           refine_stop_iter=refine_at + 1, grow_grad2d=grow_grad2d, verbose=False,
                                           release_cached_memory=release_cached_memory)
     strategy.check_sanity(params, opts)
