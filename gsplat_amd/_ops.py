@@ -435,7 +435,8 @@ def _isect_fused_emit(st, tile_mask, n_isects):
     if st.binned:
         ws = torch.empty(_cabi.isect_binned_emit_workspace_bytes(n_isects), device=dev, dtype=torch.uint8)
         call("gsx_isect_binned_emit_sort", st.rows, st.I, tile_size, tile_width, tile_height, ptr(st.count_ws),
-             st.count_ws.numel(), ptr(st.offsets), n_isects, ptr(isect_ids), ptr(flatten_ids), ptr(ws), ws.numel())
+             st.count_ws.numel(), ptr(st.offsets), n_isects, int(isect_max_tile_len(st)), ptr(isect_ids), ptr(flatten_ids),
+             ptr(ws), ws.numel())
     else:
         ws = torch.empty(_cabi.isect_fused_emit_workspace_bytes(n_isects, st.I, tile_width, tile_height), device=dev,
                          dtype=torch.uint8)

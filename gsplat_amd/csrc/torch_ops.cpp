@@ -511,7 +511,7 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
                 if (M == 0) return {tiles_per_gauss, ids, flat};
                 Tensor ws = bytes(gsx_isect_binned_emit_workspace_bytes(M), means2d);
                 { Timed timed_("gsx_isect_binned_emit_sort", L.stream); check(gsx_isect_binned_emit_sort(rows, uI, uts, utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(),
-                                                 cp<int32_t>(offsets), M, mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
+                                                 cp<int32_t>(offsets), M, /*longest_list=*/0, mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
                       "gsx_isect_binned_emit_sort"); }
                 return {tiles_per_gauss, ids, flat};
             }
@@ -792,7 +792,7 @@ isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &dep
     if (binned) {
         Tensor ws = bytes(gsx_isect_binned_emit_workspace_bytes(M), means2d);
         { Timed timed_("gsx_isect_binned_emit_sort", L.stream); check(gsx_isect_binned_emit_sort(rows, uI, uts, utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(),
-                                         cp<int32_t>(offsets), M, mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
+                                         cp<int32_t>(offsets), M, (int64_t)slot[1], mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
               "gsx_isect_binned_emit_sort"); }
         return {ids, flat};
     }

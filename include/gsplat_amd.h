@@ -376,7 +376,8 @@ int gsx_isect_binned_count(const float *means2d, const int32_t *radii, const flo
                            void *count_workspace, int64_t count_workspace_bytes, void *stream);
 int gsx_isect_binned_emit_sort(int64_t rows, uint32_t n_images, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                                void *count_workspace, int64_t count_workspace_bytes, const int32_t *isect_offsets,
-                               int64_t n_isects, int64_t *isect_ids_sorted, int32_t *flatten_ids_sorted, void *workspace,
+                               int64_t n_isects, int64_t longest_list /* from the count half; 0 = unknown */,
+                               int64_t *isect_ids_sorted, int32_t *flatten_ids_sorted, void *workspace,
                                int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
