@@ -554,6 +554,12 @@ def main():
 
             torch.cuda.empty_cache()
             result["train_step"] = train_step_bench.run(steps=100, device=device)
+            torch.cuda.empty_cache()
+            # the same step with the coefficients handed over as they are stored, (sh0, shN): the split SH kernels read and
+            # write them in place - no torch.cat each way (an extension of rasterization()'s `colors` argument)
+            split = train_step_bench.run(steps=100, device=device, split_sh=True)
+            result["train_step"]["split_sh"] = {k: split[k] for k in ("ms_per_step", "steps_per_s", "refinement_step_ms",
+                                                                        "gaussians_after", "final_loss")}
         except Exception as e:
             result["train_step"] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()

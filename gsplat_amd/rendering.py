@@ -54,7 +54,7 @@ def rasterization(
     quats: Optional[Tensor],  # [..., N, 4]
     scales: Optional[Tensor],  # [..., N, 3]
     opacities: Tensor,  # [..., N]
-    colors: Optional[Tensor],  # [..., (C,) N, D] or [N, K, D]
+    colors: Optional[Tensor],  # [..., (C,) N, D] or [N, K, D]; or (sh0 [N, 1, D], shN [N, K - 1, D]) with sh_degree
     viewmats: Tensor,  # [..., C, 4, 4]
     Ks: Tensor,  # [..., C, 3, 3]
     width: int,
@@ -431,7 +431,17 @@ def _validate_rasterization_inputs(means, covars, quats, scales, opacities, colo
     _check(external_distortion_coeffs is None or with_ut, "External distortion requires with_ut=True")
     if has_color:
         _check(colors is not None, "colors must be provided for color render modes")
-        if sh_degree is not None:
+        if isinstance(colors, (tuple, list)):
+            # (sh0 [N, 1, D], shN [N, K - 1, D]): the trainer's parameter layout, evaluated by the split SH kernels without
+            # ever forming torch.cat([sh0, shN], 1) (an extension: the reference's rasterization() takes the concatenation)
+            _check(sh_degree is not None and len(colors) == 2, "colors = (sh0, shN) needs sh_degree")
+            _check(not distributed and nb == 0, "colors = (sh0, shN) is not supported with batch dimensions / distributed=True")
+            sh0, shN = colors
+            _check(sh0.dim() == 3 and tuple(sh0.shape[:2]) == (N, 1), "sh0 must have shape [N, 1, D], got ", list(sh0.shape))
+            _check(shN.dim() == 3 and shN.shape[0] == N and shN.shape[-1] == sh0.shape[-1],
+                   "shN must have shape [N, K - 1, D], got ", list(shN.shape))
+            _check((sh_degree + 1) ** 2 - 1 <= shN.shape[-2], "sh_degree requires more color SH coefficients than provided")
+        elif sh_degree is not None:
             _check(colors.dim() == 3 and colors.shape[0] == N, "SH colors must have shape [N, K, D], got ",
                    list(colors.shape))
             _check((sh_degree + 1) ** 2 <= colors.shape[-2], "sh_degree requires more color SH coefficients than provided")
@@ -464,6 +474,23 @@ def _project_features(features, sh_degree, clamp, means, viewmats, radii, batch_
         if packed:
             return features.reshape(B * N, D).index_select(0, gaussian_ids if B == 1 else batch_ids * N + gaussian_ids)
         return torch.broadcast_to(features[..., None, :, :], batch_dims + (C, N, D))
+    if isinstance(features, (tuple, list)):
+        # split coefficients (sh0, shN): band 0 is view-independent, bands >= 1 come from the band kernels reading shN in
+        # place (csrc/sh_band.hip); the sum, the + 0.5 and the clamp are three small element-wise passes over [.., D]
+        from ._wrapper import spherical_harmonics_l0, spherical_harmonics_l1_plus
+
+        sh0, shN = features
+        base = spherical_harmonics_l0(sh0)  # [N, D]
+        base = base.index_select(0, gaussian_ids) if packed else base[None].expand(C, -1, -1)
+        valid = None if packed else (radii > 0).all(dim=-1)
+        vals = base
+        if sh_degree > 0:
+            vals = vals + spherical_harmonics_l1_plus(sh_degree, means, viewmats, shN, masks=valid, batch_ids=batch_ids,
+                                                      camera_ids=camera_ids, gaussian_ids=gaussian_ids)
+        vals = vals + 0.5
+        if clamp:
+            vals = vals.clamp_min(0.0)
+        return vals if valid is None else vals * valid[..., None]
     if clamp:
         # primary colours: SH + the `clamp_min(colors + 0.5, 0)` post-op + the radii > 0 row mask in ONE kernel each
         # way (the reference runs them as separate torch ops: Rendering.cpp:1146-1160, rendering.py:714-718)

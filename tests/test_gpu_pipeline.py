@@ -357,3 +357,24 @@ def test_rasterization_degenerate_scenes(G, packed, case):
         for k in NAMES:
             assert_grad_close(leaves[k].grad.cpu(), ref["grads"][k], rel=5e-3, max_bad_ratio=1e-3, name=f"v_{k}")
         assert float(meta["means2d"].absgrad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_rasterization_takes_split_sh_coefficients(G, packed):
+    """colors = (sh0, shN): same image and gradients as the concatenated [N, K, D] (the split SH kernels against the full one)."""
+    sc, W, H = make_scene(N=3000, C=2, width=128, height=96, seed=12, sh_degree=3)
+    a = {k: v.to(DEV) for k, v in sc.items()}
+    names = ("means", "quats", "scales", "opacities")
+    out = {}
+    for mode in ("cat", "split"):
+        leaves = {k: a[k].clone().requires_grad_(True) for k in names}
+        sh0 = a["colors"][:, :1].clone().requires_grad_(True)
+        shN = a["colors"][:, 1:].clone().requires_grad_(True)
+        colors = torch.cat([sh0, shN], 1) if mode == "cat" else (sh0, shN)
+        rc, ra, _ = G.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], colors,
+                                    a["viewmats"], a["Ks"], W, H, sh_degree=3, packed=packed)
+        (rc.square().sum() + ra.sum()).backward()
+        out[mode] = (rc.detach().cpu(), [leaves[k].grad.cpu() for k in names] + [sh0.grad.cpu(), shN.grad.cpu()])
+    assert_close_ratio(out["split"][0], out["cat"][0], 1e-5, 1e-6, name="render")
+    for nm, x, y in zip(names + ("sh0", "shN"), out["split"][1], out["cat"][1]):
+        assert_grad_close(x, y, rel=1e-4, name=f"v_{nm}")

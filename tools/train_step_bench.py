@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_every=None, grow_grad2d=2e-7,
-        release_cached_memory=False, refine=True):
+        release_cached_memory=False, refine=True, split_sh=False):
     import bench
     import gsplat_amd
 
@@ -59,7 +59,8 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_ever
     state = strategy.initialize_state(scene_scale=1.0)
 
     def step(i):
-        colors = torch.cat([params["sh0"], params["shN"]], 1)
+        # split_sh: (sh0, shN) go to the split SH kernels as they are stored; otherwise the reference trainer's concatenation
+        colors = (params["sh0"], params["shN"]) if split_sh else torch.cat([params["sh0"], params["shN"]], 1)
         rc, ra, info = gsplat_amd.rasterization(params["means"], params["quats"], torch.exp(params["scales"]),
                                                 torch.sigmoid(params["opacities"]), colors, sc["viewmats"], sc["Ks"], W, H,
                                                 sh_degree=3, packed=packed)
@@ -100,7 +101,7 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_ever
         "mpixels_per_s": round(W * H * steps / wall / 1e6, 2),
         "refinement_at_step": refine_at, "refinement_step_ms": refine_ms[0] if refine_ms else None,
         "gaussians_at_start": n_start, "gaussians_before": n0, "gaussians_after": n1,
-        "release_cached_memory": release_cached_memory, "final_loss": round(float(loss.detach()), 6),
+        "release_cached_memory": release_cached_memory, "split_sh": split_sh, "final_loss": round(float(loss.detach()), 6),
         "reference": "examples/simple_trainer.py:795-1170 (rasterization :722, optimizer + strategy steps :1137-1166)",
     }
 
@@ -111,5 +112,6 @@ if __name__ == "__main__":
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--packed", action="store_true")
     ap.add_argument("--release-cached-memory", action="store_true", help="torch.cuda.empty_cache() after a refinement, as the reference does")
+    ap.add_argument("--split-sh", action="store_true", help="pass colors=(sh0, shN) instead of torch.cat([sh0, shN], 1)")
     a = ap.parse_args()
-    print(json.dumps(run(a.steps, a.gaussians, a.packed, release_cached_memory=a.release_cached_memory)))
+    print(json.dumps(run(a.steps, a.gaussians, a.packed, release_cached_memory=a.release_cached_memory, split_sh=a.split_sh)))
