@@ -55,6 +55,9 @@ __device__ __forceinline__ void band_view_dir(const BandArgs &a, uint32_t b, uin
 // global <-> LDS copy of the wave's block of `n_rows` consecutive coefficient rows (row_elems elements of T each), in 16-byte
 // pieces where the block allows it (its start is 16-byte aligned when the first row index is a multiple of 8) and element by
 // element for the ragged end.
+// All the 16-byte pieces a lane moves are issued BEFORE the first one is consumed (up to 16 in flight per lane: a full
+// 64-row block of degree-3 rows is 11.25 pieces per lane); the straightforward load -> store loop exposed one memory round
+// trip per piece (forward 68 us against the 41 us of the full-band kernel for 6 % fewer bytes).
 template <typename T, bool TO_LDS>
 __device__ __forceinline__ void band_block_copy(T *gmem, T *lds, uint32_t n_elems, uint32_t lane, bool wide = true)
 {
@@ -63,9 +66,22 @@ __device__ __forceinline__ void band_block_copy(T *gmem, T *lds, uint32_t n_elem
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     u4 *g4 = reinterpret_cast<u4 *>(gmem);
     u4 *l4 = reinterpret_cast<u4 *>(lds);
-    for (uint32_t i = lane; i < n16; i += 64u) {
-        if (TO_LDS) l4[i] = __builtin_nontemporal_load(g4 + i);
-        else __builtin_nontemporal_store(l4[i], g4 + i);
+    constexpr int kFlight = 16;
+    for (uint32_t base = 0; base < n16; base += 64u * kFlight) {
+        u4 v[kFlight];
+#pragma unroll
+        for (int it = 0; it < kFlight; ++it) {
+            const uint32_t i = base + (uint32_t)it * 64u + lane;
+            if (i < n16) v[it] = TO_LDS ? __builtin_nontemporal_load(g4 + i) : l4[i];
+        }
+#pragma unroll
+        for (int it = 0; it < kFlight; ++it) {
+            const uint32_t i = base + (uint32_t)it * 64u + lane;
+            if (i < n16) {
+                if (TO_LDS) l4[i] = v[it];
+                else __builtin_nontemporal_store(v[it], g4 + i);
+            }
+        }
     }
     for (uint32_t i = n16 * per16 + lane; i < n_elems; i += 64u) {
         if (TO_LDS) lds[i] = gmem[i];
@@ -93,6 +109,7 @@ __global__ void __launch_bounds__(256) sh_band_fwd_kernel(const BandArgs a)
     const uint32_t row_elems = a.KM * 3u;
     const T *co_g = reinterpret_cast<const T *>(a.coeffs);
     const T *my_row = co_g + (size_t)g * row_elems;
+    bool from_tile  = false; // wave-uniform
     if (NBM > 0 && live_mask != 0ull) {
         // the wave's coefficient rows are one block when its Gaussians are g0, g0 + 1, ... (dense rows inside one image)
         const uint32_t g0 = (uint32_t)__shfl((int)g, 0);
@@ -102,7 +119,7 @@ __global__ void __launch_bounds__(256) sh_band_fwd_kernel(const BandArgs a)
             T *tile = reinterpret_cast<T *>(band_smem) + (size_t)wave * 64u * row_elems;
             band_block_copy<T, true>(const_cast<T *>(co_g) + (size_t)g0 * row_elems, tile, n_rows * row_elems, lane);
             wave_lds_sync();
-            my_row = tile + (size_t)lane * row_elems;
+            from_tile = true;
         }
     }
     if (!have) return;
@@ -118,13 +135,18 @@ __global__ void __launch_bounds__(256) sh_band_fwd_kernel(const BandArgs a)
     float Y[NB];
     sh_bases<false>(DEG, d[0] * inv, d[1] * inv, d[2] * inv, Y, nullptr, nullptr, nullptr);
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    // two copies of the loop: one pointer that is either LDS or global makes every read a FLAT load (68 us instead of 45)
+    auto accumulate = [&](const T *src) {
 #pragma unroll
-    for (int k = K0; k < NB; ++k) {
-        const T *q = my_row + 3 * (k - K0);
-        r0 += Y[k] * cf_load<T>(q);
-        r1 += Y[k] * cf_load<T>(q + 1);
-        r2 += Y[k] * cf_load<T>(q + 2);
-    }
+        for (int k = K0; k < NB; ++k) {
+            const T *q = src + 3 * (k - K0);
+            r0 += Y[k] * cf_load<T>(q);
+            r1 += Y[k] * cf_load<T>(q + 1);
+            r2 += Y[k] * cf_load<T>(q + 2);
+        }
+    };
+    if (from_tile) accumulate(reinterpret_cast<const T *>(band_smem) + ((size_t)wave * 64u + lane) * row_elems);
+    else accumulate(my_row);
     out[0] = r0; out[1] = r1; out[2] = r2;
 }
 
