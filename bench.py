@@ -338,6 +338,10 @@ def main():
                 # counters of OTHER kernel sources are not this run's traffic: report none rather than a stale number
                 traffic_src["stale"] = f"measured on kernel sources {meta_pmc.get('kernel_sources')}: re-run tools/gpu_profile.sh"
                 traffic = None
+            elif not (workload == "c3" and not distributed and n_local == 1_000_000 and n_cams == 1 and not packed):
+                # the counters were taken on the default c3 scene: they say nothing about another size / layout
+                traffic_src["not_applicable"] = "counters belong to the default c3 workload (1 M Gaussians, one camera, dense rows)"
+                traffic = None
         except Exception:
             traffic = None
     # Instruction-issue view of the dominant kernel: its VALU wave-instructions per launch (SQ_INSTS_VALU of the same PMC
@@ -365,13 +369,13 @@ def main():
                                      "SQ_INSTS_VALU_TRANS_F32")) and cls:
                 fma, mul, add, trans = (sq["SQ_INSTS_VALU_FMA_F32"], sq["SQ_INSTS_VALU_MUL_F32"], sq["SQ_INSTS_VALU_ADD_F32"],
                                         sq["SQ_INSTS_VALU_TRANS_F32"])
-                other = max(sq["SQ_INSTS_VALU"] - fma - mul - add - trans, 0.0)
+                rest = max(sq["SQ_INSTS_VALU"] - fma - mul - add - trans, 0.0)
                 r_fma, r_full = cls["v_fma_f32 (VOP3)"], cls["VOP2 fp32 / int add, mul"]
                 r_trans, r_half = cls["v_exp_f32 / v_rcp_f32 / v_permlane32_swap"], cls["v_cmp_e64 -> sgpr pair"]
                 r_other = 2.0 / (1.0 / r_full + 1.0 / r_half)
-                ns = (fma / r_fma + (mul + add) / r_full + trans / r_trans + other / r_other) / N_SIMDS
+                ns = (fma / r_fma + (mul + add) / r_full + trans / r_trans + rest / r_other) / N_SIMDS
                 valu_issue["by_class"] = {"fma": int(fma), "mul_add": int(mul + add), "transcendental": int(trans),
-                                          "other": int(other), "issue_ns_per_simd": round(ns, 1),
+                                          "other": int(rest), "issue_ns_per_simd": round(ns, 1),
                                           "frac_of_launch": round(ns / (dom_ms * 1e6), 4)}
     except Exception:
         valu_issue = None

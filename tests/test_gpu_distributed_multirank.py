@@ -139,3 +139,34 @@ def test_bench_plain_form_launches_its_own_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["rehearsal"] is True and r["value"] > 0
+
+
+def test_bench_single_gpu_line_has_the_contract_fields():
+    """The N = 1 line as the driver reads it, on a reduced scene: every contract field present and of the right kind (a
+    sub-record that turns into a number, or a roofline object that loses a key, fails here instead of in the driver's parser)."""
+    import json
+    import subprocess
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--gaussians", "100000", "--no-extra",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["higher_is_better"] is True and r["scaling"] == "weak"
+    assert r["unit"] == "Mpixels/s" and r["value"] > 0 and r["ms_per_step"] > 0 and r["dtype"] == "f32" and r["data"] == "synthetic"
+    assert r["vs_baseline"] is None and isinstance(r["config"], dict) and "workload" in r["config"]
+    roof = r["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "valu_issue_frac"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1
+    assert roof["traffic"] is None or roof["traffic"] > 0
+    if roof["valu_issue"] is not None:
+        assert 0 < roof["valu_issue"]["frac"] < 1 and 0 < roof["valu_issue"]["by_class"]["frac_of_launch"] < 1.5
+    other = r["other_layout"]
+    assert isinstance(other, dict) and other["packed"] is True and other["ms_per_step"] > 0 and other["value"] > 0
+    assert isinstance(r["stage_ms_per_step"], dict) and r["raster_launch_ms"]["fwd"] > 0 and r["raster_launch_ms"]["bwd"] > 0

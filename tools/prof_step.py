@@ -30,3 +30,11 @@ tot = sum(e.self_device_time_total for e in rows)
 print(f"total device time per step {tot / 3 / 1e3:.3f} ms")
 for e in rows[:45]:
     print(f"{e.key[:100]:100s} n={e.count:4d} per_step_us={e.self_device_time_total / 3:9.1f}")
+if "shapes" in sys.argv:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof2:
+        for _ in range(3): step()
+        torch.cuda.synchronize()
+    print("---- torch ops by shape (per step us)")
+    for e in sorted(prof2.key_averages(group_by_input_shape=True), key=lambda e: -e.self_device_time_total):
+        if e.key.startswith("aten::") and e.self_device_time_total / 3 > 3:
+            print(f"{e.key:22s} n={e.count / 3:5.1f} us={e.self_device_time_total / 3:8.1f} {str(e.input_shapes)[:110]}")
