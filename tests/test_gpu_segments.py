@@ -162,3 +162,39 @@ def test_uniformly_long_lists_stay_on_the_per_tile_walk(G):
     ref = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl)
     hinted = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl, _longest_tile_list=longest)
     assert torch.equal(ref[0], hinted[0]) and torch.equal(ref[1], hinted[1])
+
+
+@pytest.mark.parametrize("case", ["absgrad", "five_channels", "tile8"])
+def test_segment_hint_with_backward_fallbacks(G, case):
+    """Configurations whose BACKWARD has no segment form (absgrad, more than four channels, tiles smaller than 16): the forward
+    may run in segments, the backward takes the per-tile kernel on the segmented forward's alphas / last_ids - gradients must
+    still agree with the plain pair of launches."""
+    m2, con, op, off, fl, longest, W, H, tw, th = _lists(G, 40000, 1, 320, 192, 0.01, seed=31)
+    D = 5 if case == "five_channels" else 3
+    ts = 16
+    if case == "tile8":
+        # tile size 8 needs its own lists; the hint is then above the cut of THAT grid or not - either way results must agree
+        ts = 8
+        sc, _, _ = make_scene(N=40000, C=1, width=W, height=H, seed=31)
+        a = {k: v.to(DEV) for k, v in sc.items()}
+        a["means"][:, :2] *= 0.25
+        a["opacities"] = torch.full_like(a["opacities"], 0.01)
+        rad, m2, d, con, _ = G.fully_fused_projection(a["means"], None, a["quats"], a["scales"], a["viewmats"], a["Ks"], W, H,
+                                                      opacities=a["opacities"])
+        op = a["opacities"][None].contiguous()
+        tw, th = math.ceil(W / ts), math.ceil(H / ts)
+        _, ids, fl = G.isect_tiles(m2, rad, d, ts, tw, th, conics=con, opacities=op)
+        off = G.isect_offset_encode(ids, 1, tw, th)
+        counts = torch.diff(torch.cat([off.flatten(), torch.tensor([fl.numel()], device=DEV, dtype=off.dtype)]))
+        longest = int(counts.max())
+    g = torch.Generator().manual_seed(3)
+    colors = torch.rand(m2.shape[:-1] + (D,), generator=g).to(DEV)
+    w_c = torch.randn(1, H, W, D, generator=g).to(DEV)
+    grads = {}
+    for name, hint in (("tile", 0), ("seg", longest)):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (m2, con, colors, op)]
+        rc, ra = G.rasterize_to_pixels(*leaves, W, H, ts, off, fl, absgrad=(case == "absgrad"), _longest_tile_list=hint)
+        ((rc * w_c).sum() + ra.sum()).backward()
+        grads[name] = [t.grad.cpu() for t in leaves] + ([leaves[0].absgrad.cpu()] if case == "absgrad" else [])
+    for nm, x, y in zip(("means2d", "conics", "colors", "opacities", "absgrad"), grads["seg"], grads["tile"]):
+        assert_grad_close(x, y, name=f"{case} v_{nm}")
