@@ -266,7 +266,7 @@ projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const
         const auto t0 = std::chrono::steady_clock::now();
         for (uint64_t spin = 0;; ++spin) {
             const int64_t v = *nnz_slot;
-            if (v >= 0) return v;
+            if (v >= 0 && v == *nnz_slot) return v; // two equal reads: a value caught half-written cannot pass
             if ((spin & 63u) == 63u) std::this_thread::yield();
             if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
         }
@@ -763,7 +763,7 @@ isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &dep
         const auto t0 = std::chrono::steady_clock::now();
         for (uint64_t spin = 0;; ++spin) {
             M = *slot;
-            if (M != -1) break;
+            if (M != -1 && M == *slot) break; // two equal reads: a value caught half-written cannot pass
             if ((spin & 63u) == 63u) std::this_thread::yield(); // the wait is ~10-100 us: do not pin a core at 100 % for it
             if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                 hip_stream.synchronize();
