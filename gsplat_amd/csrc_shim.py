@@ -31,12 +31,8 @@ def build_config() -> dict:
     # 3dgut: UT projection + from-world compositing fwd / bwd for pinhole / distorted pinhole / ortho / fisheye cameras with
     # a global shutter; f-theta, lidar, rolling shutter, hit distances and normals are refused by the ops themselves
     has_3dgut = _ops.COMPOSITE_UNAVAILABLE is None and "rasterize_to_pixels_from_world_3dgs" in _ops.CLASS_SCHEMAS
-    # the keys of the reference's build_config() (ext.cpp:83-97) + the 3DGUT sub-features this backend refuses, spelled out so
-    # that a caller who checks "3dgut" does not have to find out from an exception
     return {"3dgs": True, "2dgs": has_2dgs, "3dgut": has_3dgut, "adam": "adam" in _ops.SCHEMAS,
-            "reloc": "relocation" in _ops.SCHEMAS, "losses": False, "camera_wrappers": False,
-            "3dgut_ftheta": False, "3dgut_lidar": False, "3dgut_rolling_shutter": False, "3dgut_hit_distance": False,
-            "3dgut_normals": False, "3dgut_parallel_batch": False}
+            "reloc": "relocation" in _ops.SCHEMAS, "losses": False, "camera_wrappers": False}
 
 
 def null() -> None:  # ext.cpp:82
