@@ -53,6 +53,7 @@ struct BinGeom {
     uint32_t n_images, cpi, rpc, n_chunks;
     uint32_t tile_size, tile_w, tile_h, n_tiles;
     uint32_t bw, bh, bins_x, bins_y, n_bins, n_bins_total, tile_bits;
+    int32_t skew_cap; // > 0: a bin with more entries than this sends the call back to the Gaussian-major path (bin_plan)
 };
 
 struct BinBuffers {
@@ -196,8 +197,12 @@ __global__ void __launch_bounds__(1024) bin_plan_kernel(const BinArgs a)
     __shared__ int64_t s_part[16];
     const BinGeom &g = a.g;
     const uint32_t nb = g.n_bins_total;
-    const int64_t n_entries = block_scan_i32_1024(a.b.bin_count, a.b.bin_start, nb, s_part, nullptr);
-    const bool overflow     = n_entries > g.cap_entries;
+    __shared__ int32_t s_max;
+    const int64_t n_entries = block_scan_i32_1024(a.b.bin_count, a.b.bin_start, nb, s_part, &s_max);
+    // A crowded bin (a real scene's dense region: garden x25 has bins of > 10 k entries next to a mean of ~2 k) does not fit
+    // the sort kernel's LDS arena and goes through its slow paths - emit + sort 0.80 ms where the Gaussian-major path takes
+    // 0.20. Seen HERE, 30 us into the call, the whole binned path steps aside (same retry contract as a workspace overflow).
+    const bool overflow = n_entries > g.cap_entries || (g.skew_cap > 0 && s_max > g.skew_cap);
     if (threadIdx.x == 0) {
         a.b.bin_start[nb]  = (int32_t)(overflow ? 0 : n_entries);
         a.b.hdr->overflow  = overflow ? 1 : 0;
@@ -680,7 +685,8 @@ extern "C" int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint3
     if (force && force[0] == 'b') return 1;
     // measured (MI355X, profiles/r07_ab.md): 1 M rows x 8160 tiles (c3) 0.214 vs 0.249 ms; 4 M rows per image (c4:
     // ~1800 entries per tile, one wave sorting 2048 words) 4.3 vs 2.5 ms -> dense images and small calls stay Gaussian-major
-    return rows >= 65536 && g.rows_per_image <= 256ll * (int64_t)g.n_tiles;
+    // (and the binned path's eight launches do not pay below ~0.5 M rows: garden x1, 112 k rows: 0.29 vs 0.17 ms)
+    return rows >= 524288 && g.rows_per_image <= 256ll * (int64_t)g.n_tiles;
 }
 
 extern "C" int64_t gsx_isect_binned_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
@@ -706,6 +712,13 @@ static int binned_setup(const char *fn, BinArgs &a, int64_t rows, uint32_t n_ima
     GSX_REQUIRE(bin_geometry(a.g, rows, n_images, tile_size, tile_w, tile_h, bin_cap_entries(rows)),
                 "%s: %u images x %u x %u tiles not supported", fn, n_images, tile_w, tile_h);
     if (const char *e = getenv("GSX_ISECT_DBG")) a.dbg = (uint32_t)atoi(e);
+    // skew abort: 3/4 of the sort arena's words (a c3 bin of 4x2 tiles holds ~1400 entries, its longest ~1700); not when the
+    // path was forced (tests drive the big-list code with it); GSX_ISECT_BIN_SKEW overrides (0 = never)
+    {
+        const char *force = getenv("GSX_ISECT_PATH"), *sk = getenv("GSX_ISECT_BIN_SKEW");
+        a.g.skew_cap = (force && force[0] == 'b') ? 0 : (int32_t)(kArenaPerWave * (int)(a.g.bw * a.g.bh) * 3 / 4);
+        if (sk) a.g.skew_cap = atoi(sk);
+    }
     unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
     if (ws == nullptr || (base - reinterpret_cast<unsigned char *>(ws)) + bin_layout(a.g, base, &a.b) > ws_bytes) {
         set_last_error("%s: count workspace too small", fn);

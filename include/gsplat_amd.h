@@ -400,7 +400,8 @@ int gsx_raster3d_fwd(const float *means2d, const float *conics, const float *col
                      const int32_t *flatten_ids, uint32_t n_images, uint32_t n_isects, uint32_t cdim,
                      uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                      float *render_colors, float *render_alphas, int32_t *last_ids, void *stream);
-/* The list length above which gsx_raster3d_{fwd,bwd}_seg cut a tile's list into slices: max(2 seg_len, 3 x the mean list).
+/* The longest-list length above which a caller should take gsx_raster3d_{fwd,bwd}_seg: max(2 seg_len, 3 x the mean list,
+ * n_isects / 1024 = a workgroup slot's share of the launch); inside them, lists longer than max(2 seg_len, 3 x the mean) are cut.
  * A caller that knows the longest list (the intersection reports it) takes the _seg entries only when it exceeds this. */
 int64_t gsx_raster3d_seg_cut(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, uint32_t seg_len);
 
