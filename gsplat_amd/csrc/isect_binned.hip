@@ -685,8 +685,13 @@ extern "C" int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint3
     if (force && force[0] == 'b') return 1;
     // measured (MI355X, profiles/r07_ab.md): 1 M rows x 8160 tiles (c3) 0.214 vs 0.249 ms; 4 M rows per image (c4:
     // ~1800 entries per tile, one wave sorting 2048 words) 4.3 vs 2.5 ms -> dense images and small calls stay Gaussian-major
-    // (and the binned path's eight launches do not pay below ~0.5 M rows: garden x1, 112 k rows: 0.29 vs 0.17 ms)
-    return rows >= 524288 && g.rows_per_image <= 256ll * (int64_t)g.n_tiles;
+    // What decides is the typical tile list: one wave sorts a list padded to a power of two, and the eight lists of a bin share
+    // a 4096-word arena - lists of up to 512 entries (c3: 122 rows per tile, 466 per list) fit in one go. Uniform scene,
+    // fused vs binned in ms (tools/gpu_isect_sizes.py): 250 k rows 0.141 / 0.103, 600 k 0.189 / 0.156, 1 M 0.245 / 0.209,
+    // 2 M (245 rows per tile, lists of ~930) 0.399 / 0.470; four cameras: 4 x 250 k 0.265 / 0.222, 4 x 1 M 0.757 / 0.584.
+    // Clustered scenes are caught by the skew test in bin_plan; very small calls (garden x1, 112 k clustered rows: 0.17 / 0.29)
+    // stay Gaussian-major - per IMAGE: four cameras over the same 112 k rows (1020 nearly empty bins each) 0.28 / 0.41.
+    return g.rows_per_image >= 196608 && g.rows_per_image <= 144ll * (int64_t)g.n_tiles;
 }
 
 extern "C" int64_t gsx_isect_binned_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
