@@ -336,10 +336,12 @@ def rasterize_to_pixels(
     if masks is not None:
         masks = masks.contiguous()
     _impl.set_long_tile_hint(_longest_tile_list)
-    render_colors, render_alphas, means2d_absgrad, _last_ids = _ops.rasterize_to_pixels_3dgs(
-        means2d.contiguous(), conics.contiguous(), colors.contiguous(), opacities.contiguous(), backgrounds, masks,
-        image_width, image_height, tile_size, isect_offsets.contiguous(), flatten_ids.contiguous(), packed, absgrad)
-    _impl.set_long_tile_hint(0)
+    try:
+        render_colors, render_alphas, means2d_absgrad, _last_ids = _ops.rasterize_to_pixels_3dgs(
+            means2d.contiguous(), conics.contiguous(), colors.contiguous(), opacities.contiguous(), backgrounds, masks,
+            image_width, image_height, tile_size, isect_offsets.contiguous(), flatten_ids.contiguous(), packed, absgrad)
+    finally:
+        _impl.set_long_tile_hint(0)  # also when the op raises: the hint belongs to THIS call only
     if absgrad:
         means2d.absgrad = means2d_absgrad
     return render_colors, render_alphas
