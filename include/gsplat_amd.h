@@ -355,14 +355,16 @@ int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *radii, const 
 /* ---------------------------------------------------------------------------------------------
  * Binned isect_tiles(sort=True) + isect_offset_encode (csrc/isect_binned.hip): the same outputs as the fused pair above,
  * bit for bit (= gsplat::intersect_tile with sort + gsplat::intersect_offset: ext.cpp:1022-1027; Intersect.cpp:170-329;
- * IntersectTile.cu:214-464, 925-988, 1078-1121), built tile-owner-major: the screen is cut into bins of 4 x 4 tiles, every
- * row is entered once per bin its tile rectangle overlaps, the exact walk runs clipped to the bin and yields a 16-bit tile
- * mask per entry, and ONE workgroup per bin (or run of a bin's tiles) gathers its entries, sorts them once by (depth, row)
- * in LDS, splits the sorted run into the tile lists and writes keys and row ids contiguously. No scattered stores, no
- * intermediate pair array, no per-chunk tile table. Dense rows [n_images * N] or packed rows of ONE image.
+ * IntersectTile.cu:214-464, 925-988, 1078-1121), built tile-owner-major: the screen is cut into bins of 4 x 2 tiles, every
+ * row is entered once per bin its tile rectangle overlaps ((depth, row) + a tile mask from the exact walk clipped to the
+ * bin), and ONE workgroup per bin deals its entries into per-tile runs in LDS, one wave sorts each run by (depth, row) and
+ * writes keys and row ids once, contiguously. No per-intersection scattered stores, no per-chunk tile table. Dense rows
+ * [n_images * N] or packed rows of ONE image. gsx_isect_binned_supported() says whether an input is in the range where this
+ * beats the fused pair (mid-sized inputs with tile lists of up to ~512 entries: DESIGN.md section 4).
  *   1. gsx_isect_binned_count (needs depths already): tiles_per_gauss int32 [rows] (or NULL), isect_offsets int32
  *      [n_images * tiles], *n_isects (device or pinned host memory). *n_isects == GSX_ISECT_RETRY (-2): the entries did
- *      not fit the workspace (a scene of very large Gaussians) - nothing else was written, run gsx_isect_fused_* instead.
+ *      not fit the workspace (a scene of very large Gaussians) or one bin is too crowded for the sort's LDS arena (a real
+ *      scene's dense region; not when GSX_ISECT_PATH=binned forces the path) - run gsx_isect_fused_* instead.
  *   2. gsx_isect_binned_emit_sort with the SAME count workspace (untouched in between).
  * ------------------------------------------------------------------------------------------- */
 #define GSX_ISECT_RETRY (-2)
