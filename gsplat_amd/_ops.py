@@ -84,9 +84,44 @@ def long_tile_hint_of_call() -> int:
 
 
 def set_long_tile_hint(longest: int) -> None:
+    """Called by the WRAPPER around an op call (and with 0 in its finally block)."""
     _hint.longest = _hint.of_call = int(longest)
     if _set_hint_compiled is not None:
         _set_hint_compiled(int(longest))
+
+
+def _consume_long_tile_hint() -> int:
+    """Called by an op BODY: returns the hint and clears it for nested calls, but leaves long_tile_hint_of_call() alone - the
+    autograd setup_context runs after the body and stores it for the backward."""
+    longest = getattr(_hint, "longest", 0)
+    _hint.longest = 0
+    return longest
+
+# Stage-level callers (isect_tiles -> isect_offset_encode -> rasterize_to_pixels without rasterization() in between) have no
+# orchestrator to carry the hint: the intersection notes the longest list of its result under the address + length of
+# flatten_ids and a compositing call without a hint looks it up (csrc/torch_ops.cpp keeps the notes when the compiled shim is
+# loaded, so that Python and compiled bodies see the same ones).
+_note_compiled = _lookup_compiled = None
+_notes_py: dict = {}
+
+
+def _note_longest(flatten_ids: Tensor, longest: int) -> None:
+    if flatten_ids.numel() == 0:
+        return
+    if _note_compiled is not None:
+        _note_compiled(flatten_ids.data_ptr(), flatten_ids.numel(), int(longest))
+        return
+    if len(_notes_py) >= 16:
+        _notes_py.pop(next(iter(_notes_py)))
+    _notes_py[flatten_ids.data_ptr()] = (flatten_ids.numel(), int(longest))
+
+
+def _lookup_longest(flatten_ids: Tensor) -> int:
+    if _lookup_compiled is not None:
+        return int(_lookup_compiled(flatten_ids.data_ptr(), flatten_ids.numel()))
+    n, longest = _notes_py.get(flatten_ids.data_ptr(), (0, 0))
+    return longest if n == flatten_ids.numel() else 0
+
 
 COMPILED_OPS: frozenset = frozenset()  # ops whose CUDA-key body is C++ (csrc/torch_ops.cpp) rather than a function of this file
 
@@ -98,6 +133,14 @@ def _read_compiled_ops(path: str) -> None:
     global COMPILED_OPS
     import ctypes
 
+    global _note_compiled, _lookup_compiled
+    try:
+        lib = ctypes.CDLL(path)
+        _note_compiled, _lookup_compiled = lib.gsx_torch_note_longest, lib.gsx_torch_lookup_longest
+        _note_compiled.argtypes, _note_compiled.restype = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64], None
+        _lookup_compiled.argtypes, _lookup_compiled.restype = [ctypes.c_void_p, ctypes.c_int64], ctypes.c_int64
+    except (OSError, AttributeError):
+        _note_compiled = _lookup_compiled = None
     if os.environ.get("GSPLAT_AMD_LIB"):
         # An A/B build of the kernel library is in use (tools/mkvariant.sh): the compiled bodies are linked against the
         # DEFAULT libgsplat_amd.so and would silently run its kernels instead - keep every op on the ctypes path.
@@ -569,6 +612,7 @@ def isect_finish(st: "_IsectPending"):
     if st.fused:
         n_isects = _isect_fused_total(st, None)
         isect_ids, flatten_ids = _isect_fused_emit(st, None, n_isects)
+        _note_longest(flatten_ids, isect_max_tile_len(st))
         return tiles_per_gauss, isect_ids, flatten_ids
     n_isects = int(st.host_total[0].item())
     cum = st.cum
@@ -739,6 +783,41 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
     means, viewmats, Ks = means.contiguous(), viewmats.contiguous(), Ks.contiguous()
     covars, quats, scales = _c(covars), _c(quats), _c(scales)
     nnz = gaussian_ids.shape[0]
+    v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
+    v_means2d, m2_stride = _row_view(v_means2d, 2)
+    v_conics, con_stride = _row_view(v_conics, 3)
+    head = (ptr(means), ptr(covars), ptr(None if covars is not None else quats),
+            ptr(None if covars is not None else scales), ptr(viewmats), ptr(Ks), B, C, N, image_width, image_height,
+            eps2d, int(camera_model), nnz, ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()),
+            ptr(gaussian_ids.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
+            ptr_strided(v_means2d), m2_stride, ptr(_c(v_depths)), ptr_strided(v_conics), con_stride,
+            ptr(_c(v_compensations)))
+    if sparse_grad:
+        # COO gradients exactly as the reference builds them (Projection.cpp:1125-1200): the kernel writes one [nnz, .] row per
+        # packed row, indices = gaussian_ids, coalesced iff a single image (every Gaussian appears at most once). No dense
+        # [N, .] tensor is allocated and nothing is read back. rasterization() refuses batch dimensions with sparse_grad
+        # (Rendering.cpp:278); a stage-level caller with batch dimensions gets a two-row index (batch, gaussian).
+        def rows(width):
+            return torch.empty((nnz, width), device=means.device, dtype=means.dtype)
+
+        r_means = rows(3)
+        r_covars = rows(6) if covars is not None else None
+        r_quats = rows(4) if covars is None else None
+        r_scales = rows(3) if covars is None else None
+        call("gsx_project_ewa_packed_bwd_rows", *head, ptr(r_means), ptr(r_covars), ptr(r_quats), ptr(r_scales),
+             ptr(v_viewmats))
+        flat = len(batch_dims) == 0
+        indices = gaussian_ids.unsqueeze(0) if flat else torch.stack([batch_ids, gaussian_ids])
+        coalesced = B * C == 1
+
+        def coo(vals, like):
+            if vals is None:
+                return None
+            size = ((N,) if flat else (B, N)) + (like.shape[-1],)
+            sp = torch.sparse_coo_tensor(indices, vals, size=size, is_coalesced=coalesced)
+            return sp if len(batch_dims) <= 1 else sp.to_dense().reshape(like.shape)
+
+        return coo(r_means, means), coo(r_covars, covars), coo(r_quats, quats), coo(r_scales, scales), v_viewmats
     # several images: walk the packed rows Gaussian-major through a row map (each output row written once, no atomics);
     # a single image: every Gaussian has at most one row and the row-major kernel stores without atomics
     row_map = _packed_row_map(batch_ids, camera_ids, gaussian_ids, B, C, N) if (B * C > 1 and nnz > 0 and N > 0) else None
@@ -749,27 +828,8 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
         v_covars = alloc(covars)
     else:
         v_quats, v_scales = alloc(quats), alloc(scales)
-    v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
-    v_means2d, m2_stride = _row_view(v_means2d, 2)
-    v_conics, con_stride = _row_view(v_conics, 3)
-    call("gsx_project_ewa_packed_bwd", ptr(means), ptr(covars), ptr(None if covars is not None else quats),
-         ptr(None if covars is not None else scales), ptr(viewmats), ptr(Ks), B, C, N, image_width, image_height,
-         eps2d, int(camera_model), nnz, ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()),
-         ptr(gaussian_ids.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
-         ptr_strided(v_means2d), m2_stride, ptr(_c(v_depths)), ptr_strided(v_conics), con_stride,
-         ptr(_c(v_compensations)), ptr(row_map), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales),
+    call("gsx_project_ewa_packed_bwd", *head, ptr(row_map), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales),
          ptr(v_viewmats))
-    if sparse_grad:
-        # COO gradients like the reference (Projection.cpp:1140-1200): rows = gaussian ids touched
-        def to_sparse(dense):
-            if dense is None:
-                return None
-            flat = dense.reshape((B * N,) + dense.shape[len(batch_dims) + 1:])
-            rows = torch.unique(batch_ids * N + gaussian_ids)
-            sp = torch.sparse_coo_tensor(rows[None], flat[rows], size=flat.shape, is_coalesced=True)
-            return sp if len(batch_dims) == 0 else sp.to_dense().reshape(dense.shape)
-
-        v_means, v_covars, v_quats, v_scales = map(to_sparse, (v_means, v_covars, v_quats, v_scales))
     return v_means, v_covars, v_quats, v_scales, v_viewmats
 
 
@@ -798,8 +858,7 @@ def rasterize_to_pixels_3dgs(means2d, conics, colors, opacities, backgrounds, ma
     renders = torch.empty(image_dims + (image_height, image_width, D), device=dev, dtype=dt)
     alphas = torch.empty(image_dims + (image_height, image_width, 1), device=dev, dtype=dt)
     last_ids = torch.empty(image_dims + (image_height, image_width), device=dev, dtype=torch.int32)
-    longest = long_tile_hint()
-    set_long_tile_hint(0)  # consumed
+    longest = _consume_long_tile_hint() or _lookup_longest(flatten_ids)
     if longest > SEG_MIN_LONGEST and longest > _seg_cut(flatten_ids.numel(), I, tw, th):
         ws = torch.empty(_cabi._lib.gsx_raster3d_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN), device=dev,
                          dtype=torch.uint8)
@@ -829,8 +888,7 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     R = opacities.numel()
     geo = 8 if absgrad else 6
     rows = torch.zeros((R, geo + D), device=means2d.device, dtype=means2d.dtype)
-    longest = long_tile_hint()  # set by the autograd formula around this call
-    set_long_tile_hint(0)
+    longest = _consume_long_tile_hint() or _lookup_longest(flatten_ids)  # set by the autograd formula around this call
     if (longest > SEG_MIN_LONGEST and not absgrad and D <= 4 and tile_size == 16
             and longest > _seg_cut(flatten_ids.numel(), I, tw, th)):
         ws = torch.empty(_cabi._lib.gsx_raster3d_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN),
@@ -1127,21 +1185,26 @@ def projection_2dgs_packed_bwd(means, quats, scales, viewmats, Ks, image_width, 
     batch_dims, B, C, N = _proj_dims(means, viewmats)
     means, quats, scales, viewmats, Ks = (t.contiguous() for t in (means, quats, scales, viewmats, Ks))
     nnz = gaussian_ids.shape[0]
-    v_means, v_quats, v_scales = torch.zeros_like(means), torch.zeros_like(quats), torch.zeros_like(scales)
     v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
     (v_means2d, v_rt, v_normals), vstride = _common_row_views(
         (v_means2d, v_ray_transforms.reshape(v_ray_transforms.shape[:-2] + (9,)), v_normals), (2, 9, 3))
-    call("gsx_project_2dgs_packed_bwd", ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), B, C, N, nnz,
-         ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()), ptr(gaussian_ids.contiguous()),
-         ptr(ray_transforms.contiguous()), ptr_strided(v_means2d), ptr(_c(v_depths)), ptr_strided(v_rt),
-         ptr_strided(v_normals), vstride, ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
+    head = (ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), B, C, N, nnz,
+            ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()), ptr(gaussian_ids.contiguous()),
+            ptr(ray_transforms.contiguous()), ptr_strided(v_means2d), ptr(_c(v_depths)), ptr_strided(v_rt),
+            ptr_strided(v_normals), vstride)
     if sparse_grad and len(batch_dims) == 0:
-        rows = torch.unique(gaussian_ids)
+        # COO gradients as the reference builds them (Projection.cpp:1780-1863): [nnz, .] rows from the kernel, indices =
+        # gaussian_ids, coalesced iff a single image; no dense [N, .] tensor, nothing read back
+        r_means, r_quats, r_scales = (torch.empty((nnz, w), device=means.device, dtype=means.dtype) for w in (3, 4, 3))
+        call("gsx_project_2dgs_packed_bwd_rows", *head, ptr(r_means), ptr(r_quats), ptr(r_scales), ptr(v_viewmats))
+        indices = gaussian_ids.unsqueeze(0)
 
-        def to_sparse(dense):
-            return torch.sparse_coo_tensor(rows[None], dense[rows], size=dense.shape, is_coalesced=True)
+        def coo(vals, like):
+            return torch.sparse_coo_tensor(indices, vals, size=like.shape, is_coalesced=(C == 1))
 
-        v_means, v_quats, v_scales = map(to_sparse, (v_means, v_quats, v_scales))
+        return coo(r_means, means), coo(r_quats, quats), coo(r_scales, scales), v_viewmats
+    v_means, v_quats, v_scales = torch.zeros_like(means), torch.zeros_like(quats), torch.zeros_like(scales)
+    call("gsx_project_2dgs_packed_bwd", *head, ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
     return v_means, v_quats, v_scales, v_viewmats
 
 
@@ -1331,7 +1394,8 @@ def intersect_tile_sparse(means2d, radii, depths, image_ids, tile_mask, active_t
         st = _IsectPending()
         st.args = (means2d, radii, depths, None, None, None)
         st.rows, st.I, st.geom = rows, I, (tile_size, tile_width, tile_height)
-        st.tiles_per_gauss = None
+        st.tiles_per_gauss = st.cum = st.event = st.count_ws = st.n_dev = None
+        st.n_per, st.sort, st.fused = 1, True, True  # every slot set: _isect_fused_emit reads st.fused through isect_max_tile_len
         st.offsets = offsets = torch.empty(I * n_tiles, device=dev, dtype=torch.int32)
         st.host_total = torch.zeros(2, dtype=torch.int64, pin_memory=True)
         st.binned = _cabi.isect_binned_supported(rows, I, tile_width, tile_height, packed)

@@ -330,7 +330,9 @@ def rasterize_to_pixels(
     """Front-to-back alpha compositing of the depth-sorted per-tile lists. Returns
     (render_colors [..., H, W, channels], render_alphas [..., H, W, 1]). With ``absgrad`` the
     backward pass also fills ``means2d.absgrad``. ``_longest_tile_list`` (private; rendering.py passes what the
-    intersection reported): above ``_ops.SEG_MIN_LONGEST`` long lists are cut into segments composited in parallel."""
+    intersection reported): above ``_ops.SEG_MIN_LONGEST`` long lists are cut into segments composited in parallel.
+    0 = unknown: the ops look up what the intersection that produced ``flatten_ids`` noted (stage-level callers get the
+    segments too); negative = one workgroup per tile whatever the lists look like."""
     if backgrounds is not None:
         backgrounds = backgrounds.contiguous()
     if masks is not None:

@@ -44,6 +44,13 @@ inline FusedGeom fused_geometry(int64_t rows, uint32_t n_images, uint32_t tile_s
     // measured (count + emit+sort, ms): garden x25 256 chunks 0.423, 384 0.344, 768 0.310, 2048 0.310; c4 256 2.44, 768 2.60
     // A/B: GSX_FUSED_WG = "<threads>x<chunks>" (e.g. 512x512); 512-thread workgroups (two per CU) gained nothing
     int64_t kMaxChunks = rows <= 6000000 ? 768 : 256;
+    // "the table must stay small": 768 chunks were measured at 8160 tiles (25 MB of table). A larger tile grid keeps the table
+    // below that budget instead of growing it threefold (4K image, 32 k tiles, 3 M rows: 95 MB and a 3x longer column scan).
+    {
+        const int64_t n_tiles   = (int64_t)tile_w * tile_h > 0 ? (int64_t)tile_w * tile_h : 1;
+        const int64_t by_budget = 768ll * 8192 / n_tiles; // [chunk][tile] cells of the measured configuration
+        if (kMaxChunks > 256 && by_budget < kMaxChunks) kMaxChunks = by_budget < 256 ? 256 : by_budget;
+    }
     g.threads = 1024;
     static const char *const wg_env = getenv("GSX_FUSED_WG");
     if (wg_env) {

@@ -302,6 +302,7 @@ struct ProjBwdArgs {
     int64_t nnz;
     const int64_t *batch_ids, *camera_ids, *gaussian_ids;
     const int32_t *row_map; // packed rows walked Gaussian-major: [B*C*N] -> packed row or -1
+    int rows_out;           // sparse_grad: the per-Gaussian outputs are [nnz, .] rows (one per packed row), not [B, N, .]
     float *v_means, *v_covars, *v_quats, *v_scales, *v_viewmats;
 };
 
@@ -370,10 +371,11 @@ __device__ __forceinline__ void pair_vjp(const ProjBwdArgs &a, const Cam &cam, c
     }
 }
 
-// write per-Gaussian gradients from (v_p, v_S)
+// write per-Gaussian gradients from (v_p, v_S); `out` = output row (the Gaussian's own row bg, or the packed row when the
+// caller asked for [nnz, .] gradient rows)
 template <bool ATOMIC>
-__device__ __forceinline__ void store_gaussian_grads(const ProjBwdArgs &a, uint32_t b, uint32_t g, const float *v_p,
-                                                     const float *v_S)
+__device__ __forceinline__ void store_gaussian_grads(const ProjBwdArgs &a, uint32_t b, uint32_t g, size_t out,
+                                                     const float *v_p, const float *v_S)
 {
     const size_t bg = (size_t)b * a.N + g;
     auto put = [](float *dst, float v) {
@@ -381,15 +383,15 @@ __device__ __forceinline__ void store_gaussian_grads(const ProjBwdArgs &a, uint3
         else *dst = v;
     };
     if (a.v_means)
-        for (int i = 0; i < 3; ++i) put(a.v_means + bg * 3 + i, v_p[i]);
+        for (int i = 0; i < 3; ++i) put(a.v_means + out * 3 + i, v_p[i]);
     if (a.covars) {
         if (a.v_covars) {
-            put(a.v_covars + bg * 6 + 0, v_S[0]);
-            put(a.v_covars + bg * 6 + 1, v_S[1] + v_S[3]);
-            put(a.v_covars + bg * 6 + 2, v_S[2] + v_S[6]);
-            put(a.v_covars + bg * 6 + 3, v_S[4]);
-            put(a.v_covars + bg * 6 + 4, v_S[5] + v_S[7]);
-            put(a.v_covars + bg * 6 + 5, v_S[8]);
+            put(a.v_covars + out * 6 + 0, v_S[0]);
+            put(a.v_covars + out * 6 + 1, v_S[1] + v_S[3]);
+            put(a.v_covars + out * 6 + 2, v_S[2] + v_S[6]);
+            put(a.v_covars + out * 6 + 3, v_S[4]);
+            put(a.v_covars + out * 6 + 4, v_S[5] + v_S[7]);
+            put(a.v_covars + out * 6 + 5, v_S[8]);
         }
     } else {
         const float *q = a.quats + bg * 4;
@@ -399,9 +401,9 @@ __device__ __forceinline__ void store_gaussian_grads(const ProjBwdArgs &a, uint3
         quat_to_rotmat(qn, Rq);
         quat_scale_to_covar_vjp(qn, inv, Rq, s, v_S, v_q, v_s);
         if (a.v_quats)
-            for (int i = 0; i < 4; ++i) put(a.v_quats + bg * 4 + i, v_q[i]);
+            for (int i = 0; i < 4; ++i) put(a.v_quats + out * 4 + i, v_q[i]);
         if (a.v_scales)
-            for (int i = 0; i < 3; ++i) put(a.v_scales + bg * 3 + i, v_s[i]);
+            for (int i = 0; i < 3; ++i) put(a.v_scales + out * 3 + i, v_s[i]);
     }
 }
 
@@ -486,7 +488,7 @@ project_bwd_kernel(const ProjBwdArgs a)
             }
         }
     }
-    if (live) store_gaussian_grads<false>(a, b, g, v_p, v_S);
+    if (live) store_gaussian_grads<false>(a, b, g, (size_t)b * a.N + g, v_p, v_S);
 }
 
 // UNIQUE: every Gaussian appears in at most one row (a single image, B*C == 1): plain stores into the zero-filled
@@ -510,7 +512,7 @@ __global__ void __launch_bounds__(256) project_packed_bwd_kernel(const ProjBwdAr
         const float p[3] = {pm[0], pm[1], pm[2]};
         const Cam cam = load_cam(a.viewmats + ((size_t)b * a.C + c) * 16, a.Ks + ((size_t)b * a.C + c) * 9);
         pair_vjp(a, cam, p, S, row, v_p, v_S, v_R, v_t, POSE);
-        store_gaussian_grads<!UNIQUE>(a, b, g, v_p, v_S);
+        store_gaussian_grads<!UNIQUE>(a, b, g, a.rows_out ? (size_t)row : (size_t)b * a.N + g, v_p, v_S);
     }
     if (POSE) {
         // rows are sorted by image; a wave spans a small contiguous range of images
@@ -909,6 +911,39 @@ extern "C" int gsx_project_ewa_packed_bwd(const float *means, const float *covar
         else project_packed_bwd_kernel<false, false><<<grid, block, 0, s>>>(a);
     }
     return check_launch("project_ewa_packed_bwd");
+}
+
+// sparse_grad=True (reference Projection.cpp:1125-1200, kernel ProjectionEWA3DGSPacked.cu:385-684): the per-Gaussian
+// gradients are [nnz, .] ROWS, one per packed row, written once each with plain stores (the caller wraps them as COO over
+// gaussian_ids; no dense [N, .] tensor exists anywhere). v_viewmats as in gsx_project_ewa_packed_bwd.
+extern "C" int gsx_project_ewa_packed_bwd_rows(const float *means, const float *covars, const float *quats,
+                                               const float *scales, const float *viewmats, const float *Ks, uint32_t B,
+                                               uint32_t C, uint32_t N, uint32_t width, uint32_t height, float eps2d,
+                                               int camera_model, int64_t nnz, const int64_t *batch_ids,
+                                               const int64_t *camera_ids, const int64_t *gaussian_ids,
+                                               const float *conics, const float *compensations, const float *v_means2d,
+                                               uint32_t v_means2d_stride, const float *v_depths, const float *v_conics,
+                                               uint32_t v_conics_stride, const float *v_compensations,
+                                               float *v_means_rows, float *v_covars_rows, float *v_quats_rows,
+                                               float *v_scales_rows, float *v_viewmats, void *stream)
+{
+    if (nnz <= 0) return GSX_OK;
+    int rc = check_proj_common("gsx_project_ewa_packed_bwd_rows", means, covars, quats, scales, viewmats, Ks, camera_model);
+    if (rc != GSX_OK) return rc;
+    GSX_REQUIRE(batch_ids && camera_ids && gaussian_ids && conics && v_means2d && v_conics,
+                "gsx_project_ewa_packed_bwd_rows: null input");
+    GSX_REQUIRE(v_means2d_stride >= 2 && v_conics_stride >= 3,
+                "gsx_project_ewa_packed_bwd_rows: row strides must be >= 2 / >= 3");
+    ProjBwdArgs a{};
+    fill_bwd(a, means, covars, quats, scales, viewmats, Ks, B, C, N, width, height, eps2d, camera_model, conics,
+             compensations, v_means2d, v_means2d_stride, v_depths, v_conics, v_conics_stride, v_compensations,
+             v_means_rows, v_covars_rows, v_quats_rows, v_scales_rows, v_viewmats);
+    a.nnz = nnz; a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
+    a.rows_out = 1;
+    const dim3 grid((uint32_t)ceil_div(nnz, 256)), block(256);
+    if (v_viewmats) project_packed_bwd_kernel<true, true><<<grid, block, 0, (hipStream_t)stream>>>(a);
+    else project_packed_bwd_kernel<false, true><<<grid, block, 0, (hipStream_t)stream>>>(a);
+    return check_launch("project_ewa_packed_bwd_rows");
 }
 
 extern "C" int gsx_quat_scale_to_covar_fwd(const float *quats, const float *scales, int64_t n, int triu,

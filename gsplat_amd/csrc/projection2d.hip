@@ -161,6 +161,7 @@ struct Proj2BwdArgs {
     uint32_t m2_stride, rt_stride, n_stride; // row strides (floats): 2 / 9 / 3, or the stride of the AoS gradient rows
     int64_t nnz;
     const int64_t *batch_ids, *camera_ids, *gaussian_ids;
+    int rows_out; // packed, sparse_grad: outputs are [nnz, .] rows (one per packed row) instead of [B, N, .]
     float *v_means, *v_quats, *v_scales, *v_viewmats;
 };
 
@@ -342,12 +343,22 @@ __global__ void __launch_bounds__(256) project2_packed_bwd_kernel(const Proj2Bwd
         const Cam cam = load_cam(a.viewmats + ((size_t)b * a.C + c) * 16, a.Ks + ((size_t)b * a.C + c) * 9);
         pair2_vjp(a, cam, p, Rq, s, row, v_p, v_Rq, v_s, v_R, v_t, POSE);
         quat_to_rotmat_vjp(qn, inv, v_Rq, v_q);
+        if (a.rows_out) { // sparse_grad: [nnz, .] rows, each written once
 #pragma unroll
-        for (int i = 0; i < 3; ++i) atomic_add_f32(a.v_means + bg * 3 + i, v_p[i]);
+            for (int i = 0; i < 3; ++i) a.v_means[row * 3 + i] = v_p[i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) atomic_add_f32(a.v_quats + bg * 4 + i, v_q[i]);
-        atomic_add_f32(a.v_scales + bg * 3 + 0, v_s[0]);
-        atomic_add_f32(a.v_scales + bg * 3 + 1, v_s[1]);
+            for (int i = 0; i < 4; ++i) a.v_quats[row * 4 + i] = v_q[i];
+            a.v_scales[row * 3 + 0] = v_s[0];
+            a.v_scales[row * 3 + 1] = v_s[1];
+            a.v_scales[row * 3 + 2] = 0.0f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) atomic_add_f32(a.v_means + bg * 3 + i, v_p[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomic_add_f32(a.v_quats + bg * 4 + i, v_q[i]);
+            atomic_add_f32(a.v_scales + bg * 3 + 0, v_s[0]);
+            atomic_add_f32(a.v_scales + bg * 3 + 1, v_s[1]);
+        }
     }
     if (POSE) {
         // rows are sorted by image: most waves hold a single (b,c); loop over the images present in the wave
@@ -499,4 +510,36 @@ extern "C" int gsx_project_2dgs_packed_bwd(const float *means, const float *quat
     if (v_viewmats) project2_packed_bwd_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
     else project2_packed_bwd_kernel<false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
     return check_launch("project_2dgs_packed_bwd");
+}
+
+// sparse_grad=True (reference Projection.cpp:1780-1863): v_means / v_quats / v_scales are [nnz, .] rows, one per packed row,
+// written once each with plain stores; the caller wraps them as COO over gaussian_ids.
+extern "C" int gsx_project_2dgs_packed_bwd_rows(const float *means, const float *quats, const float *scales,
+                                           const float *viewmats, const float *Ks, uint32_t B, uint32_t C, uint32_t N,
+                                           int64_t nnz, const int64_t *batch_ids, const int64_t *camera_ids,
+                                           const int64_t *gaussian_ids, const float *ray_transforms,
+                                           const float *v_means2d, const float *v_depths, const float *v_ray_transforms,
+                                           const float *v_normals, uint32_t v_row_stride, float *v_means,
+                                           float *v_quats, float *v_scales,
+                                           float *v_viewmats, void *stream)
+{
+    if (nnz == 0) return GSX_OK;
+    int rc = check2("gsx_project_2dgs_packed_bwd_rows", means, quats, scales, viewmats, Ks);
+    if (rc != GSX_OK) return rc;
+    GSX_REQUIRE(batch_ids && camera_ids && gaussian_ids && ray_transforms && v_means2d && v_ray_transforms
+                && v_normals, "gsx_project_2dgs_packed_bwd_rows: null input");
+    GSX_REQUIRE(v_means && v_quats && v_scales, "gsx_project_2dgs_packed_bwd_rows: null output");
+    Proj2BwdArgs a{};
+    a.means = means; a.quats = quats; a.scales = scales; a.viewmats = viewmats; a.Ks = Ks; a.B = B; a.C = C; a.N = N;
+    a.nnz = nnz; a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
+    a.ray_transforms = ray_transforms; a.v_means2d = v_means2d; a.v_depths = v_depths;
+    a.v_ray_transforms = v_ray_transforms; a.v_normals = v_normals;
+    a.m2_stride = v_row_stride ? v_row_stride : 2u; a.rt_stride = v_row_stride ? v_row_stride : 9u;
+    a.n_stride = v_row_stride ? v_row_stride : 3u;
+    a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_viewmats = v_viewmats;
+    a.rows_out = 1;
+    const dim3 grid((uint32_t)ceil_div(nnz, 256));
+    if (v_viewmats) project2_packed_bwd_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
+    else project2_packed_bwd_kernel<false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
+    return check_launch("project_2dgs_packed_bwd_rows");
 }

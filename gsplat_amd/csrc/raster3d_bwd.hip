@@ -565,7 +565,7 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
             }
             // invalid lanes: alpha = 0 -> fac = 0, w = 0, T and buffer unchanged (1 / (1 - 0) == 1 exactly)
             const float alpha = valid ? al_r : 0.0f;
-            const float ra    = __builtin_amdgcn_rcpf(1.0f - alpha); // alpha <= kMaxAlpha = 0.999: no guard needed
+            const float ra    = __builtin_amdgcn_rcpf(1.0f - alpha); // alpha <= kMaxAlpha = 0.99: no guard needed
             T                *= ra;
             const float fac   = alpha * T;
             // v_alpha = sum_k (c_k T - buffer_k / (1 - alpha)) v_c,k + T_final / (1 - alpha) (v_a - bg . v_c)  (Device.cuh:105-173)
@@ -576,7 +576,7 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
             for (int k = 1; k < CH; ++k) cv = fmaf(col[k], v_c[k], cv);
             const float v_alpha = fmaf(ra, tail_term - behind, cv * T);
             behind              = fmaf(fac, cv, behind);
-            // alpha-clamp branch (opac exp(-sigma) > 0.999): no geometry gradient; invalid lanes: none either
+            // alpha-clamp branch (opac exp(-sigma) > 0.99): no geometry gradient; invalid lanes: none either
             const float v_sigma = (valid && ov_r <= kMaxAlpha) ? -ov_r * v_alpha : 0.0f;
             *reinterpret_cast<float2 *>(w_ptr) = make_float2(fac, v_sigma); // ds_write_b64 into slot `slot`
             w_ptr += WROW;

@@ -448,6 +448,32 @@ spherical_harmonics_bwd(int64_t degrees_to_use, const Tensor &means_, const Tens
     return {v_coeffs, v_means, v_viewmats, OptTensor()};
 }
 
+// ---- longest tile list of an intersection result, for the compositing calls that consume it ---------------------------
+// A caller that drives the STAGE ops itself (the reference's isect_tiles -> isect_offset_encode -> rasterize_to_pixels, e.g.
+// its own Python over this shim) has no orchestrator to carry the hint: the intersection notes the longest list of the result
+// it returns under the address + length of `flatten_ids`, and a compositing call without a hint looks its `flatten_ids` up.
+// A stale match (the allocator handed the same block to another intersection of the same length) can only pick the other,
+// equally correct, decomposition: both kernels plan from the tile offsets, the number only gates which one is launched.
+struct LongestNote { const void *ptr; int64_t n, longest; };
+static std::mutex g_notes_mu;
+static LongestNote g_notes[16];
+static unsigned g_notes_next = 0;
+void note_longest(const void *ptr, int64_t n, int64_t longest)
+{
+    if (!ptr || n <= 0) return;
+    std::lock_guard<std::mutex> lock(g_notes_mu);
+    for (auto &e : g_notes)
+        if (e.ptr == ptr) { e.n = n; e.longest = longest; return; }
+    g_notes[g_notes_next++ % 16u] = LongestNote{ptr, n, longest};
+}
+int64_t lookup_longest(const void *ptr, int64_t n)
+{
+    std::lock_guard<std::mutex> lock(g_notes_mu);
+    for (const auto &e : g_notes)
+        if (e.ptr == ptr && e.n == n) return e.longest;
+    return 0;
+}
+
 // ---- tile intersection --------------------------------------------------------------------------------------------------
 Tensor bytes(int64_t n, const Tensor &like) { return at::empty({n < 8 ? 8 : n}, like.options().dtype(at::kByte)); }
 
@@ -491,7 +517,9 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
     if (rows == 0) return none();
     const uint32_t uI = (uint32_t)I, uts = (uint32_t)tile_size, utw = (uint32_t)tile_w, uth = (uint32_t)tile_h;
     // the grand total comes back through pinned host memory (the one host sync of this op: Intersect.cpp:258-259)
-    Tensor host_total = at::empty({1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    Tensor host_total = at::empty({2}, at::TensorOptions().dtype(at::kLong).pinned_memory(true)); // [n_isects, longest tile list]
+    host_total.mutable_data_ptr<int64_t>()[1] = 0;
+    int64_t *const host_longest = host_total.mutable_data_ptr<int64_t>() + 1;
     auto hip_stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means2d.device().index());
     if (sort && !f64 && gsx_isect_fused_supported(uI, utw, uth, packed ? 1 : 0)) {
         Tensor offsets = at::empty({I * tile_w * tile_h}, means2d.options().dtype(at::kInt));
@@ -501,7 +529,7 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
             Tensor count_ws = bytes(gsx_isect_binned_count_workspace_bytes(rows, uI, utw, uth), means2d);
             { Timed timed_("gsx_isect_binned_count", L.stream); check(gsx_isect_binned_count(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI,
                                          uts, utw, uth, mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets),
-                                         host_total.mutable_data_ptr<int64_t>(), nullptr, count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
+                                         host_total.mutable_data_ptr<int64_t>(), host_longest, count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
                   "gsx_isect_binned_count"); }
             hip_stream.synchronize();
             M = *host_total.const_data_ptr<int64_t>();
@@ -511,14 +539,15 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
                 if (M == 0) return {tiles_per_gauss, ids, flat};
                 Tensor ws = bytes(gsx_isect_binned_emit_workspace_bytes(M), means2d);
                 { Timed timed_("gsx_isect_binned_emit_sort", L.stream); check(gsx_isect_binned_emit_sort(rows, uI, uts, utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(),
-                                                 cp<int32_t>(offsets), M, /*longest_list=*/0, mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
+                                                 cp<int32_t>(offsets), M, *host_longest, mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
                       "gsx_isect_binned_emit_sort"); }
+                note_longest(flat.const_data_ptr(), M, *host_longest);
                 return {tiles_per_gauss, ids, flat};
             }
         }
         Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
         { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
-                                    mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(), nullptr,
+                                    mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(), host_longest,
                                     count_ws.mutable_data_ptr(), count_ws.numel(), L.stream),
               "gsx_isect_fused_count"); }
         hip_stream.synchronize();
@@ -531,6 +560,7 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
                                         utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(), cp<int32_t>(offsets), M,
                                         mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
               "gsx_isect_fused_emit_sort"); }
+        note_longest(flat.const_data_ptr(), M, *host_longest);
         return {tiles_per_gauss, ids, flat};
     }
     if (f64) {
@@ -648,8 +678,9 @@ rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Te
     Tensor renders = at::empty(shape({height, width, r.D}), means2d.options());
     Tensor alphas = at::empty(shape({height, width, 1}), means2d.options());
     Tensor last_ids = at::empty(shape({height, width}), means2d.options().dtype(at::kInt));
-    const int64_t longest = g_long_tile_hint;
+    int64_t longest = g_long_tile_hint;
     g_long_tile_hint = 0;
+    if (longest == 0) longest = lookup_longest(flat.const_data_ptr(), flat.numel()); // stage-level caller: no orchestrator hint
     if (kSegLen > 0 && longest > gsx_raster3d_seg_cut(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)kSegLen)) {
         Tensor ws = at::empty({gsx_raster3d_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
                                                               (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
@@ -688,8 +719,9 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
     // ONE zero-filled array-of-structures buffer [R][6 (+2) + D]; the gradients are COLUMN VIEWS of it (gsplat_amd.h)
     const int64_t R = opac.numel(), geo = absgrad ? 8 : 6;
     Tensor rows = at::zeros({R, geo + r.D}, means2d.options());
-    const int64_t longest = g_long_tile_hint; // set by the autograd formula around this call (gsplat_amd/_autograd.py)
+    int64_t longest = g_long_tile_hint; // set by the autograd formula around this call (gsplat_amd/_autograd.py)
     g_long_tile_hint = 0;
+    if (longest == 0) longest = lookup_longest(flat.const_data_ptr(), flat.numel()); // e.g. the reference's own autograd formula
     if (kSegLen > 0 && !absgrad && r.D <= 4 && tile_size == 16
         && longest > gsx_raster3d_seg_cut(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)kSegLen)) {
         Tensor ws = at::empty({gsx_raster3d_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
@@ -729,11 +761,15 @@ isect_fused_begin(const Tensor &means2d, const Tensor &radii, const Tensor &dept
     const uint32_t uI = (uint32_t)I, uts = (uint32_t)tile_size, utw = (uint32_t)tile_w, uth = (uint32_t)tile_h;
     Tensor tiles_per_gauss = at::empty(out_shape, means2d.options().dtype(at::kInt));
     // pinned host words: [0] n_isects (sentinel -1 until the count has run), [1] the longest tile list (written first)
-    Tensor host_total = at::empty({2}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    // [2] which count ran (1 = tile-owner-major): the second half reads the workspace laid out by THIS choice, whatever the
+    // environment switches say by then
+    Tensor host_total = at::empty({3}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
     host_total.mutable_data_ptr<int64_t>()[0] = -1;
     host_total.mutable_data_ptr<int64_t>()[1] = 0;
+    const bool binned_path = gsx_isect_binned_supported(rows, uI, utw, uth, 0) != 0;
+    host_total.mutable_data_ptr<int64_t>()[2] = binned_path ? 1 : 0;
     Tensor offsets = at::empty({I * tile_w * tile_h}, means2d.options().dtype(at::kInt));
-    if (gsx_isect_binned_supported(rows, uI, utw, uth, 0)) { // tile-owner-major path (csrc/isect_binned.hip)
+    if (binned_path) { // tile-owner-major path (csrc/isect_binned.hip)
         Tensor count_ws = bytes(gsx_isect_binned_count_workspace_bytes(rows, uI, utw, uth), means2d);
         { Timed timed_("gsx_isect_binned_count", L.stream); check(gsx_isect_binned_count(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI, uts,
                                      utw, uth, mp<int32_t>(tiles_per_gauss), mp<int32_t>(offsets), host_total.mutable_data_ptr<int64_t>(),
@@ -772,7 +808,7 @@ isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &dep
             }
         }
     }
-    bool binned = gsx_isect_binned_supported(rows, uI, utw, uth, 0) != 0;
+    bool binned = host_total.numel() > 2 ? slot[2] != 0 : gsx_isect_binned_supported(rows, uI, utw, uth, 0) != 0;
     if (binned && M == GSX_ISECT_RETRY) {
         // the binned path's entry workspace was too small for this scene (very large Gaussians): count again Gaussian-major
         binned   = false;
@@ -794,6 +830,7 @@ isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &dep
         { Timed timed_("gsx_isect_binned_emit_sort", L.stream); check(gsx_isect_binned_emit_sort(rows, uI, uts, utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(),
                                          cp<int32_t>(offsets), M, (int64_t)slot[1], mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
               "gsx_isect_binned_emit_sort"); }
+        note_longest(flat.const_data_ptr(), M, (int64_t)slot[1]);
         return {ids, flat};
     }
     Tensor ws = bytes(gsx_isect_fused_emit_workspace_bytes(M, uI, utw, uth), means2d);
@@ -801,6 +838,7 @@ isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &dep
                                     utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(), cp<int32_t>(offsets), M,
                                     mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
           "gsx_isect_fused_emit_sort"); }
+    note_longest(flat.const_data_ptr(), M, (int64_t)slot[1]);
     return {ids, flat};
 }
 
@@ -880,10 +918,15 @@ rasterize_to_pixels_2dgs(const Tensor &means2d_, const Tensor &ray_transforms_, 
 
 } // namespace
 void set_long_tile_hint(int64_t longest) { g_long_tile_hint = longest; }
+void note_longest_c(const void *p, int64_t n, int64_t longest) { note_longest(p, n, longest); }
+int64_t lookup_longest_c(const void *p, int64_t n) { return lookup_longest(p, n); }
 } // namespace gsplat_amd
 
 // gsplat_amd/_ops.py (ctypes): the longest tile list of the intersection that the next compositing call of THIS thread consumes
 extern "C" void gsx_torch_set_long_tile_hint(int64_t longest) { gsplat_amd::set_long_tile_hint(longest); }
+// the Python op bodies (GSPLAT_AMD_COMPILED_OPS=0, A/B kernel libraries) share the compiled bodies' notes
+extern "C" void gsx_torch_note_longest(const void *flatten_ids, int64_t n, int64_t longest) { gsplat_amd::note_longest_c(flatten_ids, n, longest); }
+extern "C" int64_t gsx_torch_lookup_longest(const void *flatten_ids, int64_t n) { return gsplat_amd::lookup_longest_c(flatten_ids, n); }
 
 TORCH_LIBRARY(gsplat_amd, m)
 {

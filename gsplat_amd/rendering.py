@@ -143,8 +143,9 @@ def rasterization(
         )
     if camera_model not in ("pinhole", "ortho", "fisheye"):
         raise ValueError(f"camera_model '{camera_model}' is not supported (pinhole / ortho / fisheye)")
-    if segmented:
-        raise RuntimeError("segmented radix sort is not implemented (the global sort is used; results are identical)")
+    # `segmented` (gsplat/rendering.py:262; IntersectTile.cu:1125-1176) only selects how the reference sorts - per image instead
+    # of one global radix sort. Both give the same (image, tile, depth) order with ties in emission order, which is what the
+    # per-tile sort of this backend produces, so the flag is accepted and changes nothing.
 
     if covars is not None and _covars_triu:
         # gsplat::rasterization_3dgs receives the upper-triangular 6-vectors (gsplat/rendering.py:540-544 converts)
@@ -372,7 +373,8 @@ def _validate_rasterization_inputs(means, covars, quats, scales, opacities, colo
                and external_distortion_coeffs is None, "distributed=True does not support camera distortion")
         _check(lidar_coeffs is None, "distributed=True does not support lidar coefficients")
         if has_color and sh_degree is None:
-            _check(colors is not None and colors.dim() == 2, "distributed=True only supports per-Gaussian colors")
+            _check(colors is not None and not isinstance(colors, (tuple, list)) and colors.dim() == 2,
+                   "distributed=True only supports per-Gaussian colors")
         if extra_signals is not None and extra_signals_sh_degree is None:
             _check(extra_signals.dim() == 2, "distributed=True only supports per-Gaussian extra signals")
     if rasterize_mode != "classic" and (with_ut or with_eval3d):  # gsplat/rendering.py:170-175

@@ -117,12 +117,14 @@ class DefaultStrategy(Strategy):
         # pairs first (`torch.where` + three boolean-mask indexings: each a nonzero with a device-to-host read of its size,
         # 0.15 ms of kernels and three pipeline drains per training step at 1 M Gaussians); nothing here leaves the device.
         seen = (info["radii"] > 0).all(dim=-1).reshape(-1, n)  # [C, N]
-        norms = (grad * half).norm(dim=-1).reshape(-1, n) * seen
-        state["grad2d"] += norms.sum(dim=0)
-        state["count"] += seen.sum(dim=0)
+        # selects, not products: a non-finite gradient in a row that is NOT visible (the reference's `grads[sel]` never reads
+        # such rows) must not turn into NaN * 0 = NaN
+        norms = (grad * half).norm(dim=-1).reshape(-1, n)
+        state["grad2d"] += torch.where(seen, norms, norms.new_zeros(())).sum(dim=0)
+        state["count"] += seen.sum(dim=0).to(state["count"].dtype)
         if self.refine_scale2d_stop_iter > 0:
             rel = info["radii"].amax(dim=-1).reshape(-1, n).to(state["radii"].dtype) / float(max(info["width"], info["height"]))
-            state["radii"] = torch.maximum(state["radii"], (rel * seen).amax(dim=0))
+            state["radii"] = torch.maximum(state["radii"], torch.where(seen, rel, rel.new_zeros(())).amax(dim=0))
 
     # ---- one refinement = one plan -------------------------------------------------------------------------------------
     @torch.no_grad()

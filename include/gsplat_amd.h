@@ -145,6 +145,21 @@ int gsx_project_ewa_packed_bwd(const float *means, const float *covars, const fl
                                                          row written once (no atomics, outputs need no zero-fill) */,
                                float *v_means, float *v_covars, float *v_quats, float *v_scales,
                                float *v_viewmats, void *stream);
+/* sparse_grad=True (reference host fn Projection.cpp:1125-1200: `at::zeros({nnz, .})` + make_sparse_coo_grad; kernel
+ * ProjectionEWA3DGSPacked.cu:385-684 with sparse_grad): the per-Gaussian gradients are [nnz, 3] / [nnz, 6] / [nnz, 4] /
+ * [nnz, 3] ROWS, one per packed row, each written exactly once (no zero-fill needed, no dense [N, .] tensor anywhere). The
+ * caller wraps them as COO over gaussian_ids. v_viewmats [B,C,4,4] (zero-filled by the caller) or NULL. */
+int gsx_project_ewa_packed_bwd_rows(const float *means, const float *covars, const float *quats, const float *scales,
+                                    const float *viewmats, const float *Ks,
+                                    uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                                    float eps2d, int camera_model, int64_t nnz,
+                                    const int64_t *batch_ids, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                                    const float *conics, const float *compensations,
+                                    const float *v_means2d, uint32_t v_means2d_stride, const float *v_depths,
+                                    const float *v_conics, uint32_t v_conics_stride,
+                                    const float *v_compensations,
+                                    float *v_means_rows, float *v_covars_rows, float *v_quats_rows, float *v_scales_rows,
+                                    float *v_viewmats, void *stream);
 /* row_map int32 [B*C*N]: index of the packed row of (batch, camera, gaussian), or -1 when that pair is not stored.
  * Lets the packed backward kernels (projection, SH with D = 3) run one thread per Gaussian over its rows instead of
  * one thread per row with atomics (10 resp. 3*K fp32 atomics per row when a Gaussian is seen by several cameras). */
@@ -524,6 +539,14 @@ int gsx_project_2dgs_packed_bwd(const float *means, const float *quats, const fl
                                 const float *ray_transforms, const float *v_means2d, const float *v_depths,
                                 const float *v_ray_transforms, const float *v_normals, uint32_t v_row_stride,
                                 float *v_means, float *v_quats, float *v_scales, float *v_viewmats, void *stream);
+/* sparse_grad=True (reference Projection.cpp:1780-1863): v_means / v_quats / v_scales are [nnz, 3] / [nnz, 4] / [nnz, 3]
+ * rows, one per packed row, each written once; the caller wraps them as COO over gaussian_ids. */
+int gsx_project_2dgs_packed_bwd_rows(const float *means, const float *quats, const float *scales, const float *viewmats,
+                                     const float *Ks, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
+                                     const int64_t *batch_ids, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                                     const float *ray_transforms, const float *v_means2d, const float *v_depths,
+                                     const float *v_ray_transforms, const float *v_normals, uint32_t v_row_stride,
+                                     float *v_means, float *v_quats, float *v_scales, float *v_viewmats, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * rasterize_to_pixels (2DGS): gsplat::rasterize_to_pixels_2dgs{,_bwd} (ext.cpp:1186-1199; kernels

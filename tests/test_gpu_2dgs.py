@@ -84,14 +84,16 @@ def test_projection_2dgs_dense_fwd_bwd(G, O, pose):
     _proj_compare(G, O, sc, W, H, pose)
 
 
-def test_projection_2dgs_packed_matches_dense(G):
-    sc, W, H = make_scene(N=3000, C=2, width=160, height=120, seed=4)
+@pytest.mark.parametrize("sparse_grad,C", [(False, 2), (True, 2), (True, 1)])
+def test_projection_2dgs_packed_matches_dense(G, sparse_grad, C):
+    sc, W, H = make_scene(N=3000, C=C, width=160, height=120, seed=4)
     dsc = {k: v.to(DEV) for k, v in sc.items()}
     names = ("means", "quats", "scales", "viewmats")
     ld = [dsc[k].clone().requires_grad_(True) for k in names]
     lp = [dsc[k].clone().requires_grad_(True) for k in names]
     rad, m2, d, M, n = G.fully_fused_projection_2dgs(*ld, dsc["Ks"], W, H)
-    bi, ci, gi, indptr, rad_p, m2_p, d_p, M_p, n_p = G.fully_fused_projection_2dgs(*lp, dsc["Ks"], W, H, packed=True)
+    bi, ci, gi, indptr, rad_p, m2_p, d_p, M_p, n_p = G.fully_fused_projection_2dgs(*lp, dsc["Ks"], W, H, packed=True,
+                                                                                   sparse_grad=sparse_grad)
     vis = (rad > 0).all(-1)
     c_ref, g_ref = torch.where(vis)
     assert torch.equal(ci, c_ref) and torch.equal(gi, g_ref) and (bi == 0).all()
@@ -103,7 +105,12 @@ def test_projection_2dgs_packed_matches_dense(G):
     ((m2_p * w[0]).sum() + (d_p * w[1]).sum() + (M_p * w[2]).sum() + (n_p * w[3]).sum()).backward()
     ((m2[vis] * w[0]).sum() + (d[vis] * w[1]).sum() + (M[vis] * w[2]).sum() + (n[vis] * w[3]).sum()).backward()
     for nm, a, b in zip(names, lp, ld):
-        assert_grad_close(cpu(a.grad), cpu(b.grad), rel=1e-4, name="packed v_" + nm)
+        ga = a.grad
+        if sparse_grad and nm != "viewmats":  # reference layout: Projection.cpp:1780-1863
+            assert ga.is_sparse and ga._nnz() == gi.numel() and ga.is_coalesced() == (C == 1), nm
+            assert torch.equal(ga._indices(), gi[None]), nm
+            ga = ga.to_dense()
+        assert_grad_close(cpu(ga), cpu(b.grad), rel=1e-4, name="packed v_" + nm)
 
 
 def _raster2d_case(G, O, N, C, W, H, tile_size, D, seed, bg=False, masks=False, absgrad=False, distloss=True,

@@ -130,9 +130,9 @@ def test_projection_culling_rules(G, O):
     assert (cpu(rad)[big].max(-1).values > 2).all(), "radius_clip must drop splats with both radii <= clip"
 
 
-@pytest.mark.parametrize("sparse_grad", [False])
-def test_projection_packed_matches_dense(G, sparse_grad):
-    sc, W, H = make_scene(N=5000, C=3, width=200, height=150, seed=3)
+@pytest.mark.parametrize("sparse_grad,C", [(False, 3), (True, 3), (True, 1)])
+def test_projection_packed_matches_dense(G, sparse_grad, C):
+    sc, W, H = make_scene(N=5000, C=C, width=200, height=150, seed=3)
     a = {k: v.to(DEV) for k, v in sc.items()}
     leaves_d = [a[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "viewmats")]
     leaves_p = [a[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "viewmats")]
@@ -155,7 +155,48 @@ def test_projection_packed_matches_dense(G, sparse_grad):
     ((m2_p * w2).sum() + (d_p * wd).sum() + (con_p * wc).sum() + (comp_p * wk).sum()).backward()
     ((m2[vis] * w2).sum() + (d[vis] * wd).sum() + (con[vis] * wc).sum() + (comp[vis] * wk).sum()).backward()
     for nm, lp, ld in zip(("means", "quats", "scales", "viewmats"), leaves_p, leaves_d):
-        assert_grad_close(cpu(lp.grad), cpu(ld.grad), rel=1e-4, name=f"packed v_{nm}")
+        g = lp.grad
+        if sparse_grad and nm != "viewmats":
+            # the reference's layout (Projection.cpp:1125-1200): COO over the Gaussian axis, one entry per packed row in
+            # packed-row order, coalesced iff a single image
+            assert g.is_sparse and g.shape == ld.shape and g._nnz() == gi.numel(), nm
+            assert g.is_coalesced() == (C == 1), nm
+            assert torch.equal(g._indices(), gi[None]), nm
+            g = g.to_dense()
+        else:
+            assert not g.is_sparse, nm
+        assert_grad_close(cpu(g), cpu(ld.grad), rel=1e-4, name=f"packed v_{nm}")
+
+
+def test_projection_packed_sparse_grad_allocates_no_dense_rows(G):
+    """sparse_grad exists to keep the backward's memory proportional to the visible rows (the reference's 49 M / 107 M
+    Gaussian profiles are packed + sparse_grad, docs/source/tests/profile.rst:127,143): with 1 % of 2 M Gaussians in view the
+    backward must stay far below one dense [N, 10] gradient set (80 MB)."""
+    N = 2_000_000
+    g = torch.Generator().manual_seed(5)
+    means = torch.randn(N, 3, generator=g) * 0.5
+    means[:, 2] += 5.0
+    means[N // 100:, 2] = -5.0  # behind the camera: culled
+    quats = torch.nn.functional.normalize(torch.randn(N, 4, generator=g), dim=-1)
+    scales = torch.rand(N, 3, generator=g) * 0.02 + 0.005
+    viewmats = torch.eye(4)[None]
+    Ks = torch.tensor([[[300.0, 0, 128], [0, 300.0, 128], [0, 0, 1]]])
+    lv = [t.to(DEV).requires_grad_(True) for t in (means, quats, scales)]
+    out = G.fully_fused_projection(lv[0], None, lv[1], lv[2], viewmats.to(DEV), Ks.to(DEV), 256, 256, packed=True,
+                                   sparse_grad=True)
+    m2_p, d_p, con_p = out[5], out[6], out[7]
+    nnz = m2_p.shape[0]
+    assert 0 < nnz <= N // 100
+    loss = m2_p.sum() + d_p.sum() + con_p.sum()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    loss.backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < 16 * 2 ** 20, f"sparse_grad backward peaked at {peak / 2**20:.1f} MiB above the forward state"
+    for t in lv:
+        assert t.grad.is_sparse and t.grad._nnz() == nnz
 
 
 # K * 3 floats per row a multiple of four: rows move as wave-cooperative tiles (K == bands in use, or with unused bands

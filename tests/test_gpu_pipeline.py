@@ -69,6 +69,28 @@ def test_rasterization_matches_oracle(G, packed, render_mode, sh_degree, rasteri
     assert abs(meta["isect_ids"].numel() - ref["n_isects"]) <= max(4, ref["n_isects"] // 2000)
 
 
+@pytest.mark.parametrize("C", [1, 2])
+def test_rasterization_sparse_grad_layout_and_values(G, C):
+    """The reference's test_rasterization_cpp_classic_sparse_grad_layout (tests/test_basic.py:5761-5790): packed=True,
+    sparse_grad=True gives sparse COO gradients for means / quats / scales and dense ones for opacities / colors - plus
+    what the reference's test leaves out: the VALUES equal the dense-gradient run."""
+    sc, W, H = make_scene(N=4000, C=C, width=160, height=112, seed=19)
+    g = torch.Generator().manual_seed(7)
+    v_rc, v_ra = torch.randn(C, H, W, 3, generator=g), torch.randn(C, H, W, 1, generator=g)
+    _, _, meta_s, sparse = _run(G, sc, W, H, v_rc, v_ra, packed=True, sparse_grad=True)
+    _, _, _, dense = _run(G, sc, W, H, v_rc, v_ra, packed=True, sparse_grad=False)
+    nnz = meta_s["gaussian_ids"].numel()
+    for name in ("means", "quats", "scales"):
+        gs = sparse[name].grad
+        assert gs is not None and gs.is_sparse, f"{name} gradient should use sparse COO layout"
+        assert 0 < gs._nnz() == nnz and gs.is_coalesced() == (C == 1)
+        assert_grad_close(gs.to_dense().cpu(), dense[name].grad.cpu(), rel=1e-5, name=f"sparse v_{name}")
+    for name in ("opacities", "colors"):
+        gs = sparse[name].grad
+        assert gs is not None and not gs.is_sparse and gs.abs().sum() > 0
+        assert_grad_close(gs.cpu(), dense[name].grad.cpu(), rel=1e-5, name=f"sparse-run v_{name}")
+
+
 @pytest.mark.parametrize("packed", [True, False])
 def test_rasterization_pose_gradient(G, packed):
     """viewmats.requires_grad (pose optimisation): the gradient reaches the view matrices through BOTH the projection
@@ -217,6 +239,70 @@ def test_c3_matches_oracle(G):
         for k in NAMES:
             assert_grad_close(leaves[k].grad.cpu(), ref["grads"][k], rel=5e-3, max_bad_ratio=1e-3,
                               name=f"c3 v_{k} packed={packed}")
+
+
+def test_c4_matches_oracle(G):
+    """BASELINE.json configs[3] (c4) at FULL size, the per-rank work of the 8-GPU line: 4 M Gaussians, four 1080p cameras in
+    one batch, SH degree 3 (59 M intersections, tile lists of 1800-2200 entries: the Gaussian-major intersection and the
+    work-list sort that only this size selects). The GPU renders all four cameras in one call; the CPU oracle is run for
+    cameras 0 and 3 (one camera at a time: ~4 x the c3 oracle step each), the cotangents of cameras 1 and 2 are zero so that
+    the leaf gradients are those two cameras' sums, and the images of cameras 1 and 2 must equal their own single-camera
+    renders on the GPU."""
+    import os
+
+    import bench
+    from oracle import oracle as O
+    from oracle.pipeline import rasterization_cpu
+
+    O.set_threads(min(os.cpu_count() or 1, 32))
+    sc, W, H = bench.make_workload(4_000_000, "cpu", n_cameras=4)
+    C, checked = 4, (0, 3)
+    g = torch.Generator().manual_seed(4)
+    v_rc, v_ra = torch.zeros(C, H, W, 3), torch.zeros(C, H, W, 1)
+    for c in checked:
+        v_rc[c], v_ra[c] = torch.randn(H, W, 3, generator=g), torch.randn(H, W, 1, generator=g)
+    rc, ra, meta, leaves = _run(G, sc, W, H, v_rc, v_ra, sh_degree=3, packed=False)
+    M = meta["isect_ids"].numel()
+    assert M > 50_000_000, M
+    ids = meta["isect_ids"]
+    assert bool((ids[1:] >= ids[:-1]).all()), "keys must be sorted"
+    rc, ra = rc.detach().cpu(), ra.detach().cpu()
+    grads = {k: leaves[k].grad.cpu() for k in NAMES}
+    del leaves, meta, ids
+    torch.cuda.empty_cache()
+    ref_grads, n_isects = None, 0
+    for c in checked:
+        ref = rasterization_cpu(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], sc["viewmats"][c:c + 1],
+                                sc["Ks"][c:c + 1], W, H, sh_degree=3, render_mode="RGB", v_render_colors=v_rc[c:c + 1],
+                                v_render_alphas=v_ra[c:c + 1])
+        assert_close_ratio(rc[c:c + 1], ref["render_colors"], 1e-3, 1e-4, max_bad_ratio=1e-3, name=f"c4 colors cam {c}")
+        assert_close_ratio(ra[c:c + 1], ref["render_alphas"], 1e-4, 5e-5, max_bad_ratio=1e-3, name=f"c4 alphas cam {c}")
+        n_isects += ref["n_isects"]
+        ref_grads = ref["grads"] if ref_grads is None else {k: ref_grads[k] + ref["grads"][k] for k in NAMES}
+        del ref
+    for k in NAMES:
+        assert_grad_close(grads[k], ref_grads[k], rel=5e-3, max_bad_ratio=1e-3, name=f"c4 v_{k}")
+    # the two cameras the oracle did not render: the batched call against single-camera calls of the same backend, and the
+    # four cameras' intersection counts against the two the oracle counted (every camera sees about the same scene)
+    assert abs(M - 2 * n_isects) <= 0.02 * M, (M, n_isects)
+    dsc = {k: v.to(DEV) for k, v in sc.items()}
+    for c in (1, 2):
+        one_c, one_a, _ = G.rasterization(dsc["means"], dsc["quats"], dsc["scales"], dsc["opacities"], dsc["colors"],
+                                          dsc["viewmats"][c:c + 1], dsc["Ks"][c:c + 1], W, H, sh_degree=3, packed=False)
+        assert_close_ratio(rc[c:c + 1], one_c.cpu(), 1e-5, 1e-6, max_bad_ratio=1e-5, name=f"c4 batched vs single cam {c}")
+        assert_close_ratio(ra[c:c + 1], one_a.cpu(), 1e-5, 1e-6, max_bad_ratio=1e-5, name=f"c4 batched vs single alpha {c}")
+
+
+def test_rasterization_segmented_flag_is_accepted(G):
+    """`segmented=True` (gsplat/rendering.py:262) selects a per-image sort in the reference; order and results are the same, so
+    the flag is accepted and the outputs are bit-identical."""
+    sc, W, H = make_scene(N=3000, C=2, width=160, height=112, seed=6)
+    d = {k: v.to(DEV) for k, v in sc.items()}
+    outs = [G.rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"], d["Ks"], W, H,
+                            segmented=flag) for flag in (False, True)]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2]["isect_ids"], outs[1][2]["isect_ids"])
+    assert torch.equal(outs[0][2]["flatten_ids"], outs[1][2]["flatten_ids"])
 
 
 def test_c2_garden_scene_1080p_matches_oracle(G):

@@ -56,7 +56,7 @@ def test_segmented_forward_matches_per_tile_walk(G, kind, D):
     masks = torch.ones(2, th, tw, dtype=torch.bool, device=DEV)
     masks[0, th // 2, tw // 2] = False  # a masked tile in the crowded centre
     for kw in (dict(), dict(backgrounds=bg), dict(backgrounds=bg, masks=masks)):
-        ref_c, ref_a = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl, **kw)
+        ref_c, ref_a = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl, _longest_tile_list=-1, **kw)  # per tile
         seg_c, seg_a = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl, _longest_tile_list=longest, **kw)
         # the two differ only in the association order of the transmittance products (and, on saturating tiles, not at all)
         assert_close_ratio(seg_c.cpu(), ref_c.cpu(), 2e-5, 2e-6, max_bad_ratio=1e-5, name=f"{kind} colours {sorted(kw)}")
@@ -73,7 +73,7 @@ def test_segmented_forward_last_ids_and_oracle(G):
     from gsplat_amd import _ops
 
     outs = {}
-    for name, hint in (("tile", 0), ("seg", longest)):
+    for name, hint in (("tile", -1), ("seg", longest)):  # -1: per tile, whatever the intersection noted
         _ops.set_long_tile_hint(hint)
         outs[name] = torch.ops.gsplat.rasterize_to_pixels_3dgs(m2, con, colors, op, None, None, W, H, 16, off, fl, False, False)
         _ops.set_long_tile_hint(0)
@@ -99,7 +99,7 @@ def test_segmented_backward_matches_per_tile_walk(G, kind, D):
     w_a = torch.randn(2, H, W, 1, generator=g).to(DEV)
     for kw in (dict(), dict(backgrounds=bg, masks=masks)):
         grads = {}
-        for name, hint in (("tile", 0), ("seg", longest)):
+        for name, hint in (("tile", -1), ("seg", longest)):  # -1: per tile, whatever the intersection noted
             leaves = [t.detach().clone().requires_grad_(True) for t in (m2, con, colors, op)]
             extra = dict(kw)
             if "backgrounds" in extra:
@@ -127,7 +127,7 @@ def test_segmented_backward_through_rasterization(G):
     seen = []
     saved = rendering._isect_max_tile_len
     for mode in ("seg", "tile"):
-        rendering._isect_max_tile_len = (lambda st: seen.append(saved(st)) or seen[-1]) if mode == "seg" else (lambda st: 0)
+        rendering._isect_max_tile_len = (lambda st: seen.append(saved(st)) or seen[-1]) if mode == "seg" else (lambda st: -1)
         try:
             leaves = {k: a[k].detach().clone().requires_grad_(True) for k in names}
             rc, ra, info = G.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
@@ -159,7 +159,7 @@ def test_uniformly_long_lists_stay_on_the_per_tile_walk(G):
     longest = int(counts.max())
     assert longest > _ops.SEG_MIN_LONGEST and longest <= _ops._seg_cut(fl.numel(), 1, 4, 4), (longest, fl.numel())
     colors = torch.rand(m2.shape[:-1] + (3,), generator=torch.Generator().manual_seed(1)).to(DEV)
-    ref = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl)
+    ref = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl, _longest_tile_list=-1)
     hinted = G.rasterize_to_pixels(m2, con, colors, op, W, H, 16, off, fl, _longest_tile_list=longest)
     assert torch.equal(ref[0], hinted[0]) and torch.equal(ref[1], hinted[1])
 
@@ -191,10 +191,33 @@ def test_segment_hint_with_backward_fallbacks(G, case):
     colors = torch.rand(m2.shape[:-1] + (D,), generator=g).to(DEV)
     w_c = torch.randn(1, H, W, D, generator=g).to(DEV)
     grads = {}
-    for name, hint in (("tile", 0), ("seg", longest)):
+    for name, hint in (("tile", -1), ("seg", longest)):  # -1: per tile, whatever the intersection noted
         leaves = [t.detach().clone().requires_grad_(True) for t in (m2, con, colors, op)]
         rc, ra = G.rasterize_to_pixels(*leaves, W, H, ts, off, fl, absgrad=(case == "absgrad"), _longest_tile_list=hint)
         ((rc * w_c).sum() + ra.sum()).backward()
         grads[name] = [t.grad.cpu() for t in leaves] + ([leaves[0].absgrad.cpu()] if case == "absgrad" else [])
     for nm, x, y in zip(("means2d", "conics", "colors", "opacities", "absgrad"), grads["seg"], grads["tile"]):
         assert_grad_close(x, y, name=f"{case} v_{nm}")
+
+
+def test_stage_level_callers_get_segments_without_a_hint(G):
+    """isect_tiles -> isect_offset_encode -> rasterize_to_pixels driven by hand (the reference's stage API, no rasterization()
+    in between): the intersection notes the longest list of its result under flatten_ids, the compositing ops look it up -
+    forward AND backward take the segment kernels, bit-identical to the explicitly hinted call and not to the per-tile walk."""
+    m2, con, op, off, fl, longest, W, H, tw, th = _lists(G, 40000, 1, 320, 192, 0.01, seed=41)
+    colors = torch.rand(m2.shape[:-1] + (3,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    w_c = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(3)).to(DEV)
+    res = {}
+    for name, kw in (("noted", {}), ("hinted", dict(_longest_tile_list=longest)), ("tile", dict(_longest_tile_list=-1))):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (m2, con, colors, op)]
+        rc, ra = G.rasterize_to_pixels(*leaves, W, H, 16, off, fl, **kw)
+        ((rc * w_c).sum() + ra.sum()).backward()
+        res[name] = [rc.detach(), ra.detach()] + [t.grad for t in leaves]
+    assert all(torch.equal(a, b) for a, b in zip(res["noted"][:2], res["hinted"][:2])), "forward did not take the segments"
+    assert not torch.equal(res["noted"][0], res["tile"][0]), "segments and per-tile walk are expected to differ in rounding"
+    # atomics make the backward's last bits vary from run to run: compare it to both at the segment tolerance instead
+    for a, b in zip(res["noted"][2:], res["hinted"][2:]):
+        assert_grad_close(a.cpu(), b.cpu(), name="noted vs hinted")
+    # through the raw torch ops too (what the reference's Python calls)
+    out = torch.ops.gsplat.rasterize_to_pixels_3dgs(m2, con, colors, op, None, None, W, H, 16, off, fl, False, False)
+    assert torch.equal(out[0], res["hinted"][0])
