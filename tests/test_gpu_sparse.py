@@ -77,10 +77,15 @@ def test_layout_on_device_matches_oracle(G, O, tile_size):
         assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("path", [None, "binned", "legacy"])
 @pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("C", [1, 2])
-def test_isect_sparse_exact(G, O, packed, C):
-    # C == 1 packed and every dense case run the fused masked kernels; C == 2 packed takes the enumerate-and-filter route
+def test_isect_sparse_exact(G, O, packed, C, path, monkeypatch):
+    # C == 1 packed and every dense case run the fused masked kernels; C == 2 packed takes the enumerate-and-filter route.
+    # `path`: the tile-owner-major intersection is chosen on its own only for 200 k - 1.2 M rows per 1080p image; forced here so
+    # that the sparse caller of both fused paths is exercised at test size (the binned branch used to crash)
+    if path is not None:
+        monkeypatch.setenv("GSX_ISECT_PATH", path)
     W, H, ts = 150, 100, 16
     rad, m2, d, con, op, ci = _scene(G, 3000, C, W, H, seed=17, packed=packed)
     tw, th = math.ceil(W / ts), math.ceil(H / ts)
