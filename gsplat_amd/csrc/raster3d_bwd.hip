@@ -282,6 +282,9 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
 // Tunables (A/B builds: make SUFFIX=_x EXTRA=-DGSX_BWD_T_...=..; measured on c3, MI355X, profiles/r04_ab_variant_t.md).
 // The defaults keep a workgroup at 30.4 KiB of LDS and <= 102 VGPRs, i.e. 5 workgroups per CU: occupancy and batch length
 // pull in opposite directions (BATCH 128 / 144 / 160 -> 533 / 526 / 572 us: 160 drops to 4 workgroups per CU).
+#ifndef GSX_RASTER3D_BWD_DEFAULT // 't': variant T, 'w': variant W (one wave per tile, below); GSX_RASTER3D_BWD=r|t|w at run time
+#define GSX_RASTER3D_BWD_DEFAULT 't'
+#endif
 #ifndef GSX_BWD_T_BATCH
 #define GSX_BWD_T_BATCH 128
 #endif
@@ -656,15 +659,324 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
     }
 }
 
-// Variant T is the default where it applies; GSX_RASTER3D_BWD=r selects the reduction kernel (read once per process).
-static bool use_variant_t()
+// ---- variant W: ONE WAVE PER TILE ----------------------------------------------------------------------------------------
+// Variant T still pays for the fact that a tile belongs to FOUR waves: every per-(tile, Gaussian) sum is combined across them
+// with LDS float atomics (ds_add_f32 retires ~0.75 lanes per cycle and CU: 0.067 of the 0.43 ms launch), the staged list is
+// shared through workgroup barriers (staging + barriers: a quarter of the launch), and the loop control of the pixel walk -
+// scalar instructions and broadcast LDS reads - is paid once per (wave, Gaussian) pair, 2.8 times per staged Gaussian on c3.
+// Here a tile is ONE wave64 and a lane owns FOUR pixels, the same position in each 8 x 8 quadrant:
+//   * staging is wave-private (64 Gaussians per batch, one per lane): no __syncthreads anywhere in the kernel;
+//   * the staging lane tests its Gaussian against the four quadrant rectangles (the same two-stage test as the wave-level
+//     culling of variant T, vectorised over 64 Gaussians) and keeps the 4-bit answer in a register; the walk reads the staged
+//     row ONCE per Gaussian and branches over the quadrants that can be reached (scalar bit tests);
+//   * (fac, w) of the 256 pixels are parked per slot and quadrant; every FOUR contributing Gaussians the wave turns round:
+//     lane (slot, quadrant, row pair) sums 16 pixels with plain FMAs (cotangents in registers), lanes of quadrants the
+//     Gaussian did not reach skip their reads, the 16 lanes of a slot are one DPP row: a row all-reduce gives every lane
+//     the K totals, and lane c of the row turns them into column c of the gradient row and adds it to HBM - consecutive
+//     lanes, consecutive floats of one row. No accumulator table, no LDS atomics, no re-zeroing, no separate flush pass.
+// LDS per wave: 64 x (48 + 16) B staged + 4 slots x 2304 B of W = 13.3 KB -> 12 waves per CU, each with up to 168 VGPRs;
+// the four independent pixel chains per lane give the instruction-level parallelism that variant T gets from occupancy.
+// CH <= 4, 16 x 16 tiles, no absgrad (as variant T).
+#ifndef GSX_BWD_W_WAVES
+#define GSX_BWD_W_WAVES 3
+#endif
+template <int CH>
+struct BwdWCfg {
+    static constexpr int K     = CH + 6;
+    static constexpr int NCOL  = 6 + CH;
+    static constexpr int BATCH = 64;     // one staged Gaussian per lane
+    static constexpr int SLOTS = 4;      // Gaussians per turn: 4 slots x 4 quadrants x 4 row pairs = 64 lanes
+    static constexpr int GP    = 36;     // floats per group of 16 pixels (two rows of a quadrant): 16 x (fac, w) + 4 (bank spread)
+    static constexpr int QP    = 4 * GP; // per quadrant
+    static constexpr int SP    = 4 * QP; // per slot
+    static constexpr size_t smem = (size_t)BATCH * (sizeof(StagedRow) + sizeof(float4)) + sizeof(float) * SLOTS * SP;
+};
+
+template <int CH>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSX_BWD_W_WAVES)))
+raster3d_bwd_w_kernel(Raster3DArgs a)
 {
-    static const bool on = [] {
-        const char *e = getenv("GSX_RASTER3D_BWD");
-        return !(e && (e[0] == 'r' || e[0] == 'R'));
-    }();
-    return on;
+    using Cfg           = BwdWCfg<CH>;
+    constexpr int K     = Cfg::K;
+    constexpr int NCOL  = Cfg::NCOL;
+    constexpr int BATCH = Cfg::BATCH;
+    constexpr int SLOTS = Cfg::SLOTS;
+    constexpr int GP = Cfg::GP, QP = Cfg::QP, SP = Cfg::SP;
+    static_assert(CH <= 4, "cotangent rows are exchanged as float4");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    StagedRow *s_st = reinterpret_cast<StagedRow *>(smem_raw);  // e-form of the exponent + colours (raster3d.hpp)
+    float4 *s_aux   = reinterpret_cast<float4 *>(s_st + BATCH); // mean - tile centre (x, y), flatten id (bits), -
+    float *s_w      = reinterpret_cast<float *>(s_aux + BATCH); // [SLOTS][4 quadrants][4 groups][GP]: (fac, w) per pixel
+
+    TileCtx tc;
+    if (!tile_context(a, blockIdx.x, tc)) return;
+    if (a.masks && !a.masks[(size_t)tc.image_id * (a.tile_w * a.tile_h) + tc.tile_id]) return;
+    const int32_t range_start = tc.range_start;
+    if (tc.range_end <= range_start) return;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    // this lane's four pixels: (qx, qy) inside each quadrant; centres relative to the tile centre (multiples of 0.5: exact)
+    const uint32_t qx = lane & 7u, qy = lane >> 3;
+    const float pu[2] = {(float)qx - 7.5f, (float)qx + 0.5f}, pv[2] = {(float)qy - 7.5f, (float)qy + 0.5f};
+    const float tile_cx = (float)(tc.tile_x * 16u) + 8.0f, tile_cy = (float)(tc.tile_y * 16u) + 8.0f;
+
+    float T[4], behind[4], tail_term[4], v_c[4][CH];
+    int32_t bin_final[4];
+    int32_t tile_last = -1;
+    int32_t qmax[4]; // last contributor of each quadrant (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t lx = ((uint32_t)(q & 1) << 3) | qx, ly = ((uint32_t)(q >> 1) << 3) | qy;
+        const int64_t prow = pixel_row(a, tc, blockIdx.x, lx, ly);
+        const bool inside  = prow >= 0;
+        const size_t pix   = inside ? (size_t)prow : 0;
+        const float T_fin  = inside ? 1.0f - a.render_alphas[pix] : 1.0f;
+        T[q]               = T_fin;
+        behind[q]          = 0.0f;
+        bin_final[q]       = inside ? a.last_ids[pix] : -1;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) v_c[q][k] = (inside && k < (int)a.nch) ? a.v_render_colors[pix * a.cdim + a.ch_off + k] : 0.0f;
+        const float v_a = (inside && a.first_chunk && a.v_render_alphas) ? a.v_render_alphas[pix] : 0.0f;
+        float bg_dot    = 0.0f;
+        if (a.backgrounds) {
+            const float *bg = a.backgrounds + (size_t)tc.image_id * a.cdim + a.ch_off;
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (k < (int)a.nch) bg_dot += bg[k] * v_c[q][k];
+        }
+        tail_term[q] = T_fin * (v_a - bg_dot); // T_final (v_a - bg . v_c): what lies behind the whole list
+        qmax[q]      = wave_max_i32(bin_final[q]);
+        tile_last    = max(tile_last, qmax[q]);
+    }
+    // nothing behind the tile's last contributor is ever needed (early termination cut the lists in the forward pass)
+    const int32_t range_end = min(tc.range_end, tile_last + 1);
+    const int32_t n_batches = (range_end - range_start + BATCH - 1) / BATCH;
+    if (n_batches <= 0) return;
+
+    // roles in a turn: lane = (slot tg, quadrant tq, row pair tj) sums the 16 pixels of rows 2 tj, 2 tj + 1 of quadrant tq
+    const int tg = (int)(lane >> 4), tq = (int)((lane >> 2) & 3u), tj = (int)(lane & 3u);
+    // their cotangents, in registers for the whole kernel (handed over through the still unused W region)
+    float vcr[16][CH];
+    {
+        float4 *tmp = reinterpret_cast<float4 *>(s_w); // [4 quadrants][64 pixels]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+            float *r   = reinterpret_cast<float *>(&row);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) r[k] = v_c[q][k];
+            tmp[q * 64 + (int)lane] = row;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float4 o    = tmp[tq * 64 + 16 * tj + p];
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int k = 0; k < CH; ++k) vcr[p][k] = ov[k];
+        }
+        wave_lds_sync();
+    }
+
+    // where this lane's (fac, w) of quadrant q lives inside a slot: in-quadrant pixel index = lane
+    float *const w_ptr0 = s_w + (int)(lane >> 4) * GP + 2 * (int)(lane & 15u);
+    float *w_ptr        = w_ptr0; // ... of the next free slot
+    int slot            = 0;      // wave-uniform: slots filled since the last turn
+    int slot_info       = 0;      // LANE s (s < SLOTS): staged index << 4 | quadrants that contributed, of the Gaussian in slot s
+
+    // one turn: sums of the filled slots -> gradient rows in HBM (all lanes take part)
+    auto turn = [&](int n_slots) {
+        wave_lds_sync();
+        const int info  = __builtin_amdgcn_ds_bpermute(tg << 2, slot_info);
+        const bool live = tg < n_slots;
+        float acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+        if (live && ((info >> tq) & 1)) { // quadrants the Gaussian did not reach were never written: their lanes add nothing
+            const v4f *rd = reinterpret_cast<const v4f *>(s_w + tg * SP + tq * QP + tj * GP);
+            float rs[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}; // per row: sum w, sum w ul, sum w ul^2 (ul = 0..7: constants)
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const v4f x       = rd[h]; // (fac, w) of pixels 2h, 2h + 1
+                const float ff[2] = {x.x, x.z}, ww[2] = {x.y, x.w};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int pp   = 2 * h + e;
+                    const float ul = (float)(pp & 7);
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) acc[k] = fmaf(ff[e], vcr[pp][k], acc[k]);
+                    rs[pp >> 3][0] += ww[e];
+                    rs[pp >> 3][1] = fmaf(ww[e], ul, rs[pp >> 3][1]);
+                    rs[pp >> 3][2] = fmaf(ww[e], ul * ul, rs[pp >> 3][2]);
+                }
+            }
+            // local (ul, vl in {0, 1}) -> tile-centre coordinates: u = ul + u0, v = vl + v0
+            const float u0 = (float)((tq & 1) << 3) - 7.5f, v0 = (float)(((tq >> 1) << 3) + 2 * tj) - 7.5f;
+            const float s0 = rs[0][0] + rs[1][0], s1 = rs[0][1] + rs[1][1], s2 = rs[0][2] + rs[1][2];
+            const float t1 = rs[1][0], m11 = rs[1][1]; // sum w vl (= sum w vl^2), sum w ul vl
+            const float Su = fmaf(u0, s0, s1);
+            acc[CH + 0]    = s0;
+            acc[CH + 1]    = Su;
+            acc[CH + 2]    = fmaf(v0, s0, t1);
+            acc[CH + 3]    = s2 + u0 * (2.0f * s1 + u0 * s0);
+            acc[CH + 4]    = m11 + u0 * t1 + v0 * Su;
+            acc[CH + 5]    = t1 + v0 * (2.0f * t1 + v0 * s0);
+        }
+        // the 16 lanes of a slot are one DPP row: every lane of the row gets the K totals
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = row16_sum(acc[k]);
+        // lane c of the row -> column c of the Gaussian's gradient row. Raw tile-centre moments -> moments of d = mean - pixel
+        // = a - (u, v):  S_x = ax S0 - Su, S_xx = ax^2 S0 - 2 ax Su + Suu, S_xy = ax ay S0 - ax Sv - ay Su + Suv, ...
+        const int c = (int)(lane & 15u);
+        if (live && c < NCOL) {
+            constexpr float kInvLog2e = 1.0f / kLog2e;
+            const int t_g    = info >> 4;
+            const float4 aux = s_aux[t_g];
+            const v4f p1     = s_st[t_g].p1; // (-A, -B, -C) of the staged form: Q = (2A, B; B, 2C) / log2(e)
+            const float lo   = s_st[t_g].p0.w;
+            const float ax = aux.x, ay = aux.y;
+            const int32_t id = __float_as_int(aux.z);
+            const float S0 = acc[CH], Su = acc[CH + 1], Sv = acc[CH + 2];
+            const float sx = fmaf(ax, S0, -Su), sy = fmaf(ay, S0, -Sv);
+            float val;
+            int col  = c;
+            bool put = true;
+            if (c == 0) val = -kInvLog2e * (2.0f * p1.x * sx + p1.y * sy);
+            else if (c == 1) val = -kInvLog2e * (p1.y * sx + 2.0f * p1.z * sy);
+            else if (c == 2) val = 0.5f * (ax * (ax * S0 - 2.0f * Su) + acc[CH + 3]);
+            else if (c == 3) val = ax * (ay * S0 - Sv) - ay * Su + acc[CH + 4];
+            else if (c == 4) val = 0.5f * (ay * (ay * S0 - 2.0f * Sv) + acc[CH + 5]);
+            else if (c == 5) val = -S0 * __builtin_amdgcn_exp2f(-lo); // v_opacity = sum vis v_alpha = -S_w / opacity
+            else {
+                const int k = c - 6;
+                val         = 0.0f;
+#pragma unroll
+                for (int kk = 0; kk < CH; ++kk) val = (k == kk) ? acc[kk] : val;
+                put = k < (int)a.nch;
+                col = 6 + (int)a.ch_off + k;
+            }
+            if (put) atomic_add_f32(a.v_rows + (size_t)id * a.row_stride + col, val);
+        }
+        wave_lds_sync();
+    };
+
+    for (int32_t b = 0; b < n_batches; ++b) {
+        // back to front: staged slot s is list entry batch_end - s
+        const int32_t batch_end = range_end - 1 - BATCH * b;
+        int hitmask             = 0; // this lane's staged Gaussian: quadrants whose pixels it can reach
+        {
+            const int32_t idx = batch_end - (int32_t)lane;
+            if (idx >= range_start) {
+                const int32_t g  = a.flatten_ids[idx];
+                const float2 xy  = reinterpret_cast<const float2 *>(a.means2d)[g];
+                const float opac = a.opacities[g];
+                const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
+                const float ax = xy.x - tile_cx, ay = xy.y - tile_cy;
+                v4f p0;
+                float nA, nB, nC;
+                stage_gaussian_e(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
+                const float *cp = a.colors + (size_t)g * a.cdim + a.ch_off;
+                float cv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cv[k] = (k < CH && k < (int)a.nch) ? cp[k] : 0.0f;
+                const v4f p1 = v4f{nA, nB, nC, cv[2]};
+                s_st[lane].p0 = p0;
+                s_st[lane].p1 = p1;
+                s_st[lane].p2 = v4f{cv[0], cv[1], cv[3], 0.0f};
+                s_aux[lane]   = make_float4(ax, ay, __int_as_float(g), 0.0f);
+                // the two-stage test of the wave-level culling (raster3d.hpp), once per quadrant; a quadrant whose pixels all
+                // stopped in front of this entry cannot be reached either
+                const float2 he = cull_half_extent(opac, ca, cb, cc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    WaveRect r;
+                    r.cx = (q & 1) ? 4.0f : -4.0f; r.cy = (q >> 1) ? 4.0f : -4.0f; r.hw = 3.5f; r.hh = 3.5f; r.any = true;
+                    bool hit = idx <= qmax[q] && (fabsf(ax - r.cx) - r.hw <= he.x) && (fabsf(ay - r.cy) - r.hh <= he.y);
+                    if (hit) hit = rect_reaches_level(p0, p1, ax, ay, r);
+                    hitmask |= hit ? (1 << q) : 0;
+                }
+            }
+        }
+        wave_lds_sync();
+
+        const int32_t behind_s = __builtin_amdgcn_readfirstlane(batch_end); // list index of staged slot t = behind_s - t
+        uint64_t todo          = __builtin_amdgcn_ballot_w64(hitmask != 0);
+        while (todo) {
+            const int32_t t = (int32_t)__builtin_ctzll(todo);
+            asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(t)); // todo &= todo - 1 in one scalar instruction
+            const int qm = __builtin_amdgcn_readlane(hitmask, t);
+            const v4f p0 = s_st[t].p0;
+            const v4f p1 = s_st[t].p1;
+            const v4f p2 = s_st[t].p2;
+            float col[CH];
+            col[0] = p2.x;
+            if constexpr (CH > 1) col[1] = p2.y;
+            if constexpr (CH > 2) col[2] = p1.w;
+            if constexpr (CH > 3) col[3] = p2.z;
+            const int32_t list_idx = behind_s - t;
+            int contributed        = 0; // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!(qm & (1 << q))) continue; // scalar
+                const float e    = staged_e(p0, p1.x, p1.y, p1.z, pu[q & 1], pv[q >> 1]);
+                const float ov_r = __builtin_amdgcn_exp2f(e); // opac * exp(-sigma), unclamped
+                const float al_r = fminf(kMaxAlpha, ov_r);
+                // pixels outside the image have bin_final = -1 and can never be valid; e > lo <=> sigma < 0
+                const bool valid = (bin_final[q] >= list_idx) && !(e > p0.w) && !(al_r < kAlphaThreshold);
+                if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform
+                // invalid lanes: alpha = 0 -> fac = 0, w = 0, T and `behind` unchanged (1 / (1 - 0) == 1 exactly)
+                const float alpha = valid ? al_r : 0.0f;
+                const float ra    = __builtin_amdgcn_rcpf(1.0f - alpha); // alpha <= kMaxAlpha = 0.99: no guard needed
+                T[q]             *= ra;
+                const float fac   = alpha * T[q];
+                // v_alpha = sum_k (c_k T - buffer_k / (1 - alpha)) v_c,k + T_final / (1 - alpha) (v_a - bg . v_c)  (Device.cuh:105-173);
+                // only B = sum_k buffer_k v_c,k is ever used and it obeys B += fac (c . v_c)  (as variant T)
+                float cvd = col[0] * v_c[q][0];
+#pragma unroll
+                for (int k = 1; k < CH; ++k) cvd = fmaf(col[k], v_c[q][k], cvd);
+                const float v_alpha = fmaf(ra, tail_term[q] - behind[q], cvd * T[q]);
+                behind[q]           = fmaf(fac, cvd, behind[q]);
+                // alpha-clamp branch (opac exp(-sigma) > 0.99): no geometry gradient; invalid lanes: none either
+                const float v_sigma = (valid && ov_r <= kMaxAlpha) ? -ov_r * v_alpha : 0.0f;
+                *reinterpret_cast<float2 *>(w_ptr + q * QP) = make_float2(fac, v_sigma); // ds_write_b64 into (slot, quadrant q)
+                contributed |= 1 << q;
+            }
+            if (contributed) {
+                const int info = (t << 4) | contributed;
+                uint32_t m0_saved; // the lane select of v_writelane travels in M0 (saved and restored: the compiler reserves it)
+                asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                    : "+v"(slot_info), "=&s"(m0_saved)
+                    : "s"(info), "s"(slot));
+                w_ptr += SP;
+                if (++slot == SLOTS) {
+                    turn(SLOTS);
+                    slot  = 0;
+                    w_ptr = w_ptr0;
+                }
+            }
+        }
+        if (slot) { // the staged rows the open slots point into are overwritten by the next batch: finish the turn first
+            turn(slot);
+            slot  = 0;
+            w_ptr = w_ptr0;
+        }
+    }
 }
+
+// Variant T is the default where it applies; GSX_RASTER3D_BWD=r selects the reduction kernel (read once per process).
+static char bwd_variant()
+{
+    static const char v = [] {
+        const char *e = getenv("GSX_RASTER3D_BWD");
+        if (e && (e[0] == 'r' || e[0] == 'R')) return 'r';
+        if (e && (e[0] == 't' || e[0] == 'T')) return 't';
+        if (e && (e[0] == 'w' || e[0] == 'W')) return 'w';
+        return GSX_RASTER3D_BWD_DEFAULT;
+    }();
+    return v;
+}
+static bool use_variant_t() { return bwd_variant() != 'r'; }
 
 template <int CH, bool ABS>
 static int launch_bwd(const Raster3DArgs &a, hipStream_t stream)
@@ -673,6 +985,10 @@ static int launch_bwd(const Raster3DArgs &a, hipStream_t stream)
     if (n_blocks == 0 || a.n_isects == 0) return GSX_OK;
     const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
     if constexpr (!ABS && CH <= 4) {
+        if (a.tile_size == 16 && bwd_variant() == 'w') {
+            raster3d_bwd_w_kernel<CH><<<dim3(grid), dim3(64), BwdWCfg<CH>::smem, stream>>>(a);
+            return check_launch("raster3d_bwd_w");
+        }
         if (a.tile_size == 16 && use_variant_t()) {
             raster3d_bwd_t_kernel<CH><<<dim3(grid), dim3(256), BwdTCfg<CH>::smem, stream>>>(a);
             return check_launch("raster3d_bwd_t");

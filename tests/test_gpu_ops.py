@@ -160,12 +160,18 @@ def test_projection_packed_matches_dense(G, sparse_grad, C):
             # the reference's layout (Projection.cpp:1125-1200): COO over the Gaussian axis, one entry per packed row in
             # packed-row order, coalesced iff a single image
             assert g.is_sparse and g.shape == ld.shape and g._nnz() == gi.numel(), nm
-            assert g.is_coalesced() == (C == 1), nm
             assert torch.equal(g._indices(), gi[None]), nm
             g = g.to_dense()
         else:
             assert not g.is_sparse, nm
         assert_grad_close(cpu(g), cpu(ld.grad), rel=1e-4, name=f"packed v_{nm}")
+    if sparse_grad:
+        # the op itself (autograd's accumulation does not keep the flag): coalesced iff a single image, like the reference
+        out = torch.ops.gsplat.projection_ewa_3dgs_packed_bwd(
+            a["means"], None, a["quats"], a["scales"], a["viewmats"], a["Ks"], W, H, 0.3, 0, True, bi, ci, gi, con_p.detach(),
+            comp_p.detach(), w2, wd, wc, wk, False)
+        assert out[0].is_sparse and out[0].is_coalesced() == (C == 1) and out[1] is None
+        assert out[2].is_sparse and out[3].is_sparse and out[4] is None
 
 
 def test_projection_packed_sparse_grad_allocates_no_dense_rows(G):
@@ -500,15 +506,17 @@ def test_golden_rasterize_vs_reference_outputs(G, golden):
     assert_close_ratio(cpu(rc), golden["rast_render_colors"], 1e-4, 2e-5, max_bad_ratio=1e-4, name="render_colors")
     assert_close_ratio(cpu(ra), golden["rast_render_alphas"], 1e-4, 2e-5, max_bad_ratio=1e-4, name="render_alphas")
     ((rc * to_t(golden["rast_v_render_colors"], DEV)).sum() + (ra * to_t(golden["rast_v_render_alphas"], DEV)).sum()).backward()
-    # the reference's own PER-ELEMENT band for this op (tests/test_basic.py:2664-2675: interior rtol / atol per gradient), on top
-    # of the scale-relative + cosine check: a scale-relative tolerance alone lets small-magnitude rows be arbitrarily wrong
-    per_element = {"v_means2d": (2.5e-4, 1.6e-3), "v_conics": (1e-5, 1e-3), "v_colors": (1e-5, 1e-3),
-                   "v_opacities": (1e-5, 2e-3), "v_backgrounds": (1e-5, 1e-3)}
+    # the reference's own PER-ELEMENT band for this op, on top of the scale-relative + cosine check (which alone would let
+    # small-magnitude rows be arbitrarily wrong); the allowed share of outliers is twice what two fp32 CPU evaluations of the
+    # same fixture show against each other (tests/_util.py)
+    from _util import RASTER_BWD_BAND, RASTER_BWD_BAND_CPU_ENVELOPE
+
     for leaf, key in zip(leaves, ("v_means2d", "v_conics", "v_colors", "v_opacities", "v_backgrounds")):
         assert_grad_close(cpu(leaf.grad), golden["rast_" + key], rel=2e-3, max_bad_ratio=2e-4, name=key)
-        rtol, atol = per_element[key]
+        rtol, atol = RASTER_BWD_BAND[key]
         assert torch.isfinite(leaf.grad).all(), key
-        assert_close_ratio(cpu(leaf.grad), golden["rast_" + key], rtol, atol, max_bad_ratio=1e-3, name=key + " per element")
+        assert_close_ratio(cpu(leaf.grad), golden["rast_" + key], rtol, atol,
+                           max_bad_ratio=max(2 * RASTER_BWD_BAND_CPU_ENVELOPE[key], 1e-4), name=key + " per element")
 
 
 def test_golden_isect_and_projection_vs_reference_outputs(G, golden):

@@ -91,7 +91,9 @@ for tag, kw in (("packed (the default)", {}), ("packed explicit", dict(packed=Tr
     ref_out, own_out = run_kw(gsplat.rasterization, **kw), run_kw(gsplat_amd.rasterization, **kw)
     compare(tag, ref_out, own_out)
     if "sparse_grad" in kw:
-        assert run_kw(gsplat.rasterization, **kw)[-1]["means"].is_sparse
+        # (means also receives the dense view-direction gradient of the SH colours: sparse + dense accumulates dense)
+        g_sp = run_kw(gsplat.rasterization, **kw)[-1]
+        assert g_sp["quats"].is_sparse and g_sp["scales"].is_sparse
 print("3DGS configurations OK")
 
 # rasterization_2dgs through the reference's Python (RGB+ED, distortion loss, packed and dense)

@@ -61,7 +61,10 @@ def run_case(G, case):
     return out
 
 
-def test_raster3d_bwd_reduction_kernel_matches_default_variant_t():
+@pytest.mark.parametrize("variant", ["r", "t", "w"])
+def test_raster3d_bwd_variants_match_the_default(variant):
+    """r: wave reductions; t: transposed per-Gaussian accumulation (four waves per tile); w: one wave per tile, four pixels per
+    lane (csrc/raster3d_bwd.hip). Whichever is the default, the other two must give the same gradients."""
     if not torch.cuda.is_available():
         pytest.skip("needs a ROCm GPU")
     assert os.environ.get("GSX_RASTER3D_BWD", "") == "", "run this test with the default kernel selection"
@@ -70,7 +73,7 @@ def test_raster3d_bwd_reduction_kernel_matches_default_variant_t():
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "t.npz")
         code = _SCRIPT % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
-        env = dict(os.environ, GSX_RASTER3D_BWD="r")
+        env = dict(os.environ, GSX_RASTER3D_BWD=variant)
         if os.environ.get("GSX_VARIANT_LIB"):  # an alternative build of the library for the variant side (A/B builds)
             env["GSPLAT_AMD_LIB"] = os.environ["GSX_VARIANT_LIB"]
         r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env, timeout=600)

@@ -159,3 +159,18 @@ def test_isect_tiles_float64_matches_reference_torch_restatement():
         assert torch.equal(off.reshape(-1), torch.from_numpy(g[f"{name}_offsets"]).reshape(-1))
     with pytest.raises(TypeError):
         O.isect_tiles(m, r, d, ts, tw, th, conics=torch.ones(C, N, 3), opacities=torch.ones(C, N))
+
+
+def test_rasterize_bwd_per_element_band(golden):
+    """The reference's per-element band (tests/test_basic.py:2664-2675) on the golden fixture, C oracle vs the stored outputs of
+    the reference's torch autograd: two fp32 CPU evaluations of the same sums. The share of elements outside the band is the
+    envelope the GPU kernels are held to twice over (tests/_util.py: RASTER_BWD_BAND_CPU_ENVELOPE)."""
+    from _util import RASTER_BWD_BAND, RASTER_BWD_BAND_CPU_ENVELOPE
+
+    W, H, ts, m2, con, col, op, off, fl, bg = _rast_inputs(golden)
+    rc, ra, li = O.rasterize_to_pixels(m2, con, col, op, W, H, ts, off, fl, backgrounds=bg)
+    g = O.rasterize_to_pixels_bwd(m2, con, col, op, W, H, ts, off, fl, ra, li, to_t(golden["rast_v_render_colors"]),
+                                  to_t(golden["rast_v_render_alphas"]), backgrounds=bg)
+    for k, (rtol, atol) in RASTER_BWD_BAND.items():
+        assert_close_ratio(g[k].reshape(golden["rast_" + k].shape), golden["rast_" + k], rtol, atol,
+                           max_bad_ratio=RASTER_BWD_BAND_CPU_ENVELOPE[k], name=k + " per element (CPU vs CPU)")
