@@ -147,6 +147,32 @@ def timed(step_fn, steps, warmup, barrier, profile_only=None):
     return elapsed, meta, prof
 
 
+def smi_state_under_load(step_fn, device_index: int):
+    """Clock / power state of the GPU WHILE the timed workload runs: `rocm-smi --showclocks --showpower --showmaxpower
+    --showperflevel --json` is started and steps are issued until it returns (an idle GPU reports its parked clocks: 94 MHz).
+    Lets a reader separate box-to-box spread (different power cap or clock) from run-to-run noise. None if rocm-smi is absent."""
+    try:
+        proc = subprocess.Popen(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showmaxpower",
+                                 "--showperflevel", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    except Exception:
+        return None
+    t0 = time.perf_counter()
+    while proc.poll() is None and time.perf_counter() - t0 < 20.0:
+        step_fn()
+    torch.cuda.synchronize()
+    try:
+        out, _ = proc.communicate(timeout=5)
+        card = next(iter(json.loads(out).values()))
+    except Exception:
+        return None
+    keep = {}
+    for k, v in card.items():
+        kl = k.lower()
+        if any(w in kl for w in ("sclk", "mclk", "fclk", "power", "performance level")):
+            keep[k] = v
+    return keep or None
+
+
 def pair_stats(meta, n_images, W, H):
     """Work counters of the compositing pass (C-ABI gsx_raster3d_pair_stats: instrumentation, replays the forward walk)."""
     from gsplat_amd._cabi import call, ptr
@@ -177,6 +203,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the c5 and c4_single_gpu sub-records")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the distributed=True code path in a 1-rank RCCL group (measures the seams' overhead)")
+    ap.add_argument("--windows", type=int, default=6,
+                    help="extra repeats of the K-step timed window after the headline one (reported as windows_ms, value_median, "
+                         "value_best); 0 switches them off")
     ap.add_argument("--lean", action="store_true",
                     help="only warmup + timed steps (no stage table, no sub-records, no CPU baseline): for rocprofv3 runs")
     args = ap.parse_args()
@@ -286,6 +315,32 @@ def main():
     # stall the host for ~45 ms, once (seen as a 55 ms second step on a fresh box). Steady state holds two sets.
     meta = None
     elapsed, meta, prof = timed(step, args.steps, 0, barrier, profile_only=("gsx_raster3d_fwd", "gsx_raster3d_bwd"))
+
+    def max_over_ranks(x: float) -> float:
+        if not distributed:
+            return x
+        t = torch.tensor([x], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # The headline stays the window the driver specified (the K steps above). The SAME window is then repeated: a 20-step
+    # window is ~20 ms, a 3 % kernel change is invisible in one of them next to box-to-box spread - the repeats give run noise
+    # (min / median / max) on THIS box, the SMI state below says which box it was.
+    n_windows = 0 if args.lean else args.windows
+    exchange_bytes = None
+    if distributed:
+        from gsplat_amd import distributed as _gd
+
+        _gd.reset_exchange_stats()
+    windows_s = [max_over_ranks(elapsed)]
+    for _ in range(n_windows):
+        e_w, _, _ = timed(step, args.steps, 0, barrier)
+        windows_s.append(max_over_ranks(e_w))
+    if distributed and n_windows:
+        exchange_bytes = _gd.EXCHANGE_STATS["bytes_to_peers"] / (n_windows * args.steps)
+    smi = smi_state_under_load(step, local_rank) if (rank == 0 and not args.lean) else None
+    if distributed:
+        dist.barrier()
     # per-stage table: a few extra (untimed) steps with an event pair around every C-ABI call
     n_stage = 0 if args.lean else min(5, args.steps)
     _cabi.profile_begin()
@@ -299,10 +354,7 @@ def main():
         t_other /= args.steps
         other = {"packed": not packed, "ms_per_step": round(t_other * 1e3, 4),
                  "value": round(n_cams * W * H / t_other / 1e6, 2)}
-    if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = windows_s[0]  # max over ranks of the headline window
 
     images = n_cams * n_gpus
     pixels = images * W * H
@@ -395,11 +447,21 @@ def main():
         if t_fwd == t_fwd:
             valu["fwd_frac_of_peak_reference_work"] = round(valu["fwd_reference_work_TFLOPs"] / FP32_PEAK_TFLOPS, 4)
             valu["fwd_frac_of_peak_executed"] = round(valu["fwd_executed_TFLOPs"] / FP32_PEAK_TFLOPS, 4)
+    def hbm_view(nbytes, ms):
+        if not (ms == ms and ms > 0):
+            return None
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"algorithmic_bytes_per_launch": int(nbytes), "launch_ms": round(ms, 4), "achieved": round(gbs, 2),
+                "frac": round(gbs / HBM_PEAK_GBS, 5)}
+
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": int(dom_bytes), "launch_ms": round(dom_ms, 4),
-        "n_isects": M, "rows": V, "pixels_per_launch": P_local, "valu": valu,
+        "n_isects": M, "rows": V, "pixels_per_launch": P_local,
+        # the forward launch and the pair the north star quotes (rasterize_to_pixels forward + backward), same recipe
+        "fwd": hbm_view(b_fwd, t_fwd), "bwd": hbm_view(b_bwd, t_bwd), "fwd_plus_bwd": hbm_view(b_fwd + b_bwd, t_fwd + t_bwd),
+        "valu": valu,
         "valu_issue_frac": valu_issue["frac"] if valu_issue else None, "valu_issue": valu_issue,
         "note": "compositing is bound by instruction issue (scalar + vector) and LDS, not by HBM (SURVEY.md 8(d)); see DESIGN.md",
     }
@@ -445,6 +507,11 @@ def main():
         "roofline": roofline,
         **({"rehearsal": True, "rehearsal_note": "all ranks on ONE GPU over gloo: code-path check, timings meaningless"}
            if rehearsal else {}),
+        # the driver-specified window first, then its repeats: ms per step of each, and the throughput of the median / best window
+        "windows_ms": [round(w / args.steps * 1e3, 4) for w in windows_s],
+        "value_median": round(pixels * args.steps / sorted(windows_s)[len(windows_s) // 2] / 1e6, 2),
+        "value_best": round(pixels * args.steps / min(windows_s) / 1e6, 2),
+        "gpu_state_under_load": smi,
         "raster_launch_ms": {"fwd": round(t_fwd, 4) if t_fwd == t_fwd else None,
                              "bwd": round(t_bwd, 4) if t_bwd == t_bwd else None},  # HIP events inside the timed region
         "stage_ms_per_step": {k.replace("gsx_", ""): round(v, 4) for k, v in sorted(per_step_ms.items())},
@@ -452,6 +519,9 @@ def main():
     }
     if other is not None:
         result["other_layout"] = other
+    if exchange_bytes is not None:
+        # rank 0's row exchanges (forward messages + reverse exchange of the gradients), bytes handed to OTHER ranks per step
+        result["a2a_bytes_per_rank"] = int(exchange_bytes)
 
     extras = rank == 0 and not distributed and not args.lean and not args.no_extra and workload == "c3"
     # ---- c5 (BASELINE.json configs[4]): 2DGS, same scene, RGB+ED + normals + distortion, same timing recipe -------------

@@ -680,6 +680,12 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
 #ifndef GSX_BWD_W_WAVES
 #define GSX_BWD_W_WAVES 3
 #endif
+#ifndef GSX_BWD_W_PREFETCH // the next survivor's staged row is read while the current one is composited
+#define GSX_BWD_W_PREFETCH 0
+#endif
+#ifndef GSX_BWD_W_EAGER // exponent / alpha / validity of the four quadrants before any branch
+#define GSX_BWD_W_EAGER 0
+#endif
 template <int CH>
 struct BwdWCfg {
     static constexpr int K     = CH + 6;
@@ -902,13 +908,27 @@ raster3d_bwd_w_kernel(Raster3DArgs a)
 
         const int32_t behind_s = __builtin_amdgcn_readfirstlane(batch_end); // list index of staged slot t = behind_s - t
         uint64_t todo          = __builtin_amdgcn_ballot_w64(hitmask != 0);
+#if GSX_BWD_W_PREFETCH
+        // software pipeline: the staged row of the NEXT survivor is requested while the current one is composited
+        int32_t t_next = todo ? (int32_t)__builtin_ctzll(todo) : 0;
+        v4f n0 = s_st[t_next].p0, n1 = s_st[t_next].p1, n2 = s_st[t_next].p2;
+#endif
         while (todo) {
+#if GSX_BWD_W_PREFETCH
+            const int32_t t = t_next;
+            asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(t));
+            const v4f p0 = n0, p1 = n1, p2 = n2;
+            t_next = todo ? (int32_t)__builtin_ctzll(todo) : t;
+            n0 = s_st[t_next].p0; n1 = s_st[t_next].p1; n2 = s_st[t_next].p2;
+            const int qm = __builtin_amdgcn_readlane(hitmask, t);
+#else
             const int32_t t = (int32_t)__builtin_ctzll(todo);
             asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(t)); // todo &= todo - 1 in one scalar instruction
             const int qm = __builtin_amdgcn_readlane(hitmask, t);
             const v4f p0 = s_st[t].p0;
             const v4f p1 = s_st[t].p1;
             const v4f p2 = s_st[t].p2;
+#endif
             float col[CH];
             col[0] = p2.x;
             if constexpr (CH > 1) col[1] = p2.y;
@@ -916,14 +936,31 @@ raster3d_bwd_w_kernel(Raster3DArgs a)
             if constexpr (CH > 3) col[3] = p2.z;
             const int32_t list_idx = behind_s - t;
             int contributed        = 0; // wave-uniform
+#if GSX_BWD_W_EAGER
+            // the four quadrants' exponent / alpha / validity first, branch-free (four independent chains in flight), ...
+            float ov_q[4], al_q[4];
+            bool valid_q[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                const float e = staged_e(p0, p1.x, p1.y, p1.z, pu[q & 1], pv[q >> 1]);
+                ov_q[q]       = __builtin_amdgcn_exp2f(e);
+                al_q[q]       = fminf(kMaxAlpha, ov_q[q]);
+                valid_q[q]    = (qm & (1 << q)) && (bin_final[q] >= list_idx) && !(e > p0.w) && !(al_q[q] < kAlphaThreshold);
+            }
+#endif
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#if GSX_BWD_W_EAGER
+                const float ov_r = ov_q[q], al_r = al_q[q];
+                const bool valid = valid_q[q];
+#else
                 if (!(qm & (1 << q))) continue; // scalar
                 const float e    = staged_e(p0, p1.x, p1.y, p1.z, pu[q & 1], pv[q >> 1]);
                 const float ov_r = __builtin_amdgcn_exp2f(e); // opac * exp(-sigma), unclamped
                 const float al_r = fminf(kMaxAlpha, ov_r);
                 // pixels outside the image have bin_final = -1 and can never be valid; e > lo <=> sigma < 0
                 const bool valid = (bin_final[q] >= list_idx) && !(e > p0.w) && !(al_r < kAlphaThreshold);
+#endif
                 if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform
                 // invalid lanes: alpha = 0 -> fac = 0, w = 0, T and `behind` unchanged (1 / (1 - 0) == 1 exactly)
                 const float alpha = valid ? al_r : 0.0f;

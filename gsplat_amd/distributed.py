@@ -104,8 +104,31 @@ def all_to_all_tensor_list(world_size: int, tensor_list: List[Tensor], splits: L
     return outs
 
 
+# Bytes this rank hands to OTHER ranks in row exchanges since the last reset (forward messages and the reverse exchange of the
+# gradients; the rows a rank keeps for its own cameras do not cross a link). bench.py reports it per step next to the N > 1 line
+# so that a scaling run can be checked against SURVEY.md section 8(e)'s volume (c4 dense, 8 ranks: 0.67 GB per direction).
+EXCHANGE_STATS = {"bytes_to_peers": 0, "collectives": 0}
+
+
+def reset_exchange_stats() -> None:
+    EXCHANGE_STATS["bytes_to_peers"] = 0
+    EXCHANGE_STATS["collectives"] = 0
+
+
+def _count_exchange(buf: Tensor, send_splits: List[int]) -> None:
+    rows_out = sum(int(x) for x in send_splits)
+    if dist.is_initialized():
+        r = dist.get_rank()
+        if r < len(send_splits):
+            rows_out -= int(send_splits[r])
+    row_bytes = buf.element_size() * (buf.numel() // max(buf.shape[0], 1)) if buf.dim() else buf.element_size()
+    EXCHANGE_STATS["bytes_to_peers"] += rows_out * row_bytes
+    EXCHANGE_STATS["collectives"] += 1
+
+
 def _all_to_all_rows(data: Tensor, in_splits: List[int], out_splits: List[int]) -> Tensor:
     """Row-wise all-to-all: autograd-aware for floating tensors that require grad."""
+    _count_exchange(data, in_splits)
     out = torch.empty((sum(out_splits),) + tuple(data.shape[1:]), dtype=data.dtype, device=data.device)
     if data.is_floating_point() and data.requires_grad:
         return distF.all_to_all_single(out, data.contiguous(), out_splits, in_splits)
@@ -124,6 +147,7 @@ class _ExchangeRows(torch.autograd.Function):
         F_ = payload.shape[1]
         buf = torch.cat([payload, radii.contiguous().view(torch.float32)], dim=1)  # [rows, F + 2]
         out = torch.empty((sum(out_splits), F_ + 2), dtype=payload.dtype, device=payload.device)
+        _count_exchange(buf, in_splits)
         dist.all_to_all_single(out, buf, out_splits, in_splits)
         ctx.splits = (in_splits, out_splits)
         recv_r = out[:, F_:].contiguous().view(torch.int32)
@@ -137,6 +161,7 @@ class _ExchangeRows(torch.autograd.Function):
             return None, None, None, None
         v_payload = v_payload.contiguous()
         back = torch.empty((sum(in_splits), v_payload.shape[1]), dtype=v_payload.dtype, device=v_payload.device)
+        _count_exchange(v_payload, out_splits)
         dist.all_to_all_single(back, v_payload, in_splits, out_splits)
         return back, None, None, None
 
@@ -174,6 +199,7 @@ class _AsyncExchange(torch.autograd.Function):
         # The collective writes `out` AFTER the views below exist. A backend that bumps the tensor's version counter when
         # the work completes (gloo does; RCCL bumps it at launch) would make autograd reject every later view of those
         # views ("its base has been modified inplace"). `.data` aliases the storage with a version counter of its own.
+        _count_exchange(buf, in_splits)
         fwd.work = dist.all_to_all_single(out.data, buf, out_splits, in_splits, async_op=True)
         ctx.splits, ctx.bwd = (in_splits, out_splits), bwd
         recv_r = out[:, F_:]  # float32 VIEW of the radii bits (no data is touched before the caller waits)
@@ -187,6 +213,7 @@ class _AsyncExchange(torch.autograd.Function):
         in_splits, out_splits = ctx.splits
         v_payload = v_payload.contiguous()
         back = torch.empty((sum(in_splits), v_payload.shape[1]), dtype=v_payload.dtype, device=v_payload.device)
+        _count_exchange(v_payload, out_splits)
         work = dist.all_to_all_single(back, v_payload, in_splits, out_splits, async_op=True)
         if ctx.bwd is None:
             work.wait()
