@@ -629,6 +629,10 @@ def main():
             torch.cuda.empty_cache()
             result["train_step"] = train_step_bench.run(steps=100, device=device)
             torch.cuda.empty_cache()
+            # what the SSIM term of the reference's loss costs: the same step with L1 alone
+            l1_only = train_step_bench.run(steps=100, device=device, ssim_lambda=0.0)
+            result["train_step"]["l1_only_ms_per_step"] = l1_only["ms_per_step"]
+            torch.cuda.empty_cache()
             # the same step with the coefficients handed over as they are stored, (sh0, shN): the split SH kernels read and
             # write them in place - no torch.cat each way (an extension of rasterization()'s `colors` argument)
             split = train_step_bench.run(steps=100, device=device, split_sh=True)

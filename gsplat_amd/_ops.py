@@ -898,10 +898,12 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
              ptr(last_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
              image_width, image_height, tile_size, tw, th, ptr(rows), geo + D, SEG_LEN, ptr(ws), ws.numel())
     else:
-        call("gsx_raster3d_bwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+        # workspace for the longest-first tile order of the launch (csrc/raster3d_bwd.hip: "longest tiles first")
+        ws = torch.empty(_cabi._lib.gsx_raster3d_bwd_workspace_bytes(I, tw, th), device=means2d.device, dtype=torch.uint8)
+        call("gsx_raster3d_bwd_ws", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
              ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
              ptr(last_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
-             image_width, image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D)
+             image_width, image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D, ptr(ws), ws.numel())
     v_means2d, v_conics = rows[:, 0:2].view(means2d.shape), rows[:, 2:5].view(conics.shape)
     v_opacities, v_colors = rows[:, 5].view(opacities.shape), rows[:, geo:].view(colors.shape)
     v_abs = rows[:, 6:8].view(means2d.shape) if absgrad else None

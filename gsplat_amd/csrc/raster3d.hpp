@@ -74,6 +74,8 @@ struct Raster3DArgs {
     float *seg_T;             // [item][256]  mode 1 out: transmittance of the slice; then (prefix kernel) in front of it: mode 2 in
     float *seg_out;           // [item][nch + 1][256]  mode 2 out: partial colours, transmittance at the end of the slice
     int32_t *seg_last;        // [item][256]  mode 2 out: last contributing list index, -1 = none
+    // backward, dense layouts: workgroup -> tile map sorted by work (raster3d_bwd.hip: tile_order_*), or null = launch order
+    const int32_t *tile_order;
 };
 
 // Block index -> (image, tile) with an XCD-aware remap: hardware places workgroup b on

@@ -262,6 +262,95 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
     }
 }
 
+// ---- longest tiles first ---------------------------------------------------------------------------------------------------
+// What a tile costs the backward is the length of its list UP TO ITS LAST CONTRIBUTOR (early termination in the forward
+// pass): on c3 that is 160 entries on average, 49 .. 486 per tile (the full lists: 466 +- 30). Workgroups are dispatched in
+// index order onto a few slots per CU, so in launch order the kernel lasts as long as its unluckiest slot: list scheduling
+// of the measured costs gives 1.23 x the ideal sum / slots at 5 workgroups per CU (variant T) and 1.66 x at 12 one-wave
+// workgroups (variant W), against 1.06 x / 1.09 x longest-first (tools/tile_balance.py). Three small launches build the
+// order: (1) one wave per tile takes the maximum of last_ids over its pixels -> cost, histogram per XCD over cost / 4;
+// (2) one wave per XCD scans its histogram from the top; (3) one thread per tile takes a slot in its bucket. The XCD-aware
+// map is kept: workgroup b still runs on XCD b % 8 and XCD x still owns the contiguous tile range x, only the order INSIDE the
+// range changes (neighbouring tiles share Gaussians: they stay in one XCD's L2). Ties inside a bucket are ordered by atomics:
+// scheduling only, the gradients are accumulated with float atomics in either case.
+constexpr uint32_t kOrderBuckets = 1024; // cost / 4, saturating: lists of up to 4096 staged entries are told apart
+struct TileOrderArgs {
+    const int32_t *isect_offsets, *last_ids;
+    uint32_t n_images, tile_w, tile_h, width, height, n_isects, n_blocks, per_xcd;
+    int32_t *cost;  // [n_blocks]
+    int32_t *hist;  // [8][kOrderBuckets]: histogram, then (in place) the first slot of every bucket
+    int32_t *order; // [n_blocks] in xcd_remap() index space
+};
+__global__ void __launch_bounds__(256) tile_order_cost_kernel(const TileOrderArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u, blk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (blk >= a.n_blocks) return;
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
+    const uint32_t image = blk / tiles_per_image, tile = blk % tiles_per_image;
+    const uint32_t x0 = (tile % a.tile_w) * 16u, y0 = (tile / a.tile_w) * 16u;
+    int32_t m = -1;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t p = lane + 64u * i, ox = x0 + (p & 15u), oy = y0 + (p >> 4);
+        if (ox < a.width && oy < a.height) m = max(m, a.last_ids[((size_t)image * a.height + oy) * a.width + ox]);
+    }
+    m = wave_max_i32(m);
+    if (lane == 0) {
+        const int32_t start = a.isect_offsets[blk];
+        const int32_t end   = (blk == a.n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
+        const int32_t cost  = max(0, min(end, m + 1) - start);
+        a.cost[blk]         = cost;
+        atomicAdd(&a.hist[(blk / a.per_xcd) * kOrderBuckets + min((uint32_t)cost >> 2, kOrderBuckets - 1u)], 1);
+    }
+}
+__global__ void __launch_bounds__(512) tile_order_scan_kernel(int32_t *hist)
+{
+    // wave x: XCD x's buckets from the most expensive down; lane l owns buckets 1023 - 16 l .. 1023 - 16 l - 15
+    const uint32_t lane = threadIdx.x & 63u;
+    int32_t *h = hist + (threadIdx.x >> 6) * kOrderBuckets;
+    int32_t v[16], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        v[j] = h[kOrderBuckets - 1u - (16u * lane + j)];
+        sum += v[j];
+    }
+    int32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t y = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += y;
+    }
+    int32_t run = inc - sum;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        h[kOrderBuckets - 1u - (16u * lane + j)] = run;
+        run += v[j];
+    }
+}
+__global__ void __launch_bounds__(256) tile_order_scatter_kernel(const TileOrderArgs a)
+{
+    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= a.n_blocks) return;
+    const uint32_t x   = blk / a.per_xcd;
+    const int32_t slot = atomicAdd(&a.hist[x * kOrderBuckets + min((uint32_t)a.cost[blk] >> 2, kOrderBuckets - 1u)], 1);
+    a.order[x * a.per_xcd + (uint32_t)slot] = (int32_t)blk;
+}
+// tile_context() through the order (dense layouts)
+__device__ __forceinline__ bool tile_context_ordered(const Raster3DArgs &a, uint32_t block, TileCtx &t)
+{
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h, n_blocks = tiles_per_image * a.n_images;
+    const uint32_t idx = xcd_remap(block, n_blocks);
+    if (idx >= n_blocks) return false;
+    const uint32_t blk = (uint32_t)a.tile_order[idx];
+    t.image_id = blk / tiles_per_image;
+    t.tile_id  = blk % tiles_per_image;
+    t.tile_x   = t.tile_id % a.tile_w;
+    t.tile_y   = t.tile_id / a.tile_w;
+    t.range_start = a.isect_offsets[blk];
+    t.range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
+    return true;
+}
+
 // ---- variant T: per-Gaussian sums by a TRANSPOSED walk instead of cross-lane reductions ---------------------------------
 // The kernel above spends about half of its VALU instructions turning 64 per-pixel values into one per-Gaussian value
 // (K = CH + 6 wave reductions per (wave, Gaussian)). Every one of those sums has the form
@@ -338,8 +427,10 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
     float *s_w       = s_acc + Cfg::NACC * BATCH * KP;             // [4 waves][SLOTS][WROW]
 
     TileCtx tc;
-    uint32_t seg_item;
-    if (!tile_context_seg(a, blockIdx.x, tc, seg_item)) return;
+    uint32_t seg_item = 0;
+    if (a.tile_order) {
+        if (!tile_context_ordered(a, blockIdx.x, tc)) return;
+    } else if (!tile_context_seg(a, blockIdx.x, tc, seg_item)) return;
     const bool in_segment = a.seg_mode != 0u && seg_item != 0xFFFFFFFFu; // a slice of a long tile list (raster3d_seg.hip)
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
     const uint32_t image_id = tc.image_id, tile_id = tc.tile_id;
@@ -699,8 +790,7 @@ struct BwdWCfg {
 };
 
 template <int CH>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSX_BWD_W_WAVES)))
-raster3d_bwd_w_kernel(Raster3DArgs a)
+__device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
 {
     using Cfg           = BwdWCfg<CH>;
     constexpr int K     = Cfg::K;
@@ -716,7 +806,7 @@ raster3d_bwd_w_kernel(Raster3DArgs a)
     float *s_w      = reinterpret_cast<float *>(s_aux + BATCH); // [SLOTS][4 quadrants][4 groups][GP]: (fac, w) per pixel
 
     TileCtx tc;
-    if (!tile_context(a, blockIdx.x, tc)) return;
+    if (a.tile_order ? !tile_context_ordered(a, blockIdx.x, tc) : !tile_context(a, blockIdx.x, tc)) return;
     if (a.masks && !a.masks[(size_t)tc.image_id * (a.tile_w * a.tile_h) + tc.tile_id]) return;
     const int32_t range_start = tc.range_start;
     if (tc.range_end <= range_start) return;
@@ -1001,6 +1091,19 @@ raster3d_bwd_w_kernel(Raster3DArgs a)
     }
 }
 
+// three waves per SIMD (<= 168 VGPRs) hold the state of one to three channels; four channels (64 cotangent registers per lane)
+// take two waves per SIMD rather than spill
+template <int CH>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSX_BWD_W_WAVES)))
+raster3d_bwd_w_kernel(Raster3DArgs a)
+{
+    raster3d_bwd_w_body<CH>(a);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) raster3d_bwd_w4_kernel(Raster3DArgs a)
+{
+    raster3d_bwd_w_body<4>(a);
+}
+
 // Variant T is the default where it applies; GSX_RASTER3D_BWD=r selects the reduction kernel (read once per process).
 static char bwd_variant()
 {
@@ -1015,6 +1118,46 @@ static char bwd_variant()
 }
 static bool use_variant_t() { return bwd_variant() != 'r'; }
 
+// GSX_RASTER3D_BWD_ORDER: "0" / "launch" = workgroups in launch order (A/B); "force" = sort however few tiles there are (tests:
+// small images then take the ordered path too); default: sort when there are more tiles than a round of workgroup slots
+static int bwd_lpt_mode()
+{
+    static const int mode = [] {
+        const char *e = getenv("GSX_RASTER3D_BWD_ORDER");
+        if (e && (e[0] == '0' || e[0] == 'l')) return 0;
+        if (e && e[0] == 'f') return 2;
+        return 1;
+    }();
+    return mode;
+}
+// Builds the longest-first order in `ws` (>= gsx_raster3d_bwd_workspace_bytes) and returns the pointer for Raster3DArgs, or
+// null when the launch keeps its launch order (no workspace, sparse layout, fewer tiles than workgroup slots, switched off).
+static const int32_t *build_tile_order(const Raster3DArgs &a, void *ws, int64_t ws_bytes, hipStream_t stream, int *rc)
+{
+    *rc = GSX_OK;
+    const uint32_t n_blocks = a.tile_w * a.tile_h * a.n_images;
+    const int mode = bwd_lpt_mode();
+    if (!ws || a.sp_active_tiles || a.tile_size != 16 || mode == 0 || (mode == 1 && n_blocks < 2048u)) return nullptr;
+    const int64_t need = (int64_t)sizeof(int32_t) * (2ll * n_blocks + 8ll * kOrderBuckets);
+    if (ws_bytes < need) return nullptr;
+    TileOrderArgs o{};
+    o.isect_offsets = a.isect_offsets; o.last_ids = a.last_ids; o.n_images = a.n_images; o.tile_w = a.tile_w; o.tile_h = a.tile_h;
+    o.width = a.width; o.height = a.height; o.n_isects = a.n_isects; o.n_blocks = n_blocks; o.per_xcd = (n_blocks + 7u) / 8u;
+    o.hist  = reinterpret_cast<int32_t *>(ws);
+    o.cost  = o.hist + 8 * kOrderBuckets;
+    o.order = o.cost + n_blocks;
+    if (hipMemsetAsync(o.hist, 0, sizeof(int32_t) * 8 * kOrderBuckets, stream) != hipSuccess) {
+        set_last_error("gsx_raster3d_bwd: memset of the tile-order histogram failed");
+        *rc = GSX_ERR_LAUNCH;
+        return nullptr;
+    }
+    tile_order_cost_kernel<<<dim3((n_blocks + 3u) / 4u), dim3(256), 0, stream>>>(o);
+    tile_order_scan_kernel<<<dim3(1), dim3(512), 0, stream>>>(o.hist);
+    tile_order_scatter_kernel<<<dim3((n_blocks + 255u) / 256u), dim3(256), 0, stream>>>(o);
+    *rc = check_launch("raster3d_bwd tile order");
+    return *rc == GSX_OK ? o.order : nullptr;
+}
+
 template <int CH, bool ABS>
 static int launch_bwd(const Raster3DArgs &a, hipStream_t stream)
 {
@@ -1023,7 +1166,8 @@ static int launch_bwd(const Raster3DArgs &a, hipStream_t stream)
     const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
     if constexpr (!ABS && CH <= 4) {
         if (a.tile_size == 16 && bwd_variant() == 'w') {
-            raster3d_bwd_w_kernel<CH><<<dim3(grid), dim3(64), BwdWCfg<CH>::smem, stream>>>(a);
+            if constexpr (CH == 4) raster3d_bwd_w4_kernel<<<dim3(grid), dim3(64), BwdWCfg<4>::smem, stream>>>(a);
+            else raster3d_bwd_w_kernel<CH><<<dim3(grid), dim3(64), BwdWCfg<CH>::smem, stream>>>(a);
             return check_launch("raster3d_bwd_w");
         }
         if (a.tile_size == 16 && use_variant_t()) {
@@ -1079,12 +1223,32 @@ static int bwd_dispatch(Raster3DArgs a, hipStream_t stream)
 
 } // namespace gsx
 
+extern "C" int64_t gsx_raster3d_bwd_workspace_bytes(uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
+{
+    return (int64_t)sizeof(int32_t) * (2ll * n_images * tile_w * tile_h + 8ll * gsx::kOrderBuckets);
+}
+
 extern "C" int gsx_raster3d_bwd(
     const float *means2d, const float *conics, const float *colors, const float *opacities,
     const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
     const float *render_alphas, const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
     uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
     uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows, uint32_t row_stride, void *stream)
+{
+    return gsx_raster3d_bwd_ws(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas,
+                               last_ids, v_render_colors, v_render_alphas, n_images, n_isects, cdim, width, height, tile_size,
+                               tile_w, tile_h, has_abs, v_rows, row_stride, nullptr, 0, stream);
+}
+
+// gsx_raster3d_bwd with a workspace (gsx_raster3d_bwd_workspace_bytes): the launch then takes the tiles longest-first (see
+// "longest tiles first" above). Same results; without a workspace the tiles run in launch order.
+extern "C" int gsx_raster3d_bwd_ws(
+    const float *means2d, const float *conics, const float *colors, const float *opacities,
+    const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+    const float *render_alphas, const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+    uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+    uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows, uint32_t row_stride, void *workspace,
+    int64_t workspace_bytes, void *stream)
 {
     using namespace gsx;
     GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster3d_bwd: tile_size must be in [1,16], got %u", tile_size);
@@ -1104,6 +1268,11 @@ extern "C" int gsx_raster3d_bwd(
     a.render_alphas = const_cast<float *>(render_alphas); a.last_ids = const_cast<int32_t *>(last_ids);
     a.v_render_colors = v_render_colors; a.v_render_alphas = v_render_alphas;
     a.v_rows = v_rows; a.row_stride = row_stride;
+    if (!has_abs && cdim <= 4 && bwd_variant() != 'r') { // the launches that read the order: variants T and W
+        int rc       = GSX_OK;
+        a.tile_order = build_tile_order(a, workspace, workspace_bytes, (hipStream_t)stream, &rc);
+        if (rc != GSX_OK) return rc;
+    }
     return has_abs ? bwd_dispatch<true>(a, (hipStream_t)stream) : bwd_dispatch<false>(a, (hipStream_t)stream);
 }
 

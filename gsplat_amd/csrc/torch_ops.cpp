@@ -734,12 +734,17 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
                                    mp<float>(rows), (uint32_t)(geo + r.D), (uint32_t)kSegLen, ws.mutable_data_ptr(), ws.numel(), L.stream),
               "gsx_raster3d_bwd_seg");
     } else
-    { Timed timed_("gsx_raster3d_bwd", L.stream); check(gsx_raster3d_bwd(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
-                           masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
-                           cp<int32_t>(flat), fp(ra), cp<int32_t>(li), fp(v_rc), fp(v_ra), (uint32_t)r.I, (uint32_t)flat.numel(),
-                           (uint32_t)r.D, (uint32_t)width, (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th,
-                           absgrad ? 1 : 0, mp<float>(rows), (uint32_t)(geo + r.D), L.stream),
-          "gsx_raster3d_bwd"); }
+    {
+        // workspace for the longest-first tile order of the launch (csrc/raster3d_bwd.hip: "longest tiles first")
+        Tensor ws = at::empty({gsx_raster3d_bwd_workspace_bytes((uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th)}, means2d.options().dtype(at::kByte));
+        Timed timed_("gsx_raster3d_bwd", L.stream);
+        check(gsx_raster3d_bwd_ws(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
+                                  masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
+                                  cp<int32_t>(flat), fp(ra), cp<int32_t>(li), fp(v_rc), fp(v_ra), (uint32_t)r.I, (uint32_t)flat.numel(),
+                                  (uint32_t)r.D, (uint32_t)width, (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th,
+                                  absgrad ? 1 : 0, mp<float>(rows), (uint32_t)(geo + r.D), ws.mutable_data_ptr(), ws.numel(), L.stream),
+              "gsx_raster3d_bwd");
+    }
     Tensor v_means2d = rows.slice(1, 0, 2).view(means2d.sizes()), v_conics = rows.slice(1, 2, 5).view(conics.sizes());
     Tensor v_opac = rows.select(1, 5).view(opac.sizes()), v_colors = rows.slice(1, geo, geo + r.D).view(colors.sizes());
     OptTensor v_abs, v_bg;

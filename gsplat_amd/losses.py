@@ -1,0 +1,55 @@
+"""Image losses of the training step around the rasterizer.
+
+`ssim_loss` mirrors ``gsplat/losses.py:150-200`` (``1 - SSIM`` with an 11 x 11 Gaussian window of sigma 1.5, zero padding,
+constants C1 = 0.01^2 / C2 = 0.03^2, mean over batch, channels and pixels - the term the reference trainer blends with L1,
+``examples/simple_trainer.py:951-961``: ``loss = lerp(l1, ssim_loss, 0.2)``). The reference evaluates five depthwise 11 x 11
+convolutions (or the third-party ``fused_ssim`` CUDA extension, not available here); the window is an outer product, so this
+version runs the five maps as ONE stacked tensor through a vertical and a horizontal 11-tap pass - the same sums, 22 taps per
+output instead of 121. Plain torch ops: differentiable through autograd, runs on any device.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+_WINDOW_CACHE: dict = {}
+
+
+def _window_1d(window_size: int, sigma: float, device, dtype) -> Tensor:
+    key = (window_size, sigma, str(device), dtype)
+    w = _WINDOW_CACHE.get(key)
+    if w is None:
+        x = torch.arange(window_size, device=device, dtype=torch.float32)
+        g = torch.exp(-((x - window_size // 2) ** 2) / (2 * sigma ** 2))
+        w = (g / g.sum()).to(dtype)
+        _WINDOW_CACHE[key] = w
+    return w
+
+
+def ssim_map(img1: Tensor, img2: Tensor, window_size: int = 11) -> Tensor:
+    """SSIM map [B, C, H, W] of two image batches [B, C, H, W] in [0, 1] (gsplat/losses.py: torch_ssim_loss)."""
+    if img1.shape != img2.shape or img1.dim() != 4:
+        raise ValueError(f"ssim: expected two [B, C, H, W] batches of one shape, got {tuple(img1.shape)} / {tuple(img2.shape)}")
+    B, C, H, W = img1.shape
+    w = _window_1d(window_size, 1.5, img1.device, img1.dtype)
+    pad = window_size // 2
+    maps = torch.cat([img1, img2, img1 * img1, img2 * img2, img1 * img2], dim=1)  # [B, 5 C, H, W]
+    G = 5 * C
+    maps = F.conv2d(maps, w.view(1, 1, window_size, 1).expand(G, 1, window_size, 1), padding=(pad, 0), groups=G)
+    maps = F.conv2d(maps, w.view(1, 1, 1, window_size).expand(G, 1, 1, window_size), padding=(0, pad), groups=G)
+    mu1, mu2, s11, s22, s12 = maps.split(C, dim=1)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    sigma1_sq, sigma2_sq, sigma12 = s11 - mu1_sq, s22 - mu2_sq, s12 - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+
+
+def ssim_loss(img1: Tensor, img2: Tensor, window_size: int = 11) -> Tensor:
+    """``1 - mean(SSIM)`` (gsplat/losses.py:150-200)."""
+    return 1.0 - ssim_map(img1, img2, window_size).mean()
+
+
+def l1_loss(pred: Tensor, target: Tensor) -> Tensor:
+    """Per-element L1 (gsplat/losses.py:48-63)."""
+    return (pred - target).abs()

@@ -61,10 +61,11 @@ def run_case(G, case):
     return out
 
 
-@pytest.mark.parametrize("variant", ["r", "t", "w"])
+@pytest.mark.parametrize("variant", ["r", "t", "w", "t+force", "w+force", "w+launch"])
 def test_raster3d_bwd_variants_match_the_default(variant):
     """r: wave reductions; t: transposed per-Gaussian accumulation (four waves per tile); w: one wave per tile, four pixels per
-    lane (csrc/raster3d_bwd.hip). Whichever is the default, the other two must give the same gradients."""
+    lane (csrc/raster3d_bwd.hip). Whichever is the default, the others must give the same gradients. "+force": the
+    longest-first tile order also on these small images (it starts at 2048 tiles otherwise); "+launch": never."""
     if not torch.cuda.is_available():
         pytest.skip("needs a ROCm GPU")
     assert os.environ.get("GSX_RASTER3D_BWD", "") == "", "run this test with the default kernel selection"
@@ -73,7 +74,10 @@ def test_raster3d_bwd_variants_match_the_default(variant):
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "t.npz")
         code = _SCRIPT % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
-        env = dict(os.environ, GSX_RASTER3D_BWD=variant)
+        kernel, _, order = variant.partition("+")
+        env = dict(os.environ, GSX_RASTER3D_BWD=kernel)
+        if order:
+            env["GSX_RASTER3D_BWD_ORDER"] = order
         if os.environ.get("GSX_VARIANT_LIB"):  # an alternative build of the library for the variant side (A/B builds)
             env["GSPLAT_AMD_LIB"] = os.environ["GSX_VARIANT_LIB"]
         r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env, timeout=600)

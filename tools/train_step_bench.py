@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """One TRAINING step around the rasterizer on the MI355X, timed end to end: what examples/simple_trainer.py does per
-iteration (reference examples/simple_trainer.py:795-1170: rasterization :722, L1 loss, backward, the optimizers' step
+iteration (reference examples/simple_trainer.py:795-1170: rasterization :722, loss = lerp(L1, 1 - SSIM, 0.2) :951-961, backward, the optimizers' step
 :1137-1150, strategy.step_post_backward :1156-1166), on the c3-sized model - 1 M Gaussians, one 1080p camera, SH degree 3,
 parameters in the trainer's layout (log-scales, logit-opacities, sh0 / shN stored apart and optimised with their own
 rates), SelectiveAdam (visibility-masked fused Adam) and DefaultStrategy (densification statistics every step, ONE
@@ -21,9 +21,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_every=None, grow_grad2d=2e-7,
-        release_cached_memory=False, refine=True, split_sh=False):
+        release_cached_memory=False, refine=True, split_sh=False, ssim_lambda=0.2):
     import bench
     import gsplat_amd
+    from gsplat_amd.losses import ssim_loss
 
     dev = device or torch.device("cuda", 0)
     sc, W, H = bench.make_workload(n_gaussians, dev)
@@ -64,7 +65,12 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_ever
         rc, ra, info = gsplat_amd.rasterization(params["means"], params["quats"], torch.exp(params["scales"]),
                                                 torch.sigmoid(params["opacities"]), colors, sc["viewmats"], sc["Ks"], W, H,
                                                 sh_degree=3, packed=packed)
-        loss = (rc - target).abs().mean()
+        # the reference trainer's loss (examples/simple_trainer.py:951-961): lerp(L1, 1 - SSIM, ssim_lambda = 0.2)
+        l1 = (rc - target).abs().mean()
+        if ssim_lambda > 0.0:
+            loss = torch.lerp(l1, ssim_loss(rc.permute(0, 3, 1, 2), target.permute(0, 3, 1, 2)), ssim_lambda)
+        else:
+            loss = l1
         strategy.step_pre_backward(params, opts, state, i, info)
         loss.backward()
         if packed:
@@ -96,7 +102,9 @@ def run(steps=100, n_gaussians=1_000_000, packed=False, device=None, refine_ever
     refine_ms = [round(t * 1e3, 3) for (i, t) in per_step if i == refine_at]
     return {
         "workload": f"training step on the c3-sized model: {n0} Gaussians, 1x{W}x{H}, SH deg 3, sh0 / shN apart, "
-                    f"packed={packed}; rasterization + L1 + backward + SelectiveAdam (6 tensors) + DefaultStrategy",
+                    f"packed={packed}; rasterization + lerp(L1, 1 - SSIM, {ssim_lambda}) + backward + SelectiveAdam (6 tensors) + "
+                    "DefaultStrategy",
+        "ssim_lambda": ssim_lambda,
         "steps": steps, "ms_per_step": round(wall / steps * 1e3, 4), "steps_per_s": round(steps / wall, 2),
         "mpixels_per_s": round(W * H * steps / wall / 1e6, 2),
         "refinement_at_step": refine_at, "refinement_step_ms": refine_ms[0] if refine_ms else None,
@@ -113,5 +121,7 @@ if __name__ == "__main__":
     ap.add_argument("--packed", action="store_true")
     ap.add_argument("--release-cached-memory", action="store_true", help="torch.cuda.empty_cache() after a refinement, as the reference does")
     ap.add_argument("--split-sh", action="store_true", help="pass colors=(sh0, shN) instead of torch.cat([sh0, shN], 1)")
+    ap.add_argument("--ssim-lambda", type=float, default=0.2, help="weight of the SSIM term (the reference's default 0.2; 0 = L1 only)")
     a = ap.parse_args()
-    print(json.dumps(run(a.steps, a.gaussians, a.packed, release_cached_memory=a.release_cached_memory, split_sh=a.split_sh)))
+    print(json.dumps(run(a.steps, a.gaussians, a.packed, release_cached_memory=a.release_cached_memory, split_sh=a.split_sh,
+                         ssim_lambda=a.ssim_lambda)))
