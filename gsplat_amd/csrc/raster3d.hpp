@@ -177,6 +177,15 @@ __device__ __forceinline__ int64_t pixel_row(const Args &a, const TileCtx &t, ui
     return a.sp_pixel_map[first + rank];
 }
 
+// Longest tiles first (csrc/tile_order.hip): builds, in `ws`, the workgroup -> tile map of a backward compositing launch
+// sorted by the tile's cost (its list up to its last contributor), per XCD. Returns the map (indexed by xcd_remap()), or null
+// when the launch keeps its launch order (no / too small a workspace, tiles other than 16 x 16, fewer tiles than a round of
+// workgroup slots, GSX_RASTER3D_BWD_ORDER=0); *rc is a GSX_* code.
+int64_t tile_order_workspace_bytes(uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
+const int32_t *build_tile_order(const int32_t *isect_offsets, const int32_t *last_ids, uint32_t n_images, uint32_t tile_size,
+                                uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height, uint32_t n_isects, void *ws,
+                                int64_t ws_bytes, hipStream_t stream, int *rc);
+
 // thread -> pixel inside the tile.
 __device__ __forceinline__ void tile_pixel(uint32_t tid, uint32_t tile_size, uint32_t &lx, uint32_t &ly)
 {

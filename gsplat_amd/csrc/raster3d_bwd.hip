@@ -262,79 +262,7 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
     }
 }
 
-// ---- longest tiles first ---------------------------------------------------------------------------------------------------
-// What a tile costs the backward is the length of its list UP TO ITS LAST CONTRIBUTOR (early termination in the forward
-// pass): on c3 that is 160 entries on average, 49 .. 486 per tile (the full lists: 466 +- 30). Workgroups are dispatched in
-// index order onto a few slots per CU, so in launch order the kernel lasts as long as its unluckiest slot: list scheduling
-// of the measured costs gives 1.23 x the ideal sum / slots at 5 workgroups per CU (variant T) and 1.66 x at 12 one-wave
-// workgroups (variant W), against 1.06 x / 1.09 x longest-first (tools/tile_balance.py). Three small launches build the
-// order: (1) one wave per tile takes the maximum of last_ids over its pixels -> cost, histogram per XCD over cost / 4;
-// (2) one wave per XCD scans its histogram from the top; (3) one thread per tile takes a slot in its bucket. The XCD-aware
-// map is kept: workgroup b still runs on XCD b % 8 and XCD x still owns the contiguous tile range x, only the order INSIDE the
-// range changes (neighbouring tiles share Gaussians: they stay in one XCD's L2). Ties inside a bucket are ordered by atomics:
-// scheduling only, the gradients are accumulated with float atomics in either case.
-constexpr uint32_t kOrderBuckets = 1024; // cost / 4, saturating: lists of up to 4096 staged entries are told apart
-struct TileOrderArgs {
-    const int32_t *isect_offsets, *last_ids;
-    uint32_t n_images, tile_w, tile_h, width, height, n_isects, n_blocks, per_xcd;
-    int32_t *cost;  // [n_blocks]
-    int32_t *hist;  // [8][kOrderBuckets]: histogram, then (in place) the first slot of every bucket
-    int32_t *order; // [n_blocks] in xcd_remap() index space
-};
-__global__ void __launch_bounds__(256) tile_order_cost_kernel(const TileOrderArgs a)
-{
-    const uint32_t lane = threadIdx.x & 63u, blk = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (blk >= a.n_blocks) return;
-    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
-    const uint32_t image = blk / tiles_per_image, tile = blk % tiles_per_image;
-    const uint32_t x0 = (tile % a.tile_w) * 16u, y0 = (tile / a.tile_w) * 16u;
-    int32_t m = -1;
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-        const uint32_t p = lane + 64u * i, ox = x0 + (p & 15u), oy = y0 + (p >> 4);
-        if (ox < a.width && oy < a.height) m = max(m, a.last_ids[((size_t)image * a.height + oy) * a.width + ox]);
-    }
-    m = wave_max_i32(m);
-    if (lane == 0) {
-        const int32_t start = a.isect_offsets[blk];
-        const int32_t end   = (blk == a.n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
-        const int32_t cost  = max(0, min(end, m + 1) - start);
-        a.cost[blk]         = cost;
-        atomicAdd(&a.hist[(blk / a.per_xcd) * kOrderBuckets + min((uint32_t)cost >> 2, kOrderBuckets - 1u)], 1);
-    }
-}
-__global__ void __launch_bounds__(512) tile_order_scan_kernel(int32_t *hist)
-{
-    // wave x: XCD x's buckets from the most expensive down; lane l owns buckets 1023 - 16 l .. 1023 - 16 l - 15
-    const uint32_t lane = threadIdx.x & 63u;
-    int32_t *h = hist + (threadIdx.x >> 6) * kOrderBuckets;
-    int32_t v[16], sum = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        v[j] = h[kOrderBuckets - 1u - (16u * lane + j)];
-        sum += v[j];
-    }
-    int32_t inc = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int32_t y = __shfl_up(inc, o);
-        if ((int)lane >= o) inc += y;
-    }
-    int32_t run = inc - sum;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        h[kOrderBuckets - 1u - (16u * lane + j)] = run;
-        run += v[j];
-    }
-}
-__global__ void __launch_bounds__(256) tile_order_scatter_kernel(const TileOrderArgs a)
-{
-    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blk >= a.n_blocks) return;
-    const uint32_t x   = blk / a.per_xcd;
-    const int32_t slot = atomicAdd(&a.hist[x * kOrderBuckets + min((uint32_t)a.cost[blk] >> 2, kOrderBuckets - 1u)], 1);
-    a.order[x * a.per_xcd + (uint32_t)slot] = (int32_t)blk;
-}
+// ---- longest tiles first: csrc/tile_order.hip builds the order, the kernels below read it through Raster3DArgs::tile_order ----
 // tile_context() through the order (dense layouts)
 __device__ __forceinline__ bool tile_context_ordered(const Raster3DArgs &a, uint32_t block, TileCtx &t)
 {
@@ -372,7 +300,7 @@ __device__ __forceinline__ bool tile_context_ordered(const Raster3DArgs &a, uint
 // The defaults keep a workgroup at 30.4 KiB of LDS and <= 102 VGPRs, i.e. 5 workgroups per CU: occupancy and batch length
 // pull in opposite directions (BATCH 128 / 144 / 160 -> 533 / 526 / 572 us: 160 drops to 4 workgroups per CU).
 #ifndef GSX_RASTER3D_BWD_DEFAULT // 't': variant T, 'w': variant W (one wave per tile, below); GSX_RASTER3D_BWD=r|t|w at run time
-#define GSX_RASTER3D_BWD_DEFAULT 't'
+#define GSX_RASTER3D_BWD_DEFAULT 'w'
 #endif
 #ifndef GSX_BWD_T_BATCH
 #define GSX_BWD_T_BATCH 128
@@ -777,6 +705,9 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
 #ifndef GSX_BWD_W_EAGER // exponent / alpha / validity of the four quadrants before any branch
 #define GSX_BWD_W_EAGER 0
 #endif
+#ifndef GSX_BWD_W_STAGE_AHEAD // the next batch's rows are requested before the current batch is walked
+#define GSX_BWD_W_STAGE_AHEAD 1
+#endif
 template <int CH>
 struct BwdWCfg {
     static constexpr int K     = CH + 6;
@@ -957,29 +888,52 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
         wave_lds_sync();
     };
 
+    // Staging is wave-private, so its two dependent global reads (list entry -> the Gaussian's rows) would sit in front of every
+    // batch with nothing of this wave to hide them: the rows of batch b + 1 and the list entries of batch b + 2 are requested
+    // before batch b is walked (GSX_BWD_W_STAGE_AHEAD=0: the plain order, for A/B).
+    struct Fetched { float2 xy; float opac, ca, cb, cc, cv[4]; };
+    auto entry_of = [&](int32_t b) -> int32_t { // flatten id of this lane's entry of batch b, -1 = none
+        const int32_t idx = range_end - 1 - BATCH * b - (int32_t)lane;
+        return (b < n_batches && idx >= range_start) ? a.flatten_ids[idx] : -1;
+    };
+    auto fetch = [&](int32_t g, Fetched &f) {
+        if (g < 0) return;
+        f.xy   = reinterpret_cast<const float2 *>(a.means2d)[g];
+        f.opac = a.opacities[g];
+        f.ca = a.conics[3 * (size_t)g]; f.cb = a.conics[3 * (size_t)g + 1]; f.cc = a.conics[3 * (size_t)g + 2];
+        const float *cp = a.colors + (size_t)g * a.cdim + a.ch_off;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f.cv[k] = (k < CH && k < (int)a.nch) ? cp[k] : 0.0f;
+    };
+#if GSX_BWD_W_STAGE_AHEAD
+    int32_t g_cur = entry_of(0), g_nxt = entry_of(1);
+    Fetched f_cur{};
+    fetch(g_cur, f_cur);
+#endif
     for (int32_t b = 0; b < n_batches; ++b) {
         // back to front: staged slot s is list entry batch_end - s
         const int32_t batch_end = range_end - 1 - BATCH * b;
         int hitmask             = 0; // this lane's staged Gaussian: quadrants whose pixels it can reach
         {
             const int32_t idx = batch_end - (int32_t)lane;
-            if (idx >= range_start) {
-                const int32_t g  = a.flatten_ids[idx];
-                const float2 xy  = reinterpret_cast<const float2 *>(a.means2d)[g];
-                const float opac = a.opacities[g];
-                const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
-                const float ax = xy.x - tile_cx, ay = xy.y - tile_cy;
+#if GSX_BWD_W_STAGE_AHEAD
+            const int32_t g = g_cur;
+            const Fetched f = f_cur;
+#else
+            const int32_t g = entry_of(b);
+            Fetched f{};
+            fetch(g, f);
+#endif
+            if (g >= 0) {
+                const float opac = f.opac, ca = f.ca, cb = f.cb, cc = f.cc;
+                const float ax = f.xy.x - tile_cx, ay = f.xy.y - tile_cy;
                 v4f p0;
                 float nA, nB, nC;
                 stage_gaussian_e(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
-                const float *cp = a.colors + (size_t)g * a.cdim + a.ch_off;
-                float cv[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cv[k] = (k < CH && k < (int)a.nch) ? cp[k] : 0.0f;
-                const v4f p1 = v4f{nA, nB, nC, cv[2]};
+                const v4f p1 = v4f{nA, nB, nC, f.cv[2]};
                 s_st[lane].p0 = p0;
                 s_st[lane].p1 = p1;
-                s_st[lane].p2 = v4f{cv[0], cv[1], cv[3], 0.0f};
+                s_st[lane].p2 = v4f{f.cv[0], f.cv[1], f.cv[3], 0.0f};
                 s_aux[lane]   = make_float4(ax, ay, __int_as_float(g), 0.0f);
                 // the two-stage test of the wave-level culling (raster3d.hpp), once per quadrant; a quadrant whose pixels all
                 // stopped in front of this entry cannot be reached either
@@ -994,6 +948,11 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
                 }
             }
         }
+#if GSX_BWD_W_STAGE_AHEAD
+        g_cur = g_nxt;
+        fetch(g_cur, f_cur);   // rows of batch b + 1: in flight while batch b is walked
+        g_nxt = entry_of(b + 2);
+#endif
         wave_lds_sync();
 
         const int32_t behind_s = __builtin_amdgcn_readfirstlane(batch_end); // list index of staged slot t = behind_s - t
@@ -1118,46 +1077,6 @@ static char bwd_variant()
 }
 static bool use_variant_t() { return bwd_variant() != 'r'; }
 
-// GSX_RASTER3D_BWD_ORDER: "0" / "launch" = workgroups in launch order (A/B); "force" = sort however few tiles there are (tests:
-// small images then take the ordered path too); default: sort when there are more tiles than a round of workgroup slots
-static int bwd_lpt_mode()
-{
-    static const int mode = [] {
-        const char *e = getenv("GSX_RASTER3D_BWD_ORDER");
-        if (e && (e[0] == '0' || e[0] == 'l')) return 0;
-        if (e && e[0] == 'f') return 2;
-        return 1;
-    }();
-    return mode;
-}
-// Builds the longest-first order in `ws` (>= gsx_raster3d_bwd_workspace_bytes) and returns the pointer for Raster3DArgs, or
-// null when the launch keeps its launch order (no workspace, sparse layout, fewer tiles than workgroup slots, switched off).
-static const int32_t *build_tile_order(const Raster3DArgs &a, void *ws, int64_t ws_bytes, hipStream_t stream, int *rc)
-{
-    *rc = GSX_OK;
-    const uint32_t n_blocks = a.tile_w * a.tile_h * a.n_images;
-    const int mode = bwd_lpt_mode();
-    if (!ws || a.sp_active_tiles || a.tile_size != 16 || mode == 0 || (mode == 1 && n_blocks < 2048u)) return nullptr;
-    const int64_t need = (int64_t)sizeof(int32_t) * (2ll * n_blocks + 8ll * kOrderBuckets);
-    if (ws_bytes < need) return nullptr;
-    TileOrderArgs o{};
-    o.isect_offsets = a.isect_offsets; o.last_ids = a.last_ids; o.n_images = a.n_images; o.tile_w = a.tile_w; o.tile_h = a.tile_h;
-    o.width = a.width; o.height = a.height; o.n_isects = a.n_isects; o.n_blocks = n_blocks; o.per_xcd = (n_blocks + 7u) / 8u;
-    o.hist  = reinterpret_cast<int32_t *>(ws);
-    o.cost  = o.hist + 8 * kOrderBuckets;
-    o.order = o.cost + n_blocks;
-    if (hipMemsetAsync(o.hist, 0, sizeof(int32_t) * 8 * kOrderBuckets, stream) != hipSuccess) {
-        set_last_error("gsx_raster3d_bwd: memset of the tile-order histogram failed");
-        *rc = GSX_ERR_LAUNCH;
-        return nullptr;
-    }
-    tile_order_cost_kernel<<<dim3((n_blocks + 3u) / 4u), dim3(256), 0, stream>>>(o);
-    tile_order_scan_kernel<<<dim3(1), dim3(512), 0, stream>>>(o.hist);
-    tile_order_scatter_kernel<<<dim3((n_blocks + 255u) / 256u), dim3(256), 0, stream>>>(o);
-    *rc = check_launch("raster3d_bwd tile order");
-    return *rc == GSX_OK ? o.order : nullptr;
-}
-
 template <int CH, bool ABS>
 static int launch_bwd(const Raster3DArgs &a, hipStream_t stream)
 {
@@ -1225,7 +1144,7 @@ static int bwd_dispatch(Raster3DArgs a, hipStream_t stream)
 
 extern "C" int64_t gsx_raster3d_bwd_workspace_bytes(uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
 {
-    return (int64_t)sizeof(int32_t) * (2ll * n_images * tile_w * tile_h + 8ll * gsx::kOrderBuckets);
+    return gsx::tile_order_workspace_bytes(n_images, tile_w, tile_h);
 }
 
 extern "C" int gsx_raster3d_bwd(
@@ -1270,7 +1189,10 @@ extern "C" int gsx_raster3d_bwd_ws(
     a.v_rows = v_rows; a.row_stride = row_stride;
     if (!has_abs && cdim <= 4 && bwd_variant() != 'r') { // the launches that read the order: variants T and W
         int rc       = GSX_OK;
-        a.tile_order = build_tile_order(a, workspace, workspace_bytes, (hipStream_t)stream, &rc);
+        a.tile_order = a.sp_active_tiles ? nullptr
+                                         : build_tile_order(a.isect_offsets, a.last_ids, a.n_images, a.tile_size, a.tile_w, a.tile_h,
+                                                            a.width, a.height, a.n_isects, workspace, workspace_bytes,
+                                                            (hipStream_t)stream, &rc);
         if (rc != GSX_OK) return rc;
     }
     return has_abs ? bwd_dispatch<true>(a, (hipStream_t)stream) : bwd_dispatch<false>(a, (hipStream_t)stream);

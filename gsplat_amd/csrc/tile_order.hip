@@ -1,0 +1,134 @@
+// Longest tiles first: the workgroup -> tile order of the backward compositing launches (3DGS variants T / W, 2DGS).
+// Not in the reference (its backward takes the tiles in launch order, RasterizeToPixels3DGSSerialBatchBwd.cu:41-110); a
+// scheduling change only - the same tiles run, the gradients are accumulated with float atomics in either order.
+#include <cstdlib>
+
+#include "raster3d.hpp"
+
+namespace gsx {
+
+// What a tile costs the backward is the length of its list UP TO ITS LAST CONTRIBUTOR (early termination in the forward
+// pass): on c3 that is 160 entries on average, 49 .. 486 per tile (the full lists: 466 +- 30). Workgroups are dispatched in
+// index order onto a few slots per CU, so in launch order the kernel lasts as long as its unluckiest slot: list scheduling
+// of the measured costs gives 1.23 x the ideal sum / slots at 5 workgroups per CU (variant T) and 1.66 x at 12 one-wave
+// workgroups (variant W), against 1.06 x / 1.09 x longest-first (tools/tile_balance.py). Three small launches build the
+// order: (1) one wave per tile takes the maximum of last_ids over its pixels -> cost, histogram per XCD over cost / 4;
+// (2) one wave per XCD scans its histogram from the top; (3) one thread per tile takes a slot in its bucket. The XCD-aware
+// map is kept: workgroup b still runs on XCD b % 8 and XCD x still owns the contiguous tile range x, only the order INSIDE the
+// range changes (neighbouring tiles share Gaussians: they stay in one XCD's L2). Ties inside a bucket are ordered by atomics:
+// scheduling only, the gradients are accumulated with float atomics in either case.
+constexpr uint32_t kOrderBuckets = 1024; // cost / 4, saturating: lists of up to 4096 staged entries are told apart
+struct TileOrderArgs {
+    const int32_t *isect_offsets, *last_ids;
+    uint32_t n_images, tile_w, tile_h, width, height, n_isects, n_blocks, per_xcd;
+    int32_t *cost;  // [n_blocks]
+    int32_t *hist;  // [8][kOrderBuckets]: histogram, then (in place) the first slot of every bucket
+    int32_t *order; // [n_blocks] in xcd_remap() index space
+};
+__global__ void __launch_bounds__(256) tile_order_cost_kernel(const TileOrderArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u, blk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (blk >= a.n_blocks) return;
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
+    const uint32_t image = blk / tiles_per_image, tile = blk % tiles_per_image;
+    const uint32_t x0 = (tile % a.tile_w) * 16u, y0 = (tile / a.tile_w) * 16u;
+    int32_t m = -1;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t p = lane + 64u * i, ox = x0 + (p & 15u), oy = y0 + (p >> 4);
+        if (ox < a.width && oy < a.height) m = max(m, a.last_ids[((size_t)image * a.height + oy) * a.width + ox]);
+    }
+    m = wave_max_i32(m);
+    if (lane == 0) {
+        const int32_t start = a.isect_offsets[blk];
+        const int32_t end   = (blk == a.n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
+        const int32_t cost  = max(0, min(end, m + 1) - start);
+        a.cost[blk]         = cost;
+        atomicAdd(&a.hist[(blk / a.per_xcd) * kOrderBuckets + min((uint32_t)cost >> 2, kOrderBuckets - 1u)], 1);
+    }
+}
+__global__ void __launch_bounds__(512) tile_order_scan_kernel(int32_t *hist)
+{
+    // wave x: XCD x's buckets from the most expensive down; lane l owns buckets 1023 - 16 l .. 1023 - 16 l - 15
+    const uint32_t lane = threadIdx.x & 63u;
+    int32_t *h = hist + (threadIdx.x >> 6) * kOrderBuckets;
+    int32_t v[16], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        v[j] = h[kOrderBuckets - 1u - (16u * lane + j)];
+        sum += v[j];
+    }
+    int32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t y = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += y;
+    }
+    int32_t run = inc - sum;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        h[kOrderBuckets - 1u - (16u * lane + j)] = run;
+        run += v[j];
+    }
+}
+__global__ void __launch_bounds__(256) tile_order_scatter_kernel(const TileOrderArgs a)
+{
+    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= a.n_blocks) return;
+    const uint32_t x   = blk / a.per_xcd;
+    const int32_t slot = atomicAdd(&a.hist[x * kOrderBuckets + min((uint32_t)a.cost[blk] >> 2, kOrderBuckets - 1u)], 1);
+    a.order[x * a.per_xcd + (uint32_t)slot] = (int32_t)blk;
+}
+
+} // namespace gsx
+
+namespace gsx {
+
+// GSX_RASTER3D_BWD_ORDER: "0" / "launch" = workgroups in launch order (A/B); "force" = sort however few tiles there are (tests:
+// small images then take the ordered path too); default: sort when there are more tiles than a round of workgroup slots
+static int bwd_lpt_mode()
+{
+    static const int mode = [] {
+        const char *e = getenv("GSX_RASTER3D_BWD_ORDER");
+        if (e && (e[0] == '0' || e[0] == 'l')) return 0;
+        if (e && e[0] == 'f') return 2;
+        return 1;
+    }();
+    return mode;
+}
+// Builds the longest-first order in `ws` (>= gsx_raster3d_bwd_workspace_bytes) and returns the pointer for Raster3DArgs, or
+// null when the launch keeps its launch order (no workspace, sparse layout, fewer tiles than workgroup slots, switched off).
+const int32_t *build_tile_order(const int32_t *isect_offsets, const int32_t *last_ids, uint32_t n_images, uint32_t tile_size,
+                                uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height, uint32_t n_isects, void *ws,
+                                int64_t ws_bytes, hipStream_t stream, int *rc)
+{
+    *rc = GSX_OK;
+    const uint32_t n_blocks = tile_w * tile_h * n_images;
+    const int mode = bwd_lpt_mode();
+    if (!ws || tile_size != 16 || mode == 0 || (mode == 1 && n_blocks < 2048u)) return nullptr;
+    if (ws_bytes < tile_order_workspace_bytes(n_images, tile_w, tile_h)) return nullptr;
+    TileOrderArgs o{};
+    o.isect_offsets = isect_offsets; o.last_ids = last_ids; o.n_images = n_images; o.tile_w = tile_w; o.tile_h = tile_h;
+    o.width = width; o.height = height; o.n_isects = n_isects; o.n_blocks = n_blocks; o.per_xcd = (n_blocks + 7u) / 8u;
+    o.hist  = reinterpret_cast<int32_t *>(ws);
+    o.cost  = o.hist + 8 * kOrderBuckets;
+    o.order = o.cost + n_blocks;
+    if (hipMemsetAsync(o.hist, 0, sizeof(int32_t) * 8 * kOrderBuckets, stream) != hipSuccess) {
+        set_last_error("tile order: memset of the histogram failed");
+        *rc = GSX_ERR_LAUNCH;
+        return nullptr;
+    }
+    tile_order_cost_kernel<<<dim3((n_blocks + 3u) / 4u), dim3(256), 0, stream>>>(o);
+    tile_order_scan_kernel<<<dim3(1), dim3(512), 0, stream>>>(o.hist);
+    tile_order_scatter_kernel<<<dim3((n_blocks + 255u) / 256u), dim3(256), 0, stream>>>(o);
+    *rc = check_launch("tile order");
+    return *rc == GSX_OK ? o.order : nullptr;
+}
+
+
+int64_t tile_order_workspace_bytes(uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
+{
+    return (int64_t)sizeof(int32_t) * (2ll * n_images * tile_w * tile_h + 8ll * kOrderBuckets);
+}
+
+} // namespace gsx
