@@ -41,6 +41,7 @@ struct Raster2DArgs {
     // (v_means2d 2 | v_opacities 1 | v_densify 2 | v_normals 3 | v_ray_transforms 9 | [v_means2d_abs 2] | v_colors cdim)
     float *v_rows;
     uint32_t row_stride;
+    const int32_t *tile_order; // backward: workgroup -> tile map, longest first (csrc/tile_order.hip), or null = launch order
 };
 
 // Bounding box (centre, half extents) of the pixels where a surfel can reach alpha >= 1/255, i.e. where
@@ -337,8 +338,9 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
 
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
     const uint32_t n_blocks        = tiles_per_image * a.n_images;
-    const uint32_t blk             = xcd_remap(blockIdx.x, n_blocks);
-    if (blk >= n_blocks) return;
+    const uint32_t slot            = xcd_remap(blockIdx.x, n_blocks);
+    if (slot >= n_blocks) return;
+    const uint32_t blk = a.tile_order ? (uint32_t)a.tile_order[slot] : slot;
     const uint32_t image_id = blk / tiles_per_image, tile_id = blk % tiles_per_image;
     if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) return;
     const uint32_t tile_x = tile_id % a.tile_w, tile_y = tile_id / a.tile_w;
@@ -680,6 +682,25 @@ extern "C" int gsx_raster2d_bwd(const float *means2d, const float *ray_transform
                                 uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                                 int has_abs, float *v_rows, uint32_t row_stride, void *stream)
 {
+    return gsx_raster2d_bwd_ws(means2d, ray_transforms, colors, opacities, normals, backgrounds, masks, isect_offsets, flatten_ids,
+                               render_colors, render_alphas, last_ids, median_ids, v_render_colors, v_render_alphas,
+                               v_render_normals, v_render_distort, v_render_median, n_images, n_isects, cdim, width, height,
+                               tile_size, tile_w, tile_h, has_abs, v_rows, row_stride, nullptr, 0, stream);
+}
+
+// gsx_raster2d_bwd with a workspace of gsx_raster3d_bwd_workspace_bytes(n_images, tile_w, tile_h): tiles longest-first
+// (csrc/tile_order.hip; same rule and same results as gsx_raster3d_bwd_ws)
+extern "C" int gsx_raster2d_bwd_ws(const float *means2d, const float *ray_transforms, const float *colors,
+                                   const float *opacities, const float *normals, const float *backgrounds,
+                                   const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                   const float *render_colors, const float *render_alphas, const int32_t *last_ids,
+                                   const int32_t *median_ids, const float *v_render_colors, const float *v_render_alphas,
+                                   const float *v_render_normals, const float *v_render_distort,
+                                   const float *v_render_median, uint32_t n_images, uint32_t n_isects, uint32_t cdim,
+                                   uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                                   int has_abs, float *v_rows, uint32_t row_stride, void *workspace, int64_t workspace_bytes,
+                                   void *stream)
+{
     GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster2d_bwd: tile_size must be in [1,16], got %u", tile_size);
     GSX_REQUIRE(cdim >= 1 && cdim <= 32, "gsx_raster2d_bwd: unsupported number of channels %u (1..32)", cdim);
     if (n_isects == 0) return GSX_OK; // no intersections: nothing to add to the (zero-filled, possibly empty) gradient rows
@@ -701,5 +722,11 @@ extern "C" int gsx_raster2d_bwd(const float *means2d, const float *ray_transform
     a.v_render_distort = v_render_distort; a.v_render_median = v_render_median;
     a.v_rows = v_rows; a.row_stride = row_stride;
     hipStream_t s = (hipStream_t)stream;
+    {
+        int rc       = GSX_OK;
+        a.tile_order = build_tile_order(isect_offsets, last_ids, n_images, tile_size, tile_w, tile_h, width, height, n_isects,
+                                        workspace, workspace_bytes, s, &rc);
+        if (rc != GSX_OK) return rc;
+    }
     return has_abs ? dispatch2_bwd<true>(a, s) : dispatch2_bwd<false>(a, s);
 }

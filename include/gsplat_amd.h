@@ -586,6 +586,16 @@ int gsx_raster2d_bwd(const float *means2d, const float *ray_transforms, const fl
                      const float *v_render_median, uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width,
                      uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows,
                      uint32_t row_stride, void *stream);
+/* The same launch with the tiles taken longest-first (see gsx_raster3d_bwd_ws; workspace of
+ * gsx_raster3d_bwd_workspace_bytes(n_images, tile_w, tile_h); NULL = launch order). */
+int gsx_raster2d_bwd_ws(const float *means2d, const float *ray_transforms, const float *colors, const float *opacities,
+                     const float *normals, const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                     const int32_t *flatten_ids, const float *render_colors, const float *render_alphas,
+                     const int32_t *last_ids, const int32_t *median_ids, const float *v_render_colors,
+                     const float *v_render_alphas, const float *v_render_normals, const float *v_render_distort,
+                     const float *v_render_median, uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width,
+                     uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows,
+                     uint32_t row_stride, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 2DGS per-pixel post-processing (reference: gsplat/rendering.py:1519-1552; C++ orchestrator
