@@ -334,8 +334,6 @@ def main():
     exchange_bytes = None
     if distributed:
         from gsplat_amd import distributed as _gd
-
-        _gd.reset_exchange_stats()
     windows_s = [max_over_ranks(elapsed)]
     if args.lean:  # profiling runs: one window only, instrumented
         instrumented_window_s = windows_s[0]
@@ -343,6 +341,8 @@ def main():
         e_i, _, prof = timed(step, args.steps, 0, barrier, profile_only=raster_entries)
         instrumented_window_s = max_over_ranks(e_i)
     prof = {k.replace("_ws", "").replace("_seg", ""): v for k, v in prof.items()}
+    if distributed:
+        _gd.reset_exchange_stats()
     for _ in range(n_windows):
         e_w, _, _ = timed(step, args.steps, 0, barrier)
         windows_s.append(max_over_ranks(e_w))

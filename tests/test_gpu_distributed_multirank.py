@@ -79,9 +79,10 @@ def _worker(rank, port, results, packed, c_local, WORLD):
 
 
 @pytest.mark.parametrize("world,c_local,packed", [(2, 2, False), (2, 1, False), (2, 2, True), (2, 1, True), (3, 2, False),
-                                                  (3, 1, True), (4, 1, False)])
+                                                  (3, 1, True), (4, 1, False), (8, 4, False), (8, 1, True)])
 def test_ranks_sharing_one_gpu_match_the_single_process_render(world, packed, c_local):
-    """world 3: shards of unequal size (1334 / 1334 / 1333 Gaussians); world 4: three peers per rank."""
+    """world 3: shards of unequal size (1334 / 1334 / 1333 Gaussians); world 4: three peers per rank; world 8: the shape of
+    BASELINE.json configs[3] - seven peers per rank, shards of 501 / 500 Gaussians, four cameras per rank (32 in the job)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a ROCm GPU")
     mgr = mp.Manager()
@@ -118,6 +119,34 @@ def test_bench_two_rank_path_rehearsal():
     ref = r["c4_single_gpu"]  # rank 0's single-GPU reference of the same workload, measured after the timed region
     assert ref["value"] > 0 and "120000 synthetic Gaussians" in ref["workload"] and "rank 0" in ref["note"]
     assert r["speedup_vs_1gpu"] == pytest.approx(r["value"] / ref["value"], rel=1e-2) and r["efficiency"] > 0
+
+
+def test_bench_eight_rank_path_rehearsal():
+    """`python bench.py --gpus 8` as the driver's scaling run launches it (c4: 4 cameras per rank, the scene stride-sharded
+    eight ways), rehearsed with the eight ranks sharing this GPU over gloo: the line must carry the all-to-all volume per rank
+    so that a real run can be checked against SURVEY.md section 8(e) (dense rows: 7 peers x C_local N_local rows x 48 B per
+    direction, doubled by the reverse exchange of the 40-byte gradient rows)."""
+    import json
+    import subprocess
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GSPLAT_BENCH_REHEARSAL"] = "1"
+    n_local = 5000
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--gaussians", str(n_local),
+           "--no-extra", "--windows", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["rehearsal"] is True and r["value"] > 0 and r["config"]["cameras_per_gpu"] == 4
+    assert r["config"]["parallelism"] == "gaussian-sharded x8" and len(r["windows_ms"]) == 2
+    # forward: rows to 7 peers, 4 of their cameras each, (7 geometry + 3 colour floats + 2 radii words) = 48 B per row; backward:
+    # the gradient of the 10 payload floats comes back = 40 B per row
+    rows_to_peers = 7 * 4 * n_local
+    assert r["a2a_bytes_per_rank"] == pytest.approx(rows_to_peers * (48 + 40), rel=0.02), r["a2a_bytes_per_rank"]
 
 
 def test_bench_plain_form_launches_its_own_ranks():
@@ -170,3 +199,8 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     other = r["other_layout"]
     assert isinstance(other, dict) and other["packed"] is True and other["ms_per_step"] > 0 and other["value"] > 0
     assert isinstance(r["stage_ms_per_step"], dict) and r["raster_launch_ms"]["fwd"] > 0 and r["raster_launch_ms"]["bwd"] > 0
+    # the driver-specified window first, then its repeats; the forward and the pair the north star quotes next to the backward
+    assert len(r["windows_ms"]) == 7 and r["windows_ms"][0] == pytest.approx(r["ms_per_step"], rel=1e-3)
+    assert r["value_best"] >= r["value_median"] > 0 and r["instrumented_window_ms"] > 0
+    for view in ("fwd", "bwd", "fwd_plus_bwd"):
+        assert 0 < roof[view]["frac"] < 1 and roof[view]["launch_ms"] > 0, view
