@@ -147,19 +147,29 @@ def timed(step_fn, steps, warmup, barrier, profile_only=None):
     return elapsed, meta, prof
 
 
-def smi_state_under_load(step_fn, device_index: int):
+def smi_state_under_load(step_fn, device_index: int, sample: bool, fixed_steps: int = 0):
     """Clock / power state of the GPU WHILE the timed workload runs: `rocm-smi --showclocks --showpower --showmaxpower
     --showperflevel --json` is started and steps are issued until it returns (an idle GPU reports its parked clocks: 94 MHz).
-    Lets a reader separate box-to-box spread (different power cap or clock) from run-to-run noise. None if rocm-smi is absent."""
-    try:
-        proc = subprocess.Popen(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showmaxpower",
-                                 "--showperflevel", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-    except Exception:
-        return None
-    t0 = time.perf_counter()
-    while proc.poll() is None and time.perf_counter() - t0 < 20.0:
-        step_fn()
+    Lets a reader separate box-to-box spread (different power cap or clock) from run-to-run noise. None if rocm-smi is absent.
+    `fixed_steps` > 0 (N > 1): EVERY rank runs exactly that many steps - a step contains collectives, so the ranks must not
+    decide for themselves how many to run - and only the sampling rank (`sample`) starts rocm-smi."""
+    proc = None
+    if sample:
+        try:
+            proc = subprocess.Popen(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showmaxpower",
+                                     "--showperflevel", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        except Exception:
+            proc = None
+    if fixed_steps > 0:
+        for _ in range(fixed_steps):
+            step_fn()
+    elif proc is not None:
+        t0 = time.perf_counter()
+        while proc.poll() is None and time.perf_counter() - t0 < 20.0:
+            step_fn()
     torch.cuda.synchronize()
+    if proc is None:
+        return None
     try:
         out, _ = proc.communicate(timeout=5)
         card = next(iter(json.loads(out).values()))
@@ -348,7 +358,9 @@ def main():
         windows_s.append(max_over_ranks(e_w))
     if distributed and n_windows:
         exchange_bytes = _gd.EXCHANGE_STATS["bytes_to_peers"] / (n_windows * args.steps)
-    smi = smi_state_under_load(step, local_rank) if (rank == 0 and not args.lean) else None
+    smi = None
+    if not args.lean:
+        smi = smi_state_under_load(step, local_rank, sample=(rank == 0), fixed_steps=(max(args.steps, 20) if distributed else 0))
     if distributed:
         dist.barrier()
     # per-stage table: a few extra (untimed) steps with an event pair around every C-ABI call
