@@ -45,8 +45,51 @@ def ssim_map(img1: Tensor, img2: Tensor, window_size: int = 11) -> Tensor:
     return ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
 
 
+class _FusedSsimMean(torch.autograd.Function):
+    """mean(SSIM map) on the MI355X: csrc/ssim.hip (gsx_ssim_fwd / gsx_ssim_bwd), one kernel per direction, images read
+    through their strides (a [B, H, W, C] render permuted to [B, C, H, W] is consumed in place). Differentiable in img1."""
+
+    @staticmethod
+    def forward(ctx, img1: Tensor, img2: Tensor):
+        import ctypes
+
+        from . import _cabi
+
+        B, C, H, W = img1.shape
+        img2 = img2.detach()
+        dev = img1.device
+        partial = torch.empty(_cabi._lib.gsx_ssim_blocks(B, C, H, W), device=dev, dtype=torch.float32)
+        need_grad = img1.requires_grad
+        dmaps = torch.empty((B, C, H, W, 3), device=dev, dtype=torch.float32) if need_grad else None
+        s1, s2 = (ctypes.c_int64 * 4)(*img1.stride()), (ctypes.c_int64 * 4)(*img2.stride())
+        _cabi.call("gsx_ssim_fwd", _cabi.ptr_strided(img1), s1, _cabi.ptr_strided(img2), s2, B, C, H, W, _cabi.ptr(partial),
+                   _cabi.ptr(dmaps))
+        ctx.save_for_backward(img1, img2, dmaps)
+        return partial.sum() / float(B * C * H * W)
+
+    @staticmethod
+    def backward(ctx, v_mean: Tensor):
+        import ctypes
+
+        from . import _cabi
+
+        img1, img2, dmaps = ctx.saved_tensors
+        B, C, H, W = img1.shape
+        v_img1 = torch.empty_strided(img1.shape, img1.stride(), device=img1.device, dtype=torch.float32) \
+            if img1.is_non_overlapping_and_dense() else torch.empty_like(img1, memory_format=torch.contiguous_format)
+        s1, s2, sv = ((ctypes.c_int64 * 4)(*t.stride()) for t in (img1, img2, v_img1))
+        v_mean = v_mean.reshape(1).to(torch.float32).contiguous()  # stays on the device: the kernel multiplies by it
+        _cabi.call("gsx_ssim_bwd", _cabi.ptr_strided(img1), s1, _cabi.ptr_strided(img2), s2, B, C, H, W, _cabi.ptr(dmaps),
+                   1.0 / float(B * C * H * W), _cabi.ptr(v_mean), _cabi.ptr_strided(v_img1), sv)
+        return v_img1, None
+
+
 def ssim_loss(img1: Tensor, img2: Tensor, window_size: int = 11) -> Tensor:
-    """``1 - mean(SSIM)`` (gsplat/losses.py:150-200)."""
+    """``1 - mean(SSIM)`` (gsplat/losses.py:150-200). float32 images on the GPU with the default window take the fused
+    kernels (what the reference gets from the third-party ``fused_ssim`` extension); anything else the torch evaluation."""
+    if (img1.is_cuda and img2.is_cuda and window_size == 11 and img1.dtype == torch.float32 and img2.dtype == torch.float32
+            and img1.dim() == 4 and img1.shape == img2.shape and not img2.requires_grad):
+        return 1.0 - _FusedSsimMean.apply(img1, img2)
     return 1.0 - ssim_map(img1, img2, window_size).mean()
 
 

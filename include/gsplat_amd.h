@@ -729,6 +729,23 @@ int gsx_relocation(const float *opacities, const float *scales, const int32_t *r
 int gsx_mcmc_perturb(float *positions, const float *quats, const float *scales_log, const float *opacities_logit,
                      const float *noise, int64_t n, float noise_scale, float t, float k, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused SSIM loss of the training step. Replaces what gsplat/losses.py:150-200 (ssim_loss)
+ * evaluates - the third-party `fused_ssim` CUDA extension when installed, else torch_ssim_loss: five depthwise 11 x 11
+ * convolutions - with one kernel per direction: 11-tap Gaussian window (sigma 1.5), zero padding, C1 = 0.01^2, C2 = 0.03^2.
+ * Images are [B, C, H, W] addressed through element strides (b, c, h, w), so channels-last renders are read in place.
+ * fwd: partial_sums [gsx_ssim_blocks(B, C, H, W)] = per-workgroup sums of the SSIM map (the caller adds them up and divides
+ * by B C H W); dmaps [B, C, H, W, 3] (or NULL) = d ssim / d (mu1, E[x x], E[x y]) for the backward.
+ * bwd: v_img1 (strides_v) = g * d sum(ssim map) / d img1 with g = dL / d map (a constant for a mean) = grad_scale, times the
+ * device scalar *grad_scale_device when that is given (the incoming gradient of the mean: no host read). */
+int64_t gsx_ssim_blocks(uint32_t B, uint32_t C, uint32_t H, uint32_t W);
+int gsx_ssim_fwd(const float *img1, const int64_t *strides1, const float *img2, const int64_t *strides2, uint32_t B, uint32_t C,
+                 uint32_t H, uint32_t W, float *partial_sums, float *dmaps, void *stream);
+int gsx_ssim_bwd(const float *img1, const int64_t *strides1, const float *img2, const int64_t *strides2, uint32_t B, uint32_t C,
+                 uint32_t H, uint32_t W, const float *dmaps, float grad_scale, const float *grad_scale_device, float *v_img1,
+                 const int64_t *strides_v,
+                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif
