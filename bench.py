@@ -82,7 +82,7 @@ def raster_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("raster3d_fwd.hip", "raster3d_bwd.hip", "raster3d.hpp", "common.hpp"):
+    for f in ("raster3d_fwd.hip", "raster3d_bwd.hip", "tile_order.hip", "raster3d.hpp", "common.hpp"):
         with open(os.path.join(ROOT, "gsplat_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -403,8 +403,9 @@ def main():
     if os.path.exists(tpath):
         try:
             pmc = json.load(open(tpath))
-            # the backward runs as variant T for <= 4 channels (csrc/raster3d_bwd.hip): its counters are filed under that name
-            traffic = (pmc.get(dom + "_t") or pmc.get(dom) or {}).get("bytes")
+            # the backward runs as variant W (or T) for <= 4 channels (csrc/raster3d_bwd.hip): counters are filed under the kernel's name
+            pmc_dom = pmc.get(dom + "_w") or pmc.get(dom + "_t") or pmc.get(dom) or {}
+            traffic = pmc_dom.get("bytes")
             meta_pmc = pmc.get("_meta") or {}
             traffic_src = {"file": "profiles/pmc_traffic.json", "measured_at_commit": meta_pmc.get("commit"),
                            "bench_commit": _git_head(), "kernel_sources": raster_source_hash()}
@@ -424,7 +425,7 @@ def main():
     valu_issue = None
     try:
         rate = json.load(open(os.path.join(ROOT, "profiles", "issue_rate.json")))["summary"]
-        sq = (pmc.get(dom + "_t") or pmc.get(dom) or {}).get("sq") if traffic is not None else None
+        sq = pmc_dom.get("sq") if traffic is not None else None
         if sq and sq.get("SQ_INSTS_VALU") and dom_ms == dom_ms:
             per_simd_ns = sq["SQ_INSTS_VALU"] / N_SIMDS / (dom_ms * 1e6)
             valu_issue = {"valu_instructions_per_launch": int(sq["SQ_INSTS_VALU"]),
