@@ -11,18 +11,17 @@ namespace gsx {
 // pass): on c3 that is 160 entries on average, 49 .. 486 per tile (the full lists: 466 +- 30). Workgroups are dispatched in
 // index order onto a few slots per CU, so in launch order the kernel lasts as long as its unluckiest slot: list scheduling
 // of the measured costs gives 1.23 x the ideal sum / slots at 5 workgroups per CU (variant T) and 1.66 x at 12 one-wave
-// workgroups (variant W), against 1.06 x / 1.09 x longest-first (tools/tile_balance.py). Three small launches build the
-// order: (1) one wave per tile takes the maximum of last_ids over its pixels -> cost, histogram per XCD over cost / 4;
-// (2) one wave per XCD scans its histogram from the top; (3) one thread per tile takes a slot in its bucket. The XCD-aware
-// map is kept: workgroup b still runs on XCD b % 8 and XCD x still owns the contiguous tile range x, only the order INSIDE the
-// range changes (neighbouring tiles share Gaussians: they stay in one XCD's L2). Ties inside a bucket are ordered by atomics:
-// scheduling only, the gradients are accumulated with float atomics in either case.
+// workgroups (variant W), against 1.06 x / 1.09 x longest-first (tools/tile_balance.py). Two small launches build the
+// order: (1) one wave per tile takes the maximum of last_ids over its pixels -> cost; (2) one workgroup per XCD sorts the
+// tiles of its range by cost / 4, descending, entirely in LDS (histogram, scan from the top, one slot per tile). The
+// XCD-aware map is kept: workgroup b still runs on XCD b % 8 and XCD x still owns the contiguous tile range x, only the order
+// INSIDE the range changes (neighbouring tiles share Gaussians: they stay in one XCD's L2). Ties inside a bucket are ordered by
+// LDS atomics: scheduling only, the gradients are accumulated with float atomics in either case.
 constexpr uint32_t kOrderBuckets = 1024; // cost / 4, saturating: lists of up to 4096 staged entries are told apart
 struct TileOrderArgs {
     const int32_t *isect_offsets, *last_ids;
     uint32_t n_images, tile_w, tile_h, width, height, n_isects, n_blocks, per_xcd;
     int32_t *cost;  // [n_blocks]
-    int32_t *hist;  // [8][kOrderBuckets]: histogram, then (in place) the first slot of every bucket
     int32_t *order; // [n_blocks] in xcd_remap() index space
 };
 __global__ void __launch_bounds__(256) tile_order_cost_kernel(const TileOrderArgs a)
@@ -42,42 +41,39 @@ __global__ void __launch_bounds__(256) tile_order_cost_kernel(const TileOrderArg
     if (lane == 0) {
         const int32_t start = a.isect_offsets[blk];
         const int32_t end   = (blk == a.n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
-        const int32_t cost  = max(0, min(end, m + 1) - start);
-        a.cost[blk]         = cost;
-        atomicAdd(&a.hist[(blk / a.per_xcd) * kOrderBuckets + min((uint32_t)cost >> 2, kOrderBuckets - 1u)], 1);
+        a.cost[blk]         = max(0, min(end, m + 1) - start);
     }
 }
-__global__ void __launch_bounds__(512) tile_order_scan_kernel(int32_t *hist)
+// one workgroup per XCD range: bucket sort by cost / 4, most expensive first
+__global__ void __launch_bounds__(1024) tile_order_sort_kernel(const TileOrderArgs a)
 {
-    // wave x: XCD x's buckets from the most expensive down; lane l owns buckets 1023 - 16 l .. 1023 - 16 l - 15
-    const uint32_t lane = threadIdx.x & 63u;
-    int32_t *h = hist + (threadIdx.x >> 6) * kOrderBuckets;
-    int32_t v[16], sum = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        v[j] = h[kOrderBuckets - 1u - (16u * lane + j)];
-        sum += v[j];
-    }
-    int32_t inc = sum;
+    __shared__ int32_t s_hist[kOrderBuckets];
+    __shared__ int32_t s_wave[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t first = blockIdx.x * a.per_xcd, last = min(first + a.per_xcd, a.n_blocks);
+    s_hist[tid] = 0; // kOrderBuckets == blockDim.x
+    __syncthreads();
+    for (uint32_t blk = first + tid; blk < last; blk += 1024u)
+        atomicAdd(&s_hist[min((uint32_t)a.cost[blk] >> 2, kOrderBuckets - 1u)], 1);
+    __syncthreads();
+    // exclusive scan from the top: thread t owns bucket 1023 - t
+    const int32_t mine = s_hist[kOrderBuckets - 1u - tid];
+    int32_t inc        = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int32_t y = __shfl_up(inc, o);
         if ((int)lane >= o) inc += y;
     }
-    int32_t run = inc - sum;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        h[kOrderBuckets - 1u - (16u * lane + j)] = run;
-        run += v[j];
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads();
+    int32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+    s_hist[kOrderBuckets - 1u - tid] = before + inc - mine; // first slot of the bucket
+    __syncthreads();
+    for (uint32_t blk = first + tid; blk < last; blk += 1024u) {
+        const int32_t slot = atomicAdd(&s_hist[min((uint32_t)a.cost[blk] >> 2, kOrderBuckets - 1u)], 1);
+        a.order[first + (uint32_t)slot] = (int32_t)blk;
     }
-}
-__global__ void __launch_bounds__(256) tile_order_scatter_kernel(const TileOrderArgs a)
-{
-    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blk >= a.n_blocks) return;
-    const uint32_t x   = blk / a.per_xcd;
-    const int32_t slot = atomicAdd(&a.hist[x * kOrderBuckets + min((uint32_t)a.cost[blk] >> 2, kOrderBuckets - 1u)], 1);
-    a.order[x * a.per_xcd + (uint32_t)slot] = (int32_t)blk;
 }
 
 } // namespace gsx
@@ -110,17 +106,10 @@ const int32_t *build_tile_order(const int32_t *isect_offsets, const int32_t *las
     TileOrderArgs o{};
     o.isect_offsets = isect_offsets; o.last_ids = last_ids; o.n_images = n_images; o.tile_w = tile_w; o.tile_h = tile_h;
     o.width = width; o.height = height; o.n_isects = n_isects; o.n_blocks = n_blocks; o.per_xcd = (n_blocks + 7u) / 8u;
-    o.hist  = reinterpret_cast<int32_t *>(ws);
-    o.cost  = o.hist + 8 * kOrderBuckets;
+    o.cost  = reinterpret_cast<int32_t *>(ws);
     o.order = o.cost + n_blocks;
-    if (hipMemsetAsync(o.hist, 0, sizeof(int32_t) * 8 * kOrderBuckets, stream) != hipSuccess) {
-        set_last_error("tile order: memset of the histogram failed");
-        *rc = GSX_ERR_LAUNCH;
-        return nullptr;
-    }
     tile_order_cost_kernel<<<dim3((n_blocks + 3u) / 4u), dim3(256), 0, stream>>>(o);
-    tile_order_scan_kernel<<<dim3(1), dim3(512), 0, stream>>>(o.hist);
-    tile_order_scatter_kernel<<<dim3((n_blocks + 255u) / 256u), dim3(256), 0, stream>>>(o);
+    tile_order_sort_kernel<<<dim3((n_blocks + o.per_xcd - 1u) / o.per_xcd), dim3(1024), 0, stream>>>(o);
     *rc = check_launch("tile order");
     return *rc == GSX_OK ? o.order : nullptr;
 }
@@ -128,7 +117,7 @@ const int32_t *build_tile_order(const int32_t *isect_offsets, const int32_t *las
 
 int64_t tile_order_workspace_bytes(uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
 {
-    return (int64_t)sizeof(int32_t) * (2ll * n_images * tile_w * tile_h + 8ll * kOrderBuckets);
+    return (int64_t)sizeof(int32_t) * 2ll * n_images * tile_w * tile_h;
 }
 
 } // namespace gsx

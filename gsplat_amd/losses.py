@@ -75,8 +75,7 @@ class _FusedSsimMean(torch.autograd.Function):
 
         img1, img2, dmaps = ctx.saved_tensors
         B, C, H, W = img1.shape
-        v_img1 = torch.empty_strided(img1.shape, img1.stride(), device=img1.device, dtype=torch.float32) \
-            if img1.is_non_overlapping_and_dense() else torch.empty_like(img1, memory_format=torch.contiguous_format)
+        v_img1 = torch.empty_like(img1)  # preserve_format: a dense permuted view (channels-last render) keeps its strides
         s1, s2, sv = ((ctypes.c_int64 * 4)(*t.stride()) for t in (img1, img2, v_img1))
         v_mean = v_mean.reshape(1).to(torch.float32).contiguous()  # stays on the device: the kernel multiplies by it
         _cabi.call("gsx_ssim_bwd", _cabi.ptr_strided(img1), s1, _cabi.ptr_strided(img2), s2, B, C, H, W, _cabi.ptr(dmaps),

@@ -455,7 +455,7 @@ int gsx_raster3d_bwd(const float *means2d, const float *conics, const float *col
                      int has_abs, float *v_rows, uint32_t row_stride, void *stream);
 /* The same launch with the tiles taken LONGEST-FIRST: what a tile costs the backward is its list up to its last contributor
  * (49 .. 486 entries on the c3 scene around a mean of 160), and in launch order the kernel lasts as long as its unluckiest
- * workgroup slot. With a workspace of gsx_raster3d_bwd_workspace_bytes() three small launches sort the tiles by that cost
+ * workgroup slot. With a workspace of gsx_raster3d_bwd_workspace_bytes() two small launches sort the tiles by that cost
  * (per XCD, so that neighbouring tiles keep sharing an L2) before the compositing launch; results are the same. NULL / too
  * small a workspace, sparse layouts, absgrad, more than four channels: launch order, exactly gsx_raster3d_bwd. */
 int64_t gsx_raster3d_bwd_workspace_bytes(uint32_t n_images, uint32_t tile_w, uint32_t tile_h);

@@ -366,7 +366,11 @@ def test_distributed_single_rank_matches_local(G, packed, force_exchange, monkey
     created = False
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        import socket
+
+        with socket.socket() as sk:  # a free port: this test also runs inside test_gpu_python_bodies' subprocess, concurrently
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         created = True

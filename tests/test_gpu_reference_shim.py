@@ -113,7 +113,10 @@ print("2DGS configurations OK")
 # distributed=True in a 1-rank RCCL group through the reference's Python (gsplat/rendering.py:178-198 hands the default NCCL
 # group's name to the op): must equal the local render (reference tests/test_rasterization.py:819-868)
 import os, torch.distributed as dist
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+import socket
+with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0)); free_port = sk.getsockname()[1]
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(free_port)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 try:
