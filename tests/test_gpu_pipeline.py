@@ -468,3 +468,45 @@ def test_rasterization_takes_split_sh_coefficients(G, packed):
     assert_close_ratio(out["split"][0], out["cat"][0], 1e-5, 1e-6, name="render")
     for nm, x, y in zip(names + ("sh0", "shN"), out["split"][1], out["cat"][1]):
         assert_grad_close(x, y, rel=1e-4, name=f"v_{nm}")
+
+
+def test_concurrent_threads_and_streams_poll_their_own_counts(G):
+    """The intersection count comes back through a pinned host word that the second half of the op polls (csrc/torch_ops.cpp:
+    isect_fused_finish) - no event, no stream synchronisation. Several threads, each on its own stream and its own scene size,
+    run forward + backward passes at the same time: every call must read ITS count (a stale or foreign word would give a wrong
+    number of intersections or a wrong image) and the results must equal the ones computed alone."""
+    import threading
+
+    scenes = []
+    for i, n in enumerate((3000, 5000, 8000, 12000)):
+        sc, W, H = make_scene(N=n, C=1, width=160 + 16 * i, height=112, seed=30 + i)
+        d = {k: v.to(DEV) for k, v in sc.items()}
+        with torch.no_grad():
+            rc, ra, meta = G.rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"], d["Ks"], W, H)
+        scenes.append((d, W, H, rc.clone(), int(meta["isect_ids"].numel())))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(idx):
+        try:
+            d, W, H, want, n_isects = scenes[idx]
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(25):
+                    leaves = {k: d[k].clone().requires_grad_(True) for k in NAMES}
+                    rc, ra, meta = G.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
+                                                   leaves["colors"], d["viewmats"], d["Ks"], W, H)
+                    rc.sum().backward()
+                    assert int(meta["isect_ids"].numel()) == n_isects, (idx, int(meta["isect_ids"].numel()), n_isects)
+                    assert torch.equal(rc.detach(), want), idx
+                    assert torch.isfinite(leaves["means"].grad).all()
+            stream.synchronize()
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append(f"thread {idx}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(scenes))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not errors, "\n".join(errors)
