@@ -12,11 +12,11 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def _replay(packed, C, device):
-    import pin_strategy_against_reference as pin  # the generator's own scene / info / driver (no reference import at module level)
+    from oracle import pin_strategy_against_reference as pin  # the generator's own scene / info / driver (the reference itself is
+    #                                                           only imported inside its main())
 
     from gsplat_amd.strategy import DefaultStrategy
 
