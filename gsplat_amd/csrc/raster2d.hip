@@ -15,6 +15,8 @@
 // Per-sample math (Fwd.cu:356-428): h_u = px w_M - u_M, h_v = py w_M - v_M, zeta = h_u x h_v, s = zeta.xy / zeta.z,
 // G3 = |s|^2, G2 = 2 |mean2d - p|^2, sigma = min(G3, G2) / 2, alpha = min(0.99, opac exp(-sigma)); skip if zeta.z == 0,
 // sigma < 0 or alpha < 1/255; stop (exclusive) if T (1 - alpha) <= 1e-4.
+#include <cstdlib>
+
 #include "raster3d.hpp"
 #include "../../include/gsplat_amd.h"
 
@@ -599,6 +601,317 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
     }
 }
 
+// ---- backward, ONE WAVE PER TILE (the decomposition of variant W in raster3d_bwd.hip) -------------------------------------
+// The kernel above reduces K = 15 + D values per (wave, surfel) pair over the 64 pixels of one 8 x 8 quadrant - 62 of its
+// ~160 VALU instructions per pair, 2.8 pairs per staged surfel on c5 - and combines the four waves of a tile with LDS float
+// atomics between workgroup barriers. Here a tile is one wave64 and a lane owns the same pixel of each quadrant: the K values
+// are first summed over the lane's (up to) four pixels with plain adds and reduced ONCE per (tile, surfel); the totals pass
+// through a 2-slot LDS scratch, and lane c of slot g turns them into column c of the gradient row (the cross products of the
+// ray-transform gradient are linear in nine moments, as above) and adds it to HBM. Wave-private staging (64 surfels per
+// batch, one per lane, rows requested one batch ahead), a 4-bit quadrant mask per staged surfel from the two-stage cull,
+// no __syncthreads, no LDS atomics, no accumulator table; tiles longest-first (tile_order.hip). D <= 4, 16 x 16 tiles, no
+// absgrad - everything else takes the kernel above.
+template <int CH>
+struct Bwd2WCfg {
+    static constexpr int K     = CH + 15;
+    static constexpr int KQ    = (K + 3) / 4;
+    static constexpr int NCOL  = 17 + CH;
+    static constexpr int BATCH = 64;
+    static constexpr int SLOTS = 2;  // surfels per flush: 2 slots x 32 lanes
+    static constexpr int TP    = 24; // floats per slot of the totals scratch (K <= 19)
+    static constexpr size_t smem = (size_t)BATCH * (8 * sizeof(float4)) + sizeof(float) * SLOTS * TP;
+};
+
+template <int CH>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) raster2d_bwd_w_kernel(const Raster2DArgs a)
+{
+    using Cfg           = Bwd2WCfg<CH>;
+    constexpr int K     = Cfg::K;
+    constexpr int KQ    = Cfg::KQ;
+    constexpr int NCOL  = Cfg::NCOL;
+    constexpr int BATCH = Cfg::BATCH;
+    constexpr int SLOTS = Cfg::SLOTS;
+    constexpr int TP    = Cfg::TP;
+    static_assert(CH <= 4, "colours are staged as one float4");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4 *s_A   = reinterpret_cast<float4 *>(smem_raw); // u_M, mean.x
+    float4 *s_B   = s_A + BATCH;                          // v_M, mean.y
+    float4 *s_C   = s_B + BATCH;                          // w_M, opacity
+    float4 *s_N   = s_C + BATCH;                          // normal, flatten id (bits)
+    float4 *s_Za  = s_N + BATCH;                          // evaluation form (stage_surfel)
+    float4 *s_Zb  = s_Za + BATCH;
+    float4 *s_Zc  = s_Zb + BATCH;
+    float4 *s_col = s_Zc + BATCH;                         // colours (zero padded)
+    float *s_tot  = reinterpret_cast<float *>(s_col + BATCH); // [SLOTS][TP] totals of the open slots
+
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
+    const uint32_t n_blocks        = tiles_per_image * a.n_images;
+    const uint32_t slot_idx        = xcd_remap(blockIdx.x, n_blocks);
+    if (slot_idx >= n_blocks) return;
+    const uint32_t blk      = a.tile_order ? (uint32_t)a.tile_order[slot_idx] : slot_idx;
+    const uint32_t image_id = blk / tiles_per_image, tile_id = blk % tiles_per_image;
+    if (a.masks && !a.masks[(size_t)image_id * tiles_per_image + tile_id]) return;
+    const uint32_t tile_x = tile_id % a.tile_w, tile_y = tile_id / a.tile_w;
+    const int32_t range_start = a.isect_offsets[blk];
+    const int32_t list_end    = (blk == n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
+    if (list_end <= range_start) return;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lqx = lane & 7u, lqy = lane >> 3;
+    const int nch = (int)a.cdim;
+    const float tcx = (float)(tile_x * 16u) + 8.0f, tcy = (float)(tile_y * 16u) + 8.0f; // tile centre
+    const float X0 = (float)(tile_x * 16u), Y0 = (float)(tile_y * 16u);                   // tile origin
+    const bool dist = a.v_render_distort != nullptr;
+
+    // per-pixel state, pixel q = this lane's pixel of quadrant q
+    float T[4], behind[4], tail_term[4], v_c[4][CH], v_n[4][3], v_median[4];
+    float v_distort[4], accum_d[4], accum_w[4], accum_d_buffer[4], accum_w_buffer[4], distort_buffer[4];
+    int32_t bin_final[4], median_idx[4], qmax[4];
+    int32_t tile_last = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t lx = ((uint32_t)(q & 1) << 3) | lqx, ly = ((uint32_t)(q >> 1) << 3) | lqy;
+        const uint32_t ox = tile_x * 16u + lx, oy = tile_y * 16u + ly;
+        const bool inside = ox < a.width && oy < a.height;
+        const size_t pix  = inside ? ((size_t)image_id * a.height + oy) * a.width + ox : 0;
+        const float T_fin = inside ? 1.0f - a.render_alphas[pix] : 1.0f;
+        T[q] = T_fin; behind[q] = 0.0f;
+        bin_final[q]  = inside ? a.last_ids[pix] : -1;
+        median_idx[q] = inside ? a.median_ids[pix] : -1;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) v_c[q][k] = (inside && k < nch) ? a.v_render_colors[pix * a.cdim + k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v_n[q][k] = inside ? a.v_render_normals[pix * 3 + k] : 0.0f;
+        const float v_a = inside ? a.v_render_alphas[pix] : 0.0f;
+        v_median[q]     = inside ? a.v_render_median[pix] : 0.0f;
+        float bg_dot    = 0.0f;
+        if (a.backgrounds) {
+            const float *bg = a.backgrounds + (size_t)image_id * a.cdim;
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (k < nch) bg_dot += bg[k] * v_c[q][k];
+        }
+        tail_term[q] = T_fin * (v_a - bg_dot);
+        v_distort[q] = accum_d[q] = accum_w[q] = accum_d_buffer[q] = accum_w_buffer[q] = distort_buffer[q] = 0.0f;
+        if (dist && inside) {
+            v_distort[q]      = a.v_render_distort[pix];
+            accum_d_buffer[q] = a.render_colors[pix * a.cdim + nch - 1];
+            accum_d[q]        = accum_d_buffer[q];
+            accum_w_buffer[q] = a.render_alphas[pix];
+            accum_w[q]        = accum_w_buffer[q];
+        }
+        qmax[q]   = wave_max_i32(bin_final[q]);
+        tile_last = max(tile_last, qmax[q]);
+    }
+    const int32_t range_end = min(list_end, tile_last + 1); // nothing behind the tile's last contributor is needed
+    const int32_t n_batches = (range_end - range_start + BATCH - 1) / BATCH;
+    if (n_batches <= 0) return;
+
+    int slot      = 0; // wave-uniform: open slots
+    int slot_t[2] = {0, 0}; // staged index of the surfel in each slot (wave-uniform)
+
+    // totals of the open slots -> gradient rows: lane (slot g = lane / 32, column c = lane % 32)
+    auto flush = [&](int n_slots) {
+        wave_lds_sync();
+        const int g = (int)(lane >> 5), c = (int)(lane & 31u);
+        if (g < n_slots && c < NCOL) {
+            const int s      = g == 0 ? slot_t[0] : slot_t[1];
+            const float *row = s_tot + g * TP;
+            constexpr int GEO = 17;
+            float val;
+            int col = c;
+            bool put = true;
+            if (c < 2) val = row[CH + 12 + c];                               // v_means2d
+            else if (c == 2) val = row[CH + 14];                             // v_opacities
+            else if (c < 5 || (c >= 8 && c < 17)) {
+                // component k of row r (0 = u_M, 1 = v_M, 2 = w_M) of the ray-transform gradient from the moments;
+                // v_densify (columns 3, 4) = (v_uM.z, v_vM.z) * w_M.z  (see the flush of the kernel above)
+                const int r = c < 5 ? c - 3 : (c - 8) / 3, k = c < 5 ? 2 : (c - 8) % 3;
+                const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+                const float4 A4 = s_A[s], B4 = s_B[s], C4 = s_C[s];
+                auto pick = [](const float4 &q4, int i) { return i == 0 ? q4.x : (i == 1 ? q4.y : q4.z); };
+                const float u1 = pick(A4, k1), u2 = pick(A4, k2), v1 = pick(B4, k1), v2 = pick(B4, k2);
+                const float w1 = pick(C4, k1), w2 = pick(C4, k2);
+                const float s01 = row[CH + 3 + k1], s02 = row[CH + 3 + k2];
+                const float sx1 = X0 * s01 + row[CH + 6 + k1], sx2 = X0 * s02 + row[CH + 6 + k2];
+                const float sy1 = Y0 * s01 + row[CH + 9 + k1], sy2 = Y0 * s02 + row[CH + 9 + k2];
+                if (r == 0) val = (v1 * s02 - v2 * s01) - (w1 * sy2 - w2 * sy1);      // v_uM = v x S0 - w x Sy
+                else if (r == 1) val = (s01 * u2 - s02 * u1) - (sx1 * w2 - sx2 * w1); // v_vM = S0 x u - Sx x w
+                else val = (sx1 * v2 - sx2 * v1) + (u1 * sy2 - u2 * sy1);             // v_wM = Sx x v + u x Sy
+                if (c < 5) val *= C4.z;
+            } else if (c < 8) val = row[CH + (c - 5)];                       // v_normals
+            else {
+                const int k = c - GEO;
+                put = k < nch;
+                val = row[k < CH ? k : 0];
+                col = GEO + k;
+            }
+            if (put) atomic_add_f32(a.v_rows + (size_t)__float_as_int(s_N[s].w) * a.row_stride + col, val);
+        }
+        wave_lds_sync();
+    };
+
+    struct Fetched { float M[9]; float2 xy; float opac, n[3], cv[4]; };
+    auto entry_of = [&](int32_t b) -> int32_t {
+        const int32_t idx = range_end - 1 - BATCH * b - (int32_t)lane;
+        return (b < n_batches && idx >= range_start) ? a.flatten_ids[idx] : -1;
+    };
+    auto fetch = [&](int32_t gi, Fetched &f) {
+        if (gi < 0) return;
+        const float *M = a.ray_transforms + 9 * (size_t)gi;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) f.M[i] = M[i];
+        f.xy   = reinterpret_cast<const float2 *>(a.means2d)[gi];
+        f.opac = a.opacities[gi];
+        const float *n = a.normals + 3 * (size_t)gi;
+        f.n[0] = n[0]; f.n[1] = n[1]; f.n[2] = n[2];
+        const float *cp = a.colors + (size_t)gi * a.cdim;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f.cv[k] = (k < CH && k < nch) ? cp[k] : 0.0f;
+    };
+    int32_t g_cur = entry_of(0), g_nxt = entry_of(1);
+    Fetched f_cur{};
+    fetch(g_cur, f_cur);
+
+    for (int32_t b = 0; b < n_batches; ++b) {
+        const int32_t batch_end = range_end - 1 - BATCH * b;
+        int hitmask             = 0;
+        {
+            const int32_t idx = batch_end - (int32_t)lane;
+            const int32_t gi  = g_cur;
+            const Fetched f   = f_cur;
+            if (gi >= 0) {
+                s_A[lane] = make_float4(f.M[0], f.M[1], f.M[2], f.xy.x);
+                s_B[lane] = make_float4(f.M[3], f.M[4], f.M[5], f.xy.y);
+                s_C[lane] = make_float4(f.M[6], f.M[7], f.M[8], f.opac);
+                s_N[lane] = make_float4(f.n[0], f.n[1], f.n[2], __int_as_float(gi));
+                float4 za, zb, zc;
+                stage_surfel(f.M, f.xy.x, f.xy.y, f.opac, tcx, tcy, za, zb, zc);
+                s_Za[lane] = za; s_Zb[lane] = zb; s_Zc[lane] = zc;
+                s_col[lane] = make_float4(f.cv[0], f.cv[1], f.cv[2], f.cv[3]);
+                const float4 cu = surfel_cull_box(f.M, f.xy.x, f.xy.y, f.opac);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float rcx = (q & 1) ? 4.0f : -4.0f, rcy = (q >> 1) ? 4.0f : -4.0f; // quadrant centre - tile centre
+                    bool hit = idx <= qmax[q] && (fabsf(cu.x - (tcx + rcx)) - 3.5f <= cu.z)
+                            && (fabsf(cu.y - (tcy + rcy)) - 3.5f <= cu.w);
+                    if (hit) hit = surfel_reaches_rect(za, zb, zc, rcx, rcy, 3.5f, 3.5f);
+                    hitmask |= hit ? (1 << q) : 0;
+                }
+            }
+        }
+        g_cur = g_nxt;
+        fetch(g_cur, f_cur); // rows of batch b + 1: in flight while batch b is walked
+        g_nxt = entry_of(b + 2);
+        wave_lds_sync();
+
+        const int32_t behind_s = __builtin_amdgcn_readfirstlane(batch_end);
+        uint64_t todo          = __builtin_amdgcn_ballot_w64(hitmask != 0);
+        while (todo) {
+            const int32_t t = (int32_t)__builtin_ctzll(todo);
+            asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(t));
+            const int qm       = __builtin_amdgcn_readlane(hitmask, t);
+            const float4 Za = s_Za[t], Zb = s_Zb[t], Zc = s_Zc[t];
+            const float4 nr    = s_N[t];
+            const float4 c4    = s_col[t];
+            const float colv[4] = {c4.x, c4.y, c4.z, c4.w};
+            const float nrv[3]  = {nr.x, nr.y, nr.z};
+            const float opac    = Zc.w;
+            const int32_t list_idx = behind_s - t;
+            float sum[KQ * 4];
+#pragma unroll
+            for (int k = 0; k < KQ * 4; ++k) sum[k] = 0.0f;
+            bool contributed = false; // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!(qm & (1 << q))) continue; // scalar
+                const float qx = (float)(((q & 1) << 3) | (int)lqx) - 7.5f, qy = (float)(((q >> 1) << 3) | (int)lqy) - 7.5f;
+                const Surfel sf  = eval_surfel(Za, Zb, Zc, qx, qy);
+                const bool valid = (list_idx <= bin_final[q]) && sf.valid; // outside pixels: bin_final = -1
+                if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+                contributed = true;
+                // branch-free: invalid lanes run with alpha = vis = 0 (every contribution becomes exactly 0)
+                const float alpha = valid ? sf.alpha : 0.0f;
+                const float vis   = valid ? sf.vis : 0.0f;
+                const float ra    = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
+                T[q]             *= ra;
+                const float fac   = alpha * T[q];
+                float cv = 0.0f;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    sum[k] = fmaf(fac, v_c[q][k], sum[k]);
+                    cv     = fmaf(colv[k], v_c[q][k], cv);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    sum[CH + k] = fmaf(fac, v_n[q][k], sum[CH + k]);
+                    cv          = fmaf(nrv[k], v_n[q][k], cv);
+                }
+                float v_alpha    = fmaf(ra, tail_term[q] - behind[q], cv * T[q]);
+                behind[q]        = fmaf(fac, cv, behind[q]);
+                float v_depth_ch = (valid && (list_idx == median_idx[q])) ? v_median[q] : 0.0f; // extra grad of the last channel
+                if (dist) {
+                    float depth = colv[0];
+#pragma unroll
+                    for (int k = 1; k < CH; ++k)
+                        if (k == nch - 1) depth = colv[k];
+                    const float dl_dw = 2.0f * (2.0f * (depth * accum_w_buffer[q] - accum_d_buffer[q]) + (accum_d[q] - depth * accum_w[q]));
+                    v_alpha          += (dl_dw * T[q] - distort_buffer[q] * ra) * v_distort[q];
+                    accum_d_buffer[q] -= fac * depth;
+                    accum_w_buffer[q] -= fac;
+                    distort_buffer[q] += dl_dw * fac;
+                    v_depth_ch        += 2.0f * fac * (2.0f - 2.0f * T[q] - accum_w[q] + fac) * v_distort[q];
+                }
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+                    if (k == nch - 1) sum[k] += v_depth_ch;
+
+                const float ov       = opac * vis;
+                const bool unclamped = valid && (ov <= kMaxAlpha);
+                const float v_G      = unclamped ? opac * v_alpha : 0.0f;
+                const bool use3d     = sf.gw3 <= sf.gw2;
+                const float g3   = use3d ? v_G * -vis : 0.0f;
+                const float a_   = g3 * sf.sx * sf.rcz_inv, b_ = g3 * sf.sy * sf.rcz_inv;
+                const float vrc[3] = {a_, b_, -(a_ * sf.sx + b_ * sf.sy)};
+                const float plx = (float)(((q & 1) << 3) | (int)lqx) + 0.5f, ply = (float)(((q >> 1) << 3) | (int)lqy) + 0.5f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    // g3 == 0 can still meet inf/NaN geometry on invalid lanes: select, do not multiply
+                    const float vr   = (use3d && unclamped) ? vrc[k] : 0.0f;
+                    sum[CH + 3 + k] += vr;
+                    sum[CH + 6 + k]  = fmaf(plx, vr, sum[CH + 6 + k]);
+                    sum[CH + 9 + k]  = fmaf(ply, vr, sum[CH + 9 + k]);
+                }
+                const float g2 = (!use3d && unclamped) ? v_G * (-vis * kFilterInvSquare2DGS) : 0.0f;
+                sum[CH + 12] = fmaf(g2, sf.dx, sum[CH + 12]);
+                sum[CH + 13] = fmaf(g2, sf.dy, sum[CH + 13]);
+                sum[CH + 14] += unclamped ? vis * v_alpha : 0.0f;
+            }
+            if (!contributed) continue;
+            // ONE reduction per (tile, surfel): row r of group j ends up with the total of value 4 j + r
+            float mine = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                const float r = wave_sum4_scatter(sum[4 * j], sum[4 * j + 1], sum[4 * j + 2], sum[4 * j + 3]);
+                if ((int)(lane & 15u) == j) mine = r;
+            }
+            const int vidx = 4 * (int)(lane & 15u) + (int)(lane >> 4);
+            if ((int)(lane & 15u) < KQ && vidx < K) s_tot[slot * TP + vidx] = mine;
+            if (slot == 0) slot_t[0] = t;
+            else slot_t[1] = t;
+            if (++slot == SLOTS) {
+                flush(SLOTS);
+                slot = 0;
+            }
+        }
+        if (slot) { // the staged rows the open slots point into are overwritten by the next batch
+            flush(slot);
+            slot = 0;
+        }
+    }
+}
+
 template <int CH>
 static int launch2_fwd(const Raster2DArgs &a, hipStream_t stream)
 {
@@ -618,6 +931,17 @@ static int launch2_bwd(const Raster2DArgs &a, hipStream_t stream)
     if (n_blocks == 0 || a.n_isects == 0) return GSX_OK;
     const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
     const uint32_t block = a.tile_size <= 8 ? 64u : 256u;
+    if constexpr (!ABS && CH <= 4) {
+        // one wave per tile (GSX_RASTER2D_BWD=r: the reduction kernel below, A/B)
+        static const bool use_w = [] {
+            const char *e = getenv("GSX_RASTER2D_BWD");
+            return !(e && (e[0] == 'r' || e[0] == 'R'));
+        }();
+        if (a.tile_size == 16 && use_w) {
+            raster2d_bwd_w_kernel<CH><<<dim3(grid), dim3(64), Bwd2WCfg<CH>::smem, stream>>>(a);
+            return check_launch("raster2d_bwd_w");
+        }
+    }
     raster2d_bwd_kernel<CH, ABS><<<dim3(grid), dim3(block), Bwd2Cfg<CH, ABS>::smem, stream>>>(a);
     return check_launch("raster2d_bwd");
 }
