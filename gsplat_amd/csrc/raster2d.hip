@@ -610,7 +610,13 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
 // ray-transform gradient are linear in nine moments, as above) and adds it to HBM. Wave-private staging (64 surfels per
 // batch, one per lane, rows requested one batch ahead), a 4-bit quadrant mask per staged surfel from the two-stage cull,
 // no __syncthreads, no LDS atomics, no accumulator table; tiles longest-first (tile_order.hip). D <= 4, 16 x 16 tiles, no
-// absgrad - everything else takes the kernel above.
+// absgrad. Parity-green (tests/test_gpu_variants.py) and selectable (GSX_RASTER2D_BWD=w); not the default, see launch2_bwd.
+#ifndef GSX_BWD2_W_WAVES // 168 VGPRs (three waves per SIMD) spill 51 registers at four channels: two
+#define GSX_BWD2_W_WAVES 2
+#endif
+#ifndef GSX_BWD2_W_STAGE_AHEAD
+#define GSX_BWD2_W_STAGE_AHEAD 1
+#endif
 template <int CH>
 struct Bwd2WCfg {
     static constexpr int K     = CH + 15;
@@ -622,8 +628,8 @@ struct Bwd2WCfg {
     static constexpr size_t smem = (size_t)BATCH * (8 * sizeof(float4)) + sizeof(float) * SLOTS * TP;
 };
 
-template <int CH>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) raster2d_bwd_w_kernel(const Raster2DArgs a)
+template <int CH, bool DIST>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : GSX_BWD2_W_WAVES))) raster2d_bwd_w_kernel(const Raster2DArgs a)
 {
     using Cfg           = Bwd2WCfg<CH>;
     constexpr int K     = Cfg::K;
@@ -662,7 +668,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) ra
     const int nch = (int)a.cdim;
     const float tcx = (float)(tile_x * 16u) + 8.0f, tcy = (float)(tile_y * 16u) + 8.0f; // tile centre
     const float X0 = (float)(tile_x * 16u), Y0 = (float)(tile_y * 16u);                   // tile origin
-    const bool dist = a.v_render_distort != nullptr;
+    constexpr bool dist = DIST; // the distortion loss adds six per-pixel values: its own instantiation (two waves per SIMD)
 
     // per-pixel state, pixel q = this lane's pixel of quadrant q
     float T[4], behind[4], tail_term[4], v_c[4][CH], v_n[4][3], v_median[4];
@@ -932,13 +938,16 @@ static int launch2_bwd(const Raster2DArgs &a, hipStream_t stream)
     const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
     const uint32_t block = a.tile_size <= 8 ? 64u : 256u;
     if constexpr (!ABS && CH <= 4) {
-        // one wave per tile (GSX_RASTER2D_BWD=r: the reduction kernel below, A/B)
+        // GSX_RASTER2D_BWD=w: one wave per tile. NOT the default: on c5 it issues 19 % fewer VALU and half the LDS
+        // instructions than the reduction kernel but needs 246 VGPRs - two waves per SIMD, 75 % VALU issue where the
+        // reduction kernel (five waves) runs at 97 % - and takes the same 1.9 ms (profiles/r08_ab.md #19, #20)
         static const bool use_w = [] {
             const char *e = getenv("GSX_RASTER2D_BWD");
-            return !(e && (e[0] == 'r' || e[0] == 'R'));
+            return e && (e[0] == 'w' || e[0] == 'W');
         }();
         if (a.tile_size == 16 && use_w) {
-            raster2d_bwd_w_kernel<CH><<<dim3(grid), dim3(64), Bwd2WCfg<CH>::smem, stream>>>(a);
+            if (a.v_render_distort) raster2d_bwd_w_kernel<CH, true><<<dim3(grid), dim3(64), Bwd2WCfg<CH>::smem, stream>>>(a);
+            else raster2d_bwd_w_kernel<CH, false><<<dim3(grid), dim3(64), Bwd2WCfg<CH>::smem, stream>>>(a);
             return check_launch("raster2d_bwd_w");
         }
     }
