@@ -91,3 +91,58 @@ def test_raster3d_bwd_variants_match_the_default(variant):
                 continue
             assert_grad_close(torch.from_numpy(alt[f"{i}_{k}"]), torch.from_numpy(v), rel=3e-4, max_bad_ratio=1e-5,
                               name=f"case {i} v_{k}")
+
+
+_SCRIPT_2DGS = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import gsplat_amd
+from test_gpu_variants import run_case_2dgs
+np.savez(sys.argv[1], **run_case_2dgs(gsplat_amd))
+'''
+
+
+def run_case_2dgs(G):
+    from _util import make_scene
+
+    out = {}
+    for tag, (N, C, W, H, mode, distloss, sh) in {"a": (6000, 2, 208, 144, "RGB+ED", True, 3), "b": (30000, 1, 160, 112, "RGB", False, None),
+                                                  "c": (3000, 1, 100, 70, "D", True, None)}.items():
+        sc, W, H = make_scene(N=N, C=C, width=W, height=H, seed=N % 89, sh_degree=sh, scale_range=(0.02, 0.15))
+        names = ("means", "quats", "scales", "opacities", "colors")
+        leaves = {k: sc[k].cuda().clone().requires_grad_(True) for k in names}
+        rc, ra, rn, sn, rd, rm, _ = G.rasterization_2dgs(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
+                                                        leaves["colors"], sc["viewmats"].cuda(), sc["Ks"].cuda(), W, H,
+                                                        sh_degree=sh, render_mode=mode, distloss=distloss)
+        g = torch.Generator().manual_seed(3)
+        w = [torch.randn(t.shape, generator=g).cuda() for t in (rc, ra, rn, rd, rm)]
+        ((rc * w[0]).sum() + (ra * w[1]).sum() + (rn * w[2]).sum() + (rd * w[3]).sum() + (rm * w[4]).sum()).backward()
+        for k in names:
+            if leaves[k].grad is not None:
+                out[f"{tag}_{k}"] = leaves[k].grad.cpu().numpy()
+        out[f"{tag}_render"] = rc.detach().cpu().numpy()
+    return out
+
+
+def test_raster2d_bwd_one_wave_per_tile_matches_the_default():
+    """GSX_RASTER2D_BWD=w (csrc/raster2d.hip: raster2d_bwd_w_kernel, one wave per tile; measured and not the default) must give
+    the gradients of the reduction kernel: RGB+ED with distortion loss and SH, long lists, a single depth channel."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    assert os.environ.get("GSX_RASTER2D_BWD", "") == ""
+    import gsplat_amd
+
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "t.npz")
+        code = _SCRIPT_2DGS % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True,
+                           env=dict(os.environ, GSX_RASTER2D_BWD="w", GSX_RASTER3D_BWD_ORDER="force"), timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        alt = dict(np.load(path))
+    ref = run_case_2dgs(gsplat_amd)
+    assert set(alt) == set(ref)
+    for k, v in ref.items():
+        if k.endswith("_render"):
+            assert np.array_equal(alt[k], v), k
+        else:
+            assert_grad_close(torch.from_numpy(alt[k]), torch.from_numpy(v), rel=3e-4, max_bad_ratio=1e-5, name=k)
