@@ -1,7 +1,7 @@
 """Diagnostic (run on the GPU box): is the forward + backward of one fixed scene bit-reproducible inside a process - before,
 after and WHILE four other threads render other scenes on their own streams? Prints the number of mismatching repeats per phase
 (images, intersection keys, flatten ids, projected means). Written in round 4 after one flaky cross-process comparison in the
-suite (not reproduced: 0 mismatches of 180; the cause was a test that put oracle/ at the head of sys.path)."""
+suite (one process had rendered a different image of the same scene than a fresh one; not reproduced since: 0 mismatches of 180)."""
 import os
 import sys
 import threading
