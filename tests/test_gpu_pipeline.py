@@ -510,3 +510,55 @@ def test_concurrent_threads_and_streams_poll_their_own_counts(G):
     for t in threads:
         t.join(timeout=240)
     assert not errors, "\n".join(errors)
+
+
+@pytest.mark.parametrize("which", ["3dgs_dense", "3dgs_packed", "2dgs"])
+def test_results_do_not_depend_on_what_the_allocator_hands_out(G, which):
+    """Every output and workspace comes from torch's caching allocator (`at::empty`): a fresh process gets zero pages, a
+    long-lived one whatever the previous tensors left behind. Run a step, POISON the allocator's free blocks (tensors of many
+    sizes filled with NaN bit patterns, then freed), run the same step again: images must be bit-identical and gradients equal
+    to atomics' rounding - a kernel that reads memory it never wrote would show NaN or a different image here."""
+    sc, W, H = make_scene(N=20000, C=2, width=208, height=144, seed=12, sh_degree=3)
+    d = {k: v.to(DEV) for k, v in sc.items()}
+    bg = torch.rand(2, 4 if which != "2dgs" else 4, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def step():
+        leaves = {k: d[k].clone().requires_grad_(True) for k in NAMES}
+        if which == "2dgs":
+            out = G.rasterization_2dgs(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
+                                       d["viewmats"], d["Ks"], W, H, sh_degree=3, render_mode="RGB+ED", distloss=True,
+                                       backgrounds=bg)
+            imgs = [out[0], out[1], out[2], out[4], out[5]]
+            loss = out[0].sum() + out[1].sum() + out[2].sum() + out[4].sum()
+        else:
+            rc, ra, meta = G.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
+                                           leaves["colors"], d["viewmats"], d["Ks"], W, H, sh_degree=3, render_mode="RGB+ED",
+                                           packed=(which == "3dgs_packed"), backgrounds=bg, absgrad=False)
+            imgs = [rc, ra, meta["isect_ids"], meta["flatten_ids"]]
+            loss = (rc * rc).sum() + ra.sum()
+        loss.backward()
+        return [t.detach().clone() for t in imgs], [leaves[k].grad.detach().clone() for k in NAMES]
+
+    def poison():
+        junk = []
+        nan_bits = torch.tensor(0x7FC00000, dtype=torch.int32)
+        for shift in range(8, 29):  # 256 B .. 256 MB, two of each size class and a few odd sizes
+            for n in (1 << shift, (1 << shift) + 512, 3 << (shift - 1)):
+                try:
+                    t = torch.empty(n // 4, dtype=torch.int32, device=DEV)
+                except RuntimeError:
+                    continue
+                t.fill_(int(nan_bits))
+                junk.append(t)
+        torch.cuda.synchronize()
+        del junk  # back to the allocator's free lists, still holding the pattern
+
+    base_i, base_g = step()
+    for round_ in range(3):
+        poison()
+        imgs, grads = step()
+        for a, b in zip(imgs, base_i):
+            assert torch.equal(a, b), f"{which}: an output changed after poisoning the allocator (round {round_})"
+        for k, a, b in zip(NAMES, grads, base_g):
+            assert torch.isfinite(a).all(), f"{which}: v_{k} is not finite after poisoning the allocator"
+            assert_grad_close(a.cpu(), b.cpu(), rel=2e-4, max_bad_ratio=1e-5, name=f"{which} v_{k} after poisoning")
