@@ -873,6 +873,24 @@ def rasterize_to_pixels_3dgs(means2d, conics, colors, opacities, backgrounds, ma
     return renders, alphas, holder, last_ids
 
 
+def _pixel_linear_strides(t):
+    """(pixel stride, channel stride) in elements when the float32 tensor t [..., H, W, D] is not contiguous but still
+    addresses pixel p = ((i H) + y) W + x, channel k at p * ps + k * cs (expanded scalars, channel slices of a wider
+    contiguous image, ...); None when it is contiguous or needs a copy."""
+    if t.is_contiguous() or t.dim() < 3:
+        return None
+    shape, stride = t.shape, t.stride()
+    cs, ps = stride[-1], stride[-2]
+    if cs < 0 or ps < 0:
+        return None
+    expect = ps
+    for d in range(t.dim() - 2, -1, -1):
+        if shape[d] != 1 and stride[d] != expect:
+            return None
+        expect *= shape[d]
+    return int(ps), int(cs)
+
+
 @_op("rasterize_to_pixels_3dgs_bwd")
 def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds, masks, tile_offsets, flatten_ids,
                                  render_alphas, last_ids, image_width, image_height, tile_size, absgrad,
@@ -881,7 +899,7 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     means2d, conics, colors, opacities = (means2d.contiguous(), conics.contiguous(), colors.contiguous(),
                                           opacities.contiguous())
     backgrounds, masks = _c(backgrounds), _c(masks)
-    v_render_colors, v_render_alphas = v_render_colors.contiguous(), _c(v_render_alphas)  # None = zeros
+    v_render_alphas = _c(v_render_alphas)  # None = zeros
     # ONE zero-filled array-of-structures buffer [R][6 (+2) + D] (layout: include/gsplat_amd.h, gsx_raster3d_bwd); the
     # gradients the reference returns as separate tensors are COLUMN VIEWS of it. A Gaussian's gradients share a cache
     # line, which is what makes the kernel's atomic flush cheap; projection_ewa_3dgs_*_bwd reads the views in place.
@@ -889,8 +907,15 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     geo = 8 if absgrad else 6
     rows = torch.zeros((R, geo + D), device=means2d.device, dtype=means2d.dtype)
     longest = _consume_long_tile_hint() or _lookup_longest(flatten_ids)  # set by the autograd formula around this call
-    if (longest > SEG_MIN_LONGEST and not absgrad and D <= 4 and tile_size == 16
-            and longest > _seg_cut(flatten_ids.numel(), I, tw, th)):
+    segmented = (longest > SEG_MIN_LONGEST and not absgrad and D <= 4 and tile_size == 16
+                 and longest > _seg_cut(flatten_ids.numel(), I, tw, th))
+    # autograd hands cotangents over as views (the gradient of sum() is ONE float expanded to [.., H, W, D]): the per-tile
+    # launch reads any layout that is linear in the pixel index in place instead of materialising 4 D bytes per pixel
+    vrc_strides = None if segmented else _pixel_linear_strides(v_render_colors)
+    if vrc_strides is None:
+        v_render_colors = v_render_colors.contiguous()
+        vrc_strides = (-1, 1)
+    if segmented:
         ws = torch.empty(_cabi._lib.gsx_raster3d_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN),
                          device=means2d.device, dtype=torch.uint8)
         call("gsx_raster3d_bwd_seg", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
@@ -902,8 +927,9 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
         ws = torch.empty(_cabi._lib.gsx_raster3d_bwd_workspace_bytes(I, tw, th), device=means2d.device, dtype=torch.uint8)
         call("gsx_raster3d_bwd_ws", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
              ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
-             ptr(last_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
-             image_width, image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D, ptr(ws), ws.numel())
+             ptr(last_ids.contiguous()), ptr_strided(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
+             image_width, image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D, vrc_strides[0],
+             vrc_strides[1], ptr(ws), ws.numel())
     v_means2d, v_conics = rows[:, 0:2].view(means2d.shape), rows[:, 2:5].view(conics.shape)
     v_opacities, v_colors = rows[:, 5].view(opacities.shape), rows[:, geo:].view(colors.shape)
     v_abs = rows[:, 6:8].view(means2d.shape) if absgrad else None

@@ -34,6 +34,7 @@
 // of the reference (stable sort on the key).
 // Compiled with -ffp-contract=off (the walk must be bit-exact with the oracle; isect_walk.hpp / isect_binwalk.hpp).
 #include "isect_binwalk.hpp"
+#include "bitonic64.hpp"
 #include "isect_fused.hpp"
 #include <cstdlib>
 
@@ -85,6 +86,7 @@ struct BinArgs {
     int32_t *vals_out;
     uint2 *bucketed;
     uint32_t dbg; // GSX_ISECT_DBG ablation bits (timing experiments only; outputs are wrong when set)
+    uint32_t sort_int; // GSX_ISECT_SORT=int: every list on the integer network
 };
 
 __device__ __forceinline__ void bn_chunk_rows(const BinGeom &g, uint32_t chunk, int64_t &lo, int64_t &hi, uint32_t &img)
@@ -408,86 +410,8 @@ __global__ void __launch_bounds__(1024) tile_plan_kernel(const BinArgs a)
 }
 
 // ---- G: per bin: deal the entries to the tiles' LDS lists, one wave sorts each list, write ---------------------------------
-__device__ __forceinline__ int bn_phys(int i) { return i + (i >> 3); }
-__device__ __forceinline__ void bn_cmpx(uint64_t &x, uint64_t &y, bool up)
-{
-    const bool sw     = (x > y) == up;
-    const uint64_t lo = sw ? y : x, hi = sw ? x : y;
-    x = lo;
-    y = hi;
-}
-
-// Bitonic sort of s[0 .. P) (P a power of two >= 64, words at bn_phys) by NT threads with rank `tid`; SYNC() orders the LDS
-// traffic between the steps (a workgroup barrier, or nothing but a compiler fence when one wave owns the array).
-// Phases k = 2, 4, 8 run in registers on 8 consecutive words; every later phase is cut into groups of three strides for
-// which a thread owns all 8 words (see tile_sort.hip: 512 entries in 16 round trips instead of 45).
-// ascending compare-exchange: the select masks come straight from the vector compare (a mask that passes through the scalar
-// unit first - e.g. xor-ed with a per-lane direction flag - stalls every dependent v_cndmask on gfx950)
-__device__ __forceinline__ void bn_cmpx_up(uint64_t &x, uint64_t &y)
-{
-    const bool sw    = x > y;
-    const uint64_t t = sw ? y : x;
-    y                = sw ? x : y;
-    x                = t;
-}
-
-template <int G, int NT>
-__device__ __forceinline__ void bn_group(uint64_t *s, int P, int lk, int lj, int tid)
-{
-    constexpr int R = 1 << G;
-    for (int t = tid; t < (P >> G); t += NT) {
-        const int i = ((t >> lj) << (lj + G)) | (t & ((1 << lj) - 1));
-        // a descending block is an ascending one on the complemented words: m = all ones where (i & k) != 0
-        const uint32_t m32 = 0u - (((uint32_t)i >> lk) & 1u);
-        const uint64_t m   = ((uint64_t)m32 << 32) | m32;
-        uint64_t e[R];
-#pragma unroll
-        for (int b = 0; b < R; ++b) e[b] = s[bn_phys(i | (b << lj))] ^ m;
-#pragma unroll
-        for (int q = G - 1; q >= 0; --q)
-#pragma unroll
-            for (int b = 0; b < R; ++b)
-                if (!(b & (1 << q))) bn_cmpx_up(e[b], e[b | (1 << q)]);
-#pragma unroll
-        for (int b = 0; b < R; ++b) s[bn_phys(i | (b << lj))] = e[b] ^ m;
-    }
-}
-
-template <int NT, typename Sync>
-__device__ __forceinline__ void bn_bitonic(uint64_t *s, int lp, int tid, Sync &&SYNC)
-{
-    const int P = 1 << lp;
-    for (int t = tid; t < (P >> 3); t += NT) {
-        uint64_t e[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) e[b] = s[bn_phys(8 * t + b)];
-#pragma unroll
-        for (int lk = 1; lk <= 3; ++lk)
-#pragma unroll
-            for (int q = lk - 1; q >= 0; --q)
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (!(b & (1 << q))) {
-                        const bool up = lk < 3 ? ((b & (1 << lk)) == 0) : ((t & 1) == 0); // ((8 t + b) & k) == 0
-                        bn_cmpx(e[b], e[b | (1 << q)], up);
-                    }
-#pragma unroll
-        for (int b = 0; b < 8; ++b) s[bn_phys(8 * t + b)] = e[b];
-    }
-    SYNC();
-    for (int lk = 4; lk <= lp; ++lk) {
-        for (int top = lk - 1; top >= 0;) {
-            const int gsz = top + 1 < 3 ? top + 1 : 3;
-            const int lj  = top - gsz + 1;
-            if (gsz == 3) bn_group<3, NT>(s, P, lk, lj, tid);
-            else if (gsz == 2) bn_group<2, NT>(s, P, lk, lj, tid);
-            else bn_group<1, NT>(s, P, lk, lj, tid);
-            SYNC();
-            top -= gsz;
-        }
-    }
-}
-
+// The network is bitonic64.hpp's: on the keys as doubles (v_min_f64 / v_max_f64) unless a list holds a depth that does not
+// order like a positive normal double (the deal loop flags it) - that list takes the integer network.
 constexpr int kArenaPerWave = 512; // arena sort words per tile-wave: 16 waves -> 8192 words (+ 1/8 padding) = 72 KiB
 
 __global__ void __launch_bounds__(1024) bin_sort_kernel(const BinArgs a)
@@ -498,6 +422,7 @@ __global__ void __launch_bounds__(1024) bin_sort_kernel(const BinArgs a)
     const int arena_words = kArenaPerWave * n_bits;
     uint64_t *s_arena = reinterpret_cast<uint64_t *>(smem_raw); // [arena_words + arena_words / 8]
     __shared__ int32_t s_tcnt[16], s_goff[16], s_base[16], s_batch[16], s_cur[16], s_nbatch, s_n;
+    __shared__ uint32_t s_odd; // bit t: tile t's list holds a key the f64 network cannot order (bt_key_is_odd)
     __shared__ uint64_t s_hi[16];
     const uint32_t bin = blockIdx.x;
     const int32_t e0 = a.b.bin_start[bin], e1 = a.b.bin_start[bin + 1];
@@ -539,6 +464,7 @@ __global__ void __launch_bounds__(1024) bin_sort_kernel(const BinArgs a)
     const int n_batch = s_nbatch;
     for (int b = 0; b < n_batch; ++b) {
         if (threadIdx.x < 16) s_cur[threadIdx.x] = 0;
+        if (threadIdx.x == 16) s_odd = a.sort_int ? 0xFFFFu : 0u;
         uint32_t bmask = 0;
         for (int t = 0; t < n_bits; ++t) bmask |= (s_batch[t] == b) ? (1u << t) : 0u;
         __syncthreads();
@@ -548,11 +474,12 @@ __global__ void __launch_bounds__(1024) bin_sort_kernel(const BinArgs a)
             if (m == 0u) continue;
             const uint2 pr     = a.b.e_pair[e];
             const uint64_t key = ((uint64_t)pr.x << 32) | pr.y;
+            if (bt_key_is_odd(pr.x)) atomicOr(&s_odd, m);
             while (m) {
                 const int t = __builtin_ctz(m);
                 m &= m - 1u;
                 const int32_t pos = atomicAdd(&s_cur[t], 1);
-                s_arena[s_base[t] + bn_phys(pos)] = key;
+                s_arena[s_base[t] + bt_phys(pos)] = key;
             }
         }
         __syncthreads();
@@ -561,13 +488,17 @@ __global__ void __launch_bounds__(1024) bin_sort_kernel(const BinArgs a)
             const int n  = s_tcnt[wave];
             int lp = 6;
             while ((1 << lp) < n) ++lp;
-            for (int i = n + lane; i < (1 << lp); i += 64) sw[bn_phys(i)] = ~0ull;
+            const bool as_int = (s_odd >> wave) & 1u; // wave-uniform
+            const uint64_t pad = as_int ? kBtPadInt : kBtPadF64;
+            for (int i = n + lane; i < (1 << lp); i += 64) sw[bt_phys(i)] = pad;
             wave_lds_sync();
-            if (!(a.dbg & 1u)) bn_bitonic<64>(sw, lp, lane, [] { wave_lds_sync(); });
+            if (a.dbg & 1u) {
+            } else if (as_int) bt_sort_int<64>(sw, lp, lane, [] { wave_lds_sync(); });
+            else bt_sort_f64<64>(sw, lp, lane, [] { wave_lds_sync(); });
             const int64_t off = s_goff[wave];
             const uint64_t hi = s_hi[wave];
             for (int i = lane; i < n; i += 64) {
-                const uint64_t w    = sw[bn_phys(i)];
+                const uint64_t w    = sw[bt_phys(i)];
                 a.keys_out[off + i] = hi | (w >> 32);
                 a.vals_out[off + i] = (int32_t)(uint32_t)w;
             }
@@ -717,6 +648,7 @@ static int binned_setup(const char *fn, BinArgs &a, int64_t rows, uint32_t n_ima
     GSX_REQUIRE(bin_geometry(a.g, rows, n_images, tile_size, tile_w, tile_h, bin_cap_entries(rows)),
                 "%s: %u images x %u x %u tiles not supported", fn, n_images, tile_w, tile_h);
     if (const char *e = getenv("GSX_ISECT_DBG")) a.dbg = (uint32_t)atoi(e);
+    a.sort_int = bitonic_f64_enabled() ? 0u : 1u;
     // skew abort: 3/4 of the sort arena's words (a c3 bin of 4x2 tiles holds ~1400 entries, its longest ~1700); not when the
     // path was forced (tests drive the big-list code with it); GSX_ISECT_BIN_SKEW overrides (0 = never)
     {

@@ -84,6 +84,7 @@ struct TileSortArgs {
     uint2 *scratch;        // [n] ping-pong for oversized tiles
     int32_t *big_count;    // number of tiles longer than kCapSmall (filled by the MODE 0 launch)
     int32_t *big_list;     // [n_bins] their bin ids
+    int32_t sort_int;      // GSX_ISECT_SORT=int: every list on the integer network (bitonic64.hpp)
 };
 
 int launch_fused_count_hist(const FusedArgs &a, hipStream_t s);

@@ -45,7 +45,9 @@ struct Raster3DArgs {
     float *render_alphas; // [I, H, W, 1]
     int32_t *last_ids;    // [I, H, W]
     // backward inputs
-    const float *v_render_colors; // [I, H, W, cdim]
+    const float *v_render_colors; // [I, H, W, cdim]; vrc_strided: element (pixel p, channel k) at p * vrc_ps + k * vrc_cs
+    uint32_t vrc_strided;
+    int64_t vrc_ps, vrc_cs;
     const float *v_render_alphas; // [I, H, W, 1]
     // backward output (zero-initialised by the caller; accumulated with atomics): ONE array-of-structures buffer
     // [R][row_stride]; row = (v_mean2d.x, v_mean2d.y, v_conic.a, v_conic.b, v_conic.c, v_opacity,
@@ -92,6 +94,14 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n_blocks)
 // Which tile does this workgroup own, which slice of the sorted intersection list, and which output row does this lane
 // write? Dense: tile = block, row = pixel index in the [I, H, W] image. Sparse: tile = active_tiles[block], list slice from
 // the per-active-tile offsets, row = pixel_map[first row of the tile + rank of the lane's pixel among the set bits].
+// index of cotangent (pixel row `pix`, channel k) in v_render_colors: contiguous rows of cdim floats, or any layout that is
+// linear in the pixel index (an expanded scalar - the gradient of sum() - has both strides 0)
+template <typename Args>
+__device__ __forceinline__ size_t vrc_index(const Args &a, size_t pix, uint32_t k)
+{
+    return a.vrc_strided ? (size_t)((int64_t)pix * a.vrc_ps + (int64_t)k * a.vrc_cs) : pix * a.cdim + k;
+}
+
 struct TileCtx {
     uint32_t image_id, tile_id, tile_x, tile_y;
     int32_t range_start, range_end;

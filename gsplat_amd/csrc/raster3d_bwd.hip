@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
     float v_c[CH], buffer[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
-        v_c[k]    = (inside && k < (int)a.nch) ? a.v_render_colors[pix * a.cdim + a.ch_off + k] : 0.0f;
+        v_c[k]    = (inside && k < (int)a.nch) ? a.v_render_colors[vrc_index(a, pix, a.ch_off + (uint32_t)k)] : 0.0f;
         buffer[k] = 0.0f;
     }
     // alpha-gradient term and background term belong to exactly one channel chunk / all chunks resp.
@@ -401,7 +401,7 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
     if (n_batches <= 0) return; // uniform: no pixel of the tile has a contributor
     float v_c[CH];
 #pragma unroll
-    for (int k = 0; k < CH; ++k) v_c[k] = (inside && k < (int)a.nch) ? a.v_render_colors[pix * a.cdim + a.ch_off + k] : 0.0f;
+    for (int k = 0; k < CH; ++k) v_c[k] = (inside && k < (int)a.nch) ? a.v_render_colors[vrc_index(a, pix, a.ch_off + (uint32_t)k)] : 0.0f;
     const float v_a = (inside && a.first_chunk && a.v_render_alphas) ? a.v_render_alphas[pix] : 0.0f;
     float bg_dot    = 0.0f;
     if (a.backgrounds) {
@@ -763,7 +763,7 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
         behind[q]          = 0.0f;
         bin_final[q]       = inside ? a.last_ids[pix] : -1;
 #pragma unroll
-        for (int k = 0; k < CH; ++k) v_c[q][k] = (inside && k < (int)a.nch) ? a.v_render_colors[pix * a.cdim + a.ch_off + k] : 0.0f;
+        for (int k = 0; k < CH; ++k) v_c[q][k] = (inside && k < (int)a.nch) ? a.v_render_colors[vrc_index(a, pix, a.ch_off + (uint32_t)k)] : 0.0f;
         const float v_a = (inside && a.first_chunk && a.v_render_alphas) ? a.v_render_alphas[pix] : 0.0f;
         float bg_dot    = 0.0f;
         if (a.backgrounds) {
@@ -1156,18 +1156,21 @@ extern "C" int gsx_raster3d_bwd(
 {
     return gsx_raster3d_bwd_ws(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas,
                                last_ids, v_render_colors, v_render_alphas, n_images, n_isects, cdim, width, height, tile_size,
-                               tile_w, tile_h, has_abs, v_rows, row_stride, nullptr, 0, stream);
+                               tile_w, tile_h, has_abs, v_rows, row_stride, -1, 1, nullptr, 0, stream);
 }
 
 // gsx_raster3d_bwd with a workspace (gsx_raster3d_bwd_workspace_bytes): the launch then takes the tiles longest-first (see
 // "longest tiles first" above). Same results; without a workspace the tiles run in launch order.
+// v_colors_pixel_stride >= 0: v_render_colors is not [I, H, W, cdim]-contiguous but linear in the pixel index p = (i H + y) W + x:
+// element (p, k) at p * pixel_stride + k * channel_stride floats (autograd hands over expanded or sliced cotangents as
+// views: the gradient of sum() has both strides 0); -1: contiguous.
 extern "C" int gsx_raster3d_bwd_ws(
     const float *means2d, const float *conics, const float *colors, const float *opacities,
     const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
     const float *render_alphas, const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
     uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
-    uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows, uint32_t row_stride, void *workspace,
-    int64_t workspace_bytes, void *stream)
+    uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows, uint32_t row_stride, int64_t v_colors_pixel_stride,
+    int64_t v_colors_channel_stride, void *workspace, int64_t workspace_bytes, void *stream)
 {
     using namespace gsx;
     GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster3d_bwd: tile_size must be in [1,16], got %u", tile_size);
@@ -1187,6 +1190,10 @@ extern "C" int gsx_raster3d_bwd_ws(
     a.render_alphas = const_cast<float *>(render_alphas); a.last_ids = const_cast<int32_t *>(last_ids);
     a.v_render_colors = v_render_colors; a.v_render_alphas = v_render_alphas;
     a.v_rows = v_rows; a.row_stride = row_stride;
+    if (v_colors_pixel_stride >= 0) { // cotangents read in place from a layout that is linear in the pixel index
+        GSX_REQUIRE(v_colors_channel_stride >= 0, "gsx_raster3d_bwd_ws: negative channel stride");
+        a.vrc_strided = 1u; a.vrc_ps = v_colors_pixel_stride; a.vrc_cs = v_colors_channel_stride;
+    }
     if (!has_abs && cdim <= 4 && bwd_variant() != 'r') { // the launches that read the order: variants T and W
         int rc       = GSX_OK;
         a.tile_order = a.sp_active_tiles ? nullptr

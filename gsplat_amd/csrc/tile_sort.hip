@@ -20,8 +20,10 @@
 //                     through global ping-pong buffers (rare; correct, slower). Either way the output does not depend
 //                     on the arrival order produced by C.
 // HBM traffic: read 12 B + write 8 B (C) + read 8 B + write 12 B (D) per pair = 40 B instead of 144 B.
-#include "common.hpp"
+#include "bitonic64.hpp"
 #include "isect_fused.hpp"
+#include <cstdlib>
+#include <cstring>
 
 namespace gsx {
 
@@ -195,49 +197,10 @@ __device__ __forceinline__ void fix_ties(Ptr a, int n)
     __syncthreads();
 }
 
-// Small tiles (n <= kCapSmall): bitonic sort of the 64-bit (depth bits, flatten id) words in LDS. The id in the low half
-// makes exact depth ties come out in ascending id order, so no tie pass is needed. Longer tiles are appended to the work
-// list for the radix kernel below.
-//
-// The network is LDS-bandwidth bound (one read + write of the whole array per stride when done stride by stride: 45
-// round trips for 512 entries), so each thread resolves up to THREE consecutive strides per round trip on eight words
-// held in registers: the phases k = 2, 4, 8 run entirely in registers on 8 consecutive words, and every later phase
-// (strides k/2 ... 1) is cut into groups of three strides (j, j/2, j/4): a thread owns the 8 words i | b * (j/4),
-// b = 0..7, for which all three compare-exchange levels are internal. 512 entries: 16 round trips instead of 45.
-// Words live at ts_phys(i) = i + i/8 (one pad word per eight), which spreads the 8-word-strided accesses of the lowest
-// group over the banks.
-constexpr int kTsGroup = 3;
+// Small tiles (n <= kCapSmall): bitonic sort of the 64-bit (depth bits, flatten id) words in LDS (bitonic64.hpp). The id in
+// the low half makes exact depth ties come out in ascending id order, so no tie pass is needed. Longer tiles are appended to
+// the work list for the radix kernel below.
 constexpr int kTsSmallWords = kCapSmall + kCapSmall / 8;
-__device__ __forceinline__ int ts_phys(int i) { return i + (i >> 3); }
-__device__ __forceinline__ void ts_cmpx(uint64_t &x, uint64_t &y, bool up)
-{
-    const bool sw     = (x > y) == up;
-    const uint64_t lo = sw ? y : x, hi = sw ? x : y;
-    x = lo;
-    y = hi;
-}
-
-// strides 2^(lj+G-1) ... 2^lj of phase k on 2^G words per thread
-template <int G>
-__device__ __forceinline__ void bitonic_group(uint64_t *s, int P, int k, int lj)
-{
-    constexpr int R = 1 << G;
-    for (int t = threadIdx.x; t < (P >> G); t += kTsThreads) {
-        const int i   = ((t >> lj) << (lj + G)) | (t & ((1 << lj) - 1));
-        const bool up = (i & k) == 0;
-        uint64_t e[R];
-#pragma unroll
-        for (int b = 0; b < R; ++b) e[b] = s[ts_phys(i | (b << lj))];
-#pragma unroll
-        for (int q = G - 1; q >= 0; --q)
-#pragma unroll
-            for (int b = 0; b < R; ++b)
-                if (!(b & (1 << q))) ts_cmpx(e[b], e[b | (1 << q)], up);
-#pragma unroll
-        for (int b = 0; b < R; ++b) s[ts_phys(i | (b << lj))] = e[b];
-    }
-    __syncthreads();
-}
 
 __global__ void __launch_bounds__(kTsThreads) tile_sort_small_kernel(const TileSortArgs a)
 {
@@ -256,51 +219,36 @@ __global__ void __launch_bounds__(kTsThreads) tile_sort_small_kernel(const TileS
     while ((1 << lp) < n) ++lp;
     const int P = 1 << lp;
     const uint2 *g_in = a.bucketed + start;
-    for (int i = threadIdx.x; i < P; i += kTsThreads) {
-        uint64_t w = ~0ull;
+    // the thread's words wait in registers until the workgroup knows which network sorts them (the pad differs)
+    constexpr int kPer = kCapSmall / kTsThreads;
+    uint64_t w[kPer];
+    bool odd = a.sort_int != 0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int i = (int)threadIdx.x + u * kTsThreads;
+        w[u]        = 0ull;
         if (i < n) {
             const uint2 e = g_in[i];
-            w = ((uint64_t)e.x << 32) | e.y;
-        }
-        s[ts_phys(i)] = w;
-    }
-    __syncthreads();
-    // phases k = 2, 4, 8 on 8 consecutive words per thread
-    for (int t = threadIdx.x; t < (P >> 3); t += kTsThreads) {
-        uint64_t e[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) e[b] = s[ts_phys(8 * t + b)];
-#pragma unroll
-        for (int lk = 1; lk <= 3; ++lk)
-#pragma unroll
-            for (int q = lk - 1; q >= 0; --q)
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (!(b & (1 << q))) {
-                        const bool up = lk < 3 ? ((b & (1 << lk)) == 0) : ((t & 1) == 0); // ((8 t + b) & k) == 0
-                        ts_cmpx(e[b], e[b | (1 << q)], up);
-                    }
-#pragma unroll
-        for (int b = 0; b < 8; ++b) s[ts_phys(8 * t + b)] = e[b];
-    }
-    __syncthreads();
-    for (int lk = 4; lk <= lp; ++lk) {
-        const int k = 1 << lk;
-        for (int top = lk - 1; top >= 0;) { // log2 of the largest stride still to do in this phase
-            const int g = top + 1 < kTsGroup ? top + 1 : kTsGroup;
-            const int lj = top - g + 1;
-            if (g == 3) bitonic_group<3>(s, P, k, lj);
-            else if (g == 2) bitonic_group<2>(s, P, k, lj);
-            else bitonic_group<1>(s, P, k, lj);
-            top -= g;
+            w[u]          = ((uint64_t)e.x << 32) | e.y;
+            odd |= bt_key_is_odd(e.x);
         }
     }
+    const bool as_int  = __syncthreads_or(odd);
+    const uint64_t pad = as_int ? kBtPadInt : kBtPadF64;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int i = (int)threadIdx.x + u * kTsThreads;
+        if (i < P) s[bt_phys(i)] = i < n ? w[u] : pad;
+    }
+    __syncthreads();
+    if (as_int) bt_sort_int<kTsThreads>(s, lp, (int)threadIdx.x, [] { __syncthreads(); });
+    else bt_sort_f64<kTsThreads>(s, lp, (int)threadIdx.x, [] { __syncthreads(); });
     const uint64_t tile = bin % a.n_tiles, img = bin / a.n_tiles;
     const uint64_t hi   = ((img << a.tile_bits) | tile) << 32;
     for (int i = threadIdx.x; i < n; i += kTsThreads) {
-        const uint64_t w      = s[ts_phys(i)];
-        a.keys_out[start + i] = hi | (w >> 32);
-        a.vals_out[start + i] = (int32_t)(uint32_t)w;
+        const uint64_t v      = s[bt_phys(i)];
+        a.keys_out[start + i] = hi | (v >> 32);
+        a.vals_out[start + i] = (int32_t)(uint32_t)v;
     }
 }
 
@@ -363,6 +311,12 @@ __global__ void __launch_bounds__(kWlWaves * 64) tile_sort_kernel(const TileSort
 }
 
 static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+bool bitonic_f64_enabled() // read per call: the tests switch it inside one process
+{
+    const char *e = getenv("GSX_ISECT_SORT");
+    return !(e && strcmp(e, "int") == 0);
+}
 
 static uint32_t ts_chunks(int64_t n)
 {
@@ -507,6 +461,7 @@ extern "C" int gsx_isect_tile_sort(const int64_t *isect_ids, const int32_t *flat
     }
     hipStream_t s = (hipStream_t)stream;
     TileSortArgs a{};
+    a.sort_int = bitonic_f64_enabled() ? 0 : 1;
     a.keys_in = reinterpret_cast<const uint64_t *>(isect_ids);
     a.vals_in = flatten_ids;
     a.n = n_isects; a.n_tiles = n_tiles; a.tile_bits = bits_for(n_tiles); a.n_bins = n_bins;
@@ -636,6 +591,7 @@ extern "C" int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *ra
         return GSX_ERR_WORKSPACE;
     }
     TileSortArgs a{};
+    a.sort_int = bitonic_f64_enabled() ? 0 : 1;
     a.n = n_isects; a.n_tiles = n_tiles; a.tile_bits = bits_for(n_tiles); a.n_bins = n_bins;
     a.n_chunks = 1; // table_scanned[bin * 1] = start of segment `bin`
     a.table_scanned = const_cast<int32_t *>(isect_offsets);

@@ -742,7 +742,8 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
                                   masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
                                   cp<int32_t>(flat), fp(ra), cp<int32_t>(li), fp(v_rc), fp(v_ra), (uint32_t)r.I, (uint32_t)flat.numel(),
                                   (uint32_t)r.D, (uint32_t)width, (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th,
-                                  absgrad ? 1 : 0, mp<float>(rows), (uint32_t)(geo + r.D), ws.mutable_data_ptr(), ws.numel(), L.stream),
+                                  absgrad ? 1 : 0, mp<float>(rows), (uint32_t)(geo + r.D), (int64_t)-1, (int64_t)1, ws.mutable_data_ptr(), ws.numel(),
+                                  L.stream),
               "gsx_raster3d_bwd");
     }
     Tensor v_means2d = rows.slice(1, 0, 2).view(means2d.sizes()), v_conics = rows.slice(1, 2, 5).view(conics.sizes());

@@ -457,7 +457,10 @@ int gsx_raster3d_bwd(const float *means2d, const float *conics, const float *col
  * (49 .. 486 entries on the c3 scene around a mean of 160), and in launch order the kernel lasts as long as its unluckiest
  * workgroup slot. With a workspace of gsx_raster3d_bwd_workspace_bytes() two small launches sort the tiles by that cost
  * (per XCD, so that neighbouring tiles keep sharing an L2) before the compositing launch; results are the same. NULL / too
- * small a workspace, sparse layouts, absgrad, more than four channels: launch order, exactly gsx_raster3d_bwd. */
+ * small a workspace, sparse layouts, absgrad, more than four channels: launch order, exactly gsx_raster3d_bwd.
+ * v_colors_pixel_stride >= 0: v_render_colors is read in place from a layout that is linear in the pixel index
+ * p = (image * height + y) * width + x - element (p, k) at p * v_colors_pixel_stride + k * v_colors_channel_stride floats
+ * (autograd hands cotangents over as views: the gradient of sum() is one float with both strides 0); -1 = contiguous. */
 int64_t gsx_raster3d_bwd_workspace_bytes(uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
 int gsx_raster3d_bwd_ws(const float *means2d, const float *conics, const float *colors, const float *opacities,
                      const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
@@ -465,7 +468,8 @@ int gsx_raster3d_bwd_ws(const float *means2d, const float *conics, const float *
                      const float *v_render_colors, const float *v_render_alphas,
                      uint32_t n_images, uint32_t n_isects, uint32_t cdim,
                      uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
-                     int has_abs, float *v_rows, uint32_t row_stride, void *workspace, int64_t workspace_bytes, void *stream);
+                     int has_abs, float *v_rows, uint32_t row_stride, int64_t v_colors_pixel_stride,
+                     int64_t v_colors_channel_stride, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Sparse pixel sets: gsplat::rasterize_to_pixels_sparse{,_bwd} (ext.cpp:1090-1104; RasterizeToPixelsSparse{Fwd,Bwd}.cu,
  * RasterizeSparseAddressing.cuh). One workgroup per ACTIVE tile (active_tiles int32 [AT], ascending dense tile ids;

@@ -320,9 +320,38 @@ _ISECT_CASES = {
     "packed": (20000, 1, 320, 200, 16, "ellipse", "packed"),
     "depth-ties": (20000, 2, 320, 200, 16, "ellipse", "ties"),
     "one-depth": (6000, 1, 320, 200, 16, "aabb", "flat"),
+    # depths that do not order like positive normal doubles: those lists leave the f64 sorting network (bitonic64.hpp)
+    "odd-depths": (20000, 2, 320, 200, 16, "ellipse", "odd"),
+    "odd-depths-long-tiles": (40000, 1, 640, 360, 16, "aabb", "odd-cluster"),
     "cluster-long-tiles": (40000, 1, 640, 360, 16, "ellipse", "cluster"),  # tiles beyond the LDS arena: work-list sort
     "giants-retry": (20000, 1, 640, 360, 16, "ellipse", "giant"),  # more (row, bin) entries than the workspace: retry path
 }
+
+
+def _odd_depths(d, seed=5):
+    """A few per cent of the depths replaced by values whose float bits are no positive normal double's high word: negative,
+    zero, denormal, +inf, NaN (one quiet pattern: the key carries the bits). Ties among them included."""
+    g = torch.Generator().manual_seed(seed)
+    d = d.clone()
+    flat = d.view(-1)
+    pick = torch.rand(flat.numel(), generator=g).to(d.device)
+    kind = torch.randint(0, 5, (flat.numel(),), generator=g).to(d.device)
+    odd = pick < 0.04
+    vals = torch.tensor([-1.5, 0.0, 1e-42, float("inf"), float("nan")], device=d.device)
+    flat[odd] = vals[kind[odd]]
+    flat[odd & (kind == 0)] *= torch.randint(1, 4, (int((odd & (kind == 0)).sum()),), generator=g).to(d.device).float()
+    return d
+
+
+@pytest.mark.parametrize("sort", ["f64", "int"])
+@pytest.mark.parametrize("path", ["binned", "legacy"])
+@pytest.mark.parametrize("case", ["odd-depths", "depth-ties", "cluster-long-tiles", "aabb-3img-ts8"])
+def test_isect_sort_networks_match_oracle(G, O, monkeypatch, path, case, sort):
+    """GSX_ISECT_SORT=int keeps every tile list on the integer compare-exchange network; the default sorts the same words as
+    doubles. Both are the oracle's order, bit for bit."""
+    if sort == "int":
+        monkeypatch.setenv("GSX_ISECT_SORT", "int")
+    test_isect_paths_match_oracle(G, O, monkeypatch, path, case)
 
 
 @pytest.mark.parametrize("path", ["binned", "legacy"])
@@ -333,7 +362,7 @@ def test_isect_paths_match_oracle(G, O, monkeypatch, path, case):
     bit for bit: tiles_per_gauss, sorted keys, row ids, offsets."""
     N, C, W, H, ts, mode, variant = _ISECT_CASES[case]
     sc, W, H = make_scene(N=N, C=C, width=W, height=H, seed=11)
-    if variant == "cluster":
+    if variant in ("cluster", "odd-cluster"):
         sc["means"][:, :2] *= 0.05
     if variant == "giant":
         sc["scales"] = torch.full_like(sc["scales"], 0.4)
@@ -342,6 +371,8 @@ def test_isect_paths_match_oracle(G, O, monkeypatch, path, case):
         d = (d * 2).round() / 2 + 0.25
     if variant == "flat":
         d = torch.ones_like(d)
+    if variant in ("odd", "odd-cluster"):
+        d = _odd_depths(d)
     tw, th = math.ceil(W / ts), math.ceil(H / ts)
     kw, kwo = {}, {}
     if variant == "packed":
@@ -493,6 +524,39 @@ def test_rasterize_dense_overdraw_long_lists(G, O):
     assert_close_ratio(cpu(rc), rc_o, 1e-4, 5e-5, max_bad_ratio=1e-3, name="render_colors")
     assert_close_ratio(cpu(ra), ra_o, 1e-4, 5e-5, max_bad_ratio=1e-3, name="render_alphas")
     assert ra.max() <= 1.0 and ra.min() >= 0.0 and (ra > 0.999).float().mean() > 0.5
+
+
+@pytest.mark.parametrize("kind", ["expanded-scalar", "channel-slice", "row-broadcast"])
+def test_rasterize_bwd_reads_cotangent_views_in_place(G, kind):
+    """autograd hands v_render_colors over as a VIEW (the gradient of sum() is one float expanded to [I, H, W, D]; a slice of a
+    wider image; ...). Layouts that are linear in the pixel index are read in place by the per-tile launches
+    (gsx_raster3d_bwd_ws, v_colors_pixel_stride); the gradients must be those of the materialised copy."""
+    from gsplat_amd import _ops
+    sc, W, H = make_scene(N=5000, C=2, width=176, height=120, seed=77)
+    a, rad, m2, d, con, op = _project_scene(G, sc, W, H)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    _, ids, fl = G.isect_tiles(m2, rad, d, 16, tw, th, conics=con, opacities=op)
+    off = G.isect_offset_encode(ids, 2, tw, th)
+    colors = torch.rand(2, 5000, 3, device=DEV)
+    rc, ra, _, last = _ops.rasterize_to_pixels_3dgs(m2, con, colors, op, None, None, W, H, 16, off, fl, False, False)
+    if kind == "expanded-scalar":
+        v = torch.tensor(0.75, device=DEV).expand(rc.shape)
+    elif kind == "channel-slice":
+        v = torch.randn(2, H, W, 5, device=DEV)[..., 1:4]
+    else:  # one value per channel, broadcast over the pixels
+        v = torch.randn(3, device=DEV).expand(rc.shape)
+    assert not v.is_contiguous() and _ops._pixel_linear_strides(v) is not None
+    args = (m2, con, colors, op, None, None, off, fl, ra, last, W, H, 16, False)
+    got = _ops.rasterize_to_pixels_3dgs_bwd(*args, v, None, False)
+    want = _ops.rasterize_to_pixels_3dgs_bwd(*args, v.contiguous(), None, False)
+    for g_, w_, name in zip(got[1:5], want[1:5], ("v_means2d", "v_conics", "v_colors", "v_opacities")):
+        assert_grad_close(cpu(g_), cpu(w_), rel=1e-4, max_bad_ratio=1e-4, name=name)
+    # a layout that is NOT linear in the pixel index is copied, not misread
+    t = torch.randn(2, W, H, 3, device=DEV).transpose(1, 2)
+    assert _ops._pixel_linear_strides(t) is None
+    got = _ops.rasterize_to_pixels_3dgs_bwd(*args, t, None, False)
+    want = _ops.rasterize_to_pixels_3dgs_bwd(*args, t.contiguous(), None, False)
+    assert_grad_close(cpu(got[3]), cpu(want[3]), rel=1e-4, max_bad_ratio=1e-4, name="v_colors (copied)")
 
 
 def test_golden_rasterize_vs_reference_outputs(G, golden):

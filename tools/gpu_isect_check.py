@@ -16,22 +16,27 @@ from gsplat_amd._wrapper import isect_tiles_begin, isect_tiles_finish
 dev = torch.device("cuda", 0)
 
 
-def isect(m2, rad, d, ts, tw, th, legacy, **kw):
+def isect(m2, rad, d, ts, tw, th, legacy, sort_int=False, **kw):
     os.environ["GSX_ISECT_PATH"] = "legacy" if legacy else "binned"
+    if sort_int:
+        os.environ["GSX_ISECT_SORT"] = "int"
     try:
         tpg, ids, fl = isect_tiles_finish(isect_tiles_begin(m2, rad, d, ts, tw, th, **kw))
         I = kw.get("n_images") or (math.prod(m2.shape[:-2]) if m2.dim() > 2 else 1)
         off = gsplat_amd.isect_offset_encode(ids, I, tw, th)
     finally:
         os.environ.pop("GSX_ISECT_PATH", None)
+        os.environ.pop("GSX_ISECT_SORT", None)
     return tpg, ids, fl, off
 
 
 def compare(name, m2, rad, d, ts, W, H, **kw):
     tw, th = math.ceil(W / ts), math.ceil(H / ts)
     a = isect(m2, rad, d, ts, tw, th, False, **kw)
-    b = isect(m2, rad, d, ts, tw, th, True, **kw)
+    b = isect(m2, rad, d, ts, tw, th, True, sort_int=True, **kw)  # round 3's integer network: the baseline
     ok = all(torch.equal(x, y) for x, y in zip(a, b))
+    for other in (isect(m2, rad, d, ts, tw, th, True, **kw), isect(m2, rad, d, ts, tw, th, False, sort_int=True, **kw)):
+        ok &= all(torch.equal(x, y) for x, y in zip(other, b))
     print(f"{'OK  ' if ok else 'FAIL'} {name}: M={a[1].numel()} rows={rad.numel() // 2} tiles={tw}x{th}", flush=True)
     if not ok:
         for nm, x, y in zip(("tpg", "ids", "flat", "off"), a, b):
@@ -74,6 +79,12 @@ def check():
         ok &= compare(f"ties    N={N}", m2, rad, dq, 16, W, H, conics=con, opacities=op)
         # all depths equal
         ok &= compare(f"flat    N={N}", m2, rad, torch.ones_like(d), 16, W, H)
+        # depths the f64 network cannot order (negative, zero, denormal, inf, NaN): those lists take the integer network
+        dodd = d.clone()
+        r = torch.rand_like(d)
+        for lo, v in ((0.00, -2.0), (0.01, 0.0), (0.02, 1e-42), (0.03, float("inf")), (0.04, float("nan"))):
+            dodd[(r >= lo) & (r < lo + 0.01)] = v
+        ok &= compare(f"odd     N={N}", m2, rad, dodd, 16, W, H, conics=con, opacities=op)
     # giant Gaussians: more (row, bin) entries than the workspace holds -> the GSX_ISECT_RETRY path
     for (N, scale, W, H) in ((30000, 0.5, 640, 360), (5000, 1.5, 1920, 1080), (60000, 0.2, 1920, 1080)):
         sc, W, H = make_scene(N=N, C=1, width=W, height=H, seed=3)
@@ -124,15 +135,16 @@ def bench_all(c4):
     rad, m2, d, con, op = project(sc, W, H)
     C = sc["viewmats"].shape[0]
     tw, th = (W + 15) // 16, (H + 15) // 16
-    variants = [("auto", {}), ("legacy", {"GSX_ISECT_PATH": "legacy"})]
+    variants = [("auto", {}), ("auto-intsort", {"GSX_ISECT_SORT": "int"}), ("legacy", {"GSX_ISECT_PATH": "legacy"}),
+                ("legacy-intsort", {"GSX_ISECT_PATH": "legacy", "GSX_ISECT_SORT": "int"})]
     for b in ("4x4", "4x2", "2x2", "8x2", "2x4"):
         variants.append((f"bin{b}", {"GSX_ISECT_BIN": b, "GSX_ISECT_PATH": "binned"}))
     for name, env in variants:
-        for k in ("GSX_ISECT_PATH", "GSX_ISECT_BIN"):
+        for k in ("GSX_ISECT_PATH", "GSX_ISECT_BIN", "GSX_ISECT_SORT"):
             os.environ.pop(k, None)
         os.environ.update(env)
         print(json.dumps({"scene": "c4" if c4 else "c3", "variant": name, **timed(m2, rad, d, con, op, C, tw, th)}), flush=True)
-    for k in ("GSX_ISECT_PATH", "GSX_ISECT_BIN"):
+    for k in ("GSX_ISECT_PATH", "GSX_ISECT_BIN", "GSX_ISECT_SORT"):
         os.environ.pop(k, None)
 
 

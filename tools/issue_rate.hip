@@ -15,7 +15,7 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum Op { FMA, PK_FMA, MUL, ADD, CNDMASK, EXP, RCP, MAD_U32_U24, ADD_U32, LSHL_ADD, CMP_BALLOT, DS_ADD_F32, DS_ADD_F32_SAME, DS_READ_B64, DS_READ_B128, DS_WRITE_B64, S_ADD, S_AND_B64, MIX_V_S, DPP_ADD, READLANE, CNDMASK_SGPR, CMP_E64, CMP_CNDMASK, DS_ADD_U32, DS_ADD_RTN_U32, DS_BPERMUTE, PERMLANE32_SWAP, GLOBAL_ATOMIC_ADD, SALU_VCC_CND, SALU_SGPR_CND, VCMP_SGPR_CND, VCMP_SXOR_CND, V_MOV, V_MIN, V_AND, V_CMP_E32, CND_VALU_VCC, V_MAC, N_OPS };
+enum Op { FMA, PK_FMA, MUL, ADD, CNDMASK, EXP, RCP, MAD_U32_U24, ADD_U32, LSHL_ADD, CMP_BALLOT, DS_ADD_F32, DS_ADD_F32_SAME, DS_READ_B64, DS_READ_B128, DS_WRITE_B64, S_ADD, S_AND_B64, MIX_V_S, DPP_ADD, READLANE, CNDMASK_SGPR, CMP_E64, CMP_CNDMASK, DS_ADD_U32, DS_ADD_RTN_U32, DS_BPERMUTE, PERMLANE32_SWAP, GLOBAL_ATOMIC_ADD, SALU_VCC_CND, SALU_SGPR_CND, VCMP_SGPR_CND, VCMP_SXOR_CND, V_MOV, V_MIN, V_AND, V_CMP_E32, CND_VALU_VCC, V_MAC, MIN_F64, CMP_U64, CMP_U64_CND, N_OPS };
 static const char *kNames[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_add_f32", "v_cndmask_b32", "v_exp_f32", "v_rcp_f32",
                                     "v_mad_u32_u24", "v_add_u32", "v_lshl_add_u32", "v_cmp+s_and(ballot)", "ds_add_f32(distinct)",
                                     "ds_add_f32(same addr)", "ds_read_b64", "ds_read_b128", "ds_write_b64", "s_add_u32", "s_and_b64",
@@ -23,7 +23,8 @@ static const char *kNames[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v
                                     "v_cmp(vcc)+v_cndmask(vcc)", "ds_add_u32(distinct)", "ds_add_rtn_u32(distinct)", "ds_bpermute_b32", "v_permlane32_swap_b32",
                                     "global_atomic_add_u32(no return, distinct dwords)", "s_and_b64(vcc)+v_cndmask(vcc)", "s_and_b64(sgpr)+v_cndmask_e64(sgpr)",
                                     "v_cmp_e64(sgpr)+v_cndmask_e64(sgpr)", "v_cmp_e64(sgpr)+s_xor_b64+v_cndmask_e64(sgpr)",
-                                    "v_mov_b32", "v_min_f32", "v_and_b32", "v_cmp_lt_f32_e32(vcc)", "v_cndmask_b32(vcc written by one v_cmp)", "v_fmac_f32_e32"};
+                                    "v_mov_b32", "v_min_f32", "v_and_b32", "v_cmp_lt_f32_e32(vcc)", "v_cndmask_b32(vcc written by one v_cmp)", "v_fmac_f32_e32",
+                                    "v_min_f64", "v_cmp_gt_u64_e64->sgpr", "v_cmp_gt_u64(vcc)+2 v_cndmask(vcc)"};
 
 // One asm statement holds the whole 64-instruction block: the compiler cannot see into it, so it neither reorders it nor
 // pads it with s_nop (it does pad BETWEEN separate asm statements, which would be measured as issue slots).
@@ -79,6 +80,9 @@ static const char *kNames[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v
 #define I_AND(r) "v_and_b32 %" #r ", %" #r ", %8\n"
 #define I_CMP32(r) "v_cmp_lt_f32 vcc, %" #r ", %8\n"
 #define I_MAC(r) "v_fmac_f32 %" #r ", %8, %9\n"
+#define I_MINF64(r) "v_min_f64 %" #r ", %" #r ", %8\n"
+#define I_CMPU64(r) "v_cmp_gt_u64_e64 %10, %" #r ", %8\n"
+#define I_CMPU64CND(r) "v_cmp_gt_u64 vcc, %" #r ", %8\n v_cndmask_b32 %" #r ", %" #r ", %9, vcc\n v_cndmask_b32 %11, %11, %9, vcc\n"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -147,6 +151,9 @@ __global__ void __launch_bounds__(1024) rate_kernel(int iters, uint64_t *cycles,
             BLOCK(I_CND, VREGS, "v"(a), "v"(b));
         }
         if (OP == V_MAC) BLOCK(I_MAC, VREGS, "v"(a), "v"(b));
+        if (OP == MIN_F64) BLOCK(I_MINF64, PREGS, "v"(a2), "v"(b2));
+        if (OP == CMP_U64) asm volatile(IND64(I_CMPU64) : PREGS, "+v"(a2), "+v"(b2), "+s"(sm) : : );
+        if (OP == CMP_U64_CND) { if (DEP) asm volatile(DEP64(I_CMPU64CND) : PREGS, "+v"(a2), "+v"(b), "+s"(sm), "+v"(a) : : "vcc"); else asm volatile(IND64(I_CMPU64CND) : PREGS, "+v"(a2), "+v"(b), "+s"(sm), "+v"(a) : : "vcc"); }
         if (OP == GLOBAL_ATOMIC_ADD) asm volatile(DEP64(I_GATOM) "s_waitcnt vmcnt(0)\n" : UREGS, "+v"(a), "+v"(c), "+v"(gaddr) : : "memory");
     }
     const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
@@ -175,7 +182,7 @@ static void run_op(std::string &out, bool &first)
     const int iters = (OP == EXP || OP == RCP || lds_op) ? 2000 : 8000;
     for (int dep = 1; dep >= 0; --dep) {
         if (!dep && (OP == DS_ADD_F32 || OP == DS_ADD_F32_SAME || OP == S_AND_B64 || OP == CMP_BALLOT || OP == DS_ADD_U32 || OP == GLOBAL_ATOMIC_ADD)) continue;
-        if (dep && (OP == READLANE || OP == DS_WRITE_B64 || OP == CMP_E64 || OP == DS_ADD_RTN_U32 || OP == DS_BPERMUTE)) continue;
+        if (dep && (OP == READLANE || OP == DS_WRITE_B64 || OP == CMP_E64 || OP == CMP_U64 || OP == DS_ADD_RTN_U32 || OP == DS_BPERMUTE)) continue;
         for (int w : {1, 2, 4, 8}) { // waves per SIMD; one block per CU (LDS-limited), two blocks of 1024 threads for w = 8
             const int blocks_per_cu = w == 8 ? 2 : 1;
             const int threads = 256 * (w / blocks_per_cu);
@@ -199,7 +206,7 @@ static void run_op(std::string &out, bool &first)
             double mc = 0, mr = 0;
             for (int i = 0; i < n_waves; ++i) { mc += (double)hc[i]; mr += (double)hr[i]; }
             mc /= n_waves; mr /= n_waves;
-            const double instr = (double)iters * 64 * (OP == VCMP_SXOR_CND ? 3 : (OP == MIX_V_S || OP == CMP_BALLOT || OP == CMP_CNDMASK || OP == SALU_VCC_CND || OP == SALU_SGPR_CND || OP == VCMP_SGPR_CND || (OP == S_ADD && !dep)) ? 2 : 1);
+            const double instr = (double)iters * 64 * ((OP == VCMP_SXOR_CND || OP == CMP_U64_CND) ? 3 : (OP == MIX_V_S || OP == CMP_BALLOT || OP == CMP_CNDMASK || OP == SALU_VCC_CND || OP == SALU_SGPR_CND || OP == VCMP_SGPR_CND || (OP == S_ADD && !dep)) ? 2 : 1);
             const double ns = mr * 10.0; // 100 MHz real-time counter
             char buf[512];
             snprintf(buf, sizeof buf,
