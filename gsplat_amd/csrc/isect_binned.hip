@@ -11,9 +11,10 @@
 //   before the host learns n_isects
 //   A  bin_rect      per row: the walk's tile rectangle (walk_prepare) -> rectangle of bins; LDS histogram of bins per chunk
 //                    of rows -> table[chunk][bin]
-//   B  bin_colscan   running sum over an image's chunks per bin (in place) + bin totals
-//   C  bin_plan      one workgroup: scan of the bin totals -> bin_start; capacity check
-//   D  bin_scatter   per row again (its data is in registers: no gather): for every overlapped bin the walk CLIPPED to the
+//   B  bin_colscan   running sum over an image's chunks per bin (in place) + bin totals, entries per image, largest bin
+//   D  bin_scatter   every workgroup scans its image's bin totals itself (-> LDS cursors; the image's first workgroup also
+//                    stores them as bin_start) and checks the capacity: no one-workgroup planning launch in between. Then
+//                    per row again (its data is in registers: no gather): for every overlapped bin the walk CLIPPED to the
 //                    bin (walk_clipped: only the slabs inside it) -> 16-bit mask of the bin's tiles the Gaussian touches;
 //                    entry = (depth, row) + mask written at an LDS cursor (bin_start + chunk prefix); tiles_per_gauss.
 //                    Rows over several bins are shared out over the workgroup as (row, bin) pairs through an LDS queue.
@@ -45,8 +46,10 @@ constexpr int kBnThreads      = 256;   // kernel E
 constexpr int kBnMaxBins      = 16384; // bins in total (images x bins per image)
 constexpr uint32_t kBnMaxTiles = 36864;
 
-struct BinHeader { // device memory
-    int32_t overflow, n_entries, big_count, pad[5];
+struct BinHeader { // device memory; zeroed by the first workgroup of kernel A
+    int32_t max_bin;   // largest bin (atomicMax by kernel B)
+    int32_t big_count; // tiles handed to the work-list sort (kernel G)
+    int32_t pad[6];
 };
 
 struct BinGeom {
@@ -54,13 +57,14 @@ struct BinGeom {
     uint32_t n_images, cpi, rpc, n_chunks;
     uint32_t tile_size, tile_w, tile_h, n_tiles;
     uint32_t bw, bh, bins_x, bins_y, n_bins, n_bins_total, tile_bits;
-    int32_t skew_cap; // > 0: a bin with more entries than this sends the call back to the Gaussian-major path (bin_plan)
+    int32_t skew_cap; // > 0: a bin with more entries than this sends the call back to the Gaussian-major path (bn_overflow)
 };
 
 struct BinBuffers {
     BinHeader *hdr;
     int32_t *table;      // [n_chunks][n_bins]
     int32_t *bin_count;  // [n_bins_total]
+    int32_t *img_total;  // [n_images] entries per image (atomicAdd by kernel B)
     int32_t *bin_start;  // [n_bins_total + 1]
     uint2 *e_pair;       // [cap] (depth bits, row)
     uint16_t *e_mask;    // [cap]
@@ -131,6 +135,10 @@ __global__ void __launch_bounds__(kRowThreads) bin_rect_kernel(const BinArgs a)
     extern __shared__ int32_t s_hist[];
     const BinGeom &g = a.g;
     for (uint32_t i = threadIdx.x; i < g.n_bins; i += kRowThreads) s_hist[i] = 0;
+    if (blockIdx.x == 0) { // what kernel B accumulates into
+        if (threadIdx.x == 0) { a.b.hdr->max_bin = 0; a.b.hdr->big_count = 0; }
+        for (uint32_t i = threadIdx.x; i < g.n_images; i += kRowThreads) a.b.img_total[i] = 0;
+    }
     __syncthreads();
     int64_t lo, hi;
     uint32_t img;
@@ -166,7 +174,8 @@ __global__ void __launch_bounds__(kRowThreads) bin_rect_kernel(const BinArgs a)
 // per workgroup, two passes over a segment of ~cpi / 32 entries.
 constexpr int kCsCols = 32, kCsSegs2 = 32;
 __global__ void __launch_bounds__(kCsCols *kCsSegs2) bin_colscan_kernel(int32_t *table, int32_t *totals, uint32_t n_cols,
-                                                                        uint32_t cpi, uint32_t col_groups)
+                                                                        uint32_t cpi, uint32_t col_groups, int32_t *img_total,
+                                                                        int32_t *max_bin)
 {
     __shared__ int32_t s_seg[kCsSegs2][kCsCols + 1];
     const uint32_t img = blockIdx.x / col_groups, cg = blockIdx.x % col_groups;
@@ -191,26 +200,33 @@ __global__ void __launch_bounds__(kCsCols *kCsSegs2) bin_colscan_kernel(int32_t 
         }
         if (seg == kCsSegs2 - 1) totals[(int64_t)img * n_cols + c] = run;
     }
+    // the last segment's threads hold the bin totals of this workgroup's 32 bins (the upper half of the last wave): their
+    // sum goes to the image's entry count, their maximum to the skew test - one atomic each per workgroup
+    if (seg == kCsSegs2 - 1) {
+        int32_t sum = live ? run : 0, mx = sum;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            sum += __shfl_xor(sum, o);
+            mx = max(mx, __shfl_xor(mx, o));
+        }
+        if (lane_c == 0) {
+            atomicAdd(&img_total[img], sum);
+            atomicMax(max_bin, mx);
+        }
+    }
 }
 
-// ---- C: bin starts --------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) bin_plan_kernel(const BinArgs a)
+// Entries in all bins, and whether the call has to go back to the Gaussian-major path: more entries than the workspace
+// holds, or a crowded bin - a real scene's dense region (garden x25 has bins of > 10 k entries next to a mean of ~2 k) does not
+// fit the sort kernel's LDS arena and goes through its slow paths: emit + sort 0.80 ms where the Gaussian-major path takes
+// 0.20 (same retry contract as a workspace overflow). A pure function of what kernel B left behind: every later kernel
+// evaluates it for itself.
+__device__ __forceinline__ bool bn_overflow(const BinArgs &a, int64_t *n_entries_out = nullptr)
 {
-    __shared__ int64_t s_part[16];
-    const BinGeom &g = a.g;
-    const uint32_t nb = g.n_bins_total;
-    __shared__ int32_t s_max;
-    const int64_t n_entries = block_scan_i32_1024(a.b.bin_count, a.b.bin_start, nb, s_part, &s_max);
-    // A crowded bin (a real scene's dense region: garden x25 has bins of > 10 k entries next to a mean of ~2 k) does not fit
-    // the sort kernel's LDS arena and goes through its slow paths - emit + sort 0.80 ms where the Gaussian-major path takes
-    // 0.20. Seen HERE, 30 us into the call, the whole binned path steps aside (same retry contract as a workspace overflow).
-    const bool overflow = n_entries > g.cap_entries || (g.skew_cap > 0 && s_max > g.skew_cap);
-    if (threadIdx.x == 0) {
-        a.b.bin_start[nb]  = (int32_t)(overflow ? 0 : n_entries);
-        a.b.hdr->overflow  = overflow ? 1 : 0;
-        a.b.hdr->n_entries = overflow ? 0 : (int32_t)n_entries;
-        a.b.hdr->big_count = 0;
-    }
+    int64_t n = 0;
+    for (uint32_t i = 0; i < a.g.n_images; ++i) n += a.b.img_total[i];
+    if (n_entries_out) *n_entries_out = n;
+    return n > a.g.cap_entries || (a.g.skew_cap > 0 && a.b.hdr->max_bin > a.g.skew_cap);
 }
 
 // ---- D: entries (depth, row | mask) grouped by bin ----------------------------------------------------------------------
@@ -251,14 +267,44 @@ __global__ void __launch_bounds__(kRowThreads) bin_scatter_kernel(const BinArgs 
     __shared__ float s_row[kDMulti][10]; // mean, radii, conic, opacity, depth bits, row slot
     __shared__ int32_t s_tpg[kDRows];
     __shared__ int32_t s_qn, s_qlim, s_mn;
+    __shared__ int32_t s_wsum[kRowThreads / 64];
     const BinGeom &g = a.g;
-    if (a.b.hdr->overflow) return;
+    int64_t n_entries;
+    if (bn_overflow(a, &n_entries)) return; // the same answer in every workgroup
     int64_t lo, hi;
     uint32_t img;
     bn_chunk_rows(g, blockIdx.x, lo, hi, img);
-    const int32_t *pre   = a.b.table + (int64_t)blockIdx.x * g.n_bins; // exclusive prefix over this image's chunks
-    const int32_t *start = a.b.bin_start + (int64_t)img * g.n_bins;
-    for (uint32_t i = threadIdx.x; i < g.n_bins; i += kRowThreads) s_cur[i] = start[i] + pre[i];
+    {
+        // cursors = (entries of the images before this one) + (exclusive scan of this image's bin totals) + (this chunk's
+        // prefix inside the bin): thread t scans the run [t per, (t + 1) per) of bins
+        const int32_t *cnt = a.b.bin_count + (int64_t)img * g.n_bins;
+        const int32_t *pre = a.b.table + (int64_t)blockIdx.x * g.n_bins; // exclusive prefix over this image's chunks
+        const uint32_t per = (g.n_bins + kRowThreads - 1) / kRowThreads;
+        const uint32_t i0 = threadIdx.x * per, i1 = min(i0 + per, g.n_bins);
+        int32_t mine = 0;
+        for (uint32_t i = i0; i < i1; ++i) mine += cnt[i];
+        int32_t inc = mine;
+        const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t y = __shfl_up(inc, o);
+            if (lane >= o) inc += y;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        int32_t run = 0;
+        for (uint32_t j = 0; j < img; ++j) run += a.b.img_total[j];
+        for (int w = 0; w < wave; ++w) run += s_wsum[w];
+        run += inc - mine;
+        const bool keeper = blockIdx.x % g.cpi == 0; // the image's first workgroup stores bin_start for kernels E and G
+        int32_t *start    = a.b.bin_start + (int64_t)img * g.n_bins;
+        for (uint32_t i = i0; i < i1; ++i) {
+            if (keeper) start[i] = run;
+            s_cur[i] = run + pre[i];
+            run += cnt[i];
+        }
+        if (keeper && img == g.n_images - 1 && threadIdx.x == 0) a.b.bin_start[g.n_bins_total] = (int32_t)n_entries;
+    }
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)img * g.n_tiles : nullptr;
     constexpr int kU = kDRows / kRowThreads;
@@ -353,7 +399,7 @@ __global__ void __launch_bounds__(kBnThreads) bin_tiles_kernel(const BinArgs a)
 {
     __shared__ int32_t s_cnt[16];
     const BinGeom &g = a.g;
-    if (a.b.hdr->overflow) return;
+    if (bn_overflow(a)) return;
     const uint32_t bin = blockIdx.x;
     const int32_t e0 = a.b.bin_start[bin], e1 = a.b.bin_start[bin + 1];
     const int lane = (int)(threadIdx.x & 63u);
@@ -393,7 +439,7 @@ __global__ void __launch_bounds__(1024) tile_plan_kernel(const BinArgs a)
     __shared__ int64_t s_part[16];
     __shared__ int32_t s_max;
     const BinGeom &g = a.g;
-    if (a.b.hdr->overflow) {
+    if (bn_overflow(a)) {
         if (threadIdx.x == 0) {
             __threadfence_system();
             *a.n_isects = GSX_ISECT_RETRY; // the caller reruns the Gaussian-major path (gsx_isect_binned_count's contract)
@@ -590,6 +636,7 @@ static int64_t bin_layout(const BinGeom &g, unsigned char *base, BinBuffers *b)
     t.hdr        = reinterpret_cast<BinHeader *>(take(sizeof(BinHeader)));
     t.table      = reinterpret_cast<int32_t *>(take((int64_t)g.n_chunks * g.n_bins * 4));
     t.bin_count  = reinterpret_cast<int32_t *>(take((int64_t)g.n_bins_total * 4));
+    t.img_total  = reinterpret_cast<int32_t *>(take((int64_t)g.n_images * 4));
     t.bin_start  = reinterpret_cast<int32_t *>(take(((int64_t)g.n_bins_total + 1) * 4));
     t.e_pair     = reinterpret_cast<uint2 *>(take(g.cap_entries * 8));
     t.e_mask     = reinterpret_cast<uint16_t *>(take(g.cap_entries * 2));
@@ -620,7 +667,7 @@ extern "C" int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint3
     // a 4096-word arena - lists of up to 512 entries (c3: 122 rows per tile, 466 per list) fit in one go. Uniform scene,
     // fused vs binned in ms (tools/gpu_isect_sizes.py): 250 k rows 0.141 / 0.103, 600 k 0.189 / 0.156, 1 M 0.245 / 0.209,
     // 2 M (245 rows per tile, lists of ~930) 0.399 / 0.470; four cameras: 4 x 250 k 0.265 / 0.222, 4 x 1 M 0.757 / 0.584.
-    // Clustered scenes are caught by the skew test in bin_plan; very small calls (garden x1, 112 k clustered rows: 0.17 / 0.29)
+    // Clustered scenes are caught by the skew test (bn_overflow); very small calls (garden x1, 112 k clustered rows: 0.17 / 0.29)
     // stay Gaussian-major - per IMAGE: four cameras over the same 112 k rows (1020 nearly empty bins each) 0.28 / 0.41.
     return g.rows_per_image >= 196608 && g.rows_per_image <= 144ll * (int64_t)g.n_tiles;
 }
@@ -693,9 +740,8 @@ extern "C" int gsx_isect_binned_count(const float *means2d, const int32_t *radii
     const size_t bins_lds = (size_t)a.g.n_bins * sizeof(int32_t);
     bin_rect_kernel<<<dim3(a.g.n_chunks), dim3(kRowThreads), bins_lds, s>>>(a);
     const uint32_t col_groups = (a.g.n_bins + kCsCols - 1) / kCsCols;
-    bin_colscan_kernel<<<dim3(col_groups * a.g.n_images), dim3(kCsCols * kCsSegs2), 0, s>>>(a.b.table, a.b.bin_count, a.g.n_bins,
-                                                                                             a.g.cpi, col_groups);
-    bin_plan_kernel<<<dim3(1), dim3(1024), 0, s>>>(a);
+    bin_colscan_kernel<<<dim3(col_groups * a.g.n_images), dim3(kCsCols * kCsSegs2), 0, s>>>(
+        a.b.table, a.b.bin_count, a.g.n_bins, a.g.cpi, col_groups, a.b.img_total, &a.b.hdr->max_bin);
     bin_scatter_kernel<<<dim3(a.g.n_chunks), dim3(kRowThreads), bins_lds, s>>>(a);
     bin_tiles_kernel<<<dim3(a.g.n_bins_total), dim3(kBnThreads), 0, s>>>(a);
     tile_plan_kernel<<<dim3(1), dim3(1024), 0, s>>>(a);

@@ -7,7 +7,13 @@
 //   column scan  (tile_sort.hip)            per (image, tile): running sum over that image's chunks (exclusive, in place)
 //                                           + tile totals -> exclusive scan -> isect_offsets (the reference's
 //                                           intersect_offset output, for free) and n_isects
-//   emit+scatter gsx_isect_fused_emit_sort  same walk; slot = LDS cursor[tile]++ (cursor = offset + chunk prefix);
+//                                           very large inputs (fused_records_spans): + the row's SPANS (one 16-byte record:
+//                                           first slab, up to six (start, length) pairs) - what the walk found, so that the
+//                                           emission does not repeat its divisions and square roots. c4 (16 M rows): count
+//                                           0.61 -> 0.77 ms, emit + sort 1.79 -> 1.50; garden x25 (2.8 M rows): 0.108 -> 0.131,
+//                                           0.198 -> 0.198 - the emission of a small input is bound by its scattered stores
+//   emit+scatter gsx_isect_fused_emit_sort  the same walk, or the recorded spans (rows that did not fit a record walk again);
+//                                           slot = LDS cursor[tile]++ (cursor = offset + chunk prefix);
 //                                           bucketed[slot] = (depth bits, row)
 //   tile sort    (tile_sort.hip)            per-tile LDS sort by (depth, row), unchanged
 //
@@ -55,10 +61,59 @@ __device__ __forceinline__ RowGeom load_row_geom(const FusedArgs &a, int64_t r, 
     return q;
 }
 
+// ---- a row's spans, as recorded by the counting pass ---------------------------------------------------------------------
+// x: [11:0] first slab u0, [23:12] first span's start v_first, [24] alongY, [31:28] slabs n (0 = no tile, kSpanWalk = the row
+// does not fit: the emission walks it again); y, z, w: six 16-bit (int8 start - v_first | uint8 length << 8), slab k is u0 + k.
+constexpr uint32_t kSpanSlabs = 6, kSpanWalk = 15;
+struct SpanPacker {
+    uint32_t hdr = 0, w[3] = {0u, 0u, 0u};
+    int n = 0, v_first = 0;
+    bool walk = false;
+    __device__ __forceinline__ void add(bool alongY, int u, int tv0, int tv1)
+    {
+        const int len = tv1 > tv0 ? tv1 - tv0 : 0;
+        if (n == 0) {
+            v_first = tv0;
+            hdr     = (uint32_t)u | ((uint32_t)tv0 << 12) | (alongY ? 1u << 24 : 0u);
+            walk |= u > 4095 || tv0 > 4095;
+        }
+        const int rel = len ? tv0 - v_first : 0;
+        walk |= n >= (int)kSpanSlabs || rel < -128 || rel > 127 || len > 255;
+        if (!walk) w[n >> 1] |= (((uint32_t)rel & 0xFFu) | ((uint32_t)len << 8)) << (16 * (n & 1));
+        ++n;
+    }
+    __device__ __forceinline__ uint4 record() const
+    {
+        return make_uint4(hdr | ((walk ? kSpanWalk : (uint32_t)n) << 28), w[0], w[1], w[2]);
+    }
+};
+__device__ __forceinline__ uint32_t span_slabs(const uint4 &rec) { return rec.x >> 28; }
+__device__ __forceinline__ int span_tiles(const uint4 &rec) // tiles of a recorded row (kSpanWalk rows: unknown -> "many")
+{
+    const uint32_t n = span_slabs(rec);
+    if (n == kSpanWalk) return 1 << 20;
+    return (int)(((rec.y >> 8) & 0xFFu) + (rec.y >> 24) + ((rec.z >> 8) & 0xFFu) + (rec.z >> 24) + ((rec.w >> 8) & 0xFFu) + (rec.w >> 24));
+}
+// visits the tiles of a recorded row in the order of the walk
+template <typename Emit>
+__device__ __forceinline__ void span_tiles_visit(const uint4 &rec, uint32_t tile_w, Emit &&emit)
+{
+    const uint32_t n = span_slabs(rec);
+    const int u0 = (int)(rec.x & 0xFFFu), v_first = (int)((rec.x >> 12) & 0xFFFu);
+    const bool alongY = (rec.x >> 24) & 1u;
+    const uint64_t lo64 = ((uint64_t)rec.z << 32) | rec.y;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t e = k < 4 ? (uint32_t)(lo64 >> (16 * k)) & 0xFFFFu : (rec.w >> (16 * (k - 4))) & 0xFFFFu;
+        const int v0 = v_first + (int)(int8_t)(e & 0xFFu), len = (int)(e >> 8), u = u0 + (int)k;
+        for (int v = v0; v < v0 + len; ++v) emit(alongY ? (int64_t)u * tile_w + v : (int64_t)v * tile_w + u);
+    }
+}
+
 // ---- load balancing of the walk ------------------------------------------------------------------------------------
 // The walk of one row costs (slabs + tiles) of that row, and a wave pays for its LARGEST row: with rows in storage order
 // (near, large Gaussians scattered among thousands of 1-4 tile ones) most lanes idle most of the time. So every
-// kFusedSub rows of a chunk are first ordered by a size class — the tile area of the radius box, 63 = largest — with an
+// kFusedSub rows of a chunk are first ordered by a size class — the tile area of the radius box (counting pass) or the
+// recorded tile count (emission), 0 = largest — with an
 // LDS counting sort, and thread t walks the t-th row of that order: waves get rows of similar cost, the big ones first.
 // Which thread walks a row changes nothing in the outputs (counts per row; slots inside a tile segment are sorted later).
 constexpr int kFusedPer = 4; // rows per thread and round: a sub-chunk is kFusedPer x THREADS rows
@@ -81,13 +136,13 @@ __device__ __forceinline__ int size_class(const FusedArgs &a, int64_t r)
 // `body(row, data)` once per row. The walk of a row starts with two dependent global reads (radii, then the geometry of a
 // live row); issued row by row they cost two full memory latencies per row at 16 waves per CU - 46 of the 62 us of the
 // counting kernel on c3 (r05 ablation). Loading the kPer rows of a thread up front turns eight serial latencies into one.
-template <int kFusedThreads, typename Load, typename Body>
-__device__ __forceinline__ void for_rows_balanced(const FusedArgs &a, int64_t lo, int64_t hi, Load &&load, Body &&body)
+template <int kFusedThreads, typename Classify, typename Load, typename Body>
+__device__ __forceinline__ void for_rows_balanced(const FusedArgs &a, int64_t lo, int64_t hi, uint16_t *s_order, int32_t *s_cnt,
+                                                  Classify &&classify, Load &&load, Body &&body)
 {
-    constexpr int kFusedSub = kFusedPer * kFusedThreads;
+    constexpr int kFusedSub = kFusedPer * kFusedThreads; // s_order: kFusedSub entries, s_cnt: 64 (static LDS of the caller:
+                                                         // a kernel that calls this twice must not pay for two copies)
     static_assert(kFusedSub <= 65536, "order entries are uint16");
-    __shared__ uint16_t s_order[kFusedSub];
-    __shared__ int32_t s_cnt[64];
     constexpr int kPer = kFusedPer;
     for (int64_t sub = lo; sub < hi; sub += kFusedSub) {
         const int n = (int)min((int64_t)kFusedSub, hi - sub);
@@ -97,7 +152,7 @@ __device__ __forceinline__ void for_rows_balanced(const FusedArgs &a, int64_t lo
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
             const int i = (int)threadIdx.x + q * kFusedThreads;
-            cls[q]      = i < n ? size_class(a, sub + i) : -1;
+            cls[q]      = i < n ? classify(sub + i) : -1;
             if (cls[q] >= 0) atomicAdd(&s_cnt[cls[q]], 1);
         }
         __syncthreads();
@@ -135,6 +190,8 @@ template <int kFusedThreads>
 __global__ void __launch_bounds__(kFusedThreads) fused_count_hist_kernel(const FusedArgs a)
 {
     extern __shared__ int32_t s_hist[];
+    __shared__ uint16_t s_order[kFusedPer * kFusedThreads];
+    __shared__ int32_t s_cnt[64];
     const FusedGeom &g = a.geom;
     for (uint32_t t = threadIdx.x; t < g.n_tiles; t += kFusedThreads) s_hist[t] = 0;
     __syncthreads();
@@ -143,15 +200,23 @@ __global__ void __launch_bounds__(kFusedThreads) fused_count_hist_kernel(const F
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)(blockIdx.x / g.cpi) * g.n_tiles : nullptr;
     for_rows_balanced<kFusedThreads>(
-        a, lo, hi, [&](int64_t r) { return load_row_geom(a, r, has_conic); },
+        a, lo, hi, s_order, s_cnt, [&](int64_t r) { return size_class(a, r); },
+        [&](int64_t r) { return load_row_geom(a, r, has_conic); },
         [&](int64_t r, const RowGeom &q) {
             int32_t n = 0;
+            SpanPacker sp;
             if (q.live)
-                n = walk_tiles(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h,
-                               [&](int64_t tile) {
+                walk_spans(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h,
+                           [&](bool alongY, int u, int tv0, int tv1) {
+                               if (a.spans) sp.add(alongY, u, tv0, tv1);
+                               for (int v = tv0; v < tv1; ++v) {
+                                   const int64_t tile = alongY ? (int64_t)u * g.tile_w + v : (int64_t)v * g.tile_w + u;
                                    if (!tmask || tmask[tile]) atomicAdd(&s_hist[tile], 1);
-                               });
+                                   ++n;
+                               }
+                           });
             if (a.tiles_per_gauss) a.tiles_per_gauss[r] = n;
+            if (a.spans) a.spans[r] = sp.record();
         });
     __syncthreads();
     int32_t *out = a.table + (int64_t)blockIdx.x * g.n_tiles;
@@ -162,6 +227,8 @@ template <int kFusedThreads>
 __global__ void __launch_bounds__(kFusedThreads) fused_emit_scatter_kernel(const FusedArgs a)
 {
     extern __shared__ int32_t s_cur[];
+    __shared__ uint16_t s_order[kFusedPer * kFusedThreads];
+    __shared__ int32_t s_cnt[64];
     const FusedGeom &g = a.geom;
     const uint32_t img = blockIdx.x / g.cpi;
     const int32_t *pre = a.table + (int64_t)blockIdx.x * g.n_tiles;      // exclusive prefix over this image's chunks
@@ -172,12 +239,46 @@ __global__ void __launch_bounds__(kFusedThreads) fused_emit_scatter_kernel(const
     chunk_rows(g, blockIdx.x, lo, hi);
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
     const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)img * g.n_tiles : nullptr;
+    if (a.spans) { // the counting pass recorded what its walk found
+        struct RowEmit {
+            uint4 rec;
+            uint32_t dbits;
+        };
+        for_rows_balanced<kFusedThreads>(
+            a, lo, hi, s_order, s_cnt,
+            [&](int64_t r) { // most tiles first; rows without tiles last
+                const int n = span_tiles(a.spans[r]);
+                return n == 0 ? 63 : 62 - min(n, 62);
+            },
+            [&](int64_t r) {
+                RowEmit e;
+                e.rec   = a.spans[r];
+                e.dbits = __float_as_uint(a.depths[r]);
+                return e;
+            },
+            [&](int64_t r, const RowEmit &e) {
+                const uint32_t dbits = e.dbits;
+                auto put = [&](int64_t tile) {
+                    if (tmask && !tmask[tile]) return;
+                    const int32_t slot = atomicAdd(&s_cur[tile], 1);
+                    a.bucketed[slot]   = make_uint2(dbits, (uint32_t)r);
+                };
+                if (span_slabs(e.rec) != kSpanWalk) {
+                    span_tiles_visit(e.rec, g.tile_w, put);
+                    return;
+                }
+                const RowGeom q = load_row_geom(a, r, has_conic); // more slabs / longer spans than a record holds: walk again
+                if (!q.live) return;
+                walk_tiles(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h, put);
+            });
+        return;
+    }
     struct RowEmit {
         RowGeom q;
         uint32_t dbits;
     };
     for_rows_balanced<kFusedThreads>(
-        a, lo, hi,
+        a, lo, hi, s_order, s_cnt, [&](int64_t r) { return size_class(a, r); },
         [&](int64_t r) {
             RowEmit e;
             e.q     = load_row_geom(a, r, has_conic);
@@ -202,8 +303,12 @@ static void set_lds_limit_once()
 {
     static PerDeviceOnce once;
     if (once.first()) {
-        (void)hipFuncSetAttribute((const void *)fused_count_hist_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxDynLds);
-        (void)hipFuncSetAttribute((const void *)fused_emit_scatter_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxDynLds);
+        // a refused limit would otherwise surface as the NEXT launch's "invalid argument" (hipGetLastError is sticky)
+        if (hipFuncSetAttribute((const void *)fused_count_hist_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxDynLds) != hipSuccess
+            || hipFuncSetAttribute((const void *)fused_emit_scatter_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxDynLds) != hipSuccess) {
+            (void)hipGetLastError();
+            fprintf(stderr, "gsplat_amd: isect_fused: dynamic LDS limit of %d bytes refused (static LDS grew?)\n", kFusedMaxDynLds);
+        }
     }
 }
 

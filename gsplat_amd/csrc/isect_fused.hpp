@@ -25,9 +25,19 @@ struct FusedArgs {
     const uint8_t *tile_mask;     // [n_images * n_tiles] or null: only tiles with a non-zero flag receive intersections
     int32_t *tiles_per_gauss;     // [R]   (count)
     int32_t *table;               // [n_chunks][n_tiles]: histogram, then exclusive prefix over an image's chunks
+    uint4 *spans;                 // [R] or null: what the counting pass's walk found, row by row (isect_fused.hip: SpanPacker)
     const int32_t *isect_offsets; // [n_images * n_tiles] (emit)
     uint2 *bucketed;              // [M] (emit)
 };
+
+// Does the counting pass record the rows' spans for the emission (isect_fused.hip)? It pays on very large inputs only;
+// GSX_FUSED_SPANS=1 / 0 forces it (tests, A/B).
+inline bool fused_records_spans(int64_t rows)
+{
+    const char *e = getenv("GSX_FUSED_SPANS");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return rows > 6000000;
+}
 
 // workgroups of 1024 threads, one chunk of rows each: at least 4096 rows per chunk, at most 768 (256 for huge inputs) chunks
 inline FusedGeom fused_geometry(int64_t rows, uint32_t n_images, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h)

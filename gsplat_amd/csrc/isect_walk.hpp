@@ -33,11 +33,13 @@ __host__ __device__ __forceinline__ void ellipse_cut(float B, float coeff, float
     hi               = (mbh + root) / coeff + pv;
 }
 
-// Visits every tile touched by the Gaussian; calls emit(tile_id). Returns the tile count.
-template <typename Emit>
-__host__ __device__ __forceinline__ int32_t walk_tiles(
+// The walk, slab by slab: span(alongY, u, tv0, tv1) = the tiles (x, y) = (v, u) [alongY] or (u, v) for v in [tv0, tv1), in
+// the order walk_tiles emits them (an empty span, tv1 <= tv0, may be reported). A row's spans are what the Gaussian-major
+// path keeps from its counting pass so that the emission pass does not repeat the arithmetic (isect_fused.hip).
+template <typename Span>
+__host__ __device__ __forceinline__ void walk_spans(
     float mx, float my, float rx, float ry, bool has_conic, float A, float B, float C, float opacity,
-    uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, Emit &&emit)
+    uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, Span &&span)
 {
     const float ts = (float)tile_size;
     // x / ts, bit for bit: for a power-of-two tile size the product with the (exact) reciprocal IS the correctly
@@ -45,14 +47,13 @@ __host__ __device__ __forceinline__ int32_t walk_tiles(
     const bool ts_pow2 = (tile_size & (tile_size - 1u)) == 0u;
     const float ts_inv = 1.0f / ts;
     auto div_ts        = [&](float x) { return ts_pow2 ? x * ts_inv : x / ts; };
-    int32_t count  = 0;
     if (has_conic) {
         // exact ellipse-vs-tile walk (SNUGBOX bbox + per-slab extents), opacity-aware level set
         const float disc = B * B - A * C;
         float t          = 2.0f * det_logf(opacity * 255.0f);
         const float tmax = kGaussianExtend * kGaussianExtend;
         if (t > tmax) t = tmax;
-        if (!(t > 0.0f) || !(disc < 0.0f)) return 0;
+        if (!(t > 0.0f) || !(disc < 0.0f)) return;
         const float s  = -t / disc;
         const float ex = sqrtf(s * C), ey = sqrtf(s * A);
         const float bminx = mx - ex, bmaxx = mx + ex, bminy = my - ey, bmaxy = my + ey;
@@ -66,7 +67,7 @@ __host__ __device__ __forceinline__ int32_t walk_tiles(
         const int rmaxx = clampi(f2i_trunc_sat(div_ts(bmaxx) + 1.0f), 0, (int)tile_w);
         const int rmaxy = clampi(f2i_trunc_sat(div_ts(bmaxy) + 1.0f), 0, (int)tile_h);
         const int yspan = rmaxy - rminy, xspan = rmaxx - rminx;
-        if (yspan <= 0 || xspan <= 0) return 0;
+        if (yspan <= 0 || xspan <= 0) return;
 
         // iterate slabs along the SHORTER span (u), solve the covered range on the other axis (v)
         const bool alongY = yspan < xspan;
@@ -92,15 +93,12 @@ __host__ __device__ __forceinline__ int32_t walk_tiles(
             const float vmax = (line_lo <= u_at_vmax && u_at_vmax < line_hi) ? bmax_v : fmaxf(lo_hi, hi_hi);
             const int tv0    = clampi(f2i_trunc_sat(div_ts(vmin)), v0, v1);
             const int tv1    = clampi(f2i_trunc_sat(div_ts(vmax) + 1.0f), v0, v1);
-            for (int v = tv0; v < tv1; ++v) {
-                emit(alongY ? (int64_t)u * tile_w + v : (int64_t)v * tile_w + u);
-                ++count;
-            }
+            span(alongY, u, tv0, tv1);
             lo_lo   = hi_lo;
             lo_hi   = hi_hi;
             line_lo = line_hi;
         }
-        return count;
+        return;
     }
     // axis-aligned bounding box of (mean +- radius): min inclusive (floor), max exclusive (ceil)
     const float tx = div_ts(mx), ty = div_ts(my), trx = div_ts(rx), try_ = div_ts(ry);
@@ -108,11 +106,22 @@ __host__ __device__ __forceinline__ int32_t walk_tiles(
     const int y0 = clampi(f2i_trunc_sat(floorf(ty - try_)), 0, (int)tile_h);
     const int x1 = clampi(f2i_trunc_sat(ceilf(tx + trx)), 0, (int)tile_w);
     const int y1 = clampi(f2i_trunc_sat(ceilf(ty + try_)), 0, (int)tile_h);
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) {
-            emit((int64_t)y * tile_w + x);
+    for (int y = y0; y < y1; ++y) span(true, y, x0, x1);
+}
+
+// Visits every tile touched by the Gaussian; calls emit(tile_id). Returns the tile count.
+template <typename Emit>
+__host__ __device__ __forceinline__ int32_t walk_tiles(
+    float mx, float my, float rx, float ry, bool has_conic, float A, float B, float C, float opacity,
+    uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, Emit &&emit)
+{
+    int32_t count = 0;
+    walk_spans(mx, my, rx, ry, has_conic, A, B, C, opacity, tile_size, tile_w, tile_h, [&](bool alongY, int u, int tv0, int tv1) {
+        for (int v = tv0; v < tv1; ++v) {
+            emit(alongY ? (int64_t)u * tile_w + v : (int64_t)v * tile_w + u);
             ++count;
         }
+    });
     return count;
 }
 

@@ -354,6 +354,15 @@ def test_isect_sort_networks_match_oracle(G, O, monkeypatch, path, case, sort):
     test_isect_paths_match_oracle(G, O, monkeypatch, path, case)
 
 
+@pytest.mark.parametrize("case", ["giants-retry", "ellipse-ts4", "aabb-3img-ts8", "cluster-long-tiles", "packed", "depth-ties"])
+def test_isect_fused_span_records_match_oracle(G, O, monkeypatch, case):
+    """Very large inputs (c4: 16 M rows) keep, per row, the spans the counting pass's walk found, and the emission reads them
+    back instead of walking again (csrc/isect_fused.hip). GSX_FUSED_SPANS=1 switches that on at test sizes: giants overflow the
+    16-byte record and walk again, tile sizes 4 / 8 change the spans' lengths, ... - the oracle's lists, bit for bit."""
+    monkeypatch.setenv("GSX_FUSED_SPANS", "1")
+    test_isect_paths_match_oracle(G, O, monkeypatch, "legacy", case)
+
+
 @pytest.mark.parametrize("path", ["binned", "legacy"])
 @pytest.mark.parametrize("case", sorted(_ISECT_CASES))
 def test_isect_paths_match_oracle(G, O, monkeypatch, path, case):
