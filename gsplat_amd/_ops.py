@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -284,12 +285,25 @@ def _common_row_views(ts, widths):
     return [t.contiguous() for t in ts], 0
 
 
+_row_map_lock = threading.Lock()
+_row_map_cache: list = []  # newest first: (key, the id tensors - kept alive so that their addresses stay theirs -, row_map)
+
+
 def _packed_row_map(batch_ids, camera_ids, gaussian_ids, B: int, C: int, N: int) -> Tensor:
     """int32 [B*C*N]: packed row of every (batch, camera, gaussian), -1 where the pair is not stored. The packed
-    backward kernels walk it Gaussian-major (one thread per Gaussian, no atomics)."""
+    backward kernels walk it Gaussian-major (one thread per Gaussian, no atomics). The SH backward and the projection
+    backward of a step ask for the same map: the last two are kept (keyed by the id tensors' storage and version)."""
+    ids = (batch_ids.contiguous(), camera_ids.contiguous(), gaussian_ids.contiguous())
+    key = tuple((t.data_ptr(), t.numel(), t._version) for t in ids) + (B, C, N)
+    with _row_map_lock:
+        for k, _, rm in _row_map_cache:
+            if k == key:
+                return rm
     row_map = torch.empty(B * C * N, device=gaussian_ids.device, dtype=torch.int32)
-    call("gsx_packed_row_map", ptr(batch_ids.contiguous()), ptr(camera_ids.contiguous()), ptr(gaussian_ids.contiguous()),
-         gaussian_ids.shape[0], B, C, N, ptr(row_map))
+    call("gsx_packed_row_map", ptr(ids[0]), ptr(ids[1]), ptr(ids[2]), gaussian_ids.shape[0], B, C, N, ptr(row_map))
+    with _row_map_lock:
+        _row_map_cache.insert(0, (key, ids, row_map))
+        del _row_map_cache[2:]
     return row_map
 
 
@@ -720,6 +734,7 @@ def projection_ewa_3dgs_fused_bwd(means, covars, quats, scales, viewmats, Ks, im
 
 _PACKED_ROW_BYTES = 64  # 3 int64 ids + radii + means2d + depth + conic (+ compensation) per packed row
 _PACKED_PREALLOC_LIMIT = 1 << 30  # upper-bound row buffers are only used below this size
+_PACKED_COMPACT_ABOVE = 1 << 28  # ... and their unused tails are given back when they exceed this many bytes
 
 
 @_op("projection_ewa_3dgs_packed")
@@ -765,9 +780,11 @@ def projection_ewa_3dgs_packed(means, covars, quats, scales, opacities, viewmats
     ev.synchronize()  # host round trip: exact-length COO outputs (reference: Projection.cpp:928-941)
     nnz = int(host_nnz.item())
     if prealloc:
-        # a view pins the whole upper-bound buffer for as long as the step (and its autograd graph) holds the rows: when
-        # few pairs are visible - the case packed rows exist for - copy the heads out and let the big buffers go
-        compact = 2 * nnz < total
+        # a view pins the whole upper-bound buffer for as long as the step (and its autograd graph) holds the rows: copy the
+        # heads out and let the big buffers go only when that is a real amount of memory - seven copies cost 32 us of kernels
+        # and as much host time, which left the GPU idle behind the write pass (c3 at 25 % visibility: packed 0.86 ms per
+        # step against dense 0.80, profiles/r08_ab.md #28)
+        compact = (total - nnz) * _PACKED_ROW_BYTES > _PACKED_COMPACT_ABOVE
         return tuple(t if (t is None or i == 3) else (t[:nnz].clone() if compact else t[:nnz]) for i, t in enumerate(bufs))
     bufs = outputs(nnz)
     call("gsx_project_ewa_packed_write_blocks", *common, ptr(blocks[1]), *[ptr(t) for t in bufs])
@@ -818,9 +835,9 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
             return sp if len(batch_dims) <= 1 else sp.to_dense().reshape(like.shape)
 
         return coo(r_means, means), coo(r_covars, covars), coo(r_quats, quats), coo(r_scales, scales), v_viewmats
-    # several images: walk the packed rows Gaussian-major through a row map (each output row written once, no atomics);
-    # a single image: every Gaussian has at most one row and the row-major kernel stores without atomics
-    row_map = _packed_row_map(batch_ids, camera_ids, gaussian_ids, B, C, N) if (B * C > 1 and nnz > 0 and N > 0) else None
+    # walk the packed rows Gaussian-major through a row map: each output row is written once, no atomics and no zero-filled
+    # outputs (three fills of [N, .] per step for a single image before); the map is the one the SH backward asked for
+    row_map = _packed_row_map(batch_ids, camera_ids, gaussian_ids, B, C, N) if (nnz > 0 and N > 0) else None
     alloc = torch.empty_like if row_map is not None else torch.zeros_like
     v_means = alloc(means)
     v_covars = v_quats = v_scales = None

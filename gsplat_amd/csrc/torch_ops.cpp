@@ -289,9 +289,10 @@ projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const
         write(total, o);
         const int64_t nnz = wait_nnz(); // host round trip: exact-length COO outputs
         auto &[bi, ci, gi, indptr, radii, m2, dep, con, comp] = o;
-        // a view pins the whole upper-bound buffer for as long as the step (and its autograd graph) holds the rows: when
-        // few pairs are visible - the case packed rows exist for - copy the heads out and let the big buffers go
-        const bool compact = 2 * nnz < total;
+        // a view pins the whole upper-bound buffer for as long as the step (and its autograd graph) holds the rows: copy the
+        // heads out and let the big buffers go only when that is a real amount of memory (> 256 MiB) - the seven copies cost
+        // 32 us of kernels and as much host time, which left the GPU idle behind the write pass (profiles/r08_ab.md #28)
+        const bool compact = (total - nnz) * kPackedRowBytes > (int64_t(1) << 28);
         auto head = [&](const Tensor &t) { return compact ? t.narrow(0, 0, nnz).clone() : t.narrow(0, 0, nnz); };
         return {head(bi), head(ci), head(gi), indptr, head(radii), head(m2), head(dep), head(con),
                 comp ? OptTensor(head(*comp)) : OptTensor()};
