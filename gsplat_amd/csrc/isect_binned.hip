@@ -610,6 +610,13 @@ static bool bin_geometry(BinGeom &g, int64_t rows, uint32_t n_images, uint32_t t
     // chunks of >= 2048 rows, image-aligned, at most ~1024 in total (the [chunk][bin] table stays small)
     const int64_t max_cpi = 1024 / g.n_images > 0 ? 1024 / g.n_images : 1;
     int64_t cpi = (g.rows_per_image + 2047) / 2048;
+    // fewer rows than 256 chunks of 2048: halve the chunks rather than leave CUs without a workgroup (250 k packed rows: 122
+    // workgroups of the 256 the chip runs at once)
+    {
+        const int64_t per_image = (256 + (int64_t)g.n_images - 1) / (int64_t)g.n_images;
+        const int64_t floor_cpi = g.rows_per_image / 1024 < per_image ? g.rows_per_image / 1024 : per_image;
+        if (cpi < floor_cpi) cpi = floor_cpi;
+    }
     if (cpi < 1) cpi = 1;
     if (cpi > max_cpi) cpi = max_cpi;
     g.cpi = (uint32_t)cpi;

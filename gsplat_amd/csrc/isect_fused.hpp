@@ -70,6 +70,14 @@ inline FusedGeom fused_geometry(int64_t rows, uint32_t n_images, uint32_t tile_s
     constexpr int64_t kMinRows = 4096;
     const int64_t max_cpi = kMaxChunks / g.n_images > 0 ? kMaxChunks / g.n_images : 1;
     int64_t cpi = (g.rows_per_image + kMinRows - 1) / kMinRows;
+    // ... but a small input still wants a workgroup per CU: 100 k packed rows (a camera that sees a tenth of a 1 M scene) made
+    // 25 chunks - 25 of 256 CUs walking, and the near, large Gaussians that survive such a cut are the expensive rows (packed
+    // step 0.849 ms against 0.747 dense). Down to 256 rows per chunk the table stays at the c3 size or below.
+    {
+        const int64_t per_image = (256 + (int64_t)g.n_images - 1) / (int64_t)g.n_images;
+        const int64_t floor_cpi = g.rows_per_image / 256 < per_image ? g.rows_per_image / 256 : per_image;
+        if (cpi < floor_cpi) cpi = floor_cpi;
+    }
     if (cpi < 1) cpi = 1;
     if (cpi > max_cpi) cpi = max_cpi;
     g.cpi = (uint32_t)cpi;
