@@ -508,6 +508,7 @@ def _isect_fused_total(st, tile_mask):
     n_isects = int(st.host_total[0].item())
     if st.binned and n_isects == -2:
         st.binned = False
+        _cabi._lib.gsx_isect_binned_note_retry(st.rows, st.I, st.geom[1], st.geom[2])  # not tried again for the next 63 calls
         _isect_fused_count(st, tile_mask)
         torch.cuda.current_stream(st.args[0].device).synchronize()
         n_isects = int(st.host_total[0].item())

@@ -38,6 +38,7 @@
 #include "bitonic64.hpp"
 #include "isect_fused.hpp"
 #include <cstdlib>
+#include <mutex>
 
 namespace gsx {
 
@@ -58,6 +59,7 @@ struct BinGeom {
     uint32_t tile_size, tile_w, tile_h, n_tiles;
     uint32_t bw, bh, bins_x, bins_y, n_bins, n_bins_total, tile_bits;
     int32_t skew_cap; // > 0: a bin with more entries than this sends the call back to the Gaussian-major path (bn_overflow)
+    int32_t skew_ratio; // > 0: ... and so does a largest bin of more than this many times the mean bin
 };
 
 struct BinBuffers {
@@ -226,7 +228,11 @@ __device__ __forceinline__ bool bn_overflow(const BinArgs &a, int64_t *n_entries
     int64_t n = 0;
     for (uint32_t i = 0; i < a.g.n_images; ++i) n += a.b.img_total[i];
     if (n_entries_out) *n_entries_out = n;
-    return n > a.g.cap_entries || (a.g.skew_cap > 0 && a.b.hdr->max_bin > a.g.skew_cap);
+    const int64_t mx = a.b.hdr->max_bin;
+    // clustered but small (garden x1: 112 k rows, no bin near the arena's size): the crowded bins' workgroups are the launch's
+    // tail - binned 0.218 ms against 0.128 Gaussian-major - while a uniform scene's largest bin is ~1.5 x its mean
+    const bool lopsided = a.g.skew_ratio > 0 && mx * (int64_t)a.g.n_bins_total > (int64_t)a.g.skew_ratio * n && mx > 256;
+    return n > a.g.cap_entries || (a.g.skew_cap > 0 && mx > a.g.skew_cap) || lopsided;
 }
 
 // ---- D: entries (depth, row | mask) grouped by bin ----------------------------------------------------------------------
@@ -657,6 +663,45 @@ static int64_t bin_layout(const BinGeom &g, unsigned char *base, BinBuffers *b)
 
 using namespace gsx;
 
+// ---- inputs that sent the binned path back recently ---------------------------------------------------------------------------
+// A clustered scene fails the skew test 25 us into the count half and the call starts over Gaussian-major (garden x25, packed:
+// forward 1258 fps where the Gaussian-major path alone gives 1340). A trainer renders the same scene every step: after a retry
+// the next 63 calls of that shape (row count to 64 k, images, tile grid) skip the attempt, the 64th probes again.
+namespace {
+struct RetryNote { uint64_t key; int left; };
+std::mutex g_retry_mutex;
+RetryNote g_retry[16];
+uint32_t g_retry_next = 0;
+uint64_t retry_key(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
+{
+    return ((uint64_t)(rows >> 16) << 40) ^ ((uint64_t)n_images << 32) ^ ((uint64_t)tile_w << 16) ^ (uint64_t)tile_h ^ (1ull << 63);
+}
+bool retried_recently(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
+{
+    const uint64_t key = retry_key(rows, n_images, tile_w, tile_h);
+    std::lock_guard<std::mutex> lock(g_retry_mutex);
+    for (auto &n : g_retry)
+        if (n.key == key && n.left > 0) {
+            --n.left;
+            return true;
+        }
+    return false;
+}
+} // namespace
+
+extern "C" int gsx_isect_binned_note_retry(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
+{
+    const uint64_t key = retry_key(rows, n_images, tile_w, tile_h);
+    std::lock_guard<std::mutex> lock(g_retry_mutex);
+    for (auto &n : g_retry)
+        if (n.key == key) {
+            n.left = 63;
+            return GSX_OK;
+        }
+    g_retry[g_retry_next++ % 16u] = RetryNote{key, 63};
+    return GSX_OK;
+}
+
 extern "C" int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed)
 {
     // GSX_ISECT_PATH = binned | legacy forces the choice (tests, A/B); GSX_ISECT_LEGACY is the older spelling of "legacy"
@@ -676,7 +721,12 @@ extern "C" int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint3
     // 2 M (245 rows per tile, lists of ~930) 0.399 / 0.470; four cameras: 4 x 250 k 0.265 / 0.222, 4 x 1 M 0.757 / 0.584.
     // Clustered scenes are caught by the skew test (bn_overflow); very small calls (garden x1, 112 k clustered rows: 0.17 / 0.29)
     // stay Gaussian-major - per IMAGE: four cameras over the same 112 k rows (1020 nearly empty bins each) 0.28 / 0.41.
-    return g.rows_per_image >= 196608 && g.rows_per_image <= 144ll * (int64_t)g.n_tiles;
+    // Round 4 (f64 sort network, a workgroup per CU on small inputs: profiles/r08_ab.md #29): the uniform scene is faster binned
+    // from 60 k rows on (0.068 / 0.114 ms; 120 k 0.071 / 0.117; the 100 k near rows a far plane leaves of c3 0.107 / 0.167), the
+    // clustered garden stays faster Gaussian-major at every size (x1 0.207 / 0.128 forced) - it fails the skew test, and an
+    // input that did is not tried again for a while (retried_recently).
+    if (!(g.rows_per_image >= 49152 && g.rows_per_image <= 144ll * (int64_t)g.n_tiles)) return 0;
+    return retried_recently(rows, n_images, tile_w, tile_h) ? 0 : 1;
 }
 
 extern "C" int64_t gsx_isect_binned_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
@@ -708,7 +758,8 @@ static int binned_setup(const char *fn, BinArgs &a, int64_t rows, uint32_t n_ima
     {
         const char *force = getenv("GSX_ISECT_PATH"), *sk = getenv("GSX_ISECT_BIN_SKEW");
         a.g.skew_cap = (force && force[0] == 'b') ? 0 : (int32_t)(kArenaPerWave * (int)(a.g.bw * a.g.bh) * 3 / 4);
-        if (sk) a.g.skew_cap = atoi(sk);
+        a.g.skew_ratio = (force && force[0] == 'b') ? 0 : 4;
+        if (sk) { a.g.skew_cap = atoi(sk); a.g.skew_ratio = a.g.skew_cap > 0 ? 4 : 0; }
     }
     unsigned char *base = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
     if (ws == nullptr || (base - reinterpret_cast<unsigned char *>(ws)) + bin_layout(a.g, base, &a.b) > ws_bytes) {

@@ -545,6 +545,7 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
                 note_longest(flat.const_data_ptr(), M, *host_longest);
                 return {tiles_per_gauss, ids, flat};
             }
+            gsx_isect_binned_note_retry(rows, uI, utw, uth); // sent back: not tried again for the next 63 calls of this shape
         }
         Tensor count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
         { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
@@ -817,8 +818,10 @@ isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &dep
     }
     bool binned = host_total.numel() > 2 ? slot[2] != 0 : gsx_isect_binned_supported(rows, uI, utw, uth, 0) != 0;
     if (binned && M == GSX_ISECT_RETRY) {
-        // the binned path's entry workspace was too small for this scene (very large Gaussians): count again Gaussian-major
+        // the binned path's entry workspace was too small for this scene (very large Gaussians), or a bin too crowded: count
+        // again Gaussian-major, and do not try this shape again for a while
         binned   = false;
+        gsx_isect_binned_note_retry(rows, uI, utw, uth);
         count_ws = bytes(gsx_isect_fused_count_workspace_bytes(rows, uI, utw, uth), means2d);
         { Timed timed_("gsx_isect_fused_count", L.stream); check(gsx_isect_fused_count(fp(means2d), cp<int32_t>(radii), fp(conics), fp(opac), nullptr, rows, uI, uts, utw, uth,
                                     mp<int32_t>(tiles_per_gauss), offsets.mutable_data_ptr<int32_t>(),

@@ -384,6 +384,9 @@ int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *radii, const 
  * ------------------------------------------------------------------------------------------- */
 #define GSX_ISECT_RETRY (-2)
 int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed);
+/* A binding that got GSX_ISECT_RETRY says so: gsx_isect_binned_supported() then answers 0 for the next 63 inputs of that shape
+ * (row count to 64 k, images, tile grid) - a trainer renders the same clustered scene every step - and probes again after. */
+int gsx_isect_binned_note_retry(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h); /* returns 0 */
 int64_t gsx_isect_binned_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
 int64_t gsx_isect_binned_emit_workspace_bytes(int64_t n_isects);
 int gsx_isect_binned_count(const float *means2d, const int32_t *radii, const float *depths, const float *conics,

@@ -354,6 +354,29 @@ def test_isect_sort_networks_match_oracle(G, O, monkeypatch, path, case, sort):
     test_isect_paths_match_oracle(G, O, monkeypatch, path, case)
 
 
+def test_isect_remembers_an_input_that_sent_the_binned_path_back(G, O):
+    """A clustered scene fails the binned path's skew test and the call starts over Gaussian-major; the next calls of that shape
+    must not pay for the attempt again (gsx_isect_binned_note_retry), and every call returns the oracle's lists."""
+    from gsplat_amd import _cabi
+    sc, W, H = make_scene(N=300000, C=1, width=1280, height=720, seed=4)
+    sc["means"][:, :2] *= 0.12
+    a, rad, m2, d, con, op = _project_scene(G, sc, W, H)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    if not _cabi._lib.gsx_isect_binned_supported(rad.numel() // 2, 1, tw, th, 0):
+        pytest.skip("this shape was sent back earlier in this process")
+    tried = []
+    for _ in range(3):
+        _cabi.profile_begin()
+        tpg, ids, fl = G.isect_tiles(m2, rad, d, 16, tw, th, conics=con, opacities=op)
+        torch.cuda.synchronize()
+        tried.append(any("binned" in k for k in _cabi.profile_end()))
+    assert tried[0], "the first call tries the tile-owner-major path"
+    tpg_o, ids_o, fl_o = O.isect_tiles(cpu(m2), cpu(rad), cpu(d), 16, tw, th, conics=cpu(con), opacities=cpu(op))
+    assert torch.equal(cpu(ids), ids_o) and torch.equal(cpu(fl), fl_o) and torch.equal(cpu(tpg), tpg_o)
+    # the scene is crowded enough to be sent back (x0.12: bins of > 10 k entries): no second attempt
+    assert tried[1:] == [False, False], tried
+
+
 @pytest.mark.parametrize("case", ["giants-retry", "ellipse-ts4", "aabb-3img-ts8", "cluster-long-tiles", "packed", "depth-ties"])
 def test_isect_fused_span_records_match_oracle(G, O, monkeypatch, case):
     """Very large inputs (c4: 16 M rows) keep, per row, the spans the counting pass's walk found, and the emission reads them
