@@ -5,8 +5,10 @@
 //
 // Two networks over the same layout:
 //   *_int   compare-exchange on the words as unsigned integers. On gfx950 that is v_cmp_lt_u64 + v_cmp_gt_u64 (the compiler
-//           turns the two selects into umin / umax and expands each) + 4 v_cndmask per exchange: ~46 issue cycles per wave.
-//   *_f64   the same words read as IEEE doubles: v_min_f64 + v_max_f64 per exchange (8 .. 16 cycles). A positive normal double
+//           turns the two selects into umin / umax and expands each) + 4 v_cndmask per exchange: six instructions of the
+//           3.6-cycle class (profiles/issue_rate_f64.json: v_cmp_gt_u64 0.56 / ns / SIMD, like every compare).
+//   *_f64   the same words read as IEEE doubles: v_min_f64 + v_max_f64 per exchange - two instructions of the same class
+//           (v_min_f64 0.55 / ns / SIMD). A positive normal double
 //           orders exactly like its bit pattern, min / max return one operand unchanged, and a descending block is the
 //           ascending network on the NEGATED words (one v_xor on the high dword when a word is loaded and stored, where the
 //           integer network complements both dwords). Valid when every high dword (the depth's float bits) lies in

@@ -82,7 +82,7 @@ static const char *kNames[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v
 #define I_MAC(r) "v_fmac_f32 %" #r ", %8, %9\n"
 #define I_MINF64(r) "v_min_f64 %" #r ", %" #r ", %8\n"
 #define I_CMPU64(r) "v_cmp_gt_u64_e64 %10, %" #r ", %8\n"
-#define I_CMPU64CND(r) "v_cmp_gt_u64 vcc, %" #r ", %8\n v_cndmask_b32 %" #r ", %" #r ", %9, vcc\n v_cndmask_b32 %11, %11, %9, vcc\n"
+#define I_CMPU64CND(r) "v_cmp_gt_u64 vcc, %" #r ", %8\n v_cndmask_b32 %11, %11, %9, vcc\n v_cndmask_b32 %12, %12, %9, vcc\n"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(1024) rate_kernel(int iters, uint64_t *cycles,
         if (OP == V_MAC) BLOCK(I_MAC, VREGS, "v"(a), "v"(b));
         if (OP == MIN_F64) BLOCK(I_MINF64, PREGS, "v"(a2), "v"(b2));
         if (OP == CMP_U64) asm volatile(IND64(I_CMPU64) : PREGS, "+v"(a2), "+v"(b2), "+s"(sm) : : );
-        if (OP == CMP_U64_CND) { if (DEP) asm volatile(DEP64(I_CMPU64CND) : PREGS, "+v"(a2), "+v"(b), "+s"(sm), "+v"(a) : : "vcc"); else asm volatile(IND64(I_CMPU64CND) : PREGS, "+v"(a2), "+v"(b), "+s"(sm), "+v"(a) : : "vcc"); }
+        if (OP == CMP_U64_CND) { float c2 = b; if (DEP) asm volatile(DEP64(I_CMPU64CND) : PREGS, "+v"(a2), "+v"(b), "+s"(sm), "+v"(a), "+v"(c2) : : "vcc"); else asm volatile(IND64(I_CMPU64CND) : PREGS, "+v"(a2), "+v"(b), "+s"(sm), "+v"(a), "+v"(c2) : : "vcc"); a += c2; }
         if (OP == GLOBAL_ATOMIC_ADD) asm volatile(DEP64(I_GATOM) "s_waitcnt vmcnt(0)\n" : UREGS, "+v"(a), "+v"(c), "+v"(gaddr) : : "memory");
     }
     const uint64_t t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
