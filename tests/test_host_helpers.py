@@ -49,3 +49,48 @@ def test_tile_origin_moments_give_the_mean_relative_moments(seed):
                      yy=(np.abs(w64) * dy * dy).sum())
         for k in want:  # error relative to the size of the terms that are summed (what an fp32 direct sum would also see)
             assert abs(float(got[k]) - want[k]) <= 2e-5 * scale[k] + 1e-6, (k, ax, ay, float(got[k]), want[k])
+
+
+def test_sort_words_order_like_doubles_where_the_kernels_say_so():
+    """csrc/bitonic64.hpp sorts the 64-bit words (depth bits << 32 | row) with v_min_f64 / v_max_f64: a word whose high dword
+    lies in [0x00100000, 0x7FF00000) is a positive normal double, and those order exactly like their bit patterns; negating
+    both words (the network's descending blocks) reverses the order; +inf (the pad) is behind every such word. Everything
+    else (bt_key_is_odd) takes the integer network. This is that claim, on the edges and on random words."""
+    lo_edge, hi_edge = 0x00100000, 0x7FF00000
+
+    def is_odd(depth_bits):  # bt_key_is_odd
+        return ((depth_bits - lo_edge) & 0xFFFFFFFF) >= (hi_edge - lo_edge)
+
+    for bits, odd in ((0x00000000, True), (0x000FFFFF, True), (0x00100000, False), (0x3F800000, False), (0x7F7FFFFF, False),
+                      (0x7F800000, False), (0x7FC00000, False), (0x7FEFFFFF, False), (0x7FF00000, True), (0x80000000, True),
+                      (0xBF800000, True), (0xFFFFFFFF, True)):
+        assert is_odd(bits) == odd, hex(bits)
+    rng = np.random.default_rng(0)
+    hi = rng.integers(lo_edge, hi_edge, size=20000, dtype=np.uint64)
+    hi[:6] = [lo_edge, lo_edge, hi_edge - 1, hi_edge - 1, 0x3F800000, 0x3F800000]  # ties on the depth: the row decides
+    lo = rng.integers(0, 1 << 32, size=20000, dtype=np.uint64)
+    words = np.unique((hi << np.uint64(32)) | lo)
+    as_f64 = words.view(np.float64)
+    assert np.all(np.isfinite(as_f64)) and np.all(as_f64 > 0)
+    assert np.all(np.diff(as_f64) > 0), "ascending words are ascending doubles (np.unique sorted the integers)"
+    assert np.all(np.diff((words ^ np.uint64(1 << 63)).view(np.float64)) < 0), "negated: descending"
+    assert np.uint64(0x7FF0000000000000).view(np.float64) == np.inf and np.all(as_f64 < np.inf)
+    pair = np.array([words[5], words[4]])
+    assert np.minimum(*pair.view(np.float64)).view(np.uint64) == words[4], "min returns an operand's bits unchanged"
+
+
+def test_pixel_linear_strides_recognises_the_views_autograd_hands_over():
+    """_ops._pixel_linear_strides: which v_render_colors layouts the compositing backward reads in place."""
+    from gsplat_amd._ops import _pixel_linear_strides as f
+
+    I, H, W, D = 2, 5, 7, 3
+    assert f(torch.zeros(I, H, W, D)) is None  # contiguous: the plain path
+    assert f(torch.tensor(1.0).expand(I, H, W, D)) == (0, 0)  # gradient of sum()
+    assert f(torch.zeros(D).expand(I, H, W, D)) == (0, 1)  # one value per channel
+    assert f(torch.zeros(I, H, W, 5)[..., 1:4]) == (5, 1)  # channels of a wider image
+    assert f(torch.zeros(I, H, W, 1).expand(I, H, W, D)) == (1, 0)  # one value per pixel
+    assert f(torch.zeros(I, W, H, D).transpose(1, 2)) is None  # not linear in (i H + y) W + x: copied
+    assert f(torch.zeros(I, H, 2 * W, D)[:, :, ::2]) == (6, 1)  # every other column of a 2 W image: still linear in the pixel
+    assert f(torch.zeros(I, H, W + 2, D)[:, :, :W]) is None  # padded rows: row stride != W * pixel stride
+    assert f(torch.zeros(1, H, W, D)[0].expand(I, H, W, D)) is None  # images on top of each other
+    assert f(torch.zeros(H, W, 6)[..., ::2]) == (6, 2)  # no image dimension
