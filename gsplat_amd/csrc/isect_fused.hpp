@@ -7,6 +7,9 @@
 
 namespace gsx {
 
+struct SpanRecord;                     // isect_spans.hpp: 16 bytes per row
+constexpr int64_t kSpanRecordBytes = 16;
+
 struct FusedGeom {
     int64_t rows;           // all rows
     int64_t rows_per_image; // dense: N; packed (single image): rows
@@ -25,7 +28,7 @@ struct FusedArgs {
     const uint8_t *tile_mask;     // [n_images * n_tiles] or null: only tiles with a non-zero flag receive intersections
     int32_t *tiles_per_gauss;     // [R]   (count)
     int32_t *table;               // [n_chunks][n_tiles]: histogram, then exclusive prefix over an image's chunks
-    uint4 *spans;                 // [R] or null: what the counting pass's walk found, row by row (isect_fused.hip: SpanPacker)
+    SpanRecord *spans;            // [R] or null: what the counting pass's walk found, row by row (isect_fused.hip: SpanPacker)
     const int32_t *isect_offsets; // [n_images * n_tiles] (emit)
     uint2 *bucketed;              // [M] (emit)
 };

@@ -414,7 +414,7 @@ int launch_big_tile_sort(const TileSortArgs &a, hipStream_t s) { return launch_w
 static int64_t fused_count_ws_bytes(const FusedGeom &g)
 {
     return align256((int64_t)g.n_chunks * g.n_tiles * 4) + align256((int64_t)g.n_images * g.n_tiles * 4)
-           + (fused_records_spans(g.rows) ? align256((g.rows > 0 ? g.rows : 1) * (int64_t)sizeof(uint4)) : 0) + 512;
+           + (fused_records_spans(g.rows) ? align256((g.rows > 0 ? g.rows : 1) * kSpanRecordBytes) : 0) + 512;
 }
 static int64_t fused_emit_ws_bytes(int64_t n, uint32_t n_bins)
 {
@@ -530,7 +530,7 @@ static int fused_setup(const char *fn, FusedArgs &a, int64_t rows, uint32_t n_im
     unsigned char *p = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(count_ws) + 255) & ~(uintptr_t)255);
     a.table = reinterpret_cast<int32_t *>(p); p += align256((int64_t)a.geom.n_chunks * a.geom.n_tiles * 4);
     *totals = reinterpret_cast<int32_t *>(p); p += align256((int64_t)a.geom.n_images * a.geom.n_tiles * 4);
-    a.spans = fused_records_spans(a.geom.rows) ? reinterpret_cast<uint4 *>(p) : nullptr;
+    a.spans = fused_records_spans(a.geom.rows) ? reinterpret_cast<SpanRecord *>(p) : nullptr;
     return GSX_OK;
 }
 

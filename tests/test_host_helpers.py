@@ -94,3 +94,23 @@ def test_pixel_linear_strides_recognises_the_views_autograd_hands_over():
     assert f(torch.zeros(I, H, W + 2, D)[:, :, :W]) is None  # padded rows: row stride != W * pixel stride
     assert f(torch.zeros(1, H, W, D)[0].expand(I, H, W, D)) is None  # images on top of each other
     assert f(torch.zeros(H, W, 6)[..., ::2]) == (6, 2)  # no image dimension
+
+
+@pytest.mark.parametrize("tool", ["check_binwalk", "check_spans"])
+def test_tile_walk_host_checks(tool, tmp_path):
+    """The walk headers are host + device code: tools/check_binwalk.cpp (clipped walks over a partition of the grid = the walk)
+    and tools/check_spans.cpp (a row's 16-byte span record replays as the walk, or says it does not fit) are compiled for the
+    HOST and run over 300 k random and adversarial Gaussians."""
+    import os
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / tool)
+    subprocess.run([hipcc, "-O2", "-std=c++17", "-ffp-contract=off", "-x", "hip", "--cuda-host-only", "-w", "-o", exe,
+                    os.path.join(root, "tools", tool + ".cpp")], check=True, timeout=600)
+    r = subprocess.run([exe, "300000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " bad 0" in r.stdout, r.stdout + r.stderr
