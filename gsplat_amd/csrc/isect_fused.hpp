@@ -28,7 +28,7 @@ struct FusedArgs {
     const uint8_t *tile_mask;     // [n_images * n_tiles] or null: only tiles with a non-zero flag receive intersections
     int32_t *tiles_per_gauss;     // [R]   (count)
     int32_t *table;               // [n_chunks][n_tiles]: histogram, then exclusive prefix over an image's chunks
-    SpanRecord *spans;            // [R] or null: what the counting pass's walk found, row by row (isect_fused.hip: SpanPacker)
+    SpanRecord *spans;            // [R] or null: what the counting pass's walk found, row by row (isect_spans.hpp: SpanPacker)
     const int32_t *isect_offsets; // [n_images * n_tiles] (emit)
     uint2 *bucketed;              // [M] (emit)
 };
