@@ -286,13 +286,21 @@ def _common_row_views(ts, widths):
 
 
 _row_map_lock = threading.Lock()
-_row_map_cache: list = []  # newest first: (key, the id tensors - kept alive so that their addresses stay theirs -, row_map)
+_row_map_cache: list = []  # at most one (key, id tensors, row_map): see _packed_row_map
+
+
+def clear_row_map_cache() -> None:
+    """Drops the cached row map (and with it the references that keep a step's id tensors alive). rasterization() calls this
+    when a new forward pass starts: the map only ever serves the two packed backward kernels of ONE step."""
+    with _row_map_lock:
+        _row_map_cache.clear()
 
 
 def _packed_row_map(batch_ids, camera_ids, gaussian_ids, B: int, C: int, N: int) -> Tensor:
     """int32 [B*C*N]: packed row of every (batch, camera, gaussian), -1 where the pair is not stored. The packed
     backward kernels walk it Gaussian-major (one thread per Gaussian, no atomics). The SH backward and the projection
-    backward of a step ask for the same map: the last two are kept (keyed by the id tensors' storage and version)."""
+    backward of a step ask for the same map: the last one is kept, keyed by the id tensors' storage and version - and the
+    entry HOLDS those tensors, so that their addresses cannot be handed to other tensors while it is alive."""
     ids = (batch_ids.contiguous(), camera_ids.contiguous(), gaussian_ids.contiguous())
     key = tuple((t.data_ptr(), t.numel(), t._version) for t in ids) + (B, C, N)
     with _row_map_lock:
@@ -302,8 +310,7 @@ def _packed_row_map(batch_ids, camera_ids, gaussian_ids, B: int, C: int, N: int)
     row_map = torch.empty(B * C * N, device=gaussian_ids.device, dtype=torch.int32)
     call("gsx_packed_row_map", ptr(ids[0]), ptr(ids[1]), ptr(ids[2]), gaussian_ids.shape[0], B, C, N, ptr(row_map))
     with _row_map_lock:
-        _row_map_cache.insert(0, (key, ids, row_map))
-        del _row_map_cache[2:]
+        _row_map_cache[:] = [(key, ids, row_map)]
     return row_map
 
 

@@ -170,6 +170,10 @@ def rasterization(
     else:
         viewmats_proj, Ks_proj, C_proj = viewmats, Ks, C
 
+    if packed:
+        from ._ops import clear_row_map_cache
+
+        clear_row_map_cache()  # the previous step's row map (and the id tensors it holds) can go
     calc_comp = rasterize_mode == "antialiased"
     if with_ut:
         # Unscented-Transform projection through the (possibly distorted) camera model; no gradient reaches the geometry
