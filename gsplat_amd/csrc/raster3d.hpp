@@ -78,6 +78,9 @@ struct Raster3DArgs {
     int32_t *seg_last;        // [item][256]  mode 2 out: last contributing list index, -1 = none
     // backward, dense layouts: workgroup -> tile map sorted by work (raster3d_bwd.hip: tile_order_*), or null = launch order
     const int32_t *tile_order;
+    // forward, dense layouts (one-wave kernel, raster3d_fwd_w.hip): [I * tile_h * tile_w] what each tile costs the backward - its
+    // list up to the last contributor, the quantity tile_order.hip sorts by - or null
+    int32_t *tile_cost;
 };
 
 // Block index -> (image, tile) with an XCD-aware remap: hardware places workgroup b on
@@ -195,6 +198,13 @@ int64_t tile_order_workspace_bytes(uint32_t n_images, uint32_t tile_w, uint32_t 
 const int32_t *build_tile_order(const int32_t *isect_offsets, const int32_t *last_ids, uint32_t n_images, uint32_t tile_size,
                                 uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height, uint32_t n_isects, void *ws,
                                 int64_t ws_bytes, hipStream_t stream, int *rc);
+
+// One wave per tile (raster3d_fwd_w.hip): <= 4 channels per launch, 16 x 16 tiles, no segments. GSX_RASTER3D_FWD=q|w at run time.
+#ifndef GSX_RASTER3D_FWD_DEFAULT
+#define GSX_RASTER3D_FWD_DEFAULT 'w'
+#endif
+bool raster3d_fwd_w_applies(const Raster3DArgs &a);
+int raster3d_fwd_w_launch(const Raster3DArgs &a, hipStream_t stream);
 
 // thread -> pixel inside the tile.
 __device__ __forceinline__ void tile_pixel(uint32_t tid, uint32_t tile_size, uint32_t &lx, uint32_t &ly)

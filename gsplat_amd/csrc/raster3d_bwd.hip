@@ -699,6 +699,12 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
 #ifndef GSX_BWD_W_WAVES
 #define GSX_BWD_W_WAVES 3
 #endif
+#ifndef GSX_BWD_W_WIDE_MIN_DEFAULT
+#define GSX_BWD_W_WIDE_MIN_DEFAULT 9
+#endif
+#ifndef GSX_BWD_W_ABS_WAVES
+#define GSX_BWD_W_ABS_WAVES 2
+#endif
 #ifndef GSX_BWD_W_PREFETCH // the next survivor's staged row is read while the current one is composited
 #define GSX_BWD_W_PREFETCH 0
 #endif
@@ -708,10 +714,11 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
 #ifndef GSX_BWD_W_STAGE_AHEAD // the next batch's rows are requested before the current batch is walked
 #define GSX_BWD_W_STAGE_AHEAD 1
 #endif
-template <int CH>
+template <int CH, bool ABS = false>
 struct BwdWCfg {
-    static constexpr int K     = CH + 6;
-    static constexpr int NCOL  = 6 + CH;
+    static constexpr int GEO   = 6 + (ABS ? 2 : 0); // geometry columns of the gradient row (+ |v_mean2d| with absgrad)
+    static constexpr int K     = CH + GEO;
+    static constexpr int NCOL  = GEO + CH;
     static constexpr int BATCH = 64;     // one staged Gaussian per lane
     static constexpr int SLOTS = 4;      // Gaussians per turn: 4 slots x 4 quadrants x 4 row pairs = 64 lanes
     static constexpr int GP    = 36;     // floats per group of 16 pixels (two rows of a quadrant): 16 x (fac, w) + 4 (bank spread)
@@ -720,12 +727,14 @@ struct BwdWCfg {
     static constexpr size_t smem = (size_t)BATCH * (sizeof(StagedRow) + sizeof(float4)) + sizeof(float) * SLOTS * SP;
 };
 
-template <int CH>
+template <int CH, bool ABS>
 __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
 {
-    using Cfg           = BwdWCfg<CH>;
+    using Cfg           = BwdWCfg<CH, ABS>;
     constexpr int K     = Cfg::K;
     constexpr int NCOL  = Cfg::NCOL;
+    constexpr int GEO   = Cfg::GEO;
+    static_assert(NCOL <= 16, "lane c of a 16-lane row owns column c of the gradient row");
     constexpr int BATCH = Cfg::BATCH;
     constexpr int SLOTS = Cfg::SLOTS;
     constexpr int GP = Cfg::GP, QP = Cfg::QP, SP = Cfg::SP;
@@ -823,6 +832,22 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
         if (live && ((info >> tq) & 1)) { // quadrants the Gaussian did not reach were never written: their lanes add nothing
             const v4f *rd = reinterpret_cast<const v4f *>(s_w + tg * SP + tq * QP + tj * GP);
             float rs[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}; // per row: sum w, sum w ul, sum w ul^2 (ul = 0..7: constants)
+            // local (ul, vl in {0, 1}) -> tile-centre coordinates: u = ul + u0, v = vl + v0
+            const float u0 = (float)((tq & 1) << 3) - 7.5f, v0 = (float)(((tq >> 1) << 3) + 2 * tj) - 7.5f;
+            // absgrad (reference Device.cuh: v_xy_abs = |v_sigma * conic . d|, summed per PIXEL): not a moment of w, but
+            // conic . d * log2(e) is affine in the pixel - the gradient of the staged exponent, (gu + 2 nA u + nB v,
+            // gv + nB u + 2 nC v) - so the turn forms it per pixel from two row constants: two instructions per pixel and axis
+            [[maybe_unused]] float gxr[2] = {0.f, 0.f}, gyr[2] = {0.f, 0.f}, ax2 = 0.f, bx1 = 0.f, sabs[2] = {0.f, 0.f};
+            if constexpr (ABS) {
+                const v4f q0 = s_st[info >> 4].p0, q1 = s_st[info >> 4].p1; // e0, gu, gv, lo | nA, nB, nC, -
+                ax2 = 2.0f * q1.x; bx1 = q1.y;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float vr = v0 + (float)r;
+                    gxr[r] = fmaf(ax2, u0, fmaf(q1.y, vr, q0.y));
+                    gyr[r] = fmaf(q1.y, u0, fmaf(2.0f * q1.z, vr, q0.z));
+                }
+            }
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
                 const v4f x       = rd[h]; // (fac, w) of pixels 2h, 2h + 1
@@ -836,10 +861,17 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
                     rs[pp >> 3][0] += ww[e];
                     rs[pp >> 3][1] = fmaf(ww[e], ul, rs[pp >> 3][1]);
                     rs[pp >> 3][2] = fmaf(ww[e], ul * ul, rs[pp >> 3][2]);
+                    if constexpr (ABS) {
+                        const float gx = fmaf(ax2, ul, gxr[pp >> 3]), gy = fmaf(bx1, ul, gyr[pp >> 3]);
+                        sabs[0] = fmaf(fabsf(ww[e]), fabsf(gx), sabs[0]);
+                        sabs[1] = fmaf(fabsf(ww[e]), fabsf(gy), sabs[1]);
+                    }
                 }
             }
-            // local (ul, vl in {0, 1}) -> tile-centre coordinates: u = ul + u0, v = vl + v0
-            const float u0 = (float)((tq & 1) << 3) - 7.5f, v0 = (float)(((tq >> 1) << 3) + 2 * tj) - 7.5f;
+            if constexpr (ABS) {
+                acc[CH + 6] = sabs[0];
+                acc[CH + 7] = sabs[1];
+            }
             const float s0 = rs[0][0] + rs[1][0], s1 = rs[0][1] + rs[1][1], s2 = rs[0][2] + rs[1][2];
             const float t1 = rs[1][0], m11 = rs[1][1]; // sum w vl (= sum w vl^2), sum w ul vl
             const float Su = fmaf(u0, s0, s1);
@@ -875,13 +907,14 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
             else if (c == 3) val = ax * (ay * S0 - Sv) - ay * Su + acc[CH + 4];
             else if (c == 4) val = 0.5f * (ay * (ay * S0 - 2.0f * Sv) + acc[CH + 5]);
             else if (c == 5) val = -S0 * __builtin_amdgcn_exp2f(-lo); // v_opacity = sum vis v_alpha = -S_w / opacity
+            else if (ABS && c < GEO) val = kInvLog2e * (c == 6 ? acc[CH + (ABS ? 6 : 0)] : acc[CH + (ABS ? 7 : 0)]); // sum |v_mean2d|
             else {
-                const int k = c - 6;
+                const int k = c - GEO;
                 val         = 0.0f;
 #pragma unroll
                 for (int kk = 0; kk < CH; ++kk) val = (k == kk) ? acc[kk] : val;
                 put = k < (int)a.nch;
-                col = 6 + (int)a.ch_off + k;
+                col = GEO + (int)a.ch_off + k;
             }
             if (put) atomic_add_f32(a.v_rows + (size_t)id * a.row_stride + col, val);
         }
@@ -1056,11 +1089,18 @@ template <int CH>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSX_BWD_W_WAVES)))
 raster3d_bwd_w_kernel(Raster3DArgs a)
 {
-    raster3d_bwd_w_body<CH>(a);
+    raster3d_bwd_w_body<CH, false>(a);
 }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) raster3d_bwd_w4_kernel(Raster3DArgs a)
 {
-    raster3d_bwd_w_body<4>(a);
+    raster3d_bwd_w_body<4, false>(a);
+}
+// absgrad: two more sums per (tile, Gaussian), formed per pixel in the turn (see there); two waves per SIMD
+template <int CH>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSX_BWD_W_ABS_WAVES)))
+raster3d_bwd_w_abs_kernel(Raster3DArgs a)
+{
+    raster3d_bwd_w_body<CH, true>(a);
 }
 
 // Variant T is the default where it applies; GSX_RASTER3D_BWD=r selects the reduction kernel (read once per process).
@@ -1083,15 +1123,18 @@ static int launch_bwd(const Raster3DArgs &a, hipStream_t stream)
     const uint32_t n_blocks = a.sp_active_tiles ? a.n_active : a.tile_w * a.tile_h * a.n_images;
     if (n_blocks == 0 || a.n_isects == 0) return GSX_OK;
     const uint32_t grid  = ((n_blocks + 7u) / 8u) * 8u;
-    if constexpr (!ABS && CH <= 4) {
+    if constexpr (CH <= 4) {
         if (a.tile_size == 16 && bwd_variant() == 'w') {
-            if constexpr (CH == 4) raster3d_bwd_w4_kernel<<<dim3(grid), dim3(64), BwdWCfg<4>::smem, stream>>>(a);
+            if constexpr (ABS) raster3d_bwd_w_abs_kernel<CH><<<dim3(grid), dim3(64), BwdWCfg<CH, true>::smem, stream>>>(a);
+            else if constexpr (CH == 4) raster3d_bwd_w4_kernel<<<dim3(grid), dim3(64), BwdWCfg<4>::smem, stream>>>(a);
             else raster3d_bwd_w_kernel<CH><<<dim3(grid), dim3(64), BwdWCfg<CH>::smem, stream>>>(a);
             return check_launch("raster3d_bwd_w");
         }
-        if (a.tile_size == 16 && use_variant_t()) {
-            raster3d_bwd_t_kernel<CH><<<dim3(grid), dim3(256), BwdTCfg<CH>::smem, stream>>>(a);
-            return check_launch("raster3d_bwd_t");
+        if constexpr (!ABS) {
+            if (a.tile_size == 16 && use_variant_t()) {
+                raster3d_bwd_t_kernel<CH><<<dim3(grid), dim3(256), BwdTCfg<CH>::smem, stream>>>(a);
+                return check_launch("raster3d_bwd_t");
+            }
         }
     }
     const uint32_t block = a.tile_size <= 8 ? 64u : 256u;
@@ -1114,14 +1157,31 @@ int raster3d_bwd_t_launch_items(const Raster3DArgs &a, hipStream_t stream)
 }
 bool raster3d_bwd_uses_variant_t() { return use_variant_t(); }
 
+// More than four channels: variant W takes them FOUR AT A TIME (the gradient of alpha is linear in the channels, so every
+// launch adds its share of the geometry gradients; first_chunk carries the alpha cotangent) from `GSX_BWD_W_WIDE_MIN` channels
+// on; below that one launch of the reduction kernel is cheaper than two of W. 0 switches the chunked launches off.
+static uint32_t bwd_w_wide_min()
+{
+    static const uint32_t v = [] {
+        const char *e = getenv("GSX_BWD_W_WIDE_MIN");
+        return e ? (uint32_t)atoi(e) : (uint32_t)GSX_BWD_W_WIDE_MIN_DEFAULT;
+    }();
+    return v;
+}
+static bool bwd_w_wide(const Raster3DArgs &a)
+{
+    return a.cdim > 4 && a.tile_size == 16 && bwd_variant() == 'w' && bwd_w_wide_min() != 0 && a.cdim >= bwd_w_wide_min();
+}
+
 template <bool ABS>
 static int bwd_dispatch(Raster3DArgs a, hipStream_t stream)
 {
+    const uint32_t width = bwd_w_wide(a) ? 4u : 32u; // channels per launch
     uint32_t off = 0;
     bool first   = true;
     do {
         const uint32_t rem = a.cdim - off;
-        const uint32_t n   = rem > 32 ? 32 : rem;
+        const uint32_t n   = rem > width ? width : rem;
         a.ch_off           = off;
         a.nch              = n;
         a.first_chunk      = first ? 1u : 0u;
@@ -1194,7 +1254,8 @@ extern "C" int gsx_raster3d_bwd_ws(
         GSX_REQUIRE(v_colors_channel_stride >= 0, "gsx_raster3d_bwd_ws: negative channel stride");
         a.vrc_strided = 1u; a.vrc_ps = v_colors_pixel_stride; a.vrc_cs = v_colors_channel_stride;
     }
-    if (!has_abs && cdim <= 4 && bwd_variant() != 'r') { // the launches that read the order: variants T and W
+    // the launches that read the order: variant W (also with absgrad, and four channels at a time), variant T
+    if (bwd_variant() == 'w' ? (tile_size == 16 && (cdim <= 4 || bwd_w_wide(a))) : (!has_abs && cdim <= 4 && bwd_variant() != 'r')) {
         int rc       = GSX_OK;
         a.tile_order = a.sp_active_tiles ? nullptr
                                          : build_tile_order(a.isect_offsets, a.last_ids, a.n_images, a.tile_size, a.tile_w, a.tile_h,

@@ -93,6 +93,33 @@ def test_raster3d_bwd_variants_match_the_default(variant):
                               name=f"case {i} v_{k}")
 
 
+def test_raster3d_fwd_four_waves_per_tile_matches_the_default():
+    """GSX_RASTER3D_FWD=q: the four-waves-per-tile forward (csrc/raster3d_fwd.hip) against the default one-wave-per-tile
+    kernel (csrc/raster3d_fwd_w.hip). Same staged form and the same per-pixel arithmetic in the same order: the renders must
+    agree to rounding (a different cull never changes a result), the gradients (which start from the forward's state) too."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    assert os.environ.get("GSX_RASTER3D_FWD", "") == "", "run this test with the default kernel selection"
+    import gsplat_amd
+    from _util import assert_close_ratio
+
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "t.npz")
+        code = _SCRIPT % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True,
+                           env=dict(os.environ, GSX_RASTER3D_FWD="q"), timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        alt = dict(np.load(path))
+    for i, case in enumerate(CASES):
+        ref = run_case(gsplat_amd, case)
+        assert_close_ratio(torch.from_numpy(alt[f"{i}_render"]), torch.from_numpy(ref["render"]), 1e-6, 1e-6, max_bad_ratio=1e-5,
+                           name=f"case {i} render")
+        for k, v in ref.items():
+            if k != "render":
+                assert_grad_close(torch.from_numpy(alt[f"{i}_{k}"]), torch.from_numpy(v), rel=3e-4, max_bad_ratio=1e-5,
+                                  name=f"case {i} v_{k}")
+
+
 _SCRIPT_2DGS = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--scale-mult", type=float, default=1.0)
+    ap.add_argument("--absgrad", action="store_true")
+    ap.add_argument("--tag", default="")
     args = ap.parse_args()
     import bench
     import gsplat_amd
@@ -50,9 +52,10 @@ def main():
 
     def bwd():
         return ops.rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opac, None, None, offs, fl, alphas, last_ids,
-                                                W, H, 16, False, v_rc, v_ra, False)
+                                                W, H, 16, args.absgrad, v_rc, v_ra, False)
 
-    res = {"lib": os.path.basename(_cabi.lib_path()), "n_isects": int(fl.numel()), "channels": D}
+    res = {"tag": args.tag, "lib": os.path.basename(_cabi.lib_path()), "n_isects": int(fl.numel()), "channels": D,
+           "absgrad": args.absgrad, "env": {k: v for k, v in os.environ.items() if k.startswith("GSX_")}}
     for name, fn in (("fwd", fwd), ("bwd", bwd)):
         for _ in range(3):
             fn()
