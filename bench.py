@@ -726,18 +726,34 @@ def main():
                       f"compositing/intersection + torch-CPU projection/SH) on {cores} host threads",
             "t_fwd_s": round(ref["t_fwd"], 3), "t_bwd_s": round(ref["t_bwd"], 3), "n_isects": ref["n_isects"],
         }
-        # the reference's OWN CPU path can only run configs[0] (c1) and only where its checkout is (the build container):
-        # tools/time_c1_reference_cpu.py timed it there next to this port; quoted from the committed record, host stated
+        # the reference's OWN CPU path (gsplat/cuda/_torch_impl.py) can only run configs[0] (c1): timed HERE, on this host's
+        # cores, from the archive of the reference's Python files that build() stages and that travels with the snapshot
+        # (oracle/_ref/reference_py.zip; a subprocess, so that the reference's `gsplat` package never enters this process).
+        # Without the archive the committed record of the build container is quoted, labelled as such.
+        ref_zip = os.path.join(ROOT, "oracle", "_ref", "reference_py.zip")
+        c1 = None
+        if os.path.exists(ref_zip):
+            try:
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_c1_reference_cpu.py"), "--ref", ref_zip,
+                                      "--out", "-", "--reps", "3", "--where", "this run's host"], capture_output=True, text=True,
+                                     timeout=180)
+                c1 = json.loads(out.stdout.strip().splitlines()[-1])
+                c1["source"] = "measured in this run (tools/time_c1_reference_cpu.py on oracle/_ref/reference_py.zip)"
+            except Exception as e:
+                c1 = None
+                result["cpu_baseline"]["c1_reference_error"] = f"{type(e).__name__}: {e}"[:300]
         c1p = os.path.join(ROOT, "profiles", "c1_reference_cpu.json")
-        if os.path.exists(c1p):
+        if c1 is None and os.path.exists(c1p):
             try:
                 c1 = json.load(open(c1p))
-                result["cpu_baseline"]["c1_reference"] = {
-                    "config": c1["config"], "reference_mpixels_per_s": c1["reference_cpu"]["mpixels_per_s"],
-                    "port_mpixels_per_s": c1["port_cpu"]["mpixels_per_s"], "host": c1["host"],
-                    "source": "profiles/c1_reference_cpu.json (not measured in this run)"}
+                c1["source"] = "profiles/c1_reference_cpu.json (not measured in this run)"
             except Exception:
-                pass
+                c1 = None
+        if c1 is not None:
+            result["cpu_baseline"]["c1_reference"] = {
+                "config": c1["config"], "reference_mpixels_per_s": c1["reference_cpu"]["mpixels_per_s"],
+                "reference_s_per_step": c1["reference_cpu"]["s_per_step"], "port_mpixels_per_s": c1["port_cpu"]["mpixels_per_s"],
+                "cores": c1["host"].get("torch_threads"), "host": c1["host"], "kind": "reference", "source": c1["source"]}
     if rank == 0:
         print(json.dumps(result), file=json_out, flush=True)
     if distributed:

@@ -99,29 +99,40 @@ def _consume_long_tile_hint() -> int:
     return longest
 
 # Stage-level callers (isect_tiles -> isect_offset_encode -> rasterize_to_pixels without rasterization() in between) have no
-# orchestrator to carry the hint: the intersection notes the longest list of its result under the address + length of
-# flatten_ids and a compositing call without a hint looks it up (csrc/torch_ops.cpp keeps the notes when the compiled shim is
-# loaded, so that Python and compiled bodies see the same ones).
-_note_compiled = _lookup_compiled = None
-_notes_py: dict = {}
+# orchestrator to carry the hint: the intersection notes the longest list of its result and a compositing call without a hint
+# looks its flatten_ids up. A note is keyed by the IDENTITY of the tensor's storage, never by an address the allocator may hand
+# out again (csrc/torch_ops.cpp keeps the notes - weak references to the StorageImpl - when the compiled shim is loaded, so that
+# Python and compiled bodies see the same ones; the fallback below holds weak references to the storages the same way).
+_notes_compiled = False
+_notes_py: list = []  # [(weakref to the untyped storage, storage offset, numel, longest)], newest last
+_notes_lock = __import__("threading").Lock()
 
 
 def _note_longest(flatten_ids: Tensor, longest: int) -> None:
     if flatten_ids.numel() == 0:
         return
-    if _note_compiled is not None:
-        _note_compiled(flatten_ids.data_ptr(), flatten_ids.numel(), int(longest))
+    if _notes_compiled:
+        torch.ops.gsplat_amd.note_longest(flatten_ids, int(longest))
         return
-    if len(_notes_py) >= 16:
-        _notes_py.pop(next(iter(_notes_py)))
-    _notes_py[flatten_ids.data_ptr()] = (flatten_ids.numel(), int(longest))
+    import weakref
+
+    st = flatten_ids.untyped_storage()
+    with _notes_lock:
+        _notes_py[:] = [e for e in _notes_py if e[0]() is not None and e[0]() is not st][-15:]
+        _notes_py.append((weakref.ref(st), flatten_ids.storage_offset(), flatten_ids.numel(), int(longest)))
 
 
 def _lookup_longest(flatten_ids: Tensor) -> int:
-    if _lookup_compiled is not None:
-        return int(_lookup_compiled(flatten_ids.data_ptr(), flatten_ids.numel()))
-    n, longest = _notes_py.get(flatten_ids.data_ptr(), (0, 0))
-    return longest if n == flatten_ids.numel() else 0
+    if _notes_compiled:
+        return int(torch.ops.gsplat_amd.lookup_longest(flatten_ids))
+    if flatten_ids.numel() == 0:
+        return 0
+    st = flatten_ids.untyped_storage()
+    with _notes_lock:
+        for ref, off, n, longest in _notes_py:
+            if ref() is st and off == flatten_ids.storage_offset() and n == flatten_ids.numel():
+                return longest
+    return 0
 
 
 COMPILED_OPS: frozenset = frozenset()  # ops whose CUDA-key body is C++ (csrc/torch_ops.cpp) rather than a function of this file
@@ -134,14 +145,8 @@ def _read_compiled_ops(path: str) -> None:
     global COMPILED_OPS
     import ctypes
 
-    global _note_compiled, _lookup_compiled
-    try:
-        lib = ctypes.CDLL(path)
-        _note_compiled, _lookup_compiled = lib.gsx_torch_note_longest, lib.gsx_torch_lookup_longest
-        _note_compiled.argtypes, _note_compiled.restype = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64], None
-        _lookup_compiled.argtypes, _lookup_compiled.restype = [ctypes.c_void_p, ctypes.c_int64], ctypes.c_int64
-    except (OSError, AttributeError):
-        _note_compiled = _lookup_compiled = None
+    global _notes_compiled
+    _notes_compiled = hasattr(torch.ops, "gsplat_amd") and hasattr(torch.ops.gsplat_amd, "note_longest")
     if os.environ.get("GSPLAT_AMD_LIB"):
         # An A/B build of the kernel library is in use (tools/mkvariant.sh): the compiled bodies are linked against the
         # DEFAULT libgsplat_amd.so and would silently run its kernels instead - keep every op on the ctypes path.

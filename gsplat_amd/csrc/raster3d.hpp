@@ -200,8 +200,9 @@ const int32_t *build_tile_order(const int32_t *isect_offsets, const int32_t *las
                                 int64_t ws_bytes, hipStream_t stream, int *rc);
 
 // One wave per tile (raster3d_fwd_w.hip): <= 4 channels per launch, 16 x 16 tiles, no segments. GSX_RASTER3D_FWD=q|w at run time.
+// NOT the default: measured SLOWER than the four-waves-per-tile kernel (0.290 against 0.199 ms at c3, see raster3d_fwd_w.hip).
 #ifndef GSX_RASTER3D_FWD_DEFAULT
-#define GSX_RASTER3D_FWD_DEFAULT 'w'
+#define GSX_RASTER3D_FWD_DEFAULT 'q'
 #endif
 bool raster3d_fwd_w_applies(const Raster3DArgs &a);
 int raster3d_fwd_w_launch(const Raster3DArgs &a, hipStream_t stream);

@@ -19,6 +19,7 @@
 //      touches ~6 cache lines instead of 64. Measured on c3: the per-tensor layout (64 lines per instruction)
 //      cost 160 us of exposed L2-atomic time out of 707 us; the AoS flush costs < 5 us.
 #include <cstdlib>
+#include <cstring>
 
 #include "raster3d.hpp"
 #include "../../include/gsplat_amd.h"
@@ -699,9 +700,6 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
 #ifndef GSX_BWD_W_WAVES
 #define GSX_BWD_W_WAVES 3
 #endif
-#ifndef GSX_BWD_W_WIDE_MIN_DEFAULT
-#define GSX_BWD_W_WIDE_MIN_DEFAULT 9
-#endif
 #ifndef GSX_BWD_W_ABS_WAVES
 #define GSX_BWD_W_ABS_WAVES 2
 #endif
@@ -1157,26 +1155,37 @@ int raster3d_bwd_t_launch_items(const Raster3DArgs &a, hipStream_t stream)
 }
 bool raster3d_bwd_uses_variant_t() { return use_variant_t(); }
 
-// More than four channels: variant W takes them FOUR AT A TIME (the gradient of alpha is linear in the channels, so every
-// launch adds its share of the geometry gradients; first_chunk carries the alpha cotangent) from `GSX_BWD_W_WIDE_MIN` channels
-// on; below that one launch of the reduction kernel is cheaper than two of W. 0 switches the chunked launches off.
-static uint32_t bwd_w_wide_min()
+// Five to eight channels: variant W takes them FOUR AT A TIME (the gradient of alpha is linear in the channels, so every launch
+// adds its share of the geometry gradients; first_chunk carries the alpha cotangent). Measured at c3 (profiles/r09_ab.md):
+// 8 channels 0.856 ms in two launches of W against 0.890 for one of the reduction kernel; 16 channels 1.70 against 1.33, 32
+// channels 3.45 against 2.48 - every launch walks the pixels again, and from three launches on that outweighs the cheaper sums.
+// Not with absgrad: sum |v_sigma g| over the pixels is not linear in the channels. GSX_BWD_W_WIDE=lo,hi overrides the range
+// (0,0 = never).
+static void bwd_w_wide_range(uint32_t &lo, uint32_t &hi)
 {
-    static const uint32_t v = [] {
-        const char *e = getenv("GSX_BWD_W_WIDE_MIN");
-        return e ? (uint32_t)atoi(e) : (uint32_t)GSX_BWD_W_WIDE_MIN_DEFAULT;
+    static const uint64_t v = [] {
+        uint32_t l = 5, h = 8;
+        if (const char *e = getenv("GSX_BWD_W_WIDE")) {
+            l = (uint32_t)atoi(e);
+            const char *c = strchr(e, ',');
+            h = c ? (uint32_t)atoi(c + 1) : l;
+        }
+        return ((uint64_t)l << 32) | h;
     }();
-    return v;
+    lo = (uint32_t)(v >> 32);
+    hi = (uint32_t)v;
 }
-static bool bwd_w_wide(const Raster3DArgs &a)
+static bool bwd_w_wide(const Raster3DArgs &a, bool has_abs)
 {
-    return a.cdim > 4 && a.tile_size == 16 && bwd_variant() == 'w' && bwd_w_wide_min() != 0 && a.cdim >= bwd_w_wide_min();
+    uint32_t lo, hi;
+    bwd_w_wide_range(lo, hi);
+    return !has_abs && a.cdim > 4 && a.tile_size == 16 && bwd_variant() == 'w' && a.cdim >= lo && a.cdim <= hi;
 }
 
 template <bool ABS>
 static int bwd_dispatch(Raster3DArgs a, hipStream_t stream)
 {
-    const uint32_t width = bwd_w_wide(a) ? 4u : 32u; // channels per launch
+    const uint32_t width = bwd_w_wide(a, ABS) ? 4u : 32u; // channels per launch
     uint32_t off = 0;
     bool first   = true;
     do {
@@ -1255,7 +1264,7 @@ extern "C" int gsx_raster3d_bwd_ws(
         a.vrc_strided = 1u; a.vrc_ps = v_colors_pixel_stride; a.vrc_cs = v_colors_channel_stride;
     }
     // the launches that read the order: variant W (also with absgrad, and four channels at a time), variant T
-    if (bwd_variant() == 'w' ? (tile_size == 16 && (cdim <= 4 || bwd_w_wide(a))) : (!has_abs && cdim <= 4 && bwd_variant() != 'r')) {
+    if (bwd_variant() == 'w' ? (tile_size == 16 && (cdim <= 4 || bwd_w_wide(a, has_abs != 0))) : (!has_abs && cdim <= 4 && bwd_variant() != 'r')) {
         int rc       = GSX_OK;
         a.tile_order = a.sp_active_tiles ? nullptr
                                          : build_tile_order(a.isect_offsets, a.last_ids, a.n_images, a.tile_size, a.tile_w, a.tile_h,

@@ -7,6 +7,9 @@
 
 namespace gsx {
 
+#ifndef GSX_FWD_AT // 1: blended alpha through one select (alpha or 0), then plain arithmetic; 0: selects on w and T (A/B)
+#define GSX_FWD_AT 1
+#endif
 constexpr int kBatch = 256;
 // Staged layout: one 48-byte row per Gaussian (raster3d.hpp StagedRow: the tile-centre polynomial of the exponent + up to
 // four colours) read with b128 + b128 + b64 from one address register; colours 4.. in a separate table.
@@ -170,7 +173,12 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 const float next_T = fmaf(-T, alpha, T);
                 const bool low     = PRE ? false : next_T <= kTransmittanceThresh; // saturated: this Gaussian is excluded
                 const bool sat = ok && low, take = ok && !sat;
+#if GSX_FWD_AT
+                const float at = take ? alpha : 0.0f;
+                const float w  = at * T;
+#else
                 const float w  = take ? alpha * T : 0.0f;
+#endif
                 acc[0] += p2.x * w;
                 if constexpr (CH > 1) acc[1] += p2.y * w;
                 if constexpr (CH > 2) acc[2] += p1.w * w;
@@ -178,7 +186,11 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
 #pragma unroll
                 for (int k = 4; k < CH; ++k) acc[k] += s_col[t * CX + k - 4] * w;
                 cur_idx = take ? (uint32_t)(batch_start + t) : cur_idx;
+#if GSX_FWD_AT
+                T       = fmaf(-T, at, T); // == next_T where the Gaussian is blended, T exactly where not: a full-rate fma for a select
+#else
                 T       = take ? next_T : T;
+#endif
                 thr     = sat ? INFINITY : thr;
             }
         }

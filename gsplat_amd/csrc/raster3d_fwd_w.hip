@@ -19,7 +19,17 @@
 //     done; a quadrant whose pixels are all done leaves the scalar mask of open quadrants, the tile stops when it is empty;
 //   * the tile's cost for the backward (its list up to the last contributor, tile_order.hip) is a by-product: one wave
 //     maximum of the last-contributor indices the lanes hold anyway.
-// LDS: 64 x 48 B per wave; registers are what bounds residency (state of four pixels + one prefetched row).
+// LDS: 64 x 48 B per wave; registers are what bounds residency (state of four pixels + one prefetched row: 86 VGPRs).
+//
+// MEASURED AND NOT THE DEFAULT (round 5, profiles/r09_ab.md #1): parity-green on its first run, and 0.290 ms at c3 where the
+// four-wave kernel takes 0.199 in the same harness - at 4, 5 and 6 waves per SIMD alike, with or without the shrinking
+// rectangles. What the backward's variant W could absorb the forward cannot: a tile is now ONE instruction stream, a wave
+// issues at most one instruction every ~5 cycles however idle its SIMD is (tools/issue_rate.hip), and per staged Gaussian the
+// stream is ~100 issue slots plus an LDS round trip and up to nine branches - so the longest tile of c3 (486 entries to its
+// last contributor against a mean of 160) needs 0.1 - 0.2 ms on its own, as long as the whole launch should take. The
+// backward hides the same tail by starting the long tiles first (tile_order.hip), but the forward only learns a tile's cost by
+// running it (the list lengths, 466 +- 30, say nothing); four waves per tile cut the critical path by the number of quadrants.
+// Kept selectable (GSX_RASTER3D_FWD=w) and covered by tests/test_gpu_variants.py.
 #include <cstdlib>
 
 #include "raster3d.hpp"

@@ -453,25 +453,38 @@ spherical_harmonics_bwd(int64_t degrees_to_use, const Tensor &means_, const Tens
 // A caller that drives the STAGE ops itself (the reference's isect_tiles -> isect_offset_encode -> rasterize_to_pixels, e.g.
 // its own Python over this shim) has no orchestrator to carry the hint: the intersection notes the longest list of the result
 // it returns under the address + length of `flatten_ids`, and a compositing call without a hint looks its `flatten_ids` up.
-// A stale match (the allocator handed the same block to another intersection of the same length) can only pick the other,
-// equally correct, decomposition: both kernels plan from the tile offsets, the number only gates which one is launched.
-struct LongestNote { const void *ptr; int64_t n, longest; };
+// The key is the IDENTITY OF THE STORAGE, not an address: a note holds a weak reference to the StorageImpl of the tensor it was
+// taken for, which keeps that object's address from being handed out again for as long as the note exists - a later tensor
+// that the allocator placed at the same device address has another StorageImpl and does not match (round 4 keyed the notes by
+// data pointer + length: after allocator reuse a stage-level call could pick up another intersection's value, and which
+// kernel ran - and so the float summation order - depended on the process' history).
+struct LongestNote {
+    std::optional<c10::weak_intrusive_ptr<c10::StorageImpl>> storage; // empty slot: no value
+    int64_t offset = 0, n = 0, longest = 0;
+    const c10::StorageImpl *target() const { return storage ? storage->_unsafe_get_target() : nullptr; }
+};
 static std::mutex g_notes_mu;
 static LongestNote g_notes[16];
 static unsigned g_notes_next = 0;
-void note_longest(const void *ptr, int64_t n, int64_t longest)
+void note_longest(const Tensor &flat, int64_t longest)
 {
-    if (!ptr || n <= 0) return;
+    if (!flat.defined() || flat.numel() <= 0 || !flat.has_storage()) return;
+    c10::StorageImpl *impl = flat.storage().unsafeGetStorageImpl();
     std::lock_guard<std::mutex> lock(g_notes_mu);
+    LongestNote fresh;
+    fresh.storage = c10::weak_intrusive_ptr<c10::StorageImpl>(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(impl));
+    fresh.offset = flat.storage_offset(); fresh.n = flat.numel(); fresh.longest = longest;
     for (auto &e : g_notes)
-        if (e.ptr == ptr) { e.n = n; e.longest = longest; return; }
-    g_notes[g_notes_next++ % 16u] = LongestNote{ptr, n, longest};
+        if (e.target() == impl) { e = std::move(fresh); return; }
+    g_notes[g_notes_next++ % 16u] = std::move(fresh);
 }
-int64_t lookup_longest(const void *ptr, int64_t n)
+int64_t lookup_longest(const Tensor &flat)
 {
+    if (!flat.defined() || flat.numel() <= 0 || !flat.has_storage()) return 0;
+    const c10::StorageImpl *impl = flat.storage().unsafeGetStorageImpl();
     std::lock_guard<std::mutex> lock(g_notes_mu);
     for (const auto &e : g_notes)
-        if (e.ptr == ptr && e.n == n) return e.longest;
+        if (e.target() == impl && e.offset == flat.storage_offset() && e.n == flat.numel()) return e.longest;
     return 0;
 }
 
@@ -542,7 +555,7 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
                 { Timed timed_("gsx_isect_binned_emit_sort", L.stream); check(gsx_isect_binned_emit_sort(rows, uI, uts, utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(),
                                                  cp<int32_t>(offsets), M, *host_longest, mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
                       "gsx_isect_binned_emit_sort"); }
-                note_longest(flat.const_data_ptr(), M, *host_longest);
+                note_longest(flat, *host_longest);
                 return {tiles_per_gauss, ids, flat};
             }
             gsx_isect_binned_note_retry(rows, uI, utw, uth); // sent back: not tried again for the next 63 calls of this shape
@@ -562,7 +575,7 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
                                         utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(), cp<int32_t>(offsets), M,
                                         mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
               "gsx_isect_fused_emit_sort"); }
-        note_longest(flat.const_data_ptr(), M, *host_longest);
+        note_longest(flat, *host_longest);
         return {tiles_per_gauss, ids, flat};
     }
     if (f64) {
@@ -682,7 +695,7 @@ rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Te
     Tensor last_ids = at::empty(shape({height, width}), means2d.options().dtype(at::kInt));
     int64_t longest = g_long_tile_hint;
     g_long_tile_hint = 0;
-    if (longest == 0) longest = lookup_longest(flat.const_data_ptr(), flat.numel()); // stage-level caller: no orchestrator hint
+    if (longest == 0) longest = lookup_longest(flatten_ids_); // stage-level caller: no orchestrator hint
     if (kSegLen > 0 && longest > gsx_raster3d_seg_cut(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)kSegLen)) {
         Tensor ws = at::empty({gsx_raster3d_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
                                                               (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
@@ -723,7 +736,7 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
     Tensor rows = at::zeros({R, geo + r.D}, means2d.options());
     int64_t longest = g_long_tile_hint; // set by the autograd formula around this call (gsplat_amd/_autograd.py)
     g_long_tile_hint = 0;
-    if (longest == 0) longest = lookup_longest(flat.const_data_ptr(), flat.numel()); // e.g. the reference's own autograd formula
+    if (longest == 0) longest = lookup_longest(flatten_ids_); // e.g. the reference's own autograd formula
     if (kSegLen > 0 && !absgrad && r.D <= 4 && tile_size == 16
         && longest > gsx_raster3d_seg_cut(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)kSegLen)) {
         Tensor ws = at::empty({gsx_raster3d_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
@@ -840,7 +853,7 @@ isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &dep
         { Timed timed_("gsx_isect_binned_emit_sort", L.stream); check(gsx_isect_binned_emit_sort(rows, uI, uts, utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(),
                                          cp<int32_t>(offsets), M, (int64_t)slot[1], mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
               "gsx_isect_binned_emit_sort"); }
-        note_longest(flat.const_data_ptr(), M, (int64_t)slot[1]);
+        note_longest(flat, (int64_t)slot[1]);
         return {ids, flat};
     }
     Tensor ws = bytes(gsx_isect_fused_emit_workspace_bytes(M, uI, utw, uth), means2d);
@@ -848,7 +861,7 @@ isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &dep
                                     utw, uth, count_ws.mutable_data_ptr(), count_ws.numel(), cp<int32_t>(offsets), M,
                                     mp<int64_t>(ids), mp<int32_t>(flat), ws.mutable_data_ptr(), ws.numel(), L.stream),
           "gsx_isect_fused_emit_sort"); }
-    note_longest(flat.const_data_ptr(), M, (int64_t)slot[1]);
+    note_longest(flat, (int64_t)slot[1]);
     return {ids, flat};
 }
 
@@ -928,15 +941,12 @@ rasterize_to_pixels_2dgs(const Tensor &means2d_, const Tensor &ray_transforms_, 
 
 } // namespace
 void set_long_tile_hint(int64_t longest) { g_long_tile_hint = longest; }
-void note_longest_c(const void *p, int64_t n, int64_t longest) { note_longest(p, n, longest); }
-int64_t lookup_longest_c(const void *p, int64_t n) { return lookup_longest(p, n); }
+void note_longest_op(const Tensor &flatten_ids, int64_t longest) { note_longest(flatten_ids, longest); }
+int64_t lookup_longest_op(const Tensor &flatten_ids) { return lookup_longest(flatten_ids); }
 } // namespace gsplat_amd
 
 // gsplat_amd/_ops.py (ctypes): the longest tile list of the intersection that the next compositing call of THIS thread consumes
 extern "C" void gsx_torch_set_long_tile_hint(int64_t longest) { gsplat_amd::set_long_tile_hint(longest); }
-// the Python op bodies (GSPLAT_AMD_COMPILED_OPS=0, A/B kernel libraries) share the compiled bodies' notes
-extern "C" void gsx_torch_note_longest(const void *flatten_ids, int64_t n, int64_t longest) { gsplat_amd::note_longest_c(flatten_ids, n, longest); }
-extern "C" int64_t gsx_torch_lookup_longest(const void *flatten_ids, int64_t n) { return gsplat_amd::lookup_longest_c(flatten_ids, n); }
 
 TORCH_LIBRARY(gsplat_amd, m)
 {
@@ -944,12 +954,17 @@ TORCH_LIBRARY(gsplat_amd, m)
           "int tile_w, int tile_h, int[] out_shape) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("isect_fused_finish(Tensor means2d, Tensor radii, Tensor depths, Tensor? conics, Tensor? opacities, int rows, int n_images, "
           "int tile_size, int tile_w, int tile_h, Tensor count_ws, Tensor offsets, Tensor host_total, Tensor tiles_per_gauss) -> (Tensor, Tensor)");
+    // the Python op bodies (GSPLAT_AMD_COMPILED_OPS=0, A/B kernel libraries) share the compiled bodies' notes
+    m.def("note_longest(Tensor flatten_ids, int longest) -> ()");
+    m.def("lookup_longest(Tensor flatten_ids) -> int");
 }
 
 TORCH_LIBRARY_IMPL(gsplat_amd, CUDA, m)
 {
     m.impl("isect_fused_begin", &gsplat_amd::isect_fused_begin);
     m.impl("isect_fused_finish", &gsplat_amd::isect_fused_finish);
+    m.impl("note_longest", &gsplat_amd::note_longest_op);
+    m.impl("lookup_longest", &gsplat_amd::lookup_longest_op);
 }
 
 TORCH_LIBRARY_IMPL(gsplat, CUDA, m)

@@ -372,6 +372,101 @@ void gso_raster3d_bwd(const float *means2d, const float *conics, const float *co
     }
 }
 
+/* The same backward with the PER-SAMPLE math in fp64 as well (inputs and the forward state it starts from are the fp32
+ * values): what every fp32 evaluation of these sums approximates. tests/test_gpu_pipeline.py measures, per element, how far
+ * the fp32 oracle above AND the GPU kernels are from it - two fp32 evaluations held to the same band. The contributor set is
+ * the fp32 one (`last_ids`, and the alpha test on the fp64 alpha: a pair exactly on the 1/255 edge may differ). */
+void gso_raster3d_bwd_f64(const float *means2d, const float *conics, const float *colors, const float *opacities,
+                          const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                          const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,
+                          const float *v_render_colors, const float *v_render_alphas, uint32_t n_images,
+                          uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+                          uint32_t tile_w, uint32_t tile_h, int64_t n_rows, double *v_means2d_abs, double *v_means2d,
+                          double *v_conics, double *v_colors, double *v_opacities)
+{
+    const int64_t n_tiles = (int64_t)tile_w * tile_h, total = n_tiles * n_images;
+    if (v_means2d_abs) memset(v_means2d_abs, 0, sizeof(double) * 2 * (size_t)n_rows);
+    memset(v_means2d, 0, sizeof(double) * 2 * (size_t)n_rows);
+    memset(v_conics, 0, sizeof(double) * 3 * (size_t)n_rows);
+    memset(v_colors, 0, sizeof(double) * (size_t)cdim * (size_t)n_rows);
+    memset(v_opacities, 0, sizeof(double) * (size_t)n_rows);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t blk = 0; blk < total; ++blk) {
+        if (masks && !masks[blk]) continue;
+        const uint32_t img = (uint32_t)(blk / n_tiles), tile = (uint32_t)(blk % n_tiles);
+        const uint32_t tx = tile % tile_w, ty = tile / tile_w;
+        const float *bg = backgrounds ? backgrounds + (size_t)img * cdim : NULL;
+        const int32_t start = isect_offsets[blk];
+        const int32_t end   = (blk == total - 1) ? (int32_t)n_isects : isect_offsets[blk + 1];
+        if (end <= start) continue;
+        double *buffer = (double *)malloc(sizeof(double) * cdim);
+        for (uint32_t ly = 0; ly < tile_size; ++ly)
+            for (uint32_t lx = 0; lx < tile_size; ++lx) {
+                const uint32_t ox = tx * tile_size + lx, oy = ty * tile_size + ly;
+                if (ox >= width || oy >= height) continue;
+                const size_t pix = ((size_t)img * height + oy) * width + ox;
+                const double px = (double)ox + 0.5, py = (double)oy + 0.5;
+                const double T_final = 1.0 - (double)render_alphas[pix];
+                double T = T_final;
+                const int32_t bin_final = last_ids[pix];
+                const float *v_c = v_render_colors + pix * cdim;
+                const double v_a = v_render_alphas[pix];
+                for (uint32_t k = 0; k < cdim; ++k) buffer[k] = 0.0;
+                int32_t hi = bin_final < end - 1 ? bin_final : end - 1;
+                for (int32_t idx = hi; idx >= start; --idx) {
+                    const int32_t g = flatten_ids[idx];
+                    const double dx = (double)means2d[2 * (size_t)g] - px, dy = (double)means2d[2 * (size_t)g + 1] - py;
+                    const double a = conics[3 * (size_t)g], b = conics[3 * (size_t)g + 1], c = conics[3 * (size_t)g + 2];
+                    const double opac  = opacities[g];
+                    const double sigma = 0.5 * (a * dx * dx + c * dy * dy) + b * dx * dy;
+                    const double vis   = exp(-sigma);
+                    const double alpha = fmin((double)MAX_ALPHA, opac * vis);
+                    if (sigma < 0.0 || alpha < (double)ALPHA_THRESHOLD) continue;
+                    const double ra = 1.0 / fmax((double)MIN_ONE_MINUS_ALPHA, 1.0 - alpha);
+                    T *= ra;
+                    const double fac = alpha * T;
+                    double v_alpha = 0.0;
+                    const float *col = colors + (size_t)g * cdim;
+                    for (uint32_t k = 0; k < cdim; ++k) {
+#pragma omp atomic
+                        v_colors[(size_t)g * cdim + k] += fac * (double)v_c[k];
+                        v_alpha += ((double)col[k] * T - buffer[k] * ra) * (double)v_c[k];
+                    }
+                    v_alpha += T_final * ra * v_a;
+                    if (bg) {
+                        double accum = 0.0;
+                        for (uint32_t k = 0; k < cdim; ++k) accum += (double)bg[k] * (double)v_c[k];
+                        v_alpha += -T_final * ra * accum;
+                    }
+                    if (opac * vis <= (double)MAX_ALPHA) {
+                        const double v_sigma = -opac * vis * v_alpha;
+                        const double vx = v_sigma * (a * dx + b * dy), vy = v_sigma * (b * dx + c * dy);
+#pragma omp atomic
+                        v_conics[3 * (size_t)g + 0] += 0.5 * v_sigma * dx * dx;
+#pragma omp atomic
+                        v_conics[3 * (size_t)g + 1] += v_sigma * dx * dy;
+#pragma omp atomic
+                        v_conics[3 * (size_t)g + 2] += 0.5 * v_sigma * dy * dy;
+#pragma omp atomic
+                        v_means2d[2 * (size_t)g + 0] += vx;
+#pragma omp atomic
+                        v_means2d[2 * (size_t)g + 1] += vy;
+                        if (v_means2d_abs) {
+#pragma omp atomic
+                            v_means2d_abs[2 * (size_t)g + 0] += fabs(vx);
+#pragma omp atomic
+                            v_means2d_abs[2 * (size_t)g + 1] += fabs(vy);
+                        }
+#pragma omp atomic
+                        v_opacities[g] += vis * v_alpha;
+                    }
+                    for (uint32_t k = 0; k < cdim; ++k) buffer[k] += (double)col[k] * fac;
+                }
+            }
+        free(buffer);
+    }
+}
+
 /* rasterize_to_indices (RasterizeToIndices3DGSSerialBatch.cu:128-192): the (gaussian, pixel, image)
  * triples that contribute, in the order the reference's torch rasterizer consumes them. Used only
  * to drive the reference's own `accumulate` when pinning this oracle. Two-pass: call with out

@@ -1,0 +1,103 @@
+"""GPU: the forward pass is bit-reproducible across processes and across a process' history.
+
+Round 4 saw, once, a long-lived process render a different image of a scene than a fresh process (tools/render_determinism.py:
+0 of 180 afterwards). Nothing in the forward path sums in an unspecified order - projection, keys, the (depth, row) sort and the
+per-pixel front-to-back walk are sequential per output - so any difference means that WHICH kernel ran depended on history:
+the tile-owner-major / Gaussian-major intersection choice (bit-identical by construction, csrc/isect_binned.hip), or the
+segmented compositing, which a stale "longest tile list" note could select (the notes were keyed by device address until round
+5; they are keyed by storage identity now, csrc/torch_ops.cpp). This test bounds it: one scene on each intersection path,
+rendered 200 times - in this pytest process (which has run other tests: warm allocator, remembered shapes) interleaved with
+renders of other scenes and stage-level calls, and in three fresh processes (plain, interleaved, Python op bodies) - must
+give ONE hash of (image, alpha, sorted keys, row ids, projected means)."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCENES = {  # tag: N, C, W, H, sh_degree   ("big" has enough rows per image for the tile-owner-major intersection)
+    "small": (6000, 2, 208, 144, 3),
+    "big": (60000, 1, 640, 480, 0),
+}
+
+
+def _hash(*tensors):
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(t.detach().contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()[:24]
+
+
+def render_hashes(G, repeats, noise):
+    from _util import make_scene
+
+    out = {k: set() for k in SCENES}
+    scenes = {}
+    for tag, (N, C, W, H, deg) in SCENES.items():
+        sc, W, H = make_scene(N=N, C=C, width=W, height=H, seed=N % 97, sh_degree=deg)
+        scenes[tag] = ({k: v.cuda() for k, v in sc.items()}, W, H, deg)
+    others = []
+    if noise:
+        for i in range(4):
+            sc, W, H = make_scene(N=2500 + 3500 * i, C=1 + i % 2, width=160 + 48 * i, height=112 + 16 * i, seed=40 + i,
+                                  scale_range=(0.02, 0.15) if i < 3 else (0.3, 0.8))
+            others.append(({k: v.cuda() for k, v in sc.items()}, W, H))
+    for r in range(repeats):
+        for tag, (d, W, H, deg) in scenes.items():
+            lv = {k: d[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+            rc, ra, meta = G.rasterization(lv["means"], lv["quats"], lv["scales"], lv["opacities"], lv["colors"], d["viewmats"],
+                                           d["Ks"], W, H, sh_degree=deg, packed=bool(r & 1))
+            rc.sum().backward()  # the backward allocates and frees workspaces between two forward passes, as a trainer does
+            # packed and dense rows give the same image; ids / means are only comparable within a layout
+            out[tag].add(("img", _hash(rc, ra)))
+            m2 = meta["means2d"]
+            if not (r & 1):  # dense rows of culled Gaussians are never written (like the reference's at::empty outputs)
+                m2 = m2[(meta["radii"] > 0).all(-1)]
+            out[tag].add((f"rows packed={r & 1}", _hash(meta["isect_ids"], meta["flatten_ids"], m2)))
+        if noise:
+            d, W, H = others[r % len(others)]
+            with torch.no_grad():
+                G.rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"], d["Ks"], W, H)
+            if r % 5 == 0:
+                torch.cuda.empty_cache()  # hands the blocks back: the next allocations land on other addresses
+    return {k: sorted(map(list, v)) for k, v in out.items()}
+
+
+_SCRIPT = r'''
+import sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import gsplat_amd
+from test_gpu_determinism import render_hashes
+print("HASHES " + json.dumps(render_hashes(gsplat_amd, int(sys.argv[1]), sys.argv[2] == "1")))
+'''
+
+
+def test_forward_is_bit_reproducible_across_processes_and_history():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import gsplat_amd
+
+    code = _SCRIPT % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+    procs = []
+    for noise, env in (("0", {}), ("1", {}), ("1", {"GSPLAT_AMD_COMPILED_OPS": "0"})):
+        procs.append(subprocess.Popen([sys.executable, "-c", code, "50", noise], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=dict(os.environ, **env)))
+    mine = render_hashes(gsplat_amd, 50, True)  # this process: whatever the suite ran before + interleaved other scenes
+    results = [("this process", mine)]
+    for i, p in enumerate(procs):
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, se[-3000:]
+        line = [l for l in so.splitlines() if l.startswith("HASHES ")][-1]
+        results.append((f"fresh process {i}", json.loads(line[len("HASHES "):])))
+    for tag in SCENES:
+        ref = results[0][1][tag]
+        # one image hash, one row hash per layout - in every process
+        assert len(ref) == 3, f"{tag}: this process rendered {len(ref)} distinct (image | rows) hashes over 50 repeats: {ref}"
+        for name, r in results[1:]:
+            assert r[tag] == ref, f"{tag}: {name} differs from this process: {r[tag]} vs {ref}"

@@ -84,6 +84,56 @@ def test_isect_exact(golden):
     assert (tpa <= tpg).all()
 
 
+def _pairs(ids, fl, tile_bits):
+    """(image, tile, row) triples of an intersection list as one int64 key per entry."""
+    ids = ids.numpy().astype(np.int64)
+    tile = (ids >> 32) & ((1 << tile_bits) - 1)
+    img = ids >> (32 + tile_bits)
+    return (img << 48) | (tile << 24) | fl.numpy().astype(np.int64)  # rows < 2^24 in these fixtures
+
+
+@pytest.mark.parametrize("source", ["isect", "proj_pinhole", "proj_fisheye"])
+def test_accutile_drops_only_invisible_pairs_of_the_reference_aabb_set(golden, source):
+    """The exact-ellipse tile walk (AccuTile: IntersectTile.cu:83-207, 288-373 - CUDA only in the reference, so the oracle's
+    restatement of it cannot be replayed against reference vectors) is pinned by a PROPERTY instead: on the garden fixture its
+    (tile, Gaussian) set is a subset of the radius-box set - which IS pinned to the reference's `_isect_tiles` golden above -
+    and every pair it drops is invisible: max over the tile's pixel centres of min(0.99, opacity exp(-sigma)) < 1/255, the
+    compositing kernels' own alpha test (RasterizeToPixels3DGSDevice.cuh:44-56). So dropping it cannot change a pixel."""
+    if source == "isect":
+        ts, tw, th = (int(v) for v in golden["isect_tile"])
+        m2, rad, dep = (to_t(golden["isect_" + k]) for k in ("means2d", "radii", "depths"))
+        con, op = to_t(golden["isect_conics"]), to_t(golden["isect_opacities"])
+    else:
+        W, H = (int(v) for v in golden["proj_wh"])
+        ts = 16
+        tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
+        m2, rad, dep, con = (to_t(golden[f"{source}_{k}"]) for k in ("means2d", "radii", "depths", "conics"))
+        valid = to_t(golden[f"{source}_valid"])
+        rad = rad * valid[..., None].to(rad.dtype)  # the reference leaves the other fields of culled rows undefined
+        m2, dep, con = (torch.nan_to_num(t * valid.reshape(valid.shape + (1,) * (t.dim() - 2)).to(t.dtype)) for t in (m2, dep, con))
+        op = to_t(golden["proj_opacities"])[None].expand(m2.shape[:2]).contiguous()
+    I, N = m2.shape[:2]
+    tile_bits = O.bits_for_count(tw * th)
+    _, ids_b, fl_b = O.isect_tiles(m2, rad, dep, ts, tw, th, sort=True)
+    _, ids_a, fl_a = O.isect_tiles(m2, rad, dep, ts, tw, th, sort=True, conics=con, opacities=op)
+    box, accu = _pairs(ids_b, fl_b, tile_bits), _pairs(ids_a, fl_a, tile_bits)
+    assert np.unique(accu).size == accu.size and np.isin(accu, box).all(), "the ellipse walk visits a tile outside the radius box"
+    dropped = box[~np.isin(box, accu)]
+    assert 0 < dropped.size < box.size, "the fixture must exercise the exact test"
+    row, tile = dropped & 0xFFFFFF, (dropped >> 24) & 0xFFFFFF
+    m2f, conf, opf = m2.reshape(-1, 2).double().numpy(), con.reshape(-1, 3).double().numpy(), op.reshape(-1).double().numpy()
+    u = np.arange(ts) + 0.5
+    px = (tile % tw)[:, None, None] * ts + u[None, None, :]      # [pairs, 1, ts]
+    py = (tile // tw)[:, None, None] * ts + u[None, :, None]     # [pairs, ts, 1]
+    dx, dy = m2f[row, 0][:, None, None] - px, m2f[row, 1][:, None, None] - py
+    A, B, C = (conf[row, k][:, None, None] for k in range(3))
+    sigma = 0.5 * (A * dx * dx + C * dy * dy) + B * dx * dy
+    alpha = np.minimum(0.99, opf[row][:, None, None] * np.exp(-sigma))
+    alpha = np.where(sigma < 0, 0.0, alpha)                      # the kernels skip sigma < 0
+    worst = alpha.reshape(dropped.size, -1).max(1)
+    assert worst.max() < 1.0 / 255.0, f"a dropped (tile, Gaussian) pair is visible: alpha {worst.max():.6f} at pair {int(worst.argmax())}"
+
+
 def _rast_inputs(golden):
     W, H, ts = (int(v) for v in golden["rast_wh"])
     keys = ("rast_means2d", "rast_conics", "rast_colors", "rast_opacities", "rast_offsets", "rast_flatten_ids",
@@ -174,3 +224,21 @@ def test_rasterize_bwd_per_element_band(golden):
     for k, (rtol, atol) in RASTER_BWD_BAND.items():
         assert_close_ratio(g[k].reshape(golden["rast_" + k].shape), golden["rast_" + k], rtol, atol,
                            max_bad_ratio=RASTER_BWD_BAND_CPU_ENVELOPE[k], name=k + " per element (CPU vs CPU)")
+
+
+def test_rasterize_bwd_fp64_samples_agree_with_the_fp32_oracle(golden):
+    """gso_raster3d_bwd_f64 (per-sample math in fp64: the reference value of tests/test_gpu_pipeline.py's per-element band at
+    c3) against the fp32-sample oracle and the reference's stored autograd values on the golden fixture."""
+    from _util import RASTER_BWD_BAND
+
+    W, H, ts, m2, con, col, op, off, fl, bg = _rast_inputs(golden)
+    rc, ra, li = O.rasterize_to_pixels(m2, con, col, op, W, H, ts, off, fl, backgrounds=bg)
+    v_rc, v_ra = to_t(golden["rast_v_render_colors"]), to_t(golden["rast_v_render_alphas"])
+    g32 = O.rasterize_to_pixels_bwd(m2, con, col, op, W, H, ts, off, fl, ra, li, v_rc, v_ra, backgrounds=bg, absgrad=True)
+    g64 = O.rasterize_to_pixels_bwd(m2, con, col, op, W, H, ts, off, fl, ra, li, v_rc, v_ra, backgrounds=bg, absgrad=True,
+                                    sample_f64=True)
+    for k in g32:
+        assert_grad_close(g32[k], g64[k], rel=1e-4, max_bad_ratio=1e-4, name=k)
+    for k, (rtol, atol) in RASTER_BWD_BAND.items():
+        assert_close_ratio(g64[k].reshape(golden["rast_" + k].shape), golden["rast_" + k], rtol, atol, max_bad_ratio=1e-2,
+                           name=k + " fp64 samples vs the reference's autograd")

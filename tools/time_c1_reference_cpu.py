@@ -2,11 +2,11 @@
 """BASELINE.json configs[0] ("c1": 10 k random Gaussians, 256 x 256, SH degree 0) timed through the REFERENCE's own CPU path
 (gsplat/cuda/_torch_impl.py: _fully_fused_projection, _spherical_harmonics, accumulate + torch autograd for the backward; the
 tile / sample lists, CUDA-only in the reference, come from the pinned oracle stages as in oracle/pin_c1_against_reference.py)
-next to the repo's own CPU port (oracle/pipeline.py) on the same scene and host. Needs the reference checkout, so it runs
-where /root/reference exists (the build container), NOT on the GPU box: the result is committed as
-profiles/c1_reference_cpu.json and bench.py quotes it, labelled with the host it was measured on, next to its live
-`cpu_baseline`.
-    python tools/time_c1_reference_cpu.py [--ref /root/reference] [--reps 3]"""
+next to the repo's own CPU port (oracle/pipeline.py) on the same scene and host. Needs the reference's PYTHON files only:
+a checkout (`--ref /root/reference`, the build container) or the archive `__graft_entry__.build()` stages,
+oracle/_ref/reference_py.zip, which travels to the GPU box - bench.py runs this script there in a subprocess and reports the
+result as `cpu_baseline.c1_reference` (measured in that run, on that host's cores).
+    python tools/time_c1_reference_cpu.py [--ref /root/reference | oracle/_ref/reference_py.zip] [--reps 3] [--out file]"""
 import argparse
 import json
 import os
@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "c1_reference_cpu.json"))
+    ap.add_argument("--where", default="build container")
     args = ap.parse_args()
     sys.path.insert(0, args.ref)
     sys.dont_write_bytecode = True
@@ -88,10 +89,11 @@ def main():
         "port_cpu": {"s_per_step": round(t_port, 4), "mpixels_per_s": round(pix / t_port / 1e6, 4),
                      "path": "oracle/pipeline.py (OpenMP C compositing + torch-CPU projection / SH)"},
         "host": {"machine": platform.machine(), "cores": os.cpu_count(), "torch_threads": torch.get_num_threads(),
-                 "where": "build container (the GPU box has no reference checkout)"},
+                 "where": args.where, "reference_from": os.path.basename(args.ref.rstrip("/"))},
         "reps": args.reps,
     }
-    json.dump(rec, open(args.out, "w"), indent=1)
+    if args.out != "-":
+        json.dump(rec, open(args.out, "w"), indent=1)
     print(json.dumps(rec))
 
 
