@@ -381,14 +381,23 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
     }
     const int32_t n_batches = (range_end - range_start + BATCH - 1) / BATCH;
     if (n_batches <= 0) return;
-    const int32_t median_idx = inside ? a.median_ids[pix] : -1;
     float v_c[CH], v_n[3];
 #pragma unroll
     for (int k = 0; k < CH; ++k) v_c[k] = (inside && k < nch) ? a.v_render_colors[pix * a.cdim + k] : 0.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) v_n[k] = inside ? a.v_render_normals[pix * 3 + k] : 0.0f;
     const float v_a      = inside ? a.v_render_alphas[pix] : 0.0f;
-    const float v_median = inside ? a.v_render_median[pix] : 0.0f;
+    // The cotangent of the median depth goes to the depth channel of ONE surfel per pixel, the one the forward pass recorded
+    // (median_ids; a pixel with any contributor has one: the first contributor sees T = 1 > 0.5). It is added here, once per
+    // pixel, instead of being tested for on every (pixel, surfel) pair of the walk (two instructions and two registers less
+    // per pair; reference Bwd.cu adds it inside the walk).
+    if (inside && T_final < 1.0f) {
+        const float v_median = a.v_render_median[pix];
+        if (v_median != 0.0f) {
+            constexpr int GEO0 = 17 + (ABS ? 2 : 0);
+            atomic_add_f32(a.v_rows + (size_t)a.flatten_ids[a.median_ids[pix]] * a.row_stride + GEO0 + nch - 1, v_median);
+        }
+    }
     float bg_dot = 0.0f;
     if (a.backgrounds) {
         const float *bg = a.backgrounds + (size_t)image_id * a.cdim;
@@ -398,14 +407,20 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
     }
     const float tail_term = T_final * (v_a - bg_dot); // what lies behind the whole list
     float behind          = 0.0f;                     // B (see the pixel loop)
+    // Distortion loss, restated (reference Bwd.cu:560-600 keeps accum_d, accum_w, their two back-buffers and a distortion
+    // buffer per pixel): with Wb / Db the sums of fac and fac * depth over the surfels BEHIND,
+    //   dl_dw = 2 (2 (depth (accum_w - Wb) - (accum_d - Db)) + accum_d - depth accum_w) = 2 (depth P - Q),
+    //   P = accum_w - 2 Wb,  Q = accum_d - 2 Db   (two running values; accum_d itself drops out),
+    // and the distortion buffer only ever enters v_alpha next to `behind` with the same factors, so it is carried inside it:
+    //   v_alpha = T (cv + dl_dw v_distort) + (tail - behind') / (1 - alpha),  behind' += fac (cv + dl_dw v_distort).
+    // Four values per pixel instead of six, nine instructions per pair instead of seventeen; same sums in another order.
     const bool dist = a.v_render_distort != nullptr;
-    float v_distort = 0.f, accum_d = 0.f, accum_w = 0.f, accum_d_buffer = 0.f, accum_w_buffer = 0.f, distort_buffer = 0.f;
+    float vd2 = 0.f, c2aw = 0.f, dP = 0.f, dQ = 0.f; // 2 v_distort | 2 - accum_w | P | Q
     if (dist && inside) {
-        v_distort      = a.v_render_distort[pix];
-        accum_d_buffer = a.render_colors[pix * a.cdim + nch - 1];
-        accum_d        = accum_d_buffer;
-        accum_w_buffer = a.render_alphas[pix];
-        accum_w        = accum_w_buffer;
+        vd2  = 2.0f * a.v_render_distort[pix];
+        dQ   = a.render_colors[pix * a.cdim + nch - 1];
+        dP   = a.render_alphas[pix];
+        c2aw = 2.0f - dP;
     }
 
     for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
@@ -487,21 +502,18 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
                 loc[CH + k] = fac * v_n[k];
                 cv          = fmaf(nrv[k], v_n[k], cv);
             }
-            float v_alpha = fmaf(ra, tail_term - behind, cv * T);
-            behind        = fmaf(fac, cv, behind);
-            float v_depth_ch = (valid && (batch_end - t == median_idx)) ? v_median : 0.0f; // extra grad of last channel
             if (dist) {
                 const float depth = s_col[t * CH + nch - 1];
-                const float dl_dw = 2.0f * (2.0f * (depth * accum_w_buffer - accum_d_buffer) + (accum_d - depth * accum_w));
-                v_alpha        += (dl_dw * T - distort_buffer * ra) * v_distort;
-                accum_d_buffer -= fac * depth;
-                accum_w_buffer -= fac;
-                distort_buffer += dl_dw * fac;
-                v_depth_ch     += 2.0f * fac * (2.0f - 2.0f * T - accum_w + fac) * v_distort;
-            }
+                cv                = fmaf(fmaf(depth, dP, -dQ), vd2, cv);                    // cv + dl_dw v_distort
+                const float v_depth_ch = fac * vd2 * (fmaf(-2.0f, T, c2aw) + fac);        // 2 fac (2 - 2 T - accum_w + fac) v_distort
+                dP = fmaf(-2.0f, fac, dP);
+                dQ = fmaf(-2.0f * depth, fac, dQ);
 #pragma unroll
-            for (int k = 0; k < CH; ++k)
-                if (k == nch - 1) loc[k] += v_depth_ch;
+                for (int k = 0; k < CH; ++k)
+                    if (k == nch - 1) loc[k] += v_depth_ch;
+            }
+            const float v_alpha = fmaf(ra, tail_term - behind, cv * T);
+            behind              = fmaf(fac, cv, behind);
 
             const float ov       = opac * vis;
             const bool unclamped = valid && (ov <= kMaxAlpha);
@@ -671,9 +683,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 
     constexpr bool dist = DIST; // the distortion loss adds six per-pixel values: its own instantiation (two waves per SIMD)
 
     // per-pixel state, pixel q = this lane's pixel of quadrant q
-    float T[4], behind[4], tail_term[4], v_c[4][CH], v_n[4][3], v_median[4];
-    float v_distort[4], accum_d[4], accum_w[4], accum_d_buffer[4], accum_w_buffer[4], distort_buffer[4];
-    int32_t bin_final[4], median_idx[4], qmax[4];
+    float T[4], behind[4], tail_term[4], v_c[4][CH], v_n[4][3];
+    float vd2[4], c2aw[4], dP[4], dQ[4]; // distortion loss, see raster2d_bwd_kernel: 2 v_distort | 2 - accum_w | P | Q
+    int32_t bin_final[4], qmax[4];
     int32_t tile_last = -1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -684,13 +696,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 
         const float T_fin = inside ? 1.0f - a.render_alphas[pix] : 1.0f;
         T[q] = T_fin; behind[q] = 0.0f;
         bin_final[q]  = inside ? a.last_ids[pix] : -1;
-        median_idx[q] = inside ? a.median_ids[pix] : -1;
+        if (inside && T_fin < 1.0f) { // the median depth's cotangent: once per pixel (see raster2d_bwd_kernel)
+            const float v_median = a.v_render_median[pix];
+            if (v_median != 0.0f)
+                atomic_add_f32(a.v_rows + (size_t)a.flatten_ids[a.median_ids[pix]] * a.row_stride + 17 + nch - 1, v_median);
+        }
 #pragma unroll
         for (int k = 0; k < CH; ++k) v_c[q][k] = (inside && k < nch) ? a.v_render_colors[pix * a.cdim + k] : 0.0f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) v_n[q][k] = inside ? a.v_render_normals[pix * 3 + k] : 0.0f;
         const float v_a = inside ? a.v_render_alphas[pix] : 0.0f;
-        v_median[q]     = inside ? a.v_render_median[pix] : 0.0f;
         float bg_dot    = 0.0f;
         if (a.backgrounds) {
             const float *bg = a.backgrounds + (size_t)image_id * a.cdim;
@@ -699,13 +714,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 
                 if (k < nch) bg_dot += bg[k] * v_c[q][k];
         }
         tail_term[q] = T_fin * (v_a - bg_dot);
-        v_distort[q] = accum_d[q] = accum_w[q] = accum_d_buffer[q] = accum_w_buffer[q] = distort_buffer[q] = 0.0f;
+        vd2[q] = c2aw[q] = dP[q] = dQ[q] = 0.0f;
         if (dist && inside) {
-            v_distort[q]      = a.v_render_distort[pix];
-            accum_d_buffer[q] = a.render_colors[pix * a.cdim + nch - 1];
-            accum_d[q]        = accum_d_buffer[q];
-            accum_w_buffer[q] = a.render_alphas[pix];
-            accum_w[q]        = accum_w_buffer[q];
+            vd2[q]  = 2.0f * a.v_render_distort[pix];
+            dQ[q]   = a.render_colors[pix * a.cdim + nch - 1];
+            dP[q]   = a.render_alphas[pix];
+            c2aw[q] = 2.0f - dP[q];
         }
         qmax[q]   = wave_max_i32(bin_final[q]);
         tile_last = max(tile_last, qmax[q]);
@@ -854,24 +868,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 
                     sum[CH + k] = fmaf(fac, v_n[q][k], sum[CH + k]);
                     cv          = fmaf(nrv[k], v_n[q][k], cv);
                 }
-                float v_alpha    = fmaf(ra, tail_term[q] - behind[q], cv * T[q]);
-                behind[q]        = fmaf(fac, cv, behind[q]);
-                float v_depth_ch = (valid && (list_idx == median_idx[q])) ? v_median[q] : 0.0f; // extra grad of the last channel
                 if (dist) {
                     float depth = colv[0];
 #pragma unroll
                     for (int k = 1; k < CH; ++k)
                         if (k == nch - 1) depth = colv[k];
-                    const float dl_dw = 2.0f * (2.0f * (depth * accum_w_buffer[q] - accum_d_buffer[q]) + (accum_d[q] - depth * accum_w[q]));
-                    v_alpha          += (dl_dw * T[q] - distort_buffer[q] * ra) * v_distort[q];
-                    accum_d_buffer[q] -= fac * depth;
-                    accum_w_buffer[q] -= fac;
-                    distort_buffer[q] += dl_dw * fac;
-                    v_depth_ch        += 2.0f * fac * (2.0f - 2.0f * T[q] - accum_w[q] + fac) * v_distort[q];
-                }
+                    cv = fmaf(fmaf(depth, dP[q], -dQ[q]), vd2[q], cv);                          // cv + dl_dw v_distort
+                    const float v_depth_ch = fac * vd2[q] * (fmaf(-2.0f, T[q], c2aw[q]) + fac); // extra grad of the last channel
+                    dP[q] = fmaf(-2.0f, fac, dP[q]);
+                    dQ[q] = fmaf(-2.0f * depth, fac, dQ[q]);
 #pragma unroll
-                for (int k = 0; k < CH; ++k)
-                    if (k == nch - 1) sum[k] += v_depth_ch;
+                    for (int k = 0; k < CH; ++k)
+                        if (k == nch - 1) sum[k] += v_depth_ch;
+                }
+                const float v_alpha = fmaf(ra, tail_term[q] - behind[q], cv * T[q]);
+                behind[q]           = fmaf(fac, cv, behind[q]);
 
                 const float ov       = opac * vis;
                 const bool unclamped = valid && (ov <= kMaxAlpha);

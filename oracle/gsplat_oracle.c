@@ -467,6 +467,106 @@ void gso_raster3d_bwd_f64(const float *means2d, const float *conics, const float
     }
 }
 
+/* The same backward with the SUMS in fp32 too: per (tile, Gaussian) a float running sum over the tile's pixels in raster
+ * order, added to float totals - one of the many orders in which the reference's fp32 atomics may combine the same terms
+ * (its kernel reduces a warp with a tree and adds the result to global memory with atomicAdd, Bwd.cu:270-318). This is the
+ * "other fp32 evaluation" whose distance from gso_raster3d_bwd_f64 is the envelope of tests/test_gpu_pipeline.py's per-element
+ * band. Outputs fp64 arrays holding the float totals. No absgrad. */
+void gso_raster3d_bwd_f32sum(const float *means2d, const float *conics, const float *colors, const float *opacities,
+                             const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                             const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,
+                             const float *v_render_colors, const float *v_render_alphas, uint32_t n_images,
+                             uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+                             uint32_t tile_w, uint32_t tile_h, int64_t n_rows, double *v_means2d_abs, double *v_means2d,
+                             double *v_conics, double *v_colors, double *v_opacities)
+{
+    (void)v_means2d_abs;
+    const int64_t n_tiles = (int64_t)tile_w * tile_h, total = n_tiles * n_images;
+    const uint32_t K = 6 + cdim; /* per Gaussian: v_mean2d 2 | v_conic 3 | v_opacity 1 | v_color cdim */
+    float *tot = (float *)calloc((size_t)n_rows * K, sizeof(float));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t blk = 0; blk < total; ++blk) {
+        if (masks && !masks[blk]) continue;
+        const uint32_t img = (uint32_t)(blk / n_tiles), tile = (uint32_t)(blk % n_tiles);
+        const uint32_t tx = tile % tile_w, ty = tile / tile_w;
+        const float *bg = backgrounds ? backgrounds + (size_t)img * cdim : NULL;
+        const int32_t start = isect_offsets[blk];
+        const int32_t end   = (blk == total - 1) ? (int32_t)n_isects : isect_offsets[blk + 1];
+        if (end <= start) continue;
+        float *buffer = (float *)malloc(sizeof(float) * cdim);
+        float *loc    = (float *)calloc((size_t)(end - start) * K, sizeof(float));
+        for (uint32_t ly = 0; ly < tile_size; ++ly)
+            for (uint32_t lx = 0; lx < tile_size; ++lx) {
+                const uint32_t ox = tx * tile_size + lx, oy = ty * tile_size + ly;
+                if (ox >= width || oy >= height) continue;
+                const size_t pix = ((size_t)img * height + oy) * width + ox;
+                const float px = (float)ox + 0.5f, py = (float)oy + 0.5f;
+                const float T_final = 1.0f - render_alphas[pix];
+                float T = T_final;
+                const int32_t bin_final = last_ids[pix];
+                const float *v_c = v_render_colors + pix * cdim;
+                const float v_a  = v_render_alphas[pix];
+                for (uint32_t k = 0; k < cdim; ++k) buffer[k] = 0.0f;
+                int32_t hi = bin_final < end - 1 ? bin_final : end - 1;
+                for (int32_t idx = hi; idx >= start; --idx) {
+                    const int32_t g = flatten_ids[idx];
+                    float *acc = loc + (size_t)(idx - start) * K;
+                    const float dx = means2d[2 * (size_t)g] - px, dy = means2d[2 * (size_t)g + 1] - py;
+                    const float a = conics[3 * (size_t)g], b = conics[3 * (size_t)g + 1], c = conics[3 * (size_t)g + 2];
+                    const float opac  = opacities[g];
+                    const float sigma = 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
+                    const float vis   = expf(-sigma);
+                    const float alpha = fminf(MAX_ALPHA, opac * vis);
+                    if (sigma < 0.0f || alpha < ALPHA_THRESHOLD) continue;
+                    const float ra = 1.0f / fmaxf(MIN_ONE_MINUS_ALPHA, 1.0f - alpha);
+                    T *= ra;
+                    const float fac = alpha * T;
+                    float v_alpha = 0.0f;
+                    const float *col = colors + (size_t)g * cdim;
+                    for (uint32_t k = 0; k < cdim; ++k) {
+                        acc[6 + k] += fac * v_c[k];
+                        v_alpha += (col[k] * T - buffer[k] * ra) * v_c[k];
+                    }
+                    v_alpha += T_final * ra * v_a;
+                    if (bg) {
+                        float accum = 0.0f;
+                        for (uint32_t k = 0; k < cdim; ++k) accum += bg[k] * v_c[k];
+                        v_alpha += -T_final * ra * accum;
+                    }
+                    if (opac * vis <= MAX_ALPHA) {
+                        const float v_sigma = -opac * vis * v_alpha;
+                        acc[0] += v_sigma * (a * dx + b * dy);
+                        acc[1] += v_sigma * (b * dx + c * dy);
+                        acc[2] += 0.5f * v_sigma * dx * dx;
+                        acc[3] += v_sigma * dx * dy;
+                        acc[4] += 0.5f * v_sigma * dy * dy;
+                        acc[5] += vis * v_alpha;
+                    }
+                    for (uint32_t k = 0; k < cdim; ++k) buffer[k] += col[k] * fac;
+                }
+            }
+        for (int32_t idx = start; idx < end; ++idx) {
+            const float *acc = loc + (size_t)(idx - start) * K;
+            float *t         = tot + (size_t)flatten_ids[idx] * K;
+            for (uint32_t k = 0; k < K; ++k)
+                if (acc[k] != 0.0f) {
+#pragma omp atomic
+                    t[k] += acc[k];
+                }
+        }
+        free(loc);
+        free(buffer);
+    }
+    for (int64_t g = 0; g < n_rows; ++g) {
+        const float *t = tot + (size_t)g * K;
+        v_means2d[2 * g] = t[0]; v_means2d[2 * g + 1] = t[1];
+        v_conics[3 * g] = t[2]; v_conics[3 * g + 1] = t[3]; v_conics[3 * g + 2] = t[4];
+        v_opacities[g] = t[5];
+        for (uint32_t k = 0; k < cdim; ++k) v_colors[(size_t)g * cdim + k] = t[6 + k];
+    }
+    free(tot);
+}
+
 /* rasterize_to_indices (RasterizeToIndices3DGSSerialBatch.cu:128-192): the (gaussian, pixel, image)
  * triples that contribute, in the order the reference's torch rasterizer consumes them. Used only
  * to drive the reference's own `accumulate` when pinning this oracle. Two-pass: call with out

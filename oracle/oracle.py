@@ -517,11 +517,13 @@ def rasterize_to_pixels(
 def rasterize_to_pixels_bwd(
     means2d, conics, colors, opacities, image_width: int, image_height: int, tile_size: int, isect_offsets,
     flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas, backgrounds=None, masks=None,
-    absgrad: bool = False, sample_f64: bool = False,
+    absgrad: bool = False, sample_f64: bool = False, sum_f32: bool = False,
 ):
     """gsplat rasterize_to_pixels backward (RasterizeToPixels3DGSSerialBatchBwd.cu:41-320,
     Rasterization.cpp:567-577 for v_backgrounds). Returns dict of float64 numpy arrays. sample_f64: the per-sample math in
-    fp64 too (gso_raster3d_bwd_f64: the value the fp32 evaluations approximate; per-element bands are measured against it)."""
+    fp64 too (gso_raster3d_bwd_f64: the value the fp32 evaluations approximate; per-element bands are measured against it);
+    sum_f32: the sums in fp32 as well (gso_raster3d_bwd_f32sum: an fp32 evaluation in one of the orders the reference's atomics
+    may take - the envelope of those bands)."""
     off, I, th, tw, cdim, m2, cn, cl, op = _raster_common(means2d, conics, colors, opacities, isect_offsets)
     fl = _np(flatten_ids, np.int32)
     rows = m2.shape[0]
@@ -536,7 +538,8 @@ def rasterize_to_pixels_bwd(
     v_cn = np.zeros((rows, 3), dtype=np.float64)
     v_cl = np.zeros((rows, cdim), dtype=np.float64)
     v_op = np.zeros((rows,), dtype=np.float64)
-    fn = lib().gso_raster3d_bwd_f64 if sample_f64 else lib().gso_raster3d_bwd
+    assert not (sum_f32 and (sample_f64 or absgrad))
+    fn = lib().gso_raster3d_bwd_f64 if sample_f64 else (lib().gso_raster3d_bwd_f32sum if sum_f32 else lib().gso_raster3d_bwd)
     fn(_p(m2), _p(cn), _p(cl), _p(op), _p(bg), _p(mk), _p(off), _p(fl), _p(ra), _p(li), _p(vc),
                            _p(va), ctypes.c_uint32(I), ctypes.c_uint32(fl.shape[0]), ctypes.c_uint32(cdim),
                            ctypes.c_uint32(image_width), ctypes.c_uint32(image_height), ctypes.c_uint32(tile_size),

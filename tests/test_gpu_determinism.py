@@ -54,8 +54,8 @@ def render_hashes(G, repeats, noise):
             rc, ra, meta = G.rasterization(lv["means"], lv["quats"], lv["scales"], lv["opacities"], lv["colors"], d["viewmats"],
                                            d["Ks"], W, H, sh_degree=deg, packed=bool(r & 1))
             rc.sum().backward()  # the backward allocates and frees workspaces between two forward passes, as a trainer does
-            # packed and dense rows give the same image; ids / means are only comparable within a layout
-            out[tag].add(("img", _hash(rc, ra)))
+            # hashes are compared within a layout (packed / dense rows)
+            out[tag].add((f"img packed={r & 1}", _hash(rc, ra)))
             m2 = meta["means2d"]
             if not (r & 1):  # dense rows of culled Gaussians are never written (like the reference's at::empty outputs)
                 m2 = m2[(meta["radii"] > 0).all(-1)]
@@ -97,7 +97,7 @@ def test_forward_is_bit_reproducible_across_processes_and_history():
         results.append((f"fresh process {i}", json.loads(line[len("HASHES "):])))
     for tag in SCENES:
         ref = results[0][1][tag]
-        # one image hash, one row hash per layout - in every process
-        assert len(ref) == 3, f"{tag}: this process rendered {len(ref)} distinct (image | rows) hashes over 50 repeats: {ref}"
+        # one image hash and one row hash per layout - in every process
+        assert len(ref) == 4, f"{tag}: this process rendered {len(ref)} distinct (image | rows) hashes over 50 repeats: {ref}"
         for name, r in results[1:]:
             assert r[tag] == ref, f"{tag}: {name} differs from this process: {r[tag]} vs {ref}"

@@ -118,7 +118,8 @@ def test_bench_two_rank_path_rehearsal():
     assert "cpu_baseline" not in r and "roofline" in r  # the CPU baseline is an N = 1 leg
     ref = r["c4_single_gpu"]  # rank 0's single-GPU reference of the same workload, measured after the timed region
     assert ref["value"] > 0 and "120000 synthetic Gaussians" in ref["workload"] and "rank 0" in ref["note"]
-    assert r["speedup_vs_1gpu"] == pytest.approx(r["value"] / ref["value"], rel=1e-2) and r["efficiency"] > 0
+    # the line rounds the ratio to three decimals: compare on that grid (0.021 against 0.02123 is not a 1 % difference)
+    assert r["speedup_vs_1gpu"] == pytest.approx(r["value"] / ref["value"], rel=1e-2, abs=6e-4) and r["efficiency"] > 0
 
 
 def test_bench_eight_rank_path_rehearsal():

@@ -245,10 +245,11 @@ def test_c3_compositing_gradients_per_element_band(G):
     """The scale-relative checks above bound |a - e| by a fraction of the tensor's LARGEST element: a small row could be
     wrong unnoticed. Here the compositing stage alone (rasterize_to_pixels forward + backward on c3's own intersection lists:
     3.8 M intersections, 0.93 M visible rows) is held to the reference's PER-ELEMENT band (tests/test_basic.py:2664-2675 ->
-    tests/_util.py RASTER_BWD_BAND). What the band lets through is measured, not assumed: the same sums evaluated with the
-    per-sample math in fp64 (oracle gso_raster3d_bwd_f64) are the value both fp32 evaluations approximate; the share of
-    elements of the fp32 CPU oracle outside the band around it is the envelope, and the GPU kernel may have at most twice
-    that share (+ 1e-5: pixels whose 1/255 or 1e-4 decision differs between the two forward passes) outside it."""
+    tests/_util.py RASTER_BWD_BAND). What the band lets through is measured, not assumed: the same sums evaluated in fp64
+    throughout (oracle gso_raster3d_bwd_f64) are the value every fp32 evaluation approximates; an fp32 evaluation on the CPU
+    (gso_raster3d_bwd_f32sum: fp32 samples AND fp32 sums, per tile in raster order - one of the orders the reference's atomics
+    may take) is outside the band around it for some share of the elements - the envelope - and the GPU kernel may have at
+    most twice that share (+ 1e-5: pixels whose 1/255 or 1e-4 decision differs between the two forward passes) outside it."""
     import os
 
     from _util import RASTER_BWD_BAND
@@ -273,22 +274,30 @@ def test_c3_compositing_gradients_per_element_band(G):
     args = (cpu(m2), cpu(con), cpu(col), cpu(op), W, H, 16, cpu(off), cpu(fl))
     rc_o, ra_o, li_o = O.rasterize_to_pixels(*args, backgrounds=cpu(bg))
     assert_close_ratio(cpu(rc), rc_o, 1e-4, 2e-5, max_bad_ratio=1e-4, name="c3 stage colors")
-    g32 = O.rasterize_to_pixels_bwd(*args, ra_o, li_o, v_rc, v_ra, backgrounds=cpu(bg))
     g64 = O.rasterize_to_pixels_bwd(*args, ra_o, li_o, v_rc, v_ra, backgrounds=cpu(bg), sample_f64=True)
-    report = {}
+    gs32 = O.rasterize_to_pixels_bwd(*args, ra_o, li_o, v_rc, v_ra, backgrounds=cpu(bg), sum_f32=True)
+    report, failures = {}, []
     for leaf, key in zip(leaves, ("v_means2d", "v_conics", "v_colors", "v_opacities")):
         rtol, atol = RASTER_BWD_BAND[key]
         truth = torch.from_numpy(g64[key]).reshape(leaf.shape)
         tol = atol + rtol * truth.abs()
-        env = ((torch.from_numpy(g32[key]).reshape(leaf.shape) - truth).abs() > tol).double().mean().item()
+        err_cpu = (torch.from_numpy(gs32[key]).reshape(leaf.shape) - truth).abs()
+        env = (err_cpu > tol).double().mean().item()
         err = (cpu(leaf.grad).double() - truth).abs()
         bad = (err > tol).double().mean().item()
-        report[key] = (env, bad, err.max().item())
-        assert bad <= 2.0 * env + 1e-5, f"c3 {key}: {bad:.3e} of the elements outside the per-element band ({rtol}, {atol}); " \
-                                        f"fp32 CPU envelope {env:.3e}; max err {err.max().item():.3e}"
-        # a grossly wrong element fails whatever the share: nothing further out than 50 x the band
-        assert (err <= 50.0 * tol).all(), f"c3 {key}: an element is off by more than 50 x its band, max err {err.max().item():.3e}"
-    print("c3 per-element band (fp32 CPU envelope, GPU share outside, GPU max err):", report)
+        worst = int(err.flatten().argmax())
+        report[key] = dict(cpu_fp32_outside=env, gpu_outside=bad, gpu_max_err=err.max().item(), cpu_max_err=err_cpu.max().item(),
+                           at_truth=truth.flatten()[worst].item(), max_over_tol=(err / tol).max().item(),
+                           cpu_max_over_tol=(err_cpu / tol).max().item(), scale=truth.abs().max().item())
+        if not bad <= 2.0 * env + 1e-5:
+            failures.append(f"c3 {key}: {bad:.3e} of the elements outside the per-element band ({rtol}, {atol}); fp32-sum CPU "
+                            f"envelope {env:.3e}; max err {err.max().item():.3e}")
+        # a grossly wrong element fails whatever the share: nothing further out than 4 x the worst element of the fp32 CPU sums
+        if not (err / tol).max().item() <= max(50.0, 4.0 * (err_cpu / tol).max().item()):
+            failures.append(f"c3 {key}: an element is {(err / tol).max().item():.1f} bands out (fp32-sum CPU: "
+                            f"{(err_cpu / tol).max().item():.1f})")
+    print("c3 per-element band:", report)
+    assert not failures, "; ".join(failures) + f" | {report}"
 
 
 def test_c4_matches_oracle(G):

@@ -239,6 +239,9 @@ def test_rasterize_bwd_fp64_samples_agree_with_the_fp32_oracle(golden):
                                     sample_f64=True)
     for k in g32:
         assert_grad_close(g32[k], g64[k], rel=1e-4, max_bad_ratio=1e-4, name=k)
+    gs = O.rasterize_to_pixels_bwd(m2, con, col, op, W, H, ts, off, fl, ra, li, v_rc, v_ra, backgrounds=bg, sum_f32=True)
+    for k in gs:
+        assert_grad_close(gs[k], g64[k], rel=1e-4, max_bad_ratio=1e-4, name=k + " (fp32 sums)")
     for k, (rtol, atol) in RASTER_BWD_BAND.items():
         assert_close_ratio(g64[k].reshape(golden["rast_" + k].shape), golden["rast_" + k], rtol, atol, max_bad_ratio=1e-2,
                            name=k + " fp64 samples vs the reference's autograd")
