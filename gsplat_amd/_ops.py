@@ -949,7 +949,7 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
         v_render_colors = v_render_colors.contiguous()
         vrc_strides = (-1, 1)
     if segmented:
-        ws = torch.empty(_cabi._lib.gsx_raster3d_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN),
+        ws = torch.empty(_cabi._lib.gsx_raster3d_bwd_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN),
                          device=means2d.device, dtype=torch.uint8)
         call("gsx_raster3d_bwd_seg", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
              ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),

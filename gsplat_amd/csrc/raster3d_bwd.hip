@@ -744,7 +744,11 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
     float *s_w      = reinterpret_cast<float *>(s_aux + BATCH); // [SLOTS][4 quadrants][4 groups][GP]: (fac, w) per pixel
 
     TileCtx tc;
-    if (a.tile_order ? !tile_context_ordered(a, blockIdx.x, tc) : !tile_context(a, blockIdx.x, tc)) return;
+    uint32_t seg_item = 0;
+    if (a.seg_mode != 0u) { // a launch over slices of long tile lists + the short tiles behind them (raster3d_seg.hip)
+        if (!tile_context_seg(a, blockIdx.x, tc, seg_item)) return;
+    } else if (a.tile_order ? !tile_context_ordered(a, blockIdx.x, tc) : !tile_context(a, blockIdx.x, tc)) return;
+    const bool in_segment = a.seg_mode != 0u && seg_item != 0xFFFFFFFFu;
     if (a.masks && !a.masks[(size_t)tc.image_id * (a.tile_w * a.tile_h) + tc.tile_id]) return;
     const int32_t range_start = tc.range_start;
     if (tc.range_end <= range_start) return;
@@ -766,8 +770,10 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
         const bool inside  = prow >= 0;
         const size_t pix   = inside ? (size_t)prow : 0;
         const float T_fin  = inside ? 1.0f - a.render_alphas[pix] : 1.0f;
-        T[q]               = T_fin;
-        behind[q]          = 0.0f;
+        // a slice starts (back to front) from the transmittance at ITS end and from what lies behind it; the pre-pass stores
+        // both per pixel in the four-wave kernels' thread order: quadrant q, lane (raster3d_seg.hip: seg_bwd_prefix_kernel)
+        T[q]               = in_segment ? a.seg_T[(size_t)seg_item * 256 + (size_t)q * 64 + lane] : T_fin;
+        behind[q]          = in_segment ? a.seg_out[(size_t)seg_item * 256 + (size_t)q * 64 + lane] : 0.0f;
         bin_final[q]       = inside ? a.last_ids[pix] : -1;
 #pragma unroll
         for (int k = 0; k < CH; ++k) v_c[q][k] = (inside && k < (int)a.nch) ? a.v_render_colors[vrc_index(a, pix, a.ch_off + (uint32_t)k)] : 0.0f;
@@ -1154,6 +1160,18 @@ int raster3d_bwd_t_launch_items(const Raster3DArgs &a, hipStream_t stream)
     return check_launch("raster3d_bwd_t(segments)");
 }
 bool raster3d_bwd_uses_variant_t() { return use_variant_t(); }
+bool raster3d_bwd_uses_variant_w() { return bwd_variant() == 'w'; }
+// variant W over the same item list (one wave per slice / short tile); a.nch <= 4, tile size 16, no absgrad
+int raster3d_bwd_w_launch_items(const Raster3DArgs &a, hipStream_t stream)
+{
+    const uint32_t grid = ((a.seg_grid + 7u) / 8u) * 8u;
+    if (grid == 0) return GSX_OK;
+    if (a.nch <= 1) raster3d_bwd_w_kernel<1><<<dim3(grid), dim3(64), BwdWCfg<1>::smem, stream>>>(a);
+    else if (a.nch <= 2) raster3d_bwd_w_kernel<2><<<dim3(grid), dim3(64), BwdWCfg<2>::smem, stream>>>(a);
+    else if (a.nch <= 3) raster3d_bwd_w_kernel<3><<<dim3(grid), dim3(64), BwdWCfg<3>::smem, stream>>>(a);
+    else raster3d_bwd_w4_kernel<<<dim3(grid), dim3(64), BwdWCfg<4>::smem, stream>>>(a);
+    return check_launch("raster3d_bwd_w(segments)");
+}
 
 // Five to eight channels: variant W takes them FOUR AT A TIME (the gradient of alpha is linear in the channels, so every launch
 // adds its share of the geometry gradients; first_chunk carries the alpha cotangent). Measured at c3 (profiles/r09_ab.md):

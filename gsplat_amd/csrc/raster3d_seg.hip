@@ -21,6 +21,8 @@
 // first): ~1e-7 relative, which can move a threshold decision on a pixel that sits exactly on it - the class of difference
 // the reference's own CUDA-vs-torch tolerances cover. The price is pass 3: the alphas of a long tile are evaluated twice
 // (~0.6 of a forward); in exchange its critical path is one segment instead of the whole list.
+#include <cstdlib>
+
 #include "raster3d.hpp"
 #include "../../include/gsplat_amd.h"
 
@@ -29,7 +31,25 @@ namespace gsx {
 int raster3d_fwd_launch_chunk(const Raster3DArgs &a, hipStream_t stream);   // raster3d_fwd.hip
 int raster3d_bwd_prepass_launch(const Raster3DArgs &a, hipStream_t stream); // raster3d_fwd.hip (forward kernel, PRE = true)
 int raster3d_bwd_t_launch_items(const Raster3DArgs &a, hipStream_t stream); // raster3d_bwd.hip
+int raster3d_bwd_w_launch_items(const Raster3DArgs &a, hipStream_t stream); // raster3d_bwd.hip
 bool raster3d_bwd_uses_variant_t();
+bool raster3d_bwd_uses_variant_w();
+
+// Slice length of the BACKWARD for a forward slice length: the one-wave-per-tile kernel (variant W) walks a slice as ONE
+// instruction stream, so its slices are a quarter as long as those of the four-wave kernels (the critical path of a launch is
+// its longest unit of work); the pre-pass costs the same either way (it evaluates every entry of the long lists once).
+// GSX_BWD_SEG_DIV overrides the divisor (A/B).
+static uint32_t bwd_slice_len(uint32_t seg_len)
+{
+    if (!raster3d_bwd_uses_variant_w() || seg_len == 0) return seg_len;
+    static const uint32_t div = [] {
+        const char *e = getenv("GSX_BWD_SEG_DIV");
+        const int v   = e ? atoi(e) : 4;
+        return (uint32_t)(v >= 1 ? v : 1);
+    }();
+    const uint32_t l = seg_len / div;
+    return l < 256u ? 256u : l;
+}
 
 struct SegHeader { // device memory, zeroed before every use
     int32_t n_items, n_long, pad[2];
@@ -212,6 +232,13 @@ extern "C" int64_t gsx_raster3d_seg_workspace_bytes(int64_t n_isects, uint32_t n
     return seg_layout(n_isects, n_images * tile_w * tile_h, nch_max, seg_len, nullptr, nullptr) + 512;
 }
 
+// workspace of gsx_raster3d_bwd_seg (its slices may be shorter than the forward's: bwd_slice_len)
+extern "C" int64_t gsx_raster3d_bwd_seg_workspace_bytes(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h,
+                                                        uint32_t cdim, uint32_t seg_len)
+{
+    return gsx_raster3d_seg_workspace_bytes(n_isects, n_images, tile_w, tile_h, cdim, bwd_slice_len(seg_len));
+}
+
 extern "C" int gsx_raster3d_fwd_seg(
     const float *means2d, const float *conics, const float *colors, const float *opacities, const float *backgrounds,
     const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images, uint32_t n_isects,
@@ -297,6 +324,7 @@ extern "C" int gsx_raster3d_bwd_seg(
                                 tile_w, tile_h, 0, v_rows, row_stride, stream);
     GSX_REQUIRE(seg_len >= 256, "gsx_raster3d_bwd_seg: seg_len must be >= 256, got %u", seg_len);
     if (n_isects == 0) return GSX_OK;
+    seg_len = bwd_slice_len(seg_len); // workspace: gsx_raster3d_bwd_seg_workspace_bytes
     GSX_REQUIRE(v_rows && row_stride >= 6u + cdim, "gsx_raster3d_bwd_seg: gradient rows missing / too narrow");
     GSX_REQUIRE(means2d && conics && colors && opacities && flatten_ids && render_alphas && last_ids && v_render_colors
                 && isect_offsets, "gsx_raster3d_bwd_seg: null input");
@@ -332,7 +360,7 @@ extern "C" int gsx_raster3d_bwd_seg(
         seg_bwd_prefix_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(p);
     }
     a.seg_mode = 2; a.seg_grid = p.max_items + n_blocks; // the slices first, the short tiles behind them
-    rc = raster3d_bwd_t_launch_items(a, s);
+    rc = raster3d_bwd_uses_variant_w() ? raster3d_bwd_w_launch_items(a, s) : raster3d_bwd_t_launch_items(a, s);
     if (rc != GSX_OK) return rc;
     return check_launch("raster3d_bwd_seg");
 }

@@ -739,8 +739,8 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
     if (longest == 0) longest = lookup_longest(flatten_ids_); // e.g. the reference's own autograd formula
     if (kSegLen > 0 && !absgrad && r.D <= 4 && tile_size == 16
         && longest > gsx_raster3d_seg_cut(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)kSegLen)) {
-        Tensor ws = at::empty({gsx_raster3d_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
-                                                              (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
+        Tensor ws = at::empty({gsx_raster3d_bwd_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
+                                                                  (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
         Timed timed_("gsx_raster3d_bwd", L.stream);
         check(gsx_raster3d_bwd_seg(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
                                    masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),

@@ -439,9 +439,13 @@ int gsx_raster3d_fwd_seg(const float *means2d, const float *conics, const float 
                          float *render_colors, float *render_alphas, int32_t *last_ids, uint32_t seg_len, void *workspace,
                          int64_t workspace_bytes, void *stream);
 /* Backward counterpart of gsx_raster3d_fwd_seg (<= 4 channels, 16 x 16 tiles, no absgrad - where the backward runs its
- * variant T): a pre-pass gives every slice its own transmittance and colour-cotangent sum, a per-pixel prefix turns them
+ * variants T / W): a pre-pass gives every slice its own transmittance and colour-cotangent sum, a per-pixel prefix turns them
  * into the transmittance and the "behind" sum at the END of every slice, and the slices are then walked back to front
- * independently, together with the short tiles. Same workspace size function as the forward. */
+ * independently, together with the short tiles. `seg_len` is the forward's slice length; the one-wave-per-tile kernel cuts
+ * its slices a quarter as long (one instruction stream per slice), so the workspace has its own size function. Replaces the
+ * same reference op as gsx_raster3d_bwd (gsplat::rasterize_to_pixels_3dgs_bwd, Rasterization.cpp:484-587). */
+int64_t gsx_raster3d_bwd_seg_workspace_bytes(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, uint32_t cdim,
+                                             uint32_t seg_len);
 int gsx_raster3d_bwd_seg(const float *means2d, const float *conics, const float *colors, const float *opacities,
                          const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
                          const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,

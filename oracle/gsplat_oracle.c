@@ -376,6 +376,12 @@ void gso_raster3d_bwd(const float *means2d, const float *conics, const float *co
  * values): what every fp32 evaluation of these sums approximates. tests/test_gpu_pipeline.py measures, per element, how far
  * the fp32 oracle above AND the GPU kernels are from it - two fp32 evaluations held to the same band. The contributor set is
  * the fp32 one (`last_ids`, and the alpha test on the fp64 alpha: a pair exactly on the 1/255 edge may differ). */
+/* optional second output of gso_raster3d_bwd_f64: [n_rows][6 + cdim] sums of the ABSOLUTE values of the terms of every
+ * gradient component (v_mean2d 2 | v_conic 3 | v_opacity 1 | v_color cdim) - the conditioning of each sum: an evaluation
+ * whose samples carry a relative error eps is off by at most eps times this. Set before the call, cleared by it. */
+static double *g_abs_terms = NULL;
+void gso_set_abs_terms(double *p) { g_abs_terms = p; }
+
 void gso_raster3d_bwd_f64(const float *means2d, const float *conics, const float *colors, const float *opacities,
                           const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
                           const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,
@@ -390,6 +396,10 @@ void gso_raster3d_bwd_f64(const float *means2d, const float *conics, const float
     memset(v_conics, 0, sizeof(double) * 3 * (size_t)n_rows);
     memset(v_colors, 0, sizeof(double) * (size_t)cdim * (size_t)n_rows);
     memset(v_opacities, 0, sizeof(double) * (size_t)n_rows);
+    double *abs_terms = g_abs_terms;
+    g_abs_terms       = NULL;
+    const uint32_t KA = 6 + cdim;
+    if (abs_terms) memset(abs_terms, 0, sizeof(double) * (size_t)KA * (size_t)n_rows);
 #pragma omp parallel for schedule(dynamic, 4)
     for (int64_t blk = 0; blk < total; ++blk) {
         if (masks && !masks[blk]) continue;
@@ -430,6 +440,10 @@ void gso_raster3d_bwd_f64(const float *means2d, const float *conics, const float
                     for (uint32_t k = 0; k < cdim; ++k) {
 #pragma omp atomic
                         v_colors[(size_t)g * cdim + k] += fac * (double)v_c[k];
+                        if (abs_terms) {
+#pragma omp atomic
+                            abs_terms[(size_t)g * KA + 6 + k] += fabs(fac * (double)v_c[k]);
+                        }
                         v_alpha += ((double)col[k] * T - buffer[k] * ra) * (double)v_c[k];
                     }
                     v_alpha += T_final * ra * v_a;
@@ -459,6 +473,21 @@ void gso_raster3d_bwd_f64(const float *means2d, const float *conics, const float
                         }
 #pragma omp atomic
                         v_opacities[g] += vis * v_alpha;
+                        if (abs_terms) {
+                            double *at = abs_terms + (size_t)g * KA;
+#pragma omp atomic
+                            at[0] += fabs(vx);
+#pragma omp atomic
+                            at[1] += fabs(vy);
+#pragma omp atomic
+                            at[2] += fabs(0.5 * v_sigma * dx * dx);
+#pragma omp atomic
+                            at[3] += fabs(v_sigma * dx * dy);
+#pragma omp atomic
+                            at[4] += fabs(0.5 * v_sigma * dy * dy);
+#pragma omp atomic
+                            at[5] += fabs(vis * v_alpha);
+                        }
                     }
                     for (uint32_t k = 0; k < cdim; ++k) buffer[k] += (double)col[k] * fac;
                 }

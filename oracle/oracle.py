@@ -517,13 +517,14 @@ def rasterize_to_pixels(
 def rasterize_to_pixels_bwd(
     means2d, conics, colors, opacities, image_width: int, image_height: int, tile_size: int, isect_offsets,
     flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas, backgrounds=None, masks=None,
-    absgrad: bool = False, sample_f64: bool = False, sum_f32: bool = False,
+    absgrad: bool = False, sample_f64: bool = False, sum_f32: bool = False, abs_sums: bool = False,
 ):
     """gsplat rasterize_to_pixels backward (RasterizeToPixels3DGSSerialBatchBwd.cu:41-320,
     Rasterization.cpp:567-577 for v_backgrounds). Returns dict of float64 numpy arrays. sample_f64: the per-sample math in
     fp64 too (gso_raster3d_bwd_f64: the value the fp32 evaluations approximate; per-element bands are measured against it);
     sum_f32: the sums in fp32 as well (gso_raster3d_bwd_f32sum: an fp32 evaluation in one of the orders the reference's atomics
-    may take - the envelope of those bands)."""
+    may take - the envelope of those bands); abs_sums (with sample_f64): also out["abs_terms"], the sum of |term| behind
+    every gradient element."""
     off, I, th, tw, cdim, m2, cn, cl, op = _raster_common(means2d, conics, colors, opacities, isect_offsets)
     fl = _np(flatten_ids, np.int32)
     rows = m2.shape[0]
@@ -540,12 +541,20 @@ def rasterize_to_pixels_bwd(
     v_op = np.zeros((rows,), dtype=np.float64)
     assert not (sum_f32 and (sample_f64 or absgrad))
     fn = lib().gso_raster3d_bwd_f64 if sample_f64 else (lib().gso_raster3d_bwd_f32sum if sum_f32 else lib().gso_raster3d_bwd)
+    abs_terms = None
+    if abs_sums:
+        assert sample_f64, "abs_sums is an output of the fp64 evaluation"
+        abs_terms = np.zeros((rows, 6 + cdim), dtype=np.float64)
+        lib().gso_set_abs_terms(_p(abs_terms))
     fn(_p(m2), _p(cn), _p(cl), _p(op), _p(bg), _p(mk), _p(off), _p(fl), _p(ra), _p(li), _p(vc),
                            _p(va), ctypes.c_uint32(I), ctypes.c_uint32(fl.shape[0]), ctypes.c_uint32(cdim),
                            ctypes.c_uint32(image_width), ctypes.c_uint32(image_height), ctypes.c_uint32(tile_size),
                            ctypes.c_uint32(tw), ctypes.c_uint32(th), ctypes.c_int64(rows), _p(v_abs), _p(v_m),
                            _p(v_cn), _p(v_cl), _p(v_op))
     out = {"v_means2d": v_m, "v_conics": v_cn, "v_colors": v_cl, "v_opacities": v_op}
+    if abs_terms is not None:  # sum of |term| per gradient component: the conditioning of each sum (gso_set_abs_terms)
+        out["abs_terms"] = {"v_means2d": abs_terms[:, 0:2], "v_conics": abs_terms[:, 2:5], "v_opacities": abs_terms[:, 5],
+                            "v_colors": abs_terms[:, 6:]}
     if absgrad:
         out["v_means2d_abs"] = v_abs
     if backgrounds is not None:

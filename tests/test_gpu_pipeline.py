@@ -241,15 +241,29 @@ def test_c3_matches_oracle(G):
                               name=f"c3 v_{k} packed={packed}")
 
 
+# What a per-element check of the compositing gradients can demand (test below). Every gradient element is a sum of terms
+# t_j over (pixel, Gaussian) pairs with mixed signs; an evaluation whose samples carry a relative error eps is off by up to
+# eps * A, A = sum |t_j|, whatever the size of the sum itself. The reference's band (rtol, atol per tensor: RASTER_BWD_BAND) is
+# therefore widened by eps * A with the sample accuracy each evaluation is built for:
+#   * CPU, fp32 samples and fp32 sums in the reference's form (sigma from the pixel offsets): 1e-6;
+#   * this backend: 4e-5 - the compositing kernels evaluate the exponent as a tile-centre polynomial (csrc/raster3d.hpp,
+#     "e-form": five FMAs per pixel instead of eight instructions), whose rounding is ~2e-5 ABSOLUTE on log2(alpha) for
+#     the tightest footprints, i.e. ~1.4e-5 relative on alpha, coherent over a tile; a documented trade
+#     inside the reference's own CUDA-vs-torch tolerances, and this test is what keeps it from growing.
+C3_SAMPLE_EPS = {"cpu_fp32": 1e-6, "gpu": 4e-5}
+
+
 def test_c3_compositing_gradients_per_element_band(G):
     """The scale-relative checks above bound |a - e| by a fraction of the tensor's LARGEST element: a small row could be
     wrong unnoticed. Here the compositing stage alone (rasterize_to_pixels forward + backward on c3's own intersection lists:
-    3.8 M intersections, 0.93 M visible rows) is held to the reference's PER-ELEMENT band (tests/test_basic.py:2664-2675 ->
-    tests/_util.py RASTER_BWD_BAND). What the band lets through is measured, not assumed: the same sums evaluated in fp64
-    throughout (oracle gso_raster3d_bwd_f64) are the value every fp32 evaluation approximates; an fp32 evaluation on the CPU
-    (gso_raster3d_bwd_f32sum: fp32 samples AND fp32 sums, per tile in raster order - one of the orders the reference's atomics
-    may take) is outside the band around it for some share of the elements - the envelope - and the GPU kernel may have at
-    most twice that share (+ 1e-5: pixels whose 1/255 or 1e-4 decision differs between the two forward passes) outside it."""
+    3.8 M intersections, 0.93 M visible rows) is checked ELEMENT BY ELEMENT against the same sums evaluated in fp64
+    throughout (oracle gso_raster3d_bwd_f64, which also returns A = the sum of |term| behind every element):
+        |gpu - fp64| <= atol + rtol |fp64| + eps A      for EVERY element of v_means2d, v_conics, v_colors, v_opacities
+    with (rtol, atol) the reference's per-element band (tests/test_basic.py:2664-2675 -> tests/_util.py RASTER_BWD_BAND) and
+    eps the sample accuracy (C3_SAMPLE_EPS). An fp32 evaluation on the CPU (gso_raster3d_bwd_f32sum: fp32 samples and fp32
+    sums per tile in raster order, one of the orders the reference's atomics may take) is put through the same inequality with
+    its own eps, so the two numbers printed per tensor - the eps each evaluation would need - are measured the same way.
+    Up to 1e-5 of the elements may miss (pixels whose 1/255 or 1e-4 decision differs between the two forward passes)."""
     import os
 
     from _util import RASTER_BWD_BAND
@@ -274,28 +288,28 @@ def test_c3_compositing_gradients_per_element_band(G):
     args = (cpu(m2), cpu(con), cpu(col), cpu(op), W, H, 16, cpu(off), cpu(fl))
     rc_o, ra_o, li_o = O.rasterize_to_pixels(*args, backgrounds=cpu(bg))
     assert_close_ratio(cpu(rc), rc_o, 1e-4, 2e-5, max_bad_ratio=1e-4, name="c3 stage colors")
-    g64 = O.rasterize_to_pixels_bwd(*args, ra_o, li_o, v_rc, v_ra, backgrounds=cpu(bg), sample_f64=True)
+    g64 = O.rasterize_to_pixels_bwd(*args, ra_o, li_o, v_rc, v_ra, backgrounds=cpu(bg), sample_f64=True, abs_sums=True)
     gs32 = O.rasterize_to_pixels_bwd(*args, ra_o, li_o, v_rc, v_ra, backgrounds=cpu(bg), sum_f32=True)
     report, failures = {}, []
     for leaf, key in zip(leaves, ("v_means2d", "v_conics", "v_colors", "v_opacities")):
         rtol, atol = RASTER_BWD_BAND[key]
         truth = torch.from_numpy(g64[key]).reshape(leaf.shape)
-        tol = atol + rtol * truth.abs()
-        err_cpu = (torch.from_numpy(gs32[key]).reshape(leaf.shape) - truth).abs()
-        env = (err_cpu > tol).double().mean().item()
-        err = (cpu(leaf.grad).double() - truth).abs()
-        bad = (err > tol).double().mean().item()
-        worst = int(err.flatten().argmax())
-        report[key] = dict(cpu_fp32_outside=env, gpu_outside=bad, gpu_max_err=err.max().item(), cpu_max_err=err_cpu.max().item(),
-                           at_truth=truth.flatten()[worst].item(), max_over_tol=(err / tol).max().item(),
-                           cpu_max_over_tol=(err_cpu / tol).max().item(), scale=truth.abs().max().item())
-        if not bad <= 2.0 * env + 1e-5:
-            failures.append(f"c3 {key}: {bad:.3e} of the elements outside the per-element band ({rtol}, {atol}); fp32-sum CPU "
-                            f"envelope {env:.3e}; max err {err.max().item():.3e}")
-        # a grossly wrong element fails whatever the share: nothing further out than 4 x the worst element of the fp32 CPU sums
-        if not (err / tol).max().item() <= max(50.0, 4.0 * (err_cpu / tol).max().item()):
-            failures.append(f"c3 {key}: an element is {(err / tol).max().item():.1f} bands out (fp32-sum CPU: "
-                            f"{(err_cpu / tol).max().item():.1f})")
+        A = torch.from_numpy(g64["abs_terms"][key]).reshape(leaf.shape)
+        band = atol + rtol * truth.abs()
+        rec = {"scale": truth.abs().max().item()}
+        for who, val in (("cpu_fp32", torch.from_numpy(gs32[key]).reshape(leaf.shape)), ("gpu", cpu(leaf.grad).double())):
+            err = (val - truth).abs()
+            need = ((err - band).clamp_min(0.0) / (A + 1e-30)).flatten()  # the eps this element needs on top of the band
+            outside = (err > band + C3_SAMPLE_EPS[who] * A).double().mean().item()
+            rec[who] = {"outside_plain_band": (err > band).double().mean().item(), "outside_with_eps": outside,
+                        "eps_needed_p9999": need.kthvalue(max(1, int(0.9999 * need.numel()))).values.item(),
+                        "eps_needed_max": need.max().item(), "max_err": err.max().item()}
+            if outside > 1e-5:
+                failures.append(f"c3 {key} ({who}): {outside:.3e} of the elements outside band + {C3_SAMPLE_EPS[who]:g} sum|terms|")
+            # no element may be grossly wrong: within ten times the allowance, every one of them
+            if not bool((err <= 10.0 * (band + C3_SAMPLE_EPS[who] * A)).all()):
+                failures.append(f"c3 {key} ({who}): an element is more than 10 x its allowance out (max err {err.max().item():.3e})")
+        report[key] = rec
     print("c3 per-element band:", report)
     assert not failures, "; ".join(failures) + f" | {report}"
 
