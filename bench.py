@@ -361,7 +361,10 @@ def main():
     else:
         e_i, _, prof = timed(step, args.steps, 0, barrier, profile_only=raster_entries)
         instrumented_window_s = max_over_ranks(e_i)
-    prof = {k.replace("_ws", "").replace("_seg", ""): v for k, v in prof.items()}
+    merged = {}  # gsx_raster3d_bwd / _ws / _seg are one stage: their launch times are pooled, never overwritten
+    for k, v in prof.items():
+        merged.setdefault(k.replace("_ws", "").replace("_seg", ""), []).extend(v)
+    prof = merged
     if distributed:
         _gd.reset_exchange_stats()
     for _ in range(n_windows):

@@ -271,7 +271,13 @@ def isect_fused_emit_workspace_bytes(n: int, n_images: int, tile_w: int, tile_h:
 
 
 def isect_binned_supported(rows: int, n_images: int, tile_w: int, tile_h: int, packed: bool) -> bool:
+    """Pure query (asking changes nothing)."""
     return bool(_lib.gsx_isect_binned_supported(rows, n_images, tile_w, tile_h, int(packed)))
+
+
+def isect_binned_should_try(rows: int, n_images: int, tile_w: int, tile_h: int, packed: bool) -> bool:
+    """The decision of ONE intersection (counts a skipped call while a retry note is active): call once, keep the answer."""
+    return bool(_lib.gsx_isect_binned_should_try(rows, n_images, tile_w, tile_h, int(packed)))
 
 
 def isect_binned_count_workspace_bytes(rows: int, n_images: int, tile_w: int, tile_h: int) -> int:

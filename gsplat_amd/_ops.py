@@ -295,8 +295,9 @@ _row_map_cache: list = []  # at most one (key, id tensors, row_map): see _packed
 
 
 def clear_row_map_cache() -> None:
-    """Drops the cached row map (and with it the references that keep a step's id tensors alive). rasterization() calls this
-    when a new forward pass starts: the map only ever serves the two packed backward kernels of ONE step."""
+    """Drops the cached row map (and with it the references that keep a step's id tensors alive). The packed projection
+    backward - the last of the two kernels of a step that walk the map - calls this when it is done, and rasterization() when a
+    new forward pass starts: the map only ever serves the packed backward kernels of ONE step."""
     with _row_map_lock:
         _row_map_cache.clear()
 
@@ -595,7 +596,7 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
     st.host_total = torch.zeros(2, dtype=torch.int64, pin_memory=True)  # [n_isects, longest tile list]
     if st.fused:
         st.offsets = torch.empty(I * tile_width * tile_height, device=dev, dtype=torch.int32)
-        st.binned = _cabi.isect_binned_supported(rows, I, tile_width, tile_height, packed)
+        st.binned = _cabi.isect_binned_should_try(rows, I, tile_width, tile_height, packed)  # once; st carries it
         _isect_fused_count(st, None)
         st.event = torch.cuda.Event()
         st.event.record()
@@ -863,6 +864,9 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
         v_quats, v_scales = alloc(quats), alloc(scales)
     call("gsx_project_ewa_packed_bwd", *head, ptr(row_map), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales),
          ptr(v_viewmats))
+    # the last consumer of a step's row map (autograd runs the SH backward, created later, first): drop it here, and with it
+    # the references that keep the step's id tensors alive - a stage-level caller has no next rasterization() to do that
+    clear_row_map_cache()
     return v_means, v_covars, v_quats, v_scales, v_viewmats
 
 
@@ -1461,7 +1465,7 @@ def intersect_tile_sparse(means2d, radii, depths, image_ids, tile_mask, active_t
         st.n_per, st.sort, st.fused = 1, True, True  # every slot set: _isect_fused_emit reads st.fused through isect_max_tile_len
         st.offsets = offsets = torch.empty(I * n_tiles, device=dev, dtype=torch.int32)
         st.host_total = torch.zeros(2, dtype=torch.int64, pin_memory=True)
-        st.binned = _cabi.isect_binned_supported(rows, I, tile_width, tile_height, packed)
+        st.binned = _cabi.isect_binned_should_try(rows, I, tile_width, tile_height, packed)  # once; st carries it
         _isect_fused_count(st, tile_mask)
         torch.cuda.current_stream(dev).synchronize()  # host sync: exact-length outputs (reference: Intersect.cpp:637)
         n_isects = _isect_fused_total(st, tile_mask)

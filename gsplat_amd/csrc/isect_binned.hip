@@ -676,13 +676,14 @@ uint64_t retry_key(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t ti
 {
     return ((uint64_t)(rows >> 16) << 40) ^ ((uint64_t)n_images << 32) ^ ((uint64_t)tile_w << 16) ^ (uint64_t)tile_h ^ (1ull << 63);
 }
-bool retried_recently(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
+// consume = true: this call IS one of the 63 that skip the attempt (gsx_isect_binned_should_try, once per intersection)
+bool retried_recently(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, bool consume)
 {
     const uint64_t key = retry_key(rows, n_images, tile_w, tile_h);
     std::lock_guard<std::mutex> lock(g_retry_mutex);
     for (auto &n : g_retry)
         if (n.key == key && n.left > 0) {
-            --n.left;
+            if (consume) --n.left;
             return true;
         }
     return false;
@@ -702,7 +703,19 @@ extern "C" int gsx_isect_binned_note_retry(int64_t rows, uint32_t n_images, uint
     return GSX_OK;
 }
 
+// A pure function of its arguments, the environment switches and the retry notes: querying it changes nothing (a binding
+// may size a workspace with it, a test may probe it). The decision that COUNTS one of the 63 skipped calls is
+// gsx_isect_binned_should_try, made once per intersection.
+static int binned_decide(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed, bool consume);
 extern "C" int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed)
+{
+    return binned_decide(rows, n_images, tile_w, tile_h, packed, false);
+}
+extern "C" int gsx_isect_binned_should_try(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed)
+{
+    return binned_decide(rows, n_images, tile_w, tile_h, packed, true);
+}
+static int binned_decide(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed, bool consume)
 {
     // GSX_ISECT_PATH = binned | legacy forces the choice (tests, A/B); GSX_ISECT_LEGACY is the older spelling of "legacy"
     const char *force = getenv("GSX_ISECT_PATH");
@@ -726,7 +739,7 @@ extern "C" int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint3
     // clustered garden stays faster Gaussian-major at every size (x1 0.207 / 0.128 forced) - it fails the skew test, and an
     // input that did is not tried again for a while (retried_recently).
     if (!(g.rows_per_image >= 49152 && g.rows_per_image <= 144ll * (int64_t)g.n_tiles)) return 0;
-    return retried_recently(rows, n_images, tile_w, tile_h) ? 0 : 1;
+    return retried_recently(rows, n_images, tile_w, tile_h, consume) ? 0 : 1;
 }
 
 extern "C" int64_t gsx_isect_binned_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)

@@ -149,7 +149,13 @@ __device__ __forceinline__ bool tile_context_seg(const Raster3DArgs &a, uint32_t
         // compositing pass: the workgroups behind the segment items take the SHORT tiles, whole list, straight into the
         // image (item = ~0) - one launch for everything, the long segments first
         if (a.seg_mode != 2u) return false;
-        const uint32_t blk = block - (uint32_t)n_items;
+        uint32_t blk = block - (uint32_t)n_items;
+        if (a.tile_order) { // backward, one wave per unit: the short tiles longest-first too (tile_order.hip; per XCD range)
+            if (blk >= ((n_blocks + 7u) / 8u) * 8u) return false;
+            const uint32_t idx = xcd_remap(blk, n_blocks);
+            if (idx >= n_blocks) return false;
+            blk = (uint32_t)a.tile_order[idx];
+        }
         if (blk >= n_blocks) return false;
         item       = 0xFFFFFFFFu;
         t.image_id = blk / tiles_per_image;

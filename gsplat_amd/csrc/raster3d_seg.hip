@@ -36,15 +36,16 @@ bool raster3d_bwd_uses_variant_t();
 bool raster3d_bwd_uses_variant_w();
 
 // Slice length of the BACKWARD for a forward slice length: the one-wave-per-tile kernel (variant W) walks a slice as ONE
-// instruction stream, so its slices are a quarter as long as those of the four-wave kernels (the critical path of a launch is
+// instruction stream, so its slices are half as long as those of the four-wave kernels (the critical path of a launch is
 // its longest unit of work); the pre-pass costs the same either way (it evaluates every entry of the long lists once).
-// GSX_BWD_SEG_DIV overrides the divisor (A/B).
+// Garden x25, backward in ms (profiles/r09_ab.md): slices of 1024 0.863, 512 0.634 - 0.653, 256 0.667 - 0.698; variant T on
+// slices of 1024: 0.647 - 0.656. GSX_BWD_SEG_DIV overrides the divisor (A/B).
 static uint32_t bwd_slice_len(uint32_t seg_len)
 {
     if (!raster3d_bwd_uses_variant_w() || seg_len == 0) return seg_len;
     static const uint32_t div = [] {
         const char *e = getenv("GSX_BWD_SEG_DIV");
-        const int v   = e ? atoi(e) : 4;
+        const int v   = e ? atoi(e) : 2;
         return (uint32_t)(v >= 1 ? v : 1);
     }();
     const uint32_t l = seg_len / div;
@@ -236,7 +237,9 @@ extern "C" int64_t gsx_raster3d_seg_workspace_bytes(int64_t n_isects, uint32_t n
 extern "C" int64_t gsx_raster3d_bwd_seg_workspace_bytes(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h,
                                                         uint32_t cdim, uint32_t seg_len)
 {
-    return gsx_raster3d_seg_workspace_bytes(n_isects, n_images, tile_w, tile_h, cdim, bwd_slice_len(seg_len));
+    // + the longest-first order of the short tiles (variant W: one wave per unit of work, tile_order.hip)
+    return gsx_raster3d_seg_workspace_bytes(n_isects, n_images, tile_w, tile_h, cdim, bwd_slice_len(seg_len))
+           + tile_order_workspace_bytes(n_images, tile_w, tile_h) + 256;
 }
 
 extern "C" int gsx_raster3d_fwd_seg(
@@ -360,6 +363,16 @@ extern "C" int gsx_raster3d_bwd_seg(
         seg_bwd_prefix_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(p);
     }
     a.seg_mode = 2; a.seg_grid = p.max_items + n_blocks; // the slices first, the short tiles behind them
+    if (raster3d_bwd_uses_variant_w()) {
+        // one wave per unit: a short tile of up to seg_cut entries started late is the launch's tail - take them longest-first
+        // (the order lives behind the segment plan in the workspace, when the caller sized it with the backward's own function)
+        unsigned char *ord = base + align256(seg_layout(n_isects, n_blocks, cdim, seg_len, base, nullptr));
+        const int64_t left = workspace_bytes - (ord - reinterpret_cast<unsigned char *>(workspace));
+        int orc = GSX_OK;
+        a.tile_order = build_tile_order(isect_offsets, last_ids, n_images, tile_size, tile_w, tile_h, width, height, n_isects, ord,
+                                        left, s, &orc);
+        if (orc != GSX_OK) return orc;
+    }
     rc = raster3d_bwd_uses_variant_w() ? raster3d_bwd_w_launch_items(a, s) : raster3d_bwd_t_launch_items(a, s);
     if (rc != GSX_OK) return rc;
     return check_launch("raster3d_bwd_seg");

@@ -50,10 +50,14 @@ __global__ void __launch_bounds__(kSsimTw *kSsimTh) ssim_kernel(const SsimArgs a
         const int r = i / IW, q = i % IW, gy = y0 + r - kSsimPad, gx = x0 + q - kSsimPad;
         const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         if constexpr (BWD) {
-            const float *d = pd + ((size_t)gy * a.W + gx) * 3;
-            s_in[0][r][q] = in ? d[0] : 0.0f;
-            s_in[1][r][q] = in ? d[1] : 0.0f;
-            s_in[2][r][q] = in ? d[2] : 0.0f;
+            float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+            if (in) { // the address is only formed for pixels of the image (gy, gx may be negative in the halo)
+                const float *d = pd + ((size_t)gy * a.W + (size_t)gx) * 3;
+                d0 = d[0]; d1 = d[1]; d2 = d[2];
+            }
+            s_in[0][r][q] = d0;
+            s_in[1][r][q] = d1;
+            s_in[2][r][q] = d2;
         } else {
             const float vx = in ? px[gy * a.sx[2] + gx * a.sx[3]] : 0.0f, vy = in ? py[gy * a.sy[2] + gx * a.sy[3]] : 0.0f;
             s_in[0][r][q] = vx;

@@ -538,7 +538,7 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
     if (sort && !f64 && gsx_isect_fused_supported(uI, utw, uth, packed ? 1 : 0)) {
         Tensor offsets = at::empty({I * tile_w * tile_h}, means2d.options().dtype(at::kInt));
         int64_t M = GSX_ISECT_RETRY;
-        if (gsx_isect_binned_supported(rows, uI, utw, uth, packed ? 1 : 0)) {
+        if (gsx_isect_binned_should_try(rows, uI, utw, uth, packed ? 1 : 0)) { // the one decision of this intersection
             // tile-owner-major path (csrc/isect_binned.hip); GSX_ISECT_RETRY = its entry workspace was too small
             Tensor count_ws = bytes(gsx_isect_binned_count_workspace_bytes(rows, uI, utw, uth), means2d);
             { Timed timed_("gsx_isect_binned_count", L.stream); check(gsx_isect_binned_count(fp(means2d), cp<int32_t>(radii), fp(depths), fp(conics), fp(opac), nullptr, rows, uI,
@@ -787,7 +787,7 @@ isect_fused_begin(const Tensor &means2d, const Tensor &radii, const Tensor &dept
     Tensor host_total = at::empty({3}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
     host_total.mutable_data_ptr<int64_t>()[0] = -1;
     host_total.mutable_data_ptr<int64_t>()[1] = 0;
-    const bool binned_path = gsx_isect_binned_supported(rows, uI, utw, uth, 0) != 0;
+    const bool binned_path = gsx_isect_binned_should_try(rows, uI, utw, uth, 0) != 0; // the one decision; slot [2] carries it
     host_total.mutable_data_ptr<int64_t>()[2] = binned_path ? 1 : 0;
     Tensor offsets = at::empty({I * tile_w * tile_h}, means2d.options().dtype(at::kInt));
     if (binned_path) { // tile-owner-major path (csrc/isect_binned.hip)
@@ -829,7 +829,8 @@ isect_fused_finish(const Tensor &means2d, const Tensor &radii, const Tensor &dep
             }
         }
     }
-    bool binned = host_total.numel() > 2 ? slot[2] != 0 : gsx_isect_binned_supported(rows, uI, utw, uth, 0) != 0;
+    TORCH_CHECK(host_total.numel() > 2, "isect_fused_finish: host_total must be the three pinned words of isect_fused_begin");
+    bool binned = slot[2] != 0; // the choice isect_fused_begin made (never re-derived: a query here could answer differently)
     if (binned && M == GSX_ISECT_RETRY) {
         // the binned path's entry workspace was too small for this scene (very large Gaussians), or a bin too crowded: count
         // again Gaussian-major, and do not try this shape again for a while
@@ -963,6 +964,11 @@ TORCH_LIBRARY_IMPL(gsplat_amd, CUDA, m)
 {
     m.impl("isect_fused_begin", &gsplat_amd::isect_fused_begin);
     m.impl("isect_fused_finish", &gsplat_amd::isect_fused_finish);
+}
+
+// the notes are keyed by storage identity: any backend (tools/dry_run.py drives the host paths with CPU tensors)
+TORCH_LIBRARY_IMPL(gsplat_amd, CompositeExplicitAutograd, m)
+{
     m.impl("note_longest", &gsplat_amd::note_longest_op);
     m.impl("lookup_longest", &gsplat_amd::lookup_longest_op);
 }

@@ -59,7 +59,7 @@ class _FusedSsimMean(torch.autograd.Function):
         img2 = img2.detach()
         dev = img1.device
         partial = torch.empty(_cabi._lib.gsx_ssim_blocks(B, C, H, W), device=dev, dtype=torch.float32)
-        need_grad = img1.requires_grad
+        need_grad = ctx.needs_input_grad[0]
         dmaps = torch.empty((B, C, H, W, 3), device=dev, dtype=torch.float32) if need_grad else None
         s1, s2 = (ctypes.c_int64 * 4)(*img1.stride()), (ctypes.c_int64 * 4)(*img2.stride())
         _cabi.call("gsx_ssim_fwd", _cabi.ptr_strided(img1), s1, _cabi.ptr_strided(img2), s2, B, C, H, W, _cabi.ptr(partial),
@@ -68,12 +68,15 @@ class _FusedSsimMean(torch.autograd.Function):
         return partial.sum() / float(B * C * H * W)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable  # the backward kernel is not itself differentiable
     def backward(ctx, v_mean: Tensor):
         import ctypes
 
         from . import _cabi
 
         img1, img2, dmaps = ctx.saved_tensors
+        if dmaps is None:  # forward ran without a gradient request for img1
+            return None, None
         B, C, H, W = img1.shape
         v_img1 = torch.empty_like(img1)  # preserve_format: a dense permuted view (channels-last render) keeps its strides
         s1, s2, sv = ((ctypes.c_int64 * 4)(*t.stride()) for t in (img1, img2, v_img1))
@@ -85,9 +88,12 @@ class _FusedSsimMean(torch.autograd.Function):
 
 def ssim_loss(img1: Tensor, img2: Tensor, window_size: int = 11) -> Tensor:
     """``1 - mean(SSIM)`` (gsplat/losses.py:150-200). float32 images on the GPU with the default window take the fused
-    kernels (what the reference gets from the third-party ``fused_ssim`` extension); anything else the torch evaluation."""
+    kernels (what the reference gets from the third-party ``fused_ssim`` extension); anything else the torch evaluation.
+    Zero ("same") padding like gsplat/losses.py's torch path; the reference's optional fused_ssim fast path defaults to
+    padding="valid" and is a different loss value - not offered here."""
     if (img1.is_cuda and img2.is_cuda and window_size == 11 and img1.dtype == torch.float32 and img2.dtype == torch.float32
-            and img1.dim() == 4 and img1.shape == img2.shape and not img2.requires_grad):
+            and img1.dim() == 4 and img1.shape == img2.shape and not img2.requires_grad
+            and img1.shape[0] * img1.shape[1] <= 65535):  # the kernels' grid: one z-slice per (batch, channel) plane
         return 1.0 - _FusedSsimMean.apply(img1, img2)
     return 1.0 - ssim_map(img1, img2, window_size).mean()
 

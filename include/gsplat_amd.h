@@ -384,8 +384,13 @@ int gsx_isect_fused_emit_sort(const float *means2d, const int32_t *radii, const 
  * ------------------------------------------------------------------------------------------- */
 #define GSX_ISECT_RETRY (-2)
 int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed);
-/* A binding that got GSX_ISECT_RETRY says so: gsx_isect_binned_supported() then answers 0 for the next 63 inputs of that shape
- * (row count to 64 k, images, tile grid) - a trainer renders the same clustered scene every step - and probes again after. */
+/* A binding that got GSX_ISECT_RETRY says so (gsx_isect_binned_note_retry): the next 63 intersections of that shape (row count
+ * to 64 k, images, tile grid) then skip the attempt - a trainer renders the same clustered scene every step - and the 64th
+ * probes again. gsx_isect_binned_supported() is a pure query (range + notes; asking changes nothing);
+ * gsx_isect_binned_should_try() is the same answer AND counts one skipped intersection: a binding calls it exactly once per
+ * intersection, where it chooses the path, and carries that choice to the second half. Same reference op as
+ * gsx_isect_binned_count (gsplat::intersect_tile, Intersect.cpp:170-329). */
+int gsx_isect_binned_should_try(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed);
 int gsx_isect_binned_note_retry(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h); /* returns 0 */
 int64_t gsx_isect_binned_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
 int64_t gsx_isect_binned_emit_workspace_bytes(int64_t n_isects);
@@ -442,7 +447,7 @@ int gsx_raster3d_fwd_seg(const float *means2d, const float *conics, const float 
  * variants T / W): a pre-pass gives every slice its own transmittance and colour-cotangent sum, a per-pixel prefix turns them
  * into the transmittance and the "behind" sum at the END of every slice, and the slices are then walked back to front
  * independently, together with the short tiles. `seg_len` is the forward's slice length; the one-wave-per-tile kernel cuts
- * its slices a quarter as long (one instruction stream per slice), so the workspace has its own size function. Replaces the
+ * its slices half as long (one instruction stream per slice), so the workspace has its own size function. Replaces the
  * same reference op as gsx_raster3d_bwd (gsplat::rasterize_to_pixels_3dgs_bwd, Rasterization.cpp:484-587). */
 int64_t gsx_raster3d_bwd_seg_workspace_bytes(int64_t n_isects, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, uint32_t cdim,
                                              uint32_t seg_len);

@@ -245,12 +245,16 @@ def test_c3_matches_oracle(G):
 # t_j over (pixel, Gaussian) pairs with mixed signs; an evaluation whose samples carry a relative error eps is off by up to
 # eps * A, A = sum |t_j|, whatever the size of the sum itself. The reference's band (rtol, atol per tensor: RASTER_BWD_BAND) is
 # therefore widened by eps * A with the sample accuracy each evaluation is built for:
-#   * CPU, fp32 samples and fp32 sums in the reference's form (sigma from the pixel offsets): 1e-6;
-#   * this backend: 4e-5 - the compositing kernels evaluate the exponent as a tile-centre polynomial (csrc/raster3d.hpp,
-#     "e-form": five FMAs per pixel instead of eight instructions), whose rounding is ~2e-5 ABSOLUTE on log2(alpha) for
-#     the tightest footprints, i.e. ~1.4e-5 relative on alpha, coherent over a tile; a documented trade
-#     inside the reference's own CUDA-vs-torch tolerances, and this test is what keeps it from growing.
-C3_SAMPLE_EPS = {"cpu_fp32": 1e-6, "gpu": 4e-5}
+#   * CPU, fp32 samples and fp32 running sums of ~10^3 terms in the reference's form (sigma from the pixel offsets): 1e-5
+#     (measured on the MI355X box's host, round 5: 99.999 % of the elements of v_conics need <= 3.7e-6, the other tensors 0);
+#   * this backend: 2e-5 (measured: 99.999 % of v_conics need <= 5.5e-6, the other tensors 0 - the same accuracy class as
+#     the CPU's fp32 sums). The compositing kernels evaluate the exponent as a tile-centre polynomial (csrc/raster3d.hpp,
+#     "e-form": five FMAs per pixel instead of eight instructions) whose WORST-CASE rounding is ~2e-5 absolute on log2(alpha)
+#     for the tightest footprints, coherent over a tile, and take the moments about the tile centre; this test is what keeps
+#     that trade inside an fp32 evaluation's accuracy. The plain band alone - no eps A term - is missed by
+#     0.21 % of v_conics on the GPU and 0.009 % on the CPU: elements whose terms cancel to a small sum, where rtol |sum| says
+#     nothing about an fp32 sum of terms thousands of times larger.
+C3_SAMPLE_EPS = {"cpu_fp32": 1e-5, "gpu": 2e-5}
 
 
 def test_c3_compositing_gradients_per_element_band(G):
@@ -303,12 +307,15 @@ def test_c3_compositing_gradients_per_element_band(G):
             outside = (err > band + C3_SAMPLE_EPS[who] * A).double().mean().item()
             rec[who] = {"outside_plain_band": (err > band).double().mean().item(), "outside_with_eps": outside,
                         "eps_needed_p9999": need.kthvalue(max(1, int(0.9999 * need.numel()))).values.item(),
+                        "eps_needed_p99999": need.kthvalue(max(1, int(0.99999 * need.numel()))).values.item(),
                         "eps_needed_max": need.max().item(), "max_err": err.max().item()}
             if outside > 1e-5:
                 failures.append(f"c3 {key} ({who}): {outside:.3e} of the elements outside band + {C3_SAMPLE_EPS[who]:g} sum|terms|")
-            # no element may be grossly wrong: within ten times the allowance, every one of them
-            if not bool((err <= 10.0 * (band + C3_SAMPLE_EPS[who] * A)).all()):
-                failures.append(f"c3 {key} ({who}): an element is more than 10 x its allowance out (max err {err.max().item():.3e})")
+            # no element may be grossly wrong: a flipped 1/255 decision moves one term (|t| <= A), a lost tile or a wrong
+            # moment shift moves a fixed share of them - every element stays within the band + 1 % of the sum of its |terms|
+            if not bool((err <= band + 1e-2 * A).all()):
+                failures.append(f"c3 {key} ({who}): an element is off by more than 1 % of the sum of its |terms| "
+                                f"(needs {need.max().item():.3e})")
         report[key] = rec
     print("c3 per-element band:", report)
     assert not failures, "; ".join(failures) + f" | {report}"
