@@ -213,6 +213,28 @@ const int32_t *build_tile_order(const int32_t *isect_offsets, const int32_t *las
 bool raster3d_fwd_w_applies(const Raster3DArgs &a);
 int raster3d_fwd_w_launch(const Raster3DArgs &a, hipStream_t stream);
 
+// ---- longest tiles first: csrc/tile_order.hip builds the order, the backward kernels read it through Raster3DArgs::tile_order ----
+// tile_context() through the order (dense layouts)
+__device__ __forceinline__ bool tile_context_ordered(const Raster3DArgs &a, uint32_t block, TileCtx &t)
+{
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h, n_blocks = tiles_per_image * a.n_images;
+    const uint32_t idx = xcd_remap(block, n_blocks);
+    if (idx >= n_blocks) return false;
+    const uint32_t blk = (uint32_t)a.tile_order[idx];
+    t.image_id = blk / tiles_per_image;
+    t.tile_id  = blk % tiles_per_image;
+    t.tile_x   = t.tile_id % a.tile_w;
+    t.tile_y   = t.tile_id / a.tile_w;
+    t.range_start = a.isect_offsets[blk];
+    t.range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
+    return true;
+}
+
+// Wide colour rows (5 .. 32 channels per launch, 16 x 16 tiles, no absgrad) on the matrix cores: raster3d_bwd_m.hip.
+// GSX_RASTER3D_BWD_WIDE=r keeps the reduction kernel.
+bool raster3d_bwd_m_applies(const Raster3DArgs &a, bool has_abs);
+int raster3d_bwd_m_launch(const Raster3DArgs &a, hipStream_t stream);
+
 // thread -> pixel inside the tile.
 __device__ __forceinline__ void tile_pixel(uint32_t tid, uint32_t tile_size, uint32_t &lx, uint32_t &ly)
 {

@@ -72,20 +72,17 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
     const float py     = (float)(tc.tile_y * a.tile_size + ly) + 0.5f;
     const size_t pix   = inside ? (size_t)prow : 0;
 
-    const int32_t range_start = tc.range_start, range_end = tc.range_end;
-    const int32_t n_batches   = (range_end - range_start + BATCH - 1) / BATCH;
-    if (n_batches <= 0) return;
+    const int32_t range_start = tc.range_start;
+    if (tc.range_end <= range_start) return;
 
     // per-pixel state
     const float T_final     = inside ? 1.0f - a.render_alphas[pix] : 1.0f;
     float T                 = T_final;
     const int32_t bin_final = inside ? a.last_ids[pix] : -1;
-    float v_c[CH], buffer[CH];
+    float v_c[CH];
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-        v_c[k]    = (inside && k < (int)a.nch) ? a.v_render_colors[vrc_index(a, pix, a.ch_off + (uint32_t)k)] : 0.0f;
-        buffer[k] = 0.0f;
-    }
+    for (int k = 0; k < CH; ++k)
+        v_c[k] = (inside && k < (int)a.nch) ? a.v_render_colors[vrc_index(a, pix, a.ch_off + (uint32_t)k)] : 0.0f;
     // alpha-gradient term and background term belong to exactly one channel chunk / all chunks resp.
     const float v_a = (inside && a.first_chunk && a.v_render_alphas) ? a.v_render_alphas[pix] : 0.0f; // null = zeros
     float bg_dot    = 0.0f; // sum_k bg_k * v_c_k (this chunk)
@@ -95,9 +92,28 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
         for (int k = 0; k < CH; ++k)
             if (k < (int)a.nch) bg_dot += bg[k] * v_c[k];
     }
-    const float va_minus_bg      = v_a - bg_dot;
+    // v_alpha = sum_k (c_k T - buffer_k / (1 - alpha)) v_c,k + T_final / (1 - alpha) (v_a - bg . v_c)  (Device.cuh:105-173) with
+    // buffer_k = sum over the Gaussians behind of c_k fac. Only B = sum_k buffer_k v_c,k is ever used, and B += fac (c . v_c):
+    // ONE scalar per pixel instead of CH back-buffers (as variants T / W) - two instead of five instructions per channel
+    // and pair, CH registers less: at 32 channels that is a third of this kernel's vector instructions.
+    const float tail_term        = T_final * (v_a - bg_dot); // what lies behind the whole list
+    float behind                 = 0.0f;
     const int32_t wave_bin_final = wave_max_i32(bin_final);
     const WaveRect rect          = wave_pixel_rect(inside, px, py);
+    // nothing behind the LAST contributor of the whole tile is needed (the forward's early termination cuts the lists of a
+    // dense scene to a fraction): those entries are not even staged (as variants T / W)
+    int32_t range_end = tc.range_end;
+    {
+        int32_t *s_m = reinterpret_cast<int32_t *>(smem_raw); // staging area, not in use yet
+        if (lane == 0) s_m[tid >> 6] = wave_bin_final;
+        __syncthreads();
+        int32_t m = s_m[0];
+        for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) m = max(m, s_m[w]);
+        __syncthreads();
+        range_end = min(range_end, m + 1);
+    }
+    const int32_t n_batches = (range_end - range_start + BATCH - 1) / BATCH;
+    if (n_batches <= 0) return; // uniform: no pixel of the tile has a contributor
 
     // zero the accumulator rows this thread owns
     for (int s = (int)tid; s < BATCH; s += (int)blockDim.x) {
@@ -166,15 +182,14 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
                 const float ra  = __builtin_amdgcn_rcpf(fmaxf(kMinOneMinusAlpha, 1.0f - alpha));
                 T              *= ra;
                 const float fac = alpha * T;
-                float v_alpha   = 0.0f;
+                float cv        = 0.0f;
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
-                    const float c = s_col[t * CH + k];
-                    loc[k]        = fac * v_c[k];
-                    v_alpha      += (c * T - buffer[k] * ra) * v_c[k];
-                    buffer[k]    += c * fac;
+                    loc[k] = fac * v_c[k];
+                    cv     = fmaf(s_col[t * CH + k], v_c[k], cv);
                 }
-                v_alpha += T_final * ra * va_minus_bg;
+                const float v_alpha = fmaf(ra, tail_term - behind, cv * T);
+                behind              = fmaf(fac, cv, behind);
                 const bool unclamped = ov <= kMaxAlpha; // alpha-clamp branch: geometry/opacity grads vanish
                 const float v_sigma  = unclamped ? -ov * v_alpha : 0.0f;
                 const float wdx = v_sigma * dx, wdy = v_sigma * dy;
@@ -261,23 +276,6 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
         // The next iteration's staging writes s_ga/s_gb/s_col/s_id (read above only by the owner
         // thread or before the barrier); its barrier orders the zeroed rows before new ds_adds.
     }
-}
-
-// ---- longest tiles first: csrc/tile_order.hip builds the order, the kernels below read it through Raster3DArgs::tile_order ----
-// tile_context() through the order (dense layouts)
-__device__ __forceinline__ bool tile_context_ordered(const Raster3DArgs &a, uint32_t block, TileCtx &t)
-{
-    const uint32_t tiles_per_image = a.tile_w * a.tile_h, n_blocks = tiles_per_image * a.n_images;
-    const uint32_t idx = xcd_remap(block, n_blocks);
-    if (idx >= n_blocks) return false;
-    const uint32_t blk = (uint32_t)a.tile_order[idx];
-    t.image_id = blk / tiles_per_image;
-    t.tile_id  = blk % tiles_per_image;
-    t.tile_x   = t.tile_id % a.tile_w;
-    t.tile_y   = t.tile_id / a.tile_w;
-    t.range_start = a.isect_offsets[blk];
-    t.range_end   = (blk == n_blocks - 1) ? (int32_t)a.n_isects : a.isect_offsets[blk + 1];
-    return true;
 }
 
 // ---- variant T: per-Gaussian sums by a TRANSPOSED walk instead of cross-lane reductions ---------------------------------
@@ -1182,7 +1180,7 @@ int raster3d_bwd_w_launch_items(const Raster3DArgs &a, hipStream_t stream)
 static void bwd_w_wide_range(uint32_t &lo, uint32_t &hi)
 {
     static const uint64_t v = [] {
-        uint32_t l = 5, h = 8;
+        uint32_t l = 0, h = 0; // off since the matrix-core kernel (raster3d_bwd_m.hip) takes 5 .. 32 channels
         if (const char *e = getenv("GSX_BWD_W_WIDE")) {
             l = (uint32_t)atoi(e);
             const char *c = strchr(e, ',');
@@ -1213,7 +1211,8 @@ static int bwd_dispatch(Raster3DArgs a, hipStream_t stream)
         a.nch              = n;
         a.first_chunk      = first ? 1u : 0u;
         int rc;
-        if (n <= 1) rc = launch_bwd<1, ABS>(a, stream);
+        if (bwd_variant() != 'r' && raster3d_bwd_m_applies(a, ABS)) rc = raster3d_bwd_m_launch(a, stream); // 5 .. 32 channels: raster3d_bwd_m.hip
+        else if (n <= 1) rc = launch_bwd<1, ABS>(a, stream);
         else if (n <= 2) rc = launch_bwd<2, ABS>(a, stream);
         else if (n <= 3) rc = launch_bwd<3, ABS>(a, stream);
         else if (n <= 4) rc = launch_bwd<4, ABS>(a, stream);
@@ -1282,7 +1281,10 @@ extern "C" int gsx_raster3d_bwd_ws(
         a.vrc_strided = 1u; a.vrc_ps = v_colors_pixel_stride; a.vrc_cs = v_colors_channel_stride;
     }
     // the launches that read the order: variant W (also with absgrad, and four channels at a time), variant T
-    if (bwd_variant() == 'w' ? (tile_size == 16 && (cdim <= 4 || bwd_w_wide(a, has_abs != 0))) : (!has_abs && cdim <= 4 && bwd_variant() != 'r')) {
+    a.nch = cdim > 32 ? 32 : cdim; // what the first launch will see (bwd_dispatch sets it per chunk)
+    const bool wide_m = cdim > 4 && bwd_variant() != 'r' && raster3d_bwd_m_applies(a, has_abs != 0);
+    if (wide_m || (bwd_variant() == 'w' ? (tile_size == 16 && (cdim <= 4 || bwd_w_wide(a, has_abs != 0)))
+                                        : (!has_abs && cdim <= 4 && bwd_variant() != 'r'))) {
         int rc       = GSX_OK;
         a.tile_order = a.sp_active_tiles ? nullptr
                                          : build_tile_order(a.isect_offsets, a.last_ids, a.n_images, a.tile_size, a.tile_w, a.tile_h,
