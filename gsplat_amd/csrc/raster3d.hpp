@@ -210,6 +210,10 @@ const int32_t *build_tile_order(const int32_t *isect_offsets, const int32_t *las
 #ifndef GSX_RASTER3D_FWD_DEFAULT
 #define GSX_RASTER3D_FWD_DEFAULT 'q'
 #endif
+// Wide colour rows (5 .. 32 channels per launch, 16 x 16 tiles, no segments) on the matrix cores: raster3d_fwd_m.hip.
+// GSX_RASTER3D_FWD_WIDE=q keeps the four-wave kernel.
+bool raster3d_fwd_m_applies(const Raster3DArgs &a);
+int raster3d_fwd_m_launch(const Raster3DArgs &a, hipStream_t stream);
 bool raster3d_fwd_w_applies(const Raster3DArgs &a);
 int raster3d_fwd_w_launch(const Raster3DArgs &a, hipStream_t stream);
 

@@ -261,6 +261,7 @@ int raster3d_fwd_launch_chunk(const Raster3DArgs &a, hipStream_t stream)
 {
     const uint32_t n = a.nch;
     if (raster3d_fwd_w_applies(a)) return raster3d_fwd_w_launch(a, stream); // one wave per tile (raster3d_fwd_w.hip)
+    if (raster3d_fwd_m_applies(a)) return raster3d_fwd_m_launch(a, stream); // 5 .. 32 channels: the render as a matrix product
     if (n <= 1) return launch_fwd<1>(a, stream);
     if (n <= 2) return launch_fwd<2>(a, stream);
     if (n <= 3) return launch_fwd<3>(a, stream);
