@@ -152,9 +152,11 @@ def run_case_2dgs(G):
     return out
 
 
-def test_raster2d_bwd_one_wave_per_tile_matches_the_default():
-    """GSX_RASTER2D_BWD=w (csrc/raster2d.hip: raster2d_bwd_w_kernel, one wave per tile; measured and not the default) must give
-    the gradients of the reduction kernel: RGB+ED with distortion loss and SH, long lists, a single depth channel."""
+@pytest.mark.parametrize("variant", ["w", "m"])
+def test_raster2d_bwd_variants_match_the_default(variant):
+    """GSX_RASTER2D_BWD=w (csrc/raster2d.hip: raster2d_bwd_w_kernel, one wave per tile) and =m (csrc/raster2d_bwd_m.hip: the
+    per-(tile, surfel) sums as one fp32-MFMA product per four surfels) - both measured and not the default - must give the
+    gradients of the reduction kernel: RGB+ED with distortion loss and SH, long lists, a single depth channel."""
     if not torch.cuda.is_available():
         pytest.skip("needs a ROCm GPU")
     assert os.environ.get("GSX_RASTER2D_BWD", "") == ""
@@ -164,7 +166,7 @@ def test_raster2d_bwd_one_wave_per_tile_matches_the_default():
         path = os.path.join(d, "t.npz")
         code = _SCRIPT_2DGS % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
         r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True,
-                           env=dict(os.environ, GSX_RASTER2D_BWD="w", GSX_RASTER3D_BWD_ORDER="force"), timeout=600)
+                           env=dict(os.environ, GSX_RASTER2D_BWD=variant, GSX_RASTER3D_BWD_ORDER="force"), timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         alt = dict(np.load(path))
     ref = run_case_2dgs(gsplat_amd)
