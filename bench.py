@@ -438,14 +438,20 @@ def main():
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     # HBM bytes per launch from the rocprofv3 PMC passes (tools/gpu_profile.sh -> profiles/pmc_traffic.json); the file
     # names the commit it was measured at, so a stale number is visible as such
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_raw = None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             pmc = json.load(open(tpath))
             # the backward runs as variant W (or T) for <= 4 channels (csrc/raster3d_bwd.hip): counters are filed under the kernel's name
             pmc_dom = pmc.get(dom + "_w") or pmc.get(dom + "_t") or pmc.get(dom) or {}
-            traffic = pmc_dom.get("bytes")
+            # FETCH_SIZE counts a wide coalesced streaming read at half its bytes on gfx950 (MI355X_MICROARCH.md, HBM section:
+            # 128-byte requests tallied at 64 B); other access widths and WRITE_SIZE are uncalibrated. The compositing kernels
+            # gather 8 / 12 / 4-byte pieces of rows through flatten_ids, so neither reading is exact: `traffic` quotes the
+            # CORRECTED figure (fetch x 2 + write: the upper bound), `traffic_raw` the counters as read.
+            traffic = pmc_dom.get("bytes_if_fetch_x2", pmc_dom.get("bytes"))
+            traffic_raw = {"bytes": pmc_dom.get("bytes"), "fetch_bytes": pmc_dom.get("fetch_bytes"),
+                           "write_bytes": pmc_dom.get("write_bytes")}
             meta_pmc = pmc.get("_meta") or {}
             traffic_src = {"file": "profiles/pmc_traffic.json", "measured_at_commit": meta_pmc.get("commit"),
                            "bench_commit": _git_head(), "kernel_sources": raster_source_hash()}
@@ -519,7 +525,10 @@ def main():
 
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_raw": traffic_raw if traffic is not None else None,
+        "traffic_basis": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; quoted = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 "
+                         "correction for wide reads applied to all of the fetch: an upper bound), raw counters beside it",
+        "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": int(dom_bytes), "launch_ms": round(dom_ms, 4),
         "n_isects": M, "rows": V, "pixels_per_launch": P_local,
         # the forward launch and the pair the north star quotes (rasterize_to_pixels forward + backward), same recipe
@@ -687,6 +696,24 @@ def main():
             }
         except Exception as e:
             result["c2_garden"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+        # ---- the reference's published WIDE-CHANNEL profile row (profile.rst: "32 ch, batch 1", scene_grid 1): 32 colour
+        # channels through the matrix-core compositing kernels (csrc/raster3d_{fwd,bwd}_m.hip), same harness as c2
+        try:
+            g3 = _brp.run(1, 32, 1, False, 10, device, stages=True, quiet=True)
+            f_ms, b_ms = g3["stages"]["fwd_ms"].get("raster3d_fwd"), g3["stages"]["bwd_ms"].get("raster3d_bwd")
+            M3, P3, V3 = g3["n_isects"], 1920 * 1080, g3["n_gaussians"]  # rows: every Gaussian of the one image (upper bound of the visible ones)
+            by_b = (28 + 4 * 32) * M3 + (4 * 32 + 12) * P3 + 2 * (4 * 32 + 24) * V3  # SURVEY.md 8(d) backward bytes at D = 32
+            result["garden_32ch"] = {
+                "workload": "garden x 1 = %d Gaussians, 1x1920x1080, 32 colour channels, fwd and bwd timed apart (the reference's "
+                            "profiling/main.py recipe, its published '32 ch' row)" % g3["n_gaussians"],
+                "fps_fwd": g3["fps_fwd"], "fps_bwd": g3["fps_bwd"], "n_isects": M3,
+                "raster_launch_ms": {"raster3d_fwd": f_ms, "raster3d_bwd": b_ms},
+                "bwd_hbm": {"algorithmic_bytes_per_launch": int(by_b), "frac": round(by_b / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} if b_ms else None,
+                "published_titan_rtx_fps_fwd_bwd": g3["published_titan_rtx_fps_fwd_bwd"],
+            }
+        except Exception as e:
+            result["garden_32ch"] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
     # ---- the training step around the rasterizer: tools/train_step_bench.py ----------------
     if extras:
