@@ -539,6 +539,14 @@ def test_rasterize_one_wave_backward_absgrad_and_wide(G, O, D, absgrad):
     _raster_case(G, O, N=5000, C=1, W=176, H=120, tile_size=16, D=D, seed=70 + D, bg=(D % 2 == 0), absgrad=absgrad)
 
 
+@pytest.mark.parametrize("D,packed,masks", [(17, False, True), (20, True, False), (31, False, False), (70, False, True), (6, True, True)])
+def test_rasterize_wide_channels_on_the_matrix_cores(G, O, D, packed, masks):
+    """csrc/raster3d_{fwd,bwd}_m.hip (fp32 MFMA): channel counts that are not multiples of 4 or 16, one and two column blocks,
+    more than 32 channels in chunks (70 = 32 + 32 + 6: the last chunk runs the four-wave forward), tile masks, packed rows,
+    an image that is not a multiple of the tile, two images."""
+    _raster_case(G, O, N=5000, C=2, W=168, H=120, tile_size=16, D=D, seed=90 + D, bg=(D != 31), masks=masks, packed=packed)
+
+
 @pytest.mark.parametrize("tile_size", [16, 8, 4])
 def test_rasterize_tile_sizes(G, O, tile_size):
     _raster_case(G, O, N=3000, C=1, W=150, H=100, tile_size=tile_size, D=3, seed=20 + tile_size, bg=True)

@@ -198,9 +198,11 @@ def _sparse_vs_dense(G, O, N, C, W, H, ts, D, seed, packed=False, bg=False, mask
         assert_grad_close(cpu(ls_s[0].absgrad), cpu(ls_d[0].absgrad), rel=2e-4, max_bad_ratio=1e-5, name="absgrad")
 
 
-@pytest.mark.parametrize("D", [3, 1, 40])
+@pytest.mark.parametrize("D", [3, 1, 40, 20, 9])
 def test_sparse_raster_channels(G, O, D):
-    _sparse_vs_dense(G, O, N=2500, C=2, W=150, H=100, ts=16, D=D, seed=21, bg=(D == 3))
+    """D = 40 / 20: the matrix-core forward (from 17 channels per launch: bit-equal to the dense render because its groups are
+    fixed list positions) and backward (5 .. 32 channels) on a sparse pixel set; D = 9: the four-wave forward with that backward."""
+    _sparse_vs_dense(G, O, N=2500, C=2, W=150, H=100, ts=16, D=D, seed=21, bg=(D in (3, 20)))
 
 
 @pytest.mark.parametrize("ts", [8, 4])

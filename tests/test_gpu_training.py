@@ -60,7 +60,11 @@ def test_selective_adam_optimizer(G, O):
     torch.testing.assert_close(param.detach().cpu(), ref_p, rtol=1e-5, atol=1e-6)
 
 
-def test_relocation_matches_oracle(G, O):
+def test_relocation_matches_oracle_restatement_unpinned_to_the_reference(G, O):
+    """`compute_relocation` against the oracle's restatement of gsplat/relocation.py:25 + Relocation.cu (the published formula
+    of "3D Gaussian Splatting as Markov Chain Monte Carlo", eq. 9). PARITY UNPINNED TO THE REFERENCE: its implementation is a CUDA
+    op with no Python restatement and no golden vector in its tests (tests/test_strategy.py only checks shapes), so the oracle
+    cannot be replayed against reference outputs here - this test pins the kernel to the formula, not to the reference's bits."""
     st = G.MCMCStrategy().initialize_state()
     binoms = st["binoms"]
     g = torch.Generator().manual_seed(2)
