@@ -1760,12 +1760,12 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
                              eps2d, near_plane, far_plane, radius_clip, calc_compensations, camera_model, global_z_order,
                              ut_params, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, ftheta_coeffs,
                              lidar_coeffs, external_distortion_params):
-    """gsplat::projection_ut_3dgs_fused (kernel ``ProjectionUT3DGSFused.cu``): perfect / OpenCV pinhole and orthographic
-    cameras, global shutter. What is not built yet is refused, never approximated."""
+    """gsplat::projection_ut_3dgs_fused (kernel ``ProjectionUT3DGSFused.cu``): perfect / OpenCV pinhole, orthographic, OpenCV
+    fisheye and f-theta cameras, global shutter. What is not built yet is refused, never approximated."""
     if viewmats1 is not None or rs_type != _ROLLING_SHUTTER_GLOBAL:
         raise NotImplementedError("gsplat_amd: rolling-shutter UT projection is not built yet")
-    if camera_model not in (0, 1, 2):
-        raise NotImplementedError(f"gsplat_amd: UT projection is built for pinhole, ortho and fisheye cameras, not "
+    if camera_model not in (0, 1, 2, 3):
+        raise NotImplementedError(f"gsplat_amd: UT projection is built for pinhole, ortho, fisheye and f-theta cameras, not "
                                   f"'{_CAMERA_MODEL_NAMES.get(camera_model, camera_model)}'")
     if lidar_coeffs is not None or external_distortion_params is not None:
         raise NotImplementedError("gsplat_amd: lidar / external-distortion UT projection is not built yet")
@@ -1778,6 +1778,21 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
     if quats.shape != batch + (N, 4) or scales.shape != batch + (N, 3) or viewmats0.shape != batch + (C, 4, 4) \
             or Ks.shape != batch + (C, 3, 3) or (opacities is not None and opacities.shape != batch + (N,)):
         raise ValueError("projection_ut_3dgs_fused: inconsistent input shapes")
+    ftheta_rec = None
+    if camera_model == 3:  # f-theta: one parameter record per call, no OpenCV coefficients
+        if radial_coeffs is not None or tangential_coeffs is not None or thin_prism_coeffs is not None:
+            raise ValueError("the f-theta camera model takes ftheta_coeffs, not radial / tangential / thin-prism coefficients")
+        if ftheta_coeffs is None:
+            raise ValueError("camera_model='ftheta' needs ftheta_coeffs (FThetaCameraDistortionParameters)")
+        import ctypes
+
+        p2a, a2p = list(ftheta_coeffs.pixeldist_to_angle_poly), list(ftheta_coeffs.angle_to_pixeldist_poly)
+        cde = list(ftheta_coeffs.linear_cde)
+        if len(p2a) != 6 or len(a2p) != 6 or len(cde) != 3:
+            raise ValueError("ftheta_coeffs: the polynomials have 6 terms, linear_cde 3")
+        vals = [1.0 if int(ftheta_coeffs.reference_poly) != 0 else 0.0] + [float(v) for v in p2a] + [float(v) for v in a2p] \
+            + [float(ftheta_coeffs.max_angle)] + [float(v) for v in cde]
+        ftheta_rec = (ctypes.c_float * 17)(*vals)
     max_angle = None
     if camera_model == 2:  # fisheye: k1..k4 only, plus the per-camera angle limit
         if tangential_coeffs is not None or thin_prism_coeffs is not None:
@@ -1809,6 +1824,14 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
     depths = torch.empty(batch + (C, N), device=dev, dtype=dt)
     conics = torch.empty(batch + (C, N, 3), device=dev, dtype=dt)
     comps = torch.empty(batch + (C, N), device=dev, dtype=dt) if calc_compensations else None
+    if ftheta_rec is not None:
+        import ctypes
+
+        call("gsx_project_ut_ftheta_fwd", ptr(means.contiguous()), ptr(quats.contiguous()), ptr(scales.contiguous()),
+             ptr(_c(opacities)), ptr(viewmats0.contiguous()), ptr(Ks.contiguous()), ctypes.addressof(ftheta_rec), B, C, N,
+             int(image_width), int(image_height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
+             alpha, beta, kappa, margin, int(all_valid), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(comps))
+        return radii, means2d, depths, conics, comps
     call("gsx_project_ut_fwd", ptr(means.contiguous()), ptr(quats.contiguous()), ptr(scales.contiguous()),
          ptr(_c(opacities)), ptr(viewmats0.contiguous()), ptr(Ks.contiguous()), ptr(_c(radial_coeffs)),
          ptr(_c(tangential_coeffs)), ptr(_c(thin_prism_coeffs)), ptr(max_angle), B, C, N, int(image_width),

@@ -13,9 +13,11 @@
 //   4. blur + compensation, determinant / diagonal checks, conic = inverse (of cov + 1e-6 I, like the reference),
 //      opacity-aware extent, eigenvalue-bounded radii, radius clip, image-bounds cull. Invalid rows are zero.
 // Built so far: camera_model 0 (pinhole, with optional radial[6] / tangential[2] / thin-prism[4] coefficients),
-// 1 (orthographic) and 2 (OpenCV fisheye, _torch_cameras.py:1335-1697: k1..k4 in radial[0..3]; the largest angle the
-// model projects is a per-camera quantity computed by the caller), global shutter. F-theta, lidar, rolling shutter and
-// the windshield model are rejected.
+// 1 (orthographic), 2 (OpenCV fisheye, _torch_cameras.py:1335-1697: k1..k4 in radial[0..3]; the largest angle the
+// model projects is a per-camera quantity computed by the caller) and 3 (f-theta, _torch_cameras.py FThetaCamera:
+// pixel distance = polynomial of the ray angle, either polynomial direction as the calibrated one, linear (c, d, e) sensor map,
+// principal point shifted by half a pixel; gsx_project_ut_ftheta_fwd), global shutter. Lidar, rolling shutter and the
+// windshield model are rejected.
 #include "projmath.hpp"
 #include "../../include/gsplat_amd.h"
 
@@ -30,6 +32,10 @@ struct ProjUtArgs {
     float eps2d, near_plane, far_plane, radius_clip;
     int camera_model, require_all_valid, distorted;
     float w_m0, w_c0, w_i, spread, margin;
+    // f-theta (camera_model 3; Cameras.h FThetaCameraDistortionParameters): one record per call
+    int ft_reference_poly;        // 1: angle -> pixel distance is the calibrated polynomial; 0: its inverse is (Newton on it)
+    float ft_p2a[6], ft_a2p[6];   // pixeldist_to_angle_poly, angle_to_pixeldist_poly (lowest degree first)
+    float ft_max_angle, ft_c, ft_d, ft_e;
     int32_t *radii;       // [B,C,N,2]
     float *means2d;       // [B,C,N,2]
     float *depths;        // [B,C,N]
@@ -65,6 +71,34 @@ __device__ __forceinline__ bool ut_project_point(const ProjUtArgs &a, const Cam 
         const float mx = (float)a.width * a.margin, my = (float)a.height * a.margin;
         const bool inb = (px >= -mx) && (px < (float)a.width + mx) && (py >= -my) && (py < (float)a.height + my);
         return front && (delta > 0.0f) && (th_full < d.max_angle) && inb;
+    }
+    if (a.camera_model == 3) { // f-theta: pixel distance from the principal point = polynomial of the ray angle
+        const float ax = fabsf(p[0]), ay = fabsf(p[1]);
+        const float big = fmaxf(ax, ay), small = fminf(ax, ay);
+        const float ratio = big > 0.0f ? small / big : 0.0f;
+        float rxy = big > 0.0f ? big * sqrtf(1.0f + ratio * ratio) : 0.0f; // overflow-safe hypot, like the reference
+        if (!(rxy > 0.0f)) rxy = 1.1920929e-07f;
+        const float th_full = atan2f(rxy, p[2]);
+        const float th = fminf(th_full, a.ft_max_angle);
+        auto poly6 = [](const float *k, float x) { return k[0] + x * (k[1] + x * (k[2] + x * (k[3] + x * (k[4] + x * k[5])))); };
+        float dist = poly6(a.ft_a2p, th);
+        if (a.ft_reference_poly == 0) { // the angle-of-distance polynomial is the calibrated one: invert it (three Newton steps)
+            bool done = false;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const float slope = a.ft_p2a[1] + dist * (2.0f * a.ft_p2a[2] + dist * (3.0f * a.ft_p2a[3]
+                                    + dist * (4.0f * a.ft_p2a[4] + dist * (5.0f * a.ft_p2a[5]))));
+                const float step = (poly6(a.ft_p2a, dist) - th) / slope;
+                dist = done ? dist : dist - step;
+                done = done || (fabsf(step) < 1e-6f);
+            }
+        }
+        const float ix = dist * p[0] / rxy, iy = dist * p[1] / rxy;
+        px = a.ft_c * ix + a.ft_d * iy + (c.cx + 0.5f);
+        py = a.ft_e * ix + iy + (c.cy + 0.5f);
+        const float mx = (float)a.width * a.margin, my = (float)a.height * a.margin;
+        const bool inb = (px >= -mx) && (px < (float)a.width + mx) && (py >= -my) && (py < (float)a.height + my);
+        return (th_full < a.ft_max_angle) && inb; // no "in front" test for this model
     }
     if (a.camera_model == 1) { // orthographic
         u = p[0];
@@ -228,26 +262,28 @@ __global__ void __launch_bounds__(256) project_ut_kernel(const ProjUtArgs a)
 
 } // namespace gsx
 
-extern "C" int gsx_project_ut_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
-                                  const float *viewmats, const float *Ks, const float *radial, const float *tangential,
-                                  const float *thin_prism, const float *fisheye_max_angle, uint32_t B, uint32_t C, uint32_t N, uint32_t width,
-                                  uint32_t height, float eps2d, float near_plane, float far_plane, float radius_clip,
-                                  int camera_model, float ut_alpha, float ut_beta, float ut_kappa,
-                                  float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii,
-                                  float *means2d, float *depths, float *conics, float *compensations, void *stream)
+static int project_ut_launch(const float *means, const float *quats, const float *scales, const float *opacities,
+                             const float *viewmats, const float *Ks, const float *radial, const float *tangential,
+                             const float *thin_prism, const float *fisheye_max_angle, const float *ftheta, uint32_t B, uint32_t C,
+                             uint32_t N, uint32_t width, uint32_t height, float eps2d, float near_plane, float far_plane,
+                             float radius_clip, int camera_model, float ut_alpha, float ut_beta, float ut_kappa,
+                             float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii, float *means2d,
+                             float *depths, float *conics, float *compensations, void *stream)
 {
     using namespace gsx;
     const int64_t rows = (int64_t)B * C * N;
     if (rows == 0) return GSX_OK;
     GSX_REQUIRE(means && quats && scales && viewmats && Ks, "gsx_project_ut_fwd: null input");
     GSX_REQUIRE(radii && means2d && depths && conics, "gsx_project_ut_fwd: null output");
-    GSX_REQUIRE(camera_model >= 0 && camera_model <= 2,
-                "gsx_project_ut_fwd: camera model %d is not built (pinhole = 0, orthographic = 1 and fisheye = 2 are)",
+    GSX_REQUIRE(camera_model >= 0 && camera_model <= 3,
+                "gsx_project_ut_fwd: camera model %d is not built (pinhole = 0, orthographic = 1, fisheye = 2 and f-theta = 3 are)",
                 camera_model);
     GSX_REQUIRE(camera_model != 1 || (!radial && !tangential && !thin_prism),
                 "gsx_project_ut_fwd: the orthographic model takes no distortion coefficients");
     GSX_REQUIRE(camera_model != 2 || (fisheye_max_angle && !tangential && !thin_prism),
                 "gsx_project_ut_fwd: the fisheye model needs fisheye_max_angle and takes radial coefficients only");
+    GSX_REQUIRE(camera_model != 3 || (ftheta && !radial && !tangential && !thin_prism),
+                "gsx_project_ut_ftheta_fwd: the f-theta model needs its parameter record and takes no other coefficients");
     const double lam = (double)ut_alpha * ut_alpha * (3.0 + ut_kappa) - 3.0;
     GSX_REQUIRE(3.0 + lam > 0.0, "gsx_project_ut_fwd: alpha^2 (3 + kappa) must be positive");
     ProjUtArgs a{};
@@ -257,6 +293,11 @@ extern "C" int gsx_project_ut_fwd(const float *means, const float *quats, const 
     a.eps2d = eps2d; a.near_plane = near_plane; a.far_plane = far_plane; a.radius_clip = radius_clip;
     a.camera_model = camera_model; a.require_all_valid = require_all_sigma_points_valid;
     a.distorted = (radial || tangential || thin_prism) ? 1 : 0;
+    if (camera_model == 3) {
+        a.ft_reference_poly = ftheta[0] != 0.0f ? 1 : 0;
+        for (int i = 0; i < 6; ++i) { a.ft_p2a[i] = ftheta[1 + i]; a.ft_a2p[i] = ftheta[7 + i]; }
+        a.ft_max_angle = ftheta[13]; a.ft_c = ftheta[14]; a.ft_d = ftheta[15]; a.ft_e = ftheta[16];
+    }
     a.w_m0 = (float)(lam / (3.0 + lam));
     a.w_c0 = (float)(lam / (3.0 + lam) + (1.0 - (double)ut_alpha * ut_alpha + ut_beta));
     a.w_i  = (float)(1.0 / (2.0 * (3.0 + lam)));
@@ -265,4 +306,35 @@ extern "C" int gsx_project_ut_fwd(const float *means, const float *quats, const 
     a.radii = radii; a.means2d = means2d; a.depths = depths; a.conics = conics; a.compensations = compensations;
     project_ut_kernel<<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
     return check_launch("project_ut_fwd");
+}
+
+extern "C" int gsx_project_ut_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                                  const float *viewmats, const float *Ks, const float *radial, const float *tangential,
+                                  const float *thin_prism, const float *fisheye_max_angle, uint32_t B, uint32_t C, uint32_t N, uint32_t width,
+                                  uint32_t height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                                  int camera_model, float ut_alpha, float ut_beta, float ut_kappa,
+                                  float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii,
+                                  float *means2d, float *depths, float *conics, float *compensations, void *stream)
+{
+    GSX_REQUIRE(camera_model != 3, "gsx_project_ut_fwd: the f-theta model takes its parameters through gsx_project_ut_ftheta_fwd");
+    return project_ut_launch(means, quats, scales, opacities, viewmats, Ks, radial, tangential, thin_prism, fisheye_max_angle, nullptr,
+                             B, C, N, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, ut_alpha, ut_beta,
+                             ut_kappa, in_image_margin_factor, require_all_sigma_points_valid, radii, means2d, depths, conics,
+                             compensations, stream);
+}
+
+// f-theta cameras: `ftheta` is a HOST array of 17 floats - reference_poly (0 / 1), pixeldist_to_angle_poly[6],
+// angle_to_pixeldist_poly[6], max_angle, linear_cde[3] (the fields of FThetaCameraDistortionParameters, Cameras.h:103-117)
+extern "C" int gsx_project_ut_ftheta_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                                         const float *viewmats, const float *Ks, const float *ftheta, uint32_t B, uint32_t C,
+                                         uint32_t N, uint32_t width, uint32_t height, float eps2d, float near_plane, float far_plane,
+                                         float radius_clip, float ut_alpha, float ut_beta, float ut_kappa,
+                                         float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii,
+                                         float *means2d, float *depths, float *conics, float *compensations, void *stream)
+{
+    GSX_REQUIRE(ftheta != nullptr, "gsx_project_ut_ftheta_fwd: null parameter record");
+    return project_ut_launch(means, quats, scales, opacities, viewmats, Ks, nullptr, nullptr, nullptr, nullptr, ftheta, B, C, N,
+                             width, height, eps2d, near_plane, far_plane, radius_clip, 3, ut_alpha, ut_beta, ut_kappa,
+                             in_image_margin_factor, require_all_sigma_points_valid, radii, means2d, depths, conics, compensations,
+                             stream);
 }

@@ -9,7 +9,7 @@ of the reference (``gsplat/rendering.py:234-690``) and the stage order of its C+
     -> tile intersection (exact ellipse test) + sort + offsets  ->  alpha compositing
     -> expected-depth normalisation.
 
-3DGUT: ``with_ut`` (Unscented-Transform projection through pinhole / distorted-pinhole / ortho / fisheye cameras,
+3DGUT: ``with_ut`` (Unscented-Transform projection through pinhole / distorted-pinhole / ortho / fisheye / f-theta cameras,
 global shutter) and ``with_eval3d`` (from-world compositing) are built; what is NOT built is refused up front, before
 any kernel launches, never approximated: f-theta / lidar cameras, rolling shutter, external (windshield) distortion,
 ray generation for distorted cameras (pass ``rays``), the hit-distance render modes and ``return_normals``.
@@ -130,19 +130,23 @@ def rasterization(
                                               or tangential_coeffs is not None or thin_prism_coeffs is not None),
         "hit-distance render modes ('d', 'Ed', 'RGB-d', 'RGB-Ed')": render_mode in _HIT_MODES,
         "return_normals": bool(return_normals),
-        "ftheta_coeffs": ftheta_coeffs is not None,
-        "camera_model='ftheta'": camera_model == "ftheta", "camera_model='lidar'": camera_model == "lidar",
+        "camera_model='ftheta' / ftheta_coeffs outside the UT projection (with_ut=True without with_eval3d, or with rays given)":
+            (camera_model == "ftheta" or ftheta_coeffs is not None) and not (with_ut and (not with_eval3d or rays is not None)),
+        "camera_model='lidar'": camera_model == "lidar",
         "rolling shutter": viewmats_rs is not None, "external_distortion_coeffs": external_distortion_coeffs is not None,
     }
     bad = [k for k, v in unsupported.items() if v]
     if bad:
         raise RuntimeError(
             "gsplat_amd builds the classic 3DGS path and, of 3DGUT, the unscented projection and the from-world rasterizer for "
-            "global-shutter pinhole / distorted-pinhole / orthographic / fisheye cameras (build_config()['3dgut'] is True); "
+            "global-shutter pinhole / distorted-pinhole / orthographic / fisheye (and, for the projection, f-theta) cameras "
+            "(build_config()['3dgut'] is True); "
             f"these sub-features are not built - not supported, refused rather than approximated: {', '.join(bad)}"
         )
-    if camera_model not in ("pinhole", "ortho", "fisheye"):
-        raise ValueError(f"camera_model '{camera_model}' is not supported (pinhole / ortho / fisheye)")
+    if camera_model not in ("pinhole", "ortho", "fisheye", "ftheta"):
+        raise ValueError(f"camera_model '{camera_model}' is not supported (pinhole / ortho / fisheye / ftheta)")
+    if (camera_model == "ftheta") != (ftheta_coeffs is not None):
+        raise ValueError("ftheta_coeffs must be given if and only if camera_model is 'ftheta'")
     # `segmented` (gsplat/rendering.py:262; IntersectTile.cu:1125-1176) only selects how the reference sorts - per image instead
     # of one global radix sort. Both give the same (image, tile, depth) order with ties in emission order, which is what the
     # per-tile sort of this backend produces, so the flag is accepted and changes nothing.
@@ -184,7 +188,7 @@ def rasterization(
             means, quats, scales, opacities, viewmats_proj, Ks_proj, width, height, eps2d=eps2d, near_plane=near_plane,
             far_plane=far_plane, radius_clip=radius_clip, calc_compensations=calc_comp, camera_model=camera_model,
             ut_params=ut_params, radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs,
-            thin_prism_coeffs=thin_prism_coeffs, global_z_order=global_z_order)
+            thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=ftheta_coeffs, global_z_order=global_z_order)
     else:
         proj = fully_fused_projection(
             means, covars, quats, scales, viewmats_proj, Ks_proj, width, height, eps2d=eps2d, near_plane=near_plane,

@@ -214,7 +214,7 @@ int gsx_sh_bwd(int degrees_to_use, const float *means, const float *viewmats, co
  * camera model; mean2d / cov2d are the UT-weighted moments of their pixels (sums stop at the first invalid point when
  * require_all_sigma_points_valid). Then blur (+eps2d I) and compensation, conic = inverse, opacity-aware extent (opacities
  * NULL = none), eigenvalue-bounded radii, radius clip, image cull. Rows that fail a check are written as zeros.
- * compensations may be NULL. Other camera models (f-theta, lidar) and rolling shutter are not built: -1.
+ * compensations may be NULL. f-theta cameras: gsx_project_ut_ftheta_fwd below. Lidar and rolling shutter are not built: -1.
  * ------------------------------------------------------------------------------------------- */
 int gsx_project_ut_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
                        const float *viewmats, const float *Ks, const float *radial, const float *tangential,
@@ -224,6 +224,19 @@ int gsx_project_ut_fwd(const float *means, const float *quats, const float *scal
                        float ut_alpha, float ut_beta, float ut_kappa, float in_image_margin_factor,
                        int require_all_sigma_points_valid, int32_t *radii, float *means2d, float *depths,
                        float *conics, float *compensations, void *stream);
+/* The same op for camera_model 3, f-theta (gsplat/cuda/_torch_cameras.py FThetaCamera; parameter record
+ * FThetaCameraDistortionParameters, Cameras.h:103-117 / ext.cpp:165-226): the pixel distance from the principal point is a
+ * polynomial of the ray angle - `angle_to_pixeldist_poly` when reference_poly = 1, three Newton steps on
+ * `pixeldist_to_angle_poly` from that start when reference_poly = 0 - the angle is clamped at max_angle (rays beyond it are
+ * invalid; there is no in-front test), pixel = (c, d; e, 1) offset + principal point + 0.5. `ftheta` is a HOST array of 17
+ * floats: reference_poly (0 / 1), pixeldist_to_angle_poly[6], angle_to_pixeldist_poly[6] (lowest degree first), max_angle,
+ * linear_cde[3]. One record per call (as in the reference); everything else as gsx_project_ut_fwd. */
+int gsx_project_ut_ftheta_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                              const float *viewmats, const float *Ks, const float *ftheta, uint32_t B, uint32_t C, uint32_t N,
+                              uint32_t width, uint32_t height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                              float ut_alpha, float ut_beta, float ut_kappa, float in_image_margin_factor,
+                              int require_all_sigma_points_valid, int32_t *radii, float *means2d, float *depths,
+                              float *conics, float *compensations, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * From-world ("eval3d") compositing of 3DGUT, FORWARD: the compositing half of gsplat::rasterize_to_pixels_from_world_3dgs

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from _util import make_scene
-from test_oracle_ut import CASES, check_against_reference, ut_case
+from test_oracle_ut import CASES, FTHETA, check_against_reference, ut_case
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,9 +28,12 @@ def gold():
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "ut_ref.npz")))
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + FTHETA)
 def test_ut_projection_matches_reference_outputs(G, gold, name):
     kw, ut, dist, use_op, (N, C, W, H) = ut_case(name)
+    if "ftheta" in kw:  # the f-theta parameter record, as the reference's Python builds it (gsplat/rendering.py:576-580)
+        kw = dict(kw, ftheta_coeffs=torch.classes.gsplat.FThetaCameraDistortionParameters(**kw["ftheta"]))
+        del kw["ftheta"]
     sc = {k: torch.from_numpy(gold[f"{name}.{k}"]).to(DEV) for k in ("means", "quats", "scales", "opacities", "viewmats", "Ks")}
     cam = {k + "_coeffs": (None if v is None else torch.tensor(v, device=DEV).repeat(C, 1)) for k, v in dist.items()}
     got = G.fully_fused_projection_with_ut(
@@ -90,6 +93,21 @@ def test_rasterization_with_ut(G):
     assert float(colors.grad.abs().sum()) > 0 and float(opac.grad.abs().sum()) > 0
     with pytest.raises(RuntimeError, match="Packed mode is not supported with UT"):
         G.rasterization(*args, packed=True, with_ut=True)
+    # f-theta: an (almost) equidistant lens r = f theta with the pinhole's focal length renders the image centre like the
+    # pinhole does (theta ~ tan theta there); the record is required, and the model needs the UT projection
+    fx = float(a["Ks"][0, 0, 0])
+    ft = torch.classes.gsplat.FThetaCameraDistortionParameters(
+        reference_poly=1, pixeldist_to_angle_poly=[0.0, 1.0 / fx, 0.0, 0.0, 0.0, 0.0],
+        angle_to_pixeldist_poly=[0.0, fx, 0.0, 0.0, 0.0, 0.0], max_angle=1.3, linear_cde=[1.0, 0.0, 0.0])
+    t1, ta1, _ = G.rasterization(*args, packed=False, camera_model="ftheta", with_ut=True, ftheta_coeffs=ft)
+    assert torch.isfinite(t1).all() and float(ta1.mean()) > 0.05
+    cy, cx2 = H // 2, W // 2
+    centre = (slice(None), slice(cy - 8, cy + 8), slice(cx2 - 8, cx2 + 8))
+    assert float((t1[centre] - rc1[centre]).abs().mean()) < 3e-2
+    with pytest.raises(ValueError, match="ftheta_coeffs must be given"):
+        G.rasterization(*args, packed=False, camera_model="ftheta", with_ut=True)
+    with pytest.raises(RuntimeError, match="only supported via UT"):
+        G.rasterization(*args, packed=False, camera_model="ftheta", ftheta_coeffs=ft)
     # fisheye: UT render vs the EWA fisheye render, and with distortion coefficients
     f0, fa0, _ = G.rasterization(*args, packed=False, camera_model="fisheye")
     f1, fa1, _ = G.rasterization(*args, packed=False, camera_model="fisheye", with_ut=True)

@@ -10,7 +10,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = ["pinhole", "pinhole_all_valid", "pinhole_comp_clip", "pinhole_no_opacity", "opencv_full", "opencv_radial4",
          "opencv_strong", "ortho", "fisheye_plain", "fisheye_k", "fisheye_k4", "fisheye_tight"]
-ORACLE_ONLY = ["ftheta_forward", "ftheta_inverse"]  # camera models the product kernel does not cover yet
+FTHETA = ["ftheta_forward", "ftheta_inverse"]  # f-theta cameras: parameters travel as a record (ftheta=dict(...) in the case table)
 
 
 @pytest.fixture(scope="module")
@@ -48,7 +48,7 @@ def check_against_reference(got, gold, name, radii_atol=1, means_atol=2e-2, coni
         assert got[4] is None
 
 
-@pytest.mark.parametrize("name", CASES + ORACLE_ONLY)
+@pytest.mark.parametrize("name", CASES + FTHETA)
 def test_ut_oracle_matches_reference(gold, name):
     from oracle import ut as O
 
