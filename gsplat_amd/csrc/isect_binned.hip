@@ -9,15 +9,15 @@
 // The screen is cut into BINS of bw x bh tiles (bw * bh <= 16: a bin's tiles are the bits of a 16-bit mask).
 //
 //   before the host learns n_isects
-//   A  bin_rect      per row: the walk's tile rectangle (walk_prepare) -> rectangle of bins; LDS histogram of bins per chunk
-//                    of rows -> table[chunk][bin]
-//   B  bin_colscan   running sum over an image's chunks per bin (in place) + bin totals, entries per image, largest bin
-//   D  bin_scatter   every workgroup scans its image's bin totals itself (-> LDS cursors; the image's first workgroup also
-//                    stores them as bin_start) and checks the capacity: no one-workgroup planning launch in between. Then
-//                    per row again (its data is in registers: no gather): for every overlapped bin the walk CLIPPED to the
-//                    bin (walk_clipped: only the slabs inside it) -> 16-bit mask of the bin's tiles the Gaussian touches;
-//                    entry = (depth, row) + mask written at an LDS cursor (bin_start + chunk prefix); tiles_per_gauss.
-//                    Rows over several bins are shared out over the workgroup as (row, bin) pairs through an LDS queue.
+//   A  bin_rect      per row: the WALK, once (round 5): a row inside one block of 2 x 4 bins (8 x 8 tiles) leaves a 16-byte
+//                    record - the block's 64 tiles as one bit each, the block's origin, the bins in use, the depth bits; a row
+//                    of many slabs or over several blocks goes through an LDS queue of (row, block) units that the workgroup
+//                    drains together, the units of a row over several blocks become unit records in the chunk's region. LDS
+//                    histogram of the bins in use per chunk of rows -> table[chunk][bin]; tiles_per_gauss.
+//   B  bin_colscan   running sum over an image's chunks per bin (in place) + bin totals; the workgroup that finishes last
+//                    scans the totals into bin_start and decides whether the call goes back (capacity, crowded bins)
+//   D  bin_scatter   deals the records out: entry = (depth, row) + the bin's 16-bit tile mask (a few shifts of the record's
+//                    word) at an LDS cursor (bin_start + chunk prefix). No floating point. Consecutive chunks run on one XCD.
 //   E  bin_tiles     one workgroup per bin: per-tile counts from the masks (wave ballots) -> tile_count
 //   F  tile_plan     one workgroup: scan of the tile counts -> isect_offsets, n_isects (pinned host word)
 //   after the host allocated the exact-length outputs
@@ -47,10 +47,11 @@ constexpr int kBnThreads      = 256;   // kernel E
 constexpr int kBnMaxBins      = 16384; // bins in total (images x bins per image)
 constexpr uint32_t kBnMaxTiles = 36864;
 
-struct BinHeader { // device memory; zeroed by the first workgroup of kernel A
-    int32_t max_bin;   // largest bin (atomicMax by kernel B)
+struct BinHeader { // device memory; the first four words are zeroed by the first workgroup of kernel A
+    int32_t overflow;  // kernel B's verdict: the call goes back to the Gaussian-major path
     int32_t big_count; // tiles handed to the work-list sort (kernel G)
-    int32_t pad[6];
+    int32_t b_done;    // workgroups of kernel B that have finished (the last one plans)
+    int32_t pad[5];
 };
 
 struct BinGeom {
@@ -58,6 +59,7 @@ struct BinGeom {
     uint32_t n_images, cpi, rpc, n_chunks;
     uint32_t tile_size, tile_w, tile_h, n_tiles;
     uint32_t bw, bh, bins_x, bins_y, n_bins, n_bins_total, tile_bits;
+    uint32_t kx, ky; // a row record's BLOCK: kx x ky bins = (kx bw) x (ky bh) <= 64 tiles, one bit each
     int32_t skew_cap; // > 0: a bin with more entries than this sends the call back to the Gaussian-major path (bn_overflow)
     int32_t skew_ratio; // > 0: ... and so does a largest bin of more than this many times the mean bin
 };
@@ -66,8 +68,11 @@ struct BinBuffers {
     BinHeader *hdr;
     int32_t *table;      // [n_chunks][n_bins]
     int32_t *bin_count;  // [n_bins_total]
-    int32_t *img_total;  // [n_images] entries per image (atomicAdd by kernel B)
+    int32_t *unit_count; // [n_chunks] unit records of a chunk (may exceed kUnitCap: the call is sent back then)
+    uint4 *unit_rec;     // [n_chunks][kUnitCap] one block of a row over several blocks (layout of row_rec)
+    uint32_t *unit_row;  // [n_chunks][kUnitCap] its row
     int32_t *bin_start;  // [n_bins_total + 1]
+    uint4 *row_rec;      // [rows] kernel A's verdict on a row: (tile mask of its block: 64 bits, origin | kind | bins, depth bits)
     uint2 *e_pair;       // [cap] (depth bits, row)
     uint16_t *e_mask;    // [cap]
     int32_t *tile_count; // [n_images * n_tiles]
@@ -131,62 +136,275 @@ __device__ __forceinline__ WalkPrep bn_prepare(const BnRow &q, bool has_conic, c
     return walk_prepare(q.mx, q.my, q.rx, q.ry, has_conic, q.A, q.B, q.C, q.op, g.tile_size, g.tile_w, g.tile_h);
 }
 
-// ---- A: rectangle of bins per row, histogram ---------------------------------------------------------------------------
+// ---- A: the walk of every row, once ----------------------------------------------------------------------------------------
+// Round 5. Until round 4 this kernel took a row's rectangle of bins only, and kernel D prepared the row again and walked every
+// (row, bin) pair clipped to the bin (1900 instructions per 64 rows, 78 us at c3). Now the walk happens HERE, once:
+//   * a row whose tile rectangle lies inside a BLOCK of kx x ky bins (2 x 4 bins of 4 x 2 tiles = 8 x 8 tiles: 98.9 % of c3's
+//     visible rows) is walked over that block and its record keeps the block's 64 tiles as one bit each - a slab's span
+//     [tv0, tv1) enters the word as a run of bits (a row of the block) or a run of a strided column pattern, never tile by
+//     tile, and the mask of one bin is a few shifts of the word;
+//   * a wave pays for its most expensive lane (c3: 1.6 slabs per row on average, but 4.7 % of the rows have four or more), so
+//     a lane walks its row itself only up to kInlineSlabs slabs. Longer rows, and every row over more than one block (as one
+//     UNIT per block of its rectangle), park their prepared walk in LDS and push units on a queue that the whole workgroup
+//     drains: a unit = the walk clipped to one block -> one mask word;
+//   * a unit of a row over several blocks becomes a UNIT RECORD (the row record's layout + the row id) in the chunk's region of
+//     kUnitCap records. A chunk that needs more sends the call back to the Gaussian-major path (kernel B's verdict).
+// The bin counts are exact: a bin the walk leaves empty gets no entry (the bin rectangle of round 4 counted it). Kernel D
+// deals records out and does no floating point.
+constexpr uint32_t kRecNone = 0u, kRecSmall = 1u, kRecBig = 2u; // bits 16, 17 of the record's origin word; bits 18.. = bins in use
+constexpr int kInlineSlabs  = 2;    // slabs a lane walks itself
+constexpr int kAPark        = 512;  // rows parked per round
+constexpr int kAQueue       = 2048; // units per round
+constexpr int kATake        = 128;  // units one row may push per round (bounds the serial work of the pushing thread)
+constexpr int kParkWords    = 17;   // rectangle (2), slot | flags, bins, depth bits, the prepared walk (12)
+constexpr uint32_t kUnitCap = 1024; // unit records per chunk
+
+// The bin shape as the row kernels see it: the default (4 x 2 tiles, blocks of 2 x 4 bins) as compile-time constants - the
+// quotients and remainders by it are shifts -, any other shape (GSX_ISECT_BIN, an A/B switch) from the geometry record.
+template <bool FIXED>
+struct BinShape {
+    uint32_t bw, bh, kx, ky;
+    __device__ __forceinline__ explicit BinShape(const BinGeom &g)
+        : bw(FIXED ? 4u : g.bw), bh(FIXED ? 2u : g.bh), kx(FIXED ? 2u : g.kx), ky(FIXED ? 4u : g.ky) {}
+};
+// tiles of bin (i, j) of the block, as the 16-bit mask the sort kernel deals from: bit y' * bw + x'
+template <bool FIXED>
+__device__ __forceinline__ uint32_t rec_bin_mask(uint64_t M, const BinShape<FIXED> &sh, uint32_t i, uint32_t j)
+{
+    return block_bin_mask(M, sh.bw, sh.bh, sh.kx, i, j);
+}
+// record of a block's mask; counts the bins it uses in the chunk's histogram
+template <bool FIXED>
+__device__ __forceinline__ uint4 make_record(uint64_t M, uint32_t bbx, uint32_t bby, uint32_t dbits, const BinGeom &g,
+                                             const BinShape<FIXED> &sh, int32_t *s_hist)
+{
+    uint32_t used = 0;
+    for (uint32_t j = 0; j < sh.ky; ++j)
+        for (uint32_t i = 0; i < sh.kx; ++i)
+            if (rec_bin_mask(M, sh, i, j)) {
+                used |= 1u << (j * sh.kx + i);
+                if (s_hist) atomicAdd(&s_hist[(bby + j) * g.bins_x + bbx + i], 1);
+            }
+    return make_uint4((uint32_t)M, (uint32_t)(M >> 32), bbx | (bby << 8) | (kRecSmall << 16) | (used << 18), dbits);
+}
+
+__device__ __forceinline__ void park_walk(uint32_t *rw, const WalkPrep &p, uint32_t slot, bool one, uint32_t org, uint32_t dbits)
+{
+    rw[0] = (uint32_t)p.x0 | ((uint32_t)p.y0 << 16); rw[1] = (uint32_t)p.x1 | ((uint32_t)p.y1 << 16);
+    rw[2] = slot | (p.ellipse ? 1u << 16 : 0u) | (p.alongY ? 1u << 17 : 0u) | (one ? 1u << 18 : 0u);
+    rw[3] = org;
+    rw[4] = dbits;
+    const float pf[12] = {p.B, p.coeff, p.disc, p.t, p.pu, p.pv, p.bmin_u, p.bmax_u, p.bmin_v, p.bmax_v, p.u_at_vmin, p.u_at_vmax};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) rw[5 + k] = __float_as_uint(pf[k]);
+}
+__device__ __forceinline__ WalkPrep parked_walk(const uint32_t *rw)
+{
+    WalkPrep p;
+    p.x0 = (int)(rw[0] & 0xFFFFu); p.y0 = (int)(rw[0] >> 16); p.x1 = (int)(rw[1] & 0xFFFFu); p.y1 = (int)(rw[1] >> 16);
+    p.any = true; p.ellipse = (rw[2] >> 16) & 1u; p.alongY = (rw[2] >> 17) & 1u;
+    p.B = __uint_as_float(rw[5]); p.coeff = __uint_as_float(rw[6]); p.disc = __uint_as_float(rw[7]);
+    p.t = __uint_as_float(rw[8]); p.pu = __uint_as_float(rw[9]); p.pv = __uint_as_float(rw[10]);
+    p.bmin_u = __uint_as_float(rw[11]); p.bmax_u = __uint_as_float(rw[12]); p.bmin_v = __uint_as_float(rw[13]);
+    p.bmax_v = __uint_as_float(rw[14]); p.u_at_vmin = __uint_as_float(rw[15]); p.u_at_vmax = __uint_as_float(rw[16]);
+    return p;
+}
+
+template <bool FIXED>
 __global__ void __launch_bounds__(kRowThreads) bin_rect_kernel(const BinArgs a)
 {
     extern __shared__ int32_t s_hist[];
+    __shared__ uint32_t s_q[kAQueue];
+    __shared__ uint32_t s_row[kAPark][kParkWords];
+    __shared__ int32_t s_tpg[2 * kRowThreads];
+    __shared__ int32_t s_qn, s_qlim, s_mn, s_units, s_anybig;
     const BinGeom &g = a.g;
+    const BinShape<FIXED> sh(g);
     for (uint32_t i = threadIdx.x; i < g.n_bins; i += kRowThreads) s_hist[i] = 0;
-    if (blockIdx.x == 0) { // what kernel B accumulates into
-        if (threadIdx.x == 0) { a.b.hdr->max_bin = 0; a.b.hdr->big_count = 0; }
-        for (uint32_t i = threadIdx.x; i < g.n_images; i += kRowThreads) a.b.img_total[i] = 0;
+    if (threadIdx.x == 0) {
+        s_units = 0; s_mn = 0; s_qn = 0; s_qlim = kAQueue; s_anybig = 0;
+        if (blockIdx.x == 0) { a.b.hdr->overflow = 0; a.b.hdr->big_count = 0; a.b.hdr->b_done = 0; }
     }
-    __syncthreads();
     int64_t lo, hi;
     uint32_t img;
     bn_chunk_rows(g, blockIdx.x, lo, hi, img);
     const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
+    const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)img * g.n_tiles : nullptr;
+    const uint32_t W = sh.kx * sh.bw, Hh = sh.ky * sh.bh;
+    uint64_t col = 0; // one bit per row of the block, in column 0
+    for (uint32_t y = 0; y < Hh; ++y) col |= 1ull << (y * W);
+    uint4 *unit_rec    = a.b.unit_rec + (size_t)blockIdx.x * kUnitCap;
+    uint32_t *unit_row = a.b.unit_row + (size_t)blockIdx.x * kUnitCap;
     constexpr int kU = 2;
     for (int64_t base = lo; base < hi; base += kRowThreads * kU) {
         BnRow q[kU];
+        uint32_t dbits[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) { // every load of the thread's rows is in flight before any is used
             const int64_t r = base + u * kRowThreads + threadIdx.x;
             q[u].rx = q[u].ry = 0.0f;
-            if (r < hi) q[u] = bn_load_row(a, r, has_conic);
+            dbits[u] = 0u;
+            if (r < hi) {
+                q[u]     = bn_load_row(a, r, has_conic);
+                dbits[u] = __float_as_uint(a.depths[r]);
+            }
         }
+        if (base != lo) { // (a chunk of more than 2048 rows) everyone has left the previous iteration's queue
+            __syncthreads();
+            if (threadIdx.x == 0) { s_mn = 0; s_qn = 0; s_qlim = kAQueue; s_anybig = 0; }
+        }
+        __syncthreads(); // the queue's counters, s_hist
+        // a row that waits for the queue: its units, how many were pushed, its parking slot (-1: none yet)
+        uint32_t units[kU], done[kU];
+        int32_t ms[kU];
+        bool left = false; // units that found no room in the first round
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
+            const int64_t r = base + u * kRowThreads + threadIdx.x;
+            units[u] = done[u] = 0u;
+            ms[u]    = -1;
+            if (r >= hi) continue;
+            uint4 rec        = make_uint4(0u, 0u, kRecNone << 16, dbits[u]);
             const WalkPrep p = bn_prepare(q[u], has_conic, g);
+            bool now         = true;
             if (p.any) {
-                const uint32_t bx0 = (uint32_t)p.x0 / g.bw, bx1 = ((uint32_t)p.x1 + g.bw - 1) / g.bw;
-                const uint32_t by0 = (uint32_t)p.y0 / g.bh, by1 = ((uint32_t)p.y1 + g.bh - 1) / g.bh;
-                for (uint32_t by = by0; by < by1; ++by)
-                    for (uint32_t bx = bx0; bx < bx1; ++bx) atomicAdd(&s_hist[by * g.bins_x + bx], 1);
+                const uint32_t bx0 = (uint32_t)p.x0 / sh.bw, bx1 = ((uint32_t)p.x1 + sh.bw - 1) / sh.bw;
+                const uint32_t by0 = (uint32_t)p.y0 / sh.bh, by1 = ((uint32_t)p.y1 + sh.bh - 1) / sh.bh;
+                const uint32_t w = bx1 - bx0, h = by1 - by0;
+                const bool one   = w <= sh.kx && h <= sh.ky;
+                const int slabs  = p.ellipse ? min(p.x1 - p.x0, p.y1 - p.y0) : 1;
+                if (one && slabs <= (int)(((a.dbg >> 16) & 15u) ? ((a.dbg >> 16) & 15u) : (uint32_t)kInlineSlabs) && !(a.dbg & 16u)) {
+                    const int cx0 = (int)(bx0 * sh.bw), cy0 = (int)(by0 * sh.bh);
+                    rec = make_record(block_mask(p, g.tile_size, g.tile_w, cx0, cy0, cx0 + (int)W, cy0 + (int)Hh, W, col, tmask), bx0, by0, dbits[u], g, sh, s_hist);
+                } else if (!(a.dbg & 64u)) {
+                    // park the prepared walk and push its units at once: in the usual case one barrier separates this from the drain
+                    units[u] = one ? 1u : ((w + sh.kx - 1) / sh.kx) * ((h + sh.ky - 1) / sh.ky);
+                    const int32_t m = atomicAdd(&s_mn, 1);
+                    if (m < kAPark) {
+                        ms[u] = m;
+                        park_walk(s_row[m], p, (uint32_t)(u * kRowThreads) + threadIdx.x, one,
+                                  bx0 | (by0 << 8) | ((w - 1u) << 16) | ((h - 1u) << 24), dbits[u]);
+                        const int32_t take = (int32_t)min(units[u], (uint32_t)kATake);
+                        const int32_t qpos = atomicAdd(&s_qn, take);
+                        if (qpos + take > kAQueue) atomicMin(&s_qlim, qpos); // units are valid below the first reservation that did not fit
+                        else {
+                            for (int32_t k = 0; k < take; ++k) s_q[qpos + k] = (uint32_t)m | ((uint32_t)k << 9);
+                            done[u] = (uint32_t)take;
+                        }
+                    }
+                    left |= done[u] != units[u];
+                    if (one) now = false; // its record is written by the lane that takes the unit
+                    else {
+                        rec.z = kRecBig << 16;
+                        s_tpg[u * kRowThreads + threadIdx.x] = 0;
+                        s_anybig = 1;
+                    }
+                }
+            }
+            if (now && !(a.dbg & 32u)) {
+                a.b.row_rec[r] = rec;
+                if (a.tiles_per_gauss && ((rec.z >> 16) & 3u) != kRecBig) a.tiles_per_gauss[r] = __popc(rec.x) + __popc(rec.y);
+            }
+        }
+        // rounds of { drain the queue together } / (rare) { park and push what found no room }
+        for (bool more = __syncthreads_or(left);;) {
+            const int32_t n_q = (a.dbg & 256u) ? 0 : min(s_qn, s_qlim);
+            for (int32_t k = (int32_t)threadIdx.x; k < n_q; k += kRowThreads) {
+                const uint32_t pr  = s_q[k];
+                const uint32_t *rw = s_row[pr & 511u];
+                const WalkPrep p   = parked_walk(rw);
+                const int slot     = (int)(rw[2] & 0xFFFFu);
+                const bool one     = (rw[2] >> 18) & 1u;
+                const uint32_t o = rw[3], bx0 = o & 255u, by0 = (o >> 8) & 255u, w = ((o >> 16) & 255u) + 1u;
+                const uint32_t wb = (w + sh.kx - 1) / sh.kx, idx = pr >> 9;
+                const uint32_t bbx = bx0 + (idx % wb) * sh.kx, bby = by0 + (idx / wb) * sh.ky;
+                const int cx0 = (int)(bbx * sh.bw), cy0 = (int)(bby * sh.bh);
+                const uint64_t M = (a.dbg & 512u) ? 1ull : block_mask(p, g.tile_size, g.tile_w, cx0, cy0, cx0 + (int)W, cy0 + (int)Hh, W, col, tmask);
+                const int64_t r  = base + slot;
+                if (one) {
+                    a.b.row_rec[r] = make_record(M, bbx, bby, rw[4], g, sh, s_hist);
+                    if (a.tiles_per_gauss) a.tiles_per_gauss[r] = __popcll(M);
+                } else if (M) {
+                    const uint32_t at = (uint32_t)atomicAdd(&s_units, 1);
+                    const uint4 rec   = make_record(M, bbx, bby, rw[4], g, sh, s_hist); // counted even when the region is full:
+                    if (at < kUnitCap) {                                               // the call is sent back anyway
+                        unit_rec[at] = rec;
+                        unit_row[at] = (uint32_t)r;
+                    }
+                    atomicAdd(&s_tpg[slot], __popcll(M));
+                }
+            }
+            if (!more) break;
+            // (rare: more waiting rows than parking slots, a row of more than kATake units, a full queue)
+            __syncthreads(); // this round's reads of s_q / s_row
+            if (threadIdx.x == 0) { s_mn = 0; s_qn = 0; s_qlim = kAQueue; }
+            __syncthreads();
+            left = false;
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                if (units[u] == done[u]) continue;
+                const int32_t m = atomicAdd(&s_mn, 1);
+                if (m < kAPark) {
+                    const int64_t r  = base + u * kRowThreads + threadIdx.x;
+                    const WalkPrep p = bn_prepare(bn_load_row(a, r, has_conic), has_conic, g);
+                    const uint32_t bx0 = (uint32_t)p.x0 / sh.bw, bx1 = ((uint32_t)p.x1 + sh.bw - 1) / sh.bw;
+                    const uint32_t by0 = (uint32_t)p.y0 / sh.bh, by1 = ((uint32_t)p.y1 + sh.bh - 1) / sh.bh;
+                    park_walk(s_row[m], p, (uint32_t)(u * kRowThreads) + threadIdx.x, units[u] == 1u,
+                              bx0 | (by0 << 8) | ((bx1 - bx0 - 1u) << 16) | ((by1 - by0 - 1u) << 24), dbits[u]);
+                    const int32_t take = (int32_t)min(units[u] - done[u], (uint32_t)kATake);
+                    const int32_t qpos = atomicAdd(&s_qn, take);
+                    if (qpos + take > kAQueue) atomicMin(&s_qlim, qpos);
+                    else {
+                        for (int32_t k = 0; k < take; ++k) s_q[qpos + k] = (uint32_t)m | ((done[u] + (uint32_t)k) << 9);
+                        done[u] += (uint32_t)take;
+                    }
+                }
+                left |= done[u] != units[u];
+            }
+            more = __syncthreads_or(left);
+        }
+        if (s_anybig) { // uniform: written before the first barrier of the rounds
+            __syncthreads();
+            if (a.tiles_per_gauss) {
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int64_t r = base + u * kRowThreads + threadIdx.x;
+                    if (r < hi && units[u] > 1u) a.tiles_per_gauss[r] = s_tpg[u * kRowThreads + threadIdx.x];
+                }
             }
         }
     }
     __syncthreads();
     int32_t *out = a.b.table + (int64_t)blockIdx.x * g.n_bins;
     for (uint32_t i = threadIdx.x; i < g.n_bins; i += kRowThreads) out[i] = s_hist[i];
+    if (threadIdx.x == 0) a.b.unit_count[blockIdx.x] = s_units;
 }
 
-// ---- B: exclusive running sum over an image's chunks for every (image, bin), in place; totals[bin] ---------------------
+// ---- B: exclusive running sum over an image's chunks for every (image, bin), in place; totals[bin]; the plan ---------------
 // The table is short and wide in the wrong direction (hundreds of chunks x a few hundred bins): 32 bins x 32 chunk segments
-// per workgroup, two passes over a segment of ~cpi / 32 entries.
+// per workgroup, two passes over a segment of ~cpi / 32 entries. The workgroup that finishes LAST scans the bin totals into
+// bin_start (kernel D's cursors are bin_start + the chunk's prefix: two loads) and decides whether the call goes back to the
+// Gaussian-major path:
+//   * more entries than the workspace holds, a chunk with more unit records than its region;
+//   * a crowded bin - a real scene's dense region (garden x25 has bins of > 10 k entries next to a mean of ~2 k) does not fit
+//     the sort kernel's LDS arena and goes through its slow paths: emit + sort 0.80 ms where the Gaussian-major path takes 0.20;
+//   * clustered but small (garden x1: 112 k rows, no bin near the arena's size): the crowded bins' workgroups are the launch's
+//     tail - binned 0.218 ms against 0.128 Gaussian-major - while a uniform scene's largest bin is ~1.5 x its mean.
 constexpr int kCsCols = 32, kCsSegs2 = 32;
-__global__ void __launch_bounds__(kCsCols *kCsSegs2) bin_colscan_kernel(int32_t *table, int32_t *totals, uint32_t n_cols,
-                                                                        uint32_t cpi, uint32_t col_groups, int32_t *img_total,
-                                                                        int32_t *max_bin)
+__global__ void __launch_bounds__(kCsCols *kCsSegs2) bin_colscan_kernel(const BinArgs a, uint32_t col_groups)
 {
     __shared__ int32_t s_seg[kCsSegs2][kCsCols + 1];
+    __shared__ int64_t s_part[16];
+    __shared__ int32_t s_max, s_last, s_umax[16];
+    const BinGeom &g      = a.g;
+    const uint32_t n_cols = g.n_bins, cpi = g.cpi;
     const uint32_t img = blockIdx.x / col_groups, cg = blockIdx.x % col_groups;
     const uint32_t lane_c = threadIdx.x % kCsCols, seg = threadIdx.x / kCsCols;
     const uint32_t c      = cg * kCsCols + lane_c;
     const bool live       = c < n_cols;
     const uint32_t per    = (cpi + kCsSegs2 - 1) / kCsSegs2;
     const uint32_t r0 = seg * per, r1 = min(r0 + per, cpi);
-    int32_t *col = table + (int64_t)img * cpi * n_cols + c;
+    int32_t *col = a.b.table + (int64_t)img * cpi * n_cols + c;
     int32_t sum  = 0;
     if (live)
         for (uint32_t r = r0; r < r1; ++r) sum += col[(int64_t)r * n_cols];
@@ -200,212 +418,96 @@ __global__ void __launch_bounds__(kCsCols *kCsSegs2) bin_colscan_kernel(int32_t 
             col[(int64_t)r * n_cols] = run;
             run += v;
         }
-        if (seg == kCsSegs2 - 1) totals[(int64_t)img * n_cols + c] = run;
+        if (seg == kCsSegs2 - 1) a.b.bin_count[(int64_t)img * n_cols + c] = run;
     }
-    // the last segment's threads hold the bin totals of this workgroup's 32 bins (the upper half of the last wave): their
-    // sum goes to the image's entry count, their maximum to the skew test - one atomic each per workgroup
-    if (seg == kCsSegs2 - 1) {
-        int32_t sum = live ? run : 0, mx = sum;
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) {
-            sum += __shfl_xor(sum, o);
-            mx = max(mx, __shfl_xor(mx, o));
-        }
-        if (lane_c == 0) {
-            atomicAdd(&img_total[img], sum);
-            atomicMax(max_bin, mx);
-        }
+    // the last workgroup to get here plans the rest of the call (every ticket is a release at device scope, the last one acquires)
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&a.b.hdr->b_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int64_t n = block_scan_i32_1024(a.b.bin_count, a.b.bin_start, g.n_bins_total, s_part, &s_max);
+    int32_t um = 0;
+    for (uint32_t i = threadIdx.x; i < g.n_chunks; i += kCsCols * kCsSegs2) um = max(um, a.b.unit_count[i]);
+    um = wave_max_i32(um);
+    if ((threadIdx.x & 63u) == 0) s_umax[threadIdx.x >> 6] = um;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) um = max(um, s_umax[w]);
+        const int64_t mx    = s_max;
+        const bool lopsided = g.skew_ratio > 0 && mx * (int64_t)g.n_bins_total > (int64_t)g.skew_ratio * n && mx > 256;
+        a.b.bin_start[g.n_bins_total] = (int32_t)min(n, (int64_t)INT32_MAX);
+        a.b.hdr->overflow = (n > g.cap_entries || um > (int32_t)kUnitCap || (g.skew_cap > 0 && mx > g.skew_cap) || lopsided) ? 1 : 0;
     }
-}
-
-// Entries in all bins, and whether the call has to go back to the Gaussian-major path: more entries than the workspace
-// holds, or a crowded bin - a real scene's dense region (garden x25 has bins of > 10 k entries next to a mean of ~2 k) does not
-// fit the sort kernel's LDS arena and goes through its slow paths: emit + sort 0.80 ms where the Gaussian-major path takes
-// 0.20 (same retry contract as a workspace overflow). A pure function of what kernel B left behind: every later kernel
-// evaluates it for itself.
-__device__ __forceinline__ bool bn_overflow(const BinArgs &a, int64_t *n_entries_out = nullptr)
-{
-    int64_t n = 0;
-    for (uint32_t i = 0; i < a.g.n_images; ++i) n += a.b.img_total[i];
-    if (n_entries_out) *n_entries_out = n;
-    const int64_t mx = a.b.hdr->max_bin;
-    // clustered but small (garden x1: 112 k rows, no bin near the arena's size): the crowded bins' workgroups are the launch's
-    // tail - binned 0.218 ms against 0.128 Gaussian-major - while a uniform scene's largest bin is ~1.5 x its mean
-    const bool lopsided = a.g.skew_ratio > 0 && mx * (int64_t)a.g.n_bins_total > (int64_t)a.g.skew_ratio * n && mx > 256;
-    return n > a.g.cap_entries || (a.g.skew_cap > 0 && mx > a.g.skew_cap) || lopsided;
 }
 
 // ---- D: entries (depth, row | mask) grouped by bin ----------------------------------------------------------------------
-// A row's cost is the number of bins and tiles it covers, and a wave pays for its most expensive lane: with one row per lane a
-// single near Gaussian (hundreds of tiles) stalls 63 lanes. So only rows inside ONE bin (at most bw x bh tiles) are walked by
-// the thread that loaded them; a row over several bins parks its ten input words in LDS and pushes one (row, bin) pair per
-// bin on an LDS queue, and the workgroup then shares the pairs out evenly: every unit of work is one walk clipped to one bin.
-constexpr int kDRows  = 2 * kRowThreads; // rows per iteration
-constexpr int kDMulti = 1024;            // rows over several bins parked per round
-constexpr int kDQueue = 6144;            // (row, bin) pairs per round
-constexpr int kDTake  = 128;             // pairs one row may push per round (bounds the serial work of the pushing thread)
-
-__device__ __forceinline__ uint32_t bn_entry(const BinArgs &a, const WalkPrep &p, uint32_t bx, uint32_t by, const uint8_t *tmask,
-                                            uint32_t dbits, int64_t r, int32_t *s_cur)
+// Row records and the chunk's unit records are dealt out: one entry per bin in use, at the bin's LDS cursor = bin_start + the
+// chunk's prefix inside the bin. Workgroups go to the eight XCDs round robin; consecutive CHUNKS write neighbouring slots of
+// every bin (their prefixes follow each other), so a run of consecutive chunks is given to one XCD: a line of the entry
+// arrays fills up in one L2 (c3: the scattered stores cost 24 us with chunk = workgroup index, 13 us with this map).
+template <bool FIXED>
+__device__ __forceinline__ void bn_deal(const BinArgs &a, const BinShape<FIXED> &sh, const uint4 &rec, uint32_t row, int32_t *s_cur)
 {
-    const BinGeom &g = a.g;
-    const int cx0 = (int)(bx * g.bw), cy0 = (int)(by * g.bh);
-    const int cx1 = min(cx0 + (int)g.bw, (int)g.tile_w), cy1 = min(cy0 + (int)g.bh, (int)g.tile_h);
-    uint32_t mask = 0;
-    if (a.dbg & 4u) mask = 1u;
-    else
-    walk_clipped(p, g.tile_size, cx0, cy0, cx1, cy1, [&](int x, int y) {
-        if (tmask && !tmask[(size_t)y * g.tile_w + x]) return;
-        mask |= 1u << ((y - cy0) * (int)g.bw + (x - cx0));
-    });
-    const int32_t slot = atomicAdd(&s_cur[by * g.bins_x + bx], 1);
-    if (!(a.dbg & 8u)) {
-    a.b.e_pair[slot]   = make_uint2(dbits, (uint32_t)r);
-    a.b.e_mask[slot]   = (uint16_t)mask;
+    const uint32_t bx0 = rec.z & 255u, by0 = (rec.z >> 8) & 255u;
+    const uint64_t M   = ((uint64_t)rec.y << 32) | rec.x;
+    for (uint32_t used = rec.z >> 18; used;) {
+        const uint32_t k = (uint32_t)__builtin_ctz(used);
+        used &= used - 1u;
+        const uint32_t i = k % sh.kx, j = k / sh.kx;
+        const int32_t slot = atomicAdd(&s_cur[(by0 + j) * a.g.bins_x + bx0 + i], 1);
+        if (a.dbg & 8u) continue;
+        a.b.e_pair[slot] = make_uint2(rec.w, row);
+        a.b.e_mask[slot] = (uint16_t)rec_bin_mask(M, sh, i, j);
     }
-    return (uint32_t)__popc(mask);
 }
 
+template <bool FIXED>
 __global__ void __launch_bounds__(kRowThreads) bin_scatter_kernel(const BinArgs a)
 {
     extern __shared__ int32_t s_cur[];
-    __shared__ uint32_t s_q[kDQueue];
-    __shared__ float s_row[kDMulti][10]; // mean, radii, conic, opacity, depth bits, row slot
-    __shared__ int32_t s_tpg[kDRows];
-    __shared__ int32_t s_qn, s_qlim, s_mn;
-    __shared__ int32_t s_wsum[kRowThreads / 64];
     const BinGeom &g = a.g;
-    int64_t n_entries;
-    if (bn_overflow(a, &n_entries)) return; // the same answer in every workgroup
+    const BinShape<FIXED> sh(g);
+    const uint32_t per_xcd = gridDim.x / 8u;
+    const uint32_t chunk   = (a.dbg & 4096u) ? blockIdx.x : (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+    if (chunk >= g.n_chunks) return;
     int64_t lo, hi;
     uint32_t img;
-    bn_chunk_rows(g, blockIdx.x, lo, hi, img);
-    {
-        // cursors = (entries of the images before this one) + (exclusive scan of this image's bin totals) + (this chunk's
-        // prefix inside the bin): thread t scans the run [t per, (t + 1) per) of bins
-        const int32_t *cnt = a.b.bin_count + (int64_t)img * g.n_bins;
-        const int32_t *pre = a.b.table + (int64_t)blockIdx.x * g.n_bins; // exclusive prefix over this image's chunks
-        const uint32_t per = (g.n_bins + kRowThreads - 1) / kRowThreads;
-        const uint32_t i0 = threadIdx.x * per, i1 = min(i0 + per, g.n_bins);
-        int32_t mine = 0;
-        for (uint32_t i = i0; i < i1; ++i) mine += cnt[i];
-        int32_t inc = mine;
-        const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    bn_chunk_rows(g, chunk, lo, hi, img);
+    constexpr int kU = 2;
+    uint4 rec[kU];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int32_t y = __shfl_up(inc, o);
-            if (lane >= o) inc += y;
-        }
-        if (lane == 63) s_wsum[wave] = inc;
-        __syncthreads();
-        int32_t run = 0;
-        for (uint32_t j = 0; j < img; ++j) run += a.b.img_total[j];
-        for (int w = 0; w < wave; ++w) run += s_wsum[w];
-        run += inc - mine;
-        const bool keeper = blockIdx.x % g.cpi == 0; // the image's first workgroup stores bin_start for kernels E and G
-        int32_t *start    = a.b.bin_start + (int64_t)img * g.n_bins;
-        for (uint32_t i = i0; i < i1; ++i) {
-            if (keeper) start[i] = run;
-            s_cur[i] = run + pre[i];
-            run += cnt[i];
-        }
-        if (keeper && img == g.n_images - 1 && threadIdx.x == 0) a.b.bin_start[g.n_bins_total] = (int32_t)n_entries;
+    for (int u = 0; u < kU; ++u) { // the first records travel while the cursors are made
+        const int64_t r = lo + u * kRowThreads + threadIdx.x;
+        rec[u]          = r < hi ? a.b.row_rec[r] : make_uint4(0u, 0u, 0u, 0u);
     }
-    const bool has_conic = (a.conics != nullptr) && (a.opacities != nullptr);
-    const uint8_t *tmask = a.tile_mask ? a.tile_mask + (size_t)img * g.n_tiles : nullptr;
-    constexpr int kU = kDRows / kRowThreads;
-    for (int64_t base = lo; base < hi; base += kDRows) {
-        BnRow q[kU];
-        uint32_t dbits[kU], rect[kU], wh[kU], done[kU]; // bin rectangle of a row over several bins (wh == 0: nothing pending)
+    const int32_t *start = a.b.bin_start + (int64_t)img * g.n_bins;
+    const int32_t *pre   = a.b.table + (int64_t)chunk * g.n_bins; // exclusive prefix over this image's chunks
+    for (uint32_t i = threadIdx.x; i < g.n_bins; i += kRowThreads) s_cur[i] = start[i] + pre[i];
+    const int32_t n_units = min(a.b.unit_count[chunk], (int32_t)kUnitCap);
+    if (a.b.hdr->overflow) return; // the same answer in every workgroup
+    __syncthreads();
+    for (int64_t base = lo; base < hi; base += kU * kRowThreads) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int64_t r = base + u * kRowThreads + threadIdx.x;
-            q[u].rx = q[u].ry = 0.0f;
-            dbits[u] = rect[u] = wh[u] = done[u] = 0;
-            if (r < hi) {
-                q[u]     = bn_load_row(a, r, has_conic);
-                dbits[u] = __float_as_uint(a.depths[r]);
-            }
-            s_tpg[u * kRowThreads + threadIdx.x] = 0;
+            if (base != lo) rec[u] = r < hi ? a.b.row_rec[r] : make_uint4(0u, 0u, 0u, 0u);
+            if (((rec[u].z >> 16) & 3u) == kRecSmall) bn_deal(a, sh, rec[u], (uint32_t)r, s_cur);
         }
-        __syncthreads(); // s_cur (first iteration), s_tpg
-#pragma unroll
-        for (int u = 0; u < kU; ++u) { // rows inside one bin: walked here
-            const int64_t r = base + u * kRowThreads + threadIdx.x;
-            if (r >= hi) continue;
-            const WalkPrep p = bn_prepare(q[u], has_conic, g);
-            if (!p.any) continue;
-            const uint32_t bx0 = (uint32_t)p.x0 / g.bw, bx1 = ((uint32_t)p.x1 + g.bw - 1) / g.bw;
-            const uint32_t by0 = (uint32_t)p.y0 / g.bh, by1 = ((uint32_t)p.y1 + g.bh - 1) / g.bh;
-            if ((bx1 - bx0) * (by1 - by0) == 1u)
-                s_tpg[u * kRowThreads + threadIdx.x] = (int32_t)bn_entry(a, p, bx0, by0, tmask, dbits[u], r, s_cur);
-            else {
-                rect[u] = bx0 | (by0 << 8);
-                wh[u]   = (bx1 - bx0) | ((by1 - by0) << 16);
-            }
-        }
-        // rows over several bins: rounds of { park the row, push up to kDTake (row, bin) pairs } / { drain the queue together }
-        for (;;) {
-            if (threadIdx.x == 0) { s_qn = 0; s_qlim = kDQueue; s_mn = 0; }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                if (wh[u] == 0u) continue;
-                const uint32_t w = wh[u] & 0xFFFFu, h = wh[u] >> 16;
-                const uint32_t rem = w * h - done[u];
-                const int32_t take = (int32_t)min(rem, (uint32_t)kDTake);
-                const int32_t ms   = atomicAdd(&s_mn, 1);
-                if (ms >= kDMulti) continue; // next round
-                const int32_t qpos = atomicAdd(&s_qn, take);
-                if (qpos + take > kDQueue) {
-                    atomicMin(&s_qlim, qpos); // pairs are valid below the first reservation that did not fit
-                    continue;
-                }
-                float *rw = s_row[ms];
-                rw[0] = q[u].mx; rw[1] = q[u].my; rw[2] = q[u].rx; rw[3] = q[u].ry; rw[4] = q[u].A; rw[5] = q[u].B; rw[6] = q[u].C;
-                rw[7] = q[u].op; rw[8] = __uint_as_float(dbits[u]); rw[9] = __int_as_float(u * kRowThreads + (int)threadIdx.x);
-                const uint32_t bx0 = rect[u] & 255u, by0 = (rect[u] >> 8) & 255u;
-                for (int32_t k = 0; k < take; ++k) {
-                    const uint32_t idx = done[u] + (uint32_t)k;
-                    s_q[qpos + k]      = (uint32_t)ms | ((bx0 + idx % w) << 10) | ((by0 + idx / w) << 18);
-                }
-                done[u] += (uint32_t)take;
-                if (done[u] == w * h) wh[u] = 0u;
-            }
-            __syncthreads();
-            const int32_t n_q = min(s_qn, s_qlim);
-            for (int32_t k = (int32_t)threadIdx.x; k < n_q; k += kRowThreads) {
-                const uint32_t pr = s_q[k];
-                const float *rw   = s_row[pr & 1023u];
-                BnRow qq;
-                qq.mx = rw[0]; qq.my = rw[1]; qq.rx = rw[2]; qq.ry = rw[3]; qq.A = rw[4]; qq.B = rw[5]; qq.C = rw[6]; qq.op = rw[7];
-                const int slot   = __float_as_int(rw[9]);
-                const WalkPrep p = bn_prepare(qq, has_conic, g);
-                const uint32_t n = bn_entry(a, p, (pr >> 10) & 255u, pr >> 18, tmask, __float_as_uint(rw[8]), base + slot, s_cur);
-                if (n) atomicAdd(&s_tpg[slot], (int32_t)n);
-            }
-            bool pending = false;
-#pragma unroll
-            for (int u = 0; u < kU; ++u) pending |= wh[u] != 0u;
-            if (!__syncthreads_or(pending)) break; // also orders this round's reads of s_q / s_row before the next round
-        }
-        if (a.tiles_per_gauss) {
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const int64_t r = base + u * kRowThreads + threadIdx.x;
-                if (r < hi) a.tiles_per_gauss[r] = s_tpg[u * kRowThreads + threadIdx.x];
-            }
-        }
-        __syncthreads(); // s_tpg is rewritten by the next iteration
     }
+    for (int32_t k = (int32_t)threadIdx.x; k < n_units; k += kRowThreads)
+        bn_deal(a, sh, a.b.unit_rec[(size_t)chunk * kUnitCap + k], a.b.unit_row[(size_t)chunk * kUnitCap + k], s_cur);
 }
 
 // ---- E: per-tile counts of one bin --------------------------------------------------------------------------------------
+// (Round 5 tried the scan of kernel F in the last workgroup of this one: a release at device scope per workgroup - 1020 L2
+// write-backs - costs more than the launch it saves: 27 us against 6.4 + 5.7.)
 __global__ void __launch_bounds__(kBnThreads) bin_tiles_kernel(const BinArgs a)
 {
     __shared__ int32_t s_cnt[16];
     const BinGeom &g = a.g;
-    if (bn_overflow(a)) return;
+    if (a.b.hdr->overflow) return;
     const uint32_t bin = blockIdx.x;
     const int32_t e0 = a.b.bin_start[bin], e1 = a.b.bin_start[bin + 1];
     const int lane = (int)(threadIdx.x & 63u);
@@ -445,7 +547,7 @@ __global__ void __launch_bounds__(1024) tile_plan_kernel(const BinArgs a)
     __shared__ int64_t s_part[16];
     __shared__ int32_t s_max;
     const BinGeom &g = a.g;
-    if (bn_overflow(a)) {
+    if (a.b.hdr->overflow) {
         if (threadIdx.x == 0) {
             __threadfence_system();
             *a.n_isects = GSX_ISECT_RETRY; // the caller reruns the Gaussian-major path (gsx_isect_binned_count's contract)
@@ -520,7 +622,9 @@ __global__ void __launch_bounds__(1024) bin_sort_kernel(const BinArgs a)
         uint32_t bmask = 0;
         for (int t = 0; t < n_bits; ++t) bmask |= (s_batch[t] == b) ? (1u << t) : 0u;
         __syncthreads();
-        // deal every entry to the lists of the tiles in its mask (LDS cursor per tile)
+        // deal every entry to the lists of the tiles in its mask (LDS cursor per tile). (Round 5: requesting several trips'
+        // entries together, or a group ahead, changes nothing - 70.6 .. 71.9 us for 1 / 2 / 4 / 8 trips -: with eight waves per
+        // SIMD the other waves cover a wave's round trips; the group held ahead costs registers and a workgroup per CU, 77 us.)
         for (int32_t e = e0 + (int32_t)threadIdx.x; e < e1 && !(a.dbg & 2u); e += n_thr) {
             uint32_t m = (uint32_t)a.b.e_mask[e] & bmask;
             if (m == 0u) continue;
@@ -611,6 +715,7 @@ static bool bin_geometry(BinGeom &g, int64_t rows, uint32_t n_images, uint32_t t
     bin_dims(g.bw, g.bh);
     g.tile_size = tile_size; g.tile_w = tile_w; g.tile_h = tile_h; g.n_tiles = tile_w * tile_h;
     g.bins_x = (tile_w + g.bw - 1) / g.bw; g.bins_y = (tile_h + g.bh - 1) / g.bh;
+    g.kx = 2; g.ky = g.bw * g.bh <= 8 ? 4 : 2; // 4 x 2 tiles per bin: a block of 8 x 8 tiles
     g.n_bins = g.bins_x * g.bins_y; g.n_bins_total = g.n_bins * g.n_images;
     g.tile_bits = bits_for(g.n_tiles);
     // chunks of >= 2048 rows, image-aligned, at most ~1024 in total (the [chunk][bin] table stays small)
@@ -649,8 +754,11 @@ static int64_t bin_layout(const BinGeom &g, unsigned char *base, BinBuffers *b)
     t.hdr        = reinterpret_cast<BinHeader *>(take(sizeof(BinHeader)));
     t.table      = reinterpret_cast<int32_t *>(take((int64_t)g.n_chunks * g.n_bins * 4));
     t.bin_count  = reinterpret_cast<int32_t *>(take((int64_t)g.n_bins_total * 4));
-    t.img_total  = reinterpret_cast<int32_t *>(take((int64_t)g.n_images * 4));
+    t.unit_count = reinterpret_cast<int32_t *>(take((int64_t)g.n_chunks * 4));
+    t.unit_rec   = reinterpret_cast<uint4 *>(take((int64_t)g.n_chunks * kUnitCap * 16));
+    t.unit_row   = reinterpret_cast<uint32_t *>(take((int64_t)g.n_chunks * kUnitCap * 4));
     t.bin_start  = reinterpret_cast<int32_t *>(take(((int64_t)g.n_bins_total + 1) * 4));
+    t.row_rec    = reinterpret_cast<uint4 *>(take(g.rows * 16));
     t.e_pair     = reinterpret_cast<uint2 *>(take(g.cap_entries * 8));
     t.e_mask     = reinterpret_cast<uint16_t *>(take(g.cap_entries * 2));
     t.tile_count = reinterpret_cast<int32_t *>(take((int64_t)g.n_images * g.n_tiles * 4));
@@ -809,11 +917,19 @@ extern "C" int gsx_isect_binned_count(const float *means2d, const int32_t *radii
     a.tile_mask = tile_mask; a.tiles_per_gauss = tiles_per_gauss; a.isect_offsets = isect_offsets; a.n_isects = n_isects;
     a.max_tile_len = max_tile_len;
     const size_t bins_lds = (size_t)a.g.n_bins * sizeof(int32_t);
-    bin_rect_kernel<<<dim3(a.g.n_chunks), dim3(kRowThreads), bins_lds, s>>>(a);
+    const bool fixed      = a.g.bw == 4 && a.g.bh == 2 && a.g.kx == 2 && a.g.ky == 4;
+    static PerDeviceOnce once;
+    if (once.first()) {
+        (void)hipFuncSetAttribute((const void *)bin_rect_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void *)bin_rect_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    }
+    if (fixed) bin_rect_kernel<true><<<dim3(a.g.n_chunks), dim3(kRowThreads), bins_lds, s>>>(a);
+    else bin_rect_kernel<false><<<dim3(a.g.n_chunks), dim3(kRowThreads), bins_lds, s>>>(a);
     const uint32_t col_groups = (a.g.n_bins + kCsCols - 1) / kCsCols;
-    bin_colscan_kernel<<<dim3(col_groups * a.g.n_images), dim3(kCsCols * kCsSegs2), 0, s>>>(
-        a.b.table, a.b.bin_count, a.g.n_bins, a.g.cpi, col_groups, a.b.img_total, &a.b.hdr->max_bin);
-    bin_scatter_kernel<<<dim3(a.g.n_chunks), dim3(kRowThreads), bins_lds, s>>>(a);
+    bin_colscan_kernel<<<dim3(col_groups * a.g.n_images), dim3(kCsCols * kCsSegs2), 0, s>>>(a, col_groups);
+    const uint32_t d_grid = (a.g.n_chunks + 7u) / 8u * 8u; // a whole number of workgroups per XCD (chunk map of kernel D)
+    if (fixed) bin_scatter_kernel<true><<<dim3(d_grid), dim3(kRowThreads), bins_lds, s>>>(a);
+    else bin_scatter_kernel<false><<<dim3(d_grid), dim3(kRowThreads), bins_lds, s>>>(a);
     bin_tiles_kernel<<<dim3(a.g.n_bins_total), dim3(kBnThreads), 0, s>>>(a);
     tile_plan_kernel<<<dim3(1), dim3(1024), 0, s>>>(a);
     return check_launch("isect_binned_count");

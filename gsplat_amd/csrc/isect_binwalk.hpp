@@ -74,22 +74,18 @@ __host__ __device__ __forceinline__ WalkPrep walk_prepare(float mx, float my, fl
     return p;
 }
 
-// Visits the tiles of the walk that lie in [cx0,cx1) x [cy0,cy1): emit(tile_x, tile_y). Returns their number.
-template <typename Emit>
-__host__ __device__ __forceinline__ int32_t walk_clipped(const WalkPrep &p, uint32_t tile_size, int cx0, int cy0, int cx1,
-                                                         int cy1, Emit &&emit)
+// The part of the walk inside [cx0,cx1) x [cy0,cy1), slab by slab: span(alongY, u, tv0, tv1) = the tiles (x, y) = (v, u)
+// [alongY] or (u, v) for v in [tv0, tv1) (an empty span, tv1 <= tv0, may be reported).
+template <typename Span>
+__host__ __device__ __forceinline__ void walk_clipped_spans(const WalkPrep &p, uint32_t tile_size, int cx0, int cy0, int cx1,
+                                                            int cy1, Span &&span)
 {
-    if (!p.any) return 0;
-    int32_t count = 0;
+    if (!p.any) return;
     if (!p.ellipse) {
         const int xa = p.x0 > cx0 ? p.x0 : cx0, xb = p.x1 < cx1 ? p.x1 : cx1;
         const int ya = p.y0 > cy0 ? p.y0 : cy0, yb = p.y1 < cy1 ? p.y1 : cy1;
-        for (int y = ya; y < yb; ++y)
-            for (int x = xa; x < xb; ++x) {
-                emit(x, y);
-                ++count;
-            }
-        return count;
+        for (int y = ya; y < yb; ++y) span(true, y, xa, xb);
+        return;
     }
     const float ts     = (float)tile_size;
     const bool ts_pow2 = (tile_size & (tile_size - 1u)) == 0u;
@@ -100,8 +96,8 @@ __host__ __device__ __forceinline__ int32_t walk_clipped(const WalkPrep &p, uint
     const int cu0 = p.alongY ? cy0 : cx0, cu1 = p.alongY ? cy1 : cx1;
     const int cv0 = p.alongY ? cx0 : cy0, cv1 = p.alongY ? cx1 : cy1;
     const int us = u0 > cu0 ? u0 : cu0, ue = u1 < cu1 ? u1 : cu1;
-    if (us >= ue) return 0;
-    if ((v0 > cv0 ? v0 : cv0) >= (v1 < cv1 ? v1 : cv1)) return 0;
+    if (us >= ue) return;
+    if ((v0 > cv0 ? v0 : cv0) >= (v1 < cv1 ? v1 : cv1)) return;
 
     float hi_lo = p.bmax_v, hi_hi = p.bmin_v; // "empty" interval
     float lo_lo, lo_hi;
@@ -130,16 +126,62 @@ __host__ __device__ __forceinline__ int32_t walk_clipped(const WalkPrep &p, uint
         int tv1          = clampi(f2i_trunc_sat(div_ts(vmax) + 1.0f), v0, v1);
         if (tv0 < cv0) tv0 = cv0;
         if (tv1 > cv1) tv1 = cv1;
-        for (int v = tv0; v < tv1; ++v) {
-            if (p.alongY) emit(v, u);
-            else emit(u, v);
-            ++count;
-        }
+        span(p.alongY, u, tv0, tv1);
         lo_lo   = hi_lo;
         lo_hi   = hi_hi;
         line_lo = line_hi;
     }
+}
+
+// Visits the tiles of the walk that lie in [cx0,cx1) x [cy0,cy1): emit(tile_x, tile_y). Returns their number.
+template <typename Emit>
+__host__ __device__ __forceinline__ int32_t walk_clipped(const WalkPrep &p, uint32_t tile_size, int cx0, int cy0, int cx1,
+                                                         int cy1, Emit &&emit)
+{
+    int32_t count = 0;
+    walk_clipped_spans(p, tile_size, cx0, cy0, cx1, cy1, [&](bool alongY, int u, int tv0, int tv1) {
+        for (int v = tv0; v < tv1; ++v) {
+            if (alongY) emit(v, u);
+            else emit(u, v);
+            ++count;
+        }
+    });
     return count;
+}
+
+// ---- a block of tiles as one 64-bit word (isect_binned.hip, round 5) ---------------------------------------------------------
+// A block is kx x ky bins of bw x bh tiles, W = kx * bw tiles wide, at most 64 tiles: bit dy * W + dx.
+__host__ __device__ __forceinline__ uint64_t low_bits64(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
+
+// The tiles of the walk inside the block whose first tile is (cx0, cy0), clipped to [cx0,cx1) x [cy0,cy1). A slab's span
+// enters the word as a run of bits (a row of the block) or as a run of `col` = one bit per row of the block, in column 0.
+__host__ __device__ __forceinline__ uint64_t block_mask(const WalkPrep &p, uint32_t tile_size, uint32_t tile_w, int cx0, int cy0,
+                                                        int cx1, int cy1, uint32_t W, uint64_t col, const uint8_t *tmask)
+{
+    uint64_t M = 0;
+    walk_clipped_spans(p, tile_size, cx0, cy0, cx1, cy1, [&](bool alongY, int uu, int tv0, int tv1) {
+        if (tv1 <= tv0) return;
+        if (alongY) // tiles x in [tv0, tv1) at y = uu
+            M |= (low_bits64((uint32_t)(tv1 - cx0)) ^ low_bits64((uint32_t)(tv0 - cx0))) << ((uint32_t)(uu - cy0) * W);
+        else // tiles y in [tv0, tv1) at x = uu
+            M |= (col & (low_bits64((uint32_t)(tv1 - cy0) * W) ^ low_bits64((uint32_t)(tv0 - cy0) * W))) << (uu - cx0);
+    });
+    if (tmask) // (rare) tiles the caller masked out
+        for (uint64_t left = M; left;) {
+            const int b = __builtin_ctzll(left);
+            left &= left - 1ull;
+            if (!tmask[(size_t)(cy0 + b / (int)W) * tile_w + (size_t)(cx0 + b % (int)W)]) M &= ~(1ull << b);
+        }
+    return M;
+}
+
+// tiles of bin (i, j) of the block, as the 16-bit mask the sort kernel deals from: bit y' * bw + x'
+__host__ __device__ __forceinline__ uint32_t block_bin_mask(uint64_t M, uint32_t bw, uint32_t bh, uint32_t kx, uint32_t i, uint32_t j)
+{
+    const uint32_t W = kx * bw, row_bits = (1u << bw) - 1u;
+    uint32_t m = 0;
+    for (uint32_t y = 0; y < bh; ++y) m |= ((uint32_t)(M >> ((j * bh + y) * W + i * bw)) & row_bits) << (y * bw);
+    return m;
 }
 
 } // namespace gsx

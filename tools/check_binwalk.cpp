@@ -1,6 +1,6 @@
 // Host check of csrc/isect_binwalk.hpp: for random and adversarial Gaussians, the union of walk_clipped() over a
 // partition of the tile grid into bins must be walk_tiles(), tile for tile (and every tile must come from the bin that
-// contains it). Build + run: tools/check_binwalk.sh  (hipcc, host code only; no GPU needed)
+// contains it); so must the block records of the binned path (block_mask + block_bin_mask). Build + run: tools/check_binwalk.sh  (hipcc, host code only; no GPU needed)
 #include "../gsplat_amd/csrc/isect_binwalk.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -39,7 +39,7 @@ int main(int argc, char **argv)
         if (it % 101 == 0) { B = 0.f; }
         const bool has_conic = (it % 5) != 0;
         const float rx = ceilf(3.33f * sqrtf(a)), ry = ceilf(3.33f * sqrtf(d));
-        std::vector<int64_t> ref, got;
+        std::vector<int64_t> ref, got, got_blocks;
         walk_tiles(mx, my, rx, ry, has_conic, A, B, C, op, ts, tw, th, [&](int64_t t) { ref.push_back(t); });
         const WalkPrep p = walk_prepare(mx, my, rx, ry, has_conic, A, B, C, op, ts, tw, th);
         if (p.any) {
@@ -52,6 +52,30 @@ int main(int argc, char **argv)
                         got.push_back((int64_t)y * tw + x);
                     });
                 }
+            // the block records of isect_binned.hip: the row's rectangle of bins cut into blocks of kx x ky bins, every block's
+            // walk as one 64-bit word, every bin's 16-bit mask cut out of it - their union must be the walk as well
+            if (BW * BH <= 16) {
+                const int kx = 2, ky = BW * BH <= 8 ? 4 : 2, Wb = kx * BW, Hb = ky * BH;
+                uint64_t col = 0;
+                for (int y = 0; y < Hb; ++y) col |= 1ull << (y * Wb);
+                for (int by = by0; by < by1; by += ky)
+                    for (int bx = bx0; bx < bx1; bx += kx) {
+                        const int cx0 = bx * BW, cy0 = by * BH;
+                        const uint64_t M = block_mask(p, ts, tw, cx0, cy0, cx0 + Wb, cy0 + Hb, (uint32_t)Wb, col, nullptr);
+                        uint64_t seen = 0;
+                        for (int j = 0; j < ky; ++j)
+                            for (int i = 0; i < kx; ++i) {
+                                const uint32_t m = block_bin_mask(M, BW, BH, kx, i, j);
+                                for (int b = 0; b < BW * BH; ++b)
+                                    if ((m >> b) & 1u) {
+                                        const int x = cx0 + i * BW + b % BW, y = cy0 + j * BH + b / BW;
+                                        got_blocks.push_back((int64_t)y * tw + x);
+                                        seen |= 1ull << ((y - cy0) * Wb + (x - cx0));
+                                    }
+                            }
+                        if (seen != M) ++bad;
+                    }
+            }
             // and the unclipped call must reproduce walk_tiles in ORDER
             std::vector<int64_t> full;
             walk_clipped(p, ts, 0, 0, (int)tw, (int)th, [&](int x, int y) { full.push_back((int64_t)y * tw + x); });
@@ -63,6 +87,10 @@ int main(int argc, char **argv)
         }
         std::sort(ref.begin(), ref.end());
         std::sort(got.begin(), got.end());
+        std::sort(got_blocks.begin(), got_blocks.end());
+        if (BW * BH <= 16 && ref != got_blocks) {
+            if (++bad < 10) fprintf(stderr, "block mismatch case %ld cfg %d: ref %zu got %zu\n", it, cfg, ref.size(), got_blocks.size());
+        }
         if (ref != got) {
             if (++bad < 10) fprintf(stderr, "mismatch case %ld cfg %d: ref %zu got %zu\n", it, cfg, ref.size(), got.size());
         }
