@@ -21,6 +21,34 @@ for N, C in ((60_000, 1), (120_000, 1), (250_000, 1), (600_000, 1), (1_000_000, 
     print(json.dumps(row), flush=True)
 
 
+# clustered scenes (the rule's thresholds were read off uniform scenes): the screen-space extent of the cloud shrunk towards
+# the image centre (x0.6 / x0.3: the same rows on 36 % / 9 % of the screen), and a mixture - a fifth of the rows in a cluster
+# of a tenth of the extent over a uniform background. "binned" is FORCED here: no skew test, no way back.
+def family(N, C, kind):
+    sc, W, H = bench.make_workload(N, dev, n_cameras=C)
+    if kind.startswith("x"):
+        sc["means"][:, :2] *= float(kind[1:])
+    else:  # mixture
+        n = N // 5
+        sc["means"][:n, :2] *= 0.1
+    return sc, W, H
+
+
+for N, C, kind in ((250_000, 1, "x0.6"), (250_000, 1, "x0.3"), (1_000_000, 1, "x0.6"), (1_000_000, 1, "x0.3"), (1_000_000, 1, "mix"),
+                   (250_000, 1, "mix"), (1_000_000, 4, "x0.6")):
+    sc, W, H = family(N, C, kind)
+    rad, m2, d, con, op = G.project(sc, W, H)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    row = {"N": N, "C": C, "scene": kind}
+    for name, env in (("auto", {}), ("auto_again", {}), ("legacy", {"GSX_ISECT_PATH": "legacy"}), ("binned", {"GSX_ISECT_PATH": "binned"})):
+        os.environ.pop("GSX_ISECT_PATH", None)
+        os.environ.update(env)
+        r = G.timed(m2, rad, d, con, op, C, tw, th)
+        row[name] = {"sum_ms": r["sum_ms"], "wall_ms": r["wall_ms"], "path": "binned" if any(k.startswith("binned_emit") for k in r) else "fused", "M": r["M"]}
+    os.environ.pop("GSX_ISECT_PATH", None)
+    print(json.dumps(row), flush=True)
+
+
 # packed rows of the c3 scene cut at a far plane: few rows, each of them a near (large) Gaussian
 import time
 import gsplat_amd
