@@ -851,10 +851,12 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
         return coo(r_means, means), coo(r_covars, covars), coo(r_quats, quats), coo(r_scales, scales), v_viewmats
     # several images: walk the packed rows Gaussian-major through a row map (each output row written once, no atomics; the map
     # is the one the SH backward asked for); a single image: every Gaussian has at most one row and the row-major kernel
-    # stores without atomics into zero-filled outputs - the Gaussian-major walk was tried there too: equal at c3 (35 us either
-    # way at 25 % visibility), 0.5 ms slower on the 49 M-Gaussian scene (fps_bwd 616 -> 463), where it visits 49 M Gaussians
-    # for 2 M rows
-    row_map = _packed_row_map(batch_ids, camera_ids, gaussian_ids, B, C, N) if (B * C > 1 and nnz > 0 and N > 0) else None
+    # stores without atomics into zero-filled outputs - the Gaussian-major walk is equal there at 25 % visibility (35 us either
+    # way) and 0.5 ms slower on the 49 M-Gaussian scene (fps_bwd 616 -> 463), where it visits 49 M Gaussians for 2 M rows.
+    # Round 5: with at least half of the Gaussians visible the single image goes Gaussian-major too - the three zero fills of
+    # the row-major route (40 B per Gaussian, 16.5 us at c3) are what it saves.
+    gaussian_major = B * C > 1 or 2 * nnz >= N
+    row_map = _packed_row_map(batch_ids, camera_ids, gaussian_ids, B, C, N) if (gaussian_major and nnz > 0 and N > 0) else None
     alloc = torch.empty_like if row_map is not None else torch.zeros_like
     v_means = alloc(means)
     v_covars = v_quats = v_scales = None
