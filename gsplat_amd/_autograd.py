@@ -80,17 +80,19 @@ def _proj_setup(ctx, inputs, output):
     ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, radii, conics, compensations)
 
 
-def _proj_backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_compensations):
+def _proj_backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_compensations, v_view_opacities=None):
     means, covars, quats, scales, viewmats, Ks, radii, conics, compensations = ctx.saved_tensors
     # v_means2d / v_conics are NOT made contiguous here: when they are column views of the compositing backward's AoS
     # gradient rows the op reads them in place through a row stride (_ops._row_view)
     if v_compensations is not None:
         v_compensations = v_compensations.contiguous()
-    v_means, v_covars, v_quats, v_scales, v_viewmats = _bwd("projection_ewa_3dgs_fused")(
+    res = _bwd("projection_ewa_3dgs_fused")(
         means, covars, quats, scales, viewmats, Ks, ctx.width, ctx.height, ctx.eps2d, ctx.camera_model, radii, conics,
         compensations, _z(v_means2d, ctx.m2_shape, conics), None if v_depths is None else v_depths.contiguous(),
-        _z(v_conics, conics.shape, conics), v_compensations, ctx.needs_input_grad[5],
+        _z(v_conics, conics.shape, conics), v_compensations, ctx.needs_input_grad[5], _v_view_opacities=v_view_opacities,
     )
+    v_means, v_covars, v_quats, v_scales, v_viewmats = res[:5]
+    v_opacities = res[5] if v_view_opacities is not None else None  # ProjectionWithViewOpacities only
     if not ctx.needs_input_grad[0]:
         v_means = None
     if not ctx.needs_input_grad[1]:
@@ -99,7 +101,31 @@ def _proj_backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_compensations)
         v_quats = None
     if not ctx.needs_input_grad[3]:
         v_scales = None
-    return (v_means, v_covars, v_quats, v_scales, None, v_viewmats) + (None,) * 9
+    return (v_means, v_covars, v_quats, v_scales, v_opacities, v_viewmats) + (None,) * 9
+
+
+class ProjectionWithViewOpacities(torch.autograd.Function):
+    """projection_ewa_3dgs_fused (dense rows) that also hands out the per-view opacities [..., C, N] - the broadcast view
+    rasterization() builds from `opacities` (reference gsplat/rendering.py:511-520) - as one of ITS outputs, so that their
+    cotangent comes back to the projection backward: the kernel sums it over the views while it reads the gradient rows it is
+    a column of. Left to autograd, the strided column is copied out by a kernel that reads every row again (7.7 us at c3) and,
+    with several views, reduced by another. gsplat_amd's rasterization() only; the op keeps the reference's schema."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        with torch._C._AutoDispatchBelowAutograd():
+            out = getattr(torch.ops, NS).projection_ewa_3dgs_fused.default(*args)
+        _proj_setup(ctx, args, out)
+        opacities, viewmats = args[4], args[5]
+        per_view = torch.broadcast_to(opacities[..., None, :], opacities.shape[:-1] + (viewmats.shape[-3], opacities.shape[-1]))
+        ctx.mark_non_differentiable(out[0])
+        return tuple(out) + (per_view,)
+
+    @staticmethod
+    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_compensations, v_per_view):
+        if not ctx.needs_input_grad[4]:
+            v_per_view = None
+        return _proj_backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_compensations, v_per_view)
 
 
 # ---- projection, packed (reference _wrapper.py:1065-1191) ---------------------------------------

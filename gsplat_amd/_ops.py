@@ -279,6 +279,30 @@ def _row_view(t: Tensor, width: int):
     return t.contiguous(), width
 
 
+def _elem_view(t: Tensor):
+    """(tensor, element stride) for a float tensor whose elements, taken in row-major order, sit at ONE uniform stride - a
+    contiguous tensor (stride 1) or a single column of the compositing backward's gradient rows (their row stride) - else a
+    contiguous copy. The kernels read such a column in place."""
+    if t.is_contiguous():
+        return t, 1
+    if t.dim() >= 1 and t.numel() > 0:
+        st = t.stride(-1) if t.shape[-1] != 1 else None
+        ok, expect = True, None
+        for d in range(t.dim() - 1, -1, -1):
+            if t.shape[d] == 1:
+                continue
+            if expect is None:
+                st, expect = t.stride(d), t.stride(d) * t.shape[d]
+            elif t.stride(d) != expect:
+                ok = False
+                break
+            else:
+                expect *= t.shape[d]
+        if ok and st is not None and st >= 1:
+            return t, int(st)
+    return t.contiguous(), 1
+
+
 def _common_row_views(ts, widths):
     """Three gradient tensors for the 2DGS projection backward: (tensors, common row stride or 0). If every one is a
     column view with the SAME row stride (views of one AoS gradient buffer) they are used in place, otherwise they are
@@ -725,7 +749,9 @@ def projection_ewa_3dgs_fused(means, covars, quats, scales, opacities, viewmats,
 @_op("projection_ewa_3dgs_fused_bwd")
 def projection_ewa_3dgs_fused_bwd(means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
                                   camera_model, radii, conics, compensations, v_means2d, v_depths, v_conics,
-                                  v_compensations, viewmats_requires_grad):
+                                  v_compensations, viewmats_requires_grad, *, _v_view_opacities=None):
+    """`_v_view_opacities` (private, gsplat_amd's own autograd only): the cotangent of the per-view opacities [..., C, N]; the
+    kernel sums it over the views and a sixth value, v_opacities [..., N], is returned."""
     batch_dims, B, C, N = _proj_dims(means, viewmats)
     means, viewmats, Ks = means.contiguous(), viewmats.contiguous(), Ks.contiguous()
     covars, quats, scales = _c(covars), _c(quats), _c(scales)
@@ -738,11 +764,18 @@ def projection_ewa_3dgs_fused_bwd(means, covars, quats, scales, viewmats, Ks, im
     v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
     v_means2d, m2_stride = _row_view(v_means2d, 2)
     v_conics, con_stride = _row_view(v_conics, 3)
-    call("gsx_project_ewa_bwd", ptr(means), ptr(covars), ptr(None if covars is not None else quats),
-         ptr(None if covars is not None else scales), ptr(viewmats), ptr(Ks), B, C, N, image_width, image_height,
-         eps2d, int(camera_model), ptr(radii.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
-         ptr_strided(v_means2d), m2_stride, ptr(_c(v_depths)), ptr_strided(v_conics), con_stride,
-         ptr(_c(v_compensations)), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
+    head = (ptr(means), ptr(covars), ptr(None if covars is not None else quats),
+            ptr(None if covars is not None else scales), ptr(viewmats), ptr(Ks), B, C, N, image_width, image_height,
+            eps2d, int(camera_model), ptr(radii.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
+            ptr_strided(v_means2d), m2_stride, ptr(_c(v_depths)), ptr_strided(v_conics), con_stride,
+            ptr(_c(v_compensations)))
+    if _v_view_opacities is not None:
+        v_view, opac_stride = _elem_view(_v_view_opacities)
+        v_opacities = torch.empty(tuple(batch_dims) + (N,), device=means.device, dtype=means.dtype)
+        call("gsx_project_ewa_bwd_opac", *head, ptr_strided(v_view), opac_stride, ptr(v_means), ptr(v_covars), ptr(v_quats),
+             ptr(v_scales), ptr(v_viewmats), ptr(v_opacities))
+        return v_means, v_covars, v_quats, v_scales, v_viewmats, v_opacities
+    call("gsx_project_ewa_bwd", *head, ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
     return v_means, v_covars, v_quats, v_scales, v_viewmats
 
 

@@ -304,6 +304,12 @@ struct ProjBwdArgs {
     const int32_t *row_map; // packed rows walked Gaussian-major: [B*C*N] -> packed row or -1
     int rows_out;           // sparse_grad: the per-Gaussian outputs are [nnz, .] rows (one per packed row), not [B, N, .]
     float *v_means, *v_covars, *v_quats, *v_scales, *v_viewmats;
+    // (optional) the cotangent of the per-view opacities [B, C, N] - a column of the compositing backward's gradient rows,
+    // opac_stride floats apart - summed over the views into v_opacities [B, N] by the Gaussian-major kernel: it reads those
+    // rows anyway, and autograd would otherwise copy the strided column out on its own (36 MB read for 4 MB at c3)
+    const float *v_view_opacities;
+    uint32_t opac_stride;
+    float *v_opacities;
 };
 
 // Gradient of one (camera, gaussian) pair wrt world mean (3), world covariance (3x3) and the camera
@@ -446,6 +452,7 @@ project_bwd_kernel(const ProjBwdArgs a)
         load_world_covar(fa, b, g, S);
     }
     float v_p[3] = {0.f, 0.f, 0.f}, v_S[9];
+    float v_o = 0.0f;
 #pragma unroll
     for (int i = 0; i < 9; ++i) v_S[i] = 0.0f;
 
@@ -468,6 +475,8 @@ project_bwd_kernel(const ProjBwdArgs a)
                 const Cam cam = load_cam(a.viewmats + ((size_t)b * a.C + c) * 16, a.Ks + ((size_t)b * a.C + c) * 9);
                 pair_vjp(a, cam, p, S, row, v_p, v_S, v_R, v_t, POSE);
             }
+            // dense rows: an invisible pair's entry is the exact zero the compositing backward never touched
+            if (a.v_view_opacities && (visible || !a.row_map)) v_o += a.v_view_opacities[(size_t)row * a.opac_stride];
         }
         if (POSE) {
             // all lanes of a wave usually share b; handle straddling waves batch by batch
@@ -489,6 +498,7 @@ project_bwd_kernel(const ProjBwdArgs a)
         }
     }
     if (live) store_gaussian_grads<false>(a, b, g, (size_t)b * a.N + g, v_p, v_S);
+    if (live && a.v_opacities) a.v_opacities[(size_t)b * a.N + g] = v_o;
 }
 
 // UNIQUE: every Gaussian appears in at most one row (a single image, B*C == 1): plain stores into the zero-filled
@@ -866,6 +876,46 @@ extern "C" int gsx_project_ewa_bwd(const float *means, const float *covars, cons
     if (v_viewmats) project_bwd_kernel<true><<<grid, block, 0, (hipStream_t)stream>>>(a);
     else project_bwd_kernel<false><<<grid, block, 0, (hipStream_t)stream>>>(a);
     return check_launch("project_ewa_bwd");
+}
+
+// gsx_project_ewa_bwd that also reduces the cotangent of the per-view opacities: v_view_opacities[(b C + c) N + g] at
+// v_view_opacities_stride floats per element (1 = contiguous; the row stride of gsx_raster3d_bwd's gradient rows when it is
+// their opacity column) -> v_opacities[b N + g] = sum over c. No counterpart in the reference, where the per-view opacities are a
+// broadcast view and autograd reduces their gradient with its own kernels (gsplat/rendering.py:511-520).
+extern "C" int gsx_project_ewa_bwd_opac(const float *means, const float *covars, const float *quats, const float *scales,
+                                        const float *viewmats, const float *Ks, uint32_t B, uint32_t C, uint32_t N,
+                                        uint32_t width, uint32_t height, float eps2d, int camera_model,
+                                        const int32_t *radii, const float *conics, const float *compensations,
+                                        const float *v_means2d, uint32_t v_means2d_stride, const float *v_depths,
+                                        const float *v_conics, uint32_t v_conics_stride, const float *v_compensations,
+                                        const float *v_view_opacities, uint32_t v_view_opacities_stride, float *v_means,
+                                        float *v_covars, float *v_quats, float *v_scales, float *v_viewmats,
+                                        float *v_opacities, void *stream)
+{
+    const int64_t count = (int64_t)B * N;
+    if (count == 0) return GSX_OK;
+    GSX_REQUIRE(v_view_opacities && v_opacities && v_view_opacities_stride >= 1, "gsx_project_ewa_bwd_opac: null opacity cotangent / output");
+    if (C == 0) {
+        if (hipMemsetAsync(v_opacities, 0, (size_t)count * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+            set_last_error("gsx_project_ewa_bwd_opac: memset failed");
+            return GSX_ERR_LAUNCH;
+        }
+        return GSX_OK;
+    }
+    int rc = check_proj_common("gsx_project_ewa_bwd_opac", means, covars, quats, scales, viewmats, Ks, camera_model);
+    if (rc != GSX_OK) return rc;
+    GSX_REQUIRE(radii && conics && v_means2d && v_conics, "gsx_project_ewa_bwd_opac: null input");
+    GSX_REQUIRE(v_means2d_stride >= 2 && v_conics_stride >= 3, "gsx_project_ewa_bwd_opac: row strides must be >= 2 / >= 3");
+    ProjBwdArgs a{};
+    fill_bwd(a, means, covars, quats, scales, viewmats, Ks, B, C, N, width, height, eps2d, camera_model, conics,
+             compensations, v_means2d, v_means2d_stride, v_depths, v_conics, v_conics_stride, v_compensations, v_means,
+             v_covars, v_quats, v_scales, v_viewmats);
+    a.radii = radii;
+    a.v_view_opacities = v_view_opacities; a.opac_stride = v_view_opacities_stride; a.v_opacities = v_opacities;
+    const dim3 grid((uint32_t)ceil_div(count, 256)), block(256);
+    if (v_viewmats) project_bwd_kernel<true><<<grid, block, 0, (hipStream_t)stream>>>(a);
+    else project_bwd_kernel<false><<<grid, block, 0, (hipStream_t)stream>>>(a);
+    return check_launch("project_ewa_bwd_opac");
 }
 
 extern "C" int gsx_project_ewa_packed_bwd(const float *means, const float *covars, const float *quats,

@@ -39,6 +39,10 @@ _DEPTH_MODES = ("D", "ED", "RGB+D", "RGB+ED")
 _HIT_MODES = ("d", "Ed", "RGB-d", "RGB-Ed")
 
 
+# GSPLAT_AMD_VIEW_OPACITIES=0 (A/B switch): the per-view opacities are a plain broadcast view again and autograd reduces their
+# gradient with its own kernels
+_VIEW_OPACITIES = __import__("os").environ.get("GSPLAT_AMD_VIEW_OPACITIES", "1") != "0"
+
 def _resolve_tile_size(tile_size: Optional[int], with_eval3d: bool = False, width: int = 0, height: int = 0) -> int:
     """None -> the path's default: 16 for the classic path; for the from-world path 16 at 1080p and above, else 8
     (reference gsplat/rendering.py:201-231)."""
@@ -179,6 +183,7 @@ def rasterization(
 
         clear_row_map_cache()  # the previous step's row map (and the id tensors it holds) can go
     calc_comp = rasterize_mode == "antialiased"
+    view_opacities = None
     if with_ut:
         # Unscented-Transform projection through the (possibly distorted) camera model; no gradient reaches the geometry
         # on this path (the reference runs the op under no_grad as well, Rendering.cpp:890-925)
@@ -189,6 +194,15 @@ def rasterization(
             far_plane=far_plane, radius_clip=radius_clip, calc_compensations=calc_comp, camera_model=camera_model,
             ut_params=ut_params, radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs,
             thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=ftheta_coeffs, global_z_order=global_z_order)
+    elif not packed and not calc_comp and means.is_cuda and _VIEW_OPACITIES:
+        # dense rows, classic mode: the per-view opacities come out of the projection's own autograd node, whose backward sums
+        # their gradient over the views inside the kernel that reads the gradient rows anyway (_autograd.py)
+        from ._wrapper import fully_fused_projection_view_opacities
+
+        proj = fully_fused_projection_view_opacities(
+            means, covars, quats, scales, viewmats_proj, Ks_proj, width, height, opacities, eps2d=eps2d,
+            near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, camera_model=camera_model)
+        proj, view_opacities = proj[:5], proj[5]
     else:
         proj = fully_fused_projection(
             means, covars, quats, scales, viewmats_proj, Ks_proj, width, height, eps2d=eps2d, near_plane=near_plane,
@@ -204,7 +218,8 @@ def rasterization(
     else:
         radii, means2d, depths, conics, compensations = proj
         batch_ids = camera_ids = gaussian_ids = image_ids = None
-        proj_opacities = torch.broadcast_to(opacities[..., None, :], batch_dims + (C_proj, N))
+        proj_opacities = view_opacities if view_opacities is not None else \
+            torch.broadcast_to(opacities[..., None, :], batch_dims + (C_proj, N))
     if compensations is not None:
         proj_opacities = proj_opacities * compensations
 

@@ -86,6 +86,20 @@ int gsx_project_ewa_bwd(const float *means, const float *covars, const float *qu
                         const float *v_compensations,
                         float *v_means, float *v_covars, float *v_quats, float *v_scales, float *v_viewmats,
                         void *stream);
+/* gsx_project_ewa_bwd that also reduces the cotangent of the per-view opacities: v_view_opacities[(b C + c) N + g], elements
+ * v_view_opacities_stride floats apart (1 = contiguous; the row stride of gsx_raster3d_bwd's gradient rows when it is their
+ * opacity column, read in place) -> v_opacities[b N + g] = sum over c. The kernel reads those rows anyway; autograd would
+ * otherwise copy the strided column out with a kernel of its own. No counterpart in the reference (the per-view opacities are a
+ * broadcast view there: gsplat/rendering.py:511-520). */
+int gsx_project_ewa_bwd_opac(const float *means, const float *covars, const float *quats, const float *scales,
+                             const float *viewmats, const float *Ks, uint32_t B, uint32_t C, uint32_t N,
+                             uint32_t width, uint32_t height, float eps2d, int camera_model,
+                             const int32_t *radii, const float *conics, const float *compensations,
+                             const float *v_means2d, uint32_t v_means2d_stride, const float *v_depths,
+                             const float *v_conics, uint32_t v_conics_stride, const float *v_compensations,
+                             const float *v_view_opacities, uint32_t v_view_opacities_stride, float *v_means,
+                             float *v_covars, float *v_quats, float *v_scales, float *v_viewmats,
+                             float *v_opacities, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * fully_fused_projection (packed): gsplat::projection_ewa_3dgs_packed{,_bwd}

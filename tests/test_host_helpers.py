@@ -114,3 +114,25 @@ def test_tile_walk_host_checks(tool, tmp_path):
                     os.path.join(root, "tools", tool + ".cpp")], check=True, timeout=600)
     r = subprocess.run([exe, "300000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " bad 0" in r.stdout, r.stdout + r.stderr
+
+
+def test_elem_view_reads_single_columns_in_place():
+    """_ops._elem_view: a contiguous tensor or ONE column of an array-of-structures buffer is handed to the kernels in place
+    (with its element stride); anything else is made contiguous."""
+    import torch
+    from gsplat_amd._ops import _elem_view
+
+    rows = torch.arange(5 * 9, dtype=torch.float32).reshape(5, 9)
+    t, st = _elem_view(rows[:, 5])
+    assert st == 9 and t.data_ptr() == rows[:, 5].data_ptr()
+    t, st = _elem_view(rows[:, 5].view(1, 5))  # [C, N] over the same column
+    assert st == 9 and t.data_ptr() == rows[:, 5].data_ptr()
+    big = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(6, 9)
+    t, st = _elem_view(big[:, 4].view(2, 3))  # two views, rows view-major
+    assert st == 9
+    t, st = _elem_view(torch.zeros(4, 3))
+    assert st == 1
+    t, st = _elem_view(torch.zeros(3, 4).t())  # not one uniform stride
+    assert st == 1 and t.is_contiguous()
+    t, st = _elem_view(torch.zeros(1).expand(4))  # stride 0: a copy
+    assert st == 1 and t.is_contiguous() and t.numel() == 4
