@@ -70,6 +70,7 @@ def _seg_cut(n_isects: int, n_images: int, tw: int, th: int) -> int:
     """Lists longer than this are cut into slices: max(2 slices, 3 x the mean list) - segments are for outliers."""
     return _cabi._lib.gsx_raster3d_seg_cut(int(n_isects), int(n_images), int(tw), int(th), SEG_LEN) if SEG_LEN > 0 else 1 << 62
 
+_ROWS_FILL_TORCH = os.environ.get("GSPLAT_AMD_ROWS_FILL", "") == "torch"  # A/B switch: torch.zeros in front of the compositing backward
 _hint = __import__("threading").local()
 _set_hint_compiled = None  # gsx_torch_set_long_tile_hint of libgsplat_amd_torch.so (the compiled op bodies read it)
 
@@ -977,10 +978,12 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     # line, which is what makes the kernel's atomic flush cheap; projection_ewa_3dgs_*_bwd reads the views in place.
     R = opacities.numel()
     geo = 8 if absgrad else 6
-    rows = torch.zeros((R, geo + D), device=means2d.device, dtype=means2d.dtype)
     longest = _consume_long_tile_hint() or _lookup_longest(flatten_ids)  # set by the autograd formula around this call
     segmented = (longest > SEG_MIN_LONGEST and not absgrad and D <= 4 and tile_size == 16
                  and longest > _seg_cut(flatten_ids.numel(), I, tw, th))
+    # the per-tile launch zero-fills the rows itself (inside its tile-order kernel: gsx_raster3d_bwd_fill)
+    own_fill = segmented or _ROWS_FILL_TORCH
+    rows = (torch.zeros if own_fill else torch.empty)((R, geo + D), device=means2d.device, dtype=means2d.dtype)
     # autograd hands cotangents over as views (the gradient of sum() is ONE float expanded to [.., H, W, D]): the per-tile
     # launch reads any layout that is linear in the pixel index in place instead of materialising 4 D bytes per pixel
     vrc_strides = None if segmented else _pixel_linear_strides(v_render_colors)
@@ -997,10 +1000,10 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     else:
         # workspace for the longest-first tile order of the launch (csrc/raster3d_bwd.hip: "longest tiles first")
         ws = torch.empty(_cabi._lib.gsx_raster3d_bwd_workspace_bytes(I, tw, th), device=means2d.device, dtype=torch.uint8)
-        call("gsx_raster3d_bwd_ws", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+        call("gsx_raster3d_bwd_fill", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
              ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
              ptr(last_ids.contiguous()), ptr_strided(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
-             image_width, image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D, vrc_strides[0],
+             image_width, image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D, 0 if own_fill else R, vrc_strides[0],
              vrc_strides[1], ptr(ws), ws.numel())
     v_means2d, v_conics = rows[:, 0:2].view(means2d.shape), rows[:, 2:5].view(conics.shape)
     v_opacities, v_colors = rows[:, 5].view(opacities.shape), rows[:, geo:].view(colors.shape)

@@ -203,7 +203,7 @@ __device__ __forceinline__ int64_t pixel_row(const Args &a, const TileCtx &t, ui
 int64_t tile_order_workspace_bytes(uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
 const int32_t *build_tile_order(const int32_t *isect_offsets, const int32_t *last_ids, uint32_t n_images, uint32_t tile_size,
                                 uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height, uint32_t n_isects, void *ws,
-                                int64_t ws_bytes, hipStream_t stream, int *rc);
+                                int64_t ws_bytes, hipStream_t stream, int *rc, void *zero_ptr = nullptr, int64_t zero_bytes = 0);
 
 // One wave per tile (raster3d_fwd_w.hip): <= 4 channels per launch, 16 x 16 tiles, no segments. GSX_RASTER3D_FWD=q|w at run time.
 // NOT the default: measured SLOWER than the four-waves-per-tile kernel (0.290 against 0.199 ms at c3, see raster3d_fwd_w.hip).

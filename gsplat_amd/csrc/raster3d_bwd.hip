@@ -1258,10 +1258,36 @@ extern "C" int gsx_raster3d_bwd_ws(
     uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows, uint32_t row_stride, int64_t v_colors_pixel_stride,
     int64_t v_colors_channel_stride, void *workspace, int64_t workspace_bytes, void *stream)
 {
+    return gsx_raster3d_bwd_fill(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas,
+                                 last_ids, v_render_colors, v_render_alphas, n_images, n_isects, cdim, width, height, tile_size,
+                                 tile_w, tile_h, has_abs, v_rows, row_stride, 0, v_colors_pixel_stride, v_colors_channel_stride,
+                                 workspace, workspace_bytes, stream);
+}
+
+// gsx_raster3d_bwd_ws for gradient rows that are NOT zero-filled yet: the call fills v_rows_to_fill rows of row_stride floats
+// itself - inside the tile-order cost kernel when one is launched (a kernel short of memory work: 36 MB of zeros cost it ~2 us
+// where a fill kernel of its own takes 7.5), with a memset otherwise. v_rows_to_fill == 0: the caller filled them.
+extern "C" int gsx_raster3d_bwd_fill(
+    const float *means2d, const float *conics, const float *colors, const float *opacities,
+    const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+    const float *render_alphas, const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+    uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+    uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows, uint32_t row_stride, int64_t v_rows_to_fill,
+    int64_t v_colors_pixel_stride, int64_t v_colors_channel_stride, void *workspace, int64_t workspace_bytes, void *stream)
+{
     using namespace gsx;
+    int64_t fill_bytes = v_rows_to_fill > 0 ? v_rows_to_fill * (int64_t)row_stride * 4 : 0;
+    auto fill_now      = [&]() -> int { // rows not filled by a kernel of this call
+        if (fill_bytes > 0 && v_rows && hipMemsetAsync(v_rows, 0, (size_t)fill_bytes, (hipStream_t)stream) != hipSuccess) {
+            set_last_error("gsx_raster3d_bwd_fill: memset failed");
+            return GSX_ERR_LAUNCH;
+        }
+        fill_bytes = 0;
+        return GSX_OK;
+    };
     GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster3d_bwd: tile_size must be in [1,16], got %u", tile_size);
     GSX_REQUIRE(cdim >= 1, "gsx_raster3d_bwd: channels must be >= 1");
-    if (n_isects == 0) return GSX_OK; // no intersections: nothing to add to the (zero-filled, possibly empty) gradient rows
+    if (n_isects == 0) return fill_now(); // no intersections: nothing to add to the (zero-filled, possibly empty) gradient rows
     GSX_REQUIRE(v_rows, "gsx_raster3d_bwd: null gradient output");
     GSX_REQUIRE(row_stride >= 6u + (has_abs ? 2u : 0u) + cdim,
                 "gsx_raster3d_bwd: row_stride %u too small for 6%s + %u channels", row_stride, has_abs ? " + 2" : "", cdim);
@@ -1286,12 +1312,15 @@ extern "C" int gsx_raster3d_bwd_ws(
     if (wide_m || (bwd_variant() == 'w' ? (tile_size == 16 && (cdim <= 4 || bwd_w_wide(a, has_abs != 0)))
                                         : (!has_abs && cdim <= 4 && bwd_variant() != 'r'))) {
         int rc       = GSX_OK;
+        const bool in_kernel = fill_bytes > 0 && (reinterpret_cast<uintptr_t>(v_rows) & 15u) == 0;
         a.tile_order = a.sp_active_tiles ? nullptr
                                          : build_tile_order(a.isect_offsets, a.last_ids, a.n_images, a.tile_size, a.tile_w, a.tile_h,
                                                             a.width, a.height, a.n_isects, workspace, workspace_bytes,
-                                                            (hipStream_t)stream, &rc);
+                                                            (hipStream_t)stream, &rc, in_kernel ? v_rows : nullptr, fill_bytes);
         if (rc != GSX_OK) return rc;
+        if (a.tile_order && in_kernel) fill_bytes = 0; // done by the cost kernel
     }
+    if (int rc = fill_now(); rc != GSX_OK) return rc;
     return has_abs ? bwd_dispatch<true>(a, (hipStream_t)stream) : bwd_dispatch<false>(a, (hipStream_t)stream);
 }
 

@@ -23,9 +23,18 @@ struct TileOrderArgs {
     uint32_t n_images, tile_w, tile_h, width, height, n_isects, n_blocks, per_xcd;
     int32_t *cost;  // [n_blocks]
     int32_t *order; // [n_blocks] in xcd_remap() index space
+    void *zero_ptr; // (optional) the launch's gradient rows, zero-filled by the cost kernel: 16-byte aligned, zero_bytes % 4 == 0
+    int64_t zero_bytes;
 };
 __global__ void __launch_bounds__(256) tile_order_cost_kernel(const TileOrderArgs a)
 {
+    if (a.zero_ptr) { // the gradient rows the compositing launch accumulates into: this kernel is short of memory work
+        const int64_t n16 = a.zero_bytes >> 4;
+        uint4 *z          = reinterpret_cast<uint4 *>(a.zero_ptr);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (blockIdx.x == 0 && (int64_t)threadIdx.x < ((a.zero_bytes & 15) >> 2))
+            reinterpret_cast<float *>(a.zero_ptr)[n16 * 4 + threadIdx.x] = 0.0f;
+    }
     const uint32_t lane = threadIdx.x & 63u, blk = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (blk >= a.n_blocks) return;
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
@@ -96,7 +105,7 @@ static int bwd_lpt_mode()
 // null when the launch keeps its launch order (no workspace, sparse layout, fewer tiles than workgroup slots, switched off).
 const int32_t *build_tile_order(const int32_t *isect_offsets, const int32_t *last_ids, uint32_t n_images, uint32_t tile_size,
                                 uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height, uint32_t n_isects, void *ws,
-                                int64_t ws_bytes, hipStream_t stream, int *rc)
+                                int64_t ws_bytes, hipStream_t stream, int *rc, void *zero_ptr, int64_t zero_bytes)
 {
     *rc = GSX_OK;
     const uint32_t n_blocks = tile_w * tile_h * n_images;
@@ -108,6 +117,7 @@ const int32_t *build_tile_order(const int32_t *isect_offsets, const int32_t *las
     o.width = width; o.height = height; o.n_isects = n_isects; o.n_blocks = n_blocks; o.per_xcd = (n_blocks + 7u) / 8u;
     o.cost  = reinterpret_cast<int32_t *>(ws);
     o.order = o.cost + n_blocks;
+    o.zero_ptr = zero_ptr; o.zero_bytes = zero_bytes; // the caller fills the rows itself when no order is built (null return)
     tile_order_cost_kernel<<<dim3((n_blocks + 3u) / 4u), dim3(256), 0, stream>>>(o);
     tile_order_sort_kernel<<<dim3((n_blocks + o.per_xcd - 1u) / o.per_xcd), dim3(1024), 0, stream>>>(o);
     *rc = check_launch("tile order");

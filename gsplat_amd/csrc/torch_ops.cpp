@@ -733,12 +733,14 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
     const Tensor v_ra = v_render_alphas_.defined() ? contig(v_render_alphas_) : Tensor(); // undefined = zeros
     // ONE zero-filled array-of-structures buffer [R][6 (+2) + D]; the gradients are COLUMN VIEWS of it (gsplat_amd.h)
     const int64_t R = opac.numel(), geo = absgrad ? 8 : 6;
-    Tensor rows = at::zeros({R, geo + r.D}, means2d.options());
     int64_t longest = g_long_tile_hint; // set by the autograd formula around this call (gsplat_amd/_autograd.py)
     g_long_tile_hint = 0;
     if (longest == 0) longest = lookup_longest(flatten_ids_); // e.g. the reference's own autograd formula
-    if (kSegLen > 0 && !absgrad && r.D <= 4 && tile_size == 16
-        && longest > gsx_raster3d_seg_cut(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)kSegLen)) {
+    const bool segmented = kSegLen > 0 && !absgrad && r.D <= 4 && tile_size == 16
+        && longest > gsx_raster3d_seg_cut(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)kSegLen);
+    // the per-tile launch zero-fills the rows itself (inside its tile-order kernel: gsx_raster3d_bwd_fill)
+    Tensor rows = segmented ? at::zeros({R, geo + r.D}, means2d.options()) : at::empty({R, geo + r.D}, means2d.options());
+    if (segmented) {
         Tensor ws = at::empty({gsx_raster3d_bwd_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
                                                                   (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
         Timed timed_("gsx_raster3d_bwd", L.stream);
@@ -753,11 +755,11 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
         // workspace for the longest-first tile order of the launch (csrc/raster3d_bwd.hip: "longest tiles first")
         Tensor ws = at::empty({gsx_raster3d_bwd_workspace_bytes((uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th)}, means2d.options().dtype(at::kByte));
         Timed timed_("gsx_raster3d_bwd", L.stream);
-        check(gsx_raster3d_bwd_ws(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
+        check(gsx_raster3d_bwd_fill(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
                                   masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
                                   cp<int32_t>(flat), fp(ra), cp<int32_t>(li), fp(v_rc), fp(v_ra), (uint32_t)r.I, (uint32_t)flat.numel(),
                                   (uint32_t)r.D, (uint32_t)width, (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th,
-                                  absgrad ? 1 : 0, mp<float>(rows), (uint32_t)(geo + r.D), (int64_t)-1, (int64_t)1, ws.mutable_data_ptr(), ws.numel(),
+                                  absgrad ? 1 : 0, mp<float>(rows), (uint32_t)(geo + r.D), R, (int64_t)-1, (int64_t)1, ws.mutable_data_ptr(), ws.numel(),
                                   L.stream),
               "gsx_raster3d_bwd");
     }

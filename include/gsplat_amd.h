@@ -509,6 +509,17 @@ int gsx_raster3d_bwd_ws(const float *means2d, const float *conics, const float *
                      uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                      int has_abs, float *v_rows, uint32_t row_stride, int64_t v_colors_pixel_stride,
                      int64_t v_colors_channel_stride, void *workspace, int64_t workspace_bytes, void *stream);
+/* gsx_raster3d_bwd_ws for gradient rows that are NOT zero-filled yet: the call fills v_rows_to_fill rows of row_stride floats
+ * itself - inside the tile-order cost kernel when one is launched (a kernel short of memory work), with a memset otherwise.
+ * v_rows_to_fill == 0 is exactly gsx_raster3d_bwd_ws (the caller filled the rows). */
+int gsx_raster3d_bwd_fill(const float *means2d, const float *conics, const float *colors, const float *opacities,
+                     const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                     const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,
+                     const float *v_render_colors, const float *v_render_alphas,
+                     uint32_t n_images, uint32_t n_isects, uint32_t cdim,
+                     uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                     int has_abs, float *v_rows, uint32_t row_stride, int64_t v_rows_to_fill, int64_t v_colors_pixel_stride,
+                     int64_t v_colors_channel_stride, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Sparse pixel sets: gsplat::rasterize_to_pixels_sparse{,_bwd} (ext.cpp:1090-1104; RasterizeToPixelsSparse{Fwd,Bwd}.cu,
  * RasterizeSparseAddressing.cuh). One workgroup per ACTIVE tile (active_tiles int32 [AT], ascending dense tile ids;
