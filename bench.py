@@ -88,6 +88,16 @@ def raster_source_hash():
     return h.hexdigest()[:16]
 
 
+def stage_of(entry: str) -> str:
+    """C-ABI entries that are one stage of the step table: the per-tile compositing backward is gsx_raster3d_bwd / _ws (with a
+    tile-order workspace) / _fill (zero-fills its rows itself) / _seg (long lists in slices); the dense projection backward is
+    gsx_project_ewa_bwd / _opac (also reduces the per-view opacity cotangent)."""
+    for tail in ("_ws", "_fill", "_seg", "_opac"):
+        if entry.endswith(tail) and ("raster3d_bwd" in entry or "raster3d_fwd" in entry or "project_ewa_bwd" in entry):
+            return entry[: -len(tail)]
+    return entry
+
+
 def algorithmic_bytes(M, V, P, T, D):
     """SURVEY.md §8(d), fp32, compulsory traffic only."""
     fwd = (28 + 4 * D) * M + 4 * T + (4 * D + 8) * P
@@ -338,7 +348,8 @@ def main():
     # The headline window carries NO instrumentation (an event pair around each of the two compositing launches costs the step
     # ~50 us: r4d measured 1.05 ms per step with them, 0.996 ms without). The dominant kernels are timed live with HIP events
     # (on the launch stream) in the FIRST REPEAT of the same window, which is reported but kept out of value_median / value_best.
-    raster_entries = ("gsx_raster3d_fwd", "gsx_raster3d_bwd", "gsx_raster3d_bwd_ws", "gsx_raster3d_fwd_seg", "gsx_raster3d_bwd_seg")
+    raster_entries = ("gsx_raster3d_fwd", "gsx_raster3d_bwd", "gsx_raster3d_bwd_ws", "gsx_raster3d_bwd_fill", "gsx_raster3d_fwd_seg",
+                      "gsx_raster3d_bwd_seg")
     elapsed, meta, prof = timed(step, args.steps, 0, barrier, profile_only=raster_entries if args.lean else None)
 
     def max_over_ranks(x: float) -> float:
@@ -361,9 +372,9 @@ def main():
     else:
         e_i, _, prof = timed(step, args.steps, 0, barrier, profile_only=raster_entries)
         instrumented_window_s = max_over_ranks(e_i)
-    merged = {}  # gsx_raster3d_bwd / _ws / _seg are one stage: their launch times are pooled, never overwritten
+    merged = {}  # gsx_raster3d_bwd / _ws / _fill / _seg are one stage: their launch times are pooled, never overwritten
     for k, v in prof.items():
-        merged.setdefault(k.replace("_ws", "").replace("_seg", ""), []).extend(v)
+        merged.setdefault(stage_of(k), []).extend(v)
     prof = merged
     if distributed:
         _gd.reset_exchange_stats()
@@ -431,7 +442,9 @@ def main():
     D = 3
     b_fwd, b_bwd = algorithmic_bytes(M, V, P_local, T_local, D)
     mean_ms = {k: sum(v) / len(v) for k, v in prof.items()}
-    per_step_ms = {k.replace("gsx_raster3d_bwd_ws", "gsx_raster3d_bwd"): sum(v) / max(n_stage, 1) for k, v in stage_prof.items()}
+    per_step_ms = {}
+    for k, v in stage_prof.items():
+        per_step_ms[stage_of(k)] = per_step_ms.get(stage_of(k), 0.0) + sum(v) / max(n_stage, 1)
     t_fwd = mean_ms.get("gsx_raster3d_fwd", float("nan"))
     t_bwd = mean_ms.get("gsx_raster3d_bwd", float("nan"))
     dom, dom_bytes, dom_ms = ("raster3d_bwd", b_bwd, t_bwd) if not (t_fwd > t_bwd) else ("raster3d_fwd", b_fwd, t_fwd)
@@ -647,7 +660,10 @@ def main():
             step4 = make_step(l4, sc4, packed=False, distributed=False)
             t4, m4, _ = timed(step4, steps4, 2, torch.cuda.synchronize)
             _, _, p4 = timed(step4, steps4, 0, torch.cuda.synchronize, profile_only=raster_entries)
-            p4 = {k.replace("_ws", "").replace("_seg", ""): v for k, v in p4.items()}
+            p4m = {}
+            for k, v in p4.items():
+                p4m.setdefault(stage_of(k), []).extend(v)
+            p4 = p4m
             return {
                 "workload": f"c4 per-rank work on one GPU: {n4} synthetic Gaussians, {c4n}x1920x1080 cameras batched, SH deg 3, "
                             "fwd+bwd, no exchange",

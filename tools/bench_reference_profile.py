@@ -88,7 +88,7 @@ def run(batch, channels, grid, packed, repeats, dev, stages=None, quiet=False):
             bwd()
         pb = _cabi.profile_end()
         stages = {"fwd_ms": {k.replace("gsx_", ""): round(sum(v) / 5, 4) for k, v in sorted(pf.items())},
-                  "bwd_ms": {k.replace("gsx_", "").replace("raster3d_bwd_ws", "raster3d_bwd"): round(sum(v) / 5, 4)
+                  "bwd_ms": {k.replace("gsx_", "").replace("raster3d_bwd_ws", "raster3d_bwd").replace("raster3d_bwd_fill", "raster3d_bwd").replace("project_ewa_bwd_opac", "project_ewa_bwd"): round(sum(v) / 5, 4)
                              for k, v in sorted(pb.items())}}
     pub = PUBLISHED.get((batch, channels, grid, packed))
     row = {"batch": batch, "channels": channels, "scene_grid": grid, "packed": packed, "n_gaussians": int(means.shape[0]),
