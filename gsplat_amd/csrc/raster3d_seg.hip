@@ -40,9 +40,21 @@ bool raster3d_bwd_uses_variant_w();
 // its longest unit of work); the pre-pass costs the same either way (it evaluates every entry of the long lists once).
 // Garden x25, backward in ms (profiles/r09_ab.md): slices of 1024 0.863, 512 0.634 - 0.653, 256 0.667 - 0.698; variant T on
 // slices of 1024: 0.647 - 0.656. GSX_BWD_SEG_DIV overrides the divisor (A/B).
+// Which kernel walks the slices: variant T (four waves per unit) unless GSX_RASTER3D_BWD_SEG=w. Variant W over half-length
+// slices ties it on the garden x25 scene (0.645 against 0.646 ms) and LOSES on the 49 M-Gaussian scene of the reference's
+// profiling table (7.1 M intersections: 1.21 against 0.89 ms; slices of 1024 / 256: 1.12 / 1.27) - profiles/r09_ab.md #40.
+static bool seg_bwd_on_variant_w()
+{
+    static const bool w = [] {
+        const char *e = getenv("GSX_RASTER3D_BWD_SEG");
+        return e && e[0] == 'w';
+    }();
+    return w && raster3d_bwd_uses_variant_w();
+}
+
 static uint32_t bwd_slice_len(uint32_t seg_len)
 {
-    if (!raster3d_bwd_uses_variant_w() || seg_len == 0) return seg_len;
+    if (!seg_bwd_on_variant_w() || seg_len == 0) return seg_len;
     static const uint32_t div = [] {
         const char *e = getenv("GSX_BWD_SEG_DIV");
         const int v   = e ? atoi(e) : 2;
@@ -363,7 +375,7 @@ extern "C" int gsx_raster3d_bwd_seg(
         seg_bwd_prefix_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(p);
     }
     a.seg_mode = 2; a.seg_grid = p.max_items + n_blocks; // the slices first, the short tiles behind them
-    if (raster3d_bwd_uses_variant_w()) {
+    if (seg_bwd_on_variant_w()) {
         // one wave per unit: a short tile of up to seg_cut entries started late is the launch's tail - take them longest-first
         // (the order lives behind the segment plan in the workspace, when the caller sized it with the backward's own function)
         unsigned char *ord = base + align256(seg_layout(n_isects, n_blocks, cdim, seg_len, base, nullptr));
@@ -373,7 +385,7 @@ extern "C" int gsx_raster3d_bwd_seg(
                                         left, s, &orc);
         if (orc != GSX_OK) return orc;
     }
-    rc = raster3d_bwd_uses_variant_w() ? raster3d_bwd_w_launch_items(a, s) : raster3d_bwd_t_launch_items(a, s);
+    rc = seg_bwd_on_variant_w() ? raster3d_bwd_w_launch_items(a, s) : raster3d_bwd_t_launch_items(a, s);
     if (rc != GSX_OK) return rc;
     return check_launch("raster3d_bwd_seg");
 }

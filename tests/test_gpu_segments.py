@@ -221,3 +221,20 @@ def test_stage_level_callers_get_segments_without_a_hint(G):
     # through the raw torch ops too (what the reference's Python calls)
     out = torch.ops.gsplat.rasterize_to_pixels_3dgs(m2, con, colors, op, None, None, W, H, 16, off, fl, False, False)
     assert torch.equal(out[0], res["hinted"][0])
+
+
+def test_segmented_backward_on_the_one_wave_kernel():
+    """GSX_RASTER3D_BWD_SEG=w (read once per process): the slices walked by variant W - half-length slices, short tiles
+    longest-first - instead of the default four-wave kernel; the same comparisons as above, in a subprocess."""
+    import os
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSX_RASTER3D_BWD_SEG="w")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_segments.py"), "-q", "-m", "gpu", "-x",
+                        "-p", "no:cacheprovider", "-k", "segmented_backward_matches_per_tile_walk and (mixed or opaque) and not 1]"],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
