@@ -141,17 +141,19 @@ def _projp_setup(ctx, inputs, output):
 
 
 def _projp_backward(ctx, v_batch_ids, v_camera_ids, v_gaussian_ids, v_indptr, v_radii, v_means2d, v_depths, v_conics,
-                    v_compensations):
+                    v_compensations, v_view_opacities=None):
     (means, covars, quats, scales, viewmats, Ks, batch_ids, camera_ids, gaussian_ids, conics,
      compensations) = ctx.saved_tensors
     if v_compensations is not None:
         v_compensations = v_compensations.contiguous()
-    v_means, v_covars, v_quats, v_scales, v_viewmats = _bwd("projection_ewa_3dgs_packed")(
+    res = _bwd("projection_ewa_3dgs_packed")(
         means, covars, quats, scales, viewmats, Ks, ctx.width, ctx.height, ctx.eps2d, ctx.camera_model,
         ctx.sparse_grad, batch_ids, camera_ids, gaussian_ids, conics, compensations,
         _z(v_means2d, ctx.m2_shape, conics), None if v_depths is None else v_depths.contiguous(),
-        _z(v_conics, conics.shape, conics), v_compensations, ctx.needs_input_grad[5],
+        _z(v_conics, conics.shape, conics), v_compensations, ctx.needs_input_grad[5], _v_view_opacities=v_view_opacities,
     )
+    v_means, v_covars, v_quats, v_scales, v_viewmats = res[:5]
+    v_opacities = res[5] if v_view_opacities is not None else None  # PackedProjectionWithViewOpacities only
     if not ctx.needs_input_grad[0]:
         v_means = None
     if not ctx.needs_input_grad[1]:
@@ -160,7 +162,34 @@ def _projp_backward(ctx, v_batch_ids, v_camera_ids, v_gaussian_ids, v_indptr, v_
         v_quats = None
     if not ctx.needs_input_grad[3]:
         v_scales = None
-    return (v_means, v_covars, v_quats, v_scales, None, v_viewmats) + (None,) * 10
+    return (v_means, v_covars, v_quats, v_scales, v_opacities, v_viewmats) + (None,) * 10
+
+
+class PackedProjectionWithViewOpacities(torch.autograd.Function):
+    """projection_ewa_3dgs_packed that also hands out the packed rows' opacities [nnz] (`opacities[gaussian_ids]` in the
+    reference's rasterization(), gsplat/rendering.py:507-510) as one of ITS outputs: their cotangent - a column of the
+    compositing backward's gradient rows - comes back to the projection backward, whose Gaussian-major kernel sums it per
+    Gaussian while it walks the row map (no index_add, no zero fill). gsplat_amd's rasterization() only."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        with torch._C._AutoDispatchBelowAutograd():
+            out = getattr(torch.ops, NS).projection_ewa_3dgs_packed.default(*args)
+        _projp_setup(ctx, args, out)
+        opacities = args[4]
+        batch_ids, gaussian_ids = out[0], out[2]
+        N = opacities.shape[-1]
+        flat_ids = gaussian_ids if opacities.dim() == 1 else batch_ids * N + gaussian_ids
+        row_opacities = opacities.reshape(-1).index_select(0, flat_ids)
+        ctx.mark_non_differentiable(*[t for t in out[:5] if t is not None])
+        return tuple(out) + (row_opacities,)
+
+    @staticmethod
+    def backward(ctx, v_b, v_c, v_g, v_indptr, v_radii, v_means2d, v_depths, v_conics, v_compensations, v_row_opacities):
+        if not ctx.needs_input_grad[4]:
+            v_row_opacities = None
+        return _projp_backward(ctx, v_b, v_c, v_g, v_indptr, v_radii, v_means2d, v_depths, v_conics, v_compensations,
+                               v_row_opacities)
 
 
 # ---- rasterize_to_pixels (reference _wrapper.py:2010-2117) --------------------------------------

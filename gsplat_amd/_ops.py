@@ -843,7 +843,9 @@ def projection_ewa_3dgs_packed(means, covars, quats, scales, opacities, viewmats
 def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
                                    camera_model, sparse_grad, batch_ids, camera_ids, gaussian_ids, conics,
                                    compensations, v_means2d, v_depths, v_conics, v_compensations,
-                                   viewmats_requires_grad):
+                                   viewmats_requires_grad, *, _v_view_opacities=None):
+    """`_v_view_opacities` (private, gsplat_amd's own autograd only): the cotangent of the packed rows' opacities [nnz]; a
+    sixth value, v_opacities [..., N], is returned - summed in the Gaussian-major kernel where that one runs."""
     batch_dims, B, C, N = _proj_dims(means, viewmats)
     means, viewmats, Ks = means.contiguous(), viewmats.contiguous(), Ks.contiguous()
     covars, quats, scales = _c(covars), _c(quats), _c(scales)
@@ -857,6 +859,11 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
             ptr(gaussian_ids.contiguous()), ptr(conics.contiguous()), ptr(_c(compensations)),
             ptr_strided(v_means2d), m2_stride, ptr(_c(v_depths)), ptr_strided(v_conics), con_stride,
             ptr(_c(v_compensations)))
+    def scatter_opacities():  # where no Gaussian-major kernel runs: what autograd does for opacities[ids] (an index_add)
+        flat = torch.zeros(B * N, device=means.device, dtype=means.dtype)
+        flat.index_add_(0, batch_ids * N + gaussian_ids if B > 1 else gaussian_ids, _v_view_opacities.reshape(-1))
+        return flat.reshape(tuple(batch_dims) + (N,))
+
     if sparse_grad:
         # COO gradients exactly as the reference builds them (Projection.cpp:1125-1200): the kernel writes one [nnz, .] row per
         # packed row, indices = gaussian_ids, coalesced iff a single image (every Gaussian appears at most once). No dense
@@ -882,7 +889,8 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
             sp = torch.sparse_coo_tensor(indices, vals, size=size, is_coalesced=coalesced)
             return sp if len(batch_dims) <= 1 else sp.to_dense().reshape(like.shape)
 
-        return coo(r_means, means), coo(r_covars, covars), coo(r_quats, quats), coo(r_scales, scales), v_viewmats
+        res = (coo(r_means, means), coo(r_covars, covars), coo(r_quats, quats), coo(r_scales, scales), v_viewmats)
+        return res if _v_view_opacities is None else res + (scatter_opacities(),)
     # several images: walk the packed rows Gaussian-major through a row map (each output row written once, no atomics; the map
     # is the one the SH backward asked for); a single image: every Gaussian has at most one row and the row-major kernel
     # stores without atomics into zero-filled outputs - the Gaussian-major walk is equal there at 25 % visibility (35 us either
@@ -898,12 +906,22 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
         v_covars = alloc(covars)
     else:
         v_quats, v_scales = alloc(quats), alloc(scales)
-    call("gsx_project_ewa_packed_bwd", *head, ptr(row_map), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales),
-         ptr(v_viewmats))
+    v_opacities = None
+    if _v_view_opacities is not None and row_map is not None:
+        v_view, opac_stride = _elem_view(_v_view_opacities)
+        v_opacities = torch.empty(tuple(batch_dims) + (N,), device=means.device, dtype=means.dtype)
+        call("gsx_project_ewa_packed_bwd_opac", *head, ptr_strided(v_view), opac_stride, ptr(row_map), ptr(v_means), ptr(v_covars),
+             ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities))
+    else:
+        call("gsx_project_ewa_packed_bwd", *head, ptr(row_map), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales),
+             ptr(v_viewmats))
+        if _v_view_opacities is not None:
+            v_opacities = scatter_opacities()
     # the last consumer of a step's row map (autograd runs the SH backward, created later, first): drop it here, and with it
     # the references that keep the step's id tensors alive - a stage-level caller has no next rasterization() to do that
     clear_row_map_cache()
-    return v_means, v_covars, v_quats, v_scales, v_viewmats
+    res = (v_means, v_covars, v_quats, v_scales, v_viewmats)
+    return res if _v_view_opacities is None else res + (v_opacities,)
 
 
 # ----------------------------------------------------------------------------------------------

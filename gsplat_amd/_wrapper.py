@@ -267,6 +267,21 @@ def fully_fused_projection_view_opacities(means, covars, quats, scales, viewmats
         radius_clip, calc_compensations, _camera_model_id(camera_model))
 
 
+def fully_fused_projection_packed_row_opacities(means, covars, quats, scales, viewmats, Ks, width, height, opacities, eps2d=0.3,
+                                                near_plane=0.01, far_plane=1e10, radius_clip=0.0, calc_compensations=False,
+                                                camera_model="pinhole"):
+    """fully_fused_projection(packed=True) + the packed rows' opacities [nnz] as a tenth output whose gradient the projection
+    backward reduces (``_autograd.PackedProjectionWithViewOpacities``). What gsplat_amd's rasterization() calls; not part of
+    the reference's surface."""
+    c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+    if covars is None:
+        assert quats is not None and scales is not None, "covars or (quats, scales) required"
+    return _autograd.PackedProjectionWithViewOpacities.apply(
+        means.contiguous(), c(covars), None if covars is not None else c(quats), None if covars is not None else c(scales),
+        opacities.contiguous(), viewmats.contiguous(), Ks.contiguous(), width, height, eps2d, near_plane, far_plane,
+        radius_clip, False, calc_compensations, _camera_model_id(camera_model))
+
+
 @torch.no_grad()
 def isect_tiles(
     means2d: Tensor,  # [..., N, 2] or [nnz, 2]

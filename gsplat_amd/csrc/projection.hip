@@ -975,6 +975,52 @@ extern "C" int gsx_project_ewa_packed_bwd(const float *means, const float *covar
     return check_launch("project_ewa_packed_bwd");
 }
 
+// gsx_project_ewa_packed_bwd, Gaussian-major (row_map required), that also reduces the cotangent of the packed rows'
+// opacities: v_view_opacities[row] at v_view_opacities_stride floats per row (the opacity column of gsx_raster3d_bwd's gradient
+// rows, read in place) -> v_opacities[b N + g] = sum over the Gaussian's rows, 0 for a Gaussian without rows. Replaces the
+// index_add (+ zero fill) autograd runs for `opacities[gaussian_ids]` (reference gsplat/rendering.py:507-510).
+extern "C" int gsx_project_ewa_packed_bwd_opac(const float *means, const float *covars, const float *quats,
+                                               const float *scales, const float *viewmats, const float *Ks, uint32_t B,
+                                               uint32_t C, uint32_t N, uint32_t width, uint32_t height, float eps2d,
+                                               int camera_model, int64_t nnz, const int64_t *batch_ids,
+                                               const int64_t *camera_ids, const int64_t *gaussian_ids, const float *conics,
+                                               const float *compensations, const float *v_means2d,
+                                               uint32_t v_means2d_stride, const float *v_depths, const float *v_conics,
+                                               uint32_t v_conics_stride, const float *v_compensations,
+                                               const float *v_view_opacities, uint32_t v_view_opacities_stride,
+                                               const int32_t *row_map, float *v_means, float *v_covars, float *v_quats,
+                                               float *v_scales, float *v_viewmats, float *v_opacities, void *stream)
+{
+    GSX_REQUIRE(row_map && v_view_opacities && v_opacities && v_view_opacities_stride >= 1,
+                "gsx_project_ewa_packed_bwd_opac: needs the row map, the opacity cotangent and its output");
+    hipStream_t s = (hipStream_t)stream;
+    if ((int64_t)B * N == 0) return GSX_OK;
+    if (nnz <= 0) {
+        if (hipMemsetAsync(v_opacities, 0, (size_t)B * N * sizeof(float), s) != hipSuccess) {
+            set_last_error("gsx_project_ewa_packed_bwd_opac: memset failed");
+            return GSX_ERR_LAUNCH;
+        }
+        return GSX_OK;
+    }
+    int rc = check_proj_common("gsx_project_ewa_packed_bwd_opac", means, covars, quats, scales, viewmats, Ks, camera_model);
+    if (rc != GSX_OK) return rc;
+    GSX_REQUIRE(batch_ids && camera_ids && gaussian_ids && conics && v_means2d && v_conics,
+                "gsx_project_ewa_packed_bwd_opac: null input");
+    GSX_REQUIRE(v_means2d_stride >= 2 && v_conics_stride >= 3,
+                "gsx_project_ewa_packed_bwd_opac: row strides must be >= 2 / >= 3");
+    ProjBwdArgs a{};
+    fill_bwd(a, means, covars, quats, scales, viewmats, Ks, B, C, N, width, height, eps2d, camera_model, conics,
+             compensations, v_means2d, v_means2d_stride, v_depths, v_conics, v_conics_stride, v_compensations, v_means,
+             v_covars, v_quats, v_scales, v_viewmats);
+    a.nnz = nnz; a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
+    a.row_map = row_map;
+    a.v_view_opacities = v_view_opacities; a.opac_stride = v_view_opacities_stride; a.v_opacities = v_opacities;
+    const dim3 g2((uint32_t)ceil_div((int64_t)B * N, 256));
+    if (v_viewmats) project_bwd_kernel<true><<<g2, dim3(256), 0, s>>>(a);
+    else project_bwd_kernel<false><<<g2, dim3(256), 0, s>>>(a);
+    return check_launch("project_ewa_packed_bwd_opac");
+}
+
 // sparse_grad=True (reference Projection.cpp:1125-1200, kernel ProjectionEWA3DGSPacked.cu:385-684): the per-Gaussian
 // gradients are [nnz, .] ROWS, one per packed row, written once each with plain stores (the caller wraps them as COO over
 // gaussian_ids; no dense [N, .] tensor exists anywhere). v_viewmats as in gsx_project_ewa_packed_bwd.

@@ -203,6 +203,14 @@ def rasterization(
             means, covars, quats, scales, viewmats_proj, Ks_proj, width, height, opacities, eps2d=eps2d,
             near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, camera_model=camera_model)
         proj, view_opacities = proj[:5], proj[5]
+    elif packed and not sparse_grad and not calc_comp and means.is_cuda and _VIEW_OPACITIES:
+        # packed rows: the rows' opacities come out of the projection's own autograd node as well (no index_add in the backward)
+        from ._wrapper import fully_fused_projection_packed_row_opacities
+
+        proj = fully_fused_projection_packed_row_opacities(
+            means, covars, quats, scales, viewmats_proj, Ks_proj, width, height, opacities, eps2d=eps2d,
+            near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, camera_model=camera_model)
+        proj, view_opacities = proj[:9], proj[9]
     else:
         proj = fully_fused_projection(
             means, covars, quats, scales, viewmats_proj, Ks_proj, width, height, eps2d=eps2d, near_plane=near_plane,
@@ -213,7 +221,8 @@ def rasterization(
         batch_ids, camera_ids, gaussian_ids, indptr, radii, means2d, depths, conics, compensations = proj
         # index_select (backward = atomic index_add) instead of advanced indexing (backward = index_put, which SORTS
         # the nnz indices first: ~0.2 ms per step at 1M Gaussians)
-        proj_opacities = opacities.reshape(-1).index_select(0, batch_ids * N + gaussian_ids if B > 1 else gaussian_ids)
+        proj_opacities = view_opacities if view_opacities is not None else \
+            opacities.reshape(-1).index_select(0, batch_ids * N + gaussian_ids if B > 1 else gaussian_ids)
         image_ids = camera_ids if B == 1 else batch_ids * C_proj + camera_ids
     else:
         radii, means2d, depths, conics, compensations = proj

@@ -159,6 +159,20 @@ int gsx_project_ewa_packed_bwd(const float *means, const float *covars, const fl
                                                          row written once (no atomics, outputs need no zero-fill) */,
                                float *v_means, float *v_covars, float *v_quats, float *v_scales,
                                float *v_viewmats, void *stream);
+/* gsx_project_ewa_packed_bwd, Gaussian-major (row_map required), that also reduces the cotangent of the packed rows'
+ * opacities: v_view_opacities[row], v_view_opacities_stride floats apart (1 = contiguous; the row stride of gsx_raster3d_bwd's
+ * gradient rows when it is their opacity column) -> v_opacities[b N + g] = sum over the Gaussian's rows (0 without rows).
+ * Replaces the index_add (+ zero fill) autograd runs for opacities[gaussian_ids] (reference gsplat/rendering.py:507-510). */
+int gsx_project_ewa_packed_bwd_opac(const float *means, const float *covars, const float *quats, const float *scales,
+                                    const float *viewmats, const float *Ks, uint32_t B, uint32_t C, uint32_t N,
+                                    uint32_t width, uint32_t height, float eps2d, int camera_model, int64_t nnz,
+                                    const int64_t *batch_ids, const int64_t *camera_ids, const int64_t *gaussian_ids,
+                                    const float *conics, const float *compensations, const float *v_means2d,
+                                    uint32_t v_means2d_stride, const float *v_depths, const float *v_conics,
+                                    uint32_t v_conics_stride, const float *v_compensations,
+                                    const float *v_view_opacities, uint32_t v_view_opacities_stride,
+                                    const int32_t *row_map, float *v_means, float *v_covars, float *v_quats,
+                                    float *v_scales, float *v_viewmats, float *v_opacities, void *stream);
 /* sparse_grad=True (reference host fn Projection.cpp:1125-1200: `at::zeros({nnz, .})` + make_sparse_coo_grad; kernel
  * ProjectionEWA3DGSPacked.cu:385-684 with sparse_grad): the per-Gaussian gradients are [nnz, 3] / [nnz, 6] / [nnz, 4] /
  * [nnz, 3] ROWS, one per packed row, each written exactly once (no zero-fill needed, no dense [N, .] tensor anywhere). The
