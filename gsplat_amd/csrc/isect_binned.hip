@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(kRowThreads) bin_rect_kernel(const BinArgs a)
 //     the sort kernel's LDS arena and goes through its slow paths: emit + sort 0.80 ms where the Gaussian-major path takes 0.20;
 //   * clustered but small (garden x1: 112 k rows, no bin near the arena's size): the crowded bins' workgroups are the launch's
 //     tail - binned 0.218 ms against 0.128 Gaussian-major - while a uniform scene's largest bin is ~1.5 x its mean.
-constexpr int kCsCols = 32, kCsSegs2 = 32;
+constexpr int kCsCols = 32, kCsSegs2 = 32, kCsPer = 32; // kCsPer >= ceil(max chunks per image / kCsSegs2)
 __global__ void __launch_bounds__(kCsCols *kCsSegs2) bin_colscan_kernel(const BinArgs a, uint32_t col_groups)
 {
     __shared__ int32_t s_seg[kCsSegs2][kCsCols + 1];
@@ -405,18 +405,27 @@ __global__ void __launch_bounds__(kCsCols *kCsSegs2) bin_colscan_kernel(const Bi
     const uint32_t per    = (cpi + kCsSegs2 - 1) / kCsSegs2;
     const uint32_t r0 = seg * per, r1 = min(r0 + per, cpi);
     int32_t *col = a.b.table + (int64_t)img * cpi * n_cols + c;
-    int32_t sum  = 0;
-    if (live)
-        for (uint32_t r = r0; r < r1; ++r) sum += col[(int64_t)r * n_cols];
+    // the segment lives in registers: ONE round trip to memory for its up to kCsPer loads (cpi <= 1024: bin_geometry), not one
+    // per entry in two dependent loops
+    int32_t v[kCsPer];
+    int32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kCsPer; ++i) {
+        const uint32_t r = r0 + (uint32_t)i;
+        v[i]             = (live && r < r1) ? col[(int64_t)r * n_cols] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < kCsPer; ++i) sum += v[i];
     s_seg[seg][lane_c] = sum;
     __syncthreads();
     int32_t run = 0;
     for (uint32_t k = 0; k < seg; ++k) run += s_seg[k][lane_c];
     if (live) {
-        for (uint32_t r = r0; r < r1; ++r) {
-            const int32_t v           = col[(int64_t)r * n_cols];
-            col[(int64_t)r * n_cols] = run;
-            run += v;
+#pragma unroll
+        for (int i = 0; i < kCsPer; ++i) {
+            const uint32_t r = r0 + (uint32_t)i;
+            if (r < r1) col[(int64_t)r * n_cols] = run;
+            run += v[i];
         }
         if (seg == kCsSegs2 - 1) a.b.bin_count[(int64_t)img * n_cols + c] = run;
     }
