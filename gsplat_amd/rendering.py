@@ -17,6 +17,7 @@ ray generation for distorted cameras (pass ``rays``), the hit-distance render mo
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -39,9 +40,10 @@ _DEPTH_MODES = ("D", "ED", "RGB+D", "RGB+ED")
 _HIT_MODES = ("d", "Ed", "RGB-d", "RGB-Ed")
 
 
-# GSPLAT_AMD_VIEW_OPACITIES=0 (A/B switch): the per-view opacities are a plain broadcast view again and autograd reduces their
-# gradient with its own kernels
-_VIEW_OPACITIES = __import__("os").environ.get("GSPLAT_AMD_VIEW_OPACITIES", "1") != "0"
+# GSPLAT_AMD_VIEW_OPACITIES=0 (A/B switch): the per-view / per-row opacities are built with torch again (a broadcast view, an
+# index_select) and autograd reduces their gradient with its own kernels
+_VIEW_OPACITIES = os.environ.get("GSPLAT_AMD_VIEW_OPACITIES", "1") != "0"
+
 
 def _resolve_tile_size(tile_size: Optional[int], with_eval3d: bool = False, width: int = 0, height: int = 0) -> int:
     """None -> the path's default: 16 for the classic path; for the from-world path 16 at 1080p and above, else 8
