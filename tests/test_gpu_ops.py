@@ -354,6 +354,15 @@ def test_isect_sort_networks_match_oracle(G, O, monkeypatch, path, case, sort):
     test_isect_paths_match_oracle(G, O, monkeypatch, path, case)
 
 
+@pytest.mark.parametrize("shape", ["2x2", "8x2", "4x4", "3x5", "16x1"])
+@pytest.mark.parametrize("case", ["giants-retry", "ellipse-ts4", "aabb-3img-ts8", "cluster-long-tiles", "depth-ties"])
+def test_isect_binned_bin_shapes_match_oracle(G, O, monkeypatch, case, shape):
+    """GSX_ISECT_BIN=WxH: bins other than the default 4 x 2 tiles run the row kernels' generic instantiation (block records of
+    2 x 4 or 2 x 2 bins, csrc/isect_binned.hip: BinShape<false>) - the oracle's lists, bit for bit, whatever the shape."""
+    monkeypatch.setenv("GSX_ISECT_BIN", shape)
+    test_isect_paths_match_oracle(G, O, monkeypatch, "binned", case)
+
+
 def test_isect_remembers_an_input_that_sent_the_binned_path_back(G, O):
     """A clustered scene fails the binned path's skew test and the call starts over Gaussian-major; the next calls of that shape
     must not pay for the attempt again (gsx_isect_binned_note_retry), and every call returns the oracle's lists."""
