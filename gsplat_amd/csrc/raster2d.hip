@@ -488,6 +488,9 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
 // batch, one per lane, rows requested one batch ahead), a 4-bit quadrant mask per staged surfel from the two-stage cull,
 // no __syncthreads, no LDS atomics, no accumulator table; tiles longest-first (tile_order.hip). D <= 4, 16 x 16 tiles, no
 // absgrad. Parity-green (tests/test_gpu_variants.py) and selectable (GSX_RASTER2D_BWD=w); not the default, see launch2_bwd.
+#ifndef GSX_BWD2_H_WAVES // the half-tile variant (NQ = 2)
+#define GSX_BWD2_H_WAVES 3
+#endif
 #ifndef GSX_BWD2_W_WAVES // 168 VGPRs (three waves per SIMD) spill 51 registers at four channels: two
 #define GSX_BWD2_W_WAVES 2
 #endif
@@ -505,8 +508,12 @@ struct Bwd2WCfg {
     static constexpr size_t smem = (size_t)BATCH * (8 * sizeof(float4)) + sizeof(float) * SLOTS * TP;
 };
 
-template <int CH, bool DIST>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : GSX_BWD2_W_WAVES))) raster2d_bwd_w_kernel(const Raster2DArgs a)
+// NQ = 4: one wave per tile (four pixels per lane). NQ = 2 (round 5): one wave per HALF tile - the quadrants above or below
+// the tile's middle, two pixels per lane: half the per-pixel state (three waves per SIMD instead of two), one reduction per
+// (half tile, surfel) instead of one per (quadrant, surfel) as in the four-wave kernel; the halves of a tile are workgroups b
+// and b + 8 (the same XCD, dispatched next to each other: the staged surfels are still in its L2).
+template <int CH, bool DIST, int NQ>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NQ == 2 ? GSX_BWD2_H_WAVES : (DIST ? 2 : GSX_BWD2_W_WAVES)))) raster2d_bwd_w_kernel(const Raster2DArgs a)
 {
     using Cfg           = Bwd2WCfg<CH>;
     constexpr int K     = Cfg::K;
@@ -530,7 +537,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 
 
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
     const uint32_t n_blocks        = tiles_per_image * a.n_images;
-    const uint32_t slot_idx        = xcd_remap(blockIdx.x, n_blocks);
+    // NQ == 2: workgroups 16 i + j and 16 i + 8 + j (j < 8) are the upper and the lower half of tile slot 8 i + j
+    const uint32_t unit     = NQ == 4 ? blockIdx.x : (blockIdx.x >> 4) * 8u + (blockIdx.x & 7u);
+    const uint32_t q_first  = NQ == 4 ? 0u : ((blockIdx.x >> 3) & 1u) * 2u; // first quadrant of this wave
+    const uint32_t slot_idx = xcd_remap(unit, n_blocks);
     if (slot_idx >= n_blocks) return;
     const uint32_t blk      = a.tile_order ? (uint32_t)a.tile_order[slot_idx] : slot_idx;
     const uint32_t image_id = blk / tiles_per_image, tile_id = blk % tiles_per_image;
@@ -548,13 +558,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 
     constexpr bool dist = DIST; // the distortion loss adds six per-pixel values: its own instantiation (two waves per SIMD)
 
     // per-pixel state, pixel q = this lane's pixel of quadrant q
-    float T[4], behind[4], tail_term[4], v_c[4][CH], v_n[4][3];
-    float vd2[4], c2aw[4], dP[4], dQ[4]; // distortion loss, see raster2d_bwd_kernel: 2 v_distort | 2 - accum_w | P | Q
-    int32_t bin_final[4], qmax[4];
+    float T[NQ], behind[NQ], tail_term[NQ], v_c[NQ][CH], v_n[NQ][3];
+    float vd2[NQ], c2aw[NQ], dP[NQ], dQ[NQ]; // distortion loss, see raster2d_bwd_kernel: 2 v_distort | 2 - accum_w | P | Q
+    int32_t bin_final[NQ], qmax[NQ];
     int32_t tile_last = -1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t lx = ((uint32_t)(q & 1) << 3) | lqx, ly = ((uint32_t)(q >> 1) << 3) | lqy;
+    for (int q = 0; q < NQ; ++q) {
+        const uint32_t gq = q_first + (uint32_t)q; // quadrant of the tile
+        const uint32_t lx = ((gq & 1u) << 3) | lqx, ly = ((gq >> 1) << 3) | lqy;
         const uint32_t ox = tile_x * 16u + lx, oy = tile_y * 16u + ly;
         const bool inside = ox < a.width && oy < a.height;
         const size_t pix  = inside ? ((size_t)image_id * a.height + oy) * a.width + ox : 0;
@@ -677,8 +688,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 
                 s_col[lane] = make_float4(f.cv[0], f.cv[1], f.cv[2], f.cv[3]);
                 const float4 cu = surfel_cull_box(f.M, f.xy.x, f.xy.y, f.opac);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float rcx = (q & 1) ? 4.0f : -4.0f, rcy = (q >> 1) ? 4.0f : -4.0f; // quadrant centre - tile centre
+                for (int q = 0; q < NQ; ++q) {
+                    const uint32_t gq = q_first + (uint32_t)q;
+                    const float rcx = (gq & 1u) ? 4.0f : -4.0f, rcy = (gq >> 1) ? 4.0f : -4.0f; // quadrant centre - tile centre
                     bool hit = idx <= qmax[q] && (fabsf(cu.x - (tcx + rcx)) - 3.5f <= cu.z)
                             && (fabsf(cu.y - (tcy + rcy)) - 3.5f <= cu.w);
                     if (hit) hit = surfel_reaches_rect(za, zb, zc, rcx, rcy, 3.5f, 3.5f);
@@ -709,9 +721,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 
             for (int k = 0; k < KQ * 4; ++k) sum[k] = 0.0f;
             bool contributed = false; // wave-uniform
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 if (!(qm & (1 << q))) continue; // scalar
-                const float qx = (float)(((q & 1) << 3) | (int)lqx) - 7.5f, qy = (float)(((q >> 1) << 3) | (int)lqy) - 7.5f;
+                const int gq   = (int)q_first + q;
+                const float qx = (float)(((gq & 1) << 3) | (int)lqx) - 7.5f, qy = (float)(((gq >> 1) << 3) | (int)lqy) - 7.5f;
                 const Surfel sf  = eval_surfel(Za, Zb, Zc, qx, qy);
                 const bool valid = (list_idx <= bin_final[q]) && sf.valid; // outside pixels: bin_final = -1
                 if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
@@ -756,7 +769,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 
                 const float g3   = use3d ? v_G * -vis : 0.0f;
                 const float a_   = g3 * sf.sx * sf.rcz_inv, b_ = g3 * sf.sy * sf.rcz_inv;
                 const float vrc[3] = {a_, b_, -(a_ * sf.sx + b_ * sf.sy)};
-                const float plx = (float)(((q & 1) << 3) | (int)lqx) + 0.5f, ply = (float)(((q >> 1) << 3) | (int)lqy) + 0.5f;
+                const float plx = (float)(((gq & 1) << 3) | (int)lqx) + 0.5f, ply = (float)(((gq >> 1) << 3) | (int)lqy) + 0.5f;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     // g3 == 0 can still meet inf/NaN geometry on invalid lanes: select, do not multiply
@@ -815,17 +828,27 @@ static int launch2_bwd(const Raster2DArgs &a, hipStream_t stream)
     const uint32_t block = a.tile_size <= 8 ? 64u : 256u;
     if constexpr (!ABS && CH <= 4) {
         if (raster2d_bwd_m_applies(a, ABS)) return raster2d_bwd_m_launch(a, stream); // the sums as one matrix product
-        // GSX_RASTER2D_BWD=w: one wave per tile. NOT the default: on c5 it issues 19 % fewer VALU and half the LDS
-        // instructions than the reduction kernel but needs 246 VGPRs - two waves per SIMD, 75 % VALU issue where the
-        // reduction kernel (five waves) runs at 97 % - and takes the same 1.9 ms (profiles/r08_ab.md #19, #20)
-        static const bool use_w = [] {
+        // w: one wave per tile: on c5 it issues 19 % fewer VALU and half the LDS instructions than the reduction kernel but
+        // needs 246 VGPRs - two waves per SIMD, 75 % VALU issue where the reduction kernel (five waves) runs at 97 % - and
+        // takes the same time (profiles/r08_ab.md #19, #20). h keeps half of that saving at 152 VGPRs, three waves per SIMD
+        // GSX_RASTER2D_BWD = h (default since round 5: one wave per HALF tile, 1.75 ms on c5) | r (the four-wave reduction
+        // kernel below, 1.83) | w (one wave per tile, 1.83) | m (raster2d_bwd_m.hip, 2.74); read once per process
+        static const char use = [] {
             const char *e = getenv("GSX_RASTER2D_BWD");
-            return e && (e[0] == 'w' || e[0] == 'W');
+            if (e && (e[0] == 'w' || e[0] == 'W')) return 'w';
+            if (e && (e[0] == 'r' || e[0] == 'R')) return 'r';
+            if (e && (e[0] == 'm' || e[0] == 'M')) return 'm';
+            return 'h';
         }();
-        if (a.tile_size == 16 && use_w) {
-            if (a.v_render_distort) raster2d_bwd_w_kernel<CH, true><<<dim3(grid), dim3(64), Bwd2WCfg<CH>::smem, stream>>>(a);
-            else raster2d_bwd_w_kernel<CH, false><<<dim3(grid), dim3(64), Bwd2WCfg<CH>::smem, stream>>>(a);
+        if (a.tile_size == 16 && use == 'w') {
+            if (a.v_render_distort) raster2d_bwd_w_kernel<CH, true, 4><<<dim3(grid), dim3(64), Bwd2WCfg<CH>::smem, stream>>>(a);
+            else raster2d_bwd_w_kernel<CH, false, 4><<<dim3(grid), dim3(64), Bwd2WCfg<CH>::smem, stream>>>(a);
             return check_launch("raster2d_bwd_w");
+        }
+        if (a.tile_size == 16 && use == 'h') { // one wave per half tile
+            if (a.v_render_distort) raster2d_bwd_w_kernel<CH, true, 2><<<dim3(2u * grid), dim3(64), Bwd2WCfg<CH>::smem, stream>>>(a);
+            else raster2d_bwd_w_kernel<CH, false, 2><<<dim3(2u * grid), dim3(64), Bwd2WCfg<CH>::smem, stream>>>(a);
+            return check_launch("raster2d_bwd_h");
         }
     }
     raster2d_bwd_kernel<CH, ABS><<<dim3(grid), dim3(block), Bwd2Cfg<CH, ABS>::smem, stream>>>(a);

@@ -152,9 +152,10 @@ def run_case_2dgs(G):
     return out
 
 
-@pytest.mark.parametrize("variant", ["w", "m"])
+@pytest.mark.parametrize("variant", ["r", "w", "m"])
 def test_raster2d_bwd_variants_match_the_default(variant):
-    """GSX_RASTER2D_BWD=w (csrc/raster2d.hip: raster2d_bwd_w_kernel, one wave per tile) and =m (csrc/raster2d_bwd_m.hip: the
+    """The default is one wave per HALF tile (csrc/raster2d.hip: raster2d_bwd_w_kernel<.., 2>). GSX_RASTER2D_BWD=r (the four-wave
+    reduction kernel), =w (the same kernel as the default, one wave per tile) and =m (csrc/raster2d_bwd_m.hip: the
     per-(tile, surfel) sums as one fp32-MFMA product per four surfels) - both measured and not the default - must give the
     gradients of the reduction kernel: RGB+ED with distortion loss and SH, long lists, a single depth channel."""
     if not torch.cuda.is_available():
