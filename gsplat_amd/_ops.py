@@ -907,16 +907,15 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
     else:
         v_quats, v_scales = alloc(quats), alloc(scales)
     v_opacities = None
-    if _v_view_opacities is not None and row_map is not None:
+    if _v_view_opacities is not None:
         v_view, opac_stride = _elem_view(_v_view_opacities)
-        v_opacities = torch.empty(tuple(batch_dims) + (N,), device=means.device, dtype=means.dtype)
+        # [..., N]: written once per Gaussian through the row map, accumulated into zeros without one
+        v_opacities = (torch.empty if row_map is not None else torch.zeros)(tuple(batch_dims) + (N,), device=means.device, dtype=means.dtype)
         call("gsx_project_ewa_packed_bwd_opac", *head, ptr_strided(v_view), opac_stride, ptr(row_map), ptr(v_means), ptr(v_covars),
              ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities))
     else:
         call("gsx_project_ewa_packed_bwd", *head, ptr(row_map), ptr(v_means), ptr(v_covars), ptr(v_quats), ptr(v_scales),
              ptr(v_viewmats))
-        if _v_view_opacities is not None:
-            v_opacities = scatter_opacities()
     # the last consumer of a step's row map (autograd runs the SH backward, created later, first): drop it here, and with it
     # the references that keep the step's id tensors alive - a stage-level caller has no next rasterization() to do that
     clear_row_map_cache()

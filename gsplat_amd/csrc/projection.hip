@@ -535,6 +535,11 @@ __global__ void __launch_bounds__(256) project_packed_bwd_kernel(const ProjBwdAr
         const Cam cam = load_cam(a.viewmats + ((size_t)b * a.C + c) * 16, a.Ks + ((size_t)b * a.C + c) * 9);
         pair_vjp(a, cam, p, S, row, v_p, v_S, v_R, v_t, POSE);
         store_gaussian_grads<!UNIQUE>(a, b, g, a.rows_out ? (size_t)row : (size_t)b * a.N + g, v_p, v_S);
+        if (a.v_opacities) { // the row's opacity cotangent -> its Gaussian (zero-filled output, like the others of this route)
+            const float v_o = a.v_view_opacities[(size_t)row * a.opac_stride];
+            if (UNIQUE) a.v_opacities[(size_t)b * a.N + g] = v_o;
+            else atomic_add_f32(a.v_opacities + (size_t)b * a.N + g, v_o);
+        }
     }
     if (POSE) {
         // rows are sorted by image; a wave spans a small contiguous range of images
@@ -975,8 +980,8 @@ extern "C" int gsx_project_ewa_packed_bwd(const float *means, const float *covar
     return check_launch("project_ewa_packed_bwd");
 }
 
-// gsx_project_ewa_packed_bwd, Gaussian-major (row_map required), that also reduces the cotangent of the packed rows'
-// opacities: v_view_opacities[row] at v_view_opacities_stride floats per row (the opacity column of gsx_raster3d_bwd's gradient
+// gsx_project_ewa_packed_bwd (either route: with a row map Gaussian-major, without one row-major into zero-filled outputs,
+// v_opacities included) that also reduces the cotangent of the packed rows' opacities: v_view_opacities[row] at v_view_opacities_stride floats per row (the opacity column of gsx_raster3d_bwd's gradient
 // rows, read in place) -> v_opacities[b N + g] = sum over the Gaussian's rows, 0 for a Gaussian without rows. Replaces the
 // index_add (+ zero fill) autograd runs for `opacities[gaussian_ids]` (reference gsplat/rendering.py:507-510).
 extern "C" int gsx_project_ewa_packed_bwd_opac(const float *means, const float *covars, const float *quats,
@@ -991,8 +996,8 @@ extern "C" int gsx_project_ewa_packed_bwd_opac(const float *means, const float *
                                                const int32_t *row_map, float *v_means, float *v_covars, float *v_quats,
                                                float *v_scales, float *v_viewmats, float *v_opacities, void *stream)
 {
-    GSX_REQUIRE(row_map && v_view_opacities && v_opacities && v_view_opacities_stride >= 1,
-                "gsx_project_ewa_packed_bwd_opac: needs the row map, the opacity cotangent and its output");
+    GSX_REQUIRE(v_view_opacities && v_opacities && v_view_opacities_stride >= 1,
+                "gsx_project_ewa_packed_bwd_opac: needs the opacity cotangent and its output");
     hipStream_t s = (hipStream_t)stream;
     if ((int64_t)B * N == 0) return GSX_OK;
     if (nnz <= 0) {
@@ -1015,9 +1020,22 @@ extern "C" int gsx_project_ewa_packed_bwd_opac(const float *means, const float *
     a.nnz = nnz; a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
     a.row_map = row_map;
     a.v_view_opacities = v_view_opacities; a.opac_stride = v_view_opacities_stride; a.v_opacities = v_opacities;
-    const dim3 g2((uint32_t)ceil_div((int64_t)B * N, 256));
-    if (v_viewmats) project_bwd_kernel<true><<<g2, dim3(256), 0, s>>>(a);
-    else project_bwd_kernel<false><<<g2, dim3(256), 0, s>>>(a);
+    if (row_map) { // Gaussian-major: every output row written once
+        const dim3 g2((uint32_t)ceil_div((int64_t)B * N, 256));
+        if (v_viewmats) project_bwd_kernel<true><<<g2, dim3(256), 0, s>>>(a);
+        else project_bwd_kernel<false><<<g2, dim3(256), 0, s>>>(a);
+        return check_launch("project_ewa_packed_bwd_opac");
+    }
+    // row-major: into ZERO-FILLED outputs (v_opacities as well), plain stores for a single image, atomics otherwise
+    const dim3 grid((uint32_t)ceil_div(nnz, 256)), block(256);
+    const bool unique = (uint64_t)B * C == 1;
+    if (v_viewmats) {
+        if (unique) project_packed_bwd_kernel<true, true><<<grid, block, 0, s>>>(a);
+        else project_packed_bwd_kernel<true, false><<<grid, block, 0, s>>>(a);
+    } else {
+        if (unique) project_packed_bwd_kernel<false, true><<<grid, block, 0, s>>>(a);
+        else project_packed_bwd_kernel<false, false><<<grid, block, 0, s>>>(a);
+    }
     return check_launch("project_ewa_packed_bwd_opac");
 }
 

@@ -159,8 +159,8 @@ int gsx_project_ewa_packed_bwd(const float *means, const float *covars, const fl
                                                          row written once (no atomics, outputs need no zero-fill) */,
                                float *v_means, float *v_covars, float *v_quats, float *v_scales,
                                float *v_viewmats, void *stream);
-/* gsx_project_ewa_packed_bwd, Gaussian-major (row_map required), that also reduces the cotangent of the packed rows'
- * opacities: v_view_opacities[row], v_view_opacities_stride floats apart (1 = contiguous; the row stride of gsx_raster3d_bwd's
+/* gsx_project_ewa_packed_bwd (with a row map: Gaussian-major, every output written once; without: row-major into ZERO-FILLED
+ * outputs, v_opacities included) that also reduces the cotangent of the packed rows' opacities: v_view_opacities[row], v_view_opacities_stride floats apart (1 = contiguous; the row stride of gsx_raster3d_bwd's
  * gradient rows when it is their opacity column) -> v_opacities[b N + g] = sum over the Gaussian's rows (0 without rows).
  * Replaces the index_add (+ zero fill) autograd runs for opacities[gaussian_ids] (reference gsplat/rendering.py:507-510). */
 int gsx_project_ewa_packed_bwd_opac(const float *means, const float *covars, const float *quats, const float *scales,
