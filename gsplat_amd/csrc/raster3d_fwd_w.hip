@@ -56,7 +56,9 @@ __device__ __forceinline__ void open_range(uint64_t m, int &xmin, int &xmax, int
     xmax = 31 - (int)__builtin_clz(c);
 }
 
-template <int CH>
+// NQ = 4: one wave per tile. NQ = 2 (GSX_RASTER3D_FWD=h): one wave per HALF tile, two pixels per lane - workgroups 16 i + j and
+// 16 i + 8 + j (j < 8: the same XCD, dispatched next to each other) are the upper and the lower half of tile slot 8 i + j.
+template <int CH, int NQ>
 __device__ __forceinline__ void raster3d_fwd_w_body(const Raster3DArgs &a)
 {
     constexpr int BATCH = 64;
@@ -64,23 +66,27 @@ __device__ __forceinline__ void raster3d_fwd_w_body(const Raster3DArgs &a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     StagedRow *s_st = reinterpret_cast<StagedRow *>(smem_raw); // [BATCH]: e-form of the exponent + colours (raster3d.hpp)
 
+    constexpr uint32_t kParts = 4u / (uint32_t)NQ; // waves per tile
+    const uint32_t unit    = (blockIdx.x / (8u * kParts)) * 8u + (blockIdx.x & 7u);
+    const uint32_t q_first = ((blockIdx.x >> 3) % kParts) * (uint32_t)NQ; // first quadrant of this wave
     TileCtx tc;
-    if (!tile_context(a, blockIdx.x, tc)) return;
+    if (!tile_context(a, unit, tc)) return;
     const uint32_t tiles_per_image = a.tile_w * a.tile_h;
     const uint32_t lane = threadIdx.x & 63u, qx = lane & 7u, qy = lane >> 3;
     // this lane's four pixels: (qx, qy) inside each quadrant; centres relative to the tile centre (multiples of 0.5: exact)
     const float pu[2] = {(float)qx - 7.5f, (float)qx + 0.5f}, pv[2] = {(float)qy - 7.5f, (float)qy + 0.5f};
     const float tile_cx = (float)(tc.tile_x * 16u) + 8.0f, tile_cy = (float)(tc.tile_y * 16u) + 8.0f;
     const float *bg = a.backgrounds ? a.backgrounds + (size_t)tc.image_id * a.cdim + a.ch_off : nullptr;
-    auto row_of = [&](int q) -> int64_t { // output row of the lane's pixel in quadrant q, -1 = not rendered
-        return pixel_row(a, tc, blockIdx.x, ((uint32_t)(q & 1) << 3) | qx, ((uint32_t)(q >> 1) << 3) | qy);
+    auto row_of = [&](int q) -> int64_t { // output row of the lane's pixel in this wave's quadrant q, -1 = not rendered
+        const uint32_t gq = q_first + (uint32_t)q;
+        return pixel_row(a, tc, unit, ((gq & 1u) << 3) | qx, ((gq >> 1) << 3) | qy);
     };
-    int32_t *cost_out = (a.tile_cost && !a.sp_active_tiles) ? a.tile_cost + (size_t)tc.image_id * tiles_per_image + tc.tile_id : nullptr;
+    int32_t *cost_out = (NQ == 4 && a.tile_cost && !a.sp_active_tiles) ? a.tile_cost + (size_t)tc.image_id * tiles_per_image + tc.tile_id : nullptr;
 
     // masked-off tile: background colour, zero alpha, last_id 0 (reference Fwd.cu:141-159)
     if (a.masks && !a.masks[(size_t)tc.image_id * tiles_per_image + tc.tile_id]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int64_t prow = row_of(q);
             if (prow < 0) continue;
             const size_t pix = (size_t)prow;
@@ -96,10 +102,10 @@ __device__ __forceinline__ void raster3d_fwd_w_body(const Raster3DArgs &a)
         return;
     }
 
-    float T[4], thr[4], acc[4][CH];
-    uint32_t cur_idx[4];
+    float T[NQ], thr[NQ], acc[NQ][CH];
+    uint32_t cur_idx[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         T[q]       = 1.0f;
         thr[q]     = row_of(q) >= 0 ? kAlphaThreshold : INFINITY; // alpha threshold of the pixel; +inf = done (or not rendered)
         cur_idx[q] = 0u;
@@ -128,13 +134,13 @@ __device__ __forceinline__ void raster3d_fwd_w_body(const Raster3DArgs &a)
     Fetched f_cur{};
     fetch(g_cur, f_cur);
 
-    uint32_t open = 0xFu; // quadrants with a pixel that is not done (wave-uniform)
+    uint32_t open = (1u << NQ) - 1u; // quadrants with a pixel that is not done (wave-uniform)
     for (int32_t b = 0; b < n_batches; ++b) {
         // the rectangle of each quadrant's open pixels, tile-centre coordinates (it shrinks as pixels saturate)
-        float rcx[4], rcy[4], rhw[4], rhh[4];
+        float rcx[NQ], rcy[NQ], rhw[NQ], rhh[NQ];
         open = 0u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const uint64_t m = __builtin_amdgcn_ballot_w64(thr[q] < INFINITY);
             rcx[q] = rcy[q] = rhw[q] = rhh[q] = 0.0f;
             if (m) {
@@ -143,8 +149,9 @@ __device__ __forceinline__ void raster3d_fwd_w_body(const Raster3DArgs &a)
 #if GSX_FWD_W_RECT
                 open_range(m, xmin, xmax, ymin, ymax);
 #endif
-                rcx[q] = 0.5f * (float)(xmin + xmax) + ((q & 1) ? 0.5f : -7.5f);
-                rcy[q] = 0.5f * (float)(ymin + ymax) + ((q >> 1) ? 0.5f : -7.5f);
+                const uint32_t gq = q_first + (uint32_t)q;
+                rcx[q] = 0.5f * (float)(xmin + xmax) + ((gq & 1u) ? 0.5f : -7.5f);
+                rcy[q] = 0.5f * (float)(ymin + ymax) + ((gq >> 1) ? 0.5f : -7.5f);
                 rhw[q] = 0.5f * (float)(xmax - xmin);
                 rhh[q] = 0.5f * (float)(ymax - ymin);
             }
@@ -167,7 +174,7 @@ __device__ __forceinline__ void raster3d_fwd_w_body(const Raster3DArgs &a)
                 s_st[lane].p2 = v4f{f.cv[0], f.cv[1], f.cv[3], 0.0f};
                 const float2 he = cull_half_extent(opac, ca, cb, cc);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     if (!(open & (1u << q))) continue; // scalar
                     WaveRect r;
                     r.cx = rcx[q]; r.cy = rcy[q]; r.hw = rhw[q]; r.hh = rhh[q]; r.any = true;
@@ -197,9 +204,10 @@ __device__ __forceinline__ void raster3d_fwd_w_body(const Raster3DArgs &a)
             uint32_t idx;
             asm("v_mov_b32 %0, %1" : "=v"(idx) : "s"(batch_start + t));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 if (!(qm & (1u << q))) continue; // scalar
-                const float e     = staged_e(p0, p1.x, p1.y, p1.z, pu[q & 1], pv[q >> 1]);
+                const uint32_t gq = q_first + (uint32_t)q;
+                const float e     = staged_e(p0, p1.x, p1.y, p1.z, pu[gq & 1u], pv[gq >> 1]);
                 const float alpha = fminf(kMaxAlpha, __builtin_amdgcn_exp2f(e));
                 // branch-free body (raster3d_fwd.hip): passes / saturates / is blended are lane masks combined on the scalar side
                 const bool ok = !(e > p0.w) && !(alpha < thr[q]); // e > lo <=> sigma < 0
@@ -231,7 +239,7 @@ __device__ __forceinline__ void raster3d_fwd_w_body(const Raster3DArgs &a)
 
     int32_t last = -1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int64_t prow = row_of(q);
         if (prow < 0) continue;
         const size_t pix = (size_t)prow;
@@ -250,11 +258,11 @@ __device__ __forceinline__ void raster3d_fwd_w_body(const Raster3DArgs &a)
     }
 }
 
-template <int CH>
+template <int CH, int NQ>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSX_FWD_W_WAVES)))
 raster3d_fwd_w_kernel(const Raster3DArgs a)
 {
-    raster3d_fwd_w_body<CH>(a);
+    raster3d_fwd_w_body<CH, NQ>(a);
 }
 
 // GSX_RASTER3D_FWD=q selects the four-waves-per-tile kernel (A/B; read once per process)
@@ -264,13 +272,14 @@ static char fwd_variant()
         const char *e = getenv("GSX_RASTER3D_FWD");
         if (e && (e[0] == 'q' || e[0] == 'Q')) return 'q';
         if (e && (e[0] == 'w' || e[0] == 'W')) return 'w';
+        if (e && (e[0] == 'h' || e[0] == 'H')) return 'h';
         return GSX_RASTER3D_FWD_DEFAULT;
     }();
     return v;
 }
 bool raster3d_fwd_w_applies(const Raster3DArgs &a)
 {
-    return fwd_variant() == 'w' && a.tile_size == 16 && a.nch <= 4 && a.seg_mode == 0 && a.seg_len == 0;
+    return (fwd_variant() == 'w' || fwd_variant() == 'h') && a.tile_size == 16 && a.nch <= 4 && a.seg_mode == 0 && a.seg_len == 0;
 }
 int raster3d_fwd_w_launch(const Raster3DArgs &a, hipStream_t stream)
 {
@@ -278,10 +287,17 @@ int raster3d_fwd_w_launch(const Raster3DArgs &a, hipStream_t stream)
     if (n_blocks == 0) return GSX_OK;
     const uint32_t grid = ((n_blocks + 7u) / 8u) * 8u; // xcd_remap needs a multiple of 8
     const size_t smem   = 64 * sizeof(StagedRow);
-    if (a.nch <= 1) raster3d_fwd_w_kernel<1><<<dim3(grid), dim3(64), smem, stream>>>(a);
-    else if (a.nch <= 2) raster3d_fwd_w_kernel<2><<<dim3(grid), dim3(64), smem, stream>>>(a);
-    else if (a.nch <= 3) raster3d_fwd_w_kernel<3><<<dim3(grid), dim3(64), smem, stream>>>(a);
-    else raster3d_fwd_w_kernel<4><<<dim3(grid), dim3(64), smem, stream>>>(a);
+    if (fwd_variant() == 'h') { // one wave per half tile
+        if (a.nch <= 1) raster3d_fwd_w_kernel<1, 2><<<dim3(2u * grid), dim3(64), smem, stream>>>(a);
+        else if (a.nch <= 2) raster3d_fwd_w_kernel<2, 2><<<dim3(2u * grid), dim3(64), smem, stream>>>(a);
+        else if (a.nch <= 3) raster3d_fwd_w_kernel<3, 2><<<dim3(2u * grid), dim3(64), smem, stream>>>(a);
+        else raster3d_fwd_w_kernel<4, 2><<<dim3(2u * grid), dim3(64), smem, stream>>>(a);
+        return check_launch("raster3d_fwd_h");
+    }
+    if (a.nch <= 1) raster3d_fwd_w_kernel<1, 4><<<dim3(grid), dim3(64), smem, stream>>>(a);
+    else if (a.nch <= 2) raster3d_fwd_w_kernel<2, 4><<<dim3(grid), dim3(64), smem, stream>>>(a);
+    else if (a.nch <= 3) raster3d_fwd_w_kernel<3, 4><<<dim3(grid), dim3(64), smem, stream>>>(a);
+    else raster3d_fwd_w_kernel<4, 4><<<dim3(grid), dim3(64), smem, stream>>>(a);
     return check_launch("raster3d_fwd_w");
 }
 

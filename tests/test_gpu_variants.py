@@ -93,8 +93,9 @@ def test_raster3d_bwd_variants_match_the_default(variant):
                               name=f"case {i} v_{k}")
 
 
-def test_raster3d_fwd_one_wave_per_tile_matches_the_default():
-    """GSX_RASTER3D_FWD=w: the one-wave-per-tile forward (csrc/raster3d_fwd_w.hip; measured slower, not the default) against
+@pytest.mark.parametrize("variant", ["w", "h"])
+def test_raster3d_fwd_one_wave_per_tile_matches_the_default(variant):
+    """GSX_RASTER3D_FWD=w / h: the forward with one wave per tile / per half tile (csrc/raster3d_fwd_w.hip; not the default) against
     the four-waves-per-tile kernel (csrc/raster3d_fwd.hip). Same staged form and the same per-pixel arithmetic in the same
     order: the renders must agree to rounding (a different cull never changes a result), and so must the gradients, which
     start from the forward's state."""
@@ -108,7 +109,7 @@ def test_raster3d_fwd_one_wave_per_tile_matches_the_default():
         path = os.path.join(d, "t.npz")
         code = _SCRIPT % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
         r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True,
-                           env=dict(os.environ, GSX_RASTER3D_FWD="w"), timeout=600)
+                           env=dict(os.environ, GSX_RASTER3D_FWD=variant), timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         alt = dict(np.load(path))
     for i, case in enumerate(CASES):
