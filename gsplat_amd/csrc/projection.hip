@@ -911,14 +911,15 @@ extern "C" int gsx_project_ewa_bwd_opac(const float *means, const float *covars,
 {
     const int64_t count = (int64_t)B * N;
     if (count == 0) return GSX_OK;
-    GSX_REQUIRE(v_view_opacities && v_opacities && v_view_opacities_stride >= 1, "gsx_project_ewa_bwd_opac: null opacity cotangent / output");
-    if (C == 0) {
+    GSX_REQUIRE(v_opacities, "gsx_project_ewa_bwd_opac: null v_opacities");
+    if (C == 0) { // no views: the cotangent is empty, every Gaussian's gradient is zero
         if (hipMemsetAsync(v_opacities, 0, (size_t)count * sizeof(float), (hipStream_t)stream) != hipSuccess) {
             set_last_error("gsx_project_ewa_bwd_opac: memset failed");
             return GSX_ERR_LAUNCH;
         }
         return GSX_OK;
     }
+    GSX_REQUIRE(v_view_opacities && v_view_opacities_stride >= 1, "gsx_project_ewa_bwd_opac: null opacity cotangent");
     int rc = check_proj_common("gsx_project_ewa_bwd_opac", means, covars, quats, scales, viewmats, Ks, camera_model);
     if (rc != GSX_OK) return rc;
     GSX_REQUIRE(radii && conics && v_means2d && v_conics, "gsx_project_ewa_bwd_opac: null input");
@@ -996,17 +997,17 @@ extern "C" int gsx_project_ewa_packed_bwd_opac(const float *means, const float *
                                                const int32_t *row_map, float *v_means, float *v_covars, float *v_quats,
                                                float *v_scales, float *v_viewmats, float *v_opacities, void *stream)
 {
-    GSX_REQUIRE(v_view_opacities && v_opacities && v_view_opacities_stride >= 1,
-                "gsx_project_ewa_packed_bwd_opac: needs the opacity cotangent and its output");
     hipStream_t s = (hipStream_t)stream;
-    if ((int64_t)B * N == 0) return GSX_OK;
-    if (nnz <= 0) {
+    if ((int64_t)B * N == 0) return GSX_OK; // no Gaussians: nothing to write
+    GSX_REQUIRE(v_opacities, "gsx_project_ewa_packed_bwd_opac: null v_opacities");
+    if (nnz <= 0) { // no rows: the cotangent is empty (its pointer may be null), every Gaussian's gradient is zero
         if (hipMemsetAsync(v_opacities, 0, (size_t)B * N * sizeof(float), s) != hipSuccess) {
             set_last_error("gsx_project_ewa_packed_bwd_opac: memset failed");
             return GSX_ERR_LAUNCH;
         }
         return GSX_OK;
     }
+    GSX_REQUIRE(v_view_opacities && v_view_opacities_stride >= 1, "gsx_project_ewa_packed_bwd_opac: null opacity cotangent");
     int rc = check_proj_common("gsx_project_ewa_packed_bwd_opac", means, covars, quats, scales, viewmats, Ks, camera_model);
     if (rc != GSX_OK) return rc;
     GSX_REQUIRE(batch_ids && camera_ids && gaussian_ids && conics && v_means2d && v_conics,
