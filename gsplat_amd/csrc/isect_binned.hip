@@ -708,7 +708,8 @@ static uint32_t bits_for(uint64_t count)
 
 static void bin_dims(uint32_t &bw, uint32_t &bh)
 {
-    bw = 4; bh = 2; // measured on c3 (r3f / r3g): 4x4 0.233, 4x2 0.206, 2x4 0.209, 2x2 0.225, 8x2 0.235 ms
+    bw = 4; bh = 2; // measured on c3 (r3f / r3g): 4x4 0.233, 4x2 0.206, 2x4 0.209, 2x2 0.225, 8x2 0.235 ms; round 5 (the other
+                    // shapes on the row kernels' generic instantiation): 0.205, 0.171, 0.198, 0.189, 0.203
     if (const char *e = getenv("GSX_ISECT_BIN")) { // "WxH" (tiles), W * H <= 16: A/B switch
         unsigned w = 0, h = 0;
         if (sscanf(e, "%ux%u", &w, &h) == 2 && w >= 1 && h >= 1 && w * h <= 16) { bw = w; bh = h; }
