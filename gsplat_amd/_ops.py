@@ -352,9 +352,19 @@ def bits_for_count(count: int) -> int:
 # ----------------------------------------------------------------------------------------------
 # quat_scale_to_covar_preci
 # ----------------------------------------------------------------------------------------------
+def _qs_dtype(*tensors) -> bool:
+    """float32 or float64 throughout (the reference dispatches this op over both, QuatScaleToCovarCUDA.cu:145); True = float64."""
+    dts = {t.dtype for t in tensors if t is not None}
+    if dts == {torch.float64}:
+        return True
+    if dts != {torch.float32}:
+        raise TypeError(f"gsplat_amd: quat_scale_to_covar_preci takes float32 or float64 tensors of ONE type (got {sorted(map(str, dts))})")
+    return False
+
+
 @_op("quat_scale_to_covar_preci")
 def quat_scale_to_covar_preci(quats, scales, compute_covar, compute_preci, triu):
-    _check_f32(quats=quats, scales=scales)
+    f64 = _qs_dtype(quats, scales)
     batch = quats.shape[:-1]
     if quats.shape[-1] != 4 or scales.shape != batch + (3,):
         raise ValueError(f"quat_scale_to_covar_preci: bad shapes {tuple(quats.shape)} / {tuple(scales.shape)}")
@@ -363,17 +373,19 @@ def quat_scale_to_covar_preci(quats, scales, compute_covar, compute_preci, triu)
     tail = (6,) if triu else (3, 3)
     covars = torch.empty(batch + tail, device=quats.device, dtype=quats.dtype) if compute_covar else None
     precis = torch.empty(batch + tail, device=quats.device, dtype=quats.dtype) if compute_preci else None
-    call("gsx_quat_scale_to_covar_fwd", ptr(quats), ptr(scales), n, int(triu), ptr(covars), ptr(precis))
+    call("gsx_quat_scale_to_covar_fwd_f64" if f64 else "gsx_quat_scale_to_covar_fwd", ptr(quats), ptr(scales), n, int(triu),
+         ptr(covars), ptr(precis))
     return covars, precis
 
 
 @_op("quat_scale_to_covar_preci_bwd")
 def quat_scale_to_covar_preci_bwd(quats, scales, triu, v_covars, v_precis):
+    f64 = _qs_dtype(quats, scales, v_covars, v_precis)
     quats, scales = quats.contiguous(), scales.contiguous()
     n = math.prod(quats.shape[:-1])
     v_quats, v_scales = torch.empty_like(quats), torch.empty_like(scales)
-    call("gsx_quat_scale_to_covar_bwd", ptr(quats), ptr(scales), n, int(triu), ptr(_c(v_covars)), ptr(_c(v_precis)),
-         ptr(v_quats), ptr(v_scales))
+    call("gsx_quat_scale_to_covar_bwd_f64" if f64 else "gsx_quat_scale_to_covar_bwd", ptr(quats), ptr(scales), n, int(triu),
+         ptr(_c(v_covars)), ptr(_c(v_precis)), ptr(v_quats), ptr(v_scales))
     return v_quats, v_scales
 
 

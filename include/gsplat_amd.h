@@ -57,6 +57,13 @@ int gsx_quat_scale_to_covar_fwd(const float *quats, const float *scales, int64_t
 int gsx_quat_scale_to_covar_bwd(const float *quats, const float *scales, int64_t n, int triu,
                                 const float *v_covars, const float *v_precis,
                                 float *v_quats, float *v_scales, void *stream);
+/* The same op in double precision (the reference instantiates it for float and double: QuatScaleToCovarCUDA.cu:145,
+ * AT_DISPATCH_FLOATING_TYPES; its tests pass float64): identical layouts, every operation in IEEE double. */
+int gsx_quat_scale_to_covar_fwd_f64(const double *quats, const double *scales, int64_t n, int triu,
+                                    double *covars, double *precis, void *stream);
+int gsx_quat_scale_to_covar_bwd_f64(const double *quats, const double *scales, int64_t n, int triu,
+                                    const double *v_covars, const double *v_precis,
+                                    double *v_quats, double *v_scales, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * fully_fused_projection (dense): gsplat::projection_ewa_3dgs_fused{,_bwd}

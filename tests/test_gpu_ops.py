@@ -65,6 +65,32 @@ def test_quat_scale_to_covar_preci(G, O, triu):
     assert none_p is None and only_c.shape == c.shape
 
 
+@pytest.mark.parametrize("triu", [False, True])
+def test_quat_scale_to_covar_preci_float64(G, O, triu):
+    """The reference instantiates this op for double as well (QuatScaleToCovarCUDA.cu:145) and its tests pass float64: the
+    double-precision kernels (csrc/quat_scale_f64.hip) against the oracle's torch formulas evaluated in float64, forward and
+    gradients, to double rounding; mixed dtypes are refused."""
+    N = 777
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(N, 4, generator=g, dtype=torch.float64)
+    s = torch.rand(N, 3, generator=g, dtype=torch.float64) * 0.5 + 0.05
+    qg, sg = q.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
+    c, p = G.quat_scale_to_covar_preci(qg, sg, True, True, triu)
+    assert c.dtype == torch.float64 and p.dtype == torch.float64
+    qo, so = q.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    c_o, p_o = O.quat_scale_to_covar_preci(qo, so, True, True, triu)
+    assert c_o.dtype == torch.float64
+    torch.testing.assert_close(cpu(c), c_o, rtol=1e-12, atol=1e-13)
+    torch.testing.assert_close(cpu(p), p_o, rtol=1e-11, atol=1e-11)
+    wc, wp = torch.randn(c_o.shape, generator=g, dtype=torch.float64), torch.randn(p_o.shape, generator=g, dtype=torch.float64) * 1e-3
+    (c * wc.to(DEV)).sum().add((p * wp.to(DEV)).sum()).backward()
+    (c_o * wc).sum().add((p_o * wp).sum()).backward()
+    torch.testing.assert_close(cpu(qg.grad), qo.grad, rtol=1e-9, atol=1e-10)
+    torch.testing.assert_close(cpu(sg.grad), so.grad, rtol=1e-9, atol=1e-10)
+    with pytest.raises(TypeError):
+        G.quat_scale_to_covar_preci(qg.detach(), sg.detach().float(), True, True, triu)
+
+
 def _proj_both(G, O, sc, W, H, cam, use_covars=False, opac=True, comp=True, radius_clip=0.0, grads=True):
     names = ("means", "quats", "scales", "viewmats")
     tg = {k: sc[k].to(DEV).clone().requires_grad_(grads) for k in names}
