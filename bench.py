@@ -93,7 +93,7 @@ def stage_of(entry: str) -> str:
     tile-order workspace) / _fill (zero-fills its rows itself) / _seg (long lists in slices); the dense projection backward is
     gsx_project_ewa_bwd / _opac (also reduces the per-view opacity cotangent)."""
     for tail in ("_ws", "_fill", "_seg", "_opac"):
-        if entry.endswith(tail) and ("raster3d_bwd" in entry or "raster3d_fwd" in entry or "project_ewa_bwd" in entry):
+        if entry.endswith(tail) and any(n in entry for n in ("raster3d_bwd", "raster3d_fwd", "raster2d_bwd", "project_ewa_bwd")):
             return entry[: -len(tail)]
     return entry
 
@@ -625,8 +625,9 @@ def main():
 
         steps5 = max(3, args.steps // 2)
         t5, m5, _ = timed(step5, steps5, 3, barrier)  # the clean window gives ms per step, an instrumented repeat the launches
-        _, _, p5 = timed(step5, steps5, 0, barrier, profile_only=("gsx_raster2d_fwd", "gsx_raster2d_bwd", "gsx_raster2d_bwd_ws"))
-        p5 = {k.replace("_ws", ""): v for k, v in p5.items()}
+        _, _, p5 = timed(step5, steps5, 0, barrier, profile_only=("gsx_raster2d_fwd", "gsx_raster2d_bwd", "gsx_raster2d_bwd_ws",
+                                                                 "gsx_raster2d_bwd_fill"))
+        p5 = {stage_of(k): v for k, v in p5.items()}
         M5, D5 = int(m5["isect_ids"].numel()), 4
         V5 = int((m5["radii"] > 0).all(-1).sum().item())
         ms5 = {k.replace("gsx_", ""): round(sum(v) / len(v), 4) for k, v in p5.items()}

@@ -26,6 +26,11 @@ def _bwd(name):
     return _ops.impl(name + "_bwd")
 
 
+def _cg(v):
+    """An incoming gradient made contiguous; an undefined one (None = zeros) stays None for ops that take it as such."""
+    return None if v is None else v.contiguous()
+
+
 def _z(v, shape, like):
     """Materialise an undefined gradient (None) as zeros only where an op needs a real tensor."""
     return like.new_zeros(shape) if v is None else v
@@ -293,6 +298,8 @@ def _r2_setup(ctx, inputs, output):
     (render_colors, render_alphas, _rn, _rd, _rm, means2d_absgrad, last_ids, median_ids) = output
     ctx.mark_non_differentiable(last_ids, median_ids, means2d_absgrad)
     ctx.width, ctx.height, ctx.tile_size, ctx.absgrad = image_width, image_height, tile_size, absgrad
+    ctx.set_materialize_grads(False)  # an output the loss does not use gets no zero-filled gradient (the kernels take NULL = zeros)
+    ctx.rc_shape = render_colors.shape
     ctx.save_for_backward(means2d, ray_transforms, colors, opacities, normals, densify, backgrounds, masks,
                           tile_offsets, flatten_ids, render_colors, render_alphas, last_ids, median_ids,
                           means2d_absgrad)
@@ -306,8 +313,8 @@ def _r2_backward(ctx, v_render_colors, v_render_alphas, v_render_normals, v_rend
      v_backgrounds) = _bwd("rasterize_to_pixels_2dgs")(
         means2d, ray_transforms, colors, opacities, normals, densify, backgrounds, masks, tile_offsets, flatten_ids,
         render_colors, render_alphas, last_ids, median_ids, ctx.width, ctx.height, ctx.tile_size, ctx.absgrad,
-        v_render_colors.contiguous(), v_render_alphas.contiguous(), v_render_normals.contiguous(),
-        v_render_distort.contiguous(), v_render_median.contiguous(), ctx.needs_input_grad[6])
+        _z(v_render_colors, ctx.rc_shape, render_alphas).contiguous(), _cg(v_render_alphas), _cg(v_render_normals),
+        _cg(v_render_distort), _cg(v_render_median), ctx.needs_input_grad[6])
     if ctx.absgrad and v_means2d_abs is not None:
         means2d_absgrad.copy_(v_means2d_abs)
     return (v_means2d, v_ray_transforms, v_colors, v_opacities, v_normals, v_densify, v_backgrounds) + (None,) * 9

@@ -1380,19 +1380,21 @@ def rasterize_to_pixels_2dgs_bwd(means2d, ray_transforms, colors, opacities, nor
     means2d, ray_transforms, colors, opacities, normals = (t.contiguous() for t in (means2d, ray_transforms, colors,
                                                                                     opacities, normals))
     backgrounds, masks = _c(backgrounds), _c(masks)
-    v_render_colors, v_render_alphas = v_render_colors.contiguous(), v_render_alphas.contiguous()
-    # one zero-filled AoS gradient buffer; the reference's gradient tensors are column views of it (include/gsplat_amd.h)
+    v_render_colors = v_render_colors.contiguous()
+    # one AoS gradient buffer, zero-filled by the launch itself (gsx_raster2d_bwd_fill: inside its tile-order kernel); the
+    # reference's gradient tensors are column views of it (include/gsplat_amd.h). Cotangents of outputs the loss does not use
+    # arrive as None from gsplat_amd's own autograd and go to the kernels as NULL (= zeros)
     R = opacities.numel()
     geo = 19 if absgrad else 17
-    rows = torch.zeros((R, geo + D), device=means2d.device, dtype=means2d.dtype)
+    rows = torch.empty((R, geo + D), device=means2d.device, dtype=means2d.dtype)
     # workspace for the longest-first tile order of the launch (csrc/tile_order.hip)
     ws = torch.empty(_cabi._lib.gsx_raster3d_bwd_workspace_bytes(I, tw, th), device=means2d.device, dtype=torch.uint8)
-    call("gsx_raster2d_bwd_ws", ptr(means2d), ptr(ray_transforms), ptr(colors), ptr(opacities), ptr(normals),
+    call("gsx_raster2d_bwd_fill", ptr(means2d), ptr(ray_transforms), ptr(colors), ptr(opacities), ptr(normals),
          ptr(backgrounds), ptr(masks), ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()),
          ptr(render_colors.contiguous()), ptr(render_alphas.contiguous()), ptr(last_ids.contiguous()),
-         ptr(median_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), ptr(v_render_normals.contiguous()),
-         ptr(_c(v_render_distort)), ptr(v_render_median.contiguous()), I, flatten_ids.numel(), D, image_width,
-         image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D, ptr(ws), ws.numel())
+         ptr(median_ids.contiguous()), ptr(v_render_colors), ptr(_c(v_render_alphas)), ptr(_c(v_render_normals)),
+         ptr(_c(v_render_distort)), ptr(_c(v_render_median)), I, flatten_ids.numel(), D, image_width,
+         image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D, R, ptr(ws), ws.numel())
     v_means2d, v_opacities = rows[:, 0:2].view(means2d.shape), rows[:, 2].view(opacities.shape)
     v_densify, v_normals = rows[:, 3:5].view(means2d.shape), rows[:, 5:8].view(normals.shape)
     v_rt = rows[:, 8:17].view(ray_transforms.shape)

@@ -250,14 +250,14 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
 #pragma unroll
     for (int k = 0; k < CH; ++k) v_c[k] = (inside && k < nch) ? a.v_render_colors[pix * a.cdim + k] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v_n[k] = inside ? a.v_render_normals[pix * 3 + k] : 0.0f;
-    const float v_a      = inside ? a.v_render_alphas[pix] : 0.0f;
+    for (int k = 0; k < 3; ++k) v_n[k] = (inside && a.v_render_normals) ? a.v_render_normals[pix * 3 + k] : 0.0f;
+    const float v_a      = (inside && a.v_render_alphas) ? a.v_render_alphas[pix] : 0.0f;
     // The cotangent of the median depth goes to the depth channel of ONE surfel per pixel, the one the forward pass recorded
     // (median_ids; a pixel with any contributor has one: the first contributor sees T = 1 > 0.5). It is added here, once per
     // pixel, instead of being tested for on every (pixel, surfel) pair of the walk (two instructions and two registers less
     // per pair; reference Bwd.cu adds it inside the walk).
     if (inside && T_final < 1.0f) {
-        const float v_median = a.v_render_median[pix];
+        const float v_median = a.v_render_median ? a.v_render_median[pix] : 0.0f;
         if (v_median != 0.0f) {
             constexpr int GEO0 = 17 + (ABS ? 2 : 0);
             atomic_add_f32(a.v_rows + (size_t)a.flatten_ids[a.median_ids[pix]] * a.row_stride + GEO0 + nch - 1, v_median);
@@ -573,15 +573,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NQ == 2
         T[q] = T_fin; behind[q] = 0.0f;
         bin_final[q]  = inside ? a.last_ids[pix] : -1;
         if (inside && T_fin < 1.0f) { // the median depth's cotangent: once per pixel (see raster2d_bwd_kernel)
-            const float v_median = a.v_render_median[pix];
+            const float v_median = a.v_render_median ? a.v_render_median[pix] : 0.0f;
             if (v_median != 0.0f)
                 atomic_add_f32(a.v_rows + (size_t)a.flatten_ids[a.median_ids[pix]] * a.row_stride + 17 + nch - 1, v_median);
         }
 #pragma unroll
         for (int k = 0; k < CH; ++k) v_c[q][k] = (inside && k < nch) ? a.v_render_colors[pix * a.cdim + k] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v_n[q][k] = inside ? a.v_render_normals[pix * 3 + k] : 0.0f;
-        const float v_a = inside ? a.v_render_alphas[pix] : 0.0f;
+        for (int k = 0; k < 3; ++k) v_n[q][k] = (inside && a.v_render_normals) ? a.v_render_normals[pix * 3 + k] : 0.0f;
+        const float v_a = (inside && a.v_render_alphas) ? a.v_render_alphas[pix] : 0.0f;
         float bg_dot    = 0.0f;
         if (a.backgrounds) {
             const float *bg = a.backgrounds + (size_t)image_id * a.cdim;
@@ -934,14 +934,43 @@ extern "C" int gsx_raster2d_bwd_ws(const float *means2d, const float *ray_transf
                                    int has_abs, float *v_rows, uint32_t row_stride, void *workspace, int64_t workspace_bytes,
                                    void *stream)
 {
+    return gsx_raster2d_bwd_fill(means2d, ray_transforms, colors, opacities, normals, backgrounds, masks, isect_offsets, flatten_ids,
+                                 render_colors, render_alphas, last_ids, median_ids, v_render_colors, v_render_alphas,
+                                 v_render_normals, v_render_distort, v_render_median, n_images, n_isects, cdim, width, height,
+                                 tile_size, tile_w, tile_h, has_abs, v_rows, row_stride, 0, workspace, workspace_bytes, stream);
+}
+
+// gsx_raster2d_bwd_ws for gradient rows that are NOT zero-filled yet: the call fills v_rows_to_fill rows of row_stride floats
+// itself - inside the tile-order cost kernel when one is launched, with a memset otherwise (as gsx_raster3d_bwd_fill).
+extern "C" int gsx_raster2d_bwd_fill(const float *means2d, const float *ray_transforms, const float *colors,
+                                   const float *opacities, const float *normals, const float *backgrounds,
+                                   const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                   const float *render_colors, const float *render_alphas, const int32_t *last_ids,
+                                   const int32_t *median_ids, const float *v_render_colors, const float *v_render_alphas,
+                                   const float *v_render_normals, const float *v_render_distort,
+                                   const float *v_render_median, uint32_t n_images, uint32_t n_isects, uint32_t cdim,
+                                   uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                                   int has_abs, float *v_rows, uint32_t row_stride, int64_t v_rows_to_fill, void *workspace,
+                                   int64_t workspace_bytes,
+                                   void *stream)
+{
     GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster2d_bwd: tile_size must be in [1,16], got %u", tile_size);
     GSX_REQUIRE(cdim >= 1 && cdim <= 32, "gsx_raster2d_bwd: unsupported number of channels %u (1..32)", cdim);
-    if (n_isects == 0) return GSX_OK; // no intersections: nothing to add to the (zero-filled, possibly empty) gradient rows
+    int64_t fill_bytes = v_rows_to_fill > 0 ? v_rows_to_fill * (int64_t)row_stride * 4 : 0;
+    auto fill_now      = [&]() -> int { // rows not filled by a kernel of this call
+        if (fill_bytes > 0 && v_rows && hipMemsetAsync(v_rows, 0, (size_t)fill_bytes, (hipStream_t)stream) != hipSuccess) {
+            set_last_error("gsx_raster2d_bwd_fill: memset failed");
+            return GSX_ERR_LAUNCH;
+        }
+        fill_bytes = 0;
+        return GSX_OK;
+    };
+    if (n_isects == 0) return fill_now(); // no intersections: nothing to add to the (zero-filled, possibly empty) gradient rows
     GSX_REQUIRE(v_rows, "gsx_raster2d_bwd: null gradient output");
     GSX_REQUIRE(row_stride >= 17u + (has_abs ? 2u : 0u) + cdim, "gsx_raster2d_bwd: row_stride %u too small", row_stride);
     GSX_REQUIRE(n_isects == 0 || (means2d && ray_transforms && colors && opacities && normals && flatten_ids
                                   && render_colors && render_alphas && last_ids && median_ids && v_render_colors
-                                  && v_render_alphas && v_render_normals && v_render_median && isect_offsets),
+                                  && isect_offsets), // v_render_alphas / _normals / _distort / _median: NULL = zeros
                 "gsx_raster2d_bwd: null input");
     Raster2DArgs a{};
     a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height; a.tile_size = tile_size;
@@ -956,10 +985,13 @@ extern "C" int gsx_raster2d_bwd_ws(const float *means2d, const float *ray_transf
     a.v_rows = v_rows; a.row_stride = row_stride;
     hipStream_t s = (hipStream_t)stream;
     {
-        int rc       = GSX_OK;
+        int rc               = GSX_OK;
+        const bool in_kernel = fill_bytes > 0 && (reinterpret_cast<uintptr_t>(v_rows) & 15u) == 0;
         a.tile_order = build_tile_order(isect_offsets, last_ids, n_images, tile_size, tile_w, tile_h, width, height, n_isects,
-                                        workspace, workspace_bytes, s, &rc);
+                                        workspace, workspace_bytes, s, &rc, in_kernel ? v_rows : nullptr, fill_bytes);
         if (rc != GSX_OK) return rc;
+        if (a.tile_order && in_kernel) fill_bytes = 0; // done by the cost kernel
     }
+    if (int rc = fill_now(); rc != GSX_OK) return rc;
     return has_abs ? dispatch2_bwd<true>(a, s) : dispatch2_bwd<false>(a, s);
 }

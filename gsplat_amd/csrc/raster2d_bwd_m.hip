@@ -122,11 +122,11 @@ raster2d_bwd_m_kernel(const Raster2DArgs a)
 #pragma unroll
     for (int k = 0; k < CH; ++k) v_c[k] = (inside && k < nch) ? a.v_render_colors[pix * a.cdim + k] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v_n[k] = inside ? a.v_render_normals[pix * 3 + k] : 0.0f;
-    const float v_a = inside ? a.v_render_alphas[pix] : 0.0f;
+    for (int k = 0; k < 3; ++k) v_n[k] = (inside && a.v_render_normals) ? a.v_render_normals[pix * 3 + k] : 0.0f;
+    const float v_a = (inside && a.v_render_alphas) ? a.v_render_alphas[pix] : 0.0f;
     // the median depth's cotangent: once per pixel, to the recorded surfel's depth channel (see raster2d_bwd_kernel)
     if (inside && T_final < 1.0f) {
-        const float v_median = a.v_render_median[pix];
+        const float v_median = a.v_render_median ? a.v_render_median[pix] : 0.0f;
         if (v_median != 0.0f)
             atomic_add_f32(a.v_rows + (size_t)a.flatten_ids[a.median_ids[pix]] * a.row_stride + 17 + nch - 1, v_median);
     }

@@ -671,6 +671,17 @@ int gsx_raster2d_bwd_ws(const float *means2d, const float *ray_transforms, const
                      const float *v_render_median, uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width,
                      uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows,
                      uint32_t row_stride, void *workspace, int64_t workspace_bytes, void *stream);
+/* gsx_raster2d_bwd_ws for gradient rows that are NOT zero-filled yet (v_rows_to_fill rows; 0 = the caller filled them): the
+ * call fills them itself, inside the tile-order cost kernel when one is launched. In both entries v_render_alphas,
+ * v_render_normals, v_render_distort and v_render_median may be NULL (= zeros: an output the loss does not use). */
+int gsx_raster2d_bwd_fill(const float *means2d, const float *ray_transforms, const float *colors, const float *opacities,
+                     const float *normals, const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets,
+                     const int32_t *flatten_ids, const float *render_colors, const float *render_alphas,
+                     const int32_t *last_ids, const int32_t *median_ids, const float *v_render_colors,
+                     const float *v_render_alphas, const float *v_render_normals, const float *v_render_distort,
+                     const float *v_render_median, uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width,
+                     uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows,
+                     uint32_t row_stride, int64_t v_rows_to_fill, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 2DGS per-pixel post-processing (reference: gsplat/rendering.py:1519-1552; C++ orchestrator
