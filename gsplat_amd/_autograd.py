@@ -267,12 +267,38 @@ def _p2_setup(ctx, inputs, output):
     ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, ray_transforms)
 
 
-def _p2_backward(ctx, v_radii, v_means2d, v_depths, v_ray_transforms, v_normals):
+def _p2_backward(ctx, v_radii, v_means2d, v_depths, v_ray_transforms, v_normals, v_view_opacities=None):
     means, quats, scales, viewmats, Ks, radii, ray_transforms = ctx.saved_tensors
-    v_means, v_quats, v_scales, v_viewmats = _bwd("projection_2dgs_fused")(
+    res = _bwd("projection_2dgs_fused")(
         means, quats, scales, viewmats, Ks, ctx.width, ctx.height, radii, ray_transforms, v_means2d,
-        v_depths.contiguous(), v_ray_transforms, v_normals, ctx.needs_input_grad[3])  # row views are read in place
-    return (v_means, v_quats, v_scales, v_viewmats) + (None,) * 7
+        v_depths.contiguous(), v_ray_transforms, v_normals, ctx.needs_input_grad[3],  # row views are read in place
+        _v_view_opacities=v_view_opacities)
+    if v_view_opacities is not None:  # Projection2DGSWithViewOpacities: its twelfth input is `opacities`
+        return tuple(res[:4]) + (None,) * 7 + (res[4],)
+    return tuple(res) + (None,) * 7
+
+
+class Projection2DGSWithViewOpacities(torch.autograd.Function):
+    """projection_2dgs_fused (dense rows) that also hands out the per-view opacities [..., C, N] as one of its outputs, so that
+    their cotangent - a column of the 2DGS compositing backward's gradient rows - is summed over the views by the projection
+    backward kernel (see ProjectionWithViewOpacities). `opacities` is the LAST input. gsplat_amd's rasterization_2dgs() only."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        op_args, opacities = args[:-1], args[-1]
+        with torch._C._AutoDispatchBelowAutograd():
+            out = getattr(torch.ops, NS).projection_2dgs_fused.default(*op_args)
+        _p2_setup(ctx, op_args, out)
+        viewmats = op_args[3]
+        per_view = torch.broadcast_to(opacities[..., None, :], opacities.shape[:-1] + (viewmats.shape[-3], opacities.shape[-1]))
+        ctx.mark_non_differentiable(out[0])
+        return tuple(out) + (per_view,)
+
+    @staticmethod
+    def backward(ctx, v_radii, v_means2d, v_depths, v_ray_transforms, v_normals, v_per_view):
+        if v_per_view is None or not ctx.needs_input_grad[11]:
+            return _p2_backward(ctx, v_radii, v_means2d, v_depths, v_ray_transforms, v_normals) + (None,)
+        return _p2_backward(ctx, v_radii, v_means2d, v_depths, v_ray_transforms, v_normals, v_per_view)
 
 
 def _p2p_setup(ctx, inputs, output):

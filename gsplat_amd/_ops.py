@@ -1266,16 +1266,26 @@ def projection_2dgs_fused(means, quats, scales, viewmats, Ks, image_width, image
 
 @_op("projection_2dgs_fused_bwd")
 def projection_2dgs_fused_bwd(means, quats, scales, viewmats, Ks, image_width, image_height, radii, ray_transforms,
-                              v_means2d, v_depths, v_ray_transforms, v_normals, viewmats_requires_grad):
+                              v_means2d, v_depths, v_ray_transforms, v_normals, viewmats_requires_grad, *,
+                              _v_view_opacities=None):
+    """`_v_view_opacities` (private, gsplat_amd's own autograd only): the cotangent of the per-view opacities [..., C, N]; the
+    kernel sums it over the views and a fifth value, v_opacities [..., N], is returned."""
     batch_dims, B, C, N = _proj_dims(means, viewmats)
     means, quats, scales, viewmats, Ks = (t.contiguous() for t in (means, quats, scales, viewmats, Ks))
     v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
     v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
     (v_means2d, v_rt, v_normals), vstride = _common_row_views(
         (v_means2d, v_ray_transforms.reshape(v_ray_transforms.shape[:-2] + (9,)), v_normals), (2, 9, 3))
-    call("gsx_project_2dgs_bwd", ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), B, C, N,
-         ptr(radii.contiguous()), ptr(ray_transforms.contiguous()), ptr_strided(v_means2d), ptr(_c(v_depths)),
-         ptr_strided(v_rt), ptr_strided(v_normals), vstride, ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
+    head = (ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), B, C, N,
+            ptr(radii.contiguous()), ptr(ray_transforms.contiguous()), ptr_strided(v_means2d), ptr(_c(v_depths)),
+            ptr_strided(v_rt), ptr_strided(v_normals), vstride)
+    if _v_view_opacities is not None:
+        v_view, opac_stride = _elem_view(_v_view_opacities)
+        v_opacities = torch.empty(tuple(batch_dims) + (N,), device=means.device, dtype=means.dtype)
+        call("gsx_project_2dgs_bwd_opac", *head, ptr_strided(v_view), opac_stride, ptr(v_means), ptr(v_quats), ptr(v_scales),
+             ptr(v_viewmats), ptr(v_opacities))
+        return v_means, v_quats, v_scales, v_viewmats, v_opacities
+    call("gsx_project_2dgs_bwd", *head, ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
     return v_means, v_quats, v_scales, v_viewmats
 
 

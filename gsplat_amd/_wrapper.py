@@ -411,6 +411,16 @@ def fully_fused_projection_2dgs(
                                       radius_clip)
 
 
+def fully_fused_projection_2dgs_view_opacities(means, quats, scales, viewmats, Ks, width, height, opacities, eps2d=0.3,
+                                               near_plane=0.01, far_plane=1e10, radius_clip=0.0):
+    """fully_fused_projection_2dgs (dense rows) + the per-view opacities [..., C, N] as a sixth output whose gradient the
+    projection backward reduces (``_autograd.Projection2DGSWithViewOpacities``). What gsplat_amd's rasterization_2dgs() calls;
+    not part of the reference's surface."""
+    return _autograd.Projection2DGSWithViewOpacities.apply(
+        means.contiguous(), quats.contiguous(), scales.contiguous(), viewmats.contiguous(), Ks.contiguous(), width, height,
+        eps2d, near_plane, far_plane, radius_clip, opacities.contiguous())
+
+
 def rasterize_to_pixels_2dgs(
     means2d: Tensor,  # [..., N, 2] or [nnz, 2]
     ray_transforms: Tensor,  # [..., N, 3, 3] or [nnz, 3, 3]

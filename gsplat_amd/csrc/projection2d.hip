@@ -163,6 +163,11 @@ struct Proj2BwdArgs {
     const int64_t *batch_ids, *camera_ids, *gaussian_ids;
     int rows_out; // packed, sparse_grad: outputs are [nnz, .] rows (one per packed row) instead of [B, N, .]
     float *v_means, *v_quats, *v_scales, *v_viewmats;
+    // (optional, dense) the cotangent of the per-view opacities [B, C, N], opac_stride floats apart (a column of the compositing
+    // backward's gradient rows), summed over the views into v_opacities [B, N] - as in projection.hip
+    const float *v_view_opacities;
+    uint32_t opac_stride;
+    float *v_opacities;
 };
 
 // VJP of one (camera, surfel) pair. Accumulates v_p (world mean), v_Rq (rotation matrix of the surfel, 3x3),
@@ -313,6 +318,11 @@ __global__ void __launch_bounds__(256) project2_bwd_kernel(const Proj2BwdArgs a)
         a.v_scales[bg * 3 + 0] = v_s[0];
         a.v_scales[bg * 3 + 1] = v_s[1];
         a.v_scales[bg * 3 + 2] = 0.0f;
+        if (a.v_opacities) { // an invisible pair's entry is the exact zero the compositing backward never touched
+            float v_o = 0.0f;
+            for (uint32_t c = 0; c < a.C; ++c) v_o += a.v_view_opacities[(size_t)(((int64_t)b * a.C + c) * a.N + g) * a.opac_stride];
+            a.v_opacities[bg] = v_o;
+        }
     }
 }
 
@@ -481,6 +491,36 @@ extern "C" int gsx_project_2dgs_bwd(const float *means, const float *quats, cons
     if (v_viewmats) project2_bwd_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
     else project2_bwd_kernel<false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
     return check_launch("project_2dgs_bwd");
+}
+
+// gsx_project_2dgs_bwd that also reduces the cotangent of the per-view opacities (see gsx_project_ewa_bwd_opac):
+// v_view_opacities[(b C + c) N + g] at v_view_opacities_stride floats per element -> v_opacities[b N + g] = sum over c.
+extern "C" int gsx_project_2dgs_bwd_opac(const float *means, const float *quats, const float *scales, const float *viewmats,
+                                         const float *Ks, uint32_t B, uint32_t C, uint32_t N, const int32_t *radii,
+                                         const float *ray_transforms, const float *v_means2d, const float *v_depths,
+                                         const float *v_ray_transforms, const float *v_normals, uint32_t v_row_stride,
+                                         const float *v_view_opacities, uint32_t v_view_opacities_stride, float *v_means,
+                                         float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities, void *stream)
+{
+    if ((int64_t)B * N == 0) return GSX_OK;
+    GSX_REQUIRE(v_opacities, "gsx_project_2dgs_bwd_opac: null v_opacities");
+    int rc = check2("gsx_project_2dgs_bwd_opac", means, quats, scales, viewmats, Ks);
+    if (rc != GSX_OK) return rc;
+    GSX_REQUIRE(C == 0 || (radii && ray_transforms && v_means2d && v_ray_transforms && v_normals && v_view_opacities
+                           && v_view_opacities_stride >= 1), "gsx_project_2dgs_bwd_opac: null input");
+    GSX_REQUIRE(v_means && v_quats && v_scales, "gsx_project_2dgs_bwd_opac: null output");
+    Proj2BwdArgs a{};
+    a.means = means; a.quats = quats; a.scales = scales; a.viewmats = viewmats; a.Ks = Ks; a.B = B; a.C = C; a.N = N;
+    a.radii = radii; a.ray_transforms = ray_transforms; a.v_means2d = v_means2d; a.v_depths = v_depths;
+    a.v_ray_transforms = v_ray_transforms; a.v_normals = v_normals;
+    a.m2_stride = v_row_stride ? v_row_stride : 2u; a.rt_stride = v_row_stride ? v_row_stride : 9u;
+    a.n_stride = v_row_stride ? v_row_stride : 3u;
+    a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_viewmats = v_viewmats;
+    a.v_view_opacities = v_view_opacities; a.opac_stride = v_view_opacities_stride; a.v_opacities = v_opacities;
+    const dim3 grid((uint32_t)ceil_div((int64_t)B * N, 256));
+    if (v_viewmats) project2_bwd_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
+    else project2_bwd_kernel<false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
+    return check_launch("project_2dgs_bwd_opac");
 }
 
 extern "C" int gsx_project_2dgs_packed_bwd(const float *means, const float *quats, const float *scales,

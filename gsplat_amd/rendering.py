@@ -741,9 +741,19 @@ def rasterization_2dgs(
            and tuple(Ks.shape) == batch_dims + (C, 3, 3), "inputs must share the batch dimensions of means ",
            list(batch_dims))
 
-    proj = fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width, height, eps2d=eps2d,
-                                       near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,
-                                       packed=packed, sparse_grad=sparse_grad)
+    view_opacities = None
+    if not packed and means.is_cuda and _VIEW_OPACITIES:
+        # dense rows: the per-view opacities come out of the projection's own autograd node (see rasterization())
+        from ._wrapper import fully_fused_projection_2dgs_view_opacities
+
+        proj = fully_fused_projection_2dgs_view_opacities(means, quats, scales, viewmats, Ks, width, height, opacities,
+                                                          eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
+                                                          radius_clip=radius_clip)
+        proj, view_opacities = proj[:5], proj[5]
+    else:
+        proj = fully_fused_projection_2dgs(means, quats, scales, viewmats, Ks, width, height, eps2d=eps2d,
+                                           near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,
+                                           packed=packed, sparse_grad=sparse_grad)
     if packed:
         batch_ids, camera_ids, gaussian_ids, _indptr, radii, means2d, depths, ray_transforms, normals = proj
         proj_opacities = opacities.reshape(-1).index_select(0, batch_ids * N + gaussian_ids if B > 1 else gaussian_ids)
@@ -751,7 +761,8 @@ def rasterization_2dgs(
     else:
         radii, means2d, depths, ray_transforms, normals = proj
         batch_ids = camera_ids = gaussian_ids = image_ids = None
-        proj_opacities = torch.broadcast_to(opacities[..., None, :], batch_dims + (C, N))
+        proj_opacities = view_opacities if view_opacities is not None else \
+            torch.broadcast_to(opacities[..., None, :], batch_dims + (C, N))
     densify = torch.zeros_like(means2d).requires_grad_(True)
 
     # tile intersection in two halves around the SH kernels, as in rasterization(): the host round trip for the number of
