@@ -401,6 +401,82 @@ def _sh_dims(means, viewmats, coeffs, gaussian_ids):
     return packed, B, C, N, K, D
 
 
+_SH_MAX_DEGREE = 4
+
+
+def _check_sh_inputs(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, omit_l0=False,
+                     gathered=True):
+    """The reference's input contract, message for message (SphericalHarmonics.cpp:38-131, check_spherical_harmonics_inputs);
+    `gathered=False` (private in-place layout: [N, K, D] rows read through gaussian_ids) skips the nnz row count."""
+    if not 0 <= degrees_to_use <= _SH_MAX_DEGREE:
+        raise ValueError(f"degrees_to_use must be between 0 and {_SH_MAX_DEGREE}, got {degrees_to_use}")
+    if means.dim() < 2 or means.shape[-1] != 3:
+        raise ValueError(f"means must have shape [..., N, 3], got {tuple(means.shape)}")
+    if viewmats.dim() != means.dim() + 1 or viewmats.shape[-2:] != (4, 4):
+        raise ValueError(f"viewmats must have shape [..., C, 4, 4], got {tuple(viewmats.shape)}")
+    if means.shape[:-2] != viewmats.shape[:-3]:
+        raise ValueError("means and viewmats batch dimensions must match")
+    if coeffs.dim() != 3:
+        raise ValueError(f"coeffs must have shape [N, K, D] or [nnz, K, D], got {tuple(coeffs.shape)}")
+    if coeffs.shape[-1] < 1:
+        raise ValueError(f"coeffs last dim D must be >= 1, got {coeffs.shape[-1]}")
+    if (degrees_to_use + 1) ** 2 - (1 if omit_l0 else 0) > coeffs.shape[-2]:
+        raise ValueError(f"degrees_to_use requires more SH coefficients than provided; degree {degrees_to_use}, "
+                         f"coeffs shape {tuple(coeffs.shape)}")
+    ids = (batch_ids, camera_ids, gaussian_ids)
+    packed = any(t is not None for t in ids)
+    if packed and not all(t is not None for t in ids):
+        raise ValueError("batch_ids, camera_ids, and gaussian_ids must either all be provided or all be None")
+    if packed:
+        nnz = coeffs.shape[0] if gathered else gaussian_ids.numel()
+        for t in ids:
+            if t.dim() != 1 or t.numel() != nnz:
+                raise ValueError("packed ID tensors must have shape [nnz]")
+            if t.dtype != torch.int64:
+                raise ValueError("packed ID tensors must be int64")
+        if masks is not None and (masks.dim() != 1 or masks.numel() != nnz):
+            raise ValueError("packed masks must have shape [nnz]")
+        if not gathered and coeffs.shape[0] != means.shape[-2]:
+            raise ValueError(f"coefficient rows are indexed by Gaussian: expected {means.shape[-2]} rows, got {coeffs.shape[0]}")
+    else:
+        if means.shape[-2] != coeffs.shape[0]:
+            raise ValueError("means N must match coeffs N in dense mode")
+        if masks is not None and tuple(masks.shape) != tuple(viewmats.shape[:-2]) + (means.shape[-2],):
+            raise ValueError("dense masks must have shape [..., C, N]")
+
+
+def _sh_rs_viewmats(viewmats, viewmats_rs):
+    """Rolling-shutter SH (reference SphericalHarmonics.cuh:40-65): the view direction is mean + offset with the camera
+    offset R^T t AVERAGED over the two shutter endpoints. An equivalent global-shutter view matrix (identity rotation,
+    t = that average) lets the kernels run unchanged."""
+    if tuple(viewmats_rs.shape) != tuple(viewmats.shape):
+        raise ValueError("viewmats_rs must match viewmats shape")
+    _check_f32(viewmats_rs=viewmats_rs)
+
+    def offset(vm):
+        return torch.einsum("...ji,...j->...i", vm[..., :3, :3], vm[..., :3, 3])
+
+    syn = torch.zeros_like(viewmats)
+    for d in range(4):
+        syn[..., d, d] = 1.0
+    syn[..., :3, 3] = 0.5 * (offset(viewmats) + offset(viewmats_rs))
+    return syn
+
+
+def _sh_rs_split(v_syn, viewmats, viewmats_rs, want, want_rs):
+    """Gradient of the synthetic matrix -> the two endpoints: v_syn[:3, 3] = S = sum over rows of v_dir (identity rotation);
+    offset_j = sum_i R_ij t_i, each endpoint weighs 1/2: v_R = t (x) S / 2, v_t = R S / 2."""
+    S = v_syn[..., :3, 3]
+
+    def back(vm):
+        g = torch.zeros_like(vm)
+        g[..., :3, :3] = 0.5 * vm[..., :3, 3][..., :, None] * S[..., None, :]
+        g[..., :3, 3] = 0.5 * torch.einsum("...ij,...j->...i", vm[..., :3, :3], S)
+        return g
+
+    return (back(viewmats) if want else None), (back(viewmats_rs) if want_rs else None)
+
+
 @_op("spherical_harmonics")
 def spherical_harmonics(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids,
                         viewmats_rs=None, *, _gathered: bool = True, _radii=None, _post: bool = False):
@@ -408,7 +484,8 @@ def spherical_harmonics(degrees_to_use, means, viewmats, coeffs, masks, batch_id
     coefficients through gaussian_ids; `_radii` masks rows by radii > 0 instead of a bool tensor; `_post` fuses the
     orchestrator's `clamp_min(colors + 0.5, 0)`."""
     if viewmats_rs is not None:
-        raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
+        viewmats = _sh_rs_viewmats(viewmats, viewmats_rs)
+    _check_sh_inputs(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, gathered=_gathered)
     if coeffs.dtype == torch.float16:
         # half coefficients, float arithmetic and colours (reference SphericalHarmonicsCUDA.cu:609-638): the band kernels
         # read [N, K, 3] half rows in place; gathered packed rows / D != 3 widen first (rare layouts)
@@ -442,8 +519,14 @@ def spherical_harmonics(degrees_to_use, means, viewmats, coeffs, masks, batch_id
 def spherical_harmonics_bwd(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids,
                             viewmats_rs, v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs,
                             *, _gathered: bool = True, _radii=None, _post_colors=None):
-    if viewmats_rs is not None or compute_v_viewmats_rs:
-        raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
+    if viewmats_rs is not None:
+        v_co, v_me, v_syn, _ = spherical_harmonics_bwd(
+            degrees_to_use, means, _sh_rs_viewmats(viewmats, viewmats_rs), coeffs, masks, batch_ids, camera_ids, gaussian_ids,
+            None, v_colors, compute_v_means, compute_v_viewmats or compute_v_viewmats_rs, False, _gathered=_gathered,
+            _radii=_radii, _post_colors=_post_colors)
+        v_vm, v_rs = (None, None) if v_syn is None else _sh_rs_split(v_syn, viewmats, viewmats_rs, compute_v_viewmats,
+                                                                     compute_v_viewmats_rs)
+        return v_co, v_me, v_vm, v_rs
     if coeffs.dtype == torch.float16:  # see spherical_harmonics: v_coeffs comes back in the coefficients' own type
         packed = gaussian_ids is not None
         if _band_kernels_apply(coeffs) and _radii is None and _post_colors is None and (not packed or not _gathered):
@@ -590,6 +673,10 @@ def isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_i
     else:
         _check_f32(means2d=means2d, depths=depths, conics=conics, opacities=opacities)
     packed = image_ids is not None
+    if packed and segmented:
+        # the reference refuses the combination (Intersect.cpp:207-211: its packed segment offsets collapse to one segment);
+        # `segmented` changes nothing here (the per-tile sort gives the same order), but the contract is the reference's
+        raise RuntimeError("segmented sort is not supported for packed inputs")
     means2d, radii, depths = means2d.contiguous(), radii.contiguous(), depths.contiguous()
     if radii.dtype != torch.int32:
         radii = radii.to(torch.int32)
@@ -902,6 +989,7 @@ def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, i
             return sp if len(batch_dims) <= 1 else sp.to_dense().reshape(like.shape)
 
         res = (coo(r_means, means), coo(r_covars, covars), coo(r_quats, quats), coo(r_scales, scales), v_viewmats)
+        clear_row_map_cache()  # the SH backward of this step (which runs first) may have left its map: this is the last consumer
         return res if _v_view_opacities is None else res + (scatter_opacities(),)
     # several images: walk the packed rows Gaussian-major through a row map (each output row written once, no atomics; the map
     # is the one the SH backward asked for); a single image: every Gaussian has at most one row and the row-major kernel
@@ -1053,15 +1141,23 @@ _SH_C0 = 0.2820947917738781
 
 @_op("spherical_harmonics_l0")
 def spherical_harmonics_l0(sh0):
-    _check_f32(sh0=sh0)
-    if sh0.dim() != 3 or sh0.shape[1] != 1:
+    """[N, 1, D] -> [N, D] in float32 (fp16 rows widen like the other SH ops' coefficients; SphericalHarmonics.cpp:149-262)."""
+    if sh0.dim() != 3:
         raise ValueError(f"sh0 must have shape [N, 1, D], got {tuple(sh0.shape)}")
-    return sh0[:, 0, :] * _SH_C0
+    if sh0.shape[-2] != 1:
+        raise ValueError(f"sh0 must contain exactly one SH coefficient, got {tuple(sh0.shape)}")
+    if sh0.shape[-1] < 1:
+        raise ValueError(f"sh0 last dim D must be >= 1, got {sh0.shape[-1]}")
+    if sh0.dtype not in (torch.float32, torch.float16):
+        raise TypeError(f"gsplat_amd: sh0 must be float32 or float16 (got {sh0.dtype})")
+    return sh0[:, 0, :].float() * _SH_C0
 
 
 @_op("spherical_harmonics_l0_bwd")
 def spherical_harmonics_l0_bwd(sh0, v_colors):
-    return (v_colors * _SH_C0)[:, None, :].contiguous()
+    if v_colors.dim() != 2 or v_colors.shape[0] != sh0.shape[0] or v_colors.shape[1] != sh0.shape[2]:
+        raise ValueError(f"v_colors must have shape [N, D], got {tuple(v_colors.shape)}")
+    return (v_colors * _SH_C0)[:, None, :].to(sh0.dtype).contiguous()
 
 
 def _pad_band0(shN):
@@ -1130,31 +1226,52 @@ def _band_kernels_apply(coeffs) -> bool:
 
 @_op("spherical_harmonics_l1_plus")
 def spherical_harmonics_l1_plus(degrees_to_use, means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids,
-                                viewmats_rs=None):
-    """colours of bands l >= 1 from shN [N, K - 1, D] read IN PLACE (csrc/sh_band.hip; reference
-    SphericalHarmonicsL1PlusCUDA.cu:441): no concatenation with a zero band. D != 3 goes through the general kernels on a
-    zero-padded band 0 (same arithmetic for k >= 1)."""
+                                viewmats_rs=None, *, _gathered: bool = True):
+    """colours of bands l >= 1 from shN [N, K - 1, D] (packed: the reference's contract is PRE-GATHERED rows [nnz, K - 1, D],
+    SphericalHarmonics.cpp:90-104). D == 3 rows indexed by Gaussian are read IN PLACE (csrc/sh_band.hip; reference
+    SphericalHarmonicsL1PlusCUDA.cu:441: no concatenation with a zero band); gathered packed rows and D != 3 go through the
+    general kernels on a zero-padded band 0 (same arithmetic for k >= 1). Private keyword `_gathered=False` (rendering.py):
+    packed rows read [N, K - 1, 3] through gaussian_ids."""
     if viewmats_rs is not None:
-        raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
+        viewmats = _sh_rs_viewmats(viewmats, viewmats_rs)
+    if shN.dim() != 3:
+        raise ValueError(f"shN must have shape [N, K - 1, D], got {tuple(shN.shape)}")
+    _check_sh_inputs(degrees_to_use, means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids, omit_l0=True,
+                     gathered=_gathered)
     _check_f32(means=means, viewmats=viewmats)
-    if _band_kernels_apply(shN):
+    packed = gaussian_ids is not None
+    if degrees_to_use == 0 or shN.shape[-2] == 0:  # no band >= 1 is evaluated (deg-0 zero contract; shN may be [N, 0, D])
+        shape = (shN.shape[0] if _gathered else gaussian_ids.shape[0], shN.shape[-1]) if packed \
+            else tuple(viewmats.shape[:-2]) + (means.shape[-2], shN.shape[-1])
+        return torch.zeros(shape, device=means.device, dtype=means.dtype)
+    if _band_kernels_apply(shN) and not (packed and _gathered):
         return _sh_band_fwd(degrees_to_use, 1, means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids)
     return spherical_harmonics(degrees_to_use, means, viewmats, _pad_band0(shN), masks, batch_ids, camera_ids,
-                               gaussian_ids, None, _gathered=False)
+                               gaussian_ids, None, _gathered=_gathered)
 
 
 @_op("spherical_harmonics_l1_plus_bwd")
 def spherical_harmonics_l1_plus_bwd(degrees_to_use, means, viewmats, shN, masks, batch_ids, camera_ids, gaussian_ids,
-                                    viewmats_rs, v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs):
-    if viewmats_rs is not None or compute_v_viewmats_rs:
-        raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
-    if _band_kernels_apply(shN):
+                                    viewmats_rs, v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs,
+                                    *, _gathered: bool = True):
+    if viewmats_rs is not None:
+        v_shN, v_me, v_syn, _ = spherical_harmonics_l1_plus_bwd(
+            degrees_to_use, means, _sh_rs_viewmats(viewmats, viewmats_rs), shN, masks, batch_ids, camera_ids, gaussian_ids, None,
+            v_colors, compute_v_means, compute_v_viewmats or compute_v_viewmats_rs, False, _gathered=_gathered)
+        v_vm, v_rs = (None, None) if v_syn is None else _sh_rs_split(v_syn, viewmats, viewmats_rs, compute_v_viewmats,
+                                                                     compute_v_viewmats_rs)
+        return v_shN, v_me, v_vm, v_rs
+    packed = gaussian_ids is not None
+    if degrees_to_use == 0 or shN.shape[-2] == 0:
+        return (torch.zeros_like(shN), torch.zeros_like(means) if compute_v_means else None,
+                torch.zeros_like(viewmats) if compute_v_viewmats else None, None)
+    if _band_kernels_apply(shN) and not (packed and _gathered):
         v_shN, v_means, v_viewmats = _sh_band_bwd(degrees_to_use, 1, means, viewmats, shN, masks, batch_ids, camera_ids,
                                                   gaussian_ids, v_colors, compute_v_means, compute_v_viewmats)
         return v_shN, v_means, v_viewmats, None
     v_coeffs, v_means, v_viewmats, v_rs = spherical_harmonics_bwd(
         degrees_to_use, means, viewmats, _pad_band0(shN), masks, batch_ids, camera_ids, gaussian_ids, viewmats_rs,
-        v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs, _gathered=False)
+        v_colors, compute_v_means, compute_v_viewmats, compute_v_viewmats_rs, _gathered=_gathered)
     return v_coeffs[:, 1:].contiguous(), v_means, v_viewmats, v_rs
 
 
@@ -1344,9 +1461,11 @@ def projection_2dgs_packed_bwd(means, quats, scales, viewmats, Ks, image_width, 
         def coo(vals, like):
             return torch.sparse_coo_tensor(indices, vals, size=like.shape, is_coalesced=(C == 1))
 
+        clear_row_map_cache()  # a packed 2DGS step's SH backward leaves its map; nothing after this op walks it
         return coo(r_means, means), coo(r_quats, quats), coo(r_scales, scales), v_viewmats
     v_means, v_quats, v_scales = torch.zeros_like(means), torch.zeros_like(quats), torch.zeros_like(scales)
     call("gsx_project_2dgs_packed_bwd", *head, ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats))
+    clear_row_map_cache()
     return v_means, v_quats, v_scales, v_viewmats
 
 
@@ -1386,6 +1505,10 @@ def rasterize_to_pixels_2dgs_bwd(means2d, ray_transforms, colors, opacities, nor
                                  tile_offsets, flatten_ids, render_colors, render_alphas, last_ids, median_ids,
                                  image_width, image_height, tile_size, absgrad, v_render_colors, v_render_alphas,
                                  v_render_normals, v_render_distort, v_render_median, compute_v_backgrounds):
+    """The dispatcher schema (verbatim from the reference's ext.cpp) declares the five cotangents as non-optional tensors; this
+    body ALSO accepts None for v_render_alphas / _normals / _distort / _median, but only through the private Python entry
+    (`_ops.impl()`, used by gsplat_amd's own autograd node) - a dispatcher call must pass dense cotangents
+    (tests/test_gpu_2dgs.py::test_dispatcher_2dgs_bwd_with_dense_cotangents)."""
     image_dims, I, th, tw, D = _raster_dims(tile_offsets, colors)
     means2d, ray_transforms, colors, opacities, normals = (t.contiguous() for t in (means2d, ray_transforms, colors,
                                                                                     opacities, normals))
@@ -1511,7 +1634,9 @@ def build_sparse_tile_layout(pixels, image_ids, n_images, tile_size, tile_width,
 @_op("intersect_tile_sparse")
 def intersect_tile_sparse(means2d, radii, depths, image_ids, tile_mask, active_tiles, I, tile_size, tile_width,
                           tile_height):
-    _check_f32(means2d=means2d, depths=depths)
+    f64 = means2d.dtype == torch.float64  # the reference dispatches over float and double (radius boxes in double; the depth
+    if not f64:                           # in the sort key is narrowed to float32): double rows take the generic kernels below
+        _check_f32(means2d=means2d, depths=depths)
     if tile_mask.dtype != torch.bool:
         raise TypeError("tile_mask must be bool")
     if active_tiles.dtype != torch.int32:
@@ -1533,7 +1658,7 @@ def intersect_tile_sparse(means2d, radii, depths, image_ids, tile_mask, active_t
     if rows == 0 or AT == 0:
         return empty
     sentinel = lambda n: torch.full((1,), n, device=dev, dtype=torch.int32)  # noqa: E731
-    if _cabi.isect_fused_supported(I, tile_width, tile_height, packed):
+    if not f64 and _cabi.isect_fused_supported(I, tile_width, tile_height, packed):
         # the dense fused path with the tile mask applied inside the walk (AABB test: conics / opacities NULL, as the
         # reference's sparse enumeration, Intersect.cpp:617-634): inactive tiles get empty segments, so the dense
         # offsets of the active tiles ARE the compacted offsets
@@ -1748,7 +1873,7 @@ def assemble_proj_features_unpacked_fwd(degrees_to_use, B, C, N, Dc, E, color_po
                                         relu_mask):
     """Checks follow the reference host op (SphericalHarmonics.cpp:572-676). Writes ``out`` (and ``relu_mask``) in place."""
     if viewmats_rs is not None:
-        raise NotImplementedError("gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path")
+        viewmats = _sh_rs_viewmats(viewmats, viewmats_rs)  # view direction from the averaged camera offset
     _check_f32(means=means, viewmats=viewmats, coeffs=coeffs, out=out, extra=extra, depths=depths)
     width, lead = Dc + E + (1 if has_depth else 0), B * C * N
     if coeffs.dim() != 3 or coeffs.shape[0] != N or coeffs.shape[2] != Dc:
@@ -2129,7 +2254,37 @@ def _os_environ_get(k, d):
     return os.environ.get(k, d)
 
 
+class CheckError(RuntimeError, ValueError):
+    """A failed argument check of an op body, as the DISPATCHER reports it. The reference's bodies use TORCH_CHECK, which
+    Python sees as RuntimeError (its tests assert `pytest.raises(RuntimeError, match=...)`); this package's own Python API
+    documents ValueError / TypeError. An op called through `torch.ops.gsplat.*` raises a class that is both."""
+
+
+class CheckTypeError(RuntimeError, TypeError):
+    pass
+
+
+def _torch_check(fn):
+    """The dispatcher-side face of a Python op body: ValueError / TypeError become RuntimeError subclasses (see CheckError)."""
+    import functools
+
+    @functools.wraps(fn)
+    def body(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        except RuntimeError:
+            raise
+        except ValueError as e:
+            raise CheckError(str(e)) from None
+        except TypeError as e:
+            raise CheckTypeError(str(e)) from None
+
+    return body
+
+
 def _register():
+    for name in list(_impls):
+        _impls[name] = _torch_check(_impls[name])
     for name, schema in SCHEMAS.items():
         qual = f"{NS}::{name}"
         try:

@@ -288,8 +288,17 @@ __device__ __forceinline__ float staged_alpha_raw(const float4 &ga, float q)
 // bounded by |u| (|gu| + ...) with |u| <= 7.5 and, for the Gaussians that can pass the alpha test at all, |a| <= 7.5 +
 // extent: a few hundred at most for the tightest footprint (eps2d = 0.3) -> ~2e-5 absolute on e, ~1.5e-5 relative on alpha
 // (the tolerance of the parity tests is 1e-4 .. 1e-3; variant T's moments about the tile centre are conditioned alike).
+//
+// The sigma < 0 test. Mathematically e <= lo wherever the conic is positive definite, with equality at the mean; in fp32 the
+// cancelling terms leave e a few 1e-5 ABOVE lo for a pixel centre that sits (almost) exactly on the mean - and `e > lo` then
+// dropped the Gaussian at the one pixel where it weighs most (found by the reference's own
+// test_rasterize_num_contributing_gaussians, whose means are pixel centres). The staged reject level is therefore
+// lo + kLoMargin: a pair is rejected only where sigma < -kLoMargin / log2(e) ~ -8.5e-5, which a valid conic never reaches and
+// which costs an invalid one nothing that matters (alpha within 1.0001 of the opacity). Readers that need lo itself (the
+// backward's 1 / opacity) subtract the margin again.
+constexpr float kLoMargin = 1.220703125e-4f; // 2^-13
 struct StagedRow { // one staged Gaussian in LDS: 48 bytes, read as b128 + b128 + b64 from ONE address register
-    v4f p0;        // e0, gu, gv, lo
+    v4f p0;        // e0, gu, gv, lo + kLoMargin
     v4f p1;        // nA, nB, nC, colour 2
     v4f p2;        // colour 0, colour 1, colour 3, -
 };
@@ -299,7 +308,7 @@ __device__ __forceinline__ void stage_gaussian_e(float ax, float ay, float opac,
     const float lo = opac > 0.0f ? __log2f(opac) : -INFINITY; // opac <= 0 (or NaN) can never pass the alpha test
     const float A = 0.5f * kLog2e * ca, B = kLog2e * cb, C = 0.5f * kLog2e * cc;
     const float q0 = fmaf(ax, fmaf(A, ax, B * ay), C * ay * ay);
-    p0 = v4f{lo - q0, fmaf(2.0f * A, ax, B * ay), fmaf(B, ax, 2.0f * C * ay), lo};
+    p0 = v4f{lo - q0, fmaf(2.0f * A, ax, B * ay), fmaf(B, ax, 2.0f * C * ay), lo + kLoMargin};
     nA = -A; nB = -B; nC = -C;
 }
 __device__ __forceinline__ float staged_e(const v4f &p0, float nA, float nB, float nC, float u, float v)

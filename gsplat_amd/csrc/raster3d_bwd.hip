@@ -655,7 +655,7 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
             } else if (c == 4) {
                 val = 0.5f * (ay * (ay * S0 - 2.0f * Sv) + row[CH + 5]);
             } else if (c == 5) {
-                val = -S0 * __builtin_amdgcn_exp2f(-s_st[s].p0.w);
+                val = -S0 * __builtin_amdgcn_exp2f(kLoMargin - s_st[s].p0.w); // 1 / opacity
             } else {
                 const int k = c - 6;
                 if (k >= (int)a.nch) continue;
@@ -895,7 +895,7 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
             const int t_g    = info >> 4;
             const float4 aux = s_aux[t_g];
             const v4f p1     = s_st[t_g].p1; // (-A, -B, -C) of the staged form: Q = (2A, B; B, 2C) / log2(e)
-            const float lo   = s_st[t_g].p0.w;
+            const float lo   = s_st[t_g].p0.w - kLoMargin;
             const float ax = aux.x, ay = aux.y;
             const int32_t id = __float_as_int(aux.z);
             const float S0 = acc[CH], Su = acc[CH + 1], Sv = acc[CH + 2];

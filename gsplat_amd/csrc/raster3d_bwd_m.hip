@@ -394,7 +394,7 @@ raster3d_bwd_m_kernel(const Raster3DArgs a)
                 } else if (c == 4) {
                     val = 0.5f * (ay * (ay * S0 - 2.0f * Sv) + row[5]);
                 } else {
-                    val = -S0 * __builtin_amdgcn_exp2f(-s_st[s].p0.w); // v_opacity = sum vis v_alpha = -S_w / opacity
+                    val = -S0 * __builtin_amdgcn_exp2f(kLoMargin - s_st[s].p0.w); // v_opacity = sum vis v_alpha = -S_w / opacity
                 }
                 atomic_add_f32(a.v_rows + (size_t)s_id[s] * a.row_stride + c, val);
             }

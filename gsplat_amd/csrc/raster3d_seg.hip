@@ -374,7 +374,9 @@ extern "C" int gsx_raster3d_bwd_seg(
         if (rc != GSX_OK) return rc;
         seg_bwd_prefix_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(p);
     }
-    a.seg_mode = 2; a.seg_grid = p.max_items + n_blocks; // the slices first, the short tiles behind them
+    // the slices first, the short tiles behind them. The short-tile range must hold round8(n_blocks) workgroups whatever the
+    // device-side item count is (xcd_remap is a bijection over round8(n_blocks) slots only)
+    a.seg_mode = 2; a.seg_grid = p.max_items + ((n_blocks + 7u) / 8u) * 8u;
     if (seg_bwd_on_variant_w()) {
         // one wave per unit: a short tile of up to seg_cut entries started late is the launch's tail - take them longest-first
         // (the order lives behind the segment plan in the workspace, when the caller sized it with the backward's own function)

@@ -6,7 +6,14 @@
 // exclusive cumsum, pass 2 writes gaussian ids and the combined pixel id (pixel + image * H * W) at those offsets.
 // `range_start` / `range_end` count batches of tile_size^2 list entries, as in the reference. Not a hot path: one thread
 // per pixel, parameters read straight from global memory.
-#include "common.hpp"
+//
+// The alpha of a pair is evaluated with the SAME staged forms as the compositing kernels (raster3d.hpp: stage_gaussian_e /
+// staged_e about the tile centre; raster2d.hpp: stage_surfel / eval_surfel) and the transmittance advances with the same
+// fma, so that the set of pairs this op reports IS the set the rasterizer blends - the contract of the reference, whose
+// two kernels share one device function (RasterizeToPixels3DGSDevice.cuh). The reference's own PyTorch rasterizer
+// (_torch_impl.py:_rasterize_to_pixels) takes its pairs from this op and is compared with the rasterizer at 1e-5: an
+// alpha test decided by two different roundings flips a pair per ~10^5 pixels (reference suite, round 6).
+#include "raster2d.hpp"
 
 namespace gsx {
 
@@ -37,7 +44,10 @@ __global__ void __launch_bounds__(256) raster_indices_kernel(const IndicesArgs a
     const int64_t lo    = start + bs * a.range_start;
     const int64_t hi    = min((int64_t)end, start + bs * (int64_t)a.range_end);
     const bool first    = a.chunk_starts == nullptr;
-    const float px = (float)ox + 0.5f, py = (float)oy + 0.5f;
+    const uint32_t tile_x = ox / a.tile_size, tile_y = oy / a.tile_size;
+    const float half = 0.5f * (float)a.tile_size; // tile centre and this pixel's centre relative to it, as the compositing kernels form them
+    const float tcx = (float)(tile_x * a.tile_size) + half, tcy = (float)(tile_y * a.tile_size) + half;
+    const float u = (float)(ox - tile_x * a.tile_size) + 0.5f - half, v = (float)(oy - tile_y * a.tile_size) + 0.5f - half;
     float T = a.transmittances[gid];
     int32_t cnt = 0;
     const int64_t base = first ? 0 : a.chunk_starts[gid];
@@ -45,25 +55,24 @@ __global__ void __launch_bounds__(256) raster_indices_kernel(const IndicesArgs a
         const int32_t g = a.flatten_ids[idx];
         float alpha;
         bool valid;
+        const float mx = a.means2d[2 * (size_t)g], my = a.means2d[2 * (size_t)g + 1];
         if (a.mode == 0) {
-            const float dx = a.means2d[2 * (size_t)g] - px, dy = a.means2d[2 * (size_t)g + 1] - py;
             const float *c = a.geom + 3 * (size_t)g;
-            const float sigma = 0.5f * (c[0] * dx * dx + c[2] * dy * dy) + c[1] * dx * dy;
-            alpha = fminf(kMaxAlpha, a.opacities[g] * __expf(-sigma));
-            valid = !(sigma < 0.0f) && !(alpha < kAlphaThreshold);
+            v4f p0;
+            float nA, nB, nC;
+            stage_gaussian_e(mx - tcx, my - tcy, a.opacities[g], c[0], c[1], c[2], p0, nA, nB, nC);
+            const float e = staged_e(p0, nA, nB, nC, u, v);
+            alpha = fminf(kMaxAlpha, __builtin_amdgcn_exp2f(e));
+            valid = !(e > p0.w) && !(alpha < kAlphaThreshold); // e > lo (+ margin) <=> sigma < 0
         } else {
-            const float *M = a.geom + 9 * (size_t)g;
-            const float hu0 = px * M[6] - M[0], hu1 = px * M[7] - M[1], hu2 = px * M[8] - M[2];
-            const float hv0 = py * M[6] - M[3], hv1 = py * M[7] - M[4], hv2 = py * M[8] - M[5];
-            const float rx = hu1 * hv2 - hu2 * hv1, ry = hu2 * hv0 - hu0 * hv2, rz = hu0 * hv1 - hu1 * hv0;
-            const float sx = rx / rz, sy = ry / rz;
-            const float dx = a.means2d[2 * (size_t)g] - px, dy = a.means2d[2 * (size_t)g + 1] - py;
-            const float sigma = 0.5f * fminf(sx * sx + sy * sy, kFilterInvSquare2DGS * (dx * dx + dy * dy));
-            alpha = fminf(kMaxAlpha, a.opacities[g] * __expf(-sigma));
-            valid = (rz != 0.0f) && !(sigma < 0.0f) && !(alpha < kAlphaThreshold);
+            float4 A, B, C;
+            stage_surfel(a.geom + 9 * (size_t)g, mx, my, a.opacities[g], tcx, tcy, A, B, C);
+            const Surfel sf = eval_surfel(A, B, C, u, v);
+            alpha = sf.alpha;
+            valid = sf.valid;
         }
         if (!valid) continue;
-        const float next_T = T * (1.0f - alpha);
+        const float next_T = fmaf(-T, alpha, T); // the compositing kernels' update
         if (next_T <= kTransmittanceThresh) break; // exclusive stop
         if (!first) {
             a.gaussian_ids[base + cnt] = (int64_t)(g % (int32_t)a.n_per_image);

@@ -83,7 +83,7 @@ void check(int rc, const char *fn)
 {
     if (rc == 0) return;
     const std::string msg = gsx_last_error();
-    TORCH_CHECK_VALUE(rc != -1, fn, ": ", msg); // GSX_ERR_ARG -> ValueError, like TORCH_CHECK_VALUE in the reference
+    TORCH_CHECK(rc != -1, fn, ": ", msg); // GSX_ERR_ARG: an argument check, RuntimeError like the reference's TORCH_CHECK
     TORCH_CHECK(false, fn, " failed (code ", rc, "): ", msg);
 }
 
@@ -93,7 +93,7 @@ bool has(const OptTensor &t) { return t.has_value() && t->defined(); }
 
 void want_f32(const Tensor &t, const char *name)
 {
-    TORCH_CHECK_TYPE(t.scalar_type() == at::kFloat, "gsplat_amd: ", name, " must be float32 (got ", t.scalar_type(),
+    TORCH_CHECK(t.scalar_type() == at::kFloat, "gsplat_amd: ", name, " must be float32 (got ", t.scalar_type(),
                      "); the gfx950 kernels compute in fp32");
 }
 void want_f32(const OptTensor &t, const char *name)
@@ -157,7 +157,7 @@ projection_ewa_3dgs_fused(const Tensor &means_, const OptTensor &covars_, const 
 {
     want_f32(means_, "means"); want_f32(covars_, "covars"); want_f32(quats_, "quats"); want_f32(scales_, "scales");
     want_f32(viewmats_, "viewmats"); want_f32(Ks_, "Ks");
-    TORCH_CHECK_VALUE(has(covars_) || (has(quats_) && has(scales_)), "projection: either covars or (quats, scales) must be given");
+    TORCH_CHECK(has(covars_) || (has(quats_) && has(scales_)), "projection: either covars or (quats, scales) must be given");
     Launch L(means_);
     const Tensor means = contig(means_), viewmats = contig(viewmats_), Ks = contig(Ks_);
     const OptTensor covars = contig(covars_), opac = contig(opacities_);
@@ -231,7 +231,7 @@ projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const
     (void)sparse_grad;
     want_f32(means_, "means"); want_f32(covars_, "covars"); want_f32(quats_, "quats"); want_f32(scales_, "scales");
     want_f32(viewmats_, "viewmats"); want_f32(Ks_, "Ks");
-    TORCH_CHECK_VALUE(has(covars_) || (has(quats_) && has(scales_)), "projection: either covars or (quats, scales) must be given");
+    TORCH_CHECK(has(covars_) || (has(quats_) && has(scales_)), "projection: either covars or (quats, scales) must be given");
     Launch L(means_);
     const Tensor means = contig(means_), viewmats = contig(viewmats_), Ks = contig(Ks_);
     const OptTensor covars = contig(covars_), opac = contig(opacities_);
@@ -312,7 +312,7 @@ ShDims sh_dims(const Tensor &means, const Tensor &viewmats, const Tensor &coeffs
 {
     ShDims d;
     d.packed = has(gaussian_ids);
-    TORCH_CHECK_VALUE(coeffs.dim() == 3, "coeffs must have shape [N, K, D] or [nnz, K, D], got ", coeffs.sizes());
+    TORCH_CHECK(coeffs.dim() == 3, "coeffs must have shape [N, K, D] or [nnz, K, D], got ", coeffs.sizes());
     d.B = prod(means.sizes().slice(0, means.dim() - 2));
     d.C = viewmats.size(-3);
     d.N = means.size(-2);
@@ -321,11 +321,73 @@ ShDims sh_dims(const Tensor &means, const Tensor &viewmats, const Tensor &coeffs
     return d;
 }
 
+// The reference's input contract, message for message (SphericalHarmonics.cpp:38-131; Python twin: _ops._check_sh_inputs)
+void check_sh_inputs(int64_t degrees_to_use, const Tensor &means, const Tensor &viewmats, const Tensor &coeffs,
+                     const OptTensor &masks, const OptTensor &batch_ids, const OptTensor &camera_ids, const OptTensor &gaussian_ids)
+{
+    TORCH_CHECK(degrees_to_use >= 0 && degrees_to_use <= 4, "degrees_to_use must be between 0 and 4, got ", degrees_to_use);
+    TORCH_CHECK(means.dim() >= 2 && means.size(-1) == 3, "means must have shape [..., N, 3], got ", means.sizes());
+    TORCH_CHECK(viewmats.dim() == means.dim() + 1 && viewmats.size(-2) == 4 && viewmats.size(-1) == 4,
+                "viewmats must have shape [..., C, 4, 4], got ", viewmats.sizes());
+    TORCH_CHECK(means.sizes().slice(0, means.dim() - 2) == viewmats.sizes().slice(0, viewmats.dim() - 3),
+                "means and viewmats batch dimensions must match");
+    TORCH_CHECK(coeffs.dim() == 3, "coeffs must have shape [N, K, D] or [nnz, K, D], got ", coeffs.sizes());
+    TORCH_CHECK(coeffs.size(-1) >= 1, "coeffs last dim D must be >= 1, got ", coeffs.size(-1));
+    TORCH_CHECK((degrees_to_use + 1) * (degrees_to_use + 1) <= coeffs.size(-2),
+                "degrees_to_use requires more SH coefficients than provided; degree ", degrees_to_use, ", coeffs shape ", coeffs.sizes());
+    const bool packed = has(batch_ids) || has(camera_ids) || has(gaussian_ids);
+    TORCH_CHECK(!packed || (has(batch_ids) && has(camera_ids) && has(gaussian_ids)),
+                "batch_ids, camera_ids, and gaussian_ids must either all be provided or all be None");
+    if (packed) {
+        const int64_t nnz = coeffs.size(0);
+        for (const OptTensor *ids : {&batch_ids, &camera_ids, &gaussian_ids}) {
+            TORCH_CHECK((*ids)->dim() == 1 && (*ids)->numel() == nnz, "packed ID tensors must have shape [nnz]");
+            TORCH_CHECK((*ids)->scalar_type() == at::kLong, "packed ID tensors must be int64");
+        }
+        if (has(masks)) TORCH_CHECK(masks->dim() == 1 && masks->numel() == nnz, "packed masks must have shape [nnz]");
+    } else {
+        TORCH_CHECK(means.size(-2) == coeffs.size(0), "means N must match coeffs N in dense mode");
+        if (has(masks)) {
+            at::DimVector mask_shape(viewmats.sizes().slice(0, viewmats.dim() - 2));
+            mask_shape.push_back(means.size(-2));
+            TORCH_CHECK(masks->sizes() == at::IntArrayRef(mask_shape), "dense masks must have shape [..., C, N]");
+        }
+    }
+}
+
+// Rolling-shutter SH (reference SphericalHarmonics.cuh:40-65): view direction = mean + offset, the camera offset R^T t
+// AVERAGED over the two shutter endpoints. An equivalent global-shutter view matrix (identity rotation, t = that average) lets
+// the kernels run unchanged (Python twin: _ops._sh_rs_viewmats / _sh_rs_split).
+Tensor sh_rs_viewmats(const Tensor &viewmats, const Tensor &viewmats_rs)
+{
+    TORCH_CHECK(viewmats_rs.sizes() == viewmats.sizes(), "viewmats_rs must match viewmats shape");
+    TORCH_CHECK(viewmats_rs.scalar_type() == at::kFloat, "viewmats_rs must be float32");
+    auto offset = [](const Tensor &vm) {
+        return at::matmul(vm.narrow(-2, 0, 3).narrow(-1, 0, 3).transpose(-1, -2), vm.narrow(-2, 0, 3).narrow(-1, 3, 1)).squeeze(-1);
+    };
+    Tensor syn = at::zeros_like(viewmats);
+    syn.diagonal(0, -2, -1).fill_(1.0f);
+    syn.narrow(-2, 0, 3).select(-1, 3).copy_(0.5f * (offset(viewmats) + offset(viewmats_rs)));
+    return syn;
+}
+// v_syn[:3, 3] = S = sum over rows of v_dir; each endpoint weighs 1/2: v_R = t (x) S / 2, v_t = R S / 2
+Tensor sh_rs_back(const Tensor &v_syn, const Tensor &vm)
+{
+    const Tensor S = v_syn.narrow(-2, 0, 3).select(-1, 3);
+    Tensor g = at::zeros_like(vm);
+    g.narrow(-2, 0, 3).narrow(-1, 0, 3).copy_(0.5f * vm.narrow(-2, 0, 3).select(-1, 3).unsqueeze(-1) * S.unsqueeze(-2));
+    g.narrow(-2, 0, 3).select(-1, 3).copy_(0.5f * at::matmul(vm.narrow(-2, 0, 3).narrow(-1, 0, 3), S.unsqueeze(-1)).squeeze(-1));
+    return g;
+}
+
 Tensor spherical_harmonics(int64_t degrees_to_use, const Tensor &means_, const Tensor &viewmats_, const Tensor &coeffs_,
                            const OptTensor &masks_, const OptTensor &batch_ids_, const OptTensor &camera_ids_,
                            const OptTensor &gaussian_ids_, const OptTensor &viewmats_rs)
 {
-    TORCH_CHECK_NOT_IMPLEMENTED(!has(viewmats_rs), "gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path");
+    if (has(viewmats_rs))
+        return spherical_harmonics(degrees_to_use, means_, sh_rs_viewmats(viewmats_, *viewmats_rs), coeffs_, masks_, batch_ids_,
+                                   camera_ids_, gaussian_ids_, OptTensor());
+    check_sh_inputs(degrees_to_use, means_, viewmats_, coeffs_, masks_, batch_ids_, camera_ids_, gaussian_ids_);
     want_f32(means_, "means"); want_f32(viewmats_, "viewmats");
     if (coeffs_.scalar_type() == at::kHalf) {
         // half coefficients, float arithmetic and colours (reference SphericalHarmonicsCUDA.cu:609-638): the band kernels of
@@ -335,7 +397,7 @@ Tensor spherical_harmonics(int64_t degrees_to_use, const Tensor &means_, const T
             const Tensor means = contig(means_), viewmats = contig(viewmats_), coeffs = contig(coeffs_);
             const OptTensor masks = contig(masks_);
             const ShDims d = sh_dims(means, viewmats, coeffs, gaussian_ids_);
-            TORCH_CHECK_VALUE(coeffs.size(0) == d.N, "means N must match coeffs N in dense mode");
+            TORCH_CHECK(coeffs.size(0) == d.N, "means N must match coeffs N in dense mode");
             std::vector<int64_t> shape(viewmats.sizes().begin(), viewmats.sizes().end() - 2);
             shape.push_back(d.N); shape.push_back(3);
             Tensor colors = at::empty(shape, means.options());
@@ -359,7 +421,7 @@ Tensor spherical_harmonics(int64_t degrees_to_use, const Tensor &means_, const T
         nnz = gi->size(0);
         colors = at::empty({nnz, d.D}, means.options());
     } else {
-        TORCH_CHECK_VALUE(coeffs.size(0) == d.N, "means N must match coeffs N in dense mode");
+        TORCH_CHECK(coeffs.size(0) == d.N, "means N must match coeffs N in dense mode");
         std::vector<int64_t> shape(viewmats.sizes().begin(), viewmats.sizes().end() - 2);
         shape.push_back(d.N); shape.push_back(d.D);
         colors = at::empty(shape, means.options());
@@ -377,8 +439,18 @@ spherical_harmonics_bwd(int64_t degrees_to_use, const Tensor &means_, const Tens
                         const OptTensor &gaussian_ids_, const OptTensor &viewmats_rs, const Tensor &v_colors_,
                         bool compute_v_means, bool compute_v_viewmats, bool compute_v_viewmats_rs)
 {
-    TORCH_CHECK_NOT_IMPLEMENTED(!has(viewmats_rs) && !compute_v_viewmats_rs,
-                                "gsplat_amd: rolling-shutter SH (viewmats_rs) is outside the classic 3DGS path");
+    if (has(viewmats_rs)) {
+        auto r = spherical_harmonics_bwd(degrees_to_use, means_, sh_rs_viewmats(viewmats_, *viewmats_rs), coeffs_, masks_, batch_ids_,
+                                         camera_ids_, gaussian_ids_, OptTensor(), v_colors_, compute_v_means,
+                                         compute_v_viewmats || compute_v_viewmats_rs, false);
+        OptTensor v_vm, v_rs;
+        if (std::get<2>(r).has_value()) {
+            if (compute_v_viewmats) v_vm = sh_rs_back(*std::get<2>(r), viewmats_);
+            if (compute_v_viewmats_rs) v_rs = sh_rs_back(*std::get<2>(r), *viewmats_rs);
+        }
+        return {std::get<0>(r), std::get<1>(r), v_vm, v_rs};
+    }
+    TORCH_CHECK(!compute_v_viewmats_rs, "compute_v_viewmats_rs needs viewmats_rs");
     if (coeffs_.scalar_type() == at::kHalf) { // see spherical_harmonics: v_coeffs comes back in the coefficients' own type
         if (coeffs_.dim() == 3 && coeffs_.size(-1) == 3 && !has(gaussian_ids_)) {
             Launch L(means_);
@@ -496,10 +568,12 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
                const OptTensor &opacities_, const OptTensor &image_ids_, const OptTensor &gaussian_ids, std::optional<int64_t> n_images,
                int64_t tile_size, int64_t tile_w, int64_t tile_h, bool sort, bool segmented)
 {
-    (void)gaussian_ids; (void)segmented; // the global sort is used (results are identical to the segmented one)
+    (void)gaussian_ids; // the global sort is used (results are identical to the segmented one), but the reference's refusal of
+    // segmented + packed (Intersect.cpp:207-211) is part of the contract
+    TORCH_CHECK(!(has(image_ids_) && segmented), "segmented sort is not supported for packed inputs");
     const bool f64 = means2d_.scalar_type() == at::kDouble; // radius boxes in double, depth narrowed to float32 in the key
     if (f64) {
-        TORCH_CHECK_TYPE(!has(conics_) && !has(opacities_), "gsplat_amd: intersect_tile with float64 rows supports the "
+        TORCH_CHECK(!has(conics_) && !has(opacities_), "gsplat_amd: intersect_tile with float64 rows supports the "
                          "radius-box test only (conics / opacities select the exact test, which is computed in fp32)");
     } else {
         want_f32(means2d_, "means2d"); want_f32(depths_, "depths"); want_f32(conics_, "conics"); want_f32(opacities_, "opacities");
@@ -512,7 +586,7 @@ intersect_tile(const Tensor &means2d_, const Tensor &radii_, const Tensor &depth
     int64_t rows, n_per, I;
     std::vector<int64_t> out_shape;
     if (packed) {
-        TORCH_CHECK_VALUE(n_images.has_value(), "n_images is required when packed");
+        TORCH_CHECK(n_images.has_value(), "n_images is required when packed");
         rows = means2d.size(0); n_per = 1; I = *n_images;
         out_shape = {rows};
     } else {
@@ -679,9 +753,9 @@ rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Te
     want_f32(backgrounds_, "backgrounds");
     Launch L(means2d_);
     const RasterDims r = raster_dims(isect_offsets_, colors_);
-    TORCH_CHECK_VALUE(r.th * tile_size >= height && r.tw * tile_size >= width,
+    TORCH_CHECK(r.th * tile_size >= height && r.tw * tile_size >= width,
                       "rasterize_to_pixels: isect_offsets tile grid does not cover the image");
-    TORCH_CHECK_TYPE(!has(masks_) || masks_->scalar_type() == at::kBool, "masks must be a bool tensor");
+    TORCH_CHECK(!has(masks_) || masks_->scalar_type() == at::kBool, "masks must be a bool tensor");
     const Tensor means2d = contig(means2d_), conics = contig(conics_), colors = contig(colors_), opac = contig(opacities_);
     const OptTensor bg = contig(backgrounds_), masks = contig(masks_);
     const Tensor offsets = contig(isect_offsets_), flat = contig(flatten_ids_);
@@ -878,7 +952,7 @@ projection_2dgs_fused(const Tensor &means_, const Tensor &quats_, const Tensor &
     want_f32(means_, "means"); want_f32(quats_, "quats"); want_f32(scales_, "scales"); want_f32(viewmats_, "viewmats");
     want_f32(Ks_, "Ks");
     const int64_t N = means_.size(-2);
-    TORCH_CHECK_VALUE(means_.size(-1) == 3 && quats_.dim() >= 2 && quats_.size(-2) == N && quats_.size(-1) == 4
+    TORCH_CHECK(means_.size(-1) == 3 && quats_.dim() >= 2 && quats_.size(-2) == N && quats_.size(-1) == 4
                           && scales_.dim() >= 2 && scales_.size(-2) == N && scales_.size(-1) == 3,
                       "projection_2dgs: bad shapes means ", means_.sizes(), " quats ", quats_.sizes(), " scales ", scales_.sizes());
     Launch L(means_);
@@ -914,9 +988,9 @@ rasterize_to_pixels_2dgs(const Tensor &means2d_, const Tensor &ray_transforms_, 
     want_f32(opacities_, "opacities"); want_f32(normals_, "normals"); want_f32(backgrounds_, "backgrounds");
     Launch L(means2d_);
     const RasterDims r = raster_dims(tile_offsets_, colors_);
-    TORCH_CHECK_VALUE(r.th * tile_size >= height && r.tw * tile_size >= width,
+    TORCH_CHECK(r.th * tile_size >= height && r.tw * tile_size >= width,
                       "rasterize_to_pixels_2dgs: tile grid does not cover the image");
-    TORCH_CHECK_TYPE(!has(masks_) || masks_->scalar_type() == at::kBool, "masks must be a bool tensor");
+    TORCH_CHECK(!has(masks_) || masks_->scalar_type() == at::kBool, "masks must be a bool tensor");
     const Tensor means2d = contig(means2d_), rt = contig(ray_transforms_), colors = contig(colors_), opac = contig(opacities_),
                  normals = contig(normals_);
     const OptTensor bg = contig(backgrounds_), masks = contig(masks_);

@@ -27,12 +27,26 @@ class RendererConfig(enum.IntEnum):  # ext.cpp:66-77
 
 
 def build_config() -> dict:
+    """What `gsplat.has_*()` report (gsplat/cuda/_wrapper.py:253-296). A flag is True only when the WHOLE feature the
+    reference means by it is built: its tests gate on these flags (`skipif(not gsplat.has_3dgut())`), so a partial True turns
+    refused sub-features into failures instead of skips.
+
+    `3dgut`: the unscented projection (pinhole / distorted pinhole / ortho / fisheye / f-theta) and the from-world rasterizer
+    fwd / bwd with a global shutter are built and reachable through rasterization(with_ut / with_eval3d) whatever the flag
+    says; lidar cameras and tiling, external distortion, rolling-shutter projection and ParallelBatch are not - so the flag
+    is False. GSPLAT_AMD_3DGUT_SUBSET=1 reports True (the reference's 3DGUT tests then RUN against the built subset; the
+    table of tools/run_reference_suite.py --with-3dgut-subset is made that way)."""
+    import os
+
     has_2dgs = "rasterize_to_pixels_2dgs" in _ops.SCHEMAS
-    # 3dgut: UT projection + from-world compositing fwd / bwd for pinhole / distorted pinhole / ortho / fisheye cameras with
-    # a global shutter; f-theta, lidar, rolling shutter, hit distances and normals are refused by the ops themselves
-    has_3dgut = _ops.COMPOSITE_UNAVAILABLE is None and "rasterize_to_pixels_from_world_3dgs" in _ops.CLASS_SCHEMAS
+    has_3dgut = built_3dgut_subset() and os.environ.get("GSPLAT_AMD_3DGUT_SUBSET", "0") not in ("0", "")
     return {"3dgs": True, "2dgs": has_2dgs, "3dgut": has_3dgut, "adam": "adam" in _ops.SCHEMAS,
             "reloc": "relocation" in _ops.SCHEMAS, "losses": False, "camera_wrappers": False}
+
+
+def built_3dgut_subset() -> bool:
+    """True when the built part of 3DGUT (see build_config) is loadable - not a key of build_config(): its key set is ext.cpp's."""
+    return _ops.COMPOSITE_UNAVAILABLE is None and "rasterize_to_pixels_from_world_3dgs" in _ops.CLASS_SCHEMAS
 
 
 def null() -> None:  # ext.cpp:82

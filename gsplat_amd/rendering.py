@@ -11,7 +11,7 @@ of the reference (``gsplat/rendering.py:234-690``) and the stage order of its C+
 
 3DGUT: ``with_ut`` (Unscented-Transform projection through pinhole / distorted-pinhole / ortho / fisheye / f-theta cameras,
 global shutter) and ``with_eval3d`` (from-world compositing) are built; what is NOT built is refused up front, before
-any kernel launches, never approximated: f-theta / lidar cameras, rolling shutter, external (windshield) distortion,
+any kernel launches, never approximated: f-theta outside the UT projection, lidar cameras, rolling shutter, external (windshield) distortion,
 ray generation for distorted cameras (pass ``rays``), the hit-distance render modes and ``return_normals``.
 """
 from __future__ import annotations
@@ -146,7 +146,7 @@ def rasterization(
         raise RuntimeError(
             "gsplat_amd builds the classic 3DGS path and, of 3DGUT, the unscented projection and the from-world rasterizer for "
             "global-shutter pinhole / distorted-pinhole / orthographic / fisheye (and, for the projection, f-theta) cameras "
-            "(build_config()['3dgut'] is True); "
+            "(csrc_shim.built_3dgut_subset(); build_config()['3dgut'] stays False while the feature is partial); "
             f"these sub-features are not built - not supported, refused rather than approximated: {', '.join(bad)}"
         )
     if camera_model not in ("pinhole", "ortho", "fisheye", "ftheta"):
@@ -155,7 +155,8 @@ def rasterization(
         raise ValueError("ftheta_coeffs must be given if and only if camera_model is 'ftheta'")
     # `segmented` (gsplat/rendering.py:262; IntersectTile.cu:1125-1176) only selects how the reference sorts - per image instead
     # of one global radix sort. Both give the same (image, tile, depth) order with ties in emission order, which is what the
-    # per-tile sort of this backend produces, so the flag is accepted and changes nothing.
+    # per-tile sort of this backend produces, so the flag changes nothing - except that, as in the reference, the intersection
+    # refuses it together with packed rows (Intersect.cpp:207-211).
 
     if covars is not None and _covars_triu:
         # gsplat::rasterization_3dgs receives the upper-triangular 6-vectors (gsplat/rendering.py:540-544 converts)
@@ -247,7 +248,7 @@ def rasterization(
     isect_pending = None
     if dist_ctx is None:
         isect_pending = isect_tiles_begin(
-            means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=False, packed=packed,
+            means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=segmented, packed=packed,
             n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids, conics=None if with_ut else conics,
             opacities=None if with_ut else proj_opacities.contiguous())  # UT: plain radius boxes (Rendering.cpp:1307-1308)
 
@@ -286,7 +287,7 @@ def rasterization(
     # ---- tile intersection (second half) -----------------------------------------------------------
     if isect_pending is None:
         isect_pending = isect_tiles_begin(
-            means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=False, packed=packed,
+            means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=segmented, packed=packed,
             n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids_r, conics=conics,
             opacities=proj_opacities.contiguous())
     tiles_per_gauss, isect_ids, flatten_ids = isect_tiles_finish(isect_pending)

@@ -449,3 +449,32 @@ def test_surfel_post_matches_tensor_ops(G, expected_depth, depth_source, C, W, H
             continue
         assert torch.isfinite(a.grad).all(), nm
         assert_grad_close(cpu(a.grad), cpu(b.grad).float(), rel=5e-3 if depth_source else 1e-5, max_bad_ratio=2e-3, name=nm)
+
+
+def test_dispatcher_2dgs_bwd_with_dense_cotangents(G):
+    """`torch.ops.gsplat.rasterize_to_pixels_2dgs_bwd` through the DISPATCHER (the schema is the reference's: five non-optional
+    cotangents) equals the private entry that gsplat_amd's autograd node uses with None for the unused ones."""
+    from gsplat_amd import _ops
+
+    N, C, W, H, ts, D = 2000, 1, 128, 96, 16, 4
+    sc, W, H = make_scene(N=N, C=C, width=W, height=H, seed=81)
+    dsc = {k: v.to(DEV) for k, v in sc.items()}
+    rad, m2, d, M, nrm = G.fully_fused_projection_2dgs(dsc["means"], dsc["quats"], dsc["scales"], dsc["viewmats"], dsc["Ks"], W, H)
+    op = dsc["opacities"][None].expand(C, -1).contiguous()
+    tw, th = math.ceil(W / ts), math.ceil(H / ts)
+    _, ids, fl = G.isect_tiles(m2, rad, d, ts, tw, th)
+    off = G.isect_offset_encode(ids, C, tw, th)
+    g = torch.Generator().manual_seed(3)
+    colors = torch.rand(C, N, D, generator=g).to(DEV)
+    densify = torch.zeros_like(m2)
+    fwd = torch.ops.gsplat.rasterize_to_pixels_2dgs(m2, M, colors, op, nrm, densify, None, None, W, H, ts, off, fl)
+    rc, ra, rn, rd, rm, last_ids, median_ids = fwd
+    v_rc = torch.randn(rc.shape, generator=g).to(DEV)
+    zeros = [torch.zeros_like(t) for t in (ra, rn, rd, rm)]
+    head = (m2, M, colors, op, nrm, densify, None, None, off, fl, rc, ra, last_ids, median_ids, W, H, ts, False, v_rc)
+    dense = torch.ops.gsplat.rasterize_to_pixels_2dgs_bwd(*head, *zeros, False)
+    private = _ops.impl("rasterize_to_pixels_2dgs_bwd")(*head, None, None, None, None, False)
+    for a, b in zip(dense, private):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)

@@ -968,7 +968,7 @@ def test_isect_tiles_float64_rows(G, O, batch_dims, via):
                           image_ids=image_ids.to(DEV), gaussian_ids=torch.zeros_like(image_ids).to(DEV))
     for a, b in zip(got_p, want_p):
         assert torch.equal(cpu(a), b)
-    with pytest.raises(TypeError):
+    with pytest.raises(RuntimeError):  # a failed check of a dispatcher op is a RuntimeError, like the reference's TORCH_CHECK
         torch.ops.gsplat.intersect_tile(means2d.to(DEV), radii.to(DEV), depths.to(DEV),
                                         torch.ones(shape + (3,), dtype=torch.float64, device=DEV),
                                         torch.ones(shape, dtype=torch.float64, device=DEV), None, None, None, ts, tw, th, True, False)

@@ -379,10 +379,14 @@ def test_rasterization_segmented_flag_is_accepted(G):
     sc, W, H = make_scene(N=3000, C=2, width=160, height=112, seed=6)
     d = {k: v.to(DEV) for k, v in sc.items()}
     outs = [G.rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"], d["Ks"], W, H,
-                            segmented=flag) for flag in (False, True)]
+                            packed=False, segmented=flag) for flag in (False, True)]
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][2]["isect_ids"], outs[1][2]["isect_ids"])
     assert torch.equal(outs[0][2]["flatten_ids"], outs[1][2]["flatten_ids"])
+    # ... and, as in the reference (Intersect.cpp:207-211), refused together with packed rows
+    with pytest.raises(RuntimeError, match="segmented sort is not supported for packed inputs"):
+        G.rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"], d["Ks"], W, H,
+                        packed=True, segmented=True)
 
 
 def test_c2_garden_scene_1080p_matches_oracle(G):

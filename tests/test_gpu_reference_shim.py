@@ -87,7 +87,7 @@ for tag, kw in (("packed (the default)", {}), ("packed explicit", dict(packed=Tr
                 ("dense absgrad", dict(packed=False, absgrad=True)), ("packed absgrad", dict(packed=True, absgrad=True)),
                 ("packed sparse_grad", dict(packed=True, sparse_grad=True)),
                 ("antialiased", dict(packed=False, rasterize_mode="antialiased")),
-                ("segmented", dict(packed=True, segmented=True))):
+                ("segmented", dict(packed=False, segmented=True))):
     ref_out, own_out = run_kw(gsplat.rasterization, **kw), run_kw(gsplat_amd.rasterization, **kw)
     compare(tag, ref_out, own_out)
     if "sparse_grad" in kw:

@@ -1,3 +1,4 @@
+import os
 """CPU: host-side helpers and the algebra the kernels rely on (no kernels run here)."""
 import numpy as np
 import pytest
@@ -24,7 +25,17 @@ def test_feature_probes_follow_build_config():
     cfg = gsplat_amd.build_config()
     assert set(cfg) == {"3dgs", "2dgs", "3dgut", "adam", "reloc", "losses", "camera_wrappers"}  # ext.cpp:83-97
     assert gsplat_amd.has_3dgs() and gsplat_amd.has_2dgs() and gsplat_amd.has_adam() and gsplat_amd.has_reloc()
-    assert gsplat_amd.has_3dgut() and not gsplat_amd.has_losses() and not gsplat_amd.has_camera_wrappers()
+    # 3DGUT is built in part (UT projection + from-world rasterizer, global shutter; no lidar / rolling-shutter projection): the
+    # reference's flag means the whole feature and its tests gate on it, so it reports False unless the subset is asked for
+    assert not gsplat_amd.has_3dgut() and not gsplat_amd.has_losses() and not gsplat_amd.has_camera_wrappers()
+    from gsplat_amd import csrc_shim
+
+    assert csrc_shim.built_3dgut_subset()
+    os.environ["GSPLAT_AMD_3DGUT_SUBSET"] = "1"
+    try:
+        assert csrc_shim.build_config()["3dgut"] is True
+    finally:
+        del os.environ["GSPLAT_AMD_3DGUT_SUBSET"]
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
@@ -136,3 +147,18 @@ def test_elem_view_reads_single_columns_in_place():
     assert st == 1 and t.is_contiguous()
     t, st = _elem_view(torch.zeros(1).expand(4))  # stride 0: a copy
     assert st == 1 and t.is_contiguous() and t.numel() == 4
+
+
+def test_storage_wrapper_identity_is_preserved_by_this_torch_build():
+    """`_ops._note_longest`'s Python fallback (compiled shim absent) keys a note by a weak reference to the tensor's untyped
+    storage WRAPPER: that only works on torch builds that hand the same PyObject back for the same StorageImpl while anything
+    holds it (PyObject preservation). Pin that behaviour: if a torch upgrade breaks it the notes silently never match."""
+    import weakref
+
+    import torch
+
+    t = torch.zeros(8)
+    ref = weakref.ref(t.untyped_storage())  # the wrapper is a temporary here, as in _note_longest
+    assert ref() is not None and ref() is t.untyped_storage() and ref() is t[2:].untyped_storage()
+    del t
+    assert ref() is None  # and the note dies with the storage

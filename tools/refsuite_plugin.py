@@ -60,6 +60,13 @@ def _accumulate_along_rays(weights, values=None, ray_indices=None, n_rays=None):
     return out.index_add(0, ray_indices.long(), src)
 
 
+def _pack_info(ray_indices, n_rays=None):
+    """[n_rays, 2] (first sample, sample count) per ray from sorted ray indices."""
+    n = int(n_rays) if n_rays is not None else (int(ray_indices.max().item()) + 1 if ray_indices.numel() else 0)
+    counts = torch.bincount(ray_indices.long(), minlength=n)
+    return torch.stack([torch.cumsum(counts, 0) - counts, counts], dim=-1)
+
+
 if "nerfacc" not in sys.modules:
     try:
         import nerfacc  # noqa: F401
@@ -67,7 +74,20 @@ if "nerfacc" not in sys.modules:
         _m = types.ModuleType("nerfacc")
         _m.render_weight_from_alpha = _render_weight_from_alpha
         _m.accumulate_along_rays = _accumulate_along_rays
+        _m.pack_info = _pack_info
         sys.modules["nerfacc"] = _m
+
+# tests/test_rasterization.py imports ONE helper (parse_lidar_camera) from tests/test_cameras.py, a module that skips itself at
+# import time unless the camera-wrapper classes are built (`has_camera_wrappers()`: out of scope here) - which would skip the
+# whole of test_rasterization.py with it. A stand-in module keeps the file collectable; the lidar cases that call the helper skip.
+if not _shim.build_config().get("camera_wrappers", False):
+    _tc = types.ModuleType("tests.test_cameras")
+
+    def _parse_lidar_camera(*_a, **_k):
+        pytest.skip("lidar camera wrappers are not built (tests/test_cameras.py is skipped without them)")
+
+    _tc.parse_lidar_camera = _parse_lidar_camera
+    sys.modules["tests.test_cameras"] = _tc
 
 _LOG = os.environ.get("REFSUITE_LOG")
 _DONE = os.environ.get("REFSUITE_DONE")

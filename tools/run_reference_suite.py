@@ -87,6 +87,8 @@ def parse_log(path):
 def run_file(tree, fname, args, log, done):
     env = dict(os.environ)
     env["REFSUITE_LOG"], env["REFSUITE_DONE"] = log, done
+    if args.with_3dgut_subset:
+        env["GSPLAT_AMD_3DGUT_SUBSET"] = "1"
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tools"), ROOT, env.get("PYTHONPATH", "")])
     cmd = [sys.executable, "-m", "pytest", "-p", "refsuite_plugin", "-p", "no:cacheprovider", "-q", "-x" if args.exitfirst else "-q",
            "--timeout", str(args.timeout), "--tb=short", "-o", "addopts=", os.path.join("tests", fname)]
@@ -117,6 +119,9 @@ def main():
     ap.add_argument("--exitfirst", action="store_true")
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--from-archives", action="store_true", help="ignore a reference checkout (what the GPU box sees)")
+    ap.add_argument("--with-3dgut-subset", action="store_true",
+                    help="GSPLAT_AMD_3DGUT_SUBSET=1: has_3dgut() reports True, so the reference's 3DGUT tests RUN against the "
+                         "built subset instead of skipping (the default build_config says False: the feature is partial)")
     args = ap.parse_args()
 
     tree = tempfile.mkdtemp(prefix="refsuite_")
@@ -156,7 +161,8 @@ def main():
     except Exception:
         device = "?"
     with open(args.out + ".txt", "w") as f:
-        f.write("# the reference's own tests over gsplat_amd.csrc_shim; reference tree from: %s; device: %s\n" % (src, device))
+        f.write("# the reference's own tests over gsplat_amd.csrc_shim; reference tree from: %s; device: %s; has_3dgut(): %s\n"
+                % (src, device, "True (GSPLAT_AMD_3DGUT_SUBSET=1)" if args.with_3dgut_subset else "False (default)"))
         f.write("# totals: %s\n" % json.dumps(total, sort_keys=True))
         for fname, c in summary.items():
             f.write("# %-36s %s\n" % (fname, json.dumps({k: v for k, v in c.items() if k != "tail"}, sort_keys=True)))
