@@ -27,6 +27,7 @@ _LAZY = {
     "has_adam": "_wrapper", "has_reloc": "_wrapper", "has_losses": "_wrapper", "has_camera_wrappers": "_wrapper",
     "rasterize_to_indices_in_range": "_wrapper", "rasterize_to_indices_in_range_2dgs": "_wrapper",
     "rasterization": "rendering", "rasterization_2dgs": "rendering", "distributed": "distributed",
+    "IsectPathMemory": "_cabi",  # per-caller memory of the intersection's path choice (include/gsplat_amd.h)
     # the training step around the rasterizer
     "SelectiveAdam": "optimizers", "compute_relocation": "relocation", "DefaultStrategy": "strategy",
     "MCMCStrategy": "strategy", "strategy": "strategy", "optimizers": "optimizers", "relocation": "relocation",

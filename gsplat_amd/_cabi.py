@@ -54,7 +54,7 @@ def _parse_header(path: str):
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     sigs = {}
-    for m in re.finditer(r"\b(int64_t|int|const char \*)\s*(gsx_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|const char \*|void \*|void)\s*(gsx_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         codes = []
         if args and args != "void":
@@ -72,7 +72,7 @@ def _parse_header(path: str):
                     codes.append("i")
                 else:
                     raise ImportError(f"gsplat_amd: cannot parse argument '{a}' of {name} in {path}")
-        sigs[name] = ({"int": "i", "int64_t": "l"}.get(ret, "s"), codes)
+        sigs[name] = ({"int": "i", "int64_t": "l", "void *": "p", "void": "v"}.get(ret, "s"), codes)
     return sigs
 
 
@@ -102,7 +102,7 @@ SIGNATURES = _load_signatures()
 def _bind():
     for name, (ret, codes) in SIGNATURES.items():
         fn = getattr(_lib, name)  # AttributeError here = header/library mismatch: fail loudly
-        fn.restype = {"i": ctypes.c_int, "l": _L, "s": ctypes.c_char_p}[ret]
+        fn.restype = {"i": ctypes.c_int, "l": _L, "s": ctypes.c_char_p, "p": ctypes.c_void_p, "v": None}[ret]
         fn.argtypes = [_CODES[c] for c in codes]
 
 
@@ -278,6 +278,32 @@ def isect_binned_supported(rows: int, n_images: int, tile_w: int, tile_h: int, p
 def isect_binned_should_try(rows: int, n_images: int, tile_w: int, tile_h: int, packed: bool) -> bool:
     """The decision of ONE intersection (counts a skipped call while a retry note is active): call once, keep the answer."""
     return bool(_lib.gsx_isect_binned_should_try(rows, n_images, tile_w, tile_h, int(packed)))
+
+
+class IsectPathMemory:
+    """The retry notes of the tile-owner-major intersection path, owned by ONE caller (include/gsplat_amd.h:
+    gsx_isect_path_memory_*). Which intersection kernel runs depends on recent history (a clustered scene that was sent back is
+    not tried again for 63 calls); `with memory:` makes that history this object's for the calls inside, on this thread - a
+    trainer and a viewer, or two trainers, each hold their own. Without one, a thread uses a private default."""
+
+    def __init__(self):
+        self._h = _lib.gsx_isect_path_memory_create()
+        if not self._h:
+            raise MemoryError("gsx_isect_path_memory_create failed")
+        self._prev = []
+
+    def __enter__(self):
+        self._prev.append(_lib.gsx_isect_path_memory_use(self._h))
+        return self
+
+    def __exit__(self, *exc):
+        _lib.gsx_isect_path_memory_use(self._prev.pop())
+        return False
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.gsx_isect_path_memory_destroy(h)
 
 
 def isect_binned_count_workspace_bytes(rows: int, n_images: int, tile_w: int, tile_h: int) -> int:

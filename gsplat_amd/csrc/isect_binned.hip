@@ -39,6 +39,7 @@
 #include "isect_fused.hpp"
 #include <cstdlib>
 #include <mutex>
+#include <new>
 
 namespace gsx {
 
@@ -785,11 +786,21 @@ using namespace gsx;
 // A clustered scene fails the skew test 25 us into the count half and the call starts over Gaussian-major (garden x25, packed:
 // forward 1258 fps where the Gaussian-major path alone gives 1340). A trainer renders the same scene every step: after a retry
 // the next 63 calls of that shape (row count to 64 k, images, tile grid) skip the attempt, the 64th probes again.
+//
+// WHOSE memory: never the process'. The notes live in a PathMemory object. A caller that wants its own (a trainer, a renderer
+// serving one scene) creates one with gsx_isect_path_memory_create() and makes it current for its calls with
+// gsx_isect_path_memory_use(); every thread that never did owns a private default. Which kernel runs therefore depends on the
+// history of THAT caller only - two scenes of one shape rendered alternately by two owners do not flip each other's path.
 namespace {
 struct RetryNote { uint64_t key; int left; };
-std::mutex g_retry_mutex;
-RetryNote g_retry[16];
-uint32_t g_retry_next = 0;
+struct PathMemory {
+    std::mutex mu;
+    RetryNote notes[16] = {};
+    uint32_t next = 0;
+};
+thread_local PathMemory t_default_memory;
+thread_local PathMemory *t_current_memory = nullptr; // null: the thread's own default
+PathMemory &current_memory() { return t_current_memory ? *t_current_memory : t_default_memory; }
 uint64_t retry_key(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
 {
     return ((uint64_t)(rows >> 16) << 40) ^ ((uint64_t)n_images << 32) ^ ((uint64_t)tile_w << 16) ^ (uint64_t)tile_h ^ (1ull << 63);
@@ -798,8 +809,9 @@ uint64_t retry_key(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t ti
 bool retried_recently(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, bool consume)
 {
     const uint64_t key = retry_key(rows, n_images, tile_w, tile_h);
-    std::lock_guard<std::mutex> lock(g_retry_mutex);
-    for (auto &n : g_retry)
+    PathMemory &m = current_memory();
+    std::lock_guard<std::mutex> lock(m.mu);
+    for (auto &n : m.notes)
         if (n.key == key && n.left > 0) {
             if (consume) --n.left;
             return true;
@@ -808,16 +820,31 @@ bool retried_recently(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t
 }
 } // namespace
 
+extern "C" void *gsx_isect_path_memory_create(void) { return new (std::nothrow) PathMemory(); }
+extern "C" void gsx_isect_path_memory_destroy(void *mem)
+{
+    PathMemory *m = static_cast<PathMemory *>(mem);
+    if (m && t_current_memory == m) t_current_memory = nullptr;
+    delete m;
+}
+extern "C" void *gsx_isect_path_memory_use(void *mem)
+{
+    void *prev = t_current_memory;
+    t_current_memory = static_cast<PathMemory *>(mem);
+    return prev;
+}
+
 extern "C" int gsx_isect_binned_note_retry(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h)
 {
     const uint64_t key = retry_key(rows, n_images, tile_w, tile_h);
-    std::lock_guard<std::mutex> lock(g_retry_mutex);
-    for (auto &n : g_retry)
+    PathMemory &m = current_memory();
+    std::lock_guard<std::mutex> lock(m.mu);
+    for (auto &n : m.notes)
         if (n.key == key) {
             n.left = 63;
             return GSX_OK;
         }
-    g_retry[g_retry_next++ % 16u] = RetryNote{key, 63};
+    m.notes[m.next++ % 16u] = RetryNote{key, 63};
     return GSX_OK;
 }
 

@@ -440,6 +440,16 @@ int gsx_isect_binned_supported(int64_t rows, uint32_t n_images, uint32_t tile_w,
  * gsx_isect_binned_count (gsplat::intersect_tile, Intersect.cpp:170-329). */
 int gsx_isect_binned_should_try(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h, int packed);
 int gsx_isect_binned_note_retry(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h); /* returns 0 */
+/* WHOSE retry notes: never the process'. They live in a path-memory object; the three functions above read and write the one
+ * that is CURRENT for the calling thread - a private per-thread default until the caller installs its own. A binding that
+ * serves several independent callers (two trainers, a trainer and a viewer) creates one object per caller and brackets that
+ * caller's intersections with gsx_isect_path_memory_use(mem) ... gsx_isect_path_memory_use(previous); which kernel runs then
+ * depends on the history of that caller alone. _use returns the previously current object (NULL = the thread's default),
+ * _destroy of the current object falls back to the default. No reference counterpart: the reference has one intersection path
+ * (Intersect.cpp:170-329); this is bookkeeping of the path choice inside gsplat::intersect_tile. */
+void *gsx_isect_path_memory_create(void);
+void gsx_isect_path_memory_destroy(void *mem);
+void *gsx_isect_path_memory_use(void *mem);
 int64_t gsx_isect_binned_count_workspace_bytes(int64_t rows, uint32_t n_images, uint32_t tile_w, uint32_t tile_h);
 int64_t gsx_isect_binned_emit_workspace_bytes(int64_t n_isects);
 int gsx_isect_binned_count(const float *means2d, const int32_t *radii, const float *depths, const float *conics,

@@ -162,3 +162,34 @@ def test_storage_wrapper_identity_is_preserved_by_this_torch_build():
     assert ref() is not None and ref() is t.untyped_storage() and ref() is t[2:].untyped_storage()
     del t
     assert ref() is None  # and the note dies with the storage
+
+
+def test_intersection_path_memory_is_per_caller_and_per_thread():
+    """Which intersection kernel runs depends on retry notes (a clustered scene that was sent back is not tried again for 63
+    calls). The notes belong to a caller-owned object or to the calling THREAD's private default - never to the process
+    (include/gsplat_amd.h: gsx_isect_path_memory_*)."""
+    import threading
+
+    import gsplat_amd
+    from gsplat_amd import _cabi
+
+    L = _cabi._lib
+    shape = (1_000_000, 1, 120, 68)
+    assert L.gsx_isect_binned_should_try(*shape, 0) == 1
+    mine, other = gsplat_amd.IsectPathMemory(), gsplat_amd.IsectPathMemory()
+    with mine:
+        L.gsx_isect_binned_note_retry(*shape)
+        assert L.gsx_isect_binned_supported(*shape, 0) == 0  # this caller was sent back: skip the attempt
+        with other:
+            assert L.gsx_isect_binned_supported(*shape, 0) == 1  # another caller's history is its own
+        assert L.gsx_isect_binned_supported(*shape, 0) == 0
+    assert L.gsx_isect_binned_supported(*shape, 0) == 1  # the thread's default never saw the retry
+    L.gsx_isect_binned_note_retry(*shape)  # ... until it is sent back itself
+    assert L.gsx_isect_binned_supported(*shape, 0) == 0
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(L.gsx_isect_binned_supported(*shape, 0)))
+    t.start()
+    t.join()
+    assert seen == [1]  # another thread has its own default
+    skipped = sum(1 for _ in range(70) if L.gsx_isect_binned_should_try(*shape, 0) == 0)
+    assert skipped == 63  # 63 intersections skip the attempt, the 64th probes again
