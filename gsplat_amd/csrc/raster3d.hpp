@@ -318,6 +318,42 @@ __device__ __forceinline__ float staged_e(const v4f &p0, float nA, float nB, flo
     return fmaf(v, t2, fmaf(u, t1, p0.x));
 }
 
+// ---- staged form of the FORWARD-side kernels ("d-form": raster3d_fwd*.hip, raster_indices.hip) ---------------------------------
+// The tile-centre polynomial costs five fmas per (pixel, Gaussian) but loses digits where its terms cancel: |e - exact| reaches
+// ~2e-5 (p99.99) on log2(alpha), 1.5e-5 relative on alpha - which the REFERENCE'S OWN forward test does not allow: it compares
+// the rasterizer with its PyTorch restatement at atol 1e-5 (tests/test_basic.py:2639, torch.testing.assert_close defaults), and
+// over the shim 23 of 2.4 M colour values missed that by up to 0.41e-5 (profiles/r10_reference_suite.txt). The forward kernels
+// therefore evaluate the exponent the way the reference does, from the offset d = mean - pixel (two subtractions more per pair):
+//   e = lo - (A dx^2 + B dx dy + C dy^2) = fma(dx, fma(nB, dy, nA dx), fma(nC dy, dy, lo))
+// whose error is a few ulp of the RESULT (~3e-6 at p99.99). e == lo exactly at the mean, so the sigma < 0 test needs no margin.
+// The backward kernels keep the polynomial (its moments want the tile-centre frame); the two agree to ~1.5e-5 on alpha, the
+// forward's decisions (last_ids, the 1/255 and 1e-4 tests) are what the backward is handed. GSX_FWD_DFORM=0 builds the
+// polynomial into the forward kernels again (A/B of the two instructions).
+#ifndef GSX_FWD_DFORM
+#define GSX_FWD_DFORM 1
+#endif
+__device__ __forceinline__ void stage_gaussian_f(float ax, float ay, float opac, float ca, float cb, float cc, v4f &p0,
+                                                 float &nA, float &nB, float &nC)
+{
+#if GSX_FWD_DFORM
+    const float lo = opac > 0.0f ? __log2f(opac) : -INFINITY; // opac <= 0 (or NaN) can never pass the alpha test
+    p0 = v4f{ax, ay, lo, lo}; // mean - tile centre | base of the exponent | reject level (e > lo <=> sigma < 0)
+    nA = -0.5f * kLog2e * ca; nB = -kLog2e * cb; nC = -0.5f * kLog2e * cc;
+#else
+    stage_gaussian_e(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
+#endif
+}
+// (u, v) = pixel centre - tile centre
+__device__ __forceinline__ float staged_f(const v4f &p0, float nA, float nB, float nC, float u, float v)
+{
+#if GSX_FWD_DFORM
+    const float dx = p0.x - u, dy = p0.y - v;
+    return fmaf(dx, fmaf(nB, dy, nA * dx), fmaf(nC * dy, dy, p0.z));
+#else
+    return staged_e(p0, nA, nB, nC, u, v);
+#endif
+}
+
 // ---- wave-level culling -------------------------------------------------------------------------
 // A Gaussian can only pass the reference's `alpha >= 1/255` test (Device.cuh:52-55) at offsets d with
 // sigma(d) = 1/2 d^T Q d <= L = ln(255 * opacity). The staging thread of each Gaussian computes the

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 const float ax = xy.x - cx, ay = xy.y - cy;
                 v4f p0;
                 float nA, nB, nC;
-                stage_gaussian_e(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
+                stage_gaussian_f(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
                 const float2 he = cull_half_extent(opac, ca, cb, cc);
                 s_cull[s]       = make_float4(ax, ay, he.x, he.y);
                 const float *c  = a.colors + (size_t)g * a.cdim + a.ch_off;
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
                 const v4f p0 = s_st[t].p0;
                 const v4f p1 = s_st[t].p1;
                 const v4f p2 = s_st[t].p2; // one address register for the three reads (b128 + b128 + b64 / b128)
-                const float e     = staged_e(p0, p1.x, p1.y, p1.z, u, v);
+                const float e     = staged_f(p0, p1.x, p1.y, p1.z, u, v);
                 const float alpha = fminf(kMaxAlpha, __builtin_amdgcn_exp2f(e));
                 // Branch-free body. The scalar unit, not the vector ALU, was the busiest pipe of this kernel when "pixel is
                 // done" lived in an EXEC-style mask (25 scalar instructions per surviving Gaussian, r05 PMC): the state now

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) raster3d_fwd_m_kernel(const Raster3DArgs 
                     const float ax = xy.x - tile_cx, ay = xy.y - tile_cy;
                     v4f p0;
                     float nA, nB, nC;
-                    stage_gaussian_e(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
+                    stage_gaussian_f(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
                     const float2 he = cull_half_extent(opac, ca, cb, cc);
                     s_cull[s]  = make_float4(ax, ay, he.x, he.y);
                     s_st[s].p0 = p0;
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) raster3d_fwd_m_kernel(const Raster3DArgs 
                     const int32_t t = SLOTS * grp + k;
                     const v4f p0 = s_st[t].p0;
                     const v4f p1 = s_st[t].p1;
-                    const float e     = staged_e(p0, p1.x, p1.y, p1.z, pu, pv);
+                    const float e     = staged_f(p0, p1.x, p1.y, p1.z, pu, pv);
                     const float alpha = fminf(kMaxAlpha, __builtin_amdgcn_exp2f(e));
                     const bool ok     = !(e > p0.w) && !(alpha < thr); // e > lo <=> sigma < 0
                     const float next_T = fmaf(-T, alpha, T);

@@ -167,7 +167,7 @@ __device__ __forceinline__ void raster3d_fwd_w_body(const Raster3DArgs &a)
                 const float ax = f.xy.x - tile_cx, ay = f.xy.y - tile_cy;
                 v4f p0;
                 float nA, nB, nC;
-                stage_gaussian_e(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
+                stage_gaussian_f(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
                 const v4f p1  = v4f{nA, nB, nC, f.cv[2]};
                 s_st[lane].p0 = p0;
                 s_st[lane].p1 = p1;
@@ -207,7 +207,7 @@ __device__ __forceinline__ void raster3d_fwd_w_body(const Raster3DArgs &a)
             for (int q = 0; q < NQ; ++q) {
                 if (!(qm & (1u << q))) continue; // scalar
                 const uint32_t gq = q_first + (uint32_t)q;
-                const float e     = staged_e(p0, p1.x, p1.y, p1.z, pu[gq & 1u], pv[gq >> 1]);
+                const float e     = staged_f(p0, p1.x, p1.y, p1.z, pu[gq & 1u], pv[gq >> 1]);
                 const float alpha = fminf(kMaxAlpha, __builtin_amdgcn_exp2f(e));
                 // branch-free body (raster3d_fwd.hip): passes / saturates / is blended are lane masks combined on the scalar side
                 const bool ok = !(e > p0.w) && !(alpha < thr[q]); // e > lo <=> sigma < 0

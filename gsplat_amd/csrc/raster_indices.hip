@@ -60,8 +60,8 @@ __global__ void __launch_bounds__(256) raster_indices_kernel(const IndicesArgs a
             const float *c = a.geom + 3 * (size_t)g;
             v4f p0;
             float nA, nB, nC;
-            stage_gaussian_e(mx - tcx, my - tcy, a.opacities[g], c[0], c[1], c[2], p0, nA, nB, nC);
-            const float e = staged_e(p0, nA, nB, nC, u, v);
+            stage_gaussian_f(mx - tcx, my - tcy, a.opacities[g], c[0], c[1], c[2], p0, nA, nB, nC);
+            const float e = staged_f(p0, nA, nB, nC, u, v);
             alpha = fminf(kMaxAlpha, __builtin_amdgcn_exp2f(e));
             valid = !(e > p0.w) && !(alpha < kAlphaThreshold); // e > lo (+ margin) <=> sigma < 0
         } else {

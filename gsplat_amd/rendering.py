@@ -522,8 +522,12 @@ def _project_features(features, sh_degree, clamp, means, viewmats, radii, batch_
         valid = None if packed else (radii > 0).all(dim=-1)
         vals = base
         if sh_degree > 0:
-            vals = vals + spherical_harmonics_l1_plus(sh_degree, means, viewmats, shN, masks=valid, batch_ids=batch_ids,
-                                                      camera_ids=camera_ids, gaussian_ids=gaussian_ids)
+            if packed:
+                # shN stays in its [N, K - 1, D] layout, read through gaussian_ids (the public op's packed contract is the
+                # reference's: rows pre-gathered to [nnz, K - 1, D])
+                vals = vals + _ShBandUngathered.apply(sh_degree, means, viewmats, shN, batch_ids, camera_ids, gaussian_ids)
+            else:
+                vals = vals + spherical_harmonics_l1_plus(sh_degree, means, viewmats, shN, masks=valid)
         vals = vals + 0.5
         if clamp:
             vals = vals.clamp_min(0.0)
@@ -571,6 +575,31 @@ class _ShColors(torch.autograd.Function):
             ctx.needs_input_grad[1], ctx.needs_input_grad[2], False, _gathered=False, _radii=radii,
             _post_colors=colors)
         return None, v_means, v_viewmats, v_coeffs, None, None, None, None
+
+
+class _ShBandUngathered(torch.autograd.Function):
+    """spherical_harmonics_l1_plus on packed rows with shN left in its [N, K - 1, D] layout (csrc/sh_band.hip reads the rows
+    through gaussian_ids). Same math and gradients as spherical_harmonics_l1_plus(shN[gaussian_ids])."""
+
+    @staticmethod
+    def forward(ctx, degree, means, viewmats, shN, batch_ids, camera_ids, gaussian_ids):
+        from ._ops import impl
+
+        means, viewmats, shN = means.contiguous(), viewmats.contiguous(), shN.contiguous()
+        ctx.degree = degree
+        ctx.save_for_backward(means, viewmats, shN, batch_ids, camera_ids, gaussian_ids)
+        return impl("spherical_harmonics_l1_plus")(degree, means, viewmats, shN, None, batch_ids, camera_ids, gaussian_ids,
+                                                   None, _gathered=False)
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        from ._ops import impl
+
+        means, viewmats, shN, batch_ids, camera_ids, gaussian_ids = ctx.saved_tensors
+        v_shN, v_means, v_viewmats, _ = impl("spherical_harmonics_l1_plus_bwd")(
+            ctx.degree, means, viewmats, shN, None, batch_ids, camera_ids, gaussian_ids, None, v_colors.contiguous(),
+            ctx.needs_input_grad[1], ctx.needs_input_grad[2], False, _gathered=False)
+        return None, v_means, v_viewmats, v_shN, None, None, None
 
 
 class _ShUngathered(torch.autograd.Function):

@@ -467,8 +467,8 @@ def test_dispatcher_2dgs_bwd_with_dense_cotangents(G):
     g = torch.Generator().manual_seed(3)
     colors = torch.rand(C, N, D, generator=g).to(DEV)
     densify = torch.zeros_like(m2)
-    fwd = torch.ops.gsplat.rasterize_to_pixels_2dgs(m2, M, colors, op, nrm, densify, None, None, W, H, ts, off, fl)
-    rc, ra, rn, rd, rm, last_ids, median_ids = fwd
+    fwd = torch.ops.gsplat.rasterize_to_pixels_2dgs(m2, M, colors, op, nrm, densify, None, None, W, H, ts, off, fl, False, False, True)
+    rc, ra, rn, rd, rm, _absgrad, last_ids, median_ids = fwd
     v_rc = torch.randn(rc.shape, generator=g).to(DEV)
     zeros = [torch.zeros_like(t) for t in (ra, rn, rd, rm)]
     head = (m2, M, colors, op, nrm, densify, None, None, off, fl, rc, ra, last_ids, median_ids, W, H, ts, False, v_rc)

@@ -778,8 +778,9 @@ def test_split_sh_matches_oracle(G, O, layout, deg, K):
     if layout == "packed":
         ci, gi = torch.where(masks)
         bi = torch.zeros_like(ci)
+        # the reference's packed contract: coefficient rows pre-gathered to [nnz, K - 1, 3] (SphericalHarmonics.cpp:90-104)
         got = G.spherical_harmonics_l0(sh0)[gi.to(DEV)] + G.spherical_harmonics_l1_plus(
-            deg, mg, vg, shN, batch_ids=bi.to(DEV), camera_ids=ci.to(DEV), gaussian_ids=gi.to(DEV))
+            deg, mg, vg, shN[gi.to(DEV)], batch_ids=bi.to(DEV), camera_ids=ci.to(DEV), gaussian_ids=gi.to(DEV))
     else:
         got = G.spherical_harmonics_l1_plus(deg, mg, vg, shN, masks=None if masks is None else masks.to(DEV))
         l0 = G.spherical_harmonics_l0(sh0)[None].expand_as(got)

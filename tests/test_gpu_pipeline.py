@@ -1,6 +1,7 @@
 """GPU parity of gsplat_amd.rasterization() (the whole hot path) against the CPU oracle pipeline, plus
 size-independent properties at BASELINE.json's full size (1M Gaussians, 1080p)."""
 import math
+import os
 
 import pytest
 import torch
@@ -9,6 +10,7 @@ from _util import assert_close_ratio, assert_grad_close, make_scene
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = ("means", "quats", "scales", "opacities", "colors")
 
 
@@ -257,22 +259,29 @@ def test_c3_matches_oracle(G):
 C3_SAMPLE_EPS = {"cpu_fp32": 1e-5, "gpu": 2e-5}
 
 
-def test_c3_compositing_gradients_per_element_band(G):
-    """The scale-relative checks above bound |a - e| by a fraction of the tensor's LARGEST element: a small row could be
-    wrong unnoticed. Here the compositing stage alone (rasterize_to_pixels forward + backward on c3's own intersection lists:
-    3.8 M intersections, 0.93 M visible rows) is checked ELEMENT BY ELEMENT against the same sums evaluated in fp64
-    throughout (oracle gso_raster3d_bwd_f64, which also returns A = the sum of |term| behind every element):
-        |gpu - fp64| <= atol + rtol |fp64| + eps A      for EVERY element of v_means2d, v_conics, v_colors, v_opacities
-    with (rtol, atol) the reference's per-element band (tests/test_basic.py:2664-2675 -> tests/_util.py RASTER_BWD_BAND) and
-    eps the sample accuracy (C3_SAMPLE_EPS). An fp32 evaluation on the CPU (gso_raster3d_bwd_f32sum: fp32 samples and fp32
-    sums per tile in raster order, one of the orders the reference's atomics may take) is put through the same inequality with
-    its own eps, so the two numbers printed per tensor - the eps each evaluation would need - are measured the same way.
-    Up to 1e-5 of the elements may miss (pixels whose 1/255 or 1e-4 decision differs between the two forward passes)."""
+_C3_BAND = {}  # the stage inputs and the fp64 / fp32 CPU evaluations, built once per process (every variant is checked against them)
+
+_C3_BAND_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import gsplat_amd as G
+d = np.load(sys.argv[1])
+t = {k: torch.from_numpy(d[k]).cuda() for k in d.files}
+W, H = int(d["W"]), int(d["H"])
+leaves = [t[k].clone().requires_grad_(True) for k in ("m2", "con", "col", "op")]
+rc, ra = G.rasterize_to_pixels(leaves[0], leaves[1], leaves[2], leaves[3], W, H, 16, t["off"], t["fl"], backgrounds=t["bg"], packed=True)
+((rc * t["v_rc"]).sum() + (ra * t["v_ra"]).sum()).backward()
+np.savez(sys.argv[2], rc=rc.detach().cpu().numpy(), **{k: l.grad.cpu().numpy() for k, l in zip(("v_means2d", "v_conics", "v_colors", "v_opacities"), leaves)})
+"""
+
+
+def _c3_band_setup(G):
     import os
 
-    from _util import RASTER_BWD_BAND
     from oracle import oracle as O
 
+    if _C3_BAND:
+        return _C3_BAND
     O.set_threads(min(os.cpu_count() or 1, 32))
     sc, W, H = _bench_scene(1_000_000, DEV)
     with torch.no_grad():
@@ -285,23 +294,73 @@ def test_c3_compositing_gradients_per_element_band(G):
     col = torch.rand(m2.shape[0], 3, generator=g).to(DEV)
     bg = torch.rand(1, 3, generator=g).to(DEV)
     v_rc, v_ra = torch.randn(1, H, W, 3, generator=g), torch.randn(1, H, W, 1, generator=g)
-    leaves = [t.clone().requires_grad_(True) for t in (m2, con, col, op)]
-    rc, ra = G.rasterize_to_pixels(leaves[0], leaves[1], leaves[2], leaves[3], W, H, 16, off, fl, backgrounds=bg, packed=True)
-    ((rc * v_rc.to(DEV)).sum() + (ra * v_ra.to(DEV)).sum()).backward()
     cpu = lambda t: t.detach().cpu()
     args = (cpu(m2), cpu(con), cpu(col), cpu(op), W, H, 16, cpu(off), cpu(fl))
     rc_o, ra_o, li_o = O.rasterize_to_pixels(*args, backgrounds=cpu(bg))
-    assert_close_ratio(cpu(rc), rc_o, 1e-4, 2e-5, max_bad_ratio=1e-4, name="c3 stage colors")
     g64 = O.rasterize_to_pixels_bwd(*args, ra_o, li_o, v_rc, v_ra, backgrounds=cpu(bg), sample_f64=True, abs_sums=True)
     gs32 = O.rasterize_to_pixels_bwd(*args, ra_o, li_o, v_rc, v_ra, backgrounds=cpu(bg), sum_f32=True)
+    _C3_BAND.update(W=W, H=H, rc_o=rc_o, g64=g64, gs32=gs32,
+                    tensors=dict(m2=m2, con=con, col=col, op=op, off=off, fl=fl, bg=bg, v_rc=v_rc.to(DEV), v_ra=v_ra.to(DEV)))
+    return _C3_BAND
+
+
+@pytest.mark.parametrize("variant", ["default", "r", "t", "w"])
+def test_c3_compositing_gradients_per_element_band(G, variant):
+    """The scale-relative checks above bound |a - e| by a fraction of the tensor's LARGEST element: a small row could be
+    wrong unnoticed. Here the compositing stage alone (rasterize_to_pixels forward + backward on c3's own intersection lists:
+    3.8 M intersections, 0.93 M visible rows) is checked ELEMENT BY ELEMENT against the same sums evaluated in fp64
+    throughout (oracle gso_raster3d_bwd_f64, which also returns A = the sum of |term| behind every element):
+        |gpu - fp64| <= atol + rtol |fp64| + eps A      for EVERY element of v_means2d, v_conics, v_colors, v_opacities
+    with (rtol, atol) the reference's per-element band (tests/test_basic.py:2664-2675 -> tests/_util.py RASTER_BWD_BAND) and
+    eps the sample accuracy (C3_SAMPLE_EPS). An fp32 evaluation on the CPU (gso_raster3d_bwd_f32sum: fp32 samples and fp32
+    sums per tile in raster order, one of the orders the reference's atomics may take) is put through the same inequality with
+    its own eps, so the two numbers printed per tensor - the eps each evaluation would need - are measured the same way.
+    Up to 1e-5 of the elements may miss (pixels whose 1/255 or 1e-4 decision differs between the two forward passes).
+
+    EVERY selectable backward kernel goes through the same inequality, not only the default (`variant`: GSX_RASTER3D_BWD = r
+    wave reductions, t four waves per tile, w one wave per tile; the switch is read once per process, so the other kernels run
+    in a subprocess on the same stage inputs): a variant may not buy speed with accuracy the default does not have."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    import numpy as np
+
+    from _util import RASTER_BWD_BAND
+
+    assert os.environ.get("GSX_RASTER3D_BWD", "") == "", "run this test with the default kernel selection"
+    S = _c3_band_setup(G)
+    W, H, g64, gs32, T = S["W"], S["H"], S["g64"], S["gs32"], S["tensors"]
+    keys = ("v_means2d", "v_conics", "v_colors", "v_opacities")
+    cpu = lambda t: t.detach().cpu()
+    if variant == "default":
+        leaves = [T[k].clone().requires_grad_(True) for k in ("m2", "con", "col", "op")]
+        rc, ra = G.rasterize_to_pixels(leaves[0], leaves[1], leaves[2], leaves[3], W, H, 16, T["off"], T["fl"],
+                                       backgrounds=T["bg"], packed=True)
+        ((rc * T["v_rc"]).sum() + (ra * T["v_ra"]).sum()).backward()
+        grads, rc = {k: cpu(l.grad) for k, l in zip(keys, leaves)}, cpu(rc)
+    else:
+        with tempfile.TemporaryDirectory() as d:
+            src, dst = os.path.join(d, "in.npz"), os.path.join(d, "out.npz")
+            np.savez(src, W=W, H=H, **{k: cpu(v).numpy() for k, v in T.items()})
+            code = _C3_BAND_SCRIPT % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+            out = subprocess.run([sys.executable, "-c", code, src, dst], env=dict(os.environ, GSX_RASTER3D_BWD=variant),
+                                 capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, out.stderr[-3000:]
+            res = np.load(dst)
+            grads, rc = {k: torch.from_numpy(res[k]) for k in keys}, torch.from_numpy(res["rc"])
+    assert_close_ratio(rc, S["rc_o"], 1e-4, 2e-5, max_bad_ratio=1e-4, name="c3 stage colors")
     report, failures = {}, []
-    for leaf, key in zip(leaves, ("v_means2d", "v_conics", "v_colors", "v_opacities")):
+    shapes = {"v_means2d": T["m2"].shape, "v_conics": T["con"].shape, "v_colors": T["col"].shape, "v_opacities": T["op"].shape}
+    for key in keys:
         rtol, atol = RASTER_BWD_BAND[key]
-        truth = torch.from_numpy(g64[key]).reshape(leaf.shape)
-        A = torch.from_numpy(g64["abs_terms"][key]).reshape(leaf.shape)
+        shape = shapes[key]
+        truth = torch.from_numpy(g64[key]).reshape(shape)
+        A = torch.from_numpy(g64["abs_terms"][key]).reshape(shape)
         band = atol + rtol * truth.abs()
         rec = {"scale": truth.abs().max().item()}
-        for who, val in (("cpu_fp32", torch.from_numpy(gs32[key]).reshape(leaf.shape)), ("gpu", cpu(leaf.grad).double())):
+        for who, val in (("cpu_fp32", torch.from_numpy(gs32[key]).reshape(shape)), ("gpu", grads[key].reshape(shape).double())):
             err = (val - truth).abs()
             need = ((err - band).clamp_min(0.0) / (A + 1e-30)).flatten()  # the eps this element needs on top of the band
             outside = (err > band + C3_SAMPLE_EPS[who] * A).double().mean().item()
@@ -317,8 +376,8 @@ def test_c3_compositing_gradients_per_element_band(G):
                 failures.append(f"c3 {key} ({who}): an element is off by more than 1 % of the sum of its |terms| "
                                 f"(needs {need.max().item():.3e})")
         report[key] = rec
-    print("c3 per-element band:", report)
-    assert not failures, "; ".join(failures) + f" | {report}"
+    print(f"c3 per-element band [{variant}]:", report)
+    assert not failures, f"[{variant}] " + "; ".join(failures) + f" | {report}"
 
 
 def test_c4_matches_oracle(G):

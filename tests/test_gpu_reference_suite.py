@@ -1,0 +1,82 @@
+"""GPU: the REFERENCE'S OWN pytest files, unedited, over the `gsplat.csrc` shim - its CUDA-vs-`_torch_impl` comparisons, with its
+tolerances and error-message assertions, executed against the HIP kernels (tools/run_reference_suite.py; the per-test table of a
+full run is committed as profiles/r10_reference_suite.txt).
+
+This test runs the files that exercise SURVEY section-8 rows A2-A9, R1-R3, G1-G3, (f)1-(f)3 and asserts:
+  * nothing crashes or errors, and no test fails except the ids in EXPECTED_FAILURES - each one named with its reason (a
+    limit of the reference's CUDA launch geometry that this backend does not have; a third-party package that is not installed);
+  * the in-scope files keep at least the pass counts of the round-6 table (a test that silently turns into a skip shows up).
+
+The reference tree comes from $GSPLAT_REFERENCE_PATH, /root/reference, or the two git-ignored archives that
+`__graft_entry__.build()` stages under oracle/_ref/ (the GPU box has no checkout). 3DGUT tests skip: build_config()["3dgut"]
+is False while that feature is partial (gsplat_amd/csrc_shim.py); `--with-3dgut-subset` of the runner opens them."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+FILES = ["test_basic.py", "test_2dgs.py", "test_rasterization.py", "test_sparse_intersect.py", "test_sparse_rasterize.py",
+         "test_sparse_tile_layout.py", "test_sparse_num_contributing.py", "test_sparse_contributing_ids.py",
+         "test_sparse_top_contributing.py", "test_mcmc_perturb.py", "test_relocation.py", "test_strategy.py"]
+
+# test id -> why it is expected to fail here (anything else that fails is a regression)
+EXPECTED_FAILURES = {
+    "tests/test_basic.py::test_fully_fused_projection_packed_grid_y_limit":
+        "asserts the reference's own launch limit (B*C <= 65535 rows on CUDA's grid.y, ProjectionEWA3DGSPacked.cu:327-334): this "
+        "backend's packed projection has no such limit and renders the 65536-camera case",
+}
+# tests that do not carry the reference's `skipif(not has_3dgut())` gate although they need a 3DGUT-only op (lidar tiling)
+EXPECTED_FAILURE_PREFIXES = {
+    "tests/test_basic.py::test_isect_lidar_corner_cases[":
+        "gsplat::intersect_tile_lidar (lidar tiling, 3DGUT) is not built; the reference gates its other lidar tests on has_3dgut() "
+        "but not this one",
+}
+MIN_PASSED = {"test_basic.py": 240, "test_2dgs.py": 18, "test_rasterization.py": 70, "test_sparse_intersect.py": 22,
+              "test_sparse_rasterize.py": 22, "test_sparse_tile_layout.py": 18, "test_sparse_num_contributing.py": 11,
+              "test_sparse_contributing_ids.py": 8, "test_sparse_top_contributing.py": 8, "test_mcmc_perturb.py": 15,
+              "test_relocation.py": 3, "test_strategy.py": 3}
+
+
+def _have_reference():
+    for cand in (os.environ.get("GSPLAT_REFERENCE_PATH"), "/root/reference"):
+        if cand and os.path.isdir(os.path.join(cand, "gsplat")) and os.path.isdir(os.path.join(cand, "tests")):
+            return True
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    return all(os.path.exists(os.path.join(ref, z)) for z in ("reference_py.zip", "reference_tests.zip"))
+
+
+def test_reference_own_gpu_tests_pass_over_the_shim(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    if not _have_reference():
+        pytest.skip("no reference tree: run __graft_entry__.build() where /root/reference exists (stages oracle/_ref/*.zip)")
+    out = str(tmp_path / "reference_suite")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    env.pop("GSPLAT_AMD_3DGUT_SUBSET", None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_suite.py"), "--files", ",".join(FILES),
+                          "--timeout", "300", "--out", out], capture_output=True, text=True, cwd=ROOT, env=env, timeout=2400)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    summary = json.load(open(out + ".json"))
+    bad, expected = [], []
+    for line in open(out + ".txt"):
+        if line.startswith("#") or not line.strip():
+            continue
+        outcome, _secs, rest = line.split(None, 2)
+        nodeid = rest.split("   # ")[0].strip()
+        if outcome in ("passed", "skipped", "xfailed", "xpassed"):
+            continue
+        if nodeid in EXPECTED_FAILURES or any(nodeid.startswith(p) for p in EXPECTED_FAILURE_PREFIXES):
+            expected.append(nodeid)
+        else:
+            bad.append(line.strip()[:400])
+    assert not bad, "%d unexpected failures of the reference's own tests:\n%s" % (len(bad), "\n".join(bad[:40]))
+    for fname, need in MIN_PASSED.items():
+        got = summary["files"].get(fname, {}).get("passed", 0)
+        assert got >= need, f"{fname}: {got} passed, the round-6 table has at least {need} ({summary['files'].get(fname)})"
+    print("reference suite over the shim:", json.dumps(summary["total"]), "| expected failures:", len(expected))
