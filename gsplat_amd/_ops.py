@@ -1965,17 +1965,19 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
                              ut_params, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, ftheta_coeffs,
                              lidar_coeffs, external_distortion_params):
     """gsplat::projection_ut_3dgs_fused (kernel ``ProjectionUT3DGSFused.cu``): perfect / OpenCV pinhole, orthographic, OpenCV
-    fisheye and f-theta cameras, global shutter. What is not built yet is refused, never approximated."""
-    if viewmats1 is not None or rs_type != _ROLLING_SHUTTER_GLOBAL:
-        raise NotImplementedError("gsplat_amd: rolling-shutter UT projection is not built yet")
+    fisheye and f-theta cameras, global or rolling shutter, z or Euclidean sort depth. Lidar and external distortion are
+    refused, never approximated."""
+    rolling = rs_type != _ROLLING_SHUTTER_GLOBAL
+    if rolling and viewmats1 is None:
+        raise ValueError("a rolling shutter needs viewmats_rs (the pose at the end of the frame)")
+    if rs_type not in (0, 1, 2, 3, 4):
+        raise ValueError(f"unknown rolling shutter type {rs_type}")
     if camera_model not in (0, 1, 2, 3):
         raise NotImplementedError(f"gsplat_amd: UT projection is built for pinhole, ortho, fisheye and f-theta cameras, not "
                                   f"'{_CAMERA_MODEL_NAMES.get(camera_model, camera_model)}'")
     if lidar_coeffs is not None or external_distortion_params is not None:
         raise NotImplementedError("gsplat_amd: lidar / external-distortion UT projection is not built yet")
-    if not global_z_order:
-        raise NotImplementedError("gsplat_amd: UT projection with global_z_order=False is not built yet")
-    _check_f32(means=means, quats=quats, scales=scales, opacities=opacities, viewmats=viewmats0, Ks=Ks,
+    _check_f32(means=means, quats=quats, scales=scales, opacities=opacities, viewmats=viewmats0, viewmats_rs=viewmats1, Ks=Ks,
                radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs, thin_prism_coeffs=thin_prism_coeffs)
     batch = tuple(means.shape[:-2])
     N, C, B = means.shape[-2], viewmats0.shape[-3], math.prod(means.shape[:-2])
@@ -2028,6 +2030,19 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
     depths = torch.empty(batch + (C, N), device=dev, dtype=dt)
     conics = torch.empty(batch + (C, N, 3), device=dev, dtype=dt)
     comps = torch.empty(batch + (C, N), device=dev, dtype=dt) if calc_compensations else None
+    if rolling or not global_z_order:
+        import ctypes
+
+        if rolling and viewmats1.shape != viewmats0.shape:
+            raise ValueError("viewmats_rs must match viewmats shape")
+        call("gsx_project_ut_rs_fwd", ptr(means.contiguous()), ptr(quats.contiguous()), ptr(scales.contiguous()),
+             ptr(_c(opacities)), ptr(viewmats0.contiguous()), ptr(_c(viewmats1)) if rolling else None, ptr(Ks.contiguous()),
+             ptr(_c(radial_coeffs)), ptr(_c(tangential_coeffs)), ptr(_c(thin_prism_coeffs)), ptr(max_angle),
+             ctypes.addressof(ftheta_rec) if ftheta_rec is not None else None, B, C, N, int(image_width), int(image_height),
+             float(eps2d), float(near_plane), float(far_plane), float(radius_clip), int(camera_model), int(rs_type),
+             int(bool(global_z_order)), alpha, beta, kappa, margin, int(all_valid), ptr(radii), ptr(means2d), ptr(depths),
+             ptr(conics), ptr(comps))
+        return radii, means2d, depths, conics, comps
     if ftheta_rec is not None:
         import ctypes
 
@@ -2062,6 +2077,85 @@ def pinhole_pixel_rays(viewmats: Tensor, Ks: Tensor, width: int, height: int) ->
     d_world = torch.einsum("...ji,...hwj->...hwi", R, d)
     o_world = -torch.einsum("...ji,...j->...i", R, t)
     return torch.cat([o_world[..., None, None, :].expand_as(d_world), d_world], dim=-1).contiguous()
+
+
+def _rotmat_to_quat_wxyz(R: Tensor) -> Tensor:
+    """glm::quat_cast of row-major rotation matrices [..., 3, 3] -> (w, x, y, z) (Cameras.cuh:85-101)."""
+    m = lambda i, j: R[..., i, j]  # noqa: E731
+    four = torch.stack([m(0, 0) + m(1, 1) + m(2, 2), m(0, 0) - m(1, 1) - m(2, 2), m(1, 1) - m(0, 0) - m(2, 2),
+                        m(2, 2) - m(0, 0) - m(1, 1)], dim=-1)
+    big = four.argmax(dim=-1)
+    val = torch.sqrt(four.gather(-1, big[..., None])[..., 0] + 1.0) * 0.5
+    mult = 0.25 / val
+    a, b, c = (m(2, 1) - m(1, 2)) * mult, (m(0, 2) - m(2, 0)) * mult, (m(1, 0) - m(0, 1)) * mult
+    d, e, f = (m(1, 0) + m(0, 1)) * mult, (m(0, 2) + m(2, 0)) * mult, (m(2, 1) + m(1, 2)) * mult
+    cands = torch.stack([torch.stack([val, a, b, c], -1), torch.stack([a, val, d, e], -1), torch.stack([b, d, val, f], -1),
+                         torch.stack([c, e, f, val], -1)], dim=-2)  # [..., case, 4]
+    return cands.gather(-2, big[..., None, None].expand(big.shape + (1, 4)))[..., 0, :]
+
+
+def _quat_rotate_wxyz(q: Tensor, v: Tensor) -> Tensor:
+    """glm::rotate(q, v) = v + 2 (w (u x v) + u x (u x v))."""
+    u = q[..., 1:]
+    uv = torch.cross(u, v, dim=-1)
+    return v + 2.0 * (q[..., :1] * uv + torch.cross(u, uv, dim=-1))
+
+
+def _slerp_wxyz(q0: Tensor, q1: Tensor, t: Tensor) -> Tensor:
+    """glm::slerp on the short arc (component-wise mix when nearly parallel), normalised (Cameras.cuh:362-429)."""
+    cos = (q0 * q1).sum(-1, keepdim=True)
+    q1 = torch.where(cos < 0, -q1, q1)
+    cos = cos.abs()
+    t = t[..., None]
+    angle = torch.acos(cos.clamp(max=1.0))
+    sin = torch.sin(angle)
+    safe = torch.where(sin > 0, sin, torch.ones_like(sin))
+    wa = torch.where(cos > 1.0 - 1.1920929e-07, 1.0 - t, torch.sin((1.0 - t) * angle) / safe)
+    wb = torch.where(cos > 1.0 - 1.1920929e-07, t, torch.sin(t * angle) / safe)
+    q = wa * q0 + wb * q1
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+def pinhole_pixel_rays_rolling(viewmats: Tensor, viewmats_rs: Tensor, Ks: Tensor, width: int, height: int, rs_type: int) -> Tensor:
+    """pinhole_pixel_rays under a ROLLING shutter: the pose of a pixel is the one interpolated (translation lerp, rotation slerp)
+    at the relative frame time at which its row / column is read - floor(y) / (H - 1) top-to-bottom, floor(x) / (W - 1)
+    left-to-right, (H - ceil(y)) / (H - 1) bottom-to-top, (W - ceil(x)) / (W - 1) right-to-left at the pixel centre
+    (Cameras.cuh:503-546; gsplat/cuda/_torch_cameras.py:424-553). [..., C, H, W, 6]."""
+    dt, dev = viewmats.dtype, viewmats.device
+    xs = torch.arange(width, device=dev, dtype=dt) + 0.5
+    ys = torch.arange(height, device=dev, dtype=dt) + 0.5
+    if rs_type == 0:
+        tm, along_rows = (torch.floor(ys) / (height - 1) if height > 1 else torch.full_like(ys, 0.5)), True
+    elif rs_type == 2:
+        tm, along_rows = ((height - torch.ceil(ys)) / (height - 1) if height > 1 else torch.full_like(ys, 0.5)), True
+    elif rs_type == 1:
+        tm, along_rows = (torch.floor(xs) / (width - 1) if width > 1 else torch.full_like(xs, 0.5)), False
+    elif rs_type == 3:
+        tm, along_rows = ((width - torch.ceil(xs)) / (width - 1) if width > 1 else torch.full_like(xs, 0.5)), False
+    else:
+        raise ValueError(f"rolling shutter type {rs_type}")
+    L = tm.shape[0]
+    lead = viewmats.shape[:-2]
+    q0 = _rotmat_to_quat_wxyz(viewmats[..., :3, :3])[..., None, :].expand(lead + (L, 4))
+    q1 = _rotmat_to_quat_wxyz(viewmats_rs[..., :3, :3])[..., None, :].expand(lead + (L, 4))
+    t0, t1 = viewmats[..., None, :3, 3], viewmats_rs[..., None, :3, 3]
+    tl = tm.expand(lead + (L,))
+    q = _slerp_wxyz(q0, q1, tl)                                   # [..., C, L, 4] pose of every line
+    t = (1.0 - tl[..., None]) * t0 + tl[..., None] * t1           # [..., C, L, 3]
+    q_inv = torch.cat([q[..., :1], -q[..., 1:]], dim=-1)
+    origin = _quat_rotate_wxyz(q_inv, -t)                          # camera position at the line's time
+    fx, fy, cx, cy = (Ks[..., 0, 0, None, None], Ks[..., 1, 1, None, None], Ks[..., 0, 2, None, None],
+                      Ks[..., 1, 2, None, None])
+    dx = ((xs[None, :] - cx) / fx).expand(Ks.shape[:-2] + (height, width))
+    dy = ((ys[:, None] - cy) / fy).expand(Ks.shape[:-2] + (height, width))
+    d = torch.stack([dx, dy, torch.ones_like(dx)], dim=-1)
+    d = d / d.norm(dim=-1, keepdim=True)
+    if along_rows:
+        qi, oi = q_inv[..., :, None, :], origin[..., :, None, :]   # [..., C, H, 1, .]
+    else:
+        qi, oi = q_inv[..., None, :, :], origin[..., None, :, :]   # [..., C, 1, W, .]
+    d_world = _quat_rotate_wxyz(qi.expand(d.shape[:-1] + (4,)), d)
+    return torch.cat([oi.expand_as(d_world), d_world], dim=-1).contiguous()
 
 
 class _FromWorldCompositing(torch.autograd.Function):
@@ -2138,15 +2232,20 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
     cameras with a global shutter. Everything else is refused, never approximated."""
     if return_sample_counts or use_hit_distance or return_normals or renderer_config != 0:
         raise NotImplementedError("gsplat_amd: sample counts / hit distance / normals / ParallelBatch are not built yet")
-    if viewmats1 is not None or rs_type != _ROLLING_SHUTTER_GLOBAL or lidar_coeffs is not None \
-            or external_distortion_params is not None:
-        raise NotImplementedError("gsplat_amd: rolling shutter / lidar / external distortion eval3d is not built yet")
+    if lidar_coeffs is not None or external_distortion_params is not None:
+        raise NotImplementedError("gsplat_amd: lidar / external distortion eval3d is not built yet")
+    rolling = rs_type != _ROLLING_SHUTTER_GLOBAL
+    if rolling and viewmats1 is None:
+        raise ValueError("a rolling shutter needs viewmats_rs (the pose at the end of the frame)")
     if rays is None:
         if camera_model != 0 or radial_coeffs is not None or tangential_coeffs is not None or thin_prism_coeffs is not None:
             raise NotImplementedError("gsplat_amd: eval3d generates rays for perfect pinhole cameras only; pass `rays` "
                                       "for other camera models")
         with torch.no_grad():
-            rays = pinhole_pixel_rays(viewmats0, Ks, int(image_width), int(image_height))
+            if rolling:  # the pose of a pixel is the one at the time its row / column is read
+                rays = pinhole_pixel_rays_rolling(viewmats0, viewmats1, Ks, int(image_width), int(image_height), int(rs_type))
+            else:
+                rays = pinhole_pixel_rays(viewmats0, Ks, int(image_width), int(image_height))
     _check_f32(means=means, quats=quats, scales=scales, colors=colors, opacities=opacities, rays=rays)
     batch = tuple(means.shape[:-2])
     N, C, D = means.shape[-2], viewmats0.shape[-3], colors.shape[-1]
@@ -2191,9 +2290,6 @@ def rasterization_3dgs(means, covars, quats, scales, opacities, colors, viewmats
     if renderer_config != 0:
         raise ValueError("RendererConfig PARALLEL_BATCH requires with_eval3d=True; the classic path only supports "
                          "MIXED_BATCH")
-    if rolling_shutter != _ROLLING_SHUTTER_GLOBAL:
-        raise RuntimeError("gsplat_amd implements the classic 3DGS rasterization path; rolling shutter belongs to the "
-                           "3DGUT path and is not supported")
     if camera_model not in _CAMERA_MODEL_NAMES:
         raise ValueError(f"unknown camera_model id {camera_model}")
     depth = ""
@@ -2213,7 +2309,8 @@ def rasterization_3dgs(means, covars, quats, scales, opacities, colors, viewmats
         segmented=segmented, covars=covars, with_ut=with_ut, with_eval3d=with_eval3d, return_normals=return_normals,
         global_z_order=global_z_order, rays=rays, radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs,
         thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=None, lidar_coeffs=lidar_coeffs, ut_params=ut_params,
-        external_distortion_coeffs=external_distortion_params, viewmats_rs=viewmats_rs, extra_signals=extra_signals,
+        external_distortion_coeffs=external_distortion_params, viewmats_rs=viewmats_rs, rolling_shutter=rolling_shutter,
+        extra_signals=extra_signals,
         extra_signals_sh_degree=None if extra_signals_sh_degree < 0 else extra_signals_sh_degree, _covars_triu=True)
     extra = meta.get("render_extra_signals")
     absgrad_holder = getattr(meta["means2d"], "absgrad", None) if absgrad else None

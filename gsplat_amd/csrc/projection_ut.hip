@@ -31,6 +31,11 @@ struct ProjUtArgs {
     uint32_t B, C, N, width, height;
     float eps2d, near_plane, far_plane, radius_clip;
     int camera_model, require_all_valid, distorted;
+    // rolling shutter (ProjectionUT3DGSFused.cu:121-127, Cameras.cuh:549-660): pose at the END of the frame, or null = global
+    const float *viewmats1; // [B,C,4,4]
+    int rs_type;            // 0 top-to-bottom, 1 left-to-right, 2 bottom-to-top, 3 right-to-left, 4 global (Cameras.h:38-45)
+    int depth_is_distance;  // global_z_order = false: the sort depth is |mean_c| instead of mean_c.z (ProjectionUT3DGSFused.cu:240)
+    int radial_cull;        // ... and f-theta cameras then cull near / far on |mean_c| (:411)
     float w_m0, w_c0, w_i, spread, margin;
     // f-theta (camera_model 3; Cameras.h FThetaCameraDistortionParameters): one record per call
     int ft_reference_poly;        // 1: angle -> pixel distance is the calibrated polynomial; 0: its inverse is (Newton on it)
@@ -127,6 +132,108 @@ __device__ __forceinline__ bool ut_project_point(const ProjUtArgs &a, const Cam 
     return ok && inb;
 }
 
+// ---- rolling shutter: the camera pose is interpolated between the start and the end of the frame at the time the sensor reads
+// the pixel a point lands on (restated from Cameras.cuh:76-135, 362-429, 503-660 and gsplat/cuda/_math.py:381-458, 513-560,
+// 587-645) ----------------------------------------------------------------------------------------------------------------------
+struct UtPose {
+    float q[4]; // w, x, y, z
+    float t[3];
+};
+// glm::quat_cast of a row-major rotation matrix
+__device__ __forceinline__ void ut_rotmat_to_quat(const float *R, float *q)
+{
+    const float fx = R[0] - R[4] - R[8], fy = R[4] - R[0] - R[8], fz = R[8] - R[0] - R[4], fw = R[0] + R[4] + R[8];
+    int big = 0;
+    float best = fw;
+    if (fx > best) { best = fx; big = 1; }
+    if (fy > best) { best = fy; big = 2; }
+    if (fz > best) { best = fz; big = 3; }
+    const float val = sqrtf(best + 1.0f) * 0.5f, mult = 0.25f / val;
+    if (big == 0) { q[0] = val; q[1] = (R[7] - R[5]) * mult; q[2] = (R[2] - R[6]) * mult; q[3] = (R[3] - R[1]) * mult; }
+    else if (big == 1) { q[0] = (R[7] - R[5]) * mult; q[1] = val; q[2] = (R[3] + R[1]) * mult; q[3] = (R[2] + R[6]) * mult; }
+    else if (big == 2) { q[0] = (R[2] - R[6]) * mult; q[1] = (R[3] + R[1]) * mult; q[2] = val; q[3] = (R[7] + R[5]) * mult; }
+    else { q[0] = (R[3] - R[1]) * mult; q[1] = (R[2] + R[6]) * mult; q[2] = (R[7] + R[5]) * mult; q[3] = val; }
+}
+// glm::rotate(q, v) = v + 2 (w (u x v) + u x (u x v)), u = q.xyz
+__device__ __forceinline__ void ut_quat_rotate(const float *q, const float *v, float *o)
+{
+    const float ux = q[2] * v[2] - q[3] * v[1], uy = q[3] * v[0] - q[1] * v[2], uz = q[1] * v[1] - q[2] * v[0];
+    const float wx = q[2] * uz - q[3] * uy, wy = q[3] * ux - q[1] * uz, wz = q[1] * uy - q[2] * ux;
+    o[0] = v[0] + 2.0f * (q[0] * ux + wx);
+    o[1] = v[1] + 2.0f * (q[0] * uy + wy);
+    o[2] = v[2] + 2.0f * (q[0] * uz + wz);
+}
+// pose at relative frame time tm: translation lerp, rotation glm::slerp (short arc, component-wise mix when nearly parallel) +
+// normalisation
+__device__ __forceinline__ UtPose ut_interpolate_pose(const UtPose &p0, const UtPose &p1, float tm)
+{
+    UtPose r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r.t[i] = (1.0f - tm) * p0.t[i] + tm * p1.t[i];
+    float cos_theta = p0.q[0] * p1.q[0] + p0.q[1] * p1.q[1] + p0.q[2] * p1.q[2] + p0.q[3] * p1.q[3];
+    const float sgn = cos_theta < 0.0f ? -1.0f : 1.0f;
+    cos_theta *= sgn;
+    float wa, wb;
+    if (cos_theta > 1.0f - 1.1920929e-07f) {
+        wa = 1.0f - tm; wb = tm;
+    } else {
+        const float angle = acosf(fminf(cos_theta, 1.0f)), inv = 1.0f / sinf(angle);
+        wa = sinf((1.0f - tm) * angle) * inv; wb = sinf(tm * angle) * inv;
+    }
+    float n2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.q[i] = wa * p0.q[i] + wb * sgn * p1.q[i]; n2 += r.q[i] * r.q[i]; }
+    const float inv_n = n2 > 0.0f ? 1.0f / sqrtf(n2) : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.q[i] *= inv_n;
+    return r;
+}
+__device__ __forceinline__ float ut_relative_frame_time(const ProjUtArgs &a, float px, float py)
+{
+    const float W = (float)a.width, H = (float)a.height;
+    switch (a.rs_type) {
+    case 0: return a.height > 1 ? floorf(py) / (H - 1.0f) : 0.5f;
+    case 1: return a.width > 1 ? floorf(px) / (W - 1.0f) : 0.5f;
+    case 2: return a.height > 1 ? (H - ceilf(py)) / (H - 1.0f) : 0.5f;
+    case 3: return a.width > 1 ? (W - ceilf(px)) / (W - 1.0f) : 0.5f;
+    default: return 0.0f;
+    }
+}
+// world point -> pixel under a rolling shutter: project with the start pose (else the end pose), then up to ten rounds of
+// "frame time of the pixel -> pose at that time -> project again" (fixed point of the read-out time)
+__device__ __forceinline__ bool ut_project_point_rs(const ProjUtArgs &a, const Cam &c, const UtDistortion &d, const UtPose &p0,
+                                                    const UtPose &p1, const float *wp, float &px, float &py)
+{
+    float cp[3], sx, sy, ex, ey;
+    ut_quat_rotate(p0.q, wp, cp);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cp[i] += p0.t[i];
+    const bool ok_s = ut_project_point(a, c, d, cp, sx, sy);
+    ut_quat_rotate(p1.q, wp, cp);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cp[i] += p1.t[i];
+    const bool ok_e = ut_project_point(a, c, d, cp, ex, ey);
+    if (!ok_s && !ok_e) { // no valid projection at either end of the frame: the end-of-frame result, invalid
+        px = ex; py = ey;
+        return false;
+    }
+    px = ok_s ? sx : ex;
+    py = ok_s ? sy : ey;
+    bool valid = true;
+    float prev_time = -3.402823466e+38f;
+    for (int it = 0; it < 10; ++it) {
+        const float tm = ut_relative_frame_time(a, px, py);
+        if (tm == prev_time) break; // same time = same pose = same pixel from here on
+        prev_time = tm;
+        const UtPose pr = ut_interpolate_pose(p0, p1, tm);
+        ut_quat_rotate(pr.q, wp, cp);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cp[i] += pr.t[i];
+        valid = ut_project_point(a, c, d, cp, px, py);
+    }
+    return valid;
+}
+
 __global__ void __launch_bounds__(256) project_ut_kernel(const ProjUtArgs a)
 {
     const int64_t rows = (int64_t)a.B * a.C * a.N;
@@ -171,10 +278,33 @@ __global__ void __launch_bounds__(256) project_ut_kernel(const ProjUtArgs a)
     float pc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) pc[i] = c.R[3 * i] * m[0] + c.R[3 * i + 1] * m[1] + c.R[3 * i + 2] * m[2] + c.t[i];
-    const float z = pc[2];
 
     float px[7], py[7];
     bool okp[7];
+    const bool rolling = a.viewmats1 != nullptr && a.rs_type != 4;
+    if (rolling) {
+        // the Gaussian's own camera-frame position (culling, depth) uses the pose at the MIDDLE of the frame; every sigma
+        // point is projected with the pose of the moment its pixel is read
+        UtPose p0, p1;
+        ut_rotmat_to_quat(c.R, p0.q);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p0.t[i] = c.t[i];
+        const float *v1 = a.viewmats1 + (size_t)bc * 16;
+        const float R1[9] = {v1[0], v1[1], v1[2], v1[4], v1[5], v1[6], v1[8], v1[9], v1[10]};
+        ut_rotmat_to_quat(R1, p1.q);
+        p1.t[0] = v1[3]; p1.t[1] = v1[7]; p1.t[2] = v1[11];
+        const UtPose mid = ut_interpolate_pose(p0, p1, 0.5f);
+        ut_quat_rotate(mid.q, m, pc);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pc[i] += mid.t[i];
+        okp[0] = ut_project_point_rs(a, c, d, p0, p1, m, px[0], py[0]);
+        for (int k = 0; k < 3; ++k) {
+            const float ox = a.spread * s[k] * Rq[k], oy = a.spread * s[k] * Rq[3 + k], oz = a.spread * s[k] * Rq[6 + k];
+            const float wpp[3] = {m[0] + ox, m[1] + oy, m[2] + oz}, wpm[3] = {m[0] - ox, m[1] - oy, m[2] - oz};
+            okp[1 + k] = ut_project_point_rs(a, c, d, p0, p1, wpp, px[1 + k], py[1 + k]);
+            okp[4 + k] = ut_project_point_rs(a, c, d, p0, p1, wpm, px[4 + k], py[4 + k]);
+        }
+    } else {
     okp[0] = ut_project_point(a, c, d, pc, px[0], py[0]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -191,6 +321,9 @@ __global__ void __launch_bounds__(256) project_ut_kernel(const ProjUtArgs a)
         for (int i = 0; i < 3; ++i) cp[i] = c.R[3 * i] * wp[0] + c.R[3 * i + 1] * wp[1] + c.R[3 * i + 2] * wp[2] + c.t[i];
         okp[4 + k] = ut_project_point(a, c, d, cp, px[4 + k], py[4 + k]);
     }
+    }
+    const float z = pc[2], dist = sqrtf(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
+    const float cull_depth = a.radial_cull ? dist : z;
 
     // UT weights; with require_all_valid the sums stop at the first invalid point (weights of the rest are zero)
     float wm[7], wc[7];
@@ -221,7 +354,7 @@ __global__ void __launch_bounds__(256) project_ut_kernel(const ProjUtArgs a)
         cxy += wc[i] * dx * dy;
         cyy += wc[i] * dy * dy;
     }
-    valid = valid && (z >= a.near_plane) && (z <= a.far_plane);
+    valid = valid && (cull_depth >= a.near_plane) && (cull_depth <= a.far_plane);
 
     const float det0 = cxx * cyy - cxy * cxy;
     cxx += a.eps2d;
@@ -253,7 +386,7 @@ __global__ void __launch_bounds__(256) project_ut_kernel(const ProjUtArgs a)
     a.radii[2 * row + 1]   = (int32_t)ry;
     a.means2d[2 * row]     = mx;
     a.means2d[2 * row + 1] = my;
-    a.depths[row]          = z;
+    a.depths[row]          = a.depth_is_distance ? dist : z;
     a.conics[3 * row]      = iyy / idet;
     a.conics[3 * row + 1]  = -cxy / idet;
     a.conics[3 * row + 2]  = ixx / idet;
@@ -268,9 +401,12 @@ static int project_ut_launch(const float *means, const float *quats, const float
                              uint32_t N, uint32_t width, uint32_t height, float eps2d, float near_plane, float far_plane,
                              float radius_clip, int camera_model, float ut_alpha, float ut_beta, float ut_kappa,
                              float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii, float *means2d,
-                             float *depths, float *conics, float *compensations, void *stream)
+                             float *depths, float *conics, float *compensations, void *stream, const float *viewmats1 = nullptr,
+                             int rs_type = 4, int global_z_order = 1)
 {
     using namespace gsx;
+    GSX_REQUIRE(rs_type >= 0 && rs_type <= 4, "gsx_project_ut_rs_fwd: rolling shutter type %d (0 .. 3 rolling, 4 global)", rs_type);
+    GSX_REQUIRE(rs_type == 4 || viewmats1 != nullptr, "gsx_project_ut_rs_fwd: a rolling shutter needs the end-of-frame poses");
     const int64_t rows = (int64_t)B * C * N;
     if (rows == 0) return GSX_OK;
     GSX_REQUIRE(means && quats && scales && viewmats && Ks, "gsx_project_ut_fwd: null input");
@@ -303,6 +439,9 @@ static int project_ut_launch(const float *means, const float *quats, const float
     a.w_i  = (float)(1.0 / (2.0 * (3.0 + lam)));
     a.spread = (float)sqrt(3.0 + lam);
     a.margin = in_image_margin_factor;
+    a.viewmats1 = rs_type == 4 ? nullptr : viewmats1; a.rs_type = rs_type;
+    a.depth_is_distance = global_z_order ? 0 : 1;
+    a.radial_cull = (!global_z_order && camera_model == 3) ? 1 : 0; // (lidar too in the reference; not built here)
     a.radii = radii; a.means2d = means2d; a.depths = depths; a.conics = conics; a.compensations = compensations;
     project_ut_kernel<<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
     return check_launch("project_ut_fwd");
@@ -337,4 +476,22 @@ extern "C" int gsx_project_ut_ftheta_fwd(const float *means, const float *quats,
                              width, height, eps2d, near_plane, far_plane, radius_clip, 3, ut_alpha, ut_beta, ut_kappa,
                              in_image_margin_factor, require_all_sigma_points_valid, radii, means2d, depths, conics, compensations,
                              stream);
+}
+
+// Every camera model of the two entries above + rolling shutter + the Euclidean sort depth, one entry: `viewmats1` = pose at the
+// end of the frame (NULL with rs_type 4 = global), `rs_type` as Cameras.h:38-45, `global_z_order` 0 = depths are |mean_c| (and
+// f-theta cameras cull near / far radially). `ftheta` = the 17-float host record of gsx_project_ut_ftheta_fwd or NULL.
+extern "C" int gsx_project_ut_rs_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                                     const float *viewmats0, const float *viewmats1, const float *Ks, const float *radial,
+                                     const float *tangential, const float *thin_prism, const float *fisheye_max_angle,
+                                     const float *ftheta, uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                                     float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
+                                     int rs_type, int global_z_order, float ut_alpha, float ut_beta, float ut_kappa,
+                                     float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii,
+                                     float *means2d, float *depths, float *conics, float *compensations, void *stream)
+{
+    return project_ut_launch(means, quats, scales, opacities, viewmats0, Ks, radial, tangential, thin_prism, fisheye_max_angle, ftheta,
+                             B, C, N, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, ut_alpha, ut_beta,
+                             ut_kappa, in_image_margin_factor, require_all_sigma_points_valid, radii, means2d, depths, conics,
+                             compensations, stream, viewmats1, rs_type, global_z_order);
 }

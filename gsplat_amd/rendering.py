@@ -11,7 +11,7 @@ of the reference (``gsplat/rendering.py:234-690``) and the stage order of its C+
 
 3DGUT: ``with_ut`` (Unscented-Transform projection through pinhole / distorted-pinhole / ortho / fisheye / f-theta cameras,
 global shutter) and ``with_eval3d`` (from-world compositing) are built; what is NOT built is refused up front, before
-any kernel launches, never approximated: f-theta outside the UT projection, lidar cameras, rolling shutter, external (windshield) distortion,
+any kernel launches, never approximated: f-theta outside the UT projection, lidar cameras, external (windshield) distortion,
 ray generation for distorted cameras (pass ``rays``), the hit-distance render modes and ``return_normals``.
 """
 from __future__ import annotations
@@ -139,7 +139,7 @@ def rasterization(
         "camera_model='ftheta' / ftheta_coeffs outside the UT projection (with_ut=True without with_eval3d, or with rays given)":
             (camera_model == "ftheta" or ftheta_coeffs is not None) and not (with_ut and (not with_eval3d or rays is not None)),
         "camera_model='lidar'": camera_model == "lidar",
-        "rolling shutter": viewmats_rs is not None, "external_distortion_coeffs": external_distortion_coeffs is not None,
+        "external_distortion_coeffs": external_distortion_coeffs is not None,
     }
     bad = [k for k, v in unsupported.items() if v]
     if bad:
@@ -187,6 +187,16 @@ def rasterization(
         clear_row_map_cache()  # the previous step's row map (and the id tensors it holds) can go
     calc_comp = rasterize_mode == "antialiased"
     view_opacities = None
+    rs_type = _ROLLING_SHUTTER_GLOBAL if rolling_shutter is None else int(rolling_shutter)
+    # rolling shutter (with_ut only, validated above): the projection interpolates the pose per sigma point, the from-world
+    # rasterizer per pixel row / column, and the view-dependent colours use the camera offset averaged over the two ends of
+    # the frame (Rendering.cpp:1057, SphericalHarmonics.cuh:40-65) - a synthetic view matrix built with differentiable tensor
+    # operations, so pose gradients reach both ends
+    viewmats_sh = viewmats_proj
+    if viewmats_rs is not None:
+        from ._ops import _sh_rs_viewmats
+
+        viewmats_sh = _sh_rs_viewmats(viewmats_proj, viewmats_rs)
     if with_ut:
         # Unscented-Transform projection through the (possibly distorted) camera model; no gradient reaches the geometry
         # on this path (the reference runs the op under no_grad as well, Rendering.cpp:890-925)
@@ -196,7 +206,8 @@ def rasterization(
             means, quats, scales, opacities, viewmats_proj, Ks_proj, width, height, eps2d=eps2d, near_plane=near_plane,
             far_plane=far_plane, radius_clip=radius_clip, calc_compensations=calc_comp, camera_model=camera_model,
             ut_params=ut_params, radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs,
-            thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=ftheta_coeffs, global_z_order=global_z_order)
+            thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=ftheta_coeffs, global_z_order=global_z_order,
+            rolling_shutter=rs_type, viewmats_rs=viewmats_rs)
     elif not packed and not calc_comp and means.is_cuda and _VIEW_OPACITIES:
         # dense rows, classic mode: the per-view opacities come out of the projection's own autograd node, whose backward sums
         # their gradient over the views inside the kernel that reads the gradient rows anyway (_autograd.py)
@@ -255,12 +266,12 @@ def rasterization(
     # ---- feature channels: [..., C, N, D] or [nnz, D] ------------------------------------------
     feats = None
     if has_color:
-        feats = _project_features(colors, sh_degree, True, means, viewmats_proj, radii, batch_dims, B, C_proj, N,
+        feats = _project_features(colors, sh_degree, True, means, viewmats_sh, radii, batch_dims, B, C_proj, N,
                                   batch_ids, camera_ids, gaussian_ids)
     n_primary = feats.shape[-1] if feats is not None else 0
     n_extra = 0
     if extra_signals is not None:
-        ex = _project_features(extra_signals, extra_signals_sh_degree, False, means, viewmats_proj, radii, batch_dims,
+        ex = _project_features(extra_signals, extra_signals_sh_degree, False, means, viewmats_sh, radii, batch_dims,
                                B, C_proj, N, batch_ids, camera_ids, gaussian_ids)
         n_extra = ex.shape[-1]
         feats = ex if feats is None else torch.cat([feats, ex], dim=-1)
@@ -338,7 +349,7 @@ def rasterization(
             render_colors, render_alphas = rasterize_to_pixels_eval3d(
                 means, quats, scales, feats.contiguous(), proj_opacities.contiguous(), viewmats, Ks, width, height,
                 tile_size, isect_offsets, flatten_ids, backgrounds=backgrounds, camera_model=camera_model,
-                ut_params=ut_params, rays=rays)
+                ut_params=ut_params, rays=rays, rolling_shutter=rs_type, viewmats_rs=viewmats_rs)
         else:
             render_colors, render_alphas = rasterize_to_pixels(
                 means2d, conics, feats, proj_opacities, width, height, tile_size, isect_offsets, flatten_ids,

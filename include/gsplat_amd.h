@@ -249,7 +249,7 @@ int gsx_sh_bwd(int degrees_to_use, const float *means, const float *viewmats, co
  * camera model; mean2d / cov2d are the UT-weighted moments of their pixels (sums stop at the first invalid point when
  * require_all_sigma_points_valid). Then blur (+eps2d I) and compensation, conic = inverse, opacity-aware extent (opacities
  * NULL = none), eigenvalue-bounded radii, radius clip, image cull. Rows that fail a check are written as zeros.
- * compensations may be NULL. f-theta cameras: gsx_project_ut_ftheta_fwd below. Lidar and rolling shutter are not built: -1.
+ * compensations may be NULL. f-theta cameras: gsx_project_ut_ftheta_fwd below; rolling shutter: gsx_project_ut_rs_fwd. Lidar is not built: -1.
  * ------------------------------------------------------------------------------------------- */
 int gsx_project_ut_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
                        const float *viewmats, const float *Ks, const float *radial, const float *tangential,
@@ -272,6 +272,21 @@ int gsx_project_ut_ftheta_fwd(const float *means, const float *quats, const floa
                               float ut_alpha, float ut_beta, float ut_kappa, float in_image_margin_factor,
                               int require_all_sigma_points_valid, int32_t *radii, float *means2d, float *depths,
                               float *conics, float *compensations, void *stream);
+/* The same op with a ROLLING SHUTTER and / or the Euclidean sort depth, for every camera model above (ProjectionUT3DGSFused.cu:
+ * 121-127, 239-240, 411; Cameras.cuh:76-135, 362-429, 549-660): `viewmats1` [B,C,4,4] = pose at the END of the frame (NULL with
+ * rs_type 4), `rs_type` 0 top-to-bottom, 1 left-to-right, 2 bottom-to-top, 3 right-to-left, 4 global (Cameras.h:38-45). Every
+ * sigma point is projected with the start pose (else the end pose), then up to ten rounds of "read-out time of its pixel -> pose at
+ * that time (translation lerp, rotation slerp) -> project again"; the Gaussian's own camera-frame position (near / far, depth)
+ * uses the pose at mid-frame. `global_z_order` 0: depths = |mean_c| instead of mean_c.z, and f-theta cameras cull near / far on
+ * |mean_c|. `ftheta`: the 17-float HOST record of gsx_project_ut_ftheta_fwd (camera_model 3) or NULL. */
+int gsx_project_ut_rs_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                          const float *viewmats0, const float *viewmats1, const float *Ks, const float *radial,
+                          const float *tangential, const float *thin_prism, const float *fisheye_max_angle,
+                          const float *ftheta, uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height,
+                          float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
+                          int rs_type, int global_z_order, float ut_alpha, float ut_beta, float ut_kappa,
+                          float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii,
+                          float *means2d, float *depths, float *conics, float *compensations, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * From-world ("eval3d") compositing of 3DGUT, FORWARD: the compositing half of gsplat::rasterize_to_pixels_from_world_3dgs

@@ -167,8 +167,9 @@ def test_rasterization_3dgs_argument_mapping(ops, monkeypatch):
     assert out[2].shape == (1, 8, 8, 2) and float(out[4].sum()) == 42.0 and out[5].numel() == 3
     with pytest.raises(ValueError):
         fn(*_args3d(renderer_config=1))
-    with pytest.raises(RuntimeError):
-        fn(*_args3d(rolling_shutter=0))
+    stub.calls.clear()
+    fn(*_args3d(rolling_shutter=0))  # a rolling shutter is handed on (the orchestrator validates it: with_ut, viewmats_rs)
+    assert stub.calls[0][1]["rolling_shutter"] == 0
 
 
 def test_covars_triu_layout_is_what_the_reference_python_sends():
