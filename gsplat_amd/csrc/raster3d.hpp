@@ -276,6 +276,13 @@ __device__ __forceinline__ float staged_alpha_raw(const float4 &ga, float q)
 {
     return __builtin_amdgcn_exp2f(ga.z - q);
 }
+// The exponent on a (x', y', lo, A | B, C) row with (x', y') = mean - TILE CENTRE and (dx, dy) = (x', y') - (pixel - tile centre):
+// instruction for instruction what staged_f() evaluates on its (ax, ay, lo | nA, nB, nC) row (negation is exact), so that the
+// reduction backward and the query kernels take the alpha test exactly where the forward took it. sigma < 0  <=>  e > ga.z.
+__device__ __forceinline__ float staged_e_offset(const float4 &ga, const float2 &gb, float dx, float dy)
+{
+    return fmaf(dx, fmaf(-gb.x, dy, -ga.w * dx), fmaf(-gb.y * dy, dy, ga.z));
+}
 
 // ---- staged form, tile-centre polynomial ("e-form"; raster3d_fwd.hip and variant T of raster3d_bwd.hip) -------------------
 // With a = mean - c (c = centre of the tile) and a lane's pixel at u = pixel - c (|u|, |v| <= 7.5, exact in fp32):
@@ -296,7 +303,10 @@ __device__ __forceinline__ float staged_alpha_raw(const float4 &ga, float q)
 // lo + kLoMargin: a pair is rejected only where sigma < -kLoMargin / log2(e) ~ -8.5e-5, which a valid conic never reaches and
 // which costs an invalid one nothing that matters (alpha within 1.0001 of the opacity). Readers that need lo itself (the
 // backward's 1 / opacity) subtract the margin again.
-constexpr float kLoMargin = 1.220703125e-4f; // 2^-13
+#ifndef GSX_DFORM
+#define GSX_DFORM 1 // 1: every kernel evaluates the exponent from the offset (stage_gaussian_f / staged_f below): e == lo at the mean
+#endif
+constexpr float kLoMargin = GSX_DFORM ? 0.0f : 1.220703125e-4f; // 2^-13 for the polynomial; the offset form needs none
 struct StagedRow { // one staged Gaussian in LDS: 48 bytes, read as b128 + b128 + b64 from ONE address register
     v4f p0;        // e0, gu, gv, lo + kLoMargin
     v4f p1;        // nA, nB, nC, colour 2
@@ -326,16 +336,16 @@ __device__ __forceinline__ float staged_e(const v4f &p0, float nA, float nB, flo
 // therefore evaluate the exponent the way the reference does, from the offset d = mean - pixel (two subtractions more per pair):
 //   e = lo - (A dx^2 + B dx dy + C dy^2) = fma(dx, fma(nB, dy, nA dx), fma(nC dy, dy, lo))
 // whose error is a few ulp of the RESULT (~3e-6 at p99.99). e == lo exactly at the mean, so the sigma < 0 test needs no margin.
-// The backward kernels keep the polynomial (its moments want the tile-centre frame); the two agree to ~1.5e-5 on alpha, the
-// forward's decisions (last_ids, the 1/255 and 1e-4 tests) are what the backward is handed. GSX_FWD_DFORM=0 builds the
-// polynomial into the forward kernels again (A/B of the two instructions).
-#ifndef GSX_FWD_DFORM
-#define GSX_FWD_DFORM 1
-#endif
+// The BACKWARD kernels evaluate the same function through the same instructions (stage_gaussian_f / staged_f): a pair is blended
+// by the backward iff the forward blended it - with the polynomial in the backward and the offset form in the forward a pair
+// within 1.5e-5 of the 1/255 test was taken by one and not by the other (6 of 369 k rows of v_means2d off by up to 6e-3 in the
+// reference's test_rasterize_to_pixels). Their moments stay in the tile-centre frame (u, v); one wave per tile (variant W)
+// shares dx / dy between the four pixels of a lane, so the offset form costs it 18 instructions where the polynomial took 20.
+// GSX_DFORM=0 builds the polynomial into every kernel again (A/B: no measurable difference at c3, profiles/r10_ab.md).
 __device__ __forceinline__ void stage_gaussian_f(float ax, float ay, float opac, float ca, float cb, float cc, v4f &p0,
                                                  float &nA, float &nB, float &nC)
 {
-#if GSX_FWD_DFORM
+#if GSX_DFORM
     const float lo = opac > 0.0f ? __log2f(opac) : -INFINITY; // opac <= 0 (or NaN) can never pass the alpha test
     p0 = v4f{ax, ay, lo, lo}; // mean - tile centre | base of the exponent | reject level (e > lo <=> sigma < 0)
     nA = -0.5f * kLog2e * ca; nB = -kLog2e * cb; nC = -0.5f * kLog2e * cc;
@@ -346,7 +356,7 @@ __device__ __forceinline__ void stage_gaussian_f(float ax, float ay, float opac,
 // (u, v) = pixel centre - tile centre
 __device__ __forceinline__ float staged_f(const v4f &p0, float nA, float nB, float nC, float u, float v)
 {
-#if GSX_FWD_DFORM
+#if GSX_DFORM
     const float dx = p0.x - u, dy = p0.y - v;
     return fmaf(dx, fmaf(nB, dy, nA * dx), fmaf(nC * dy, dy, p0.z));
 #else

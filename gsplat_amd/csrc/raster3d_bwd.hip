@@ -68,8 +68,11 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
     tile_pixel(tid, a.tile_size, lx, ly);
     const int64_t prow = pixel_row(a, tc, blockIdx.x, lx, ly);
     const bool inside  = prow >= 0;
-    const float px     = (float)(tc.tile_x * a.tile_size + lx) + 0.5f;
-    const float py     = (float)(tc.tile_y * a.tile_size + ly) + 0.5f;
+    // everything in the tile-centre frame of the forward kernels (the alpha test must be the forward's, bit for bit)
+    const float half_r = 0.5f * (float)a.tile_size;
+    const float tcx    = (float)(tc.tile_x * a.tile_size) + half_r, tcy = (float)(tc.tile_y * a.tile_size) + half_r;
+    const float px     = (float)lx + 0.5f - half_r; // pixel centre - tile centre
+    const float py     = (float)ly + 0.5f - half_r;
     const size_t pix   = inside ? (size_t)prow : 0;
 
     const int32_t range_start = tc.range_start;
@@ -137,11 +140,11 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
                 s_id[s]        = g;
                 float4 ga;
                 float2 gb;
-                stage_gaussian(xy.x, xy.y, opac, ca, cb, cc, ga, gb);
+                stage_gaussian(xy.x - tcx, xy.y - tcy, opac, ca, cb, cc, ga, gb);
                 s_ga[s]        = ga;
                 s_gb[s]        = gb;
                 const float2 he = cull_half_extent(opac, ca, cb, cc);
-                s_cull[s]      = make_float4(xy.x, xy.y, he.x, he.y);
+                s_cull[s]      = make_float4(ga.x, ga.y, he.x, he.y);
                 const float *c = a.colors + (size_t)g * a.cdim + a.ch_off;
 #pragma unroll
                 for (int k = 0; k < CH; ++k) s_col[s * CH + k] = (k < (int)a.nch) ? c[k] : 0.0f;
@@ -169,10 +172,10 @@ __global__ void __launch_bounds__(256) raster3d_bwd_kernel(const Raster3DArgs a)
             const float2 gb = s_gb[t];
             const float dx = ga.x - px;
             const float dy = ga.y - py;
-            const float q  = staged_q(ga, gb, dx, dy);
-            const float ov_r = staged_alpha_raw(ga, q); // opac * exp(-sigma), unclamped
-            // lanes outside the image have bin_final = -1 and can never be valid
-            const bool valid = (batch_end - t <= bin_final) && !(q < 0.0f) && !(fminf(kMaxAlpha, ov_r) < kAlphaThreshold);
+            const float e    = staged_e_offset(ga, gb, dx, dy);
+            const float ov_r = __builtin_amdgcn_exp2f(e); // opac * exp(-sigma), unclamped
+            // lanes outside the image have bin_final = -1 and can never be valid; e > lo <=> sigma < 0
+            const bool valid = (batch_end - t <= bin_final) && !(e > ga.z) && !(fminf(kMaxAlpha, ov_r) < kAlphaThreshold);
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform
 
             const float ov    = valid ? ov_r : 0.0f;
@@ -533,7 +536,7 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
                 const float ax = xy.x - tile_cx, ay = xy.y - tile_cy;
                 v4f p0;
                 float nA, nB, nC;
-                stage_gaussian_e(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
+                stage_gaussian_f(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
                 const float2 he = cull_half_extent(opac, ca, cb, cc);
                 s_cull[s]      = make_float4(ax, ay, he.x, he.y);
                 const float *c = a.colors + (size_t)g * a.cdim + a.ch_off;
@@ -569,7 +572,7 @@ raster3d_bwd_t_kernel(Raster3DArgs a)
             const v2f c01 = *reinterpret_cast<const v2f *>(&s_st[t].p2);
             [[maybe_unused]] const v4f p2 = CH > 3 ? s_st[t].p2 : v4f{0.f, 0.f, 0.f, 0.f};
             asm volatile("" ::"v"(c01.x), "v"(c01.y)); // keeps the read HERE (the compiler would sink it below the branch)
-            const float e     = staged_e(p0, p1.x, p1.y, p1.z, pu, pv);
+            const float e     = staged_f(p0, p1.x, p1.y, p1.z, pu, pv);
             const float ov_r  = __builtin_amdgcn_exp2f(e); // opac * exp(-sigma), unclamped
             const float al_r  = fminf(kMaxAlpha, ov_r);
             // lanes outside the image have bin_final = -1 and can never be valid; e > lo <=> sigma < 0
@@ -841,13 +844,18 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
             // gv + nB u + 2 nC v) - so the turn forms it per pixel from two row constants: two instructions per pixel and axis
             [[maybe_unused]] float gxr[2] = {0.f, 0.f}, gyr[2] = {0.f, 0.f}, ax2 = 0.f, bx1 = 0.f, sabs[2] = {0.f, 0.f};
             if constexpr (ABS) {
-                const v4f q0 = s_st[info >> 4].p0, q1 = s_st[info >> 4].p1; // e0, gu, gv, lo | nA, nB, nC, -
+                const v4f q0 = s_st[info >> 4].p0, q1 = s_st[info >> 4].p1; // staged row | nA, nB, nC, -
+#if GSX_DFORM // row = (ax, ay, lo, lo): the gradient of the exponent at the tile centre from the mean's offset
+                const float gu = -fmaf(2.0f * q1.x, q0.x, q1.y * q0.y), gv = -fmaf(q1.y, q0.x, 2.0f * q1.z * q0.y);
+#else         // row = (e0, gu, gv, lo)
+                const float gu = q0.y, gv = q0.z;
+#endif
                 ax2 = 2.0f * q1.x; bx1 = q1.y;
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const float vr = v0 + (float)r;
-                    gxr[r] = fmaf(ax2, u0, fmaf(q1.y, vr, q0.y));
-                    gyr[r] = fmaf(q1.y, u0, fmaf(2.0f * q1.z, vr, q0.z));
+                    gxr[r] = fmaf(ax2, u0, fmaf(q1.y, vr, gu));
+                    gyr[r] = fmaf(q1.y, u0, fmaf(2.0f * q1.z, vr, gv));
                 }
             }
 #pragma unroll
@@ -964,7 +972,7 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
                 const float ax = f.xy.x - tile_cx, ay = f.xy.y - tile_cy;
                 v4f p0;
                 float nA, nB, nC;
-                stage_gaussian_e(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
+                stage_gaussian_f(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
                 const v4f p1 = v4f{nA, nB, nC, f.cv[2]};
                 s_st[lane].p0 = p0;
                 s_st[lane].p1 = p1;
@@ -1026,7 +1034,7 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
             bool valid_q[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float e = staged_e(p0, p1.x, p1.y, p1.z, pu[q & 1], pv[q >> 1]);
+                const float e = staged_f(p0, p1.x, p1.y, p1.z, pu[q & 1], pv[q >> 1]);
                 ov_q[q]       = __builtin_amdgcn_exp2f(e);
                 al_q[q]       = fminf(kMaxAlpha, ov_q[q]);
                 valid_q[q]    = (qm & (1 << q)) && (bin_final[q] >= list_idx) && !(e > p0.w) && !(al_q[q] < kAlphaThreshold);
@@ -1039,7 +1047,7 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
                 const bool valid = valid_q[q];
 #else
                 if (!(qm & (1 << q))) continue; // scalar
-                const float e    = staged_e(p0, p1.x, p1.y, p1.z, pu[q & 1], pv[q >> 1]);
+                const float e    = staged_f(p0, p1.x, p1.y, p1.z, pu[q & 1], pv[q >> 1]);
                 const float ov_r = __builtin_amdgcn_exp2f(e); // opac * exp(-sigma), unclamped
                 const float al_r = fminf(kMaxAlpha, ov_r);
                 // pixels outside the image have bin_final = -1 and can never be valid; e > lo <=> sigma < 0

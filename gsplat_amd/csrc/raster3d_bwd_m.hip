@@ -206,7 +206,7 @@ raster3d_bwd_m_kernel(const Raster3DArgs a)
                     const float ax = xy.x - tile_cx, ay = xy.y - tile_cy;
                     v4f p0;
                     float nA, nB, nC;
-                    stage_gaussian_e(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
+                    stage_gaussian_f(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
                     const float2 he = cull_half_extent(opac, ca, cb, cc);
                     s_cull[s]      = make_float4(ax, ay, he.x, he.y);
                     s_st[s].p0     = p0;
@@ -292,7 +292,7 @@ raster3d_bwd_m_kernel(const Raster3DArgs a)
                     const int32_t t = __builtin_amdgcn_readlane(slot_t, k);
                     const v4f p0 = s_st[t].p0;
                     const v4f p1 = s_st[t].p1;
-                    const float e = staged_e(p0, p1.x, p1.y, p1.z, pu, pv);
+                    const float e = staged_f(p0, p1.x, p1.y, p1.z, pu, pv);
                     fr[i].ov_r = __builtin_amdgcn_exp2f(e); // opac * exp(-sigma), unclamped
                     fr[i].al_r = fminf(kMaxAlpha, fr[i].ov_r);
                     // lanes outside the image have bin_final = -1 and can never be valid; e > lo <=> sigma < 0

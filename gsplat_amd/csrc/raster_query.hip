@@ -55,7 +55,10 @@ __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
     tile_pixel(tid, a.tile_size, lx, ly);
     const int64_t prow = pixel_row(a, tc, blockIdx.x, lx, ly);
     const bool inside  = prow >= 0;
-    const float px = (float)(tc.tile_x * a.tile_size + lx) + 0.5f, py = (float)(tc.tile_y * a.tile_size + ly) + 0.5f;
+    // the tile-centre frame of the compositing kernels: the alpha test is theirs, bit for bit (raster3d.hpp: staged_e_offset)
+    const float half_q = 0.5f * (float)a.tile_size;
+    const float tcx = (float)(tc.tile_x * a.tile_size) + half_q, tcy = (float)(tc.tile_y * a.tile_size) + half_q;
+    const float px = (float)lx + 0.5f - half_q, py = (float)ly + 0.5f - half_q; // pixel centre - tile centre
     const size_t pix = inside ? (size_t)prow : 0;
 
     const int32_t range_start = tc.range_start, range_end = tc.range_end;
@@ -86,11 +89,11 @@ __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
                 const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
                 float4 ga;
                 float2 gb;
-                stage_gaussian(xy.x, xy.y, opac, ca, cb, cc, ga, gb);
+                stage_gaussian(xy.x - tcx, xy.y - tcy, opac, ca, cb, cc, ga, gb);
                 s_ga[s] = ga;
                 s_gb[s] = gb;
                 const float2 he = cull_half_extent(opac, ca, cb, cc);
-                s_cull[s]       = make_float4(xy.x, xy.y, he.x, he.y);
+                s_cull[s]       = make_float4(ga.x, ga.y, he.x, he.y);
                 s_id[s]         = a.n_per_image ? (int32_t)((uint32_t)g % a.n_per_image) : g;
             }
         }
@@ -111,15 +114,16 @@ __global__ void __launch_bounds__(256) raster3d_query_kernel(const QueryArgs a)
                 const float4 ga = s_ga[t];
                 const float2 gb = s_gb[t];
                 const float dx = ga.x - px, dy = ga.y - py;
-                const float q     = staged_q(ga, gb, dx, dy);
-                const float alpha = fminf(kMaxAlpha, staged_alpha_raw(ga, q));
+                const float e     = staged_e_offset(ga, gb, dx, dy);
+                const float alpha = fminf(kMaxAlpha, __builtin_amdgcn_exp2f(e));
+                const bool neg    = e > ga.z; // sigma < 0
                 if constexpr (MODE == kQStats) {
                     ++wave_evals;
                     lane_evals += done ? 0u : 1u;
-                    empty_evals += __builtin_amdgcn_ballot_w64(inside && !(q < 0.0f) && !(alpha < kAlphaThreshold)) == 0ull ? 1u : 0u;
+                    empty_evals += __builtin_amdgcn_ballot_w64(inside && !neg && !(alpha < kAlphaThreshold)) == 0ull ? 1u : 0u;
                 }
-                if (done || q < 0.0f || alpha < kAlphaThreshold) continue;
-                const float next_T = T * (1.0f - alpha);
+                if (done || neg || alpha < kAlphaThreshold) continue;
+                const float next_T = fmaf(-T, alpha, T); // the compositing kernels' update
                 if (next_T <= kTransmittanceThresh) {
                     done = true;
                     if constexpr (MODE == kQStats) walked = (uint32_t)(batch_start + t - range_start + 1);

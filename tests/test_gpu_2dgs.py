@@ -476,5 +476,5 @@ def test_dispatcher_2dgs_bwd_with_dense_cotangents(G):
     private = _ops.impl("rasterize_to_pixels_2dgs_bwd")(*head, None, None, None, None, False)
     for a, b in zip(dense, private):
         assert (a is None) == (b is None)
-        if a is not None:
-            assert torch.equal(a, b)
+        if a is not None:  # two launches add the per-tile sums to the gradient rows in different orders: equal to rounding
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
