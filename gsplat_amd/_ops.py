@@ -2167,7 +2167,7 @@ class _FromWorldCompositing(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, colors, opacities, rays, backgrounds, masks, width, height, tile_size,
-                tile_offsets, flatten_ids):
+                tile_offsets, flatten_ids, want_counts=False):
         batch = tuple(means.shape[:-2])
         N, C, D = means.shape[-2], colors.shape[-3], colors.shape[-1]
         I = math.prod(batch) * C
@@ -2179,16 +2179,20 @@ class _FromWorldCompositing(torch.autograd.Function):
         args = [t.contiguous() for t in (means, quats, scales, colors, opacities, rays)]
         bg, mk = _c(backgrounds), _c(masks)
         off, fl = tile_offsets.contiguous(), flatten_ids.contiguous()
-        call("gsx_raster_world_fwd", *[ptr(t) for t in args], ptr(bg), ptr(mk), ptr(off), ptr(fl), I, C, N, fl.numel(), D,
-             int(width), int(height), int(tile_size), tw, th, ptr(renders), ptr(alphas), ptr(last_ids))
+        counts = torch.empty(batch + (C, height, width), device=dev, dtype=torch.int32) if want_counts else None
+        call("gsx_raster_world_fwd_counts", *[ptr(t) for t in args], ptr(bg), ptr(mk), ptr(off), ptr(fl), I, C, N, fl.numel(), D,
+             int(width), int(height), int(tile_size), tw, th, ptr(renders), ptr(alphas), ptr(last_ids), ptr(counts))
         ctx.save_for_backward(*args, off, fl, alphas, last_ids, *([bg] if bg is not None else []),
                               *([mk] if mk is not None else []))
         ctx.flags = (bg is not None, mk is not None, I, C, N, D, int(width), int(height), int(tile_size), tw, th, batch)
         ctx.mark_non_differentiable(last_ids)
-        return renders, alphas, last_ids
+        if counts is None:
+            counts = torch.empty(0, device=dev, dtype=torch.int32)
+        ctx.mark_non_differentiable(counts)
+        return renders, alphas, last_ids, counts
 
     @staticmethod
-    def backward(ctx, v_renders, v_alphas, _v_last):
+    def backward(ctx, v_renders, v_alphas, _v_last, _v_counts=None):
         has_bg, has_mk, I, C, N, D, width, height, tile_size, tw, th, batch = ctx.flags
         saved = list(ctx.saved_tensors)
         means, quats, scales, colors, opacities, rays, off, fl, alphas, last_ids = saved[:10]
@@ -2217,7 +2221,7 @@ class _FromWorldCompositing(torch.autograd.Function):
             v_quats, v_scales = torch.autograd.grad(M, (q, sc), v_M)
         v_opac = per[..., 12].reshape(opacities.shape)
         v_cols = per[..., 13:].reshape(colors.shape)
-        return (v_means, v_quats, v_scales, v_cols, v_opac) + (None,) * 8
+        return (v_means, v_quats, v_scales, v_cols, v_opac) + (None,) * 9
 
 
 @_op("rasterize_to_pixels_from_world_3dgs")
@@ -2230,8 +2234,12 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
     """gsplat::rasterize_to_pixels_from_world_3dgs (forward + autograd, like the reference's C++ autograd function,
     Rasterization.cpp:3266-3340): dense rows, MixedBatch renderer, rays either given or generated for perfect pinhole
     cameras with a global shutter. Everything else is refused, never approximated."""
-    if return_sample_counts or use_hit_distance or return_normals or renderer_config != 0:
-        raise NotImplementedError("gsplat_amd: sample counts / hit distance / normals / ParallelBatch are not built yet")
+    if use_hit_distance or return_normals:
+        raise NotImplementedError("gsplat_amd: hit distance / normals of the from-world rasterizer are not built yet")
+    if renderer_config not in (0, 1):
+        raise ValueError(f"unknown renderer_config {renderer_config}")
+    # renderer_config 1 (PARALLEL_BATCH, Rasterization.cpp:106-117) is a scheduling choice of the reference (its lists split over
+    # several CTAs); this backend has one schedule, the results are the same
     if lidar_coeffs is not None or external_distortion_params is not None:
         raise NotImplementedError("gsplat_amd: lidar / external distortion eval3d is not built yet")
     rolling = rs_type != _ROLLING_SHUTTER_GLOBAL
@@ -2254,10 +2262,10 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
     image_dims, I, th, tw, _ = _raster_dims(tile_offsets, colors)
     if tuple(rays.shape[-3:]) != (image_height, image_width, 6) or rays.numel() != I * image_height * image_width * 6:
         raise ValueError(f"rays must be [..., C, H, W, 6], got {tuple(rays.shape)}")
-    renders, alphas, last_ids = _FromWorldCompositing.apply(
+    renders, alphas, last_ids, counts = _FromWorldCompositing.apply(
         means, quats, scales, colors, opacities, rays.detach(), backgrounds, masks, int(image_width), int(image_height),
-        int(tile_size), tile_offsets, flatten_ids)
-    return renders, alphas, (last_ids if return_last_ids else None), None, None
+        int(tile_size), tile_offsets, flatten_ids, bool(return_sample_counts))
+    return renders, alphas, (last_ids if return_last_ids else None), (counts if return_sample_counts else None), None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -2287,7 +2295,7 @@ def rasterization_3dgs(means, covars, quats, scales, opacities, colors, viewmats
     the 3DGUT / f-theta paths, which are rejected like every other out-of-scope argument."""
     from .rendering import rasterization
 
-    if renderer_config != 0:
+    if renderer_config != 0 and not with_eval3d:
         raise ValueError("RendererConfig PARALLEL_BATCH requires with_eval3d=True; the classic path only supports "
                          "MIXED_BATCH")
     if camera_model not in _CAMERA_MODEL_NAMES:

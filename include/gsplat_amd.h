@@ -305,6 +305,15 @@ int gsx_raster_world_fwd(const float *means, const float *quats, const float *sc
                          uint32_t cameras_per_batch, uint32_t n_gaussians, uint32_t n_isects, uint32_t cdim, uint32_t width,
                          uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *render_colors,
                          float *render_alphas, int32_t *last_ids, void *stream);
+/* The same launch + sample_counts int32 [I,H,W] (may be NULL): the number of samples each pixel blended - the op's
+ * `return_sample_counts` output (Rasterization.cpp:2404; `n_accumulated` in RasterizeToPixelsFromWorld3DGS.cuh:785). */
+int gsx_raster_world_fwd_counts(const float *means, const float *quats, const float *scales, const float *colors,
+                                const float *opacities, const float *rays, const float *backgrounds, const uint8_t *masks,
+                                const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images,
+                                uint32_t cameras_per_batch, uint32_t n_gaussians, uint32_t n_isects, uint32_t cdim,
+                                uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                                float *render_colors, float *render_alphas, int32_t *last_ids, int32_t *sample_counts,
+                                void *stream);
 
 /* Backward of gsx_raster_world_fwd (reference host fn rasterize_to_pixels_from_world_3dgs_bwd, Rasterization.cpp:2920;
  * kernel RasterizeToPixelsFromWorld3DGSBwd.cu). Gradient rows v_rows [I * N][row_stride >= 13 + cdim], ZEROED by the caller: v_mean (3) | v_M (9, row-major, M = S^-1 R^T) |
