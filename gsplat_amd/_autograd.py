@@ -207,6 +207,7 @@ def _rast_setup(ctx, inputs, output):
     ctx.set_materialize_grads(False)  # an unused render_alphas (or render_colors) gets no zero-filled gradient
     ctx.rc_shape = _render_colors.shape
     ctx.longest = _ops.long_tile_hint_of_call()  # the backward cuts the same long lists into segments
+    ctx.splat_rows = _ops.splat_rows_hint_of_call()  # rasterization()'s array-of-structures rows of these Gaussians (or None)
     ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids,
                           render_alphas, last_ids, means2d_absgrad)
 
@@ -216,6 +217,9 @@ def _rast_backward(ctx, v_render_colors, v_render_alphas, v_means2d_absgrad, v_l
      means2d_absgrad) = ctx.saved_tensors
     hint = _ops
     hint.set_long_tile_hint(ctx.longest)  # this (autograd) thread's hint; the op body consumes it
+    rows = getattr(ctx, "splat_rows", None)
+    if rows is not None:
+        hint.set_splat_rows_hint(rows, means2d)
     try:
         v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities, v_backgrounds = _bwd("rasterize_to_pixels_3dgs")(
             means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas, last_ids,
@@ -224,6 +228,8 @@ def _rast_backward(ctx, v_render_colors, v_render_alphas, v_means2d_absgrad, v_l
         )  # v_render_colors as it comes: the body reads pixel-linear views in place (the gradient of sum() is one float)
     finally:
         hint.set_long_tile_hint(0)
+        if rows is not None:
+            hint.set_splat_rows_hint(None, None)
     if ctx.absgrad and v_means2d_abs is not None:
         means2d_absgrad.copy_(v_means2d_abs)
     return (v_means2d, v_conics, v_colors, v_opacities, v_backgrounds) + (None,) * 8

@@ -92,6 +92,31 @@ def set_long_tile_hint(longest: int) -> None:
         _set_hint_compiled(int(longest))
 
 
+# The compositing kernels' 48-byte array-of-structures rows (csrc/raster3d.hpp: Raster3DArgs::splat_rows) travel like the long-list
+# hint: rasterization() has them written by its SH forward (gsx_sh_fwd_rows) and the WRAPPER announces them around the op call -
+# the reference's op schema has no room for a thirteenth tensor. A body only uses rows announced for ITS means2d.
+_set_rows_compiled = None  # gsx_torch_set_splat_rows of libgsplat_amd_torch.so
+
+
+def set_splat_rows_hint(rows: Optional[Tensor], means2d: Optional[Tensor]) -> None:
+    _hint.rows = _hint.rows_of_call = None if rows is None else (rows, means2d.data_ptr())
+    if _set_rows_compiled is not None:
+        _set_rows_compiled(0 if rows is None else rows.data_ptr(), 0 if rows is None else means2d.data_ptr())
+
+
+def splat_rows_hint_of_call() -> Optional[Tensor]:
+    r = getattr(_hint, "rows_of_call", None)
+    return None if r is None else r[0]
+
+
+def _consume_splat_rows_hint(means2d: Tensor, D: int) -> Optional[Tensor]:
+    r = getattr(_hint, "rows", None)
+    _hint.rows = None
+    if r is None or D != 3 or r[1] != means2d.data_ptr() or r[0].shape[0] * 2 != means2d.numel():
+        return None
+    return r[0]
+
+
 def _consume_long_tile_hint() -> int:
     """Called by an op BODY: returns the hint and clears it for nested calls, but leaves long_tile_hint_of_call() alone - the
     autograd setup_context runs after the body and stores it for the backward."""
@@ -161,6 +186,10 @@ def _read_compiled_ops(path: str) -> None:
     global _COMPILED_ISECT, _set_hint_compiled
     try:
         _set_hint_compiled = ctypes.CDLL(path).gsx_torch_set_long_tile_hint
+        global _set_rows_compiled
+        _set_rows_compiled = ctypes.CDLL(path).gsx_torch_set_splat_rows
+        _set_rows_compiled.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+        _set_rows_compiled.restype = None
         _set_hint_compiled.argtypes, _set_hint_compiled.restype = [ctypes.c_int64], None
     except (OSError, AttributeError):
         _set_hint_compiled = None
@@ -479,10 +508,12 @@ def _sh_rs_split(v_syn, viewmats, viewmats_rs, want, want_rs):
 
 @_op("spherical_harmonics")
 def spherical_harmonics(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids,
-                        viewmats_rs=None, *, _gathered: bool = True, _radii=None, _post: bool = False):
+                        viewmats_rs=None, *, _gathered: bool = True, _radii=None, _post: bool = False, _splat=None):
     """Private keywords (used by rendering.py, not part of the reference schema): `_gathered=False` reads [N,K,D]
     coefficients through gaussian_ids; `_radii` masks rows by radii > 0 instead of a bool tensor; `_post` fuses the
-    orchestrator's `clamp_min(colors + 0.5, 0)`."""
+    orchestrator's `clamp_min(colors + 0.5, 0)`; `_splat=(means2d, conics, opacities, rows)` (D == 3, float32 coefficients): the
+    kernel also writes the compositing kernels' 48-byte array-of-structures row of every live row into `rows` [n_rows, 12]
+    (gsx_sh_fwd_rows)."""
     if viewmats_rs is not None:
         viewmats = _sh_rs_viewmats(viewmats, viewmats_rs)
     _check_sh_inputs(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, gathered=_gathered)
@@ -500,18 +531,26 @@ def spherical_harmonics(degrees_to_use, means, viewmats, coeffs, masks, batch_id
     means, viewmats, coeffs, masks = means.contiguous(), viewmats.contiguous(), coeffs.contiguous(), _c(masks)
     if coeffs.dim() != 3:
         raise ValueError(f"coeffs must have shape [N, K, D] or [nnz, K, D], got {tuple(coeffs.shape)}")
+    fn, tail = "gsx_sh_fwd", ()
+    if _splat is not None and D == 3:
+        m2, con, op, rows_out = _splat
+        n_rows = gaussian_ids.shape[0] if packed else B * C * N
+        if rows_out.shape != (n_rows, 12) or not rows_out.is_contiguous() or m2.numel() != 2 * n_rows or con.numel() != 3 * n_rows \
+                or op.numel() != n_rows:
+            raise ValueError("spherical_harmonics(_splat=...): means2d / conics / opacities / rows do not cover the SH rows")
+        fn, tail = "gsx_sh_fwd_rows", (ptr(m2.contiguous()), ptr(con.contiguous()), ptr(op.contiguous()), ptr(rows_out))
     if packed:
         nnz = gaussian_ids.shape[0]
         colors = torch.empty((nnz, D), device=means.device, dtype=means.dtype)
-        call("gsx_sh_fwd", degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), ptr(_c(batch_ids)),
+        call(fn, degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), ptr(_c(batch_ids)),
              ptr(_c(camera_ids)), ptr(_c(gaussian_ids)), B, C, N, nnz, int(_gathered), K, D, ptr(_c(_radii)),
-             int(_post), ptr(colors))
+             int(_post), ptr(colors), *tail)
     else:
         if coeffs.shape[0] != N:
             raise ValueError("means N must match coeffs N in dense mode")
         colors = torch.empty(viewmats.shape[:-2] + (N, D), device=means.device, dtype=means.dtype)
-        call("gsx_sh_fwd", degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), None, None, None,
-             B, C, N, -1, 1, K, D, ptr(_c(_radii)), int(_post), ptr(colors))
+        call(fn, degrees_to_use, ptr(means), ptr(viewmats), ptr(coeffs), ptr(masks), None, None, None,
+             B, C, N, -1, 1, K, D, ptr(_c(_radii)), int(_post), ptr(colors), *tail)
     return colors
 
 
@@ -1049,12 +1088,17 @@ def rasterize_to_pixels_3dgs(means2d, conics, colors, opacities, backgrounds, ma
     alphas = torch.empty(image_dims + (image_height, image_width, 1), device=dev, dtype=dt)
     last_ids = torch.empty(image_dims + (image_height, image_width), device=dev, dtype=torch.int32)
     longest = _consume_long_tile_hint() or _lookup_longest(flatten_ids)
+    rows = _consume_splat_rows_hint(means2d, D)  # rasterization()'s array-of-structures rows of these Gaussians, or None
     if longest > SEG_MIN_LONGEST and longest > _seg_cut(flatten_ids.numel(), I, tw, th):
         ws = torch.empty(_cabi._lib.gsx_raster3d_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN), device=dev,
                          dtype=torch.uint8)
         call("gsx_raster3d_fwd_seg", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
              ptr(isect_offsets), ptr(flatten_ids), I, flatten_ids.numel(), D, image_width, image_height, tile_size, tw,
              th, ptr(renders), ptr(alphas), ptr(last_ids), SEG_LEN, ptr(ws), ws.numel())
+    elif rows is not None:
+        call("gsx_raster3d_fwd_rows", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(rows), ptr(backgrounds),
+             ptr(masks), ptr(isect_offsets), ptr(flatten_ids), I, flatten_ids.numel(), D, image_width, image_height, tile_size,
+             tw, th, ptr(renders), ptr(alphas), ptr(last_ids))
     else:
         call("gsx_raster3d_fwd", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
              ptr(isect_offsets), ptr(flatten_ids), I, flatten_ids.numel(), D, image_width, image_height, tile_size, tw,
@@ -1096,6 +1140,7 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     R = opacities.numel()
     geo = 8 if absgrad else 6
     longest = _consume_long_tile_hint() or _lookup_longest(flatten_ids)  # set by the autograd formula around this call
+    splat_rows = _consume_splat_rows_hint(means2d, D)
     segmented = (longest > SEG_MIN_LONGEST and not absgrad and D <= 4 and tile_size == 16
                  and longest > _seg_cut(flatten_ids.numel(), I, tw, th))
     # the per-tile launch zero-fills the rows itself (inside its tile-order kernel: gsx_raster3d_bwd_fill)
@@ -1117,7 +1162,8 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     else:
         # workspace for the longest-first tile order of the launch (csrc/raster3d_bwd.hip: "longest tiles first")
         ws = torch.empty(_cabi._lib.gsx_raster3d_bwd_workspace_bytes(I, tw, th), device=means2d.device, dtype=torch.uint8)
-        call("gsx_raster3d_bwd_fill", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+        head = (ptr(means2d), ptr(conics), ptr(colors), ptr(opacities)) + ((ptr(splat_rows),) if splat_rows is not None else ())
+        call("gsx_raster3d_bwd_fill_rows" if splat_rows is not None else "gsx_raster3d_bwd_fill", *head, ptr(backgrounds), ptr(masks),
              ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
              ptr(last_ids.contiguous()), ptr_strided(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
              image_width, image_height, tile_size, tw, th, int(bool(absgrad)), ptr(rows), geo + D, 0 if own_fill else R, vrc_strides[0],

@@ -356,24 +356,32 @@ def rasterize_to_pixels(
     packed: bool = False,
     absgrad: bool = False,
     _longest_tile_list: int = 0,
+    _splat_rows: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor]:
     """Front-to-back alpha compositing of the depth-sorted per-tile lists. Returns
     (render_colors [..., H, W, channels], render_alphas [..., H, W, 1]). With ``absgrad`` the
     backward pass also fills ``means2d.absgrad``. ``_longest_tile_list`` (private; rendering.py passes what the
     intersection reported): above ``_ops.SEG_MIN_LONGEST`` long lists are cut into segments composited in parallel.
     0 = unknown: the ops look up what the intersection that produced ``flatten_ids`` noted (stage-level callers get the
-    segments too); negative = one workgroup per tile whatever the lists look like."""
+    segments too); negative = one workgroup per tile whatever the lists look like. ``_splat_rows`` (private; three channels):
+    the [R, 12] array-of-structures rows rasterization()'s SH forward wrote for these very tensors (``_ops.spherical_harmonics``
+    ``_splat``) - the kernels then stage a list entry from one row instead of four arrays; results are bit-identical."""
     if backgrounds is not None:
         backgrounds = backgrounds.contiguous()
     if masks is not None:
         masks = masks.contiguous()
+    means2d_c = means2d.contiguous()
     _impl.set_long_tile_hint(_longest_tile_list)
+    if _splat_rows is not None:
+        _impl.set_splat_rows_hint(_splat_rows, means2d_c)
     try:
         render_colors, render_alphas, means2d_absgrad, _last_ids = _ops.rasterize_to_pixels_3dgs(
-            means2d.contiguous(), conics.contiguous(), colors.contiguous(), opacities.contiguous(), backgrounds, masks,
+            means2d_c, conics.contiguous(), colors.contiguous(), opacities.contiguous(), backgrounds, masks,
             image_width, image_height, tile_size, isect_offsets.contiguous(), flatten_ids.contiguous(), packed, absgrad)
     finally:
-        _impl.set_long_tile_hint(0)  # also when the op raises: the hint belongs to THIS call only
+        _impl.set_long_tile_hint(0)  # also when the op raises: the hints belong to THIS call only
+        if _splat_rows is not None:
+            _impl.set_splat_rows_hint(None, None)
     if absgrad:
         means2d.absgrad = means2d_absgrad
     return render_colors, render_alphas

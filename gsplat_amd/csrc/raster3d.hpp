@@ -40,6 +40,12 @@ struct Raster3DArgs {
     const uint8_t *masks;     // [I, tile_h, tile_w] or null (torch bool)
     const int32_t *isect_offsets; // [I, tile_h, tile_w]
     const int32_t *flatten_ids;   // [M]
+    // optional (cdim == 3 only): ONE 48-byte array-of-structures row per Gaussian row,
+    //   (x, y, conic a, conic b | conic c, opacity, colour 0, colour 1 | colour 2, -, -, -),
+    // the same values as means2d / conics / opacities / colors. A staging thread then needs three 16-byte loads from ONE row
+    // instead of four gathers from four arrays (c3 forward 0.203 -> 0.181 ms in the kernel harness, profiles/r10_ab.md): the
+    // SH forward of rasterization() writes the rows while it has the row's colours in registers (gsx_sh_fwd_rows)
+    const float *splat_rows;
     // forward outputs
     float *render_colors; // [I, H, W, cdim]
     float *render_alphas; // [I, H, W, 1]

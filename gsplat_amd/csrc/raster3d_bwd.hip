@@ -941,6 +941,13 @@ __device__ __forceinline__ void raster3d_bwd_w_body(const Raster3DArgs &a)
     };
     auto fetch = [&](int32_t g, Fetched &f) {
         if (g < 0) return;
+        if (a.splat_rows) { // one 48-byte array-of-structures row (raster3d.hpp; cdim == 3): three 16-byte loads, one address
+            const v4f *rw = reinterpret_cast<const v4f *>(a.splat_rows) + 3 * (size_t)g;
+            const v4f r0 = rw[0], r1 = rw[1], r2 = rw[2];
+            f.xy = make_float2(r0.x, r0.y); f.ca = r0.z; f.cb = r0.w; f.cc = r1.x; f.opac = r1.y;
+            f.cv[0] = r1.z; f.cv[1] = CH > 1 ? r1.w : 0.0f; f.cv[2] = CH > 2 ? r2.x : 0.0f; f.cv[3] = 0.0f;
+            return;
+        }
         f.xy   = reinterpret_cast<const float2 *>(a.means2d)[g];
         f.opac = a.opacities[g];
         f.ca = a.conics[3 * (size_t)g]; f.cb = a.conics[3 * (size_t)g + 1]; f.cc = a.conics[3 * (size_t)g + 2];
@@ -1275,8 +1282,45 @@ extern "C" int gsx_raster3d_bwd_ws(
 // gsx_raster3d_bwd_ws for gradient rows that are NOT zero-filled yet: the call fills v_rows_to_fill rows of row_stride floats
 // itself - inside the tile-order cost kernel when one is launched (a kernel short of memory work: 36 MB of zeros cost it ~2 us
 // where a fill kernel of its own takes 7.5), with a memset otherwise. v_rows_to_fill == 0: the caller filled them.
+static int raster3d_bwd_fill_impl(
+    const float *means2d, const float *conics, const float *colors, const float *opacities, const float *splat_rows,
+    const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+    const float *render_alphas, const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+    uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+    uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows, uint32_t row_stride, int64_t v_rows_to_fill,
+    int64_t v_colors_pixel_stride, int64_t v_colors_channel_stride, void *workspace, int64_t workspace_bytes, void *stream);
 extern "C" int gsx_raster3d_bwd_fill(
     const float *means2d, const float *conics, const float *colors, const float *opacities,
+    const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+    const float *render_alphas, const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+    uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+    uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows, uint32_t row_stride, int64_t v_rows_to_fill,
+    int64_t v_colors_pixel_stride, int64_t v_colors_channel_stride, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return raster3d_bwd_fill_impl(means2d, conics, colors, opacities, nullptr, backgrounds, masks, isect_offsets, flatten_ids,
+                                  render_alphas, last_ids, v_render_colors, v_render_alphas, n_images, n_isects, cdim, width, height,
+                                  tile_size, tile_w, tile_h, has_abs, v_rows, row_stride, v_rows_to_fill, v_colors_pixel_stride,
+                                  v_colors_channel_stride, workspace, workspace_bytes, stream);
+}
+// gsx_raster3d_bwd_fill with the Gaussians' 48-byte array-of-structures rows beside the four arrays (cdim == 3, no absgrad;
+// raster3d.hpp: Raster3DArgs::splat_rows). Only the one-wave-per-tile kernel reads them; every other kernel ignores the pointer.
+extern "C" int gsx_raster3d_bwd_fill_rows(
+    const float *means2d, const float *conics, const float *colors, const float *opacities, const float *splat_rows,
+    const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+    const float *render_alphas, const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+    uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+    uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows, uint32_t row_stride, int64_t v_rows_to_fill,
+    int64_t v_colors_pixel_stride, int64_t v_colors_channel_stride, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    GSX_REQUIRE(!splat_rows || cdim == 3, "gsx_raster3d_bwd_fill_rows: the rows hold three colours; cdim is %u", cdim);
+    GSX_REQUIRE(!splat_rows || (reinterpret_cast<uintptr_t>(splat_rows) & 15u) == 0, "gsx_raster3d_bwd_fill_rows: rows must be 16-byte aligned");
+    return raster3d_bwd_fill_impl(means2d, conics, colors, opacities, splat_rows, backgrounds, masks, isect_offsets, flatten_ids,
+                                  render_alphas, last_ids, v_render_colors, v_render_alphas, n_images, n_isects, cdim, width, height,
+                                  tile_size, tile_w, tile_h, has_abs, v_rows, row_stride, v_rows_to_fill, v_colors_pixel_stride,
+                                  v_colors_channel_stride, workspace, workspace_bytes, stream);
+}
+static int raster3d_bwd_fill_impl(
+    const float *means2d, const float *conics, const float *colors, const float *opacities, const float *splat_rows,
     const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
     const float *render_alphas, const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
     uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
@@ -1305,7 +1349,7 @@ extern "C" int gsx_raster3d_bwd_fill(
     Raster3DArgs a{};
     a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height;
     a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h; a.cdim = cdim;
-    a.means2d = means2d; a.conics = conics; a.colors = colors; a.opacities = opacities;
+    a.means2d = means2d; a.conics = conics; a.colors = colors; a.opacities = opacities; a.splat_rows = splat_rows;
     a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = isect_offsets; a.flatten_ids = flatten_ids;
     a.render_alphas = const_cast<float *>(render_alphas); a.last_ids = const_cast<int32_t *>(last_ids);
     a.v_render_colors = v_render_colors; a.v_render_alphas = v_render_alphas;

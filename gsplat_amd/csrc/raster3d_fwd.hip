@@ -11,6 +11,7 @@ namespace gsx {
 #define GSX_FWD_AT 1
 #endif
 constexpr int kBatch = 256;
+
 // Staged layout: one 48-byte row per Gaussian (raster3d.hpp StagedRow: the tile-centre polynomial of the exponent + up to
 // four colours) read with b128 + b128 + b64 from one address register; colours 4.. in a separate table.
 // r05 A/B on c3 (profiles/r05_ab.md): float4 + float2 + 3 floats 0.304 ms -> packed float4s 0.280 -> e-form see there.
@@ -112,19 +113,37 @@ __global__ void __launch_bounds__(256) raster3d_fwd_kernel(const Raster3DArgs a)
             const int32_t idx = batch_start + s;
             if (idx < range_end) {
                 const int32_t g  = a.flatten_ids[idx];
-                const float2 xy  = reinterpret_cast<const float2 *>(a.means2d)[g];
-                const float opac = a.opacities[g];
-                const float ca = a.conics[3 * (size_t)g], cb = a.conics[3 * (size_t)g + 1], cc = a.conics[3 * (size_t)g + 2];
+                float2 xy;
+                float opac, ca, cb, cc;
+                v4f row2 = v4f{0.f, 0.f, 0.f, 0.f}, row1 = row2;
+                if (a.splat_rows) { // one 48-byte row (raster3d.hpp): three 16-byte loads from one address
+                    const v4f *rw = reinterpret_cast<const v4f *>(a.splat_rows) + 3 * (size_t)g;
+                    const v4f row0 = rw[0];
+                    row1 = rw[1]; row2 = rw[2];
+                    xy = make_float2(row0.x, row0.y); ca = row0.z; cb = row0.w; cc = row1.x; opac = row1.y;
+                } else {
+                    xy   = reinterpret_cast<const float2 *>(a.means2d)[g];
+                    opac = a.opacities[g];
+                    ca = a.conics[3 * (size_t)g]; cb = a.conics[3 * (size_t)g + 1]; cc = a.conics[3 * (size_t)g + 2];
+                }
                 const float ax = xy.x - cx, ay = xy.y - cy;
                 v4f p0;
                 float nA, nB, nC;
                 stage_gaussian_f(ax, ay, opac, ca, cb, cc, p0, nA, nB, nC);
                 const float2 he = cull_half_extent(opac, ca, cb, cc);
                 s_cull[s]       = make_float4(ax, ay, he.x, he.y);
-                const float *c  = a.colors + (size_t)g * a.cdim + a.ch_off;
                 float cv[CH > 4 ? CH : 4];
+                if (a.splat_rows) { // cdim == 3 (checked by the entry point): the colours sit in the row
 #pragma unroll
-                for (int k = 0; k < (CH > 4 ? CH : 4); ++k) cv[k] = (k < CH && k < (int)a.nch) ? c[k] : 0.0f;
+                    for (int k = 0; k < (CH > 4 ? CH : 4); ++k) cv[k] = 0.0f;
+                    cv[0] = row1.z;
+                    if (CH > 1) cv[1] = row1.w;
+                    if (CH > 2) cv[2] = row2.x;
+                } else {
+                    const float *c = a.colors + (size_t)g * a.cdim + a.ch_off;
+#pragma unroll
+                    for (int k = 0; k < (CH > 4 ? CH : 4); ++k) cv[k] = (k < CH && k < (int)a.nch) ? c[k] : 0.0f;
+                }
                 s_st[s].p0 = p0;
                 s_st[s].p1 = v4f{nA, nB, nC, cv[2]};
                 s_st[s].p2 = v4f{cv[0], cv[1], cv[3], 0.0f};
@@ -310,6 +329,29 @@ extern "C" int gsx_raster3d_fwd(
     a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height;
     a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h; a.cdim = cdim;
     a.means2d = means2d; a.conics = conics; a.colors = colors; a.opacities = opacities;
+    a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = isect_offsets; a.flatten_ids = flatten_ids;
+    a.render_colors = render_colors; a.render_alphas = render_alphas; a.last_ids = last_ids;
+    return raster3d_fwd_dispatch(a, (hipStream_t)stream);
+}
+
+// gsx_raster3d_fwd with the Gaussians' 48-byte array-of-structures rows beside the four arrays (cdim == 3; raster3d.hpp)
+extern "C" int gsx_raster3d_fwd_rows(
+    const float *means2d, const float *conics, const float *colors, const float *opacities, const float *splat_rows,
+    const float *backgrounds, const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids,
+    uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size,
+    uint32_t tile_w, uint32_t tile_h, float *render_colors, float *render_alphas, int32_t *last_ids, void *stream)
+{
+    using namespace gsx;
+    GSX_REQUIRE(tile_size >= 1 && tile_size <= 16, "gsx_raster3d_fwd_rows: tile_size must be in [1,16], got %u", tile_size);
+    GSX_REQUIRE(!splat_rows || cdim == 3, "gsx_raster3d_fwd_rows: the rows hold three colours; cdim is %u", cdim);
+    GSX_REQUIRE(!splat_rows || (reinterpret_cast<uintptr_t>(splat_rows) & 15u) == 0, "gsx_raster3d_fwd_rows: rows must be 16-byte aligned");
+    GSX_REQUIRE(render_colors && render_alphas && last_ids, "gsx_raster3d_fwd_rows: null output");
+    GSX_REQUIRE(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids), "gsx_raster3d_fwd_rows: null input");
+    GSX_REQUIRE(isect_offsets != nullptr || n_images * tile_w * tile_h == 0, "gsx_raster3d_fwd_rows: null isect_offsets");
+    Raster3DArgs a{};
+    a.n_images = n_images; a.n_isects = n_isects; a.width = width; a.height = height;
+    a.tile_size = tile_size; a.tile_w = tile_w; a.tile_h = tile_h; a.cdim = cdim;
+    a.means2d = means2d; a.conics = conics; a.colors = colors; a.opacities = opacities; a.splat_rows = splat_rows;
     a.backgrounds = backgrounds; a.masks = masks; a.isect_offsets = isect_offsets; a.flatten_ids = flatten_ids;
     a.render_colors = render_colors; a.render_alphas = render_alphas; a.last_ids = last_ids;
     return raster3d_fwd_dispatch(a, (hipStream_t)stream);

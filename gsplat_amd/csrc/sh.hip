@@ -28,7 +28,22 @@ struct ShArgs {
     const int32_t *row_map; // optional, packed rows only: [B*C*N] -> packed row or -1 (Gaussian-major backward)
     float *v_dirs; // optional [rows,3], zero-initialised: per-row d(loss)/d(view direction) (-> v_viewmats on the host)
     int atomic_coeffs; // packed + !gathered + more than one image: rows of one Gaussian collide
+    // optional, D == 3: the compositing kernels' 48-byte array-of-structures row of every LIVE row (csrc/raster3d.hpp:
+    // Raster3DArgs::splat_rows) = (x, y, conic a, b | conic c, opacity, colour 0, 1 | colour 2, 0, 0, 0), written while the row's
+    // colours are in registers; r_* are the projection's outputs for the same rows
+    const float *r_means2d, *r_conics, *r_opacities; // [rows,2] [rows,3] [rows]
+    float *splat_rows;                               // [rows,12]
 };
+__device__ __forceinline__ void write_splat_row(const ShArgs &a, int64_t row, float c0, float c1, float c2)
+{
+    if (!a.splat_rows) return;
+    const float2 xy = reinterpret_cast<const float2 *>(a.r_means2d)[row];
+    const float *cn = a.r_conics + 3 * row;
+    v4f *dst = reinterpret_cast<v4f *>(a.splat_rows) + 3 * row;
+    dst[0] = v4f{xy.x, xy.y, cn[0], cn[1]};
+    dst[1] = v4f{cn[2], a.r_opacities[row], c0, c1};
+    dst[2] = v4f{c2, 0.0f, 0.0f, 0.0f};
+}
 
 __device__ __forceinline__ bool row_dead(const ShArgs &a, int64_t row)
 {
@@ -365,7 +380,9 @@ __global__ void __launch_bounds__(256) sh3_fwd_kernel(const ShArgs a)
         r1 += Y[k] * co[3 * k + 1];
         r2 += Y[k] * co[3 * k + 2];
     }
-    out[0] = post_color(a, r0); out[1] = post_color(a, r1); out[2] = post_color(a, r2);
+    r0 = post_color(a, r0); r1 = post_color(a, r1); r2 = post_color(a, r2);
+    out[0] = r0; out[1] = r1; out[2] = r2;
+    write_splat_row(a, row, r0, r1, r2);
 }
 
 // Dense rows of SEVERAL images: one thread per Gaussian walks the images, so that the [K][3] coefficient row (192 of the
@@ -415,7 +432,9 @@ __global__ void __launch_bounds__(256) sh3_fwd_gaussian_major_kernel(const ShArg
                 r1 += Y[k] * co[3 * k + 1];
                 r2 += Y[k] * co[3 * k + 2];
             }
-            out[0] = post_color(a, r0); out[1] = post_color(a, r1); out[2] = post_color(a, r2);
+            r0 = post_color(a, r0); r1 = post_color(a, r1); r2 = post_color(a, r2);
+            out[0] = r0; out[1] = r1; out[2] = r2;
+            write_splat_row(a, row, r0, r1, r2);
         }
 }
 
@@ -812,11 +831,39 @@ static int check_sh(const char *fn, int degree, uint32_t K, uint32_t D, const fl
 
 using namespace gsx;
 
+static int sh_fwd_impl(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
+                       const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
+                       const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
+                       int coeffs_gathered, uint32_t K, uint32_t D, const int32_t *radii, int post, float *colors,
+                       const float *r_means2d, const float *r_conics, const float *r_opacities, float *splat_rows, void *stream);
 extern "C" int gsx_sh_fwd(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
                           const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
                           const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
                           int coeffs_gathered, uint32_t K, uint32_t D, const int32_t *radii, int post, float *colors,
                           void *stream)
+{
+    return sh_fwd_impl(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, B, C, N, nnz,
+                       coeffs_gathered, K, D, radii, post, colors, nullptr, nullptr, nullptr, nullptr, stream);
+}
+// gsx_sh_fwd (D == 3) that also writes the compositing kernels' 48-byte array-of-structures row of every live row
+// (include/gsplat_amd.h): means2d [rows,2], conics [rows,3], opacities [rows] are the projection's outputs for the same rows.
+extern "C" int gsx_sh_fwd_rows(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
+                               const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
+                               const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
+                               int coeffs_gathered, uint32_t K, uint32_t D, const int32_t *radii, int post, float *colors,
+                               const float *means2d, const float *conics, const float *opacities, float *splat_rows, void *stream)
+{
+    GSX_REQUIRE(D == 3, "gsx_sh_fwd_rows: the rows hold three colours; D is %u", D);
+    GSX_REQUIRE(means2d && conics && opacities && splat_rows, "gsx_sh_fwd_rows: null row input / output");
+    GSX_REQUIRE((reinterpret_cast<uintptr_t>(splat_rows) & 15u) == 0, "gsx_sh_fwd_rows: rows must be 16-byte aligned");
+    return sh_fwd_impl(degrees_to_use, means, viewmats, coeffs, masks, batch_ids, camera_ids, gaussian_ids, B, C, N, nnz,
+                       coeffs_gathered, K, D, radii, post, colors, means2d, conics, opacities, splat_rows, stream);
+}
+static int sh_fwd_impl(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
+                       const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
+                       const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
+                       int coeffs_gathered, uint32_t K, uint32_t D, const int32_t *radii, int post, float *colors,
+                       const float *r_means2d, const float *r_conics, const float *r_opacities, float *splat_rows, void *stream)
 {
     const int64_t rows = nnz >= 0 ? nnz : (int64_t)B * C * N;
     if (rows == 0) return GSX_OK;
@@ -828,6 +875,7 @@ extern "C" int gsx_sh_fwd(int degrees_to_use, const float *means, const float *v
     a.batch_ids = batch_ids; a.camera_ids = camera_ids; a.gaussian_ids = gaussian_ids;
     a.B = B; a.C = C; a.N = N; a.K = K; a.D = D; a.nnz = nnz; a.coeffs_gathered = coeffs_gathered; a.colors = colors;
     a.radii = radii; a.post = post;
+    a.r_means2d = r_means2d; a.r_conics = r_conics; a.r_opacities = r_opacities; a.splat_rows = splat_rows;
     hipStream_t s = (hipStream_t)stream;
     if (D == 3 && nnz < 0 && (uint64_t)B * C > 1 && degrees_to_use < 4 && ((K * 3u) & 3u) == 0u) {
         // several images over the same Gaussians: Gaussian-major walk, one coefficient fetch per Gaussian

@@ -732,6 +732,17 @@ RasterDims raster_dims(const Tensor &isect_offsets, const Tensor &colors)
 // from the intersection's host word; the reference's op schema has no room for it). Above gsx_raster3d_seg_cut() the forward cuts
 // long lists into segments (csrc/raster3d_seg.hip). 0 = unknown: one workgroup per tile. Consumed (reset) by the call.
 thread_local int64_t g_long_tile_hint = 0;
+// The compositing kernels' 48-byte array-of-structures rows of the NEXT compositing call (csrc/raster3d.hpp: splat_rows), announced
+// by the wrapper like the hint above; `key` = the data pointer of the means2d they were written for: a body only uses rows
+// announced for ITS means2d. Consumed (reset) by the call.
+thread_local const float *g_splat_rows = nullptr;
+thread_local const float *g_splat_rows_key = nullptr;
+static const float *consume_splat_rows(const Tensor &means2d, int64_t D)
+{
+    const float *rows = g_splat_rows, *key = g_splat_rows_key;
+    g_splat_rows = g_splat_rows_key = nullptr;
+    return (rows && D == 3 && key == means2d.const_data_ptr<float>()) ? rows : nullptr;
+}
 // segment length / the longest list from which segmenting starts; GSPLAT_AMD_SEG_LEN overrides (A/B), 0 switches it off
 static int64_t seg_len_env()
 {
@@ -770,6 +781,7 @@ rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Te
     int64_t longest = g_long_tile_hint;
     g_long_tile_hint = 0;
     if (longest == 0) longest = lookup_longest(flatten_ids_); // stage-level caller: no orchestrator hint
+    const float *splat_rows = consume_splat_rows(means2d, r.D);
     if (kSegLen > 0 && longest > gsx_raster3d_seg_cut(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)kSegLen)) {
         Tensor ws = at::empty({gsx_raster3d_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
                                                               (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
@@ -780,7 +792,14 @@ rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Te
                                    (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th, mp<float>(renders),
                                    mp<float>(alphas), mp<int32_t>(last_ids), (uint32_t)kSegLen, ws.mutable_data_ptr(), ws.numel(), L.stream),
               "gsx_raster3d_fwd_seg");
-    } else
+    } else if (splat_rows)
+    { Timed timed_("gsx_raster3d_fwd", L.stream); check(gsx_raster3d_fwd_rows(fp(means2d), fp(conics), fp(colors), fp(opac), splat_rows, fp(bg),
+                           masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
+                           cp<int32_t>(flat), (uint32_t)r.I, (uint32_t)flat.numel(), (uint32_t)r.D, (uint32_t)width,
+                           (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th, mp<float>(renders),
+                           mp<float>(alphas), mp<int32_t>(last_ids), L.stream),
+          "gsx_raster3d_fwd_rows"); }
+    else
     { Timed timed_("gsx_raster3d_fwd", L.stream); check(gsx_raster3d_fwd(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
                            masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
                            cp<int32_t>(flat), (uint32_t)r.I, (uint32_t)flat.numel(), (uint32_t)r.D, (uint32_t)width,
@@ -810,6 +829,7 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
     int64_t longest = g_long_tile_hint; // set by the autograd formula around this call (gsplat_amd/_autograd.py)
     g_long_tile_hint = 0;
     if (longest == 0) longest = lookup_longest(flatten_ids_); // e.g. the reference's own autograd formula
+    const float *splat_rows = consume_splat_rows(means2d, r.D);
     const bool segmented = kSegLen > 0 && !absgrad && r.D <= 4 && tile_size == 16
         && longest > gsx_raster3d_seg_cut(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)kSegLen);
     // the per-tile launch zero-fills the rows itself (inside its tile-order kernel: gsx_raster3d_bwd_fill)
@@ -829,12 +849,12 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
         // workspace for the longest-first tile order of the launch (csrc/raster3d_bwd.hip: "longest tiles first")
         Tensor ws = at::empty({gsx_raster3d_bwd_workspace_bytes((uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th)}, means2d.options().dtype(at::kByte));
         Timed timed_("gsx_raster3d_bwd", L.stream);
-        check(gsx_raster3d_bwd_fill(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
+        check(gsx_raster3d_bwd_fill_rows(fp(means2d), fp(conics), fp(colors), fp(opac), splat_rows, fp(bg),
                                   masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
                                   cp<int32_t>(flat), fp(ra), cp<int32_t>(li), fp(v_rc), fp(v_ra), (uint32_t)r.I, (uint32_t)flat.numel(),
                                   (uint32_t)r.D, (uint32_t)width, (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th,
                                   absgrad ? 1 : 0, mp<float>(rows), (uint32_t)(geo + r.D), R, (int64_t)-1, (int64_t)1, ws.mutable_data_ptr(), ws.numel(),
-                                  L.stream),
+                                  L.stream), // splat_rows == NULL: the plain gsx_raster3d_bwd_fill
               "gsx_raster3d_bwd");
     }
     Tensor v_means2d = rows.slice(1, 0, 2).view(means2d.sizes()), v_conics = rows.slice(1, 2, 5).view(conics.sizes());
@@ -1018,12 +1038,17 @@ rasterize_to_pixels_2dgs(const Tensor &means2d_, const Tensor &ray_transforms_, 
 
 } // namespace
 void set_long_tile_hint(int64_t longest) { g_long_tile_hint = longest; }
+void set_splat_rows(const float *rows, const float *key) { g_splat_rows = rows; g_splat_rows_key = key; }
 void note_longest_op(const Tensor &flatten_ids, int64_t longest) { note_longest(flatten_ids, longest); }
 int64_t lookup_longest_op(const Tensor &flatten_ids) { return lookup_longest(flatten_ids); }
 } // namespace gsplat_amd
 
 // gsplat_amd/_ops.py (ctypes): the longest tile list of the intersection that the next compositing call of THIS thread consumes
 extern "C" void gsx_torch_set_long_tile_hint(int64_t longest) { gsplat_amd::set_long_tile_hint(longest); }
+extern "C" void gsx_torch_set_splat_rows(uint64_t rows, uint64_t means2d_key)
+{
+    gsplat_amd::set_splat_rows(reinterpret_cast<const float *>(rows), reinterpret_cast<const float *>(means2d_key));
+}
 
 TORCH_LIBRARY(gsplat_amd, m)
 {

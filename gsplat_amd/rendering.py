@@ -35,6 +35,7 @@ from ._wrapper import (
 
 from ._ops import isect_max_tile_len as _isect_max_tile_len
 
+_SPLAT_ROWS = os.environ.get("GSPLAT_AMD_SPLAT_ROWS", "1") not in ("0", "")  # A/B switch: array-of-structures rows for compositing
 _COLOR_MODES = ("RGB", "RGB+D", "RGB+ED")
 _DEPTH_MODES = ("D", "ED", "RGB+D", "RGB+ED")
 _HIT_MODES = ("d", "Ed", "RGB-d", "RGB-Ed")
@@ -265,9 +266,21 @@ def rasterization(
 
     # ---- feature channels: [..., C, N, D] or [nnz, D] ------------------------------------------
     feats = None
+    splat_rows = None
     if has_color:
+        splat = None
+        if (_SPLAT_ROWS and sh_degree is not None and not isinstance(colors, (tuple, list)) and colors.dim() == 3
+                and colors.shape[-1] == 3 and colors.dtype == torch.float32 and not has_depth and extra_signals is None
+                and dist_ctx is None and not with_ut and not with_eval3d and means.is_cuda and len(batch_dims) <= 1):
+            # RGB from SH coefficients, nothing else in the rows: the SH forward also writes the compositing kernels' 48-byte
+            # array-of-structures row of every visible Gaussian (x, y, conic, opacity, colours) - the compositing kernels then
+            # stage a list entry with three 16-byte loads from one row instead of four gathers from four arrays
+            # (c3 forward 0.203 -> 0.181 ms in the kernel harness, profiles/r10_ab.md)
+            n_rows = means2d.numel() // 2
+            splat_rows = torch.empty((n_rows, 12), device=device, dtype=means.dtype)
+            splat = (means2d.detach(), conics.detach(), proj_opacities.detach().contiguous(), splat_rows)
         feats = _project_features(colors, sh_degree, True, means, viewmats_sh, radii, batch_dims, B, C_proj, N,
-                                  batch_ids, camera_ids, gaussian_ids)
+                                  batch_ids, camera_ids, gaussian_ids, splat)
     n_primary = feats.shape[-1] if feats is not None else 0
     n_extra = 0
     if extra_signals is not None:
@@ -353,7 +366,8 @@ def rasterization(
         else:
             render_colors, render_alphas = rasterize_to_pixels(
                 means2d, conics, feats, proj_opacities, width, height, tile_size, isect_offsets, flatten_ids,
-                backgrounds=backgrounds, packed=packed, absgrad=absgrad, _longest_tile_list=longest_list)
+                backgrounds=backgrounds, packed=packed, absgrad=absgrad, _longest_tile_list=longest_list,
+                _splat_rows=splat_rows if feats.shape[-1] == 3 else None)
 
     # ---- post-process: split extra signals, normalise expected depth ------------------------------
     render_extra = None
@@ -505,7 +519,7 @@ def _validate_rasterization_inputs(means, covars, quats, scales, opacities, colo
 
 
 def _project_features(features, sh_degree, clamp, means, viewmats, radii, batch_dims, B, C, N, batch_ids, camera_ids,
-                      gaussian_ids):
+                      gaussian_ids, splat=None):
     """Per-view feature rows: [..., C, N, D] (dense) or [nnz, D] (packed).
     Reference: normalize_features_layout_3dgs / maybe_evaluate_feature_sh, Rendering.cpp:577-644."""
     nb = len(batch_dims)
@@ -547,7 +561,7 @@ def _project_features(features, sh_degree, clamp, means, viewmats, radii, batch_
         # primary colours: SH + the `clamp_min(colors + 0.5, 0)` post-op + the radii > 0 row mask in ONE kernel each
         # way (the reference runs them as separate torch ops: Rendering.cpp:1146-1160, rendering.py:714-718)
         return _ShColors.apply(sh_degree, means, viewmats, features, None if packed else radii, batch_ids, camera_ids,
-                               gaussian_ids)
+                               gaussian_ids, splat)
     if packed:
         # Every packed row is visible by construction (projection only emits radii > 0), so no mask; the
         # coefficient rows are read THROUGH gaussian_ids inside the kernel instead of materialising the
@@ -566,12 +580,14 @@ class _ShColors(torch.autograd.Function):
     Same values and gradients as the unfused chain (the clamp VJP passes the gradient where the output is > 0)."""
 
     @staticmethod
-    def forward(ctx, degree, means, viewmats, coeffs, radii, batch_ids, camera_ids, gaussian_ids):
+    def forward(ctx, degree, means, viewmats, coeffs, radii, batch_ids, camera_ids, gaussian_ids, splat=None):
         from ._ops import impl
 
         means, viewmats, coeffs = means.contiguous(), viewmats.contiguous(), coeffs.contiguous()
+        # splat = (means2d, conics, opacities, rows): the kernel also writes the compositing kernels' 48-byte row of every live
+        # row into `rows` (plain data for the kernels that follow; no gradient flows through it)
         colors = impl("spherical_harmonics")(degree, means, viewmats, coeffs, None, batch_ids, camera_ids, gaussian_ids,
-                                             None, _gathered=False, _radii=radii, _post=True)
+                                             None, _gathered=False, _radii=radii, _post=True, _splat=splat)
         ctx.degree = degree
         ctx.save_for_backward(means, viewmats, coeffs, radii, batch_ids, camera_ids, gaussian_ids, colors)
         return colors
@@ -585,7 +601,7 @@ class _ShColors(torch.autograd.Function):
             ctx.degree, means, viewmats, coeffs, None, batch_ids, camera_ids, gaussian_ids, None, v_colors,
             ctx.needs_input_grad[1], ctx.needs_input_grad[2], False, _gathered=False, _radii=radii,
             _post_colors=colors)
-        return None, v_means, v_viewmats, v_coeffs, None, None, None, None
+        return None, v_means, v_viewmats, v_coeffs, None, None, None, None, None
 
 
 class _ShBandUngathered(torch.autograd.Function):

@@ -223,6 +223,17 @@ int gsx_sh_fwd(int degrees_to_use, const float *means, const float *viewmats, co
                const int32_t *radii /* NULL, or [rows,2]: like masks, a row is live iff both radii > 0 */,
                int post /* 1: colors = max(sh + 0.5, 0), the rasterization() post-op (Rendering.cpp:1160) */,
                float *colors, void *stream);
+/* gsx_sh_fwd for D == 3 that ALSO writes, for every live row, the compositing kernels' array-of-structures row
+ *   splat_rows [rows][12 floats] = (x, y, conic a, conic b | conic c, opacity, colour 0, colour 1 | colour 2, 0, 0, 0)
+ * from the projection's outputs of the same rows (means2d [rows,2], conics [rows,3], opacities [rows]) and the colours it has
+ * just computed - so that gsx_raster3d_fwd_rows / gsx_raster3d_bwd_fill_rows stage a list entry with three 16-byte loads from
+ * ONE row instead of four gathers from four arrays. The reference has no counterpart: it is a layout of the intermediates of
+ * gsplat::rasterization_3dgs (Rendering.cpp:1146-1160 -> :1353-1435), invisible outside rasterization(). 16-byte aligned. */
+int gsx_sh_fwd_rows(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
+                    const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
+                    const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
+                    int coeffs_gathered, uint32_t K, uint32_t D, const int32_t *radii, int post, float *colors,
+                    const float *means2d, const float *conics, const float *opacities, float *splat_rows, void *stream);
 int gsx_sh_bwd(int degrees_to_use, const float *means, const float *viewmats, const float *coeffs,
                const uint8_t *masks, const int64_t *batch_ids, const int64_t *camera_ids,
                const int64_t *gaussian_ids, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
@@ -507,6 +518,13 @@ int gsx_raster3d_fwd(const float *means2d, const float *conics, const float *col
                      const int32_t *flatten_ids, uint32_t n_images, uint32_t n_isects, uint32_t cdim,
                      uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                      float *render_colors, float *render_alphas, int32_t *last_ids, void *stream);
+/* gsx_raster3d_fwd with the 48-byte array-of-structures rows of gsx_sh_fwd_rows beside the four arrays (cdim == 3; NULL = the
+ * plain call). Same op (gsplat::rasterize_to_pixels_3dgs), same results bit for bit: the rows hold the same values. */
+int gsx_raster3d_fwd_rows(const float *means2d, const float *conics, const float *colors, const float *opacities,
+                          const float *splat_rows, const float *backgrounds, const uint8_t *masks,
+                          const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images, uint32_t n_isects,
+                          uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                          float *render_colors, float *render_alphas, int32_t *last_ids, void *stream);
 /* The longest-list length above which a caller should take gsx_raster3d_{fwd,bwd}_seg: max(2 seg_len, 3 x the mean list,
  * n_isects / 1024 = a workgroup slot's share of the launch); inside them, lists longer than max(2 seg_len, 3 x the mean) are cut.
  * A caller that knows the longest list (the intersection reports it) takes the _seg entries only when it exceeds this. */
@@ -575,6 +593,15 @@ int gsx_raster3d_bwd_fill(const float *means2d, const float *conics, const float
                      uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                      int has_abs, float *v_rows, uint32_t row_stride, int64_t v_rows_to_fill, int64_t v_colors_pixel_stride,
                      int64_t v_colors_channel_stride, void *workspace, int64_t workspace_bytes, void *stream);
+/* gsx_raster3d_bwd_fill with the same rows (cdim == 3; read by the one-wave-per-tile kernel, ignored by the others). */
+int gsx_raster3d_bwd_fill_rows(const float *means2d, const float *conics, const float *colors, const float *opacities,
+                               const float *splat_rows, const float *backgrounds, const uint8_t *masks,
+                               const int32_t *isect_offsets, const int32_t *flatten_ids, const float *render_alphas,
+                               const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+                               uint32_t n_images, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height,
+                               uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int has_abs, float *v_rows,
+                               uint32_t row_stride, int64_t v_rows_to_fill, int64_t v_colors_pixel_stride,
+                               int64_t v_colors_channel_stride, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Sparse pixel sets: gsplat::rasterize_to_pixels_sparse{,_bwd} (ext.cpp:1090-1104; RasterizeToPixelsSparse{Fwd,Bwd}.cu,
  * RasterizeSparseAddressing.cuh). One workgroup per ACTIVE tile (active_tiles int32 [AT], ascending dense tile ids;
