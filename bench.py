@@ -92,6 +92,8 @@ def stage_of(entry: str) -> str:
     """C-ABI entries that are one stage of the step table: the per-tile compositing backward is gsx_raster3d_bwd / _ws (with a
     tile-order workspace) / _fill (zero-fills its rows itself) / _seg (long lists in slices); the dense projection backward is
     gsx_project_ewa_bwd / _opac (also reduces the per-view opacity cotangent)."""
+    if entry.endswith("_rows") and any(n in entry for n in ("raster3d_bwd", "raster3d_fwd", "sh_fwd")):
+        entry = entry[: -len("_rows")]  # the same launch with the array-of-structures rows beside the four arrays
     for tail in ("_ws", "_fill", "_seg", "_opac"):
         if entry.endswith(tail) and any(n in entry for n in ("raster3d_bwd", "raster3d_fwd", "raster2d_bwd", "project_ewa_bwd")):
             return entry[: -len(tail)]
@@ -349,7 +351,7 @@ def main():
     # ~50 us: r4d measured 1.05 ms per step with them, 0.996 ms without). The dominant kernels are timed live with HIP events
     # (on the launch stream) in the FIRST REPEAT of the same window, which is reported but kept out of value_median / value_best.
     raster_entries = ("gsx_raster3d_fwd", "gsx_raster3d_bwd", "gsx_raster3d_bwd_ws", "gsx_raster3d_bwd_fill", "gsx_raster3d_fwd_seg",
-                      "gsx_raster3d_bwd_seg")
+                      "gsx_raster3d_bwd_seg", "gsx_raster3d_fwd_rows", "gsx_raster3d_bwd_fill_rows")
     elapsed, meta, prof = timed(step, args.steps, 0, barrier, profile_only=raster_entries if args.lean else None)
 
     def max_over_ranks(x: float) -> float:

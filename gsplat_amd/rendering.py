@@ -35,7 +35,11 @@ from ._wrapper import (
 
 from ._ops import isect_max_tile_len as _isect_max_tile_len
 
-_SPLAT_ROWS = os.environ.get("GSPLAT_AMD_SPLAT_ROWS", "1") not in ("0", "")  # A/B switch: array-of-structures rows for compositing
+# Array-of-structures rows for the compositing kernels (see `splat` below): built, bit-identical, and NOT the default - in the
+# kernel harness the forward drops from 0.203 to 0.181 ms, but inside the step the four arrays are still in cache when the
+# compositing starts (forward 0.175 -> 0.171 ms, backward 0.347 -> 0.342) and writing the rows costs the SH forward 10 us
+# (0.044 -> 0.054): net zero at c3, a loss with several cameras (profiles/r10_ab.md). GSPLAT_AMD_SPLAT_ROWS=1 switches it on.
+_SPLAT_ROWS = os.environ.get("GSPLAT_AMD_SPLAT_ROWS", "0") not in ("0", "")
 _COLOR_MODES = ("RGB", "RGB+D", "RGB+ED")
 _DEPTH_MODES = ("D", "ED", "RGB+D", "RGB+ED")
 _HIT_MODES = ("d", "Ed", "RGB-d", "RGB-Ed")

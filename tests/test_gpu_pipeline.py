@@ -705,3 +705,30 @@ def test_results_do_not_depend_on_what_the_allocator_hands_out(G, which):
         for k, a, b in zip(NAMES, grads, base_g):
             assert torch.isfinite(a).all(), f"{which}: v_{k} is not finite after poisoning the allocator"
             assert_grad_close(a.cpu(), b.cpu(), rel=2e-4, max_bad_ratio=1e-5, name=f"{which} v_{k} after poisoning")
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_splat_rows_layout_renders_the_same_bits(G, packed):
+    """GSPLAT_AMD_SPLAT_ROWS (off by default): the SH forward also writes one 48-byte array-of-structures row per visible Gaussian
+    and the compositing kernels stage their list entries from it (gsx_sh_fwd_rows, gsx_raster3d_fwd_rows,
+    gsx_raster3d_bwd_fill_rows). The rows hold the same values as the four arrays: the render is bit-identical, the gradients
+    agree to the rounding of their atomic sums."""
+    from gsplat_amd import rendering
+
+    sc, W, H = make_scene(N=20000, C=2, width=320, height=208, seed=12, sh_degree=3)
+    outs = []
+    for rows in (False, True):
+        old, rendering._SPLAT_ROWS = rendering._SPLAT_ROWS, rows
+        try:
+            leaves = {k: sc[k].to(DEV).clone().requires_grad_(True) for k in NAMES}
+            rc, ra, meta = G.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
+                                           sc["viewmats"].to(DEV), sc["Ks"].to(DEV), W, H, sh_degree=3, packed=packed)
+            g = torch.Generator().manual_seed(5)
+            ((rc * torch.randn(rc.shape, generator=g).to(DEV)).sum() + (ra * torch.randn(ra.shape, generator=g).to(DEV)).sum()).backward()
+            outs.append((rc.detach(), ra.detach(), {k: leaves[k].grad for k in NAMES}))
+        finally:
+            rendering._SPLAT_ROWS = old
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in NAMES:
+        a, b = outs[0][2][k], outs[1][2][k]
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-9, k
