@@ -23,7 +23,7 @@ _LAZY = {
     "rasterize_num_contributing_gaussians_sparse": "_wrapper",
     "rasterize_contributing_gaussian_ids_sparse": "_wrapper",
     "rasterize_top_contributing_gaussian_ids_sparse": "_wrapper",
-    "fully_fused_projection_with_ut": "_wrapper", "rasterize_to_pixels_eval3d": "_wrapper", "world_to_cam": "_wrapper", "has_3dgs": "_wrapper", "has_2dgs": "_wrapper", "has_3dgut": "_wrapper",
+    "fully_fused_projection_with_ut": "_wrapper", "rasterize_to_pixels_eval3d": "_wrapper", "rasterize_to_pixels_eval3d_extra": "_wrapper", "world_to_cam": "_wrapper", "has_3dgs": "_wrapper", "has_2dgs": "_wrapper", "has_3dgut": "_wrapper",
     "has_adam": "_wrapper", "has_reloc": "_wrapper", "has_losses": "_wrapper", "has_camera_wrappers": "_wrapper",
     "rasterize_to_indices_in_range": "_wrapper", "rasterize_to_indices_in_range_2dgs": "_wrapper",
     "rasterization": "rendering", "rasterization_2dgs": "rendering", "distributed": "distributed",

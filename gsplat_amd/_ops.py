@@ -858,6 +858,25 @@ def _proj_dims(means, viewmats):
     return batch_dims, math.prod(batch_dims), viewmats.shape[-3], means.shape[-2]
 
 
+def _f64_instantiation(fn):
+    """The reference dispatches the projection ops over float AND double (AT_DISPATCH_FLOATING_TYPES, ProjectionEWA3DGSFused.cu:260,
+    686; ProjectionEWA3DGSPacked.cu:344, 733). In its double instantiation only the MEMORY type is double: the kernels load every
+    value into glm float vectors / matrices (include/Common.h:65-70), compute in float and widen the results on store. Same here:
+    double tensors are narrowed, the fp32 kernels run, floating outputs are widened (csrc/torch_ops.cpp does the same)."""
+    import functools
+
+    @functools.wraps(fn)
+    def body(means, *args, **kw):
+        if means.dtype != torch.float64:
+            return fn(means, *args, **kw)
+        down = lambda t: t.to(torch.float32) if isinstance(t, Tensor) and t.dtype == torch.float64 else t  # noqa: E731
+        up = lambda t: t.to(torch.float64) if isinstance(t, Tensor) and t.dtype == torch.float32 else t  # noqa: E731
+        out = fn(down(means), *[down(a) for a in args], **{k: down(v) for k, v in kw.items()})
+        return tuple(up(t) for t in out)
+
+    return body
+
+
 def _check_proj_inputs(means, covars, quats, scales, viewmats, Ks):
     _check_f32(means=means, covars=covars, quats=quats, scales=scales, viewmats=viewmats, Ks=Ks)
     if covars is None and (quats is None or scales is None):
@@ -865,6 +884,7 @@ def _check_proj_inputs(means, covars, quats, scales, viewmats, Ks):
 
 
 @_op("projection_ewa_3dgs_fused")
+@_f64_instantiation
 def projection_ewa_3dgs_fused(means, covars, quats, scales, opacities, viewmats, Ks, image_width, image_height,
                               eps2d, near_plane, far_plane, radius_clip, calc_compensations, camera_model):
     _check_proj_inputs(means, covars, quats, scales, viewmats, Ks)
@@ -886,6 +906,7 @@ def projection_ewa_3dgs_fused(means, covars, quats, scales, opacities, viewmats,
 
 
 @_op("projection_ewa_3dgs_fused_bwd")
+@_f64_instantiation
 def projection_ewa_3dgs_fused_bwd(means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
                                   camera_model, radii, conics, compensations, v_means2d, v_depths, v_conics,
                                   v_compensations, viewmats_requires_grad, *, _v_view_opacities=None):
@@ -924,6 +945,7 @@ _PACKED_COMPACT_ABOVE = 1 << 28  # ... and their unused tails are given back whe
 
 
 @_op("projection_ewa_3dgs_packed")
+@_f64_instantiation
 def projection_ewa_3dgs_packed(means, covars, quats, scales, opacities, viewmats, Ks, image_width, image_height,
                                eps2d, near_plane, far_plane, radius_clip, sparse_grad, calc_compensations,
                                camera_model):
@@ -978,6 +1000,7 @@ def projection_ewa_3dgs_packed(means, covars, quats, scales, opacities, viewmats
 
 
 @_op("projection_ewa_3dgs_packed_bwd")
+@_f64_instantiation
 def projection_ewa_3dgs_packed_bwd(means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
                                    camera_model, sparse_grad, batch_ids, camera_ids, gaussian_ids, conics,
                                    compensations, v_means2d, v_depths, v_conics, v_compensations,
@@ -2213,7 +2236,7 @@ class _FromWorldCompositing(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, colors, opacities, rays, backgrounds, masks, width, height, tile_size,
-                tile_offsets, flatten_ids, want_counts=False):
+                tile_offsets, flatten_ids, want_counts=False, hit_distance=False, want_normals=False):
         batch = tuple(means.shape[:-2])
         N, C, D = means.shape[-2], colors.shape[-3], colors.shape[-1]
         I = math.prod(batch) * C
@@ -2226,35 +2249,51 @@ class _FromWorldCompositing(torch.autograd.Function):
         bg, mk = _c(backgrounds), _c(masks)
         off, fl = tile_offsets.contiguous(), flatten_ids.contiguous()
         counts = torch.empty(batch + (C, height, width), device=dev, dtype=torch.int32) if want_counts else None
-        call("gsx_raster_world_fwd_counts", *[ptr(t) for t in args], ptr(bg), ptr(mk), ptr(off), ptr(fl), I, C, N, fl.numel(), D,
-             int(width), int(height), int(tile_size), tw, th, ptr(renders), ptr(alphas), ptr(last_ids), ptr(counts))
+        normals = torch.empty(batch + (C, height, width, 3), device=dev, dtype=dt) if want_normals else None
+        call("gsx_raster_world_fwd_ex", *[ptr(t) for t in args], ptr(bg), ptr(mk), ptr(off), ptr(fl), I, C, N, fl.numel(), D,
+             int(width), int(height), int(tile_size), tw, th, int(bool(hit_distance)), ptr(renders), ptr(alphas), ptr(last_ids),
+             ptr(counts), ptr(normals))
         ctx.save_for_backward(*args, off, fl, alphas, last_ids, *([bg] if bg is not None else []),
                               *([mk] if mk is not None else []))
         ctx.flags = (bg is not None, mk is not None, I, C, N, D, int(width), int(height), int(tile_size), tw, th, batch)
+        ctx.extras = (bool(hit_distance), bool(want_normals))
         ctx.mark_non_differentiable(last_ids)
         if counts is None:
             counts = torch.empty(0, device=dev, dtype=torch.int32)
         ctx.mark_non_differentiable(counts)
-        return renders, alphas, last_ids, counts
+        if normals is None:
+            normals = torch.empty(0, device=dev, dtype=dt)
+            ctx.mark_non_differentiable(normals)
+        return renders, alphas, last_ids, counts, normals
 
     @staticmethod
-    def backward(ctx, v_renders, v_alphas, _v_last, _v_counts=None):
+    def backward(ctx, v_renders, v_alphas, _v_last, _v_counts=None, v_normals=None):
         has_bg, has_mk, I, C, N, D, width, height, tile_size, tw, th, batch = ctx.flags
+        hit_distance, want_normals = ctx.extras
+        extra = hit_distance or want_normals
         saved = list(ctx.saved_tensors)
         means, quats, scales, colors, opacities, rays, off, fl, alphas, last_ids = saved[:10]
         rest = saved[10:]
         bg = rest.pop(0) if has_bg else None
         mk = rest.pop(0) if has_mk else None
-        rows = torch.zeros((I * N, 13 + D), device=means.device, dtype=means.dtype)
+        width_rows = 13 + D + (6 if extra else 0)
+        rows = torch.zeros((I * N, width_rows), device=means.device, dtype=means.dtype)
         v_r = (torch.zeros_like(alphas).expand(alphas.shape[:-1] + (D,)) if v_renders is None else v_renders).contiguous()
         v_a = None if v_alphas is None else v_alphas.contiguous()
-        call("gsx_raster_world_bwd", ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities), ptr(rays), ptr(bg),
-             ptr(mk), ptr(off), ptr(fl), ptr(alphas), ptr(last_ids), ptr(v_r), ptr(v_a), I, C, N, fl.numel(), D, width,
-             height, tile_size, tw, th, ptr(rows), 13 + D)
+        if extra:
+            v_n = None if (v_normals is None or not want_normals) else v_normals.contiguous()
+            call("gsx_raster_world_bwd_ex", ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities), ptr(rays), ptr(bg),
+                 ptr(mk), ptr(off), ptr(fl), ptr(alphas), ptr(last_ids), ptr(v_r), ptr(v_a), ptr(v_n), I, C, N, fl.numel(), D,
+                 width, height, tile_size, tw, th, int(hit_distance), ptr(rows), width_rows)
+        else:
+            call("gsx_raster_world_bwd", ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities), ptr(rays), ptr(bg),
+                 ptr(mk), ptr(off), ptr(fl), ptr(alphas), ptr(last_ids), ptr(v_r), ptr(v_a), I, C, N, fl.numel(), D, width,
+                 height, tile_size, tw, th, ptr(rows), 13 + D)
         B = I // C
-        per = rows.view(B, C, N, 13 + D)
+        per = rows.view(B, C, N, width_rows)
         v_means = per[..., 0:3].sum(1).reshape(means.shape)
         v_M = per[..., 3:12].sum(1).reshape(batch + (N, 3, 3))
+        v_n0 = per[..., 13 + D + 3:13 + D + 6].sum(1).reshape(batch + (N, 3)) if extra else None
         with torch.enable_grad():  # M = S^-1 R^T as a function of (quats, scales): chain v_M through it
             q = quats.detach().requires_grad_(True)
             sc = scales.detach().requires_grad_(True)
@@ -2264,10 +2303,16 @@ class _FromWorldCompositing(torch.autograd.Function):
                              2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
                              2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(q.shape[:-1] + (3, 3))
             M = R.transpose(-1, -2) / sc[..., :, None]
-            v_quats, v_scales = torch.autograd.grad(M, (q, sc), v_M)
+            if extra:  # + the unit third axis n0 = R[:, 2] / |R[:, 2]| (the normals' gradient reaches the quaternion through it)
+                n0 = torch.nn.functional.normalize(R[..., :, 2], dim=-1)
+                v_quats, v_scales = torch.autograd.grad((M, n0), (q, sc), (v_M, v_n0), allow_unused=True)
+            else:
+                v_quats, v_scales = torch.autograd.grad(M, (q, sc), v_M)
+        if extra:  # the hit distance |scale * d' hit_t| depends on the scale directly
+            v_scales = v_scales + per[..., 13 + D:13 + D + 3].sum(1).reshape(scales.shape)
         v_opac = per[..., 12].reshape(opacities.shape)
-        v_cols = per[..., 13:].reshape(colors.shape)
-        return (v_means, v_quats, v_scales, v_cols, v_opac) + (None,) * 9
+        v_cols = per[..., 13:13 + D].reshape(colors.shape)
+        return (v_means, v_quats, v_scales, v_cols, v_opac) + (None,) * 11
 
 
 @_op("rasterize_to_pixels_from_world_3dgs")
@@ -2278,10 +2323,8 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
                                         return_sample_counts, use_hit_distance, return_normals, renderer_config,
                                         return_last_ids, unsafe_masked_tile_outputs=False):
     """gsplat::rasterize_to_pixels_from_world_3dgs (forward + autograd, like the reference's C++ autograd function,
-    Rasterization.cpp:3266-3340): dense rows, MixedBatch renderer, rays either given or generated for perfect pinhole
-    cameras with a global shutter. Everything else is refused, never approximated."""
-    if use_hit_distance or return_normals:
-        raise NotImplementedError("gsplat_amd: hit distance / normals of the from-world rasterizer are not built yet")
+    Rasterization.cpp:3266-3340): dense rows, rays either given or generated for perfect pinhole cameras (global or rolling
+    shutter), sample counts, hit distance, normals. Lidar and external distortion are refused, never approximated."""
     if renderer_config not in (0, 1):
         raise ValueError(f"unknown renderer_config {renderer_config}")
     # renderer_config 1 (PARALLEL_BATCH, Rasterization.cpp:106-117) is a scheduling choice of the reference (its lists split over
@@ -2308,10 +2351,11 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
     image_dims, I, th, tw, _ = _raster_dims(tile_offsets, colors)
     if tuple(rays.shape[-3:]) != (image_height, image_width, 6) or rays.numel() != I * image_height * image_width * 6:
         raise ValueError(f"rays must be [..., C, H, W, 6], got {tuple(rays.shape)}")
-    renders, alphas, last_ids, counts = _FromWorldCompositing.apply(
+    renders, alphas, last_ids, counts, normals = _FromWorldCompositing.apply(
         means, quats, scales, colors, opacities, rays.detach(), backgrounds, masks, int(image_width), int(image_height),
-        int(tile_size), tile_offsets, flatten_ids, bool(return_sample_counts))
-    return renders, alphas, (last_ids if return_last_ids else None), (counts if return_sample_counts else None), None
+        int(tile_size), tile_offsets, flatten_ids, bool(return_sample_counts), bool(use_hit_distance), bool(return_normals))
+    return (renders, alphas, (last_ids if return_last_ids else None), (counts if return_sample_counts else None),
+            (normals if return_normals else None))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -2369,7 +2413,8 @@ def rasterization_3dgs(means, covars, quats, scales, opacities, colors, viewmats
     extra = meta.get("render_extra_signals")
     absgrad_holder = getattr(meta["means2d"], "absgrad", None) if absgrad else None
     ids = [meta["batch_ids"], meta["camera_ids"], meta["gaussian_ids"]]
-    return (rc, ra, _empty(rc) if extra is None else extra, _empty(rc),
+    normals = meta.get("normals")
+    return (rc, ra, _empty(rc) if extra is None else extra, _empty(rc) if normals is None else normals,
             _empty(rc) if absgrad_holder is None else absgrad_holder,
             *[_empty(rc, torch.long) if t is None else t for t in ids],
             meta["radii"], meta["means2d"], meta["depths"], meta["conics"], meta["opacities"], meta["tiles_per_gauss"],

@@ -137,6 +137,27 @@ def rasterize_to_pixels_eval3d(
     return out[0], out[1]
 
 
+def rasterize_to_pixels_eval3d_extra(means, quats, scales, colors, opacities, viewmats, Ks, image_width, image_height, tile_size,
+                                     isect_offsets, flatten_ids, backgrounds=None, masks=None, camera_model="pinhole",
+                                     ut_params=None, rays=None, radial_coeffs=None, tangential_coeffs=None, thin_prism_coeffs=None,
+                                     ftheta_coeffs=None, lidar_coeffs=None, external_distortion_coeffs=None, rolling_shutter=4,
+                                     viewmats_rs=None, return_sample_counts=False, use_hit_distance=False, return_normals=False,
+                                     renderer_config=None, return_last_ids=True):
+    """rasterize_to_pixels_eval3d + the optional outputs (reference ``gsplat/cuda/_wrapper.py:2356-2482``): returns
+    (render_colors, render_alphas, last_ids or None, sample_counts or None, render_normals or None)."""
+    models = {"pinhole": 0, "ortho": 1, "fisheye": 2, "ftheta": 3, "lidar": 4}
+    c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+    cls = torch.classes.gsplat
+    return _ops.rasterize_to_pixels_from_world_3dgs(
+        means.contiguous(), quats.contiguous(), scales.contiguous(), colors.contiguous(), opacities.contiguous(),
+        c(backgrounds), c(masks), image_width, image_height, tile_size, viewmats.contiguous(), c(viewmats_rs),
+        Ks.contiguous(), models[camera_model], ut_params if ut_params is not None else cls.UnscentedTransformParameters(),
+        int(rolling_shutter), c(rays), c(radial_coeffs), c(tangential_coeffs), c(thin_prism_coeffs),
+        ftheta_coeffs if ftheta_coeffs is not None else cls.FThetaCameraDistortionParameters(), lidar_coeffs,
+        external_distortion_coeffs, isect_offsets.contiguous(), flatten_ids.contiguous(), bool(return_sample_counts),
+        bool(use_hit_distance), bool(return_normals), 0 if renderer_config is None else int(renderer_config), bool(return_last_ids))
+
+
 def _has(feature: str) -> bool:
     from . import csrc_shim
 

@@ -101,6 +101,16 @@ void want_f32(const OptTensor &t, const char *name)
     if (has(t)) want_f32(*t, name);
 }
 
+// The reference dispatches the projection ops over float AND double (AT_DISPATCH_FLOATING_TYPES, ProjectionEWA3DGSFused.cu:260,
+// 686; ProjectionEWA3DGSPacked.cu:344, 733). In its double instantiation only the MEMORY type is double: the kernels load every
+// value into glm float vectors / matrices (Common.h:65-70: vec3 = glm::vec<3, float>, mat3 = glm::mat<3, 3, float>), compute in
+// float and widen the results on store. Same here: double tensors are narrowed, the fp32 kernels run, float outputs are widened.
+bool is_f64(const Tensor &t) { return t.defined() && t.scalar_type() == at::kDouble; }
+Tensor narrow32(const Tensor &t) { return t.defined() && t.scalar_type() == at::kDouble ? t.to(at::kFloat) : t; }
+OptTensor narrow32(const OptTensor &t) { return has(t) ? OptTensor(narrow32(*t)) : t; }
+Tensor widen64(const Tensor &t) { return t.defined() && t.scalar_type() == at::kFloat ? t.to(at::kDouble) : t; }
+OptTensor widen64(const OptTensor &t) { return has(t) ? OptTensor(widen64(*t)) : t; }
+
 template <class T> const T *cp(const Tensor &t) { return t.defined() && t.numel() ? t.const_data_ptr<T>() : nullptr; }
 template <class T> const T *cp(const OptTensor &t) { return has(t) ? cp<T>(*t) : nullptr; }
 template <class T> T *mp(Tensor &t) { return t.defined() && t.numel() ? t.mutable_data_ptr<T>() : nullptr; }
@@ -155,6 +165,12 @@ projection_ewa_3dgs_fused(const Tensor &means_, const OptTensor &covars_, const 
                           int64_t height, double eps2d, double near_plane, double far_plane, double radius_clip,
                           bool calc_compensations, int64_t camera_model)
 {
+    if (is_f64(means_)) { // the double instantiation: double in memory, float arithmetic (see narrow32)
+        auto [radii, m2, dep, con, comp] = projection_ewa_3dgs_fused(
+            narrow32(means_), narrow32(covars_), narrow32(quats_), narrow32(scales_), narrow32(opacities_), narrow32(viewmats_),
+            narrow32(Ks_), width, height, eps2d, near_plane, far_plane, radius_clip, calc_compensations, camera_model);
+        return {radii, widen64(m2), widen64(dep), widen64(con), widen64(comp)};
+    }
     want_f32(means_, "means"); want_f32(covars_, "covars"); want_f32(quats_, "quats"); want_f32(scales_, "scales");
     want_f32(viewmats_, "viewmats"); want_f32(Ks_, "Ks");
     TORCH_CHECK(has(covars_) || (has(quats_) && has(scales_)), "projection: either covars or (quats, scales) must be given");
@@ -187,6 +203,13 @@ projection_ewa_3dgs_fused_bwd(const Tensor &means_, const OptTensor &covars_, co
                               const Tensor &v_means2d_, const Tensor &v_depths_, const Tensor &v_conics_,
                               const OptTensor &v_compensations, bool viewmats_requires_grad)
 {
+    if (is_f64(means_)) { // the double instantiation: double in memory, float arithmetic (see narrow32)
+        auto [vm, vc, vq, vs, vv] = projection_ewa_3dgs_fused_bwd(
+            narrow32(means_), narrow32(covars_), narrow32(quats_), narrow32(scales_), narrow32(viewmats_), narrow32(Ks_), width,
+            height, eps2d, camera_model, radii, narrow32(conics), narrow32(compensations), narrow32(v_means2d_),
+            narrow32(v_depths_), narrow32(v_conics_), narrow32(v_compensations), viewmats_requires_grad);
+        return {widen64(vm), widen64(vc), widen64(vq), widen64(vs), widen64(vv)};
+    }
     Launch L(means_);
     const Tensor means = contig(means_), viewmats = contig(viewmats_), Ks = contig(Ks_);
     const OptTensor covars = contig(covars_);
@@ -228,6 +251,12 @@ projection_ewa_3dgs_packed(const Tensor &means_, const OptTensor &covars_, const
                            int64_t height, double eps2d, double near_plane, double far_plane, double radius_clip,
                            bool sparse_grad, bool calc_compensations, int64_t camera_model)
 {
+    if (is_f64(means_)) { // the double instantiation: double in memory, float arithmetic (see narrow32)
+        auto [bi, ci, gi, ip, radii, m2, dep, con, comp] = projection_ewa_3dgs_packed(
+            narrow32(means_), narrow32(covars_), narrow32(quats_), narrow32(scales_), narrow32(opacities_), narrow32(viewmats_),
+            narrow32(Ks_), width, height, eps2d, near_plane, far_plane, radius_clip, sparse_grad, calc_compensations, camera_model);
+        return {bi, ci, gi, ip, radii, widen64(m2), widen64(dep), widen64(con), widen64(comp)};
+    }
     (void)sparse_grad;
     want_f32(means_, "means"); want_f32(covars_, "covars"); want_f32(quats_, "quats"); want_f32(scales_, "scales");
     want_f32(viewmats_, "viewmats"); want_f32(Ks_, "Ks");

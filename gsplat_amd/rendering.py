@@ -12,7 +12,7 @@ of the reference (``gsplat/rendering.py:234-690``) and the stage order of its C+
 3DGUT: ``with_ut`` (Unscented-Transform projection through pinhole / distorted-pinhole / ortho / fisheye / f-theta cameras,
 global shutter) and ``with_eval3d`` (from-world compositing) are built; what is NOT built is refused up front, before
 any kernel launches, never approximated: f-theta outside the UT projection, lidar cameras, external (windshield) distortion,
-ray generation for distorted cameras (pass ``rays``), the hit-distance render modes and ``return_normals``.
+ray generation for distorted cameras (pass ``rays``).
 """
 from __future__ import annotations
 
@@ -114,8 +114,9 @@ def rasterization(
     if rasterize_mode not in ("classic", "antialiased"):
         raise ValueError(f"Unsupported rasterize_mode: {rasterize_mode}")
     has_color = render_mode in _COLOR_MODES or render_mode.startswith("RGB")
-    has_depth = render_mode in _DEPTH_MODES
-    expected_depth = render_mode in ("ED", "RGB+ED")
+    use_hit_distance = render_mode in _HIT_MODES  # depth channel = distance along the ray (from-world rasterizer only)
+    has_depth = render_mode in _DEPTH_MODES or use_hit_distance
+    expected_depth = render_mode in ("ED", "RGB+ED", "Ed", "RGB-Ed")
     tile_size = _resolve_tile_size(tile_size, with_eval3d, width, height)
 
     batch_dims = tuple(means.shape[:-2])
@@ -139,8 +140,6 @@ def rasterization(
         "with_eval3d with distortion (ray generation is built for perfect pinhole cameras; pass rays)":
             with_eval3d and rays is None and (camera_model != "pinhole" or radial_coeffs is not None
                                               or tangential_coeffs is not None or thin_prism_coeffs is not None),
-        "hit-distance render modes ('d', 'Ed', 'RGB-d', 'RGB-Ed')": render_mode in _HIT_MODES,
-        "return_normals": bool(return_normals),
         "camera_model='ftheta' / ftheta_coeffs outside the UT projection (with_ut=True without with_eval3d, or with rays given)":
             (camera_model == "ftheta" or ftheta_coeffs is not None) and not (with_ut and (not with_eval3d or rays is not None)),
         "camera_model='lidar'": camera_model == "lidar",
@@ -334,7 +333,9 @@ def rasterization(
 
     # ---- depth channel ---------------------------------------------------------------------------
     if has_depth:
-        d = depths[..., None]
+        # hit-distance modes: the channel is a placeholder, the kernel puts every sample's own hit distance there
+        # (Rendering.cpp:646-648)
+        d = torch.zeros_like(depths[..., None]) if use_hit_distance else depths[..., None]
         feats = d if feats is None else torch.cat([feats, d], dim=-1)
         if backgrounds is not None:
             if has_color:
@@ -345,6 +346,7 @@ def rasterization(
 
     # ---- compositing (channel chunks; alphas from the first chunk) -------------------------------
     D_total = feats.shape[-1]
+    render_normals = None
     if D_total > channel_chunk and not with_eval3d:  # the from-world kernel chunks channels itself
         rc, ra = [], None
         for s in range(0, D_total, channel_chunk):
@@ -361,12 +363,13 @@ def rasterization(
         if with_eval3d:
             # from-world compositing: every sample is the Gaussian's response along the pixel's ray (forward only so far:
             # the op refuses inputs that require gradients)
-            from ._wrapper import rasterize_to_pixels_eval3d
+            from ._wrapper import rasterize_to_pixels_eval3d_extra
 
-            render_colors, render_alphas = rasterize_to_pixels_eval3d(
+            render_colors, render_alphas, _li, _sc, render_normals = rasterize_to_pixels_eval3d_extra(
                 means, quats, scales, feats.contiguous(), proj_opacities.contiguous(), viewmats, Ks, width, height,
                 tile_size, isect_offsets, flatten_ids, backgrounds=backgrounds, camera_model=camera_model,
-                ut_params=ut_params, rays=rays, rolling_shutter=rs_type, viewmats_rs=viewmats_rs)
+                ut_params=ut_params, rays=rays, rolling_shutter=rs_type, viewmats_rs=viewmats_rs,
+                use_hit_distance=use_hit_distance, return_normals=bool(return_normals), return_last_ids=False)
         else:
             render_colors, render_alphas = rasterize_to_pixels(
                 means2d, conics, feats, proj_opacities, width, height, tile_size, isect_offsets, flatten_ids,
@@ -397,6 +400,8 @@ def rasterization(
     })
     if extra_signals is not None:
         meta["render_extra_signals"] = render_extra
+    if return_normals:
+        meta["normals"] = render_normals  # gsplat/rendering.py:687-688
     return render_colors, render_alphas, meta
 
 

@@ -325,6 +325,17 @@ int gsx_raster_world_fwd_counts(const float *means, const float *quats, const fl
                                 uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
                                 float *render_colors, float *render_alphas, int32_t *last_ids, int32_t *sample_counts,
                                 void *stream);
+/* ... + `use_hit_distance` (the LAST colour channel of every sample is the distance along the ray to its closest approach in
+ * world units, |scale * (d' hit_t)|, instead of colors[row][cdim - 1]: RasterizeToPixelsFromWorld3DGS.cuh:715-720, 745-751) and
+ * render_normals float [I,H,W,3] (may be NULL): sum of vis * the Gaussian's third axis R[:, 2], unit length, turned to face the
+ * ray (:762-768) - the op's `use_hit_distance` / `return_normals` (Rasterization.cpp:2404, 2656-2702). */
+int gsx_raster_world_fwd_ex(const float *means, const float *quats, const float *scales, const float *colors,
+                            const float *opacities, const float *rays, const float *backgrounds, const uint8_t *masks,
+                            const int32_t *isect_offsets, const int32_t *flatten_ids, uint32_t n_images,
+                            uint32_t cameras_per_batch, uint32_t n_gaussians, uint32_t n_isects, uint32_t cdim,
+                            uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h,
+                            int use_hit_distance, float *render_colors, float *render_alphas, int32_t *last_ids,
+                            int32_t *sample_counts, float *render_normals, void *stream);
 
 /* Backward of gsx_raster_world_fwd (reference host fn rasterize_to_pixels_from_world_3dgs_bwd, Rasterization.cpp:2920;
  * kernel RasterizeToPixelsFromWorld3DGSBwd.cu). Gradient rows v_rows [I * N][row_stride >= 13 + cdim], ZEROED by the caller: v_mean (3) | v_M (9, row-major, M = S^-1 R^T) |
@@ -338,6 +349,18 @@ int gsx_raster_world_bwd(const float *means, const float *quats, const float *sc
                          uint32_t n_images, uint32_t cameras_per_batch, uint32_t n_gaussians, uint32_t n_isects,
                          uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w,
                          uint32_t tile_h, float *v_rows, uint32_t row_stride, void *stream);
+/* Backward of gsx_raster_world_fwd_ex (RasterizeToPixelsFromWorld3DGSParallelBatchBwd.cu:806-880): v_rows [I * N][13 + cdim + 6],
+ * zero-initialised - the columns of gsx_raster_world_bwd, then v_scale (3: the hit distance depends on the scale directly) and
+ * the cotangent of the Gaussian's UNIT third axis n0 = R[:, 2] / |R[:, 2]| (3; the caller takes it to v_quats). With
+ * use_hit_distance the last colour channel receives no colour gradient. v_render_normals float [I,H,W,3] may be NULL. */
+int gsx_raster_world_bwd_ex(const float *means, const float *quats, const float *scales, const float *colors,
+                            const float *opacities, const float *rays, const float *backgrounds, const uint8_t *masks,
+                            const int32_t *isect_offsets, const int32_t *flatten_ids, const float *render_alphas,
+                            const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+                            const float *v_render_normals, uint32_t n_images, uint32_t cameras_per_batch,
+                            uint32_t n_gaussians, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height,
+                            uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int use_hit_distance, float *v_rows,
+                            uint32_t row_stride, void *stream);
 
 /* assemble_proj_features_unpacked_fwd: gsplat::assemble_proj_features_unpacked_fwd (ext.cpp:1015-1020; host
  * SphericalHarmonics.cpp:572-676; kernel SphericalHarmonicsCUDA.cu:1100-1250). Dense rows only. Writes

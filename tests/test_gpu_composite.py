@@ -127,10 +127,14 @@ def test_rasterization_3dgs_op_rejects_out_of_scope_arguments(G):
     for over in (dict(with_ut=True), dict(with_eval3d=True), dict(with_ut=True, with_eval3d=True)):
         out = call(**over)
         assert out[0].shape == (1, H, W, 3) and bool(torch.isfinite(out[0]).all())
+    # ... so do the hit-distance depth channel and the normals of the from-world rasterizer (round 6)
+    out = call(with_eval3d=True, use_hit_distance=True, append_depth=True)
+    assert out[0].shape == (1, H, W, 4) and bool(torch.isfinite(out[0]).all())
+    out = call(with_eval3d=True, return_normals=True)
+    assert out[3].shape == (1, H, W, 3) and bool(torch.isfinite(out[3]).all())
     # ... what is not built, or is invalid in the reference too (Rendering.cpp:120-480), is refused, never approximated
     for over in (dict(with_ut=True, packed=True), dict(with_eval3d=True, packed=True), dict(rolling_shutter=0),
-                 dict(use_hit_distance=True, append_depth=True), dict(with_eval3d=True, use_hit_distance=True,
-                 append_depth=True), dict(with_eval3d=True, return_normals=True), dict(return_normals=True),
+                 dict(use_hit_distance=True, append_depth=True), dict(return_normals=True),
                  dict(radial_coeffs=torch.zeros(1, 6, device=DEV)), dict(camera_model=3), dict(camera_model=4),
                  dict(with_ut=True, camera_model=3), dict(with_eval3d=True, camera_model=2),
                  dict(rays=torch.zeros(1, H, W, 6, device=DEV))):

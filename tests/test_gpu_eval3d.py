@@ -128,3 +128,36 @@ def test_eval3d_backward_matches_reference_gradients(G, name):
 
     for k, leaf in leaves.items():
         assert_grad_close(leaf.grad.cpu(), torch.from_numpy(gold[f"{name}.ref.v_{k}"]), rel=5e-3, max_bad_ratio=1e-3, name=f"v_{k}")
+
+
+@pytest.mark.parametrize("name", ["hit", "normals", "both"])
+def test_eval3d_hit_distance_normals_and_sample_counts_match_reference(G, name):
+    """gsx_raster_world_{fwd,bwd}_ex against the outputs AND autograd gradients of the reference's torch statement with
+    use_hit_distance / return_normals (tests/golden/eval3d_extras_ref.npz, oracle/pin_eval3d_extras_against_reference.py): the
+    last colour channel is every sample's hit distance |scale * d' hit_t|, the normals are the Gaussians' third axes turned to
+    face the ray; the hit distance carries gradients to means, quaternions and - directly - scales, the normals to quaternions."""
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "eval3d_extras_ref.npz")))
+    N, C, W, H, ts, D, hit, nrm = (int(v) for v in gold[f"{name}.shape"])
+    t = lambda k: torch.from_numpy(gold[f"{name}.{k}"]).to(DEV)  # noqa: E731
+    leaves = {k: t(k).clone().requires_grad_(True) for k in ("means", "quats", "scales", "colors", "opacities")}
+    bg = t("backgrounds") if f"{name}.backgrounds" in gold else None
+    ren, alp, last, cnt, nor = G.rasterize_to_pixels_eval3d_extra(
+        leaves["means"], leaves["quats"], leaves["scales"], leaves["colors"], leaves["opacities"], t("viewmats"), t("Ks"), W, H, ts,
+        t("isect_offsets"), t("flatten_ids"), backgrounds=bg, rays=t("rays"), return_sample_counts=True,
+        use_hit_distance=bool(hit), return_normals=bool(nrm))
+    from _util import assert_close_ratio, assert_grad_close
+
+    assert_close_ratio(ren.detach().cpu(), torch.from_numpy(gold[f"{name}.ref.render"]), 1e-4, 2e-5, max_bad_ratio=1e-3, name="render")
+    assert_close_ratio(alp.detach().cpu(), torch.from_numpy(gold[f"{name}.ref.alpha"]), 1e-4, 2e-5, max_bad_ratio=1e-3, name="alpha")
+    same = (cnt.cpu() == torch.from_numpy(gold[f"{name}.ref.sample_counts"])).float().mean()
+    assert float(same) > 0.995, float(same)  # a sample within rounding of the 1/255 or 1e-4 test moves a pixel's count by one
+    assert bool(((cnt > 0) == (last >= 0)).all())
+    loss = (ren * t("v_render")).sum() + (alp * t("v_alpha")).sum()
+    if nrm:
+        assert_close_ratio(nor.detach().cpu(), torch.from_numpy(gold[f"{name}.ref.normals"]), 1e-4, 2e-5, max_bad_ratio=1e-3, name="normals")
+        loss = loss + (nor * t("v_normals")).sum()
+    else:
+        assert nor is None
+    loss.backward()
+    for k, leaf in leaves.items():
+        assert_grad_close(leaf.grad.cpu(), torch.from_numpy(gold[f"{name}.ref.v_{k}"]), rel=5e-3, max_bad_ratio=2e-3, name=f"{name} v_{k}")

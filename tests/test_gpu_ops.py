@@ -144,6 +144,40 @@ def test_projection_dense_fwd_bwd(G, O, cam, use_covars):
         assert_grad_close(cpu(tg[k].grad), to[k].grad, rel=2e-3, name=f"v_{k}")
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_projection_double_instantiation(G, packed):
+    """The reference dispatches the projection ops over float AND double (ProjectionEWA3DGSFused.cu:260, 686,
+    ProjectionEWA3DGSPacked.cu:344, 733); its double instantiation keeps doubles in MEMORY only - every value is loaded into
+    glm float vectors (include/Common.h:65-70), the arithmetic is float, results are widened on store. So: float64 inputs give
+    float64 outputs and gradients that EQUAL the float32 run of the float-rounded inputs, bit for bit."""
+    sc, W, H = make_scene(N=3000, C=2, width=160, height=120, seed=12)
+    names = ("means", "quats", "scales", "viewmats")
+    d64 = {k: sc[k].double().to(DEV).requires_grad_(True) for k in names}
+    f32 = {k: sc[k].to(DEV).clone().requires_grad_(True) for k in names}
+    kw = dict(eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0, packed=packed, calc_compensations=True,
+              camera_model="pinhole")
+    out64 = G.fully_fused_projection(d64["means"], None, d64["quats"], d64["scales"], d64["viewmats"], sc["Ks"].double().to(DEV),
+                                     W, H, opacities=sc["opacities"].double().to(DEV), **kw)
+    out32 = G.fully_fused_projection(f32["means"], None, f32["quats"], f32["scales"], f32["viewmats"], sc["Ks"].to(DEV), W, H,
+                                     opacities=sc["opacities"].to(DEV), **kw)
+    assert len(out64) == len(out32)
+    g = torch.Generator().manual_seed(4)
+    l64 = l32 = 0.0
+    for a, b in zip(out64, out32):
+        if a.is_floating_point():
+            assert a.dtype == torch.float64 and b.dtype == torch.float32
+            assert torch.equal(a, b.double())
+            w = torch.randn(b.shape, generator=g).to(DEV)
+            l64, l32 = l64 + (a * w.double()).sum(), l32 + (b * w).sum()
+        else:
+            assert a.dtype == b.dtype and torch.equal(a, b)
+    l64.backward()
+    l32.backward()
+    for k in names:
+        assert d64[k].grad.dtype == torch.float64
+        assert torch.equal(d64[k].grad, f32[k].grad.double()), k
+
+
 def test_projection_culling_rules(G, O):
     sc, W, H = make_scene(N=3000, C=2, width=160, height=120, seed=2, z_range=(0.5, 30.0))
     sc["opacities"][:500] = 0.002  # below 1/255 -> culled when opacities are passed

@@ -146,10 +146,13 @@ def test_rasterization_rejects_out_of_scope_arguments(G):
         G.rasterization(*args, with_ut=True, packed=True)
     with pytest.raises(RuntimeError, match="Packed mode is not supported with Eval3D"):
         G.rasterization(*args, with_eval3d=True, packed=True)
-    # not built: refused before any kernel launches, never a result with the wrong channel count
-    for kw in (dict(render_mode="RGB-Ed"), dict(render_mode="d"), dict(return_normals=True)):
-        with pytest.raises(RuntimeError, match="not supported"):
-            G.rasterization(*args, with_eval3d=True, packed=False, **kw)
+    # hit-distance modes and normals of the from-world rasterizer are built (round 6): the channel counts follow the mode
+    for kw, ch in ((dict(render_mode="RGB-Ed"), 4), (dict(render_mode="d"), 1), (dict(return_normals=True), 3)):
+        rc, ra, meta = G.rasterization(*args, with_eval3d=True, packed=False, **kw)
+        assert rc.shape == (1, H, W, ch) and bool(torch.isfinite(rc).all())
+        if kw.get("return_normals"):
+            assert meta["normals"].shape == (1, H, W, 3) and bool(torch.isfinite(meta["normals"]).all())
+    # not built: refused before any kernel launches, never approximated
     with pytest.raises(RuntimeError, match="not supported"):
         G.rasterization(*args, with_eval3d=True, packed=False, camera_model="fisheye")
     with pytest.raises(RuntimeError, match="hit-distance render modes require with_eval3d=True"):

@@ -56,7 +56,8 @@ def test_reference_own_gpu_tests_pass_over_the_shim(tmp_path):
         pytest.skip("needs a ROCm GPU")
     if not _have_reference():
         pytest.skip("no reference tree: run __graft_entry__.build() where /root/reference exists (stages oracle/_ref/*.zip)")
-    out = str(tmp_path / "reference_suite")
+    # GSPLAT_AMD_REFSUITE_OUT=<prefix>: keep the per-test table of this run (tools/gpu_round.sh sets it to gpurun_out/<tag>/...)
+    out = os.environ.get("GSPLAT_AMD_REFSUITE_OUT") or str(tmp_path / "reference_suite")
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     env.pop("GSPLAT_AMD_3DGUT_SUBSET", None)
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_suite.py"), "--files", ",".join(FILES),

@@ -6,6 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
+export GSPLAT_AMD_REFSUITE_OUT=$OUT/reference_suite
 { time timeout ${TEST_TIMEOUT:-420} python -m pytest tests -m gpu -q -n ${TEST_JOBS:-4} --dist loadfile -p no:cacheprovider ; } > $OUT/gpu_tests.log 2>&1
 tail -15 $OUT/gpu_tests.log
 timeout 240 python bench.py > $OUT/bench.json 2> $OUT/bench.err
