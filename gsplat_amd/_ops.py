@@ -2227,10 +2227,69 @@ def pinhole_pixel_rays_rolling(viewmats: Tensor, viewmats_rs: Tensor, Ks: Tensor
     return torch.cat([oi.expand_as(d_world), d_world], dim=-1).contiguous()
 
 
+def _ftheta_record(ftheta_coeffs):
+    """The 17-float host record the C-ABI takes for an f-theta camera: reference_poly | pixeldist_to_angle_poly[6] |
+    angle_to_pixeldist_poly[6] | max_angle | linear_cde[3] (FThetaCameraDistortionParameters, Cameras.h:103-117)."""
+    import ctypes
+
+    p2a, a2p = list(ftheta_coeffs.pixeldist_to_angle_poly), list(ftheta_coeffs.angle_to_pixeldist_poly)
+    cde = list(ftheta_coeffs.linear_cde)
+    if len(p2a) != 6 or len(a2p) != 6 or len(cde) != 3:
+        raise ValueError("ftheta_coeffs: the polynomials have 6 terms, linear_cde 3")
+    vals = [1.0 if int(ftheta_coeffs.reference_poly) != 0 else 0.0] + [float(v) for v in p2a] + [float(v) for v in a2p] \
+        + [float(ftheta_coeffs.max_angle)] + [float(v) for v in cde]
+    return (ctypes.c_float * 17)(*vals)
+
+
+def camera_pixel_rays(viewmats: Tensor, viewmats_rs: Optional[Tensor], Ks: Tensor, width: int, height: int, camera_model: int = 0,
+                      rs_type: int = 4, radial_coeffs: Optional[Tensor] = None,
+                      tangential_coeffs: Optional[Tensor] = None, thin_prism_coeffs: Optional[Tensor] = None,
+                      ftheta_coeffs=None) -> Tensor:
+    """[..., C, H, W, 6]: world-space origin | unit direction of the ray through every pixel centre, for every built camera model
+    (perfect / OpenCV-distorted pinhole, orthographic, OpenCV fisheye, f-theta) under a global or rolling shutter - what the
+    reference's from-world kernels derive per thread when no `rays` are passed (RasterizeToPixelsFromWorld3DGS.cuh:349-529).
+    A pixel the model cannot invert gets the zero ray (no samples). One kernel: gsx_camera_rays (csrc/projection_ut.hip)."""
+    import ctypes
+
+    lead = tuple(viewmats.shape[:-2])
+    I = math.prod(lead)
+    dev, dt = viewmats.device, viewmats.dtype
+    rolling = rs_type != 4  # RollingShutterType.GLOBAL
+    if rolling and (viewmats_rs is None or viewmats_rs.shape != viewmats.shape):
+        raise ValueError("a rolling shutter needs viewmats_rs of the shape of viewmats")
+    ftheta_rec, max_angle = None, None
+    if camera_model == 3:
+        if ftheta_coeffs is None:
+            raise ValueError("camera_model='ftheta' needs ftheta_coeffs (FThetaCameraDistortionParameters)")
+        if radial_coeffs is not None or tangential_coeffs is not None or thin_prism_coeffs is not None:
+            raise ValueError("the f-theta camera model takes ftheta_coeffs, not radial / tangential / thin-prism coefficients")
+        ftheta_rec = _ftheta_record(ftheta_coeffs)
+    if camera_model == 2:
+        if tangential_coeffs is not None or thin_prism_coeffs is not None:
+            raise ValueError("the fisheye camera model takes radial_coeffs [..., C, 4] only")
+        if radial_coeffs is None:
+            radial_coeffs = torch.zeros(lead + (4,), device=dev, dtype=dt)
+        max_angle = fisheye_max_angle(radial_coeffs, Ks, int(width), int(height)).contiguous()
+    if camera_model == 1 and (radial_coeffs is not None or tangential_coeffs is not None or thin_prism_coeffs is not None):
+        raise RuntimeError("ortho camera model does not support radial_coeffs, tangential_coeffs, or thin_prism_coeffs "
+                           "parameters")
+    if radial_coeffs is not None and radial_coeffs.shape[-1] == 4:
+        radial_coeffs = torch.nn.functional.pad(radial_coeffs, (0, 2))
+    _check_f32(viewmats=viewmats, viewmats_rs=viewmats_rs, Ks=Ks, radial_coeffs=radial_coeffs,
+               tangential_coeffs=tangential_coeffs, thin_prism_coeffs=thin_prism_coeffs)
+    rays = torch.empty(lead + (int(height), int(width), 6), device=dev, dtype=dt)
+    call("gsx_camera_rays", ptr(viewmats.contiguous()), ptr(_c(viewmats_rs)) if rolling else None, ptr(Ks.contiguous()),
+         ptr(_c(radial_coeffs)), ptr(_c(tangential_coeffs)), ptr(_c(thin_prism_coeffs)), ptr(max_angle),
+         ctypes.addressof(ftheta_rec) if ftheta_rec is not None else None, I, int(width), int(height), int(camera_model),
+         int(rs_type), ptr(rays))
+    return rays
+
+
 class _FromWorldCompositing(torch.autograd.Function):
     """Autograd of the from-world compositing (the reference attaches it in C++: Rasterization.cpp:3266-3340 around
     rasterize_to_pixels_from_world_3dgs_bwd, kernel RasterizeToPixelsFromWorld3DGSBwd.cu). Gradients reach means / quats /
-    scales / colors / opacities; rays, cameras and backgrounds are constants. The kernel returns per-(image, Gaussian) rows
+    scales / colors / opacities, the rays (origins and directions: one lane owns a pixel, six sums in registers) and the
+    backgrounds (sum of T_final v_render over the pixels); cameras are constants. The kernel returns per-(image, Gaussian) rows
     [v_mean(3) | v_M(9) | v_opacity | v_colors(D)] with M = S^-1 R^T; v_quats / v_scales follow from v_M on the host side.
     Validated against the gradients the reference's own autograd gives (tests/golden/eval3d_ref.npz)."""
 
@@ -2257,6 +2316,7 @@ class _FromWorldCompositing(torch.autograd.Function):
                               *([mk] if mk is not None else []))
         ctx.flags = (bg is not None, mk is not None, I, C, N, D, int(width), int(height), int(tile_size), tw, th, batch)
         ctx.extras = (bool(hit_distance), bool(want_normals))
+        ctx.rays_shape = tuple(rays.shape)
         ctx.mark_non_differentiable(last_ids)
         if counts is None:
             counts = torch.empty(0, device=dev, dtype=torch.int32)
@@ -2270,7 +2330,8 @@ class _FromWorldCompositing(torch.autograd.Function):
     def backward(ctx, v_renders, v_alphas, _v_last, _v_counts=None, v_normals=None):
         has_bg, has_mk, I, C, N, D, width, height, tile_size, tw, th, batch = ctx.flags
         hit_distance, want_normals = ctx.extras
-        extra = hit_distance or want_normals
+        want_rays = ctx.needs_input_grad[5]
+        extra = hit_distance or want_normals or want_rays  # the wider rows' kernel also carries the rays' cotangent
         saved = list(ctx.saved_tensors)
         means, quats, scales, colors, opacities, rays, off, fl, alphas, last_ids = saved[:10]
         rest = saved[10:]
@@ -2282,10 +2343,12 @@ class _FromWorldCompositing(torch.autograd.Function):
         v_a = None if v_alphas is None else v_alphas.contiguous()
         if extra:
             v_n = None if (v_normals is None or not want_normals) else v_normals.contiguous()
+            v_rays = torch.zeros(ctx.rays_shape, device=means.device, dtype=means.dtype) if want_rays else None
             call("gsx_raster_world_bwd_ex", ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities), ptr(rays), ptr(bg),
                  ptr(mk), ptr(off), ptr(fl), ptr(alphas), ptr(last_ids), ptr(v_r), ptr(v_a), ptr(v_n), I, C, N, fl.numel(), D,
-                 width, height, tile_size, tw, th, int(hit_distance), ptr(rows), width_rows)
+                 width, height, tile_size, tw, th, int(hit_distance), ptr(rows), width_rows, ptr(v_rays))
         else:
+            v_rays = None
             call("gsx_raster_world_bwd", ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities), ptr(rays), ptr(bg),
                  ptr(mk), ptr(off), ptr(fl), ptr(alphas), ptr(last_ids), ptr(v_r), ptr(v_a), I, C, N, fl.numel(), D, width,
                  height, tile_size, tw, th, ptr(rows), 13 + D)
@@ -2312,7 +2375,10 @@ class _FromWorldCompositing(torch.autograd.Function):
             v_scales = v_scales + per[..., 13 + D:13 + D + 3].sum(1).reshape(scales.shape)
         v_opac = per[..., 12].reshape(opacities.shape)
         v_cols = per[..., 13:13 + D].reshape(colors.shape)
-        return (v_means, v_quats, v_scales, v_cols, v_opac) + (None,) * 11
+        v_bg = None
+        if has_bg and ctx.needs_input_grad[6]:  # render = sum + T_final background: v_background = sum over the pixels of T_final v_render
+            v_bg = (v_r * (1.0 - alphas)).sum(dim=(-3, -2)).reshape(bg.shape)
+        return (v_means, v_quats, v_scales, v_cols, v_opac, v_rays, v_bg) + (None,) * 9
 
 
 @_op("rasterize_to_pixels_from_world_3dgs")
@@ -2323,8 +2389,9 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
                                         return_sample_counts, use_hit_distance, return_normals, renderer_config,
                                         return_last_ids, unsafe_masked_tile_outputs=False):
     """gsplat::rasterize_to_pixels_from_world_3dgs (forward + autograd, like the reference's C++ autograd function,
-    Rasterization.cpp:3266-3340): dense rows, rays either given or generated for perfect pinhole cameras (global or rolling
-    shutter), sample counts, hit distance, normals. Lidar and external distortion are refused, never approximated."""
+    Rasterization.cpp:3266-3340): dense rows, rays either given or generated for every built camera model (global or rolling
+    shutter: camera_pixel_rays), sample counts, hit distance, normals, gradients to the rays and the backgrounds. Lidar and
+    external distortion are refused, never approximated."""
     if renderer_config not in (0, 1):
         raise ValueError(f"unknown renderer_config {renderer_config}")
     # renderer_config 1 (PARALLEL_BATCH, Rasterization.cpp:106-117) is a scheduling choice of the reference (its lists split over
@@ -2335,14 +2402,13 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
     if rolling and viewmats1 is None:
         raise ValueError("a rolling shutter needs viewmats_rs (the pose at the end of the frame)")
     if rays is None:
-        if camera_model != 0 or radial_coeffs is not None or tangential_coeffs is not None or thin_prism_coeffs is not None:
-            raise NotImplementedError("gsplat_amd: eval3d generates rays for perfect pinhole cameras only; pass `rays` "
-                                      "for other camera models")
-        with torch.no_grad():
-            if rolling:  # the pose of a pixel is the one at the time its row / column is read
-                rays = pinhole_pixel_rays_rolling(viewmats0, viewmats1, Ks, int(image_width), int(image_height), int(rs_type))
-            else:
-                rays = pinhole_pixel_rays(viewmats0, Ks, int(image_width), int(image_height))
+        if camera_model not in (0, 1, 2, 3):
+            raise NotImplementedError(f"gsplat_amd: eval3d generates rays for pinhole, ortho, fisheye and f-theta cameras, not "
+                                      f"'{_CAMERA_MODEL_NAMES.get(camera_model, camera_model)}'")
+        with torch.no_grad():  # the pose of a pixel is the one at the time its row / column is read
+            rays = camera_pixel_rays(viewmats0, viewmats1 if rolling else None, Ks, int(image_width), int(image_height),
+                                     int(camera_model), int(rs_type), radial_coeffs, tangential_coeffs, thin_prism_coeffs,
+                                     ftheta_coeffs if camera_model == 3 else None)
     _check_f32(means=means, quats=quats, scales=scales, colors=colors, opacities=opacities, rays=rays)
     batch = tuple(means.shape[:-2])
     N, C, D = means.shape[-2], viewmats0.shape[-3], colors.shape[-1]
@@ -2352,7 +2418,7 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
     if tuple(rays.shape[-3:]) != (image_height, image_width, 6) or rays.numel() != I * image_height * image_width * 6:
         raise ValueError(f"rays must be [..., C, H, W, 6], got {tuple(rays.shape)}")
     renders, alphas, last_ids, counts, normals = _FromWorldCompositing.apply(
-        means, quats, scales, colors, opacities, rays.detach(), backgrounds, masks, int(image_width), int(image_height),
+        means, quats, scales, colors, opacities, rays, backgrounds, masks, int(image_width), int(image_height),
         int(tile_size), tile_offsets, flatten_ids, bool(return_sample_counts), bool(use_hit_distance), bool(return_normals))
     return (renders, alphas, (last_ids if return_last_ids else None), (counts if return_sample_counts else None),
             (normals if return_normals else None))

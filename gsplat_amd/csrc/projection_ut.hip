@@ -393,6 +393,168 @@ __global__ void __launch_bounds__(256) project_ut_kernel(const ProjUtArgs a)
     if (a.compensations) a.compensations[row] = comp;
 }
 
+// ---- pixel -> world ray (the from-world rasterizer's ray generation when no `rays` are given) ---------------------------------
+// One thread per pixel: the camera model's INVERSE at the pixel centre (x + 0.5, y + 0.5), then the shutter pose of that pixel
+// (relative frame time of its row / column -> translation lerp + rotation slerp; a global shutter is time 0 of equal poses) takes
+// the camera ray to the world: origin = q^-1 (-t) (orthographic: q^-1 (uv, 0) - t), direction = q^-1 d. An image point the
+// model cannot invert yields the ZERO ray, which the compositing kernels treat as "no samples" (the reference marks the pixel
+// done: RasterizeToPixelsFromWorld3DGS.cuh:345-347, 512-526). Restated from Cameras.cuh:717 (perfect pinhole), :866 (orthographic),
+// :1062-1290 (OpenCV pinhole: five Newton steps on the 2 x 2 system of the distortion), :1472-1520 (OpenCV fisheye: Newton on the
+// odd polynomial from a linear first guess), :1672-1760 (f-theta: the backward polynomial, or Newton on the forward one) and
+// their torch statements in gsplat/cuda/_torch_cameras.py.
+struct RayGenArgs {
+    ProjUtArgs cam;  // viewmats (start of frame), viewmats1 (end, or null), Ks, coefficients, width, height, camera_model, rs_type, ft_*
+    uint32_t n_images;
+    float *rays;     // [I,H,W,6]
+};
+
+__device__ __forceinline__ bool pixel_to_camera_ray(const ProjUtArgs &a, const Cam &c, const UtDistortion &d, float ipx, float ipy,
+                                                    float *ray /*[3] unit direction*/, float *org /*[3] camera-frame origin*/)
+{
+    org[0] = org[1] = org[2] = 0.0f;
+    auto unit = [&](float x, float y, float z) { // _safe_normalize: the zero vector stays zero
+        const float n2 = x * x + y * y + z * z;
+        const float inv = n2 > 0.0f ? 1.0f / sqrtf(n2) : 0.0f;
+        ray[0] = x * inv; ray[1] = y * inv; ray[2] = z * inv;
+    };
+    if (a.camera_model == 3) { // f-theta: undo the affine sensor map, then angle = backward polynomial of the pixel distance
+        const float qx = ipx - (c.cx + 0.5f), qy = ipy - (c.cy + 0.5f);
+        const float det = a.ft_c - a.ft_e * a.ft_d;
+        if (fabsf(det) < 1e-8f) { ray[0] = ray[1] = 0.0f; ray[2] = 1.0f; return false; }
+        const float u = (qx - a.ft_d * qy) / det, v = (-a.ft_e * qx + a.ft_c * qy) / det;
+        const float delta = sqrtf(u * u + v * v);
+        auto poly6 = [](const float *k, float x) { return k[0] + x * (k[1] + x * (k[2] + x * (k[3] + x * (k[4] + x * k[5])))); };
+        float theta = poly6(a.ft_p2a, delta);
+        bool converged = true;
+        if (a.ft_reference_poly != 0) { // the forward polynomial is the calibrated one: three Newton steps from the backward fit
+            converged = false;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const float slope = a.ft_a2p[1] + theta * (2.0f * a.ft_a2p[2] + theta * (3.0f * a.ft_a2p[3]
+                                    + theta * (4.0f * a.ft_a2p[4] + theta * (5.0f * a.ft_a2p[5]))));
+                const float step = (poly6(a.ft_a2p, theta) - delta) / slope;
+                theta     = converged ? theta : theta - step;
+                converged = converged || (fabsf(step) < 1e-6f);
+            }
+        }
+        if (!converged) { ray[0] = ray[1] = 0.0f; ray[2] = 1.0f; return false; }
+        if (delta >= 1e-6f) {
+            const float sc = sinf(theta) / delta;
+            unit(sc * u, sc * v, cosf(theta));
+        } else {
+            ray[0] = ray[1] = 0.0f; ray[2] = 1.0f;
+        }
+        return true;
+    }
+    const float u0 = (ipx - c.cx) / c.fx, v0 = (ipy - c.cy) / c.fy;
+    if (a.camera_model == 1) { // orthographic: parallel rays, the pixel moves the ORIGIN
+        org[0] = u0; org[1] = v0;
+        ray[0] = ray[1] = 0.0f; ray[2] = 1.0f;
+        return true;
+    }
+    if (a.camera_model == 2) { // OpenCV fisheye: solve theta (1 + k1 theta^2 + .. + k4 theta^8) = |uv| by Newton
+        const float delta = sqrtf(u0 * u0 + v0 * v0);
+        const float max_norm = fmaxf((float)a.width * 0.5f / c.fx, (float)a.height * 0.5f / c.fy);
+        float theta = (d.max_angle / max_norm) * delta; // linear first guess (approx_backward_poly)
+        bool converged = false;
+        for (int it = 0; it < 20; ++it) {
+            const float t2 = theta * theta;
+            const float f  = theta * (1.0f + t2 * (d.k[0] + t2 * (d.k[1] + t2 * (d.k[2] + t2 * d.k[3]))));
+            const float df = 1.0f + t2 * (3.0f * d.k[0] + t2 * (5.0f * d.k[1] + t2 * (7.0f * d.k[2] + t2 * 9.0f * d.k[3])));
+            const float step = (f - delta) / df;
+            theta     = converged ? theta : theta - step;
+            converged = converged || (fabsf(step) < 1e-6f);
+            if (converged) break;
+        }
+        if (theta < 0.0f || !(theta < d.max_angle) || !converged) { ray[0] = ray[1] = 0.0f; ray[2] = 1.0f; return false; }
+        if (delta >= 1e-6f) {
+            const float sc = sinf(theta) / delta;
+            ray[0] = sc * u0; ray[1] = sc * v0; ray[2] = cosf(theta);
+        } else {
+            ray[0] = ray[1] = 0.0f; ray[2] = 1.0f;
+        }
+        return true;
+    }
+    if (!a.distorted) { // perfect pinhole
+        unit(u0, v0, 1.0f);
+        return true;
+    }
+    // OpenCV pinhole: find (x, y) whose distorted image is (u0, v0) - Newton on the residual of the distortion model
+    float x = u0, y = v0;
+    bool converged = false, ok = true;
+#pragma unroll 1
+    for (int it = 0; it < 5; ++it) {
+        const float r = x * x + y * y, r2 = r * r;
+        const float alpha = 1.0f + r * (d.k[0] + r * (d.k[1] + r * d.k[2]));
+        const float beta  = 1.0f + r * (d.k[3] + r * (d.k[4] + r * d.k[5]));
+        const float dd = alpha / beta;
+        const bool vj  = dd > 0.0f;
+        float fx = dd * x + 2.0f * d.p[0] * x * y + d.p[1] * (r + 2.0f * x * x) + d.s[0] * r + d.s[1] * r2 - u0;
+        float fy = dd * y + 2.0f * d.p[1] * x * y + d.p[0] * (r + 2.0f * y * y) + d.s[2] * r + d.s[3] * r2 - v0;
+        const float alpha_r = d.k[0] + r * (2.0f * d.k[1] + r * (3.0f * d.k[2]));
+        const float beta_r  = d.k[3] + r * (2.0f * d.k[4] + r * (3.0f * d.k[5]));
+        const float d_r = (alpha_r * beta - alpha * beta_r) / (beta * beta);
+        const float d_x = 2.0f * x * d_r, d_y = 2.0f * y * d_r;
+        float fx_x = dd + d_x * x + 2.0f * d.p[0] * y + 6.0f * d.p[1] * x + 2.0f * x * (d.s[0] + 2.0f * d.s[1] * r);
+        float fx_y = d_y * x + 2.0f * d.p[0] * x + 2.0f * d.p[1] * y + 2.0f * y * (d.s[0] + 2.0f * d.s[1] * r);
+        float fy_x = d_x * y + 2.0f * d.p[1] * y + 2.0f * d.p[0] * x + 2.0f * x * (d.s[2] + 2.0f * d.s[3] * r);
+        float fy_y = dd + d_y * y + 2.0f * d.p[1] * x + 6.0f * d.p[0] * y + 2.0f * y * (d.s[2] + 2.0f * d.s[3] * r);
+        if (!vj) { fx = fy = fx_x = fx_y = fy_x = fy_y = 0.0f; }
+        ok = ok && vj;
+        const float det = fx_x * fy_y - fx_y * fy_x;
+        ok = ok && (fabsf(det) >= 1e-6f);
+        const float dx = -(fx * fy_y - fy * fx_y) / det, dy = -(fy * fx_x - fx * fy_x) / det;
+        if (!(converged || !ok)) { x += dx; y += dy; }
+        converged = converged || (ok && fabsf(dx) < 1e-6f && fabsf(dy) < 1e-6f);
+    }
+    unit(x, y, 1.0f);
+    return converged;
+}
+
+__global__ void __launch_bounds__(256) camera_rays_kernel(const RayGenArgs g)
+{
+    const ProjUtArgs &a = g.cam;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)a.width * a.height;
+    if (idx >= per * g.n_images) return;
+    const uint32_t img = (uint32_t)(idx / per);
+    const uint32_t rem = (uint32_t)(idx % per), py = rem / a.width, px = rem % a.width;
+    const Cam c = load_cam(a.viewmats + (size_t)img * 16, a.Ks + (size_t)img * 9);
+    UtDistortion d{};
+    if (a.radial)
+        for (int i = 0; i < 6; ++i) d.k[i] = a.radial[(size_t)img * 6 + i];
+    if (a.tangential) { d.p[0] = a.tangential[(size_t)img * 2]; d.p[1] = a.tangential[(size_t)img * 2 + 1]; }
+    if (a.thin_prism)
+        for (int i = 0; i < 4; ++i) d.s[i] = a.thin_prism[(size_t)img * 4 + i];
+    d.max_angle = a.max_angle ? a.max_angle[img] : 0.0f;
+    const float ipx = (float)px + 0.5f, ipy = (float)py + 0.5f;
+    float ray[3], org[3];
+    const bool valid = pixel_to_camera_ray(a, c, d, ipx, ipy, ray, org);
+    // the pose of this pixel
+    UtPose p0, p1;
+    ut_rotmat_to_quat(c.R, p0.q);
+    p0.t[0] = c.t[0]; p0.t[1] = c.t[1]; p0.t[2] = c.t[2];
+    p1 = p0;
+    if (a.viewmats1) {
+        const Cam c1 = load_cam(a.viewmats1 + (size_t)img * 16, a.Ks + (size_t)img * 9);
+        ut_rotmat_to_quat(c1.R, p1.q);
+        p1.t[0] = c1.t[0]; p1.t[1] = c1.t[1]; p1.t[2] = c1.t[2];
+    }
+    const UtPose pose = ut_interpolate_pose(p0, p1, ut_relative_frame_time(a, ipx, ipy));
+    const float qi[4] = {pose.q[0], -pose.q[1], -pose.q[2], -pose.q[3]};
+    const float rel[3] = {org[0] - pose.t[0], org[1] - pose.t[1], org[2] - pose.t[2]};
+    float o[3], dw[3];
+    ut_quat_rotate(qi, rel, o);
+    ut_quat_rotate(qi, ray, dw);
+    float *out = g.rays + (size_t)idx * 6;
+    const float keep = valid ? 1.0f : 0.0f; // invalid rays are all zero
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        out[i]     = o[i] * keep;
+        out[3 + i] = dw[i] * keep;
+    }
+}
+
 } // namespace gsx
 
 static int project_ut_launch(const float *means, const float *quats, const float *scales, const float *opacities,
@@ -494,4 +656,40 @@ extern "C" int gsx_project_ut_rs_fwd(const float *means, const float *quats, con
                              B, C, N, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, ut_alpha, ut_beta,
                              ut_kappa, in_image_margin_factor, require_all_sigma_points_valid, radii, means2d, depths, conics,
                              compensations, stream, viewmats1, rs_type, global_z_order);
+}
+
+// Rays of every pixel of I images, [I,H,W,6] = world-space origin | unit direction (the zero ray where the camera model cannot
+// invert the pixel): what the reference's from-world rasterizer derives per thread when no `rays` tensor is passed
+// (compute_world_ray, RasterizeToPixelsFromWorld3DGS.cuh:349-529; BaseCameraModel::element_to_world_ray_shutter_pose,
+// Cameras.cuh:503-546). viewmats_rs NULL / rs_type 4 = global shutter; coefficients as in gsx_project_ut_rs_fwd, one record per
+// image (radial [I,6], tangential [I,2], thin_prism [I,4], fisheye_max_angle [I]); `ftheta` the 17-float HOST record.
+extern "C" int gsx_camera_rays(const float *viewmats, const float *viewmats_rs, const float *Ks, const float *radial,
+                               const float *tangential, const float *thin_prism, const float *fisheye_max_angle,
+                               const float *ftheta, uint32_t n_images, uint32_t width, uint32_t height, int camera_model,
+                               int rs_type, float *rays, void *stream)
+{
+    using namespace gsx;
+    const int64_t n = (int64_t)n_images * width * height;
+    if (n == 0) return GSX_OK;
+    GSX_REQUIRE(viewmats && Ks && rays, "gsx_camera_rays: null pointer");
+    GSX_REQUIRE(camera_model >= 0 && camera_model <= 3, "gsx_camera_rays: camera model %d is not built (pinhole 0, ortho 1, fisheye 2, f-theta 3)", camera_model);
+    GSX_REQUIRE(rs_type >= 0 && rs_type <= 4, "gsx_camera_rays: rolling shutter type %d (0 .. 3 rolling, 4 global)", rs_type);
+    GSX_REQUIRE(rs_type == 4 || viewmats_rs != nullptr, "gsx_camera_rays: a rolling shutter needs the end-of-frame poses");
+    GSX_REQUIRE(camera_model != 1 || (!radial && !tangential && !thin_prism), "gsx_camera_rays: the orthographic model takes no distortion coefficients");
+    GSX_REQUIRE(camera_model != 2 || (fisheye_max_angle && !tangential && !thin_prism), "gsx_camera_rays: the fisheye model needs fisheye_max_angle and takes radial coefficients only");
+    GSX_REQUIRE(camera_model != 3 || (ftheta && !radial && !tangential && !thin_prism), "gsx_camera_rays: the f-theta model needs its parameter record and takes no other coefficients");
+    RayGenArgs g{};
+    ProjUtArgs &a = g.cam;
+    a.viewmats = viewmats; a.viewmats1 = rs_type == 4 ? nullptr : viewmats_rs; a.Ks = Ks;
+    a.radial = radial; a.tangential = tangential; a.thin_prism = thin_prism; a.max_angle = fisheye_max_angle;
+    a.width = width; a.height = height; a.camera_model = camera_model; a.rs_type = rs_type;
+    a.distorted = (radial || tangential || thin_prism) ? 1 : 0;
+    if (camera_model == 3) {
+        a.ft_reference_poly = ftheta[0] != 0.0f ? 1 : 0;
+        for (int i = 0; i < 6; ++i) { a.ft_p2a[i] = ftheta[1 + i]; a.ft_a2p[i] = ftheta[7 + i]; }
+        a.ft_max_angle = ftheta[13]; a.ft_c = ftheta[14]; a.ft_d = ftheta[15]; a.ft_e = ftheta[16];
+    }
+    g.n_images = n_images; g.rays = rays;
+    camera_rays_kernel<<<dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(g);
+    return check_launch("camera_rays");
 }

@@ -10,9 +10,9 @@ of the reference (``gsplat/rendering.py:234-690``) and the stage order of its C+
     -> expected-depth normalisation.
 
 3DGUT: ``with_ut`` (Unscented-Transform projection through pinhole / distorted-pinhole / ortho / fisheye / f-theta cameras,
-global shutter) and ``with_eval3d`` (from-world compositing) are built; what is NOT built is refused up front, before
-any kernel launches, never approximated: f-theta outside the UT projection, lidar cameras, external (windshield) distortion,
-ray generation for distorted cameras (pass ``rays``).
+global or rolling shutter) and ``with_eval3d`` (from-world compositing: rays given or generated for each of those camera
+models, hit-distance modes, normals) are built; what is NOT built is refused up front, before any kernel launches, never
+approximated: lidar cameras and external (windshield) distortion.
 """
 from __future__ import annotations
 
@@ -137,11 +137,8 @@ def rasterization(
         channel_chunk=channel_chunk, covars_triu=_covars_triu)
     # what validates but belongs to paths this backend does not build (a reference build with BUILD_3DGUT=0)
     unsupported = {
-        "with_eval3d with distortion (ray generation is built for perfect pinhole cameras; pass rays)":
-            with_eval3d and rays is None and (camera_model != "pinhole" or radial_coeffs is not None
-                                              or tangential_coeffs is not None or thin_prism_coeffs is not None),
-        "camera_model='ftheta' / ftheta_coeffs outside the UT projection (with_ut=True without with_eval3d, or with rays given)":
-            (camera_model == "ftheta" or ftheta_coeffs is not None) and not (with_ut and (not with_eval3d or rays is not None)),
+        "camera_model='ftheta' / ftheta_coeffs without the UT projection (with_ut=True)":
+            (camera_model == "ftheta" or ftheta_coeffs is not None) and not with_ut,
         "camera_model='lidar'": camera_model == "lidar",
         "external_distortion_coeffs": external_distortion_coeffs is not None,
     }
@@ -369,7 +366,8 @@ def rasterization(
                 means, quats, scales, feats.contiguous(), proj_opacities.contiguous(), viewmats, Ks, width, height,
                 tile_size, isect_offsets, flatten_ids, backgrounds=backgrounds, camera_model=camera_model,
                 ut_params=ut_params, rays=rays, rolling_shutter=rs_type, viewmats_rs=viewmats_rs,
-                use_hit_distance=use_hit_distance, return_normals=bool(return_normals), return_last_ids=False)
+                radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs, thin_prism_coeffs=thin_prism_coeffs,
+                ftheta_coeffs=ftheta_coeffs, use_hit_distance=use_hit_distance, return_normals=bool(return_normals), return_last_ids=False)
         else:
             render_colors, render_alphas = rasterize_to_pixels(
                 means2d, conics, feats, proj_opacities, width, height, tile_size, isect_offsets, flatten_ids,

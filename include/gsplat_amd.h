@@ -352,7 +352,9 @@ int gsx_raster_world_bwd(const float *means, const float *quats, const float *sc
 /* Backward of gsx_raster_world_fwd_ex (RasterizeToPixelsFromWorld3DGSParallelBatchBwd.cu:806-880): v_rows [I * N][13 + cdim + 6],
  * zero-initialised - the columns of gsx_raster_world_bwd, then v_scale (3: the hit distance depends on the scale directly) and
  * the cotangent of the Gaussian's UNIT third axis n0 = R[:, 2] / |R[:, 2]| (3; the caller takes it to v_quats). With
- * use_hit_distance the last colour channel receives no colour gradient. v_render_normals float [I,H,W,3] may be NULL. */
+ * use_hit_distance the last colour channel receives no colour gradient. v_render_normals float [I,H,W,3] may be NULL.
+ * v_rays float [I,H,W,6] (may be NULL; zero-initialised by the caller): the cotangent of the rays, origin | direction - the
+ * reference's v_rays output (Rasterization.cpp:2920-3100; its tests differentiate with respect to the rays). */
 int gsx_raster_world_bwd_ex(const float *means, const float *quats, const float *scales, const float *colors,
                             const float *opacities, const float *rays, const float *backgrounds, const uint8_t *masks,
                             const int32_t *isect_offsets, const int32_t *flatten_ids, const float *render_alphas,
@@ -360,7 +362,18 @@ int gsx_raster_world_bwd_ex(const float *means, const float *quats, const float 
                             const float *v_render_normals, uint32_t n_images, uint32_t cameras_per_batch,
                             uint32_t n_gaussians, uint32_t n_isects, uint32_t cdim, uint32_t width, uint32_t height,
                             uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, int use_hit_distance, float *v_rows,
-                            uint32_t row_stride, void *stream);
+                            uint32_t row_stride, float *v_rays, void *stream);
+
+/* Rays of every pixel of I images, [I,H,W,6] = world-space origin | unit direction, the zero ray where the camera model cannot
+ * invert the pixel (the from-world rasterizer gives such a pixel no samples): what the reference's kernels derive per thread when
+ * no `rays` tensor is passed (compute_world_ray, RasterizeToPixelsFromWorld3DGS.cuh:349-529; element_to_world_ray_shutter_pose,
+ * Cameras.cuh:503-546; the models' image_point_to_camera_ray: Cameras.cuh:717, 866, 1062-1290, 1472-1520, 1672-1760).
+ * viewmats_rs NULL / rs_type 4 = global shutter. Coefficients as in gsx_project_ut_rs_fwd, one record per image: radial [I,6],
+ * tangential [I,2], thin_prism [I,4], fisheye_max_angle [I]; `ftheta` = the 17-float HOST record of gsx_project_ut_ftheta_fwd. */
+int gsx_camera_rays(const float *viewmats, const float *viewmats_rs, const float *Ks, const float *radial,
+                    const float *tangential, const float *thin_prism, const float *fisheye_max_angle, const float *ftheta,
+                    uint32_t n_images, uint32_t width, uint32_t height, int camera_model, int rs_type, float *rays,
+                    void *stream);
 
 /* assemble_proj_features_unpacked_fwd: gsplat::assemble_proj_features_unpacked_fwd (ext.cpp:1015-1020; host
  * SphericalHarmonics.cpp:572-676; kernel SphericalHarmonicsCUDA.cu:1100-1250). Dense rows only. Writes

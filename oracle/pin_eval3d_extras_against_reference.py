@@ -56,7 +56,7 @@ def main():
         tw, th = math.ceil(W / ts), math.ceil(H / ts)
         _, isect_ids, flatten_ids = O.isect_tiles(means2d[0], radii[0] * 2, depths[0], ts, tw, th)
         offsets = O.isect_offset_encode(isect_ids, C, tw, th)
-        rays = E.pinhole_rays(viewmats, Ks, W, H)
+        rays = E.pinhole_rays(viewmats, Ks, W, H).clone().requires_grad_(True)  # the rays are a differentiable input too
         op_in = opacities[None].expand(C, N).contiguous()
         bg = torch.rand(C, D, generator=g) if with_bg else None
         rows, present = E.candidate_lists(offsets, flatten_ids, W, H, ts)
@@ -72,6 +72,7 @@ def main():
                                                        pix // (H * W), W, H, fidx, rays.reshape(C, H * W, 6),
                                                        use_hit_distance=hit, return_normals=nrm)
         if bg is not None:
+            bg.requires_grad_(True)
             ren = ren + (1.0 - alp) * bg[:, None, None, :]
         v_r, v_a = torch.randn(ren.shape, generator=g), torch.randn(alp.shape, generator=g)
         loss = (ren * v_r).sum() + (alp * v_a).sum()
@@ -84,6 +85,10 @@ def main():
               f"{float(cnt.float().mean()):.1f}, |render| max {float(ren.abs().max()):.3f}" + (f", |normals| max {float(nor.abs().max()):.3f}" if nrm else ""))
         for nm, a in zip(("means", "quats", "scales", "opacities", "colors"), leaves):
             gold[f"{name}.ref.v_{nm}"] = a.grad.numpy()
+        gold[f"{name}.ref.v_rays"] = rays.grad.numpy()
+        if bg is not None:
+            gold[f"{name}.ref.v_backgrounds"] = bg.grad.numpy()
+        rays, bg = rays.detach(), (None if bg is None else bg.detach())
         for k, v in dict(means=means, quats=quats, scales=scales, opacities=op_in, colors=colors, viewmats=viewmats, Ks=Ks, rays=rays,
                          isect_offsets=offsets, flatten_ids=flatten_ids, v_render=v_r, v_alpha=v_a).items():
             gold[f"{name}.{k}"] = v.numpy()

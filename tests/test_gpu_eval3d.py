@@ -140,10 +140,11 @@ def test_eval3d_hit_distance_normals_and_sample_counts_match_reference(G, name):
     N, C, W, H, ts, D, hit, nrm = (int(v) for v in gold[f"{name}.shape"])
     t = lambda k: torch.from_numpy(gold[f"{name}.{k}"]).to(DEV)  # noqa: E731
     leaves = {k: t(k).clone().requires_grad_(True) for k in ("means", "quats", "scales", "colors", "opacities")}
-    bg = t("backgrounds") if f"{name}.backgrounds" in gold else None
+    bg = t("backgrounds").requires_grad_(True) if f"{name}.backgrounds" in gold else None
+    rays = t("rays").requires_grad_(True)  # the rays and the backgrounds are differentiable inputs of the reference's op too
     ren, alp, last, cnt, nor = G.rasterize_to_pixels_eval3d_extra(
         leaves["means"], leaves["quats"], leaves["scales"], leaves["colors"], leaves["opacities"], t("viewmats"), t("Ks"), W, H, ts,
-        t("isect_offsets"), t("flatten_ids"), backgrounds=bg, rays=t("rays"), return_sample_counts=True,
+        t("isect_offsets"), t("flatten_ids"), backgrounds=bg, rays=rays, return_sample_counts=True,
         use_hit_distance=bool(hit), return_normals=bool(nrm))
     from _util import assert_close_ratio, assert_grad_close
 
@@ -161,3 +162,58 @@ def test_eval3d_hit_distance_normals_and_sample_counts_match_reference(G, name):
     loss.backward()
     for k, leaf in leaves.items():
         assert_grad_close(leaf.grad.cpu(), torch.from_numpy(gold[f"{name}.ref.v_{k}"]), rel=5e-3, max_bad_ratio=2e-3, name=f"{name} v_{k}")
+    assert_grad_close(rays.grad.cpu(), torch.from_numpy(gold[f"{name}.ref.v_rays"]), rel=5e-3, max_bad_ratio=5e-3, name=f"{name} v_rays")
+    if bg is not None:
+        assert_grad_close(bg.grad.cpu(), torch.from_numpy(gold[f"{name}.ref.v_backgrounds"]), rel=2e-3, name=f"{name} v_backgrounds")
+
+
+_RAY_CASES = ["pinhole_global", "pinhole_top_bottom", "pinhole_left_right", "pinhole_bottom_top", "pinhole_right_left",
+              "opencv_global", "opencv_radial4_top_bottom", "opencv_strong", "ortho_global", "ortho_left_right",
+              "fisheye_global", "fisheye_k4_bottom_top", "fisheye_plain", "ftheta_forward_global", "ftheta_backward_right_left"]
+
+
+@pytest.mark.parametrize("name", _RAY_CASES)
+def test_camera_rays_match_reference_camera_models(G, name):
+    """gsx_camera_rays (the ray of every pixel centre when the from-world rasterizer is given no `rays`) against the reference's
+    torch statement of its camera models - perfect and OpenCV-distorted pinhole (Newton undistortion), orthographic, OpenCV
+    fisheye (Newton on the odd polynomial), f-theta (either calibrated polynomial) - under a global shutter and the four rolling
+    ones (tests/golden/camera_rays_ref.npz, oracle/pin_camera_rays_against_reference.py)."""
+    from gsplat_amd import _ops
+
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "camera_rays_ref.npz")))
+    rs, model, W, H = (int(v) for v in gold[f"{name}.meta"])
+    t = lambda k: torch.from_numpy(gold[f"{name}.{k}"]).float().to(DEV) if f"{name}.{k}" in gold else None  # noqa: E731
+    ft = None
+    if f"{name}.ftheta" in gold:
+        r = [float(v) for v in gold[f"{name}.ftheta"]]
+        ft = torch.classes.gsplat.FThetaCameraDistortionParameters(int(r[0]), r[1:7], r[7:13], r[13], r[14:17])
+    rays = _ops.camera_pixel_rays(t("viewmats"), t("viewmats_rs"), t("Ks"), W, H, model, rs, t("radial_coeffs"),
+                                  t("tangential_coeffs"), t("thin_prism_coeffs"), ft).cpu()
+    ref = torch.from_numpy(gold[f"{name}.ref.rays"])
+    assert rays.shape == ref.shape
+    # origins in scene units (a few units from the origin), directions unit vectors: fp32 rounding of two different evaluation
+    # orders (the Newton iterations end at their 1e-6 step test)
+    torch.testing.assert_close(rays[..., :3], ref[..., :3], rtol=0, atol=5e-6)
+    torch.testing.assert_close(rays[..., 3:], ref[..., 3:], rtol=0, atol=5e-6)
+
+
+def test_rasterization_eval3d_generates_rays_for_distorted_cameras(G):
+    """rasterization(with_ut=True, with_eval3d=True) without `rays` through a distorted pinhole and a fisheye camera: the
+    generated rays (gsx_camera_rays) render the same image as the same rays passed explicitly, and a distortion that is zero
+    renders what the perfect pinhole renders."""
+    from gsplat_amd import _ops
+
+    sc, W, H = make_scene(N=2000, C=2, width=96, height=64, seed=21)
+    a = {k: v.to(DEV) for k, v in sc.items()}
+    args = (a["means"], a["quats"], a["scales"], a["opacities"], a["colors"], a["viewmats"], a["Ks"], W, H)
+    rad = torch.tensor([0.08, -0.02, 0.004, 0.0, 0.0, 0.0], device=DEV).repeat(2, 1)
+    for kw, model in ((dict(radial_coeffs=rad), 0), (dict(camera_model="fisheye", radial_coeffs=rad[:, :4] * 0.3), 2)):
+        rc, ra, _ = G.rasterization(*args, packed=False, with_ut=True, with_eval3d=True, **kw)
+        rays = _ops.camera_pixel_rays(a["viewmats"], None, a["Ks"], W, H, model, 4, kw["radial_coeffs"])
+        rc2, ra2, _ = G.rasterization(*args, packed=False, with_ut=True, with_eval3d=True, rays=rays, **kw)
+        assert torch.equal(rc, rc2) and torch.equal(ra, ra2)
+        assert float(ra.max()) > 0.5 and bool(torch.isfinite(rc).all())
+    rc0, ra0, _ = G.rasterization(*args, packed=False, with_ut=True, with_eval3d=True)
+    rcz, raz, _ = G.rasterization(*args, packed=False, with_ut=True, with_eval3d=True, radial_coeffs=torch.zeros_like(rad))
+    torch.testing.assert_close(rcz, rc0, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(raz, ra0, rtol=1e-4, atol=1e-4)

@@ -175,7 +175,10 @@ def test_projection_double_instantiation(G, packed):
     l32.backward()
     for k in names:
         assert d64[k].grad.dtype == torch.float64
-        assert torch.equal(d64[k].grad, f32[k].grad.double()), k
+        if k == "viewmats":  # summed over the Gaussians with float atomics: the order of two launches may differ
+            torch.testing.assert_close(d64[k].grad, f32[k].grad.double(), rtol=1e-5, atol=1e-3)
+        else:
+            assert torch.equal(d64[k].grad, f32[k].grad.double()), k
 
 
 def test_projection_culling_rules(G, O):
