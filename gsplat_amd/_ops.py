@@ -2290,12 +2290,16 @@ class _FromWorldCompositing(torch.autograd.Function):
     rasterize_to_pixels_from_world_3dgs_bwd, kernel RasterizeToPixelsFromWorld3DGSBwd.cu). Gradients reach means / quats /
     scales / colors / opacities, the rays (origins and directions: one lane owns a pixel, six sums in registers) and the
     backgrounds (sum of T_final v_render over the pixels); cameras are constants. The kernel returns per-(image, Gaussian) rows
-    [v_mean(3) | v_M(9) | v_opacity | v_colors(D)] with M = S^-1 R^T; v_quats / v_scales follow from v_M on the host side.
+    [v_mean(3) | torque(3) | v_scale(3) | v_opacity | v_colors(D)]; v_quats follows from the torque in closed form (backward below).
     Validated against the gradients the reference's own autograd gives (tests/golden/eval3d_ref.npz)."""
 
     @staticmethod
     def forward(ctx, means, quats, scales, colors, opacities, rays, backgrounds, masks, width, height, tile_size,
-                tile_offsets, flatten_ids, want_counts=False, hit_distance=False, want_normals=False):
+                tile_offsets, flatten_ids, want_counts=False, hit_distance=False, want_normals=False, *tracked):
+        # `tracked`: the op's other tensor inputs (poses, intrinsics, distortion coefficients). They receive no gradient, but - like
+        # torch::autograd::Function::apply() in the reference's C++ adapter - an input that requires grad keeps the outputs on
+        # the autograd graph (the reference's test_rasterize_eval3d_autograd_tracks_any_tensor_input)
+        ctx.n_tracked = len(tracked)
         batch = tuple(means.shape[:-2])
         N, C, D = means.shape[-2], colors.shape[-3], colors.shape[-1]
         I = math.prod(batch) * C
@@ -2331,16 +2335,17 @@ class _FromWorldCompositing(torch.autograd.Function):
         has_bg, has_mk, I, C, N, D, width, height, tile_size, tw, th, batch = ctx.flags
         hit_distance, want_normals = ctx.extras
         want_rays = ctx.needs_input_grad[5]
-        extra = hit_distance or want_normals or want_rays  # the wider rows' kernel also carries the rays' cotangent
+        extra = hit_distance or want_normals or want_rays
         saved = list(ctx.saved_tensors)
         means, quats, scales, colors, opacities, rays, off, fl, alphas, last_ids = saved[:10]
         rest = saved[10:]
         bg = rest.pop(0) if has_bg else None
         mk = rest.pop(0) if has_mk else None
-        width_rows = 13 + D + (6 if extra else 0)
+        width_rows = 10 + D  # v_mean 3 | torque 3 | v_scale 3 | v_opacity | v_colors
         rows = torch.zeros((I * N, width_rows), device=means.device, dtype=means.dtype)
         v_r = (torch.zeros_like(alphas).expand(alphas.shape[:-1] + (D,)) if v_renders is None else v_renders).contiguous()
         v_a = None if v_alphas is None else v_alphas.contiguous()
+        v_rays = None
         if extra:
             v_n = None if (v_normals is None or not want_normals) else v_normals.contiguous()
             v_rays = torch.zeros(ctx.rays_shape, device=means.device, dtype=means.dtype) if want_rays else None
@@ -2348,37 +2353,26 @@ class _FromWorldCompositing(torch.autograd.Function):
                  ptr(mk), ptr(off), ptr(fl), ptr(alphas), ptr(last_ids), ptr(v_r), ptr(v_a), ptr(v_n), I, C, N, fl.numel(), D,
                  width, height, tile_size, tw, th, int(hit_distance), ptr(rows), width_rows, ptr(v_rays))
         else:
-            v_rays = None
             call("gsx_raster_world_bwd", ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities), ptr(rays), ptr(bg),
                  ptr(mk), ptr(off), ptr(fl), ptr(alphas), ptr(last_ids), ptr(v_r), ptr(v_a), I, C, N, fl.numel(), D, width,
-                 height, tile_size, tw, th, ptr(rows), 13 + D)
+                 height, tile_size, tw, th, ptr(rows), width_rows)
         B = I // C
         per = rows.view(B, C, N, width_rows)
         v_means = per[..., 0:3].sum(1).reshape(means.shape)
-        v_M = per[..., 3:12].sum(1).reshape(batch + (N, 3, 3))
-        v_n0 = per[..., 13 + D + 3:13 + D + 6].sum(1).reshape(batch + (N, 3)) if extra else None
-        with torch.enable_grad():  # M = S^-1 R^T as a function of (quats, scales): chain v_M through it
-            q = quats.detach().requires_grad_(True)
-            sc = scales.detach().requires_grad_(True)
-            qn = torch.nn.functional.normalize(q, dim=-1)
-            w, x, y, z = qn.unbind(-1)
-            R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
-                             2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
-                             2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(q.shape[:-1] + (3, 3))
-            M = R.transpose(-1, -2) / sc[..., :, None]
-            if extra:  # + the unit third axis n0 = R[:, 2] / |R[:, 2]| (the normals' gradient reaches the quaternion through it)
-                n0 = torch.nn.functional.normalize(R[..., :, 2], dim=-1)
-                v_quats, v_scales = torch.autograd.grad((M, n0), (q, sc), (v_M, v_n0), allow_unused=True)
-            else:
-                v_quats, v_scales = torch.autograd.grad(M, (q, sc), v_M)
-        if extra:  # the hit distance |scale * d' hit_t| depends on the scale directly
-            v_scales = v_scales + per[..., 13 + D:13 + D + 3].sum(1).reshape(scales.shape)
-        v_opac = per[..., 12].reshape(opacities.shape)
-        v_cols = per[..., 13:13 + D].reshape(colors.shape)
+        v_scales = per[..., 6:9].sum(1).reshape(scales.shape)
+        # torque (dL/dw for R -> exp([w]x) R) -> the raw quaternion: v_q = (2 / |q|) (0, torque) (x) q_unit, Hamilton product with
+        # the scalar part first: (0, t) (x) (w, v) = (-t . v, w t + t x v)
+        tq = per[..., 3:6].sum(1).reshape(means.shape)
+        qn_inv = 1.0 / quats.norm(dim=-1, keepdim=True)
+        qu = quats * qn_inv
+        qw, qv = qu[..., :1], qu[..., 1:]
+        v_quats = 2.0 * qn_inv * torch.cat([-(tq * qv).sum(-1, keepdim=True), qw * tq + torch.cross(tq, qv, dim=-1)], dim=-1)
+        v_opac = per[..., 9].reshape(opacities.shape)
+        v_cols = per[..., 10:10 + D].reshape(colors.shape)
         v_bg = None
         if has_bg and ctx.needs_input_grad[6]:  # render = sum + T_final background: v_background = sum over the pixels of T_final v_render
             v_bg = (v_r * (1.0 - alphas)).sum(dim=(-3, -2)).reshape(bg.shape)
-        return (v_means, v_quats, v_scales, v_cols, v_opac, v_rays, v_bg) + (None,) * 9
+        return (v_means, v_quats, v_scales, v_cols, v_opac, v_rays, v_bg) + (None,) * (9 + ctx.n_tracked)
 
 
 @_op("rasterize_to_pixels_from_world_3dgs")
@@ -2419,7 +2413,8 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
         raise ValueError(f"rays must be [..., C, H, W, 6], got {tuple(rays.shape)}")
     renders, alphas, last_ids, counts, normals = _FromWorldCompositing.apply(
         means, quats, scales, colors, opacities, rays, backgrounds, masks, int(image_width), int(image_height),
-        int(tile_size), tile_offsets, flatten_ids, bool(return_sample_counts), bool(use_hit_distance), bool(return_normals))
+        int(tile_size), tile_offsets, flatten_ids, bool(return_sample_counts), bool(use_hit_distance), bool(return_normals),
+        *[t for t in (viewmats0, viewmats1, Ks, radial_coeffs, tangential_coeffs, thin_prism_coeffs) if isinstance(t, Tensor)])
     return (renders, alphas, (last_ids if return_last_ids else None), (counts if return_sample_counts else None),
             (normals if return_normals else None))
 
@@ -2472,7 +2467,8 @@ def rasterization_3dgs(means, covars, quats, scales, opacities, colors, viewmats
         distributed=process_group_name is not None or world_size > 1, camera_model=_CAMERA_MODEL_NAMES[camera_model],
         segmented=segmented, covars=covars, with_ut=with_ut, with_eval3d=with_eval3d, return_normals=return_normals,
         global_z_order=global_z_order, rays=rays, radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs,
-        thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=None, lidar_coeffs=lidar_coeffs, ut_params=ut_params,
+        thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=ftheta_coeffs if camera_model == 3 else None,
+        lidar_coeffs=lidar_coeffs, ut_params=ut_params,
         external_distortion_coeffs=external_distortion_params, viewmats_rs=viewmats_rs, rolling_shutter=rolling_shutter,
         extra_signals=extra_signals,
         extra_signals_sh_degree=None if extra_signals_sh_degree < 0 else extra_signals_sh_degree, _covars_triu=True)

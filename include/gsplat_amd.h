@@ -338,10 +338,12 @@ int gsx_raster_world_fwd_ex(const float *means, const float *quats, const float 
                             int32_t *sample_counts, float *render_normals, void *stream);
 
 /* Backward of gsx_raster_world_fwd (reference host fn rasterize_to_pixels_from_world_3dgs_bwd, Rasterization.cpp:2920;
- * kernel RasterizeToPixelsFromWorld3DGSBwd.cu). Gradient rows v_rows [I * N][row_stride >= 13 + cdim], ZEROED by the caller: v_mean (3) | v_M (9, row-major, M = S^-1 R^T) |
- * v_opacity | v_colors[cdim]; rows of the cameras of one batch are summed by the caller for v_mean / v_M, and v_quats /
- * v_scales follow from v_M (M is a per-Gaussian function of the two). render_alphas / last_ids are the forward outputs;
- * v_render_alphas may be NULL. */
+ * kernel RasterizeToPixelsFromWorld3DGSParallelBatchBwd.cu:300-930). Gradient rows v_rows [I * N][row_stride >= 10 + cdim],
+ * ZEROED by the caller: v_mean (3) | torque (3) | v_scale (3) | v_opacity | v_colors[cdim]. `torque` = dL/dw for a world-frame
+ * rotation vector w applied to the Gaussian's rotation (R -> exp([w]x) R); the caller sums the rows of one batch's cameras and
+ * maps it to the raw quaternion: v_quat = (2 / |q|) (0, torque) (x) q / |q| (Hamilton product, w first). The reference forms
+ * v_quats per sample from v_M (:840-890); the torque is the same derivative without the nine-term intermediate whose
+ * stretch part cancels. render_alphas / last_ids are the forward outputs; v_render_alphas may be NULL. */
 int gsx_raster_world_bwd(const float *means, const float *quats, const float *scales, const float *colors,
                          const float *opacities, const float *rays, const float *backgrounds, const uint8_t *masks,
                          const int32_t *isect_offsets, const int32_t *flatten_ids, const float *render_alphas,
@@ -349,10 +351,10 @@ int gsx_raster_world_bwd(const float *means, const float *quats, const float *sc
                          uint32_t n_images, uint32_t cameras_per_batch, uint32_t n_gaussians, uint32_t n_isects,
                          uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w,
                          uint32_t tile_h, float *v_rows, uint32_t row_stride, void *stream);
-/* Backward of gsx_raster_world_fwd_ex (RasterizeToPixelsFromWorld3DGSParallelBatchBwd.cu:806-880): v_rows [I * N][13 + cdim + 6],
- * zero-initialised - the columns of gsx_raster_world_bwd, then v_scale (3: the hit distance depends on the scale directly) and
- * the cotangent of the Gaussian's UNIT third axis n0 = R[:, 2] / |R[:, 2]| (3; the caller takes it to v_quats). With
- * use_hit_distance the last colour channel receives no colour gradient. v_render_normals float [I,H,W,3] may be NULL.
+/* Backward of gsx_raster_world_fwd_ex (RasterizeToPixelsFromWorld3DGSParallelBatchBwd.cu:806-880): the rows of
+ * gsx_raster_world_bwd - the hit distance's direct dependence on the scale goes into the v_scale columns, the normals' share
+ * (n0 x v_n0, n0 = the Gaussian's unit third axis) into the torque columns. With use_hit_distance the last colour channel
+ * receives no colour gradient. v_render_normals float [I,H,W,3] may be NULL.
  * v_rays float [I,H,W,6] (may be NULL; zero-initialised by the caller): the cotangent of the rays, origin | direction - the
  * reference's v_rays output (Rasterization.cpp:2920-3100; its tests differentiate with respect to the rays). */
 int gsx_raster_world_bwd_ex(const float *means, const float *quats, const float *scales, const float *colors,
