@@ -136,7 +136,7 @@ def test_rasterization_3dgs_op_rejects_out_of_scope_arguments(G):
     for over in (dict(with_ut=True, packed=True), dict(with_eval3d=True, packed=True), dict(rolling_shutter=0),
                  dict(use_hit_distance=True, append_depth=True), dict(return_normals=True),
                  dict(radial_coeffs=torch.zeros(1, 6, device=DEV)), dict(camera_model=3), dict(camera_model=4),
-                 dict(with_ut=True, camera_model=3), dict(with_eval3d=True, camera_model=4),
+                 dict(with_eval3d=True, camera_model=4),
                  dict(rays=torch.zeros(1, H, W, 6, device=DEV))):
         with pytest.raises((RuntimeError, ValueError, NotImplementedError)):
             call(**over)
