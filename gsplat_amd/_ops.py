@@ -251,6 +251,8 @@ SCHEMAS = {
     # training-step ops around the rasterizer: ext.cpp:1217-1221, 1224-1227, 1256-1258
     "adam": "(Tensor(a!) param, Tensor param_grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor? valid, float lr, float b1, float b2, float eps) -> ()",
     "relocation": "(Tensor opacities, Tensor scales, Tensor ratios, Tensor binoms, int n_max, float min_opacity=0.0) -> (Tensor, Tensor)",
+    "distort_camera_rays": "(Tensor rays, Tensor h_poly, Tensor v_poly, Tensor h_inv_poly, Tensor v_inv_poly, int reference_poly, bool inverse) -> Tensor",
+    "eval_bivariate_poly": "(Tensor x, Tensor y, Tensor poly_coeffs, int order) -> Tensor",
     "mcmc_perturb_positions": "(Tensor(a!) positions, Tensor quats, Tensor scales, Tensor opacities, Tensor noise, float noise_scale, float t=0.005, float k=100.) -> ()",
 }
 
@@ -2044,8 +2046,8 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
     if camera_model not in (0, 1, 2, 3):
         raise NotImplementedError(f"gsplat_amd: UT projection is built for pinhole, ortho, fisheye and f-theta cameras, not "
                                   f"'{_CAMERA_MODEL_NAMES.get(camera_model, camera_model)}'")
-    if lidar_coeffs is not None or external_distortion_params is not None:
-        raise NotImplementedError("gsplat_amd: lidar / external-distortion UT projection is not built yet")
+    if lidar_coeffs is not None:
+        raise NotImplementedError("gsplat_amd: lidar UT projection is not built")
     _check_f32(means=means, quats=quats, scales=scales, opacities=opacities, viewmats=viewmats0, viewmats_rs=viewmats1, Ks=Ks,
                radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs, thin_prism_coeffs=thin_prism_coeffs)
     batch = tuple(means.shape[:-2])
@@ -2099,18 +2101,24 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
     depths = torch.empty(batch + (C, N), device=dev, dtype=dt)
     conics = torch.empty(batch + (C, N, 3), device=dev, dtype=dt)
     comps = torch.empty(batch + (C, N), device=dev, dtype=dt) if calc_compensations else None
-    if rolling or not global_z_order:
+    if rolling or not global_z_order or external_distortion_params is not None:
         import ctypes
 
         if rolling and viewmats1.shape != viewmats0.shape:
             raise ValueError("viewmats_rs must match viewmats shape")
-        call("gsx_project_ut_rs_fwd", ptr(means.contiguous()), ptr(quats.contiguous()), ptr(scales.contiguous()),
-             ptr(_c(opacities)), ptr(viewmats0.contiguous()), ptr(_c(viewmats1)) if rolling else None, ptr(Ks.contiguous()),
-             ptr(_c(radial_coeffs)), ptr(_c(tangential_coeffs)), ptr(_c(thin_prism_coeffs)), ptr(max_angle),
-             ctypes.addressof(ftheta_rec) if ftheta_rec is not None else None, B, C, N, int(image_width), int(image_height),
-             float(eps2d), float(near_plane), float(far_plane), float(radius_clip), int(camera_model), int(rs_type),
-             int(bool(global_z_order)), alpha, beta, kappa, margin, int(all_valid), ptr(radii), ptr(means2d), ptr(depths),
-             ptr(conics), ptr(comps))
+        head = (ptr(means.contiguous()), ptr(quats.contiguous()), ptr(scales.contiguous()),
+                ptr(_c(opacities)), ptr(viewmats0.contiguous()), ptr(_c(viewmats1)) if rolling else None, ptr(Ks.contiguous()),
+                ptr(_c(radial_coeffs)), ptr(_c(tangential_coeffs)), ptr(_c(thin_prism_coeffs)), ptr(max_angle),
+                ctypes.addressof(ftheta_rec) if ftheta_rec is not None else None)
+        tail = (B, C, N, int(image_width), int(image_height),
+                float(eps2d), float(near_plane), float(far_plane), float(radius_clip), int(camera_model), int(rs_type),
+                int(bool(global_z_order)), alpha, beta, kappa, margin, int(all_valid), ptr(radii), ptr(means2d), ptr(depths),
+                ptr(conics), ptr(comps))
+        if external_distortion_params is not None:  # behind a windshield: sigma points go through the forward polynomials
+            ext = _windshield_record(external_distortion_params)
+            call("gsx_project_ut_ext_fwd", *head, ctypes.addressof(ext), *tail)
+        else:
+            call("gsx_project_ut_rs_fwd", *head, *tail)
         return radii, means2d, depths, conics, comps
     if ftheta_rec is not None:
         import ctypes
@@ -2241,10 +2249,72 @@ def _ftheta_record(ftheta_coeffs):
     return (ctypes.c_float * 17)(*vals)
 
 
+def _windshield_record(params):
+    """The 84-float host record the C-ABI takes for the external (windshield) distortion: horizontal | vertical | horizontal
+    inverse | vertical inverse polynomial of BivariateWindshieldModelParameters, each padded to the order-5 triangular layout of
+    21 coefficients (block k = the coefficients in x of y^k; pad_coefficients_to_max_order, ExternalDistortion.cuh:104-124)."""
+    import ctypes
+
+    def pad(t, what):
+        vals = [float(v) for v in (t.detach().cpu().reshape(-1).tolist() if isinstance(t, Tensor) else list(t))]
+        order = (-3 + int(math.sqrt(1 + 8 * len(vals)))) // 2  # compute_order
+        if len(vals) not in (1, 3, 6, 10, 15, 21) or (order + 1) * (order + 2) // 2 != len(vals):
+            raise RuntimeError(f"Invalid number of bivariate polynomial coefficients: {len(vals)}. Expected triangular number: "
+                               f"1, 3, 6, 10, 15, or 21. ({what})")
+        out, src = [], 0
+        for k in range(6):
+            n_src = order - k + 1 if k <= order else 0
+            out += vals[src:src + n_src] + [0.0] * (6 - k - n_src)
+            src += n_src
+        return out
+
+    rec = (pad(params.horizontal_poly, "horizontal_poly") + pad(params.vertical_poly, "vertical_poly")
+           + pad(params.horizontal_poly_inverse, "horizontal_poly_inverse") + pad(params.vertical_poly_inverse, "vertical_poly_inverse"))
+    return (ctypes.c_float * 84)(*rec)
+
+
+@_op("distort_camera_rays")
+def distort_camera_rays(rays, horizontal_poly, vertical_poly, horizontal_poly_inverse, vertical_poly_inverse, reference_poly,
+                        inverse):
+    """gsplat::distort_camera_rays (ExternalDistortionWrappers.cu:96-160): the windshield model on rays [..., 3]; `inverse`
+    applies the inverse pair of polynomials."""
+    import ctypes
+    import types as _types
+
+    if rays.dtype != torch.float32 or rays.dim() < 1 or rays.shape[-1] != 3:
+        raise RuntimeError("rays must be float32 with shape [..., 3]")
+    rec = _windshield_record(_types.SimpleNamespace(horizontal_poly=horizontal_poly, vertical_poly=vertical_poly,
+                                                    horizontal_poly_inverse=horizontal_poly_inverse,
+                                                    vertical_poly_inverse=vertical_poly_inverse))
+    base = ctypes.addressof(rec)
+    h, v = (base + 4 * 42, base + 4 * 63) if inverse else (base, base + 4 * 21)
+    rays = rays.contiguous()
+    out = torch.empty_like(rays)
+    call("gsx_distort_camera_rays", ptr(rays), rays.numel() // 3, h, v, ptr(out))
+    return out
+
+
+@_op("eval_bivariate_poly")
+def eval_bivariate_poly(x, y, poly_coeffs, order):
+    """gsplat::eval_bivariate_poly (ExternalDistortionWrappers.cu:30-94)."""
+    import ctypes
+    import types as _types
+
+    if x.dtype != torch.float32 or y.dtype != torch.float32 or x.numel() != y.numel():
+        raise RuntimeError("x and y must be float32 tensors with the same number of elements")
+    one = _types.SimpleNamespace(horizontal_poly=poly_coeffs, vertical_poly=[0.0], horizontal_poly_inverse=[0.0],
+                                 vertical_poly_inverse=[0.0])
+    rec = _windshield_record(one)
+    x, y = x.contiguous(), y.contiguous()
+    out = torch.empty_like(x)
+    call("gsx_eval_bivariate_poly", ptr(x), ptr(y), x.numel(), ctypes.addressof(rec), ptr(out))
+    return out
+
+
 def camera_pixel_rays(viewmats: Tensor, viewmats_rs: Optional[Tensor], Ks: Tensor, width: int, height: int, camera_model: int = 0,
                       rs_type: int = 4, radial_coeffs: Optional[Tensor] = None,
                       tangential_coeffs: Optional[Tensor] = None, thin_prism_coeffs: Optional[Tensor] = None,
-                      ftheta_coeffs=None) -> Tensor:
+                      ftheta_coeffs=None, external_distortion_params=None) -> Tensor:
     """[..., C, H, W, 6]: world-space origin | unit direction of the ray through every pixel centre, for every built camera model
     (perfect / OpenCV-distorted pinhole, orthographic, OpenCV fisheye, f-theta) under a global or rolling shutter - what the
     reference's from-world kernels derive per thread when no `rays` are passed (RasterizeToPixelsFromWorld3DGS.cuh:349-529).
@@ -2278,10 +2348,15 @@ def camera_pixel_rays(viewmats: Tensor, viewmats_rs: Optional[Tensor], Ks: Tenso
     _check_f32(viewmats=viewmats, viewmats_rs=viewmats_rs, Ks=Ks, radial_coeffs=radial_coeffs,
                tangential_coeffs=tangential_coeffs, thin_prism_coeffs=thin_prism_coeffs)
     rays = torch.empty(lead + (int(height), int(width), 6), device=dev, dtype=dt)
-    call("gsx_camera_rays", ptr(viewmats.contiguous()), ptr(_c(viewmats_rs)) if rolling else None, ptr(Ks.contiguous()),
-         ptr(_c(radial_coeffs)), ptr(_c(tangential_coeffs)), ptr(_c(thin_prism_coeffs)), ptr(max_angle),
-         ctypes.addressof(ftheta_rec) if ftheta_rec is not None else None, I, int(width), int(height), int(camera_model),
-         int(rs_type), ptr(rays))
+    head = (ptr(viewmats.contiguous()), ptr(_c(viewmats_rs)) if rolling else None, ptr(Ks.contiguous()),
+            ptr(_c(radial_coeffs)), ptr(_c(tangential_coeffs)), ptr(_c(thin_prism_coeffs)), ptr(max_angle),
+            ctypes.addressof(ftheta_rec) if ftheta_rec is not None else None)
+    tail = (I, int(width), int(height), int(camera_model), int(rs_type), ptr(rays))
+    if external_distortion_params is not None:  # behind a windshield: the camera model's ray goes through the inverse polynomials
+        ext = _windshield_record(external_distortion_params)
+        call("gsx_camera_rays_ext", *head, ctypes.addressof(ext), *tail)
+    else:
+        call("gsx_camera_rays", *head, *tail)
     return rays
 
 
@@ -2390,8 +2465,8 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
         raise ValueError(f"unknown renderer_config {renderer_config}")
     # renderer_config 1 (PARALLEL_BATCH, Rasterization.cpp:106-117) is a scheduling choice of the reference (its lists split over
     # several CTAs); this backend has one schedule, the results are the same
-    if lidar_coeffs is not None or external_distortion_params is not None:
-        raise NotImplementedError("gsplat_amd: lidar / external distortion eval3d is not built yet")
+    if lidar_coeffs is not None:
+        raise NotImplementedError("gsplat_amd: lidar eval3d is not built")
     rolling = rs_type != _ROLLING_SHUTTER_GLOBAL
     if rolling and viewmats1 is None:
         raise ValueError("a rolling shutter needs viewmats_rs (the pose at the end of the frame)")
@@ -2402,7 +2477,7 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
         with torch.no_grad():  # the pose of a pixel is the one at the time its row / column is read
             rays = camera_pixel_rays(viewmats0, viewmats1 if rolling else None, Ks, int(image_width), int(image_height),
                                      int(camera_model), int(rs_type), radial_coeffs, tangential_coeffs, thin_prism_coeffs,
-                                     ftheta_coeffs if camera_model == 3 else None)
+                                     ftheta_coeffs if camera_model == 3 else None, external_distortion_params)
     _check_f32(means=means, quats=quats, scales=scales, colors=colors, opacities=opacities, rays=rays)
     batch = tuple(means.shape[:-2])
     N, C, D = means.shape[-2], viewmats0.shape[-3], colors.shape[-1]

@@ -41,6 +41,11 @@ struct ProjUtArgs {
     int ft_reference_poly;        // 1: angle -> pixel distance is the calibrated polynomial; 0: its inverse is (Newton on it)
     float ft_p2a[6], ft_a2p[6];   // pixeldist_to_angle_poly, angle_to_pixeldist_poly (lowest degree first)
     float ft_max_angle, ft_c, ft_d, ft_e;
+    // external (windshield) distortion, one record per call (ExternalDistortion.h / .cuh: BivariateWindshieldModel): bivariate
+    // polynomials of the ray's two angles, order 5 layout (21 coefficients, lower orders zero-padded by the caller)
+    int ext;                      // 0: none
+    float ext_h[21], ext_v[21];   // forward (distort): horizontal, vertical
+    float ext_hi[21], ext_vi[21]; // inverse (undistort)
     int32_t *radii;       // [B,C,N,2]
     float *means2d;       // [B,C,N,2]
     float *depths;        // [B,C,N]
@@ -53,8 +58,62 @@ struct UtDistortion {
     float max_angle;
 };
 
+// ---- external distortion: the bivariate windshield model (restated from ExternalDistortion.cuh:64-92, 168-205 and its Python
+// statement gsplat/cuda/_torch_external_distortion.py:38-77). A ray is described by the two angles phi = asin(x / |r|),
+// theta = asin(y / |r|); two polynomials of (phi, theta) give the angles of the distorted ray, whose z keeps the sign of the
+// input's. The polynomial is stored by descending inner order: block k holds the 6 - k coefficients (in x) of y^k.
+__device__ __forceinline__ float bivariate_poly21(const float *c, float x, float y)
+{
+    float outer[6];
+    int start = 0;
+#pragma unroll
+    for (int inner = 5; inner >= 0; --inner) {
+        float r = 0.0f;
+#pragma unroll
+        for (int i = start + inner; i >= start; --i) r = r * x + c[i];
+        outer[5 - inner] = r;
+        start += inner + 1;
+    }
+    float r = 0.0f;
+#pragma unroll
+    for (int i = 5; i >= 0; --i) r = r * y + outer[i];
+    return r;
+}
+__device__ __forceinline__ void windshield_ray(const float *hp, const float *vp, const float *in, float *out)
+{
+    const float len = sqrtf(in[0] * in[0] + in[1] * in[1] + in[2] * in[2]);
+    if (len < 1e-6f) { out[0] = in[0]; out[1] = in[1]; out[2] = in[2]; return; }
+    const float phi   = asinf(fminf(1.0f, fmaxf(-1.0f, in[0] / len)));
+    const float theta = asinf(fminf(1.0f, fmaxf(-1.0f, in[1] / len)));
+    const float x = sinf(bivariate_poly21(hp, phi, theta)), y = sinf(bivariate_poly21(vp, phi, theta));
+    out[0] = x; out[1] = y;
+    out[2] = sqrtf(1.0f - fminf(x * x + y * y, 1.0f)) * (in[2] < 0.0f ? -1.0f : 1.0f);
+}
+
 // camera-frame point -> pixel; returns validity
+__device__ __forceinline__ bool ut_project_point_model(const ProjUtArgs &a, const Cam &c, const UtDistortion &d, const float *p,
+                                                       float &px, float &py);
+// ... behind the windshield: the ray is distorted BEFORE the camera model sees it (BaseCameraModel::camera_ray_to_image_point,
+// Cameras.cuh:462-470); the orthographic model, whose input is a point, goes through the ray (x, y, 1) and back (:795-829)
 __device__ __forceinline__ bool ut_project_point(const ProjUtArgs &a, const Cam &c, const UtDistortion &d, const float *p,
+                                                 float &px, float &py)
+{
+    if (!a.ext) return ut_project_point_model(a, c, d, p, px, py);
+    float q[3];
+    if (a.camera_model == 1) {
+        if (!(p[2] > 0.0f)) { px = py = 0.0f; return false; }
+        const float r[3] = {p[0], p[1], 1.0f};
+        float o[3];
+        windshield_ray(a.ext_h, a.ext_v, r, o);
+        const float x = o[0] / o[2], y = o[1] / o[2];
+        if (!(o[2] > 0.0f) || !isfinite(x) || !isfinite(y)) { px = py = 0.0f; return false; }
+        q[0] = x; q[1] = y; q[2] = p[2];
+    } else {
+        windshield_ray(a.ext_h, a.ext_v, p, q);
+    }
+    return ut_project_point_model(a, c, d, q, px, py);
+}
+__device__ __forceinline__ bool ut_project_point_model(const ProjUtArgs &a, const Cam &c, const UtDistortion &d, const float *p,
                                                  float &px, float &py)
 {
     const bool front = p[2] > 0.0f;
@@ -529,7 +588,21 @@ __global__ void __launch_bounds__(256) camera_rays_kernel(const RayGenArgs g)
     d.max_angle = a.max_angle ? a.max_angle[img] : 0.0f;
     const float ipx = (float)px + 0.5f, ipy = (float)py + 0.5f;
     float ray[3], org[3];
-    const bool valid = pixel_to_camera_ray(a, c, d, ipx, ipy, ray, org);
+    bool valid = pixel_to_camera_ray(a, c, d, ipx, ipy, ray, org);
+    if (a.ext && valid) { // the camera model's ray is the one BEHIND the windshield: undo it (Cameras.cuh:473-484; ortho :862-886)
+        if (a.camera_model == 1) {
+            const float r[3] = {org[0], org[1], 1.0f};
+            float o[3];
+            windshield_ray(a.ext_hi, a.ext_vi, r, o);
+            const float x = o[0] / o[2], y = o[1] / o[2];
+            valid  = (o[2] > 0.0f) && isfinite(x) && isfinite(y);
+            org[0] = x; org[1] = y;
+        } else {
+            float o[3];
+            windshield_ray(a.ext_hi, a.ext_vi, ray, o);
+            ray[0] = o[0]; ray[1] = o[1]; ray[2] = o[2];
+        }
+    }
     // the pose of this pixel
     UtPose p0, p1;
     ut_rotmat_to_quat(c.R, p0.q);
@@ -557,6 +630,17 @@ __global__ void __launch_bounds__(256) camera_rays_kernel(const RayGenArgs g)
 
 } // namespace gsx
 
+// `ext`: HOST array of 84 floats = horizontal | vertical | horizontal inverse | vertical inverse polynomial, each in the order-5
+// layout (21 coefficients); NULL = no external distortion
+static void set_external_distortion(gsx::ProjUtArgs &a, const float *ext)
+{
+    a.ext = ext ? 1 : 0;
+    if (!ext) return;
+    for (int i = 0; i < 21; ++i) {
+        a.ext_h[i] = ext[i]; a.ext_v[i] = ext[21 + i]; a.ext_hi[i] = ext[42 + i]; a.ext_vi[i] = ext[63 + i];
+    }
+}
+
 static int project_ut_launch(const float *means, const float *quats, const float *scales, const float *opacities,
                              const float *viewmats, const float *Ks, const float *radial, const float *tangential,
                              const float *thin_prism, const float *fisheye_max_angle, const float *ftheta, uint32_t B, uint32_t C,
@@ -564,7 +648,7 @@ static int project_ut_launch(const float *means, const float *quats, const float
                              float radius_clip, int camera_model, float ut_alpha, float ut_beta, float ut_kappa,
                              float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii, float *means2d,
                              float *depths, float *conics, float *compensations, void *stream, const float *viewmats1 = nullptr,
-                             int rs_type = 4, int global_z_order = 1)
+                             int rs_type = 4, int global_z_order = 1, const float *ext = nullptr)
 {
     using namespace gsx;
     GSX_REQUIRE(rs_type >= 0 && rs_type <= 4, "gsx_project_ut_rs_fwd: rolling shutter type %d (0 .. 3 rolling, 4 global)", rs_type);
@@ -602,6 +686,7 @@ static int project_ut_launch(const float *means, const float *quats, const float
     a.spread = (float)sqrt(3.0 + lam);
     a.margin = in_image_margin_factor;
     a.viewmats1 = rs_type == 4 ? nullptr : viewmats1; a.rs_type = rs_type;
+    set_external_distortion(a, ext);
     a.depth_is_distance = global_z_order ? 0 : 1;
     a.radial_cull = (!global_z_order && camera_model == 3) ? 1 : 0; // (lidar too in the reference; not built here)
     a.radii = radii; a.means2d = means2d; a.depths = depths; a.conics = conics; a.compensations = compensations;
@@ -663,10 +748,10 @@ extern "C" int gsx_project_ut_rs_fwd(const float *means, const float *quats, con
 // (compute_world_ray, RasterizeToPixelsFromWorld3DGS.cuh:349-529; BaseCameraModel::element_to_world_ray_shutter_pose,
 // Cameras.cuh:503-546). viewmats_rs NULL / rs_type 4 = global shutter; coefficients as in gsx_project_ut_rs_fwd, one record per
 // image (radial [I,6], tangential [I,2], thin_prism [I,4], fisheye_max_angle [I]); `ftheta` the 17-float HOST record.
-extern "C" int gsx_camera_rays(const float *viewmats, const float *viewmats_rs, const float *Ks, const float *radial,
-                               const float *tangential, const float *thin_prism, const float *fisheye_max_angle,
-                               const float *ftheta, uint32_t n_images, uint32_t width, uint32_t height, int camera_model,
-                               int rs_type, float *rays, void *stream)
+static int camera_rays_impl(const float *viewmats, const float *viewmats_rs, const float *Ks, const float *radial,
+                            const float *tangential, const float *thin_prism, const float *fisheye_max_angle,
+                            const float *ftheta, const float *ext, uint32_t n_images, uint32_t width, uint32_t height,
+                            int camera_model, int rs_type, float *rays, void *stream)
 {
     using namespace gsx;
     const int64_t n = (int64_t)n_images * width * height;
@@ -689,7 +774,87 @@ extern "C" int gsx_camera_rays(const float *viewmats, const float *viewmats_rs, 
         for (int i = 0; i < 6; ++i) { a.ft_p2a[i] = ftheta[1 + i]; a.ft_a2p[i] = ftheta[7 + i]; }
         a.ft_max_angle = ftheta[13]; a.ft_c = ftheta[14]; a.ft_d = ftheta[15]; a.ft_e = ftheta[16];
     }
+    set_external_distortion(a, ext);
     g.n_images = n_images; g.rays = rays;
     camera_rays_kernel<<<dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(g);
     return check_launch("camera_rays");
+}
+
+extern "C" int gsx_camera_rays(const float *viewmats, const float *viewmats_rs, const float *Ks, const float *radial,
+                               const float *tangential, const float *thin_prism, const float *fisheye_max_angle,
+                               const float *ftheta, uint32_t n_images, uint32_t width, uint32_t height, int camera_model,
+                               int rs_type, float *rays, void *stream)
+{
+    return camera_rays_impl(viewmats, viewmats_rs, Ks, radial, tangential, thin_prism, fisheye_max_angle, ftheta, nullptr, n_images,
+                            width, height, camera_model, rs_type, rays, stream);
+}
+// ... behind a windshield: `ext` = HOST array of 84 floats (horizontal | vertical | horizontal inverse | vertical inverse
+// polynomial, order-5 layout of 21 coefficients each: BivariateWindshieldModelParameters, ExternalDistortion.h); the camera
+// model's ray is taken through the INVERSE polynomials (BaseCameraModel::image_point_to_camera_ray, Cameras.cuh:473-484)
+extern "C" int gsx_camera_rays_ext(const float *viewmats, const float *viewmats_rs, const float *Ks, const float *radial,
+                                   const float *tangential, const float *thin_prism, const float *fisheye_max_angle,
+                                   const float *ftheta, const float *ext, uint32_t n_images, uint32_t width, uint32_t height,
+                                   int camera_model, int rs_type, float *rays, void *stream)
+{
+    return camera_rays_impl(viewmats, viewmats_rs, Ks, radial, tangential, thin_prism, fisheye_max_angle, ftheta, ext, n_images,
+                            width, height, camera_model, rs_type, rays, stream);
+}
+// gsx_project_ut_rs_fwd behind a windshield (`ext` as above): every sigma point's ray is taken through the FORWARD polynomials
+// before the camera model projects it (BaseCameraModel::camera_ray_to_image_point, Cameras.cuh:462-470)
+extern "C" int gsx_project_ut_ext_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                                      const float *viewmats0, const float *viewmats1, const float *Ks, const float *radial,
+                                      const float *tangential, const float *thin_prism, const float *fisheye_max_angle,
+                                      const float *ftheta, const float *ext, uint32_t B, uint32_t C, uint32_t N, uint32_t width,
+                                      uint32_t height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                                      int camera_model, int rs_type, int global_z_order, float ut_alpha, float ut_beta,
+                                      float ut_kappa, float in_image_margin_factor, int require_all_sigma_points_valid,
+                                      int32_t *radii, float *means2d, float *depths, float *conics, float *compensations,
+                                      void *stream)
+{
+    return project_ut_launch(means, quats, scales, opacities, viewmats0, Ks, radial, tangential, thin_prism, fisheye_max_angle, ftheta,
+                             B, C, N, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, ut_alpha, ut_beta,
+                             ut_kappa, in_image_margin_factor, require_all_sigma_points_valid, radii, means2d, depths, conics,
+                             compensations, stream, viewmats1, rs_type, global_z_order, ext);
+}
+
+// gsplat::distort_camera_rays / gsplat::eval_bivariate_poly (ExternalDistortionWrappers.cu:30-160): the windshield model on a
+// batch of rays [n,3] with ONE pair of polynomials (host arrays of 21 floats, order-5 layout; pass the inverse pair to undistort),
+// and one bivariate polynomial at n points.
+namespace gsx {
+struct Poly21 { float c[21]; };
+__global__ void __launch_bounds__(256) distort_rays_kernel(const float *rays, Poly21 h, Poly21 v, float *out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float in[3] = {rays[3 * i], rays[3 * i + 1], rays[3 * i + 2]};
+    float o[3];
+    windshield_ray(h.c, v.c, in, o);
+    out[3 * i] = o[0]; out[3 * i + 1] = o[1]; out[3 * i + 2] = o[2];
+}
+__global__ void __launch_bounds__(256) bivariate_poly_kernel(const float *x, const float *y, Poly21 p, float *out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bivariate_poly21(p.c, x[i], y[i]);
+}
+} // namespace gsx
+extern "C" int gsx_distort_camera_rays(const float *rays, int64_t n, const float *horizontal_poly, const float *vertical_poly,
+                                       float *out, void *stream)
+{
+    using namespace gsx;
+    if (n <= 0) return GSX_OK;
+    GSX_REQUIRE(rays && horizontal_poly && vertical_poly && out, "gsx_distort_camera_rays: null pointer");
+    Poly21 h, v;
+    for (int i = 0; i < 21; ++i) { h.c[i] = horizontal_poly[i]; v.c[i] = vertical_poly[i]; }
+    distort_rays_kernel<<<dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(rays, h, v, out, n);
+    return check_launch("distort_camera_rays");
+}
+extern "C" int gsx_eval_bivariate_poly(const float *x, const float *y, int64_t n, const float *poly, float *out, void *stream)
+{
+    using namespace gsx;
+    if (n <= 0) return GSX_OK;
+    GSX_REQUIRE(x && y && poly && out, "gsx_eval_bivariate_poly: null pointer");
+    Poly21 p;
+    for (int i = 0; i < 21; ++i) p.c[i] = poly[i];
+    bivariate_poly_kernel<<<dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(x, y, p, out, n);
+    return check_launch("eval_bivariate_poly");
 }

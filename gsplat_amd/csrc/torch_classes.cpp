@@ -37,8 +37,8 @@ struct FThetaCameraDistortionParameters : torch::CustomClassHolder {
 
 struct BivariateWindshieldModelParameters : torch::CustomClassHolder {
     static constexpr int64_t kMaxOrder = 5, kMaxCoeffs = 21; // ExternalDistortion.h:44-45
-    std::vector<double> horizontal_poly, vertical_poly, horizontal_poly_inverse, vertical_poly_inverse;
-    int64_t reference_poly = 1;
+    at::Tensor horizontal_poly, vertical_poly, horizontal_poly_inverse, vertical_poly_inverse; // float tensors, like the reference
+    int64_t reference_poly = 1;                                                                // FORWARD = 1, BACKWARD = 2
 };
 
 struct FOV : torch::CustomClassHolder {

@@ -12,7 +12,8 @@ of the reference (``gsplat/rendering.py:234-690``) and the stage order of its C+
 3DGUT: ``with_ut`` (Unscented-Transform projection through pinhole / distorted-pinhole / ortho / fisheye / f-theta cameras,
 global or rolling shutter) and ``with_eval3d`` (from-world compositing: rays given or generated for each of those camera
 models, hit-distance modes, normals) are built; what is NOT built is refused up front, before any kernel launches, never
-approximated: lidar cameras and external (windshield) distortion.
+approximated: lidar cameras. External (windshield) distortion (the reference's bivariate model) is built for every one of those
+camera models in both 3DGUT kernels.
 """
 from __future__ import annotations
 
@@ -140,7 +141,6 @@ def rasterization(
         "camera_model='ftheta' / ftheta_coeffs without the UT projection (with_ut=True)":
             (camera_model == "ftheta" or ftheta_coeffs is not None) and not with_ut,
         "camera_model='lidar'": camera_model == "lidar",
-        "external_distortion_coeffs": external_distortion_coeffs is not None,
     }
     bad = [k for k, v in unsupported.items() if v]
     if bad:
@@ -208,7 +208,7 @@ def rasterization(
             far_plane=far_plane, radius_clip=radius_clip, calc_compensations=calc_comp, camera_model=camera_model,
             ut_params=ut_params, radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs,
             thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=ftheta_coeffs, global_z_order=global_z_order,
-            rolling_shutter=rs_type, viewmats_rs=viewmats_rs)
+            rolling_shutter=rs_type, viewmats_rs=viewmats_rs, external_distortion_coeffs=external_distortion_coeffs)
     elif not packed and not calc_comp and means.is_cuda and _VIEW_OPACITIES:
         # dense rows, classic mode: the per-view opacities come out of the projection's own autograd node, whose backward sums
         # their gradient over the views inside the kernel that reads the gradient rows anyway (_autograd.py)
@@ -367,7 +367,8 @@ def rasterization(
                 tile_size, isect_offsets, flatten_ids, backgrounds=backgrounds, camera_model=camera_model,
                 ut_params=ut_params, rays=rays, rolling_shutter=rs_type, viewmats_rs=viewmats_rs,
                 radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs, thin_prism_coeffs=thin_prism_coeffs,
-                ftheta_coeffs=ftheta_coeffs, use_hit_distance=use_hit_distance, return_normals=bool(return_normals), return_last_ids=False)
+                ftheta_coeffs=ftheta_coeffs, external_distortion_coeffs=external_distortion_coeffs,
+                use_hit_distance=use_hit_distance, return_normals=bool(return_normals), return_last_ids=False)
         else:
             render_colors, render_alphas = rasterize_to_pixels(
                 means2d, conics, feats, proj_opacities, width, height, tile_size, isect_offsets, flatten_ids,

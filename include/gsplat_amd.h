@@ -377,6 +377,31 @@ int gsx_camera_rays(const float *viewmats, const float *viewmats_rs, const float
                     uint32_t n_images, uint32_t width, uint32_t height, int camera_model, int rs_type, float *rays,
                     void *stream);
 
+/* External (windshield) distortion, the reference's BivariateWindshieldModel (ExternalDistortion.h / .cuh; Python statement
+ * gsplat/cuda/_torch_external_distortion.py). `ext` = HOST array of 84 floats: horizontal | vertical | horizontal inverse |
+ * vertical inverse polynomial, each in the order-5 triangular layout of 21 coefficients (lower orders zero-padded the way
+ * pad_coefficients_to_max_order does, ExternalDistortion.cuh:104-124).
+ * gsx_camera_rays_ext = gsx_camera_rays behind the windshield (the camera model's ray goes through the inverse polynomials,
+ * Cameras.cuh:473-484; orthographic :862-886); gsx_project_ut_ext_fwd = gsx_project_ut_rs_fwd behind it (every sigma point's
+ * ray goes through the forward polynomials before the camera model, Cameras.cuh:462-470; orthographic :795-829). */
+int gsx_camera_rays_ext(const float *viewmats, const float *viewmats_rs, const float *Ks, const float *radial,
+                        const float *tangential, const float *thin_prism, const float *fisheye_max_angle, const float *ftheta,
+                        const float *ext, uint32_t n_images, uint32_t width, uint32_t height, int camera_model, int rs_type,
+                        float *rays, void *stream);
+int gsx_project_ut_ext_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                           const float *viewmats0, const float *viewmats1, const float *Ks, const float *radial,
+                           const float *tangential, const float *thin_prism, const float *fisheye_max_angle, const float *ftheta,
+                           const float *ext, uint32_t B, uint32_t C, uint32_t N, uint32_t width, uint32_t height, float eps2d,
+                           float near_plane, float far_plane, float radius_clip, int camera_model, int rs_type,
+                           int global_z_order, float ut_alpha, float ut_beta, float ut_kappa, float in_image_margin_factor,
+                           int require_all_sigma_points_valid, int32_t *radii, float *means2d, float *depths, float *conics,
+                           float *compensations, void *stream);
+/* gsplat::distort_camera_rays / gsplat::eval_bivariate_poly (ExternalDistortionWrappers.cu:30-160): the model on n rays [n,3]
+ * with ONE pair of polynomials (HOST arrays of 21 floats; the inverse pair undistorts), one bivariate polynomial at n points. */
+int gsx_distort_camera_rays(const float *rays, int64_t n, const float *horizontal_poly, const float *vertical_poly, float *out,
+                            void *stream);
+int gsx_eval_bivariate_poly(const float *x, const float *y, int64_t n, const float *poly, float *out, void *stream);
+
 /* assemble_proj_features_unpacked_fwd: gsplat::assemble_proj_features_unpacked_fwd (ext.cpp:1015-1020; host
  * SphericalHarmonics.cpp:572-676; kernel SphericalHarmonicsCUDA.cu:1100-1250). Dense rows only. Writes
  * out [B,C,N, Dc + E + has_depth] = [ post(SH colours of coeffs [N,K,Dc]) | extra (+0.5 when extra_post == 1) | depth ]

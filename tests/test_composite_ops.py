@@ -45,8 +45,8 @@ def test_custom_classes(ops):
     b = c.BivariateWindshieldModelParameters()
     assert c.BivariateWindshieldModelParameters.get_max_order() == 5
     assert c.BivariateWindshieldModelParameters.get_max_coeffs() == 21
-    b.horizontal_poly = [1.0, 2.0]
-    assert b.horizontal_poly == [1.0, 2.0]
+    b.horizontal_poly = torch.tensor([0.0, 1.0, 0.0])  # tensor fields, like the reference's class (ext.cpp:430-440)
+    assert b.horizontal_poly.tolist() == [0.0, 1.0, 0.0] and b.reference_poly == 1
     fov = c.FOV(0.25, 1.5)
     lp = c.RowOffsetStructuredSpinningLidarModelParametersExt(
         torch.zeros(4), torch.zeros(8), torch.zeros(4), 1, 10.0, fov, c.FOV(), 1e-3, torch.zeros(2, 2), 8, 4,

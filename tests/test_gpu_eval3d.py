@@ -217,3 +217,76 @@ def test_rasterization_eval3d_generates_rays_for_distorted_cameras(G):
     rcz, raz, _ = G.rasterization(*args, packed=False, with_ut=True, with_eval3d=True, radial_coeffs=torch.zeros_like(rad))
     torch.testing.assert_close(rcz, rc0, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(raz, ra0, rtol=1e-4, atol=1e-4)
+
+
+def _windshield(h, v, hi=None, vi=None):
+    p = torch.classes.gsplat.BivariateWindshieldModelParameters()
+    ident_h, ident_v = [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]
+    p.horizontal_poly, p.vertical_poly = torch.tensor(h, dtype=torch.float32), torch.tensor(v, dtype=torch.float32)
+    p.horizontal_poly_inverse = torch.tensor(ident_h if hi is None else hi, dtype=torch.float32)
+    p.vertical_poly_inverse = torch.tensor(ident_v if vi is None else vi, dtype=torch.float32)
+    return p
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 4, 5])
+def test_external_distortion_matches_reference_statement(G, order):
+    """gsplat::eval_bivariate_poly / gsplat::distort_camera_rays (gsx_eval_bivariate_poly, gsx_distort_camera_rays) against the
+    reference's Python statement of the bivariate windshield model for every polynomial order - the functions its own
+    tests/test_external_distortion.py holds its CUDA kernels to (tests/golden/external_distortion_ref.npz)."""
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "external_distortion_ref.npz")))
+    h, v = gold[f"o{order}.h"].tolist(), gold[f"o{order}.v"].tolist()
+    x, y = torch.from_numpy(gold[f"o{order}.x"]).to(DEV), torch.from_numpy(gold[f"o{order}.y"]).to(DEV)
+    got = torch.ops.gsplat.eval_bivariate_poly(x, y, torch.tensor(h, dtype=torch.float32, device=DEV), order).cpu().double()
+    torch.testing.assert_close(got, torch.from_numpy(gold[f"o{order}.ref.poly"]), rtol=1e-5, atol=1e-6)
+    rays = torch.from_numpy(gold[f"o{order}.rays"]).to(DEV)
+    hp, vp = torch.tensor(h, dtype=torch.float32, device=DEV), torch.tensor(v, dtype=torch.float32, device=DEV)
+    ident = torch.tensor([0.0, 1.0, 0.0], device=DEV), torch.tensor([0.0, 0.0, 1.0], device=DEV)
+    out = torch.ops.gsplat.distort_camera_rays(rays, hp, vp, ident[0], ident[1], 1, False).cpu().double()
+    torch.testing.assert_close(out, torch.from_numpy(gold[f"o{order}.ref.distorted"]), rtol=0, atol=5e-6)
+    # `inverse` applies the other pair: with the pairs swapped it is the same computation
+    out_inv = torch.ops.gsplat.distort_camera_rays(rays, ident[0], ident[1], hp, vp, 1, True).cpu().double()
+    assert torch.equal(out, out_inv)
+
+
+def test_external_distortion_in_the_3dgut_kernels(G):
+    """The windshield model inside the two 3DGUT kernels: (a) the identity polynomials change nothing (the reference's
+    test_identity_distortion_matches_no_distortion / test_ortho_identity_distortion_matches_no_distortion); (b) a real distortion
+    with its exact inverse pair keeps projection and ray generation consistent - the generated ray of the pixel a point projects
+    to passes through the point (pinhole, fisheye); (c) rasterization(external_distortion_coeffs=...) renders."""
+    from gsplat_amd import _ops
+
+    sc, W, H = make_scene(N=1500, C=2, width=96, height=64, seed=23)
+    a = {k: v.to(DEV) for k, v in sc.items()}
+    args = (a["means"], a["quats"], a["scales"], a["opacities"], a["colors"], a["viewmats"], a["Ks"], W, H)
+    ident = _windshield([0.0, 1.0, 0.0], [0.0, 0.0, 1.0])
+    for kw in (dict(), dict(camera_model="ortho")):
+        Ks = a["Ks"].clone()
+        if kw:
+            Ks[:, 0, 0] = Ks[:, 1, 1] = 20.0
+        base = list(args)
+        base[6] = Ks
+        rc0, ra0, _ = G.rasterization(*base, packed=False, with_ut=True, with_eval3d=True, **kw)
+        rc1, ra1, _ = G.rasterization(*base, packed=False, with_ut=True, with_eval3d=True, external_distortion_coeffs=ident, **kw)
+        torch.testing.assert_close(rc1, rc0, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(ra1, ra0, rtol=1e-4, atol=1e-4)
+    # (b) phi' = 1.05 phi + 0.01, theta' = 0.97 theta - 0.02 and its exact inverse
+    fwd = _windshield([0.01, 1.05, 0.0], [-0.02, 0.0, 0.97], [-0.01 / 1.05, 1 / 1.05, 0.0], [0.02 / 0.97, 0.0, 1 / 0.97])
+    for model, name in ((0, "pinhole"), (2, "fisheye")):
+        radii, m2, depths, _, _ = G.fully_fused_projection_with_ut(
+            a["means"], a["quats"], a["scales"] * 0.05, None, a["viewmats"], a["Ks"], W, H, camera_model=name,
+            external_distortion_coeffs=fwd)
+        rays = _ops.camera_pixel_rays(a["viewmats"], None, a["Ks"], W, H, model, 4, None, None, None, None, fwd)
+        vis = (radii > 0).all(-1)
+        assert int(vis.sum()) > 200
+        cam, idx = torch.where(vis)
+        px = m2[cam, idx]
+        ix, iy = px[:, 0].floor().long().clamp(0, W - 1), px[:, 1].floor().long().clamp(0, H - 1)
+        inside = (px[:, 0] >= 0) & (px[:, 0] < W) & (px[:, 1] >= 0) & (px[:, 1] < H)
+        r = rays[cam, iy, ix]
+        to_pt = torch.nn.functional.normalize(a["means"][idx] - r[:, :3], dim=-1)
+        ang = torch.acos((to_pt * r[:, 3:]).sum(-1).clamp(-1, 1))[inside]
+        # the point lies within the pixel the projection names: the angle to the pixel CENTRE's ray is under a pixel's span
+        pixel_span = 1.5 / float(a["Ks"][0, 0, 0])
+        assert float(ang.max()) < pixel_span, (name, float(ang.max()), pixel_span)
+    rc, ra, _ = G.rasterization(*args, packed=False, with_ut=True, with_eval3d=True, external_distortion_coeffs=fwd)
+    assert bool(torch.isfinite(rc).all()) and float(ra.max()) > 0.5

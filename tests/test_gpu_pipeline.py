@@ -154,7 +154,7 @@ def test_rasterization_rejects_out_of_scope_arguments(G):
             assert meta["normals"].shape == (1, H, W, 3) and bool(torch.isfinite(meta["normals"]).all())
     # not built: refused before any kernel launches, never approximated
     with pytest.raises(RuntimeError, match="not supported"):
-        G.rasterization(*args, with_ut=True, with_eval3d=True, packed=False, external_distortion_coeffs=object())
+        G.rasterization(*args, with_ut=True, with_eval3d=True, packed=False, camera_model="lidar", lidar_coeffs=object())
     with pytest.raises(RuntimeError, match="hit-distance render modes require with_eval3d=True"):
         G.rasterization(*args, render_mode="RGB-Ed")
     with pytest.raises(RuntimeError, match="ftheta camera is only supported via UT"):
