@@ -23,7 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FILES = ["test_basic.py", "test_2dgs.py", "test_rasterization.py", "test_sparse_intersect.py", "test_sparse_rasterize.py",
          "test_sparse_tile_layout.py", "test_sparse_num_contributing.py", "test_sparse_contributing_ids.py",
-         "test_sparse_top_contributing.py", "test_mcmc_perturb.py", "test_relocation.py", "test_strategy.py"]
+         "test_sparse_top_contributing.py", "test_mcmc_perturb.py", "test_relocation.py", "test_strategy.py",
+         "test_external_distortion.py"]
 
 # test id -> why it is expected to fail here (anything else that fails is a regression)
 EXPECTED_FAILURES = {
@@ -40,7 +41,7 @@ EXPECTED_FAILURE_PREFIXES = {
 MIN_PASSED = {"test_basic.py": 240, "test_2dgs.py": 18, "test_rasterization.py": 70, "test_sparse_intersect.py": 22,
               "test_sparse_rasterize.py": 22, "test_sparse_tile_layout.py": 18, "test_sparse_num_contributing.py": 11,
               "test_sparse_contributing_ids.py": 8, "test_sparse_top_contributing.py": 8, "test_mcmc_perturb.py": 15,
-              "test_relocation.py": 3, "test_strategy.py": 3}
+              "test_relocation.py": 3, "test_strategy.py": 3, "test_external_distortion.py": 40}
 
 
 def _have_reference():
