@@ -39,9 +39,9 @@ def _load() -> ctypes.CDLL:
 
 _lib = _load()
 
-# signature table: p = pointer (device pointer or NULL), u = uint32, i = int, l = int64, f = float
+# signature table: p = pointer (device pointer or NULL), u = uint32, i = int, l = int64, f = float, d = double
 _P, _U, _I, _L, _F = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int64, ctypes.c_float
-_CODES = {"p": _P, "u": _U, "i": _I, "l": _L, "f": _F}
+_CODES = {"p": _P, "u": _U, "i": _I, "l": _L, "f": _F, "d": ctypes.c_double}
 
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "gsplat_amd.h")
 
@@ -68,6 +68,8 @@ def _parse_header(path: str):
                     codes.append("l")
                 elif a.startswith("float"):
                     codes.append("f")
+                elif a.startswith("double"):
+                    codes.append("d")
                 elif a.startswith("int "):
                     codes.append("i")
                 else:

@@ -267,6 +267,7 @@ COMPOSITE_SCHEMAS = {
 
 # Ops whose schemas name the custom classes but carry no gradient (CUDA key only).
 CLASS_SCHEMAS = {
+    "intersect_tile_lidar": "(__torch__.torch.classes.gsplat.RowOffsetStructuredSpinningLidarModelParametersExt lidar, Tensor means2d, Tensor radii, Tensor depths, Tensor? image_ids, Tensor? gaussian_ids, int? n_images, bool sort, bool segmented) -> (Tensor, Tensor, Tensor)",
     # Unscented-Transform projection of 3DGUT (ext.cpp:1230-1239)
     # from-world compositing of 3DGUT (ext.cpp:1241-1252); differentiable (the body builds its own autograd graph)
     "rasterize_to_pixels_from_world_3dgs": "(Tensor means, Tensor quats, Tensor scales, Tensor colors, Tensor opacities, Tensor? backgrounds, Tensor? masks, int image_width, int image_height, int tile_size, Tensor viewmats0, Tensor? viewmats1, Tensor Ks, int camera_model, __torch__.torch.classes.gsplat.UnscentedTransformParameters ut_params, int rs_type, Tensor? rays, Tensor? radial_coeffs, Tensor? tangential_coeffs, Tensor? thin_prism_coeffs, __torch__.torch.classes.gsplat.FThetaCameraDistortionParameters ftheta_coeffs, __torch__.torch.classes.gsplat.RowOffsetStructuredSpinningLidarModelParametersExt? lidar_coeffs, __torch__.torch.classes.gsplat.BivariateWindshieldModelParameters? external_distortion_params, Tensor tile_offsets, Tensor flatten_ids, bool return_sample_counts, bool use_hit_distance, bool return_normals, int renderer_config, bool return_last_ids, bool unsafe_masked_tile_outputs=False) -> (Tensor, Tensor, Tensor?, Tensor?, Tensor?)",
@@ -842,6 +843,89 @@ def intersect_tile(means2d, radii, depths, conics, opacities, image_ids, gaussia
                    tile_width, tile_height, sort, segmented):
     return isect_finish(isect_begin(means2d, radii, depths, conics, opacities, image_ids, gaussian_ids, n_images,
                                     tile_size, tile_width, tile_height, sort, segmented))
+
+
+def _lidar_tiling_args(lidar, dev):
+    """(fields of view, direction, tiling sizes, the two tables on `dev`) of a RowOffsetStructuredSpinningLidarModelParametersExt."""
+    cdf_el = lidar.cdf_elevation.to(device=dev, dtype=torch.int32).contiguous()
+    raycdf = lidar.cdf_dense_ray_mask.to(device=dev, dtype=torch.int32).contiguous()
+    if cdf_el.dim() != 1 or raycdf.dim() != 2 or raycdf.shape[0] != cdf_el.shape[0]:
+        raise RuntimeError("lidar tiling: cdf_elevation [R + 1] and cdf_dense_ray_mask [R + 1, A + 1] expected")
+    return ((float(lidar.fov_horiz_rad.start), float(lidar.fov_horiz_rad.span), float(lidar.fov_vert_rad.start),
+             float(lidar.fov_vert_rad.span), int(lidar.spinning_direction), int(lidar.n_bins_azimuth), int(lidar.n_bins_elevation),
+             int(raycdf.shape[1] - 1), int(raycdf.shape[0] - 1), ptr(cdf_el), ptr(raycdf)), (cdf_el, raycdf))
+
+
+@_op("intersect_tile_lidar")
+def intersect_tile_lidar(lidar, means2d, radii, depths, image_ids, gaussian_ids, n_images, sort, segmented):
+    """gsplat::intersect_tile_lidar (Intersect.cpp:388-520): tiles of a spinning lidar's angular tiling touched by every
+    Gaussian's (azimuth x elevation) box; same outputs as intersect_tile."""
+    packed = means2d.dim() == 2
+    if packed:
+        if image_ids is None or gaussian_ids is None:
+            raise RuntimeError("When packed is set, image_ids and gaussian_ids must be provided.")
+        if n_images is None:
+            raise RuntimeError("n_images is required when means2d is packed ([nnz, 2]).")
+        if segmented:
+            raise RuntimeError("segmented sort is not supported for packed inputs")
+        I = int(n_images)
+        if means2d.shape[-1] != 2 or tuple(radii.shape) != tuple(means2d.shape) or tuple(depths.shape) != (means2d.shape[0],):
+            raise RuntimeError(f"means2d must be [nnz, 2] with matching radii / depths, got {tuple(means2d.shape)}")
+        n_per = 1
+    else:
+        if means2d.dim() < 2 or means2d.shape[-1] != 2:
+            raise RuntimeError(f"means2d must be [..., N, 2], got {tuple(means2d.shape)}")
+        if tuple(radii.shape) != tuple(means2d.shape):
+            raise RuntimeError(f"radii must be [..., N, 2] matching means2d, got {tuple(radii.shape)}")
+        if tuple(depths.shape) != tuple(means2d.shape[:-1]):
+            raise RuntimeError(f"depths must be [..., N], got {tuple(depths.shape)}")
+        I = math.prod(means2d.shape[:-2])
+        n_per = means2d.shape[-2]
+    n_tiles = int(lidar.n_bins_azimuth) * int(lidar.n_bins_elevation)
+    tile_bits, image_bits = bits_for_count(n_tiles), bits_for_count(I)
+    if tile_bits + image_bits > 32:
+        raise RuntimeError(f"intersect_tile_lidar: (image, tile) id packing needs {tile_bits + image_bits} bits but only 32 are "
+                           f"available (I={I}, n_tiles={n_tiles}).")
+    dev = means2d.device
+    _check_f32(means2d=means2d, depths=depths)
+    means2d, depths = means2d.contiguous(), depths.contiguous()
+    radii = radii.contiguous()
+    if radii.dtype not in (torch.int32, torch.float32):
+        radii = radii.to(torch.float32) if radii.is_floating_point() else radii.to(torch.int32)
+    r_i, r_f = (ptr(radii), None) if radii.dtype == torch.int32 else (None, ptr(radii))
+    rows = depths.numel()
+    tiles_per_gauss = torch.empty(depths.shape, device=dev, dtype=torch.int32)
+    empty = (tiles_per_gauss, torch.empty(0, device=dev, dtype=torch.int64), torch.empty(0, device=dev, dtype=torch.int32))
+    if rows == 0:
+        return empty
+    targs, _keep = _lidar_tiling_args(lidar, dev)
+    n_per_arg = max(int(n_per), 1)
+    call("gsx_isect_lidar_count", ptr(means2d), r_i, r_f, rows, n_per_arg, *targs, ptr(tiles_per_gauss))
+    cum = torch.cumsum(tiles_per_gauss.reshape(-1), 0, dtype=torch.int64)
+    n_isects = int(cum[-1].item())  # host sync: exact-length outputs, like the reference (Intersect.cpp:470-480)
+    if n_isects >= 2**31:
+        raise RuntimeError(f"intersect_tile_lidar: {n_isects} intersections overflow the int32 index space")
+    if n_isects == 0:
+        return empty
+    isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
+    flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
+    img = image_ids.contiguous().to(torch.int64) if packed else None
+    call("gsx_isect_lidar_emit", ptr(means2d), r_i, r_f, ptr(depths), ptr(img), ptr(cum), rows, n_per_arg, I, *targs,
+         ptr(isect_ids), ptr(flatten_ids))
+    if sort:
+        tw, th = int(lidar.n_bins_azimuth), int(lidar.n_bins_elevation)
+        if _cabi.tile_sort_supported(I, tw, th):
+            keys_s, vals_s = torch.empty_like(isect_ids), torch.empty_like(flatten_ids)
+            ws = torch.empty(_cabi.tile_sort_workspace_bytes(n_isects, I, tw, th), device=dev, dtype=torch.uint8)
+            call("gsx_isect_tile_sort", ptr(isect_ids), ptr(flatten_ids), n_isects, I, tw, th, ptr(keys_s), ptr(vals_s), ptr(ws),
+                 ws.numel())
+            isect_ids, flatten_ids = keys_s, vals_s
+        else:
+            keys_alt, vals_alt = torch.empty_like(isect_ids), torch.empty_like(flatten_ids)
+            ws = torch.empty(_cabi.sort_workspace_bytes(n_isects), device=dev, dtype=torch.uint8)
+            if _cabi.sort_pairs(isect_ids, flatten_ids, keys_alt, vals_alt, n_isects, 32 + tile_bits + image_bits, ws):
+                isect_ids, flatten_ids = keys_alt, vals_alt
+    return tiles_per_gauss, isect_ids, flatten_ids
 
 
 @_op("intersect_offset")

@@ -181,5 +181,12 @@ TORCH_LIBRARY_FRAGMENT(gsplat, m)
         .def_readwrite("spinning_frequency_hz", &LP::spinning_frequency_hz)
         .def_readwrite("fov_eps_rad", &LP::fov_eps_rad)
         .def_readwrite("n_bins_azimuth", &LP::n_bins_azimuth)
-        .def_readwrite("n_bins_elevation", &LP::n_bins_elevation);
+        .def_readwrite("n_bins_elevation", &LP::n_bins_elevation)
+        .def_readwrite("fov_vert_rad", &LP::fov_vert_rad)
+        .def_readwrite("fov_horiz_rad", &LP::fov_horiz_rad)
+        .def_readwrite("angles_to_columns_map", &LP::angles_to_columns_map)
+        .def_readwrite("cdf_elevation", &LP::cdf_elevation)
+        .def_readwrite("cdf_dense_ray_mask", &LP::cdf_dense_ray_mask)
+        .def_readwrite("tiles_pack_info", &LP::tiles_pack_info)
+        .def_readwrite("tiles_to_elements_map", &LP::tiles_to_elements_map);
 }

@@ -402,6 +402,27 @@ int gsx_distort_camera_rays(const float *rays, int64_t n, const float *horizonta
                             void *stream);
 int gsx_eval_bivariate_poly(const float *x, const float *y, int64_t n, const float *poly, float *out, void *stream);
 
+/* Tile intersection of spinning-lidar cameras: gsplat::intersect_tile_lidar (ext.cpp:1037-1040; Intersect.cpp:388-520;
+ * IntersectTileLidar.cu:136-415; torch statement gsplat/cuda/_torch_impl_lidar.py:34-394). means2d / radii are azimuth |
+ * elevation in ANGULAR PIXELS (angle * 1024); radii as int32 (what the projection writes) or float (one of the two pointers);
+ * the tiling of RowOffsetStructuredSpinningLidarModelParametersExt: fields of view (radians; python doubles), spinning direction
+ * (1 = counter-clockwise), n_bins_{azimuth,elevation}, cdf_elevation int32 [res_el + 1], cdf_dense_ray_mask int32
+ * [res_el + 1][res_az + 1] (summed-area table of the rays). count -> tiles_per_gauss int32 [rows]; the caller takes its INCLUSIVE
+ * prefix sum (int64) and calls emit, which writes (image | tile | depth bits) keys and row ids in the order of the torch
+ * statement (elevation-major, region A before region B); the keys then go through gsx_isect_tile_sort / gsx_sort_pairs with
+ * tile_width = n_bins_azimuth, tile_height = n_bins_elevation. */
+int gsx_isect_lidar_count(const float *means2d, const int32_t *radii_i32, const float *radii_f32, int64_t rows,
+                          int64_t n_per_image, double fov_horiz_start, double fov_horiz_span, double fov_vert_start,
+                          double fov_vert_span, int spinning_ccw, uint32_t n_bins_azimuth, uint32_t n_bins_elevation,
+                          uint32_t cdf_resolution_azimuth, uint32_t cdf_resolution_elevation, const int32_t *cdf_elevation,
+                          const int32_t *cdf_dense_ray_mask, int32_t *tiles_per_gauss, void *stream);
+int gsx_isect_lidar_emit(const float *means2d, const int32_t *radii_i32, const float *radii_f32, const float *depths,
+                         const int64_t *image_ids, const int64_t *cum_tiles, int64_t rows, int64_t n_per_image,
+                         uint32_t n_images, double fov_horiz_start, double fov_horiz_span, double fov_vert_start,
+                         double fov_vert_span, int spinning_ccw, uint32_t n_bins_azimuth, uint32_t n_bins_elevation,
+                         uint32_t cdf_resolution_azimuth, uint32_t cdf_resolution_elevation, const int32_t *cdf_elevation,
+                         const int32_t *cdf_dense_ray_mask, int64_t *isect_ids, int32_t *flatten_ids, void *stream);
+
 /* assemble_proj_features_unpacked_fwd: gsplat::assemble_proj_features_unpacked_fwd (ext.cpp:1015-1020; host
  * SphericalHarmonics.cpp:572-676; kernel SphericalHarmonicsCUDA.cu:1100-1250). Dense rows only. Writes
  * out [B,C,N, Dc + E + has_depth] = [ post(SH colours of coeffs [N,K,Dc]) | extra (+0.5 when extra_post == 1) | depth ]
