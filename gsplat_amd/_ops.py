@@ -2114,6 +2114,101 @@ def fisheye_max_angle(radial_coeffs: Tensor, Ks: Tensor, width: int, height: int
     return torch.minimum(angle, torch.maximum(corner / fx, corner / fy))
 
 
+def _lidar_fov_args(lidar):
+    return (float(lidar.fov_horiz_rad.start), float(lidar.fov_horiz_rad.span), float(lidar.fov_vert_rad.start),
+            float(lidar.fov_vert_rad.span))
+
+
+def _lidar_angle_map(lidar, dev):
+    """angles_to_columns_map as int32 on `dev` (it maps a relative (elevation, azimuth) to the column that fires there)."""
+    m = lidar.angles_to_columns_map
+    if m is None or m.numel() == 0:
+        return None
+    return m.to(device=dev, dtype=torch.int32).contiguous()
+
+
+def _projection_ut_lidar(means, quats, scales, opacities, viewmats0, viewmats1, Ks, eps2d, near_plane, far_plane, radius_clip,
+                         calc_compensations, global_z_order, ut_params, rs_type, lidar, radial_coeffs, tangential_coeffs,
+                         thin_prism_coeffs, external_distortion_params):
+    """projection_ut_3dgs_fused for a spinning lidar (gsx_project_ut_lidar_fwd): means2d / radii come out in angular pixels
+    (azimuth, elevation) * 1024."""
+    if radial_coeffs is not None or tangential_coeffs is not None or thin_prism_coeffs is not None \
+            or external_distortion_params is not None:
+        raise RuntimeError("the lidar camera model takes no distortion coefficients")
+    rolling = rs_type != _ROLLING_SHUTTER_GLOBAL
+    if rolling and viewmats1 is None:
+        raise ValueError("a rolling shutter needs viewmats_rs (the pose at the end of the frame)")
+    _check_f32(means=means, quats=quats, scales=scales, opacities=opacities, viewmats=viewmats0, viewmats_rs=viewmats1, Ks=Ks)
+    batch = tuple(means.shape[:-2])
+    N, C, B = means.shape[-2], viewmats0.shape[-3], math.prod(means.shape[:-2])
+    alpha, beta, kappa, margin, all_valid = 0.1, 2.0, 0.0, 0.1, False  # Cameras.h:59-64
+    if ut_params is not None:
+        alpha, beta, kappa = float(ut_params.alpha), float(ut_params.beta), float(ut_params.kappa)
+        margin, all_valid = float(ut_params.in_image_margin_factor), bool(ut_params.require_all_sigma_points_valid)
+    dev, dt = means.device, means.dtype
+    radii = torch.empty(batch + (C, N, 2), device=dev, dtype=torch.int32)
+    means2d = torch.empty(batch + (C, N, 2), device=dev, dtype=dt)
+    depths = torch.empty(batch + (C, N), device=dev, dtype=dt)
+    conics = torch.empty(batch + (C, N, 3), device=dev, dtype=dt)
+    comps = torch.empty(batch + (C, N), device=dev, dtype=dt) if calc_compensations else None
+    amap = _lidar_angle_map(lidar, dev) if rolling else None
+    mh, mw = (int(amap.shape[0]), int(amap.shape[1])) if amap is not None else (0, 0)
+    call("gsx_project_ut_lidar_fwd", ptr(means.contiguous()), ptr(quats.contiguous()), ptr(scales.contiguous()),
+         ptr(_c(opacities)), ptr(viewmats0.contiguous()), ptr(_c(viewmats1)) if rolling else None, ptr(Ks.contiguous()),
+         *_lidar_fov_args(lidar), int(lidar.spinning_direction), ptr(amap), mh, mw, int(lidar.column_azimuths_rad.shape[0]), B, C,
+         N, float(eps2d), float(near_plane), float(far_plane), float(radius_clip), int(rs_type), int(bool(global_z_order)), alpha,
+         beta, kappa, margin, int(all_valid), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(comps))
+    return radii, means2d, depths, conics, comps
+
+
+def lidar_element_rays(viewmats: Tensor, viewmats_rs: Optional[Tensor], lidar, rs_type: int = 4) -> Tensor:
+    """[..., C, n_rows, n_columns, 6]: world ray of every element of a spinning lidar (gsx_lidar_rays) - the rays the reference's
+    from-world kernels derive per thread for lidar elements; the zero ray outside the fields of view."""
+    lead = tuple(viewmats.shape[:-2])
+    dev, dt = viewmats.device, viewmats.dtype
+    rolling = rs_type != 4
+    if rolling and (viewmats_rs is None or viewmats_rs.shape != viewmats.shape):
+        raise ValueError("a rolling shutter needs viewmats_rs of the shape of viewmats")
+    rows = lidar.row_elevations_rad.to(device=dev, dtype=torch.float32).contiguous()
+    cols = lidar.column_azimuths_rad.to(device=dev, dtype=torch.float32).contiguous()
+    offs = lidar.row_azimuth_offsets_rad.to(device=dev, dtype=torch.float32).contiguous()
+    amap = _lidar_angle_map(lidar, dev) if rolling else None
+    mh, mw = (int(amap.shape[0]), int(amap.shape[1])) if amap is not None else (0, 0)
+    rays = torch.empty(lead + (rows.shape[0], cols.shape[0], 6), device=dev, dtype=dt)
+    call("gsx_lidar_rays", ptr(viewmats.contiguous()), ptr(_c(viewmats_rs)) if rolling else None, ptr(rows), ptr(cols), ptr(offs),
+         math.prod(lead), int(rows.shape[0]), int(cols.shape[0]), *_lidar_fov_args(lidar), float(lidar.fov_eps_rad),
+         int(lidar.spinning_direction), ptr(amap), mh, mw, int(rs_type), ptr(rays))
+    return rays
+
+
+def _lidar_virtual_layout(lidar, dev):
+    """Elements of a lidar tile -> pixels of a square VIRTUAL tile, so that the from-world kernels (square pixel tiles) composite
+    lidar tiles unchanged: tile t of the lidar's tiling (n_bins_elevation x n_bins_azimuth, tiles_pack_info = (first, count) into
+    tiles_to_elements_map = (column, row) pairs; RasterizeToPixelsFromWorld3DGS.cuh:262-330) becomes the S x S block t of a
+    virtual image, its e-th element the block's e-th pixel; the other pixels carry the zero ray (no samples). Returns
+    (S, virtual width, virtual height, element index [K], virtual pixel index [K])."""
+    pack = lidar.tiles_pack_info.to(device=dev, dtype=torch.int64)
+    emap = lidar.tiles_to_elements_map.to(device=dev, dtype=torch.int64)
+    tw, th = int(lidar.n_bins_azimuth), int(lidar.n_bins_elevation)
+    if pack.shape != (tw * th, 2) or emap.dim() != 2 or emap.shape[1] != 2:
+        raise RuntimeError("lidar tiling: tiles_pack_info [n_tiles, 2] and tiles_to_elements_map [n_elements, 2] expected")
+    most = int(pack[:, 1].max().item()) if pack.numel() else 0
+    if most > 256:
+        raise NotImplementedError(f"gsplat_amd: lidar tiles of up to 256 elements are built, this tiling has {most}")
+    S = 8 if most <= 64 else 16
+    n_cols = int(lidar.column_azimuths_rad.shape[0])
+    e = torch.arange(S * S, device=dev)
+    valid = e[None, :] < pack[:, 1:2]                                        # [T, S*S]
+    src = (pack[:, 0:1] + e[None, :]).clamp_(max=max(emap.shape[0] - 1, 0))  # [T, S*S] rows of the element map
+    elem = emap[src]                                                         # [T, S*S, 2] (column, row)
+    elem_flat = elem[..., 1] * n_cols + elem[..., 0]
+    t = torch.arange(tw * th, device=dev)
+    vy = (t // tw)[:, None] * S + e[None, :] // S
+    vx = (t % tw)[:, None] * S + e[None, :] % S
+    virt_flat = vy * (tw * S) + vx
+    return S, tw * S, th * S, elem_flat[valid], virt_flat[valid]
+
+
 @_op("projection_ut_3dgs_fused")
 def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmats1, Ks, image_width, image_height,
                              eps2d, near_plane, far_plane, radius_clip, calc_compensations, camera_model, global_z_order,
@@ -2127,11 +2222,16 @@ def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmat
         raise ValueError("a rolling shutter needs viewmats_rs (the pose at the end of the frame)")
     if rs_type not in (0, 1, 2, 3, 4):
         raise ValueError(f"unknown rolling shutter type {rs_type}")
-    if camera_model not in (0, 1, 2, 3):
-        raise NotImplementedError(f"gsplat_amd: UT projection is built for pinhole, ortho, fisheye and f-theta cameras, not "
+    if camera_model not in (0, 1, 2, 3, 4):
+        raise NotImplementedError(f"gsplat_amd: UT projection is built for pinhole, ortho, fisheye, f-theta and lidar cameras, not "
                                   f"'{_CAMERA_MODEL_NAMES.get(camera_model, camera_model)}'")
-    if lidar_coeffs is not None:
-        raise NotImplementedError("gsplat_amd: lidar UT projection is not built")
+    if (camera_model == 4) != (lidar_coeffs is not None):
+        raise RuntimeError("Lidar coefficients must be given for lidar camera model" if camera_model == 4 else
+                           "lidar_coeffs given but camera_model is not lidar")
+    if camera_model == 4:
+        return _projection_ut_lidar(means, quats, scales, opacities, viewmats0, viewmats1, Ks, eps2d, near_plane, far_plane,
+                                    radius_clip, calc_compensations, global_z_order, ut_params, rs_type, lidar_coeffs,
+                                    radial_coeffs, tangential_coeffs, thin_prism_coeffs, external_distortion_params)
     _check_f32(means=means, quats=quats, scales=scales, opacities=opacities, viewmats=viewmats0, viewmats_rs=viewmats1, Ks=Ks,
                radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs, thin_prism_coeffs=thin_prism_coeffs)
     batch = tuple(means.shape[:-2])
@@ -2534,6 +2634,60 @@ class _FromWorldCompositing(torch.autograd.Function):
         return (v_means, v_quats, v_scales, v_cols, v_opac, v_rays, v_bg) + (None,) * (9 + ctx.n_tracked)
 
 
+def _from_world_lidar(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, viewmats0,
+                      viewmats1, rs_type, rays, lidar, tile_offsets, flatten_ids, return_sample_counts, use_hit_distance,
+                      return_normals, return_last_ids):
+    """The from-world rasterizer for a spinning lidar: the "image" is [n_rows, n_columns] ELEMENTS, a tile of the lidar's tiling
+    holds an arbitrary set of them (tiles_to_elements_map). The elements of a tile are laid out as the pixels of a square
+    virtual tile (_lidar_virtual_layout), the compositing kernels run on the virtual image unchanged, and the results are
+    carried back to the elements; the index moves are differentiable torch ops, so the rays' and every other gradient follow."""
+    batch = tuple(means.shape[:-2])
+    N, C, D = means.shape[-2], viewmats0.shape[-3], colors.shape[-1]
+    lead = batch + (C,)
+    I = math.prod(lead)
+    dev, dt = means.device, means.dtype
+    n_rows, n_cols = int(lidar.row_elevations_rad.shape[0]), int(lidar.column_azimuths_rad.shape[0])
+    if (int(image_width), int(image_height)) != (n_cols, n_rows):
+        raise RuntimeError(f"a lidar renders [n_rows, n_columns] = [{n_rows}, {n_cols}] elements, got height {image_height}, "
+                           f"width {image_width}")
+    if colors.shape != batch + (C, N, D) or opacities.shape != batch + (C, N):
+        raise ValueError("eval3d takes dense rows: colors [..., C, N, D] and opacities [..., C, N]")
+    P = n_rows * n_cols
+    if rays is None:
+        with torch.no_grad():
+            rays = lidar_element_rays(viewmats0, viewmats1, lidar, int(rs_type))
+    elif rays.numel() != I * P * 6 or rays.shape[-1] != 6:
+        raise ValueError(f"rays must be [..., C, n_rows * n_columns, 6], got {tuple(rays.shape)}")
+    _check_f32(means=means, quats=quats, scales=scales, colors=colors, opacities=opacities, rays=rays)
+    S, VW, VH, eidx, vidx = _lidar_virtual_layout(lidar, dev)
+    th, tw = tile_offsets.shape[-2], tile_offsets.shape[-1]
+    if (tw * S, th * S) != (VW, VH):
+        raise RuntimeError(f"tile_offsets must be [..., C, n_bins_elevation, n_bins_azimuth], got {tuple(tile_offsets.shape)}")
+    rays_e = rays.reshape(I, P, 6)
+    rays_v = torch.zeros((I, VH * VW, 6), device=dev, dtype=dt).index_copy(1, vidx, rays_e.index_select(1, eidx))
+    out = _FromWorldCompositing.apply(
+        means, quats, scales, colors, opacities, rays_v.reshape(lead + (VH, VW, 6)), backgrounds, masks, VW, VH, S,
+        tile_offsets, flatten_ids, bool(return_sample_counts), bool(use_hit_distance), bool(return_normals),
+        *[t for t in (viewmats0, viewmats1) if isinstance(t, Tensor)])
+    renders_v, alphas_v, last_v, counts_v, normals_v = out
+
+    def to_elements(x_v, k, base):  # [..., C, VH, VW(, k)] -> [..., C, n_rows, n_columns(, k)]
+        x = base.index_copy(1, eidx, x_v.reshape(I, VH * VW, k).index_select(1, vidx))
+        return x.reshape(lead + (n_rows, n_cols) + ((k,) if x_v.dim() > len(lead) + 2 else ()))
+
+    base_c = torch.zeros((I, P, D), device=dev, dtype=dt)
+    if backgrounds is not None:  # an element no tile holds shows its background
+        base_c = base_c + backgrounds.reshape(I, 1, D)
+    renders = to_elements(renders_v, D, base_c)
+    alphas = to_elements(alphas_v, 1, torch.zeros((I, P, 1), device=dev, dtype=dt))
+    last_ids = to_elements(last_v[..., None], 1, torch.full((I, P, 1), -1, device=dev, dtype=torch.int32))[..., 0] \
+        if return_last_ids else None
+    counts = to_elements(counts_v[..., None], 1, torch.zeros((I, P, 1), device=dev, dtype=torch.int32))[..., 0] \
+        if return_sample_counts else None
+    normals = to_elements(normals_v, 3, torch.zeros((I, P, 3), device=dev, dtype=dt)) if return_normals else None
+    return renders, alphas, last_ids, counts, normals
+
+
 @_op("rasterize_to_pixels_from_world_3dgs")
 def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities, backgrounds, masks, image_width,
                                         image_height, tile_size, viewmats0, viewmats1, Ks, camera_model, ut_params, rs_type,
@@ -2549,11 +2703,15 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
         raise ValueError(f"unknown renderer_config {renderer_config}")
     # renderer_config 1 (PARALLEL_BATCH, Rasterization.cpp:106-117) is a scheduling choice of the reference (its lists split over
     # several CTAs); this backend has one schedule, the results are the same
-    if lidar_coeffs is not None:
-        raise NotImplementedError("gsplat_amd: lidar eval3d is not built")
     rolling = rs_type != _ROLLING_SHUTTER_GLOBAL
     if rolling and viewmats1 is None:
         raise ValueError("a rolling shutter needs viewmats_rs (the pose at the end of the frame)")
+    if (camera_model == 4) != (lidar_coeffs is not None):
+        raise RuntimeError("Lidar coefficients must be given if and only if camera model is lidar")
+    if camera_model == 4:
+        return _from_world_lidar(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height,
+                                 viewmats0, viewmats1 if rolling else None, rs_type, rays, lidar_coeffs, tile_offsets, flatten_ids,
+                                 return_sample_counts, use_hit_distance, return_normals, return_last_ids)
     if rays is None:
         if camera_model not in (0, 1, 2, 3):
             raise NotImplementedError(f"gsplat_amd: eval3d generates rays for pinhole, ortho, fisheye and f-theta cameras, not "
@@ -2568,8 +2726,9 @@ def rasterize_to_pixels_from_world_3dgs(means, quats, scales, colors, opacities,
     if colors.shape != batch + (C, N, D) or opacities.shape != batch + (C, N):
         raise ValueError("eval3d takes dense rows: colors [..., C, N, D] and opacities [..., C, N]")
     image_dims, I, th, tw, _ = _raster_dims(tile_offsets, colors)
-    if tuple(rays.shape[-3:]) != (image_height, image_width, 6) or rays.numel() != I * image_height * image_width * 6:
-        raise ValueError(f"rays must be [..., C, H, W, 6], got {tuple(rays.shape)}")
+    if rays.numel() != I * image_height * image_width * 6 or rays.shape[-1] != 6:
+        raise ValueError(f"rays must be [..., C, H, W, 6] (or [..., C, H * W, 6]), got {tuple(rays.shape)}")
+    rays = rays.reshape(batch + (C, int(image_height), int(image_width), 6))
     renders, alphas, last_ids, counts, normals = _FromWorldCompositing.apply(
         means, quats, scales, colors, opacities, rays, backgrounds, masks, int(image_width), int(image_height),
         int(tile_size), tile_offsets, flatten_ids, bool(return_sample_counts), bool(use_hit_distance), bool(return_normals),

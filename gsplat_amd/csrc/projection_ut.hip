@@ -43,6 +43,11 @@ struct ProjUtArgs {
     float ft_max_angle, ft_c, ft_d, ft_e;
     // external (windshield) distortion, one record per call (ExternalDistortion.h / .cuh: BivariateWindshieldModel): bivariate
     // polynomials of the ray's two angles, order 5 layout (21 coefficients, lower orders zero-padded by the caller)
+    // spinning lidar (camera_model 4; Lidars.cuh, gsplat/cuda/_torch_lidars.py): the "image" is (azimuth, elevation) * 1024
+    float ld_h0, ld_hs, ld_v0, ld_vs; // fields of view: start and span, radians
+    int ld_ccw;                       // spinning direction: 1 = counter-clockwise
+    const int32_t *ld_map;            // angles_to_columns_map [ld_map_h][ld_map_w] (rolling shutter: angle -> column -> time)
+    int ld_map_h, ld_map_w, ld_columns;
     int ext;                      // 0: none
     float ext_h[21], ext_v[21];   // forward (distort): horizontal, vertical
     float ext_hi[21], ext_vi[21]; // inverse (undistort)
@@ -57,6 +62,14 @@ struct UtDistortion {
     float k[6], p[2], s[4];
     float max_angle;
 };
+
+// torch.remainder on floats (the result takes the sign of the divisor): the lidar's relative azimuth
+__device__ __forceinline__ float lidar_mod(float x, float period)
+{
+    float m = fmodf(x, period);
+    if (m != 0.0f && ((period < 0.0f) != (m < 0.0f))) m += period;
+    return m;
+}
 
 // ---- external distortion: the bivariate windshield model (restated from ExternalDistortion.cuh:64-92, 168-205 and its Python
 // statement gsplat/cuda/_torch_external_distortion.py:38-77). A ray is described by the two angles phi = asin(x / |r|),
@@ -116,6 +129,16 @@ __device__ __forceinline__ bool ut_project_point(const ProjUtArgs &a, const Cam 
 __device__ __forceinline__ bool ut_project_point_model(const ProjUtArgs &a, const Cam &c, const UtDistortion &d, const float *p,
                                                  float &px, float &py)
 {
+    if (a.camera_model == 4) { // spinning lidar: image point = (azimuth, elevation) in angular pixels; valid inside the fields of view
+        const float n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+        const float inv = n2 > 0.0f ? 1.0f / sqrtf(n2) : 0.0f;
+        const float az = atan2f(p[1] * inv, p[0] * inv), el = asinf(p[2] * inv);
+        px = az * 1024.0f;
+        py = el * 1024.0f;
+        const float rel_az = lidar_mod(a.ld_ccw ? az - a.ld_h0 : a.ld_h0 - az, 6.2831855f), rel_el = a.ld_v0 - el;
+        const float m_el = a.margin * a.ld_vs, m_az = a.margin * a.ld_hs;
+        return (rel_el <= a.ld_vs + m_el) && (rel_az <= a.ld_hs + m_az) && (rel_el >= -m_el) && (rel_az >= -m_az);
+    }
     const bool front = p[2] > 0.0f;
     bool ok          = front;
     float u, v;
@@ -249,6 +272,16 @@ __device__ __forceinline__ UtPose ut_interpolate_pose(const UtPose &p0, const Ut
 }
 __device__ __forceinline__ float ut_relative_frame_time(const ProjUtArgs &a, float px, float py)
 {
+    if (a.camera_model == 4) { // lidar: the column that fires at this angle (looked up in the angle map) / (columns - 1)
+        if (a.rs_type == 4 || !a.ld_map) return 0.0f;
+        const float kToAngle = 1.0f / 1024.0f;
+        const float az = px * kToAngle, el = py * kToAngle;
+        const float rel_az = lidar_mod(a.ld_ccw ? az - a.ld_h0 : a.ld_h0 - az, 6.2831855f), rel_el = a.ld_v0 - el;
+        const float res_h = a.ld_hs / (float)(a.ld_map_w - 1), res_v = a.ld_vs / (float)(a.ld_map_h - 1);
+        const int iv = (int)fminf(fmaxf(rel_el / res_v + 0.5f, 0.0f), (float)(a.ld_map_h - 1));
+        const int ih = (int)fminf(fmaxf(rel_az / res_h + 0.5f, 0.0f), (float)(a.ld_map_w - 1));
+        return (float)a.ld_map[(size_t)iv * a.ld_map_w + ih] / (float)(a.ld_columns - 1);
+    }
     const float W = (float)a.width, H = (float)a.height;
     switch (a.rs_type) {
     case 0: return a.height > 1 ? floorf(py) / (H - 1.0f) : 0.5f;
@@ -434,7 +467,8 @@ __global__ void __launch_bounds__(256) project_ut_kernel(const ProjUtArgs a)
     const float rx = ceilf(fminf(extend * sqrtf(fmaxf(cxx, 0.0f)), r_eig));
     const float ry = ceilf(fminf(extend * sqrtf(fmaxf(cyy, 0.0f)), r_eig));
     valid = valid && (fmaxf(rx, ry) > a.radius_clip);
-    valid = valid && (mx + rx > 0.0f) && (mx - rx < (float)a.width) && (my + ry > 0.0f) && (my - ry < (float)a.height);
+    if (a.camera_model != 4) // (a lidar's sigma points were tested against its fields of view)
+        valid = valid && (mx + rx > 0.0f) && (mx - rx < (float)a.width) && (my + ry > 0.0f) && (my - ry < (float)a.height);
     if (!valid) {
         write_invalid();
         return;
@@ -641,6 +675,19 @@ static void set_external_distortion(gsx::ProjUtArgs &a, const float *ext)
     }
 }
 
+struct LidarHost { // the lidar record of one call (fields of view in radians; the angle -> column map lives on the device)
+    double h0, hs, v0, vs;
+    int ccw;
+    const int32_t *map;
+    int map_h, map_w, n_columns;
+};
+static void set_lidar(gsx::ProjUtArgs &a, const LidarHost *l)
+{
+    if (!l) return;
+    a.ld_h0 = (float)l->h0; a.ld_hs = (float)l->hs; a.ld_v0 = (float)l->v0; a.ld_vs = (float)l->vs;
+    a.ld_ccw = l->ccw ? 1 : 0; a.ld_map = l->map; a.ld_map_h = l->map_h; a.ld_map_w = l->map_w; a.ld_columns = l->n_columns;
+}
+
 static int project_ut_launch(const float *means, const float *quats, const float *scales, const float *opacities,
                              const float *viewmats, const float *Ks, const float *radial, const float *tangential,
                              const float *thin_prism, const float *fisheye_max_angle, const float *ftheta, uint32_t B, uint32_t C,
@@ -648,7 +695,7 @@ static int project_ut_launch(const float *means, const float *quats, const float
                              float radius_clip, int camera_model, float ut_alpha, float ut_beta, float ut_kappa,
                              float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii, float *means2d,
                              float *depths, float *conics, float *compensations, void *stream, const float *viewmats1 = nullptr,
-                             int rs_type = 4, int global_z_order = 1, const float *ext = nullptr)
+                             int rs_type = 4, int global_z_order = 1, const float *ext = nullptr, const LidarHost *lidar = nullptr)
 {
     using namespace gsx;
     GSX_REQUIRE(rs_type >= 0 && rs_type <= 4, "gsx_project_ut_rs_fwd: rolling shutter type %d (0 .. 3 rolling, 4 global)", rs_type);
@@ -657,9 +704,13 @@ static int project_ut_launch(const float *means, const float *quats, const float
     if (rows == 0) return GSX_OK;
     GSX_REQUIRE(means && quats && scales && viewmats && Ks, "gsx_project_ut_fwd: null input");
     GSX_REQUIRE(radii && means2d && depths && conics, "gsx_project_ut_fwd: null output");
-    GSX_REQUIRE(camera_model >= 0 && camera_model <= 3,
-                "gsx_project_ut_fwd: camera model %d is not built (pinhole = 0, orthographic = 1, fisheye = 2 and f-theta = 3 are)",
+    GSX_REQUIRE(camera_model >= 0 && camera_model <= 4,
+                "gsx_project_ut_fwd: camera model %d is not built (pinhole = 0, orthographic = 1, fisheye = 2, f-theta = 3, lidar = 4 are)",
                 camera_model);
+    GSX_REQUIRE((camera_model == 4) == (lidar != nullptr), "gsx_project_ut_fwd: the lidar model (4) goes through gsx_project_ut_lidar_fwd");
+    GSX_REQUIRE(camera_model != 4 || (!radial && !tangential && !thin_prism && !ext), "gsx_project_ut_lidar_fwd: a lidar takes no distortion coefficients");
+    GSX_REQUIRE(camera_model != 4 || rs_type == 4 || (lidar->map && lidar->map_h > 1 && lidar->map_w > 1 && lidar->n_columns > 1),
+                "gsx_project_ut_lidar_fwd: a rolling shutter needs the angles_to_columns_map");
     GSX_REQUIRE(camera_model != 1 || (!radial && !tangential && !thin_prism),
                 "gsx_project_ut_fwd: the orthographic model takes no distortion coefficients");
     GSX_REQUIRE(camera_model != 2 || (fisheye_max_angle && !tangential && !thin_prism),
@@ -687,8 +738,9 @@ static int project_ut_launch(const float *means, const float *quats, const float
     a.margin = in_image_margin_factor;
     a.viewmats1 = rs_type == 4 ? nullptr : viewmats1; a.rs_type = rs_type;
     set_external_distortion(a, ext);
+    set_lidar(a, lidar);
     a.depth_is_distance = global_z_order ? 0 : 1;
-    a.radial_cull = (!global_z_order && camera_model == 3) ? 1 : 0; // (lidar too in the reference; not built here)
+    a.radial_cull = (!global_z_order && (camera_model == 3 || camera_model == 4)) ? 1 : 0; // models that accept rays with z <= 0
     a.radii = radii; a.means2d = means2d; a.depths = depths; a.conics = conics; a.compensations = compensations;
     project_ut_kernel<<<dim3((uint32_t)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
     return check_launch("project_ut_fwd");
@@ -857,4 +909,110 @@ extern "C" int gsx_eval_bivariate_poly(const float *x, const float *y, int64_t n
     for (int i = 0; i < 21; ++i) p.c[i] = poly[i];
     bivariate_poly_kernel<<<dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(x, y, p, out, n);
     return check_launch("eval_bivariate_poly");
+}
+
+// Spinning-lidar cameras (camera_model 4; Lidars.cuh:40-330, gsplat/cuda/_torch_lidars.py:214-374): a sigma point's image point is
+// (azimuth, elevation) * 1024, valid inside the fields of view (+ the UT margin); no image-bounds culling; radial near / far
+// culling and depth with global_z_order = 0; a rolling shutter reads the time of an angle off `angles_to_columns_map`
+// (int32 [map_h][map_w] on the device; NULL with rs_type 4). Ks is not used by this model (pass any [B,C,3,3]).
+extern "C" int gsx_project_ut_lidar_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                                        const float *viewmats0, const float *viewmats1, const float *Ks, double fov_horiz_start,
+                                        double fov_horiz_span, double fov_vert_start, double fov_vert_span, int spinning_ccw,
+                                        const int32_t *angles_to_columns_map, uint32_t map_h, uint32_t map_w, uint32_t n_columns,
+                                        uint32_t B, uint32_t C, uint32_t N, float eps2d, float near_plane, float far_plane,
+                                        float radius_clip, int rs_type, int global_z_order, float ut_alpha, float ut_beta,
+                                        float ut_kappa, float in_image_margin_factor, int require_all_sigma_points_valid,
+                                        int32_t *radii, float *means2d, float *depths, float *conics, float *compensations,
+                                        void *stream)
+{
+    LidarHost l{fov_horiz_start, fov_horiz_span, fov_vert_start, fov_vert_span, spinning_ccw, angles_to_columns_map,
+                (int)map_h, (int)map_w, (int)n_columns};
+    return project_ut_launch(means, quats, scales, opacities, viewmats0, Ks, nullptr, nullptr, nullptr, nullptr, nullptr, B, C, N,
+                             n_columns, map_h, eps2d, near_plane, far_plane, radius_clip, 4, ut_alpha, ut_beta, ut_kappa,
+                             in_image_margin_factor, require_all_sigma_points_valid, radii, means2d, depths, conics, compensations,
+                             stream, viewmats1, rs_type, global_z_order, nullptr, &l);
+}
+
+// World rays of a spinning lidar's elements, [I, n_rows, n_columns, 6] (origin | unit direction; the zero ray for an element
+// outside the fields of view): element (row, column) looks along azimuth = column_azimuths[column] + row_azimuth_offsets[row]
+// (wrapped into (-pi, pi]) and elevation = row_elevations[row] (Lidars.cuh element_to_image_point / image_point_to_camera_ray;
+// gsplat/cuda/_torch_lidars.py:266-324); its pose is the one at the time its column fires (rolling shutter) or the frame's.
+namespace gsx {
+struct LidarRayArgs {
+    ProjUtArgs cam; // viewmats, viewmats1, rs_type, ld_*
+    const float *row_el, *col_az, *row_off;
+    uint32_t n_images, n_rows, n_cols;
+    float eps;      // fov_eps_rad
+    float *rays;
+};
+__global__ void __launch_bounds__(256) lidar_rays_kernel(const LidarRayArgs g)
+{
+    const ProjUtArgs &a = g.cam;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)g.n_rows * g.n_cols;
+    if (idx >= per * g.n_images) return;
+    const uint32_t img = (uint32_t)(idx / per), rem = (uint32_t)(idx % per), row = rem / g.n_cols, col = rem % g.n_cols;
+    const float kPi = 3.1415927f;
+    const float el = g.row_el[row];
+    float az = g.col_az[col] + g.row_off[row];
+    az = az > kPi ? az - 2.0f * kPi : az;
+    az = az <= -kPi ? az + 2.0f * kPi : az;
+    const float ipx = az * 1024.0f, ipy = el * 1024.0f; // the element's image point
+    // image point -> camera ray (through the scaled angles, like the reference)
+    const float kToAngle = 1.0f / 1024.0f;
+    const float aa = ipx * kToAngle, ee = ipy * kToAngle, ce = cosf(ee);
+    float ray[3] = {cosf(aa) * ce, sinf(aa) * ce, sinf(ee)};
+    const float n2 = ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2], inv = n2 > 0.0f ? 1.0f / sqrtf(n2) : 0.0f;
+    ray[0] *= inv; ray[1] *= inv; ray[2] *= inv;
+    // valid_sensor_angles: inside the fields of view widened by eps on both sides
+    const float v0 = a.ld_v0 + g.eps, h0 = a.ld_ccw ? a.ld_h0 - g.eps : a.ld_h0 + g.eps;
+    const float rel_el = v0 - ee, rel_az = lidar_mod(a.ld_ccw ? aa - h0 : h0 - aa, 6.2831855f);
+    const bool valid = (rel_el <= a.ld_vs + g.eps * 2.0f) && (rel_az <= a.ld_hs + g.eps * 2.0f);
+    const Cam c = load_cam(a.viewmats + (size_t)img * 16, a.viewmats + (size_t)img * 16); // (intrinsics are not used)
+    UtPose p0, p1;
+    ut_rotmat_to_quat(c.R, p0.q);
+    p0.t[0] = c.t[0]; p0.t[1] = c.t[1]; p0.t[2] = c.t[2];
+    p1 = p0;
+    if (a.viewmats1) {
+        const Cam c1 = load_cam(a.viewmats1 + (size_t)img * 16, a.viewmats1 + (size_t)img * 16);
+        ut_rotmat_to_quat(c1.R, p1.q);
+        p1.t[0] = c1.t[0]; p1.t[1] = c1.t[1]; p1.t[2] = c1.t[2];
+    }
+    const UtPose pose = ut_interpolate_pose(p0, p1, ut_relative_frame_time(a, ipx, ipy));
+    const float qi[4] = {pose.q[0], -pose.q[1], -pose.q[2], -pose.q[3]};
+    const float rel[3] = {-pose.t[0], -pose.t[1], -pose.t[2]};
+    float o[3], dw[3];
+    ut_quat_rotate(qi, rel, o);
+    ut_quat_rotate(qi, ray, dw);
+    float *out = g.rays + (size_t)idx * 6;
+    const float keep = valid ? 1.0f : 0.0f;
+    for (int i = 0; i < 3; ++i) {
+        out[i]     = o[i] * keep;
+        out[3 + i] = dw[i] * keep;
+    }
+}
+} // namespace gsx
+extern "C" int gsx_lidar_rays(const float *viewmats, const float *viewmats_rs, const float *row_elevations,
+                              const float *column_azimuths, const float *row_azimuth_offsets, uint32_t n_images, uint32_t n_rows,
+                              uint32_t n_columns, double fov_horiz_start, double fov_horiz_span, double fov_vert_start,
+                              double fov_vert_span, double fov_eps, int spinning_ccw, const int32_t *angles_to_columns_map,
+                              uint32_t map_h, uint32_t map_w, int rs_type, float *rays, void *stream)
+{
+    using namespace gsx;
+    const int64_t n = (int64_t)n_images * n_rows * n_columns;
+    if (n == 0) return GSX_OK;
+    GSX_REQUIRE(viewmats && row_elevations && column_azimuths && row_azimuth_offsets && rays, "gsx_lidar_rays: null pointer");
+    GSX_REQUIRE(rs_type >= 0 && rs_type <= 4, "gsx_lidar_rays: rolling shutter type %d (0 .. 3 rolling, 4 global)", rs_type);
+    GSX_REQUIRE(rs_type == 4 || (viewmats_rs && angles_to_columns_map && map_h > 1 && map_w > 1 && n_columns > 1),
+                "gsx_lidar_rays: a rolling shutter needs the end-of-frame poses and the angles_to_columns_map");
+    LidarRayArgs g{};
+    LidarHost l{fov_horiz_start, fov_horiz_span, fov_vert_start, fov_vert_span, spinning_ccw, angles_to_columns_map, (int)map_h,
+                (int)map_w, (int)n_columns};
+    set_lidar(g.cam, &l);
+    g.cam.camera_model = 4; g.cam.rs_type = rs_type;
+    g.cam.viewmats = viewmats; g.cam.viewmats1 = rs_type == 4 ? nullptr : viewmats_rs;
+    g.row_el = row_elevations; g.col_az = column_azimuths; g.row_off = row_azimuth_offsets;
+    g.n_images = n_images; g.n_rows = n_rows; g.n_cols = n_columns; g.eps = (float)fov_eps; g.rays = rays;
+    lidar_rays_kernel<<<dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(g);
+    return check_launch("lidar_rays");
 }

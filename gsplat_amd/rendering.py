@@ -12,8 +12,9 @@ of the reference (``gsplat/rendering.py:234-690``) and the stage order of its C+
 3DGUT: ``with_ut`` (Unscented-Transform projection through pinhole / distorted-pinhole / ortho / fisheye / f-theta cameras,
 global or rolling shutter) and ``with_eval3d`` (from-world compositing: rays given or generated for each of those camera
 models, hit-distance modes, normals) are built; what is NOT built is refused up front, before any kernel launches, never
-approximated: lidar cameras. External (windshield) distortion (the reference's bivariate model) is built for every one of those
-camera models in both 3DGUT kernels.
+approximated. External (windshield) distortion (the reference's bivariate model) is built for every one of those camera models in
+both 3DGUT kernels; spinning-lidar cameras (``camera_model="lidar"``: angle-space projection and tiling, element rays, tiles of
+elements composited as virtual pixel tiles) with ``with_ut=True, with_eval3d=True``.
 """
 from __future__ import annotations
 
@@ -140,7 +141,6 @@ def rasterization(
     unsupported = {
         "camera_model='ftheta' / ftheta_coeffs without the UT projection (with_ut=True)":
             (camera_model == "ftheta" or ftheta_coeffs is not None) and not with_ut,
-        "camera_model='lidar'": camera_model == "lidar",
     }
     bad = [k for k, v in unsupported.items() if v]
     if bad:
@@ -150,8 +150,14 @@ def rasterization(
             "(csrc_shim.built_3dgut_subset(); build_config()['3dgut'] stays False while the feature is partial); "
             f"these sub-features are not built - not supported, refused rather than approximated: {', '.join(bad)}"
         )
-    if camera_model not in ("pinhole", "ortho", "fisheye", "ftheta"):
-        raise ValueError(f"camera_model '{camera_model}' is not supported (pinhole / ortho / fisheye / ftheta)")
+    if camera_model not in ("pinhole", "ortho", "fisheye", "ftheta", "lidar"):
+        raise ValueError(f"camera_model '{camera_model}' is not supported (pinhole / ortho / fisheye / ftheta / lidar)")
+    is_lidar = camera_model == "lidar"
+    if is_lidar:
+        if hasattr(lidar_coeffs, "to_cpp"):  # the reference's Python parameter object: its custom-class record
+            lidar_coeffs = lidar_coeffs.to_cpp()
+        if not with_eval3d:
+            raise RuntimeError("Lidar camera model requires with_eval3d=True (its tiles hold elements, not pixel blocks)")
     if (camera_model == "ftheta") != (ftheta_coeffs is not None):
         raise ValueError("ftheta_coeffs must be given if and only if camera_model is 'ftheta'")
     # `segmented` (gsplat/rendering.py:262; IntersectTile.cu:1125-1176) only selects how the reference sorts - per image instead
@@ -208,7 +214,8 @@ def rasterization(
             far_plane=far_plane, radius_clip=radius_clip, calc_compensations=calc_comp, camera_model=camera_model,
             ut_params=ut_params, radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs,
             thin_prism_coeffs=thin_prism_coeffs, ftheta_coeffs=ftheta_coeffs, global_z_order=global_z_order,
-            rolling_shutter=rs_type, viewmats_rs=viewmats_rs, external_distortion_coeffs=external_distortion_coeffs)
+            rolling_shutter=rs_type, viewmats_rs=viewmats_rs, external_distortion_coeffs=external_distortion_coeffs,
+            lidar_coeffs=lidar_coeffs)
     elif not packed and not calc_comp and means.is_cuda and _VIEW_OPACITIES:
         # dense rows, classic mode: the per-view opacities come out of the projection's own autograd node, whose backward sums
         # their gradient over the views inside the kernel that reads the gradient rows anyway (_autograd.py)
@@ -257,8 +264,10 @@ def rasterization(
     # not depend on them; by the time isect_tiles_finish() needs the number on the host the GPU is still busy.
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
+    if is_lidar:  # the tiles of the lidar's own tiling, in angle space
+        tile_width, tile_height = int(lidar_coeffs.n_bins_azimuth), int(lidar_coeffs.n_bins_elevation)
     isect_pending = None
-    if dist_ctx is None:
+    if dist_ctx is None and not is_lidar:
         isect_pending = isect_tiles_begin(
             means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=segmented, packed=packed,
             n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids, conics=None if with_ut else conics,
@@ -309,20 +318,28 @@ def rasterization(
         n_rows_per_image = N
 
     # ---- tile intersection (second half) -----------------------------------------------------------
-    if isect_pending is None:
-        isect_pending = isect_tiles_begin(
-            means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=segmented, packed=packed,
-            n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids_r, conics=conics,
-            opacities=proj_opacities.contiguous())
-    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles_finish(isect_pending)
-    if isect_pending.offsets is not None:  # the fused intersection path produces the tile offsets as a by-product
-        isect_offsets = isect_pending.offsets
-    else:
+    if is_lidar:  # boxes in angle space against the lidar's tiling (gsplat::intersect_tile_lidar, Rendering.cpp:1309-1320)
+        from . import _ops
+
+        tiles_per_gauss, isect_ids, flatten_ids = _ops.intersect_tile_lidar(
+            lidar_coeffs, means2d.contiguous(), radii.contiguous(), depths.contiguous(), None, None, None, True, segmented)
         isect_offsets = isect_offset_encode(isect_ids, I, tile_width, tile_height)
+        longest_list = 0
+    else:
+        if isect_pending is None:
+            isect_pending = isect_tiles_begin(
+                means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, segmented=segmented, packed=packed,
+                n_images=I, image_ids=image_ids, gaussian_ids=gaussian_ids_r, conics=conics,
+                opacities=proj_opacities.contiguous())
+        tiles_per_gauss, isect_ids, flatten_ids = isect_tiles_finish(isect_pending)
+        if isect_pending.offsets is not None:  # the fused intersection path produces the tile offsets as a by-product
+            isect_offsets = isect_pending.offsets
+        else:
+            isect_offsets = isect_offset_encode(isect_ids, I, tile_width, tile_height)
+        # the intersection also reports its longest tile list (same host words as n_isects): long lists are composited in
+        # segments (csrc/raster3d_seg.hip); 0 when the path taken does not report it
+        longest_list = _isect_max_tile_len(isect_pending)
     isect_offsets = isect_offsets.reshape(batch_dims + (C, tile_height, tile_width))
-    # the intersection also reports its longest tile list (same host words as n_isects): long lists are composited in
-    # segments (csrc/raster3d_seg.hip); 0 when the path taken does not report it
-    longest_list = _isect_max_tile_len(isect_pending)
 
     # ---- feature rows still in flight (distributed, dense): needed from here on -----------------------
     if recv_features is not None:
@@ -367,7 +384,7 @@ def rasterization(
                 tile_size, isect_offsets, flatten_ids, backgrounds=backgrounds, camera_model=camera_model,
                 ut_params=ut_params, rays=rays, rolling_shutter=rs_type, viewmats_rs=viewmats_rs,
                 radial_coeffs=radial_coeffs, tangential_coeffs=tangential_coeffs, thin_prism_coeffs=thin_prism_coeffs,
-                ftheta_coeffs=ftheta_coeffs, external_distortion_coeffs=external_distortion_coeffs,
+                ftheta_coeffs=ftheta_coeffs, external_distortion_coeffs=external_distortion_coeffs, lidar_coeffs=lidar_coeffs,
                 use_hit_distance=use_hit_distance, return_normals=bool(return_normals), return_last_ids=False)
         else:
             render_colors, render_alphas = rasterize_to_pixels(

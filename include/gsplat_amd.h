@@ -423,6 +423,27 @@ int gsx_isect_lidar_emit(const float *means2d, const int32_t *radii_i32, const f
                          uint32_t cdf_resolution_azimuth, uint32_t cdf_resolution_elevation, const int32_t *cdf_elevation,
                          const int32_t *cdf_dense_ray_mask, int64_t *isect_ids, int32_t *flatten_ids, void *stream);
 
+/* Spinning-lidar cameras in the two 3DGUT kernels (camera_model 4; Lidars.cuh:40-330; torch statement
+ * gsplat/cuda/_torch_lidars.py:214-374). gsx_project_ut_lidar_fwd = gsplat::projection_ut_3dgs_fused with `lidar_coeffs`: the
+ * image point of a sigma point is (azimuth, elevation) * 1024, valid inside the fields of view (+ the UT margin), no
+ * image-bounds culling, radial near / far culling and depth with global_z_order = 0; a rolling shutter reads the time of an
+ * angle off angles_to_columns_map (int32 [map_h][map_w], device; NULL with rs_type 4). Ks is not used (any [B,C,3,3]).
+ * gsx_lidar_rays: the world ray of every element [I, n_rows, n_columns, 6] (origin | unit direction; the zero ray outside the
+ * fields of view) - what the from-world kernels derive per thread for lidar elements (element_to_world_ray_shutter_pose). */
+int gsx_project_ut_lidar_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                             const float *viewmats0, const float *viewmats1, const float *Ks, double fov_horiz_start,
+                             double fov_horiz_span, double fov_vert_start, double fov_vert_span, int spinning_ccw,
+                             const int32_t *angles_to_columns_map, uint32_t map_h, uint32_t map_w, uint32_t n_columns, uint32_t B,
+                             uint32_t C, uint32_t N, float eps2d, float near_plane, float far_plane, float radius_clip,
+                             int rs_type, int global_z_order, float ut_alpha, float ut_beta, float ut_kappa,
+                             float in_image_margin_factor, int require_all_sigma_points_valid, int32_t *radii, float *means2d,
+                             float *depths, float *conics, float *compensations, void *stream);
+int gsx_lidar_rays(const float *viewmats, const float *viewmats_rs, const float *row_elevations, const float *column_azimuths,
+                   const float *row_azimuth_offsets, uint32_t n_images, uint32_t n_rows, uint32_t n_columns,
+                   double fov_horiz_start, double fov_horiz_span, double fov_vert_start, double fov_vert_span, double fov_eps,
+                   int spinning_ccw, const int32_t *angles_to_columns_map, uint32_t map_h, uint32_t map_w, int rs_type,
+                   float *rays, void *stream);
+
 /* assemble_proj_features_unpacked_fwd: gsplat::assemble_proj_features_unpacked_fwd (ext.cpp:1015-1020; host
  * SphericalHarmonics.cpp:572-676; kernel SphericalHarmonicsCUDA.cu:1100-1250). Dense rows only. Writes
  * out [B,C,N, Dc + E + has_depth] = [ post(SH colours of coeffs [N,K,Dc]) | extra (+0.5 when extra_post == 1) | depth ]

@@ -15,6 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 
 SCALE = 1024.0
 # name: (rows, columns, elevation start / end, azimuth start / end of the base columns, clockwise, row offset amplitude, seed)
@@ -90,6 +91,45 @@ def main():
         gold[f"{name}.ref.tiles_per_gauss"], gold[f"{name}.ref.isect_ids"] = tpg.numpy(), ids.numpy()
         gold[f"{name}.ref.flatten_ids"] = fl.numpy()
         gold[f"{name}.ref.isect_ids_unsorted"], gold[f"{name}.ref.flatten_ids_unsorted"] = ids_u.numpy(), fl_u.numpy()
+        # ---- the lidar as a CAMERA: unscented projection and element rays (global and rolling shutter) ------------------
+        from gsplat.cuda._torch_impl_eval3d import _generate_rays
+        from gsplat.cuda._torch_impl_ut import _fully_fused_projection_with_ut as ref_ut
+        from gsplat.cuda._torch_lidars import _RowOffsetStructuredSpinningLidarModel
+        from gsplat.cuda._wrapper import RollingShutterType
+
+        Np, C = 500, 2
+        r = torch.rand(Np, generator=g) * 7 + 2
+        th_ = (torch.rand(Np, generator=g) * 2 - 1) * math.pi
+        ph_ = (torch.rand(Np, generator=g) * 2 - 1) * 0.6
+        pts = torch.stack([r * torch.cos(ph_) * torch.cos(th_), r * torch.cos(ph_) * torch.sin(th_), r * torch.sin(ph_)], -1)
+        quats = torch.nn.functional.normalize(torch.randn(Np, 4, generator=g), dim=-1)
+        scales = torch.rand(Np, 3, generator=g) * 0.15 + 0.02
+        opac = torch.rand(Np, generator=g) * 0.9 + 0.1
+        vm = torch.eye(4).repeat(C, 1, 1)
+        for c in range(C):
+            ax = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0)
+            ang = 0.05 * (c + 1)
+            K = torch.tensor([[0.0, -ax[2], ax[1]], [ax[2], 0.0, -ax[0]], [-ax[1], ax[0], 0.0]])
+            vm[c, :3, :3] = torch.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * (K @ K)
+            vm[c, :3, 3] = torch.randn(3, generator=g) * 0.2
+        from pin_ut_rs_against_reference import end_poses
+
+        vm1 = end_poses(vm, 7)
+        Ks = torch.eye(3).repeat(C, 1, 1)
+        for tag, rs, gz in (("global", 4, True), ("rs_distance", 0, False)):
+            kw = dict(rolling_shutter=RollingShutterType(rs), viewmats_rs=vm1 if rs != 4 else None, global_z_order=gz)
+            ref = ref_ut(pts, quats, scales, opac, vm, Ks, n_cols, n_rows, camera_model="lidar", lidar_coeffs=lidar,
+                         ut_params=torch.classes.gsplat.UnscentedTransformParameters(), **kw)
+            vis = (ref[0] > 0).all(-1)
+            print(f"   projection {tag}: visible {int(vis.sum())}/{vis.numel()}")
+            assert int(vis.sum()) > 30, (name, tag)
+            for k, v in zip(("radii", "means2d", "depths", "conics"), ref[:4]):
+                gold[f"{name}.proj_{tag}.{k}"] = v.numpy()
+            cam = _RowOffsetStructuredSpinningLidarModel(lidar)
+            rays = _generate_rays(cam, n_cols, n_rows, vm, vm1 if rs != 4 else None).reshape(C, n_rows, n_cols, 6)
+            gold[f"{name}.rays_{tag}"] = rays.numpy()
+        for k, v in dict(pts=pts, quats=quats, scales=scales, opac=opac, viewmats=vm, viewmats_rs=vm1, Ks=Ks).items():
+            gold[f"{name}.cam.{k}"] = v.numpy()
     np.savez_compressed(args.out, **gold)
     print("wrote", args.out, os.path.getsize(args.out), "bytes")
 

@@ -60,3 +60,88 @@ def test_lidar_tile_intersection_equals_reference(G, name):
     assert torch.equal(tpg_p, tpg.reshape(-1)) and torch.equal(ids_p, ids) and torch.equal(fl_p, fl)
     offsets = torch.ops.gsplat.intersect_offset(ids, I, int(lidar.n_bins_azimuth), int(lidar.n_bins_elevation))
     assert offsets.shape == (I, int(lidar.n_bins_elevation), int(lidar.n_bins_azimuth))
+
+
+@pytest.mark.parametrize("name", ["cw_120", "ccw_periodic", "ccw_90"])
+@pytest.mark.parametrize("tag,rs,gz", [("global", 4, True), ("rs_distance", 0, False)])
+def test_lidar_unscented_projection_and_rays_match_reference(G, name, tag, rs, gz):
+    """The lidar as a camera of the two 3DGUT kernels against the reference's torch statements: gsx_project_ut_lidar_fwd (image
+    points = (azimuth, elevation) * 1024, field-of-view validity, radial culling / depth with global_z_order=False, the rolling
+    shutter's time read off the angle map) and gsx_lidar_rays (one world ray per element)."""
+    from gsplat_amd import _ops
+
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "lidar_ref.npz")))
+    lidar = lidar_from_golden(gold, name)
+    t = lambda k: torch.from_numpy(gold[f"{name}.cam.{k}"]).to(DEV)  # noqa: E731
+    vm1 = t("viewmats_rs") if rs != 4 else None
+    radii, m2, dep, con, _ = G.fully_fused_projection_with_ut(
+        t("pts"), t("quats"), t("scales"), t("opac"), t("viewmats"), t("Ks"), int(lidar.column_azimuths_rad.shape[0]),
+        int(lidar.row_elevations_rad.shape[0]), camera_model="lidar", lidar_coeffs=lidar, rolling_shutter=rs, viewmats_rs=vm1,
+        global_z_order=gz)
+    ref = {k: torch.from_numpy(gold[f"{name}.proj_{tag}.{k}"]) for k in ("radii", "means2d", "depths", "conics")}
+    vis, vis_r = (radii.cpu() > 0).all(-1), (ref["radii"] > 0).all(-1)
+    assert float((vis == vis_r).float().mean()) > 0.995  # a sigma point within rounding of the field of view's edge may flip a row
+    both = vis & vis_r
+    assert int(both.sum()) > 30
+    assert int((radii.cpu()[both] - ref["radii"][both]).abs().max()) <= 1
+    # angular pixels of magnitude up to ~3200 (one float32 ulp = 2.4e-4) through UT weights of ~ -99
+    assert float((m2.cpu()[both] - ref["means2d"][both]).abs().max()) < 0.1
+    torch.testing.assert_close(dep.cpu()[both], ref["depths"][both], rtol=1e-5, atol=1e-5)
+    rel = (con.cpu()[both] - ref["conics"][both]).abs() / (ref["conics"][both].abs().max(-1, keepdim=True).values + 1e-12)
+    assert float(rel.max()) < 5e-2 and float(rel.median()) < 1e-3
+    rays = _ops.lidar_element_rays(t("viewmats"), vm1, lidar, rs).cpu()
+    torch.testing.assert_close(rays, torch.from_numpy(gold[f"{name}.rays_{tag}"]), rtol=0, atol=5e-6)
+
+
+def test_lidar_rasterization_renders_elements(G):
+    """rasterization(camera_model='lidar', with_ut=True, with_eval3d=True): angle-space projection -> lidar tiling -> the
+    from-world kernels on virtual pixel tiles -> [n_rows, n_columns] elements. Every element lands in exactly one tile; the
+    render equals compositing each element's own ray through a ONE-tile-per-element pinhole-free path: the same op fed the
+    element rays directly as an image of [n_rows, n_columns] pixels with square tiles (no lidar tiling involved)."""
+    from gsplat_amd import _ops
+
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "lidar_ref.npz")))
+    name = "cw_120"
+    lidar = lidar_from_golden(gold, name)
+    t = lambda k: torch.from_numpy(gold[f"{name}.cam.{k}"]).to(DEV)  # noqa: E731
+    n_rows, n_cols = int(lidar.row_elevations_rad.shape[0]), int(lidar.column_azimuths_rad.shape[0])
+    pack = lidar.tiles_pack_info.cpu()
+    emap = lidar.tiles_to_elements_map.cpu()
+    assert int(pack[:, 1].sum()) == n_rows * n_cols and emap.shape[0] == n_rows * n_cols
+    assert torch.unique(emap[:, 1].long() * n_cols + emap[:, 0].long()).numel() == n_rows * n_cols
+    leaves = {k: t(k).clone().requires_grad_(True) for k in ("pts", "quats", "scales", "opac")}
+    colors = torch.rand(leaves["pts"].shape[0], 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    colors.requires_grad_(True)
+    bg = torch.rand(2, 3, device=DEV)
+    rc, ra, meta = G.rasterization(leaves["pts"], leaves["quats"], leaves["scales"] * 3.0, leaves["opac"], colors, t("viewmats"),
+                                   t("Ks"), n_cols, n_rows, camera_model="lidar", lidar_coeffs=lidar, with_ut=True,
+                                   with_eval3d=True, packed=False, backgrounds=bg)
+    assert rc.shape == (2, n_rows, n_cols, 3) and ra.shape == (2, n_rows, n_cols, 1)
+    assert bool(torch.isfinite(rc).all()) and float(ra.max()) > 0.3 and float((ra > 0).float().mean()) > 0.05
+    (rc.sum() + ra.sum()).backward()
+    for k, leaf in leaves.items():
+        assert leaf.grad is not None and bool(torch.isfinite(leaf.grad).all()) and float(leaf.grad.abs().max()) > 0, k
+    # the same Gaussians, every Gaussian offered to EVERY pixel tile (lists = all visible rows in depth order): an upper bound of
+    # what any tiling can blend. Where the lidar tiling's lists are complete the two agree; a tile list can only miss Gaussians
+    # whose box does not reach the tile, i.e. whose contribution is below the 3.33-sigma cut of the extent
+    rays = _ops.lidar_element_rays(t("viewmats"), None, lidar, 4)
+    radii, depths = meta["radii"], meta["depths"]
+    vis = (radii > 0).all(-1)
+    C, N = vis.shape
+    ts, tw, th = 8, (n_cols + 7) // 8, (n_rows + 7) // 8
+    lists, offsets, base = [], [], 0
+    for c in range(C):
+        rows = torch.nonzero(vis[c])[:, 0]
+        rows = rows[torch.argsort(depths[c][rows], stable=True)] + c * N
+        for _ in range(th * tw):
+            offsets.append(base)
+            lists.append(rows)
+            base += rows.numel()
+    fl = torch.cat(lists).to(torch.int32)
+    off = torch.tensor(offsets, device=DEV, dtype=torch.int32).reshape(C, th, tw)
+    cols_cn = colors.detach()[None].expand(C, N, 3).contiguous()
+    full, fa, _, _, _ = G.rasterize_to_pixels_eval3d_extra(
+        leaves["pts"].detach(), leaves["quats"].detach(), leaves["scales"].detach() * 3.0, cols_cn,
+        meta["opacities"].detach().contiguous(), t("viewmats"), t("Ks"), n_cols, n_rows, ts, off, fl, backgrounds=bg, rays=rays)
+    diff = (full - rc.detach()).abs()
+    assert float(diff.mean()) < 2e-3 and float((diff > 2e-2).float().mean()) < 5e-3, (float(diff.mean()), float(diff.max()))
