@@ -116,10 +116,32 @@ def main():
 
         vm1 = end_poses(vm, 7)
         Ks = torch.eye(3).repeat(C, 1, 1)
+        import gsplat.cuda._torch_impl_ut as ut_mod
+
+        class SpinningShutterLidar(_RowOffsetStructuredSpinningLidarModel):
+            """The torch lidar with the shutter its CUDA twin hard-codes (Lidars.cuh:86: every lidar is a ROLLING sensor whose
+            frame time is `shutter_relative_frame_time` of the angle map); the torch class leaves the base's GLOBAL default, which
+            would project every sigma point with the start pose. The time function's own precondition assert (all angles inside
+            the field of view) is lifted: the CUDA twin clamps the map index instead (Lidars.cuh:131-137), and so does the torch
+            code below the assert."""
+
+            def __init__(self, params):
+                super().__init__(params)
+                self.shutter_type = RollingShutterType.ROLLING_LEFT_TO_RIGHT
+
+            def valid_sensor_angles(self, angles, *, scale=1):
+                return torch.ones(angles.shape[:-1], dtype=torch.bool)
+
         for tag, rs, gz in (("global", 4, True), ("rs_distance", 0, False)):
             kw = dict(rolling_shutter=RollingShutterType(rs), viewmats_rs=vm1 if rs != 4 else None, global_z_order=gz)
-            ref = ref_ut(pts, quats, scales, opac, vm, Ks, n_cols, n_rows, camera_model="lidar", lidar_coeffs=lidar,
-                         ut_params=torch.classes.gsplat.UnscentedTransformParameters(), **kw)
+            stock = ut_mod._RowOffsetStructuredSpinningLidarModel
+            if rs != 4:
+                ut_mod._RowOffsetStructuredSpinningLidarModel = SpinningShutterLidar
+            try:
+                ref = ref_ut(pts, quats, scales, opac, vm, Ks, n_cols, n_rows, camera_model="lidar", lidar_coeffs=lidar,
+                             ut_params=torch.classes.gsplat.UnscentedTransformParameters(), **kw)
+            finally:
+                ut_mod._RowOffsetStructuredSpinningLidarModel = stock
             vis = (ref[0] > 0).all(-1)
             print(f"   projection {tag}: visible {int(vis.sum())}/{vis.numel()}")
             assert int(vis.sum()) > 30, (name, tag)
