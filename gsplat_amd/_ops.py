@@ -128,10 +128,15 @@ def _consume_long_tile_hint() -> int:
 # orchestrator to carry the hint: the intersection notes the longest list of its result and a compositing call without a hint
 # looks its flatten_ids up. A note is keyed by the IDENTITY of the tensor's storage, never by an address the allocator may hand
 # out again (csrc/torch_ops.cpp keeps the notes - weak references to the StorageImpl - when the compiled shim is loaded, so that
-# Python and compiled bodies see the same ones; the fallback below holds weak references to the storages the same way).
+# Python and compiled bodies see the same ones; the fallback below keeps the noted tensors of its 16-entry ring alive instead).
 _notes_compiled = False
-_notes_py: list = []  # [(weakref to the untyped storage, storage offset, numel, longest)], newest last
+_notes_py: list = []  # [((StorageImpl address, storage offset, numel), the tensor (kept alive), longest)], newest last
 _notes_lock = __import__("threading").Lock()
+
+
+def _note_key(t: Tensor):
+    st = t.untyped_storage()
+    return (st._cdata, t.storage_offset(), t.numel())
 
 
 def _note_longest(flatten_ids: Tensor, longest: int) -> None:
@@ -140,12 +145,13 @@ def _note_longest(flatten_ids: Tensor, longest: int) -> None:
     if _notes_compiled:
         torch.ops.gsplat_amd.note_longest(flatten_ids, int(longest))
         return
-    import weakref
-
-    st = flatten_ids.untyped_storage()
+    # fallback (no compiled shim, or GSPLAT_AMD_LIB set): keyed by the StorageImpl's address + view, with a STRONG reference
+    # to the tensor in a 16-entry ring - the address cannot be handed out again while its note is alive, and the note does not
+    # depend on torch preserving the Python wrapper of a storage between calls
+    key = _note_key(flatten_ids)
     with _notes_lock:
-        _notes_py[:] = [e for e in _notes_py if e[0]() is not None and e[0]() is not st][-15:]
-        _notes_py.append((weakref.ref(st), flatten_ids.storage_offset(), flatten_ids.numel(), int(longest)))
+        _notes_py[:] = [e for e in _notes_py if e[0] != key][-15:]
+        _notes_py.append((key, flatten_ids, int(longest)))
 
 
 def _lookup_longest(flatten_ids: Tensor) -> int:
@@ -153,10 +159,10 @@ def _lookup_longest(flatten_ids: Tensor) -> int:
         return int(torch.ops.gsplat_amd.lookup_longest(flatten_ids))
     if flatten_ids.numel() == 0:
         return 0
-    st = flatten_ids.untyped_storage()
+    key = _note_key(flatten_ids)
     with _notes_lock:
-        for ref, off, n, longest in _notes_py:
-            if ref() is st and off == flatten_ids.storage_offset() and n == flatten_ids.numel():
+        for k, _keep, longest in _notes_py:
+            if k == key:
                 return longest
     return 0
 
@@ -887,6 +893,12 @@ def intersect_tile_lidar(lidar, means2d, radii, depths, image_ids, gaussian_ids,
         raise RuntimeError(f"intersect_tile_lidar: (image, tile) id packing needs {tile_bits + image_bits} bits but only 32 are "
                            f"available (I={I}, n_tiles={n_tiles}).")
     dev = means2d.device
+    # the reference's second instantiation (scalar_t = double, IntersectTileLidar.cu:479-493) loads every value into float and
+    # narrows the depth of the key to float (:185-186, :387-392): the double call IS the float call on narrowed inputs
+    if means2d.dtype == torch.float64:
+        means2d = means2d.to(torch.float32)
+    if depths.dtype == torch.float64:
+        depths = depths.to(torch.float32)
     _check_f32(means2d=means2d, depths=depths)
     means2d, depths = means2d.contiguous(), depths.contiguous()
     radii = radii.contiguous()

@@ -31,11 +31,10 @@ def build_config() -> dict:
     reference means by it is built: its tests gate on these flags (`skipif(not gsplat.has_3dgut())`), so a partial True turns
     refused sub-features into failures instead of skips.
 
-    `3dgut`: the unscented projection and the from-world rasterizer fwd / bwd for pinhole / distorted pinhole / ortho / fisheye
-    / f-theta cameras, global and rolling shutter, hit distance, normals, generated rays and the windshield distortion are
-    built and reachable through rasterization(with_ut / with_eval3d) whatever the flag says; LIDAR cameras and their tiling
-    are not - so the flag is False. GSPLAT_AMD_3DGUT_SUBSET=1 reports True (the reference's 3DGUT tests then RUN against the
-    built subset; the table of tools/run_reference_suite.py --with-3dgut-subset is made that way).
+    `3dgut`: True since the lidar pieces exist (round 6): the unscented projection and the from-world rasterizer fwd / bwd for
+    pinhole / distorted pinhole / ortho / fisheye / f-theta / spinning-lidar cameras, global and rolling shutter, hit distance,
+    normals, generated rays, the windshield distortion, the lidar tiling (`intersect_tile_lidar`). GSPLAT_AMD_3DGUT=0 reports
+    False (the reference's 3DGUT tests then skip).
     `camera_wrappers`: the Python-visible camera classes of CameraWrappers.cu are not built, so False; of that build flag's
     ops the two of the windshield model (gsplat::distort_camera_rays, eval_bivariate_poly) exist, and
     GSPLAT_AMD_CAMERA_WRAPPER_OPS=1 reports True so that the reference's tests of THOSE ops run (the runner deselects the tests
@@ -44,14 +43,14 @@ def build_config() -> dict:
 
     on = lambda k: os.environ.get(k, "0") not in ("0", "")  # noqa: E731
     has_2dgs = "rasterize_to_pixels_2dgs" in _ops.SCHEMAS
-    has_3dgut = built_3dgut_subset() and on("GSPLAT_AMD_3DGUT_SUBSET")
+    has_3dgut = built_3dgut_subset() and os.environ.get("GSPLAT_AMD_3DGUT", "1") not in ("0", "")
     return {"3dgs": True, "2dgs": has_2dgs, "3dgut": has_3dgut, "adam": "adam" in _ops.SCHEMAS,
             "reloc": "relocation" in _ops.SCHEMAS, "losses": False,
             "camera_wrappers": "distort_camera_rays" in _ops.SCHEMAS and on("GSPLAT_AMD_CAMERA_WRAPPER_OPS")}
 
 
 def built_3dgut_subset() -> bool:
-    """True when the built part of 3DGUT (see build_config) is loadable - not a key of build_config(): its key set is ext.cpp's."""
+    """True when the 3DGUT ops (see build_config) are loadable - not a key of build_config(): its key set is ext.cpp's."""
     return _ops.COMPOSITE_UNAVAILABLE is None and "rasterize_to_pixels_from_world_3dgs" in _ops.CLASS_SCHEMAS
 
 

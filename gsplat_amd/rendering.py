@@ -14,7 +14,8 @@ global or rolling shutter) and ``with_eval3d`` (from-world compositing: rays giv
 models, hit-distance modes, normals) are built; what is NOT built is refused up front, before any kernel launches, never
 approximated. External (windshield) distortion (the reference's bivariate model) is built for every one of those camera models in
 both 3DGUT kernels; spinning-lidar cameras (``camera_model="lidar"``: angle-space projection and tiling, element rays, tiles of
-elements composited as virtual pixel tiles) with ``with_ut=True, with_eval3d=True``.
+elements composited as virtual pixel tiles) with ``with_ut=True, with_eval3d=True`` (and, like the reference's orchestrator,
+the lidar's tile lists through the classic kernels with ``with_eval3d=False``).
 """
 from __future__ import annotations
 
@@ -145,9 +146,8 @@ def rasterization(
     bad = [k for k, v in unsupported.items() if v]
     if bad:
         raise RuntimeError(
-            "gsplat_amd builds the classic 3DGS path and, of 3DGUT, the unscented projection and the from-world rasterizer for "
-            "global-shutter pinhole / distorted-pinhole / orthographic / fisheye (and, for the projection, f-theta) cameras "
-            "(csrc_shim.built_3dgut_subset(); build_config()['3dgut'] stays False while the feature is partial); "
+            "gsplat_amd builds the classic 3DGS path and 3DGUT (the unscented projection and the from-world rasterizer for "
+            "pinhole / distorted-pinhole / orthographic / fisheye / f-theta / spinning-lidar cameras); "
             f"these sub-features are not built - not supported, refused rather than approximated: {', '.join(bad)}"
         )
     if camera_model not in ("pinhole", "ortho", "fisheye", "ftheta", "lidar"):
@@ -156,8 +156,9 @@ def rasterization(
     if is_lidar:
         if hasattr(lidar_coeffs, "to_cpp"):  # the reference's Python parameter object: its custom-class record
             lidar_coeffs = lidar_coeffs.to_cpp()
-        if not with_eval3d:
-            raise RuntimeError("Lidar camera model requires with_eval3d=True (its tiles hold elements, not pixel blocks)")
+        # with_eval3d=False is accepted like in the reference (Rendering.cpp:1399-1425): the classic compositing kernels then
+        # take the lidar's tile lists as lists of tile_size x tile_size PIXEL tiles of a [n_rows, n_columns] image - that is
+        # what the reference's orchestrator does too; a lidar's elements are rendered by with_eval3d=True
     if (camera_model == "ftheta") != (ftheta_coeffs is not None):
         raise ValueError("ftheta_coeffs must be given if and only if camera_model is 'ftheta'")
     # `segmented` (gsplat/rendering.py:262; IntersectTile.cu:1125-1176) only selects how the reference sorts - per image instead

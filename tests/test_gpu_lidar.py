@@ -145,3 +145,36 @@ def test_lidar_rasterization_renders_elements(G):
         meta["opacities"].detach().contiguous(), t("viewmats"), t("Ks"), n_cols, n_rows, ts, off, fl, backgrounds=bg, rays=rays)
     diff = (full - rc.detach()).abs()
     assert float(diff.mean()) < 2e-3 and float((diff > 2e-2).float().mean()) < 5e-3, (float(diff.mean()), float(diff.max()))
+
+
+def test_lidar_without_eval3d_composites_the_lidar_lists_as_pixel_tiles(G):
+    """rasterization(camera_model='lidar', with_ut=True, with_eval3d=False) is what the reference's orchestrator does with it
+    (Rendering.cpp:1309-1425): angle-space projection -> lidar tiling -> the CLASSIC compositing kernels fed those lists as
+    tile_size x tile_size pixel tiles of a [n_rows, n_columns] image. The same call chain made by hand gives the same image, the
+    absgrad switch does not change the forward, and float64 boxes / depths give the lists of their float32 values (the
+    reference's second instantiation narrows on load, IntersectTileLidar.cu:185-186, 387-392)."""
+    from gsplat_amd import _ops  # noqa: F401
+
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "lidar_ref.npz")))
+    name = "cw_120"
+    lidar = lidar_from_golden(gold, name)
+    t = lambda k: torch.from_numpy(gold[f"{name}.cam.{k}"]).to(DEV)  # noqa: E731
+    n_rows, n_cols = int(lidar.row_elevations_rad.shape[0]), int(lidar.column_azimuths_rad.shape[0])
+    colors = torch.rand(t("pts").shape[0], 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    args = (t("pts"), t("quats"), t("scales") * 3.0, t("opac"), colors, t("viewmats"), t("Ks"), n_cols, n_rows)
+    kw = dict(camera_model="lidar", lidar_coeffs=lidar, with_ut=True, with_eval3d=False, packed=False, tile_size=16,
+              render_mode="RGB+D")
+    rc, ra, meta = G.rasterization(*args, **kw)
+    assert rc.shape == (2, n_rows, n_cols, 4) and bool(torch.isfinite(rc).all()) and bool(torch.isfinite(ra).all())
+    assert meta["tile_width"] == int(lidar.n_bins_azimuth) and meta["tile_height"] == int(lidar.n_bins_elevation)
+    rc2, ra2, _ = G.rasterization(*args, absgrad=True, **kw)
+    assert torch.equal(rc, rc2) and torch.equal(ra, ra2)
+    feats = torch.cat([colors[None].expand(2, -1, -1), meta["depths"][..., None]], -1).contiguous()
+    hc, ha = G.rasterize_to_pixels(meta["means2d"], meta["conics"], feats, meta["opacities"], n_cols, n_rows, 16,
+                                   meta["isect_offsets"], meta["flatten_ids"])
+    assert torch.equal(hc, rc) and torch.equal(ha, ra)
+    # float64 instantiation of the lidar tiling
+    m2, rad, dep = meta["means2d"], meta["radii"], meta["depths"]
+    a32 = torch.ops.gsplat.intersect_tile_lidar(lidar, m2, rad, dep, None, None, None, True, False)
+    a64 = torch.ops.gsplat.intersect_tile_lidar(lidar, m2.double(), rad, dep.double(), None, None, None, True, False)
+    assert all(torch.equal(x, y) for x, y in zip(a32, a64))

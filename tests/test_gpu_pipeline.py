@@ -153,8 +153,8 @@ def test_rasterization_rejects_out_of_scope_arguments(G):
         if kw.get("return_normals"):
             assert meta["normals"].shape == (1, H, W, 3) and bool(torch.isfinite(meta["normals"]).all())
     # not built: refused before any kernel launches, never approximated
-    with pytest.raises(RuntimeError, match="Lidar camera model requires with_eval3d=True"):
-        G.rasterization(*args, with_ut=True, packed=False, camera_model="lidar", lidar_coeffs=object())
+    with pytest.raises(RuntimeError, match="Lidar camera model requires with_ut=True"):
+        G.rasterization(*args, packed=False, camera_model="lidar", lidar_coeffs=object())
     with pytest.raises(RuntimeError, match="hit-distance render modes require with_eval3d=True"):
         G.rasterization(*args, render_mode="RGB-Ed")
     with pytest.raises(RuntimeError, match="ftheta camera is only supported via UT"):

@@ -25,17 +25,17 @@ def test_feature_probes_follow_build_config():
     cfg = gsplat_amd.build_config()
     assert set(cfg) == {"3dgs", "2dgs", "3dgut", "adam", "reloc", "losses", "camera_wrappers"}  # ext.cpp:83-97
     assert gsplat_amd.has_3dgs() and gsplat_amd.has_2dgs() and gsplat_amd.has_adam() and gsplat_amd.has_reloc()
-    # 3DGUT is built in part (UT projection + from-world rasterizer, global shutter; no lidar / rolling-shutter projection): the
-    # reference's flag means the whole feature and its tests gate on it, so it reports False unless the subset is asked for
-    assert not gsplat_amd.has_3dgut() and not gsplat_amd.has_losses() and not gsplat_amd.has_camera_wrappers()
+    # 3DGUT (UT projection + from-world rasterizer for every camera model incl. the spinning lidar, global / rolling shutter,
+    # lidar tiling) is built: the flag is True like a full build of the reference; GSPLAT_AMD_3DGUT=0 switches it off
+    assert gsplat_amd.has_3dgut() and not gsplat_amd.has_losses() and not gsplat_amd.has_camera_wrappers()
     from gsplat_amd import csrc_shim
 
     assert csrc_shim.built_3dgut_subset()
-    os.environ["GSPLAT_AMD_3DGUT_SUBSET"] = "1"
+    os.environ["GSPLAT_AMD_3DGUT"] = "0"
     try:
-        assert csrc_shim.build_config()["3dgut"] is True
+        assert csrc_shim.build_config()["3dgut"] is False
     finally:
-        del os.environ["GSPLAT_AMD_3DGUT_SUBSET"]
+        del os.environ["GSPLAT_AMD_3DGUT"]
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
@@ -149,19 +149,29 @@ def test_elem_view_reads_single_columns_in_place():
     assert st == 1 and t.is_contiguous() and t.numel() == 4
 
 
-def test_storage_wrapper_identity_is_preserved_by_this_torch_build():
-    """`_ops._note_longest`'s Python fallback (compiled shim absent) keys a note by a weak reference to the tensor's untyped
-    storage WRAPPER: that only works on torch builds that hand the same PyObject back for the same StorageImpl while anything
-    holds it (PyObject preservation). Pin that behaviour: if a torch upgrade breaks it the notes silently never match."""
-    import weakref
-
+def test_longest_list_notes_python_fallback_is_keyed_by_storage_and_view():
+    """`_ops._note_longest`'s Python fallback (compiled shim absent, or GSPLAT_AMD_LIB set) keys a note by the StorageImpl's
+    address + the view (offset, numel) and keeps the noted tensor alive in its 16-entry ring, so the address cannot be handed
+    out again while the note exists and nothing depends on torch preserving a storage's Python wrapper between calls."""
     import torch
 
-    t = torch.zeros(8)
-    ref = weakref.ref(t.untyped_storage())  # the wrapper is a temporary here, as in _note_longest
-    assert ref() is not None and ref() is t.untyped_storage() and ref() is t[2:].untyped_storage()
-    del t
-    assert ref() is None  # and the note dies with the storage
+    from gsplat_amd import _ops
+
+    was = _ops._notes_compiled
+    _ops._notes_compiled = False
+    try:
+        t = torch.arange(16, dtype=torch.int32)
+        _ops._note_longest(t, 7)
+        assert _ops._lookup_longest(t) == 7 and _ops._lookup_longest(t.view(16)) == 7
+        assert _ops._lookup_longest(t[2:]) == 0 and _ops._lookup_longest(torch.arange(16, dtype=torch.int32)) == 0
+        _ops._note_longest(t, 9)  # a newer note of the same view replaces the old one
+        assert _ops._lookup_longest(t) == 9
+        for i in range(20):  # the ring holds 16 notes
+            _ops._note_longest(torch.zeros(4 + i, dtype=torch.int32), i)
+        assert len(_ops._notes_py) == 16 and _ops._lookup_longest(t) == 0
+    finally:
+        _ops._notes_py.clear()
+        _ops._notes_compiled = was
 
 
 def test_intersection_path_memory_is_per_caller_and_per_thread():

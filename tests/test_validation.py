@@ -92,8 +92,9 @@ def test_distributed_needs_a_process_group():
     (dict(with_ut=True, packed=False, covars=torch.rand(6, 3, 3), quats=None, scales=None), RuntimeError,
      "UT and Eval3D rasterization require quats and scales, not covars"),
     (dict(with_eval3d=True), RuntimeError, "Packed mode is not supported with Eval3D"),
-    (dict(with_ut=True, packed=False, camera_model="lidar", lidar_coeffs=object()), RuntimeError,
-     "Lidar camera model requires with_eval3d=True"),
+    (dict(packed=False, camera_model="lidar", lidar_coeffs=object()), RuntimeError, "Lidar camera model requires with_ut=True"),
+    (dict(with_ut=True, packed=False, camera_model="lidar"), RuntimeError,
+     "Lidar coefficients must be given if and only if camera model is lidar"),
 ])
 def test_classic_path_validation(over, exc, match):
     import gsplat_amd

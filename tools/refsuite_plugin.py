@@ -77,17 +77,35 @@ if "nerfacc" not in sys.modules:
         _m.pack_info = _pack_info
         sys.modules["nerfacc"] = _m
 
-# tests/test_rasterization.py imports ONE helper (parse_lidar_camera) from tests/test_cameras.py, a module that skips itself at
-# import time unless the camera-wrapper classes are built (`has_camera_wrappers()`: out of scope here) - which would skip the
-# whole of test_rasterization.py with it. A stand-in module keeps the file collectable; the lidar cases that call the helper skip.
+# tests/test_rasterization.py and tests/test_basic.py import ONE helper (parse_lidar_camera: it builds a lidar's parameter
+# record with the reference's Python preprocessing, no compiled class involved) from tests/test_cameras.py, a module that skips
+# itself at import time unless the camera-wrapper classes are built (`has_camera_wrappers()`: out of scope here) - which would
+# skip the whole of test_rasterization.py with it. The reference's own module is imported ONCE here, from the staged tree, with
+# that one gate held open for the duration of the import (its tests are never collected by the runner, only the helper is
+# used); if that import fails the lidar cases skip through a stand-in.
 if not _shim.build_config().get("camera_wrappers", False):
-    _tc = types.ModuleType("tests.test_cameras")
+    import importlib
 
-    def _parse_lidar_camera(*_a, **_k):
-        pytest.skip("lidar camera wrappers are not built (tests/test_cameras.py is skipped without them)")
+    import gsplat.cuda._wrapper as _gw
 
-    _tc.parse_lidar_camera = _parse_lidar_camera
-    sys.modules["tests.test_cameras"] = _tc
+    _gate = _gw.has_camera_wrappers
+    try:
+        _gw.has_camera_wrappers = lambda: True
+        if torch.cuda.is_available():
+            importlib.import_module("tests.test_cameras")
+        else:
+            raise ImportError("no GPU")
+    except BaseException as _e:  # pytest.skip raises an Exception subclass of BaseException in some versions
+        _why = "%s: %s" % (type(_e).__name__, _e)
+        _tc = types.ModuleType("tests.test_cameras")
+
+        def _parse_lidar_camera(*_a, **_k):
+            pytest.skip("tests/test_cameras.py could not be imported for its parse_lidar_camera helper (%s)" % _why)
+
+        _tc.parse_lidar_camera = _parse_lidar_camera
+        sys.modules["tests.test_cameras"] = _tc
+    finally:
+        _gw.has_camera_wrappers = _gate
 
 _LOG = os.environ.get("REFSUITE_LOG")
 _DONE = os.environ.get("REFSUITE_DONE")

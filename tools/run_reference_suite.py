@@ -93,8 +93,8 @@ def parse_log(path):
 def run_file(tree, fname, args, log, done):
     env = dict(os.environ)
     env["REFSUITE_LOG"], env["REFSUITE_DONE"] = log, done
-    if args.with_3dgut_subset:
-        env["GSPLAT_AMD_3DGUT_SUBSET"] = "1"
+    if args.without_3dgut:
+        env["GSPLAT_AMD_3DGUT"] = "0"
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tools"), ROOT, env.get("PYTHONPATH", "")])
     cmd = [sys.executable, "-m", "pytest", "-p", "refsuite_plugin", "-p", "no:cacheprovider", "-q", "-x" if args.exitfirst else "-q",
            "--timeout", str(args.timeout), "--tb=short", "-o", "addopts=", os.path.join("tests", fname)]
@@ -127,9 +127,9 @@ def main():
     ap.add_argument("--exitfirst", action="store_true")
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--from-archives", action="store_true", help="ignore a reference checkout (what the GPU box sees)")
-    ap.add_argument("--with-3dgut-subset", action="store_true",
-                    help="GSPLAT_AMD_3DGUT_SUBSET=1: has_3dgut() reports True, so the reference's 3DGUT tests RUN against the "
-                         "built subset instead of skipping (the default build_config says False: the feature is partial)")
+    ap.add_argument("--without-3dgut", action="store_true",
+                    help="GSPLAT_AMD_3DGUT=0: has_3dgut() reports False, so the reference's 3DGUT tests skip (the classic path alone)")
+    ap.add_argument("--with-3dgut-subset", action="store_true", help="accepted and ignored (has_3dgut() is True by default since round 6)")
     args = ap.parse_args()
 
     tree = tempfile.mkdtemp(prefix="refsuite_")
@@ -170,7 +170,7 @@ def main():
         device = "?"
     with open(args.out + ".txt", "w") as f:
         f.write("# the reference's own tests over gsplat_amd.csrc_shim; reference tree from: %s; device: %s; has_3dgut(): %s\n"
-                % (src, device, "True (GSPLAT_AMD_3DGUT_SUBSET=1)" if args.with_3dgut_subset else "False (default)"))
+                % (src, device, "False (GSPLAT_AMD_3DGUT=0)" if args.without_3dgut else "True (default)"))
         f.write("# totals: %s\n" % json.dumps(total, sort_keys=True))
         for fname, c in summary.items():
             f.write("# %-36s %s\n" % (fname, json.dumps({k: v for k, v in c.items() if k != "tail"}, sort_keys=True)))
