@@ -67,7 +67,7 @@ def test_reference_own_gpu_tests_pass_over_the_shim(tmp_path):
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     env.pop("GSPLAT_AMD_3DGUT", None)
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_suite.py"), "--files", ",".join(FILES),
-                          "--timeout", "300", "--out", out], capture_output=True, text=True, cwd=ROOT, env=env, timeout=2400)
+                          "--timeout", "300", "--jobs", "4", "--out", out], capture_output=True, text=True, cwd=ROOT, env=env, timeout=2400)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     summary = json.load(open(out + ".json"))
     bad, expected = [], []

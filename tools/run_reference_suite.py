@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--timeout", type=int, default=300)
     ap.add_argument("--max-crashes", type=int, default=8)
     ap.add_argument("--exitfirst", action="store_true")
+    ap.add_argument("--jobs", type=int, default=1, help="test files run side by side (one interpreter each, one GPU)")
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--from-archives", action="store_true", help="ignore a reference checkout (what the GPU box sees)")
     ap.add_argument("--without-3dgut", action="store_true",
@@ -141,10 +142,17 @@ def main():
         f.write("[pytest]\ntestpaths = tests\npythonpath = .\nmarkers =\n    gradcheck: numerical gradcheck\n")
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     summary, lines = {}, []
-    for fname in [x for x in args.files.split(",") if x]:
-        log = os.path.join(tree, fname + ".log")
-        done = os.path.join(tree, fname + ".done")
-        tails = run_file(tree, fname, args, log, done)
+    files = [x for x in args.files.split(",") if x]
+    paths = {f: (os.path.join(tree, f + ".log"), os.path.join(tree, f + ".done")) for f in files}
+    if args.jobs > 1:  # files side by side (each in its own interpreter anyway); the table keeps the order of --files
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(args.jobs) as pool:
+            futs = {f: pool.submit(run_file, tree, f, args, *paths[f]) for f in sorted(files, key=lambda f: f != "test_basic.py")}
+            all_tails = {f: futs[f].result() for f in files}
+    for fname in files:
+        log, done = paths[fname]
+        tails = all_tails[fname] if args.jobs > 1 else run_file(tree, fname, args, log, done)
         order, res, _ = parse_log(log)
         counts = {}
         for nodeid in order:
