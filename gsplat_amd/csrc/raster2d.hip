@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(256) raster2d_bwd_kernel(const Raster2DArgs a)
 // no __syncthreads, no LDS atomics, no accumulator table; tiles longest-first (tile_order.hip). D <= 4, 16 x 16 tiles, no
 // absgrad. Parity-green (tests/test_gpu_variants.py) and selectable (GSX_RASTER2D_BWD=w); not the default, see launch2_bwd.
 #ifndef GSX_BWD2_H_WAVES // the half-tile variant (NQ = 2)
-#define GSX_BWD2_H_WAVES 3
+#define GSX_BWD2_H_WAVES 4
 #endif
 #ifndef GSX_BWD2_W_WAVES // 168 VGPRs (three waves per SIMD) spill 51 registers at four channels: two
 #define GSX_BWD2_W_WAVES 2
