@@ -71,7 +71,7 @@ def test_reference_python_accepts_the_shim_as_gsplat_csrc():
         "from gsplat.cuda._backend import _C\n"
         "from gsplat.cuda import _wrapper as w\n"
         "assert _C is shim\n"
-        "assert w.has_3dgs() and not w.has_3dgut() and shim.built_3dgut_subset()  # partial 3DGUT: the flag says False\n"
+        "assert w.has_3dgs() and w.has_3dgut() and shim.built_3dgut_subset()  # 3DGUT incl. lidar cameras is built (round 6)\n"
         "import torch\n"
         "for op in ('rasterize_to_pixels_3dgs', 'projection_ewa_3dgs_fused', 'intersect_tile', 'spherical_harmonics'):\n"
         "    assert hasattr(torch.ops.gsplat, op)\n"
