@@ -351,7 +351,7 @@ def main():
     # ~50 us: r4d measured 1.05 ms per step with them, 0.996 ms without). The dominant kernels are timed live with HIP events
     # (on the launch stream) in the FIRST REPEAT of the same window, which is reported but kept out of value_median / value_best.
     raster_entries = ("gsx_raster3d_fwd", "gsx_raster3d_bwd", "gsx_raster3d_bwd_ws", "gsx_raster3d_bwd_fill", "gsx_raster3d_fwd_seg",
-                      "gsx_raster3d_bwd_seg", "gsx_raster3d_fwd_rows", "gsx_raster3d_bwd_fill_rows")
+                      "gsx_raster3d_bwd_seg", "gsx_raster3d_bwd_seg_reuse", "gsx_raster3d_fwd_rows", "gsx_raster3d_bwd_fill_rows")
     elapsed, meta, prof = timed(step, args.steps, 0, barrier, profile_only=raster_entries if args.lean else None)
 
     def max_over_ranks(x: float) -> float:

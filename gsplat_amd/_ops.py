@@ -62,7 +62,7 @@ _COMPILED_ISECT = False  # torch.ops.gsplat_amd.isect_fused_{begin,finish} avail
 # rendering.py learns the longest tile list from the intersection's pinned host words; the reference's op schemas have no
 # room for it, so it travels as a per-thread hint around the op call: above SEG_MIN_LONGEST the forward / backward cut long
 # lists into segments that separate workgroups composite (csrc/raster3d_seg.hip). No hint (0) = one workgroup per tile.
-SEG_LEN = int(os.environ.get("GSPLAT_AMD_SEG_LEN", "1024"))  # 0 switches segmenting off (A/B)
+SEG_LEN = int(os.environ.get("GSPLAT_AMD_SEG_LEN", "768"))  # 0 switches segmenting off (A/B); 768: profiles/r11_ab.md #2
 SEG_MIN_LONGEST = 2 * SEG_LEN if SEG_LEN > 0 else 1 << 62  # lower bound of the cut (csrc/raster3d_seg.hip: seg_cut_for)
 
 
@@ -165,6 +165,23 @@ def _lookup_longest(flatten_ids: Tensor) -> int:
             if k == key:
                 return longest
     return 0
+
+
+# The segment workspace of a compositing forward, for the backward over the same lists (csrc/raster3d_seg.hip:
+# gsx_raster3d_bwd_seg_reuse). The notes live in libgsplat_amd_torch.so (csrc/torch_ops.cpp: keyed by the identity of last_ids,
+# shared with the compiled op bodies); without the compiled shim the backward simply runs its pre-pass.
+_SEG_REUSE = os.environ.get("GSPLAT_AMD_SEG_REUSE", "1") not in ("0", "")
+
+
+def _note_seg_workspace(last_ids: Tensor, ws: Tensor, n_isects: int, D: int) -> None:
+    if _SEG_REUSE and _notes_compiled and hasattr(torch.ops.gsplat_amd, "note_seg_workspace"):
+        torch.ops.gsplat_amd.note_seg_workspace(last_ids, ws, int(n_isects), int(D), SEG_LEN)
+
+
+def _lookup_seg_workspace(last_ids: Tensor, n_isects: int, D: int) -> Optional[Tensor]:
+    if _SEG_REUSE and _notes_compiled and hasattr(torch.ops.gsplat_amd, "lookup_seg_workspace"):
+        return torch.ops.gsplat_amd.lookup_seg_workspace(last_ids, int(n_isects), int(D), SEG_LEN)
+    return None
 
 
 COMPILED_OPS: frozenset = frozenset()  # ops whose CUDA-key body is C++ (csrc/torch_ops.cpp) rather than a function of this file
@@ -1216,6 +1233,10 @@ def rasterize_to_pixels_3dgs(means2d, conics, colors, opacities, backgrounds, ma
         call("gsx_raster3d_fwd_seg", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
              ptr(isect_offsets), ptr(flatten_ids), I, flatten_ids.numel(), D, image_width, image_height, tile_size, tw,
              th, ptr(renders), ptr(alphas), ptr(last_ids), SEG_LEN, ptr(ws), ws.numel())
+        if D <= 4 and tile_size == 16:
+            # the backward over these lists starts its slices from the sums this call left in `ws` (no pre-pass): noted
+            # under the identity of last_ids, the tensor every autograd formula hands to the backward op
+            _note_seg_workspace(last_ids, ws, flatten_ids.numel(), D)
     elif rows is not None:
         call("gsx_raster3d_fwd_rows", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(rows), ptr(backgrounds),
              ptr(masks), ptr(isect_offsets), ptr(flatten_ids), I, flatten_ids.numel(), D, image_width, image_height, tile_size,
@@ -1276,10 +1297,12 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     if segmented:
         ws = torch.empty(_cabi._lib.gsx_raster3d_bwd_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN),
                          device=means2d.device, dtype=torch.uint8)
-        call("gsx_raster3d_bwd_seg", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
+        fws = _lookup_seg_workspace(last_ids, flatten_ids.numel(), D)  # the forward call's workspace, if still around
+        call("gsx_raster3d_bwd_seg_reuse", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
              ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
              ptr(last_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,
-             image_width, image_height, tile_size, tw, th, ptr(rows), geo + D, SEG_LEN, ptr(ws), ws.numel())
+             image_width, image_height, tile_size, tw, th, ptr(rows), geo + D, SEG_LEN, ptr(fws),
+             0 if fws is None else fws.numel(), ptr(ws), ws.numel())
     else:
         # workspace for the longest-first tile order of the launch (csrc/raster3d_bwd.hip: "longest tiles first")
         ws = torch.empty(_cabi._lib.gsx_raster3d_bwd_workspace_bytes(I, tw, th), device=means2d.device, dtype=torch.uint8)

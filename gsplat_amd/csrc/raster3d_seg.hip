@@ -191,6 +191,42 @@ __global__ void __launch_bounds__(256) seg_bwd_prefix_kernel(SegPlan p)
     }
 }
 
+// The same two per-slice values WITHOUT a pre-pass, for a caller that kept the workspace of the forward call over the same lists
+// (gsx_raster3d_bwd_seg_reuse): the forward's compositing pass left, per slice k and pixel, the colour sums C_k,c = sum_i alpha_i T_i
+// c_i,c taken with the TRUE running transmittance (plane c of `out`) and that transmittance at the slice's end (plane nch), so
+//   T at the end of slice k = out[k][nch],      B at the end of slice k = sum_(j > k) sum_c v_colour,c C_j,c.
+// A pixel that stopped inside slice k keeps its final transmittance there and has zero sums behind it - exactly what the
+// backward of its last contributor starts from. One workgroup per long tile of the FORWARD's plan, thread = pixel (tile_pixel).
+__global__ void __launch_bounds__(256) seg_bwd_from_fwd_kernel(const Raster3DArgs a, SegPlan pf, float *T_end, float *B_end)
+{
+    const int32_t li = (int32_t)blockIdx.x;
+    if (li >= pf.hdr->n_long) return;
+    const uint32_t blk = (uint32_t)pf.longs[3 * li];
+    const int32_t s0 = pf.longs[3 * li + 1], n_seg = pf.longs[3 * li + 2];
+    const uint32_t tiles_per_image = a.tile_w * a.tile_h;
+    TileCtx tc;
+    tc.image_id = blk / tiles_per_image; tc.tile_id = blk % tiles_per_image;
+    tc.tile_x = tc.tile_id % a.tile_w; tc.tile_y = tc.tile_id / a.tile_w;
+    tc.range_start = tc.range_end = 0;
+    const uint32_t tid = threadIdx.x;
+    uint32_t lx, ly;
+    tile_pixel(tid, a.tile_size, lx, ly);
+    const int64_t prow = pixel_row(a, tc, 0u, lx, ly);
+    float v_c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (prow >= 0)
+        for (uint32_t c = 0; c < a.nch; ++c) v_c[c] = a.v_render_colors[vrc_index(a, (size_t)prow, a.ch_off + c)];
+    const uint32_t planes = a.nch + 1;
+    float behind = 0.0f;
+    for (int32_t k = n_seg - 1; k >= 0; --k) {
+        const size_t it = (size_t)(s0 + k);
+        T_end[it * 256 + tid] = pf.out[(it * planes + a.nch) * 256 + tid];
+        B_end[it * 256 + tid] = behind;
+        float d = 0.0f;
+        for (uint32_t c = 0; c < a.nch; ++c) d += v_c[c] * pf.out[(it * planes + c) * 256 + tid];
+        behind += d;
+    }
+}
+
 // one workgroup per long tile; thread = pixel in the per-tile launch's order (tile_pixel)
 __global__ void __launch_bounds__(256) seg_combine_kernel(const Raster3DArgs a, SegPlan p)
 {
@@ -305,6 +341,8 @@ extern "C" int gsx_raster3d_fwd_seg(
                 seg_prefix_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(p);
             }
             // ONE compositing launch: the segment items first (the longest units of work), the short tiles behind them
+            // (in launch order: taking the short tiles longest-first like the one-wave backward does COSTS the forward 0.39 ->
+            // 0.45 ms on the garden x25 scene - neighbouring tiles stop sharing an L2 - profiles/r11_ab.md #3)
             a.seg_mode = 2; a.seg_grid = p.max_items + n_blocks;
             rc = raster3d_fwd_launch_chunk(a, s);
             if (rc != GSX_OK) return rc;
@@ -323,12 +361,13 @@ extern "C" int gsx_raster3d_fwd_seg(
 
 // Backward with long tile lists cut into segments (see seg_bwd_prefix_kernel). Applies where the backward runs its variant T
 // (<= 4 channels, 16 x 16 tiles, no absgrad); anything else is the caller's to send to gsx_raster3d_bwd.
-extern "C" int gsx_raster3d_bwd_seg(
+static int raster3d_bwd_seg_impl(
     const float *means2d, const float *conics, const float *colors, const float *opacities, const float *backgrounds,
     const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids, const float *render_alphas,
     const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas, uint32_t n_images, uint32_t n_isects,
     uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *v_rows,
-    uint32_t row_stride, uint32_t seg_len, void *workspace, int64_t workspace_bytes, void *stream)
+    uint32_t row_stride, uint32_t seg_len, const void *fwd_workspace, int64_t fwd_workspace_bytes, void *workspace,
+    int64_t workspace_bytes, void *stream)
 {
     GSX_REQUIRE(tile_size == 16 && cdim >= 1 && cdim <= 4,
                 "gsx_raster3d_bwd_seg: needs 16 x 16 tiles and <= 4 channels (got tile %u, %u channels): use gsx_raster3d_bwd",
@@ -339,6 +378,7 @@ extern "C" int gsx_raster3d_bwd_seg(
                                 tile_w, tile_h, 0, v_rows, row_stride, stream);
     GSX_REQUIRE(seg_len >= 256, "gsx_raster3d_bwd_seg: seg_len must be >= 256, got %u", seg_len);
     if (n_isects == 0) return GSX_OK;
+    const uint32_t fwd_seg_len = seg_len;
     seg_len = bwd_slice_len(seg_len); // workspace: gsx_raster3d_bwd_seg_workspace_bytes
     GSX_REQUIRE(v_rows && row_stride >= 6u + cdim, "gsx_raster3d_bwd_seg: gradient rows missing / too narrow");
     GSX_REQUIRE(means2d && conics && colors && opacities && flatten_ids && render_alphas && last_ids && v_render_colors
@@ -363,16 +403,36 @@ extern "C" int gsx_raster3d_bwd_seg(
         set_last_error("gsx_raster3d_bwd_seg: workspace too small");
         return GSX_ERR_WORKSPACE;
     }
-    if (hipMemsetAsync(p.hdr, 0, sizeof(SegHeader), s) != hipSuccess) return check_launch("raster3d_bwd_seg memset");
-    seg_plan_kernel<<<dim3((n_blocks + 255) / 256), dim3(256), 0, s>>>(isect_offsets, n_blocks, n_isects, seg_len, seg_cut, p);
-    a.seg_len = seg_len; a.seg_cut = seg_cut; a.seg_items = p.items; a.seg_count = &p.hdr->n_items;
+    // The forward's workspace over the same lists (gsx_raster3d_bwd_seg_reuse): its plan IS this launch's plan and its
+    // per-slice sums replace the pre-pass - when the backward cuts its slices as long as the forward did (variant T)
+    SegPlan pf{};
+    bool reuse = false;
+    if (fwd_workspace && seg_len == fwd_seg_len) {
+        unsigned char *fbase = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(fwd_workspace) + 255) & ~(uintptr_t)255);
+        const int64_t need = (fbase - reinterpret_cast<const unsigned char *>(fwd_workspace))
+                             + seg_layout(n_isects, n_blocks, cdim, fwd_seg_len, fbase, &pf);
+        if (need > fwd_workspace_bytes) {
+            set_last_error("gsx_raster3d_bwd_seg_reuse: forward workspace too small for these lists (not the forward call's?)");
+            return GSX_ERR_WORKSPACE;
+        }
+        reuse = true;
+    }
+    a.seg_len = seg_len; a.seg_cut = seg_cut;
     a.seg_T = p.T; a.seg_out = p.out; a.seg_last = p.last;
     int rc;
-    if (p.max_items > 0) {
-        a.seg_mode = 1; a.seg_grid = p.max_items;
-        rc = raster3d_bwd_prepass_launch(a, s);
-        if (rc != GSX_OK) return rc;
-        seg_bwd_prefix_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(p);
+    if (reuse) {
+        a.seg_items = pf.items; a.seg_count = &pf.hdr->n_items;
+        if (pf.max_items > 0) seg_bwd_from_fwd_kernel<<<dim3(pf.max_long), dim3(256), 0, s>>>(a, pf, p.T, p.out);
+    } else {
+        if (hipMemsetAsync(p.hdr, 0, sizeof(SegHeader), s) != hipSuccess) return check_launch("raster3d_bwd_seg memset");
+        seg_plan_kernel<<<dim3((n_blocks + 255) / 256), dim3(256), 0, s>>>(isect_offsets, n_blocks, n_isects, seg_len, seg_cut, p);
+        a.seg_items = p.items; a.seg_count = &p.hdr->n_items;
+        if (p.max_items > 0) {
+            a.seg_mode = 1; a.seg_grid = p.max_items;
+            rc = raster3d_bwd_prepass_launch(a, s);
+            if (rc != GSX_OK) return rc;
+            seg_bwd_prefix_kernel<<<dim3(p.max_long), dim3(256), 0, s>>>(p);
+        }
     }
     // the slices first, the short tiles behind them. The short-tile range must hold round8(n_blocks) workgroups whatever the
     // device-side item count is (xcd_remap is a bijection over round8(n_blocks) slots only)
@@ -390,4 +450,32 @@ extern "C" int gsx_raster3d_bwd_seg(
     rc = seg_bwd_on_variant_w() ? raster3d_bwd_w_launch_items(a, s) : raster3d_bwd_t_launch_items(a, s);
     if (rc != GSX_OK) return rc;
     return check_launch("raster3d_bwd_seg");
+}
+
+extern "C" int gsx_raster3d_bwd_seg(
+    const float *means2d, const float *conics, const float *colors, const float *opacities, const float *backgrounds,
+    const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids, const float *render_alphas,
+    const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas, uint32_t n_images, uint32_t n_isects,
+    uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *v_rows,
+    uint32_t row_stride, uint32_t seg_len, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return raster3d_bwd_seg_impl(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas,
+                                 last_ids, v_render_colors, v_render_alphas, n_images, n_isects, cdim, width, height, tile_size,
+                                 tile_w, tile_h, v_rows, row_stride, seg_len, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+// gsx_raster3d_bwd_seg for a caller that still holds the workspace of the gsx_raster3d_fwd_seg call over the same lists (same
+// seg_len, <= 4 channels = one channel chunk): no pre-pass (seg_bwd_from_fwd_kernel). NULL = gsx_raster3d_bwd_seg.
+extern "C" int gsx_raster3d_bwd_seg_reuse(
+    const float *means2d, const float *conics, const float *colors, const float *opacities, const float *backgrounds,
+    const uint8_t *masks, const int32_t *isect_offsets, const int32_t *flatten_ids, const float *render_alphas,
+    const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas, uint32_t n_images, uint32_t n_isects,
+    uint32_t cdim, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_w, uint32_t tile_h, float *v_rows,
+    uint32_t row_stride, uint32_t seg_len, const void *fwd_workspace, int64_t fwd_workspace_bytes, void *workspace,
+    int64_t workspace_bytes, void *stream)
+{
+    return raster3d_bwd_seg_impl(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas,
+                                 last_ids, v_render_colors, v_render_alphas, n_images, n_isects, cdim, width, height, tile_size,
+                                 tile_w, tile_h, v_rows, row_stride, seg_len, fwd_workspace, fwd_workspace_bytes, workspace,
+                                 workspace_bytes, stream);
 }

@@ -589,6 +589,62 @@ int64_t lookup_longest(const Tensor &flat)
     return 0;
 }
 
+// ---- the segment workspace of a compositing FORWARD, for the backward over the same lists ------------------------------
+// gsx_raster3d_fwd_seg leaves every slice's colour sums and end transmittance in its workspace; a backward that still has it
+// needs no pre-pass (gsx_raster3d_bwd_seg_reuse). The reference's op schemas have no slot for a workspace, so the forward
+// body notes it under the identity of the `last_ids` it returns (the tensor every autograd formula - this package's and the
+// reference's own - saves and hands to the backward op), the same way the longest list is noted above: a weak reference to
+// the StorageImpl, never an address. The workspace itself is held STRONGLY (tens of MB for a 1080p scene) in a ring of four;
+// a note whose last_ids died is dropped at the next call of either function.
+struct SegWsNote {
+    std::optional<c10::weak_intrusive_ptr<c10::StorageImpl>> storage;
+    int64_t offset = 0, n = 0, n_isects = 0, cdim = 0, seg_len = 0;
+    Tensor ws;
+    const c10::StorageImpl *target() const { return storage ? storage->_unsafe_get_target() : nullptr; }
+};
+static std::mutex g_seg_ws_mu;
+static SegWsNote g_seg_ws[4];
+static unsigned g_seg_ws_next = 0;
+static void seg_ws_purge_locked()
+{
+    for (auto &e : g_seg_ws)
+        if (e.storage && e.storage->expired()) e = SegWsNote();
+}
+void note_seg_workspace(const Tensor &last_ids, const Tensor &ws, int64_t n_isects, int64_t cdim, int64_t seg_len)
+{
+    if (!last_ids.defined() || last_ids.numel() <= 0 || !last_ids.has_storage()) return;
+    c10::StorageImpl *impl = last_ids.storage().unsafeGetStorageImpl();
+    std::lock_guard<std::mutex> lock(g_seg_ws_mu);
+    seg_ws_purge_locked();
+    SegWsNote fresh;
+    fresh.storage = c10::weak_intrusive_ptr<c10::StorageImpl>(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(impl));
+    fresh.offset = last_ids.storage_offset(); fresh.n = last_ids.numel();
+    fresh.n_isects = n_isects; fresh.cdim = cdim; fresh.seg_len = seg_len; fresh.ws = ws;
+    for (auto &e : g_seg_ws)
+        if (e.target() == impl) { e = std::move(fresh); return; }
+    g_seg_ws[g_seg_ws_next++ % 4u] = std::move(fresh);
+}
+Tensor lookup_seg_workspace(const Tensor &last_ids, int64_t n_isects, int64_t cdim, int64_t seg_len)
+{
+    if (!last_ids.defined() || last_ids.numel() <= 0 || !last_ids.has_storage()) return Tensor();
+    const c10::StorageImpl *impl = last_ids.storage().unsafeGetStorageImpl();
+    std::lock_guard<std::mutex> lock(g_seg_ws_mu);
+    seg_ws_purge_locked();
+    for (const auto &e : g_seg_ws)
+        if (e.target() == impl && e.offset == last_ids.storage_offset() && e.n == last_ids.numel() && e.n_isects == n_isects
+            && e.cdim == cdim && e.seg_len == seg_len && e.ws.defined() && e.ws.device() == last_ids.device())
+            return e.ws;
+    return Tensor();
+}
+static bool seg_reuse_env()
+{
+    static const bool v = [] {
+        const char *e = std::getenv("GSPLAT_AMD_SEG_REUSE"); // 0: always the pre-pass (A/B)
+        return !(e && (e[0] == '0' || e[0] == 0));
+    }();
+    return v;
+}
+
 // ---- tile intersection --------------------------------------------------------------------------------------------------
 Tensor bytes(int64_t n, const Tensor &like) { return at::empty({n < 8 ? 8 : n}, like.options().dtype(at::kByte)); }
 
@@ -777,7 +833,7 @@ static int64_t seg_len_env()
 {
     static const int64_t v = [] {
         const char *e = std::getenv("GSPLAT_AMD_SEG_LEN");
-        return e ? (int64_t)std::atoll(e) : (int64_t)1024;
+        return e ? (int64_t)std::atoll(e) : (int64_t)768;
     }();
     return v;
 }
@@ -821,6 +877,8 @@ rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Te
                                    (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th, mp<float>(renders),
                                    mp<float>(alphas), mp<int32_t>(last_ids), (uint32_t)kSegLen, ws.mutable_data_ptr(), ws.numel(), L.stream),
               "gsx_raster3d_fwd_seg");
+        // the backward over these lists starts its slices from the sums this call left (no pre-pass): <= 4 channels only
+        if (r.D <= 4 && tile_size == 16 && seg_reuse_env()) note_seg_workspace(last_ids, ws, flat.numel(), r.D, kSegLen);
     } else if (splat_rows)
     { Timed timed_("gsx_raster3d_fwd", L.stream); check(gsx_raster3d_fwd_rows(fp(means2d), fp(conics), fp(colors), fp(opac), splat_rows, fp(bg),
                            masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
@@ -866,13 +924,17 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
     if (segmented) {
         Tensor ws = at::empty({gsx_raster3d_bwd_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
                                                                   (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
+        // the forward call's workspace, when this process still has it (noted under last_ids): no pre-pass
+        const Tensor fws = seg_reuse_env() ? lookup_seg_workspace(last_ids_, flat.numel(), r.D, kSegLen) : Tensor();
         Timed timed_("gsx_raster3d_bwd", L.stream);
-        check(gsx_raster3d_bwd_seg(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
+        check(gsx_raster3d_bwd_seg_reuse(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
                                    masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
                                    cp<int32_t>(flat), fp(ra), cp<int32_t>(li), fp(v_rc), fp(v_ra), (uint32_t)r.I, (uint32_t)flat.numel(),
                                    (uint32_t)r.D, (uint32_t)width, (uint32_t)height, (uint32_t)tile_size, (uint32_t)r.tw, (uint32_t)r.th,
-                                   mp<float>(rows), (uint32_t)(geo + r.D), (uint32_t)kSegLen, ws.mutable_data_ptr(), ws.numel(), L.stream),
-              "gsx_raster3d_bwd_seg");
+                                   mp<float>(rows), (uint32_t)(geo + r.D), (uint32_t)kSegLen,
+                                   fws.defined() ? fws.const_data_ptr() : nullptr, fws.defined() ? fws.numel() : 0,
+                                   ws.mutable_data_ptr(), ws.numel(), L.stream),
+              "gsx_raster3d_bwd_seg_reuse");
     } else
     {
         // workspace for the longest-first tile order of the launch (csrc/raster3d_bwd.hip: "longest tiles first")
@@ -1070,6 +1132,15 @@ void set_long_tile_hint(int64_t longest) { g_long_tile_hint = longest; }
 void set_splat_rows(const float *rows, const float *key) { g_splat_rows = rows; g_splat_rows_key = key; }
 void note_longest_op(const Tensor &flatten_ids, int64_t longest) { note_longest(flatten_ids, longest); }
 int64_t lookup_longest_op(const Tensor &flatten_ids) { return lookup_longest(flatten_ids); }
+void note_seg_workspace_op(const Tensor &last_ids, const Tensor &ws, int64_t n_isects, int64_t cdim, int64_t seg_len)
+{
+    note_seg_workspace(last_ids, ws, n_isects, cdim, seg_len);
+}
+std::optional<Tensor> lookup_seg_workspace_op(const Tensor &last_ids, int64_t n_isects, int64_t cdim, int64_t seg_len)
+{
+    Tensor t = lookup_seg_workspace(last_ids, n_isects, cdim, seg_len);
+    return t.defined() ? std::optional<Tensor>(t) : std::nullopt;
+}
 } // namespace gsplat_amd
 
 // gsplat_amd/_ops.py (ctypes): the longest tile list of the intersection that the next compositing call of THIS thread consumes
@@ -1088,6 +1159,8 @@ TORCH_LIBRARY(gsplat_amd, m)
     // the Python op bodies (GSPLAT_AMD_COMPILED_OPS=0, A/B kernel libraries) share the compiled bodies' notes
     m.def("note_longest(Tensor flatten_ids, int longest) -> ()");
     m.def("lookup_longest(Tensor flatten_ids) -> int");
+    m.def("note_seg_workspace(Tensor last_ids, Tensor ws, int n_isects, int cdim, int seg_len) -> ()");
+    m.def("lookup_seg_workspace(Tensor last_ids, int n_isects, int cdim, int seg_len) -> Tensor?");
 }
 
 TORCH_LIBRARY_IMPL(gsplat_amd, CUDA, m)
@@ -1101,6 +1174,8 @@ TORCH_LIBRARY_IMPL(gsplat_amd, CompositeExplicitAutograd, m)
 {
     m.impl("note_longest", &gsplat_amd::note_longest_op);
     m.impl("lookup_longest", &gsplat_amd::lookup_longest_op);
+    m.impl("note_seg_workspace", &gsplat_amd::note_seg_workspace_op);
+    m.impl("lookup_seg_workspace", &gsplat_amd::lookup_seg_workspace_op);
 }
 
 TORCH_LIBRARY_IMPL(gsplat, CUDA, m)

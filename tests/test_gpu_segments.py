@@ -2,7 +2,8 @@
 lists, which the other suites pin to the oracle - and against the oracle directly on a small scene. Scenes: faint Gaussians
 (no pixel saturates: every slice contributes), opaque ones (early termination fires inside the first slices: the later ones
 carry transmittance 0 and stop at once), a mix, backgrounds, tile masks, more than 32 channels (two channel chunks),
-several images. The backward (pre-pass + per-pixel prefix + slices walked back to front) against the per-tile backward."""
+several images. The backward (per-slice state from the forward's workspace, or pre-pass + per-pixel prefix, then slices walked
+back to front) against the per-tile backward."""
 import math
 
 import pytest
@@ -221,6 +222,49 @@ def test_stage_level_callers_get_segments_without_a_hint(G):
     # through the raw torch ops too (what the reference's Python calls)
     out = torch.ops.gsplat.rasterize_to_pixels_3dgs(m2, con, colors, op, None, None, W, H, 16, off, fl, False, False)
     assert torch.equal(out[0], res["hinted"][0])
+
+
+@pytest.mark.parametrize("kind", ["faint", "opaque", "mixed"])
+def test_segmented_backward_from_the_forward_workspace_equals_the_prepass(G, kind):
+    """gsx_raster3d_bwd_seg_reuse: the forward op notes its segment workspace under the identity of the last_ids it returns;
+    a backward op that receives THAT tensor starts its slices from the forward's per-slice sums (no pre-pass), one that
+    receives a copy of it (another storage: no note) runs the pre-pass. Same gradients up to the association order of the
+    "behind" sums; the workspace is only read, so a second backward over the same forward gives the same answer."""
+    from gsplat_amd import _ops
+
+    opacity = {"faint": 0.008, "opaque": 0.9, "mixed": (lambda o: torch.where(torch.rand_like(o) < 0.5, o * 0.02 + 0.004, o))}[kind]
+    m2, con, op, off, fl, longest, W, H, tw, th = _lists(G, 40000, 2, 320, 192, opacity, seed=23)
+    g = torch.Generator().manual_seed(77)
+    colors = torch.rand(m2.shape[:-1] + (3,), generator=g).to(DEV)
+    bg = torch.rand(2, 3, generator=g).to(DEV)
+    w_c = torch.randn(2, H, W, 3, generator=g).to(DEV)
+    w_a = torch.randn(2, H, W, 1, generator=g).to(DEV)
+    _ops.set_long_tile_hint(longest)
+    rc, ra, _, last_ids = torch.ops.gsplat.rasterize_to_pixels_3dgs(m2, con, colors, op, bg, None, W, H, 16, off, fl, False, False)
+    _ops.set_long_tile_hint(0)
+    noted = torch.ops.gsplat_amd.lookup_seg_workspace(last_ids, fl.numel(), 3, _ops.SEG_LEN)
+    assert noted is not None, "the forward did not note its segment workspace"
+    assert torch.ops.gsplat_amd.lookup_seg_workspace(last_ids.clone(), fl.numel(), 3, _ops.SEG_LEN) is None
+    assert torch.ops.gsplat_amd.lookup_seg_workspace(last_ids, fl.numel() - 1, 3, _ops.SEG_LEN) is None  # other lists
+    before = noted.clone()
+
+    def backward(li):
+        _ops.set_long_tile_hint(longest)
+        try:
+            return torch.ops.gsplat.rasterize_to_pixels_3dgs_bwd(m2, con, colors, op, bg, None, off, fl, ra, li, W, H, 16, False,
+                                                                 w_c, w_a, True)
+        finally:
+            _ops.set_long_tile_hint(0)
+
+    reuse, again, prepass = backward(last_ids), backward(last_ids), backward(last_ids.clone())
+    assert torch.equal(noted, before), "the backward wrote into the forward's workspace"
+    for nm, a, b, c in zip(("abs", "means2d", "conics", "colors", "opacities", "backgrounds"), reuse, again, prepass):
+        if a is None:
+            assert b is None and c is None
+            continue
+        assert_grad_close(a.cpu(), c.cpu(), name=f"{kind} reuse vs pre-pass v_{nm}")
+        assert_grad_close(a.cpu(), b.cpu(), name=f"{kind} reuse, second backward v_{nm}")
+    del rc
 
 
 def test_segmented_backward_on_the_one_wave_kernel():
