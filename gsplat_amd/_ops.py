@@ -173,14 +173,16 @@ def _lookup_longest(flatten_ids: Tensor) -> int:
 _SEG_REUSE = os.environ.get("GSPLAT_AMD_SEG_REUSE", "1") not in ("0", "")
 
 
-def _note_seg_workspace(last_ids: Tensor, ws: Tensor, n_isects: int, D: int) -> None:
+def _note_seg_workspace(last_ids: Tensor, ws: Tensor, n_isects: int, D: int, inputs) -> None:
+    """`inputs`: (means2d, conics, colors, opacities, isect_offsets, flatten_ids) as the op received them - the note only serves
+    a backward that brings the same tensors, unwritten since (address + version counter)."""
     if _SEG_REUSE and _notes_compiled and hasattr(torch.ops.gsplat_amd, "note_seg_workspace"):
-        torch.ops.gsplat_amd.note_seg_workspace(last_ids, ws, int(n_isects), int(D), SEG_LEN)
+        torch.ops.gsplat_amd.note_seg_workspace(last_ids, ws, int(n_isects), int(D), SEG_LEN, list(inputs))
 
 
-def _lookup_seg_workspace(last_ids: Tensor, n_isects: int, D: int) -> Optional[Tensor]:
+def _lookup_seg_workspace(last_ids: Tensor, n_isects: int, D: int, inputs) -> Optional[Tensor]:
     if _SEG_REUSE and _notes_compiled and hasattr(torch.ops.gsplat_amd, "lookup_seg_workspace"):
-        return torch.ops.gsplat_amd.lookup_seg_workspace(last_ids, int(n_isects), int(D), SEG_LEN)
+        return torch.ops.gsplat_amd.lookup_seg_workspace(last_ids, int(n_isects), int(D), SEG_LEN, list(inputs))
     return None
 
 
@@ -1212,6 +1214,7 @@ def _raster_dims(isect_offsets, colors):
 def rasterize_to_pixels_3dgs(means2d, conics, colors, opacities, backgrounds, masks, image_width, image_height,
                              tile_size, isect_offsets, flatten_ids, packed, absgrad):
     _check_f32(means2d=means2d, conics=conics, colors=colors, opacities=opacities, backgrounds=backgrounds)
+    as_received = (means2d, conics, colors, opacities, isect_offsets, flatten_ids)  # key of the segment-workspace note
     image_dims, I, th, tw, D = _raster_dims(isect_offsets, colors)
     if th * tile_size < image_height or tw * tile_size < image_width:
         raise ValueError("rasterize_to_pixels: isect_offsets tile grid does not cover the image")
@@ -1236,7 +1239,7 @@ def rasterize_to_pixels_3dgs(means2d, conics, colors, opacities, backgrounds, ma
         if D <= 4 and tile_size == 16:
             # the backward over these lists starts its slices from the sums this call left in `ws` (no pre-pass): noted
             # under the identity of last_ids, the tensor every autograd formula hands to the backward op
-            _note_seg_workspace(last_ids, ws, flatten_ids.numel(), D)
+            _note_seg_workspace(last_ids, ws, flatten_ids.numel(), D, as_received)
     elif rows is not None:
         call("gsx_raster3d_fwd_rows", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(rows), ptr(backgrounds),
              ptr(masks), ptr(isect_offsets), ptr(flatten_ids), I, flatten_ids.numel(), D, image_width, image_height, tile_size,
@@ -1272,6 +1275,7 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
                                  render_alphas, last_ids, image_width, image_height, tile_size, absgrad,
                                  v_render_colors, v_render_alphas, compute_v_backgrounds):
     image_dims, I, th, tw, D = _raster_dims(tile_offsets, colors)
+    as_received = (means2d, conics, colors, opacities, tile_offsets, flatten_ids)  # key of the segment-workspace note
     means2d, conics, colors, opacities = (means2d.contiguous(), conics.contiguous(), colors.contiguous(),
                                           opacities.contiguous())
     backgrounds, masks = _c(backgrounds), _c(masks)
@@ -1297,7 +1301,7 @@ def rasterize_to_pixels_3dgs_bwd(means2d, conics, colors, opacities, backgrounds
     if segmented:
         ws = torch.empty(_cabi._lib.gsx_raster3d_bwd_seg_workspace_bytes(flatten_ids.numel(), I, tw, th, D, SEG_LEN),
                          device=means2d.device, dtype=torch.uint8)
-        fws = _lookup_seg_workspace(last_ids, flatten_ids.numel(), D)  # the forward call's workspace, if still around
+        fws = _lookup_seg_workspace(last_ids, flatten_ids.numel(), D, as_received)  # the forward call's workspace, if still around
         call("gsx_raster3d_bwd_seg_reuse", ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds), ptr(masks),
              ptr(tile_offsets.contiguous()), ptr(flatten_ids.contiguous()), ptr(render_alphas.contiguous()),
              ptr(last_ids.contiguous()), ptr(v_render_colors), ptr(v_render_alphas), I, flatten_ids.numel(), D,

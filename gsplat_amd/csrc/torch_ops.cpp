@@ -599,18 +599,31 @@ int64_t lookup_longest(const Tensor &flat)
 struct SegWsNote {
     std::optional<c10::weak_intrusive_ptr<c10::StorageImpl>> storage;
     int64_t offset = 0, n = 0, n_isects = 0, cdim = 0, seg_len = 0;
+    std::vector<int64_t> inputs; // (address, version) of every tensor the forward composited from: see seg_ws_inputs_key
     Tensor ws;
     const c10::StorageImpl *target() const { return storage ? storage->_unsafe_get_target() : nullptr; }
 };
 static std::mutex g_seg_ws_mu;
 static SegWsNote g_seg_ws[4];
 static unsigned g_seg_ws_next = 0;
+// The sums in the workspace belong to the forward's INPUTS: a backward call that brings other tensors than the forward saw, or
+// the same ones written to since (version counter), gets no workspace and runs its pre-pass on what it was given.
+static std::vector<int64_t> seg_ws_inputs_key(at::TensorList inputs)
+{
+    std::vector<int64_t> k;
+    for (const Tensor &t : inputs) {
+        k.push_back(t.defined() ? (int64_t)reinterpret_cast<intptr_t>(t.const_data_ptr()) : 0);
+        k.push_back(t.defined() && !t.is_inference() ? (int64_t)t._version() : 0);
+    }
+    return k;
+}
 static void seg_ws_purge_locked()
 {
     for (auto &e : g_seg_ws)
         if (e.storage && e.storage->expired()) e = SegWsNote();
 }
-void note_seg_workspace(const Tensor &last_ids, const Tensor &ws, int64_t n_isects, int64_t cdim, int64_t seg_len)
+void note_seg_workspace(const Tensor &last_ids, const Tensor &ws, int64_t n_isects, int64_t cdim, int64_t seg_len,
+                        at::TensorList inputs)
 {
     if (!last_ids.defined() || last_ids.numel() <= 0 || !last_ids.has_storage()) return;
     c10::StorageImpl *impl = last_ids.storage().unsafeGetStorageImpl();
@@ -620,18 +633,20 @@ void note_seg_workspace(const Tensor &last_ids, const Tensor &ws, int64_t n_isec
     fresh.storage = c10::weak_intrusive_ptr<c10::StorageImpl>(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(impl));
     fresh.offset = last_ids.storage_offset(); fresh.n = last_ids.numel();
     fresh.n_isects = n_isects; fresh.cdim = cdim; fresh.seg_len = seg_len; fresh.ws = ws;
+    fresh.inputs = seg_ws_inputs_key(inputs);
     for (auto &e : g_seg_ws)
         if (e.target() == impl) { e = std::move(fresh); return; }
     g_seg_ws[g_seg_ws_next++ % 4u] = std::move(fresh);
 }
-Tensor lookup_seg_workspace(const Tensor &last_ids, int64_t n_isects, int64_t cdim, int64_t seg_len)
+Tensor lookup_seg_workspace(const Tensor &last_ids, int64_t n_isects, int64_t cdim, int64_t seg_len, at::TensorList inputs)
 {
     if (!last_ids.defined() || last_ids.numel() <= 0 || !last_ids.has_storage()) return Tensor();
     const c10::StorageImpl *impl = last_ids.storage().unsafeGetStorageImpl();
     std::lock_guard<std::mutex> lock(g_seg_ws_mu);
     seg_ws_purge_locked();
+    const std::vector<int64_t> key = seg_ws_inputs_key(inputs);
     for (const auto &e : g_seg_ws)
-        if (e.target() == impl && e.offset == last_ids.storage_offset() && e.n == last_ids.numel() && e.n_isects == n_isects
+        if (e.target() == impl && e.inputs == key && e.offset == last_ids.storage_offset() && e.n == last_ids.numel() && e.n_isects == n_isects
             && e.cdim == cdim && e.seg_len == seg_len && e.ws.defined() && e.ws.device() == last_ids.device())
             return e.ws;
     return Tensor();
@@ -878,7 +893,8 @@ rasterize_to_pixels_3dgs(const Tensor &means2d_, const Tensor &conics_, const Te
                                    mp<float>(alphas), mp<int32_t>(last_ids), (uint32_t)kSegLen, ws.mutable_data_ptr(), ws.numel(), L.stream),
               "gsx_raster3d_fwd_seg");
         // the backward over these lists starts its slices from the sums this call left (no pre-pass): <= 4 channels only
-        if (r.D <= 4 && tile_size == 16 && seg_reuse_env()) note_seg_workspace(last_ids, ws, flat.numel(), r.D, kSegLen);
+        if (r.D <= 4 && tile_size == 16 && seg_reuse_env())
+            note_seg_workspace(last_ids, ws, flat.numel(), r.D, kSegLen, {means2d_, conics_, colors_, opacities_, isect_offsets_, flatten_ids_});
     } else if (splat_rows)
     { Timed timed_("gsx_raster3d_fwd", L.stream); check(gsx_raster3d_fwd_rows(fp(means2d), fp(conics), fp(colors), fp(opac), splat_rows, fp(bg),
                            masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
@@ -925,7 +941,9 @@ rasterize_to_pixels_3dgs_bwd(const Tensor &means2d_, const Tensor &conics_, cons
         Tensor ws = at::empty({gsx_raster3d_bwd_seg_workspace_bytes(flat.numel(), (uint32_t)r.I, (uint32_t)r.tw, (uint32_t)r.th, (uint32_t)r.D,
                                                                   (uint32_t)kSegLen)}, means2d.options().dtype(at::kByte));
         // the forward call's workspace, when this process still has it (noted under last_ids): no pre-pass
-        const Tensor fws = seg_reuse_env() ? lookup_seg_workspace(last_ids_, flat.numel(), r.D, kSegLen) : Tensor();
+        const Tensor fws = seg_reuse_env() ? lookup_seg_workspace(last_ids_, flat.numel(), r.D, kSegLen,
+                                                                  {means2d_, conics_, colors_, opacities_, tile_offsets_, flatten_ids_})
+                                           : Tensor();
         Timed timed_("gsx_raster3d_bwd", L.stream);
         check(gsx_raster3d_bwd_seg_reuse(fp(means2d), fp(conics), fp(colors), fp(opac), fp(bg),
                                    masks ? (const uint8_t *)masks->const_data_ptr<bool>() : nullptr, cp<int32_t>(offsets),
@@ -1132,13 +1150,15 @@ void set_long_tile_hint(int64_t longest) { g_long_tile_hint = longest; }
 void set_splat_rows(const float *rows, const float *key) { g_splat_rows = rows; g_splat_rows_key = key; }
 void note_longest_op(const Tensor &flatten_ids, int64_t longest) { note_longest(flatten_ids, longest); }
 int64_t lookup_longest_op(const Tensor &flatten_ids) { return lookup_longest(flatten_ids); }
-void note_seg_workspace_op(const Tensor &last_ids, const Tensor &ws, int64_t n_isects, int64_t cdim, int64_t seg_len)
+void note_seg_workspace_op(const Tensor &last_ids, const Tensor &ws, int64_t n_isects, int64_t cdim, int64_t seg_len,
+                           at::TensorList inputs)
 {
-    note_seg_workspace(last_ids, ws, n_isects, cdim, seg_len);
+    note_seg_workspace(last_ids, ws, n_isects, cdim, seg_len, inputs);
 }
-std::optional<Tensor> lookup_seg_workspace_op(const Tensor &last_ids, int64_t n_isects, int64_t cdim, int64_t seg_len)
+std::optional<Tensor> lookup_seg_workspace_op(const Tensor &last_ids, int64_t n_isects, int64_t cdim, int64_t seg_len,
+                                              at::TensorList inputs)
 {
-    Tensor t = lookup_seg_workspace(last_ids, n_isects, cdim, seg_len);
+    Tensor t = lookup_seg_workspace(last_ids, n_isects, cdim, seg_len, inputs);
     return t.defined() ? std::optional<Tensor>(t) : std::nullopt;
 }
 } // namespace gsplat_amd
@@ -1159,8 +1179,8 @@ TORCH_LIBRARY(gsplat_amd, m)
     // the Python op bodies (GSPLAT_AMD_COMPILED_OPS=0, A/B kernel libraries) share the compiled bodies' notes
     m.def("note_longest(Tensor flatten_ids, int longest) -> ()");
     m.def("lookup_longest(Tensor flatten_ids) -> int");
-    m.def("note_seg_workspace(Tensor last_ids, Tensor ws, int n_isects, int cdim, int seg_len) -> ()");
-    m.def("lookup_seg_workspace(Tensor last_ids, int n_isects, int cdim, int seg_len) -> Tensor?");
+    m.def("note_seg_workspace(Tensor last_ids, Tensor ws, int n_isects, int cdim, int seg_len, Tensor[] inputs) -> ()");
+    m.def("lookup_seg_workspace(Tensor last_ids, int n_isects, int cdim, int seg_len, Tensor[] inputs) -> Tensor?");
 }
 
 TORCH_LIBRARY_IMPL(gsplat_amd, CUDA, m)

@@ -242,10 +242,21 @@ def test_segmented_backward_from_the_forward_workspace_equals_the_prepass(G, kin
     _ops.set_long_tile_hint(longest)
     rc, ra, _, last_ids = torch.ops.gsplat.rasterize_to_pixels_3dgs(m2, con, colors, op, bg, None, W, H, 16, off, fl, False, False)
     _ops.set_long_tile_hint(0)
-    noted = torch.ops.gsplat_amd.lookup_seg_workspace(last_ids, fl.numel(), 3, _ops.SEG_LEN)
+    ins = [m2, con, colors, op, off, fl]
+    lookup = torch.ops.gsplat_amd.lookup_seg_workspace
+    noted = lookup(last_ids, fl.numel(), 3, _ops.SEG_LEN, ins)
     assert noted is not None, "the forward did not note its segment workspace"
-    assert torch.ops.gsplat_amd.lookup_seg_workspace(last_ids.clone(), fl.numel(), 3, _ops.SEG_LEN) is None
-    assert torch.ops.gsplat_amd.lookup_seg_workspace(last_ids, fl.numel() - 1, 3, _ops.SEG_LEN) is None  # other lists
+    assert lookup(last_ids.clone(), fl.numel(), 3, _ops.SEG_LEN, ins) is None
+    assert lookup(last_ids, fl.numel() - 1, 3, _ops.SEG_LEN, ins) is None  # other lists
+    # the sums belong to the forward's inputs: other tensors, or the same ones written to since, get no workspace
+    assert lookup(last_ids, fl.numel(), 3, _ops.SEG_LEN, [m2, con, colors.clone(), op, off, fl]) is None
+    op.mul_(1.0)
+    assert lookup(last_ids, fl.numel(), 3, _ops.SEG_LEN, ins) is None, "an input was written to after the forward"
+    _ops.set_long_tile_hint(longest)
+    rc, ra, _, last_ids = torch.ops.gsplat.rasterize_to_pixels_3dgs(m2, con, colors, op, bg, None, W, H, 16, off, fl, False, False)
+    _ops.set_long_tile_hint(0)
+    noted = lookup(last_ids, fl.numel(), 3, _ops.SEG_LEN, ins)
+    assert noted is not None
     before = noted.clone()
 
     def backward(li):

@@ -7,12 +7,12 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd $ROOT
 timeout 900 python -m pytest tests/test_gpu_segments.py -q -m gpu -x -p no:cacheprovider > $OUT/tests.log 2>&1; tail -5 $OUT/tests.log
-IFS=';' read -ra CF <<< "${CFGS:-1 1024 1;1 1024 0;1 768 1;1 768 0;1 512 1;0 1024 0}"
+IFS=';' read -ra CF <<< "${CFGS:-1 768;0 768;1 1024;1 512}"
 for rep in 1 2; do
 for cfg in "${CF[@]}"; do
   set -- $cfg
-  echo "== reuse=$1 seg_len=$2 fwd_order=$3 (run $rep)"
-  GSPLAT_AMD_SEG_REUSE=$1 GSPLAT_AMD_SEG_LEN=$2 GSX_FWD_SEG_ORDER=$3 timeout 300 python tools/bench_reference_profile.py --only 0 --repeats 40 --stages 2>&1 | grep '^{' | python -c "
+  echo "== reuse=$1 seg_len=$2 (run $rep)"
+  GSPLAT_AMD_SEG_REUSE=$1 GSPLAT_AMD_SEG_LEN=$2 timeout 300 python tools/bench_reference_profile.py --only 0 --repeats 40 --stages 2>&1 | grep '^{' | python -c "
 import sys, json
 for l in sys.stdin:
     d = json.loads(l); s = d.get('stages', {})
