@@ -216,14 +216,33 @@ __global__ void __launch_bounds__(256) seg_bwd_from_fwd_kernel(const Raster3DArg
     if (prow >= 0)
         for (uint32_t c = 0; c < a.nch; ++c) v_c[c] = a.v_render_colors[vrc_index(a, (size_t)prow, a.ch_off + c)];
     const uint32_t planes = a.nch + 1;
+    const float *__restrict__ src = pf.out;
+    float *__restrict__ t_out = T_end, *__restrict__ b_out = B_end;
     float behind = 0.0f;
-    for (int32_t k = n_seg - 1; k >= 0; --k) {
-        const size_t it = (size_t)(s0 + k);
-        T_end[it * 256 + tid] = pf.out[(it * planes + a.nch) * 256 + tid];
-        B_end[it * 256 + tid] = behind;
-        float d = 0.0f;
-        for (uint32_t c = 0; c < a.nch; ++c) d += v_c[c] * pf.out[(it * planes + c) * 256 + tid];
-        behind += d;
+    // four slices per round: their 4 (nch + 1) reads are independent of each other and of the stores (one slice per round was a
+    // chain of dependent round trips to memory per workgroup: 24 us for ~300 workgroups)
+    for (int32_t k1 = n_seg; k1 > 0; k1 -= 4) {
+        float te[4], d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t k = k1 - 1 - j;
+            te[j] = 0.0f; d[j] = 0.0f;
+            if (k >= 0) {
+                const size_t it = (size_t)(s0 + k);
+                te[j] = src[(it * planes + a.nch) * 256 + tid];
+                for (uint32_t c = 0; c < a.nch; ++c) d[j] = fmaf(v_c[c], src[(it * planes + c) * 256 + tid], d[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t k = k1 - 1 - j;
+            if (k >= 0) {
+                const size_t it = (size_t)(s0 + k);
+                t_out[it * 256 + tid] = te[j];
+                b_out[it * 256 + tid] = behind;
+                behind += d[j];
+            }
+        }
     }
 }
 
