@@ -73,13 +73,10 @@ __device__ __forceinline__ float depth_at(const SurfelPostArgs &a, size_t pix)
     return a.expected_depth ? acc / fmaxf(a.alphas[pix], kAlphaFloor) : acc;
 }
 
-// central differences of the unprojected points around interior pixel (x, y), in world space
-__device__ __forceinline__ void point_differences(const SurfelPostArgs &a, const Mat3 &R, const Intrinsics &K, size_t img,
-                                                  uint32_t x, uint32_t y, float (&du)[3], float (&dv)[3])
+// central differences of the unprojected points around interior pixel (x, y), in world space, from its four neighbours' depths
+__device__ __forceinline__ void point_differences(const Mat3 &R, const Intrinsics &K, uint32_t x, uint32_t y, float d_up, float d_dn,
+                                                  float d_lf, float d_rt, float (&du)[3], float (&dv)[3])
 {
-    const size_t pix = img + (size_t)y * a.width + x;
-    const float d_up = depth_at(a, pix - a.width), d_dn = depth_at(a, pix + a.width);
-    const float d_lf = depth_at(a, pix - 1), d_rt = depth_at(a, pix + 1);
     float rx, ry, rx1, ry1, rx0, ry0;
     K.dir(x, y, rx, ry);
     K.dir(x + 1, y + 1, rx1, ry1);
@@ -101,16 +98,43 @@ __device__ __forceinline__ Intrinsics load_intrinsics(const float *__restrict__ 
     return Intrinsics{1.0f / K[0], 1.0f / K[4], K[2], K[5]};
 }
 
+// Workgroup = 32 x 8 pixels. The depth map of the block and a halo is formed ONCE per pixel in LDS (with expected depths that is
+// two strided loads and a division): a pixel's central differences read its four neighbours there instead of evaluating
+// depth_at() four times from global memory (round 6: forward 45 -> see profiles/r11_ab.md; same values, same arithmetic).
+constexpr int kPBX = 32, kPBY = 8;
+
+__device__ __forceinline__ float depth_or_zero(const SurfelPostArgs &a, size_t img, int gx, int gy)
+{
+    return (gx >= 0 && gy >= 0 && gx < (int)a.width && gy < (int)a.height) ? depth_at(a, img + (size_t)gy * a.width + gx) : 0.0f;
+}
+
 __global__ void __launch_bounds__(256) surfel_post_fwd_kernel(const SurfelPostArgs a)
 {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), im = blockIdx.z;
+    __shared__ float s_d[kPBY + 2][kPBX + 2]; // depths, halo 1
+    const int bx0 = (int)blockIdx.x * kPBX, by0 = (int)blockIdx.y * kPBY;
+    const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5, im = blockIdx.z;
+    const uint32_t x = (uint32_t)bx0 + tx, y = (uint32_t)by0 + ty;
+    const size_t img = (size_t)im * a.width * a.height;
+    if (a.surf_normals) {
+        for (int i = (int)threadIdx.x; i < (kPBY + 2) * (kPBX + 2); i += 256) {
+            const int ry = i / (kPBX + 2), rx = i % (kPBX + 2);
+            s_d[ry][rx] = depth_or_zero(a, img, bx0 + rx - 1, by0 + ry - 1);
+        }
+        __syncthreads();
+    }
     if (x >= a.width || y >= a.height) return;
-    const Mat3 R       = cam_to_world_rotation(a.viewmats + 16 * (size_t)im);
-    const size_t img   = (size_t)im * a.width * a.height, pix = img + (size_t)y * a.width + x;
+    const Mat3 R     = cam_to_world_rotation(a.viewmats + 16 * (size_t)im);
+    const size_t pix = img + (size_t)y * a.width + x;
     if (a.colors_out) {
         const float inv = 1.0f / fmaxf(a.alphas[pix], kAlphaFloor);
-        for (uint32_t k = 0; k + 1 < a.cdim; ++k) a.colors_out[pix * a.cdim + k] = a.colors[pix * a.cdim + k];
-        a.colors_out[pix * a.cdim + a.cdim - 1] = a.colors[pix * a.cdim + a.cdim - 1] * inv;
+        if (a.cdim == 4 && ((reinterpret_cast<uintptr_t>(a.colors) | reinterpret_cast<uintptr_t>(a.colors_out)) & 15u) == 0) { // RGB + depth: 16-byte accesses
+            float4 c = reinterpret_cast<const float4 *>(a.colors)[pix];
+            c.w *= inv;
+            reinterpret_cast<float4 *>(a.colors_out)[pix] = c;
+        } else {
+            for (uint32_t k = 0; k + 1 < a.cdim; ++k) a.colors_out[pix * a.cdim + k] = a.colors[pix * a.cdim + k];
+            a.colors_out[pix * a.cdim + a.cdim - 1] = a.colors[pix * a.cdim + a.cdim - 1] * inv;
+        }
     }
     float wx, wy, wz;
     R.mul(a.normals[3 * pix], a.normals[3 * pix + 1], a.normals[3 * pix + 2], wx, wy, wz);
@@ -120,7 +144,7 @@ __global__ void __launch_bounds__(256) surfel_post_fwd_kernel(const SurfelPostAr
         if (x >= 1 && y >= 1 && x + 1 < a.width && y + 1 < a.height) {
             const Intrinsics K = load_intrinsics(a.Ks + 9 * (size_t)im);
             float du[3], dv[3];
-            point_differences(a, R, K, img, x, y, du, dv);
+            point_differences(R, K, x, y, s_d[ty][tx + 1], s_d[ty + 2][tx + 1], s_d[ty + 1][tx], s_d[ty + 1][tx + 2], du, dv);
             cross3(du, dv, n);
             const float s = 1.0f / fmaxf(sqrtf(fmaf(n[0], n[0], fmaf(n[1], n[1], n[2] * n[2]))), kNormFloor);
             n[0] *= s; n[1] *= s; n[2] *= s;
@@ -131,11 +155,12 @@ __global__ void __launch_bounds__(256) surfel_post_fwd_kernel(const SurfelPostAr
 
 // gradient of the loss w.r.t. the two point differences of interior pixel (x, y), given the gradient of its unit normal
 __device__ __forceinline__ void difference_grads(const SurfelPostArgs &a, const Mat3 &R, const Intrinsics &K, size_t img,
-                                                 uint32_t x, uint32_t y, float (&v_du)[3], float (&v_dv)[3])
+                                                 uint32_t x, uint32_t y, float d_up, float d_dn, float d_lf, float d_rt,
+                                                 float (&v_du)[3], float (&v_dv)[3])
 {
     const size_t pix = img + (size_t)y * a.width + x;
     float du[3], dv[3], n[3];
-    point_differences(a, R, K, img, x, y, du, dv);
+    point_differences(R, K, x, y, d_up, d_dn, d_lf, d_rt, du, dv);
     cross3(du, dv, n);
     const float g[3]  = {a.v_surf_normals[3 * pix], a.v_surf_normals[3 * pix + 1], a.v_surf_normals[3 * pix + 2]};
     const float len   = sqrtf(fmaf(n[0], n[0], fmaf(n[1], n[1], n[2] * n[2])));
@@ -150,38 +175,64 @@ __device__ __forceinline__ void difference_grads(const SurfelPostArgs &a, const 
     cross3(v_n, du, v_dv); // d((du x dv) . v_n) / d dv = v_n x du
 }
 
+// Same blocks as the forward. A pixel's depth gradient collects the difference gradients of its four neighbours; each of those
+// used to be evaluated by every pixel that needed it (four times, from sixteen depth_at() calls per pixel): now the block forms
+// the depth map (halo 2) and every site's difference gradients (halo 1) once, in LDS. Sites that are not interior pixels of the
+// image hold zeros, so the four terms are added unconditionally (x + 0 is exact: the same sums as the guarded form).
 __global__ void __launch_bounds__(256) surfel_post_bwd_kernel(const SurfelPostArgs a)
 {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), im = blockIdx.z;
-    if (x >= a.width || y >= a.height) return;
+    __shared__ float s_d[kPBY + 4][kPBX + 4];    // depths, halo 2
+    __shared__ float s_g[6][kPBY + 2][kPBX + 2]; // v_du[3] | v_dv[3] of every site, halo 1
+    const int bx0 = (int)blockIdx.x * kPBX, by0 = (int)blockIdx.y * kPBY;
+    const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5, im = blockIdx.z;
+    const uint32_t x = (uint32_t)bx0 + tx, y = (uint32_t)by0 + ty;
     const Mat3 R     = cam_to_world_rotation(a.viewmats + 16 * (size_t)im);
-    const size_t img = (size_t)im * a.width * a.height, pix = img + (size_t)y * a.width + x;
+    const size_t img = (size_t)im * a.width * a.height;
+    const bool want_depth_grad = a.v_surf_normals && a.depth_source;
+    if (want_depth_grad) {
+        const Intrinsics K = load_intrinsics(a.Ks + 9 * (size_t)im);
+        for (int i = (int)threadIdx.x; i < (kPBY + 4) * (kPBX + 4); i += 256) {
+            const int ry = i / (kPBX + 4), rx = i % (kPBX + 4);
+            s_d[ry][rx] = depth_or_zero(a, img, bx0 + rx - 2, by0 + ry - 2);
+        }
+        __syncthreads();
+        for (int i = (int)threadIdx.x; i < (kPBY + 2) * (kPBX + 2); i += 256) {
+            const int ry = i / (kPBX + 2), rx = i % (kPBX + 2);
+            const int gx = bx0 + rx - 1, gy = by0 + ry - 1;
+            float v_du[3] = {0.0f, 0.0f, 0.0f}, v_dv[3] = {0.0f, 0.0f, 0.0f};
+            if (gx >= 1 && gy >= 1 && gx + 1 < (int)a.width && gy + 1 < (int)a.height) // site (gx, gy) = s_d[ry + 1][rx + 1]
+                difference_grads(a, R, K, img, (uint32_t)gx, (uint32_t)gy, s_d[ry][rx + 1], s_d[ry + 2][rx + 1], s_d[ry + 1][rx],
+                                 s_d[ry + 1][rx + 2], v_du, v_dv);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s_g[k][ry][rx]     = v_du[k];
+                s_g[3 + k][ry][rx] = v_dv[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (x >= a.width || y >= a.height) return;
+    const size_t pix = img + (size_t)y * a.width + x;
 
     float cx, cy, cz;
     R.mul_t(a.v_normals_world[3 * pix], a.v_normals_world[3 * pix + 1], a.v_normals_world[3 * pix + 2], cx, cy, cz);
     a.v_normals[3 * pix] = cx; a.v_normals[3 * pix + 1] = cy; a.v_normals[3 * pix + 2] = cz;
 
-    // gradient of this pixel's depth from the (up to four) interior neighbours whose differences read it
+    // gradient of this pixel's depth from the (up to four) interior neighbours whose differences read it: pixel (x, y) is site
+    // [ty + 1][tx + 1]; it is the lower neighbour of (x, y-1): +v_du, the upper one of (x, y+1): -v_du, the right one of
+    // (x-1, y): +v_dv, the left one of (x+1, y): -v_dv
     float v_depth = 0.0f;
-    if (a.v_surf_normals && a.depth_source) {
+    if (want_depth_grad) {
         const Intrinsics K = load_intrinsics(a.Ks + 9 * (size_t)im);
-        float vp[3]        = {0.0f, 0.0f, 0.0f}, v_du[3], v_dv[3];
-        const bool col_in = x >= 1 && x + 1 < a.width, row_in = y >= 1 && y + 1 < a.height;
-        if (col_in && y >= 2 && y < a.height) { // (x, y-1): this pixel is its lower neighbour: +v_du
-            difference_grads(a, R, K, img, x, y - 1, v_du, v_dv);
-            for (int k = 0; k < 3; ++k) vp[k] += v_du[k];
-        }
-        if (col_in && y + 2 < a.height) { // (x, y+1): upper neighbour: -v_du
-            difference_grads(a, R, K, img, x, y + 1, v_du, v_dv);
-            for (int k = 0; k < 3; ++k) vp[k] -= v_du[k];
-        }
-        if (row_in && x >= 2 && x < a.width) { // (x-1, y): right neighbour: +v_dv
-            difference_grads(a, R, K, img, x - 1, y, v_du, v_dv);
-            for (int k = 0; k < 3; ++k) vp[k] += v_dv[k];
-        }
-        if (row_in && x + 2 < a.width) { // (x+1, y): left neighbour: -v_dv
-            difference_grads(a, R, K, img, x + 1, y, v_du, v_dv);
-            for (int k = 0; k < 3; ++k) vp[k] -= v_dv[k];
+        float vp[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v = 0.0f;
+            v += s_g[k][ty][tx + 1];
+            v -= s_g[k][ty + 2][tx + 1];
+            v += s_g[3 + k][ty + 1][tx];
+            v -= s_g[3 + k][ty + 1][tx + 2];
+            vp[k] = v;
         }
         float rx, ry, wx, wy, wz;
         K.dir(x, y, rx, ry);
@@ -192,7 +243,13 @@ __global__ void __launch_bounds__(256) surfel_post_bwd_kernel(const SurfelPostAr
 
     const uint32_t D = a.cdim, last = D - 1;
     float v_last     = a.depth_source == 1 ? v_depth : 0.0f; // gradient of the (normalised) depth channel
-    if (a.v_colors_out) {
+    const bool quad  = D == 4 && a.v_colors_out && (reinterpret_cast<uintptr_t>(a.v_colors_out) & 15u) == 0
+                      && (reinterpret_cast<uintptr_t>(a.v_colors) & 15u) == 0; // RGB + depth: 16-byte accesses
+    float4 vq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (quad) {
+        vq = reinterpret_cast<const float4 *>(a.v_colors_out)[pix];
+        v_last += vq.w;
+    } else if (a.v_colors_out) {
         for (uint32_t k = 0; k < last; ++k) a.v_colors[pix * D + k] = a.v_colors_out[pix * D + k];
         v_last += a.v_colors_out[pix * D + last];
     } else {
@@ -204,7 +261,12 @@ __global__ void __launch_bounds__(256) surfel_post_bwd_kernel(const SurfelPostAr
         if (alpha >= kAlphaFloor) v_alpha = -v_last * a.colors[pix * D + last] * inv * inv;
         v_last *= inv;
     }
-    a.v_colors[pix * D + last] = v_last;
+    if (quad) {
+        vq.w = v_last;
+        reinterpret_cast<float4 *>(a.v_colors)[pix] = vq;
+    } else {
+        a.v_colors[pix * D + last] = v_last;
+    }
     if (a.v_alphas) a.v_alphas[pix] = v_alpha;
 }
 
@@ -245,7 +307,7 @@ extern "C" int gsx_surfel_post_fwd(const float *colors, const float *alphas, con
     a.colors = colors; a.alphas = alphas; a.normals = normals; a.median = median; a.viewmats = viewmats; a.Ks = Ks;
     a.width = width; a.height = height; a.cdim = cdim; a.expected_depth = expected_depth; a.depth_source = depth_source;
     a.colors_out = colors_out; a.normals_world = normals_world; a.surf_normals = surf_normals;
-    surfel_post_fwd_kernel<<<dim3((uint32_t)ceil_div(width, 64), (uint32_t)ceil_div(height, 4), n_images), dim3(256), 0,
+    surfel_post_fwd_kernel<<<dim3((uint32_t)ceil_div(width, kPBX), (uint32_t)ceil_div(height, kPBY), n_images), dim3(256), 0,
                              (hipStream_t)stream>>>(a);
     return check_launch("surfel_post_fwd");
 }
@@ -268,7 +330,7 @@ extern "C" int gsx_surfel_post_bwd(const float *colors, const float *alphas, con
     a.width = width; a.height = height; a.cdim = cdim; a.expected_depth = expected_depth; a.depth_source = depth_source;
     a.v_colors_out = v_colors_out; a.v_normals_world = v_normals_world; a.v_surf_normals = v_surf_normals;
     a.v_colors = v_colors; a.v_alphas = v_alphas; a.v_normals = v_normals; a.v_median = v_median;
-    surfel_post_bwd_kernel<<<dim3((uint32_t)ceil_div(width, 64), (uint32_t)ceil_div(height, 4), n_images), dim3(256), 0,
+    surfel_post_bwd_kernel<<<dim3((uint32_t)ceil_div(width, kPBX), (uint32_t)ceil_div(height, kPBY), n_images), dim3(256), 0,
                              (hipStream_t)stream>>>(a);
     return check_launch("surfel_post_bwd");
 }
