@@ -729,6 +729,9 @@ class _SurfelPost(torch.autograd.Function):
              int(expected_depth), depth_source, ptr(colors_out), ptr(normals_world), ptr(surf))
         ctx.save_for_backward(colors, alphas, normals, median, viewmats, Ks)
         ctx.cfg = (I, W, H, D, bool(expected_depth), depth_source)
+        # an output the loss does not use gets None in backward, not a zero image: with no cotangent for the depth-map normals
+        # the backward kernel skips the whole depth-gradient stage (its LDS tiles, a third of its time)
+        ctx.set_materialize_grads(False)
         unused = [colors.new_empty(0) for _ in range(2)]  # placeholders for the outputs this mode does not produce
         if not expected_depth:
             colors_out = unused[0]
