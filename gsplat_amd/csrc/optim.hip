@@ -137,6 +137,34 @@ extern "C" int gsx_adam(float *param, const float *param_grad, float *exp_avg, f
     return check_launch("adam");
 }
 
+// DefaultStrategy's per-step statistics for dense rows [C, N] (reference gsplat/strategy/default.py:226-285, _update_state): per
+// Gaussian, over the views it is visible in (both radii > 0): grad2d += |(g.x half_w, g.y half_h)|, count += 1,
+// radii = max(radii, max(r.x, r.y) / max_dim). The reference gathers the visible pairs (torch.where + three mask indexings, each
+// with a host read of its size) and scatters with index_add_; the tensor-op form this replaces took ~10 launches per step.
+// One thread per Gaussian, the views in ascending order; a row that is not visible is never read for its gradient's VALUE
+// (a non-finite gradient there must not reach the sum: selects, not products).
+__global__ void __launch_bounds__(256) strategy_accumulate_kernel(const float *grad, uint32_t grad_stride, const int32_t *radii,
+                                                                  uint32_t C, uint32_t N, float half_w, float half_h,
+                                                                  float inv_max_dim, float *grad2d, float *count, float *radii_state)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= N) return;
+    float sum = 0.0f, cnt = 0.0f, rmax = 0.0f;
+    for (uint32_t c = 0; c < C; ++c) {
+        const size_t row = (size_t)c * N + g;
+        const int2 r     = reinterpret_cast<const int2 *>(radii)[row];
+        if (r.x > 0 && r.y > 0) {
+            const float gx = grad[row * grad_stride] * half_w, gy = grad[row * grad_stride + 1] * half_h;
+            sum += sqrtf(gx * gx + gy * gy);
+            cnt += 1.0f;
+            rmax = fmaxf(rmax, (float)max(r.x, r.y) * inv_max_dim);
+        }
+    }
+    grad2d[g] += sum;
+    count[g] += cnt;
+    if (radii_state) radii_state[g] = fmaxf(radii_state[g], rmax);
+}
+
 extern "C" int gsx_relocation(const float *opacities, const float *scales, const int32_t *ratios, const float *binoms,
                               int64_t n, int n_max, float min_opacity, float *new_opacities, float *new_scales,
                               void *stream)
@@ -147,4 +175,16 @@ extern "C" int gsx_relocation(const float *opacities, const float *scales, const
     relocation_kernel<<<dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(
         opacities, scales, ratios, binoms, n, n_max, min_opacity, new_opacities, new_scales);
     return check_launch("relocation");
+}
+
+extern "C" int gsx_strategy_accumulate(const float *grad, uint32_t grad_stride, const int32_t *radii, uint32_t C, uint32_t N,
+                                       float half_w, float half_h, float inv_max_dim, float *grad2d, float *count,
+                                       float *radii_state, void *stream)
+{
+    if (C == 0 || N == 0) return GSX_OK;
+    GSX_REQUIRE(grad && radii && grad2d && count, "gsx_strategy_accumulate: null pointer");
+    GSX_REQUIRE(grad_stride >= 2, "gsx_strategy_accumulate: gradient rows are at least two floats apart, got %u", grad_stride);
+    strategy_accumulate_kernel<<<dim3((uint32_t)ceil_div((int64_t)N, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        grad, grad_stride, radii, C, N, half_w, half_h, inv_max_dim, grad2d, count, radii_state);
+    return check_launch("strategy_accumulate");
 }

@@ -1000,6 +1000,14 @@ int gsx_copy_message_columns(void *message, uint32_t message_stride, int64_t row
  * ------------------------------------------------------------------------------------------- */
 int gsx_adam(float *param, const float *param_grad, float *exp_avg, float *exp_avg_sq, const uint8_t *valid,
              int64_t n_rows, uint32_t row_width, float lr, float b1, float b2, float eps, void *stream);
+/* DefaultStrategy's per-step statistics for dense rows (reference gsplat/strategy/default.py:226-285, _update_state - there a
+ * torch.where + three boolean-mask gathers with host reads + index_add_): per Gaussian g over the C views it is visible in
+ * (radii[(c N + g)] > 0 on both axes): grad2d[g] += |(grad.x half_w, grad.y half_h)|, count[g] += 1,
+ * radii_state[g] = max(radii_state[g], max(radii) * inv_max_dim) (radii_state may be NULL). grad element (c, g, k) at
+ * grad[(c N + g) * grad_stride + k]: the retained gradient of means2d is a column view of the compositing backward's rows. */
+int gsx_strategy_accumulate(const float *grad, uint32_t grad_stride, const int32_t *radii, uint32_t C, uint32_t N,
+                            float half_w, float half_h, float inv_max_dim, float *grad2d, float *count, float *radii_state,
+                            void *stream);
 int gsx_relocation(const float *opacities, const float *scales, const int32_t *ratios, const float *binoms, int64_t n,
                    int n_max, float min_opacity, float *new_opacities, float *new_scales, void *stream);
 int gsx_mcmc_perturb(float *positions, const float *quats, const float *scales_log, const float *opacities_logit,
