@@ -27,7 +27,7 @@ def O():
     return oracle
 
 
-@pytest.mark.parametrize("shape", [(1000, 3), (777,), (500, 16, 3), (64, 4)])
+@pytest.mark.parametrize("shape", [(1000, 3), (777,), (500, 16, 3), (64, 4), (2000, 15, 3), (4096, 3), (8192,), (4100, 2), (1001, 45)])
 @pytest.mark.parametrize("masked", [True, False])
 def test_adam_matches_oracle(G, O, shape, masked):
     g = torch.Generator().manual_seed(1)
