@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, gsplat_amd
 
 dev = torch.device("cuda", 0)
-sc, W, H = bench.make_workload(1_000_000, dev, n_cameras=1)
+N_G, N_C = int(os.environ.get("STEP_OPS_N", 1_000_000)), int(os.environ.get("STEP_OPS_C", 1))  # c4: 4000000 / 4
+sc, W, H = bench.make_workload(N_G, dev, n_cameras=N_C)
 leaves = {k: sc[k].clone().requires_grad_(True) for k in bench.NAMES}
 
 
