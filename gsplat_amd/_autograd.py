@@ -280,7 +280,7 @@ def _p2_backward(ctx, v_radii, v_means2d, v_depths, v_ray_transforms, v_normals,
     means, quats, scales, viewmats, Ks, radii, ray_transforms = ctx.saved_tensors
     res = _bwd("projection_2dgs_fused")(
         means, quats, scales, viewmats, Ks, ctx.width, ctx.height, radii, ray_transforms, v_means2d,
-        v_depths.contiguous(), v_ray_transforms, v_normals, ctx.needs_input_grad[3],  # row views are read in place
+        v_depths, v_ray_transforms, v_normals, ctx.needs_input_grad[3],  # row / column views are read in place
         _v_view_opacities=v_view_opacities)
     if v_view_opacities is not None:  # Projection2DGSWithViewOpacities: its twelfth input is `opacities`
         return tuple(res[:4]) + (None,) * 7 + (res[4],)

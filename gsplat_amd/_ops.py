@@ -1587,9 +1587,12 @@ def projection_2dgs_fused_bwd(means, quats, scales, viewmats, Ks, image_width, i
     v_viewmats = torch.zeros_like(viewmats) if viewmats_requires_grad else None
     (v_means2d, v_rt, v_normals), vstride = _common_row_views(
         (v_means2d, v_ray_transforms.reshape(v_ray_transforms.shape[:-2] + (9,)), v_normals), (2, 9, 3))
+    # the depth cotangent is read in place when it is one column of the gradient rows (the slice autograd cuts out of the
+    # colour cotangent of a depth render mode), like the three above
+    v_dep, dep_stride = (None, 1) if v_depths is None else _elem_view(v_depths)
     head = (ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), B, C, N,
-            ptr(radii.contiguous()), ptr(ray_transforms.contiguous()), ptr_strided(v_means2d), ptr(_c(v_depths)),
-            ptr_strided(v_rt), ptr_strided(v_normals), vstride)
+            ptr(radii.contiguous()), ptr(ray_transforms.contiguous()), ptr_strided(v_means2d),
+            None if v_dep is None else ptr_strided(v_dep), ptr_strided(v_rt), ptr_strided(v_normals), vstride, int(dep_stride))
     if _v_view_opacities is not None:
         v_view, opac_stride = _elem_view(_v_view_opacities)
         v_opacities = torch.empty(tuple(batch_dims) + (N,), device=means.device, dtype=means.dtype)

@@ -158,6 +158,7 @@ struct Proj2BwdArgs {
     const int32_t *radii;          // dense only
     const float *ray_transforms;   // per row
     const float *v_means2d, *v_depths, *v_ray_transforms, *v_normals;
+    uint32_t depth_stride; // floats between the depth cotangents of consecutive rows (1 = contiguous)
     uint32_t m2_stride, rt_stride, n_stride; // row strides (floats): 2 / 9 / 3, or the stride of the AoS gradient rows
     int64_t nnz;
     const int64_t *batch_ids, *camera_ids, *gaussian_ids;
@@ -180,7 +181,7 @@ __device__ __forceinline__ void pair2_vjp(const Proj2BwdArgs &a, const Cam &cam,
     float vM[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) vM[i] = a.v_ray_transforms[(size_t)a.rt_stride * row + i];
-    if (a.v_depths) vM[8] += a.v_depths[row]; // depth = M2.z (null = no gradient reaches the depths)
+    if (a.v_depths) vM[8] += a.v_depths[(size_t)a.depth_stride * row]; // depth = M2.z (null = no gradient reaches the depths)
     const float vmx = a.v_means2d[(size_t)a.m2_stride * row], vmy = a.v_means2d[(size_t)a.m2_stride * row + 1];
     if (vmx != 0.0f || vmy != 0.0f) {
         // mean2d_x = sum(sgn M0 M2) / d, d = sum(sgn M2 M2), sgn = (1,1,-1)
@@ -471,7 +472,7 @@ extern "C" int gsx_project_2dgs_bwd(const float *means, const float *quats, cons
                                     const float *Ks, uint32_t B, uint32_t C, uint32_t N, const int32_t *radii,
                                     const float *ray_transforms, const float *v_means2d, const float *v_depths,
                                     const float *v_ray_transforms, const float *v_normals, uint32_t v_row_stride,
-                                    float *v_means, float *v_quats,
+                                    uint32_t v_depths_stride, float *v_means, float *v_quats,
                                     float *v_scales, float *v_viewmats, void *stream)
 {
     if ((int64_t)B * N == 0) return GSX_OK;
@@ -486,6 +487,7 @@ extern "C" int gsx_project_2dgs_bwd(const float *means, const float *quats, cons
     a.v_ray_transforms = v_ray_transforms; a.v_normals = v_normals;
     a.m2_stride = v_row_stride ? v_row_stride : 2u; a.rt_stride = v_row_stride ? v_row_stride : 9u;
     a.n_stride = v_row_stride ? v_row_stride : 3u;
+    a.depth_stride = v_depths_stride ? v_depths_stride : 1u;
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_viewmats = v_viewmats;
     const dim3 grid((uint32_t)ceil_div((int64_t)B * N, 256));
     if (v_viewmats) project2_bwd_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
@@ -499,7 +501,8 @@ extern "C" int gsx_project_2dgs_bwd_opac(const float *means, const float *quats,
                                          const float *Ks, uint32_t B, uint32_t C, uint32_t N, const int32_t *radii,
                                          const float *ray_transforms, const float *v_means2d, const float *v_depths,
                                          const float *v_ray_transforms, const float *v_normals, uint32_t v_row_stride,
-                                         const float *v_view_opacities, uint32_t v_view_opacities_stride, float *v_means,
+                                         uint32_t v_depths_stride, const float *v_view_opacities,
+                                         uint32_t v_view_opacities_stride, float *v_means,
                                          float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities, void *stream)
 {
     if ((int64_t)B * N == 0) return GSX_OK;
@@ -515,6 +518,7 @@ extern "C" int gsx_project_2dgs_bwd_opac(const float *means, const float *quats,
     a.v_ray_transforms = v_ray_transforms; a.v_normals = v_normals;
     a.m2_stride = v_row_stride ? v_row_stride : 2u; a.rt_stride = v_row_stride ? v_row_stride : 9u;
     a.n_stride = v_row_stride ? v_row_stride : 3u;
+    a.depth_stride = v_depths_stride ? v_depths_stride : 1u;
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_viewmats = v_viewmats;
     a.v_view_opacities = v_view_opacities; a.opac_stride = v_view_opacities_stride; a.v_opacities = v_opacities;
     const dim3 grid((uint32_t)ceil_div((int64_t)B * N, 256));
@@ -545,6 +549,7 @@ extern "C" int gsx_project_2dgs_packed_bwd(const float *means, const float *quat
     a.v_ray_transforms = v_ray_transforms; a.v_normals = v_normals;
     a.m2_stride = v_row_stride ? v_row_stride : 2u; a.rt_stride = v_row_stride ? v_row_stride : 9u;
     a.n_stride = v_row_stride ? v_row_stride : 3u;
+    a.depth_stride = 1u;
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_viewmats = v_viewmats;
     const dim3 grid((uint32_t)ceil_div(nnz, 256));
     if (v_viewmats) project2_packed_bwd_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
@@ -576,6 +581,7 @@ extern "C" int gsx_project_2dgs_packed_bwd_rows(const float *means, const float 
     a.v_ray_transforms = v_ray_transforms; a.v_normals = v_normals;
     a.m2_stride = v_row_stride ? v_row_stride : 2u; a.rt_stride = v_row_stride ? v_row_stride : 9u;
     a.n_stride = v_row_stride ? v_row_stride : 3u;
+    a.depth_stride = 1u;
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_viewmats = v_viewmats;
     a.rows_out = 1;
     const dim3 grid((uint32_t)ceil_div(nnz, 256));

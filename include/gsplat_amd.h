@@ -801,6 +801,8 @@ int gsx_project_2dgs_bwd(const float *means, const float *quats, const float *sc
                          const float *v_ray_transforms, const float *v_normals,
                          uint32_t v_row_stride /* 0: the three gradients are contiguous [rows,2] / [rows,9] / [rows,3];
                                                   else they are column views of gsx_raster2d_bwd's v_rows with this stride */,
+                         uint32_t v_depths_stride /* floats between consecutive rows' depth cotangents: 0 / 1 = contiguous, or
+                                                     the row stride of v_rows when it is their depth-channel column */,
                          float *v_means, float *v_quats, float *v_scales, float *v_viewmats, void *stream);
 /* gsx_project_2dgs_bwd that also reduces the cotangent of the per-view opacities (as gsx_project_ewa_bwd_opac):
  * v_view_opacities[(b C + c) N + g], v_view_opacities_stride floats apart (1 = contiguous; the row stride of gsx_raster2d_bwd's
@@ -809,7 +811,7 @@ int gsx_project_2dgs_bwd_opac(const float *means, const float *quats, const floa
                               const float *Ks, uint32_t B, uint32_t C, uint32_t N, const int32_t *radii,
                               const float *ray_transforms, const float *v_means2d, const float *v_depths,
                               const float *v_ray_transforms, const float *v_normals, uint32_t v_row_stride,
-                              const float *v_view_opacities, uint32_t v_view_opacities_stride, float *v_means,
+                              uint32_t v_depths_stride, const float *v_view_opacities, uint32_t v_view_opacities_stride, float *v_means,
                               float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities, void *stream);
 int gsx_project_2dgs_packed_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
                                 const float *Ks, uint32_t B, uint32_t C, uint32_t N, int64_t nnz,
